@@ -1,0 +1,173 @@
+/*
+ * vectorian_hip.h -- C-ABI of the MI355X (gfx950) brute-force alignment search.
+ *
+ * This is the drop-in boundary for ONE path of poke1024/vectorian: what
+ * BruteForceIndex._find (vectorian/index.py:530-560) obtains today from the
+ * pybind11 module `vectorian_core` (vectorian/core/cpp/module.cpp:36-151) by calling
+ *     core.Query(...).initialize(tokens, **options)      module.cpp:115-120, query.cpp:32-154
+ *     core.Document(...).find(query, booster)            module.cpp:124-127, document.cpp:60-69
+ *     ResultSet.extend / ResultSet.best_n                module.cpp:142-145, result_set.h:70-93
+ * The reference's native seam is welded to Python objects (string vocabularies,
+ * numpy callbacks), so it is not re-exported 1:1; instead the same
+ * data contracts -- token vectors / token ids, sentence spans, option values,
+ * bounded result set with scores and the injective flow mapping -- cross this
+ * plain-pointer interface.  Each entry point names the reference interface it
+ * replaces.  No torch / numpy / pybind types appear here; INTEGRATION.md shows the
+ * ctypes binding the reference's maintainers would add.
+ *
+ * Conventions: every function returns a vk_status (0 = ok); on error
+ * vk_last_error() returns a thread-local message.  Host buffers are borrowed for
+ * the duration of the call; the library owns device copies behind the opaque
+ * handle; outputs go to caller-allocated buffers.  Calls on different handles
+ * may run concurrently from different threads; calls on one handle must be
+ * serialised by the caller.
+ */
+#ifndef VECTORIAN_HIP_H
+#define VECTORIAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VK_ABI_VERSION 1
+#define VK_MAX_QUERY_LEN 16   /* query tokens handled by one 16-wide MFMA column block */
+#define VK_MAX_SENT_LEN 64    /* tokens per sentence (slice), SURVEY 8: |s| <= 64 */
+#define VK_MAX_MATCHES 1024
+
+typedef enum {
+	VK_OK = 0,
+	VK_ERR_INVALID = 1,      /* bad argument / option (query.cpp:60-63 throws std::runtime_error) */
+	VK_ERR_UNSUPPORTED = 2,  /* option the HIP path does not implement: explicit, never a fallback */
+	VK_ERR_HIP = 3,          /* HIP runtime error */
+	VK_ERR_NO_DEVICE = 4,
+	VK_ERR_STATE = 5         /* call order violated (e.g. query before finalize) */
+} vk_status;
+
+/* pyalign::enums::Locality (metric/alignment.h:363-364; vectorian/alignment.py:97,130,187) */
+typedef enum { VK_LOCAL = 0, VK_GLOBAL = 1, VK_SEMIGLOBAL = 2 } vk_locality;
+
+/* pyalign.gaps families: linear w(k)=u*k, affine w(k)=u+v*k,
+ * table w(k)=table[k] (ConstantGapCost / ExponentialGapCost / any GapCost.costs(n)) */
+typedef enum { VK_GAP_LINEAR = 0, VK_GAP_AFFINE = 1, VK_GAP_TABLE = 2 } vk_gap_kind;
+
+/* 'algorithm' of the alignment option dict (vectorian/alignment.py:33,277,310) */
+typedef enum { VK_ALG_ALIGN = 0, VK_ALG_RWMD = 1, VK_ALG_WRD = 2 } vk_algorithm;
+
+typedef enum { VK_F32 = 0, VK_BF16 = 1 } vk_dtype;
+typedef enum { VK_MEM_HOST = 0, VK_MEM_DEVICE = 1 } vk_mem;
+
+/* VK_LAYOUT_CONTEXTUAL: one vector per token occurrence (ContextualEmbeddingSlice,
+ *   slice/contextual.h:65-67; metric/contextual.cpp:26-63).
+ * VK_LAYOUT_STATIC: token ids + vocabulary table (StaticEmbeddingSlice,
+ *   slice/static.h:71-75; metric/static.cpp:9-78). */
+typedef enum { VK_LAYOUT_CONTEXTUAL = 0, VK_LAYOUT_STATIC = 1 } vk_layout;
+
+typedef struct vk_corpus vk_corpus_t;
+
+typedef struct {
+	int32_t layout;        /* vk_layout */
+	int32_t d;             /* embedding dimension */
+	int64_t n_tokens;      /* total tokens of this shard (< 2^31) */
+	int64_t n_sentences;   /* slices of this shard */
+	int32_t vocab_size;    /* VK_LAYOUT_STATIC: rows of the vocabulary table */
+	int32_t keep_magnitudes; /* keep |x| per token (needed by VK_ALG_WRD, metric/contextual.cpp:49-54) */
+} vk_corpus_desc;
+
+typedef struct {
+	int32_t kind;          /* vk_gap_kind */
+	float u, v;
+	const float *table;    /* host, VK_GAP_TABLE: table[0..n_table), table[0] = 0 */
+	int32_t n_table;       /* must cover the longest gap: > max(len_s, len_t) */
+} vk_gap;
+
+typedef struct {
+	int32_t algorithm;       /* vk_algorithm */
+	int32_t len_t;           /* query tokens, 1..VK_MAX_QUERY_LEN */
+	const void *q_vectors;   /* host [len_t x d] row-major */
+	int32_t q_dtype;         /* vk_dtype */
+	int32_t q_normalize;     /* 1: rows are L2-normalised by the library (Vectors.normalized) */
+	const int32_t *q_token_ids; /* host [len_t], VK_LAYOUT_STATIC: vocabulary id or -1;
+	                               sets sim[id(t_j)][j] = 1 (metric/static.cpp:58-67) */
+	int32_t locality;        /* vk_locality (alignment only) */
+	vk_gap gap_s;            /* cost of skipping document tokens */
+	vk_gap gap_t;            /* cost of skipping query tokens   */
+	float submatch_weight;   /* query.cpp:77-79; only 0 is implemented */
+	int32_t bidirectional;   /* query.cpp:81-83 (parsed, unused upstream); must be 0 */
+	int32_t max_matches;     /* query.cpp:87-89 */
+	float min_score;         /* query.cpp:91-93; admission is score > min_score (metric/alignment.h:284) */
+	const float *boost;      /* host [n_sentences] or NULL (Booster, matcher_impl.h:99) */
+	int32_t want_flow;       /* 1: also produce mapping + edge similarities for the winners */
+	/* VK_ALG_RWMD (vectorian/alignment.py:275-283) */
+	int32_t rwmd_injective, rwmd_symmetric, rwmd_normalize_bow;
+	/* VK_ALG_WRD (vectorian/alignment.py:308-313) */
+	int32_t wrd_normalize_magnitudes;
+} vk_query_desc;
+
+/* Bounded result set, best first.  Order: score descending, then sentence index
+ * descending (the deterministic part of Match::compare_by_score,
+ * match/match_impl.h:8-42). */
+typedef struct {
+	int32_t capacity;        /* entries the arrays below can hold (>= max_matches) */
+	int32_t n_out;           /* written by the library */
+	float *score;            /* [capacity] Score::value = raw / reference_score * boost (match.h:302-307) */
+	float *raw_score;        /* [capacity] aligner score / cost_to_score */
+	int64_t *sentence;       /* [capacity] slice index within this corpus handle */
+	int16_t *mapping;        /* [capacity x len_t] InjectiveFlow target per query token or -1
+	                            (metric/alignment.h:194-196); NULL if !want_flow */
+	float *edge_sim;         /* [capacity x len_t] S[mapping[j]][j] (ScoreComputer, metric/alignment.h:335-345
+	                            reports distance = 1 - this); NULL if !want_flow */
+} vk_topk_out;
+
+/* kernel timings of the last vk_query on a handle, milliseconds, from HIP events
+ * recorded on the handle's stream */
+typedef struct {
+	float prepare_ms;   /* query upload + static table (if any) */
+	float score_ms;     /* the fused similarity + DP kernel (dominant) */
+	float topk_ms;      /* bounded result set selection */
+	float flow_ms;      /* traceback of the winners */
+	float total_ms;     /* first to last event */
+} vk_timings;
+
+int vk_abi_version(void);
+const char *vk_last_error(void);
+
+/* selects the HIP device for the calling thread's subsequent vk_corpus_create calls */
+int vk_init(int device);
+int vk_device_count(int *count);
+
+/* --- corpus residency: replaces core.Document(...) construction (document.cpp:30-58)
+ *     and the per-document vectors handed to the contextual metric ------------- */
+int vk_corpus_create(const vk_corpus_desc *desc, vk_corpus_t **out);
+/* Appends rows in order: token vectors (contextual) or vocabulary vectors (static).
+ * rows: [n_rows x d] row-major, dtype f32/bf16, in host or device memory.
+ * normalize=1 L2-normalises each row (Vectors.normalized, vectorian/embedding/vectors.py:71-80). */
+int vk_corpus_append_vectors(vk_corpus_t *c, const void *rows, int64_t n_rows, int32_t dtype, int32_t mem, int32_t normalize);
+/* VK_LAYOUT_STATIC: token ids of the whole shard (Token.id, common.h:34-42) */
+int vk_corpus_set_token_ids(vk_corpus_t *c, const int32_t *ids, int64_t n, int32_t mem);
+/* sentence spans as CSR offsets in token units, contiguous from 0
+ * (Spans::iterate, document.h:147-169).  sent_off: host [n_sentences + 1]. */
+int vk_corpus_set_sentences(vk_corpus_t *c, const int64_t *sent_off, int64_t n_sentences);
+int vk_corpus_finalize(vk_corpus_t *c);
+int vk_corpus_free(vk_corpus_t *c);
+int vk_corpus_device_bytes(const vk_corpus_t *c, int64_t *bytes);
+
+/* --- one query against the shard: replaces Query.initialize + Document.find for
+ *     every document + ResultSet.extend/best_n (vectorian/index.py:530-560) ------ */
+int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out);
+
+/* every sentence's Score::value of the last query, for the debug hook
+ * ('alignment' callback, metric/alignment.h:145-173).  host [n_sentences]. */
+int vk_last_scores(vk_corpus_t *c, float *scores, int64_t n);
+int vk_last_timings(const vk_corpus_t *c, vk_timings *t);
+
+/* ResultSet::extend (result_set.h:70-93) over plain arrays: merges `n_sets` result
+ * sets (e.g. one per GPU rank after the all-gather) into one bounded set.
+ * sentence indices must already be global. Pure host code. */
+int vk_merge_topk(const vk_topk_out *sets, int32_t n_sets, int32_t len_t, int32_t max_matches, vk_topk_out *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

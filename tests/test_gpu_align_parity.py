@@ -1,0 +1,93 @@
+"""-m gpu: the HIP path (through the C-ABI) against the CPU oracle on the same
+seeded inputs.  Scores within 1e-4 (north_star tolerance), sentence ids and
+traceback mappings identical."""
+
+import numpy as np
+import pytest
+
+from vectorian_amd import synth
+
+from helpers import assert_same_results, hip_contextual_corpus, hip_static_corpus, prep_contextual, prep_query
+
+pytestmark = pytest.mark.gpu
+
+EXP5 = ("table", (1 - 2.0 ** (-np.arange(0, 65) / 5)).astype(np.float32))  # smooth_gap_cost(5)
+
+GAPS = {
+	"linear0.1": (0.1, 0.1),
+	"linear0": (0.0, 0.0),
+	"linear_asym": (0.25, 0.05),
+	"affine": (("affine", 0.2, 0.05), ("affine", 0.1, 0.1)),
+	"exp5": (EXP5, EXP5),
+	"mixed": (0.1, EXP5),
+}
+
+
+@pytest.mark.parametrize("locality", [0, 1, 2])
+@pytest.mark.parametrize("gap", list(GAPS))
+@pytest.mark.parametrize("shape", ["fixed32_q10", "ragged_q5", "ragged64_q16", "tiny_q1"])
+def test_contextual_parity(hip, oracle, locality, gap, shape):
+	n, lo, hi, len_t, d = {
+		"fixed32_q10": (600, 32, 32, 10, 300),
+		"ragged_q5": (500, 1, 40, 5, 300),
+		"ragged64_q16": (300, 8, 64, 16, 768),
+		"tiny_q1": (37, 1, 3, 1, 50),
+	}[shape]
+	corpus = synth.make_contextual_corpus(n, lo, hi, 2000, d)
+	Xb = prep_contextual(corpus)
+	c = hip_contextual_corpus(hip, corpus, Xb)
+	gs, gt = GAPS[gap]
+	for q in synth.make_queries(corpus, 2, len_t):
+		Qb = prep_query(q)
+		ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=corpus["sent_off"], X=Xb, Q=Qb,
+			locality=locality, gap_s=gs, gap_t=gt, max_matches=10, min_score=0.0 if locality != 1 else -100.0)
+		got = c.query(Qb, locality=locality, gap_s=gs, gap_t=gt, q_normalize=False, max_matches=10,
+			min_score=0.0 if locality != 1 else -100.0).trimmed()
+		assert_same_results(got, ref)
+		np.testing.assert_allclose(got["raw_score"], ref["raw"], atol=2e-4, rtol=0)
+	c.close()
+
+
+@pytest.mark.parametrize("locality", [0, 1, 2])
+@pytest.mark.parametrize("gap", ["linear0.1", "affine", "exp5"])
+def test_static_parity(hip, oracle, locality, gap):
+	corpus = synth.make_static_corpus(700, 1, 40, 3000, 300)
+	c, Eb = hip_static_corpus(hip, corpus)
+	gs, gt = GAPS[gap]
+	for q in synth.make_queries(corpus, 2, 7):
+		Qb = prep_query(q)
+		ref = oracle.find(layout=oracle.LAYOUT_STATIC, d=300, sent_off=corpus["sent_off"], tok_id=corpus["tok_id"], E=Eb,
+			Q=Qb, q_ids=q["ids"], locality=locality, gap_s=gs, gap_t=gt, max_matches=20,
+			min_score=0.0 if locality != 1 else -100.0)
+		got = c.query(Qb, q_token_ids=q["ids"], locality=locality, gap_s=gs, gap_t=gt, q_normalize=False,
+			max_matches=20, min_score=0.0 if locality != 1 else -100.0).trimmed()
+		assert_same_results(got, ref)
+	c.close()
+
+
+def test_all_scores_and_boost(hip, oracle):
+	corpus = synth.make_contextual_corpus(1000, 4, 40, 2000, 300)
+	Xb = prep_contextual(corpus)
+	c = hip_contextual_corpus(hip, corpus, Xb)
+	q = synth.make_queries(corpus, 1, 6)[0]
+	Qb = prep_query(q)
+	boost = np.random.default_rng(5).uniform(0.5, 1.5, size=1000).astype(np.float32)
+	ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=300, sent_off=corpus["sent_off"], X=Xb, Q=Qb,
+		gap_s=0.1, gap_t=0.1, max_matches=50, boost=boost, want_all_scores=True)
+	got = c.query(Qb, gap_s=0.1, gap_t=0.1, q_normalize=False, max_matches=50, boost=boost)
+	assert_same_results(got.trimmed(), ref)
+	np.testing.assert_allclose(c.last_scores(), ref["all_scores"], atol=1e-4, rtol=0)
+	c.close()
+
+
+def test_errors_are_loud(hip):
+	corpus = synth.make_contextual_corpus(10, 4, 8, 100, 32)
+	c = hip_contextual_corpus(hip, corpus)
+	q = np.ones((17, 32), dtype=np.float32)
+	with pytest.raises(hip.VkError):
+		c.query(q)
+	with pytest.raises(hip.VkError):
+		c.query(q[:3], submatch_weight=0.5)
+	with pytest.raises(hip.VkError):
+		c.query(q[:3], algorithm=hip.VK_ALG_WRD)
+	c.close()

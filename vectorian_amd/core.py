@@ -1,0 +1,316 @@
+"""ctypes binding of libvectorian_hip.so (C-ABI: include/vectorian_hip.h).
+
+Takes the place of `vectorian.core` (vectorian/core/__init__.py:20-31, the pybind11
+module `vectorian_core`) for the brute-force alignment search path.  There is no
+CPU fallback: if the shared library is missing or no gfx950 device is present the
+calls raise (RuntimeError), they never compute elsewhere.
+"""
+
+import ctypes as C
+import enum
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvectorian_hip.so")
+
+VK_MAX_QUERY_LEN = 16
+VK_MAX_SENT_LEN = 64
+VK_MAX_MATCHES = 1024
+
+VK_F32, VK_BF16 = 0, 1
+VK_MEM_HOST, VK_MEM_DEVICE = 0, 1
+VK_LAYOUT_CONTEXTUAL, VK_LAYOUT_STATIC = 0, 1
+VK_ALG_ALIGN, VK_ALG_RWMD, VK_ALG_WRD = 0, 1, 2
+VK_GAP_LINEAR, VK_GAP_AFFINE, VK_GAP_TABLE = 0, 1, 2
+
+
+class Locality(enum.IntEnum):
+	"""core.pyalign.Locality (vectorian/core/cpp/module.cpp:149-151, used at
+	vectorian/alignment.py:97,130,187)."""
+	LOCAL = 0
+	GLOBAL = 1
+	SEMIGLOBAL = 2
+
+
+class pyalign:
+	"""namespace stand-in so that `core.pyalign.Locality.GLOBAL` reads as in the reference"""
+	Locality = Locality
+
+
+class _CorpusDesc(C.Structure):
+	_fields_ = [
+		("layout", C.c_int32), ("d", C.c_int32),
+		("n_tokens", C.c_int64), ("n_sentences", C.c_int64),
+		("vocab_size", C.c_int32), ("keep_magnitudes", C.c_int32)]
+
+
+class _Gap(C.Structure):
+	_fields_ = [
+		("kind", C.c_int32), ("u", C.c_float), ("v", C.c_float),
+		("table", C.POINTER(C.c_float)), ("n_table", C.c_int32)]
+
+
+class _QueryDesc(C.Structure):
+	_fields_ = [
+		("algorithm", C.c_int32), ("len_t", C.c_int32),
+		("q_vectors", C.c_void_p), ("q_dtype", C.c_int32), ("q_normalize", C.c_int32),
+		("q_token_ids", C.c_void_p),
+		("locality", C.c_int32),
+		("gap_s", _Gap), ("gap_t", _Gap),
+		("submatch_weight", C.c_float), ("bidirectional", C.c_int32),
+		("max_matches", C.c_int32), ("min_score", C.c_float),
+		("boost", C.c_void_p), ("want_flow", C.c_int32),
+		("rwmd_injective", C.c_int32), ("rwmd_symmetric", C.c_int32), ("rwmd_normalize_bow", C.c_int32),
+		("wrd_normalize_magnitudes", C.c_int32)]
+
+
+class _TopkOut(C.Structure):
+	_fields_ = [
+		("capacity", C.c_int32), ("n_out", C.c_int32),
+		("score", C.c_void_p), ("raw_score", C.c_void_p), ("sentence", C.c_void_p),
+		("mapping", C.c_void_p), ("edge_sim", C.c_void_p)]
+
+
+class _Timings(C.Structure):
+	_fields_ = [
+		("prepare_ms", C.c_float), ("score_ms", C.c_float), ("topk_ms", C.c_float),
+		("flow_ms", C.c_float), ("total_ms", C.c_float)]
+
+
+EXPORTS = [
+	"vk_abi_version", "vk_last_error", "vk_init", "vk_device_count",
+	"vk_corpus_create", "vk_corpus_append_vectors", "vk_corpus_set_token_ids",
+	"vk_corpus_set_sentences", "vk_corpus_finalize", "vk_corpus_free", "vk_corpus_device_bytes",
+	"vk_query", "vk_last_scores", "vk_last_timings", "vk_merge_topk"]
+
+_lib = None
+
+
+def lib():
+	"""Loads the shared library (no GPU needed to load it)."""
+	global _lib
+	if _lib is None:
+		if not os.path.exists(LIB_PATH):
+			raise RuntimeError(
+				f"{LIB_PATH} is missing: build it with `make -C vectorian_amd/csrc` "
+				"(or __graft_entry__.build()); there is no CPU fallback")
+		L = C.CDLL(LIB_PATH)
+		L.vk_last_error.restype = C.c_char_p
+		L.vk_corpus_create.argtypes = [C.POINTER(_CorpusDesc), C.POINTER(C.c_void_p)]
+		L.vk_corpus_append_vectors.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32]
+		L.vk_corpus_set_token_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
+		L.vk_corpus_set_sentences.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+		L.vk_corpus_finalize.argtypes = [C.c_void_p]
+		L.vk_corpus_free.argtypes = [C.c_void_p]
+		L.vk_corpus_device_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+		L.vk_query.argtypes = [C.c_void_p, C.POINTER(_QueryDesc), C.POINTER(_TopkOut)]
+		L.vk_last_scores.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+		L.vk_last_timings.argtypes = [C.c_void_p, C.POINTER(_Timings)]
+		L.vk_merge_topk.argtypes = [C.POINTER(_TopkOut), C.c_int32, C.c_int32, C.c_int32, C.POINTER(_TopkOut)]
+		if L.vk_abi_version() != 1:
+			raise RuntimeError("libvectorian_hip.so ABI version mismatch")
+		_lib = L
+	return _lib
+
+
+class VkError(RuntimeError):
+	"""C-ABI status != 0; the reference raises RuntimeError from C++ exceptions."""
+
+	def __init__(self, status, message):
+		super().__init__(f"vectorian_hip error {status}: {message}")
+		self.status = status
+
+
+def _check(status):
+	if status != 0:
+		raise VkError(status, lib().vk_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+	n = C.c_int(0)
+	status = lib().vk_device_count(C.byref(n))
+	return n.value if status == 0 else 0
+
+
+def init(device=0):
+	_check(lib().vk_init(int(device)))
+
+
+def _np_ptr(a):
+	return a.ctypes.data_as(C.c_void_p)
+
+
+def gap_to_struct(gap, keep, n_table):
+	"""gap: object with to_special_case()/costs(n) (vectorian_amd.alignment.GapCost),
+	or a tuple ('linear', u) / ('affine', u, v) / ('table', array), or a float."""
+	g = _Gap()
+	if hasattr(gap, "to_special_case"):
+		special = gap.to_special_case()
+		if "linear" in special:
+			gap = ("linear", special["linear"])
+		elif "affine" in special:
+			gap = ("affine",) + tuple(special["affine"])
+		else:
+			gap = ("table", gap.costs(n_table))
+	if isinstance(gap, (int, float)):
+		gap = ("linear", float(gap))
+	if gap[0] == "linear":
+		g.kind, g.u, g.v = VK_GAP_LINEAR, float(gap[1]), 0.0
+	elif gap[0] == "affine":
+		g.kind, g.u, g.v = VK_GAP_AFFINE, float(gap[1]), float(gap[2])
+	elif gap[0] == "table":
+		t = np.ascontiguousarray(gap[1], dtype=np.float32)
+		keep.append(t)
+		g.kind = VK_GAP_TABLE
+		g.table = t.ctypes.data_as(C.POINTER(C.c_float))
+		g.n_table = len(t)
+	else:
+		raise ValueError(gap)
+	return g
+
+
+class TopK:
+	"""Bounded result set as plain arrays (ResultSet, vectorian/core/cpp/result_set.h:17-153)."""
+
+	def __init__(self, k, len_t):
+		self.k, self.len_t = k, len_t
+		self.score = np.zeros(k, dtype=np.float32)
+		self.raw_score = np.zeros(k, dtype=np.float32)
+		self.sentence = np.zeros(k, dtype=np.int64)
+		self.mapping = np.full((k, len_t), -1, dtype=np.int16)
+		self.edge_sim = np.zeros((k, len_t), dtype=np.float32)
+		self.n = 0
+
+	def _struct(self):
+		s = _TopkOut()
+		s.capacity, s.n_out = self.k, self.n
+		s.score, s.raw_score, s.sentence = _np_ptr(self.score), _np_ptr(self.raw_score), _np_ptr(self.sentence)
+		s.mapping, s.edge_sim = _np_ptr(self.mapping), _np_ptr(self.edge_sim)
+		return s
+
+	def trimmed(self):
+		n = self.n
+		return dict(
+			score=self.score[:n].copy(), raw_score=self.raw_score[:n].copy(), sentence=self.sentence[:n].copy(),
+			mapping=self.mapping[:n].copy(), edge_sim=self.edge_sim[:n].copy())
+
+
+def merge_topk(sets, len_t, max_matches):
+	"""ResultSet.extend over several result sets (vk_merge_topk)."""
+	arr = (_TopkOut * len(sets))(*[s._struct() for s in sets])
+	out = TopK(max_matches, len_t)
+	so = out._struct()
+	_check(lib().vk_merge_topk(arr, len(sets), len_t, max_matches, C.byref(so)))
+	out.n = so.n_out
+	return out
+
+
+class Corpus:
+	"""A corpus shard resident in HBM (opaque vk_corpus_t handle)."""
+
+	def __init__(self, *, layout, d, n_tokens, n_sentences, vocab_size=0, keep_magnitudes=False, device=None):
+		if device is not None:
+			init(device)
+		self._h = C.c_void_p()
+		desc = _CorpusDesc(layout, d, n_tokens, n_sentences, vocab_size, int(keep_magnitudes))
+		_check(lib().vk_corpus_create(C.byref(desc), C.byref(self._h)))
+		self.layout, self.d = layout, d
+		self.n_tokens, self.n_sentences, self.vocab_size = n_tokens, n_sentences, vocab_size
+
+	def append_vectors(self, rows, normalize=True):
+		"""rows: numpy float32 / uint16(bf16) [n x d] on the host."""
+		rows = np.ascontiguousarray(rows)
+		if rows.dtype == np.float32:
+			dt = VK_F32
+		elif rows.dtype == np.uint16:
+			dt = VK_BF16
+		else:
+			raise TypeError(f"vectors must be float32 or uint16 (bf16 bits), got {rows.dtype}")
+		if rows.ndim != 2 or rows.shape[1] != self.d:
+			raise ValueError(f"expected [n x {self.d}] vectors, got {rows.shape}")
+		_check(lib().vk_corpus_append_vectors(self._h, _np_ptr(rows), rows.shape[0], dt, VK_MEM_HOST, int(normalize)))
+
+	def append_vectors_device(self, ptr, n_rows, dtype, normalize=True):
+		"""ptr: device pointer (e.g. torch.Tensor.data_ptr()) to [n_rows x d] row-major rows."""
+		_check(lib().vk_corpus_append_vectors(self._h, C.c_void_p(ptr), n_rows, dtype, VK_MEM_DEVICE, int(normalize)))
+
+	def set_token_ids(self, ids):
+		ids = np.ascontiguousarray(ids, dtype=np.int32)
+		_check(lib().vk_corpus_set_token_ids(self._h, _np_ptr(ids), len(ids), VK_MEM_HOST))
+
+	def set_sentences(self, sent_off):
+		sent_off = np.ascontiguousarray(sent_off, dtype=np.int64)
+		_check(lib().vk_corpus_set_sentences(self._h, _np_ptr(sent_off), len(sent_off) - 1))
+
+	def finalize(self):
+		_check(lib().vk_corpus_finalize(self._h))
+
+	@property
+	def device_bytes(self):
+		b = C.c_int64(0)
+		_check(lib().vk_corpus_device_bytes(self._h, C.byref(b)))
+		return b.value
+
+	def query(self, q_vectors, *, locality=Locality.LOCAL, gap_s=0.0, gap_t=0.0, algorithm=VK_ALG_ALIGN,
+			q_token_ids=None, q_normalize=True, max_matches=10, min_score=0.0, boost=None, want_flow=True,
+			submatch_weight=0.0, bidirectional=False, rwmd=(True, True, True), wrd_normalize=True):
+		"""One query against the shard (vk_query).  Returns a TopK."""
+		keep = []
+		q_vectors = np.ascontiguousarray(q_vectors)
+		if q_vectors.dtype == np.uint16:
+			qdt = VK_BF16
+		else:
+			q_vectors = np.ascontiguousarray(q_vectors, dtype=np.float32)
+			qdt = VK_F32
+		if q_vectors.ndim != 2 or q_vectors.shape[1] != self.d:
+			raise ValueError(f"expected [len_t x {self.d}] query vectors, got {q_vectors.shape}")
+		len_t = q_vectors.shape[0]
+		q = _QueryDesc()
+		q.algorithm, q.len_t = int(algorithm), len_t
+		q.q_vectors, q.q_dtype, q.q_normalize = _np_ptr(q_vectors), qdt, int(q_normalize)
+		if q_token_ids is not None:
+			ids = np.ascontiguousarray(q_token_ids, dtype=np.int32)
+			keep.append(ids)
+			q.q_token_ids = _np_ptr(ids)
+		q.locality = int(locality)
+		q.gap_s = gap_to_struct(gap_s, keep, VK_MAX_SENT_LEN + 1)
+		q.gap_t = gap_to_struct(gap_t, keep, VK_MAX_SENT_LEN + 1)
+		q.submatch_weight, q.bidirectional = float(submatch_weight), int(bool(bidirectional))
+		q.max_matches, q.min_score = int(max_matches), float(min_score)
+		if boost is not None:
+			b = np.ascontiguousarray(boost, dtype=np.float32)
+			if len(b) != self.n_sentences:
+				raise ValueError("boost must have one entry per sentence")
+			keep.append(b)
+			q.boost = _np_ptr(b)
+		q.want_flow = int(bool(want_flow))
+		q.rwmd_injective, q.rwmd_symmetric, q.rwmd_normalize_bow = [int(bool(x)) for x in rwmd]
+		q.wrd_normalize_magnitudes = int(bool(wrd_normalize))
+		out = TopK(max(1, int(max_matches)), len_t)
+		so = out._struct()
+		_check(lib().vk_query(self._h, C.byref(q), C.byref(so)))
+		out.n = so.n_out
+		return out
+
+	def last_scores(self):
+		s = np.empty(self.n_sentences, dtype=np.float32)
+		_check(lib().vk_last_scores(self._h, _np_ptr(s), len(s)))
+		return s
+
+	def last_timings(self):
+		t = _Timings()
+		_check(lib().vk_last_timings(self._h, C.byref(t)))
+		return {k: getattr(t, k) for k, _ in _Timings._fields_}
+
+	def close(self):
+		if self._h:
+			lib().vk_corpus_free(self._h)
+			self._h = C.c_void_p()
+
+	def __del__(self):
+		try:
+			self.close()
+		except Exception:
+			pass

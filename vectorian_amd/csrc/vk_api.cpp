@@ -1,0 +1,563 @@
+// vk_api.cpp -- implementation of the C-ABI declared in include/vectorian_hip.h.
+// Host side only: validation, device residency, launches, result assembly.
+// No CPU compute fallback exists: without a HIP device every entry point that
+// would compute returns VK_ERR_NO_DEVICE / VK_ERR_HIP.
+
+#include "../../include/vectorian_hip.h"
+#include "vk_device.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+	g_err = msg;
+	return code;
+}
+
+#define VK_HIP(call) \
+	do { \
+		hipError_t e_ = (call); \
+		if (e_ != hipSuccess) { \
+			char buf_[512]; \
+			snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+			return fail(VK_ERR_HIP, buf_); \
+		} \
+	} while (0)
+
+uint16_t f32_to_bf16(float x) {
+	uint32_t u;
+	memcpy(&u, &x, 4);
+	if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
+	u += 0x7fffu + ((u >> 16) & 1u);
+	return (uint16_t)(u >> 16);
+}
+
+float bf16_to_f32(uint16_t b) {
+	uint32_t u = ((uint32_t)b) << 16;
+	float f;
+	memcpy(&f, &u, 4);
+	return f;
+}
+
+float gap_cost(const vk_gap &g, int k) {
+	if (k <= 0) return 0.0f;
+	switch (g.kind) {
+	case VK_GAP_LINEAR: return g.u * (float)k;
+	case VK_GAP_AFFINE: return g.u + g.v * (float)k;
+	default: return (g.table && k < g.n_table) ? g.table[k] : INFINITY;
+	}
+}
+
+constexpr int kTopkChunk = 2048;
+constexpr int64_t kStageBytes = 64ll << 20;
+
+} // namespace
+
+struct vk_corpus {
+	vk_corpus_desc desc{};
+	int device = 0;
+	hipStream_t stream = nullptr;
+	int d_pad = 0, nk32 = 0, tail = 0, tile_bytes = 0;
+	int64_t rows_total = 0, rows_appended = 0, n_tiles = 0;
+	uint8_t *d_tiles = nullptr;
+	float *d_mag = nullptr;
+	int32_t *d_tok_id = nullptr;
+	int32_t *d_sent_off = nullptr;
+	std::vector<int64_t> h_sent_off;
+	bool have_ids = false, have_sent = false, finalized = false;
+	int max_len = 0, max_group_tiles = 0, max_group_tokens = 0;
+	int64_t device_bytes = 0;
+	// workspaces
+	void *d_stage = nullptr;
+	uint8_t *d_qtile = nullptr;
+	float *d_ws = nullptr, *d_wt = nullptr;
+	int32_t *d_qids = nullptr;
+	float *d_table = nullptr;
+	float *d_scores = nullptr, *d_raw = nullptr, *d_boost = nullptr;
+	uint64_t *d_keys[2] = {nullptr, nullptr};
+	float *d_out_raw = nullptr, *d_out_sim = nullptr;
+	int16_t *d_out_map = nullptr;
+	hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+	vk_timings last{};
+	bool have_scores = false;
+};
+
+namespace {
+
+int alloc(vk_corpus *c, void **p, size_t bytes) {
+	VK_HIP(hipMalloc(p, bytes ? bytes : 16));
+	c->device_bytes += (int64_t)bytes;
+	return VK_OK;
+}
+
+template <typename T> int alloc_t(vk_corpus *c, T **p, size_t n) { return alloc(c, (void **)p, n * sizeof(T)); }
+
+} // namespace
+
+extern "C" {
+
+int vk_abi_version(void) { return VK_ABI_VERSION; }
+
+const char *vk_last_error(void) { return g_err.c_str(); }
+
+int vk_device_count(int *count) {
+	if (!count) return fail(VK_ERR_INVALID, "count is null");
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess) { *count = 0; return fail(VK_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+	*count = n;
+	return VK_OK;
+}
+
+int vk_init(int device) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(VK_ERR_NO_DEVICE, "no HIP device available");
+	if (device < 0 || device >= n) return fail(VK_ERR_INVALID, "device index out of range");
+	VK_HIP(hipSetDevice(device));
+	hipDeviceProp_t prop;
+	VK_HIP(hipGetDeviceProperties(&prop, device));
+	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+		return fail(VK_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+	return VK_OK;
+}
+
+int vk_corpus_create(const vk_corpus_desc *desc, vk_corpus_t **out) {
+	if (!desc || !out) return fail(VK_ERR_INVALID, "null argument");
+	if (desc->layout != VK_LAYOUT_CONTEXTUAL && desc->layout != VK_LAYOUT_STATIC) return fail(VK_ERR_INVALID, "bad layout");
+	if (desc->d < 1 || desc->d > 8192) return fail(VK_ERR_INVALID, "embedding dimension out of range");
+	if (desc->n_tokens < 0 || desc->n_tokens >= (1ll << 31) - 64) return fail(VK_ERR_INVALID, "n_tokens must be < 2^31 per shard");
+	if (desc->n_sentences < 0 || desc->n_sentences >= (1ll << 31) - 8) return fail(VK_ERR_INVALID, "n_sentences out of range");
+	if (desc->layout == VK_LAYOUT_STATIC && desc->vocab_size < 1) return fail(VK_ERR_INVALID, "static layout needs vocab_size >= 1");
+	if (desc->layout == VK_LAYOUT_STATIC && desc->keep_magnitudes) return fail(VK_ERR_UNSUPPORTED, "magnitudes are kept for the contextual layout only");
+
+	int dev = 0;
+	VK_HIP(hipGetDevice(&dev));
+	vk_corpus *c = new vk_corpus();
+	c->desc = *desc;
+	c->device = dev;
+	c->d_pad = (desc->d + 15) / 16 * 16;
+	c->nk32 = c->d_pad / 32;
+	c->tail = (c->d_pad % 32) ? 1 : 0;
+	c->tile_bytes = c->d_pad * 32;
+	c->rows_total = desc->layout == VK_LAYOUT_STATIC ? desc->vocab_size : desc->n_tokens;
+	c->n_tiles = (c->rows_total + 15) / 16 + 1;   // + one zero tile: waves may read one tile past the end
+
+	int rc = VK_OK;
+	do {
+		if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = fail(VK_ERR_HIP, "hipStreamCreate failed"); break; }
+		for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { rc = fail(VK_ERR_HIP, "hipEventCreate failed"); break; }
+		if (rc) break;
+		if ((rc = alloc_t(c, &c->d_tiles, (size_t)c->n_tiles * c->tile_bytes))) break;
+		if (hipMemsetAsync(c->d_tiles, 0, (size_t)c->n_tiles * c->tile_bytes, c->stream) != hipSuccess) { rc = fail(VK_ERR_HIP, "memset failed"); break; }
+		if (desc->keep_magnitudes && (rc = alloc_t(c, &c->d_mag, (size_t)c->rows_total + 16))) break;
+		if (desc->layout == VK_LAYOUT_STATIC) {
+			if ((rc = alloc_t(c, &c->d_tok_id, (size_t)desc->n_tokens + 64))) break;
+			if ((rc = alloc_t(c, &c->d_table, (size_t)c->n_tiles * 16 * 16))) break;
+		}
+		if ((rc = alloc_t(c, &c->d_sent_off, (size_t)desc->n_sentences + 8))) break;
+		if ((rc = alloc_t(c, &c->d_qtile, (size_t)c->tile_bytes))) break;
+		if ((rc = alloc_t(c, &c->d_ws, 128))) break;
+		if ((rc = alloc_t(c, &c->d_wt, 32))) break;
+		if ((rc = alloc_t(c, &c->d_qids, 32))) break;
+		if ((rc = alloc_t(c, &c->d_scores, (size_t)desc->n_sentences + 8))) break;
+		if ((rc = alloc_t(c, &c->d_raw, (size_t)desc->n_sentences + 8))) break;
+		const size_t nblk = (size_t)((desc->n_sentences + kTopkChunk - 1) / kTopkChunk) + 1;
+		if ((rc = alloc_t(c, &c->d_keys[0], nblk * VK_MAX_MATCHES + kTopkChunk))) break;
+		if ((rc = alloc_t(c, &c->d_keys[1], (nblk * VK_MAX_MATCHES) / 2 + 2 * kTopkChunk))) break;
+		if ((rc = alloc_t(c, &c->d_out_raw, VK_MAX_MATCHES))) break;
+		if ((rc = alloc_t(c, &c->d_out_sim, (size_t)VK_MAX_MATCHES * 16))) break;
+		if ((rc = alloc_t(c, &c->d_out_map, (size_t)VK_MAX_MATCHES * 16))) break;
+	} while (0);
+	if (rc) { vk_corpus_free(c); return rc; }
+	*out = c;
+	return VK_OK;
+}
+
+int vk_corpus_free(vk_corpus_t *c) {
+	if (!c) return VK_OK;
+	(void)hipSetDevice(c->device);
+	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	void *ptrs[] = {c->d_tiles, c->d_mag, c->d_tok_id, c->d_sent_off, c->d_stage, c->d_qtile, c->d_ws, c->d_wt, c->d_qids,
+		c->d_table, c->d_scores, c->d_raw, c->d_boost, c->d_keys[0], c->d_keys[1], c->d_out_raw, c->d_out_sim, c->d_out_map};
+	for (void *p : ptrs) if (p) (void)hipFree(p);
+	for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+	if (c->stream) (void)hipStreamDestroy(c->stream);
+	delete c;
+	return VK_OK;
+}
+
+int vk_corpus_device_bytes(const vk_corpus_t *c, int64_t *bytes) {
+	if (!c || !bytes) return fail(VK_ERR_INVALID, "null argument");
+	*bytes = c->device_bytes;
+	return VK_OK;
+}
+
+int vk_corpus_append_vectors(vk_corpus_t *c, const void *rows, int64_t n_rows, int32_t dtype, int32_t mem, int32_t normalize) {
+	if (!c || (!rows && n_rows > 0)) return fail(VK_ERR_INVALID, "null argument");
+	if (c->finalized) return fail(VK_ERR_STATE, "corpus already finalized");
+	if (dtype != VK_F32 && dtype != VK_BF16) return fail(VK_ERR_INVALID, "bad dtype");
+	if (n_rows < 0 || c->rows_appended + n_rows > c->rows_total) return fail(VK_ERR_INVALID, "more rows appended than declared");
+	VK_HIP(hipSetDevice(c->device));
+	const size_t esz = dtype == VK_F32 ? 4 : 2;
+	const size_t row_bytes = esz * (size_t)c->desc.d;
+	if (mem == VK_MEM_DEVICE) {
+		VK_HIP(vk_launch_pack(rows, dtype == VK_BF16, n_rows, c->desc.d, c->d_pad, c->rows_appended, c->d_tiles, c->d_mag,
+			normalize, c->stream));
+		VK_HIP(hipStreamSynchronize(c->stream));
+		c->rows_appended += n_rows;
+		return VK_OK;
+	}
+	if (mem != VK_MEM_HOST) return fail(VK_ERR_INVALID, "bad memory kind");
+	if (!c->d_stage) {
+		int rc = alloc(c, &c->d_stage, (size_t)kStageBytes);
+		if (rc) return rc;
+	}
+	const int64_t rows_per_chunk = std::max<int64_t>(1, kStageBytes / (int64_t)row_bytes);
+	for (int64_t r = 0; r < n_rows; r += rows_per_chunk) {
+		const int64_t nr = std::min(rows_per_chunk, n_rows - r);
+		VK_HIP(hipMemcpyAsync(c->d_stage, (const uint8_t *)rows + (size_t)r * row_bytes, (size_t)nr * row_bytes, hipMemcpyHostToDevice, c->stream));
+		VK_HIP(vk_launch_pack(c->d_stage, dtype == VK_BF16, nr, c->desc.d, c->d_pad, c->rows_appended + r, c->d_tiles, c->d_mag,
+			normalize, c->stream));
+		VK_HIP(hipStreamSynchronize(c->stream));
+	}
+	c->rows_appended += n_rows;
+	return VK_OK;
+}
+
+int vk_corpus_set_token_ids(vk_corpus_t *c, const int32_t *ids, int64_t n, int32_t mem) {
+	if (!c || !ids) return fail(VK_ERR_INVALID, "null argument");
+	if (c->desc.layout != VK_LAYOUT_STATIC) return fail(VK_ERR_STATE, "token ids belong to the static layout");
+	if (c->finalized) return fail(VK_ERR_STATE, "corpus already finalized");
+	if (n != c->desc.n_tokens) return fail(VK_ERR_INVALID, "token id count differs from n_tokens");
+	VK_HIP(hipSetDevice(c->device));
+	if (mem == VK_MEM_HOST) {
+		for (int64_t i = 0; i < n; i++)
+			if (ids[i] < 0 || ids[i] >= c->desc.vocab_size) return fail(VK_ERR_INVALID, "token id outside the vocabulary");
+	}
+	VK_HIP(hipMemcpyAsync(c->d_tok_id, ids, (size_t)n * 4, mem == VK_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+	VK_HIP(hipStreamSynchronize(c->stream));
+	c->have_ids = true;
+	return VK_OK;
+}
+
+int vk_corpus_set_sentences(vk_corpus_t *c, const int64_t *sent_off, int64_t n_sentences) {
+	if (!c || !sent_off) return fail(VK_ERR_INVALID, "null argument");
+	if (c->finalized) return fail(VK_ERR_STATE, "corpus already finalized");
+	if (n_sentences != c->desc.n_sentences) return fail(VK_ERR_INVALID, "sentence count differs from n_sentences");
+	if (sent_off[0] != 0) return fail(VK_ERR_INVALID, "sentence spans must start at token 0 (document.h:151-168)");
+	if (sent_off[n_sentences] != c->desc.n_tokens) return fail(VK_ERR_INVALID, "sentence spans must cover exactly n_tokens");
+	int max_len = 0;
+	for (int64_t s = 0; s < n_sentences; s++) {
+		const int64_t len = sent_off[s + 1] - sent_off[s];
+		if (len < 0) return fail(VK_ERR_INVALID, "sentence offsets must be non-decreasing");
+		if (len > VK_MAX_SENT_LEN) {
+			char buf[128];
+			snprintf(buf, sizeof buf, "sentence %lld has %lld tokens; the HIP path handles at most %d", (long long)s, (long long)len, VK_MAX_SENT_LEN);
+			return fail(VK_ERR_UNSUPPORTED, buf);
+		}
+		max_len = std::max(max_len, (int)len);
+	}
+	VK_HIP(hipSetDevice(c->device));
+	c->h_sent_off.assign(sent_off, sent_off + n_sentences + 1);
+	std::vector<int32_t> off32((size_t)n_sentences + 1);
+	for (int64_t s = 0; s <= n_sentences; s++) off32[(size_t)s] = (int32_t)sent_off[s];
+	VK_HIP(hipMemcpy(c->d_sent_off, off32.data(), off32.size() * 4, hipMemcpyHostToDevice));
+	c->max_len = max_len;
+	// per wave: groups of 4 consecutive sentences
+	int mt = 1, mtok = 1;
+	for (int64_t g = 0; g * 4 < n_sentences; g++) {
+		const int64_t a = sent_off[g * 4], b = sent_off[std::min<int64_t>(g * 4 + 4, n_sentences)];
+		const int tiles = (int)(((b + 15) >> 4) - (a >> 4));
+		mt = std::max(mt, tiles);
+		mtok = std::max(mtok, (int)(b - a));
+	}
+	c->max_group_tiles = mt;
+	c->max_group_tokens = mtok;
+	c->have_sent = true;
+	return VK_OK;
+}
+
+int vk_corpus_finalize(vk_corpus_t *c) {
+	if (!c) return fail(VK_ERR_INVALID, "null argument");
+	if (c->rows_appended != c->rows_total) return fail(VK_ERR_STATE, "not all vectors were appended");
+	if (!c->have_sent) return fail(VK_ERR_STATE, "sentence spans were not set");
+	if (c->desc.layout == VK_LAYOUT_STATIC && !c->have_ids) return fail(VK_ERR_STATE, "token ids were not set");
+	VK_HIP(hipSetDevice(c->device));
+	if (c->d_stage) { VK_HIP(hipFree(c->d_stage)); c->d_stage = nullptr; c->device_bytes -= kStageBytes; }
+	VK_HIP(hipStreamSynchronize(c->stream));
+	c->finalized = true;
+	return VK_OK;
+}
+
+static int validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_topk_out *out) {
+	if (!c || !q || !out) return fail(VK_ERR_INVALID, "null argument");
+	if (!c->finalized) return fail(VK_ERR_STATE, "corpus not finalized");
+	if (q->len_t < 1) return fail(VK_ERR_INVALID, "empty query");
+	if (q->len_t > VK_MAX_QUERY_LEN) return fail(VK_ERR_UNSUPPORTED, "query longer than VK_MAX_QUERY_LEN (16) tokens");
+	if (!q->q_vectors) return fail(VK_ERR_INVALID, "q_vectors is null");
+	if (q->q_dtype != VK_F32 && q->q_dtype != VK_BF16) return fail(VK_ERR_INVALID, "bad q_dtype");
+	if (q->max_matches < 1 || q->max_matches > VK_MAX_MATCHES) return fail(VK_ERR_INVALID, "max_matches out of range");
+	if (out->capacity < q->max_matches) return fail(VK_ERR_INVALID, "output capacity smaller than max_matches");
+	if (!out->score || !out->sentence) return fail(VK_ERR_INVALID, "output arrays missing");
+	if (q->submatch_weight != 0.0f) return fail(VK_ERR_UNSUPPORTED, "submatch_weight != 0 is not implemented on the HIP path");
+	if (q->bidirectional) return fail(VK_ERR_UNSUPPORTED, "bidirectional is not implemented (unused upstream, query.cpp:81-83)");
+	if (q->algorithm == VK_ALG_ALIGN) {
+		if (q->locality < VK_LOCAL || q->locality > VK_SEMIGLOBAL) return fail(VK_ERR_INVALID, "bad locality");
+		for (const vk_gap *g : {&q->gap_s, &q->gap_t}) {
+			if (g->kind < VK_GAP_LINEAR || g->kind > VK_GAP_TABLE) return fail(VK_ERR_INVALID, "bad gap kind");
+			if (g->kind == VK_GAP_TABLE && (!g->table || g->n_table < 1)) return fail(VK_ERR_INVALID, "gap table missing");
+		}
+		if (q->gap_s.kind == VK_GAP_TABLE && q->gap_s.n_table <= c->max_len) return fail(VK_ERR_INVALID, "gap_s table shorter than the longest sentence");
+		if (q->gap_t.kind == VK_GAP_TABLE && q->gap_t.n_table <= q->len_t) return fail(VK_ERR_INVALID, "gap_t table shorter than the query");
+		if (q->want_flow && (!out->mapping || !out->edge_sim)) return fail(VK_ERR_INVALID, "want_flow needs mapping and edge_sim arrays");
+	} else if (q->algorithm == VK_ALG_RWMD) {
+		return fail(VK_ERR_UNSUPPORTED, "VK_ALG_RWMD is not implemented yet on the HIP path");
+	} else if (q->algorithm == VK_ALG_WRD) {
+		return fail(VK_ERR_UNSUPPORTED, "VK_ALG_WRD is not implemented yet on the HIP path");
+	} else {
+		return fail(VK_ERR_INVALID, "bad algorithm");
+	}
+	return VK_OK;
+}
+
+// Vectors.normalized for the query rows, then bf16 (RNE), then tile order (16 rows,
+// rows >= len_t zero).  Same arithmetic as oracle/vk_oracle.c vko_normalize_rows_bf16.
+static void pack_query(const vk_corpus *c, const vk_query_desc *q, std::vector<uint8_t> &tile) {
+	const int d = c->desc.d, nk32 = c->nk32;
+	tile.assign((size_t)c->tile_bytes, 0);
+	std::vector<float> row((size_t)d);
+	for (int i = 0; i < q->len_t; i++) {
+		for (int k = 0; k < d; k++)
+			row[(size_t)k] = q->q_dtype == VK_F32 ? ((const float *)q->q_vectors)[(size_t)i * d + k]
+			                                       : bf16_to_f32(((const uint16_t *)q->q_vectors)[(size_t)i * d + k]);
+		if (q->q_normalize) {
+			double acc = 0.0;
+			for (int k = 0; k < d; k++) acc += (double)row[(size_t)k] * (double)row[(size_t)k];
+			float m = (float)std::sqrt(acc);
+			if (m != m) m = 0.0f;
+			for (int k = 0; k < d; k++) {
+				float v = row[(size_t)k] / m;
+				if (v != v) v = 0.0f;
+				row[(size_t)k] = v;
+			}
+		}
+		for (int k = 0; k < d; k++) {
+			const uint16_t b = f32_to_bf16(row[(size_t)k]);
+			size_t off;
+			if (k < nk32 * 32) {
+				const int t = k >> 5, g = (k & 31) >> 3, j = k & 7;
+				off = (size_t)t * 1024 + (size_t)(g * 16 + i) * 16 + (size_t)j * 2;
+			} else {
+				const int kk = k - nk32 * 32, g = kk >> 2, j = kk & 3;
+				off = (size_t)nk32 * 1024 + (size_t)(g * 16 + i) * 8 + (size_t)j * 2;
+			}
+			memcpy(&tile[off], &b, 2);
+		}
+	}
+}
+
+int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
+	int rc = validate_query(c, q, out);
+	if (rc) return rc;
+	VK_HIP(hipSetDevice(c->device));
+	hipStream_t st = c->stream;
+	const int64_t n = c->desc.n_sentences;
+	const int k = q->max_matches;
+	out->n_out = 0;
+	c->have_scores = false;
+	if (n == 0) return VK_OK;
+
+	// ---- prepare: query tile, gap tables, boost, static table -------------
+	VK_HIP(hipEventRecord(c->ev[0], st));
+	std::vector<uint8_t> qtile;
+	pack_query(c, q, qtile);
+	VK_HIP(hipMemcpyAsync(c->d_qtile, qtile.data(), qtile.size(), hipMemcpyHostToDevice, st));
+
+	VkScoreParams p{};
+	const int ks = q->gap_s.kind, kt = q->gap_t.kind;
+	float ws[128], wt[32];
+	if (ks == VK_GAP_LINEAR && kt == VK_GAP_LINEAR) {
+		p.gap_mode = 0;
+		p.gs = q->gap_s.u; p.gt = q->gap_t.u;
+	} else if ((ks == VK_GAP_LINEAR || ks == VK_GAP_AFFINE) && (kt == VK_GAP_LINEAR || kt == VK_GAP_AFFINE)) {
+		p.gap_mode = 1;
+		p.a_s = ks == VK_GAP_AFFINE ? q->gap_s.u : 0.0f;
+		p.gs = ks == VK_GAP_AFFINE ? q->gap_s.v : q->gap_s.u;
+		p.a_t = kt == VK_GAP_AFFINE ? q->gap_t.u : 0.0f;
+		p.gt = kt == VK_GAP_AFFINE ? q->gap_t.v : q->gap_t.u;
+		p.open_s = p.a_s + p.gs;
+		p.open_t = p.a_t + p.gt;
+	} else {
+		p.gap_mode = 2;
+	}
+	for (int i = 0; i < 128; i++) ws[i] = gap_cost(q->gap_s, i);
+	for (int i = 0; i < 32; i++) wt[i] = gap_cost(q->gap_t, i);
+	VK_HIP(hipMemcpyAsync(c->d_ws, ws, sizeof ws, hipMemcpyHostToDevice, st));
+	VK_HIP(hipMemcpyAsync(c->d_wt, wt, sizeof wt, hipMemcpyHostToDevice, st));
+
+	if (q->boost) {
+		if (!c->d_boost) { rc = alloc_t(c, &c->d_boost, (size_t)n + 8); if (rc) return rc; }
+		VK_HIP(hipMemcpyAsync(c->d_boost, q->boost, (size_t)n * 4, hipMemcpyHostToDevice, st));
+	}
+
+	const bool is_static = c->desc.layout == VK_LAYOUT_STATIC;
+	if (is_static) {
+		int32_t ids[32];
+		for (int j = 0; j < 32; j++) ids[j] = (q->q_token_ids && j < q->len_t) ? q->q_token_ids[j] : -1;
+		VK_HIP(hipMemcpyAsync(c->d_qids, ids, sizeof ids, hipMemcpyHostToDevice, st));
+		VK_HIP(vk_launch_table(c->d_tiles, c->d_qtile, (int32_t)c->n_tiles, c->nk32, c->tail, c->tile_bytes, c->d_table,
+			q->q_token_ids ? c->d_qids : nullptr, q->len_t, c->desc.vocab_size, st));
+	}
+
+	// ---- the fused scoring kernel ------------------------------------------
+	VK_HIP(hipEventRecord(c->ev[1], st));
+	p.tiles = c->d_tiles; p.tok_id = c->d_tok_id; p.table = c->d_table; p.sent_off = c->d_sent_off;
+	p.n_sent = (int32_t)n; p.layout = is_static ? VK_DEV_LAYOUT_STATIC : VK_DEV_LAYOUT_CONTEXTUAL;
+	p.nk32 = c->nk32; p.tail = c->tail; p.tile_bytes = c->tile_bytes;
+	p.qtile = c->d_qtile; p.len_t = q->len_t; p.locality = q->locality;
+	p.ws = c->d_ws; p.wt = c->d_wt;
+	p.boost = q->boost ? c->d_boost : nullptr;
+	p.scores = c->d_scores; p.raw = c->d_raw;
+	p.s_rows_per_wave = is_static ? (c->max_group_tokens + 15) / 16 * 16 : c->max_group_tiles * 16;
+	p.h_rows = c->max_len + 1;
+	int lds_floats = p.s_rows_per_wave * 16;
+	if (p.gap_mode == 2) lds_floats += 4 * p.h_rows * 16;
+	p.lds_floats_per_wave = lds_floats;
+	const size_t smem = (size_t)lds_floats * 4 * 4;   // 4 waves per block
+	if (smem > 160 * 1024) return fail(VK_ERR_UNSUPPORTED, "LDS demand exceeds 160 KiB per workgroup");
+	const int64_t n_groups = (n + 3) / 4;
+	const int blocks_per_cu = std::max(1, std::min(8, (int)((160 * 1024) / std::max<size_t>(smem, 1))));
+	const int grid = (int)std::min<int64_t>((n_groups + 3) / 4, (int64_t)256 * blocks_per_cu);
+	VK_HIP(vk_launch_score(&p, grid, smem, st));
+
+	// ---- bounded result set -------------------------------------------------
+	VK_HIP(hipEventRecord(c->ev[2], st));
+	int nb = 0, cur = 0;
+	VK_HIP(vk_launch_topk_scores(c->d_scores, n, q->min_score, k, c->d_keys[0], &nb, st));
+	while (nb > 1) {
+		const int64_t nkeys = (int64_t)nb * k;
+		VK_HIP(vk_launch_topk_keys(c->d_keys[cur], nkeys, k, c->d_keys[1 - cur], &nb, st));
+		cur = 1 - cur;
+	}
+
+	// ---- flow of the winners ------------------------------------------------
+	VK_HIP(hipEventRecord(c->ev[3], st));
+	if (q->want_flow) {
+		VkFlowParams f{};
+		f.tiles = c->d_tiles; f.tok_id = c->d_tok_id; f.table = c->d_table; f.sent_off = c->d_sent_off;
+		f.layout = p.layout; f.nk32 = c->nk32; f.tail = c->tail; f.tile_bytes = c->tile_bytes;
+		f.qtile = c->d_qtile; f.len_t = q->len_t; f.locality = q->locality; f.gap_mode = p.gap_mode;
+		f.gs = p.gs; f.gt = p.gt; f.a_s = p.a_s; f.a_t = p.a_t; f.open_s = p.open_s; f.open_t = p.open_t;
+		f.ws = c->d_ws; f.wt = c->d_wt;
+		f.keys = c->d_keys[cur]; f.raw_out = c->d_out_raw; f.mapping = c->d_out_map; f.edge_sim = c->d_out_sim;
+		VK_HIP(vk_launch_flow(&f, k, st));
+	}
+	VK_HIP(hipEventRecord(c->ev[4], st));
+
+	// ---- results to host ------------------------------------------------------
+	std::vector<uint64_t> keys((size_t)k);
+	std::vector<float> raw((size_t)k), sim((size_t)k * 16);
+	std::vector<int16_t> map((size_t)k * 16);
+	VK_HIP(hipMemcpyAsync(keys.data(), c->d_keys[cur], (size_t)k * 8, hipMemcpyDeviceToHost, st));
+	if (q->want_flow) {
+		VK_HIP(hipMemcpyAsync(raw.data(), c->d_out_raw, (size_t)k * 4, hipMemcpyDeviceToHost, st));
+		VK_HIP(hipMemcpyAsync(map.data(), c->d_out_map, (size_t)k * 32, hipMemcpyDeviceToHost, st));
+		VK_HIP(hipMemcpyAsync(sim.data(), c->d_out_sim, (size_t)k * 64, hipMemcpyDeviceToHost, st));
+	}
+	VK_HIP(hipStreamSynchronize(st));
+
+	int n_out = 0;
+	for (int i = 0; i < k; i++) {
+		if (keys[(size_t)i] == 0) break;
+		n_out++;
+	}
+	std::vector<float> raw_sel((size_t)std::max(n_out, 1));
+	if (!q->want_flow && out->raw_score && n_out > 0) {
+		// gather the aligner scores of the winners
+		for (int i = 0; i < n_out; i++) {
+			const int64_t g = (int64_t)(uint32_t)(keys[(size_t)i] & 0xffffffffu);
+			VK_HIP(hipMemcpyAsync(&raw_sel[(size_t)i], c->d_raw + g, 4, hipMemcpyDeviceToHost, st));
+		}
+		VK_HIP(hipStreamSynchronize(st));
+	}
+	for (int i = 0; i < n_out; i++) {
+		const uint64_t key = keys[(size_t)i];
+		const uint32_t ob = (uint32_t)(key >> 32);
+		const uint32_t bits = (ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob;
+		float s;
+		memcpy(&s, &bits, 4);
+		out->score[i] = s;
+		out->sentence[i] = (int64_t)(uint32_t)(key & 0xffffffffu);
+		if (out->raw_score) out->raw_score[i] = q->want_flow ? raw[(size_t)i] : raw_sel[(size_t)i];
+		if (q->want_flow) {
+			for (int j = 0; j < q->len_t; j++) {
+				out->mapping[(size_t)i * q->len_t + j] = map[(size_t)i * 16 + j];
+				out->edge_sim[(size_t)i * q->len_t + j] = sim[(size_t)i * 16 + j];
+			}
+		}
+	}
+	out->n_out = n_out;
+	c->have_scores = true;
+
+	float ms = 0;
+	vk_timings t{};
+	if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) t.prepare_ms = ms;
+	if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) t.score_ms = ms;
+	if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) t.topk_ms = ms;
+	if (hipEventElapsedTime(&ms, c->ev[3], c->ev[4]) == hipSuccess) t.flow_ms = ms;
+	if (hipEventElapsedTime(&ms, c->ev[0], c->ev[4]) == hipSuccess) t.total_ms = ms;
+	c->last = t;
+	return VK_OK;
+}
+
+int vk_last_scores(vk_corpus_t *c, float *scores, int64_t n) {
+	if (!c || !scores) return fail(VK_ERR_INVALID, "null argument");
+	if (!c->have_scores) return fail(VK_ERR_STATE, "no query has run on this corpus");
+	if (n != c->desc.n_sentences) return fail(VK_ERR_INVALID, "n differs from n_sentences");
+	VK_HIP(hipSetDevice(c->device));
+	VK_HIP(hipMemcpy(scores, c->d_scores, (size_t)n * 4, hipMemcpyDeviceToHost));
+	return VK_OK;
+}
+
+int vk_last_timings(const vk_corpus_t *c, vk_timings *t) {
+	if (!c || !t) return fail(VK_ERR_INVALID, "null argument");
+	*t = c->last;
+	return VK_OK;
+}
+
+int vk_merge_topk(const vk_topk_out *sets, int32_t n_sets, int32_t len_t, int32_t max_matches, vk_topk_out *out) {
+	if (!sets || !out || n_sets < 0) return fail(VK_ERR_INVALID, "null argument");
+	if (max_matches < 1 || out->capacity < max_matches) return fail(VK_ERR_INVALID, "output capacity smaller than max_matches");
+	struct Ref { float score; int64_t sent; int set, idx; };
+	std::vector<Ref> all;
+	for (int s = 0; s < n_sets; s++)
+		for (int i = 0; i < sets[s].n_out; i++) all.push_back({sets[s].score[i], sets[s].sentence[i], s, i});
+	std::sort(all.begin(), all.end(), [](const Ref &a, const Ref &b) {
+		if (a.score != b.score) return a.score > b.score;
+		return a.sent > b.sent;
+	});
+	const int n_out = (int)std::min<size_t>(all.size(), (size_t)max_matches);
+	for (int i = 0; i < n_out; i++) {
+		const Ref &r = all[(size_t)i];
+		const vk_topk_out &src = sets[r.set];
+		out->score[i] = r.score;
+		out->sentence[i] = r.sent;
+		if (out->raw_score) out->raw_score[i] = src.raw_score ? src.raw_score[r.idx] : 0.0f;
+		if (out->mapping && src.mapping)
+			memcpy(out->mapping + (size_t)i * len_t, src.mapping + (size_t)r.idx * len_t, (size_t)len_t * 2);
+		if (out->edge_sim && src.edge_sim)
+			memcpy(out->edge_sim + (size_t)i * len_t, src.edge_sim + (size_t)r.idx * len_t, (size_t)len_t * 4);
+	}
+	out->n_out = n_out;
+	return VK_OK;
+}
+
+} // extern "C"

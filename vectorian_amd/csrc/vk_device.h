@@ -1,0 +1,86 @@
+// vk_device.h -- structures shared between the kernels (vk_kernels.hip) and the
+// C-ABI implementation (vk_api.cpp).  Internal; the public interface is
+// include/vectorian_hip.h.
+#ifndef VK_DEVICE_H
+#define VK_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define VK_DEV_LOCAL 0
+#define VK_DEV_GLOBAL 1
+#define VK_DEV_SEMIGLOBAL 2
+
+#define VK_DEV_LAYOUT_CONTEXTUAL 0
+#define VK_DEV_LAYOUT_STATIC 1
+
+#define VK_DEV_MAX_SENT_LEN 64
+#define VK_DEV_MAX_QUERY_LEN 16
+
+struct VkScoreParams {
+	// corpus
+	const uint8_t *tiles;      // contextual: token tiles
+	const int32_t *tok_id;     // static: token ids
+	const float *table;        // static: per-query similarity table [V_pad x 16]
+	const int32_t *sent_off;   // [n_sent + 1]
+	int32_t n_sent;
+	int32_t layout;
+	int32_t nk32, tail, tile_bytes;
+	// query
+	const uint8_t *qtile;      // query in tile order (16 rows, rows >= len_t are zero)
+	int32_t len_t;
+	int32_t locality;
+	int32_t gap_mode;          // 0 linear, 1 affine, 2 general
+	float gs, gt;              // linear: w(k) = g*k; affine: b (extension)
+	float a_s, a_t;            // affine: a
+	float open_s, open_t;      // affine: a + b
+	const float *ws;           // general: [max_len + 1]
+	const float *wt;           // general: [17]
+	const float *boost;        // [n_sent] or null
+	// outputs
+	float *scores;             // Score::value per sentence (-inf: empty slice)
+	float *raw;                // aligner score per sentence
+	// LDS carve-up (floats)
+	int32_t lds_floats_per_wave;
+	int32_t s_rows_per_wave;   // rows of the similarity staging area
+	int32_t h_rows;            // general gap: history rows per sentence (max_len + 1)
+};
+
+struct VkFlowParams {
+	const uint8_t *tiles;
+	const int32_t *tok_id;
+	const float *table;
+	const int32_t *sent_off;
+	int32_t layout;
+	int32_t nk32, tail, tile_bytes;
+	const uint8_t *qtile;
+	int32_t len_t;
+	int32_t locality;
+	int32_t gap_mode;
+	float gs, gt, a_s, a_t, open_s, open_t;
+	const float *ws;
+	const float *wt;
+	const uint64_t *keys;      // winners, best first; 0 = empty slot
+	float *raw_out;            // [k]
+	int16_t *mapping;          // [k x 16]
+	float *edge_sim;           // [k x 16]
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+hipError_t vk_launch_pack(const void *in, int32_t dtype_bf16, int64_t n_rows, int32_t d, int32_t d_pad, int64_t row0,
+	uint8_t *tiles, float *mag_out, int32_t normalize, hipStream_t stream);
+hipError_t vk_launch_table(const uint8_t *etiles, const uint8_t *qtile, int32_t n_tiles, int32_t nk32, int32_t tail,
+	int32_t tile_bytes, float *table, const int32_t *q_ids, int32_t len_t, int32_t V, hipStream_t stream);
+hipError_t vk_launch_score(const VkScoreParams *p, int32_t grid, size_t smem_bytes, hipStream_t stream);
+hipError_t vk_launch_topk_scores(const float *scores, int64_t n, float min_score, int32_t k, uint64_t *out,
+	int32_t *n_blocks_out, hipStream_t stream);
+hipError_t vk_launch_topk_keys(const uint64_t *in, int64_t n, int32_t k, uint64_t *out, int32_t *n_blocks_out,
+	hipStream_t stream);
+hipError_t vk_launch_flow(const VkFlowParams *p, int32_t k, hipStream_t stream);
+#ifdef __cplusplus
+}
+#endif
+
+#endif

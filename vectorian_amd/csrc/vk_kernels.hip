@@ -1,0 +1,762 @@
+// vk_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the brute-force alignment search.
+//
+// Written for wave64 / MFMA / LDS of gfx950 only (no portability layer).
+// Compiled with -ffp-contract=off: the DP recurrences must be the literal fp32
+// add / subtract / max sequence of the oracle (oracle/vk_oracle.c).
+//
+// Reference functions realised here (paths relative to the reference tree):
+//   similarity  : vectorian/sim/vector.py:66-78 (cosine of unit rows),
+//                 vectorian/core/cpp/metric/metric.h:28-30 (clip),
+//                 metric/contextual.cpp:26-63, metric/static.cpp:9-78
+//   slices      : slice/contextual.h:65-67, slice/static.h:71-75, document.h:147-169
+//   alignment   : metric/alignment.h:247-294 (make_match -> pyalign solve), :84-106 (reference_score),
+//                 match/match.h:295-307 (Score)
+//   result set  : result_set.h:32-93, match/match_impl.h:8-42
+//
+// Data layout in HBM ("tiles"): rows (token vectors, or vocabulary vectors) are stored
+// as unit-norm bf16 in MFMA operand order.  A tile is 16 consecutive rows; for each
+// K-step t of 32 features the tile holds one 1 KiB block in which lane l
+// (l = 16*g + i) owns the 16 bytes  row i, features 32t + 8g .. 32t + 8g + 7.
+// If d_pad % 32 == 16 a last 512-byte block holds features 32*NK32 + 4g .. +3 of
+// row i at lane l (operand of the K=16 MFMA).  A wave therefore reads a tile with
+// NK32 perfectly coalesced global_load_dwordx4 (+1 dwordx2) and feeds the registers
+// to v_mfma_f32_16x16x32_bf16 without any shuffle or LDS staging.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vk_device.h"
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define VK_NEG_INF (-__builtin_inff())
+
+// ---------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float old, float src) {
+	// lanes without a source lane keep `old` (bound_ctrl = 0)
+	return __builtin_bit_cast(float,
+		__builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL, 0xf, 0xf, false));
+}
+#define DPP_ROW_SHR1 0x111
+#define DPP_ROW_SHR2 0x112
+#define DPP_ROW_SHR4 0x114
+#define DPP_ROW_SHR8 0x118
+
+// max over each 16-lane DPP row; result valid in lane 15 of the row
+__device__ __forceinline__ float row_max_to_lane15(float x) {
+	x = fmaxf(x, dpp_f<DPP_ROW_SHR1>(x, x));
+	x = fmaxf(x, dpp_f<DPP_ROW_SHR2>(x, x));
+	x = fmaxf(x, dpp_f<DPP_ROW_SHR4>(x, x));
+	x = fmaxf(x, dpp_f<DPP_ROW_SHR8>(x, x));
+	return x;
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+	// one wave's LDS operations execute in order; this only stops the compiler
+	// from moving LDS accesses across the point and drains lgkmcnt
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float clip01(float x) {
+	// xt::clip(sim, 0, 1); NaN -> 0 as the oracle does
+	return fminf(fmaxf(x, 0.0f), 1.0f);
+}
+
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float x) {
+	uint32_t u = __builtin_bit_cast(uint32_t, x);
+	if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
+	u += 0x7fffu + ((u >> 16) & 1u);
+	return (uint16_t)(u >> 16);
+}
+
+// ---------------------------------------------------------------------------
+// corpus upload: L2-normalise rows (Vectors.normalized, vectorian/embedding/vectors.py:71-86),
+// round to bf16 (RNE) and store in tile order.  One wave per row.
+// ---------------------------------------------------------------------------
+
+template <typename T> __device__ __forceinline__ float load_elem(const T *p);
+template <> __device__ __forceinline__ float load_elem<float>(const float *p) { return *p; }
+template <> __device__ __forceinline__ float load_elem<uint16_t>(const uint16_t *p) {
+	return __builtin_bit_cast(float, ((uint32_t)*p) << 16);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void vk_pack_rows_kernel(
+	const T *__restrict__ in, int64_t n_rows, int32_t d, int32_t d_pad, int64_t row0,
+	uint8_t *__restrict__ tiles, float *__restrict__ mag_out, int32_t normalize) {
+
+	const int lane = threadIdx.x & 63;
+	const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (r >= n_rows) return;
+	const T *row = in + r * (int64_t)d;
+
+	float m = 1.0f;
+	if (normalize || mag_out) {
+		double acc = 0.0;
+		for (int k = lane; k < d; k += 64) {
+			const double x = (double)load_elem<T>(row + k);
+			acc += x * x;
+		}
+		for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+		m = (float)sqrt(acc);
+		if (m != m) m = 0.0f;
+		if (mag_out && lane == 0) mag_out[row0 + r] = m;
+	}
+
+	const int64_t grow = row0 + r;
+	const int64_t tile = grow >> 4;
+	const int i = (int)(grow & 15);
+	const int nk32 = d_pad >> 5;
+	const int tile_bytes = d_pad * 32;
+	uint8_t *tp = tiles + tile * (int64_t)tile_bytes;
+
+	const int n8 = nk32 * 4;                    // 8-element chunks of the K=32 steps
+	const int n4 = (d_pad & 31) ? 4 : 0;        // 4-element chunks of the K=16 tail
+	for (int c = lane; c < n8 + n4; c += 64) {
+		int k0, n, off;
+		if (c < n8) {
+			k0 = c * 8; n = 8;
+			off = (c >> 2) * 1024 + ((c & 3) * 16 + i) * 16;
+		} else {
+			const int g = c - n8;
+			k0 = nk32 * 32 + g * 4; n = 4;
+			off = nk32 * 1024 + (g * 16 + i) * 8;
+		}
+		uint16_t v[8];
+		for (int j = 0; j < n; j++) {
+			float x = 0.0f;
+			if (k0 + j < d) {
+				x = load_elem<T>(row + k0 + j);
+				if (normalize) {
+					x = x / m;
+					if (x != x) x = 0.0f;
+				}
+			}
+			v[j] = f32_to_bf16_rne(x);
+		}
+		if (n == 8) {
+			uint4 w;
+			w.x = v[0] | ((uint32_t)v[1] << 16); w.y = v[2] | ((uint32_t)v[3] << 16);
+			w.z = v[4] | ((uint32_t)v[5] << 16); w.w = v[6] | ((uint32_t)v[7] << 16);
+			*reinterpret_cast<uint4 *>(tp + off) = w;
+		} else {
+			uint2 w;
+			w.x = v[0] | ((uint32_t)v[1] << 16); w.y = v[2] | ((uint32_t)v[3] << 16);
+			*reinterpret_cast<uint2 *>(tp + off) = w;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------
+// similarity of one 16-row tile against the query: S^T = Q * X^T on MFMA.
+// A operand = query fragment (rows = query tokens), B operand = token tile
+// (columns = tokens).  Result: lane l holds S[token l&15][query 4*(l>>4) + r], r=0..3.
+// ---------------------------------------------------------------------------
+
+template <int NK32, bool TAIL>
+struct QFrag {
+	bf16x8 q[NK32 > 0 ? NK32 : 1];
+	bf16x4 qt;
+};
+
+template <int NK32, bool TAIL>
+__device__ __forceinline__ void load_qfrag(QFrag<NK32, TAIL> &f, const uint8_t *__restrict__ qtile, int lane) {
+#pragma unroll
+	for (int t = 0; t < NK32; t++) f.q[t] = *reinterpret_cast<const bf16x8 *>(qtile + t * 1024 + lane * 16);
+	if (TAIL) f.qt = *reinterpret_cast<const bf16x4 *>(qtile + NK32 * 1024 + lane * 8);
+}
+
+template <int NK32, bool TAIL>
+__device__ __forceinline__ f32x4 sim_tile(const QFrag<NK32, TAIL> &f, const uint8_t *__restrict__ tile, int lane) {
+	bf16x8 x[NK32 > 0 ? NK32 : 1];
+	bf16x4 xt;
+#pragma unroll
+	for (int t = 0; t < NK32; t++) x[t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(tile + t * 1024 + lane * 16));
+	if (TAIL) xt = __builtin_nontemporal_load(reinterpret_cast<const bf16x4 *>(tile + NK32 * 1024 + lane * 8));
+	f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+	for (int t = 0; t < NK32; t++) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.q[t], x[t], acc, 0, 0, 0);
+	if (TAIL) acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(f.qt, xt, acc, 0, 0, 0);
+	acc[0] = clip01(acc[0]); acc[1] = clip01(acc[1]); acc[2] = clip01(acc[2]); acc[3] = clip01(acc[3]);
+	return acc;
+}
+
+// any d: query fragments re-read per K-step (L1/L2 resident), runtime trip count
+__device__ __forceinline__ f32x4 sim_tile_generic(const uint8_t *__restrict__ qtile, const uint8_t *__restrict__ tile,
+	int nk32, int tail, int lane) {
+	f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 4
+	for (int t = 0; t < nk32; t++) {
+		const bf16x8 q = *reinterpret_cast<const bf16x8 *>(qtile + t * 1024 + lane * 16);
+		const bf16x8 x = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(tile + t * 1024 + lane * 16));
+		acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q, x, acc, 0, 0, 0);
+	}
+	if (tail) {
+		const bf16x4 q = *reinterpret_cast<const bf16x4 *>(qtile + nk32 * 1024 + lane * 8);
+		const bf16x4 x = __builtin_nontemporal_load(reinterpret_cast<const bf16x4 *>(tile + nk32 * 1024 + lane * 8));
+		acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(q, x, acc, 0, 0, 0);
+	}
+	acc[0] = clip01(acc[0]); acc[1] = clip01(acc[1]); acc[2] = clip01(acc[2]); acc[3] = clip01(acc[3]);
+	return acc;
+}
+
+// ---------------------------------------------------------------------------
+// DP over a group of 4 sentences: DPP row sigma = lane >> 4 is one sentence, lane
+// v = lane & 15 is query column v + 1.  Rows (sentence tokens) are swept serially;
+// within a row the left-to-right dependency is resolved by a monotone fixpoint chain
+// on DPP row_shr:1, which reproduces the sequential recurrence bit for bit (max is
+// exact and x -> x - g is monotone).
+//
+// S: wave-private LDS [rows][16]; sentence sigma's token i is row rowbase + i.
+// Returns the aligner score (raw) in lane 15 of each DPP row.
+// ---------------------------------------------------------------------------
+
+struct DpArgs {
+	int32_t locality;
+	int32_t len_t;
+	float gs, gt;          // linear: w(k) = g*k ; affine: extension cost b
+	float a_s, a_t;        // affine: a
+	float open_s, open_t;  // affine: a + b
+	const float *ws;       // general: w_s[0..max_len]
+	const float *wt;       // general: w_t[0..16]
+};
+
+template <int LT>
+__device__ __forceinline__ float dp_linear(const float *__restrict__ S, int rowbase, int len, int maxlen, int v, const DpArgs &a) {
+	const bool is_local = a.locality == VK_DEV_LOCAL;
+	const bool is_global = a.locality == VK_DEV_GLOBAL;
+	const float floor0 = is_local ? 0.0f : VK_NEG_INF;
+	const float gsb = is_global ? a.gs : 0.0f;   // border H[u][0] = -(gs*u) (GLOBAL) else 0
+	const float gs = a.gs, gt = a.gt;
+	const bool last_col = v == a.len_t - 1;
+
+	float h = is_global ? -(gt * (float)(v + 1)) : 0.0f;  // H[0][v+1]
+	float best = 0.0f;
+	for (int u = 1; u <= maxlen; u++) {
+		const bool act = u <= len;
+		const float s = S[(rowbase + (act ? u - 1 : 0)) * 16 + v];
+		const float bprev = -(gsb * (float)(u - 1));
+		const float bcur = -(gsb * (float)u);
+		const float diag = dpp_f<DPP_ROW_SHR1>(bprev, h);
+		float c = fmaxf(diag + s, floor0);
+		c = fmaxf(c, h - gs);
+		// H[u][v] = max(c[v], H[u][v-1] - gt); lane 0's left neighbour is the border
+#pragma unroll
+		for (int i = 0; i < LT; i++) c = fmaxf(c, dpp_f<DPP_ROW_SHR1>(bcur, c) - gt);
+		h = act ? c : h;
+		if (is_local || last_col) best = fmaxf(best, h);
+	}
+	float m;
+	if (is_local) m = v < a.len_t ? best : 0.0f;
+	else if (is_global) m = last_col ? h : VK_NEG_INF;
+	else m = v < a.len_t ? fmaxf(h, last_col ? best : 0.0f) : 0.0f;   // last row U last column U border 0
+	m = row_max_to_lane15(m);
+	return (is_global) ? m : fmaxf(m, 0.0f);
+}
+
+// Gotoh, w(k) = a + b*k: E (gap over s tokens) lives in the lane, F (gap over query
+// tokens) is resolved with the same fixpoint chain as H.
+template <int LT>
+__device__ __forceinline__ float dp_affine(const float *__restrict__ S, int rowbase, int len, int maxlen, int v, const DpArgs &a) {
+	const bool is_local = a.locality == VK_DEV_LOCAL;
+	const bool is_global = a.locality == VK_DEV_GLOBAL;
+	const float floor0 = is_local ? 0.0f : VK_NEG_INF;
+	const float bs = a.gs, bt = a.gt, open_s = a.open_s, open_t = a.open_t;
+	const float a_s = a.a_s, a_t = a.a_t;
+	const bool last_col = v == a.len_t - 1;
+
+	// borders (GLOBAL): H[0][j] = -(a_t + bt*j), H[u][0] = -(a_s + bs*u)
+	float h = is_global ? -(a_t + bt * (float)(v + 1)) : 0.0f;
+	float e = VK_NEG_INF;                       // E[0][j]
+	float best = 0.0f;
+	for (int u = 1; u <= maxlen; u++) {
+		const bool act = u <= len;
+		const float s = S[(rowbase + (act ? u - 1 : 0)) * 16 + v];
+		const float bprev = (is_global && u > 1) ? -(a_s + bs * (float)(u - 1)) : 0.0f;
+		const float bcur = is_global ? -(a_s + bs * (float)u) : 0.0f;
+		const float diag = dpp_f<DPP_ROW_SHR1>(bprev, h);
+		const float en = fmaxf(h - open_s, e - bs);     // E[u][j]
+		float c = fmaxf(fmaxf(diag + s, floor0), en);
+		// F[u][j] = max(H[u][j-1] - open_t, F[u][j-1] - bt); F[u][0] = -inf
+		float f = VK_NEG_INF;
+		float hc = c;
+#pragma unroll
+		for (int i = 0; i < LT; i++) {
+			const float fl = fmaxf(dpp_f<DPP_ROW_SHR1>(bcur, hc) - open_t, dpp_f<DPP_ROW_SHR1>(VK_NEG_INF, f) - bt);
+			f = fl;
+			hc = fmaxf(c, f);
+		}
+		if (act) { h = hc; e = en; }
+		if (is_local || last_col) best = fmaxf(best, h);
+	}
+	float m;
+	if (is_local) m = v < a.len_t ? best : 0.0f;
+	else if (is_global) m = last_col ? h : VK_NEG_INF;
+	else m = v < a.len_t ? fmaxf(h, last_col ? best : 0.0f) : 0.0f;
+	m = row_max_to_lane15(m);
+	return (is_global) ? m : fmaxf(m, 0.0f);
+}
+
+// General gap costs (Waterman-Smith-Beyer): the column history H[0..u-1][j] of each
+// lane is staged in wave-private LDS (Hh[sigma][u][v]); the in-row dependency walks
+// the source columns left to right with ds_bpermute broadcasts.
+template <int LT>
+__device__ __forceinline__ float dp_general(const float *__restrict__ S, float *__restrict__ Hh, int hstride,
+	int rowbase, int len, int maxlen, int lane, const DpArgs &a) {
+
+	const int v = lane & 15, sigma = lane >> 4;
+	const bool is_local = a.locality == VK_DEV_LOCAL;
+	const bool is_global = a.locality == VK_DEV_GLOBAL;
+	const float floor0 = is_local ? 0.0f : VK_NEG_INF;
+	const bool last_col = v == a.len_t - 1;
+	float *hist = Hh + sigma * hstride * 16 + v;   // hist[u*16] = H[u][v+1]
+
+	// wtl[p] = w_t(j - p) for source column p < j = v + 1, else +inf (no candidate)
+	float wtl[LT];
+#pragma unroll
+	for (int p = 0; p < LT; p++) wtl[p] = (p <= v) ? a.wt[v + 1 - p] : __builtin_inff();
+
+	float h = is_global ? -a.wt[v + 1] : 0.0f;
+	hist[0] = h;
+	float best = 0.0f;
+	for (int u = 1; u <= maxlen; u++) {
+		const bool act = u <= len;
+		const float s = S[(rowbase + (act ? u - 1 : 0)) * 16 + v];
+		const float bprev = is_global ? -a.ws[u - 1] : 0.0f;    // ws[0] = 0
+		const float bcur = is_global ? -a.ws[u] : 0.0f;
+		const float diag = dpp_f<DPP_ROW_SHR1>(bprev, h);
+		float c = fmaxf(diag + s, floor0);
+		// gaps over s tokens: H[u-k][j] - w_s(k), k = 1..u (each lane re-reads its own column)
+		for (int k = 1; k <= u; k++) c = fmaxf(c, hist[(u - k) * 16] - a.ws[k]);
+		// gaps over query tokens: H[u][p] - w_t(j - p), p = 0 (border) .. j-1
+		c = fmaxf(c, bcur - wtl[0]);
+#pragma unroll
+		for (int p = 1; p < LT; p++) {
+			const float hp = __builtin_bit_cast(float,
+				__builtin_amdgcn_ds_bpermute((sigma * 16 + p - 1) * 4, __builtin_bit_cast(int, c)));
+			c = fmaxf(c, hp - wtl[p]);
+		}
+		if (act) { h = c; hist[u * 16] = c; }
+		if (is_local || last_col) best = fmaxf(best, h);
+	}
+	float m;
+	if (is_local) m = v < a.len_t ? best : 0.0f;
+	else if (is_global) m = last_col ? h : VK_NEG_INF;
+	else m = v < a.len_t ? fmaxf(h, last_col ? best : 0.0f) : 0.0f;
+	m = row_max_to_lane15(m);
+	return (is_global) ? m : fmaxf(m, 0.0f);
+}
+
+// ---------------------------------------------------------------------------
+// the fused scoring kernel: one wave = 4 sentences at a time, grid-stride over groups.
+//   MODE 0: contextual layout, d_pad == 32*NK32 + 16*TAIL, query fragments in registers
+//   MODE 1: contextual layout, any d (runtime K loop)
+//   MODE 2: static layout: gather rows of the per-query table by token id
+// GAP: 0 linear, 1 affine, 2 general.  LT: padded query length (4, 8, 12, 16).
+// ---------------------------------------------------------------------------
+
+template <int MODE, int NK32, bool TAIL, int GAP, int LT>
+__global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
+	extern __shared__ float4 vk_smem4[];
+	float *smem = reinterpret_cast<float *>(vk_smem4);
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	float *S = smem + wv * p.lds_floats_per_wave;
+	float *Hh = S + p.s_rows_per_wave * 16;
+	const int sigma = lane >> 4, v = lane & 15;
+
+	QFrag<NK32, TAIL> qf;
+	if (MODE == 0) load_qfrag<NK32, TAIL>(qf, p.qtile, lane);
+
+	DpArgs a;
+	a.locality = p.locality; a.len_t = p.len_t;
+	a.gs = p.gs; a.gt = p.gt; a.a_s = p.a_s; a.a_t = p.a_t; a.open_s = p.open_s; a.open_t = p.open_t;
+	a.ws = p.ws; a.wt = p.wt;
+	const float inv_ref = (float)p.len_t;
+
+	const int n_groups = (p.n_sent + 3) >> 2;
+	for (int grp = blockIdx.x * 4 + wv; grp < n_groups; grp += gridDim.x * 4) {
+		const int s_idx = grp * 4 + sigma;
+		const int i0 = s_idx < p.n_sent ? s_idx : p.n_sent;
+		const int i1 = s_idx + 1 < p.n_sent ? s_idx + 1 : p.n_sent;
+		const int t_a = p.sent_off[i0], t_b = p.sent_off[i1];
+		const int len = t_b - t_a;
+		const int g_a = __builtin_amdgcn_readlane(t_a, 0);
+		const int g_b = __builtin_amdgcn_readlane(t_b, 48);
+		int maxlen = __builtin_amdgcn_readlane(len, 0);
+		maxlen = max(maxlen, __builtin_amdgcn_readlane(len, 16));
+		maxlen = max(maxlen, __builtin_amdgcn_readlane(len, 32));
+		maxlen = max(maxlen, __builtin_amdgcn_readlane(len, 48));
+
+		int rowbase;
+		if (MODE == 2) {
+			// gather: lane handles token (lane >> 2) + 16*it, 4 query columns (lane & 3)
+			const int ntok = g_b - g_a;
+			for (int it = 0; it * 16 < ntok; it++) {
+				const int tk = it * 16 + (lane >> 2);
+				if (tk < ntok) {
+					const int id = p.tok_id[g_a + tk];
+					const float4 val = *reinterpret_cast<const float4 *>(p.table + (int64_t)id * 16 + (lane & 3) * 4);
+					*reinterpret_cast<float4 *>(S + tk * 16 + (lane & 3) * 4) = val;
+				}
+			}
+			rowbase = t_a - g_a;
+		} else {
+			const int tile0 = g_a >> 4;
+			const int ntiles = ((g_b + 15) >> 4) - tile0;
+			const uint8_t *tp = p.tiles + (int64_t)tile0 * p.tile_bytes;
+			for (int ti = 0; ti < ntiles; ti++) {
+				f32x4 acc;
+				if (MODE == 0) acc = sim_tile<NK32, TAIL>(qf, tp, lane);
+				else acc = sim_tile_generic(p.qtile, tp, p.nk32, p.tail, lane);
+				*reinterpret_cast<f32x4 *>(S + (ti * 16 + (lane & 15)) * 16 + (lane >> 4) * 4) = acc;
+				tp += p.tile_bytes;
+			}
+			rowbase = t_a - tile0 * 16;
+		}
+		wave_lds_fence();
+
+		float raw;
+		const int lenc = len > 0 ? len : 0;
+		const int rb = len > 0 ? rowbase : 0;
+		if (GAP == 0) raw = dp_linear<LT>(S, rb, lenc, maxlen, v, a);
+		else if (GAP == 1) raw = dp_affine<LT>(S, rb, lenc, maxlen, v, a);
+		else raw = dp_general<LT>(S, Hh, p.h_rows, rb, lenc, maxlen, lane, a);
+
+		if (v == 15 && s_idx < p.n_sent) {
+			// Score::value = raw / reference_score * boost; reference_score == len_t for
+			// submatch_weight == 0 (metric/alignment.h:84-106, match/match.h:302-307)
+			float val = VK_NEG_INF, r = VK_NEG_INF;
+			if (len >= 1) {   // document.h:160 skips empty slices
+				const float boost = p.boost ? p.boost[s_idx] : 1.0f;
+				r = raw;
+				val = (raw / inv_ref) * boost;
+			}
+			p.scores[s_idx] = val;
+			p.raw[s_idx] = r;
+		}
+		wave_lds_fence();
+	}
+}
+
+// ---------------------------------------------------------------------------
+// static layout: per-query similarity table [V_pad x 16] (metric/static.cpp:9-78)
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void vk_table_kernel(const uint8_t *__restrict__ etiles, const uint8_t *__restrict__ qtile,
+	int32_t n_tiles, int32_t nk32, int32_t tail, int32_t tile_bytes, float *__restrict__ table) {
+	const int lane = threadIdx.x & 63;
+	const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (tile >= n_tiles) return;
+	const f32x4 acc = sim_tile_generic(qtile, etiles + (int64_t)tile * tile_bytes, nk32, tail, lane);
+	*reinterpret_cast<f32x4 *>(table + ((int64_t)tile * 16 + (lane & 15)) * 16 + (lane >> 4) * 4) = acc;
+}
+
+// sim[id(t_j)][j] = 1 (metric/static.cpp:58-67); runs after vk_table_kernel
+__global__ void vk_table_fix_kernel(float *__restrict__ table, const int32_t *__restrict__ q_ids, int32_t len_t, int32_t V) {
+	const int j = threadIdx.x;
+	if (j < len_t) {
+		const int id = q_ids[j];
+		if (id >= 0 && id < V) table[(int64_t)id * 16 + j] = 1.0f;
+	}
+}
+
+// ---------------------------------------------------------------------------
+// bounded result set: keys = (orderable(score) << 32) | sentence, descending.
+// Order = score desc, sentence index desc (match/match_impl.h:8-42);
+// admission score > min_score (metric/alignment.h:284).  Each block bitonic-sorts
+// 2048 keys in LDS and emits its best k; stages repeat until one block is left.
+// ---------------------------------------------------------------------------
+
+#define VK_TOPK_CHUNK 2048
+
+__device__ __forceinline__ uint32_t float_orderable(float f) {
+	const uint32_t u = __builtin_bit_cast(uint32_t, f);
+	return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ void bitonic_sort_desc_2048(uint64_t *keys) {
+	for (int k = 2; k <= VK_TOPK_CHUNK; k <<= 1) {
+		for (int j = k >> 1; j > 0; j >>= 1) {
+			__syncthreads();
+			for (int t = threadIdx.x; t < VK_TOPK_CHUNK / 2; t += blockDim.x) {
+				const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+				const int ixj = i | j;
+				const uint64_t a = keys[i], b = keys[ixj];
+				const bool desc = (i & k) == 0;
+				if (desc ? (a < b) : (a > b)) { keys[i] = b; keys[ixj] = a; }
+			}
+		}
+	}
+	__syncthreads();
+}
+
+__global__ __launch_bounds__(256) void vk_topk_scores_kernel(const float *__restrict__ scores, int64_t n, float min_score,
+	int32_t k, uint64_t *__restrict__ out) {
+	__shared__ uint64_t keys[VK_TOPK_CHUNK];
+	const int64_t base = (int64_t)blockIdx.x * VK_TOPK_CHUNK;
+	for (int t = threadIdx.x; t < VK_TOPK_CHUNK; t += blockDim.x) {
+		const int64_t g = base + t;
+		uint64_t key = 0;
+		if (g < n) {
+			const float s = scores[g];
+			if (s > min_score) key = ((uint64_t)float_orderable(s) << 32) | (uint32_t)g;
+		}
+		keys[t] = key;
+	}
+	bitonic_sort_desc_2048(keys);
+	for (int t = threadIdx.x; t < k; t += blockDim.x) out[(int64_t)blockIdx.x * k + t] = keys[t];
+}
+
+__global__ __launch_bounds__(256) void vk_topk_keys_kernel(const uint64_t *__restrict__ in, int64_t n, int32_t k,
+	uint64_t *__restrict__ out) {
+	__shared__ uint64_t keys[VK_TOPK_CHUNK];
+	const int64_t base = (int64_t)blockIdx.x * VK_TOPK_CHUNK;
+	for (int t = threadIdx.x; t < VK_TOPK_CHUNK; t += blockDim.x) {
+		const int64_t g = base + t;
+		keys[t] = g < n ? in[g] : 0;
+	}
+	bitonic_sort_desc_2048(keys);
+	for (int t = threadIdx.x; t < k; t += blockDim.x) out[(int64_t)blockIdx.x * k + t] = keys[t];
+}
+
+// ---------------------------------------------------------------------------
+// flow of the winners: one wave per winner recomputes the similarity rows with the
+// same MFMA sequence as the scoring kernel, then lane 0 runs the sequential DP with
+// traceback exactly as the oracle states it (vko_align in oracle/vk_oracle.c):
+// candidates zero (LOCAL), diagonal, gap in s (k = 1..), gap in t (k = 1..), replace
+// on strictly greater; start cell = first maximum in row-major order.
+// Output: mapping[j] = matched sentence token or -1 (InjectiveFlow,
+// metric/alignment.h:194-196), edge_sim[j] = S[mapping[j]][j] (metric/alignment.h:335-345).
+// ---------------------------------------------------------------------------
+
+#define VK_TB_W 17
+#define VK_TB_ROWS (VK_DEV_MAX_SENT_LEN + 1)
+
+__global__ __launch_bounds__(64) void vk_flow_kernel(VkFlowParams p) {
+	__shared__ __attribute__((aligned(16))) float S[(VK_DEV_MAX_SENT_LEN + 32) * 16];
+	__shared__ float H[VK_TB_ROWS * VK_TB_W];
+	__shared__ float E[VK_TB_ROWS * VK_TB_W];
+	__shared__ float F[VK_TB_ROWS * VK_TB_W];
+	__shared__ uint8_t dirs[VK_TB_ROWS * VK_TB_W];
+	__shared__ uint8_t eext[VK_TB_ROWS * VK_TB_W];
+	__shared__ uint8_t fext[VK_TB_ROWS * VK_TB_W];
+	__shared__ int16_t dk[VK_TB_ROWS * VK_TB_W];
+
+	const int lane = threadIdx.x;
+	const int w = blockIdx.x;
+	const uint64_t key = p.keys[w];
+	if (key == 0) return;   // fewer than k admitted
+	const int64_t g = (int64_t)(uint32_t)(key & 0xffffffffu);
+	const int t_a = p.sent_off[g], t_b = p.sent_off[g + 1];
+	const int len_s = t_b - t_a, len_t = p.len_t;
+
+	int rowbase;
+	if (p.layout == VK_DEV_LAYOUT_STATIC) {
+		for (int it = 0; it * 16 < len_s; it++) {
+			const int tk = it * 16 + (lane >> 2);
+			if (tk < len_s) {
+				const int id = p.tok_id[t_a + tk];
+				*reinterpret_cast<float4 *>(S + tk * 16 + (lane & 3) * 4) =
+					*reinterpret_cast<const float4 *>(p.table + (int64_t)id * 16 + (lane & 3) * 4);
+			}
+		}
+		rowbase = 0;
+	} else {
+		const int tile0 = t_a >> 4;
+		const int ntiles = ((t_b + 15) >> 4) - tile0;
+		for (int ti = 0; ti < ntiles; ti++) {
+			const f32x4 acc = sim_tile_generic(p.qtile, p.tiles + (int64_t)(tile0 + ti) * p.tile_bytes, p.nk32, p.tail, lane);
+			*reinterpret_cast<f32x4 *>(S + (ti * 16 + (lane & 15)) * 16 + (lane >> 4) * 4) = acc;
+		}
+		rowbase = t_a - tile0 * 16;
+	}
+	__syncthreads();
+	if (lane != 0) return;
+
+	const float *Sm = S + rowbase * 16;
+	const int W = VK_TB_W;
+	const bool local = p.locality == VK_DEV_LOCAL, global = p.locality == VK_DEV_GLOBAL;
+	const int gap = p.gap_mode;
+
+	if (gap == 0) {
+		const float gs = p.gs, gt = p.gt;
+		H[0] = 0.0f;
+		for (int v = 1; v <= len_t; v++) H[v] = global ? -(gt * (float)v) : 0.0f;
+		for (int u = 1; u <= len_s; u++) {
+			H[u * W] = global ? -(gs * (float)u) : 0.0f;
+			for (int v = 1; v <= len_t; v++) {
+				float best; uint8_t d;
+				float c = H[(u - 1) * W + v - 1] + Sm[(u - 1) * 16 + v - 1];
+				if (local) { best = 0.0f; d = 0; if (c > best) { best = c; d = 1; } }
+				else { best = c; d = 1; }
+				c = H[(u - 1) * W + v] - gs;
+				if (c > best) { best = c; d = 2; }
+				c = H[u * W + v - 1] - gt;
+				if (c > best) { best = c; d = 3; }
+				H[u * W + v] = best; dirs[u * W + v] = d; dk[u * W + v] = 1;
+			}
+		}
+	} else if (gap == 2) {
+		const float *ws = p.ws, *wt = p.wt;
+		H[0] = 0.0f;
+		for (int v = 1; v <= len_t; v++) H[v] = global ? -wt[v] : 0.0f;
+		for (int u = 1; u <= len_s; u++) {
+			H[u * W] = global ? -ws[u] : 0.0f;
+			for (int v = 1; v <= len_t; v++) {
+				float best; uint8_t d; int16_t kk = 0;
+				float c = H[(u - 1) * W + v - 1] + Sm[(u - 1) * 16 + v - 1];
+				if (local) { best = 0.0f; d = 0; if (c > best) { best = c; d = 1; } }
+				else { best = c; d = 1; }
+				for (int k = 1; k <= u; k++) {
+					c = H[(u - k) * W + v] - ws[k];
+					if (c > best) { best = c; d = 2; kk = (int16_t)k; }
+				}
+				for (int k = 1; k <= v; k++) {
+					c = H[u * W + v - k] - wt[k];
+					if (c > best) { best = c; d = 3; kk = (int16_t)k; }
+				}
+				H[u * W + v] = best; dirs[u * W + v] = d; dk[u * W + v] = kk;
+			}
+		}
+	} else {
+		const float bs = p.gs, bt = p.gt, open_s = p.open_s, open_t = p.open_t;
+		const float a_s = p.a_s, a_t = p.a_t;
+		H[0] = 0.0f; E[0] = VK_NEG_INF; F[0] = VK_NEG_INF;
+		for (int v = 1; v <= len_t; v++) {
+			H[v] = global ? -(a_t + bt * (float)v) : 0.0f;
+			E[v] = VK_NEG_INF;
+			F[v] = global ? H[v] : VK_NEG_INF;
+		}
+		for (int u = 1; u <= len_s; u++) {
+			H[u * W] = global ? -(a_s + bs * (float)u) : 0.0f;
+			E[u * W] = global ? H[u * W] : VK_NEG_INF;
+			F[u * W] = VK_NEG_INF;
+			for (int v = 1; v <= len_t; v++) {
+				float e = H[(u - 1) * W + v] - open_s; uint8_t ee = 0;
+				float c = E[(u - 1) * W + v] - bs;
+				if (c > e) { e = c; ee = 1; }
+				float f = H[u * W + v - 1] - open_t; uint8_t fe = 0;
+				c = F[u * W + v - 1] - bt;
+				if (c > f) { f = c; fe = 1; }
+				float best; uint8_t d;
+				c = H[(u - 1) * W + v - 1] + Sm[(u - 1) * 16 + v - 1];
+				if (local) { best = 0.0f; d = 0; if (c > best) { best = c; d = 1; } }
+				else { best = c; d = 1; }
+				if (e > best) { best = e; d = 2; }
+				if (f > best) { best = f; d = 3; }
+				H[u * W + v] = best; E[u * W + v] = e; F[u * W + v] = f;
+				dirs[u * W + v] = d; eext[u * W + v] = ee; fext[u * W + v] = fe;
+			}
+		}
+	}
+
+	// start cell
+	int u = len_s, v = len_t;
+	float raw = H[len_s * W + len_t];
+	if (!global) {
+		raw = 0.0f; u = 0; v = 0;
+		for (int uu = 1; uu <= len_s; uu++)
+			for (int vv = 1; vv <= len_t; vv++) {
+				if (!local && !(uu == len_s || vv == len_t)) continue;
+				const float hv = H[uu * W + vv];
+				if (hv > raw) { raw = hv; u = uu; v = vv; }
+			}
+	}
+	int16_t *mp = p.mapping + (int64_t)w * 16;
+	float *es = p.edge_sim + (int64_t)w * 16;
+	for (int j = 0; j < 16; j++) { mp[j] = -1; es[j] = 0.0f; }
+	int state = 0;
+	while (u > 0 && v > 0) {
+		const int idx = u * W + v;
+		if (gap == 1 && state == 1) { if (!eext[idx]) state = 0; u--; continue; }
+		if (gap == 1 && state == 2) { if (!fext[idx]) state = 0; v--; continue; }
+		const uint8_t d = dirs[idx];
+		if (d == 0) break;
+		if (d == 1) { mp[v - 1] = (int16_t)(u - 1); es[v - 1] = Sm[(u - 1) * 16 + v - 1]; u--; v--; }
+		else if (gap == 1) state = (d == 2) ? 1 : 2;
+		else if (d == 2) u -= dk[idx];
+		else v -= dk[idx];
+	}
+	p.raw_out[w] = raw;
+}
+
+// ---------------------------------------------------------------------------
+// host-callable launchers (used by vk_api.cpp; keep all <<< >>> in this file)
+// ---------------------------------------------------------------------------
+
+extern "C" hipError_t vk_launch_pack(const void *in, int32_t dtype_bf16, int64_t n_rows, int32_t d, int32_t d_pad, int64_t row0,
+	uint8_t *tiles, float *mag_out, int32_t normalize, hipStream_t stream) {
+	if (n_rows <= 0) return hipSuccess;
+	const unsigned grid = (unsigned)((n_rows + 3) / 4);
+	if (dtype_bf16)
+		vk_pack_rows_kernel<uint16_t><<<grid, 256, 0, stream>>>((const uint16_t *)in, n_rows, d, d_pad, row0, tiles, mag_out, normalize);
+	else
+		vk_pack_rows_kernel<float><<<grid, 256, 0, stream>>>((const float *)in, n_rows, d, d_pad, row0, tiles, mag_out, normalize);
+	return hipGetLastError();
+}
+
+extern "C" hipError_t vk_launch_table(const uint8_t *etiles, const uint8_t *qtile, int32_t n_tiles, int32_t nk32, int32_t tail,
+	int32_t tile_bytes, float *table, const int32_t *q_ids, int32_t len_t, int32_t V, hipStream_t stream) {
+	vk_table_kernel<<<(n_tiles + 3) / 4, 256, 0, stream>>>(etiles, qtile, n_tiles, nk32, tail, tile_bytes, table);
+	if (q_ids) vk_table_fix_kernel<<<1, 64, 0, stream>>>(table, q_ids, len_t, V);
+	return hipGetLastError();
+}
+
+template <int MODE, int NK32, bool TAIL, int GAP>
+static hipError_t launch_score_lt(const VkScoreParams &p, int grid, size_t smem, hipStream_t stream) {
+	const int lt = p.len_t <= 4 ? 4 : p.len_t <= 8 ? 8 : p.len_t <= 12 ? 12 : 16;
+	// non-LOCAL alignments need one more chain step for the border column: covered,
+	// because LT >= len_t and lane len_t - 1 is final after len_t steps.
+	switch (lt) {
+	case 4: vk_score_kernel<MODE, NK32, TAIL, GAP, 4><<<grid, 256, smem, stream>>>(p); break;
+	case 8: vk_score_kernel<MODE, NK32, TAIL, GAP, 8><<<grid, 256, smem, stream>>>(p); break;
+	case 12: vk_score_kernel<MODE, NK32, TAIL, GAP, 12><<<grid, 256, smem, stream>>>(p); break;
+	default: vk_score_kernel<MODE, NK32, TAIL, GAP, 16><<<grid, 256, smem, stream>>>(p); break;
+	}
+	return hipGetLastError();
+}
+
+template <int MODE, int NK32, bool TAIL>
+static hipError_t launch_score_gap(const VkScoreParams &p, int grid, size_t smem, hipStream_t stream) {
+	switch (p.gap_mode) {
+	case 0: return launch_score_lt<MODE, NK32, TAIL, 0>(p, grid, smem, stream);
+	case 1: return launch_score_lt<MODE, NK32, TAIL, 1>(p, grid, smem, stream);
+	default: return launch_score_lt<MODE, NK32, TAIL, 2>(p, grid, smem, stream);
+	}
+}
+
+extern "C" hipError_t vk_launch_score(const VkScoreParams *pp, int32_t grid, size_t smem_bytes, hipStream_t stream) {
+	const VkScoreParams &p = *pp;
+	if (p.layout == VK_DEV_LAYOUT_STATIC) return launch_score_gap<2, 0, false>(p, grid, smem_bytes, stream);
+	if (p.nk32 == 9 && p.tail == 1) return launch_score_gap<0, 9, true>(p, grid, smem_bytes, stream);
+	return launch_score_gap<1, 0, false>(p, grid, smem_bytes, stream);
+}
+
+extern "C" hipError_t vk_launch_topk_scores(const float *scores, int64_t n, float min_score, int32_t k, uint64_t *out,
+	int32_t *n_blocks_out, hipStream_t stream) {
+	const int nb = (int)((n + VK_TOPK_CHUNK - 1) / VK_TOPK_CHUNK);
+	vk_topk_scores_kernel<<<nb, 256, 0, stream>>>(scores, n, min_score, k, out);
+	*n_blocks_out = nb;
+	return hipGetLastError();
+}
+
+extern "C" hipError_t vk_launch_topk_keys(const uint64_t *in, int64_t n, int32_t k, uint64_t *out, int32_t *n_blocks_out,
+	hipStream_t stream) {
+	const int nb = (int)((n + VK_TOPK_CHUNK - 1) / VK_TOPK_CHUNK);
+	vk_topk_keys_kernel<<<nb, 256, 0, stream>>>(in, n, k, out);
+	*n_blocks_out = nb;
+	return hipGetLastError();
+}
+
+extern "C" hipError_t vk_launch_flow(const VkFlowParams *p, int32_t k, hipStream_t stream) {
+	vk_flow_kernel<<<k, 64, 0, stream>>>(*p);
+	return hipGetLastError();
+}
