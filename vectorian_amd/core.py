@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvectorian_hip.so")
+LIB_PATH = os.environ.get("VECTORIAN_HIP_LIB", os.path.join(_HERE, "lib", "libvectorian_hip.so"))
 
 VK_MAX_QUERY_LEN = 16
 VK_MAX_SENT_LEN = 64

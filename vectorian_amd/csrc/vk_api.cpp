@@ -144,7 +144,7 @@ int vk_corpus_create(const vk_corpus_desc *desc, vk_corpus_t **out) {
 	c->desc = *desc;
 	c->device = dev;
 	c->d_pad = (desc->d + 15) / 16 * 16;
-	c->nk32 = c->d_pad / 32;
+	c->nk32 = (c->d_pad + 31) / 32;   // K=32 steps; the last one is half filled when tail
 	c->tail = (c->d_pad % 32) ? 1 : 0;
 	c->tile_bytes = c->d_pad * 32;
 	c->rows_total = desc->layout == VK_LAYOUT_STATIC ? desc->vocab_size : desc->n_tokens;
@@ -331,7 +331,7 @@ static int validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_t
 // Vectors.normalized for the query rows, then bf16 (RNE), then tile order (16 rows,
 // rows >= len_t zero).  Same arithmetic as oracle/vk_oracle.c vko_normalize_rows_bf16.
 static void pack_query(const vk_corpus *c, const vk_query_desc *q, std::vector<uint8_t> &tile) {
-	const int d = c->desc.d, nk32 = c->nk32;
+	const int d = c->desc.d;
 	tile.assign((size_t)c->tile_bytes, 0);
 	std::vector<float> row((size_t)d);
 	for (int i = 0; i < q->len_t; i++) {
@@ -351,14 +351,8 @@ static void pack_query(const vk_corpus *c, const vk_query_desc *q, std::vector<u
 		}
 		for (int k = 0; k < d; k++) {
 			const uint16_t b = f32_to_bf16(row[(size_t)k]);
-			size_t off;
-			if (k < nk32 * 32) {
-				const int t = k >> 5, g = (k & 31) >> 3, j = k & 7;
-				off = (size_t)t * 1024 + (size_t)(g * 16 + i) * 16 + (size_t)j * 2;
-			} else {
-				const int kk = k - nk32 * 32, g = kk >> 2, j = kk & 3;
-				off = (size_t)nk32 * 1024 + (size_t)(g * 16 + i) * 8 + (size_t)j * 2;
-			}
+			const int t = k >> 5, g = (k & 31) >> 3, j = k & 7;
+			const size_t off = (size_t)t * 1024 + (size_t)(g * 16 + i) * 16 + (size_t)j * 2;
 			memcpy(&tile[off], &b, 2);
 		}
 	}

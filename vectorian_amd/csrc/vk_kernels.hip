@@ -17,10 +17,16 @@
 // as unit-norm bf16 in MFMA operand order.  A tile is 16 consecutive rows; for each
 // K-step t of 32 features the tile holds one 1 KiB block in which lane l
 // (l = 16*g + i) owns the 16 bytes  row i, features 32t + 8g .. 32t + 8g + 7.
-// If d_pad % 32 == 16 a last 512-byte block holds features 32*NK32 + 4g .. +3 of
-// row i at lane l (operand of the K=16 MFMA).  A wave therefore reads a tile with
-// NK32 perfectly coalesced global_load_dwordx4 (+1 dwordx2) and feeds the registers
-// to v_mfma_f32_16x16x32_bf16 without any shuffle or LDS staging.
+// If d_pad % 32 == 16 the last block is a half block (512 bytes, g = 0, 1 only); lanes
+// 32..63 feed zeros to that K-step.  A wave therefore reads a tile with NK perfectly
+// coalesced global_load_dwordx4 and feeds the registers to v_mfma_f32_16x16x32_bf16
+// without any shuffle or LDS staging.
+//
+// One MFMA opcode only on the accumulator chain: on gfx950 (ROCm 7.2 hipcc) a
+// v_mfma_f32_16x16x16_bf16 whose SrcC is the vDst of the immediately preceding
+// v_mfma_f32_16x16x32_bf16 reads stale accumulator registers -- the compiler inserts no
+// wait states for that opcode change (tools/probe/mfma_hazard.hip reproduces it:
+// 128 of 256 results differ).  Hence the K=16 tail is issued as a K=32 step.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -32,6 +38,11 @@ typedef __attribute__((ext_vector_type(4))) short bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #define VK_NEG_INF (-__builtin_inff())
+#ifdef VK_DBG_NOINLINE
+#define VK_DP_INLINE __attribute__((noinline))
+#else
+#define VK_DP_INLINE __forceinline__
+#endif
 
 // ---------------------------------------------------------------------------
 // small helpers
@@ -118,20 +129,13 @@ __global__ __launch_bounds__(256) void vk_pack_rows_kernel(
 	const int tile_bytes = d_pad * 32;
 	uint8_t *tp = tiles + tile * (int64_t)tile_bytes;
 
-	const int n8 = nk32 * 4;                    // 8-element chunks of the K=32 steps
-	const int n4 = (d_pad & 31) ? 4 : 0;        // 4-element chunks of the K=16 tail
-	for (int c = lane; c < n8 + n4; c += 64) {
-		int k0, n, off;
-		if (c < n8) {
-			k0 = c * 8; n = 8;
-			off = (c >> 2) * 1024 + ((c & 3) * 16 + i) * 16;
-		} else {
-			const int g = c - n8;
-			k0 = nk32 * 32 + g * 4; n = 4;
-			off = nk32 * 1024 + (g * 16 + i) * 8;
-		}
+	const int n8 = d_pad >> 3;                  // 8-element chunks; chunk c: K-step c>>2, lane group c&3
+	(void)nk32;
+	for (int c = lane; c < n8; c += 64) {
+		const int k0 = c * 8;
+		const int off = (c >> 2) * 1024 + ((c & 3) * 16 + i) * 16;
 		uint16_t v[8];
-		for (int j = 0; j < n; j++) {
+		for (int j = 0; j < 8; j++) {
 			float x = 0.0f;
 			if (k0 + j < d) {
 				x = load_elem<T>(row + k0 + j);
@@ -142,16 +146,10 @@ __global__ __launch_bounds__(256) void vk_pack_rows_kernel(
 			}
 			v[j] = f32_to_bf16_rne(x);
 		}
-		if (n == 8) {
-			uint4 w;
-			w.x = v[0] | ((uint32_t)v[1] << 16); w.y = v[2] | ((uint32_t)v[3] << 16);
-			w.z = v[4] | ((uint32_t)v[5] << 16); w.w = v[6] | ((uint32_t)v[7] << 16);
-			*reinterpret_cast<uint4 *>(tp + off) = w;
-		} else {
-			uint2 w;
-			w.x = v[0] | ((uint32_t)v[1] << 16); w.y = v[2] | ((uint32_t)v[3] << 16);
-			*reinterpret_cast<uint2 *>(tp + off) = w;
-		}
+		uint4 w;
+		w.x = v[0] | ((uint32_t)v[1] << 16); w.y = v[2] | ((uint32_t)v[3] << 16);
+		w.z = v[4] | ((uint32_t)v[5] << 16); w.w = v[6] | ((uint32_t)v[7] << 16);
+		*reinterpret_cast<uint4 *>(tp + off) = w;
 	}
 }
 
@@ -161,48 +159,59 @@ __global__ __launch_bounds__(256) void vk_pack_rows_kernel(
 // (columns = tokens).  Result: lane l holds S[token l&15][query 4*(l>>4) + r], r=0..3.
 // ---------------------------------------------------------------------------
 
-template <int NK32, bool TAIL>
+// NK = number of K=32 steps (the last one half filled when HALF)
+template <int NK, bool HALF>
 struct QFrag {
-	bf16x8 q[NK32 > 0 ? NK32 : 1];
-	bf16x4 qt;
+	bf16x8 q[NK > 0 ? NK : 1];
 };
 
-template <int NK32, bool TAIL>
-__device__ __forceinline__ void load_qfrag(QFrag<NK32, TAIL> &f, const uint8_t *__restrict__ qtile, int lane) {
-#pragma unroll
-	for (int t = 0; t < NK32; t++) f.q[t] = *reinterpret_cast<const bf16x8 *>(qtile + t * 1024 + lane * 16);
-	if (TAIL) f.qt = *reinterpret_cast<const bf16x4 *>(qtile + NK32 * 1024 + lane * 8);
+__device__ __forceinline__ bf16x8 load_half_block(const uint8_t *__restrict__ p, int lane, bool nt) {
+	// half block: 32 x 16 bytes; lanes 32..63 contribute zeros to the K-step
+	const bf16x8 *src = reinterpret_cast<const bf16x8 *>(p + (lane & 31) * 16);
+	bf16x8 x = nt ? __builtin_nontemporal_load(src) : *src;
+	const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+	return lane < 32 ? x : z;
 }
 
-template <int NK32, bool TAIL>
-__device__ __forceinline__ f32x4 sim_tile(const QFrag<NK32, TAIL> &f, const uint8_t *__restrict__ tile, int lane) {
-	bf16x8 x[NK32 > 0 ? NK32 : 1];
-	bf16x4 xt;
+template <int NK, bool HALF>
+__device__ __forceinline__ void load_qfrag(QFrag<NK, HALF> &f, const uint8_t *__restrict__ qtile, int lane) {
 #pragma unroll
-	for (int t = 0; t < NK32; t++) x[t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(tile + t * 1024 + lane * 16));
-	if (TAIL) xt = __builtin_nontemporal_load(reinterpret_cast<const bf16x4 *>(tile + NK32 * 1024 + lane * 8));
+	for (int t = 0; t < NK; t++) {
+		if (HALF && t == NK - 1) f.q[t] = load_half_block(qtile + t * 1024, lane, false);
+		else f.q[t] = *reinterpret_cast<const bf16x8 *>(qtile + t * 1024 + lane * 16);
+	}
+}
+
+template <int NK, bool HALF>
+__device__ __forceinline__ f32x4 sim_tile(const QFrag<NK, HALF> &f, const uint8_t *__restrict__ tile, int lane) {
+	bf16x8 x[NK > 0 ? NK : 1];
+#pragma unroll
+	for (int t = 0; t < NK; t++) {
+		if (HALF && t == NK - 1) x[t] = load_half_block(tile + t * 1024, lane, true);
+		else x[t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(tile + t * 1024 + lane * 16));
+	}
 	f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-	for (int t = 0; t < NK32; t++) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.q[t], x[t], acc, 0, 0, 0);
-	if (TAIL) acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(f.qt, xt, acc, 0, 0, 0);
+	for (int t = 0; t < NK; t++) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.q[t], x[t], acc, 0, 0, 0);
 	acc[0] = clip01(acc[0]); acc[1] = clip01(acc[1]); acc[2] = clip01(acc[2]); acc[3] = clip01(acc[3]);
 	return acc;
 }
 
-// any d: query fragments re-read per K-step (L1/L2 resident), runtime trip count
+// any d: query fragments re-read per K-step (L1/L2 resident), runtime trip count.
+// Same MFMA sequence as sim_tile, hence bit-identical similarities.
 __device__ __forceinline__ f32x4 sim_tile_generic(const uint8_t *__restrict__ qtile, const uint8_t *__restrict__ tile,
-	int nk32, int tail, int lane) {
+	int nk, int half, int lane) {
 	f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 4
-	for (int t = 0; t < nk32; t++) {
+	const int nfull = half ? nk - 1 : nk;
+	for (int t = 0; t < nfull; t++) {
 		const bf16x8 q = *reinterpret_cast<const bf16x8 *>(qtile + t * 1024 + lane * 16);
 		const bf16x8 x = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(tile + t * 1024 + lane * 16));
 		acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q, x, acc, 0, 0, 0);
 	}
-	if (tail) {
-		const bf16x4 q = *reinterpret_cast<const bf16x4 *>(qtile + nk32 * 1024 + lane * 8);
-		const bf16x4 x = __builtin_nontemporal_load(reinterpret_cast<const bf16x4 *>(tile + nk32 * 1024 + lane * 8));
-		acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(q, x, acc, 0, 0, 0);
+	if (half) {
+		const bf16x8 q = load_half_block(qtile + nfull * 1024, lane, false);
+		const bf16x8 x = load_half_block(tile + nfull * 1024, lane, true);
+		acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q, x, acc, 0, 0, 0);
 	}
 	acc[0] = clip01(acc[0]); acc[1] = clip01(acc[1]); acc[2] = clip01(acc[2]); acc[3] = clip01(acc[3]);
 	return acc;
@@ -265,7 +274,7 @@ __device__ __forceinline__ float dp_linear(const float *__restrict__ S, int rowb
 // Gotoh, w(k) = a + b*k: E (gap over s tokens) lives in the lane, F (gap over query
 // tokens) is resolved with the same fixpoint chain as H.
 template <int LT>
-__device__ __forceinline__ float dp_affine(const float *__restrict__ S, int rowbase, int len, int maxlen, int v, const DpArgs &a) {
+__device__ VK_DP_INLINE float dp_affine(const float *__restrict__ S, int rowbase, int len, int maxlen, int v, const DpArgs &a) {
 	const bool is_local = a.locality == VK_DEV_LOCAL;
 	const bool is_global = a.locality == VK_DEV_GLOBAL;
 	const float floor0 = is_local ? 0.0f : VK_NEG_INF;
@@ -357,7 +366,7 @@ __device__ __forceinline__ float dp_general(const float *__restrict__ S, float *
 
 // ---------------------------------------------------------------------------
 // the fused scoring kernel: one wave = 4 sentences at a time, grid-stride over groups.
-//   MODE 0: contextual layout, d_pad == 32*NK32 + 16*TAIL, query fragments in registers
+//   MODE 0: contextual layout, NK32 K-steps (last one half filled when TAIL), query fragments in registers
 //   MODE 1: contextual layout, any d (runtime K loop)
 //   MODE 2: static layout: gather rows of the per-query table by token id
 // GAP: 0 linear, 1 affine, 2 general.  LT: padded query length (4, 8, 12, 16).
@@ -736,7 +745,7 @@ static hipError_t launch_score_gap(const VkScoreParams &p, int grid, size_t smem
 extern "C" hipError_t vk_launch_score(const VkScoreParams *pp, int32_t grid, size_t smem_bytes, hipStream_t stream) {
 	const VkScoreParams &p = *pp;
 	if (p.layout == VK_DEV_LAYOUT_STATIC) return launch_score_gap<2, 0, false>(p, grid, smem_bytes, stream);
-	if (p.nk32 == 9 && p.tail == 1) return launch_score_gap<0, 9, true>(p, grid, smem_bytes, stream);
+	if (p.nk32 == 10 && p.tail == 1) return launch_score_gap<0, 10, true>(p, grid, smem_bytes, stream);
 	return launch_score_gap<1, 0, false>(p, grid, smem_bytes, stream);
 }
 
