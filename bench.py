@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""bench.py -- sentence-alignments/sec of the brute-force alignment search on MI355X.
+
+Workload (BASELINE.json configs[1], SURVEY 8d "Config 2"): per GPU 1,000,000 sentences x 32
+tokens x 300-d bf16 (contextual layout, one vector per token occurrence), 10-token query,
+local alignment, k = 10, min_score = 0.  A "step" is one query against the resident shard:
+query upload -> fused similarity (MFMA) + DP kernel -> bounded result set -> flow of the
+winners -> results on the host (N > 1: + all-gather of the per-rank result sets + merge).
+
+  python bench.py --gpus N --steps K --warmup W [--gap exp5|linear] [--sentences n]
+
+N > 1 is launched by the driver as
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+Rank 0 prints ONE JSON line.  The corpus is sharded by sentence range (weak scaling: every
+rank holds its own 1M-sentence shard); the only exchange is the all-gather of k records.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+D = 300
+LEN_S = 32
+LEN_T = 10
+VOCAB = 50000
+K_MATCHES = 10
+HBM_PEAK = 8.0e12          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+ALG_BYTES_PER_PAIR = LEN_S * D * 2   # |s| * d * 2 bytes (bf16 token vectors, read once)
+
+
+def gap_spec(name):
+	if name == "linear":
+		return 0.1, 0.1, "local alignment, linear gap u=0.1 (Smith-Waterman)"
+	w = (1 - 2.0 ** (-np.arange(0, 65) / 5)).astype(np.float32)   # smooth_gap_cost(5)
+	return ("table", w), ("table", w), "local alignment, general gap w(k)=1-2^(-k/5) (Waterman-Smith-Beyer)"
+
+
+def build_shard(core, torch, n_sent, rank, device):
+	"""synthetic shard generated on the GPU in chunks, handed to the library by device pointer"""
+	from vectorian_amd import synth
+	E = synth.make_vocab(VOCAB, D)                                   # seeded, shared by all ranks
+	rng = np.random.default_rng(synth.SEED_CORPUS + 7919 * rank)
+	n_tok = n_sent * LEN_S
+	ids = synth.zipf_ids(n_tok, VOCAB, rng)
+	off = np.arange(n_sent + 1, dtype=np.int64) * LEN_S
+	corpus = core.Corpus(layout=core.VK_LAYOUT_CONTEXTUAL, d=D, n_tokens=n_tok, n_sentences=n_sent)
+	E_dev = torch.from_numpy(E).to(device)
+	gen = torch.Generator(device=device)
+	gen.manual_seed(1000 + rank)
+	chunk = 1 << 20
+	for a in range(0, n_tok, chunk):
+		b = min(a + chunk, n_tok)
+		idx = torch.from_numpy(ids[a:b].astype(np.int64)).to(device)
+		x = E_dev[idx] + 0.1 * torch.randn((b - a, D), device=device, generator=gen, dtype=torch.float32)
+		x = x.contiguous()
+		torch.cuda.synchronize()
+		corpus.append_vectors_device(x.data_ptr(), b - a, core.VK_F32, normalize=True)
+		del x, idx
+	corpus.set_sentences(off)
+	corpus.finalize()
+	del E_dev
+	torch.cuda.empty_cache()
+	return corpus, E, ids
+
+
+def make_queries(E, ids, n_queries, seed):
+	rng = np.random.default_rng(seed)
+	n_sent = len(ids) // LEN_S
+	qs = []
+	for i in range(n_queries):
+		if i % 2 == 0:   # planted: noisy copy of 10 consecutive tokens of a corpus sentence
+			s = int(rng.integers(0, n_sent))
+			st = s * LEN_S + int(rng.integers(0, LEN_S - LEN_T + 1))
+			qi = ids[st:st + LEN_T]
+		else:
+			qi = rng.integers(0, VOCAB, size=LEN_T)
+		qs.append(np.ascontiguousarray(E[qi] + 0.05 * rng.standard_normal((LEN_T, D)).astype(np.float32), dtype=np.float32))
+	return qs
+
+
+def cpu_baseline(gap_name, budget_s=12.0):
+	"""The CPU restatement of the reference algorithm (oracle/, kind "port": the reference's
+	own C++ path cannot be built offline) on a bounded sample of the same workload."""
+	from oracle import vk_oracle as vo
+	from vectorian_amd import synth
+	n = 20000
+	corpus = synth.make_contextual_corpus(n, LEN_S, LEN_S, VOCAB, D)
+	Xb = synth.to_bf16_bits(synth.normalize_rows(corpus["X"]))
+	qs = synth.make_queries(corpus, 64, LEN_T)
+	gs, gt, _ = gap_spec(gap_name)
+	cores = os.cpu_count() or 1
+	done, t0 = 0, time.perf_counter()
+	while True:
+		q = qs[done % len(qs)]
+		Qb = synth.to_bf16_bits(synth.normalize_rows(q["vectors"]))
+		vo.find(layout=vo.LAYOUT_CONTEXTUAL, d=D, sent_off=corpus["sent_off"], X=Xb, Q=Qb, locality=vo.LOCAL,
+			gap_s=gs, gap_t=gt, max_matches=K_MATCHES, min_score=0.0, n_threads=cores)
+		done += 1
+		el = time.perf_counter() - t0
+		if el >= budget_s or done >= 4096:
+			break
+	return {
+		"value": n * done / el, "unit": "sentence-alignments/sec", "cores": cores, "kind": "port",
+		"sample": f"{done} queries x {n} sentences x {LEN_S} tokens x {D}-d (same generator as the GPU workload), "
+			f"{cores} threads, {el:.1f} s; CPU restatement of the reference algorithm (reference not runnable offline)"}
+
+
+def main():
+	ap = argparse.ArgumentParser()
+	ap.add_argument("--gpus", type=int, default=1)
+	ap.add_argument("--steps", type=int, default=40)
+	ap.add_argument("--warmup", type=int, default=5)
+	ap.add_argument("--gap", choices=["exp5", "linear"], default="exp5")
+	ap.add_argument("--sentences", type=int, default=1000000, help="sentences per GPU")
+	ap.add_argument("--no-cpu-baseline", action="store_true")
+	args = ap.parse_args()
+
+	import torch
+	from vectorian_amd import core
+
+	world = int(os.environ.get("WORLD_SIZE", "1"))
+	rank = int(os.environ.get("RANK", "0"))
+	local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+	if world != args.gpus:
+		if rank == 0 and world == 1 and args.gpus > 1:
+			print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
+			sys.exit(2)
+	if not torch.cuda.is_available():
+		print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
+		sys.exit(2)
+	torch.cuda.set_device(local_rank)
+	device = torch.device("cuda", local_rank)
+	core.init(local_rank)
+
+	dist = None
+	if world > 1:
+		import torch.distributed as dist
+		os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+		dist.init_process_group(backend="nccl", device_id=device)
+
+	n_sent = args.sentences
+	corpus, E, ids = build_shard(core, torch, n_sent, rank, device)
+	queries = make_queries(E, ids, args.steps + args.warmup, seed=3456)
+	if world > 1:   # one query stream for the whole job: rank 0's
+		qt = torch.from_numpy(np.stack(queries)).to(device)
+		dist.broadcast(qt, src=0)
+		queries = list(qt.cpu().numpy())
+	gs, gt, gap_desc = gap_spec(args.gap)
+
+	# all-gather buffers: per rank k records {score f32, raw f32, sentence i64, mapping i16[16], sim f32[16]}
+	rec_floats = 2 + 2 + 8 + 16
+	if world > 1:
+		send = torch.zeros((K_MATCHES, rec_floats), dtype=torch.int32, device=device)
+		recv = torch.zeros((world, K_MATCHES, rec_floats), dtype=torch.int32, device=device)
+
+	def step(q):
+		top = corpus.query(q, locality=core.Locality.LOCAL, gap_s=gs, gap_t=gt, q_normalize=True,
+			max_matches=K_MATCHES, min_score=0.0, want_flow=True)
+		if world == 1:
+			return top
+		# per-rank result sets -> all ranks (RCCL all-gather over xGMI), then ResultSet.extend
+		buf = np.zeros((K_MATCHES, rec_floats), dtype=np.int32)   # records as raw 32-bit words
+		n = top.n
+		buf[:n, 0] = top.score[:n].view(np.int32)
+		buf[:n, 1] = top.raw_score[:n].view(np.int32)
+		buf[:n, 2:4] = (top.sentence[:n] + rank * n_sent).astype(np.int64).view(np.int32).reshape(n, 2)
+		buf[:n, 4:12] = np.pad(top.mapping[:n], ((0, 0), (0, 16 - LEN_T)), constant_values=-1).view(np.int32)
+		buf[:n, 12:12 + LEN_T] = top.edge_sim[:n].view(np.int32)
+		buf[:, 27] = 0
+		buf[:n, 27] = 1                                            # valid flag
+		send.copy_(torch.from_numpy(buf))
+		dist.all_gather_into_tensor(recv, send)
+		allr = recv.cpu().numpy()
+		sets = []
+		for r in range(world):
+			t = core.TopK(K_MATCHES, LEN_T)
+			m = int(allr[r, :, 27].sum())
+			t.n = m
+			t.score[:m] = np.ascontiguousarray(allr[r, :m, 0]).view(np.float32)
+			t.raw_score[:m] = np.ascontiguousarray(allr[r, :m, 1]).view(np.float32)
+			t.sentence[:m] = np.ascontiguousarray(allr[r, :m, 2:4]).view(np.int64).reshape(m)
+			t.mapping[:m] = np.ascontiguousarray(allr[r, :m, 4:12]).view(np.int16).reshape(m, 16)[:, :LEN_T]
+			t.edge_sim[:m] = np.ascontiguousarray(allr[r, :m, 12:12 + LEN_T]).view(np.float32)
+			sets.append(t)
+		return core.merge_topk(sets, LEN_T, K_MATCHES)
+
+	def sync():
+		torch.cuda.synchronize()
+		if dist is not None:
+			dist.barrier()
+			torch.cuda.synchronize()
+
+	for i in range(args.warmup):
+		step(queries[i])
+	sync()
+	score_ms = []
+	t0 = time.perf_counter()
+	for i in range(args.steps):
+		step(queries[args.warmup + i])
+		score_ms.append(corpus.last_timings()["score_ms"])
+	sync()
+	elapsed = time.perf_counter() - t0
+	timings = corpus.last_timings()
+
+	if dist is not None:
+		t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+		dist.all_reduce(t, op=dist.ReduceOp.MAX)
+		elapsed = float(t.item())
+
+	if rank == 0:
+		total_pairs = n_sent * world * args.steps
+		value = total_pairs / elapsed
+		kern_s = float(np.mean(score_ms)) * 1e-3
+		achieved = n_sent * ALG_BYTES_PER_PAIR / kern_s
+		traffic = None
+		prof = os.path.join(ROOT, "profiles", "traffic.json")
+		if os.path.exists(prof):
+			try:
+				traffic = json.load(open(prof)).get(args.gap, {}).get("hbm_bytes_per_launch")
+			except Exception:
+				traffic = None
+		out = {
+			"metric": "sentence-alignments/sec at d=300, |q|=10, |s|<=64; 1/2/4/8 GPU + %HBM roofline",
+			"value": value, "unit": "sentence-alignments/sec",
+			"n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+			"ms_per_step": elapsed / args.steps * 1e3,
+			"higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+			"dtype": "bf16", "data": "synthetic",
+			"config": {
+				"workload": f"{LEN_T}-token query over {n_sent} x {LEN_S}-token synthetic sentences per GPU, "
+					f"{D}-d bf16 per-token vectors (contextual layout), {gap_desc}, top-{K_MATCHES} with flow",
+				"sentences_per_gpu": n_sent, "len_s": LEN_S, "len_t": LEN_T, "d": D, "k": K_MATCHES,
+				"gap": args.gap, "parallelism": f"corpus shards x{world}, RCCL all-gather of k records"},
+			"roofline": {
+				"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+				"frac": achieved / HBM_PEAK, "traffic": traffic,
+				"kernel": "vk_score_kernel", "kernel_ms": kern_s * 1e3,
+				"algorithmic_bytes_per_launch": n_sent * ALG_BYTES_PER_PAIR},
+			"phases_ms_last_step": timings,
+		}
+		if not args.no_cpu_baseline and world == 1:
+			out["cpu_baseline"] = cpu_baseline(args.gap)
+		print(json.dumps(out))
+	corpus.close()
+	if dist is not None:
+		dist.barrier()
+		dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+	main()

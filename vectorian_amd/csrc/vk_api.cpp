@@ -394,6 +394,15 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	}
 	for (int i = 0; i < 128; i++) ws[i] = gap_cost(q->gap_s, i);
 	for (int i = 0; i < 32; i++) wt[i] = gap_cost(q->gap_t, i);
+	if (p.gap_mode == 2 && c->max_len <= 32) {
+		// register-history kernel: needs w_t strictly subadditive over the query length
+		// (see dp_general_reg in vk_kernels.hip); margin far above fp32 rounding of the DP values
+		bool sub = true;
+		for (int x = 1; x < q->len_t && sub; x++)
+			for (int y = 1; x + y <= q->len_t; y++)
+				if (!(wt[x] + wt[y] > wt[x + y] + 1e-4f)) { sub = false; break; }
+		if (sub) p.gap_mode = 3;
+	}
 	VK_HIP(hipMemcpyAsync(c->d_ws, ws, sizeof ws, hipMemcpyHostToDevice, st));
 	VK_HIP(hipMemcpyAsync(c->d_wt, wt, sizeof wt, hipMemcpyHostToDevice, st));
 
@@ -423,7 +432,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	p.s_rows_per_wave = is_static ? (c->max_group_tokens + 15) / 16 * 16 : c->max_group_tiles * 16;
 	p.h_rows = c->max_len + 1;
 	int lds_floats = p.s_rows_per_wave * 16;
-	if (p.gap_mode == 2) lds_floats += 4 * p.h_rows * 16;
+	if (p.gap_mode == 2) lds_floats += 4 * p.h_rows * 16;   // column history of dp_general
 	p.lds_floats_per_wave = lds_floats;
 	const size_t smem = (size_t)lds_floats * 4 * 4;   // 4 waves per block
 	if (smem > 160 * 1024) return fail(VK_ERR_UNSUPPORTED, "LDS demand exceeds 160 KiB per workgroup");
@@ -448,7 +457,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		VkFlowParams f{};
 		f.tiles = c->d_tiles; f.tok_id = c->d_tok_id; f.table = c->d_table; f.sent_off = c->d_sent_off;
 		f.layout = p.layout; f.nk32 = c->nk32; f.tail = c->tail; f.tile_bytes = c->tile_bytes;
-		f.qtile = c->d_qtile; f.len_t = q->len_t; f.locality = q->locality; f.gap_mode = p.gap_mode;
+		f.qtile = c->d_qtile; f.len_t = q->len_t; f.locality = q->locality; f.gap_mode = p.gap_mode == 3 ? 2 : p.gap_mode;
 		f.gs = p.gs; f.gt = p.gt; f.a_s = p.a_s; f.a_t = p.a_t; f.open_s = p.open_s; f.open_t = p.open_t;
 		f.ws = c->d_ws; f.wt = c->d_wt;
 		f.keys = c->d_keys[cur]; f.raw_out = c->d_out_raw; f.mapping = c->d_out_map; f.edge_sim = c->d_out_sim;

@@ -364,12 +364,77 @@ __device__ __forceinline__ float dp_general(const float *__restrict__ S, float *
 	return (is_global) ? m : fmaxf(m, 0.0f);
 }
 
+// General gap costs, fast form: sentences of at most MAXLEN tokens, the column history
+// H[0..u-1][j] lives in registers (rows fully unrolled, w_s in scalar registers), and
+// the in-row step takes its candidates from the row's values *before* in-row gaps,
+//     H[u][j] = max(c[j], max_k c[j-k] - w_t(k)),   c = max(zero, diagonal, gaps over s tokens)
+// which needs no serial chain.  This equals the sequential recurrence bit for bit when
+// w_t is strictly subadditive (w(a) + w(b) > w(a+b) by a margin far above fp32 rounding):
+// two consecutive in-row gaps are then always beaten by the single gap of the summed
+// length, so replacing H[j-k] by c[j-k] drops only dominated candidates.  The host
+// checks the margin (vk_api.cpp) and otherwise selects dp_general.
+template <int LT, int MAXLEN>
+__device__ __forceinline__ float dp_general_reg(const float *__restrict__ S, int rowbase, int len, int maxlen, int v,
+	const DpArgs &a, const float (&wsr)[MAXLEN + 1], const float (&wtr)[LT]) {
+
+	const bool is_local = a.locality == VK_DEV_LOCAL;
+	const bool is_global = a.locality == VK_DEV_GLOBAL;
+	const float floor0 = is_local ? 0.0f : VK_NEG_INF;
+	const bool last_col = v == a.len_t - 1;
+	const float wt_border = a.wt[v + 1];             // distance from the border column to column v + 1
+
+	float hreg[MAXLEN + 1];
+	float h = is_global ? -wt_border : 0.0f;
+	hreg[0] = h;
+	float best = 0.0f;
+#pragma unroll
+	for (int u = 1; u <= MAXLEN; u++) {
+		if (u <= maxlen) {
+			const bool act = u <= len;
+			const float s = S[(rowbase + (act ? u - 1 : 0)) * 16 + v];
+			const float bprev = is_global ? -wsr[u - 1] : 0.0f;
+			const float bcur = is_global ? -wsr[u] : 0.0f;
+			const float diag = dpp_f<DPP_ROW_SHR1>(bprev, hreg[u - 1]);
+			float c = fmaxf(diag + s, floor0);
+#pragma unroll
+			for (int k = 1; k <= u; k++) c = fmaxf(c, hreg[u - k] - wsr[k]);
+			float hc = fmaxf(c, bcur - wt_border);
+			if (LT > 1) hc = fmaxf(hc, dpp_f<0x111>(VK_NEG_INF, c) - wtr[1]);
+			if (LT > 2) hc = fmaxf(hc, dpp_f<0x112>(VK_NEG_INF, c) - wtr[2]);
+			if (LT > 3) hc = fmaxf(hc, dpp_f<0x113>(VK_NEG_INF, c) - wtr[3]);
+			if (LT > 4) hc = fmaxf(hc, dpp_f<0x114>(VK_NEG_INF, c) - wtr[4]);
+			if (LT > 5) hc = fmaxf(hc, dpp_f<0x115>(VK_NEG_INF, c) - wtr[5]);
+			if (LT > 6) hc = fmaxf(hc, dpp_f<0x116>(VK_NEG_INF, c) - wtr[6]);
+			if (LT > 7) hc = fmaxf(hc, dpp_f<0x117>(VK_NEG_INF, c) - wtr[7]);
+			if (LT > 8) hc = fmaxf(hc, dpp_f<0x118>(VK_NEG_INF, c) - wtr[8]);
+			if (LT > 9) hc = fmaxf(hc, dpp_f<0x119>(VK_NEG_INF, c) - wtr[9]);
+			if (LT > 10) hc = fmaxf(hc, dpp_f<0x11a>(VK_NEG_INF, c) - wtr[10]);
+			if (LT > 11) hc = fmaxf(hc, dpp_f<0x11b>(VK_NEG_INF, c) - wtr[11]);
+			if (LT > 12) hc = fmaxf(hc, dpp_f<0x11c>(VK_NEG_INF, c) - wtr[12]);
+			if (LT > 13) hc = fmaxf(hc, dpp_f<0x11d>(VK_NEG_INF, c) - wtr[13]);
+			if (LT > 14) hc = fmaxf(hc, dpp_f<0x11e>(VK_NEG_INF, c) - wtr[14]);
+			if (LT > 15) hc = fmaxf(hc, dpp_f<0x11f>(VK_NEG_INF, c) - wtr[15]);
+			hreg[u] = hc;
+			h = act ? hc : h;
+			if (is_local || last_col) best = fmaxf(best, h);
+		}
+	}
+	float m;
+	if (is_local) m = v < a.len_t ? best : 0.0f;
+	else if (is_global) m = last_col ? h : VK_NEG_INF;
+	else m = v < a.len_t ? fmaxf(h, last_col ? best : 0.0f) : 0.0f;
+	m = row_max_to_lane15(m);
+	return (is_global) ? m : fmaxf(m, 0.0f);
+}
+
 // ---------------------------------------------------------------------------
 // the fused scoring kernel: one wave = 4 sentences at a time, grid-stride over groups.
 //   MODE 0: contextual layout, NK32 K-steps (last one half filled when TAIL), query fragments in registers
 //   MODE 1: contextual layout, any d (runtime K loop)
 //   MODE 2: static layout: gather rows of the per-query table by token id
-// GAP: 0 linear, 1 affine, 2 general.  LT: padded query length (4, 8, 12, 16).
+// GAP: 0 linear, 1 affine, 2 general (LDS history, serial in-row chain),
+//      3 general, sentences <= 32 tokens, strictly subadditive w_t (register history).
+// LT: padded query length (4, 8, 12, 16).
 // ---------------------------------------------------------------------------
 
 template <int MODE, int NK32, bool TAIL, int GAP, int LT>
@@ -389,6 +454,15 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 	a.gs = p.gs; a.gt = p.gt; a.a_s = p.a_s; a.a_t = p.a_t; a.open_s = p.open_s; a.open_t = p.open_t;
 	a.ws = p.ws; a.wt = p.wt;
 	const float inv_ref = (float)p.len_t;
+
+	// general gap, fast form: gap tables in (scalar) registers for the whole kernel
+	float wsr[33], wtr[LT];
+	if (GAP == 3) {
+#pragma unroll
+		for (int k = 0; k <= 32; k++) wsr[k] = p.ws[k];
+#pragma unroll
+		for (int k = 0; k < LT; k++) wtr[k] = p.wt[k];
+	}
 
 	const int n_groups = (p.n_sent + 3) >> 2;
 	for (int grp = blockIdx.x * 4 + wv; grp < n_groups; grp += gridDim.x * 4) {
@@ -437,7 +511,8 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 		const int rb = len > 0 ? rowbase : 0;
 		if (GAP == 0) raw = dp_linear<LT>(S, rb, lenc, maxlen, v, a);
 		else if (GAP == 1) raw = dp_affine<LT>(S, rb, lenc, maxlen, v, a);
-		else raw = dp_general<LT>(S, Hh, p.h_rows, rb, lenc, maxlen, lane, a);
+		else if (GAP == 2) raw = dp_general<LT>(S, Hh, p.h_rows, rb, lenc, maxlen, lane, a);
+		else raw = dp_general_reg<LT, 32>(S, rb, lenc, maxlen, v, a, wsr, wtr);
 
 		if (v == 15 && s_idx < p.n_sent) {
 			// Score::value = raw / reference_score * boost; reference_score == len_t for
@@ -738,6 +813,7 @@ static hipError_t launch_score_gap(const VkScoreParams &p, int grid, size_t smem
 	switch (p.gap_mode) {
 	case 0: return launch_score_lt<MODE, NK32, TAIL, 0>(p, grid, smem, stream);
 	case 1: return launch_score_lt<MODE, NK32, TAIL, 1>(p, grid, smem, stream);
+	case 3: return launch_score_lt<MODE, NK32, TAIL, 3>(p, grid, smem, stream);
 	default: return launch_score_lt<MODE, NK32, TAIL, 2>(p, grid, smem, stream);
 	}
 }
