@@ -154,11 +154,7 @@ def main():
 		queries = list(qt.cpu().numpy())
 	gs, gt, gap_desc = gap_spec(args.gap)
 
-	# all-gather buffers: per rank k records {score f32, raw f32, sentence i64, mapping i16[16], sim f32[16]}
-	rec_floats = 2 + 2 + 8 + 16
-	if world > 1:
-		send = torch.zeros((K_MATCHES, rec_floats), dtype=torch.int32, device=device)
-		recv = torch.zeros((world, K_MATCHES, rec_floats), dtype=torch.int32, device=device)
+	from vectorian_amd import shards
 
 	def step(q):
 		top = corpus.query(q, locality=core.Locality.LOCAL, gap_s=gs, gap_t=gt, q_normalize=True,
@@ -166,30 +162,7 @@ def main():
 		if world == 1:
 			return top
 		# per-rank result sets -> all ranks (RCCL all-gather over xGMI), then ResultSet.extend
-		buf = np.zeros((K_MATCHES, rec_floats), dtype=np.int32)   # records as raw 32-bit words
-		n = top.n
-		buf[:n, 0] = top.score[:n].view(np.int32)
-		buf[:n, 1] = top.raw_score[:n].view(np.int32)
-		buf[:n, 2:4] = (top.sentence[:n] + rank * n_sent).astype(np.int64).view(np.int32).reshape(n, 2)
-		buf[:n, 4:12] = np.pad(top.mapping[:n], ((0, 0), (0, 16 - LEN_T)), constant_values=-1).view(np.int32)
-		buf[:n, 12:12 + LEN_T] = top.edge_sim[:n].view(np.int32)
-		buf[:, 27] = 0
-		buf[:n, 27] = 1                                            # valid flag
-		send.copy_(torch.from_numpy(buf))
-		dist.all_gather_into_tensor(recv, send)
-		allr = recv.cpu().numpy()
-		sets = []
-		for r in range(world):
-			t = core.TopK(K_MATCHES, LEN_T)
-			m = int(allr[r, :, 27].sum())
-			t.n = m
-			t.score[:m] = np.ascontiguousarray(allr[r, :m, 0]).view(np.float32)
-			t.raw_score[:m] = np.ascontiguousarray(allr[r, :m, 1]).view(np.float32)
-			t.sentence[:m] = np.ascontiguousarray(allr[r, :m, 2:4]).view(np.int64).reshape(m)
-			t.mapping[:m] = np.ascontiguousarray(allr[r, :m, 4:12]).view(np.int16).reshape(m, 16)[:, :LEN_T]
-			t.edge_sim[:m] = np.ascontiguousarray(allr[r, :m, 12:12 + LEN_T]).view(np.float32)
-			sets.append(t)
-		return core.merge_topk(sets, LEN_T, K_MATCHES)
+		return shards.allgather_merge(top, rank * n_sent, K_MATCHES, device=device)
 
 	def sync():
 		torch.cuda.synchronize()

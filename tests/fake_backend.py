@@ -1,0 +1,95 @@
+"""Test double for `vectorian_amd.core.Corpus`: same interface, scores computed by the CPU
+oracle.  Lives in tests/ only -- it lets the host-side plumbing (Session / Index / shards)
+run in the no-GPU tier; the product never imports it."""
+
+import numpy as np
+
+from oracle import vk_oracle as vo
+from vectorian_amd import core, synth
+
+
+def _gap(g, n=65):
+	if hasattr(g, "to_special_case"):
+		sp = g.to_special_case()
+		if "linear" in sp:
+			return ("linear", sp["linear"])
+		if "affine" in sp:
+			return ("affine",) + tuple(sp["affine"])
+		return ("table", g.costs(n))
+	return g
+
+
+class OracleCorpus:
+	def __init__(self, *, layout, d, n_tokens, n_sentences, vocab_size=0, keep_magnitudes=False, device=None):
+		self.layout, self.d = layout, d
+		self.n_tokens, self.n_sentences, self.vocab_size = n_tokens, n_sentences, vocab_size
+		self._rows, self._mags = [], []
+		self._ids = None
+		self._off = None
+		self._all = None
+
+	def append_vectors(self, rows, normalize=True):
+		rows = np.ascontiguousarray(rows)
+		if rows.dtype == np.uint16:
+			rows = synth.bf16_bits_to_f32(rows)
+		if normalize:
+			b, m = vo.normalize_rows_bf16(rows)
+		else:
+			b, m = synth.to_bf16_bits(rows), np.ones(len(rows), np.float32)
+		self._rows.append(b)
+		self._mags.append(m)
+
+	def set_token_ids(self, ids):
+		self._ids = np.ascontiguousarray(ids, dtype=np.int32)
+
+	def set_sentences(self, off):
+		self._off = np.ascontiguousarray(off, dtype=np.int64)
+
+	def finalize(self):
+		self._X = np.concatenate(self._rows) if self._rows else np.zeros((0, self.d), np.uint16)
+		self._mag = np.concatenate(self._mags) if self._mags else np.zeros(0, np.float32)
+
+	def query(self, q_vectors, *, locality=0, gap_s=0.0, gap_t=0.0, algorithm=0, q_token_ids=None, q_normalize=True,
+			max_matches=10, min_score=0.0, boost=None, want_flow=True, submatch_weight=0.0, bidirectional=False,
+			rwmd=(True, True, True), wrd_normalize=True):
+		q = np.ascontiguousarray(q_vectors)
+		if q.dtype == np.uint16:
+			q = synth.bf16_bits_to_f32(q)
+		q = q.astype(np.float32)
+		if q_normalize:
+			Qb, qmag = vo.normalize_rows_bf16(q)
+		else:
+			Qb, qmag = synth.to_bf16_bits(q), np.ones(len(q), np.float32)
+		kw = dict(layout=self.layout, d=self.d, sent_off=self._off, Q=Qb, algorithm=algorithm, locality=int(locality),
+			gap_s=_gap(gap_s), gap_t=_gap(gap_t), max_matches=max_matches, min_score=min_score, boost=boost,
+			submatch_weight=submatch_weight, rwmd=rwmd, wrd_normalize=wrd_normalize, want_all_scores=True)
+		if self.layout == core.VK_LAYOUT_STATIC:
+			kw.update(tok_id=self._ids, E=self._X, q_ids=q_token_ids)
+		else:
+			kw.update(X=self._X, X_mag=self._mag, Q_mag=qmag)
+		r = vo.find(**kw)
+		self._all = r["all_scores"]
+		top = core.TopK(max_matches, len(q))
+		n = len(r["score"])
+		top.n = n
+		top.score[:n], top.raw_score[:n], top.sentence[:n] = r["score"], r["raw"], r["sentence"]
+		top.mapping[:n] = r["mapping"]
+		# edge similarities as the flow kernel reports them
+		for i in range(n):
+			s = int(r["sentence"][i])
+			a, b = int(self._off[s]), int(self._off[s + 1])
+			if self.layout == core.VK_LAYOUT_STATIC:
+				table = vo.sim_table_static_bf16(self._X, Qb, q_token_ids)
+				S = table[self._ids[a:b]]
+			else:
+				S = vo.sim_bf16(self._X[a:b], Qb)
+			for j in range(len(q)):
+				if r["mapping"][i][j] >= 0:
+					top.edge_sim[i, j] = S[r["mapping"][i][j], j]
+		return top
+
+	def last_scores(self):
+		return self._all
+
+	def close(self):
+		pass

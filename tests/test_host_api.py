@@ -1,0 +1,176 @@
+"""CPU tier: the Python host surface (Session / Partition / Index.find / option dicts)
+with the oracle-backed test double in place of the HIP corpus (tests/fake_backend.py).
+BASELINE configs[0] -- the plumbing case: 5-token query over a 1k-sentence toy corpus,
+static 300-d embedding, cosine + Waterman-Smith-Beyer."""
+
+import numpy as np
+import pytest
+
+from fake_backend import OracleCorpus
+from vectorian_amd import alignment, core, synth
+from vectorian_amd.corpus import Corpus, Document
+from vectorian_amd.embedding import ContextualEmbedding, StaticEmbedding, Vectors
+from vectorian_amd.index import HipBruteForceIndex
+from vectorian_amd.session import Session
+from vectorian_amd.sim import CosineSim, EmbeddingTokenSim, OptimizedSpanSim
+
+
+def test_option_dicts_match_reference_literals():
+	# vectorian/alignment.py:31-38, 96-97, 129-130, 186-187
+	g = alignment.smooth_gap_cost(5)
+	for cls, loc in ((alignment.LocalAlignment, core.Locality.LOCAL), (alignment.GlobalAlignment, core.Locality.GLOBAL),
+			(alignment.SemiGlobalAlignment, core.Locality.SEMIGLOBAL)):
+		assert cls(gap=g).to_args(None) == {"algorithm": "pyalign", "options": {"locality": loc, "gap_cost": g}}
+	with pytest.raises(ValueError):
+		alignment.LocalAlignment(gap={"x": g})
+	# vectorian/alignment.py:231-239, 275-283
+	assert alignment.WordMoversDistance.rwmd("nbow").to_args(None) == {
+		"algorithm": "word-movers-distance", "relaxed": True, "injective": True, "symmetric": True,
+		"normalize_bow": True, "extra_mass_penalty": -1}
+	assert alignment.WordMoversDistance.wmd("nbow").to_args(None)["relaxed"] is False
+	assert alignment.WordMoversDistance.rwmd("bow/fast").to_args(None)["symmetric"] is False
+	# vectorian/alignment.py:308-313
+	assert alignment.WordRotatorsDistance().to_args(None) == {
+		"algorithm": "word-rotators-distance", "normalize_magnitudes": True, "extra_mass_penalty": -1}
+
+
+def test_gap_cost_families():
+	assert alignment.ConstantGapCost(0).to_special_case() == {"linear": 0.0}
+	assert alignment.ConstantGapCost(0.3).to_special_case() == {}
+	assert list(alignment.ConstantGapCost(0.3).costs(4)) == [0, np.float32(0.3), np.float32(0.3), np.float32(0.3)]
+	assert alignment.LinearGapCost(0.1).to_special_case() == {"linear": 0.1}
+	assert alignment.AffineGapCost(0.2, 0.05).to_special_case() == {"affine": (0.2, 0.05)}
+	assert alignment.AffineGapCost(0.2, 0.05).costs(3)[0] == 0
+	e = alignment.smooth_gap_cost(5)
+	assert e.to_tuple() == ("exponential", 2.0, 0.2)            # vectorian/interact.py:559-565
+	assert float(e.costs(3)[1]) == 0.12944944202899933           # mkdocs/docs/introduction.md:174
+	assert abs(e(5) - 0.5) < 1e-7
+	assert alignment.smooth_gap_cost(0).to_special_case() == {"linear": 0.0}
+
+
+def toy_session(n_docs=20, sents_per_doc=50, V=5000, d=300, seed=1):
+	rng = np.random.default_rng(seed)
+	E = synth.make_vocab(V, d)
+	words = [f"w{i}" for i in range(V)]
+	docs = []
+	for di in range(n_docs):
+		sents = []
+		for _ in range(sents_per_doc):
+			n = int(rng.integers(4, 41))
+			sents.append([words[i] for i in synth.zipf_ids(n, V, rng)])
+		docs.append(Document(sents, unique_id=f"doc{di}", metadata={"title": f"doc {di}"}))
+	emb = StaticEmbedding("toy-300", words, E)
+	return Session(Corpus(docs), embeddings=[emb]), emb, words, rng
+
+
+def test_find_over_toy_corpus_static_wsb(oracle):
+	session, emb, words, rng = toy_session()
+	sim = OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), alignment.LocalAlignment(gap=alignment.smooth_gap_cost(5)))
+	index = session.partition("sentence").index(sim, corpus_factory=OracleCorpus)
+	assert isinstance(index, HipBruteForceIndex)
+	assert index.n_slices == 1000
+	# plant: 5 consecutive tokens of sentence 7 of document 3
+	doc = session.documents[3]
+	st, en = doc.spans["sentence"]["start"][7], doc.spans["sentence"]["end"][7]
+	planted = doc.tokens[st + 1:st + 6]
+	result = index.find(" ".join(planted), n=5)
+	assert len(result) == 5
+	top = result[0]
+	assert top.doc_index == 3 and top.slice_id == 7
+	assert abs(top.score - 1.0) < 1e-2
+	assert list(top.flow["target"]) == [1, 2, 3, 4, 5]
+	assert top.flow["type"] == "injective" and top.flow["target"].dtype == np.int16
+	scores = [m.score for m in result]
+	assert scores == sorted(scores, reverse=True)
+	j = top.to_json()
+	assert j["slice"] == 7 and j["metric"] == "toy-300-cosine" and j["level"] == "word"
+	assert j["location"]["title"] == "doc 3" and j["location"]["start"] == st
+	matched = [r for r in j["regions"] if "edges" in r]
+	assert [r["s"] for r in matched] == planted
+	assert all(abs(r["edges"][0]["distance"]) < 1e-2 for r in matched)
+	assert result.duration >= 0
+
+	# independent check of the whole pipeline: vocabulary table + gather + WSB in the oracle
+	Eb = synth.to_bf16_bits(Vectors(emb.encode_tokens(session.vocab.tokens).unmodified).normalized)
+	ids = np.concatenate([session.doc_token_ids(i) for i in range(len(session.documents))])
+	qids = np.array([session.vocab.token_to_id(t) for t in planted], dtype=np.int32)
+	Qb = synth.to_bf16_bits(emb.encode_tokens(planted).normalized)
+	w = alignment.smooth_gap_cost(5).costs(65)
+	ref = oracle.find(layout=oracle.LAYOUT_STATIC, d=300, sent_off=index._sent_off, tok_id=ids, E=Eb, Q=Qb, q_ids=qids,
+		gap_s=("table", w), gap_t=("table", w), max_matches=5)
+	assert [int(index._slice_doc[g]) for g in ref["sentence"]] == [m.doc_index for m in result]
+	np.testing.assert_allclose([m.score for m in result], ref["score"], atol=1e-6)
+
+
+def test_regions_report_gap_penalties_like_the_reference_docs():
+	# the shape of mkdocs/docs/introduction.md:150-184: one skipped document token between
+	# the 2nd and 3rd match costs gap_cost_s(1) = 1 - 2^(-1/5)
+	words = ["get", "our", "jewels", "and", "wealth", "together", "jewelry", "riches", "x"]
+	rng = np.random.default_rng(0)
+	base = rng.standard_normal((len(words), 64)).astype(np.float32)
+	base[6] = base[2] + 0.3 * rng.standard_normal(64)     # jewelry ~ jewels
+	base[7] = base[4] + 0.3 * rng.standard_normal(64)     # riches ~ wealth
+	emb = StaticEmbedding("toy", words, base)
+	doc = Document([["get", "our", "jewels", "and", "our", "wealth", "together", "x"]], metadata={"author": "ws"})
+	session = Session([doc], embeddings=[emb])
+	sim = OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), alignment.LocalAlignment(gap=alignment.smooth_gap_cost(5)))
+	index = session.index(sim, corpus_factory=OracleCorpus)
+	m = index.find("jewelry and riches", n=1)[0]
+	assert list(m.flow["target"]) == [2, 3, 5]
+	j = m.to_json(context_size=2)
+	reg = j["regions"]
+	assert reg[0] == {"s": "get our", "gap_penalty": 0.0}
+	assert reg[1]["s"] == "jewels" and reg[1]["edges"][0]["t"]["text"] == "jewelry"
+	assert reg[2]["s"] == "and" and reg[2]["edges"][0]["distance"] < 1e-6
+	assert reg[3]["s"] == "our" and abs(reg[3]["gap_penalty"] - 0.12944944202899933) < 1e-9
+	assert reg[4]["s"] == "wealth" and reg[4]["edges"][0]["t"]["index"] == 2
+	assert reg[5] == {"s": "together", "gap_penalty": 0.0}
+	d = [reg[i]["edges"][0]["distance"] for i in (1, 2, 4)]
+	want = ((1 - d[0]) + (1 - d[1]) - 0.12944944202899933 + (1 - d[2])) / 3
+	assert abs(m.score - want) < 1e-6
+	assert j["omitted"] == []
+
+
+def test_contextual_embedding_and_boost():
+	rng = np.random.default_rng(4)
+	d = 48
+	table = {}
+	def vec(tok):
+		if tok not in table:
+			table[tok] = rng.standard_normal(d).astype(np.float32)
+		return table[tok]
+	docs = []
+	for di in range(3):
+		sents = [[f"t{int(rng.integers(0, 30))}" for _ in range(int(rng.integers(2, 9)))] for _ in range(10)]
+		toks = [t for s in sents for t in s]
+		X = np.stack([vec(t) + 0.05 * rng.standard_normal(d).astype(np.float32) for t in toks])
+		docs.append(Document(sents, contextual_embeddings={"ctx": X}))
+	emb = ContextualEmbedding("ctx", d, lambda tokens: np.stack([vec(t) for t in tokens]))
+	session = Session(docs, embeddings=[emb])
+	sim = OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), alignment.GlobalAlignment(gap=alignment.LinearGapCost(0.1)))
+	boost = np.ones(30, dtype=np.float32)
+	boost[17] = 50.0
+	index = session.index(sim, corpus_factory=OracleCorpus, saliency=boost)
+	q = " ".join(docs[1].tokens[3:6])
+	r = index.find(q, n=3, min_score=-100.0)
+	assert r[0].doc_index == 1 and r[0].slice_id == 7          # slice 17 of the session = doc 1, sentence 7
+	assert len(r) == 3
+
+
+def test_unsupported_options_are_explicit():
+	session, emb, words, rng = toy_session(n_docs=1, sents_per_doc=3, V=50, d=16)
+	ts = EmbeddingTokenSim(emb, CosineSim())
+	with pytest.raises(TypeError):
+		OptimizedSpanSim("not a token sim")
+	with pytest.raises(NotImplementedError):
+		session.partition("sentence", 2, 1).index(OptimizedSpanSim(ts), corpus_factory=OracleCorpus)
+	index = session.index(OptimizedSpanSim(ts, tag_weights={"NN": 2.0}), corpus_factory=OracleCorpus)
+	with pytest.raises(NotImplementedError):
+		index.find("w1 w2")
+	index = session.index(OptimizedSpanSim(ts, alignment.WordMoversDistance.wmd("nbow")), corpus_factory=OracleCorpus)
+	with pytest.raises(NotImplementedError):
+		index.find("w1 w2")
+	index = session.index(OptimizedSpanSim(ts), corpus_factory=OracleCorpus)
+	with pytest.raises(RuntimeError):
+		index.find("w1 w2", options={"no_such_option": 1})
+	assert index.find("", n=3).matches == []

@@ -1,0 +1,56 @@
+"""CPU tier: the N > 1 path.  Two gloo ranks, each with half of the corpus; the all-gather +
+merge must give every rank exactly the result set of the unsharded corpus."""
+
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+from vectorian_amd import shards, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_ranges():
+	assert shards.shard_ranges(10, 3) == [(0, 4), (4, 7), (7, 10)]
+	assert shards.shard_ranges(2, 4) == [(0, 1), (1, 2), (2, 2), (2, 2)]
+
+
+def test_pack_roundtrip():
+	from vectorian_amd import core
+	t = core.TopK(5, 3)
+	t.n = 2
+	t.score[:2] = [0.75, -0.5]; t.raw_score[:2] = [2.25, -1.5]; t.sentence[:2] = [2 ** 33 + 5, 7]
+	t.mapping[:2] = [[4, -1, 9], [0, 1, 2]]; t.edge_sim[:2] = [[0.5, 0, 0.25], [1, 1, 1]]
+	u = shards.unpack_topk(shards.pack_topk(t, 100, 5), 3)
+	assert u.n == 2 and list(u.sentence[:2]) == [2 ** 33 + 105, 107]
+	assert (u.mapping[:2] == t.mapping[:2]).all() and (u.edge_sim[:2] == t.edge_sim[:2]).all()
+	assert (u.score[:2] == t.score[:2]).all() and (u.raw_score[:2] == t.raw_score[:2]).all()
+
+
+def test_two_rank_gloo_matches_unsharded(tmp_path, oracle):
+	with socket.socket() as s:
+		s.bind(("127.0.0.1", 0))
+		port = s.getsockname()[1]
+	env = dict(os.environ, OMP_NUM_THREADS="1")
+	cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+		"--master-addr", "127.0.0.1", "--master-port", str(port),
+		os.path.join(ROOT, "tests", "shard_worker.py"), str(tmp_path)]
+	r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+	assert r.returncode == 0, r.stderr[-3000:]
+	got = [np.load(tmp_path / f"rank{k}.npz") for k in range(2)]
+
+	corpus = synth.make_contextual_corpus(900, 2, 30, 800, 64)
+	queries = synth.make_queries(corpus, 3, 6)
+	Xb, _ = oracle.normalize_rows_bf16(corpus["X"])
+	for qi, q in enumerate(queries):
+		Qb, _ = oracle.normalize_rows_bf16(q["vectors"])
+		for name, loc in (("local", 0), ("global", 1)):
+			ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=64, sent_off=corpus["sent_off"], X=Xb, Q=Qb, locality=loc,
+				gap_s=0.1, gap_t=0.1, max_matches=12, min_score=0.0 if loc == 0 else -100.0)
+			for g in got:
+				assert (g[f"{qi}_{name}_sentence"] == ref["sentence"]).all()
+				assert (g[f"{qi}_{name}_score"] == ref["score"]).all()
+				assert (g[f"{qi}_{name}_mapping"] == ref["mapping"]).all()

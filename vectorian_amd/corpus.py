@@ -1,0 +1,107 @@
+"""Array-backed documents: the data contract `PreparedDocument` hands to the C++ core
+(vectorian/corpus/document.py:626-662 -> core.Document, vectorian/core/cpp/document.cpp:30-58):
+a token table and sentence spans in token units, optionally one contextual vector per
+token.  Importers, on-disk storage (h5 / sqlite) and text normalisation of the reference
+are out of scope; documents arrive tokenised.
+"""
+
+import numpy as np
+
+
+class Document:
+	def __init__(self, sentences, unique_id=None, metadata=None, contextual_embeddings=None):
+		"""sentences: list of sentences, each a list of token strings.
+		contextual_embeddings: {embedding name: float32 [n_tokens x d]}"""
+		self._sentences = [list(s) for s in sentences]
+		self._tokens = [t for s in self._sentences for t in s]
+		lens = np.array([len(s) for s in self._sentences], dtype=np.int64)
+		self._spans = {"sentence": {
+			"start": np.concatenate(([0], np.cumsum(lens)[:-1])).astype(np.int32) if len(lens) else np.zeros(0, np.int32),
+			"end": np.cumsum(lens).astype(np.int32)}}
+		self._unique_id = unique_id
+		self._metadata = metadata or {}
+		self._contextual = {}
+		for name, v in (contextual_embeddings or {}).items():
+			v = np.ascontiguousarray(v, dtype=np.float32)
+			if v.shape[0] != len(self._tokens):
+				raise ValueError(f"contextual embedding {name}: {v.shape[0]} vectors for {len(self._tokens)} tokens")
+			self._contextual[name] = v
+
+	@property
+	def unique_id(self):
+		return self._unique_id
+
+	@property
+	def metadata(self):
+		return self._metadata
+
+	@property
+	def tokens(self):
+		return self._tokens
+
+	@property
+	def n_tokens(self):
+		return len(self._tokens)
+
+	@property
+	def spans(self):
+		return self._spans
+
+	def n_spans(self, level="sentence"):
+		return len(self._spans[level]["start"])
+
+	def has_contextual_embedding(self, name):
+		return name in self._contextual
+
+	def contextual_vectors(self, name):
+		return self._contextual[name]
+
+	def max_len(self, level, window_size):
+		# Document::max_len (vectorian/core/cpp/document.cpp): longest window in tokens
+		st, en = self._spans[level]["start"], self._spans[level]["end"]
+		n = len(st)
+		best = 0
+		for i in range(n):
+			j = min(i + window_size - 1, n - 1)
+			best = max(best, int(en[j] - st[i]))
+		return best
+
+	def span_tokens(self, level, slice_id, window_size=1, window_step=1):
+		st, en = self._spans[level]["start"], self._spans[level]["end"]
+		i = slice_id * window_step
+		j = min(i + window_size - 1, len(st) - 1)
+		return self._tokens[int(st[i]):int(en[j])]
+
+	def span_info(self, partition_args, slice_id):
+		st, en = self._spans[partition_args["level"]]["start"], self._spans[partition_args["level"]]["end"]
+		i = slice_id * partition_args["window_step"]
+		j = min(i + partition_args["window_size"] - 1, len(st) - 1)
+		info = dict(self._metadata)
+		info.update({"start": int(st[i]), "end": int(en[j])})
+		return info
+
+
+class Corpus:
+	"""an ordered collection of documents (the in-memory part of vectorian/corpus/corpus.py:245)"""
+
+	def __init__(self, docs=()):
+		self._docs = list(docs)
+
+	def add_doc(self, doc):
+		self._docs.append(doc)
+
+	@property
+	def docs(self):
+		return self._docs
+
+	def __len__(self):
+		return len(self._docs)
+
+	def __iter__(self):
+		return iter(self._docs)
+
+	def __getitem__(self, i):
+		return self._docs[i]
+
+	def get_doc_index(self, doc):
+		return self._docs.index(doc)

@@ -1,0 +1,511 @@
+"""Index family: `Index.find` and the MI355X brute-force index.
+
+Mirrors vectorian/index.py: Query (:25), Match / PyMatch (:192, :382), Index (:434) with
+`make_query` (:461-477) and `find` (:479-501), and BruteForceIndex (:509-560) -- whose `_find`
+(one core.Document.find per document on a thread pool + ResultSet.extend) is what
+HipBruteForceIndex replaces with one vk_query call against the corpus resident in HBM.
+"""
+
+import collections
+import logging
+import time
+
+import numpy as np
+
+from vectorian_amd import core
+from vectorian_amd.alignment import GapCost
+from vectorian_amd.sim import CosineSim, EmbeddingTokenSim, OptimizedSpanSim
+
+Region = collections.namedtuple("Region", ["s", "match", "gap_penalty"])
+TokenMatch = collections.namedtuple("TokenMatch", ["pos_s", "edges"])
+TokenMatchEdge = collections.namedtuple("TokenMatchEdge", ["t", "flow", "distance", "metric"])
+TokenMatchT = collections.namedtuple("TokenMatchT", ["text", "index", "pos"])
+PartitionData = collections.namedtuple("PartitionData", ["level", "window_size", "window_step"])
+
+
+def default_tokenizer(text):
+	"""stand-in for the spaCy pipeline `nlp` of the reference (tokenisation is out of scope)"""
+	return text.split()
+
+
+class Query:
+	def __init__(self, index, vocab, text, options):
+		self._index = index
+		self._vocab = vocab
+		self._text = text
+		self._options = options
+
+	@property
+	def index(self):
+		return self._index
+
+	@property
+	def text(self):
+		return self._text
+
+	@property
+	def options(self):
+		return self._options
+
+	def prepare(self, nlp):
+		return PreparedQuery(self, self._vocab, nlp)
+
+
+class PreparedQuery:
+	"""tokenised query + its vectors (vectorian/index.py:56-106; the spaCy specifics dropped)"""
+
+	def __init__(self, query, vocab, nlp):
+		self._query = query
+		tokens = list((nlp or default_tokenizer)(query.text))
+		for attr in ("pos_filter", "tag_filter"):
+			if query.options.get(attr):
+				raise NotImplementedError(f"{attr} needs part-of-speech tags; tokens here carry none")
+		self._tokens = tokens
+		self._token_ids = np.array([vocab.token_to_id(t) for t in tokens], dtype=np.int32)
+
+	@property
+	def index(self):
+		return self._query.index
+
+	@property
+	def text_str(self):
+		return self._query.text
+
+	@property
+	def options(self):
+		return self._query.options
+
+	@property
+	def tokens(self):
+		return self._tokens
+
+	@property
+	def token_ids(self):
+		return self._token_ids
+
+	@property
+	def n_tokens(self):
+		return len(self._tokens)
+
+	def __len__(self):
+		return len(self._tokens)
+
+
+class Match:
+	"""abstract match interface (vectorian/index.py:192-292)"""
+
+	@property
+	def index(self):
+		raise NotImplementedError()
+
+	@property
+	def partition(self):
+		return self.index.partition
+
+	@property
+	def query(self):
+		raise NotImplementedError()
+
+	@property
+	def doc(self):
+		return self.prepared_doc
+
+	@property
+	def prepared_doc(self):
+		raise NotImplementedError()
+
+	@property
+	def slice_id(self):
+		raise NotImplementedError()
+
+	@property
+	def slice(self):
+		return self.partition.slice_id_to_slice(self.slice_id)
+
+	@property
+	def score(self):
+		raise NotImplementedError()
+
+	@property
+	def metric(self):
+		raise NotImplementedError()
+
+	@property
+	def omitted(self):
+		raise NotImplementedError()
+
+	def regions(self, context_size=10):
+		raise NotImplementedError()
+
+	@property
+	def level(self):
+		raise NotImplementedError()
+
+	@property
+	def flow(self):
+		return None
+
+	def to_json(self, context_size=10):
+		regions = []
+		partition = self.query.options["partition"]
+		span_info = self.prepared_doc.span_info(partition, self.slice_id)
+		for region in self.regions(context_size):
+			s = region.s
+			if region.match:
+				edges = []
+				for e in region.match.edges:
+					edges.append({
+						"t": {"text": e.t.text, "index": e.t.index, "pos": e.t.pos},
+						"flow": e.flow,
+						"distance": e.distance,
+						"metric": e.metric
+					})
+				regions.append(dict(s=s, pos_s=region.match.pos_s, edges=edges))
+			else:
+				regions.append(dict(s=s, gap_penalty=region.gap_penalty))
+		return dict(
+			slice=self.slice_id,
+			location=span_info,
+			score=self.score,
+			metric=self.metric,
+			regions=regions,
+			omitted=self.omitted,
+			level=self.level)
+
+
+class HipMatch(Match):
+	"""one winner of a search; what CoreMatch (vectorian/index.py:295-379) exposes, computed
+	from the C-ABI result arrays"""
+
+	def __init__(self, index, query, doc_index, slice_id, token_at, len_s, score, raw_score, mapping, edge_sim, gaps):
+		self._index = index
+		self._query = query
+		self._doc_index = doc_index
+		self._slice_id = slice_id
+		self._token_at = token_at
+		self._len_s = len_s
+		self._score = float(score)
+		self._raw_score = float(raw_score)
+		self._mapping = mapping
+		self._edge_sim = edge_sim
+		self._gaps = gaps
+
+	@property
+	def index(self):
+		return self._index
+
+	@property
+	def query(self):
+		return self._query
+
+	@property
+	def prepared_doc(self):
+		return self._index.session.documents[self._doc_index]
+
+	@property
+	def doc_index(self):
+		return self._doc_index
+
+	@property
+	def slice_id(self):
+		return self._slice_id
+
+	@property
+	def score(self):
+		return self._score
+
+	@property
+	def score_max(self):
+		return float(len(self._query))   # reference_score with submatch_weight 0 (metric/alignment.h:84-106)
+
+	@property
+	def raw_score(self):
+		return self._raw_score
+
+	@property
+	def metric(self):
+		return self._index.metric_name
+
+	@property
+	def level(self):
+		return "word"
+
+	@property
+	def flow(self):
+		"""InjectiveFlow::to_py (vectorian/core/cpp/match/flow.cpp:190-216); per-edge values as
+		ScoreComputer fills them (metric/alignment.h:335-345)"""
+		target = self._mapping.astype(np.int16)
+		matched = target >= 0
+		return {
+			"type": "injective",
+			"target": target,
+			"flow": matched.astype(np.float32),
+			"dist": np.where(matched, 1.0 - self._edge_sim, 1.0).astype(np.float32)}
+
+	@property
+	def omitted(self):
+		# Flow::py_omitted (match/flow.cpp:170-188): query tokens without a partner
+		return [self._query.tokens[j] for j in range(len(self._query)) if self._mapping[j] < 0]
+
+	def regions(self, context_size=10):
+		"""Flow::py_regions (vectorian/core/cpp/match/flow.cpp:9-167) in token units: unmatched
+		document stretches carry the gap penalty gap_cost_s(skipped), matched tokens their edges"""
+		doc_tokens = self.prepared_doc.tokens
+		gap_s, gap_t = self._gaps
+		token_at = self._token_at
+		flow = self.flow
+		edges = [(int(flow["target"][j]), j) for j in range(len(self._query)) if flow["target"][j] >= 0]
+		edges.sort()
+		text = lambda a, b: " ".join(doc_tokens[a:b])
+		regions = []
+		if not edges:
+			regions.append(Region(s=text(token_at, token_at + self._len_s), match=None, gap_penalty=0.0))
+			return regions
+		last_anchor = max(0, token_at + edges[0][0] - context_size)
+		last_matched = False
+		last_source = -1
+		k = 0
+		while k < len(edges):
+			target = edges[k][0]
+			pos = token_at + target
+			if pos > last_anchor:
+				p = float(gap_s(pos - last_anchor)) if last_matched else 0.0
+				regions.append(Region(s=text(last_anchor, pos), match=None, gap_penalty=p))
+			region_edges = []
+			while k < len(edges) and edges[k][0] == target:
+				source = edges[k][1]
+				if last_source >= 0:
+					p = float(gap_t(source - last_source - 1))
+					if p > 0.0:
+						regions.append(Region(s="", match=None, gap_penalty=p))
+				last_source = source
+				region_edges.append(TokenMatchEdge(
+					t=TokenMatchT(text=self._query.tokens[source], index=source, pos=None),
+					flow=float(flow["flow"][source]),
+					distance=float(flow["dist"][source]),
+					metric=self.metric))
+				k += 1
+			regions.append(Region(s=doc_tokens[pos], match=TokenMatch(pos_s=None, edges=region_edges), gap_penalty=0.0))
+			last_anchor = pos + 1
+			last_matched = True
+		up_to = min(last_anchor + context_size, len(doc_tokens) - 1)
+		if up_to > last_anchor:
+			regions.append(Region(s=text(last_anchor, up_to), match=None, gap_penalty=0.0))
+		return regions
+
+
+class Index:
+	def __init__(self, partition, sim):
+		self._partition = partition
+		self._sim = sim
+		if not partition.contiguous:
+			logging.warning("the used partition is non-contiguous, you will miss parts of the content.")
+
+	@property
+	def partition(self):
+		return self._partition
+
+	@property
+	def session(self):
+		return self._partition.session
+
+	@property
+	def sim(self):
+		return self._sim
+
+	def make_query(self, text, n=10, min_score=0.0, debug=None, options: dict = dict()):
+		# vectorian/index.py:461-477
+		options = options.copy()
+		options["max_matches"] = n
+		options["min_score"] = min_score
+		if debug is not None:
+			options["debug"] = debug
+		options["partition"] = self._partition.to_args()
+		if self._sim is not None:
+			sim_args = self._sim.to_args(self)
+			if sim_args:
+				options["metric"] = sim_args
+		return Query(self, self._partition.session.vocab, text, options)
+
+	def find(self, text, n=10, min_score=0.0, debug=None, disable_progress=False,
+			run_task=None, make_result=None, options: dict = dict()):
+		# vectorian/index.py:479-501
+		start_time = time.time()
+		query = self.make_query(text, n=n, min_score=min_score, debug=debug, options=options)
+		session = self._partition.session
+		if make_result is None:
+			make_result = session.make_result
+		if run_task is None:
+			run_task = lambda task: session.on_progress(task, disable_progress=disable_progress)
+		matches = run_task(lambda progress: self._find(query, progress=progress))
+		return make_result(self, matches, duration=time.time() - start_time)
+
+	def _find(self, query, progress=None):
+		raise NotImplementedError()
+
+
+_QUERY_OPTION_WHITELIST = {
+	# Query::initialize (vectorian/core/cpp/query.cpp:45-55)
+	"metric", "pos_filter", "tag_filter", "submatch_weight", "bidirectional",
+	"max_matches", "min_score", "partition", "debug"}
+
+
+def _split_gap(gap):
+	"""gap_cost is one GapCost or {'s': .., 't': ..} (metric/alignment.h:365-370; vectorian/alignment.py:78-83)"""
+	if isinstance(gap, dict):
+		from vectorian_amd.alignment import ConstantGapCost
+		return gap.get("s", ConstantGapCost(0)), gap.get("t", ConstantGapCost(0))
+	return gap, gap
+
+
+class HipBruteForceIndex(Index):
+	"""Brute-force search over every slice of the session, on one MI355X.
+
+	Constructor signature of BruteForceIndex (vectorian/index.py:509-524):
+	(partition, sim, *, nlp, saliency=None); `device` selects the GPU.  The whole corpus is
+	uploaded once (token tiles in HBM); every `find` is one vk_query."""
+
+	def __init__(self, partition, sim, *, nlp=None, saliency=None, device=0, corpus_factory=None):
+		super().__init__(partition, sim)
+		self._nlp = nlp
+		if not isinstance(sim, OptimizedSpanSim):
+			raise TypeError(f"{type(sim).__name__}: the HIP index implements OptimizedSpanSim")
+		token_sim = sim.token_sim
+		if not isinstance(token_sim, EmbeddingTokenSim):
+			raise NotImplementedError("token similarity modifiers are outside the HIP path (SURVEY 2.1)")
+		if not isinstance(token_sim.similarity, CosineSim):
+			raise NotImplementedError(f"{token_sim.similarity.name}: the HIP path computes CosineSim")
+		self._embedding = token_sim.embedding
+		self._metric_name = token_sim.to_args(self)["name"]
+		if partition.window_step != partition.window_size:
+			raise NotImplementedError("overlapping / skipping windows (window_step != window_size) are a 'next' row (SURVEY 8f-3)")
+
+		session = self.session
+		level, size = partition.level, partition.window_size
+		# slices: Spans::iterate (vectorian/core/cpp/document.h:147-169) over every document
+		sent_off = [0]
+		self._slice_doc, self._slice_id, self._slice_token_at = [], [], []
+		base = 0
+		for di, doc in enumerate(session.documents):
+			st, en = doc.spans[level]["start"], doc.spans[level]["end"]
+			n = len(st)
+			if n and (st[0] != 0 or (n > 1 and (st[1:] != en[:-1]).any()) or en[-1] != doc.n_tokens):
+				raise ValueError("spans must be contiguous and cover the document (document.h:151-168)")
+			for sid in range(0, n, partition.window_step):
+				j = min(sid + size - 1, n - 1)
+				sent_off.append(base + int(en[j]))
+				self._slice_doc.append(di)
+				self._slice_id.append(sid)
+				self._slice_token_at.append(int(st[sid]))
+			base += doc.n_tokens
+		self._sent_off = np.array(sent_off, dtype=np.int64)
+		self._slice_doc = np.array(self._slice_doc, dtype=np.int64)
+		n_tokens, n_slices = base, len(self._slice_doc)
+
+		self._boost = None
+		if saliency is not None:
+			# Booster (vectorian/saliency.py:141-154 -> core.Booster): one multiplicative weight per slice
+			self._boost = np.ascontiguousarray(saliency, dtype=np.float32)
+			if self._boost.shape != (n_slices,):
+				raise ValueError("saliency must hold one float per slice")
+
+		make = corpus_factory or core.Corpus
+		emb = self._embedding
+		if emb.is_static:
+			vocab_vectors = emb.encode_tokens(session.vocab.tokens)
+			self._corpus = make(layout=core.VK_LAYOUT_STATIC, d=emb.dimension, n_tokens=n_tokens, n_sentences=n_slices,
+				vocab_size=max(1, session.vocab.size), device=device)
+			E = vocab_vectors.normalized if session.vocab.size else np.zeros((1, emb.dimension), np.float32)
+			self._corpus.append_vectors(E, normalize=False)
+			ids = np.concatenate([session.doc_token_ids(i) for i in range(len(session.documents))]) if n_tokens else np.zeros(0, np.int32)
+			self._corpus.set_token_ids(ids)
+		elif emb.is_contextual:
+			from vectorian_amd.embedding import Vectors
+			self._corpus = make(layout=core.VK_LAYOUT_CONTEXTUAL, d=emb.dimension, n_tokens=n_tokens, n_sentences=n_slices,
+				keep_magnitudes=True, device=device)
+			for doc in session.documents:
+				self._corpus.append_vectors(Vectors(doc.contextual_vectors(emb.name)).unmodified, normalize=True)
+		else:
+			raise TypeError(emb)
+		self._corpus.set_sentences(self._sent_off)
+		self._corpus.finalize()
+
+	@property
+	def metric_name(self):
+		return self._metric_name
+
+	@property
+	def n_slices(self):
+		return len(self._slice_doc)
+
+	@property
+	def corpus(self):
+		return self._corpus
+
+	def _backend_args(self, options):
+		"""option dicts of the reference -> vk_query arguments (Query::initialize,
+		vectorian/core/cpp/query.cpp:32-154; create_alignment_matcher, metric/alignment.h:780-920)"""
+		for k in options:
+			if k not in _QUERY_OPTION_WHITELIST:
+				raise RuntimeError(f"illegal option {k}")   # query.cpp:60-63
+		metric = options.get("metric")
+		if not isinstance(metric, dict) or metric.get("metric") not in ("alignment-isolated",):
+			raise NotImplementedError(f"metric {metric.get('metric') if isinstance(metric, dict) else metric} "
+				"is not implemented on the HIP path ('alignment-tag-weighted' is a next row, SURVEY 8f-1)")
+		alignment = metric["alignment"]
+		args = dict(
+			max_matches=int(options.get("max_matches", 100)),      # query.cpp:87-89
+			min_score=float(options.get("min_score", 0.2)),        # query.cpp:91-93
+			submatch_weight=float(options.get("submatch_weight", 0.0)),
+			bidirectional=bool(options.get("bidirectional", False)))
+		algorithm = alignment.get("algorithm")
+		if algorithm == "pyalign":
+			o = alignment.get("options", {})
+			gs, gt = _split_gap(o.get("gap_cost"))
+			for g in (gs, gt):
+				if not isinstance(g, GapCost):
+					raise TypeError(f"gap cost {g!r} is not a GapCost")
+			args.update(algorithm=core.VK_ALG_ALIGN, locality=int(o.get("locality", core.Locality.LOCAL)), gap_s=gs, gap_t=gt)
+			gaps = (gs, gt)
+		elif algorithm == "word-movers-distance":
+			if not alignment.get("relaxed", True):
+				raise NotImplementedError("full WMD (exact EMD) is a next row (SURVEY 8f-4); use WordMoversDistance.rwmd")
+			args.update(algorithm=core.VK_ALG_RWMD,
+				rwmd=(alignment["injective"], alignment["symmetric"], alignment["normalize_bow"]))
+			gaps = (lambda k: 0.0, lambda k: 0.0)   # gap_cost_s/t of WordMoversDistance return 0 (metric/alignment.h:632-638)
+		elif algorithm == "word-rotators-distance":
+			args.update(algorithm=core.VK_ALG_WRD, wrd_normalize=alignment.get("normalize_magnitudes", True))
+			gaps = (lambda k: 0.0, lambda k: 0.0)
+		else:
+			raise RuntimeError(f"unknown alignment algorithm {algorithm}")   # metric/alignment.h:914-919
+		return args, gaps
+
+	def _find(self, query, progress=None):
+		p_query = query.prepare(self._nlp)
+		if len(p_query) == 0:
+			return []
+		args, gaps = self._backend_args(query.options)
+		emb = self._embedding
+		qv = emb.encode_tokens(p_query.tokens)
+		if emb.is_static:
+			top = self._corpus.query(qv.normalized, q_normalize=False, q_token_ids=p_query.token_ids,
+				boost=self._boost, want_flow=True, **args)
+		else:
+			top = self._corpus.query(qv.unmodified, q_normalize=True, boost=self._boost, want_flow=True, **args)
+		if progress:
+			progress(1.0)
+		return self._matches_from_topk(p_query, top, gaps)
+
+	def _matches_from_topk(self, p_query, top, gaps):
+		matches = []
+		for i in range(top.n):
+			g = int(top.sentence[i])
+			di = int(self._slice_doc[g])
+			matches.append(HipMatch(
+				self, p_query, di, self._slice_id[g], self._slice_token_at[g],
+				int(self._sent_off[g + 1] - self._sent_off[g]),
+				top.score[i], top.raw_score[i], top.mapping[i].copy(), top.edge_sim[i].copy(), gaps))
+		return matches
+
+	def close(self):
+		self._corpus.close()

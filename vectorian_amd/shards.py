@@ -1,0 +1,72 @@
+"""Corpus shards across the GPUs of one node.
+
+Sentences are independent given the query, so the corpus is split by contiguous sentence
+ranges, one shard per process / GPU, read-only in that GPU's HBM.  The only exchange per
+query is an all-gather of the k-record result sets (RCCL over xGMI when the process
+group's backend is "nccl"; "gloo" on CPU for tests) followed by the same bounded merge the
+reference performs on the host (ResultSet::extend, vectorian/core/cpp/result_set.h:70-93).
+Global sentence index = shard offset + local index; every rank ends with the same set.
+"""
+
+import numpy as np
+
+from vectorian_amd import core
+
+_REC_WORDS = 44   # valid, score, raw, sentence(2), mapping i16[16] (8), edge_sim f32[16] (16), pad
+
+
+def shard_ranges(n_sentences, world):
+	"""contiguous sentence ranges, sizes differing by at most one"""
+	base, rem = divmod(n_sentences, world)
+	out, a = [], 0
+	for r in range(world):
+		b = a + base + (1 if r < rem else 0)
+		out.append((a, b))
+		a = b
+	return out
+
+
+def pack_topk(top, sentence_offset, k):
+	buf = np.zeros((k, _REC_WORDS), dtype=np.int32)
+	n = top.n
+	buf[:n, 0] = 1
+	buf[:n, 1] = top.score[:n].view(np.int32)
+	buf[:n, 2] = top.raw_score[:n].view(np.int32)
+	buf[:n, 3:5] = (top.sentence[:n] + sentence_offset).astype(np.int64).view(np.int32).reshape(n, 2)
+	m = np.full((n, 16), -1, dtype=np.int16)
+	m[:, :top.len_t] = top.mapping[:n]
+	buf[:n, 5:13] = m.view(np.int32)
+	e = np.zeros((n, 16), dtype=np.float32)
+	e[:, :top.len_t] = top.edge_sim[:n]
+	buf[:n, 13:29] = e.view(np.int32)
+	return buf
+
+
+def unpack_topk(buf, len_t):
+	k = buf.shape[0]
+	t = core.TopK(k, len_t)
+	n = int(buf[:, 0].sum())
+	t.n = n
+	b = np.ascontiguousarray(buf[:n])
+	t.score[:n] = np.ascontiguousarray(b[:, 1]).view(np.float32)
+	t.raw_score[:n] = np.ascontiguousarray(b[:, 2]).view(np.float32)
+	t.sentence[:n] = np.ascontiguousarray(b[:, 3:5]).view(np.int64).reshape(n)
+	t.mapping[:n] = np.ascontiguousarray(b[:, 5:13]).view(np.int16).reshape(n, 16)[:, :len_t]
+	t.edge_sim[:n] = np.ascontiguousarray(b[:, 13:29]).view(np.float32).reshape(n, 16)[:, :len_t]
+	return t
+
+
+def allgather_merge(top, sentence_offset, k, group=None, device=None):
+	"""all ranks contribute their local result set; every rank returns the merged global one"""
+	import torch
+	import torch.distributed as dist
+
+	world = dist.get_world_size(group)
+	if device is None:
+		device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+	send = torch.from_numpy(pack_topk(top, sentence_offset, k)).to(device)
+	recv = torch.empty((world * k, send.shape[1]), dtype=send.dtype, device=device)   # concatenated along dim 0
+	dist.all_gather_into_tensor(recv, send, group=group)
+	allr = recv.cpu().numpy().reshape(world, k, send.shape[1])
+	sets = [unpack_topk(allr[r], top.len_t) for r in range(world)]
+	return core.merge_topk(sets, top.len_t, k)
