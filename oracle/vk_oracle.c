@@ -884,8 +884,7 @@ static int score_sentence(const work *w, int64_t s, float *Sbuf, float *xbuf, fl
 	return 0;
 }
 
-static void *worker(void *arg) {
-	work *w = (work *)arg;
+static void run_range(work *w) {
 	const vko_query *q = w->q;
 	float *Sbuf = (float *)malloc(sizeof(float) * (size_t)VKO_MAX_LEN_S * q->len_t);
 	float *xbuf = (float *)malloc(sizeof(float) * (size_t)(w->c->d > 0 ? w->c->d : 1));
@@ -902,71 +901,98 @@ static void *worker(void *arg) {
 	}
 	free(Sbuf);
 	free(xbuf);
+}
+
+/* one thread = one static sentence range, for every query of the batch in turn (the analogue
+ * of the reference's thread-per-document pool, vectorian/index.py:544-558) */
+typedef struct { work *items; int32_t n; } thread_arg;
+
+static void *worker(void *arg) {
+	thread_arg *ta = (thread_arg *)arg;
+	for (int32_t i = 0; i < ta->n; i++) run_range(&ta->items[i]);
 	return NULL;
 }
 
-int vko_find(const vko_corpus *c, const vko_query *q, vko_result *out, int32_t n_threads) {
-	if (q->len_t < 1 || q->len_t > VKO_MAX_LEN_T || q->max_matches < 1) return 1;
+int vko_find_many(const vko_corpus *c, const vko_query *qs, int32_t n_queries, vko_result *outs, int32_t n_threads) {
+	if (n_queries < 1) return 0;
+	for (int32_t i = 0; i < n_queries; i++)
+		if (qs[i].len_t < 1 || qs[i].len_t > VKO_MAX_LEN_T || qs[i].max_matches < 1) return 1;
 	if (n_threads < 1) n_threads = 1;
 	if ((int64_t)n_threads > c->n_sentences) n_threads = c->n_sentences > 0 ? (int32_t)c->n_sentences : 1;
-	const int32_t k = q->max_matches;
 
-	float *qf = (float *)malloc(sizeof(float) * (size_t)q->len_t * c->d);
-	widen_rows(q->Q, (int64_t)q->len_t * c->d, qf);
-	float *table = NULL;
-	if (c->layout == VKO_LAYOUT_STATIC) {
-		table = (float *)malloc(sizeof(float) * (size_t)c->V * q->len_t);
-		vko_sim_table_static_bf16(c->E, c->V, c->d, q->Q, q->len_t, q->q_ids, table);
+	float **qf = (float **)calloc((size_t)n_queries, sizeof(float *));
+	float **table = (float **)calloc((size_t)n_queries, sizeof(float *));
+	for (int32_t i = 0; i < n_queries; i++) {
+		qf[i] = (float *)malloc(sizeof(float) * (size_t)qs[i].len_t * c->d);
+		widen_rows(qs[i].Q, (int64_t)qs[i].len_t * c->d, qf[i]);
+		if (c->layout == VKO_LAYOUT_STATIC) {
+			table[i] = (float *)malloc(sizeof(float) * (size_t)c->V * qs[i].len_t);
+			vko_sim_table_static_bf16(c->E, c->V, c->d, qs[i].Q, qs[i].len_t, qs[i].q_ids, table[i]);
+		}
 	}
 
-	work *ws = (work *)calloc((size_t)n_threads, sizeof(work));
+	work *ws = (work *)calloc((size_t)n_threads * n_queries, sizeof(work));
+	thread_arg *ta = (thread_arg *)calloc((size_t)n_threads, sizeof(thread_arg));
 	pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
 	for (int32_t t = 0; t < n_threads; t++) {
-		ws[t].c = c; ws[t].q = q; ws[t].qf = qf; ws[t].table = table;
-		ws[t].s0 = c->n_sentences * t / n_threads;
-		ws[t].s1 = c->n_sentences * (t + 1) / n_threads;
-		ws[t].tk.h = (hit *)malloc(sizeof(hit) * (size_t)k);
-		ws[t].tk.n = 0; ws[t].tk.k = k;
-		ws[t].all_scores = out->all_scores;
+		ta[t].items = ws + (size_t)t * n_queries;
+		ta[t].n = n_queries;
+		for (int32_t i = 0; i < n_queries; i++) {
+			work *w = &ta[t].items[i];
+			w->c = c; w->q = &qs[i]; w->qf = qf[i]; w->table = table[i];
+			w->s0 = c->n_sentences * t / n_threads;
+			w->s1 = c->n_sentences * (t + 1) / n_threads;
+			w->tk.h = (hit *)malloc(sizeof(hit) * (size_t)qs[i].max_matches);
+			w->tk.n = 0; w->tk.k = qs[i].max_matches;
+			w->all_scores = outs[i].all_scores;
+		}
 	}
-	if (n_threads == 1) worker(&ws[0]);
+	if (n_threads == 1) worker(&ta[0]);
 	else {
-		for (int32_t t = 0; t < n_threads; t++) pthread_create(&th[t], NULL, worker, &ws[t]);
+		for (int32_t t = 0; t < n_threads; t++) pthread_create(&th[t], NULL, worker, &ta[t]);
 		for (int32_t t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
 	}
 
-	/* ResultSet::extend (result_set.h:70-93): merge the bounded sets */
-	topk all;
-	all.h = (hit *)malloc(sizeof(hit) * (size_t)k);
-	all.n = 0; all.k = k;
 	int status = 0;
-	for (int32_t t = 0; t < n_threads; t++) {
-		if (ws[t].status) status = ws[t].status;
-		for (int32_t i = 0; i < ws[t].tk.n; i++) topk_push(&all, ws[t].tk.h[i]);
-		free(ws[t].tk.h);
-	}
-
-	out->n_out = all.n;
-	if (status == 0) {
-		float *Sbuf = (float *)malloc(sizeof(float) * (size_t)VKO_MAX_LEN_S * q->len_t);
-		float *xbuf = (float *)malloc(sizeof(float) * (size_t)(c->d > 0 ? c->d : 1));
-		work w0 = ws[0];
-		for (int32_t i = 0; i < all.n; i++) {
-			out->score[i] = all.h[i].score;
-			if (out->raw) out->raw[i] = all.h[i].raw;
-			out->sentence[i] = all.h[i].g;
-			if (out->mapping && q->algorithm == VKO_ALG_ALIGN) {
-				float raw, value;
-				score_sentence(&w0, all.h[i].g, Sbuf, xbuf, &raw, &value, out->mapping + (size_t)i * q->len_t);
-			}
+	for (int32_t i = 0; i < n_queries; i++) {
+		const vko_query *q = &qs[i];
+		const int32_t k = q->max_matches;
+		/* ResultSet::extend (result_set.h:70-93): merge the bounded sets */
+		topk all;
+		all.h = (hit *)malloc(sizeof(hit) * (size_t)k);
+		all.n = 0; all.k = k;
+		for (int32_t t = 0; t < n_threads; t++) {
+			work *w = &ta[t].items[i];
+			if (w->status) status = w->status;
+			for (int32_t j = 0; j < w->tk.n; j++) topk_push(&all, w->tk.h[j]);
+			free(w->tk.h);
 		}
-		free(Sbuf);
-		free(xbuf);
+		vko_result *out = &outs[i];
+		out->n_out = all.n;
+		if (status == 0) {
+			float *Sbuf = (float *)malloc(sizeof(float) * (size_t)VKO_MAX_LEN_S * q->len_t);
+			float *xbuf = (float *)malloc(sizeof(float) * (size_t)(c->d > 0 ? c->d : 1));
+			work w0 = ta[0].items[i];
+			for (int32_t j = 0; j < all.n; j++) {
+				out->score[j] = all.h[j].score;
+				if (out->raw) out->raw[j] = all.h[j].raw;
+				out->sentence[j] = all.h[j].g;
+				if (out->mapping && q->algorithm == VKO_ALG_ALIGN) {
+					float raw, value;
+					score_sentence(&w0, all.h[j].g, Sbuf, xbuf, &raw, &value, out->mapping + (size_t)j * q->len_t);
+				}
+			}
+			free(Sbuf);
+			free(xbuf);
+		}
+		free(all.h);
+		free(qf[i]);
+		free(table[i]);
 	}
-	free(all.h);
-	free(ws);
-	free(th);
-	free(qf);
-	free(table);
+	free(ws); free(ta); free(th); free(qf); free(table);
 	return status;
+}
+
+int vko_find(const vko_corpus *c, const vko_query *q, vko_result *out, int32_t n_threads) {
+	return vko_find_many(c, q, 1, out, n_threads);
 }

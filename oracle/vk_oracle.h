@@ -145,6 +145,9 @@ typedef struct {
 } vko_result;
 
 int vko_find(const vko_corpus *c, const vko_query *q, vko_result *out, int32_t n_threads);
+/* a batch of queries with the worker threads started once (each thread keeps its static
+ * sentence range and walks the queries in turn) */
+int vko_find_many(const vko_corpus *c, const vko_query *qs, int32_t n_queries, vko_result *outs, int32_t n_threads);
 
 #ifdef __cplusplus
 }

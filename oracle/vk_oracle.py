@@ -244,11 +244,12 @@ def emd(a, b, Cm):
 
 # ---- whole-corpus search --------------------------------------------------
 
-def find(*, layout, d, sent_off, Q, len_t=None, X=None, X_mag=None, tok_id=None, E=None,
-		algorithm=ALG_ALIGN, locality=LOCAL, gap_s=0.0, gap_t=0.0, q_ids=None, Q_mag=None,
+def find_many(*, layout, d, sent_off, Qs, X=None, X_mag=None, tok_id=None, E=None,
+		algorithm=ALG_ALIGN, locality=LOCAL, gap_s=0.0, gap_t=0.0, q_ids=None, Q_mags=None,
 		max_matches=10, min_score=0.0, boost=None, submatch_weight=0.0,
 		rwmd=(True, True, True), wrd_normalize=True, n_threads=1, want_all_scores=False):
-	"""Runs vko_find.  X/E/Q are uint16 bf16 arrays; returns dict(score, raw, sentence, mapping[, all_scores])."""
+	"""Runs vko_find_many over a batch of queries (Qs: list of uint16 bf16 [len_t x d]); q_ids / Q_mags
+	are per-query lists or None.  Returns a list of dict(score, raw, sentence, mapping[, all_scores])."""
 	keep = []
 	c = Corpus()
 	sent_off = np.ascontiguousarray(sent_off, dtype=np.int64)
@@ -264,37 +265,55 @@ def find(*, layout, d, sent_off, Q, len_t=None, X=None, X_mag=None, tok_id=None,
 	if E is not None:
 		E = np.ascontiguousarray(E, dtype=np.uint16); c.E = _ptr(E); c.V = E.shape[0]
 	c.sent_off = _ptr(sent_off)
-
-	q = Query()
-	Q = np.ascontiguousarray(Q, dtype=np.uint16)
-	len_t = Q.shape[0] if len_t is None else len_t
-	q.algorithm, q.len_t, q.Q = algorithm, len_t, _ptr(Q)
-	if Q_mag is not None:
-		Q_mag = _f32(Q_mag); q.Q_mag = _ptr(Q_mag)
-	if q_ids is not None:
-		q_ids = np.ascontiguousarray(q_ids, dtype=np.int32); q.q_ids = _ptr(q_ids)
-	q.locality = locality
-	q.gap_s, q.gap_t = make_gap(gap_s, keep), make_gap(gap_t, keep)
-	q.submatch_weight = submatch_weight
-	q.max_matches, q.min_score = max_matches, min_score
 	if boost is not None:
-		boost = _f32(boost); q.boost = _ptr(boost)
-	q.rwmd_injective, q.rwmd_symmetric, q.rwmd_normalize_bow = [int(x) for x in rwmd]
-	q.wrd_normalize_magnitudes = int(wrd_normalize)
+		boost = _f32(boost)
 
+	nq = len(Qs)
+	qs = (Query * nq)()
+	rs = (Result * nq)()
+	bufs = []
 	k = max_matches
-	r = Result()
-	score_ = np.zeros(k, dtype=np.float32)
-	raw_ = np.zeros(k, dtype=np.float32)
-	sent_ = np.zeros(k, dtype=np.int64)
-	map_ = np.full((k, len_t), -1, dtype=np.int16)
-	all_ = np.zeros(n_sent, dtype=np.float32) if want_all_scores else None
-	r.score, r.raw, r.sentence, r.mapping, r.all_scores = _ptr(score_), _ptr(raw_), _ptr(sent_), _ptr(map_), _ptr(all_)
-	status = lib().vko_find(C.byref(c), C.byref(q), C.byref(r), n_threads)
+	for i in range(nq):
+		Q = np.ascontiguousarray(Qs[i], dtype=np.uint16)
+		keep.append(Q)
+		q = qs[i]
+		q.algorithm, q.len_t, q.Q = algorithm, Q.shape[0], _ptr(Q)
+		if Q_mags is not None and Q_mags[i] is not None:
+			m = _f32(Q_mags[i]); keep.append(m); q.Q_mag = _ptr(m)
+		if q_ids is not None and q_ids[i] is not None:
+			ids = np.ascontiguousarray(q_ids[i], dtype=np.int32); keep.append(ids); q.q_ids = _ptr(ids)
+		q.locality = locality
+		q.gap_s, q.gap_t = make_gap(gap_s, keep), make_gap(gap_t, keep)
+		q.submatch_weight = submatch_weight
+		q.max_matches, q.min_score = max_matches, min_score
+		if boost is not None:
+			q.boost = _ptr(boost)
+		q.rwmd_injective, q.rwmd_symmetric, q.rwmd_normalize_bow = [int(x) for x in rwmd]
+		q.wrd_normalize_magnitudes = int(wrd_normalize)
+		score_ = np.zeros(k, dtype=np.float32)
+		raw_ = np.zeros(k, dtype=np.float32)
+		sent_ = np.zeros(k, dtype=np.int64)
+		map_ = np.full((k, Q.shape[0]), -1, dtype=np.int16)
+		all_ = np.zeros(n_sent, dtype=np.float32) if want_all_scores else None
+		r = rs[i]
+		r.score, r.raw, r.sentence, r.mapping, r.all_scores = _ptr(score_), _ptr(raw_), _ptr(sent_), _ptr(map_), _ptr(all_)
+		bufs.append((score_, raw_, sent_, map_, all_))
+	L = lib()
+	L.vko_find_many.restype = C.c_int
+	status = L.vko_find_many(C.byref(c), qs, C.c_int32(nq), rs, C.c_int32(n_threads))
 	if status != 0:
 		raise ValueError("vko_find failed: %d" % status)
-	n = r.n_out
-	out = dict(score=score_[:n], raw=raw_[:n], sentence=sent_[:n], mapping=map_[:n])
-	if want_all_scores:
-		out["all_scores"] = all_
-	return out
+	outs = []
+	for i in range(nq):
+		n = rs[i].n_out
+		score_, raw_, sent_, map_, all_ = bufs[i]
+		out = dict(score=score_[:n], raw=raw_[:n], sentence=sent_[:n], mapping=map_[:n])
+		if want_all_scores:
+			out["all_scores"] = all_
+		outs.append(out)
+	return outs
+
+
+def find(*, Q, q_ids=None, Q_mag=None, len_t=None, **kw):
+	"""one query (vko_find); see find_many"""
+	return find_many(Qs=[Q], q_ids=None if q_ids is None else [q_ids], Q_mags=None if Q_mag is None else [Q_mag], **kw)[0]
