@@ -633,6 +633,8 @@ __global__ __launch_bounds__(64) void vk_flow_kernel(VkFlowParams p) {
 	__shared__ uint8_t eext[VK_TB_ROWS * VK_TB_W];
 	__shared__ uint8_t fext[VK_TB_ROWS * VK_TB_W];
 	__shared__ int16_t dk[VK_TB_ROWS * VK_TB_W];
+	__shared__ float wsl[VK_DEV_MAX_SENT_LEN + 1];
+	__shared__ float wtl[VK_DEV_MAX_QUERY_LEN + 1];
 
 	const int lane = threadIdx.x;
 	const int w = blockIdx.x;
@@ -662,85 +664,90 @@ __global__ __launch_bounds__(64) void vk_flow_kernel(VkFlowParams p) {
 		}
 		rowbase = t_a - tile0 * 16;
 	}
+	// gap tables into LDS (uniform broadcast reads in the candidate loops)
+	for (int i = lane; i <= VK_DEV_MAX_SENT_LEN; i += 64) wsl[i] = p.ws[i];
+	if (lane <= VK_DEV_MAX_QUERY_LEN) wtl[lane] = p.wt[lane];
 	__syncthreads();
-	if (lane != 0) return;
 
 	const float *Sm = S + rowbase * 16;
 	const int W = VK_TB_W;
 	const bool local = p.locality == VK_DEV_LOCAL, global = p.locality == VK_DEV_GLOBAL;
 	const int gap = p.gap_mode;
+	const float gs = p.gs, gt = p.gt, open_s = p.open_s, open_t = p.open_t, a_s = p.a_s, a_t = p.a_t;
 
-	if (gap == 0) {
-		const float gs = p.gs, gt = p.gt;
-		H[0] = 0.0f;
-		for (int v = 1; v <= len_t; v++) H[v] = global ? -(gt * (float)v) : 0.0f;
-		for (int u = 1; u <= len_s; u++) {
-			H[u * W] = global ? -(gs * (float)u) : 0.0f;
-			for (int v = 1; v <= len_t; v++) {
-				float best; uint8_t d;
-				float c = H[(u - 1) * W + v - 1] + Sm[(u - 1) * 16 + v - 1];
-				if (local) { best = 0.0f; d = 0; if (c > best) { best = c; d = 1; } }
-				else { best = c; d = 1; }
-				c = H[(u - 1) * W + v] - gs;
-				if (c > best) { best = c; d = 2; }
-				c = H[u * W + v - 1] - gt;
-				if (c > best) { best = c; d = 3; }
-				H[u * W + v] = best; dirs[u * W + v] = d; dk[u * W + v] = 1;
-			}
+	// ---- fill: lanes 0..len_t-1 own one query column each.  Per row the zero / diagonal /
+	// gap-in-s candidates of all columns are evaluated in parallel, the gap-in-t candidates
+	// column by column (they need the final cells to their left).  Every cell tries its
+	// candidates in the oracle's order and replaces only on strictly greater, so values,
+	// directions and gap lengths are those of the sequential fill.
+	if (lane <= len_t) {   // borders of row 0
+		const int v = lane;
+		float h0 = 0.0f;
+		if (global && v > 0) h0 = gap == 0 ? -(gt * (float)v) : gap == 1 ? -(a_t + gt * (float)v) : -wtl[v];
+		H[v] = h0;
+		E[v] = VK_NEG_INF;
+		F[v] = (global && v > 0 && gap == 1) ? h0 : VK_NEG_INF;
+	}
+	for (int u = 1; u <= len_s; u++) {
+		wave_lds_fence();
+		float best = 0.0f, e = VK_NEG_INF;
+		uint8_t d = 0, ee = 0;
+		int16_t kk = 0;
+		const int v = lane + 1;   // this lane's column
+		if (lane == 0) {          // border column
+			float hb = 0.0f;
+			if (global) hb = gap == 0 ? -(gs * (float)u) : gap == 1 ? -(a_s + gs * (float)u) : -wsl[u];
+			H[u * W] = hb;
+			E[u * W] = (global && gap == 1) ? hb : VK_NEG_INF;
+			F[u * W] = VK_NEG_INF;
 		}
-	} else if (gap == 2) {
-		const float *ws = p.ws, *wt = p.wt;
-		H[0] = 0.0f;
-		for (int v = 1; v <= len_t; v++) H[v] = global ? -wt[v] : 0.0f;
-		for (int u = 1; u <= len_s; u++) {
-			H[u * W] = global ? -ws[u] : 0.0f;
-			for (int v = 1; v <= len_t; v++) {
-				float best; uint8_t d; int16_t kk = 0;
-				float c = H[(u - 1) * W + v - 1] + Sm[(u - 1) * 16 + v - 1];
-				if (local) { best = 0.0f; d = 0; if (c > best) { best = c; d = 1; } }
-				else { best = c; d = 1; }
+		if (v <= len_t) {
+			float c = H[(u - 1) * W + v - 1] + Sm[(u - 1) * 16 + v - 1];
+			if (local) { best = 0.0f; d = 0; if (c > best) { best = c; d = 1; } }
+			else { best = c; d = 1; }
+			if (gap == 0) {
+				c = H[(u - 1) * W + v] - gs;
+				if (c > best) { best = c; d = 2; kk = 1; }
+			} else if (gap == 1) {
+				e = H[(u - 1) * W + v] - open_s;
+				c = E[(u - 1) * W + v] - gs;
+				if (c > e) { e = c; ee = 1; }
+				if (e > best) { best = e; d = 2; }
+			} else {
 				for (int k = 1; k <= u; k++) {
-					c = H[(u - k) * W + v] - ws[k];
+					c = H[(u - k) * W + v] - wsl[k];
 					if (c > best) { best = c; d = 2; kk = (int16_t)k; }
 				}
-				for (int k = 1; k <= v; k++) {
-					c = H[u * W + v - k] - wt[k];
-					if (c > best) { best = c; d = 3; kk = (int16_t)k; }
+			}
+		}
+		wave_lds_fence();
+		for (int vv = 1; vv <= len_t; vv++) {
+			if (v == vv) {
+				float c;
+				uint8_t fe = 0;
+				float f = VK_NEG_INF;
+				if (gap == 0) {
+					c = H[u * W + v - 1] - gt;
+					if (c > best) { best = c; d = 3; kk = 1; }
+				} else if (gap == 1) {
+					f = H[u * W + v - 1] - open_t;
+					c = F[u * W + v - 1] - gt;
+					if (c > f) { f = c; fe = 1; }
+					if (f > best) { best = f; d = 3; }
+				} else {
+					for (int k = 1; k <= v; k++) {
+						c = H[u * W + v - k] - wtl[k];
+						if (c > best) { best = c; d = 3; kk = (int16_t)k; }
+					}
 				}
-				H[u * W + v] = best; dirs[u * W + v] = d; dk[u * W + v] = kk;
-			}
-		}
-	} else {
-		const float bs = p.gs, bt = p.gt, open_s = p.open_s, open_t = p.open_t;
-		const float a_s = p.a_s, a_t = p.a_t;
-		H[0] = 0.0f; E[0] = VK_NEG_INF; F[0] = VK_NEG_INF;
-		for (int v = 1; v <= len_t; v++) {
-			H[v] = global ? -(a_t + bt * (float)v) : 0.0f;
-			E[v] = VK_NEG_INF;
-			F[v] = global ? H[v] : VK_NEG_INF;
-		}
-		for (int u = 1; u <= len_s; u++) {
-			H[u * W] = global ? -(a_s + bs * (float)u) : 0.0f;
-			E[u * W] = global ? H[u * W] : VK_NEG_INF;
-			F[u * W] = VK_NEG_INF;
-			for (int v = 1; v <= len_t; v++) {
-				float e = H[(u - 1) * W + v] - open_s; uint8_t ee = 0;
-				float c = E[(u - 1) * W + v] - bs;
-				if (c > e) { e = c; ee = 1; }
-				float f = H[u * W + v - 1] - open_t; uint8_t fe = 0;
-				c = F[u * W + v - 1] - bt;
-				if (c > f) { f = c; fe = 1; }
-				float best; uint8_t d;
-				c = H[(u - 1) * W + v - 1] + Sm[(u - 1) * 16 + v - 1];
-				if (local) { best = 0.0f; d = 0; if (c > best) { best = c; d = 1; } }
-				else { best = c; d = 1; }
-				if (e > best) { best = e; d = 2; }
-				if (f > best) { best = f; d = 3; }
 				H[u * W + v] = best; E[u * W + v] = e; F[u * W + v] = f;
-				dirs[u * W + v] = d; eext[u * W + v] = ee; fext[u * W + v] = fe;
+				dirs[u * W + v] = d; dk[u * W + v] = kk; eext[u * W + v] = ee; fext[u * W + v] = fe;
 			}
+			wave_lds_fence();
 		}
 	}
+	wave_lds_fence();
+	if (lane != 0) return;
 
 	// start cell
 	int u = len_s, v = len_t;
