@@ -1,0 +1,66 @@
+"""-m gpu: relaxed Word Mover's Distance on the HIP path (through the C-ABI) against the oracle's
+restatement of the reference's BOW + RelaxedSolver code (alignment/bow.h, alignment/wmd.h)."""
+
+import numpy as np
+import pytest
+
+from vectorian_amd import synth
+
+from helpers import assert_same_results, hip_contextual_corpus, hip_static_corpus, prep_contextual, prep_query
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = {
+	"nbow": (True, True, True),        # rwmd('nbow'): injective, symmetric, normalised (vectorian/alignment.py:232-233)
+	"bow/fast": (True, False, False),  # rwmd('bow/fast') (:236-237)
+	"nbow-onesided": (True, False, True),
+	"bow-symmetric": (True, True, False),
+}
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+@pytest.mark.parametrize("shape", ["fixed32_q10", "ragged_q5", "ragged64_q16"])
+def test_contextual_rwmd(hip, oracle, variant, shape):
+	n, lo, hi, len_t, d = {"fixed32_q10": (600, 32, 32, 10, 300), "ragged_q5": (500, 1, 40, 5, 300),
+		"ragged64_q16": (300, 8, 64, 16, 768)}[shape]
+	corpus = synth.make_contextual_corpus(n, lo, hi, 2000, d)
+	Xb = prep_contextual(corpus)
+	c = hip_contextual_corpus(hip, corpus, Xb)
+	flags = VARIANTS[variant]
+	for q in synth.make_queries(corpus, 2, len_t):
+		Qb = prep_query(q)
+		ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=corpus["sent_off"], X=Xb, Q=Qb,
+			algorithm=oracle.ALG_RWMD, rwmd=flags, max_matches=15, min_score=0.0, want_all_scores=True)
+		got = c.query(Qb, algorithm=hip.VK_ALG_RWMD, rwmd=flags, q_normalize=False, max_matches=15, min_score=0.0)
+		assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=1e-5)
+		np.testing.assert_allclose(got.raw_score[:got.n], ref["raw"], atol=1e-4, rtol=0)
+		np.testing.assert_allclose(c.last_scores(), ref["all_scores"], atol=1e-5, rtol=0)
+	c.close()
+
+
+@pytest.mark.parametrize("variant", ["nbow", "bow/fast"])
+def test_static_rwmd(hip, oracle, variant):
+	# query vectors are the vocabulary's own vectors (the regime of Index.find); repeated tokens in
+	# sentences and tokens shared between query and sentence exercise the joint-vocabulary BOW builder
+	corpus = synth.make_static_corpus(700, 1, 40, 300, 300)
+	c, Eb = hip_static_corpus(hip, corpus)
+	E = synth.bf16_bits_to_f32(Eb)
+	rng = np.random.default_rng(11)
+	flags = VARIANTS[variant]
+	for _ in range(3):
+		qids = rng.integers(0, 40, size=6).astype(np.int32)      # frequent ids: overlap with sentences is common
+		Qb = Eb[qids]
+		ref = oracle.find(layout=oracle.LAYOUT_STATIC, d=300, sent_off=corpus["sent_off"], tok_id=corpus["tok_id"], E=Eb,
+			Q=Qb, q_ids=qids, algorithm=oracle.ALG_RWMD, rwmd=flags, max_matches=20, want_all_scores=True)
+		got = c.query(Qb, q_token_ids=qids, algorithm=hip.VK_ALG_RWMD, rwmd=flags, q_normalize=False, max_matches=20)
+		np.testing.assert_allclose(c.last_scores(), ref["all_scores"], atol=1e-5, rtol=0)
+		assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=1e-5, tie_tol=1e-5)
+	c.close()
+
+
+def test_non_injective_is_rejected(hip):
+	corpus = synth.make_contextual_corpus(10, 4, 8, 100, 32)
+	c = hip_contextual_corpus(hip, corpus)
+	with pytest.raises(hip.VkError):
+		c.query(np.ones((3, 32), np.float32), algorithm=hip.VK_ALG_RWMD, rwmd=(False, True, True))
+	c.close()

@@ -319,7 +319,9 @@ static int validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_t
 		if (q->gap_t.kind == VK_GAP_TABLE && q->gap_t.n_table <= q->len_t) return fail(VK_ERR_INVALID, "gap_t table shorter than the query");
 		if (q->want_flow && (!out->mapping || !out->edge_sim)) return fail(VK_ERR_INVALID, "want_flow needs mapping and edge_sim arrays");
 	} else if (q->algorithm == VK_ALG_RWMD) {
-		return fail(VK_ERR_UNSUPPORTED, "VK_ALG_RWMD is not implemented yet on the HIP path");
+		if (!q->rwmd_injective)
+			return fail(VK_ERR_UNSUPPORTED, "non-injective RWMD (rwmd('nbow/distributed')) is not implemented on the HIP path");
+		if (q->want_flow && (!out->mapping || !out->edge_sim)) return fail(VK_ERR_INVALID, "want_flow needs mapping and edge_sim arrays");
 	} else if (q->algorithm == VK_ALG_WRD) {
 		return fail(VK_ERR_UNSUPPORTED, "VK_ALG_WRD is not implemented yet on the HIP path");
 	} else {
@@ -378,7 +380,12 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	VkScoreParams p{};
 	const int ks = q->gap_s.kind, kt = q->gap_t.kind;
 	float ws[128], wt[32];
-	if (ks == VK_GAP_LINEAR && kt == VK_GAP_LINEAR) {
+	const bool is_align = q->algorithm == VK_ALG_ALIGN;
+	if (q->algorithm == VK_ALG_RWMD) {
+		p.gap_mode = 4;
+		p.rwmd_symmetric = q->rwmd_symmetric;
+		p.rwmd_normalize_bow = q->rwmd_normalize_bow;
+	} else if (ks == VK_GAP_LINEAR && kt == VK_GAP_LINEAR) {
 		p.gap_mode = 0;
 		p.gs = q->gap_s.u; p.gt = q->gap_t.u;
 	} else if ((ks == VK_GAP_LINEAR || ks == VK_GAP_AFFINE) && (kt == VK_GAP_LINEAR || kt == VK_GAP_AFFINE)) {
@@ -392,8 +399,8 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	} else {
 		p.gap_mode = 2;
 	}
-	for (int i = 0; i < 128; i++) ws[i] = gap_cost(q->gap_s, i);
-	for (int i = 0; i < 32; i++) wt[i] = gap_cost(q->gap_t, i);
+	for (int i = 0; i < 128; i++) ws[i] = is_align ? gap_cost(q->gap_s, i) : 0.0f;
+	for (int i = 0; i < 32; i++) wt[i] = is_align ? gap_cost(q->gap_t, i) : 0.0f;
 	if (p.gap_mode == 2 && c->max_len <= 32) {
 		// register-history kernel: needs w_t strictly subadditive over the query length
 		// (see dp_general_reg in vk_kernels.hip); margin far above fp32 rounding of the DP values
@@ -453,7 +460,8 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 
 	// ---- flow of the winners ------------------------------------------------
 	VK_HIP(hipEventRecord(c->ev[3], st));
-	if (q->want_flow) {
+	const bool do_flow = q->want_flow && is_align;
+	if (do_flow) {
 		VkFlowParams f{};
 		f.tiles = c->d_tiles; f.tok_id = c->d_tok_id; f.table = c->d_table; f.sent_off = c->d_sent_off;
 		f.layout = p.layout; f.nk32 = c->nk32; f.tail = c->tail; f.tile_bytes = c->tile_bytes;
@@ -470,7 +478,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	std::vector<float> raw((size_t)k), sim((size_t)k * 16);
 	std::vector<int16_t> map((size_t)k * 16);
 	VK_HIP(hipMemcpyAsync(keys.data(), c->d_keys[cur], (size_t)k * 8, hipMemcpyDeviceToHost, st));
-	if (q->want_flow) {
+	if (do_flow) {
 		VK_HIP(hipMemcpyAsync(raw.data(), c->d_out_raw, (size_t)k * 4, hipMemcpyDeviceToHost, st));
 		VK_HIP(hipMemcpyAsync(map.data(), c->d_out_map, (size_t)k * 32, hipMemcpyDeviceToHost, st));
 		VK_HIP(hipMemcpyAsync(sim.data(), c->d_out_sim, (size_t)k * 64, hipMemcpyDeviceToHost, st));
@@ -483,7 +491,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		n_out++;
 	}
 	std::vector<float> raw_sel((size_t)std::max(n_out, 1));
-	if (!q->want_flow && out->raw_score && n_out > 0) {
+	if (!do_flow && out->raw_score && n_out > 0) {
 		// gather the aligner scores of the winners
 		for (int i = 0; i < n_out; i++) {
 			const int64_t g = (int64_t)(uint32_t)(keys[(size_t)i] & 0xffffffffu);
@@ -499,11 +507,17 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		memcpy(&s, &bits, 4);
 		out->score[i] = s;
 		out->sentence[i] = (int64_t)(uint32_t)(key & 0xffffffffu);
-		if (out->raw_score) out->raw_score[i] = q->want_flow ? raw[(size_t)i] : raw_sel[(size_t)i];
-		if (q->want_flow) {
+		if (out->raw_score) out->raw_score[i] = do_flow ? raw[(size_t)i] : raw_sel[(size_t)i];
+		if (do_flow) {
 			for (int j = 0; j < q->len_t; j++) {
 				out->mapping[(size_t)i * q->len_t + j] = map[(size_t)i * 16 + j];
 				out->edge_sim[(size_t)i * q->len_t + j] = sim[(size_t)i * 16 + j];
+			}
+		} else if (q->want_flow && out->mapping && out->edge_sim) {
+			// transport flows of the winners (SparseFlow / DenseFlow) are not produced yet
+			for (int j = 0; j < q->len_t; j++) {
+				out->mapping[(size_t)i * q->len_t + j] = -1;
+				out->edge_sim[(size_t)i * q->len_t + j] = 0.0f;
 			}
 		}
 	}

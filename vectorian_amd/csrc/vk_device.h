@@ -30,7 +30,8 @@ struct VkScoreParams {
 	const uint8_t *qtile;      // query in tile order (16 rows, rows >= len_t are zero)
 	int32_t len_t;
 	int32_t locality;
-	int32_t gap_mode;          // 0 linear, 1 affine, 2 general
+	int32_t gap_mode;          // 0 linear, 1 affine, 2 general, 3 general (register history), 4 RWMD
+	int32_t rwmd_symmetric, rwmd_normalize_bow;
 	float gs, gt;              // linear: w(k) = g*k; affine: b (extension)
 	float a_s, a_t;            // affine: a
 	float open_s, open_t;      // affine: a + b

@@ -236,6 +236,7 @@ struct DpArgs {
 	float open_s, open_t;  // affine: a + b
 	const float *ws;       // general: w_s[0..max_len]
 	const float *wt;       // general: w_t[0..16]
+	int32_t rwmd_symmetric, rwmd_normalize_bow;
 };
 
 template <int LT>
@@ -427,13 +428,71 @@ __device__ __forceinline__ float dp_general_reg(const float *__restrict__ S, int
 	return (is_global) ? m : fmaxf(m, 0.0f);
 }
 
+// Relaxed Word Mover's Distance, injective form (vectorian/core/cpp/alignment/wmd.h:287-416 with
+// the BOW builders of alignment/bow.h:204-333).  For the injective solver every vocabulary entry
+// moves its whole mass to its nearest partner, so repeated tokens contribute the same distance
+// once per occurrence and the joint-vocabulary formulation reduces to positions:
+//   acc0 = sum_j w_t * min_i D[i][j]   (t -> s, wmd.h:303-306 computes this direction first)
+//   acc1 = sum_i w_s * min_j D[i][j]   (s -> t)
+// D = max(1 - S, 0) (wmd.h:107-135); nbow: w = 1/len, bow: w = 1 and acc /= len (wmd.h:379-381);
+// cost = acc0, or max(acc0, acc1) when symmetric (wmd.h:383-390); score = (max_cost - cost)/max_cost
+// with max_cost = 1 (nbow) or len_t (wmd.h:411-415).  Sums run in position order in fp32.
+template <int LT>
+__device__ __forceinline__ float rwmd_rows(const float *__restrict__ S, int rowbase, int len, int maxlen, int v, const DpArgs &a) {
+	const int len_t = a.len_t;
+	const bool nbow = a.rwmd_normalize_bow != 0;
+	const float w_t = nbow ? 1.0f / (float)len_t : 1.0f;
+	const float w_s = nbow ? 1.0f / (float)(len > 0 ? len : 1) : 1.0f;
+	const bool col_ok = v < len_t;
+	float colmin = 3.402823466e+38F;
+	float acc1 = 0.0f;
+	for (int u = 1; u <= maxlen; u++) {
+		const bool act = u <= len;
+		const float s = S[(rowbase + (act ? u - 1 : 0)) * 16 + v];
+		const float dist = fmaxf(1.0f - s, 0.0f);
+		if (act) colmin = fminf(colmin, dist);
+		// min over the query columns of this row -> lane 15
+		float m = col_ok ? dist : 3.402823466e+38F;
+		m = fminf(m, dpp_f<DPP_ROW_SHR1>(m, m));
+		m = fminf(m, dpp_f<DPP_ROW_SHR2>(m, m));
+		m = fminf(m, dpp_f<DPP_ROW_SHR4>(m, m));
+		m = fminf(m, dpp_f<DPP_ROW_SHR8>(m, m));
+		if (act) acc1 += w_s * m;
+	}
+	// acc0: sequential sum over the query columns, lane by lane
+	const float x = col_ok ? w_t * colmin : 0.0f;
+	float sum = x;
+#pragma unroll
+	for (int i = 1; i < LT; i++) {
+		const float t = dpp_f<DPP_ROW_SHR1>(0.0f, sum);
+		if (v == i) sum = t + x;
+	}
+	// lane len_t - 1 holds acc0; move it to lane 15 with a max-reduction over one valid lane
+	float acc0 = (v == len_t - 1) ? sum : VK_NEG_INF;
+	acc0 = row_max_to_lane15(acc0);
+	if (!nbow) {
+		acc0 = acc0 / (float)len_t;
+		acc1 = acc1 / (float)(len > 0 ? len : 1);
+	}
+	float cost = 0.0f;
+	if (a.rwmd_symmetric) {
+		if (acc0 > cost) cost = acc0;
+		if (acc1 > cost) cost = acc1;
+	} else {
+		cost = acc0;
+	}
+	const float max_cost = nbow ? 1.0f : (float)len_t;
+	return (max_cost - cost) / max_cost;
+}
+
 // ---------------------------------------------------------------------------
 // the fused scoring kernel: one wave = 4 sentences at a time, grid-stride over groups.
 //   MODE 0: contextual layout, NK32 K-steps (last one half filled when TAIL), query fragments in registers
 //   MODE 1: contextual layout, any d (runtime K loop)
 //   MODE 2: static layout: gather rows of the per-query table by token id
 // GAP: 0 linear, 1 affine, 2 general (LDS history, serial in-row chain),
-//      3 general, sentences <= 32 tokens, strictly subadditive w_t (register history).
+//      3 general, sentences <= 32 tokens, strictly subadditive w_t (register history),
+//      4 relaxed word mover's distance (no DP: row / column minima of 1 - S).
 // LT: padded query length (4, 8, 12, 16).
 // ---------------------------------------------------------------------------
 
@@ -453,6 +512,7 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 	a.locality = p.locality; a.len_t = p.len_t;
 	a.gs = p.gs; a.gt = p.gt; a.a_s = p.a_s; a.a_t = p.a_t; a.open_s = p.open_s; a.open_t = p.open_t;
 	a.ws = p.ws; a.wt = p.wt;
+	a.rwmd_symmetric = p.rwmd_symmetric; a.rwmd_normalize_bow = p.rwmd_normalize_bow;
 	const float inv_ref = (float)p.len_t;
 
 	// general gap, fast form: gap tables in (scalar) registers for the whole kernel
@@ -512,7 +572,8 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 		if (GAP == 0) raw = dp_linear<LT>(S, rb, lenc, maxlen, v, a);
 		else if (GAP == 1) raw = dp_affine<LT>(S, rb, lenc, maxlen, v, a);
 		else if (GAP == 2) raw = dp_general<LT>(S, Hh, p.h_rows, rb, lenc, maxlen, lane, a);
-		else raw = dp_general_reg<LT, 32>(S, rb, lenc, maxlen, v, a, wsr, wtr);
+		else if (GAP == 3) raw = dp_general_reg<LT, 32>(S, rb, lenc, maxlen, v, a, wsr, wtr);
+		else raw = rwmd_rows<LT>(S, rb, lenc, maxlen, v, a);
 
 		if (v == 15 && s_idx < p.n_sent) {
 			// Score::value = raw / reference_score * boost; reference_score == len_t for
@@ -821,6 +882,7 @@ static hipError_t launch_score_gap(const VkScoreParams &p, int grid, size_t smem
 	case 0: return launch_score_lt<MODE, NK32, TAIL, 0>(p, grid, smem, stream);
 	case 1: return launch_score_lt<MODE, NK32, TAIL, 1>(p, grid, smem, stream);
 	case 3: return launch_score_lt<MODE, NK32, TAIL, 3>(p, grid, smem, stream);
+	case 4: return launch_score_lt<MODE, NK32, TAIL, 4>(p, grid, smem, stream);
 	default: return launch_score_lt<MODE, NK32, TAIL, 2>(p, grid, smem, stream);
 	}
 }
