@@ -1,0 +1,44 @@
+"""-m gpu: Word Rotator's Distance on the HIP path: bound pass + exact EMD of the survivors must
+return exactly the result set of the oracle, which solves every sentence exactly."""
+
+import numpy as np
+import pytest
+
+from vectorian_amd import synth
+
+from helpers import assert_same_results
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", ["q10_len32", "q5_ragged", "q16_ragged64"])
+def test_contextual_wrd(hip, oracle, shape):
+	n, lo, hi, len_t, d = {"q10_len32": (1500, 32, 32, 10, 128), "q5_ragged": (1200, 1, 40, 5, 96),
+		"q16_ragged64": (600, 8, 64, 16, 768)}[shape]
+	corpus = synth.make_contextual_corpus(n, lo, hi, 2000, d, noise=0.3, norm_sigma=0.25)
+	X = corpus["X"]
+	Xb, mag = oracle.normalize_rows_bf16(X)
+	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=d, n_tokens=X.shape[0], n_sentences=n, keep_magnitudes=True)
+	c.append_vectors(X, normalize=True)
+	c.set_sentences(corpus["sent_off"])
+	c.finalize()
+	rng = np.random.default_rng(2)
+	for q in synth.make_queries(corpus, 2, len_t):
+		qv = (q["vectors"] * rng.lognormal(0, 0.25, size=(len_t, 1))).astype(np.float32)
+		Qb, qmag = oracle.normalize_rows_bf16(qv)
+		ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=corpus["sent_off"], X=Xb, X_mag=mag, Q=Qb, Q_mag=qmag,
+			algorithm=oracle.ALG_WRD, max_matches=10, min_score=0.0, n_threads=8)
+		got = c.query(qv, algorithm=hip.VK_ALG_WRD, q_normalize=True, max_matches=10, min_score=0.0)
+		assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=1e-5)
+	c.close()
+
+
+def test_wrd_needs_magnitudes(hip):
+	corpus = synth.make_contextual_corpus(10, 4, 8, 100, 32)
+	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=32, n_tokens=corpus["X"].shape[0], n_sentences=10)
+	c.append_vectors(corpus["X"], normalize=True)
+	c.set_sentences(corpus["sent_off"])
+	c.finalize()
+	with pytest.raises(hip.VkError):
+		c.query(np.ones((3, 32), np.float32), algorithm=hip.VK_ALG_WRD)
+	c.close()

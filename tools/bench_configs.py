@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Timing of the other BASELINE.json configurations / algorithms on one MI355X (not the
+driver's bench: that is bench.py).  Prints one JSON line per run.
+
+  python tools/bench_configs.py --alg rwmd --sentences 1000000
+  python tools/bench_configs.py --alg wrd --d 768 --min-len 8 --max-len 64 --sentences 500000
+  python tools/bench_configs.py --alg align --gap exp5 --locality global --d 768 --min-len 8 --max-len 64
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+	ap = argparse.ArgumentParser()
+	ap.add_argument("--alg", choices=["align", "rwmd", "wrd"], default="align")
+	ap.add_argument("--gap", choices=["exp5", "linear", "affine"], default="exp5")
+	ap.add_argument("--locality", choices=["local", "global", "semiglobal"], default="local")
+	ap.add_argument("--d", type=int, default=300)
+	ap.add_argument("--len-t", type=int, default=10)
+	ap.add_argument("--min-len", type=int, default=32)
+	ap.add_argument("--max-len", type=int, default=32)
+	ap.add_argument("--sentences", type=int, default=1000000)
+	ap.add_argument("--steps", type=int, default=10)
+	ap.add_argument("--warmup", type=int, default=2)
+	ap.add_argument("--k", type=int, default=10)
+	args = ap.parse_args()
+
+	import torch
+	from vectorian_amd import core, synth
+	core.init(0)
+	device = torch.device("cuda", 0)
+	V = 50000
+	E = synth.make_vocab(V, args.d)
+	rng = np.random.default_rng(1)
+	lens = rng.integers(args.min_len, args.max_len + 1, size=args.sentences) if args.max_len > args.min_len else np.full(args.sentences, args.min_len)
+	off = np.zeros(args.sentences + 1, dtype=np.int64)
+	np.cumsum(lens, out=off[1:])
+	n_tok = int(off[-1])
+	ids = synth.zipf_ids(n_tok, V, rng)
+	corpus = core.Corpus(layout=core.VK_LAYOUT_CONTEXTUAL, d=args.d, n_tokens=n_tok, n_sentences=args.sentences,
+		keep_magnitudes=args.alg == "wrd")
+	E_dev = torch.from_numpy(E).to(device)
+	gen = torch.Generator(device=device)
+	gen.manual_seed(7)
+	chunk = 1 << 19
+	for a in range(0, n_tok, chunk):
+		b = min(a + chunk, n_tok)
+		idx = torch.from_numpy(ids[a:b].astype(np.int64)).to(device)
+		x = E_dev[idx] + 0.3 * torch.randn((b - a, args.d), device=device, generator=gen)
+		if args.alg == "wrd":
+			x = x * torch.exp(0.25 * torch.randn((b - a, 1), device=device, generator=gen))
+		x = x.contiguous()
+		torch.cuda.synchronize()
+		corpus.append_vectors_device(x.data_ptr(), b - a, core.VK_F32, normalize=True)
+		del x, idx
+	corpus.set_sentences(off)
+	corpus.finalize()
+
+	w = (1 - 2.0 ** (-np.arange(0, 65) / 5)).astype(np.float32)
+	gap = {"exp5": ("table", w), "linear": 0.1, "affine": ("affine", 0.2, 0.05)}[args.gap]
+	loc = {"local": 0, "global": 1, "semiglobal": 2}[args.locality]
+	alg = {"align": core.VK_ALG_ALIGN, "rwmd": core.VK_ALG_RWMD, "wrd": core.VK_ALG_WRD}[args.alg]
+	qs = []
+	for i in range(args.steps + args.warmup):
+		if i % 2 == 0:
+			s = int(rng.integers(0, args.sentences))
+			st = int(off[s])
+			qi = ids[st:st + args.len_t]
+			if len(qi) < args.len_t:
+				qi = np.concatenate([qi, rng.integers(0, V, size=args.len_t - len(qi))])
+		else:
+			qi = rng.integers(0, V, size=args.len_t)
+		qs.append(np.ascontiguousarray(E[qi] + 0.05 * rng.standard_normal((args.len_t, args.d)).astype(np.float32), dtype=np.float32))
+
+	def step(q):
+		return corpus.query(q, algorithm=alg, locality=loc, gap_s=gap, gap_t=gap, q_normalize=True, max_matches=args.k,
+			min_score=0.0 if loc != 1 else -1e9, want_flow=args.alg == "align")
+
+	for i in range(args.warmup):
+		step(qs[i])
+	torch.cuda.synchronize()
+	phases = []
+	t0 = time.perf_counter()
+	for i in range(args.steps):
+		top = step(qs[args.warmup + i])
+		phases.append(corpus.last_timings())
+	el = time.perf_counter() - t0
+	score_ms = float(np.mean([p["score_ms"] for p in phases]))
+	bytes_alg = n_tok * args.d * 2
+	print(json.dumps({
+		"alg": args.alg, "gap": args.gap, "locality": args.locality, "d": args.d, "len_t": args.len_t,
+		"len_s": [args.min_len, args.max_len], "sentences": args.sentences, "tokens": n_tok,
+		"pairs_per_s": args.sentences * args.steps / el, "ms_per_query": el / args.steps * 1e3,
+		"score_kernel_ms": score_ms, "score_kernel_GBps": bytes_alg / (score_ms * 1e-3) / 1e9,
+		"hbm_frac_of_8TBps": bytes_alg / (score_ms * 1e-3) / 8e12,
+		"phases_ms_mean": {k: float(np.mean([p[k] for p in phases])) for k in phases[0]},
+		"top_score": float(top.score[0]) if top.n else None}))
+	corpus.close()
+
+
+if __name__ == "__main__":
+	main()

@@ -84,6 +84,7 @@ struct vk_corpus {
 	float *d_scores = nullptr, *d_raw = nullptr, *d_boost = nullptr;
 	uint64_t *d_keys[2] = {nullptr, nullptr};
 	float *d_out_raw = nullptr, *d_out_sim = nullptr;
+	float *d_wrd_raw = nullptr, *d_wrd_val = nullptr;
 	int16_t *d_out_map = nullptr;
 	hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 	vk_timings last{};
@@ -186,7 +187,7 @@ int vk_corpus_free(vk_corpus_t *c) {
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	void *ptrs[] = {c->d_tiles, c->d_mag, c->d_tok_id, c->d_sent_off, c->d_stage, c->d_qtile, c->d_ws, c->d_wt, c->d_qids,
-		c->d_table, c->d_scores, c->d_raw, c->d_boost, c->d_keys[0], c->d_keys[1], c->d_out_raw, c->d_out_sim, c->d_out_map};
+		c->d_table, c->d_scores, c->d_raw, c->d_boost, c->d_keys[0], c->d_keys[1], c->d_out_raw, c->d_out_sim, c->d_out_map, c->d_wrd_raw, c->d_wrd_val};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -323,7 +324,12 @@ static int validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_t
 			return fail(VK_ERR_UNSUPPORTED, "non-injective RWMD (rwmd('nbow/distributed')) is not implemented on the HIP path");
 		if (q->want_flow && (!out->mapping || !out->edge_sim)) return fail(VK_ERR_INVALID, "want_flow needs mapping and edge_sim arrays");
 	} else if (q->algorithm == VK_ALG_WRD) {
-		return fail(VK_ERR_UNSUPPORTED, "VK_ALG_WRD is not implemented yet on the HIP path");
+		if (c->desc.layout != VK_LAYOUT_CONTEXTUAL)
+			return fail(VK_ERR_UNSUPPORTED, "VK_ALG_WRD is implemented for the contextual layout only");
+		if (!c->d_mag) return fail(VK_ERR_STATE, "VK_ALG_WRD needs a corpus created with keep_magnitudes = 1");
+		if (!q->wrd_normalize_magnitudes)
+			return fail(VK_ERR_UNSUPPORTED, "WordRotatorsDistance(normalize_magnitudes=False) is not implemented on the HIP path");
+		if (q->want_flow && (!out->mapping || !out->edge_sim)) return fail(VK_ERR_INVALID, "want_flow needs mapping and edge_sim arrays");
 	} else {
 		return fail(VK_ERR_INVALID, "bad algorithm");
 	}
@@ -332,7 +338,7 @@ static int validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_t
 
 // Vectors.normalized for the query rows, then bf16 (RNE), then tile order (16 rows,
 // rows >= len_t zero).  Same arithmetic as oracle/vk_oracle.c vko_normalize_rows_bf16.
-static void pack_query(const vk_corpus *c, const vk_query_desc *q, std::vector<uint8_t> &tile) {
+static void pack_query(const vk_corpus *c, const vk_query_desc *q, std::vector<uint8_t> &tile, float *mags) {
 	const int d = c->desc.d;
 	tile.assign((size_t)c->tile_bytes, 0);
 	std::vector<float> row((size_t)d);
@@ -340,11 +346,12 @@ static void pack_query(const vk_corpus *c, const vk_query_desc *q, std::vector<u
 		for (int k = 0; k < d; k++)
 			row[(size_t)k] = q->q_dtype == VK_F32 ? ((const float *)q->q_vectors)[(size_t)i * d + k]
 			                                       : bf16_to_f32(((const uint16_t *)q->q_vectors)[(size_t)i * d + k]);
+		double acc = 0.0;
+		for (int k = 0; k < d; k++) acc += (double)row[(size_t)k] * (double)row[(size_t)k];
+		float m = (float)std::sqrt(acc);
+		if (m != m) m = 0.0f;
+		mags[i] = m;
 		if (q->q_normalize) {
-			double acc = 0.0;
-			for (int k = 0; k < d; k++) acc += (double)row[(size_t)k] * (double)row[(size_t)k];
-			float m = (float)std::sqrt(acc);
-			if (m != m) m = 0.0f;
 			for (int k = 0; k < d; k++) {
 				float v = row[(size_t)k] / m;
 				if (v != v) v = 0.0f;
@@ -374,14 +381,21 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	// ---- prepare: query tile, gap tables, boost, static table -------------
 	VK_HIP(hipEventRecord(c->ev[0], st));
 	std::vector<uint8_t> qtile;
-	pack_query(c, q, qtile);
+	float qmags[VK_MAX_QUERY_LEN] = {0};
+	pack_query(c, q, qtile, qmags);
 	VK_HIP(hipMemcpyAsync(c->d_qtile, qtile.data(), qtile.size(), hipMemcpyHostToDevice, st));
 
 	VkScoreParams p{};
 	const int ks = q->gap_s.kind, kt = q->gap_t.kind;
 	float ws[128], wt[32];
 	const bool is_align = q->algorithm == VK_ALG_ALIGN;
-	if (q->algorithm == VK_ALG_RWMD) {
+	if (q->algorithm == VK_ALG_WRD) {
+		p.gap_mode = 5;
+		float sum_t = 0.0f;
+		for (int j = 0; j < q->len_t; j++) sum_t += qmags[j];           // wrd.h:99-102, float sum in order
+		for (int j = 0; j < VK_MAX_QUERY_LEN; j++) p.qmass[j] = j < q->len_t ? qmags[j] / sum_t : 0.0f;
+		p.mag = c->d_mag;
+	} else if (q->algorithm == VK_ALG_RWMD) {
 		p.gap_mode = 4;
 		p.rwmd_symmetric = q->rwmd_symmetric;
 		p.rwmd_normalize_bow = q->rwmd_normalize_bow;
@@ -447,6 +461,81 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	const int blocks_per_cu = std::max(1, std::min(8, (int)((160 * 1024) / std::max<size_t>(smem, 1))));
 	const int grid = (int)std::min<int64_t>((n_groups + 3) / 4, (int64_t)256 * blocks_per_cu);
 	VK_HIP(vk_launch_score(&p, grid, smem, st));
+
+	if (q->algorithm == VK_ALG_WRD) {
+		// ---- stage 2: exact EMD on the candidates with the largest bounds, until the k-th best
+		// exact score is above every remaining bound (then no unsolved sentence can enter)
+		VK_HIP(hipEventRecord(c->ev[2], st));
+		const int M = 512;
+		if (!c->d_wrd_raw) {
+			rc = alloc_t(c, &c->d_wrd_raw, (size_t)VK_MAX_MATCHES); if (rc) return rc;
+			rc = alloc_t(c, &c->d_wrd_val, (size_t)VK_MAX_MATCHES); if (rc) return rc;
+		}
+		struct Cand { float val, raw; int64_t g; };
+		std::vector<Cand> best;
+		std::vector<uint64_t> keys((size_t)M);
+		std::vector<float> vals((size_t)M), raws((size_t)M);
+		for (;;) {
+			int nb = 0, cur = 0;
+			VK_HIP(vk_launch_topk_scores(c->d_scores, n, q->min_score, M, c->d_keys[0], &nb, st));
+			while (nb > 1) {
+				const int64_t nkeys = (int64_t)nb * M;
+				VK_HIP(vk_launch_topk_keys(c->d_keys[cur], nkeys, M, c->d_keys[1 - cur], &nb, st));
+				cur = 1 - cur;
+			}
+			VkWrdParams w{};
+			w.tiles = c->d_tiles; w.tok_id = c->d_tok_id; w.table = c->d_table; w.sent_off = c->d_sent_off;
+			w.layout = p.layout; w.nk32 = c->nk32; w.tail = c->tail; w.tile_bytes = c->tile_bytes;
+			w.qtile = c->d_qtile; w.len_t = q->len_t; w.mag = c->d_mag;
+			memcpy(w.qmass, p.qmass, sizeof w.qmass);
+			w.boost = p.boost; w.keys = c->d_keys[cur]; w.raw_out = c->d_wrd_raw; w.val_out = c->d_wrd_val;
+			VK_HIP(vk_launch_wrd_exact(&w, M, c->d_scores, st));
+			VK_HIP(hipMemcpyAsync(keys.data(), c->d_keys[cur], (size_t)M * 8, hipMemcpyDeviceToHost, st));
+			VK_HIP(hipMemcpyAsync(vals.data(), c->d_wrd_val, (size_t)M * 4, hipMemcpyDeviceToHost, st));
+			VK_HIP(hipMemcpyAsync(raws.data(), c->d_wrd_raw, (size_t)M * 4, hipMemcpyDeviceToHost, st));
+			VK_HIP(hipStreamSynchronize(st));
+			int n_cand = 0;
+			float ub_last = INFINITY;
+			for (int i = 0; i < M; i++) {
+				if (keys[(size_t)i] == 0) break;
+				n_cand++;
+				const uint32_t ob = (uint32_t)(keys[(size_t)i] >> 32);
+				const uint32_t bits = (ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob;
+				memcpy(&ub_last, &bits, 4);
+				if (vals[(size_t)i] > q->min_score)
+					best.push_back({vals[(size_t)i], raws[(size_t)i], (int64_t)(uint32_t)(keys[(size_t)i] & 0xffffffffu)});
+			}
+			std::sort(best.begin(), best.end(), [](const Cand &a, const Cand &b) {
+				if (a.val != b.val) return a.val > b.val;
+				return a.g > b.g;
+			});
+			if ((int)best.size() > k) best.resize((size_t)k);
+			if (n_cand < M) break;                                          // pool exhausted
+			if ((int)best.size() == k && best.back().val > ub_last) break;  // nothing left can enter
+		}
+		VK_HIP(hipEventRecord(c->ev[3], st));
+		VK_HIP(hipEventRecord(c->ev[4], st));
+		VK_HIP(hipStreamSynchronize(st));
+		for (size_t i = 0; i < best.size(); i++) {
+			out->score[i] = best[i].val;
+			out->sentence[i] = best[i].g;
+			if (out->raw_score) out->raw_score[i] = best[i].raw;
+			if (q->want_flow && out->mapping && out->edge_sim)
+				for (int j = 0; j < q->len_t; j++) {
+					out->mapping[i * (size_t)q->len_t + j] = -1;
+					out->edge_sim[i * (size_t)q->len_t + j] = 0.0f;
+				}
+		}
+		out->n_out = (int)best.size();
+		float ms = 0;
+		vk_timings t{};
+		if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) t.prepare_ms = ms;
+		if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) t.score_ms = ms;
+		if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) t.topk_ms = ms;
+		if (hipEventElapsedTime(&ms, c->ev[0], c->ev[4]) == hipSuccess) t.total_ms = ms;
+		c->last = t;
+		return VK_OK;
+	}
 
 	// ---- bounded result set -------------------------------------------------
 	VK_HIP(hipEventRecord(c->ev[2], st));

@@ -38,6 +38,8 @@ struct VkScoreParams {
 	const float *ws;           // general: [max_len + 1]
 	const float *wt;           // general: [17]
 	const float *boost;        // [n_sent] or null
+	const float *mag;          // WRD: token magnitudes (contextual) / vocabulary magnitudes (static)
+	float qmass[VK_DEV_MAX_QUERY_LEN];   // WRD: query masses |q_j| / sum |q|
 	// outputs
 	float *scores;             // Score::value per sentence (-inf: empty slice)
 	float *raw;                // aligner score per sentence
@@ -45,6 +47,23 @@ struct VkScoreParams {
 	int32_t lds_floats_per_wave;
 	int32_t s_rows_per_wave;   // rows of the similarity staging area
 	int32_t h_rows;            // general gap: history rows per sentence (max_len + 1)
+};
+
+struct VkWrdParams {
+	const uint8_t *tiles;
+	const int32_t *tok_id;
+	const float *table;
+	const int32_t *sent_off;
+	int32_t layout;
+	int32_t nk32, tail, tile_bytes;
+	const uint8_t *qtile;
+	int32_t len_t;
+	const float *mag;
+	float qmass[VK_DEV_MAX_QUERY_LEN];
+	const float *boost;
+	const uint64_t *keys;      // candidates (0 = empty slot)
+	float *raw_out;            // [n_cand]
+	float *val_out;            // [n_cand]
 };
 
 struct VkFlowParams {
@@ -80,6 +99,7 @@ hipError_t vk_launch_topk_scores(const float *scores, int64_t n, float min_score
 hipError_t vk_launch_topk_keys(const uint64_t *in, int64_t n, int32_t k, uint64_t *out, int32_t *n_blocks_out,
 	hipStream_t stream);
 hipError_t vk_launch_flow(const VkFlowParams *p, int32_t k, hipStream_t stream);
+hipError_t vk_launch_wrd_exact(const VkWrdParams *p, int32_t n_cand, float *scores_to_mark, hipStream_t stream);
 #ifdef __cplusplus
 }
 #endif

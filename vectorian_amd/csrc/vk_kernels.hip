@@ -485,6 +485,42 @@ __device__ __forceinline__ float rwmd_rows(const float *__restrict__ S, int rowb
 	return (max_cost - cost) / max_cost;
 }
 
+// Word Rotator's Distance, stage 1: an upper bound of the score for every sentence.
+// WRD = 1 - EMD of the transport problem with masses |x| / sum|x| and costs max(0, 1 - S)
+// (vectorian/core/cpp/alignment/wrd.h:62-146).  Every unit of mass travels at least to its nearest
+// partner, so both  sum_j m_t[j] min_i C[j][i]  and  sum_i m_s[i] min_j C[j][i]  bound the EMD from
+// below; the larger of the two (minus a margin for fp32 rounding) gives score <= 1 - LB.
+// Stage 2 (vk_wrd_exact_kernel) solves the survivors exactly.
+template <int LT>
+__device__ __forceinline__ float wrd_bound_rows(const float *__restrict__ S, int rowbase, int len, int maxlen, int v,
+	const DpArgs &a, const float *__restrict__ mag, float q_mass) {
+	const int len_t = a.len_t;
+	const bool col_ok = v < len_t;
+	float sum_s = 0.0f;
+	for (int u = 1; u <= maxlen; u++) if (u <= len) sum_s += mag[u - 1];
+	float colmin = 3.402823466e+38F;
+	float lb1 = 0.0f;
+	for (int u = 1; u <= maxlen; u++) {
+		const bool act = u <= len;
+		const float s = S[(rowbase + (act ? u - 1 : 0)) * 16 + v];
+		const float dist = fmaxf(1.0f - s, 0.0f);
+		if (act) colmin = fminf(colmin, dist);
+		float m = col_ok ? dist : 3.402823466e+38F;
+		m = fminf(m, dpp_f<DPP_ROW_SHR1>(m, m));
+		m = fminf(m, dpp_f<DPP_ROW_SHR2>(m, m));
+		m = fminf(m, dpp_f<DPP_ROW_SHR4>(m, m));
+		m = fminf(m, dpp_f<DPP_ROW_SHR8>(m, m));
+		if (act) lb1 += (mag[u - 1] / sum_s) * m;
+	}
+	float x = col_ok ? q_mass * colmin : 0.0f;      // sum over lanes, any order: it is only a bound
+	x += dpp_f<DPP_ROW_SHR1>(0.0f, x);
+	x += dpp_f<DPP_ROW_SHR2>(0.0f, x);
+	x += dpp_f<DPP_ROW_SHR4>(0.0f, x);
+	x += dpp_f<DPP_ROW_SHR8>(0.0f, x);
+	const float lb = fmaxf(x, lb1);
+	return fminf(1.0f - lb + 3e-5f, 1.0f);
+}
+
 // ---------------------------------------------------------------------------
 // the fused scoring kernel: one wave = 4 sentences at a time, grid-stride over groups.
 //   MODE 0: contextual layout, NK32 K-steps (last one half filled when TAIL), query fragments in registers
@@ -492,7 +528,8 @@ __device__ __forceinline__ float rwmd_rows(const float *__restrict__ S, int rowb
 //   MODE 2: static layout: gather rows of the per-query table by token id
 // GAP: 0 linear, 1 affine, 2 general (LDS history, serial in-row chain),
 //      3 general, sentences <= 32 tokens, strictly subadditive w_t (register history),
-//      4 relaxed word mover's distance (no DP: row / column minima of 1 - S).
+//      4 relaxed word mover's distance (no DP: row / column minima of 1 - S),
+//      5 word rotator's distance, upper bound of the score (stage 1).
 // LT: padded query length (4, 8, 12, 16).
 // ---------------------------------------------------------------------------
 
@@ -573,7 +610,8 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 		else if (GAP == 1) raw = dp_affine<LT>(S, rb, lenc, maxlen, v, a);
 		else if (GAP == 2) raw = dp_general<LT>(S, Hh, p.h_rows, rb, lenc, maxlen, lane, a);
 		else if (GAP == 3) raw = dp_general_reg<LT, 32>(S, rb, lenc, maxlen, v, a, wsr, wtr);
-		else raw = rwmd_rows<LT>(S, rb, lenc, maxlen, v, a);
+		else if (GAP == 4) raw = rwmd_rows<LT>(S, rb, lenc, maxlen, v, a);
+		else raw = wrd_bound_rows<LT>(S, rb, lenc, maxlen, v, a, p.mag + (len > 0 ? t_a : 0), p.qmass[v]);
 
 		if (v == 15 && s_idx < p.n_sent) {
 			// Score::value = raw / reference_score * boost; reference_score == len_t for
@@ -841,6 +879,171 @@ __global__ __launch_bounds__(64) void vk_flow_kernel(VkFlowParams p) {
 }
 
 // ---------------------------------------------------------------------------
+// Word Rotator's Distance, stage 2: exact EMD for the candidate sentences.
+// One wave per candidate recomputes the similarity rows (same MFMA sequence as the scoring
+// kernel); lane 0 then runs successive shortest paths with potentials on the bipartite
+// transportation problem in double precision -- statement for statement the oracle's vko_emd /
+// vko_wrd (oracle/vk_oracle.c), which stand in for pyemd's emd_hat_gd_metric<double>
+// (vectorian/core/cpp/alignment/transport.h:70,125-126).
+// ---------------------------------------------------------------------------
+
+// Exact EMD of a small transportation problem by successive shortest paths with potentials
+// (dense Dijkstra on reduced costs), double precision, one lane.  sup[n] / dem[m] hold the masses on
+// entry and the unshipped remainders on exit; fl[n x m] receives the flow.  Statement for statement
+// the oracle's vko_emd (oracle/vk_oracle.c).  Kept out of line: inlined into vk_wrd_exact_kernel,
+// ROCm 7.2 hipcc produced a loop that dropped the `target = x` exit (results were wrong while this
+// very function, compiled alone, matches the host bit for bit: tools/probe/ssp_probe.hip).
+__device__ __attribute__((noinline)) void vk_emd_ssp(int n, int m, const double *C, double *fl, double *sup, double *dem,
+	double *pot, double *dist, int *prevn, uint8_t *done) {
+	const int N = n + m;
+	const double EPS = 1e-13;
+	for (int i = 0; i < n * m; i++) fl[i] = 0.0;
+	for (int i = 0; i < N; i++) pot[i] = 0.0;
+	for (int iter = 0; iter < 100000; iter++) {
+		int any = 0;
+		for (int i = 0; i < N; i++) { dist[i] = __builtin_inf(); prevn[i] = -1; done[i] = 0; }
+		for (int i = 0; i < n; i++) if (sup[i] > EPS) { dist[i] = 0.0; any = 1; }
+		if (!any) break;
+		int any_dem = 0;
+		for (int j = 0; j < m; j++) if (dem[j] > EPS) any_dem = 1;
+		if (!any_dem) break;
+
+		int target = -1;
+		bool searching = true;
+		while (searching) {
+			int x = -1;
+			double bd = __builtin_inf();
+			for (int i = 0; i < N; i++) if (!done[i] && dist[i] < bd) { bd = dist[i]; x = i; }
+			if (x < 0) {
+				searching = false;
+			} else {
+				done[x] = 1;
+				if (x >= n && dem[x - n] > EPS) {
+					target = x;
+					searching = false;
+				} else if (x < n) {
+					for (int j = 0; j < m; j++) {
+						if (done[n + j]) continue;
+						double rc = C[x * m + j] + pot[x] - pot[n + j];
+						if (rc < 0) rc = 0;
+						if (dist[x] + rc < dist[n + j]) { dist[n + j] = dist[x] + rc; prevn[n + j] = x; }
+					}
+				} else {
+					const int j = x - n;
+					for (int i = 0; i < n; i++) {
+						if (done[i] || !(fl[i * m + j] > EPS)) continue;
+						double rc = -C[i * m + j] + pot[x] - pot[i];
+						if (rc < 0) rc = 0;
+						if (dist[x] + rc < dist[i]) { dist[i] = dist[x] + rc; prevn[i] = x; }
+					}
+				}
+			}
+		}
+		if (target < 0) break;
+		const double dt = dist[target];
+		for (int i = 0; i < N; i++) pot[i] += (done[i] && dist[i] < dt) ? dist[i] : dt;
+
+		double delta = dem[target - n];
+		int x = target;
+		while (prevn[x] >= 0) {
+			const int pr = prevn[x];
+			if (pr >= n) {
+				const double cap = fl[x * m + (pr - n)];
+				if (cap < delta) delta = cap;
+			}
+			x = pr;
+		}
+		if (sup[x] < delta) delta = sup[x];
+		sup[x] -= delta;
+		dem[target - n] -= delta;
+		x = target;
+		while (prevn[x] >= 0) {
+			const int pr = prevn[x];
+			if (pr < n) fl[pr * m + (x - n)] += delta;
+			else fl[x * m + (pr - n)] -= delta;
+			x = pr;
+		}
+	}
+}
+
+#define VK_WRD_N VK_DEV_MAX_QUERY_LEN
+#define VK_WRD_M VK_DEV_MAX_SENT_LEN
+
+__global__ __launch_bounds__(64) void vk_wrd_exact_kernel(VkWrdParams p) {
+	__shared__ __attribute__((aligned(16))) float S[(VK_DEV_MAX_SENT_LEN + 32) * 16];
+	__shared__ double Cm[VK_WRD_N * VK_WRD_M];
+	__shared__ double fl[VK_WRD_N * VK_WRD_M];
+	__shared__ double sup[VK_WRD_N], dem[VK_WRD_M], pot[VK_WRD_N + VK_WRD_M], dist[VK_WRD_N + VK_WRD_M];
+	__shared__ int prevn[VK_WRD_N + VK_WRD_M];
+	__shared__ uint8_t done[VK_WRD_N + VK_WRD_M];
+
+	const int lane = threadIdx.x;
+	const int w = blockIdx.x;
+	const uint64_t key = p.keys[w];
+	if (key == 0) return;
+	const int64_t g = (int64_t)(uint32_t)(key & 0xffffffffu);
+	const int t_a = p.sent_off[g], t_b = p.sent_off[g + 1];
+	const int m = t_b - t_a, n = p.len_t;
+
+	int rowbase;
+	if (p.layout == VK_DEV_LAYOUT_STATIC) {
+		for (int it = 0; it * 16 < m; it++) {
+			const int tk = it * 16 + (lane >> 2);
+			if (tk < m) {
+				const int id = p.tok_id[t_a + tk];
+				*reinterpret_cast<float4 *>(S + tk * 16 + (lane & 3) * 4) =
+					*reinterpret_cast<const float4 *>(p.table + (int64_t)id * 16 + (lane & 3) * 4);
+			}
+		}
+		rowbase = 0;
+	} else {
+		const int tile0 = t_a >> 4;
+		const int ntiles = ((t_b + 15) >> 4) - tile0;
+		for (int ti = 0; ti < ntiles; ti++) {
+			const f32x4 acc = sim_tile_generic(p.qtile, p.tiles + (int64_t)(tile0 + ti) * p.tile_bytes, p.nk32, p.tail, lane);
+			*reinterpret_cast<f32x4 *>(S + (ti * 16 + (lane & 15)) * 16 + (lane >> 4) * 4) = acc;
+		}
+		rowbase = t_a - tile0 * 16;
+	}
+	__syncthreads();
+	if (lane != 0) return;
+	const float *Sm = S + rowbase * 16;
+
+	// masses (wrd.h:99-102) and costs (:104-109)
+	float sum_s = 0.0f;
+	for (int i = 0; i < m; i++) sum_s += p.layout == VK_DEV_LAYOUT_STATIC ? p.mag[p.tok_id[t_a + i]] : p.mag[t_a + i];
+	for (int j = 0; j < n; j++) sup[j] = (double)p.qmass[j];
+	for (int i = 0; i < m; i++) {
+		const float mg = p.layout == VK_DEV_LAYOUT_STATIC ? p.mag[p.tok_id[t_a + i]] : p.mag[t_a + i];
+		dem[i] = (double)(mg / sum_s);
+	}
+	for (int j = 0; j < n; j++)
+		for (int i = 0; i < m; i++) {
+			float d = 1.0f - Sm[i * 16 + j];
+			if (!(d > 0.0f)) d = 0.0f;
+			Cm[j * m + i] = (double)d;
+		}
+	vk_emd_ssp(n, m, Cm, fl, sup, dem, pot, dist, prevn, done);
+	// score = sum((1 - D) * G) / sum(G) (wrd.h:139), G as float
+	double num = 0.0, den = 0.0;
+	for (int i = 0; i < n * m; i++) {
+		const float gq = (float)fl[i];
+		num += (double)((1.0f - (float)Cm[i]) * gq);
+		den += (double)gq;
+	}
+	const float raw = den > 0.0 ? (float)(num / den) : 0.0f;
+	const float boost = p.boost ? p.boost[g] : 1.0f;
+	p.raw_out[w] = raw;
+	p.val_out[w] = (raw / (float)n) * boost;
+}
+
+// processed candidates leave the pool: their bound becomes -inf
+__global__ void vk_mark_kernel(const uint64_t *__restrict__ keys, int32_t n, float *__restrict__ scores) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n && keys[i] != 0) scores[(uint32_t)(keys[i] & 0xffffffffu)] = VK_NEG_INF;
+}
+
+// ---------------------------------------------------------------------------
 // host-callable launchers (used by vk_api.cpp; keep all <<< >>> in this file)
 // ---------------------------------------------------------------------------
 
@@ -883,6 +1086,7 @@ static hipError_t launch_score_gap(const VkScoreParams &p, int grid, size_t smem
 	case 1: return launch_score_lt<MODE, NK32, TAIL, 1>(p, grid, smem, stream);
 	case 3: return launch_score_lt<MODE, NK32, TAIL, 3>(p, grid, smem, stream);
 	case 4: return launch_score_lt<MODE, NK32, TAIL, 4>(p, grid, smem, stream);
+	case 5: return launch_score_lt<MODE, NK32, TAIL, 5>(p, grid, smem, stream);
 	default: return launch_score_lt<MODE, NK32, TAIL, 2>(p, grid, smem, stream);
 	}
 }
@@ -907,6 +1111,12 @@ extern "C" hipError_t vk_launch_topk_keys(const uint64_t *in, int64_t n, int32_t
 	const int nb = (int)((n + VK_TOPK_CHUNK - 1) / VK_TOPK_CHUNK);
 	vk_topk_keys_kernel<<<nb, 256, 0, stream>>>(in, n, k, out);
 	*n_blocks_out = nb;
+	return hipGetLastError();
+}
+
+extern "C" hipError_t vk_launch_wrd_exact(const VkWrdParams *p, int32_t n_cand, float *scores_to_mark, hipStream_t stream) {
+	vk_wrd_exact_kernel<<<n_cand, 64, 0, stream>>>(*p);
+	if (scores_to_mark) vk_mark_kernel<<<(n_cand + 255) / 256, 256, 0, stream>>>(p->keys, n_cand, scores_to_mark);
 	return hipGetLastError();
 }
 
