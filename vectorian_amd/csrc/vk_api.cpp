@@ -415,14 +415,14 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	}
 	for (int i = 0; i < 128; i++) ws[i] = is_align ? gap_cost(q->gap_s, i) : 0.0f;
 	for (int i = 0; i < 32; i++) wt[i] = is_align ? gap_cost(q->gap_t, i) : 0.0f;
-	if (p.gap_mode == 2 && c->max_len <= 32) {
+	if (p.gap_mode == 2) {
 		// register-history kernel: needs w_t strictly subadditive over the query length
 		// (see dp_general_reg in vk_kernels.hip); margin far above fp32 rounding of the DP values
 		bool sub = true;
 		for (int x = 1; x < q->len_t && sub; x++)
 			for (int y = 1; x + y <= q->len_t; y++)
 				if (!(wt[x] + wt[y] > wt[x + y] + 1e-4f)) { sub = false; break; }
-		if (sub) p.gap_mode = 3;
+		if (sub) p.gap_mode = c->max_len <= 32 ? 3 : 6;
 	}
 	VK_HIP(hipMemcpyAsync(c->d_ws, ws, sizeof ws, hipMemcpyHostToDevice, st));
 	VK_HIP(hipMemcpyAsync(c->d_wt, wt, sizeof wt, hipMemcpyHostToDevice, st));
@@ -455,7 +455,8 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	int lds_floats = p.s_rows_per_wave * 16;
 	if (p.gap_mode == 2) lds_floats += 4 * p.h_rows * 16;   // column history of dp_general
 	p.lds_floats_per_wave = lds_floats;
-	const size_t smem = (size_t)lds_floats * 4 * 4;   // 4 waves per block
+	size_t smem = (size_t)lds_floats * 4 * 4;   // 4 waves per block
+	if (!is_static && c->nk32 == 24 && c->tail == 0) smem += (size_t)c->nk32 * 1024;   // MODE 3: query tile in LDS
 	if (smem > 160 * 1024) return fail(VK_ERR_UNSUPPORTED, "LDS demand exceeds 160 KiB per workgroup");
 	const int64_t n_groups = (n + 3) / 4;
 	const int blocks_per_cu = std::max(1, std::min(8, (int)((160 * 1024) / std::max<size_t>(smem, 1))));

@@ -197,13 +197,49 @@ __device__ __forceinline__ f32x4 sim_tile(const QFrag<NK, HALF> &f, const uint8_
 	return acc;
 }
 
+// Large d (e.g. 768): the query tile is staged once per workgroup in LDS (NK KiB) and its fragments
+// are re-read per K-step with ds_read_b128 (conflict-free: 64 consecutive 16-byte slots); the token
+// tile's NK loads are all issued up front.  Same MFMA sequence as sim_tile.
+template <int NK, bool HALF>
+__device__ __forceinline__ f32x4 sim_tile_qlds(const uint8_t *__restrict__ qlds, const uint8_t *__restrict__ tile, int lane) {
+	bf16x8 x[NK];
+#pragma unroll
+	for (int t = 0; t < NK; t++) {
+		if (HALF && t == NK - 1) x[t] = load_half_block(tile + t * 1024, lane, true);
+		else x[t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(tile + t * 1024 + lane * 16));
+	}
+	f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+	for (int t = 0; t < NK; t++) {
+		bf16x8 q = *reinterpret_cast<const bf16x8 *>(qlds + t * 1024 + ((HALF && t == NK - 1) ? (lane & 31) : lane) * 16);
+		if (HALF && t == NK - 1) {
+			const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+			q = lane < 32 ? q : z;
+		}
+		acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q, x[t], acc, 0, 0, 0);
+	}
+	acc[0] = clip01(acc[0]); acc[1] = clip01(acc[1]); acc[2] = clip01(acc[2]); acc[3] = clip01(acc[3]);
+	return acc;
+}
+
 // any d: query fragments re-read per K-step (L1/L2 resident), runtime trip count.
 // Same MFMA sequence as sim_tile, hence bit-identical similarities.
 __device__ __forceinline__ f32x4 sim_tile_generic(const uint8_t *__restrict__ qtile, const uint8_t *__restrict__ tile,
 	int nk, int half, int lane) {
 	f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 	const int nfull = half ? nk - 1 : nk;
-	for (int t = 0; t < nfull; t++) {
+	int t = 0;
+	for (; t + 4 <= nfull; t += 4) {   // four K-steps in flight
+		bf16x8 q[4], x[4];
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			x[i] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(tile + (t + i) * 1024 + lane * 16));
+			q[i] = *reinterpret_cast<const bf16x8 *>(qtile + (t + i) * 1024 + lane * 16);
+		}
+#pragma unroll
+		for (int i = 0; i < 4; i++) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q[i], x[i], acc, 0, 0, 0);
+	}
+	for (; t < nfull; t++) {
 		const bf16x8 q = *reinterpret_cast<const bf16x8 *>(qtile + t * 1024 + lane * 16);
 		const bf16x8 x = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(tile + t * 1024 + lane * 16));
 		acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q, x, acc, 0, 0, 0);
@@ -526,10 +562,12 @@ __device__ __forceinline__ float wrd_bound_rows(const float *__restrict__ S, int
 //   MODE 0: contextual layout, NK32 K-steps (last one half filled when TAIL), query fragments in registers
 //   MODE 1: contextual layout, any d (runtime K loop)
 //   MODE 2: static layout: gather rows of the per-query table by token id
+//   MODE 3: contextual layout, NK32 K-steps, query tile staged in LDS (large d)
 // GAP: 0 linear, 1 affine, 2 general (LDS history, serial in-row chain),
 //      3 general, sentences <= 32 tokens, strictly subadditive w_t (register history),
 //      4 relaxed word mover's distance (no DP: row / column minima of 1 - S),
-//      5 word rotator's distance, upper bound of the score (stage 1).
+//      5 word rotator's distance, upper bound of the score (stage 1),
+//      6 as 3 for sentences <= 64 tokens.
 // LT: padded query length (4, 8, 12, 16).
 // ---------------------------------------------------------------------------
 
@@ -538,12 +576,20 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 	extern __shared__ float4 vk_smem4[];
 	float *smem = reinterpret_cast<float *>(vk_smem4);
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	// MODE 3: the first NK32 KiB of the dynamic LDS hold the query tile (shared by the 4 waves)
+	const uint8_t *qlds = reinterpret_cast<const uint8_t *>(smem);
+	if constexpr (MODE == 3) {
+		for (int i = threadIdx.x; i < NK32 * 64; i += 256)
+			vk_smem4[i] = *reinterpret_cast<const float4 *>(p.qtile + i * 16);
+		__syncthreads();
+		smem += NK32 * 256;
+	}
 	float *S = smem + wv * p.lds_floats_per_wave;
 	float *Hh = S + p.s_rows_per_wave * 16;
 	const int sigma = lane >> 4, v = lane & 15;
 
 	QFrag<NK32, TAIL> qf;
-	if (MODE == 0) load_qfrag<NK32, TAIL>(qf, p.qtile, lane);
+	if constexpr (MODE == 0) load_qfrag<NK32, TAIL>(qf, p.qtile, lane);
 
 	DpArgs a;
 	a.locality = p.locality; a.len_t = p.len_t;
@@ -553,10 +599,11 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 	const float inv_ref = (float)p.len_t;
 
 	// general gap, fast form: gap tables in (scalar) registers for the whole kernel
-	float wsr[33], wtr[LT];
-	if (GAP == 3) {
+	constexpr int WSN = GAP == 6 ? 65 : 33;
+	float wsr[WSN], wtr[LT];
+	if (GAP == 3 || GAP == 6) {
 #pragma unroll
-		for (int k = 0; k <= 32; k++) wsr[k] = p.ws[k];
+		for (int k = 0; k < WSN; k++) wsr[k] = p.ws[k];
 #pragma unroll
 		for (int k = 0; k < LT; k++) wtr[k] = p.wt[k];
 	}
@@ -594,7 +641,8 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 			const uint8_t *tp = p.tiles + (int64_t)tile0 * p.tile_bytes;
 			for (int ti = 0; ti < ntiles; ti++) {
 				f32x4 acc;
-				if (MODE == 0) acc = sim_tile<NK32, TAIL>(qf, tp, lane);
+				if constexpr (MODE == 0) acc = sim_tile<NK32, TAIL>(qf, tp, lane);
+				else if constexpr (MODE == 3) acc = sim_tile_qlds<NK32, TAIL>(qlds, tp, lane);
 				else acc = sim_tile_generic(p.qtile, tp, p.nk32, p.tail, lane);
 				*reinterpret_cast<f32x4 *>(S + (ti * 16 + (lane & 15)) * 16 + (lane >> 4) * 4) = acc;
 				tp += p.tile_bytes;
@@ -606,11 +654,12 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 		float raw;
 		const int lenc = len > 0 ? len : 0;
 		const int rb = len > 0 ? rowbase : 0;
-		if (GAP == 0) raw = dp_linear<LT>(S, rb, lenc, maxlen, v, a);
-		else if (GAP == 1) raw = dp_affine<LT>(S, rb, lenc, maxlen, v, a);
-		else if (GAP == 2) raw = dp_general<LT>(S, Hh, p.h_rows, rb, lenc, maxlen, lane, a);
-		else if (GAP == 3) raw = dp_general_reg<LT, 32>(S, rb, lenc, maxlen, v, a, wsr, wtr);
-		else if (GAP == 4) raw = rwmd_rows<LT>(S, rb, lenc, maxlen, v, a);
+		if constexpr (GAP == 0) raw = dp_linear<LT>(S, rb, lenc, maxlen, v, a);
+		else if constexpr (GAP == 1) raw = dp_affine<LT>(S, rb, lenc, maxlen, v, a);
+		else if constexpr (GAP == 2) raw = dp_general<LT>(S, Hh, p.h_rows, rb, lenc, maxlen, lane, a);
+		else if constexpr (GAP == 3) raw = dp_general_reg<LT, 32>(S, rb, lenc, maxlen, v, a, wsr, wtr);
+		else if constexpr (GAP == 6) raw = dp_general_reg<LT, 64>(S, rb, lenc, maxlen, v, a, wsr, wtr);
+		else if constexpr (GAP == 4) raw = rwmd_rows<LT>(S, rb, lenc, maxlen, v, a);
 		else raw = wrd_bound_rows<LT>(S, rb, lenc, maxlen, v, a, p.mag + (len > 0 ? t_a : 0), p.qmass[v]);
 
 		if (v == 15 && s_idx < p.n_sent) {
@@ -1087,6 +1136,7 @@ static hipError_t launch_score_gap(const VkScoreParams &p, int grid, size_t smem
 	case 3: return launch_score_lt<MODE, NK32, TAIL, 3>(p, grid, smem, stream);
 	case 4: return launch_score_lt<MODE, NK32, TAIL, 4>(p, grid, smem, stream);
 	case 5: return launch_score_lt<MODE, NK32, TAIL, 5>(p, grid, smem, stream);
+	case 6: return launch_score_lt<MODE, NK32, TAIL, 6>(p, grid, smem, stream);
 	default: return launch_score_lt<MODE, NK32, TAIL, 2>(p, grid, smem, stream);
 	}
 }
@@ -1095,6 +1145,7 @@ extern "C" hipError_t vk_launch_score(const VkScoreParams *pp, int32_t grid, siz
 	const VkScoreParams &p = *pp;
 	if (p.layout == VK_DEV_LAYOUT_STATIC) return launch_score_gap<2, 0, false>(p, grid, smem_bytes, stream);
 	if (p.nk32 == 10 && p.tail == 1) return launch_score_gap<0, 10, true>(p, grid, smem_bytes, stream);
+	if (p.nk32 == 24 && p.tail == 0) return launch_score_gap<3, 24, false>(p, grid, smem_bytes, stream);
 	return launch_score_gap<1, 0, false>(p, grid, smem_bytes, stream);
 }
 
