@@ -137,21 +137,28 @@ def main():
 	if not torch.cuda.is_available():
 		print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
 		sys.exit(2)
-	torch.cuda.set_device(local_rank)
-	device = torch.device("cuda", local_rank)
-	core.init(local_rank)
+	# one rank per GPU; VK_BENCH_BACKEND=gloo rehearses the N > 1 path with several ranks on one GPU
+	backend = os.environ.get("VK_BENCH_BACKEND", "nccl")
+	dev_index = local_rank % torch.cuda.device_count()
+	torch.cuda.set_device(dev_index)
+	device = torch.device("cuda", dev_index)
+	core.init(dev_index)
 
 	dist = None
 	if world > 1:
 		import torch.distributed as dist
 		os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-		dist.init_process_group(backend="nccl", device_id=device)
+		if backend == "nccl":
+			dist.init_process_group(backend="nccl", device_id=device)
+		else:
+			dist.init_process_group(backend=backend)
+	xdev = device if backend == "nccl" else torch.device("cpu")   # where the exchanged records live
 
 	n_sent = args.sentences
 	corpus, E, ids = build_shard(core, torch, n_sent, rank, device)
 	queries = make_queries(E, ids, args.steps + args.warmup, seed=3456)
 	if world > 1:   # one query stream for the whole job: rank 0's
-		qt = torch.from_numpy(np.stack(queries)).to(device)
+		qt = torch.from_numpy(np.stack(queries)).to(xdev)
 		dist.broadcast(qt, src=0)
 		queries = list(qt.cpu().numpy())
 	gs, gt, gap_desc = gap_spec(args.gap)
@@ -164,7 +171,7 @@ def main():
 		if world == 1:
 			return top
 		# per-rank result sets -> all ranks (RCCL all-gather over xGMI), then ResultSet.extend
-		return shards.allgather_merge(top, rank * n_sent, K_MATCHES, device=device)
+		return shards.allgather_merge(top, rank * n_sent, K_MATCHES, device=xdev)
 
 	def sync():
 		torch.cuda.synchronize()
@@ -185,7 +192,7 @@ def main():
 	timings = corpus.last_timings()
 
 	if dist is not None:
-		t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+		t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
 		dist.all_reduce(t, op=dist.ReduceOp.MAX)
 		elapsed = float(t.item())
 
@@ -198,7 +205,7 @@ def main():
 		prof = os.path.join(ROOT, "profiles", "traffic.json")
 		if os.path.exists(prof):
 			try:
-				traffic = json.load(open(prof)).get(args.gap, {}).get("hbm_bytes_per_launch")
+				traffic = json.load(open(prof)).get(args.gap, {}).get("hbm_bytes_per_launch") if n_sent == 1000000 else None
 			except Exception:
 				traffic = None
 		out = {

@@ -459,8 +459,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	if (!is_static && c->nk32 == 24 && c->tail == 0) smem += (size_t)c->nk32 * 1024;   // MODE 3: query tile in LDS
 	if (smem > 160 * 1024) return fail(VK_ERR_UNSUPPORTED, "LDS demand exceeds 160 KiB per workgroup");
 	const int64_t n_groups = (n + 3) / 4;
-	const int blocks_per_cu = std::max(1, std::min(8, (int)((160 * 1024) / std::max<size_t>(smem, 1))));
-	const int grid = (int)std::min<int64_t>((n_groups + 3) / 4, (int64_t)256 * blocks_per_cu);
+	const int grid = (int)std::min<int64_t>((n_groups + 3) / 4, (int64_t)1 << 20);   // capped to residency by the launcher
 	VK_HIP(vk_launch_score(&p, grid, smem, st));
 
 	if (q->algorithm == VK_ALG_WRD) {

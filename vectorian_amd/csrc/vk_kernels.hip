@@ -30,6 +30,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "vk_device.h"
 
@@ -275,6 +276,28 @@ struct DpArgs {
 	int32_t rwmd_symmetric, rwmd_normalize_bow;
 };
 
+// In-row dependency of the linear recurrence H[u][j] = max(c[j], H[u][j-1] - gt): because
+// fl(max(a, b) - g) = max(fl(a - g), fl(b - g)), unrolling gives H[u][j] = max_k decay_k(c[j-k]) with
+// decay_k = k successive fp32 subtractions of gt -- bit for bit the sequential result.  Each lane
+// decays its own c (one short dependent chain), the shifted copies are combined with independent
+// row_shr:k + max.  The border column enters as decay_(j)(H[u][0]) for lane j - 1 (non-LOCAL only).
+template <int K>
+__device__ __forceinline__ float shr_k(float old, float src) { return dpp_f<0x110 + K>(old, src); }
+
+template <int LT, int K>
+struct LinChain {
+	// K = 1 .. LT: decay the lane's own value and the border once more; shifts exist for K <= 15
+	static __device__ __forceinline__ void run(float &h, float d, float bdec, float &bsel, float gt, int v) {
+		if constexpr (K <= LT) {
+			d = d - gt;                       // decay_K(c) of this lane
+			bdec = bdec - gt;                 // decay_K(border)
+			bsel = (v == K - 1) ? bdec : bsel;
+			if constexpr (K < LT && K <= 15) h = fmaxf(h, shr_k<K>(VK_NEG_INF, d));
+			LinChain<LT, K + 1>::run(h, d, bdec, bsel, gt, v);
+		}
+	}
+};
+
 template <int LT>
 __device__ __forceinline__ float dp_linear(const float *__restrict__ S, int rowbase, int len, int maxlen, int v, const DpArgs &a) {
 	const bool is_local = a.locality == VK_DEV_LOCAL;
@@ -294,10 +317,11 @@ __device__ __forceinline__ float dp_linear(const float *__restrict__ S, int rowb
 		const float diag = dpp_f<DPP_ROW_SHR1>(bprev, h);
 		float c = fmaxf(diag + s, floor0);
 		c = fmaxf(c, h - gs);
-		// H[u][v] = max(c[v], H[u][v-1] - gt); lane 0's left neighbour is the border
-#pragma unroll
-		for (int i = 0; i < LT; i++) c = fmaxf(c, dpp_f<DPP_ROW_SHR1>(bcur, c) - gt);
-		h = act ? c : h;
+		float hn = c;
+		float bsel = VK_NEG_INF;              // decay_(v+1)(border) for this lane
+		LinChain<LT, 1>::run(hn, c, bcur, bsel, gt, v);
+		if (!is_local) hn = fmaxf(hn, bsel);
+		h = act ? hn : h;
 		if (is_local || last_col) best = fmaxf(best, h);
 	}
 	float m;
@@ -1114,18 +1138,36 @@ extern "C" hipError_t vk_launch_table(const uint8_t *etiles, const uint8_t *qtil
 	return hipGetLastError();
 }
 
+// grid = every CU filled to the kernel's real residency (VGPR / LDS bound), not more: the waves
+// walk the groups with a grid stride, so a second, partially filled round of workgroups would only
+// add a tail.  VK_BLOCKS_PER_CU overrides (experiments).
+template <typename K>
+static hipError_t launch_sized(K kernel, const VkScoreParams &p, int want_blocks, size_t smem, hipStream_t stream) {
+	int occ = 0;
+	hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, smem);
+	if (e != hipSuccess) return e;
+	if (occ < 1) occ = 1;
+	// measured on MI355X (1M x 32 x 300-d): 3 workgroups (12 waves) per CU stream HBM fastest --
+	// 2.90 ms vs 3.51 ms at 5 per CU for the linear-gap kernel, 2.95 ms at 4; more concurrent streams cost bandwidth
+	if (occ > 3) occ = 3;
+	static const char *ov = getenv("VK_BLOCKS_PER_CU");
+	if (ov && atoi(ov) > 0) occ = atoi(ov);
+	int dev = 0, cus = 256;
+	if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+	const int grid = want_blocks < cus * occ ? want_blocks : cus * occ;
+	kernel<<<grid, 256, smem, stream>>>(p);
+	return hipGetLastError();
+}
+
 template <int MODE, int NK32, bool TAIL, int GAP>
 static hipError_t launch_score_lt(const VkScoreParams &p, int grid, size_t smem, hipStream_t stream) {
 	const int lt = p.len_t <= 4 ? 4 : p.len_t <= 8 ? 8 : p.len_t <= 12 ? 12 : 16;
-	// non-LOCAL alignments need one more chain step for the border column: covered,
-	// because LT >= len_t and lane len_t - 1 is final after len_t steps.
 	switch (lt) {
-	case 4: vk_score_kernel<MODE, NK32, TAIL, GAP, 4><<<grid, 256, smem, stream>>>(p); break;
-	case 8: vk_score_kernel<MODE, NK32, TAIL, GAP, 8><<<grid, 256, smem, stream>>>(p); break;
-	case 12: vk_score_kernel<MODE, NK32, TAIL, GAP, 12><<<grid, 256, smem, stream>>>(p); break;
-	default: vk_score_kernel<MODE, NK32, TAIL, GAP, 16><<<grid, 256, smem, stream>>>(p); break;
+	case 4: return launch_sized(vk_score_kernel<MODE, NK32, TAIL, GAP, 4>, p, grid, smem, stream);
+	case 8: return launch_sized(vk_score_kernel<MODE, NK32, TAIL, GAP, 8>, p, grid, smem, stream);
+	case 12: return launch_sized(vk_score_kernel<MODE, NK32, TAIL, GAP, 12>, p, grid, smem, stream);
+	default: return launch_sized(vk_score_kernel<MODE, NK32, TAIL, GAP, 16>, p, grid, smem, stream);
 	}
-	return hipGetLastError();
 }
 
 template <int MODE, int NK32, bool TAIL>
