@@ -539,12 +539,25 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 
 	// ---- bounded result set -------------------------------------------------
 	VK_HIP(hipEventRecord(c->ev[2], st));
-	int nb = 0, cur = 0;
-	VK_HIP(vk_launch_topk_scores(c->d_scores, n, q->min_score, k, c->d_keys[0], &nb, st));
-	while (nb > 1) {
-		const int64_t nkeys = (int64_t)nb * k;
-		VK_HIP(vk_launch_topk_keys(c->d_keys[cur], nkeys, k, c->d_keys[1 - cur], &nb, st));
-		cur = 1 - cur;
+	int cur = 0;
+	if (k <= 64) {
+		// wave-streaming selection: n -> ceil(n/4096) * k keys -> ... -> k keys
+		int64_t nw = 0;
+		VK_HIP(vk_launch_topk_wave(c->d_scores, nullptr, n, q->min_score, k, 4096, c->d_keys[0], &nw, st));
+		while (nw > 1) {
+			const int64_t nkeys = nw * k;
+			const int64_t per_wave = nkeys <= 16384 ? nkeys : 4096;
+			VK_HIP(vk_launch_topk_wave(nullptr, c->d_keys[cur], nkeys, 0.0f, k, per_wave, c->d_keys[1 - cur], &nw, st));
+			cur = 1 - cur;
+		}
+	} else {
+		int nb = 0;
+		VK_HIP(vk_launch_topk_scores(c->d_scores, n, q->min_score, k, c->d_keys[0], &nb, st));
+		while (nb > 1) {
+			const int64_t nkeys = (int64_t)nb * k;
+			VK_HIP(vk_launch_topk_keys(c->d_keys[cur], nkeys, k, c->d_keys[1 - cur], &nb, st));
+			cur = 1 - cur;
+		}
 	}
 
 	// ---- flow of the winners ------------------------------------------------
@@ -554,7 +567,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		VkFlowParams f{};
 		f.tiles = c->d_tiles; f.tok_id = c->d_tok_id; f.table = c->d_table; f.sent_off = c->d_sent_off;
 		f.layout = p.layout; f.nk32 = c->nk32; f.tail = c->tail; f.tile_bytes = c->tile_bytes;
-		f.qtile = c->d_qtile; f.len_t = q->len_t; f.locality = q->locality; f.gap_mode = p.gap_mode == 3 ? 2 : p.gap_mode;
+		f.qtile = c->d_qtile; f.len_t = q->len_t; f.locality = q->locality; f.gap_mode = (p.gap_mode == 3 || p.gap_mode == 6) ? 2 : p.gap_mode;
 		f.gs = p.gs; f.gt = p.gt; f.a_s = p.a_s; f.a_t = p.a_t; f.open_s = p.open_s; f.open_t = p.open_t;
 		f.ws = c->d_ws; f.wt = c->d_wt;
 		f.keys = c->d_keys[cur]; f.raw_out = c->d_out_raw; f.mapping = c->d_out_map; f.edge_sim = c->d_out_sim;

@@ -98,6 +98,8 @@ hipError_t vk_launch_topk_scores(const float *scores, int64_t n, float min_score
 	int32_t *n_blocks_out, hipStream_t stream);
 hipError_t vk_launch_topk_keys(const uint64_t *in, int64_t n, int32_t k, uint64_t *out, int32_t *n_blocks_out,
 	hipStream_t stream);
+hipError_t vk_launch_topk_wave(const float *scores, const uint64_t *keys_in, int64_t n, float min_score, int32_t k,
+	int64_t per_wave, uint64_t *out, int64_t *n_waves_out, hipStream_t stream);
 hipError_t vk_launch_flow(const VkFlowParams *p, int32_t k, hipStream_t stream);
 hipError_t vk_launch_wrd_exact(const VkWrdParams *p, int32_t n_cand, float *scores_to_mark, hipStream_t stream);
 #ifdef __cplusplus

@@ -784,6 +784,51 @@ __global__ __launch_bounds__(256) void vk_topk_keys_kernel(const uint64_t *__res
 }
 
 // ---------------------------------------------------------------------------
+// bounded result set for k <= 64: one wave streams VK_TOPK_PER_WAVE elements and keeps its k best
+// keys sorted across the lanes (lane 0 = best).  A batch of 64 candidates is tested against the
+// current k-th key with one ballot; the few that pass are inserted by a shift across lanes.
+// Two launches (n -> n/4096 * k -> k) replace the multi-stage bitonic sort.
+// ---------------------------------------------------------------------------
+
+#define VK_TOPK_PER_WAVE 4096
+
+template <int FROM_KEYS>
+__global__ __launch_bounds__(256) void vk_topk_wave_kernel(const float *__restrict__ scores, const uint64_t *__restrict__ keys_in,
+	int64_t n, float min_score, int32_t k, int64_t per_wave, uint64_t *__restrict__ out) {
+	const int lane = threadIdx.x & 63;
+	const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	const int64_t a = wave * per_wave;
+	if (a >= n) return;
+	const int64_t b = a + per_wave < n ? a + per_wave : n;
+	uint64_t mine = 0;                       // sorted descending over lanes; 0 = empty
+	uint64_t thr = 0;                        // key of lane k-1: candidates must exceed it
+	for (int64_t base = a; base < b; base += 64) {
+		const int64_t g = base + lane;
+		uint64_t key = 0;
+		if (g < b) {
+			if (FROM_KEYS) key = keys_in[g];
+			else {
+				const float s = scores[g];
+				if (s > min_score) key = ((uint64_t)float_orderable(s) << 32) | (uint32_t)g;
+			}
+		}
+		bool pending = key > thr;
+		for (;;) {
+			const unsigned long long mask = __ballot(pending && key > thr);
+			if (mask == 0) break;
+			const int src = __builtin_ctzll(mask);
+			const uint64_t nk = __shfl(key, src, 64);
+			if (lane == src) pending = false;
+			uint64_t up = __shfl_up(mine, 1, 64);
+			if (lane == 0) up = ~0ull;
+			mine = (mine >= nk) ? mine : ((up >= nk) ? nk : up);
+			thr = __shfl(mine, k - 1, 64);
+		}
+	}
+	if (lane < k) out[wave * k + lane] = mine;
+}
+
+// ---------------------------------------------------------------------------
 // flow of the winners: one wave per winner recomputes the similarity rows with the
 // same MFMA sequence as the scoring kernel, then lane 0 runs the sequential DP with
 // traceback exactly as the oracle states it (vko_align in oracle/vk_oracle.c):
@@ -847,106 +892,124 @@ __global__ __launch_bounds__(64) void vk_flow_kernel(VkFlowParams p) {
 	const int gap = p.gap_mode;
 	const float gs = p.gs, gt = p.gt, open_s = p.open_s, open_t = p.open_t, a_s = p.a_s, a_t = p.a_t;
 
-	// ---- fill: lanes 0..len_t-1 own one query column each.  Per row the zero / diagonal /
-	// gap-in-s candidates of all columns are evaluated in parallel, the gap-in-t candidates
-	// column by column (they need the final cells to their left).  Every cell tries its
-	// candidates in the oracle's order and replaces only on strictly greater, so values,
-	// directions and gap lengths are those of the sequential fill.
-	if (lane <= len_t) {   // borders of row 0
-		const int v = lane;
-		float h0 = 0.0f;
-		if (global && v > 0) h0 = gap == 0 ? -(gt * (float)v) : gap == 1 ? -(a_t + gt * (float)v) : -wtl[v];
-		H[v] = h0;
-		E[v] = VK_NEG_INF;
-		F[v] = (global && v > 0 && gap == 1) ? h0 : VK_NEG_INF;
-	}
+	// ---- fill: lane l owns query column v = l + 1 (lanes 0..len_t-1, one DPP row).  Per row the
+	// zero / diagonal / gap-in-s candidates of all columns are evaluated in parallel; the gap-in-t
+	// candidates need the final cells to the left, which become final one column per step and are
+	// broadcast with v_readlane (the wave holds ONE sentence, so the column index is wave-uniform).
+	// Candidate order and strict-greater replacement are the oracle's (vko_align): zero, diagonal,
+	// gap in s with k = 1, 2, .., gap in t with k = 1, 2, ..  In-row candidates arrive with k
+	// descending, so among them ">=" keeps the smallest k of the maximum, and the winner replaces
+	// the earlier candidates only if strictly greater.
+	const int v = lane + 1;
+	const bool col = v <= len_t;
+	float wrel[16];   // general: w_t(v - p) for source column p < v
+#pragma unroll
+	for (int pp = 0; pp < 16; pp++) wrel[pp] = (col && pp < v) ? wtl[v - pp] : __builtin_inff();
+
+	float hprev = 0.0f, eprev = VK_NEG_INF;
+	if (global && col) hprev = gap == 0 ? -(gt * (float)v) : gap == 1 ? -(a_t + gt * (float)v) : -wtl[v];
+	if (col) H[v] = hprev;
 	for (int u = 1; u <= len_s; u++) {
-		wave_lds_fence();
-		float best = 0.0f, e = VK_NEG_INF;
-		uint8_t d = 0, ee = 0;
-		int16_t kk = 0;
-		const int v = lane + 1;   // this lane's column
-		if (lane == 0) {          // border column
-			float hb = 0.0f;
-			if (global) hb = gap == 0 ? -(gs * (float)u) : gap == 1 ? -(a_s + gs * (float)u) : -wsl[u];
-			H[u * W] = hb;
-			E[u * W] = (global && gap == 1) ? hb : VK_NEG_INF;
-			F[u * W] = VK_NEG_INF;
+		float bprev = 0.0f, bcur = 0.0f;
+		if (global) {
+			bprev = u == 1 ? 0.0f : (gap == 0 ? -(gs * (float)(u - 1)) : gap == 1 ? -(a_s + gs * (float)(u - 1)) : -wsl[u - 1]);
+			bcur = gap == 0 ? -(gs * (float)u) : gap == 1 ? -(a_s + gs * (float)u) : -wsl[u];
 		}
-		if (v <= len_t) {
-			float c = H[(u - 1) * W + v - 1] + Sm[(u - 1) * 16 + v - 1];
-			if (local) { best = 0.0f; d = 0; if (c > best) { best = c; d = 1; } }
-			else { best = c; d = 1; }
-			if (gap == 0) {
-				c = H[(u - 1) * W + v] - gs;
-				if (c > best) { best = c; d = 2; kk = 1; }
-			} else if (gap == 1) {
-				e = H[(u - 1) * W + v] - open_s;
-				c = E[(u - 1) * W + v] - gs;
-				if (c > e) { e = c; ee = 1; }
-				if (e > best) { best = e; d = 2; }
-			} else {
-				for (int k = 1; k <= u; k++) {
-					c = H[(u - k) * W + v] - wsl[k];
-					if (c > best) { best = c; d = 2; kk = (int16_t)k; }
-				}
+		const float sv = Sm[(u - 1) * 16 + (col ? v - 1 : 0)];
+		const float diag = dpp_f<DPP_ROW_SHR1>(bprev, hprev);
+		float best, e = VK_NEG_INF;
+		uint8_t d, ee = 0, fe = 0;
+		int16_t kk = 0;
+		float c = diag + sv;
+		if (local) { best = 0.0f; d = 0; if (c > best) { best = c; d = 1; } }
+		else { best = c; d = 1; }
+		if (gap == 0) {
+			c = hprev - gs;
+			if (c > best) { best = c; d = 2; kk = 1; }
+		} else if (gap == 1) {
+			e = hprev - open_s;
+			c = eprev - gs;
+			if (c > e) { e = c; ee = 1; }
+			if (e > best) { best = e; d = 2; }
+		} else {
+			for (int k = 1; k <= u; k++) {
+				c = H[(u - k) * W + (col ? v : 1)] - wsl[k];
+				if (c > best) { best = c; d = 2; kk = (int16_t)k; }
 			}
 		}
-		wave_lds_fence();
-		for (int vv = 1; vv <= len_t; vv++) {
-			if (v == vv) {
-				float c;
-				uint8_t fe = 0;
-				float f = VK_NEG_INF;
-				if (gap == 0) {
-					c = H[u * W + v - 1] - gt;
-					if (c > best) { best = c; d = 3; kk = 1; }
-				} else if (gap == 1) {
-					f = H[u * W + v - 1] - open_t;
-					c = F[u * W + v - 1] - gt;
-					if (c > f) { f = c; fe = 1; }
-					if (f > best) { best = f; d = 3; }
-				} else {
-					for (int k = 1; k <= v; k++) {
-						c = H[u * W + v - k] - wtl[k];
-						if (c > best) { best = c; d = 3; kk = (int16_t)k; }
+		// in-row candidates
+		float left_best = VK_NEG_INF, f = VK_NEG_INF, fin = best, ffin = VK_NEG_INF;
+		int16_t left_k = 0;
+#pragma unroll
+		for (int pp = 0; pp < 16; pp++) {
+			if (pp < len_t) {
+				const float sp = pp == 0 ? bcur : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fin), pp - 1));
+				const float fp = pp == 0 ? VK_NEG_INF : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ffin), pp - 1));
+				if (gap == 2) {
+					const float cc = sp - wrel[pp];
+					if (v > pp && cc >= left_best) { left_best = cc; left_k = (int16_t)(v - pp); }
+				} else if (v == pp + 1) {
+					if (gap == 0) { left_best = sp - gt; left_k = 1; }
+					else {
+						f = sp - open_t;
+						const float c2 = fp - gt;
+						if (c2 > f) { f = c2; fe = 1; }
 					}
 				}
-				H[u * W + v] = best; E[u * W + v] = e; F[u * W + v] = f;
-				dirs[u * W + v] = d; dk[u * W + v] = kk; eext[u * W + v] = ee; fext[u * W + v] = fe;
+				if (v == pp + 1) {   // all sources of this column are in: finalise it
+					if (gap == 1) { if (f > best) { best = f; d = 3; } ffin = f; }
+					else if (left_best > best) { best = left_best; d = 3; kk = left_k; }
+					fin = best;
+				}
 			}
-			wave_lds_fence();
+		}
+		if (col) {
+			H[u * W + v] = best;
+			dirs[u * W + v] = d; dk[u * W + v] = kk; eext[u * W + v] = ee; fext[u * W + v] = fe;
+		}
+		hprev = best;
+		eprev = e;
+	}
+
+	// ---- start cell: first maximum in row-major order (u outer, v inner), borders (0) first
+	float bv = 0.0f;
+	int bu = 0;
+	if (col && !global) {
+		for (int uu = 1; uu <= len_s; uu++) {
+			if (!local && !(uu == len_s || v == len_t)) continue;
+			const float hv = H[uu * W + v];
+			if (hv > bv) { bv = hv; bu = uu; }
 		}
 	}
 	wave_lds_fence();
-	if (lane != 0) return;
-
-	// start cell
-	int u = len_s, v = len_t;
-	float raw = H[len_s * W + len_t];
-	if (!global) {
-		raw = 0.0f; u = 0; v = 0;
-		for (int uu = 1; uu <= len_s; uu++)
-			for (int vv = 1; vv <= len_t; vv++) {
-				if (!local && !(uu == len_s || vv == len_t)) continue;
-				const float hv = H[uu * W + vv];
-				if (hv > raw) { raw = hv; u = uu; v = vv; }
-			}
+	int u = len_s, vq = len_t;
+	float raw;
+	if (global) {
+		raw = H[len_s * W + len_t];
+	} else {
+		raw = 0.0f; u = 0; vq = 0;
+		for (int j = 0; j < len_t; j++) {
+			const float vj = __shfl(bv, j, 64);
+			const int uj = __shfl(bu, j, 64);
+			if (vj > raw || (vj == raw && vj > 0.0f && uj < u)) { raw = vj; u = uj; vq = j + 1; }
+		}
 	}
+	if (lane != 0) return;
+	int v2 = vq;
 	int16_t *mp = p.mapping + (int64_t)w * 16;
 	float *es = p.edge_sim + (int64_t)w * 16;
 	for (int j = 0; j < 16; j++) { mp[j] = -1; es[j] = 0.0f; }
 	int state = 0;
-	while (u > 0 && v > 0) {
-		const int idx = u * W + v;
+	while (u > 0 && v2 > 0) {
+		const int idx = u * W + v2;
 		if (gap == 1 && state == 1) { if (!eext[idx]) state = 0; u--; continue; }
-		if (gap == 1 && state == 2) { if (!fext[idx]) state = 0; v--; continue; }
+		if (gap == 1 && state == 2) { if (!fext[idx]) state = 0; v2--; continue; }
 		const uint8_t d = dirs[idx];
 		if (d == 0) break;
-		if (d == 1) { mp[v - 1] = (int16_t)(u - 1); es[v - 1] = Sm[(u - 1) * 16 + v - 1]; u--; v--; }
+		if (d == 1) { mp[v2 - 1] = (int16_t)(u - 1); es[v2 - 1] = Sm[(u - 1) * 16 + v2 - 1]; u--; v2--; }
 		else if (gap == 1) state = (d == 2) ? 1 : 2;
 		else if (d == 2) u -= dk[idx];
-		else v -= dk[idx];
+		else v2 -= dk[idx];
 	}
 	p.raw_out[w] = raw;
 }
@@ -1210,6 +1273,16 @@ extern "C" hipError_t vk_launch_topk_keys(const uint64_t *in, int64_t n, int32_t
 extern "C" hipError_t vk_launch_wrd_exact(const VkWrdParams *p, int32_t n_cand, float *scores_to_mark, hipStream_t stream) {
 	vk_wrd_exact_kernel<<<n_cand, 64, 0, stream>>>(*p);
 	if (scores_to_mark) vk_mark_kernel<<<(n_cand + 255) / 256, 256, 0, stream>>>(p->keys, n_cand, scores_to_mark);
+	return hipGetLastError();
+}
+
+extern "C" hipError_t vk_launch_topk_wave(const float *scores, const uint64_t *keys_in, int64_t n, float min_score, int32_t k,
+	int64_t per_wave, uint64_t *out, int64_t *n_waves_out, hipStream_t stream) {
+	const int64_t nw = (n + per_wave - 1) / per_wave;
+	const unsigned grid = (unsigned)((nw + 3) / 4);
+	if (keys_in) vk_topk_wave_kernel<1><<<grid, 256, 0, stream>>>(nullptr, keys_in, n, min_score, k, per_wave, out);
+	else vk_topk_wave_kernel<0><<<grid, 256, 0, stream>>>(scores, nullptr, n, min_score, k, per_wave, out);
+	*n_waves_out = nw;
 	return hipGetLastError();
 }
 
