@@ -1,0 +1,121 @@
+"""-m gpu: edge cases of the path, HIP (through the C-ABI) against the oracle: empty slices, corpora
+smaller than one wave group, k larger than the number of admissible slices, the k > 64 selection
+path, exact ties (total order), boundary lengths (64-token sentences, 16-token queries, 1-token
+everything), min_score admission."""
+
+import numpy as np
+import pytest
+
+from vectorian_amd import synth
+
+from helpers import assert_same_results, prep_query
+
+pytestmark = pytest.mark.gpu
+
+EXP5 = ("table", (1 - 2.0 ** (-np.arange(0, 65) / 5)).astype(np.float32))
+
+
+def build(hip, Xb, off):
+	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=Xb.shape[1], n_tokens=Xb.shape[0], n_sentences=len(off) - 1)
+	c.append_vectors(Xb, normalize=False)
+	c.set_sentences(off)
+	c.finalize()
+	return c
+
+
+def both(hip, oracle, Xb, off, Qb, **kw):
+	c = build(hip, Xb, off)
+	okw = dict(kw)
+	gs, gt = okw.pop("gap_s", 0.0), okw.pop("gap_t", 0.0)
+	rkw = dict(okw)
+	rkw.pop("want_flow", None)
+	ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=Xb.shape[1], sent_off=off, X=Xb, Q=Qb, gap_s=gs, gap_t=gt, **rkw)
+	got = c.query(Qb, q_normalize=False, gap_s=gs, gap_t=gt, **okw).trimmed()
+	c.close()
+	return got, ref
+
+
+def vectors(n, d, seed):
+	return synth.to_bf16_bits(synth.normalize_rows(np.random.default_rng(seed).standard_normal((n, d)).astype(np.float32)))
+
+
+@pytest.mark.parametrize("n_sent", [1, 2, 3, 4, 5, 7])
+def test_fewer_sentences_than_a_wave_group(hip, oracle, n_sent):
+	lens = np.arange(1, n_sent + 1) * 3
+	off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+	Xb, Qb = vectors(int(off[-1]), 48, 1), vectors(4, 48, 2)
+	got, ref = both(hip, oracle, Xb, off, Qb, gap_s=0.05, gap_t=0.05, max_matches=10, locality=0)
+	assert_same_results(got, ref)
+
+
+def test_empty_slices_are_skipped(hip, oracle):
+	# document.h:160: slices with len_s < 1 never reach the matcher
+	lens = np.array([5, 0, 0, 7, 0, 3, 0, 0, 0, 9, 1, 0])
+	off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+	Xb, Qb = vectors(int(off[-1]), 64, 3), vectors(3, 64, 4)
+	for loc, ms in ((0, 0.0), (1, -100.0), (2, -100.0)):
+		got, ref = both(hip, oracle, Xb, off, Qb, gap_s=0.1, gap_t=0.1, max_matches=20, locality=loc, min_score=ms)
+		assert_same_results(got, ref)
+		assert set(got["sentence"]) <= {0, 3, 5, 9, 10}
+
+
+def test_k_exceeds_admissible_and_min_score(hip, oracle):
+	corpus = synth.make_contextual_corpus(300, 2, 20, 500, 64)
+	Xb = synth.to_bf16_bits(synth.normalize_rows(corpus["X"]))
+	Qb = prep_query(synth.make_queries(corpus, 1, 5)[0])
+	got, ref = both(hip, oracle, Xb, corpus["sent_off"], Qb, gap_s=EXP5, gap_t=EXP5, max_matches=64, min_score=0.3)
+	assert len(ref["score"]) < 64 and (ref["score"] > 0.3).all()
+	assert_same_results(got, ref)
+	got, ref = both(hip, oracle, Xb, corpus["sent_off"], Qb, gap_s=EXP5, gap_t=EXP5, max_matches=5, min_score=2.0)
+	assert len(got["score"]) == 0 and len(ref["score"]) == 0
+
+
+@pytest.mark.parametrize("k", [1, 64, 65, 200, 1024])
+def test_selection_paths(hip, oracle, k):
+	# k <= 64: wave-streaming selection; k > 64: staged bitonic sort; 5000 slices span several blocks
+	corpus = synth.make_contextual_corpus(5000, 3, 12, 800, 32)
+	Xb = synth.to_bf16_bits(synth.normalize_rows(corpus["X"]))
+	Qb = prep_query(synth.make_queries(corpus, 1, 4)[0])
+	got, ref = both(hip, oracle, Xb, corpus["sent_off"], Qb, gap_s=0.1, gap_t=0.1, max_matches=k, want_flow=(k <= 200))
+	assert len(ref["score"]) == min(k, len(ref["score"]))
+	assert_same_results(got, ref, check_mapping=(k <= 200))
+
+
+def test_exact_ties_follow_the_total_order(hip, oracle):
+	# identical sentences score identically: order = score desc, then sentence index desc
+	base = np.random.default_rng(7).standard_normal((6, 40)).astype(np.float32)
+	sent = np.concatenate([base, base, base[:3], base])          # slices: 6, 6, 3, 6 tokens
+	X = np.concatenate([sent] * 3)                                 # three copies of that document
+	lens = np.array([6, 6, 3, 6] * 3)
+	off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+	Xb = synth.to_bf16_bits(synth.normalize_rows(X))
+	Qb = synth.to_bf16_bits(synth.normalize_rows(base[1:4]))
+	got, ref = both(hip, oracle, Xb, off, Qb, gap_s=0.2, gap_t=0.2, max_matches=7)
+	assert list(ref["sentence"]) == [11, 9, 8, 7, 5, 4, 3]
+	assert list(got["sentence"]) == list(ref["sentence"])
+	assert (got["score"] == ref["score"]).all()
+
+
+def test_boundary_lengths(hip, oracle):
+	# 64-token sentences with a 16-token query, and 1-token sentences with a 1-token query
+	X = np.random.default_rng(8).standard_normal((64 * 9, 100)).astype(np.float32)
+	off = (np.arange(10) * 64).astype(np.int64)
+	Xb = synth.to_bf16_bits(synth.normalize_rows(X))
+	Qb = synth.to_bf16_bits(synth.normalize_rows(X[70:86] + 0.1))
+	for gaps in ((0.1, 0.1), (EXP5, EXP5), (("affine", 0.3, 0.02), ("affine", 0.1, 0.05))):
+		for loc, ms in ((0, 0.0), (1, -100.0), (2, -100.0)):
+			got, ref = both(hip, oracle, Xb, off, Qb, gap_s=gaps[0], gap_t=gaps[1], max_matches=9, locality=loc, min_score=ms)
+			assert_same_results(got, ref)
+	off1 = np.arange(0, 41, dtype=np.int64)
+	got, ref = both(hip, oracle, Xb[:40], off1, Xb[5:6], gap_s=0.1, gap_t=0.1, max_matches=3)
+	assert_same_results(got, ref)
+	assert got["sentence"][0] == 5 and abs(got["score"][0] - 1.0) < 1e-3
+
+
+def test_too_long_sentence_is_rejected(hip):
+	off = np.array([0, 65], dtype=np.int64)
+	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=16, n_tokens=65, n_sentences=1)
+	c.append_vectors(np.ones((65, 16), np.float32))
+	with pytest.raises(hip.VkError):
+		c.set_sentences(off)
+	c.close()
