@@ -157,6 +157,12 @@ int vk_corpus_device_bytes(const vk_corpus_t *c, int64_t *bytes);
  *     every document + ResultSet.extend/best_n (vectorian/index.py:530-560) ------ */
 int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out);
 
+/* A batch of queries against the shard (BASELINE config 4: 256 queries per call).  Semantically
+ * n_queries calls of vk_query; for injective RWMD over a contextual corpus whose sentences all have
+ * the same length 16 / 32 / 48 / 64 it runs as one MFMA-bound GEMM with the row / column minima as
+ * epilogue (every corpus byte read once per batch).  outs: [n_queries]. */
+int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, vk_topk_out *outs);
+
 /* every sentence's Score::value of the last query, for the debug hook
  * ('alignment' callback, metric/alignment.h:145-173).  host [n_sentences]. */
 int vk_last_scores(vk_corpus_t *c, float *scores, int64_t n);

@@ -1,0 +1,52 @@
+"""-m gpu: vk_query_batch.  The GEMM-shaped RWMD path (uniform sentence length, contextual layout) and
+the generic per-query fallback must both return what single vk_query calls / the oracle return."""
+
+import numpy as np
+import pytest
+
+from vectorian_amd import synth
+
+from helpers import assert_same_results, hip_contextual_corpus, prep_contextual, prep_query
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("length,d,len_t,flags", [
+	(32, 300, 10, (True, True, True)),
+	(16, 300, 5, (True, False, False)),
+	(48, 128, 16, (True, True, False)),
+	(64, 300, 3, (True, True, True)),
+])
+def test_rwmd_gemm_batch(hip, oracle, length, d, len_t, flags):
+	n = 1037   # not a multiple of the 4 x TPW tiles of a workgroup: exercises the tail
+	corpus = synth.make_contextual_corpus(n, length, length, 2000, d)
+	Xb = prep_contextual(corpus)
+	c = hip_contextual_corpus(hip, corpus, Xb)
+	qs = [prep_query(q) for q in synth.make_queries(corpus, 9, len_t)]
+	qs[3] = qs[3][:max(1, len_t - 2)]          # queries of different lengths in one batch
+	boost = np.random.default_rng(1).uniform(0.5, 1.5, size=n).astype(np.float32) if length == 32 else None
+	outs = c.query_batch(qs, algorithm=hip.VK_ALG_RWMD, rwmd=flags, q_normalize=False, max_matches=12, min_score=0.0, boost=boost)
+	assert len(outs) == len(qs)
+	for Qb, got in zip(qs, outs):
+		ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=corpus["sent_off"], X=Xb, Q=Qb,
+			algorithm=oracle.ALG_RWMD, rwmd=flags, max_matches=12, min_score=0.0, boost=boost)
+		assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=2e-5, tie_tol=2e-5)
+		single = c.query(Qb, algorithm=hip.VK_ALG_RWMD, rwmd=flags, q_normalize=False, max_matches=12, min_score=0.0, boost=boost)
+		np.testing.assert_allclose(got.score[:got.n], single.score[:single.n], atol=2e-6)
+	c.close()
+
+
+def test_batch_fallback_for_alignment_and_ragged(hip, oracle):
+	corpus = synth.make_contextual_corpus(400, 2, 30, 800, 64)
+	Xb = prep_contextual(corpus)
+	c = hip_contextual_corpus(hip, corpus, Xb)
+	qs = [prep_query(q) for q in synth.make_queries(corpus, 4, 6)]
+	outs = c.query_batch(qs, locality=0, gap_s=0.1, gap_t=0.1, q_normalize=False, max_matches=7)
+	for Qb, got in zip(qs, outs):
+		ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=64, sent_off=corpus["sent_off"], X=Xb, Q=Qb, gap_s=0.1, gap_t=0.1, max_matches=7)
+		assert_same_results(got.trimmed(), ref)
+	outs = c.query_batch(qs, algorithm=hip.VK_ALG_RWMD, q_normalize=False, max_matches=7)   # ragged: per-query path
+	for Qb, got in zip(qs, outs):
+		ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=64, sent_off=corpus["sent_off"], X=Xb, Q=Qb, algorithm=oracle.ALG_RWMD, max_matches=7)
+		assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=1e-5)
+	c.close()

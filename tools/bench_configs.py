@@ -32,6 +32,7 @@ def main():
 	ap.add_argument("--steps", type=int, default=10)
 	ap.add_argument("--warmup", type=int, default=2)
 	ap.add_argument("--k", type=int, default=10)
+	ap.add_argument("--batch", type=int, default=0, help="queries per vk_query_batch call (config 4: 256)")
 	args = ap.parse_args()
 
 	import torch
@@ -84,6 +85,41 @@ def main():
 	def step(q):
 		return corpus.query(q, algorithm=alg, locality=loc, gap_s=gap, gap_t=gap, q_normalize=True, max_matches=args.k,
 			min_score=0.0 if loc != 1 else -1e9, want_flow=args.alg == "align")
+
+	if args.batch > 0:
+		# BASELINE config 4: a batch of queries per call
+		bq = [np.ascontiguousarray(E[rng.integers(0, V, size=args.len_t)] + 0.05 * rng.standard_normal((args.len_t, args.d)).astype(np.float32), dtype=np.float32)
+			for _ in range(args.batch)]
+		for i in range(0, len(bq), 2):    # half of them planted
+			s_ = int(rng.integers(0, args.sentences)); st_ = int(off[s_])
+			qi = ids[st_:st_ + args.len_t]
+			if len(qi) == args.len_t:
+				bq[i] = np.ascontiguousarray(E[qi] + 0.05 * rng.standard_normal((args.len_t, args.d)).astype(np.float32), dtype=np.float32)
+		def bstep():
+			return corpus.query_batch(bq, algorithm=alg, locality=loc, gap_s=gap, gap_t=gap, q_normalize=True, max_matches=args.k,
+				min_score=0.0 if loc != 1 else -1e9, want_flow=False)
+		for i in range(args.warmup):
+			bstep()
+		torch.cuda.synchronize()
+		t0 = time.perf_counter()
+		ph = []
+		for i in range(args.steps):
+			outs = bstep()
+			ph.append(corpus.last_timings())
+		el = time.perf_counter() - t0
+		score_ms = float(np.mean([p["score_ms"] for p in ph]))
+		flops = 2.0 * n_tok * args.batch * args.len_t * args.d
+		flops_padded = 2.0 * n_tok * args.batch * 16 * ((args.d + 31) // 32 * 32)
+		print(json.dumps({
+			"alg": args.alg, "batch": args.batch, "d": args.d, "len_t": args.len_t, "len_s": [args.min_len, args.max_len],
+			"sentences": args.sentences, "pairs_per_s": args.sentences * args.batch * args.steps / el,
+			"ms_per_batch": el / args.steps * 1e3, "gemm_kernel_ms": score_ms,
+			"algorithmic_TFLOPs": flops / (score_ms * 1e-3) / 1e12, "issued_mfma_TFLOPs": flops_padded / (score_ms * 1e-3) / 1e12,
+			"frac_of_2.5PF_algorithmic": flops / (score_ms * 1e-3) / 2.5e15,
+			"phases_ms_mean": {k: float(np.mean([p[k] for p in ph])) for k in ph[0]},
+			"top_score_q0": float(outs[0].score[0]) if outs[0].n else None}))
+		corpus.close()
+		return
 
 	for i in range(args.warmup):
 		step(qs[i])

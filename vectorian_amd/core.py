@@ -83,7 +83,7 @@ EXPORTS = [
 	"vk_abi_version", "vk_last_error", "vk_init", "vk_device_count",
 	"vk_corpus_create", "vk_corpus_append_vectors", "vk_corpus_set_token_ids",
 	"vk_corpus_set_sentences", "vk_corpus_finalize", "vk_corpus_free", "vk_corpus_device_bytes",
-	"vk_query", "vk_last_scores", "vk_last_timings", "vk_merge_topk"]
+	"vk_query", "vk_query_batch", "vk_last_scores", "vk_last_timings", "vk_merge_topk"]
 
 _lib = None
 
@@ -106,6 +106,7 @@ def lib():
 		L.vk_corpus_free.argtypes = [C.c_void_p]
 		L.vk_corpus_device_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
 		L.vk_query.argtypes = [C.c_void_p, C.POINTER(_QueryDesc), C.POINTER(_TopkOut)]
+		L.vk_query_batch.argtypes = [C.c_void_p, C.POINTER(_QueryDesc), C.c_int32, C.POINTER(_TopkOut)]
 		L.vk_last_scores.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 		L.vk_last_timings.argtypes = [C.c_void_p, C.POINTER(_Timings)]
 		L.vk_merge_topk.argtypes = [C.POINTER(_TopkOut), C.c_int32, C.c_int32, C.c_int32, C.POINTER(_TopkOut)]
@@ -253,11 +254,9 @@ class Corpus:
 		_check(lib().vk_corpus_device_bytes(self._h, C.byref(b)))
 		return b.value
 
-	def query(self, q_vectors, *, locality=Locality.LOCAL, gap_s=0.0, gap_t=0.0, algorithm=VK_ALG_ALIGN,
+	def _desc(self, q_vectors, keep, *, locality=Locality.LOCAL, gap_s=0.0, gap_t=0.0, algorithm=VK_ALG_ALIGN,
 			q_token_ids=None, q_normalize=True, max_matches=10, min_score=0.0, boost=None, want_flow=True,
 			submatch_weight=0.0, bidirectional=False, rwmd=(True, True, True), wrd_normalize=True):
-		"""One query against the shard (vk_query).  Returns a TopK."""
-		keep = []
 		q_vectors = np.ascontiguousarray(q_vectors)
 		if q_vectors.dtype == np.uint16:
 			qdt = VK_BF16
@@ -266,6 +265,7 @@ class Corpus:
 			qdt = VK_F32
 		if q_vectors.ndim != 2 or q_vectors.shape[1] != self.d:
 			raise ValueError(f"expected [len_t x {self.d}] query vectors, got {q_vectors.shape}")
+		keep.append(q_vectors)
 		len_t = q_vectors.shape[0]
 		q = _QueryDesc()
 		q.algorithm, q.len_t = int(algorithm), len_t
@@ -280,7 +280,8 @@ class Corpus:
 		q.submatch_weight, q.bidirectional = float(submatch_weight), int(bool(bidirectional))
 		q.max_matches, q.min_score = int(max_matches), float(min_score)
 		if boost is not None:
-			b = np.ascontiguousarray(boost, dtype=np.float32)
+			b = boost if isinstance(boost, np.ndarray) and boost.dtype == np.float32 and boost.flags.c_contiguous \
+				else np.ascontiguousarray(boost, dtype=np.float32)
 			if len(b) != self.n_sentences:
 				raise ValueError("boost must have one entry per sentence")
 			keep.append(b)
@@ -288,11 +289,37 @@ class Corpus:
 		q.want_flow = int(bool(want_flow))
 		q.rwmd_injective, q.rwmd_symmetric, q.rwmd_normalize_bow = [int(bool(x)) for x in rwmd]
 		q.wrd_normalize_magnitudes = int(bool(wrd_normalize))
-		out = TopK(max(1, int(max_matches)), len_t)
+		return q, len_t
+
+	def query(self, q_vectors, **options):
+		"""One query against the shard (vk_query).  Returns a TopK."""
+		keep = []
+		q, len_t = self._desc(q_vectors, keep, **options)
+		out = TopK(max(1, q.max_matches), len_t)
 		so = out._struct()
 		_check(lib().vk_query(self._h, C.byref(q), C.byref(so)))
 		out.n = so.n_out
 		return out
+
+	def query_batch(self, queries, **options):
+		"""A batch of queries with common options (vk_query_batch).  Returns a list of TopK."""
+		keep = []
+		n = len(queries)
+		qs = (_QueryDesc * n)()
+		sos = (_TopkOut * n)()
+		outs = []
+		if options.get("boost") is not None:
+			options = dict(options, boost=np.ascontiguousarray(options["boost"], dtype=np.float32))
+		for i, qv in enumerate(queries):
+			q, len_t = self._desc(qv, keep, **options)
+			qs[i] = q
+			t = TopK(max(1, q.max_matches), len_t)
+			outs.append(t)
+			sos[i] = t._struct()
+		_check(lib().vk_query_batch(self._h, qs, n, sos))
+		for t, so in zip(outs, sos):
+			t.n = so.n_out
+		return outs
 
 	def last_scores(self):
 		s = np.empty(self.n_sentences, dtype=np.float32)

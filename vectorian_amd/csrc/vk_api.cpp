@@ -74,6 +74,9 @@ struct vk_corpus {
 	std::vector<int64_t> h_sent_off;
 	bool have_ids = false, have_sent = false, finalized = false;
 	int max_len = 0, max_group_tiles = 0, max_group_tokens = 0;
+	int uniform_len = 0;       // > 0: every sentence has exactly this many tokens
+	uint8_t *d_bq = nullptr; int32_t *d_bqlen = nullptr; float *d_bscores = nullptr; uint64_t *d_bkeys[2] = {nullptr, nullptr};
+	size_t bq_cap = 0, bscores_cap = 0, bkeys_cap = 0;
 	int64_t device_bytes = 0;
 	// workspaces
 	void *d_stage = nullptr;
@@ -187,7 +190,7 @@ int vk_corpus_free(vk_corpus_t *c) {
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	void *ptrs[] = {c->d_tiles, c->d_mag, c->d_tok_id, c->d_sent_off, c->d_stage, c->d_qtile, c->d_ws, c->d_wt, c->d_qids,
-		c->d_table, c->d_scores, c->d_raw, c->d_boost, c->d_keys[0], c->d_keys[1], c->d_out_raw, c->d_out_sim, c->d_out_map, c->d_wrd_raw, c->d_wrd_val};
+		c->d_table, c->d_scores, c->d_raw, c->d_boost, c->d_keys[0], c->d_keys[1], c->d_out_raw, c->d_out_sim, c->d_out_map, c->d_wrd_raw, c->d_wrd_val, c->d_bq, c->d_bqlen, c->d_bscores, c->d_bkeys[0], c->d_bkeys[1]};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -272,6 +275,13 @@ int vk_corpus_set_sentences(vk_corpus_t *c, const int64_t *sent_off, int64_t n_s
 	for (int64_t s = 0; s <= n_sentences; s++) off32[(size_t)s] = (int32_t)sent_off[s];
 	VK_HIP(hipMemcpy(c->d_sent_off, off32.data(), off32.size() * 4, hipMemcpyHostToDevice));
 	c->max_len = max_len;
+	c->uniform_len = 0;
+	if (n_sentences > 0) {
+		const int64_t l0 = sent_off[1] - sent_off[0];
+		bool uni = l0 > 0;
+		for (int64_t s = 1; s < n_sentences && uni; s++) uni = (sent_off[s + 1] - sent_off[s]) == l0;
+		if (uni) c->uniform_len = (int)l0;
+	}
 	// per wave: groups of 4 consecutive sentences
 	int mt = 1, mtok = 1;
 	for (int64_t g = 0; g * 4 < n_sentences; g++) {
@@ -632,6 +642,136 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) t.score_ms = ms;
 	if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) t.topk_ms = ms;
 	if (hipEventElapsedTime(&ms, c->ev[3], c->ev[4]) == hipSuccess) t.flow_ms = ms;
+	if (hipEventElapsedTime(&ms, c->ev[0], c->ev[4]) == hipSuccess) t.total_ms = ms;
+	c->last = t;
+	return VK_OK;
+}
+
+int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, vk_topk_out *outs) {
+	if (!c || !qs || !outs || n_queries < 0) return fail(VK_ERR_INVALID, "null argument");
+	if (n_queries == 0) return VK_OK;
+	// the GEMM path: injective RWMD, contextual layout, one sentence length (multiple of 16), common options
+	bool gemm = c->finalized && c->desc.layout == VK_LAYOUT_CONTEXTUAL && c->uniform_len > 0 && c->uniform_len % 16 == 0 &&
+		c->uniform_len <= 64 && c->desc.n_sentences > 0 && qs[0].max_matches <= 64 &&
+		((c->nk32 == 10 && c->tail == 1) || (c->nk32 == 4 && c->tail == 0));
+	for (int i = 0; i < n_queries && gemm; i++) {
+		const vk_query_desc &q = qs[i];
+		gemm = q.algorithm == VK_ALG_RWMD && q.rwmd_injective && q.rwmd_symmetric == qs[0].rwmd_symmetric &&
+			q.rwmd_normalize_bow == qs[0].rwmd_normalize_bow && q.max_matches == qs[0].max_matches &&
+			q.min_score == qs[0].min_score && q.boost == qs[0].boost;
+	}
+	if (!gemm) {
+		for (int i = 0; i < n_queries; i++) {
+			const int rc = vk_query(c, &qs[i], &outs[i]);
+			if (rc) return rc;
+		}
+		return VK_OK;
+	}
+	for (int i = 0; i < n_queries; i++) {
+		const int rc = validate_query(c, &qs[i], &outs[i]);
+		if (rc) return rc;
+	}
+	VK_HIP(hipSetDevice(c->device));
+	hipStream_t st = c->stream;
+	const int64_t n = c->desc.n_sentences;
+	const int k = qs[0].max_matches;
+	int rc;
+
+	// ---- device buffers (kept for the next batch)
+	const size_t need_q = (size_t)n_queries * c->tile_bytes;
+	if (c->bq_cap < need_q) {
+		if (c->d_bq) { VK_HIP(hipFree(c->d_bq)); VK_HIP(hipFree(c->d_bqlen)); }
+		if ((rc = alloc_t(c, &c->d_bq, need_q))) return rc;
+		if ((rc = alloc_t(c, &c->d_bqlen, (size_t)n_queries))) return rc;
+		c->bq_cap = need_q;
+	}
+	const size_t need_s = (size_t)n_queries * (size_t)n;
+	if (c->bscores_cap < need_s) {
+		if (c->d_bscores) VK_HIP(hipFree(c->d_bscores));
+		if ((rc = alloc_t(c, &c->d_bscores, need_s))) return rc;
+		c->bscores_cap = need_s;
+	}
+	const int64_t nw1 = (n + 4095) / 4096;
+	const size_t need_k = (size_t)n_queries * (size_t)nw1 * (size_t)k;
+	if (c->bkeys_cap < need_k) {
+		for (auto &b : c->d_bkeys) if (b) VK_HIP(hipFree(b));
+		if ((rc = alloc_t(c, &c->d_bkeys[0], need_k))) return rc;
+		if ((rc = alloc_t(c, &c->d_bkeys[1], need_k))) return rc;
+		c->bkeys_cap = need_k;
+	}
+
+	VK_HIP(hipEventRecord(c->ev[0], st));
+	std::vector<uint8_t> all((size_t)need_q), one;
+	std::vector<int32_t> qlen((size_t)n_queries);
+	float mags[VK_MAX_QUERY_LEN];
+	for (int i = 0; i < n_queries; i++) {
+		pack_query(c, &qs[i], one, mags);
+		memcpy(all.data() + (size_t)i * c->tile_bytes, one.data(), one.size());
+		qlen[(size_t)i] = qs[i].len_t;
+	}
+	VK_HIP(hipMemcpyAsync(c->d_bq, all.data(), all.size(), hipMemcpyHostToDevice, st));
+	VK_HIP(hipMemcpyAsync(c->d_bqlen, qlen.data(), qlen.size() * 4, hipMemcpyHostToDevice, st));
+	if (qs[0].boost) {
+		if (!c->d_boost) { rc = alloc_t(c, &c->d_boost, (size_t)n + 8); if (rc) return rc; }
+		VK_HIP(hipMemcpyAsync(c->d_boost, qs[0].boost, (size_t)n * 4, hipMemcpyHostToDevice, st));
+	}
+
+	VK_HIP(hipEventRecord(c->ev[1], st));
+	VkRwmdBatchParams p{};
+	p.tiles = c->d_tiles; p.n_tiles = (c->desc.n_tokens + 15) / 16;
+	p.tile_bytes = c->tile_bytes; p.nk = c->nk32; p.half = c->tail;
+	p.qtiles = c->d_bq; p.q_len = c->d_bqlen; p.n_queries = n_queries; p.n_sent = (int32_t)n;
+	p.tiles_per_sent = c->uniform_len / 16;
+	p.symmetric = qs[0].rwmd_symmetric; p.nbow = qs[0].rwmd_normalize_bow;
+	p.boost = qs[0].boost ? c->d_boost : nullptr;
+	p.scores = c->d_bscores;
+	VK_HIP(vk_launch_rwmd_batch(&p, st));
+
+	VK_HIP(hipEventRecord(c->ev[2], st));
+	int64_t nw = 0;
+	int cur = 0;
+	VK_HIP(vk_launch_topk_wave_batch(c->d_bscores, nullptr, n, qs[0].min_score, k, 4096, n_queries, n, nw1 * k, c->d_bkeys[0], &nw, st));
+	int64_t stride = nw1 * k;
+	while (nw > 1) {
+		const int64_t nkeys = nw * k;
+		const int64_t per_wave = nkeys <= 16384 ? nkeys : 4096;
+		VK_HIP(vk_launch_topk_wave_batch(nullptr, c->d_bkeys[cur], nkeys, 0.0f, k, per_wave, n_queries, stride, stride, c->d_bkeys[1 - cur], &nw, st));
+		cur = 1 - cur;
+	}
+	VK_HIP(hipEventRecord(c->ev[3], st));
+	VK_HIP(hipEventRecord(c->ev[4], st));
+	std::vector<uint64_t> keys((size_t)n_queries * (size_t)k);
+	VK_HIP(hipMemcpy2DAsync(keys.data(), (size_t)k * 8, c->d_bkeys[cur], (size_t)stride * 8, (size_t)k * 8, (size_t)n_queries, hipMemcpyDeviceToHost, st));
+	VK_HIP(hipStreamSynchronize(st));
+	for (int i = 0; i < n_queries; i++) {
+		vk_topk_out *out = &outs[i];
+		int n_out = 0;
+		for (int j = 0; j < k; j++) {
+			const uint64_t key = keys[(size_t)i * k + j];
+			if (key == 0) break;
+			const uint32_t ob = (uint32_t)(key >> 32);
+			const uint32_t bits = (ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob;
+			float s;
+			memcpy(&s, &bits, 4);
+			const int64_t g = (int64_t)(uint32_t)(key & 0xffffffffu);
+			out->score[j] = s;
+			out->sentence[j] = g;
+			if (out->raw_score) out->raw_score[j] = (qs[i].boost ? s / qs[i].boost[g] : s) * (float)qs[i].len_t;
+			if (qs[i].want_flow && out->mapping && out->edge_sim)
+				for (int t = 0; t < qs[i].len_t; t++) {
+					out->mapping[(size_t)j * qs[i].len_t + t] = -1;
+					out->edge_sim[(size_t)j * qs[i].len_t + t] = 0.0f;
+				}
+			n_out++;
+		}
+		out->n_out = n_out;
+	}
+	c->have_scores = false;
+	float ms = 0;
+	vk_timings t{};
+	if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) t.prepare_ms = ms;
+	if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) t.score_ms = ms;
+	if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) t.topk_ms = ms;
 	if (hipEventElapsedTime(&ms, c->ev[0], c->ev[4]) == hipSuccess) t.total_ms = ms;
 	c->last = t;
 	return VK_OK;

@@ -49,6 +49,20 @@ struct VkScoreParams {
 	int32_t h_rows;            // general gap: history rows per sentence (max_len + 1)
 };
 
+struct VkRwmdBatchParams {
+	const uint8_t *tiles;      // corpus token tiles
+	int64_t n_tiles;
+	int32_t tile_bytes, nk, half;
+	const uint8_t *qtiles;     // [n_queries] query tiles, back to back
+	const int32_t *q_len;      // [n_queries]
+	int32_t n_queries;
+	int32_t n_sent;
+	int32_t tiles_per_sent;    // every sentence has 16 * tiles_per_sent tokens
+	int32_t symmetric, nbow;
+	const float *boost;
+	float *scores;             // [n_queries x n_sent]
+};
+
 struct VkWrdParams {
 	const uint8_t *tiles;
 	const int32_t *tok_id;
@@ -101,6 +115,9 @@ hipError_t vk_launch_topk_keys(const uint64_t *in, int64_t n, int32_t k, uint64_
 hipError_t vk_launch_topk_wave(const float *scores, const uint64_t *keys_in, int64_t n, float min_score, int32_t k,
 	int64_t per_wave, uint64_t *out, int64_t *n_waves_out, hipStream_t stream);
 hipError_t vk_launch_flow(const VkFlowParams *p, int32_t k, hipStream_t stream);
+hipError_t vk_launch_rwmd_batch(const VkRwmdBatchParams *p, hipStream_t stream);
+hipError_t vk_launch_topk_wave_batch(const float *scores, const uint64_t *keys_in, int64_t n, float min_score, int32_t k,
+	int64_t per_wave, int32_t n_queries, int64_t in_stride, int64_t out_stride, uint64_t *out, int64_t *n_waves_out, hipStream_t stream);
 hipError_t vk_launch_wrd_exact(const VkWrdParams *p, int32_t n_cand, float *scores_to_mark, hipStream_t stream);
 #ifdef __cplusplus
 }

@@ -829,6 +829,191 @@ __global__ __launch_bounds__(256) void vk_topk_wave_kernel(const float *__restri
 }
 
 // ---------------------------------------------------------------------------
+// Batched relaxed Word Mover's Distance (BASELINE config 4: 256 queries x 1M sentences):
+// a GEMM [T x d] . [d x (B * 16)] on MFMA with the row / column minima and the RWMD score as
+// epilogue.  MFMA-bound (intensity ~2.5 kFLOP per corpus byte), so the corpus tokens stay in
+// registers and the queries stream past them:
+//   workgroup = 4 waves; each wave loads TPW token tiles (64 tokens for TPW = 4) ONCE into
+//   registers as MFMA B operands; the B query tiles (A operands, one 16-row tile per query) are
+//   staged one after the other into a double-buffered LDS slot shared by the 4 waves
+//   (global -> registers -> LDS while the previous query's MFMAs run), so every query byte is
+//   fetched from L2 once per 256 tokens and every corpus byte from HBM once per batch.
+// Requires sentences of one length L = 16 * TPS (the config's shape); other corpora take the
+// per-query path.  Scores: scores[q * n_sent + s] = Score::value as in rwmd_rows.
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ float xor16_f(float x) {
+	return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), (0x10 << 10) | 0x1f));
+}
+
+// partner lane l ^ 32 through ds_bpermute.  (v_permlane32_swap would be cheaper, but the builtin's
+// second result did not deliver the upper halves here -- tools/probe/xlane_probe.hip -- so it is not used.)
+__device__ __forceinline__ float xor32_f(float x, int lane) {
+	return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, x)));
+}
+
+template <int NK, bool HALF, int TPS>
+__global__ __launch_bounds__(256, 2) void vk_rwmd_batch_kernel(VkRwmdBatchParams p) {
+	constexpr int TPW = TPS == 3 ? 3 : 4;          // token tiles per wave
+	constexpr int SPW = TPW / TPS;                 // sentences per wave
+	extern __shared__ float4 vk_smem4[];
+	uint8_t *qbuf = reinterpret_cast<uint8_t *>(vk_smem4);   // 2 x tile_bytes
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int g4 = lane >> 4;
+	const int n16 = p.tile_bytes >> 4;             // 16-byte pieces of one query tile
+	const int64_t n_chunks = (p.n_tiles + TPW * 4 - 1) / (TPW * 4);
+
+	for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+		const int64_t tile0 = chunk * (TPW * 4) + (int64_t)wv * TPW;
+		// ---- corpus tiles of this wave -> registers (read once per batch)
+		bf16x8 x[TPW][NK];
+#pragma unroll
+		for (int tt = 0; tt < TPW; tt++) {
+			const int64_t tile = tile0 + tt < p.n_tiles ? tile0 + tt : p.n_tiles;   // one zero tile follows the corpus
+			const uint8_t *tp = p.tiles + tile * p.tile_bytes;
+#pragma unroll
+			for (int t = 0; t < NK; t++) {
+				if (HALF && t == NK - 1) x[tt][t] = load_half_block(tp + t * 1024, lane, true);
+				else x[tt][t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(tp + t * 1024 + lane * 16));
+			}
+		}
+		// ---- stage query 0
+		__syncthreads();   // previous chunk's readers are done with the LDS slots
+		for (int i = threadIdx.x; i < n16; i += 256)
+			vk_smem4[i] = *reinterpret_cast<const float4 *>(p.qtiles + i * 16);
+		__syncthreads();
+
+		for (int q = 0; q < p.n_queries; q++) {
+			const uint8_t *cur = qbuf + (q & 1) * p.tile_bytes;
+			float4 *nxt = vk_smem4 + ((q + 1) & 1) * n16;
+			// prefetch the next query tile into registers (<= 3 pieces per thread for d <= 384)
+			float4 st0 = {0, 0, 0, 0}, st1 = st0, st2 = st0;
+			const bool more = q + 1 < p.n_queries;
+			if (more) {
+				const uint8_t *src = p.qtiles + (int64_t)(q + 1) * p.tile_bytes;
+				const int i0 = threadIdx.x, i1 = threadIdx.x + 256, i2 = threadIdx.x + 512;
+				if (i0 < n16) st0 = *reinterpret_cast<const float4 *>(src + i0 * 16);
+				if (i1 < n16) st1 = *reinterpret_cast<const float4 *>(src + i1 * 16);
+				if (i2 < n16) st2 = *reinterpret_cast<const float4 *>(src + i2 * 16);
+			}
+			// ---- S^T = Q X^T for TPW tiles
+			f32x4 acc[TPW];
+#pragma unroll
+			for (int tt = 0; tt < TPW; tt++) acc[tt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+			for (int t = 0; t < NK; t++) {
+				bf16x8 a = *reinterpret_cast<const bf16x8 *>(cur + t * 1024 + ((HALF && t == NK - 1) ? (lane & 31) : lane) * 16);
+				if (HALF && t == NK - 1) {
+					const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+					a = lane < 32 ? a : z;
+				}
+#pragma unroll
+				for (int tt = 0; tt < TPW; tt++) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, x[tt][t], acc[tt], 0, 0, 0);
+			}
+			if (more) {
+				const int i0 = threadIdx.x, i1 = threadIdx.x + 256, i2 = threadIdx.x + 512;
+				if (i0 < n16) nxt[i0] = st0;
+				if (i1 < n16) nxt[i1] = st1;
+				if (i2 < n16) nxt[i2] = st2;
+			}
+			// ---- epilogue: D = 1 - clip(S); lane holds token (lane & 15) x query columns 4*g4 .. +3
+			const int len_t = p.q_len[q];
+			const float w_t = p.nbow ? 1.0f / (float)len_t : 1.0f;
+			const float w_s = p.nbow ? 1.0f / (float)(TPS * 16) : 1.0f;
+#pragma unroll
+			for (int sw = 0; sw < SPW; sw++) {
+				float cm[4] = {3.0f, 3.0f, 3.0f, 3.0f};
+				float rsum = 0.0f;
+#pragma unroll
+				for (int ts = 0; ts < TPS; ts++) {
+					const f32x4 a4 = acc[sw * TPS + ts];
+					float dd[4];
+#pragma unroll
+					for (int r = 0; r < 4; r++) {
+						dd[r] = 1.0f - clip01(a4[r]);
+						cm[r] = fminf(cm[r], dd[r]);
+					}
+					// padded query columns have S = 0, D = 1: they never lower a minimum
+					float rm = fminf(fminf(dd[0], dd[1]), fminf(dd[2], dd[3]));
+					rm = fminf(rm, xor16_f(rm));
+					rm = fminf(rm, xor32_f(rm, lane));
+					rsum += rm;                       // row minimum of token (lane & 15) of this tile
+				}
+				// column minima over the sentence's tokens: reduce over the 16 lanes of the DPP row
+#pragma unroll
+				for (int r = 0; r < 4; r++) {
+					cm[r] = fminf(cm[r], dpp_f<DPP_ROW_SHR1>(cm[r], cm[r]));
+					cm[r] = fminf(cm[r], dpp_f<DPP_ROW_SHR2>(cm[r], cm[r]));
+					cm[r] = fminf(cm[r], dpp_f<DPP_ROW_SHR4>(cm[r], cm[r]));
+					cm[r] = fminf(cm[r], dpp_f<DPP_ROW_SHR8>(cm[r], cm[r]));
+				}
+				float c0 = 0.0f;
+#pragma unroll
+				for (int r = 0; r < 4; r++) c0 += (4 * g4 + r < len_t) ? cm[r] : 0.0f;   // valid in lane 15 of each row
+				c0 += xor16_f(c0);
+				c0 += xor32_f(c0, lane);               // lanes 15/31/47/63: sum over all query columns
+				rsum += dpp_f<DPP_ROW_SHR1>(0.0f, rsum);
+				rsum += dpp_f<DPP_ROW_SHR2>(0.0f, rsum);
+				rsum += dpp_f<DPP_ROW_SHR4>(0.0f, rsum);
+				rsum += dpp_f<DPP_ROW_SHR8>(0.0f, rsum);   // lane 15: sum over the sentence's tokens
+				float acc0 = w_t * c0, acc1 = w_s * rsum;
+				if (!p.nbow) {
+					acc0 = acc0 / (float)len_t;
+					acc1 = acc1 / (float)(TPS * 16);
+				}
+				float cost = p.symmetric ? fmaxf(0.0f, fmaxf(acc0, acc1)) : acc0;
+				const float max_cost = p.nbow ? 1.0f : (float)len_t;
+				const float raw = (max_cost - cost) / max_cost;
+				const int64_t sent = (tile0 + sw * TPS) / TPS;
+				if (lane == 15 && sent < p.n_sent) {
+					const float boost = p.boost ? p.boost[sent] : 1.0f;
+					p.scores[(int64_t)q * p.n_sent + sent] = (raw / (float)len_t) * boost;
+				}
+			}
+			__syncthreads();   // next query tile is in place; this one may be overwritten
+		}
+	}
+}
+
+// per-query selection over the [B x n] score matrix: blockIdx.y = query
+template <int FROM_KEYS>
+__global__ __launch_bounds__(256) void vk_topk_wave_batch_kernel(const float *__restrict__ scores, const uint64_t *__restrict__ keys_in,
+	int64_t n, float min_score, int32_t k, int64_t per_wave, int64_t in_stride, int64_t out_stride, uint64_t *__restrict__ out) {
+	const int lane = threadIdx.x & 63;
+	const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	const int64_t a = wave * per_wave;
+	if (a >= n) return;
+	const int64_t b = a + per_wave < n ? a + per_wave : n;
+	const float *sc = scores ? scores + (int64_t)blockIdx.y * in_stride : nullptr;
+	const uint64_t *ki = keys_in ? keys_in + (int64_t)blockIdx.y * in_stride : nullptr;
+	uint64_t mine = 0, thr = 0;
+	for (int64_t base = a; base < b; base += 64) {
+		const int64_t g = base + lane;
+		uint64_t key = 0;
+		if (g < b) {
+			if (FROM_KEYS) key = ki[g];
+			else {
+				const float s = sc[g];
+				if (s > min_score) key = ((uint64_t)float_orderable(s) << 32) | (uint32_t)g;
+			}
+		}
+		bool pending = key > thr;
+		for (;;) {
+			const unsigned long long mask = __ballot(pending && key > thr);
+			if (mask == 0) break;
+			const int src = __builtin_ctzll(mask);
+			const uint64_t nk = __shfl(key, src, 64);
+			if (lane == src) pending = false;
+			uint64_t up = __shfl_up(mine, 1, 64);
+			if (lane == 0) up = ~0ull;
+			mine = (mine >= nk) ? mine : ((up >= nk) ? nk : up);
+			thr = __shfl(mine, k - 1, 64);
+		}
+	}
+	if (lane < k) out[(int64_t)blockIdx.y * out_stride + wave * k + lane] = mine;
+}
+
+// ---------------------------------------------------------------------------
 // flow of the winners: one wave per winner recomputes the similarity rows with the
 // same MFMA sequence as the scoring kernel, then lane 0 runs the sequential DP with
 // traceback exactly as the oracle states it (vko_align in oracle/vk_oracle.c):
@@ -1282,6 +1467,40 @@ extern "C" hipError_t vk_launch_topk_wave(const float *scores, const uint64_t *k
 	const unsigned grid = (unsigned)((nw + 3) / 4);
 	if (keys_in) vk_topk_wave_kernel<1><<<grid, 256, 0, stream>>>(nullptr, keys_in, n, min_score, k, per_wave, out);
 	else vk_topk_wave_kernel<0><<<grid, 256, 0, stream>>>(scores, nullptr, n, min_score, k, per_wave, out);
+	*n_waves_out = nw;
+	return hipGetLastError();
+}
+
+template <int NK, bool HALF>
+static hipError_t launch_rwmd_batch_tps(const VkRwmdBatchParams &p, size_t smem, hipStream_t stream) {
+	int dev = 0, cus = 256;
+	if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+	const int tpw = p.tiles_per_sent == 3 ? 3 : 4;
+	const int64_t n_chunks = (p.n_tiles + tpw * 4 - 1) / (tpw * 4);
+	const int grid = (int)(n_chunks < (int64_t)cus * 2 ? n_chunks : (int64_t)cus * 2);
+	switch (p.tiles_per_sent) {
+	case 1: vk_rwmd_batch_kernel<NK, HALF, 1><<<grid, 256, smem, stream>>>(p); break;
+	case 2: vk_rwmd_batch_kernel<NK, HALF, 2><<<grid, 256, smem, stream>>>(p); break;
+	case 3: vk_rwmd_batch_kernel<NK, HALF, 3><<<grid, 256, smem, stream>>>(p); break;
+	default: vk_rwmd_batch_kernel<NK, HALF, 4><<<grid, 256, smem, stream>>>(p); break;
+	}
+	return hipGetLastError();
+}
+
+// returns hipErrorNotSupported when no batched kernel exists for this corpus shape
+extern "C" hipError_t vk_launch_rwmd_batch(const VkRwmdBatchParams *p, hipStream_t stream) {
+	const size_t smem = (size_t)p->tile_bytes * 2;
+	if (p->nk == 10 && p->half == 1) return launch_rwmd_batch_tps<10, true>(*p, smem, stream);
+	if (p->nk == 4 && p->half == 0) return launch_rwmd_batch_tps<4, false>(*p, smem, stream);
+	return hipErrorNotSupported;
+}
+
+extern "C" hipError_t vk_launch_topk_wave_batch(const float *scores, const uint64_t *keys_in, int64_t n, float min_score, int32_t k,
+	int64_t per_wave, int32_t n_queries, int64_t in_stride, int64_t out_stride, uint64_t *out, int64_t *n_waves_out, hipStream_t stream) {
+	const int64_t nw = (n + per_wave - 1) / per_wave;
+	const dim3 grid((unsigned)((nw + 3) / 4), (unsigned)n_queries);
+	if (keys_in) vk_topk_wave_batch_kernel<1><<<grid, 256, 0, stream>>>(nullptr, keys_in, n, min_score, k, per_wave, in_stride, out_stride, out);
+	else vk_topk_wave_batch_kernel<0><<<grid, 256, 0, stream>>>(scores, nullptr, n, min_score, k, per_wave, in_stride, out_stride, out);
 	*n_waves_out = nw;
 	return hipGetLastError();
 }
