@@ -846,6 +846,13 @@ __device__ __forceinline__ float xor16_f(float x) {
 	return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), (0x10 << 10) | 0x1f));
 }
 
+// DPP row broadcast used by wave reductions: CTRL 0x142 = row_bcast:15 (lane 15 of each row to the next
+// row), 0x143 = row_bcast:31; ROWS = row_mask of the rows that receive.  Lanes outside get 0.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float dpp_bcast(float x) {
+	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROWS, 0xf, false));
+}
+
 // partner lane l ^ 32 through ds_bpermute.  (v_permlane32_swap would be cheaper, but the builtin's
 // second result did not deliver the upper halves here -- tools/probe/xlane_probe.hip -- so it is not used.)
 __device__ __forceinline__ float xor32_f(float x, int lane) {
@@ -900,15 +907,21 @@ __global__ __launch_bounds__(256, 2) void vk_rwmd_batch_kernel(VkRwmdBatchParams
 			f32x4 acc[TPW];
 #pragma unroll
 			for (int tt = 0; tt < TPW; tt++) acc[tt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+			// query fragments: all NK ds_read_b128 are issued up front (40 VGPRs for d = 300) so the MFMAs
+			// of step t never wait for the LDS latency of step t
+			bf16x8 af[NK];
 #pragma unroll
 			for (int t = 0; t < NK; t++) {
-				bf16x8 a = *reinterpret_cast<const bf16x8 *>(cur + t * 1024 + ((HALF && t == NK - 1) ? (lane & 31) : lane) * 16);
+				af[t] = *reinterpret_cast<const bf16x8 *>(cur + t * 1024 + ((HALF && t == NK - 1) ? (lane & 31) : lane) * 16);
 				if (HALF && t == NK - 1) {
 					const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-					a = lane < 32 ? a : z;
+					af[t] = lane < 32 ? af[t] : z;
 				}
+			}
 #pragma unroll
-				for (int tt = 0; tt < TPW; tt++) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, x[tt][t], acc[tt], 0, 0, 0);
+			for (int t = 0; t < NK; t++) {
+#pragma unroll
+				for (int tt = 0; tt < TPW; tt++) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t], x[tt][t], acc[tt], 0, 0, 0);
 			}
 			if (more) {
 				const int i0 = threadIdx.x, i1 = threadIdx.x + 256, i2 = threadIdx.x + 512;
@@ -916,58 +929,72 @@ __global__ __launch_bounds__(256, 2) void vk_rwmd_batch_kernel(VkRwmdBatchParams
 				if (i1 < n16) nxt[i1] = st1;
 				if (i2 < n16) nxt[i2] = st2;
 			}
-			// ---- epilogue: D = 1 - clip(S); lane holds token (lane & 15) x query columns 4*g4 .. +3
+			// ---- epilogue: D = 1 - clip(S); lane holds token (lane & 15) x query columns 4*g4 .. +3.
+			// Lane exchanges across the four 16-lane rows go through the LDS crossbar (ds_swizzle /
+			// ds_bpermute); the exchanges of all tiles are issued back to back so their latencies overlap.
+			// (reciprocals instead of the oracle's divisions: a batch epilogue runs per (query, sentence) and
+			// is VALU-bound; the results differ from the per-query kernel by <= 1 ulp, far inside 1e-4)
 			const int len_t = p.q_len[q];
-			const float w_t = p.nbow ? 1.0f / (float)len_t : 1.0f;
-			const float w_s = p.nbow ? 1.0f / (float)(TPS * 16) : 1.0f;
+			const float inv_t = 1.0f / (float)len_t;
+			const float inv_s = 1.0f / (float)(TPS * 16);
+			float rm[TPW], cm[SPW][4];
+#pragma unroll
+			for (int sw = 0; sw < SPW; sw++)
+#pragma unroll
+				for (int r = 0; r < 4; r++) cm[sw][r] = 3.0f;
+#pragma unroll
+			for (int tt = 0; tt < TPW; tt++) {
+				const f32x4 a4 = acc[tt];
+				float dd[4];
+#pragma unroll
+				for (int r = 0; r < 4; r++) {
+					dd[r] = 1.0f - clip01(a4[r]);
+					cm[tt / TPS][r] = fminf(cm[tt / TPS][r], dd[r]);
+				}
+				// padded query columns have S = 0, D = 1: they never lower a minimum
+				rm[tt] = fminf(fminf(dd[0], dd[1]), fminf(dd[2], dd[3]));
+			}
+			float ex[TPW];
+#pragma unroll
+			for (int tt = 0; tt < TPW; tt++) ex[tt] = xor16_f(rm[tt]);
+#pragma unroll
+			for (int tt = 0; tt < TPW; tt++) rm[tt] = fminf(rm[tt], ex[tt]);
+#pragma unroll
+			for (int tt = 0; tt < TPW; tt++) ex[tt] = xor32_f(rm[tt], lane);
+#pragma unroll
+			for (int tt = 0; tt < TPW; tt++) rm[tt] = fminf(rm[tt], ex[tt]);   // row minimum of token (lane & 15) of tile tt
 #pragma unroll
 			for (int sw = 0; sw < SPW; sw++) {
-				float cm[4] = {3.0f, 3.0f, 3.0f, 3.0f};
 				float rsum = 0.0f;
 #pragma unroll
-				for (int ts = 0; ts < TPS; ts++) {
-					const f32x4 a4 = acc[sw * TPS + ts];
-					float dd[4];
-#pragma unroll
-					for (int r = 0; r < 4; r++) {
-						dd[r] = 1.0f - clip01(a4[r]);
-						cm[r] = fminf(cm[r], dd[r]);
-					}
-					// padded query columns have S = 0, D = 1: they never lower a minimum
-					float rm = fminf(fminf(dd[0], dd[1]), fminf(dd[2], dd[3]));
-					rm = fminf(rm, xor16_f(rm));
-					rm = fminf(rm, xor32_f(rm, lane));
-					rsum += rm;                       // row minimum of token (lane & 15) of this tile
-				}
+				for (int ts = 0; ts < TPS; ts++) rsum += rm[sw * TPS + ts];
 				// column minima over the sentence's tokens: reduce over the 16 lanes of the DPP row
 #pragma unroll
 				for (int r = 0; r < 4; r++) {
-					cm[r] = fminf(cm[r], dpp_f<DPP_ROW_SHR1>(cm[r], cm[r]));
-					cm[r] = fminf(cm[r], dpp_f<DPP_ROW_SHR2>(cm[r], cm[r]));
-					cm[r] = fminf(cm[r], dpp_f<DPP_ROW_SHR4>(cm[r], cm[r]));
-					cm[r] = fminf(cm[r], dpp_f<DPP_ROW_SHR8>(cm[r], cm[r]));
+					float x = cm[sw][r];
+					x = fminf(x, dpp_f<DPP_ROW_SHR1>(x, x));
+					x = fminf(x, dpp_f<DPP_ROW_SHR2>(x, x));
+					x = fminf(x, dpp_f<DPP_ROW_SHR4>(x, x));
+					x = fminf(x, dpp_f<DPP_ROW_SHR8>(x, x));
+					cm[sw][r] = x;
 				}
 				float c0 = 0.0f;
 #pragma unroll
-				for (int r = 0; r < 4; r++) c0 += (4 * g4 + r < len_t) ? cm[r] : 0.0f;   // valid in lane 15 of each row
-				c0 += xor16_f(c0);
-				c0 += xor32_f(c0, lane);               // lanes 15/31/47/63: sum over all query columns
+				for (int r = 0; r < 4; r++) c0 += (4 * g4 + r < len_t) ? cm[sw][r] : 0.0f;   // valid in lane 15 of each row
+				// sum of the four rows' lane 15 -> lane 63 (row_bcast:15 into rows 1, 3; row_bcast:31 into rows 2, 3)
+				c0 += dpp_bcast<0x142, 0xa>(c0);
+				c0 += dpp_bcast<0x143, 0xc>(c0);
 				rsum += dpp_f<DPP_ROW_SHR1>(0.0f, rsum);
 				rsum += dpp_f<DPP_ROW_SHR2>(0.0f, rsum);
 				rsum += dpp_f<DPP_ROW_SHR4>(0.0f, rsum);
-				rsum += dpp_f<DPP_ROW_SHR8>(0.0f, rsum);   // lane 15: sum over the sentence's tokens
-				float acc0 = w_t * c0, acc1 = w_s * rsum;
-				if (!p.nbow) {
-					acc0 = acc0 / (float)len_t;
-					acc1 = acc1 / (float)(TPS * 16);
-				}
-				float cost = p.symmetric ? fmaxf(0.0f, fmaxf(acc0, acc1)) : acc0;
-				const float max_cost = p.nbow ? 1.0f : (float)len_t;
-				const float raw = (max_cost - cost) / max_cost;
+				rsum += dpp_f<DPP_ROW_SHR8>(0.0f, rsum);   // lane 15 of every row: sum over the sentence's tokens
+				const float acc0 = inv_t * c0, acc1 = inv_s * rsum;      // nbow and bow/len agree up to rounding
+				const float cost = p.symmetric ? fmaxf(0.0f, fmaxf(acc0, acc1)) : acc0;
+				const float raw = p.nbow ? 1.0f - cost : ((float)len_t - cost) * inv_t;
 				const int64_t sent = (tile0 + sw * TPS) / TPS;
-				if (lane == 15 && sent < p.n_sent) {
+				if (lane == 63 && sent < p.n_sent) {
 					const float boost = p.boost ? p.boost[sent] : 1.0f;
-					p.scores[(int64_t)q * p.n_sent + sent] = (raw / (float)len_t) * boost;
+					p.scores[(int64_t)q * p.n_sent + sent] = (raw * inv_t) * boost;
 				}
 			}
 			__syncthreads();   // next query tile is in place; this one may be overwritten
