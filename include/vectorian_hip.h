@@ -149,6 +149,10 @@ int vk_corpus_set_token_ids(vk_corpus_t *c, const int32_t *ids, int64_t n, int32
 /* sentence spans as CSR offsets in token units, contiguous from 0
  * (Spans::iterate, document.h:147-169).  sent_off: host [n_sentences + 1]. */
 int vk_corpus_set_sentences(vk_corpus_t *c, const int64_t *sent_off, int64_t n_sentences);
+/* general slices, e.g. sliding windows with window_step != window_size (Spans::iterate with
+ * bounded_len, document.h:147-169): slice i = tokens [start[i], end[i]); starts and ends non-decreasing,
+ * at most VK_MAX_SENT_LEN tokens each; slices may overlap or leave gaps.  host arrays [n_sentences]. */
+int vk_corpus_set_slices(vk_corpus_t *c, const int64_t *start, const int64_t *end, int64_t n_sentences);
 int vk_corpus_finalize(vk_corpus_t *c);
 int vk_corpus_free(vk_corpus_t *c);
 int vk_corpus_device_bytes(const vk_corpus_t *c, int64_t *bytes);

@@ -838,7 +838,7 @@ static int score_sentence(const work *w, int64_t s, float *Sbuf, float *xbuf, fl
 
 	const vko_corpus *c = w->c;
 	const vko_query *q = w->q;
-	const int64_t t0 = c->sent_off[s], t1 = c->sent_off[s + 1];
+	const int64_t t0 = c->sent_off[s], t1 = c->sent_end ? c->sent_end[s] : c->sent_off[s + 1];
 	const int32_t len_s = (int32_t)(t1 - t0), len_t = q->len_t;
 	if (len_s < 1) return 1; /* document.h:160 */
 	if (len_s > VKO_MAX_LEN_S) return 2;

@@ -117,6 +117,7 @@ typedef struct {
 	const uint16_t *E;        /* static: bf16 [V x d] unit rows */
 	int32_t V;
 	const int64_t *sent_off;  /* [n_sentences+1], token units, contiguous (document.h:147-169, B8) */
+	const int64_t *sent_end;  /* optional [n_sentences]: slice s = [sent_off[s], sent_end[s]) (sliding windows) */
 } vko_corpus;
 
 typedef struct {

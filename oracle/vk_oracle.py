@@ -40,7 +40,7 @@ class Corpus(C.Structure):
 		("n_tokens", C.c_int64), ("n_sentences", C.c_int64),
 		("X", C.c_void_p), ("X_mag", C.c_void_p),
 		("tok_id", C.c_void_p), ("E", C.c_void_p), ("V", C.c_int32),
-		("sent_off", C.c_void_p)]
+		("sent_off", C.c_void_p), ("sent_end", C.c_void_p)]
 
 
 class Query(C.Structure):
@@ -244,7 +244,7 @@ def emd(a, b, Cm):
 
 # ---- whole-corpus search --------------------------------------------------
 
-def find_many(*, layout, d, sent_off, Qs, X=None, X_mag=None, tok_id=None, E=None,
+def find_many(*, layout, d, sent_off, Qs, sent_end=None, X=None, X_mag=None, tok_id=None, E=None,
 		algorithm=ALG_ALIGN, locality=LOCAL, gap_s=0.0, gap_t=0.0, q_ids=None, Q_mags=None,
 		max_matches=10, min_score=0.0, boost=None, submatch_weight=0.0,
 		rwmd=(True, True, True), wrd_normalize=True, n_threads=1, want_all_scores=False):
@@ -254,8 +254,12 @@ def find_many(*, layout, d, sent_off, Qs, X=None, X_mag=None, tok_id=None, E=Non
 	c = Corpus()
 	sent_off = np.ascontiguousarray(sent_off, dtype=np.int64)
 	n_sent = len(sent_off) - 1
+	if sent_end is not None:
+		sent_end = np.ascontiguousarray(sent_end, dtype=np.int64)
+		n_sent = len(sent_end)
+		c.sent_end = _ptr(sent_end)
 	c.layout, c.d = layout, d
-	c.n_tokens, c.n_sentences = int(sent_off[-1]), n_sent
+	c.n_tokens, c.n_sentences = int(max(sent_off[-1], sent_end[-1] if sent_end is not None and len(sent_end) else 0)), n_sent
 	if X is not None:
 		X = np.ascontiguousarray(X, dtype=np.uint16); c.X = _ptr(X)
 	if X_mag is not None:

@@ -44,6 +44,11 @@ class OracleCorpus:
 
 	def set_sentences(self, off):
 		self._off = np.ascontiguousarray(off, dtype=np.int64)
+		self._end = None
+
+	def set_slices(self, start, end):
+		self._off = np.ascontiguousarray(start, dtype=np.int64)
+		self._end = np.ascontiguousarray(end, dtype=np.int64)
 
 	def finalize(self):
 		self._X = np.concatenate(self._rows) if self._rows else np.zeros((0, self.d), np.uint16)
@@ -60,7 +65,7 @@ class OracleCorpus:
 			Qb, qmag = vo.normalize_rows_bf16(q)
 		else:
 			Qb, qmag = synth.to_bf16_bits(q), np.ones(len(q), np.float32)
-		kw = dict(layout=self.layout, d=self.d, sent_off=self._off, Q=Qb, algorithm=algorithm, locality=int(locality),
+		kw = dict(layout=self.layout, d=self.d, sent_off=self._off, sent_end=self._end, Q=Qb, algorithm=algorithm, locality=int(locality),
 			gap_s=_gap(gap_s), gap_t=_gap(gap_t), max_matches=max_matches, min_score=min_score, boost=boost,
 			submatch_weight=submatch_weight, rwmd=rwmd, wrd_normalize=wrd_normalize, want_all_scores=True)
 		if self.layout == core.VK_LAYOUT_STATIC:
@@ -77,7 +82,7 @@ class OracleCorpus:
 		# edge similarities as the flow kernel reports them
 		for i in range(n):
 			s = int(r["sentence"][i])
-			a, b = int(self._off[s]), int(self._off[s + 1])
+			a, b = int(self._off[s]), int(self._end[s] if self._end is not None else self._off[s + 1])
 			if self.layout == core.VK_LAYOUT_STATIC:
 				table = vo.sim_table_static_bf16(self._X, Qb, q_token_ids)
 				S = table[self._ids[a:b]]

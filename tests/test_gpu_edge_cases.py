@@ -119,3 +119,26 @@ def test_too_long_sentence_is_rejected(hip):
 	with pytest.raises(hip.VkError):
 		c.set_sentences(off)
 	c.close()
+
+
+def test_overlapping_slices(hip, oracle):
+	# sliding windows (window_size 3, window_step 1) over 40 sentences: vk_corpus_set_slices
+	rng = np.random.default_rng(12)
+	lens = rng.integers(2, 15, size=40)
+	off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+	start = off[:-1]
+	end = off[np.minimum(np.arange(40) + 3, 40)]
+	Xb, Qb = vectors(int(off[-1]), 64, 13), vectors(6, 64, 14)
+	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=64, n_tokens=Xb.shape[0], n_sentences=40)
+	c.append_vectors(Xb, normalize=False)
+	c.set_slices(start, end)
+	c.finalize()
+	for loc, ms, gaps in ((0, 0.0, (0.1, 0.1)), (1, -100.0, (EXP5, EXP5)), (2, -100.0, (("affine", 0.2, 0.05),) * 2)):
+		ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=64, sent_off=start, sent_end=end, X=Xb, Q=Qb, locality=loc,
+			gap_s=gaps[0], gap_t=gaps[1], max_matches=12, min_score=ms)
+		got = c.query(Qb, q_normalize=False, locality=loc, gap_s=gaps[0], gap_t=gaps[1], max_matches=12, min_score=ms).trimmed()
+		assert_same_results(got, ref)
+	ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=64, sent_off=start, sent_end=end, X=Xb, Q=Qb, algorithm=oracle.ALG_RWMD, max_matches=12)
+	got = c.query(Qb, q_normalize=False, algorithm=hip.VK_ALG_RWMD, max_matches=12).trimmed()
+	assert_same_results(got, ref, check_mapping=False, score_tol=1e-5)
+	c.close()

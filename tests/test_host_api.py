@@ -84,7 +84,7 @@ def test_find_over_toy_corpus_static_wsb(oracle):
 	assert scores == sorted(scores, reverse=True)
 	j = top.to_json()
 	assert j["slice"] == 7 and j["metric"] == "toy-300-cosine" and j["level"] == "word"
-	assert j["location"]["title"] == "doc 3" and j["location"]["start"] == st
+	assert j["location"] == {"start": int(st), "end": int(en)}
 	matched = [r for r in j["regions"] if "edges" in r]
 	assert [r["s"] for r in matched] == planted
 	assert all(abs(r["edges"][0]["distance"]) < 1e-2 for r in matched)
@@ -162,8 +162,6 @@ def test_unsupported_options_are_explicit():
 	ts = EmbeddingTokenSim(emb, CosineSim())
 	with pytest.raises(TypeError):
 		OptimizedSpanSim("not a token sim")
-	with pytest.raises(NotImplementedError):
-		session.partition("sentence", 2, 1).index(OptimizedSpanSim(ts), corpus_factory=OracleCorpus)
 	index = session.index(OptimizedSpanSim(ts, tag_weights={"NN": 2.0}), corpus_factory=OracleCorpus)
 	with pytest.raises(NotImplementedError):
 		index.find("w1 w2")
@@ -174,3 +172,22 @@ def test_unsupported_options_are_explicit():
 	with pytest.raises(RuntimeError):
 		index.find("w1 w2", options={"no_such_option": 1})
 	assert index.find("", n=3).matches == []
+
+
+def test_sliding_windows_overlap():
+	# Partition(level, window_size=3, window_step=1): Spans::iterate (vectorian/core/cpp/document.h:147-169)
+	# yields overlapping slices [start(i), end(min(i+2, n-1)))
+	session, emb, words, rng = toy_session(n_docs=2, sents_per_doc=6, V=200, d=32)
+	sim = OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), alignment.LocalAlignment(gap=alignment.LinearGapCost(0.05)))
+	part = session.partition("sentence", 3, 1)
+	index = part.index(sim, corpus_factory=OracleCorpus)
+	assert index.n_slices == 12 and index._sent_off is None
+	doc = session.documents[1]
+	st, en = doc.spans["sentence"]["start"], doc.spans["sentence"]["end"]
+	# a query spanning the end of sentence 2 and the start of sentence 3 of document 1
+	q = doc.tokens[en[2] - 2:en[2] + 2]
+	if len(doc.tokens[st[1]:en[3]]) <= 64:
+		r = index.find(" ".join(q), n=4)
+		assert r[0].doc_index == 1 and r[0].slice_id in (1, 2, 3)
+		assert abs(r[0].score - 1.0) < 1e-2
+		assert r[0].to_json()["location"]["start"] == st[r[0].slice_id]

@@ -82,7 +82,7 @@ class _Timings(C.Structure):
 EXPORTS = [
 	"vk_abi_version", "vk_last_error", "vk_init", "vk_device_count",
 	"vk_corpus_create", "vk_corpus_append_vectors", "vk_corpus_set_token_ids",
-	"vk_corpus_set_sentences", "vk_corpus_finalize", "vk_corpus_free", "vk_corpus_device_bytes",
+	"vk_corpus_set_sentences", "vk_corpus_set_slices", "vk_corpus_finalize", "vk_corpus_free", "vk_corpus_device_bytes",
 	"vk_query", "vk_query_batch", "vk_last_scores", "vk_last_timings", "vk_merge_topk"]
 
 _lib = None
@@ -102,6 +102,7 @@ def lib():
 		L.vk_corpus_append_vectors.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32]
 		L.vk_corpus_set_token_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
 		L.vk_corpus_set_sentences.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+		L.vk_corpus_set_slices.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
 		L.vk_corpus_finalize.argtypes = [C.c_void_p]
 		L.vk_corpus_free.argtypes = [C.c_void_p]
 		L.vk_corpus_device_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
@@ -244,6 +245,12 @@ class Corpus:
 	def set_sentences(self, sent_off):
 		sent_off = np.ascontiguousarray(sent_off, dtype=np.int64)
 		_check(lib().vk_corpus_set_sentences(self._h, _np_ptr(sent_off), len(sent_off) - 1))
+
+	def set_slices(self, start, end):
+		"""general (possibly overlapping) slices: tokens [start[i], end[i])"""
+		start = np.ascontiguousarray(start, dtype=np.int64)
+		end = np.ascontiguousarray(end, dtype=np.int64)
+		_check(lib().vk_corpus_set_slices(self._h, _np_ptr(start), _np_ptr(end), len(start)))
 
 	def finalize(self):
 		_check(lib().vk_corpus_finalize(self._h))

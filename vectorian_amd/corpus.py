@@ -66,19 +66,18 @@ class Document:
 			best = max(best, int(en[j] - st[i]))
 		return best
 
-	def span_tokens(self, level, slice_id, window_size=1, window_step=1):
+	def span_tokens(self, level, slice_id, window_size=1):
 		st, en = self._spans[level]["start"], self._spans[level]["end"]
-		i = slice_id * window_step
+		i = slice_id
 		j = min(i + window_size - 1, len(st) - 1)
 		return self._tokens[int(st[i]):int(en[j])]
 
 	def span_info(self, partition_args, slice_id):
-		st, en = self._spans[partition_args["level"]]["start"], self._spans[partition_args["level"]]["end"]
-		i = slice_id * partition_args["window_step"]
-		j = min(i + partition_args["window_size"] - 1, len(st) - 1)
-		info = dict(self._metadata)
-		info.update({"start": int(st[i]), "end": int(en[j])})
-		return info
+		"""PreparedDocument.span_info (vectorian/corpus/document.py:764-775): slice_id is already the
+		index of the window's first span; the row of the span table is reported"""
+		level = partition_args["level"] if isinstance(partition_args, dict) else partition_args.level
+		table = self._spans[level]
+		return dict((k, int(v[slice_id])) for k, v in table.items())
 
 
 class Corpus:

@@ -70,8 +70,8 @@ struct vk_corpus {
 	uint8_t *d_tiles = nullptr;
 	float *d_mag = nullptr;
 	int32_t *d_tok_id = nullptr;
-	int32_t *d_sent_off = nullptr;
-	std::vector<int64_t> h_sent_off;
+	int32_t *d_sent_start = nullptr, *d_sent_end = nullptr;
+	bool contiguous = false;   // slices are the CSR partition of the token stream
 	bool have_ids = false, have_sent = false, finalized = false;
 	int max_len = 0, max_group_tiles = 0, max_group_tokens = 0;
 	int uniform_len = 0;       // > 0: every sentence has exactly this many tokens
@@ -166,7 +166,8 @@ int vk_corpus_create(const vk_corpus_desc *desc, vk_corpus_t **out) {
 			if ((rc = alloc_t(c, &c->d_tok_id, (size_t)desc->n_tokens + 64))) break;
 			if ((rc = alloc_t(c, &c->d_table, (size_t)c->n_tiles * 16 * 16))) break;
 		}
-		if ((rc = alloc_t(c, &c->d_sent_off, (size_t)desc->n_sentences + 8))) break;
+		if ((rc = alloc_t(c, &c->d_sent_start, (size_t)desc->n_sentences + 8))) break;
+		if ((rc = alloc_t(c, &c->d_sent_end, (size_t)desc->n_sentences + 8))) break;
 		if ((rc = alloc_t(c, &c->d_qtile, (size_t)c->tile_bytes))) break;
 		if ((rc = alloc_t(c, &c->d_ws, 128))) break;
 		if ((rc = alloc_t(c, &c->d_wt, 32))) break;
@@ -189,7 +190,7 @@ int vk_corpus_free(vk_corpus_t *c) {
 	if (!c) return VK_OK;
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
-	void *ptrs[] = {c->d_tiles, c->d_mag, c->d_tok_id, c->d_sent_off, c->d_stage, c->d_qtile, c->d_ws, c->d_wt, c->d_qids,
+	void *ptrs[] = {c->d_tiles, c->d_mag, c->d_tok_id, c->d_sent_start, c->d_sent_end, c->d_stage, c->d_qtile, c->d_ws, c->d_wt, c->d_qids,
 		c->d_table, c->d_scores, c->d_raw, c->d_boost, c->d_keys[0], c->d_keys[1], c->d_out_raw, c->d_out_sim, c->d_out_map, c->d_wrd_raw, c->d_wrd_val, c->d_bq, c->d_bqlen, c->d_bscores, c->d_bkeys[0], c->d_bkeys[1]};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -252,40 +253,41 @@ int vk_corpus_set_token_ids(vk_corpus_t *c, const int32_t *ids, int64_t n, int32
 	return VK_OK;
 }
 
-int vk_corpus_set_sentences(vk_corpus_t *c, const int64_t *sent_off, int64_t n_sentences) {
-	if (!c || !sent_off) return fail(VK_ERR_INVALID, "null argument");
-	if (c->finalized) return fail(VK_ERR_STATE, "corpus already finalized");
-	if (n_sentences != c->desc.n_sentences) return fail(VK_ERR_INVALID, "sentence count differs from n_sentences");
-	if (sent_off[0] != 0) return fail(VK_ERR_INVALID, "sentence spans must start at token 0 (document.h:151-168)");
-	if (sent_off[n_sentences] != c->desc.n_tokens) return fail(VK_ERR_INVALID, "sentence spans must cover exactly n_tokens");
+static int set_slices_impl(vk_corpus_t *c, const int64_t *start, const int64_t *end, int64_t n_sentences, bool contiguous) {
 	int max_len = 0;
 	for (int64_t s = 0; s < n_sentences; s++) {
-		const int64_t len = sent_off[s + 1] - sent_off[s];
-		if (len < 0) return fail(VK_ERR_INVALID, "sentence offsets must be non-decreasing");
+		const int64_t len = end[s] - start[s];
+		if (start[s] < 0 || end[s] > c->desc.n_tokens || len < 0) return fail(VK_ERR_INVALID, "slice outside the token stream");
+		if (s > 0 && (start[s] < start[s - 1] || end[s] < end[s - 1])) return fail(VK_ERR_INVALID, "slice starts and ends must be non-decreasing");
 		if (len > VK_MAX_SENT_LEN) {
 			char buf[128];
-			snprintf(buf, sizeof buf, "sentence %lld has %lld tokens; the HIP path handles at most %d", (long long)s, (long long)len, VK_MAX_SENT_LEN);
+			snprintf(buf, sizeof buf, "slice %lld has %lld tokens; the HIP path handles at most %d", (long long)s, (long long)len, VK_MAX_SENT_LEN);
 			return fail(VK_ERR_UNSUPPORTED, buf);
 		}
 		max_len = std::max(max_len, (int)len);
 	}
 	VK_HIP(hipSetDevice(c->device));
-	c->h_sent_off.assign(sent_off, sent_off + n_sentences + 1);
-	std::vector<int32_t> off32((size_t)n_sentences + 1);
-	for (int64_t s = 0; s <= n_sentences; s++) off32[(size_t)s] = (int32_t)sent_off[s];
-	VK_HIP(hipMemcpy(c->d_sent_off, off32.data(), off32.size() * 4, hipMemcpyHostToDevice));
+	std::vector<int32_t> st32((size_t)n_sentences + 8), en32((size_t)n_sentences + 8);
+	const int32_t tail = n_sentences > 0 ? (int32_t)end[n_sentences - 1] : 0;
+	for (int64_t s = 0; s < n_sentences + 8; s++) {
+		st32[(size_t)s] = s < n_sentences ? (int32_t)start[s] : tail;   // padding: empty slices at the end
+		en32[(size_t)s] = s < n_sentences ? (int32_t)end[s] : tail;
+	}
+	VK_HIP(hipMemcpy(c->d_sent_start, st32.data(), st32.size() * 4, hipMemcpyHostToDevice));
+	VK_HIP(hipMemcpy(c->d_sent_end, en32.data(), en32.size() * 4, hipMemcpyHostToDevice));
 	c->max_len = max_len;
+	c->contiguous = contiguous;
 	c->uniform_len = 0;
-	if (n_sentences > 0) {
-		const int64_t l0 = sent_off[1] - sent_off[0];
+	if (n_sentences > 0 && contiguous) {
+		const int64_t l0 = end[0] - start[0];
 		bool uni = l0 > 0;
-		for (int64_t s = 1; s < n_sentences && uni; s++) uni = (sent_off[s + 1] - sent_off[s]) == l0;
+		for (int64_t s = 1; s < n_sentences && uni; s++) uni = (end[s] - start[s]) == l0;
 		if (uni) c->uniform_len = (int)l0;
 	}
-	// per wave: groups of 4 consecutive sentences
+	// per wave: groups of 4 consecutive slices
 	int mt = 1, mtok = 1;
 	for (int64_t g = 0; g * 4 < n_sentences; g++) {
-		const int64_t a = sent_off[g * 4], b = sent_off[std::min<int64_t>(g * 4 + 4, n_sentences)];
+		const int64_t a = start[g * 4], b = end[std::min<int64_t>(g * 4 + 3, n_sentences - 1)];
 		const int tiles = (int)(((b + 15) >> 4) - (a >> 4));
 		mt = std::max(mt, tiles);
 		mtok = std::max(mtok, (int)(b - a));
@@ -294,6 +296,24 @@ int vk_corpus_set_sentences(vk_corpus_t *c, const int64_t *sent_off, int64_t n_s
 	c->max_group_tokens = mtok;
 	c->have_sent = true;
 	return VK_OK;
+}
+
+int vk_corpus_set_sentences(vk_corpus_t *c, const int64_t *sent_off, int64_t n_sentences) {
+	if (!c || !sent_off) return fail(VK_ERR_INVALID, "null argument");
+	if (c->finalized) return fail(VK_ERR_STATE, "corpus already finalized");
+	if (n_sentences != c->desc.n_sentences) return fail(VK_ERR_INVALID, "sentence count differs from n_sentences");
+	if (sent_off[0] != 0) return fail(VK_ERR_INVALID, "sentence spans must start at token 0 (document.h:151-168)");
+	if (sent_off[n_sentences] != c->desc.n_tokens) return fail(VK_ERR_INVALID, "sentence spans must cover exactly n_tokens");
+	for (int64_t s = 0; s < n_sentences; s++)
+		if (sent_off[s + 1] < sent_off[s]) return fail(VK_ERR_INVALID, "sentence offsets must be non-decreasing");
+	return set_slices_impl(c, sent_off, sent_off + 1, n_sentences, true);
+}
+
+int vk_corpus_set_slices(vk_corpus_t *c, const int64_t *start, const int64_t *end, int64_t n_sentences) {
+	if (!c || !start || !end) return fail(VK_ERR_INVALID, "null argument");
+	if (c->finalized) return fail(VK_ERR_STATE, "corpus already finalized");
+	if (n_sentences != c->desc.n_sentences) return fail(VK_ERR_INVALID, "slice count differs from n_sentences");
+	return set_slices_impl(c, start, end, n_sentences, false);
 }
 
 int vk_corpus_finalize(vk_corpus_t *c) {
@@ -453,7 +473,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 
 	// ---- the fused scoring kernel ------------------------------------------
 	VK_HIP(hipEventRecord(c->ev[1], st));
-	p.tiles = c->d_tiles; p.tok_id = c->d_tok_id; p.table = c->d_table; p.sent_off = c->d_sent_off;
+	p.tiles = c->d_tiles; p.tok_id = c->d_tok_id; p.table = c->d_table; p.sent_start = c->d_sent_start; p.sent_end = c->d_sent_end;
 	p.n_sent = (int32_t)n; p.layout = is_static ? VK_DEV_LAYOUT_STATIC : VK_DEV_LAYOUT_CONTEXTUAL;
 	p.nk32 = c->nk32; p.tail = c->tail; p.tile_bytes = c->tile_bytes;
 	p.qtile = c->d_qtile; p.len_t = q->len_t; p.locality = q->locality;
@@ -494,7 +514,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 				cur = 1 - cur;
 			}
 			VkWrdParams w{};
-			w.tiles = c->d_tiles; w.tok_id = c->d_tok_id; w.table = c->d_table; w.sent_off = c->d_sent_off;
+			w.tiles = c->d_tiles; w.tok_id = c->d_tok_id; w.table = c->d_table; w.sent_start = c->d_sent_start; w.sent_end = c->d_sent_end;
 			w.layout = p.layout; w.nk32 = c->nk32; w.tail = c->tail; w.tile_bytes = c->tile_bytes;
 			w.qtile = c->d_qtile; w.len_t = q->len_t; w.mag = c->d_mag;
 			memcpy(w.qmass, p.qmass, sizeof w.qmass);
@@ -575,7 +595,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	const bool do_flow = q->want_flow && is_align;
 	if (do_flow) {
 		VkFlowParams f{};
-		f.tiles = c->d_tiles; f.tok_id = c->d_tok_id; f.table = c->d_table; f.sent_off = c->d_sent_off;
+		f.tiles = c->d_tiles; f.tok_id = c->d_tok_id; f.table = c->d_table; f.sent_start = c->d_sent_start; f.sent_end = c->d_sent_end;
 		f.layout = p.layout; f.nk32 = c->nk32; f.tail = c->tail; f.tile_bytes = c->tile_bytes;
 		f.qtile = c->d_qtile; f.len_t = q->len_t; f.locality = q->locality; f.gap_mode = (p.gap_mode == 3 || p.gap_mode == 6) ? 2 : p.gap_mode;
 		f.gs = p.gs; f.gt = p.gt; f.a_s = p.a_s; f.a_t = p.a_t; f.open_s = p.open_s; f.open_t = p.open_t;
@@ -651,7 +671,7 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 	if (!c || !qs || !outs || n_queries < 0) return fail(VK_ERR_INVALID, "null argument");
 	if (n_queries == 0) return VK_OK;
 	// the GEMM path: injective RWMD, contextual layout, one sentence length (multiple of 16), common options
-	bool gemm = c->finalized && c->desc.layout == VK_LAYOUT_CONTEXTUAL && c->uniform_len > 0 && c->uniform_len % 16 == 0 &&
+	bool gemm = c->finalized && c->contiguous && c->desc.layout == VK_LAYOUT_CONTEXTUAL && c->uniform_len > 0 && c->uniform_len % 16 == 0 &&
 		c->uniform_len <= 64 && c->desc.n_sentences > 0 && qs[0].max_matches <= 64 &&
 		((c->nk32 == 10 && c->tail == 1) || (c->nk32 == 4 && c->tail == 0));
 	for (int i = 0; i < n_queries && gemm; i++) {

@@ -22,7 +22,8 @@ struct VkScoreParams {
 	const uint8_t *tiles;      // contextual: token tiles
 	const int32_t *tok_id;     // static: token ids
 	const float *table;        // static: per-query similarity table [V_pad x 16]
-	const int32_t *sent_off;   // [n_sent + 1]
+	const int32_t *sent_start; // [n_sent + 8] first token of each slice (entries >= n_sent: empty)
+	const int32_t *sent_end;   // [n_sent + 8] one past the last token
 	int32_t n_sent;
 	int32_t layout;
 	int32_t nk32, tail, tile_bytes;
@@ -67,7 +68,8 @@ struct VkWrdParams {
 	const uint8_t *tiles;
 	const int32_t *tok_id;
 	const float *table;
-	const int32_t *sent_off;
+	const int32_t *sent_start;
+	const int32_t *sent_end;
 	int32_t layout;
 	int32_t nk32, tail, tile_bytes;
 	const uint8_t *qtile;
@@ -84,7 +86,8 @@ struct VkFlowParams {
 	const uint8_t *tiles;
 	const int32_t *tok_id;
 	const float *table;
-	const int32_t *sent_off;
+	const int32_t *sent_start;
+	const int32_t *sent_end;
 	int32_t layout;
 	int32_t nk32, tail, tile_bytes;
 	const uint8_t *qtile;

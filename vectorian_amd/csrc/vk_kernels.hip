@@ -635,9 +635,8 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 	const int n_groups = (p.n_sent + 3) >> 2;
 	for (int grp = blockIdx.x * 4 + wv; grp < n_groups; grp += gridDim.x * 4) {
 		const int s_idx = grp * 4 + sigma;
-		const int i0 = s_idx < p.n_sent ? s_idx : p.n_sent;
-		const int i1 = s_idx + 1 < p.n_sent ? s_idx + 1 : p.n_sent;
-		const int t_a = p.sent_off[i0], t_b = p.sent_off[i1];
+		const int i0 = s_idx < p.n_sent ? s_idx : p.n_sent;       // entries >= n_sent are empty slices
+		const int t_a = p.sent_start[i0], t_b = p.sent_end[i0];
 		const int len = t_b - t_a;
 		const int g_a = __builtin_amdgcn_readlane(t_a, 0);
 		const int g_b = __builtin_amdgcn_readlane(t_b, 48);
@@ -1070,7 +1069,7 @@ __global__ __launch_bounds__(64) void vk_flow_kernel(VkFlowParams p) {
 	const uint64_t key = p.keys[w];
 	if (key == 0) return;   // fewer than k admitted
 	const int64_t g = (int64_t)(uint32_t)(key & 0xffffffffu);
-	const int t_a = p.sent_off[g], t_b = p.sent_off[g + 1];
+	const int t_a = p.sent_start[g], t_b = p.sent_end[g];
 	const int len_s = t_b - t_a, len_t = p.len_t;
 
 	int rowbase;
@@ -1330,7 +1329,7 @@ __global__ __launch_bounds__(64) void vk_wrd_exact_kernel(VkWrdParams p) {
 	const uint64_t key = p.keys[w];
 	if (key == 0) return;
 	const int64_t g = (int64_t)(uint32_t)(key & 0xffffffffu);
-	const int t_a = p.sent_off[g], t_b = p.sent_off[g + 1];
+	const int t_a = p.sent_start[g], t_b = p.sent_end[g];
 	const int m = t_b - t_a, n = p.len_t;
 
 	int rowbase;

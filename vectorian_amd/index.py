@@ -377,13 +377,10 @@ class HipBruteForceIndex(Index):
 			raise NotImplementedError(f"{token_sim.similarity.name}: the HIP path computes CosineSim")
 		self._embedding = token_sim.embedding
 		self._metric_name = token_sim.to_args(self)["name"]
-		if partition.window_step != partition.window_size:
-			raise NotImplementedError("overlapping / skipping windows (window_step != window_size) are a 'next' row (SURVEY 8f-3)")
-
 		session = self.session
 		level, size = partition.level, partition.window_size
 		# slices: Spans::iterate (vectorian/core/cpp/document.h:147-169) over every document
-		sent_off = [0]
+		starts, ends = [], []
 		self._slice_doc, self._slice_id, self._slice_token_at = [], [], []
 		base = 0
 		for di, doc in enumerate(session.documents):
@@ -393,12 +390,17 @@ class HipBruteForceIndex(Index):
 				raise ValueError("spans must be contiguous and cover the document (document.h:151-168)")
 			for sid in range(0, n, partition.window_step):
 				j = min(sid + size - 1, n - 1)
-				sent_off.append(base + int(en[j]))
+				starts.append(base + int(st[sid]))
+				ends.append(base + int(en[j]))
 				self._slice_doc.append(di)
 				self._slice_id.append(sid)
 				self._slice_token_at.append(int(st[sid]))
 			base += doc.n_tokens
-		self._sent_off = np.array(sent_off, dtype=np.int64)
+		self._slice_start = np.array(starts, dtype=np.int64)
+		self._slice_end = np.array(ends, dtype=np.int64)
+		# contiguous partition (window_step == window_size): CSR offsets; otherwise general slices
+		contiguous = len(starts) > 0 and starts[0] == 0 and ends[-1] == base and (self._slice_start[1:] == self._slice_end[:-1]).all()
+		self._sent_off = np.concatenate(([0], self._slice_end)).astype(np.int64) if contiguous else None
 		self._slice_doc = np.array(self._slice_doc, dtype=np.int64)
 		n_tokens, n_slices = base, len(self._slice_doc)
 
@@ -427,7 +429,10 @@ class HipBruteForceIndex(Index):
 				self._corpus.append_vectors(Vectors(doc.contextual_vectors(emb.name)).unmodified, normalize=True)
 		else:
 			raise TypeError(emb)
-		self._corpus.set_sentences(self._sent_off)
+		if self._sent_off is not None:
+			self._corpus.set_sentences(self._sent_off)
+		else:
+			self._corpus.set_slices(self._slice_start, self._slice_end)
 		self._corpus.finalize()
 
 	@property
@@ -503,7 +508,7 @@ class HipBruteForceIndex(Index):
 			di = int(self._slice_doc[g])
 			matches.append(HipMatch(
 				self, p_query, di, self._slice_id[g], self._slice_token_at[g],
-				int(self._sent_off[g + 1] - self._sent_off[g]),
+				int(self._slice_end[g] - self._slice_start[g]),
 				top.score[i], top.raw_score[i], top.mapping[i].copy(), top.edge_sim[i].copy(), gaps))
 		return matches
 
