@@ -103,6 +103,14 @@ typedef struct {
 	int32_t rwmd_injective, rwmd_symmetric, rwmd_normalize_bow;
 	/* VK_ALG_WRD (vectorian/alignment.py:308-313) */
 	int32_t wrd_normalize_magnitudes;
+	/* 'alignment-tag-weighted' (vectorian/sim/span.py:63-71; TagWeightedSlice, slice/static.h:186-288):
+	 * S'[i][j] = S[i][j] * tag_weights[j] * (pos_s[i] != q_pos[j] ? 1 - pos_mismatch_penalty : 1), set to 0
+	 * when <= similarity_threshold; the score is divided by sum(tag_weights) instead of len_t.
+	 * tag_weights NULL = 'alignment-isolated'.  Alignment only; needs vk_corpus_set_token_pos. */
+	const float *tag_weights;  /* host [len_t] t_pos_weights (match/instantiate.cpp:10-38) */
+	const int8_t *q_pos;       /* host [len_t] universal POS code per query token */
+	float pos_mismatch_penalty;
+	float similarity_threshold;
 } vk_query_desc;
 
 /* Bounded result set, best first.  Order: score descending, then sentence index
@@ -146,6 +154,8 @@ int vk_corpus_create(const vk_corpus_desc *desc, vk_corpus_t **out);
 int vk_corpus_append_vectors(vk_corpus_t *c, const void *rows, int64_t n_rows, int32_t dtype, int32_t mem, int32_t normalize);
 /* VK_LAYOUT_STATIC: token ids of the whole shard (Token.id, common.h:34-42) */
 int vk_corpus_set_token_ids(vk_corpus_t *c, const int32_t *ids, int64_t n, int32_t mem);
+/* universal POS code per token occurrence (Token.pos, common.h:34-42); only needed by tag-weighted queries */
+int vk_corpus_set_token_pos(vk_corpus_t *c, const int8_t *pos, int64_t n, int32_t mem);
 /* sentence spans as CSR offsets in token units, contiguous from 0
  * (Spans::iterate, document.h:147-169).  sent_off: host [n_sentences + 1]. */
 int vk_corpus_set_sentences(vk_corpus_t *c, const int64_t *sent_off, int64_t n_sentences);

@@ -856,6 +856,17 @@ static int score_sentence(const work *w, int64_t s, float *Sbuf, float *xbuf, fl
 		}
 	}
 
+	if (q->tag_weights) {
+		/* TagWeightedSlice::similarity (slice/static.h:237-264): S * weight(i, j), zero at or below the threshold */
+		for (int32_t i = 0; i < len_s; i++)
+			for (int32_t j = 0; j < len_t; j++) {
+				float wgt = q->tag_weights[j];
+				if (c->pos_s && q->q_pos && c->pos_s[t0 + i] != q->q_pos[j]) wgt *= 1.0f - q->pos_mismatch_penalty;
+				const float sc = Sbuf[i * len_t + j] * wgt;
+				Sbuf[i * len_t + j] = sc <= q->similarity_threshold ? 0.0f : sc;
+			}
+	}
+
 	const float boost = q->boost ? q->boost[s] : 1.0f; /* matcher_impl.h:99 */
 	float raw = 0.0f;
 	if (q->algorithm == VKO_ALG_ALIGN) {
@@ -863,6 +874,17 @@ static int score_sentence(const work *w, int64_t s, float *Sbuf, float *xbuf, fl
 		int16_t *m = mapping ? mapping : local_map;
 		const int need_map = mapping != NULL || q->submatch_weight != 0.0f;
 		if (vko_align(Sbuf, len_t, len_s, len_t, q->locality, &q->gap_s, &q->gap_t, &raw, need_map ? m : NULL)) return 2;
+		if (q->tag_weights) {
+			/* reference_score with max_similarity_for_t = t_pos_weights (slice/static.h:280-286) */
+			float total = 0.0f, matched_w = 0.0f;
+			for (int32_t j = 0; j < len_t; j++) total += q->tag_weights[j];
+			if (need_map) for (int32_t j = 0; j < len_t; j++) if (m[j] >= 0) matched_w += q->tag_weights[j];
+			const float uw = powf((total - matched_w) / total, q->submatch_weight);
+			const float ref = matched_w + uw * (total - matched_w);
+			*value_out = (raw / ref) * boost;
+			*raw_out = raw;
+			return 0;
+		}
 		int32_t matched = 0;
 		if (need_map) for (int32_t j = 0; j < len_t; j++) matched += m[j] >= 0;
 		*value_out = vko_score(raw, len_t, matched, q->submatch_weight, boost);

@@ -118,6 +118,7 @@ typedef struct {
 	int32_t V;
 	const int64_t *sent_off;  /* [n_sentences+1], token units, contiguous (document.h:147-169, B8) */
 	const int64_t *sent_end;  /* optional [n_sentences]: slice s = [sent_off[s], sent_end[s]) (sliding windows) */
+	const int8_t *pos_s;      /* optional [n_tokens]: universal POS code per token (TagWeightedSlice) */
 } vko_corpus;
 
 typedef struct {
@@ -134,6 +135,11 @@ typedef struct {
 	const float *boost;       /* optional [n_sentences] */
 	int32_t rwmd_injective, rwmd_symmetric, rwmd_normalize_bow;
 	int32_t wrd_normalize_magnitudes;
+	/* alignment-tag-weighted (slice/static.h:186-288; match/instantiate.cpp:10-38,173-189) */
+	const float *tag_weights; /* optional [len_t]: t_pos_weights; NULL = alignment-isolated */
+	const int8_t *q_pos;      /* [len_t] universal POS code per query token */
+	float pos_mismatch_penalty;
+	float similarity_threshold;
 } vko_query;
 
 typedef struct {

@@ -40,7 +40,7 @@ class Corpus(C.Structure):
 		("n_tokens", C.c_int64), ("n_sentences", C.c_int64),
 		("X", C.c_void_p), ("X_mag", C.c_void_p),
 		("tok_id", C.c_void_p), ("E", C.c_void_p), ("V", C.c_int32),
-		("sent_off", C.c_void_p), ("sent_end", C.c_void_p)]
+		("sent_off", C.c_void_p), ("sent_end", C.c_void_p), ("pos_s", C.c_void_p)]
 
 
 class Query(C.Structure):
@@ -53,7 +53,9 @@ class Query(C.Structure):
 		("max_matches", C.c_int32), ("min_score", C.c_float),
 		("boost", C.c_void_p),
 		("rwmd_injective", C.c_int32), ("rwmd_symmetric", C.c_int32), ("rwmd_normalize_bow", C.c_int32),
-		("wrd_normalize_magnitudes", C.c_int32)]
+		("wrd_normalize_magnitudes", C.c_int32),
+		("tag_weights", C.c_void_p), ("q_pos", C.c_void_p),
+		("pos_mismatch_penalty", C.c_float), ("similarity_threshold", C.c_float)]
 
 
 class Result(C.Structure):
@@ -247,7 +249,8 @@ def emd(a, b, Cm):
 def find_many(*, layout, d, sent_off, Qs, sent_end=None, X=None, X_mag=None, tok_id=None, E=None,
 		algorithm=ALG_ALIGN, locality=LOCAL, gap_s=0.0, gap_t=0.0, q_ids=None, Q_mags=None,
 		max_matches=10, min_score=0.0, boost=None, submatch_weight=0.0,
-		rwmd=(True, True, True), wrd_normalize=True, n_threads=1, want_all_scores=False):
+		rwmd=(True, True, True), wrd_normalize=True, n_threads=1, want_all_scores=False,
+		pos_s=None, tag_weights=None, q_pos=None, pos_mismatch_penalty=0.0, similarity_threshold=0.0):
 	"""Runs vko_find_many over a batch of queries (Qs: list of uint16 bf16 [len_t x d]); q_ids / Q_mags
 	are per-query lists or None.  Returns a list of dict(score, raw, sentence, mapping[, all_scores])."""
 	keep = []
@@ -269,6 +272,8 @@ def find_many(*, layout, d, sent_off, Qs, sent_end=None, X=None, X_mag=None, tok
 	if E is not None:
 		E = np.ascontiguousarray(E, dtype=np.uint16); c.E = _ptr(E); c.V = E.shape[0]
 	c.sent_off = _ptr(sent_off)
+	if pos_s is not None:
+		pos_s = np.ascontiguousarray(pos_s, dtype=np.int8); c.pos_s = _ptr(pos_s)
 	if boost is not None:
 		boost = _f32(boost)
 
@@ -294,6 +299,11 @@ def find_many(*, layout, d, sent_off, Qs, sent_end=None, X=None, X_mag=None, tok
 			q.boost = _ptr(boost)
 		q.rwmd_injective, q.rwmd_symmetric, q.rwmd_normalize_bow = [int(x) for x in rwmd]
 		q.wrd_normalize_magnitudes = int(wrd_normalize)
+		if tag_weights is not None and tag_weights[i] is not None:
+			tw = _f32(tag_weights[i]); keep.append(tw); q.tag_weights = _ptr(tw)
+			if q_pos is not None and q_pos[i] is not None:
+				qp = np.ascontiguousarray(q_pos[i], dtype=np.int8); keep.append(qp); q.q_pos = _ptr(qp)
+			q.pos_mismatch_penalty, q.similarity_threshold = float(pos_mismatch_penalty), float(similarity_threshold)
 		score_ = np.zeros(k, dtype=np.float32)
 		raw_ = np.zeros(k, dtype=np.float32)
 		sent_ = np.zeros(k, dtype=np.int64)
@@ -318,6 +328,7 @@ def find_many(*, layout, d, sent_off, Qs, sent_end=None, X=None, X_mag=None, tok
 	return outs
 
 
-def find(*, Q, q_ids=None, Q_mag=None, len_t=None, **kw):
+def find(*, Q, q_ids=None, Q_mag=None, len_t=None, tag_weights=None, q_pos=None, **kw):
 	"""one query (vko_find); see find_many"""
-	return find_many(Qs=[Q], q_ids=None if q_ids is None else [q_ids], Q_mags=None if Q_mag is None else [Q_mag], **kw)[0]
+	return find_many(Qs=[Q], q_ids=None if q_ids is None else [q_ids], Q_mags=None if Q_mag is None else [Q_mag],
+		tag_weights=None if tag_weights is None else [tag_weights], q_pos=None if q_pos is None else [q_pos], **kw)[0]

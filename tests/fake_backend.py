@@ -25,6 +25,7 @@ class OracleCorpus:
 		self.n_tokens, self.n_sentences, self.vocab_size = n_tokens, n_sentences, vocab_size
 		self._rows, self._mags = [], []
 		self._ids = None
+		self._pos = None
 		self._off = None
 		self._all = None
 
@@ -42,6 +43,9 @@ class OracleCorpus:
 	def set_token_ids(self, ids):
 		self._ids = np.ascontiguousarray(ids, dtype=np.int32)
 
+	def set_token_pos(self, pos):
+		self._pos = np.ascontiguousarray(pos, dtype=np.int8)
+
 	def set_sentences(self, off):
 		self._off = np.ascontiguousarray(off, dtype=np.int64)
 		self._end = None
@@ -56,7 +60,8 @@ class OracleCorpus:
 
 	def query(self, q_vectors, *, locality=0, gap_s=0.0, gap_t=0.0, algorithm=0, q_token_ids=None, q_normalize=True,
 			max_matches=10, min_score=0.0, boost=None, want_flow=True, submatch_weight=0.0, bidirectional=False,
-			rwmd=(True, True, True), wrd_normalize=True):
+			rwmd=(True, True, True), wrd_normalize=True, tag_weights=None, q_pos=None, pos_mismatch_penalty=0.0,
+			similarity_threshold=0.0):
 		q = np.ascontiguousarray(q_vectors)
 		if q.dtype == np.uint16:
 			q = synth.bf16_bits_to_f32(q)
@@ -67,7 +72,9 @@ class OracleCorpus:
 			Qb, qmag = synth.to_bf16_bits(q), np.ones(len(q), np.float32)
 		kw = dict(layout=self.layout, d=self.d, sent_off=self._off, sent_end=self._end, Q=Qb, algorithm=algorithm, locality=int(locality),
 			gap_s=_gap(gap_s), gap_t=_gap(gap_t), max_matches=max_matches, min_score=min_score, boost=boost,
-			submatch_weight=submatch_weight, rwmd=rwmd, wrd_normalize=wrd_normalize, want_all_scores=True)
+			submatch_weight=submatch_weight, rwmd=rwmd, wrd_normalize=wrd_normalize, want_all_scores=True,
+			pos_s=self._pos, tag_weights=tag_weights, q_pos=q_pos, pos_mismatch_penalty=pos_mismatch_penalty,
+			similarity_threshold=similarity_threshold)
 		if self.layout == core.VK_LAYOUT_STATIC:
 			kw.update(tok_id=self._ids, E=self._X, q_ids=q_token_ids)
 		else:

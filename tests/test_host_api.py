@@ -163,8 +163,8 @@ def test_unsupported_options_are_explicit():
 	with pytest.raises(TypeError):
 		OptimizedSpanSim("not a token sim")
 	index = session.index(OptimizedSpanSim(ts, tag_weights={"NN": 2.0}), corpus_factory=OracleCorpus)
-	with pytest.raises(NotImplementedError):
-		index.find("w1 w2")
+	with pytest.raises(RuntimeError):
+		index.find("w1 w2")          # documents without pos / tags
 	index = session.index(OptimizedSpanSim(ts, alignment.WordMoversDistance.wmd("nbow")), corpus_factory=OracleCorpus)
 	with pytest.raises(NotImplementedError):
 		index.find("w1 w2")
@@ -191,3 +191,31 @@ def test_sliding_windows_overlap():
 		assert r[0].doc_index == 1 and r[0].slice_id in (1, 2, 3)
 		assert abs(r[0].score - 1.0) < 1e-2
 		assert r[0].to_json()["location"]["start"] == st[r[0].slice_id]
+
+
+def test_tag_weighted_metric():
+	# 'alignment-tag-weighted' (vectorian/sim/span.py:63-71): noun matches count double, a POS mismatch is
+	# penalised, and the score is divided by the sum of the query's tag weights
+	words = ["dog", "cat", "runs", "sleeps", "the", "hound", "walks"]
+	rng = np.random.default_rng(3)
+	vec = rng.standard_normal((len(words), 48)).astype(np.float32)
+	vec[5] = vec[0] + 0.2 * rng.standard_normal(48)       # hound ~ dog
+	vec[6] = vec[2] + 0.2 * rng.standard_normal(48)       # walks ~ runs
+	emb = StaticEmbedding("toy", words, vec)
+	sents = [["the", "hound", "walks"], ["the", "cat", "sleeps"], ["runs", "dog", "the"]]
+	pos = [["DET", "NOUN", "VERB"], ["DET", "NOUN", "VERB"], ["NOUN", "VERB", "DET"]]       # last sentence mis-tagged on purpose
+	tags = [["DT", "NN", "VBZ"], ["DT", "NN", "VBZ"], ["NN", "VBZ", "DT"]]
+	session = Session([Document(sents, pos=pos, tags=tags)], embeddings=[emb])
+	nlp = lambda text: [{"text": w, "pos": p, "tag": t} for w, p, t in zip(text.split(), ["NOUN", "VERB"], ["NN", "VBZ"])]
+	sim = OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), alignment.LocalAlignment(gap=alignment.LinearGapCost(0.2)),
+		tag_weights={"NN": 2.0}, pos_mismatch_penalty=0.5, similarity_threshold=0.1)
+	assert sim.to_args(type("I", (), {"partition": None})())["metric"] == "alignment-tag-weighted"
+	index = session.index(sim, nlp=nlp, corpus_factory=OracleCorpus)
+	r = index.find("dog runs", n=3)
+	assert r[0].slice_id == 0
+	d = r[0].flow["dist"]                       # unmodified distances (ScoreComputer, metric/alignment.h:339)
+	want = (2.0 * (1 - d[0]) + 1.0 * (1 - d[1])) / 3.0
+	assert abs(r[0].score - want) < 1e-6
+	# sentence 2 holds the exact words but in swapped order and with mismatching POS: one match at half weight
+	s2 = [m for m in r if m.slice_id == 2][0]
+	assert abs(s2.score - max(2.0 * 0.5, 1.0 * 0.5) / 3.0) < 1e-6

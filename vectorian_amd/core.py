@@ -63,7 +63,9 @@ class _QueryDesc(C.Structure):
 		("max_matches", C.c_int32), ("min_score", C.c_float),
 		("boost", C.c_void_p), ("want_flow", C.c_int32),
 		("rwmd_injective", C.c_int32), ("rwmd_symmetric", C.c_int32), ("rwmd_normalize_bow", C.c_int32),
-		("wrd_normalize_magnitudes", C.c_int32)]
+		("wrd_normalize_magnitudes", C.c_int32),
+		("tag_weights", C.c_void_p), ("q_pos", C.c_void_p),
+		("pos_mismatch_penalty", C.c_float), ("similarity_threshold", C.c_float)]
 
 
 class _TopkOut(C.Structure):
@@ -81,7 +83,7 @@ class _Timings(C.Structure):
 
 EXPORTS = [
 	"vk_abi_version", "vk_last_error", "vk_init", "vk_device_count",
-	"vk_corpus_create", "vk_corpus_append_vectors", "vk_corpus_set_token_ids",
+	"vk_corpus_create", "vk_corpus_append_vectors", "vk_corpus_set_token_ids", "vk_corpus_set_token_pos",
 	"vk_corpus_set_sentences", "vk_corpus_set_slices", "vk_corpus_finalize", "vk_corpus_free", "vk_corpus_device_bytes",
 	"vk_query", "vk_query_batch", "vk_last_scores", "vk_last_timings", "vk_merge_topk"]
 
@@ -101,6 +103,7 @@ def lib():
 		L.vk_corpus_create.argtypes = [C.POINTER(_CorpusDesc), C.POINTER(C.c_void_p)]
 		L.vk_corpus_append_vectors.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32]
 		L.vk_corpus_set_token_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
+		L.vk_corpus_set_token_pos.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
 		L.vk_corpus_set_sentences.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 		L.vk_corpus_set_slices.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
 		L.vk_corpus_finalize.argtypes = [C.c_void_p]
@@ -242,6 +245,11 @@ class Corpus:
 		ids = np.ascontiguousarray(ids, dtype=np.int32)
 		_check(lib().vk_corpus_set_token_ids(self._h, _np_ptr(ids), len(ids), VK_MEM_HOST))
 
+	def set_token_pos(self, pos):
+		"""universal POS code per token occurrence (int8), for tag-weighted queries"""
+		pos = np.ascontiguousarray(pos, dtype=np.int8)
+		_check(lib().vk_corpus_set_token_pos(self._h, _np_ptr(pos), len(pos), VK_MEM_HOST))
+
 	def set_sentences(self, sent_off):
 		sent_off = np.ascontiguousarray(sent_off, dtype=np.int64)
 		_check(lib().vk_corpus_set_sentences(self._h, _np_ptr(sent_off), len(sent_off) - 1))
@@ -263,7 +271,8 @@ class Corpus:
 
 	def _desc(self, q_vectors, keep, *, locality=Locality.LOCAL, gap_s=0.0, gap_t=0.0, algorithm=VK_ALG_ALIGN,
 			q_token_ids=None, q_normalize=True, max_matches=10, min_score=0.0, boost=None, want_flow=True,
-			submatch_weight=0.0, bidirectional=False, rwmd=(True, True, True), wrd_normalize=True):
+			submatch_weight=0.0, bidirectional=False, rwmd=(True, True, True), wrd_normalize=True,
+			tag_weights=None, q_pos=None, pos_mismatch_penalty=0.0, similarity_threshold=0.0):
 		q_vectors = np.ascontiguousarray(q_vectors)
 		if q_vectors.dtype == np.uint16:
 			qdt = VK_BF16
@@ -296,6 +305,14 @@ class Corpus:
 		q.want_flow = int(bool(want_flow))
 		q.rwmd_injective, q.rwmd_symmetric, q.rwmd_normalize_bow = [int(bool(x)) for x in rwmd]
 		q.wrd_normalize_magnitudes = int(bool(wrd_normalize))
+		if tag_weights is not None:
+			tw = np.ascontiguousarray(tag_weights, dtype=np.float32)
+			qp = np.ascontiguousarray(q_pos if q_pos is not None else np.zeros(len_t), dtype=np.int8)
+			if len(tw) != len_t or len(qp) != len_t:
+				raise ValueError("tag_weights / q_pos must have one entry per query token")
+			keep.extend([tw, qp])
+			q.tag_weights, q.q_pos = _np_ptr(tw), _np_ptr(qp)
+			q.pos_mismatch_penalty, q.similarity_threshold = float(pos_mismatch_penalty), float(similarity_threshold)
 		return q, len_t
 
 	def query(self, q_vectors, **options):

@@ -9,11 +9,18 @@ import numpy as np
 
 
 class Document:
-	def __init__(self, sentences, unique_id=None, metadata=None, contextual_embeddings=None):
+	def __init__(self, sentences, unique_id=None, metadata=None, contextual_embeddings=None, pos=None, tags=None):
 		"""sentences: list of sentences, each a list of token strings.
-		contextual_embeddings: {embedding name: float32 [n_tokens x d]}"""
+		contextual_embeddings: {embedding name: float32 [n_tokens x d]}
+		pos / tags: optional universal POS / Penn treebank tags, same nesting as `sentences`
+		(Token.pos, Token.tag of the reference, vectorian/core/cpp/common.h:34-42)"""
 		self._sentences = [list(s) for s in sentences]
 		self._tokens = [t for s in self._sentences for t in s]
+		self._pos = [t for s in pos for t in s] if pos is not None else None
+		self._tags = [t for s in tags for t in s] if tags is not None else None
+		for name, seq in (("pos", self._pos), ("tags", self._tags)):
+			if seq is not None and len(seq) != len(self._tokens):
+				raise ValueError(f"{name}: one entry per token expected")
 		lens = np.array([len(s) for s in self._sentences], dtype=np.int64)
 		self._spans = {"sentence": {
 			"start": np.concatenate(([0], np.cumsum(lens)[:-1])).astype(np.int32) if len(lens) else np.zeros(0, np.int32),
@@ -42,6 +49,14 @@ class Document:
 	@property
 	def n_tokens(self):
 		return len(self._tokens)
+
+	@property
+	def pos(self):
+		return self._pos
+
+	@property
+	def tags(self):
+		return self._tags
 
 	@property
 	def spans(self):

@@ -70,6 +70,7 @@ struct vk_corpus {
 	uint8_t *d_tiles = nullptr;
 	float *d_mag = nullptr;
 	int32_t *d_tok_id = nullptr;
+	int8_t *d_pos = nullptr;   // POS code per token (tag-weighted queries)
 	int32_t *d_sent_start = nullptr, *d_sent_end = nullptr;
 	bool contiguous = false;   // slices are the CSR partition of the token stream
 	bool have_ids = false, have_sent = false, finalized = false;
@@ -190,7 +191,7 @@ int vk_corpus_free(vk_corpus_t *c) {
 	if (!c) return VK_OK;
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
-	void *ptrs[] = {c->d_tiles, c->d_mag, c->d_tok_id, c->d_sent_start, c->d_sent_end, c->d_stage, c->d_qtile, c->d_ws, c->d_wt, c->d_qids,
+	void *ptrs[] = {c->d_tiles, c->d_mag, c->d_tok_id, c->d_pos, c->d_sent_start, c->d_sent_end, c->d_stage, c->d_qtile, c->d_ws, c->d_wt, c->d_qids,
 		c->d_table, c->d_scores, c->d_raw, c->d_boost, c->d_keys[0], c->d_keys[1], c->d_out_raw, c->d_out_sim, c->d_out_map, c->d_wrd_raw, c->d_wrd_val, c->d_bq, c->d_bqlen, c->d_bscores, c->d_bkeys[0], c->d_bkeys[1]};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -250,6 +251,20 @@ int vk_corpus_set_token_ids(vk_corpus_t *c, const int32_t *ids, int64_t n, int32
 	VK_HIP(hipMemcpyAsync(c->d_tok_id, ids, (size_t)n * 4, mem == VK_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
 	VK_HIP(hipStreamSynchronize(c->stream));
 	c->have_ids = true;
+	return VK_OK;
+}
+
+int vk_corpus_set_token_pos(vk_corpus_t *c, const int8_t *pos, int64_t n, int32_t mem) {
+	if (!c || !pos) return fail(VK_ERR_INVALID, "null argument");
+	if (n != c->desc.n_tokens) return fail(VK_ERR_INVALID, "POS count differs from n_tokens");
+	VK_HIP(hipSetDevice(c->device));
+	if (!c->d_pos) {
+		int rc = alloc_t(c, &c->d_pos, (size_t)n + 64);
+		if (rc) return rc;
+		VK_HIP(hipMemsetAsync(c->d_pos, 0, (size_t)n + 64, c->stream));
+	}
+	VK_HIP(hipMemcpyAsync(c->d_pos, pos, (size_t)n, mem == VK_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+	VK_HIP(hipStreamSynchronize(c->stream));
 	return VK_OK;
 }
 
@@ -349,11 +364,18 @@ static int validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_t
 		if (q->gap_s.kind == VK_GAP_TABLE && q->gap_s.n_table <= c->max_len) return fail(VK_ERR_INVALID, "gap_s table shorter than the longest sentence");
 		if (q->gap_t.kind == VK_GAP_TABLE && q->gap_t.n_table <= q->len_t) return fail(VK_ERR_INVALID, "gap_t table shorter than the query");
 		if (q->want_flow && (!out->mapping || !out->edge_sim)) return fail(VK_ERR_INVALID, "want_flow needs mapping and edge_sim arrays");
+		if (q->tag_weights) {
+			if (!q->q_pos) return fail(VK_ERR_INVALID, "tag-weighted query without q_pos");
+			if (!c->d_pos) return fail(VK_ERR_STATE, "tag-weighted query needs vk_corpus_set_token_pos");
+			if (q->similarity_threshold < 0.0f) return fail(VK_ERR_INVALID, "similarity_threshold must be >= 0 (slice/static.h:209)");
+		}
 	} else if (q->algorithm == VK_ALG_RWMD) {
+		if (q->tag_weights) return fail(VK_ERR_UNSUPPORTED, "tag-weighted similarity is implemented for alignments only");
 		if (!q->rwmd_injective)
 			return fail(VK_ERR_UNSUPPORTED, "non-injective RWMD (rwmd('nbow/distributed')) is not implemented on the HIP path");
 		if (q->want_flow && (!out->mapping || !out->edge_sim)) return fail(VK_ERR_INVALID, "want_flow needs mapping and edge_sim arrays");
 	} else if (q->algorithm == VK_ALG_WRD) {
+		if (q->tag_weights) return fail(VK_ERR_UNSUPPORTED, "tag-weighted similarity is implemented for alignments only");
 		if (c->desc.layout != VK_LAYOUT_CONTEXTUAL)
 			return fail(VK_ERR_UNSUPPORTED, "VK_ALG_WRD is implemented for the contextual layout only");
 		if (!c->d_mag) return fail(VK_ERR_STATE, "VK_ALG_WRD needs a corpus created with keep_magnitudes = 1");
@@ -480,6 +502,19 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	p.ws = c->d_ws; p.wt = c->d_wt;
 	p.boost = q->boost ? c->d_boost : nullptr;
 	p.scores = c->d_scores; p.raw = c->d_raw;
+	p.ref_total = (float)q->len_t;
+	if (q->tag_weights && is_align) {
+		float total = 0.0f;
+		for (int j = 0; j < VK_MAX_QUERY_LEN; j++) {
+			p.tw[j] = j < q->len_t ? q->tag_weights[j] : 0.0f;
+			p.tpos[j] = j < q->len_t ? (int32_t)q->q_pos[j] : -1;
+			if (j < q->len_t) total += q->tag_weights[j];
+		}
+		p.pos_s = c->d_pos;
+		p.tw_keep = 1.0f - q->pos_mismatch_penalty;
+		p.tw_threshold = q->similarity_threshold;
+		p.ref_total = total;   // reference_score with max_similarity_for_t = t_pos_weights (slice/static.h:280-286)
+	}
 	p.s_rows_per_wave = is_static ? (c->max_group_tokens + 15) / 16 * 16 : c->max_group_tiles * 16;
 	p.h_rows = c->max_len + 1;
 	int lds_floats = p.s_rows_per_wave * 16;
@@ -600,6 +635,9 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		f.qtile = c->d_qtile; f.len_t = q->len_t; f.locality = q->locality; f.gap_mode = (p.gap_mode == 3 || p.gap_mode == 6) ? 2 : p.gap_mode;
 		f.gs = p.gs; f.gt = p.gt; f.a_s = p.a_s; f.a_t = p.a_t; f.open_s = p.open_s; f.open_t = p.open_t;
 		f.ws = c->d_ws; f.wt = c->d_wt;
+		f.pos_s = p.pos_s; f.tw_keep = p.tw_keep; f.tw_threshold = p.tw_threshold;
+		memcpy(f.tw, p.tw, sizeof f.tw);
+		memcpy(f.tpos, p.tpos, sizeof f.tpos);
 		f.keys = c->d_keys[cur]; f.raw_out = c->d_out_raw; f.mapping = c->d_out_map; f.edge_sim = c->d_out_sim;
 		VK_HIP(vk_launch_flow(&f, k, st));
 	}
@@ -678,7 +716,7 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 		const vk_query_desc &q = qs[i];
 		gemm = q.algorithm == VK_ALG_RWMD && q.rwmd_injective && q.rwmd_symmetric == qs[0].rwmd_symmetric &&
 			q.rwmd_normalize_bow == qs[0].rwmd_normalize_bow && q.max_matches == qs[0].max_matches &&
-			q.min_score == qs[0].min_score && q.boost == qs[0].boost;
+			q.min_score == qs[0].min_score && q.boost == qs[0].boost && !q.tag_weights;
 	}
 	if (!gemm) {
 		for (int i = 0; i < n_queries; i++) {

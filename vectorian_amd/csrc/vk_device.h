@@ -39,6 +39,13 @@ struct VkScoreParams {
 	const float *ws;           // general: [max_len + 1]
 	const float *wt;           // general: [17]
 	const float *boost;        // [n_sent] or null
+	// tag-weighted similarity modifier (pos_s == nullptr: off)
+	const int8_t *pos_s;       // [n_tokens + pad] POS code per token
+	float tw[VK_DEV_MAX_QUERY_LEN];      // t_pos_weights
+	int32_t tpos[VK_DEV_MAX_QUERY_LEN];  // POS code per query token
+	float tw_keep;             // 1 - pos_mismatch_penalty
+	float tw_threshold;
+	float ref_total;           // reference_score: len_t, or sum(tw)
 	const float *mag;          // WRD: token magnitudes (contextual) / vocabulary magnitudes (static)
 	float qmass[VK_DEV_MAX_QUERY_LEN];   // WRD: query masses |q_j| / sum |q|
 	// outputs
@@ -97,6 +104,10 @@ struct VkFlowParams {
 	float gs, gt, a_s, a_t, open_s, open_t;
 	const float *ws;
 	const float *wt;
+	const int8_t *pos_s;
+	float tw[VK_DEV_MAX_QUERY_LEN];
+	int32_t tpos[VK_DEV_MAX_QUERY_LEN];
+	float tw_keep, tw_threshold;
 	const uint64_t *keys;      // winners, best first; 0 = empty slot
 	float *raw_out;            // [k]
 	int16_t *mapping;          // [k x 16]

@@ -254,6 +254,15 @@ __device__ __forceinline__ f32x4 sim_tile_generic(const uint8_t *__restrict__ qt
 	return acc;
 }
 
+// TagWeightedSlice::similarity (vectorian/core/cpp/slice/static.h:237-264): S * weight(i, j) with
+// weight = t_pos_weights[j] * (pos_s != pos_t ? 1 - penalty : 1); values <= threshold become 0.
+__device__ __forceinline__ float tag_weighted(float s, float w, int pos_s, int pos_t, float keep, float thr) {
+	float wgt = w;
+	if (pos_s != pos_t) wgt *= keep;
+	const float sc = s * wgt;
+	return sc <= thr ? 0.0f : sc;
+}
+
 // ---------------------------------------------------------------------------
 // DP over a group of 4 sentences: DPP row sigma = lane >> 4 is one sentence, lane
 // v = lane & 15 is query column v + 1.  Rows (sentence tokens) are swept serially;
@@ -620,7 +629,15 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 	a.gs = p.gs; a.gt = p.gt; a.a_s = p.a_s; a.a_t = p.a_t; a.open_s = p.open_s; a.open_t = p.open_t;
 	a.ws = p.ws; a.wt = p.wt;
 	a.rwmd_symmetric = p.rwmd_symmetric; a.rwmd_normalize_bow = p.rwmd_normalize_bow;
-	const float inv_ref = (float)p.len_t;
+	const float inv_ref = p.ref_total;
+	// tag-weighted modifier: this lane's four query columns (MFMA layout: 4*(lane>>4) + r)
+	float twl[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+	int tposl[4] = {0, 0, 0, 0};
+	if (p.pos_s) {
+		const int cbase = (MODE == 2) ? (lane & 3) * 4 : (lane >> 4) * 4;
+#pragma unroll
+		for (int r = 0; r < 4; r++) { twl[r] = p.tw[cbase + r]; tposl[r] = p.tpos[cbase + r]; }
+	}
 
 	// general gap, fast form: gap tables in (scalar) registers for the whole kernel
 	constexpr int WSN = GAP == 6 ? 65 : 33;
@@ -653,7 +670,14 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 				const int tk = it * 16 + (lane >> 2);
 				if (tk < ntok) {
 					const int id = p.tok_id[g_a + tk];
-					const float4 val = *reinterpret_cast<const float4 *>(p.table + (int64_t)id * 16 + (lane & 3) * 4);
+					float4 val = *reinterpret_cast<const float4 *>(p.table + (int64_t)id * 16 + (lane & 3) * 4);
+					if (p.pos_s) {
+						const int ps = p.pos_s[g_a + tk];
+						val.x = tag_weighted(val.x, twl[0], ps, tposl[0], p.tw_keep, p.tw_threshold);
+						val.y = tag_weighted(val.y, twl[1], ps, tposl[1], p.tw_keep, p.tw_threshold);
+						val.z = tag_weighted(val.z, twl[2], ps, tposl[2], p.tw_keep, p.tw_threshold);
+						val.w = tag_weighted(val.w, twl[3], ps, tposl[3], p.tw_keep, p.tw_threshold);
+					}
 					*reinterpret_cast<float4 *>(S + tk * 16 + (lane & 3) * 4) = val;
 				}
 			}
@@ -667,6 +691,11 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 				if constexpr (MODE == 0) acc = sim_tile<NK32, TAIL>(qf, tp, lane);
 				else if constexpr (MODE == 3) acc = sim_tile_qlds<NK32, TAIL>(qlds, tp, lane);
 				else acc = sim_tile_generic(p.qtile, tp, p.nk32, p.tail, lane);
+				if (p.pos_s) {
+					const int ps = p.pos_s[(tile0 + ti) * 16 + (lane & 15)];
+#pragma unroll
+					for (int r = 0; r < 4; r++) acc[r] = tag_weighted(acc[r], twl[r], ps, tposl[r], p.tw_keep, p.tw_threshold);
+				}
 				*reinterpret_cast<f32x4 *>(S + (ti * 16 + (lane & 15)) * 16 + (lane >> 4) * 4) = acc;
 				tp += p.tile_bytes;
 			}
@@ -1054,6 +1083,7 @@ __global__ __launch_bounds__(256) void vk_topk_wave_batch_kernel(const float *__
 
 __global__ __launch_bounds__(64) void vk_flow_kernel(VkFlowParams p) {
 	__shared__ __attribute__((aligned(16))) float S[(VK_DEV_MAX_SENT_LEN + 32) * 16];
+	__shared__ __attribute__((aligned(16))) float SW[(VK_DEV_MAX_SENT_LEN + 32) * 16];   // tag-weighted copy the DP runs on
 	__shared__ float H[VK_TB_ROWS * VK_TB_W];
 	__shared__ float E[VK_TB_ROWS * VK_TB_W];
 	__shared__ float F[VK_TB_ROWS * VK_TB_W];
@@ -1072,14 +1102,23 @@ __global__ __launch_bounds__(64) void vk_flow_kernel(VkFlowParams p) {
 	const int t_a = p.sent_start[g], t_b = p.sent_end[g];
 	const int len_s = t_b - t_a, len_t = p.len_t;
 
+	// S: unmodified similarities (reported per edge, metric/alignment.h:339); SW: what the DP runs on
 	int rowbase;
 	if (p.layout == VK_DEV_LAYOUT_STATIC) {
 		for (int it = 0; it * 16 < len_s; it++) {
 			const int tk = it * 16 + (lane >> 2);
 			if (tk < len_s) {
 				const int id = p.tok_id[t_a + tk];
-				*reinterpret_cast<float4 *>(S + tk * 16 + (lane & 3) * 4) =
-					*reinterpret_cast<const float4 *>(p.table + (int64_t)id * 16 + (lane & 3) * 4);
+				float4 val = *reinterpret_cast<const float4 *>(p.table + (int64_t)id * 16 + (lane & 3) * 4);
+				*reinterpret_cast<float4 *>(S + tk * 16 + (lane & 3) * 4) = val;
+				if (p.pos_s) {
+					const int ps = p.pos_s[t_a + tk], cb = (lane & 3) * 4;
+					val.x = tag_weighted(val.x, p.tw[cb + 0], ps, p.tpos[cb + 0], p.tw_keep, p.tw_threshold);
+					val.y = tag_weighted(val.y, p.tw[cb + 1], ps, p.tpos[cb + 1], p.tw_keep, p.tw_threshold);
+					val.z = tag_weighted(val.z, p.tw[cb + 2], ps, p.tpos[cb + 2], p.tw_keep, p.tw_threshold);
+					val.w = tag_weighted(val.w, p.tw[cb + 3], ps, p.tpos[cb + 3], p.tw_keep, p.tw_threshold);
+				}
+				*reinterpret_cast<float4 *>(SW + tk * 16 + (lane & 3) * 4) = val;
 			}
 		}
 		rowbase = 0;
@@ -1087,8 +1126,14 @@ __global__ __launch_bounds__(64) void vk_flow_kernel(VkFlowParams p) {
 		const int tile0 = t_a >> 4;
 		const int ntiles = ((t_b + 15) >> 4) - tile0;
 		for (int ti = 0; ti < ntiles; ti++) {
-			const f32x4 acc = sim_tile_generic(p.qtile, p.tiles + (int64_t)(tile0 + ti) * p.tile_bytes, p.nk32, p.tail, lane);
+			f32x4 acc = sim_tile_generic(p.qtile, p.tiles + (int64_t)(tile0 + ti) * p.tile_bytes, p.nk32, p.tail, lane);
 			*reinterpret_cast<f32x4 *>(S + (ti * 16 + (lane & 15)) * 16 + (lane >> 4) * 4) = acc;
+			if (p.pos_s) {
+				const int ps = p.pos_s[(tile0 + ti) * 16 + (lane & 15)], cb = (lane >> 4) * 4;
+#pragma unroll
+				for (int r = 0; r < 4; r++) acc[r] = tag_weighted(acc[r], p.tw[cb + r], ps, p.tpos[cb + r], p.tw_keep, p.tw_threshold);
+			}
+			*reinterpret_cast<f32x4 *>(SW + (ti * 16 + (lane & 15)) * 16 + (lane >> 4) * 4) = acc;
 		}
 		rowbase = t_a - tile0 * 16;
 	}
@@ -1097,7 +1142,8 @@ __global__ __launch_bounds__(64) void vk_flow_kernel(VkFlowParams p) {
 	if (lane <= VK_DEV_MAX_QUERY_LEN) wtl[lane] = p.wt[lane];
 	__syncthreads();
 
-	const float *Sm = S + rowbase * 16;
+	const float *Sm = SW + rowbase * 16;      // DP input
+	const float *Su = S + rowbase * 16;       // unmodified, for the edges
 	const int W = VK_TB_W;
 	const bool local = p.locality == VK_DEV_LOCAL, global = p.locality == VK_DEV_GLOBAL;
 	const int gap = p.gap_mode;
@@ -1217,7 +1263,7 @@ __global__ __launch_bounds__(64) void vk_flow_kernel(VkFlowParams p) {
 		if (gap == 1 && state == 2) { if (!fext[idx]) state = 0; v2--; continue; }
 		const uint8_t d = dirs[idx];
 		if (d == 0) break;
-		if (d == 1) { mp[v2 - 1] = (int16_t)(u - 1); es[v2 - 1] = Sm[(u - 1) * 16 + v2 - 1]; u--; v2--; }
+		if (d == 1) { mp[v2 - 1] = (int16_t)(u - 1); es[v2 - 1] = Su[(u - 1) * 16 + v2 - 1]; u--; v2--; }
 		else if (gap == 1) state = (d == 2) ? 1 : 2;
 		else if (d == 2) u -= dk[idx];
 		else v2 -= dk[idx];

@@ -56,10 +56,17 @@ class PreparedQuery:
 
 	def __init__(self, query, vocab, nlp):
 		self._query = query
-		tokens = list((nlp or default_tokenizer)(query.text))
+		raw = list((nlp or default_tokenizer)(query.text))
 		for attr in ("pos_filter", "tag_filter"):
 			if query.options.get(attr):
-				raise NotImplementedError(f"{attr} needs part-of-speech tags; tokens here carry none")
+				raise NotImplementedError(f"{attr} is not implemented on the HIP path")
+		# nlp may return plain strings, or dicts with 'text' / 'pos' / 'tag' (as spaCy's doc.to_json()["tokens"])
+		tokens, self._pos, self._tags = [], [], []
+		for t in raw:
+			if isinstance(t, dict):
+				tokens.append(t["text"]); self._pos.append(t.get("pos")); self._tags.append(t.get("tag"))
+			else:
+				tokens.append(t); self._pos.append(None); self._tags.append(None)
 		self._tokens = tokens
 		self._token_ids = np.array([vocab.token_to_id(t) for t in tokens], dtype=np.int32)
 
@@ -82,6 +89,14 @@ class PreparedQuery:
 	@property
 	def token_ids(self):
 		return self._token_ids
+
+	@property
+	def pos(self):
+		return self._pos
+
+	@property
+	def tags(self):
+		return self._tags
 
 	@property
 	def n_tokens(self):
@@ -429,6 +444,10 @@ class HipBruteForceIndex(Index):
 				self._corpus.append_vectors(Vectors(doc.contextual_vectors(emb.name)).unmodified, normalize=True)
 		else:
 			raise TypeError(emb)
+		self._has_pos = all(doc.pos is not None for doc in session.documents) and len(session.documents) > 0
+		if self._has_pos and n_tokens:
+			self._corpus.set_token_pos(np.array(
+				[session.pos_code(x) for doc in session.documents for x in doc.pos], dtype=np.int8))
 		if self._sent_off is not None:
 			self._corpus.set_sentences(self._sent_off)
 		else:
@@ -454,9 +473,8 @@ class HipBruteForceIndex(Index):
 			if k not in _QUERY_OPTION_WHITELIST:
 				raise RuntimeError(f"illegal option {k}")   # query.cpp:60-63
 		metric = options.get("metric")
-		if not isinstance(metric, dict) or metric.get("metric") not in ("alignment-isolated",):
-			raise NotImplementedError(f"metric {metric.get('metric') if isinstance(metric, dict) else metric} "
-				"is not implemented on the HIP path ('alignment-tag-weighted' is a next row, SURVEY 8f-1)")
+		if not isinstance(metric, dict) or metric.get("metric") not in ("alignment-isolated", "alignment-tag-weighted"):
+			raise RuntimeError(f"unknown sentence metric type {metric.get('metric') if isinstance(metric, dict) else metric}")  # instantiate.cpp:191-196
 		alignment = metric["alignment"]
 		args = dict(
 			max_matches=int(options.get("max_matches", 100)),      # query.cpp:87-89
@@ -483,6 +501,13 @@ class HipBruteForceIndex(Index):
 			gaps = (lambda k: 0.0, lambda k: 0.0)
 		else:
 			raise RuntimeError(f"unknown alignment algorithm {algorithm}")   # metric/alignment.h:914-919
+		if metric["metric"] == "alignment-tag-weighted":
+			if algorithm != "pyalign":
+				raise NotImplementedError("tag-weighted similarity is implemented for alignments only")
+			args["tag_weighted"] = dict(
+				tag_weights=metric["tag_weights"],
+				pos_mismatch_penalty=float(metric.get("pos_mismatch_penalty", 0)),
+				similarity_threshold=float(metric.get("similarity_threshold", 0)))
 		return args, gaps
 
 	def _find(self, query, progress=None):
@@ -490,6 +515,15 @@ class HipBruteForceIndex(Index):
 		if len(p_query) == 0:
 			return []
 		args, gaps = self._backend_args(query.options)
+		tw = args.pop("tag_weighted", None)
+		if tw is not None:
+			# parse_tag_weights (vectorian/core/cpp/match/instantiate.cpp:10-38): weight by Penn tag, default 1
+			if not self._has_pos:
+				raise RuntimeError("tag-weighted similarity needs documents with pos / tags")
+			args["tag_weights"] = np.array([float(tw["tag_weights"].get(t, 1.0)) for t in p_query.tags], dtype=np.float32)
+			args["q_pos"] = np.array([self.session.pos_code(x) if x is not None else 0 for x in p_query.pos], dtype=np.int8)
+			args["pos_mismatch_penalty"] = tw["pos_mismatch_penalty"]
+			args["similarity_threshold"] = tw["similarity_threshold"]
 		emb = self._embedding
 		qv = emb.encode_tokens(p_query.tokens)
 		if emb.is_static:

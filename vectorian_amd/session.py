@@ -150,6 +150,7 @@ class Session:
 					if not doc.has_contextual_embedding(embedding.name):
 						raise RuntimeError(f"doc {doc.unique_id or i} misses contextual embedding {embedding.name}")
 		self._embedding_encoders = collections.OrderedDict((e.name, e) for e in self._token_embeddings)
+		self._pos_codes = {}
 		self._vocab = Vocabulary()
 		self._doc_token_ids = []
 		for doc in corpus:
@@ -173,6 +174,16 @@ class Session:
 
 	def doc_token_ids(self, doc_index):
 		return self._doc_token_ids[doc_index]
+
+	def pos_code(self, pos):
+		"""small integer per universal POS string (the reference stores Token.pos as int8, common.h:34-42)"""
+		c = self._pos_codes.get(pos)
+		if c is None:
+			c = len(self._pos_codes) + 1
+			if c > 127:
+				raise ValueError("more than 127 distinct POS values")
+			self._pos_codes[pos] = c
+		return c
 
 	@property
 	def encoders(self):
