@@ -32,6 +32,7 @@ def main():
 	ap.add_argument("--steps", type=int, default=10)
 	ap.add_argument("--warmup", type=int, default=2)
 	ap.add_argument("--k", type=int, default=10)
+	ap.add_argument("--layout", choices=["contextual", "static"], default="contextual")
 	ap.add_argument("--batch", type=int, default=0, help="queries per vk_query_batch call (config 4: 256)")
 	args = ap.parse_args()
 
@@ -47,6 +48,43 @@ def main():
 	np.cumsum(lens, out=off[1:])
 	n_tok = int(off[-1])
 	ids = synth.zipf_ids(n_tok, V, rng)
+	if args.layout == "static":
+		# the reference's static-embedding layout: token ids + vocabulary table, per-query [V x |q|] table
+		corpus = core.Corpus(layout=core.VK_LAYOUT_STATIC, d=args.d, n_tokens=n_tok, n_sentences=args.sentences, vocab_size=V)
+		corpus.append_vectors(E, normalize=True)
+		corpus.set_token_ids(ids)
+		corpus.set_sentences(off)
+		corpus.finalize()
+		w = (1 - 2.0 ** (-np.arange(0, 65) / 5)).astype(np.float32)
+		gap = {"exp5": ("table", w), "linear": 0.1, "affine": ("affine", 0.2, 0.05)}[args.gap]
+		loc = {"local": 0, "global": 1, "semiglobal": 2}[args.locality]
+		alg = {"align": core.VK_ALG_ALIGN, "rwmd": core.VK_ALG_RWMD, "wrd": core.VK_ALG_WRD}[args.alg]
+		qs = []
+		for i in range(args.steps + args.warmup):
+			s_ = int(rng.integers(0, args.sentences)); st_ = int(off[s_])
+			qi = ids[st_:st_ + args.len_t] if i % 2 == 0 else rng.integers(0, V, size=args.len_t)
+			if len(qi) < args.len_t:
+				qi = np.concatenate([qi, rng.integers(0, V, size=args.len_t - len(qi))])
+			qs.append((np.ascontiguousarray(E[qi], dtype=np.float32), np.asarray(qi, dtype=np.int32)))
+		for i in range(args.warmup):
+			corpus.query(qs[i][0], q_token_ids=qs[i][1], algorithm=alg, locality=loc, gap_s=gap, gap_t=gap, max_matches=args.k, want_flow=args.alg == "align")
+		torch.cuda.synchronize()
+		ph = []
+		t0 = time.perf_counter()
+		for i in range(args.steps):
+			q = qs[args.warmup + i]
+			corpus.query(q[0], q_token_ids=q[1], algorithm=alg, locality=loc, gap_s=gap, gap_t=gap, max_matches=args.k, want_flow=args.alg == "align")
+			ph.append(corpus.last_timings())
+		el = time.perf_counter() - t0
+		score_ms = float(np.mean([p["score_ms"] for p in ph]))
+		cells = float(n_tok) * args.len_t
+		print(json.dumps({"layout": "static", "alg": args.alg, "gap": args.gap, "d": args.d, "len_t": args.len_t, "len_s": [args.min_len, args.max_len],
+			"sentences": args.sentences, "pairs_per_s": args.sentences * args.steps / el, "ms_per_query": el / args.steps * 1e3,
+			"score_kernel_ms": score_ms, "GCUPS": cells / (score_ms * 1e-3) / 1e9,
+			"token_id_GBps": n_tok * 4 / (score_ms * 1e-3) / 1e9,
+			"phases_ms_mean": {k: float(np.mean([p[k] for p in ph])) for k in ph[0]}}))
+		corpus.close()
+		return
 	corpus = core.Corpus(layout=core.VK_LAYOUT_CONTEXTUAL, d=args.d, n_tokens=n_tok, n_sentences=args.sentences,
 		keep_magnitudes=args.alg == "wrd")
 	E_dev = torch.from_numpy(E).to(device)

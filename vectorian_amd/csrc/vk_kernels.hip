@@ -1469,7 +1469,7 @@ static hipError_t launch_sized(K kernel, const VkScoreParams &p, int want_blocks
 	if (occ < 1) occ = 1;
 	// measured on MI355X (1M x 32 x 300-d): 3 workgroups (12 waves) per CU stream HBM fastest --
 	// 2.90 ms vs 3.51 ms at 5 per CU for the linear-gap kernel, 2.95 ms at 4; more concurrent streams cost bandwidth
-	if (occ > 3) occ = 3;
+	if (occ > 3 && p.layout != VK_DEV_LAYOUT_STATIC) occ = 3;   // the static layout is DP-bound, not a stream: keep full residency
 	static const char *ov = getenv("VK_BLOCKS_PER_CU");
 	if (ov && atoi(ov) > 0) occ = atoi(ov);
 	int dev = 0, cus = 256;
