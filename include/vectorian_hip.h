@@ -111,6 +111,10 @@ typedef struct {
 	const int8_t *q_pos;       /* host [len_t] universal POS code per query token */
 	float pos_mismatch_penalty;
 	float similarity_threshold;
+	/* VK_ALG_RWMD with 'relaxed': False (vectorian/alignment.py:206-218): the full Word Mover's Distance,
+	 * exact EMD between the two bags of words (FullSolver, alignment/wmd.h:194-270); needs
+	 * rwmd_injective = rwmd_symmetric = 0 as upstream (wmd.h:201-209) */
+	int32_t wmd_full;
 } vk_query_desc;
 
 /* Bounded result set, best first.  Order: score descending, then sentence index

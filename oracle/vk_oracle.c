@@ -536,11 +536,16 @@ static int cmp_dist_ref(const void *a, const void *b) {
 	return (x->j > y->j) - (x->j < y->j);
 }
 
-float vko_rwmd(const float *S, int32_t ld, int32_t len_s, int32_t len_t,
+double vko_emd(const double *a, int32_t n, const double *b, int32_t m, const double *C, double *flow);
+
+float vko_wmd(const float *S, int32_t ld, int32_t len_s, int32_t len_t,
 	const int32_t *ids_s, const int32_t *ids_t,
-	int32_t injective, int32_t symmetric, int32_t normalize_bow) {
+	int32_t relaxed, int32_t injective, int32_t symmetric, int32_t normalize_bow) {
 
 	if (len_s <= 0 || len_t <= 0) return 0.0f;
+	/* WMD::operator() (wmd.h:441-449) and FullSolver (wmd.h:201-209) reject these combinations */
+	if (symmetric && !normalize_bow) return NAN;
+	if (!relaxed && (injective || symmetric)) return NAN;
 	const int32_t K = len_s + len_t;
 	/* per doc (0 = s, 1 = t): bow over joint vocabulary, vocab list, first position */
 	float *bow[2];
@@ -609,6 +614,28 @@ float vko_rwmd(const float *S, int32_t ld, int32_t len_s, int32_t len_t,
 		}
 	}
 
+	if (!relaxed) {
+		/* FullSolver (wmd.h:194-270): exact EMD between the two histograms over the joint vocabulary,
+		 * transport.h:91-145 -> pyemd emd_hat_gd_metric<double>; score = sum((1-D)*G)/sum(G) (:247) */
+		double *P = (double *)calloc((size_t)vocab_size, sizeof(double));
+		double *Qm = (double *)calloc((size_t)vocab_size, sizeof(double));
+		double *Cd = (double *)malloc(sizeof(double) * (size_t)vocab_size * vocab_size);
+		double *G = (double *)malloc(sizeof(double) * (size_t)vocab_size * vocab_size);
+		for (int32_t i = 0; i < vocab_size; i++) { P[i] = (double)bow[1][i]; Qm[i] = (double)bow[0][i]; }
+		for (int64_t i = 0; i < (int64_t)vocab_size * vocab_size; i++) Cd[i] = (double)D[i];
+		vko_emd(P, vocab_size, Qm, vocab_size, Cd, G);
+		double num = 0.0, den = 0.0;
+		for (int64_t i = 0; i < (int64_t)vocab_size * vocab_size; i++) {
+			const float gq = (float)G[i];
+			num += (double)((1.0f - D[i]) * gq);
+			den += (double)gq;
+		}
+		free(P); free(Qm); free(Cd); free(G);
+		for (int c = 0; c < 2; c++) { free(bow[c]); free(vocab[c]); free(first_pos[c]); }
+		free(D);
+		return den > 0.0 ? (float)(num / den) : 0.0f;
+	}
+
 	/* RelaxedSolver: c = 0 moves t -> s, c = 1 moves s -> t (wmd.h:303-306) */
 	const int order[2] = {1, 0};
 	dist_ref *cand = (dist_ref *)malloc(sizeof(dist_ref) * (size_t)K);
@@ -664,6 +691,12 @@ float vko_rwmd(const float *S, int32_t ld, int32_t len_s, int32_t len_t,
 	free(D);
 	free(cand);
 	return (max_cost - cost) / max_cost; /* cost_to_score, wmd.h:138-140 */
+}
+
+float vko_rwmd(const float *S, int32_t ld, int32_t len_s, int32_t len_t,
+	const int32_t *ids_s, const int32_t *ids_t,
+	int32_t injective, int32_t symmetric, int32_t normalize_bow) {
+	return vko_wmd(S, ld, len_s, len_t, ids_s, ids_t, 1, injective, symmetric, normalize_bow);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -891,7 +924,8 @@ static int score_sentence(const work *w, int64_t s, float *Sbuf, float *xbuf, fl
 	} else if (q->algorithm == VKO_ALG_RWMD) {
 		const int32_t *ids_s = c->layout == VKO_LAYOUT_STATIC ? c->tok_id + t0 : NULL;
 		const int32_t *ids_t = c->layout == VKO_LAYOUT_STATIC ? q->q_ids : NULL;
-		raw = vko_rwmd(Sbuf, len_t, len_s, len_t, ids_s, ids_t, q->rwmd_injective, q->rwmd_symmetric, q->rwmd_normalize_bow);
+		raw = vko_wmd(Sbuf, len_t, len_s, len_t, ids_s, ids_t, !q->wmd_full, q->rwmd_injective, q->rwmd_symmetric, q->rwmd_normalize_bow);
+		if (raw != raw) return 2;
 		/* SparseFlow::max_score -> matched = len_t (match.h:165-176) => ref = len_t */
 		*value_out = vko_score(raw, len_t, len_t, q->submatch_weight, boost);
 	} else {

@@ -95,6 +95,12 @@ float vko_rwmd(const float *S, int32_t ld, int32_t len_s, int32_t len_t,
 	const int32_t *ids_s, const int32_t *ids_t,
 	int32_t injective, int32_t symmetric, int32_t normalize_bow);
 
+/* relaxed = 0: the full WMD (FullSolver, wmd.h:194-270), exact EMD over the joint vocabulary.
+ * Returns NaN for the option combinations the reference rejects (wmd.h:201-209, 441-449). */
+float vko_wmd(const float *S, int32_t ld, int32_t len_s, int32_t len_t,
+	const int32_t *ids_s, const int32_t *ids_t,
+	int32_t relaxed, int32_t injective, int32_t symmetric, int32_t normalize_bow);
+
 /* ---- a18: WRD ----------------------------------------------------------- */
 float vko_wrd(const float *S, int32_t ld, int32_t len_s, int32_t len_t,
 	const float *mag_s, const float *mag_t, int32_t normalize_magnitudes);
@@ -140,6 +146,7 @@ typedef struct {
 	const int8_t *q_pos;      /* [len_t] universal POS code per query token */
 	float pos_mismatch_penalty;
 	float similarity_threshold;
+	int32_t wmd_full;         /* VKO_ALG_RWMD with relaxed = False: full WMD */
 } vko_query;
 
 typedef struct {

@@ -55,7 +55,7 @@ class Query(C.Structure):
 		("rwmd_injective", C.c_int32), ("rwmd_symmetric", C.c_int32), ("rwmd_normalize_bow", C.c_int32),
 		("wrd_normalize_magnitudes", C.c_int32),
 		("tag_weights", C.c_void_p), ("q_pos", C.c_void_p),
-		("pos_mismatch_penalty", C.c_float), ("similarity_threshold", C.c_float)]
+		("pos_mismatch_penalty", C.c_float), ("similarity_threshold", C.c_float), ("wmd_full", C.c_int32)]
 
 
 class Result(C.Structure):
@@ -228,6 +228,17 @@ def rwmd(S, ids_s=None, ids_t=None, injective=True, symmetric=True, normalize_bo
 		_ptr(a), _ptr(b), C.c_int32(int(injective)), C.c_int32(int(symmetric)), C.c_int32(int(normalize_bow)))
 
 
+def wmd(S, ids_s=None, ids_t=None, relaxed=False, injective=False, symmetric=False, normalize_bow=False):
+	S = _f32(S)
+	a = None if ids_s is None else np.ascontiguousarray(ids_s, dtype=np.int32)
+	b = None if ids_t is None else np.ascontiguousarray(ids_t, dtype=np.int32)
+	L = lib()
+	L.vko_wmd.restype = C.c_float
+	return L.vko_wmd(
+		_ptr(S), C.c_int32(S.shape[1]), C.c_int32(S.shape[0]), C.c_int32(S.shape[1]), _ptr(a), _ptr(b),
+		C.c_int32(int(relaxed)), C.c_int32(int(injective)), C.c_int32(int(symmetric)), C.c_int32(int(normalize_bow)))
+
+
 def wrd(S, mag_s, mag_t, normalize_magnitudes=True):
 	S, mag_s, mag_t = _f32(S), _f32(mag_s), _f32(mag_t)
 	return lib().vko_wrd(
@@ -250,7 +261,7 @@ def find_many(*, layout, d, sent_off, Qs, sent_end=None, X=None, X_mag=None, tok
 		algorithm=ALG_ALIGN, locality=LOCAL, gap_s=0.0, gap_t=0.0, q_ids=None, Q_mags=None,
 		max_matches=10, min_score=0.0, boost=None, submatch_weight=0.0,
 		rwmd=(True, True, True), wrd_normalize=True, n_threads=1, want_all_scores=False,
-		pos_s=None, tag_weights=None, q_pos=None, pos_mismatch_penalty=0.0, similarity_threshold=0.0):
+		pos_s=None, tag_weights=None, q_pos=None, pos_mismatch_penalty=0.0, similarity_threshold=0.0, wmd_full=False):
 	"""Runs vko_find_many over a batch of queries (Qs: list of uint16 bf16 [len_t x d]); q_ids / Q_mags
 	are per-query lists or None.  Returns a list of dict(score, raw, sentence, mapping[, all_scores])."""
 	keep = []
@@ -299,6 +310,7 @@ def find_many(*, layout, d, sent_off, Qs, sent_end=None, X=None, X_mag=None, tok
 			q.boost = _ptr(boost)
 		q.rwmd_injective, q.rwmd_symmetric, q.rwmd_normalize_bow = [int(x) for x in rwmd]
 		q.wrd_normalize_magnitudes = int(wrd_normalize)
+		q.wmd_full = int(bool(wmd_full))
 		if tag_weights is not None and tag_weights[i] is not None:
 			tw = _f32(tag_weights[i]); keep.append(tw); q.tag_weights = _ptr(tw)
 			if q_pos is not None and q_pos[i] is not None:

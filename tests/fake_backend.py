@@ -61,7 +61,7 @@ class OracleCorpus:
 	def query(self, q_vectors, *, locality=0, gap_s=0.0, gap_t=0.0, algorithm=0, q_token_ids=None, q_normalize=True,
 			max_matches=10, min_score=0.0, boost=None, want_flow=True, submatch_weight=0.0, bidirectional=False,
 			rwmd=(True, True, True), wrd_normalize=True, tag_weights=None, q_pos=None, pos_mismatch_penalty=0.0,
-			similarity_threshold=0.0):
+			similarity_threshold=0.0, wmd_full=False):
 		q = np.ascontiguousarray(q_vectors)
 		if q.dtype == np.uint16:
 			q = synth.bf16_bits_to_f32(q)
@@ -74,7 +74,7 @@ class OracleCorpus:
 			gap_s=_gap(gap_s), gap_t=_gap(gap_t), max_matches=max_matches, min_score=min_score, boost=boost,
 			submatch_weight=submatch_weight, rwmd=rwmd, wrd_normalize=wrd_normalize, want_all_scores=True,
 			pos_s=self._pos, tag_weights=tag_weights, q_pos=q_pos, pos_mismatch_penalty=pos_mismatch_penalty,
-			similarity_threshold=similarity_threshold)
+			similarity_threshold=similarity_threshold, wmd_full=wmd_full)
 		if self.layout == core.VK_LAYOUT_STATIC:
 			kw.update(tok_id=self._ids, E=self._X, q_ids=q_token_ids)
 		else:

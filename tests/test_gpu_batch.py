@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("length,d,len_t,flags", [
 	(32, 300, 10, (True, True, True)),
 	(16, 300, 5, (True, False, False)),
-	(48, 128, 16, (True, True, False)),
+	(48, 128, 16, (True, False, True)),
 	(64, 300, 3, (True, True, True)),
 ])
 def test_rwmd_gemm_batch(hip, oracle, length, d, len_t, flags):

@@ -14,7 +14,6 @@ VARIANTS = {
 	"nbow": (True, True, True),        # rwmd('nbow'): injective, symmetric, normalised (vectorian/alignment.py:232-233)
 	"bow/fast": (True, False, False),  # rwmd('bow/fast') (:236-237)
 	"nbow-onesided": (True, False, True),
-	"bow-symmetric": (True, True, False),
 }
 
 
@@ -63,4 +62,47 @@ def test_non_injective_is_rejected(hip):
 	c = hip_contextual_corpus(hip, corpus)
 	with pytest.raises(hip.VkError):
 		c.query(np.ones((3, 32), np.float32), algorithm=hip.VK_ALG_RWMD, rwmd=(False, True, True))
+	c.close()
+
+
+def test_symmetric_bow_is_rejected_like_upstream(hip):
+	# WMD::operator() throws "cannot run symmetric mode WMD with bow (needs nbow)" (alignment/wmd.h:441-449)
+	corpus = synth.make_contextual_corpus(10, 4, 8, 100, 32)
+	c = hip_contextual_corpus(hip, corpus)
+	with pytest.raises(hip.VkError):
+		c.query(np.ones((3, 32), np.float32), algorithm=hip.VK_ALG_RWMD, rwmd=(True, True, False))
+	c.close()
+
+
+@pytest.mark.parametrize("variant", ["wmd/nbow", "wmd/bow"])
+@pytest.mark.parametrize("shape", ["fixed32_q10", "ragged_q5", "long_query"])
+def test_full_wmd(hip, oracle, variant, shape):
+	# WordMoversDistance.wmd (vectorian/alignment.py:206-218; labels as upstream):
+	# 'nbow' -> normalize_bow False (unit masses: an assignment problem), 'bow' -> normalize_bow True
+	n, lo, hi, len_t, d = {"fixed32_q10": (800, 32, 32, 10, 300), "ragged_q5": (600, 1, 40, 5, 128),
+		"long_query": (300, 2, 12, 16, 64)}[shape]
+	nbow = variant == "wmd/bow"
+	corpus = synth.make_contextual_corpus(n, lo, hi, 2000, d)
+	Xb = prep_contextual(corpus)
+	c = hip_contextual_corpus(hip, corpus, Xb)
+	for q in synth.make_queries(corpus, 2, len_t):
+		Qb = prep_query(q)
+		ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=corpus["sent_off"], X=Xb, Q=Qb, algorithm=oracle.ALG_RWMD,
+			rwmd=(False, False, nbow), wmd_full=True, max_matches=10, min_score=0.0, n_threads=8)
+		got = c.query(Qb, algorithm=hip.VK_ALG_RWMD, rwmd=(False, False, nbow), wmd_full=True, q_normalize=False, max_matches=10, min_score=0.0)
+		assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=1e-5, tie_tol=1e-5)
+	c.close()
+
+
+def test_full_wmd_static_layout(hip, oracle):
+	corpus = synth.make_static_corpus(500, 1, 30, 300, 300)
+	c, Eb = hip_static_corpus(hip, corpus)
+	rng = np.random.default_rng(5)
+	for _ in range(2):
+		qids = rng.integers(0, 40, size=6).astype(np.int32)
+		Qb = Eb[qids]
+		ref = oracle.find(layout=oracle.LAYOUT_STATIC, d=300, sent_off=corpus["sent_off"], tok_id=corpus["tok_id"], E=Eb, Q=Qb, q_ids=qids,
+			algorithm=oracle.ALG_RWMD, rwmd=(False, False, False), wmd_full=True, max_matches=12)
+		got = c.query(Qb, q_token_ids=qids, algorithm=hip.VK_ALG_RWMD, rwmd=(False, False, False), wmd_full=True, q_normalize=False, max_matches=12)
+		assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=1e-5, tie_tol=1e-5)
 	c.close()

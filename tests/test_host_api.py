@@ -166,8 +166,7 @@ def test_unsupported_options_are_explicit():
 	with pytest.raises(RuntimeError):
 		index.find("w1 w2")          # documents without pos / tags
 	index = session.index(OptimizedSpanSim(ts, alignment.WordMoversDistance.wmd("nbow")), corpus_factory=OracleCorpus)
-	with pytest.raises(NotImplementedError):
-		index.find("w1 w2")
+	assert len(index.find("w1 w2", n=2)) == 2          # full WMD runs (exact EMD)
 	index = session.index(OptimizedSpanSim(ts), corpus_factory=OracleCorpus)
 	with pytest.raises(RuntimeError):
 		index.find("w1 w2", options={"no_such_option": 1})

@@ -65,7 +65,7 @@ class _QueryDesc(C.Structure):
 		("rwmd_injective", C.c_int32), ("rwmd_symmetric", C.c_int32), ("rwmd_normalize_bow", C.c_int32),
 		("wrd_normalize_magnitudes", C.c_int32),
 		("tag_weights", C.c_void_p), ("q_pos", C.c_void_p),
-		("pos_mismatch_penalty", C.c_float), ("similarity_threshold", C.c_float)]
+		("pos_mismatch_penalty", C.c_float), ("similarity_threshold", C.c_float), ("wmd_full", C.c_int32)]
 
 
 class _TopkOut(C.Structure):
@@ -272,7 +272,7 @@ class Corpus:
 	def _desc(self, q_vectors, keep, *, locality=Locality.LOCAL, gap_s=0.0, gap_t=0.0, algorithm=VK_ALG_ALIGN,
 			q_token_ids=None, q_normalize=True, max_matches=10, min_score=0.0, boost=None, want_flow=True,
 			submatch_weight=0.0, bidirectional=False, rwmd=(True, True, True), wrd_normalize=True,
-			tag_weights=None, q_pos=None, pos_mismatch_penalty=0.0, similarity_threshold=0.0):
+			tag_weights=None, q_pos=None, pos_mismatch_penalty=0.0, similarity_threshold=0.0, wmd_full=False):
 		q_vectors = np.ascontiguousarray(q_vectors)
 		if q_vectors.dtype == np.uint16:
 			qdt = VK_BF16
@@ -305,6 +305,7 @@ class Corpus:
 		q.want_flow = int(bool(want_flow))
 		q.rwmd_injective, q.rwmd_symmetric, q.rwmd_normalize_bow = [int(bool(x)) for x in rwmd]
 		q.wrd_normalize_magnitudes = int(bool(wrd_normalize))
+		q.wmd_full = int(bool(wmd_full))
 		if tag_weights is not None:
 			tw = np.ascontiguousarray(tag_weights, dtype=np.float32)
 			qp = np.ascontiguousarray(q_pos if q_pos is not None else np.zeros(len_t), dtype=np.int8)

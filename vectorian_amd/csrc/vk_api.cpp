@@ -371,7 +371,12 @@ static int validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_t
 		}
 	} else if (q->algorithm == VK_ALG_RWMD) {
 		if (q->tag_weights) return fail(VK_ERR_UNSUPPORTED, "tag-weighted similarity is implemented for alignments only");
-		if (!q->rwmd_injective)
+		if (q->rwmd_symmetric && !q->rwmd_normalize_bow)
+			return fail(VK_ERR_INVALID, "cannot run symmetric mode WMD with bow (needs nbow)");   // wmd.h:441-449
+		if (q->wmd_full) {
+			if (q->rwmd_injective) return fail(VK_ERR_INVALID, "non-relaxed WMD with injective mapping is not supported");      // wmd.h:201-204
+			if (q->rwmd_symmetric) return fail(VK_ERR_INVALID, "non-relaxed WMD with symmetric computation is not supported");  // wmd.h:206-209
+		} else if (!q->rwmd_injective)
 			return fail(VK_ERR_UNSUPPORTED, "non-injective RWMD (rwmd('nbow/distributed')) is not implemented on the HIP path");
 		if (q->want_flow && (!out->mapping || !out->edge_sim)) return fail(VK_ERR_INVALID, "want_flow needs mapping and edge_sim arrays");
 	} else if (q->algorithm == VK_ALG_WRD) {
@@ -451,6 +456,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		p.gap_mode = 4;
 		p.rwmd_symmetric = q->rwmd_symmetric;
 		p.rwmd_normalize_bow = q->rwmd_normalize_bow;
+		if (q->wmd_full) p.wmd_bound = q->rwmd_normalize_bow ? 1 : 2;
 	} else if (ks == VK_GAP_LINEAR && kt == VK_GAP_LINEAR) {
 		p.gap_mode = 0;
 		p.gs = q->gap_s.u; p.gt = q->gap_t.u;
@@ -527,7 +533,8 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	const int grid = (int)std::min<int64_t>((n_groups + 3) / 4, (int64_t)1 << 20);   // capped to residency by the launcher
 	VK_HIP(vk_launch_score(&p, grid, smem, st));
 
-	if (q->algorithm == VK_ALG_WRD) {
+	const bool exact_transport = q->algorithm == VK_ALG_WRD || (q->algorithm == VK_ALG_RWMD && q->wmd_full);
+	if (exact_transport) {
 		// ---- stage 2: exact EMD on the candidates with the largest bounds, until the k-th best
 		// exact score is above every remaining bound (then no unsolved sentence can enter)
 		VK_HIP(hipEventRecord(c->ev[2], st));
@@ -552,6 +559,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 			w.tiles = c->d_tiles; w.tok_id = c->d_tok_id; w.table = c->d_table; w.sent_start = c->d_sent_start; w.sent_end = c->d_sent_end;
 			w.layout = p.layout; w.nk32 = c->nk32; w.tail = c->tail; w.tile_bytes = c->tile_bytes;
 			w.qtile = c->d_qtile; w.len_t = q->len_t; w.mag = c->d_mag;
+			w.mass_mode = q->algorithm == VK_ALG_WRD ? 0 : (q->rwmd_normalize_bow ? 1 : 2);
 			memcpy(w.qmass, p.qmass, sizeof w.qmass);
 			w.boost = p.boost; w.keys = c->d_keys[cur]; w.raw_out = c->d_wrd_raw; w.val_out = c->d_wrd_val;
 			VK_HIP(vk_launch_wrd_exact(&w, M, c->d_scores, st));
@@ -714,7 +722,7 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 		((c->nk32 == 10 && c->tail == 1) || (c->nk32 == 4 && c->tail == 0));
 	for (int i = 0; i < n_queries && gemm; i++) {
 		const vk_query_desc &q = qs[i];
-		gemm = q.algorithm == VK_ALG_RWMD && q.rwmd_injective && q.rwmd_symmetric == qs[0].rwmd_symmetric &&
+		gemm = q.algorithm == VK_ALG_RWMD && q.rwmd_injective && !q.wmd_full && q.rwmd_symmetric == qs[0].rwmd_symmetric &&
 			q.rwmd_normalize_bow == qs[0].rwmd_normalize_bow && q.max_matches == qs[0].max_matches &&
 			q.min_score == qs[0].min_score && q.boost == qs[0].boost && !q.tag_weights;
 	}

@@ -33,6 +33,7 @@ struct VkScoreParams {
 	int32_t locality;
 	int32_t gap_mode;          // 0 linear, 1 affine, 2 general, 3 general (register history), 4 RWMD
 	int32_t rwmd_symmetric, rwmd_normalize_bow;
+	int32_t wmd_bound;         // 0: RWMD score; 1: upper bound of the full WMD score, nbow; 2: same, bow
 	float gs, gt;              // linear: w(k) = g*k; affine: b (extension)
 	float a_s, a_t;            // affine: a
 	float open_s, open_t;      // affine: a + b
@@ -83,6 +84,7 @@ struct VkWrdParams {
 	int32_t len_t;
 	const float *mag;
 	float qmass[VK_DEV_MAX_QUERY_LEN];
+	int32_t mass_mode;         // 0: magnitudes (WRD); 1: 1/len per token (nbow); 2: 1 per token (bow)
 	const float *boost;
 	const uint64_t *keys;      // candidates (0 = empty slot)
 	float *raw_out;            // [n_cand]

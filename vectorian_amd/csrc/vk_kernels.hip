@@ -282,7 +282,7 @@ struct DpArgs {
 	float open_s, open_t;  // affine: a + b
 	const float *ws;       // general: w_s[0..max_len]
 	const float *wt;       // general: w_t[0..16]
-	int32_t rwmd_symmetric, rwmd_normalize_bow;
+	int32_t rwmd_symmetric, rwmd_normalize_bow, wmd_bound;
 };
 
 // In-row dependency of the linear recurrence H[u][j] = max(c[j], H[u][j-1] - gt): because
@@ -543,6 +543,15 @@ __device__ __forceinline__ float rwmd_rows(const float *__restrict__ S, int rowb
 		acc0 = acc0 / (float)len_t;
 		acc1 = acc1 / (float)(len > 0 ? len : 1);
 	}
+	if (a.wmd_bound) {
+		// stage 1 of the full WMD: every unit of the side that is shipped completely travels at least to
+		// its nearest partner, so 1 - (that side's relaxed cost) bounds the score from above.  nbow: both
+		// sides ship everything; bow (unit masses): the shorter side does.
+		float lb;
+		if (a.wmd_bound == 1) lb = fmaxf(acc0, acc1);
+		else lb = len_t <= len ? acc0 : acc1;
+		return fminf(1.0f - lb + 3e-5f, 1.0f);
+	}
 	float cost = 0.0f;
 	if (a.rwmd_symmetric) {
 		if (acc0 > cost) cost = acc0;
@@ -628,7 +637,7 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 	a.locality = p.locality; a.len_t = p.len_t;
 	a.gs = p.gs; a.gt = p.gt; a.a_s = p.a_s; a.a_t = p.a_t; a.open_s = p.open_s; a.open_t = p.open_t;
 	a.ws = p.ws; a.wt = p.wt;
-	a.rwmd_symmetric = p.rwmd_symmetric; a.rwmd_normalize_bow = p.rwmd_normalize_bow;
+	a.rwmd_symmetric = p.rwmd_symmetric; a.rwmd_normalize_bow = p.rwmd_normalize_bow; a.wmd_bound = p.wmd_bound;
 	const float inv_ref = p.ref_total;
 	// tag-weighted modifier: this lane's four query columns (MFMA layout: 4*(lane>>4) + r)
 	float twl[4] = {1.0f, 1.0f, 1.0f, 1.0f};
@@ -1403,12 +1412,17 @@ __global__ __launch_bounds__(64) void vk_wrd_exact_kernel(VkWrdParams p) {
 	const float *Sm = S + rowbase * 16;
 
 	// masses (wrd.h:99-102) and costs (:104-109)
-	float sum_s = 0.0f;
-	for (int i = 0; i < m; i++) sum_s += p.layout == VK_DEV_LAYOUT_STATIC ? p.mag[p.tok_id[t_a + i]] : p.mag[t_a + i];
-	for (int j = 0; j < n; j++) sup[j] = (double)p.qmass[j];
-	for (int i = 0; i < m; i++) {
-		const float mg = p.layout == VK_DEV_LAYOUT_STATIC ? p.mag[p.tok_id[t_a + i]] : p.mag[t_a + i];
-		dem[i] = (double)(mg / sum_s);
+	if (p.mass_mode == 0) {
+		float sum_s = 0.0f;
+		for (int i = 0; i < m; i++) sum_s += p.mag[t_a + i];
+		for (int j = 0; j < n; j++) sup[j] = (double)p.qmass[j];
+		for (int i = 0; i < m; i++) dem[i] = (double)(p.mag[t_a + i] / sum_s);
+	} else {
+		// bags of words over positions: 1 per token (bow), or 1/len (nbow, bow.h:262-270)
+		const float wt = p.mass_mode == 1 ? 1.0f / (float)n : 1.0f;
+		const float wsn = p.mass_mode == 1 ? 1.0f / (float)m : 1.0f;
+		for (int j = 0; j < n; j++) sup[j] = (double)wt;
+		for (int i = 0; i < m; i++) dem[i] = (double)wsn;
 	}
 	for (int j = 0; j < n; j++)
 		for (int i = 0; i < m; i++) {

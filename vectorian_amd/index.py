@@ -491,9 +491,7 @@ class HipBruteForceIndex(Index):
 			args.update(algorithm=core.VK_ALG_ALIGN, locality=int(o.get("locality", core.Locality.LOCAL)), gap_s=gs, gap_t=gt)
 			gaps = (gs, gt)
 		elif algorithm == "word-movers-distance":
-			if not alignment.get("relaxed", True):
-				raise NotImplementedError("full WMD (exact EMD) is a next row (SURVEY 8f-4); use WordMoversDistance.rwmd")
-			args.update(algorithm=core.VK_ALG_RWMD,
+			args.update(algorithm=core.VK_ALG_RWMD, wmd_full=not alignment.get("relaxed", True),
 				rwmd=(alignment["injective"], alignment["symmetric"], alignment["normalize_bow"]))
 			gaps = (lambda k: 0.0, lambda k: 0.0)   # gap_cost_s/t of WordMoversDistance return 0 (metric/alignment.h:632-638)
 		elif algorithm == "word-rotators-distance":
