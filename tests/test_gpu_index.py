@@ -35,3 +35,22 @@ def test_index_find_on_hip_equals_oracle_double(hip, optimizer):
 			np.testing.assert_allclose(x.flow["dist"], y.flow["dist"], atol=1e-4)
 		assert a[0].to_json()["regions"] == b[0].to_json()["regions"] or True
 	gpu.close()
+
+
+def test_span_embedding_index_on_hip(hip):
+	from test_host_api import Document, Session
+	from vectorian_amd.sim import EmbeddedSpanSim, SpanEmbedding
+	rng = np.random.default_rng(9)
+	n, d = 3000, 384
+	vectors = rng.standard_normal((n, d)).astype(np.float32)
+	docs = [Document([[f"s{i}"] for i in range(1000)]) for _ in range(3)]
+	session = Session(docs, embeddings=[])
+	qv = vectors[1234] + 0.1 * rng.standard_normal(d).astype(np.float32)
+	emb = SpanEmbedding("enc", d, lambda texts: np.stack([qv for _ in texts]))
+	index = session.partition("sentence").index(EmbeddedSpanSim(emb), vectors=vectors)
+	r = index.find("anything", n=5)
+	cos = (vectors @ qv) / (np.linalg.norm(vectors, axis=1) * np.linalg.norm(qv))
+	order = np.argsort(-cos)[:5]
+	assert [docs.index(m.prepared_doc) * 1000 + m.slice_id for m in r] == [int(i) for i in order]
+	np.testing.assert_allclose([m.score for m in r], cos[order], atol=2e-3)     # bf16 vectors
+	index.close()

@@ -218,3 +218,24 @@ def test_tag_weighted_metric():
 	# sentence 2 holds the exact words but in swapped order and with mismatching POS: one match at half weight
 	s2 = [m for m in r if m.slice_id == 2][0]
 	assert abs(s2.score - max(2.0 * 0.5, 1.0 * 0.5) / 3.0) < 1e-6
+
+
+def test_span_embedding_index():
+	# EmbeddedSpanSim -> one cosine per span + top-k (vectorian/index.py:679-731), on the alignment kernels
+	from vectorian_amd.sim import EmbeddedSpanSim, SpanEmbedding
+	rng = np.random.default_rng(8)
+	words = [f"w{i}" for i in range(50)]
+	wv = dict((w, rng.standard_normal(24).astype(np.float32)) for w in words)
+	enc = lambda texts: np.stack([np.mean([wv[t] for t in x.split()], axis=0) for x in texts])
+	docs = [Document([[words[int(i)] for i in rng.integers(0, 50, size=int(rng.integers(2, 9)))] for _ in range(12)]) for _ in range(3)]
+	session = Session(docs, embeddings=[])
+	index = session.partition("sentence").index(EmbeddedSpanSim(SpanEmbedding("mean", 24, enc)), corpus_factory=OracleCorpus)
+	target = docs[2].span_tokens("sentence", 5)
+	r = index.find(" ".join(target), n=3)
+	assert r[0].prepared_doc is docs[2] and r[0].slice_id == 5 and abs(r[0].score - 1.0) < 1e-2
+	assert r[0].level == "span" and r[0].to_json()["regions"][0]["s"] == " ".join(target)
+	# brute-force reference
+	allv = enc([" ".join(d.span_tokens("sentence", i)) for d in docs for i in range(12)])
+	qv = enc([" ".join(target)])[0]
+	cos = (allv @ qv) / (np.linalg.norm(allv, axis=1) * np.linalg.norm(qv))
+	assert [int(np.argsort(-cos)[i]) for i in range(3)] == [12 * docs.index(m.prepared_doc) + m.slice_id for m in r]

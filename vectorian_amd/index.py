@@ -546,3 +546,109 @@ class HipBruteForceIndex(Index):
 
 	def close(self):
 		self._corpus.close()
+
+
+class PyMatch(Match):
+	"""plain-data match (vectorian/index.py:382-431)"""
+
+	def __init__(self, index, query, document, slice_id, score, metric=None, omitted=None, regions=None, level="word"):
+		self._index = index
+		self._query = query
+		self._document = document
+		self._slice_id = slice_id
+		self._score = score
+		self._metric = metric or ""
+		self._omitted = omitted or []
+		self._regions = regions or []
+		self._level = level
+
+	@property
+	def index(self):
+		return self._index
+
+	@property
+	def query(self):
+		return self._query
+
+	@property
+	def prepared_doc(self):
+		return self._document
+
+	@property
+	def slice_id(self):
+		return self._slice_id
+
+	@property
+	def score(self):
+		return self._score
+
+	@property
+	def score_max(self):
+		return 1
+
+	@property
+	def metric(self):
+		return self._metric
+
+	@property
+	def omitted(self):
+		return self._omitted
+
+	def regions(self, context_size=None):
+		return self._regions
+
+	@property
+	def level(self):
+		return self._level
+
+
+class HipSpanEncoderIndex(Index):
+	"""Brute-force cosine search over ONE embedding per span: what SpanEncoderIndex / FaissCosineIndex('Flat')
+	do (vectorian/index.py:679-810), as a matrix-vector product + bounded result set on the GPU.  Realised on
+	the same kernels: a corpus of one-token slices, a one-token query, score = clip(cosine)."""
+
+	def __init__(self, partition, embedding, span_sim, nlp=None, vectors=None, device=0, corpus_factory=None):
+		super().__init__(partition, span_sim)
+		self._embedding = embedding
+		self._nlp = nlp
+		session = self.session
+		step, level = partition.window_step, partition.level
+		self._slice_doc, self._slice_id = [], []
+		for di, doc in enumerate(session.documents):
+			for sid in range(0, doc.n_spans(level), step):
+				self._slice_doc.append(di)
+				self._slice_id.append(sid)
+		n = len(self._slice_doc)
+		if vectors is None:
+			size = partition.window_size
+			texts = [" ".join(session.documents[di].span_tokens(level, sid, size)) for di, sid in zip(self._slice_doc, self._slice_id)]
+			vectors = embedding.encode(texts)
+		vectors = np.ascontiguousarray(vectors, dtype=np.float32)
+		if vectors.shape != (n, embedding.dimension):
+			raise ValueError(f"expected {(n, embedding.dimension)} span vectors, got {vectors.shape}")
+		make = corpus_factory or core.Corpus
+		self._corpus = make(layout=core.VK_LAYOUT_CONTEXTUAL, d=embedding.dimension, n_tokens=n, n_sentences=n, device=device)
+		self._corpus.append_vectors(vectors, normalize=True)
+		self._corpus.set_sentences(np.arange(n + 1, dtype=np.int64))
+		self._corpus.finalize()
+
+	def _find(self, query, progress=None):
+		qv = self._embedding.encode([query.text])
+		if qv.shape[0] != 1:
+			raise RuntimeError("query produced more than one embedding")
+		top = self._corpus.query(qv, q_normalize=True, locality=core.Locality.LOCAL, gap_s=0.0, gap_t=0.0,
+			max_matches=int(query.options.get("max_matches", 100)), min_score=float(query.options.get("min_score", 0.0)),
+			want_flow=False)
+		if progress:
+			progress(1.0)
+		matches = []
+		for i in range(top.n):
+			g = int(top.sentence[i])
+			doc = self.session.documents[self._slice_doc[g]]
+			text = " ".join(doc.span_tokens(self.partition.level, self._slice_id[g], self.partition.window_size))
+			matches.append(PyMatch(self, query, doc, self._slice_id[g], float(top.score[i]), self._sim.name,
+				regions=[Region(s=text, match=None, gap_penalty=0)], level="span"))
+		return matches
+
+	def close(self):
+		self._corpus.close()

@@ -137,3 +137,53 @@ class OptimizedSpanSim(SpanSim):
 				"similarity_threshold": self._options.get("similarity_threshold", 0),
 				"tag_weights": self._tag_weights
 			}
+
+
+class SpanEmbedding:
+	"""one vector per span (vectorian/embedding/span.py).  The sentence encoders of the reference are out of
+	scope; vectors come precomputed, `encode(texts) -> [n x d]` embeds queries."""
+
+	def __init__(self, name, dimension, encode):
+		self._name, self._dimension, self._encode = name, int(dimension), encode
+
+	@property
+	def name(self):
+		return self._name
+
+	@property
+	def dimension(self):
+		return self._dimension
+
+	def encode(self, texts):
+		v = np.ascontiguousarray(self._encode(texts), dtype=np.float32)
+		return v.reshape(len(texts), self._dimension)
+
+
+class EmbeddedSpanSim(SpanSim):
+	"""span similarity by ONE embedding per span (vectorian/sim/span.py:74-95)"""
+
+	def __init__(self, embedding: SpanEmbedding, sim: VectorSim = None):
+		if sim is None:
+			sim = CosineSim()
+		if not isinstance(sim, VectorSim):
+			raise TypeError(f"{sim} is expected to be a VectorSim")
+		self._embedding = embedding
+		self._vector_sim = sim
+
+	@property
+	def embedding(self):
+		return self._embedding
+
+	def create_index(self, partition, **kwargs):
+		# the reference picks FaissCosineIndex / SpanEncoderIndex here (vectorian/sim/span.py:83-88)
+		from vectorian_amd.index import HipSpanEncoderIndex
+		if not isinstance(self._vector_sim, CosineSim):
+			raise NotImplementedError(f"{self._vector_sim.name}: the HIP path computes CosineSim")
+		return HipSpanEncoderIndex(partition, self._embedding, self, **kwargs)
+
+	def to_args(self, index):
+		return None
+
+	@property
+	def name(self):
+		return "EmbeddedSpanSim"
