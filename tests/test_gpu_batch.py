@@ -36,6 +36,31 @@ def test_rwmd_gemm_batch(hip, oracle, length, d, len_t, flags):
 	c.close()
 
 
+@pytest.mark.parametrize("d,len_t,n_q,flags", [
+	(300, 10, 10, (True, True, True)),      # 3 queries per 32-row tile, last tile holds one
+	(300, 10, 8, (True, False, True)),      # last tile holds two
+	(300, 7, 6, (True, False, False)),
+	(300, 16, 5, (True, True, True)),       # longer than 10 tokens: 2 queries per tile
+	(128, 10, 7, (True, True, True)),
+	(128, 13, 4, (True, False, False)),
+])
+def test_rwmd_batch_32_token_sentences(hip, oracle, d, len_t, n_q, flags):
+	"""32-token sentences run on the 32x32x16 MFMA kernel (queries share A tiles)."""
+	n = 1000 + 13
+	corpus = synth.make_contextual_corpus(n, 32, 32, 2000, d)
+	Xb = prep_contextual(corpus)
+	c = hip_contextual_corpus(hip, corpus, Xb)
+	qs = [prep_query(q) for q in synth.make_queries(corpus, n_q, len_t)]
+	qs[1] = qs[1][:max(1, len_t - 3)]
+	qs[-1] = qs[-1][:1]
+	outs = c.query_batch(qs, algorithm=hip.VK_ALG_RWMD, rwmd=flags, q_normalize=False, max_matches=12, min_score=0.0)
+	for Qb, got in zip(qs, outs):
+		ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=corpus["sent_off"], X=Xb, Q=Qb,
+			algorithm=oracle.ALG_RWMD, rwmd=flags, max_matches=12, min_score=0.0)
+		assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=2e-5, tie_tol=2e-5)
+	c.close()
+
+
 def test_batch_fallback_for_alignment_and_ragged(hip, oracle):
 	corpus = synth.make_contextual_corpus(400, 2, 30, 800, 64)
 	Xb = prep_contextual(corpus)

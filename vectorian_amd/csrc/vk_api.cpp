@@ -743,12 +743,19 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 	const int k = qs[0].max_matches;
 	int rc;
 
+	// 32-token sentences take the 32x32x16 kernel: 3 queries of <= 10 tokens (else 2 of <= 16) share one 32-row A tile
+	const bool b32 = c->uniform_len == 32;
+	int qpt = 3;
+	for (int i = 0; i < n_queries; i++) if (qs[i].len_t > 10) qpt = 2;
+	const int nk16 = c->d_pad / 16;
+	const int n_qtiles = (n_queries + qpt - 1) / qpt;
+
 	// ---- device buffers (kept for the next batch)
-	const size_t need_q = (size_t)n_queries * c->tile_bytes;
+	const size_t need_q = std::max((size_t)n_queries * c->tile_bytes, b32 ? (size_t)n_qtiles * nk16 * 1024 : (size_t)0);
 	if (c->bq_cap < need_q) {
 		if (c->d_bq) { VK_HIP(hipFree(c->d_bq)); VK_HIP(hipFree(c->d_bqlen)); }
 		if ((rc = alloc_t(c, &c->d_bq, need_q))) return rc;
-		if ((rc = alloc_t(c, &c->d_bqlen, (size_t)n_queries))) return rc;
+		if ((rc = alloc_t(c, &c->d_bqlen, (size_t)n_queries + 4))) return rc;
 		c->bq_cap = need_q;
 	}
 	const size_t need_s = (size_t)n_queries * (size_t)n;
@@ -767,13 +774,33 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 	}
 
 	VK_HIP(hipEventRecord(c->ev[0], st));
-	std::vector<uint8_t> all((size_t)need_q), one;
+	std::vector<uint8_t> all((size_t)need_q, 0), one;
 	std::vector<int32_t> qlen((size_t)n_queries);
 	float mags[VK_MAX_QUERY_LEN];
 	for (int i = 0; i < n_queries; i++) {
 		pack_query(c, &qs[i], one, mags);
-		memcpy(all.data() + (size_t)i * c->tile_bytes, one.data(), one.size());
 		qlen[(size_t)i] = qs[i].len_t;
+		if (!b32) {
+			memcpy(all.data() + (size_t)i * c->tile_bytes, one.data(), one.size());
+			continue;
+		}
+		// A tile of v_mfma_f32_32x32x16_bf16: K-step t = 1 KiB, lane l = 32 (k >> 3 & 1) + M owns row M, 8 features.
+		// Row M of the result lands in accumulator register acc = 4 (M >> 3) + (M & 3) of lane half hd = M >> 2 & 1;
+		// the kernel (vk_rwmd_batch32_kernel) expects query tokens at (hd, acc) as laid out below.
+		uint8_t *dst = all.data() + (size_t)(i / qpt) * nk16 * 1024;
+		const int slot = i % qpt;
+		for (int j = 0; j < qs[i].len_t; j++) {
+			int hd, acc;
+			if (qpt == 2) { hd = slot; acc = j; }
+			else if (slot < 2) { hd = slot; acc = j; }
+			else { hd = j / 5; acc = 10 + j % 5; }
+			const int M = 8 * (acc >> 2) + 4 * hd + (acc & 3);
+			for (int k = 0; k < c->d_pad; k++) {
+				const size_t src = (size_t)(k >> 5) * 1024 + (size_t)(((k & 31) >> 3) * 16 + j) * 16 + (size_t)(k & 7) * 2;
+				const size_t off = (size_t)(k >> 4) * 1024 + (size_t)(((k >> 3) & 1) * 32 + M) * 16 + (size_t)(k & 7) * 2;
+				memcpy(dst + off, one.data() + src, 2);
+			}
+		}
 	}
 	VK_HIP(hipMemcpyAsync(c->d_bq, all.data(), all.size(), hipMemcpyHostToDevice, st));
 	VK_HIP(hipMemcpyAsync(c->d_bqlen, qlen.data(), qlen.size() * 4, hipMemcpyHostToDevice, st));
@@ -791,7 +818,9 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 	p.symmetric = qs[0].rwmd_symmetric; p.nbow = qs[0].rwmd_normalize_bow;
 	p.boost = qs[0].boost ? c->d_boost : nullptr;
 	p.scores = c->d_bscores;
-	VK_HIP(vk_launch_rwmd_batch(&p, st));
+	p.n_qtiles = n_qtiles; p.qpt = qpt;
+	if (b32) VK_HIP(vk_launch_rwmd_batch32(&p, st));
+	else VK_HIP(vk_launch_rwmd_batch(&p, st));
 
 	VK_HIP(hipEventRecord(c->ev[2], st));
 	int64_t nw = 0;

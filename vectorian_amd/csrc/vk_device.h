@@ -62,7 +62,8 @@ struct VkRwmdBatchParams {
 	const uint8_t *tiles;      // corpus token tiles
 	int64_t n_tiles;
 	int32_t tile_bytes, nk, half;
-	const uint8_t *qtiles;     // [n_queries] query tiles, back to back
+	const uint8_t *qtiles;     // [n_queries] query tiles, back to back (batch32: [n_qtiles] 32-row tiles)
+	int32_t n_qtiles, qpt;     // batch32: tiles and queries per tile (2 or 3)
 	const int32_t *q_len;      // [n_queries]
 	int32_t n_queries;
 	int32_t n_sent;
@@ -132,6 +133,7 @@ hipError_t vk_launch_topk_wave(const float *scores, const uint64_t *keys_in, int
 	int64_t per_wave, uint64_t *out, int64_t *n_waves_out, hipStream_t stream);
 hipError_t vk_launch_flow(const VkFlowParams *p, int32_t k, hipStream_t stream);
 hipError_t vk_launch_rwmd_batch(const VkRwmdBatchParams *p, hipStream_t stream);
+hipError_t vk_launch_rwmd_batch32(const VkRwmdBatchParams *p, hipStream_t stream);
 hipError_t vk_launch_topk_wave_batch(const float *scores, const uint64_t *keys_in, int64_t n, float min_score, int32_t k,
 	int64_t per_wave, int32_t n_queries, int64_t in_stride, int64_t out_stride, uint64_t *out, int64_t *n_waves_out, hipStream_t stream);
 hipError_t vk_launch_wrd_exact(const VkWrdParams *p, int32_t n_cand, float *scores_to_mark, hipStream_t stream);

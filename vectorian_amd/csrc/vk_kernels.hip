@@ -1039,6 +1039,157 @@ __global__ __launch_bounds__(256, 2) void vk_rwmd_batch_kernel(VkRwmdBatchParams
 	}
 }
 
+// ---------------------------------------------------------------------------
+// Batched RWMD for 32-token sentences (the shape of BASELINE config 4) on v_mfma_f32_32x32x16_bf16.
+// Two inefficiencies of the 16-row kernel above go away: a 10-token query no longer occupies a
+// 16-row tile (QPT = 3 queries share the 32 rows of one A tile: 30 / 32 rows used, 10 / 16 before)
+// and K is padded to 16, not 32 (d = 300: 19 steps of 16 = 304, not 320).
+//   workgroup = 8 waves; a wave keeps its 2 sentences (4 token tiles) in registers as B operands of
+//   two MFMA chains: chain 0 takes tokens 0..15 of both sentences (columns 0..15 = sentence 0,
+//   16..31 = sentence 1), chain 1 tokens 16..31.  So a lane (n = lane & 31, h = lane >> 5) holds, in
+//   acc0[i] and acc1[i], the similarities of ONE query row with tokens n & 15 and 16 + (n & 15) of
+//   sentence n >> 4: the maximum over a sentence's tokens is one in-lane max and a reduction over the
+//   16 lanes of a DPP row, never across rows.
+//   A rows: M = 8 (i >> 2) + 4 h + (i & 3) for accumulator register i of half h (hardware layout of
+//   the 32x32 result).  QPT = 3: half h, i < 10 = token i of query 3 qt + h; 10 <= i < 15 = token
+//   5 h + i - 10 of query 3 qt + 2.  QPT = 2: half h = query 2 qt + h, i = token.  The host packs the
+//   A tiles accordingly (vk_api.cpp pack_query_tiles32).
+//   The query tiles stream through a double-buffered LDS slot shared by the 8 waves.
+// ---------------------------------------------------------------------------
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8n;
+
+__device__ __forceinline__ float row_sum_to_lane15(float x) {
+	x += dpp_f<DPP_ROW_SHR1>(0.0f, x);
+	x += dpp_f<DPP_ROW_SHR2>(0.0f, x);
+	x += dpp_f<DPP_ROW_SHR4>(0.0f, x);
+	x += dpp_f<DPP_ROW_SHR8>(0.0f, x);
+	return x;
+}
+
+template <int NK16, int QPT>
+__global__ __launch_bounds__(512) void vk_rwmd_batch32_kernel(VkRwmdBatchParams p) {
+	constexpr int QT_BYTES = NK16 * 1024;
+	constexpr int N16 = QT_BYTES / 16;                 // 16-byte pieces of one query tile
+	constexpr int PER_THREAD = (N16 + 511) / 512;
+	constexpr int NMAIN = QPT == 3 ? 10 : 16;          // rows of the half's own query
+	extern __shared__ float4 vk_smem4[];
+	const uint8_t *qbuf = reinterpret_cast<const uint8_t *>(vk_smem4);
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int n32 = lane & 31, h = lane >> 5;
+	const int64_t n_chunks = ((int64_t)p.n_sent + 15) / 16;
+	const float inv_s = 1.0f / 32.0f;
+
+	for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+		const int64_t sent = chunk * 16 + wv * 2 + (n32 >> 4);   // this lane's sentence
+		// ---- the wave's token tiles -> registers (read once per batch)
+		bf16x8 x[2][NK16];
+#pragma unroll
+		for (int m = 0; m < 2; m++) {
+			const int64_t tile = sent < p.n_sent ? sent * 2 + m : p.n_tiles;   // one zero tile follows the corpus
+			const uint8_t *tp = p.tiles + tile * p.tile_bytes + (n32 & 15) * 16;
+#pragma unroll
+			for (int t = 0; t < NK16; t++)
+				x[m][t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(tp + (t >> 1) * 1024 + (2 * (t & 1) + h) * 256));
+		}
+		__syncthreads();   // previous chunk's readers are done with the LDS slots
+#pragma unroll
+		for (int u = 0; u < PER_THREAD; u++) {
+			const int i = threadIdx.x + u * 512;
+			if (i < N16) vk_smem4[i] = *reinterpret_cast<const float4 *>(p.qtiles + (size_t)i * 16);
+		}
+		__syncthreads();
+
+		for (int qt = 0; qt < p.n_qtiles; qt++) {
+			const uint8_t *cur = qbuf + (qt & 1) * QT_BYTES;
+			float4 *nxt = vk_smem4 + ((qt + 1) & 1) * N16;
+			float4 st[PER_THREAD];
+			const bool more = qt + 1 < p.n_qtiles;
+			if (more) {
+				const uint8_t *src = p.qtiles + (int64_t)(qt + 1) * QT_BYTES;
+#pragma unroll
+				for (int u = 0; u < PER_THREAD; u++) {
+					const int i = threadIdx.x + u * 512;
+					st[u] = i < N16 ? *reinterpret_cast<const float4 *>(src + (size_t)i * 16) : float4{0, 0, 0, 0};
+				}
+			}
+			f32x16 acc0, acc1;
+#pragma unroll
+			for (int i = 0; i < 16; i++) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
+#pragma unroll
+			for (int t = 0; t < NK16; t++) {
+				const bf16x8 a = *reinterpret_cast<const bf16x8 *>(cur + t * 1024 + lane * 16);
+				acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8n, a), __builtin_bit_cast(bf16x8n, x[0][t]), acc0, 0, 0, 0);
+				acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8n, a), __builtin_bit_cast(bf16x8n, x[1][t]), acc1, 0, 0, 0);
+			}
+			if (more) {
+#pragma unroll
+				for (int u = 0; u < PER_THREAD; u++) {
+					const int i = threadIdx.x + u * 512;
+					if (i < N16) nxt[i] = st[u];
+				}
+			}
+			// ---- epilogue.  D = 1 - clip(S) is monotone in S: reduce S, convert the reduced values only.
+			// (a) per token: max over the query's rows (in-lane) -> this lane's two tokens' distances -> sum
+			//     over the sentence's 32 tokens = 16 lanes x 2 chains
+			float ca0 = acc0[0], ca1 = acc1[0];
+#pragma unroll
+			for (int i = 1; i < NMAIN; i++) { ca0 = fmaxf(ca0, acc0[i]); ca1 = fmaxf(ca1, acc1[i]); }
+			float ts_main = (1.0f - clip01(ca0)) + (1.0f - clip01(ca1));
+			ts_main = row_sum_to_lane15(ts_main);
+			float ts_third = 0.0f;
+			if (QPT == 3) {
+				float cb0 = acc0[10], cb1 = acc1[10];
+#pragma unroll
+				for (int i = 11; i < 15; i++) { cb0 = fmaxf(cb0, acc0[i]); cb1 = fmaxf(cb1, acc1[i]); }
+				const float e0 = xor32_f(cb0, lane), e1 = xor32_f(cb1, lane);
+				cb0 = fmaxf(cb0, e0); cb1 = fmaxf(cb1, e1);
+				ts_third = (1.0f - clip01(cb0)) + (1.0f - clip01(cb1));
+				ts_third = row_sum_to_lane15(ts_third);
+			}
+			// (b) per query row: max over the sentence's tokens -> lane 15 of the DPP row
+			const int q_main = qt * QPT + h, q_third = qt * 3 + 2;
+			const int len_main = q_main < p.n_queries ? p.q_len[q_main] : 0;
+			float c_main = 0.0f, c_third = 0.0f;
+#pragma unroll
+			for (int i = 0; i < NMAIN; i++) {
+				const float r = row_max_to_lane15(fmaxf(acc0[i], acc1[i]));
+				c_main += i < len_main ? 1.0f - clip01(r) : 0.0f;
+			}
+			int len_third = 0;
+			if (QPT == 3) {
+				len_third = q_third < p.n_queries ? p.q_len[q_third] : 0;
+#pragma unroll
+				for (int i = 10; i < 15; i++) {
+					const float r = row_max_to_lane15(fmaxf(acc0[i], acc1[i]));
+					c_third += 5 * h + i - 10 < len_third ? 1.0f - clip01(r) : 0.0f;
+				}
+				c_third += xor32_f(c_third, lane);
+			}
+			// (c) scores (same expressions as vk_rwmd_batch_kernel)
+			if ((lane & 15) == 15 && sent < p.n_sent) {
+				const float boost = p.boost ? p.boost[sent] : 1.0f;
+				if (len_main > 0) {
+					const float inv_t = 1.0f / (float)len_main;
+					const float a0 = inv_t * c_main, a1 = inv_s * ts_main;
+					const float cost = p.symmetric ? fmaxf(0.0f, fmaxf(a0, a1)) : a0;
+					const float raw = p.nbow ? 1.0f - cost : ((float)len_main - cost) * inv_t;
+					p.scores[(int64_t)q_main * p.n_sent + sent] = (raw * inv_t) * boost;
+				}
+				if (QPT == 3 && h == 0 && len_third > 0) {
+					const float inv_t = 1.0f / (float)len_third;
+					const float a0 = inv_t * c_third, a1 = inv_s * ts_third;
+					const float cost = p.symmetric ? fmaxf(0.0f, fmaxf(a0, a1)) : a0;
+					const float raw = p.nbow ? 1.0f - cost : ((float)len_third - cost) * inv_t;
+					p.scores[(int64_t)q_third * p.n_sent + sent] = (raw * inv_t) * boost;
+				}
+			}
+			__syncthreads();   // next query tile is in place; this one may be overwritten
+		}
+	}
+}
+
 // per-query selection over the [B x n] score matrix: blockIdx.y = query
 template <int FROM_KEYS>
 __global__ __launch_bounds__(256) void vk_topk_wave_batch_kernel(const float *__restrict__ scores, const uint64_t *__restrict__ keys_in,
@@ -1570,6 +1721,25 @@ static hipError_t launch_rwmd_batch_tps(const VkRwmdBatchParams &p, size_t smem,
 	case 3: vk_rwmd_batch_kernel<NK, HALF, 3><<<grid, 256, smem, stream>>>(p); break;
 	default: vk_rwmd_batch_kernel<NK, HALF, 4><<<grid, 256, smem, stream>>>(p); break;
 	}
+	return hipGetLastError();
+}
+
+// 32-token sentences: p->qtiles holds p->n_qtiles A tiles of 32 rows (p->qpt queries each)
+extern "C" hipError_t vk_launch_rwmd_batch32(const VkRwmdBatchParams *p, hipStream_t stream) {
+	int dev = 0, cus = 256;
+	if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+	if (p->tiles_per_sent != 2 || (p->qpt != 2 && p->qpt != 3)) return hipErrorNotSupported;
+	const int64_t n_chunks = ((int64_t)p->n_sent + 15) / 16;
+	const int grid = (int)(n_chunks < (int64_t)cus ? n_chunks : (int64_t)cus);
+	if (p->nk == 10 && p->half == 1) {
+		const size_t smem = 2 * 19 * 1024;
+		if (p->qpt == 3) vk_rwmd_batch32_kernel<19, 3><<<grid, 512, smem, stream>>>(*p);
+		else vk_rwmd_batch32_kernel<19, 2><<<grid, 512, smem, stream>>>(*p);
+	} else if (p->nk == 4 && p->half == 0) {
+		const size_t smem = 2 * 8 * 1024;
+		if (p->qpt == 3) vk_rwmd_batch32_kernel<8, 3><<<grid, 512, smem, stream>>>(*p);
+		else vk_rwmd_batch32_kernel<8, 2><<<grid, 512, smem, stream>>>(*p);
+	} else return hipErrorNotSupported;
 	return hipGetLastError();
 }
 
