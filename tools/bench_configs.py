@@ -147,7 +147,11 @@ def main():
 		el = time.perf_counter() - t0
 		score_ms = float(np.mean([p["score_ms"] for p in ph]))
 		flops = 2.0 * n_tok * args.batch * args.len_t * args.d
-		flops_padded = 2.0 * n_tok * args.batch * 16 * ((args.d + 31) // 32 * 32)
+		if args.min_len == 32 and args.max_len == 32:   # vk_rwmd_batch32_kernel: 3 (len_t <= 10) or 2 queries per 32-row tile, K padded to 16
+			qpt = 3 if args.len_t <= 10 else 2
+			flops_padded = 2.0 * n_tok * ((args.batch + qpt - 1) // qpt) * 32 * ((args.d + 15) // 16 * 16)
+		else:
+			flops_padded = 2.0 * n_tok * args.batch * 16 * ((args.d + 31) // 32 * 32)
 		print(json.dumps({
 			"alg": args.alg, "batch": args.batch, "d": args.d, "len_t": args.len_t, "len_s": [args.min_len, args.max_len],
 			"sentences": args.sentences, "pairs_per_s": args.sentences * args.batch * args.steps / el,

@@ -751,11 +751,12 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 	const int n_qtiles = (n_queries + qpt - 1) / qpt;
 
 	// ---- device buffers (kept for the next batch)
-	const size_t need_q = std::max((size_t)n_queries * c->tile_bytes, b32 ? (size_t)n_qtiles * nk16 * 1024 : (size_t)0);
+	// (+1: the kernel prefetches one tile past the last)
+	const size_t need_q = std::max((size_t)n_queries * c->tile_bytes, b32 ? (size_t)(n_qtiles + 1) * nk16 * 1024 : (size_t)0);
 	if (c->bq_cap < need_q) {
 		if (c->d_bq) { VK_HIP(hipFree(c->d_bq)); VK_HIP(hipFree(c->d_bqlen)); }
 		if ((rc = alloc_t(c, &c->d_bq, need_q))) return rc;
-		if ((rc = alloc_t(c, &c->d_bqlen, (size_t)n_queries + 4))) return rc;
+		if ((rc = alloc_t(c, &c->d_bqlen, 2 * ((size_t)n_queries + 4)))) return rc;   // lengths, then their reciprocals
 		c->bq_cap = need_q;
 	}
 	const size_t need_s = (size_t)n_queries * (size_t)n;
@@ -804,6 +805,10 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 	}
 	VK_HIP(hipMemcpyAsync(c->d_bq, all.data(), all.size(), hipMemcpyHostToDevice, st));
 	VK_HIP(hipMemcpyAsync(c->d_bqlen, qlen.data(), qlen.size() * 4, hipMemcpyHostToDevice, st));
+	std::vector<float> qinv((size_t)n_queries);
+	for (int i = 0; i < n_queries; i++) qinv[(size_t)i] = 1.0f / (float)qs[i].len_t;
+	float *d_qinv = reinterpret_cast<float *>(c->d_bqlen + n_queries + 4);
+	VK_HIP(hipMemcpyAsync(d_qinv, qinv.data(), qinv.size() * 4, hipMemcpyHostToDevice, st));
 	if (qs[0].boost) {
 		if (!c->d_boost) { rc = alloc_t(c, &c->d_boost, (size_t)n + 8); if (rc) return rc; }
 		VK_HIP(hipMemcpyAsync(c->d_boost, qs[0].boost, (size_t)n * 4, hipMemcpyHostToDevice, st));
@@ -818,7 +823,9 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 	p.symmetric = qs[0].rwmd_symmetric; p.nbow = qs[0].rwmd_normalize_bow;
 	p.boost = qs[0].boost ? c->d_boost : nullptr;
 	p.scores = c->d_bscores;
-	p.n_qtiles = n_qtiles; p.qpt = qpt;
+	p.n_qtiles = n_qtiles; p.qpt = qpt; p.q_inv_len = d_qinv;
+	p.late_mask = 4;   // waves w and w + 4 of a workgroup share a SIMD
+	if (const char *e = getenv("VK_BATCH32_LATE_MASK")) p.late_mask = atoi(e);   // tuning aid
 	if (b32) VK_HIP(vk_launch_rwmd_batch32(&p, st));
 	else VK_HIP(vk_launch_rwmd_batch(&p, st));
 

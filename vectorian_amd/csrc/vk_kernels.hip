@@ -1059,6 +1059,8 @@ __global__ __launch_bounds__(256, 2) void vk_rwmd_batch_kernel(VkRwmdBatchParams
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8n;
+typedef __attribute__((address_space(3))) void *vk_lds_ptr;
+typedef __attribute__((address_space(1))) const void *vk_glb_ptr;
 
 __device__ __forceinline__ float row_sum_to_lane15(float x) {
 	x += dpp_f<DPP_ROW_SHR1>(0.0f, x);
@@ -1068,18 +1070,127 @@ __device__ __forceinline__ float row_sum_to_lane15(float x) {
 	return x;
 }
 
+// Maxima of similarities that end in clip01() may be taken on the raw bit patterns as signed integers:
+// non-negative floats order like their bits, negative floats are negative integers and lose against any
+// non-negative one, and a maximum that stays negative is clipped to 0 whichever negative value it is.
+// Integer maxima need no canonicalisation of their inputs and fuse with DPP (v_max_i32_dpp).
+__device__ __forceinline__ int fbits(float x) { return __builtin_bit_cast(int, x); }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+template <int CTRL>
+__device__ __forceinline__ int dpp_imax(int x) {
+	return imax(x, __builtin_amdgcn_update_dpp((int)0x80000000, x, CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ int row_imax_to_lane15(int x) {
+	x = dpp_imax<DPP_ROW_SHR1>(x);
+	x = dpp_imax<DPP_ROW_SHR2>(x);
+	x = dpp_imax<DPP_ROW_SHR4>(x);
+	x = dpp_imax<DPP_ROW_SHR8>(x);
+	return x;
+}
+__device__ __forceinline__ float clip01_bits(int x) { return __builtin_amdgcn_fmed3f(__builtin_bit_cast(float, x), 0.0f, 1.0f); }
+
+// S tiles of one query tile against the wave's two sentences: 2 x NK16 MFMAs, A fragments DEPTH steps ahead
+template <int NK16>
+__device__ __forceinline__ void batch32_mfma(const uint8_t *cur, const bf16x8 (&x)[2][NK16], f32x16 &acc0, f32x16 &acc1) {
+	constexpr int DEPTH = 4;                           // A fragments in flight (ds_read_b128 ahead of their MFMAs)
+#pragma unroll
+	for (int i = 0; i < 16; i++) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
+	bf16x8 a[DEPTH];
+#pragma unroll
+	for (int t = 0; t < DEPTH && t < NK16; t++) a[t] = *reinterpret_cast<const bf16x8 *>(cur + t * 1024);
+#pragma unroll
+	for (int t = 0; t < NK16; t++) {
+		const bf16x8 at = a[t % DEPTH];
+#if defined(VK_ABL) && VK_ABL == 3
+		if (t > 0) { acc0[t & 15] += (float)at[0]; acc1[t & 15] += (float)x[1][t][0] + (float)x[0][t][0]; continue; }
+#endif
+		acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8n, at), __builtin_bit_cast(bf16x8n, x[0][t]), acc0, 0, 0, 0);
+		acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8n, at), __builtin_bit_cast(bf16x8n, x[1][t]), acc1, 0, 0, 0);
+		if (t + DEPTH < NK16) a[t % DEPTH] = *reinterpret_cast<const bf16x8 *>(cur + (t + DEPTH) * 1024);
+		__builtin_amdgcn_sched_barrier(0);
+	}
+}
+
+// RWMD scores of query tile qt for the wave's two sentences from the accumulators.
+// D = 1 - clip(S) is monotone in S: reduce S (as integers, see above), convert the reduced values only.
+// Rows of absent query tokens are zero: S = 0, clip = 0, no masks.
+template <int QPT>
+__device__ __forceinline__ void batch32_epilogue(const VkRwmdBatchParams &p, int qt, int64_t sent, int lane, const f32x16 &acc0, const f32x16 &acc1) {
+	constexpr int NMAIN = QPT == 3 ? 10 : 16;          // rows of the half's own query
+	const int h = lane >> 5;
+	const float inv_s = 1.0f / 32.0f;
+#if defined(VK_ABL) && VK_ABL == 1
+	{
+		float z = 0.0f;
+#pragma unroll
+		for (int i = 0; i < 16; i++) z += acc0[i] + acc1[i];
+		if (z == 12345.0f) p.scores[0] = z;
+		return;
+	}
+#endif
+	// (a) per token: max over the query's rows (in-lane) -> this lane's two tokens' distances -> sum
+	//     over the sentence's 32 tokens = 16 lanes x 2 chains
+	int ca0 = fbits(acc0[0]), ca1 = fbits(acc1[0]);
+#pragma unroll
+	for (int i = 1; i < NMAIN; i++) { ca0 = imax(ca0, fbits(acc0[i])); ca1 = imax(ca1, fbits(acc1[i])); }
+	const float ts_main = row_sum_to_lane15((2.0f - clip01_bits(ca0)) - clip01_bits(ca1));
+	float ts_third = 0.0f;
+	if (QPT == 3) {
+		int cb0 = fbits(acc0[10]), cb1 = fbits(acc1[10]);
+#pragma unroll
+		for (int i = 11; i < 15; i++) { cb0 = imax(cb0, fbits(acc0[i])); cb1 = imax(cb1, fbits(acc1[i])); }
+		const int e0 = __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, cb0);
+		const int e1 = __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, cb1);
+		cb0 = imax(cb0, e0); cb1 = imax(cb1, e1);
+		ts_third = row_sum_to_lane15((2.0f - clip01_bits(cb0)) - clip01_bits(cb1));
+	}
+	// (b) per query row: max over the sentence's tokens -> lane 15 of the DPP row
+	const int q_main = qt * QPT + h, q_third = qt * 3 + 2;
+	float s_main = 0.0f, s_third = 0.0f;
+#pragma unroll
+	for (int i = 0; i < NMAIN; i++)
+		s_main += clip01_bits(row_imax_to_lane15(imax(fbits(acc0[i]), fbits(acc1[i]))));
+	if (QPT == 3) {
+#pragma unroll
+		for (int i = 10; i < 15; i++)
+			s_third += clip01_bits(row_imax_to_lane15(imax(fbits(acc0[i]), fbits(acc1[i]))));
+		s_third += xor32_f(s_third, lane);
+	}
+	// (c) scores (the expressions of vk_rwmd_batch_kernel; sum (1 - x) over len rows = len - sum x)
+	if ((lane & 15) == 15 && sent < p.n_sent) {
+		const float boost = p.boost ? p.boost[sent] : 1.0f;
+		const int len_main = q_main < p.n_queries ? p.q_len[q_main] : 0;
+		if (len_main > 0) {
+			const float inv_t = p.q_inv_len[q_main];
+			const float a0 = inv_t * ((float)len_main - s_main), a1 = inv_s * ts_main;
+			const float cost = p.symmetric ? fmaxf(0.0f, fmaxf(a0, a1)) : a0;
+			const float raw = p.nbow ? 1.0f - cost : ((float)len_main - cost) * inv_t;
+			p.scores[(int64_t)q_main * p.n_sent + sent] = (raw * inv_t) * boost;
+		}
+		const int len_third = (QPT == 3 && h == 0 && q_third < p.n_queries) ? p.q_len[q_third] : 0;
+		if (len_third > 0) {
+			const float inv_t = p.q_inv_len[q_third];
+			const float a0 = inv_t * ((float)len_third - s_third), a1 = inv_s * ts_third;
+			const float cost = p.symmetric ? fmaxf(0.0f, fmaxf(a0, a1)) : a0;
+			const float raw = p.nbow ? 1.0f - cost : ((float)len_third - cost) * inv_t;
+			p.scores[(int64_t)q_third * p.n_sent + sent] = (raw * inv_t) * boost;
+		}
+	}
+}
+
 template <int NK16, int QPT>
 __global__ __launch_bounds__(512) void vk_rwmd_batch32_kernel(VkRwmdBatchParams p) {
 	constexpr int QT_BYTES = NK16 * 1024;
-	constexpr int N16 = QT_BYTES / 16;                 // 16-byte pieces of one query tile
-	constexpr int PER_THREAD = (N16 + 511) / 512;
-	constexpr int NMAIN = QPT == 3 ? 10 : 16;          // rows of the half's own query
 	extern __shared__ float4 vk_smem4[];
 	const uint8_t *qbuf = reinterpret_cast<const uint8_t *>(vk_smem4);
-	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int n32 = lane & 31, h = lane >> 5;
 	const int64_t n_chunks = ((int64_t)p.n_sent + 15) / 16;
-	const float inv_s = 1.0f / 32.0f;
+	// The two waves that share a SIMD (w and w + 4 of the workgroup) run the two halves of an interval in
+	// opposite order: the "late" wave first finishes the epilogue of the previous tile (VALU) while the
+	// other one issues its MFMAs, then they swap.  Barriers would otherwise keep all waves in phase:
+	// every matrix core idle during the epilogues, every VALU idle during the MFMAs.
+	const bool late = (wv & p.late_mask) != 0;
 
 	for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
 		const int64_t sent = chunk * 16 + wv * 2 + (n32 >> 4);   // this lane's sentence
@@ -1095,98 +1206,33 @@ __global__ __launch_bounds__(512) void vk_rwmd_batch32_kernel(VkRwmdBatchParams 
 		}
 		__syncthreads();   // previous chunk's readers are done with the LDS slots
 #pragma unroll
-		for (int u = 0; u < PER_THREAD; u++) {
-			const int i = threadIdx.x + u * 512;
-			if (i < N16) vk_smem4[i] = *reinterpret_cast<const float4 *>(p.qtiles + (size_t)i * 16);
-		}
+		for (int b = wv; b < NK16; b += 8)
+			__builtin_amdgcn_global_load_lds((vk_glb_ptr)(p.qtiles + b * 1024 + lane * 16), (vk_lds_ptr)(qbuf + b * 1024), 16, 0, 0);
 		__syncthreads();
 
+		f32x16 acc0, acc1;
 		for (int qt = 0; qt < p.n_qtiles; qt++) {
-			const uint8_t *cur = qbuf + (qt & 1) * QT_BYTES;
-			float4 *nxt = vk_smem4 + ((qt + 1) & 1) * N16;
-			float4 st[PER_THREAD];
-			const bool more = qt + 1 < p.n_qtiles;
-			if (more) {
-				const uint8_t *src = p.qtiles + (int64_t)(qt + 1) * QT_BYTES;
+			const uint8_t *cur = qbuf + (qt & 1) * QT_BYTES + lane * 16;
+			// next query tile: LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, no staging
+			// registers -- the kernel sits at the VGPR cap), in flight during this tile's MFMAs and retired by
+			// the barrier at the end of the iteration.  The tile after the last one is zero padding.
+			{
+				const uint8_t *src = p.qtiles + (int64_t)(qt + 1) * QT_BYTES + lane * 16;
+				const uint8_t *nxt = qbuf + ((qt + 1) & 1) * QT_BYTES;
 #pragma unroll
-				for (int u = 0; u < PER_THREAD; u++) {
-					const int i = threadIdx.x + u * 512;
-					st[u] = i < N16 ? *reinterpret_cast<const float4 *>(src + (size_t)i * 16) : float4{0, 0, 0, 0};
-				}
+				for (int b = wv; b < NK16; b += 8)
+					__builtin_amdgcn_global_load_lds((vk_glb_ptr)(src + b * 1024), (vk_lds_ptr)(nxt + b * 1024), 16, 0, 0);
 			}
-			f32x16 acc0, acc1;
-#pragma unroll
-			for (int i = 0; i < 16; i++) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
-#pragma unroll
-			for (int t = 0; t < NK16; t++) {
-				const bf16x8 a = *reinterpret_cast<const bf16x8 *>(cur + t * 1024 + lane * 16);
-				acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8n, a), __builtin_bit_cast(bf16x8n, x[0][t]), acc0, 0, 0, 0);
-				acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8n, a), __builtin_bit_cast(bf16x8n, x[1][t]), acc1, 0, 0, 0);
-			}
-			if (more) {
-#pragma unroll
-				for (int u = 0; u < PER_THREAD; u++) {
-					const int i = threadIdx.x + u * 512;
-					if (i < N16) nxt[i] = st[u];
-				}
-			}
-			// ---- epilogue.  D = 1 - clip(S) is monotone in S: reduce S, convert the reduced values only.
-			// (a) per token: max over the query's rows (in-lane) -> this lane's two tokens' distances -> sum
-			//     over the sentence's 32 tokens = 16 lanes x 2 chains
-			float ca0 = acc0[0], ca1 = acc1[0];
-#pragma unroll
-			for (int i = 1; i < NMAIN; i++) { ca0 = fmaxf(ca0, acc0[i]); ca1 = fmaxf(ca1, acc1[i]); }
-			float ts_main = (1.0f - clip01(ca0)) + (1.0f - clip01(ca1));
-			ts_main = row_sum_to_lane15(ts_main);
-			float ts_third = 0.0f;
-			if (QPT == 3) {
-				float cb0 = acc0[10], cb1 = acc1[10];
-#pragma unroll
-				for (int i = 11; i < 15; i++) { cb0 = fmaxf(cb0, acc0[i]); cb1 = fmaxf(cb1, acc1[i]); }
-				const float e0 = xor32_f(cb0, lane), e1 = xor32_f(cb1, lane);
-				cb0 = fmaxf(cb0, e0); cb1 = fmaxf(cb1, e1);
-				ts_third = (1.0f - clip01(cb0)) + (1.0f - clip01(cb1));
-				ts_third = row_sum_to_lane15(ts_third);
-			}
-			// (b) per query row: max over the sentence's tokens -> lane 15 of the DPP row
-			const int q_main = qt * QPT + h, q_third = qt * 3 + 2;
-			const int len_main = q_main < p.n_queries ? p.q_len[q_main] : 0;
-			float c_main = 0.0f, c_third = 0.0f;
-#pragma unroll
-			for (int i = 0; i < NMAIN; i++) {
-				const float r = row_max_to_lane15(fmaxf(acc0[i], acc1[i]));
-				c_main += i < len_main ? 1.0f - clip01(r) : 0.0f;
-			}
-			int len_third = 0;
-			if (QPT == 3) {
-				len_third = q_third < p.n_queries ? p.q_len[q_third] : 0;
-#pragma unroll
-				for (int i = 10; i < 15; i++) {
-					const float r = row_max_to_lane15(fmaxf(acc0[i], acc1[i]));
-					c_third += 5 * h + i - 10 < len_third ? 1.0f - clip01(r) : 0.0f;
-				}
-				c_third += xor32_f(c_third, lane);
-			}
-			// (c) scores (same expressions as vk_rwmd_batch_kernel)
-			if ((lane & 15) == 15 && sent < p.n_sent) {
-				const float boost = p.boost ? p.boost[sent] : 1.0f;
-				if (len_main > 0) {
-					const float inv_t = 1.0f / (float)len_main;
-					const float a0 = inv_t * c_main, a1 = inv_s * ts_main;
-					const float cost = p.symmetric ? fmaxf(0.0f, fmaxf(a0, a1)) : a0;
-					const float raw = p.nbow ? 1.0f - cost : ((float)len_main - cost) * inv_t;
-					p.scores[(int64_t)q_main * p.n_sent + sent] = (raw * inv_t) * boost;
-				}
-				if (QPT == 3 && h == 0 && len_third > 0) {
-					const float inv_t = 1.0f / (float)len_third;
-					const float a0 = inv_t * c_third, a1 = inv_s * ts_third;
-					const float cost = p.symmetric ? fmaxf(0.0f, fmaxf(a0, a1)) : a0;
-					const float raw = p.nbow ? 1.0f - cost : ((float)len_third - cost) * inv_t;
-					p.scores[(int64_t)q_third * p.n_sent + sent] = (raw * inv_t) * boost;
-				}
+			if (!late) {
+				batch32_mfma<NK16>(cur, x, acc0, acc1);
+				batch32_epilogue<QPT>(p, qt, sent, lane, acc0, acc1);
+			} else {
+				if (qt > 0) batch32_epilogue<QPT>(p, qt - 1, sent, lane, acc0, acc1);
+				batch32_mfma<NK16>(cur, x, acc0, acc1);
 			}
 			__syncthreads();   // next query tile is in place; this one may be overwritten
 		}
+		if (late) batch32_epilogue<QPT>(p, p.n_qtiles - 1, sent, lane, acc0, acc1);
 	}
 }
 
