@@ -33,7 +33,9 @@ extern "C" {
 
 #define VK_ABI_VERSION 1
 #define VK_MAX_QUERY_LEN 16   /* query tokens handled by one 16-wide MFMA column block */
-#define VK_MAX_SENT_LEN 64    /* tokens per sentence (slice), SURVEY 8: |s| <= 64 */
+#define VK_MAX_SENT_LEN 512   /* tokens per sentence (slice) */
+#define VK_FAST_SENT_LEN 64   /* slices up to this length run 4 per wave in the fused kernel (|s| <= 64); longer
+                                 ones take a second launch, one slice per wave; VK_ALG_WRD and full WMD need all slices <= 64 */
 #define VK_MAX_MATCHES 1024
 
 typedef enum {

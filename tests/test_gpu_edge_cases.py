@@ -112,15 +112,6 @@ def test_boundary_lengths(hip, oracle):
 	assert got["sentence"][0] == 5 and abs(got["score"][0] - 1.0) < 1e-3
 
 
-def test_too_long_sentence_is_rejected(hip):
-	off = np.array([0, 65], dtype=np.int64)
-	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=16, n_tokens=65, n_sentences=1)
-	c.append_vectors(np.ones((65, 16), np.float32))
-	with pytest.raises(hip.VkError):
-		c.set_sentences(off)
-	c.close()
-
-
 def test_overlapping_slices(hip, oracle):
 	# sliding windows (window_size 3, window_step 1) over 40 sentences: vk_corpus_set_slices
 	rng = np.random.default_rng(12)

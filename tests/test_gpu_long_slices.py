@@ -1,0 +1,130 @@
+"""-m gpu: slices longer than the 64 tokens of the fused fast path (up to VK_MAX_SENT_LEN = 512) take a
+second launch, one slice per wave; the slice table is padded so that no group of the main launch spans
+a long slice.  HIP (through the C-ABI) against the oracle: scores, order, mappings."""
+
+import numpy as np
+import pytest
+
+from vectorian_amd import synth
+
+from helpers import assert_same_results, hip_static_corpus, prep_query
+
+pytestmark = pytest.mark.gpu
+
+EXP5L = ("table", (1 - 2.0 ** (-np.arange(0, 513) / 5)).astype(np.float32))
+AFF = ("affine", 0.2, 0.05)
+
+
+def vectors(n, d, seed):
+	return synth.to_bf16_bits(synth.normalize_rows(np.random.default_rng(seed).standard_normal((n, d)).astype(np.float32)))
+
+
+def mixed_lengths(seed, n=90):
+	rng = np.random.default_rng(seed)
+	lens = rng.integers(1, 41, size=n)
+	# long slices first, last, alone, in a run, at every position of a group of 4
+	for pos, ln in ((0, 65), (5, 100), (6, 257), (7, 70), (18, 512), (23, 131), (40, 66), (41, 64), (n - 1, 300)):
+		lens[pos] = ln
+	return np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+
+
+def planted_query(Xb_f32, off, sent, len_t, seed):
+	"""noisy copy of tokens of one (long) slice, spread out so that gaps matter"""
+	rng = np.random.default_rng(seed)
+	a, b = int(off[sent]), int(off[sent + 1])
+	idx = np.sort(rng.choice(np.arange(a, b), size=min(len_t, b - a), replace=False))
+	q = Xb_f32[idx] + 0.05 * rng.standard_normal((len(idx), Xb_f32.shape[1])).astype(np.float32)
+	return synth.to_bf16_bits(synth.normalize_rows(q))
+
+
+@pytest.mark.parametrize("d", [64, 300, 768])
+def test_long_slices_contextual(hip, oracle, d):
+	off = mixed_lengths(21)
+	X = np.random.default_rng(22).standard_normal((int(off[-1]), d)).astype(np.float32)
+	Xb = synth.to_bf16_bits(synth.normalize_rows(X))
+	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=d, n_tokens=Xb.shape[0], n_sentences=len(off) - 1)
+	c.append_vectors(Xb, normalize=False)
+	c.set_sentences(off)
+	c.finalize()
+	boost = np.random.default_rng(23).uniform(0.5, 1.5, size=len(off) - 1).astype(np.float32)
+	for qi, (sent, len_t) in enumerate(((18, 9), (6, 16), (3, 5), (89, 12))):
+		Qb = planted_query(X, off, sent, len_t, 30 + qi)
+		for loc, ms, gaps, bst in ((0, 0.0, (0.1, 0.1), None), (0, 0.0, (EXP5L, EXP5L), boost), (1, -1e9, (EXP5L, EXP5L), None),
+				(2, -1e9, (AFF, AFF), None), (1, -1e9, (0.05, 0.2), boost), (0, 0.0, (AFF, 0.1), None)):
+			ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=off, X=Xb, Q=Qb, locality=loc,
+				gap_s=gaps[0], gap_t=gaps[1], max_matches=15, min_score=ms, boost=bst, want_all_scores=True)
+			got = c.query(Qb, q_normalize=False, locality=loc, gap_s=gaps[0], gap_t=gaps[1], max_matches=15, min_score=ms, boost=bst)
+			assert_same_results(got.trimmed(), ref)
+			if loc == 0:
+				assert sent in got.sentence[:got.n]
+			sc = c.last_scores()
+			np.testing.assert_allclose(sc, ref["all_scores"], atol=1e-4)
+	# transport: the relaxed distance has no length limit, the exact ones do
+	ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=off, X=Xb, Q=Qb, algorithm=oracle.ALG_RWMD, max_matches=15)
+	got = c.query(Qb, q_normalize=False, algorithm=hip.VK_ALG_RWMD, max_matches=15).trimmed()
+	assert_same_results(got, ref, check_mapping=False, score_tol=2e-5, tie_tol=2e-5)
+	with pytest.raises(hip.VkError):
+		c.query(Qb, q_normalize=False, algorithm=hip.VK_ALG_RWMD, rwmd=(False, False, True), wmd_full=True, max_matches=5)
+	c.close()
+
+
+def test_long_slices_static_layout(hip, oracle):
+	corpus = synth.make_static_corpus(120, 1, 40, 900, 100, seed=5)
+	lens = np.diff(corpus["sent_off"]).copy()
+	for pos, ln in ((2, 90), (3, 200), (64, 65), (119, 400)):
+		lens[pos] = ln
+	off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+	rng = np.random.default_rng(6)
+	corpus["sent_off"] = off
+	corpus["tok_id"] = rng.integers(0, 900, size=int(off[-1])).astype(np.int32)
+	c, Eb = hip_static_corpus(hip, corpus)
+	for qi in range(3):
+		s = (3, 119, 50)[qi]
+		q_ids = corpus["tok_id"][off[s]:off[s] + 8 + qi].astype(np.int32)
+		Qb = Eb[q_ids]
+		for loc, ms, gaps in ((0, 0.0, (0.1, 0.1)), (1, -1e9, (EXP5L, EXP5L)), (2, -1e9, (AFF, AFF))):
+			ref = oracle.find(layout=oracle.LAYOUT_STATIC, d=100, sent_off=off, tok_id=corpus["tok_id"], E=Eb, Q=Qb, q_ids=q_ids,
+				locality=loc, gap_s=gaps[0], gap_t=gaps[1], max_matches=10, min_score=ms)
+			got = c.query(Qb, q_token_ids=q_ids, q_normalize=False, locality=loc, gap_s=gaps[0], gap_t=gaps[1], max_matches=10, min_score=ms)
+			assert_same_results(got.trimmed(), ref)
+	c.close()
+
+
+def test_long_sliding_windows(hip, oracle):
+	# window_size 4, window_step 2 over sentences of up to 40 tokens: slices of up to 160 tokens, overlapping
+	rng = np.random.default_rng(40)
+	lens = rng.integers(3, 41, size=60)
+	off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+	ids = np.arange(0, 60, 2)
+	start = off[ids]
+	end = off[np.minimum(ids + 4, 60)]
+	assert (end - start).max() > 64
+	Xb, Qb = vectors(int(off[-1]), 64, 41), vectors(7, 64, 42)
+	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=64, n_tokens=Xb.shape[0], n_sentences=len(ids))
+	c.append_vectors(Xb, normalize=False)
+	c.set_slices(start, end)
+	c.finalize()
+	for loc, ms, gaps in ((0, 0.0, (0.1, 0.1)), (1, -1e9, (EXP5L, EXP5L)), (2, -1e9, (AFF, AFF))):
+		ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=64, sent_off=start, sent_end=end, X=Xb, Q=Qb, locality=loc,
+			gap_s=gaps[0], gap_t=gaps[1], max_matches=12, min_score=ms)
+		got = c.query(Qb, q_normalize=False, locality=loc, gap_s=gaps[0], gap_t=gaps[1], max_matches=12, min_score=ms).trimmed()
+		assert_same_results(got, ref)
+	c.close()
+
+
+def test_only_long_slices_and_limit(hip, oracle):
+	off = np.array([0, 512, 512 + 65, 512 + 65 + 200], dtype=np.int64)
+	Xb, Qb = vectors(int(off[-1]), 48, 50), vectors(4, 48, 51)
+	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=48, n_tokens=Xb.shape[0], n_sentences=3)
+	c.append_vectors(Xb, normalize=False)
+	c.set_sentences(off)
+	c.finalize()
+	ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=48, sent_off=off, X=Xb, Q=Qb, gap_s=EXP5L, gap_t=EXP5L, max_matches=5)
+	got = c.query(Qb, q_normalize=False, gap_s=EXP5L, gap_t=EXP5L, max_matches=5).trimmed()
+	assert_same_results(got, ref)
+	c.close()
+	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=16, n_tokens=513, n_sentences=1)
+	c.append_vectors(np.ones((513, 16), np.float32))
+	with pytest.raises(hip.VkError):
+		c.set_sentences(np.array([0, 513], dtype=np.int64))
+	c.close()

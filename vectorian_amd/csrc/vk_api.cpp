@@ -57,6 +57,7 @@ float gap_cost(const vk_gap &g, int k) {
 }
 
 constexpr int kTopkChunk = 2048;
+constexpr int kGapTable = 640;   // entries of the gap tables sent to the device (> VK_MAX_SENT_LEN)
 constexpr int64_t kStageBytes = 64ll << 20;
 
 } // namespace
@@ -75,6 +76,12 @@ struct vk_corpus {
 	bool contiguous = false;   // slices are the CSR partition of the token stream
 	bool have_ids = false, have_sent = false, finalized = false;
 	int max_len = 0, max_group_tiles = 0, max_group_tokens = 0;
+	// slice table on the device: n_entries >= n_sentences rows.  Slices longer than VK_FAST_SENT_LEN sit alone in
+	// their group of 4 (padded with empty rows) and are scored by a second launch over d_long_groups.
+	int64_t n_entries = 0;
+	std::vector<int32_t> entry_sent;   // [n_entries] sentence of a row, -1 = padding; empty when the table is the identity
+	int32_t *d_long_groups = nullptr;
+	int n_long_groups = 0, max_short_len = 0, long_group_tiles = 0, long_group_tokens = 0;
 	int uniform_len = 0;       // > 0: every sentence has exactly this many tokens
 	uint8_t *d_bq = nullptr; int32_t *d_bqlen = nullptr; float *d_bscores = nullptr; uint64_t *d_bkeys[2] = {nullptr, nullptr};
 	size_t bq_cap = 0, bscores_cap = 0, bkeys_cap = 0;
@@ -167,17 +174,10 @@ int vk_corpus_create(const vk_corpus_desc *desc, vk_corpus_t **out) {
 			if ((rc = alloc_t(c, &c->d_tok_id, (size_t)desc->n_tokens + 64))) break;
 			if ((rc = alloc_t(c, &c->d_table, (size_t)c->n_tiles * 16 * 16))) break;
 		}
-		if ((rc = alloc_t(c, &c->d_sent_start, (size_t)desc->n_sentences + 8))) break;
-		if ((rc = alloc_t(c, &c->d_sent_end, (size_t)desc->n_sentences + 8))) break;
 		if ((rc = alloc_t(c, &c->d_qtile, (size_t)c->tile_bytes))) break;
-		if ((rc = alloc_t(c, &c->d_ws, 128))) break;
+		if ((rc = alloc_t(c, &c->d_ws, kGapTable))) break;
 		if ((rc = alloc_t(c, &c->d_wt, 32))) break;
 		if ((rc = alloc_t(c, &c->d_qids, 32))) break;
-		if ((rc = alloc_t(c, &c->d_scores, (size_t)desc->n_sentences + 8))) break;
-		if ((rc = alloc_t(c, &c->d_raw, (size_t)desc->n_sentences + 8))) break;
-		const size_t nblk = (size_t)((desc->n_sentences + kTopkChunk - 1) / kTopkChunk) + 1;
-		if ((rc = alloc_t(c, &c->d_keys[0], nblk * VK_MAX_MATCHES + kTopkChunk))) break;
-		if ((rc = alloc_t(c, &c->d_keys[1], (nblk * VK_MAX_MATCHES) / 2 + 2 * kTopkChunk))) break;
 		if ((rc = alloc_t(c, &c->d_out_raw, VK_MAX_MATCHES))) break;
 		if ((rc = alloc_t(c, &c->d_out_sim, (size_t)VK_MAX_MATCHES * 16))) break;
 		if ((rc = alloc_t(c, &c->d_out_map, (size_t)VK_MAX_MATCHES * 16))) break;
@@ -192,7 +192,7 @@ int vk_corpus_free(vk_corpus_t *c) {
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	void *ptrs[] = {c->d_tiles, c->d_mag, c->d_tok_id, c->d_pos, c->d_sent_start, c->d_sent_end, c->d_stage, c->d_qtile, c->d_ws, c->d_wt, c->d_qids,
-		c->d_table, c->d_scores, c->d_raw, c->d_boost, c->d_keys[0], c->d_keys[1], c->d_out_raw, c->d_out_sim, c->d_out_map, c->d_wrd_raw, c->d_wrd_val, c->d_bq, c->d_bqlen, c->d_bscores, c->d_bkeys[0], c->d_bkeys[1]};
+		c->d_table, c->d_scores, c->d_raw, c->d_boost, c->d_keys[0], c->d_keys[1], c->d_out_raw, c->d_out_sim, c->d_out_map, c->d_wrd_raw, c->d_wrd_val, c->d_bq, c->d_bqlen, c->d_bscores, c->d_bkeys[0], c->d_bkeys[1], c->d_long_groups};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -269,7 +269,8 @@ int vk_corpus_set_token_pos(vk_corpus_t *c, const int8_t *pos, int64_t n, int32_
 }
 
 static int set_slices_impl(vk_corpus_t *c, const int64_t *start, const int64_t *end, int64_t n_sentences, bool contiguous) {
-	int max_len = 0;
+	int max_len = 0, max_short = 0;
+	int64_t n_long = 0;
 	for (int64_t s = 0; s < n_sentences; s++) {
 		const int64_t len = end[s] - start[s];
 		if (start[s] < 0 || end[s] > c->desc.n_tokens || len < 0) return fail(VK_ERR_INVALID, "slice outside the token stream");
@@ -280,17 +281,60 @@ static int set_slices_impl(vk_corpus_t *c, const int64_t *start, const int64_t *
 			return fail(VK_ERR_UNSUPPORTED, buf);
 		}
 		max_len = std::max(max_len, (int)len);
+		if (len > VK_FAST_SENT_LEN) n_long++;
+		else max_short = std::max(max_short, (int)len);
 	}
 	VK_HIP(hipSetDevice(c->device));
-	std::vector<int32_t> st32((size_t)n_sentences + 8), en32((size_t)n_sentences + 8);
-	const int32_t tail = n_sentences > 0 ? (int32_t)end[n_sentences - 1] : 0;
-	for (int64_t s = 0; s < n_sentences + 8; s++) {
-		st32[(size_t)s] = s < n_sentences ? (int32_t)start[s] : tail;   // padding: empty slices at the end
-		en32[(size_t)s] = s < n_sentences ? (int32_t)end[s] : tail;
+
+	// ---- the slice table.  Without long slices it is the caller's table.  A long slice gets a group of 4 rows
+	// of its own ([L, empty, empty, empty]); the group before it is closed with empty rows, so that no group of
+	// the main launch spans the tokens of a long slice.  Rows stay in slice order (ties are broken by row).
+	std::vector<int32_t> st32, en32, long_groups;
+	c->entry_sent.clear();
+	if (n_long == 0) {
+		st32.resize((size_t)n_sentences); en32.resize((size_t)n_sentences);
+		for (int64_t s = 0; s < n_sentences; s++) { st32[(size_t)s] = (int32_t)start[s]; en32[(size_t)s] = (int32_t)end[s]; }
+	} else {
+		if (n_sentences + 3 * n_long + 3 >= (1ll << 31) - 16) return fail(VK_ERR_INVALID, "slice table too large");
+		auto push = [&](int32_t a, int32_t b, int32_t sent) { st32.push_back(a); en32.push_back(b); c->entry_sent.push_back(sent); };
+		for (int64_t s = 0; s < n_sentences; s++) {
+			if (end[s] - start[s] > VK_FAST_SENT_LEN) {
+				while (st32.size() % 4) push(en32.back(), en32.back(), -1);
+				long_groups.push_back((int32_t)(st32.size() / 4));
+				push((int32_t)start[s], (int32_t)end[s], (int32_t)s);
+				for (int i = 0; i < 3; i++) push((int32_t)end[s], (int32_t)end[s], -1);
+			} else {
+				push((int32_t)start[s], (int32_t)end[s], (int32_t)s);
+			}
+		}
+	}
+	const int64_t n_entries = (int64_t)st32.size();
+	const int32_t tail = n_entries > 0 ? en32.back() : 0;
+	for (int i = 0; i < 8; i++) { st32.push_back(tail); en32.push_back(tail); }   // padding: empty slices at the end
+
+	// ---- device arrays sized by the table (re-created when the slices are set again)
+	for (void *p : {(void *)c->d_sent_start, (void *)c->d_sent_end, (void *)c->d_scores, (void *)c->d_raw, (void *)c->d_keys[0], (void *)c->d_keys[1],
+			(void *)c->d_boost, (void *)c->d_long_groups})
+		if (p) VK_HIP(hipFree(p));
+	c->d_sent_start = c->d_sent_end = nullptr; c->d_scores = c->d_raw = c->d_boost = nullptr; c->d_keys[0] = c->d_keys[1] = nullptr; c->d_long_groups = nullptr;
+	int rc;
+	if ((rc = alloc_t(c, &c->d_sent_start, st32.size()))) return rc;
+	if ((rc = alloc_t(c, &c->d_sent_end, en32.size()))) return rc;
+	if ((rc = alloc_t(c, &c->d_scores, (size_t)n_entries + 8))) return rc;
+	if ((rc = alloc_t(c, &c->d_raw, (size_t)n_entries + 8))) return rc;
+	const size_t nblk = (size_t)((n_entries + kTopkChunk - 1) / kTopkChunk) + 1;
+	if ((rc = alloc_t(c, &c->d_keys[0], nblk * VK_MAX_MATCHES + kTopkChunk))) return rc;
+	if ((rc = alloc_t(c, &c->d_keys[1], (nblk * VK_MAX_MATCHES) / 2 + 2 * kTopkChunk))) return rc;
+	if (!long_groups.empty()) {
+		if ((rc = alloc_t(c, &c->d_long_groups, long_groups.size()))) return rc;
+		VK_HIP(hipMemcpy(c->d_long_groups, long_groups.data(), long_groups.size() * 4, hipMemcpyHostToDevice));
 	}
 	VK_HIP(hipMemcpy(c->d_sent_start, st32.data(), st32.size() * 4, hipMemcpyHostToDevice));
 	VK_HIP(hipMemcpy(c->d_sent_end, en32.data(), en32.size() * 4, hipMemcpyHostToDevice));
+	c->n_entries = n_entries;
+	c->n_long_groups = (int)long_groups.size();
 	c->max_len = max_len;
+	c->max_short_len = max_short;
 	c->contiguous = contiguous;
 	c->uniform_len = 0;
 	if (n_sentences > 0 && contiguous) {
@@ -299,16 +343,25 @@ static int set_slices_impl(vk_corpus_t *c, const int64_t *start, const int64_t *
 		for (int64_t s = 1; s < n_sentences && uni; s++) uni = (end[s] - start[s]) == l0;
 		if (uni) c->uniform_len = (int)l0;
 	}
-	// per wave: groups of 4 consecutive slices
-	int mt = 1, mtok = 1;
-	for (int64_t g = 0; g * 4 < n_sentences; g++) {
-		const int64_t a = start[g * 4], b = end[std::min<int64_t>(g * 4 + 3, n_sentences - 1)];
+	// per wave: groups of 4 consecutive rows; LDS strips are sized for the main launch and the long one apart
+	int mt = 1, mtok = 1, lt = 1, ltok = 1;
+	size_t li = 0;
+	for (int64_t g = 0; g * 4 < n_entries; g++) {
+		const int64_t a = st32[(size_t)(g * 4)], b = en32[(size_t)std::min<int64_t>(g * 4 + 3, n_entries - 1)];
 		const int tiles = (int)(((b + 15) >> 4) - (a >> 4));
-		mt = std::max(mt, tiles);
-		mtok = std::max(mtok, (int)(b - a));
+		if (li < long_groups.size() && long_groups[li] == g) {
+			li++;
+			lt = std::max(lt, tiles);
+			ltok = std::max(ltok, (int)(b - a));
+		} else {
+			mt = std::max(mt, tiles);
+			mtok = std::max(mtok, (int)(b - a));
+		}
 	}
 	c->max_group_tiles = mt;
 	c->max_group_tokens = mtok;
+	c->long_group_tiles = lt;
+	c->long_group_tokens = ltok;
 	c->have_sent = true;
 	return VK_OK;
 }
@@ -374,12 +427,14 @@ static int validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_t
 		if (q->rwmd_symmetric && !q->rwmd_normalize_bow)
 			return fail(VK_ERR_INVALID, "cannot run symmetric mode WMD with bow (needs nbow)");   // wmd.h:441-449
 		if (q->wmd_full) {
+			if (c->max_len > VK_FAST_SENT_LEN) return fail(VK_ERR_UNSUPPORTED, "full WMD needs every slice <= VK_FAST_SENT_LEN (64) tokens");
 			if (q->rwmd_injective) return fail(VK_ERR_INVALID, "non-relaxed WMD with injective mapping is not supported");      // wmd.h:201-204
 			if (q->rwmd_symmetric) return fail(VK_ERR_INVALID, "non-relaxed WMD with symmetric computation is not supported");  // wmd.h:206-209
 		} else if (!q->rwmd_injective)
 			return fail(VK_ERR_UNSUPPORTED, "non-injective RWMD (rwmd('nbow/distributed')) is not implemented on the HIP path");
 		if (q->want_flow && (!out->mapping || !out->edge_sim)) return fail(VK_ERR_INVALID, "want_flow needs mapping and edge_sim arrays");
 	} else if (q->algorithm == VK_ALG_WRD) {
+		if (c->max_len > VK_FAST_SENT_LEN) return fail(VK_ERR_UNSUPPORTED, "VK_ALG_WRD needs every slice <= VK_FAST_SENT_LEN (64) tokens");
 		if (q->tag_weights) return fail(VK_ERR_UNSUPPORTED, "tag-weighted similarity is implemented for alignments only");
 		if (c->desc.layout != VK_LAYOUT_CONTEXTUAL)
 			return fail(VK_ERR_UNSUPPORTED, "VK_ALG_WRD is implemented for the contextual layout only");
@@ -429,11 +484,12 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	if (rc) return rc;
 	VK_HIP(hipSetDevice(c->device));
 	hipStream_t st = c->stream;
-	const int64_t n = c->desc.n_sentences;
+	const int64_t n = c->n_entries;           // rows of the slice table (== n_sentences unless long slices were padded)
 	const int k = q->max_matches;
 	out->n_out = 0;
 	c->have_scores = false;
 	if (n == 0) return VK_OK;
+	auto sentence_of = [c](int64_t row) { return c->entry_sent.empty() ? row : (int64_t)c->entry_sent[(size_t)row]; };
 
 	// ---- prepare: query tile, gap tables, boost, static table -------------
 	VK_HIP(hipEventRecord(c->ev[0], st));
@@ -444,7 +500,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 
 	VkScoreParams p{};
 	const int ks = q->gap_s.kind, kt = q->gap_t.kind;
-	float ws[128], wt[32];
+	float ws[kGapTable], wt[32];
 	const bool is_align = q->algorithm == VK_ALG_ALIGN;
 	if (q->algorithm == VK_ALG_WRD) {
 		p.gap_mode = 5;
@@ -471,7 +527,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	} else {
 		p.gap_mode = 2;
 	}
-	for (int i = 0; i < 128; i++) ws[i] = is_align ? gap_cost(q->gap_s, i) : 0.0f;
+	for (int i = 0; i < kGapTable; i++) ws[i] = (is_align && i <= c->max_len) ? gap_cost(q->gap_s, i) : 0.0f;
 	for (int i = 0; i < 32; i++) wt[i] = is_align ? gap_cost(q->gap_t, i) : 0.0f;
 	if (p.gap_mode == 2) {
 		// register-history kernel: needs w_t strictly subadditive over the query length
@@ -480,14 +536,21 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		for (int x = 1; x < q->len_t && sub; x++)
 			for (int y = 1; x + y <= q->len_t; y++)
 				if (!(wt[x] + wt[y] > wt[x + y] + 1e-4f)) { sub = false; break; }
-		if (sub) p.gap_mode = c->max_len <= 32 ? 3 : 6;
+		if (sub) p.gap_mode = c->max_short_len <= 32 ? 3 : 6;
 	}
 	VK_HIP(hipMemcpyAsync(c->d_ws, ws, sizeof ws, hipMemcpyHostToDevice, st));
 	VK_HIP(hipMemcpyAsync(c->d_wt, wt, sizeof wt, hipMemcpyHostToDevice, st));
 
+	std::vector<float> boost_rows;
 	if (q->boost) {
 		if (!c->d_boost) { rc = alloc_t(c, &c->d_boost, (size_t)n + 8); if (rc) return rc; }
-		VK_HIP(hipMemcpyAsync(c->d_boost, q->boost, (size_t)n * 4, hipMemcpyHostToDevice, st));
+		const float *src = q->boost;
+		if (!c->entry_sent.empty()) {
+			boost_rows.resize((size_t)n);
+			for (int64_t e = 0; e < n; e++) boost_rows[(size_t)e] = c->entry_sent[(size_t)e] >= 0 ? q->boost[c->entry_sent[(size_t)e]] : 1.0f;
+			src = boost_rows.data();
+		}
+		VK_HIP(hipMemcpyAsync(c->d_boost, src, (size_t)n * 4, hipMemcpyHostToDevice, st));
 	}
 
 	const bool is_static = c->desc.layout == VK_LAYOUT_STATIC;
@@ -521,17 +584,34 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		p.tw_threshold = q->similarity_threshold;
 		p.ref_total = total;   // reference_score with max_similarity_for_t = t_pos_weights (slice/static.h:280-286)
 	}
+	p.max_short_len = VK_FAST_SENT_LEN;
 	p.s_rows_per_wave = is_static ? (c->max_group_tokens + 15) / 16 * 16 : c->max_group_tiles * 16;
-	p.h_rows = c->max_len + 1;
+	p.h_rows = c->max_short_len + 1;
 	int lds_floats = p.s_rows_per_wave * 16;
 	if (p.gap_mode == 2) lds_floats += 4 * p.h_rows * 16;   // column history of dp_general
 	p.lds_floats_per_wave = lds_floats;
 	size_t smem = (size_t)lds_floats * 4 * 4;   // 4 waves per block
-	if (!is_static && c->nk32 == 24 && c->tail == 0) smem += (size_t)c->nk32 * 1024;   // MODE 3: query tile in LDS
+	const size_t qlds = (!is_static && c->nk32 == 24 && c->tail == 0) ? (size_t)c->nk32 * 1024 : 0;   // MODE 3: query tile in LDS
+	smem += qlds;
 	if (smem > 160 * 1024) return fail(VK_ERR_UNSUPPORTED, "LDS demand exceeds 160 KiB per workgroup");
 	const int64_t n_groups = (n + 3) / 4;
 	const int grid = (int)std::min<int64_t>((n_groups + 3) / 4, (int64_t)1 << 20);   // capped to residency by the launcher
 	VK_HIP(vk_launch_score(&p, grid, smem, st));
+	if (c->n_long_groups > 0) {
+		// slices longer than VK_FAST_SENT_LEN: one per wave, one wave per workgroup, LDS strip for the longest;
+		// general gaps take the LDS-history form (the four DPP rows share one history: only row 0 is active)
+		VkScoreParams pl = p;
+		pl.group_list = c->d_long_groups; pl.n_list = c->n_long_groups;
+		if (pl.gap_mode == 3 || pl.gap_mode == 6) pl.gap_mode = 2;
+		pl.s_rows_per_wave = is_static ? (c->long_group_tokens + 15) / 16 * 16 : c->long_group_tiles * 16;
+		pl.h_rows = 0;
+		int lf = pl.s_rows_per_wave * 16;
+		if (pl.gap_mode == 2) lf += (c->max_len + 1) * 16;
+		pl.lds_floats_per_wave = lf;
+		const size_t smem_l = (size_t)lf * 4 + qlds;
+		if (smem_l > 160 * 1024) return fail(VK_ERR_UNSUPPORTED, "LDS demand of the long-slice pass exceeds 160 KiB");
+		VK_HIP(vk_launch_score(&pl, c->n_long_groups, smem_l, st));
+	}
 
 	const bool exact_transport = q->algorithm == VK_ALG_WRD || (q->algorithm == VK_ALG_RWMD && q->wmd_full);
 	if (exact_transport) {
@@ -591,7 +671,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		VK_HIP(hipStreamSynchronize(st));
 		for (size_t i = 0; i < best.size(); i++) {
 			out->score[i] = best[i].val;
-			out->sentence[i] = best[i].g;
+			out->sentence[i] = sentence_of(best[i].g);
 			if (out->raw_score) out->raw_score[i] = best[i].raw;
 			if (q->want_flow && out->mapping && out->edge_sim)
 				for (int j = 0; j < q->len_t; j++) {
@@ -641,6 +721,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		f.tiles = c->d_tiles; f.tok_id = c->d_tok_id; f.table = c->d_table; f.sent_start = c->d_sent_start; f.sent_end = c->d_sent_end;
 		f.layout = p.layout; f.nk32 = c->nk32; f.tail = c->tail; f.tile_bytes = c->tile_bytes;
 		f.qtile = c->d_qtile; f.len_t = q->len_t; f.locality = q->locality; f.gap_mode = (p.gap_mode == 3 || p.gap_mode == 6) ? 2 : p.gap_mode;
+		f.max_len = c->max_len;
 		f.gs = p.gs; f.gt = p.gt; f.a_s = p.a_s; f.a_t = p.a_t; f.open_s = p.open_s; f.open_t = p.open_t;
 		f.ws = c->d_ws; f.wt = c->d_wt;
 		f.pos_s = p.pos_s; f.tw_keep = p.tw_keep; f.tw_threshold = p.tw_threshold;
@@ -684,7 +765,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		float s;
 		memcpy(&s, &bits, 4);
 		out->score[i] = s;
-		out->sentence[i] = (int64_t)(uint32_t)(key & 0xffffffffu);
+		out->sentence[i] = sentence_of((int64_t)(uint32_t)(key & 0xffffffffu));
 		if (out->raw_score) out->raw_score[i] = do_flow ? raw[(size_t)i] : raw_sel[(size_t)i];
 		if (do_flow) {
 			for (int j = 0; j < q->len_t; j++) {
@@ -884,7 +965,14 @@ int vk_last_scores(vk_corpus_t *c, float *scores, int64_t n) {
 	if (!c->have_scores) return fail(VK_ERR_STATE, "no query has run on this corpus");
 	if (n != c->desc.n_sentences) return fail(VK_ERR_INVALID, "n differs from n_sentences");
 	VK_HIP(hipSetDevice(c->device));
-	VK_HIP(hipMemcpy(scores, c->d_scores, (size_t)n * 4, hipMemcpyDeviceToHost));
+	if (c->entry_sent.empty()) {
+		VK_HIP(hipMemcpy(scores, c->d_scores, (size_t)n * 4, hipMemcpyDeviceToHost));
+		return VK_OK;
+	}
+	std::vector<float> rows((size_t)c->n_entries);
+	VK_HIP(hipMemcpy(rows.data(), c->d_scores, rows.size() * 4, hipMemcpyDeviceToHost));
+	for (int64_t e = 0; e < c->n_entries; e++)
+		if (c->entry_sent[(size_t)e] >= 0) scores[c->entry_sent[(size_t)e]] = rows[(size_t)e];
 	return VK_OK;
 }
 

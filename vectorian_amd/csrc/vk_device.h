@@ -14,7 +14,8 @@
 #define VK_DEV_LAYOUT_CONTEXTUAL 0
 #define VK_DEV_LAYOUT_STATIC 1
 
-#define VK_DEV_MAX_SENT_LEN 64
+#define VK_DEV_MAX_SENT_LEN 64        // fused fast path: 4 slices per wave
+#define VK_DEV_MAX_LONG_LEN 512       // longer slices: one per wave, second launch
 #define VK_DEV_MAX_QUERY_LEN 16
 
 struct VkScoreParams {
@@ -27,6 +28,9 @@ struct VkScoreParams {
 	int32_t n_sent;
 	int32_t layout;
 	int32_t nk32, tail, tile_bytes;
+	const int32_t *group_list; // null: all groups of 4 slices; else the groups holding one long slice each (64-thread blocks)
+	int32_t n_list;
+	int32_t max_short_len;     // main launch: groups with a longer slice are skipped
 	// query
 	const uint8_t *qtile;      // query in tile order (16 rows, rows >= len_t are zero)
 	int32_t len_t;
@@ -106,6 +110,7 @@ struct VkFlowParams {
 	int32_t len_t;
 	int32_t locality;
 	int32_t gap_mode;
+	int32_t max_len;           // longest slice of the corpus: sizes the LDS carve-up
 	float gs, gt, a_s, a_t, open_s, open_t;
 	const float *ws;
 	const float *wt;

@@ -618,10 +618,11 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 	extern __shared__ float4 vk_smem4[];
 	float *smem = reinterpret_cast<float *>(vk_smem4);
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	// MODE 3: the first NK32 KiB of the dynamic LDS hold the query tile (shared by the 4 waves)
+	const int nwaves = blockDim.x >> 6;      // 4; 1 in the pass over long slices (group_list)
+	// MODE 3: the first NK32 KiB of the dynamic LDS hold the query tile (shared by the block's waves)
 	const uint8_t *qlds = reinterpret_cast<const uint8_t *>(smem);
 	if constexpr (MODE == 3) {
-		for (int i = threadIdx.x; i < NK32 * 64; i += 256)
+		for (int i = threadIdx.x; i < NK32 * 64; i += blockDim.x)
 			vk_smem4[i] = *reinterpret_cast<const float4 *>(p.qtile + i * 16);
 		__syncthreads();
 		smem += NK32 * 256;
@@ -658,8 +659,12 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 		for (int k = 0; k < LT; k++) wtr[k] = p.wt[k];
 	}
 
-	const int n_groups = (p.n_sent + 3) >> 2;
-	for (int grp = blockIdx.x * 4 + wv; grp < n_groups; grp += gridDim.x * 4) {
+	// groups of 4 consecutive slices; slices longer than max_short_len sit alone in their group (the host
+	// pads the slice table, vk_api.cpp set_slices_impl) and are left to a second launch that walks
+	// group_list with one wave per workgroup and a larger LDS strip
+	const int n_groups = p.group_list ? p.n_list : (p.n_sent + 3) >> 2;
+	for (int gi = blockIdx.x * nwaves + wv; gi < n_groups; gi += gridDim.x * nwaves) {
+		const int grp = p.group_list ? p.group_list[gi] : gi;
 		const int s_idx = grp * 4 + sigma;
 		const int i0 = s_idx < p.n_sent ? s_idx : p.n_sent;       // entries >= n_sent are empty slices
 		const int t_a = p.sent_start[i0], t_b = p.sent_end[i0];
@@ -670,6 +675,7 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 		maxlen = max(maxlen, __builtin_amdgcn_readlane(len, 16));
 		maxlen = max(maxlen, __builtin_amdgcn_readlane(len, 32));
 		maxlen = max(maxlen, __builtin_amdgcn_readlane(len, 48));
+		if (!p.group_list && maxlen > p.max_short_len) continue;
 
 		int rowbase;
 		if (MODE == 2) {
@@ -1285,20 +1291,28 @@ __global__ __launch_bounds__(256) void vk_topk_wave_batch_kernel(const float *__
 // ---------------------------------------------------------------------------
 
 #define VK_TB_W 17
-#define VK_TB_ROWS (VK_DEV_MAX_SENT_LEN + 1)
+
+// dynamic LDS of vk_flow_kernel for slices of at most max_len tokens (bytes); the carve-up below must match
+static inline size_t vk_flow_lds_bytes(int max_len, bool tagged) {
+	const size_t rows = (size_t)max_len + 1, srows = (size_t)max_len + 32;
+	size_t b = srows * 16 * 4 * (tagged ? 2 : 1);      // S (+ SW)
+	b += rows * VK_TB_W * 4;                           // H
+	b += (rows + 3) / 4 * 4 * 4 + 32 * 4;              // wsl, wtl
+	b += rows * VK_TB_W * 2;                           // dk
+	b += rows * VK_TB_W;                               // flags
+	return (b + 15) / 16 * 16;
+}
 
 __global__ __launch_bounds__(64) void vk_flow_kernel(VkFlowParams p) {
-	__shared__ __attribute__((aligned(16))) float S[(VK_DEV_MAX_SENT_LEN + 32) * 16];
-	__shared__ __attribute__((aligned(16))) float SW[(VK_DEV_MAX_SENT_LEN + 32) * 16];   // tag-weighted copy the DP runs on
-	__shared__ float H[VK_TB_ROWS * VK_TB_W];
-	__shared__ float E[VK_TB_ROWS * VK_TB_W];
-	__shared__ float F[VK_TB_ROWS * VK_TB_W];
-	__shared__ uint8_t dirs[VK_TB_ROWS * VK_TB_W];
-	__shared__ uint8_t eext[VK_TB_ROWS * VK_TB_W];
-	__shared__ uint8_t fext[VK_TB_ROWS * VK_TB_W];
-	__shared__ int16_t dk[VK_TB_ROWS * VK_TB_W];
-	__shared__ float wsl[VK_DEV_MAX_SENT_LEN + 1];
-	__shared__ float wtl[VK_DEV_MAX_QUERY_LEN + 1];
+	extern __shared__ float4 vk_smem4[];
+	const int rows = p.max_len + 1, srows = p.max_len + 32;
+	float *S = reinterpret_cast<float *>(vk_smem4);
+	float *SW = p.pos_s ? S + srows * 16 : S;            // tag-weighted copy the DP runs on (else S itself)
+	float *H = SW + srows * 16;
+	float *wsl = H + rows * VK_TB_W;
+	float *wtl = wsl + (rows + 3) / 4 * 4;
+	int16_t *dk = reinterpret_cast<int16_t *>(wtl + 32);
+	uint8_t *flags = reinterpret_cast<uint8_t *>(dk + rows * VK_TB_W);   // bits 0-1 direction, 2 E extended, 3 F extended
 
 	const int lane = threadIdx.x;
 	const int w = blockIdx.x;
@@ -1323,8 +1337,8 @@ __global__ __launch_bounds__(64) void vk_flow_kernel(VkFlowParams p) {
 					val.y = tag_weighted(val.y, p.tw[cb + 1], ps, p.tpos[cb + 1], p.tw_keep, p.tw_threshold);
 					val.z = tag_weighted(val.z, p.tw[cb + 2], ps, p.tpos[cb + 2], p.tw_keep, p.tw_threshold);
 					val.w = tag_weighted(val.w, p.tw[cb + 3], ps, p.tpos[cb + 3], p.tw_keep, p.tw_threshold);
+					*reinterpret_cast<float4 *>(SW + tk * 16 + (lane & 3) * 4) = val;
 				}
-				*reinterpret_cast<float4 *>(SW + tk * 16 + (lane & 3) * 4) = val;
 			}
 		}
 		rowbase = 0;
@@ -1338,13 +1352,13 @@ __global__ __launch_bounds__(64) void vk_flow_kernel(VkFlowParams p) {
 				const int ps = p.pos_s[(tile0 + ti) * 16 + (lane & 15)], cb = (lane >> 4) * 4;
 #pragma unroll
 				for (int r = 0; r < 4; r++) acc[r] = tag_weighted(acc[r], p.tw[cb + r], ps, p.tpos[cb + r], p.tw_keep, p.tw_threshold);
+				*reinterpret_cast<f32x4 *>(SW + (ti * 16 + (lane & 15)) * 16 + (lane >> 4) * 4) = acc;
 			}
-			*reinterpret_cast<f32x4 *>(SW + (ti * 16 + (lane & 15)) * 16 + (lane >> 4) * 4) = acc;
 		}
 		rowbase = t_a - tile0 * 16;
 	}
 	// gap tables into LDS (uniform broadcast reads in the candidate loops)
-	for (int i = lane; i <= VK_DEV_MAX_SENT_LEN; i += 64) wsl[i] = p.ws[i];
+	for (int i = lane; i <= p.max_len; i += 64) wsl[i] = p.ws[i];
 	if (lane <= VK_DEV_MAX_QUERY_LEN) wtl[lane] = p.wt[lane];
 	__syncthreads();
 
@@ -1428,7 +1442,8 @@ __global__ __launch_bounds__(64) void vk_flow_kernel(VkFlowParams p) {
 		}
 		if (col) {
 			H[u * W + v] = best;
-			dirs[u * W + v] = d; dk[u * W + v] = kk; eext[u * W + v] = ee; fext[u * W + v] = fe;
+			dk[u * W + v] = kk;
+			flags[u * W + v] = (uint8_t)(d | (ee << 2) | (fe << 3));
 		}
 		hprev = best;
 		eprev = e;
@@ -1465,9 +1480,10 @@ __global__ __launch_bounds__(64) void vk_flow_kernel(VkFlowParams p) {
 	int state = 0;
 	while (u > 0 && v2 > 0) {
 		const int idx = u * W + v2;
-		if (gap == 1 && state == 1) { if (!eext[idx]) state = 0; u--; continue; }
-		if (gap == 1 && state == 2) { if (!fext[idx]) state = 0; v2--; continue; }
-		const uint8_t d = dirs[idx];
+		const uint8_t fl = flags[idx];
+		if (gap == 1 && state == 1) { if (!(fl & 4)) state = 0; u--; continue; }
+		if (gap == 1 && state == 2) { if (!(fl & 8)) state = 0; v2--; continue; }
+		const uint8_t d = fl & 3;
 		if (d == 0) break;
 		if (d == 1) { mp[v2 - 1] = (int16_t)(u - 1); es[v2 - 1] = Su[(u - 1) * 16 + v2 - 1]; u--; v2--; }
 		else if (gap == 1) state = (d == 2) ? 1 : 2;
@@ -1675,7 +1691,13 @@ extern "C" hipError_t vk_launch_table(const uint8_t *etiles, const uint8_t *qtil
 template <typename K>
 static hipError_t launch_sized(K kernel, const VkScoreParams &p, int want_blocks, size_t smem, hipStream_t stream) {
 	int occ = 0;
-	hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, smem);
+	const int threads = p.group_list ? 64 : 256;
+	hipError_t e;
+	if (smem > 64 * 1024) {
+		e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+		if (e != hipSuccess) return e;
+	}
+	e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, threads, smem);
 	if (e != hipSuccess) return e;
 	if (occ < 1) occ = 1;
 	// measured on MI355X (1M x 32 x 300-d): 3 workgroups (12 waves) per CU stream HBM fastest --
@@ -1686,7 +1708,7 @@ static hipError_t launch_sized(K kernel, const VkScoreParams &p, int want_blocks
 	int dev = 0, cus = 256;
 	if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
 	const int grid = want_blocks < cus * occ ? want_blocks : cus * occ;
-	kernel<<<grid, 256, smem, stream>>>(p);
+	kernel<<<grid, threads, smem, stream>>>(p);
 	return hipGetLastError();
 }
 
@@ -1808,6 +1830,11 @@ extern "C" hipError_t vk_launch_topk_wave_batch(const float *scores, const uint6
 }
 
 extern "C" hipError_t vk_launch_flow(const VkFlowParams *p, int32_t k, hipStream_t stream) {
-	vk_flow_kernel<<<k, 64, 0, stream>>>(*p);
+	const size_t smem = vk_flow_lds_bytes(p->max_len, p->pos_s != nullptr);
+	if (smem > 64 * 1024) {
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(vk_flow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+		if (e != hipSuccess) return e;
+	}
+	vk_flow_kernel<<<k, 64, smem, stream>>>(*p);
 	return hipGetLastError();
 }
