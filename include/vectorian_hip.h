@@ -32,7 +32,9 @@ extern "C" {
 #endif
 
 #define VK_ABI_VERSION 1
-#define VK_MAX_QUERY_LEN 16   /* query tokens handled by one 16-wide MFMA column block */
+#define VK_MAX_QUERY_LEN 64   /* query tokens */
+#define VK_FAST_QUERY_LEN 16  /* queries up to this length run in the fused kernels (one 16-wide MFMA column block); longer ones
+                                 (alignments and injective RWMD only) take a one-wave-per-slice kernel, ~10x slower */
 #define VK_MAX_SENT_LEN 512   /* tokens per sentence (slice) */
 #define VK_FAST_SENT_LEN 64   /* slices up to this length run 4 per wave in the fused kernel (|s| <= 64); longer
                                  ones take a second launch, one slice per wave; VK_ALG_WRD and full WMD need all slices <= 64 */

@@ -1,0 +1,80 @@
+"""-m gpu: queries of 17 .. 64 tokens run on vk_wide_kernel (one wave per slice, lane = query column).
+HIP (through the C-ABI) against the oracle: scores, order, mappings, edge similarities."""
+
+import numpy as np
+import pytest
+
+from vectorian_amd import synth
+
+from helpers import assert_same_results, hip_contextual_corpus, hip_static_corpus, prep_contextual, prep_query
+
+pytestmark = pytest.mark.gpu
+
+EXP5L = ("table", (1 - 2.0 ** (-np.arange(0, 513) / 5)).astype(np.float32))
+AFF = ("affine", 0.2, 0.05)
+CASES = ((0, 0.0, (0.1, 0.1)), (0, 0.0, (EXP5L, EXP5L)), (1, -1e9, (EXP5L, EXP5L)), (2, -1e9, (AFF, AFF)), (1, -1e9, (0.05, 0.2)),
+	(2, -1e9, (EXP5L, 0.1)), (0, 0.0, (AFF, AFF)))
+
+
+@pytest.mark.parametrize("d,len_t", [(64, 17), (300, 32), (300, 20), (768, 40), (128, 64)])
+def test_wide_query_contextual(hip, oracle, d, len_t):
+	corpus = synth.make_contextual_corpus(300, 1, 64, 1500, d)
+	Xb = prep_contextual(corpus)
+	c = hip_contextual_corpus(hip, corpus, Xb)
+	qs = [prep_query(q) for q in synth.make_queries(corpus, 3, len_t)]
+	boost = np.random.default_rng(3).uniform(0.5, 1.5, size=300).astype(np.float32)
+	for qi, Qb in enumerate(qs):
+		for ci, (loc, ms, gaps) in enumerate(CASES):
+			bst = boost if (qi + ci) % 3 == 0 else None
+			ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=corpus["sent_off"], X=Xb, Q=Qb, locality=loc,
+				gap_s=gaps[0], gap_t=gaps[1], max_matches=12, min_score=ms, boost=bst, want_all_scores=True)
+			got = c.query(Qb, q_normalize=False, locality=loc, gap_s=gaps[0], gap_t=gaps[1], max_matches=12, min_score=ms, boost=bst)
+			assert_same_results(got.trimmed(), ref)
+			np.testing.assert_allclose(c.last_scores(), ref["all_scores"], atol=1e-4)
+			# edge similarities of the matched pairs
+			off = corpus["sent_off"]
+			for i in range(got.n):
+				s = int(got.sentence[i])
+				S = oracle.sim_bf16(Xb[off[s]:off[s + 1]], Qb)
+				for j in range(len_t):
+					m = int(got.mapping[i, j])
+					if m >= 0:
+						assert abs(got.edge_sim[i, j] - S[m, j]) < 2e-6
+	Qb = qs[0]
+	for flags in ((True, True, True), (True, False, True), (True, False, False)):
+		ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=corpus["sent_off"], X=Xb, Q=Qb, algorithm=oracle.ALG_RWMD, rwmd=flags, max_matches=12)
+		got = c.query(Qb, q_normalize=False, algorithm=hip.VK_ALG_RWMD, rwmd=flags, max_matches=12).trimmed()
+		assert_same_results(got, ref, check_mapping=False, score_tol=2e-5, tie_tol=2e-5)
+	c.close()
+
+
+def test_wide_query_static_and_long_slices(hip, oracle):
+	corpus = synth.make_static_corpus(150, 1, 40, 700, 100, seed=8)
+	lens = np.diff(corpus["sent_off"]).copy()
+	lens[[4, 77, 149]] = (150, 70, 256)
+	off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+	corpus["sent_off"] = off
+	corpus["tok_id"] = np.random.default_rng(9).integers(0, 700, size=int(off[-1])).astype(np.int32)
+	c, Eb = hip_static_corpus(hip, corpus)
+	for s, len_t in ((4, 33), (149, 24), (20, 18)):
+		q_ids = corpus["tok_id"][off[s]:off[s] + len_t].astype(np.int32)
+		if len(q_ids) < len_t:
+			q_ids = np.concatenate((q_ids, np.random.default_rng(s).integers(0, 700, size=len_t - len(q_ids)).astype(np.int32)))
+		Qb = Eb[q_ids]
+		for loc, ms, gaps in CASES[:4]:
+			ref = oracle.find(layout=oracle.LAYOUT_STATIC, d=100, sent_off=off, tok_id=corpus["tok_id"], E=Eb, Q=Qb, q_ids=q_ids,
+				locality=loc, gap_s=gaps[0], gap_t=gaps[1], max_matches=10, min_score=ms)
+			got = c.query(Qb, q_token_ids=q_ids, q_normalize=False, locality=loc, gap_s=gaps[0], gap_t=gaps[1], max_matches=10, min_score=ms)
+			assert_same_results(got.trimmed(), ref)
+	c.close()
+
+
+def test_wide_query_limits(hip):
+	corpus = synth.make_contextual_corpus(20, 4, 20, 100, 32, norm_sigma=0.2)
+	c = hip_contextual_corpus(hip, corpus, keep_magnitudes=True)
+	Q65 = np.random.default_rng(1).standard_normal((65, 32)).astype(np.float32)
+	with pytest.raises(hip.VkError):
+		c.query(Q65, max_matches=3)
+	with pytest.raises(hip.VkError):   # exact transport stays at 16 query tokens
+		c.query(Q65[:20], algorithm=hip.VK_ALG_WRD, max_matches=3)
+	c.close()

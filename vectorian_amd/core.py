@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VECTORIAN_HIP_LIB", os.path.join(_HERE, "lib", "libvectorian_hip.so"))
 
-VK_MAX_QUERY_LEN = 16
+VK_MAX_QUERY_LEN = 64
 VK_MAX_SENT_LEN = 512
 VK_MAX_MATCHES = 1024
 

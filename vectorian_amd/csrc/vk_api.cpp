@@ -172,15 +172,15 @@ int vk_corpus_create(const vk_corpus_desc *desc, vk_corpus_t **out) {
 		if (desc->keep_magnitudes && (rc = alloc_t(c, &c->d_mag, (size_t)c->rows_total + 16))) break;
 		if (desc->layout == VK_LAYOUT_STATIC) {
 			if ((rc = alloc_t(c, &c->d_tok_id, (size_t)desc->n_tokens + 64))) break;
-			if ((rc = alloc_t(c, &c->d_table, (size_t)c->n_tiles * 16 * 16))) break;
+			if ((rc = alloc_t(c, &c->d_table, (size_t)c->n_tiles * 16 * 16 * 4))) break;   // one [V_pad x 16] table per query tile
 		}
-		if ((rc = alloc_t(c, &c->d_qtile, (size_t)c->tile_bytes))) break;
+		if ((rc = alloc_t(c, &c->d_qtile, (size_t)c->tile_bytes * 4))) break;   // up to 4 tiles of 16 query rows
 		if ((rc = alloc_t(c, &c->d_ws, kGapTable))) break;
-		if ((rc = alloc_t(c, &c->d_wt, 32))) break;
-		if ((rc = alloc_t(c, &c->d_qids, 32))) break;
+		if ((rc = alloc_t(c, &c->d_wt, 80))) break;
+		if ((rc = alloc_t(c, &c->d_qids, 80))) break;
 		if ((rc = alloc_t(c, &c->d_out_raw, VK_MAX_MATCHES))) break;
-		if ((rc = alloc_t(c, &c->d_out_sim, (size_t)VK_MAX_MATCHES * 16))) break;
-		if ((rc = alloc_t(c, &c->d_out_map, (size_t)VK_MAX_MATCHES * 16))) break;
+		if ((rc = alloc_t(c, &c->d_out_sim, (size_t)VK_MAX_MATCHES * 64))) break;
+		if ((rc = alloc_t(c, &c->d_out_map, (size_t)VK_MAX_MATCHES * 64))) break;
 	} while (0);
 	if (rc) { vk_corpus_free(c); return rc; }
 	*out = c;
@@ -400,7 +400,14 @@ static int validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_t
 	if (!c || !q || !out) return fail(VK_ERR_INVALID, "null argument");
 	if (!c->finalized) return fail(VK_ERR_STATE, "corpus not finalized");
 	if (q->len_t < 1) return fail(VK_ERR_INVALID, "empty query");
-	if (q->len_t > VK_MAX_QUERY_LEN) return fail(VK_ERR_UNSUPPORTED, "query longer than VK_MAX_QUERY_LEN (16) tokens");
+	if (q->len_t > VK_MAX_QUERY_LEN) return fail(VK_ERR_UNSUPPORTED, "query longer than VK_MAX_QUERY_LEN (64) tokens");
+	if (q->len_t > VK_FAST_QUERY_LEN) {
+		if (q->algorithm == VK_ALG_WRD || (q->algorithm == VK_ALG_RWMD && q->wmd_full))
+			return fail(VK_ERR_UNSUPPORTED, "exact transport (WRD, full WMD) is implemented for queries of at most 16 tokens");
+		const int gm = q->algorithm == VK_ALG_RWMD ? 4 : (q->gap_s.kind == VK_GAP_TABLE || q->gap_t.kind == VK_GAP_TABLE) ? 2 : 1;
+		if (vk_wide_lds_demand(c->max_len, (q->len_t + 15) / 16, gm, q->tag_weights != nullptr, q->want_flow) > 160 * 1024)
+			return fail(VK_ERR_UNSUPPORTED, "query of more than 16 tokens over slices this long exceeds the LDS of a workgroup");
+	}
 	if (!q->q_vectors) return fail(VK_ERR_INVALID, "q_vectors is null");
 	if (q->q_dtype != VK_F32 && q->q_dtype != VK_BF16) return fail(VK_ERR_INVALID, "bad q_dtype");
 	if (q->max_matches < 1 || q->max_matches > VK_MAX_MATCHES) return fail(VK_ERR_INVALID, "max_matches out of range");
@@ -452,7 +459,7 @@ static int validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_t
 // rows >= len_t zero).  Same arithmetic as oracle/vk_oracle.c vko_normalize_rows_bf16.
 static void pack_query(const vk_corpus *c, const vk_query_desc *q, std::vector<uint8_t> &tile, float *mags) {
 	const int d = c->desc.d;
-	tile.assign((size_t)c->tile_bytes, 0);
+	tile.assign((size_t)c->tile_bytes * (size_t)((q->len_t + 15) / 16), 0);   // tile i / 16 holds row i % 16
 	std::vector<float> row((size_t)d);
 	for (int i = 0; i < q->len_t; i++) {
 		for (int k = 0; k < d; k++)
@@ -473,7 +480,7 @@ static void pack_query(const vk_corpus *c, const vk_query_desc *q, std::vector<u
 		for (int k = 0; k < d; k++) {
 			const uint16_t b = f32_to_bf16(row[(size_t)k]);
 			const int t = k >> 5, g = (k & 31) >> 3, j = k & 7;
-			const size_t off = (size_t)t * 1024 + (size_t)(g * 16 + i) * 16 + (size_t)j * 2;
+			const size_t off = (size_t)(i >> 4) * c->tile_bytes + (size_t)t * 1024 + (size_t)(g * 16 + (i & 15)) * 16 + (size_t)j * 2;
 			memcpy(&tile[off], &b, 2);
 		}
 	}
@@ -495,18 +502,20 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	VK_HIP(hipEventRecord(c->ev[0], st));
 	std::vector<uint8_t> qtile;
 	float qmags[VK_MAX_QUERY_LEN] = {0};
+	const bool wide = q->len_t > VK_FAST_QUERY_LEN;
+	const int nq = (q->len_t + 15) / 16;
 	pack_query(c, q, qtile, qmags);
 	VK_HIP(hipMemcpyAsync(c->d_qtile, qtile.data(), qtile.size(), hipMemcpyHostToDevice, st));
 
 	VkScoreParams p{};
 	const int ks = q->gap_s.kind, kt = q->gap_t.kind;
-	float ws[kGapTable], wt[32];
+	float ws[kGapTable], wt[80];
 	const bool is_align = q->algorithm == VK_ALG_ALIGN;
 	if (q->algorithm == VK_ALG_WRD) {
 		p.gap_mode = 5;
 		float sum_t = 0.0f;
 		for (int j = 0; j < q->len_t; j++) sum_t += qmags[j];           // wrd.h:99-102, float sum in order
-		for (int j = 0; j < VK_MAX_QUERY_LEN; j++) p.qmass[j] = j < q->len_t ? qmags[j] / sum_t : 0.0f;
+		for (int j = 0; j < VK_FAST_QUERY_LEN; j++) p.qmass[j] = j < q->len_t ? qmags[j] / sum_t : 0.0f;
 		p.mag = c->d_mag;
 	} else if (q->algorithm == VK_ALG_RWMD) {
 		p.gap_mode = 4;
@@ -528,7 +537,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		p.gap_mode = 2;
 	}
 	for (int i = 0; i < kGapTable; i++) ws[i] = (is_align && i <= c->max_len) ? gap_cost(q->gap_s, i) : 0.0f;
-	for (int i = 0; i < 32; i++) wt[i] = is_align ? gap_cost(q->gap_t, i) : 0.0f;
+	for (int i = 0; i < 80; i++) wt[i] = (is_align && i <= q->len_t) ? gap_cost(q->gap_t, i) : 0.0f;
 	if (p.gap_mode == 2) {
 		// register-history kernel: needs w_t strictly subadditive over the query length
 		// (see dp_general_reg in vk_kernels.hip); margin far above fp32 rounding of the DP values
@@ -536,7 +545,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		for (int x = 1; x < q->len_t && sub; x++)
 			for (int y = 1; x + y <= q->len_t; y++)
 				if (!(wt[x] + wt[y] > wt[x + y] + 1e-4f)) { sub = false; break; }
-		if (sub) p.gap_mode = c->max_short_len <= 32 ? 3 : 6;
+		if (sub && !wide) p.gap_mode = c->max_short_len <= 32 ? 3 : 6;
 	}
 	VK_HIP(hipMemcpyAsync(c->d_ws, ws, sizeof ws, hipMemcpyHostToDevice, st));
 	VK_HIP(hipMemcpyAsync(c->d_wt, wt, sizeof wt, hipMemcpyHostToDevice, st));
@@ -554,12 +563,14 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	}
 
 	const bool is_static = c->desc.layout == VK_LAYOUT_STATIC;
+	const int64_t table_stride = (int64_t)c->n_tiles * 16 * 16;
 	if (is_static) {
-		int32_t ids[32];
-		for (int j = 0; j < 32; j++) ids[j] = (q->q_token_ids && j < q->len_t) ? q->q_token_ids[j] : -1;
+		int32_t ids[80];
+		for (int j = 0; j < 80; j++) ids[j] = (q->q_token_ids && j < q->len_t) ? q->q_token_ids[j] : -1;
 		VK_HIP(hipMemcpyAsync(c->d_qids, ids, sizeof ids, hipMemcpyHostToDevice, st));
-		VK_HIP(vk_launch_table(c->d_tiles, c->d_qtile, (int32_t)c->n_tiles, c->nk32, c->tail, c->tile_bytes, c->d_table,
-			q->q_token_ids ? c->d_qids : nullptr, q->len_t, c->desc.vocab_size, st));
+		for (int t = 0; t < nq; t++)   // one [V_pad x 16] table per 16 query tokens
+			VK_HIP(vk_launch_table(c->d_tiles, c->d_qtile + (size_t)t * c->tile_bytes, (int32_t)c->n_tiles, c->nk32, c->tail, c->tile_bytes,
+				c->d_table + t * table_stride, q->q_token_ids ? c->d_qids + t * 16 : nullptr, std::min(16, q->len_t - t * 16), c->desc.vocab_size, st));
 	}
 
 	// ---- the fused scoring kernel ------------------------------------------
@@ -574,16 +585,33 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	p.ref_total = (float)q->len_t;
 	if (q->tag_weights && is_align) {
 		float total = 0.0f;
-		for (int j = 0; j < VK_MAX_QUERY_LEN; j++) {
+		for (int j = 0; j < q->len_t; j++) total += q->tag_weights[j];
+		for (int j = 0; j < VK_FAST_QUERY_LEN; j++) {
 			p.tw[j] = j < q->len_t ? q->tag_weights[j] : 0.0f;
 			p.tpos[j] = j < q->len_t ? (int32_t)q->q_pos[j] : -1;
-			if (j < q->len_t) total += q->tag_weights[j];
 		}
 		p.pos_s = c->d_pos;
 		p.tw_keep = 1.0f - q->pos_mismatch_penalty;
 		p.tw_threshold = q->similarity_threshold;
 		p.ref_total = total;   // reference_score with max_similarity_for_t = t_pos_weights (slice/static.h:280-286)
 	}
+	VkWideParams wp{};
+	if (wide) {
+		wp.tiles = c->d_tiles; wp.tok_id = c->d_tok_id; wp.table = c->d_table; wp.table_stride = table_stride;
+		wp.sent_start = c->d_sent_start; wp.sent_end = c->d_sent_end; wp.n_sent = (int32_t)n; wp.layout = p.layout;
+		wp.nk32 = c->nk32; wp.tail = c->tail; wp.tile_bytes = c->tile_bytes;
+		wp.qtile = c->d_qtile; wp.nq = nq; wp.len_t = q->len_t; wp.locality = q->locality; wp.gap_mode = p.gap_mode; wp.max_len = c->max_len;
+		wp.rwmd_symmetric = p.rwmd_symmetric; wp.rwmd_normalize_bow = p.rwmd_normalize_bow;
+		wp.gs = p.gs; wp.gt = p.gt; wp.a_s = p.a_s; wp.a_t = p.a_t; wp.open_s = p.open_s; wp.open_t = p.open_t;
+		wp.ws = c->d_ws; wp.wt = c->d_wt;
+		wp.pos_s = p.pos_s; wp.tw_keep = p.tw_keep; wp.tw_threshold = p.tw_threshold; wp.ref_total = p.ref_total;
+		for (int j = 0; j < VK_MAX_QUERY_LEN; j++) {
+			wp.tw[j] = (p.pos_s && j < q->len_t) ? q->tag_weights[j] : 0.0f;
+			wp.tpos[j] = (p.pos_s && j < q->len_t) ? (int32_t)q->q_pos[j] : -1;
+		}
+		wp.boost = p.boost; wp.scores = c->d_scores; wp.raw = c->d_raw;
+		VK_HIP(vk_launch_wide(&wp, 0, st));
+	} else {
 	p.max_short_len = VK_FAST_SENT_LEN;
 	p.s_rows_per_wave = is_static ? (c->max_group_tokens + 15) / 16 * 16 : c->max_group_tiles * 16;
 	p.h_rows = c->max_short_len + 1;
@@ -611,6 +639,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		const size_t smem_l = (size_t)lf * 4 + qlds;
 		if (smem_l > 160 * 1024) return fail(VK_ERR_UNSUPPORTED, "LDS demand of the long-slice pass exceeds 160 KiB");
 		VK_HIP(vk_launch_score(&pl, c->n_long_groups, smem_l, st));
+	}
 	}
 
 	const bool exact_transport = q->algorithm == VK_ALG_WRD || (q->algorithm == VK_ALG_RWMD && q->wmd_full);
@@ -716,7 +745,11 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	// ---- flow of the winners ------------------------------------------------
 	VK_HIP(hipEventRecord(c->ev[3], st));
 	const bool do_flow = q->want_flow && is_align;
-	if (do_flow) {
+	const int ostride = wide ? 64 : 16;   // row stride of the mapping / edge_sim device arrays
+	if (do_flow && wide) {
+		wp.keys = c->d_keys[cur]; wp.raw_out = c->d_out_raw; wp.mapping = c->d_out_map; wp.edge_sim = c->d_out_sim;
+		VK_HIP(vk_launch_wide(&wp, k, st));
+	} else if (do_flow) {
 		VkFlowParams f{};
 		f.tiles = c->d_tiles; f.tok_id = c->d_tok_id; f.table = c->d_table; f.sent_start = c->d_sent_start; f.sent_end = c->d_sent_end;
 		f.layout = p.layout; f.nk32 = c->nk32; f.tail = c->tail; f.tile_bytes = c->tile_bytes;
@@ -734,13 +767,13 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 
 	// ---- results to host ------------------------------------------------------
 	std::vector<uint64_t> keys((size_t)k);
-	std::vector<float> raw((size_t)k), sim((size_t)k * 16);
-	std::vector<int16_t> map((size_t)k * 16);
+	std::vector<float> raw((size_t)k), sim((size_t)k * ostride);
+	std::vector<int16_t> map((size_t)k * ostride);
 	VK_HIP(hipMemcpyAsync(keys.data(), c->d_keys[cur], (size_t)k * 8, hipMemcpyDeviceToHost, st));
 	if (do_flow) {
 		VK_HIP(hipMemcpyAsync(raw.data(), c->d_out_raw, (size_t)k * 4, hipMemcpyDeviceToHost, st));
-		VK_HIP(hipMemcpyAsync(map.data(), c->d_out_map, (size_t)k * 32, hipMemcpyDeviceToHost, st));
-		VK_HIP(hipMemcpyAsync(sim.data(), c->d_out_sim, (size_t)k * 64, hipMemcpyDeviceToHost, st));
+		VK_HIP(hipMemcpyAsync(map.data(), c->d_out_map, map.size() * 2, hipMemcpyDeviceToHost, st));
+		VK_HIP(hipMemcpyAsync(sim.data(), c->d_out_sim, sim.size() * 4, hipMemcpyDeviceToHost, st));
 	}
 	VK_HIP(hipStreamSynchronize(st));
 
@@ -769,8 +802,8 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		if (out->raw_score) out->raw_score[i] = do_flow ? raw[(size_t)i] : raw_sel[(size_t)i];
 		if (do_flow) {
 			for (int j = 0; j < q->len_t; j++) {
-				out->mapping[(size_t)i * q->len_t + j] = map[(size_t)i * 16 + j];
-				out->edge_sim[(size_t)i * q->len_t + j] = sim[(size_t)i * 16 + j];
+				out->mapping[(size_t)i * q->len_t + j] = map[(size_t)i * ostride + j];
+				out->edge_sim[(size_t)i * q->len_t + j] = sim[(size_t)i * ostride + j];
 			}
 		} else if (q->want_flow && out->mapping && out->edge_sim) {
 			// transport flows of the winners (SparseFlow / DenseFlow) are not produced yet
@@ -803,7 +836,7 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 		((c->nk32 == 10 && c->tail == 1) || (c->nk32 == 4 && c->tail == 0));
 	for (int i = 0; i < n_queries && gemm; i++) {
 		const vk_query_desc &q = qs[i];
-		gemm = q.algorithm == VK_ALG_RWMD && q.rwmd_injective && !q.wmd_full && q.rwmd_symmetric == qs[0].rwmd_symmetric &&
+		gemm = q.len_t <= VK_FAST_QUERY_LEN && q.algorithm == VK_ALG_RWMD && q.rwmd_injective && !q.wmd_full && q.rwmd_symmetric == qs[0].rwmd_symmetric &&
 			q.rwmd_normalize_bow == qs[0].rwmd_normalize_bow && q.max_matches == qs[0].max_matches &&
 			q.min_score == qs[0].min_score && q.boost == qs[0].boost && !q.tag_weights;
 	}

@@ -16,7 +16,8 @@
 
 #define VK_DEV_MAX_SENT_LEN 64        // fused fast path: 4 slices per wave
 #define VK_DEV_MAX_LONG_LEN 512       // longer slices: one per wave, second launch
-#define VK_DEV_MAX_QUERY_LEN 16
+#define VK_DEV_MAX_QUERY_LEN 16        // fused kernels: one 16-column block
+#define VK_DEV_MAX_WIDE_QUERY_LEN 64   // vk_wide_kernel: lane = query column
 
 struct VkScoreParams {
 	// corpus
@@ -124,9 +125,45 @@ struct VkFlowParams {
 	float *edge_sim;           // [k x 16]
 };
 
+// queries of 17 .. 64 tokens (vk_wide_kernel): one wave per slice
+struct VkWideParams {
+	const uint8_t *tiles;
+	const int32_t *tok_id;
+	const float *table;        // static: nq tables [V_pad x 16], table_stride floats apart
+	int64_t table_stride;
+	const int32_t *sent_start;
+	const int32_t *sent_end;
+	int32_t n_sent;
+	int32_t layout;
+	int32_t nk32, tail, tile_bytes;
+	const uint8_t *qtile;      // nq query tiles of 16 rows, tile_bytes apart
+	int32_t nq, len_t;
+	int32_t locality;
+	int32_t gap_mode;          // 0 linear, 1 affine, 2 general, 4 RWMD
+	int32_t max_len;
+	int32_t rwmd_symmetric, rwmd_normalize_bow;
+	float gs, gt, a_s, a_t, open_s, open_t;
+	const float *ws;
+	const float *wt;           // [65]
+	const int8_t *pos_s;
+	float tw[VK_DEV_MAX_WIDE_QUERY_LEN];
+	int32_t tpos[VK_DEV_MAX_WIDE_QUERY_LEN];
+	float tw_keep, tw_threshold;
+	float ref_total;
+	const float *boost;
+	float *scores;
+	float *raw;
+	const uint64_t *keys;      // FLOW: winners
+	float *raw_out;            // [k]
+	int16_t *mapping;          // [k x 64]
+	float *edge_sim;           // [k x 64]
+};
+
 #ifdef __cplusplus
 extern "C" {
 #endif
+hipError_t vk_launch_wide(const VkWideParams *p, int32_t flow_k, hipStream_t stream);
+size_t vk_wide_lds_demand(int32_t max_len, int32_t nq, int32_t gap_mode, int32_t tagged, int32_t flow);
 hipError_t vk_launch_pack(const void *in, int32_t dtype_bf16, int64_t n_rows, int32_t d, int32_t d_pad, int64_t row0,
 	uint8_t *tiles, float *mag_out, int32_t normalize, hipStream_t stream);
 hipError_t vk_launch_table(const uint8_t *etiles, const uint8_t *qtile, int32_t n_tiles, int32_t nk32, int32_t tail,

@@ -1494,6 +1494,273 @@ __global__ __launch_bounds__(64) void vk_flow_kernel(VkFlowParams p) {
 }
 
 // ---------------------------------------------------------------------------
+// Queries of 17 .. 64 tokens: one wave per slice, lane = query column (the fill of vk_flow_kernel
+// widened to the whole wave).  SCORE mode walks all slices and writes Score::value / raw like
+// vk_score_kernel; FLOW mode retraces the k winners.  The similarity rows are produced 16 tokens at
+// a time (one MFMA tile per 16 query rows) into a small LDS strip and consumed by the row-serial DP
+// at once, so LDS holds only the column history (general gaps) and, in FLOW mode, the traceback.
+// Candidate order, strict-greater replacement and start-cell rule: as vk_flow_kernel / the oracle.
+// Roughly 10 us of issue time per (32-token slice, 32-token query): a fallback that keeps long
+// queries on the device, not a roofline kernel.
+// ---------------------------------------------------------------------------
+
+static inline size_t vk_wide_lds_bytes(int max_len, int nq, int gap_mode, bool tagged, bool flow) {
+	const size_t LQ = (size_t)nq * 16, W = LQ + 1, rows = (size_t)max_len + 1;
+	size_t fl = 16 * LQ * (tagged ? 2 : 1);            // Sx (+ SWx)
+	fl += (rows + 3) / 4 * 4 + LQ + 4;                 // wsl, wtl
+	fl += 64 + 64;                                     // twl, tposl
+	if (gap_mode == 2) fl += rows * W;                 // H
+	size_t b = fl * 4;
+	if (flow) b += 64 * 2 + rows * W * 2 + rows * W;   // mapl, dk, flags
+	return (b + 15) / 16 * 16;
+}
+
+__device__ __forceinline__ float wave_min64(float m) {
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
+	return m;
+}
+
+template <bool FLOW>
+__global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
+	extern __shared__ float4 vk_smem4[];
+	const int lane = threadIdx.x;
+	const int LQ = p.nq * 16, W = LQ + 1, rows = p.max_len + 1;
+	float *Sx = reinterpret_cast<float *>(vk_smem4);       // [16][LQ] similarities of the current 16 tokens
+	float *SWx = p.pos_s ? Sx + 16 * LQ : Sx;              // tag-weighted copy the DP runs on
+	float *wsl = SWx + 16 * LQ;
+	float *wtl = wsl + (rows + 3) / 4 * 4;
+	float *twl = wtl + LQ + 4;
+	int *tposl = reinterpret_cast<int *>(twl + 64);
+	float *H = reinterpret_cast<float *>(tposl + 64);      // general gaps: H[u][v], row stride W
+	float *after = p.gap_mode == 2 ? H + rows * W : H;
+	int16_t *mapl = reinterpret_cast<int16_t *>(after);    // FLOW: mapping of the winner
+	int16_t *dk = mapl + 64;
+	uint8_t *flags = reinterpret_cast<uint8_t *>(dk + rows * W);
+
+	for (int i = lane; i <= p.max_len; i += 64) wsl[i] = p.ws[i];
+	if (lane <= LQ) wtl[lane] = p.wt[lane];
+	if (lane == 0) wtl[LQ] = p.wt[LQ <= 64 ? LQ : 64];
+	twl[lane] = p.tw[lane]; tposl[lane] = p.tpos[lane];
+	wave_lds_fence();
+
+	const int len_t = p.len_t;
+	const int v = lane + 1;
+	const bool col = v <= len_t;
+	const bool local = p.locality == VK_DEV_LOCAL, global = p.locality == VK_DEV_GLOBAL;
+	const int gap = p.gap_mode;
+	const float gs = p.gs, gt = p.gt, open_s = p.open_s, open_t = p.open_t, a_s = p.a_s, a_t = p.a_t;
+	const bool is_static = p.layout == VK_DEV_LAYOUT_STATIC;
+
+	const int64_t n_items = FLOW ? (int64_t)gridDim.x : (int64_t)p.n_sent;
+	for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+		int64_t g = item;
+		if (FLOW) {
+			const uint64_t key = p.keys[item];
+			if (key == 0) return;   // fewer than k admitted
+			g = (int64_t)(uint32_t)(key & 0xffffffffu);
+		}
+		const int t_a = p.sent_start[g], t_b = p.sent_end[g];
+		const int len_s = t_b - t_a;
+		if (len_s < 1) {
+			if (!FLOW && lane == 0) { p.scores[g] = VK_NEG_INF; p.raw[g] = VK_NEG_INF; }
+			continue;
+		}
+		// similarities of tokens base .. base + 15 (contextual: one tile, 16-aligned; static: gather)
+		auto fill = [&](int base) {
+			if (is_static) {
+				for (int r = 0; r < 16; r++) {
+					const int tok = base + r;
+					if (tok < t_b && lane < LQ) {
+						const int id = p.tok_id[tok];
+						const float sv = p.table[(int64_t)(lane >> 4) * p.table_stride + (int64_t)id * 16 + (lane & 15)];
+						Sx[r * LQ + lane] = sv;
+						if (p.pos_s) SWx[r * LQ + lane] = tag_weighted(sv, twl[lane], p.pos_s[tok], tposl[lane], p.tw_keep, p.tw_threshold);
+					}
+				}
+			} else {
+				const uint8_t *tp = p.tiles + (int64_t)(base >> 4) * p.tile_bytes;
+				for (int qt = 0; qt < p.nq; qt++) {
+					f32x4 acc = sim_tile_generic(p.qtile + (int64_t)qt * p.tile_bytes, tp, p.nk32, p.tail, lane);
+					const int c0 = qt * 16 + (lane >> 4) * 4;
+					*reinterpret_cast<f32x4 *>(Sx + (lane & 15) * LQ + c0) = acc;
+					if (p.pos_s) {
+						const int ps = p.pos_s[base + (lane & 15)];
+#pragma unroll
+						for (int r = 0; r < 4; r++) acc[r] = tag_weighted(acc[r], twl[c0 + r], ps, tposl[c0 + r], p.tw_keep, p.tw_threshold);
+						*reinterpret_cast<f32x4 *>(SWx + (lane & 15) * LQ + c0) = acc;
+					}
+				}
+			}
+		};
+		const int base0 = is_static ? t_a : (t_a >> 4) * 16;
+
+		float raw;
+		int u_start = 0, v_start = 0;
+		if (gap == 4) {
+			// ---- relaxed word mover's distance (rwmd_rows of vk_score_kernel over <= 64 columns)
+			const bool nbow = p.rwmd_normalize_bow != 0;
+			const float w_t = nbow ? 1.0f / (float)len_t : 1.0f, w_s = nbow ? 1.0f / (float)len_s : 1.0f;
+			float colmin = 3.402823466e+38F, acc1 = 0.0f;
+			for (int base = base0; base < t_b; base += 16) {
+				fill(base);
+				wave_lds_fence();
+				const int r0 = t_a > base ? t_a - base : 0, r1 = t_b - base < 16 ? t_b - base : 16;
+				for (int r = r0; r < r1; r++) {
+					const float dist = fmaxf(1.0f - Sx[r * LQ + (col ? v - 1 : 0)], 0.0f);
+					colmin = fminf(colmin, dist);
+					acc1 += w_s * wave_min64(col ? dist : 3.402823466e+38F);
+				}
+				wave_lds_fence();
+			}
+			const float x = col ? w_t * colmin : 0.0f;
+			float acc0 = 0.0f;
+			for (int j = 0; j < len_t; j++) {
+				const float xj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), j));
+				acc0 = j == 0 ? xj : acc0 + xj;
+			}
+			if (!nbow) { acc0 = acc0 / (float)len_t; acc1 = acc1 / (float)len_s; }
+			float cost = 0.0f;
+			if (p.rwmd_symmetric) { if (acc0 > cost) cost = acc0; if (acc1 > cost) cost = acc1; }
+			else cost = acc0;
+			const float max_cost = nbow ? 1.0f : (float)len_t;
+			raw = (max_cost - cost) / max_cost;
+		} else {
+			// ---- alignment: fill, lane = column
+			float hprev = 0.0f, eprev = VK_NEG_INF;
+			if (global && col) hprev = gap == 0 ? -(gt * (float)v) : gap == 1 ? -(a_t + gt * (float)v) : -wtl[v];
+			if (gap == 2 && col) H[v] = hprev;
+			float bv = 0.0f;
+			int bu = 0, u = 0;
+			for (int base = base0; base < t_b; base += 16) {
+				fill(base);
+				wave_lds_fence();
+				const int r0 = t_a > base ? t_a - base : 0, r1 = t_b - base < 16 ? t_b - base : 16;
+				for (int r = r0; r < r1; r++) {
+					u++;
+					float bprev = 0.0f, bcur = 0.0f;
+					if (global) {
+						bprev = u == 1 ? 0.0f : (gap == 0 ? -(gs * (float)(u - 1)) : gap == 1 ? -(a_s + gs * (float)(u - 1)) : -wsl[u - 1]);
+						bcur = gap == 0 ? -(gs * (float)u) : gap == 1 ? -(a_s + gs * (float)u) : -wsl[u];
+					}
+					const float sv = SWx[r * LQ + (col ? v - 1 : 0)];
+					const float up = __shfl_up(hprev, 1, 64);
+					const float diag = lane == 0 ? bprev : up;
+					float best, e = VK_NEG_INF;
+					uint8_t d, ee = 0, fe = 0;
+					int16_t kk = 0;
+					float c = diag + sv;
+					if (local) { best = 0.0f; d = 0; if (c > best) { best = c; d = 1; } }
+					else { best = c; d = 1; }
+					if (gap == 0) {
+						c = hprev - gs;
+						if (c > best) { best = c; d = 2; kk = 1; }
+					} else if (gap == 1) {
+						e = hprev - open_s;
+						c = eprev - gs;
+						if (c > e) { e = c; ee = 1; }
+						if (e > best) { best = e; d = 2; }
+					} else {
+						for (int k = 1; k <= u; k++) {
+							c = H[(u - k) * W + (col ? v : 1)] - wsl[k];
+							if (c > best) { best = c; d = 2; kk = (int16_t)k; }
+						}
+					}
+					// in-row candidates: columns become final left to right
+					float left_best = VK_NEG_INF, f = VK_NEG_INF, fin = best, ffin = VK_NEG_INF;
+					int16_t left_k = 0;
+					for (int pp = 0; pp < len_t; pp++) {
+						const float sp = pp == 0 ? bcur : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fin), pp - 1));
+						const float fp = pp == 0 ? VK_NEG_INF : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ffin), pp - 1));
+						if (gap == 2) {
+							if (col && v > pp) {
+								const float cc = sp - wtl[v - pp];
+								if (cc >= left_best) { left_best = cc; left_k = (int16_t)(v - pp); }
+							}
+						} else if (v == pp + 1) {
+							if (gap == 0) { left_best = sp - gt; left_k = 1; }
+							else {
+								f = sp - open_t;
+								const float c2 = fp - gt;
+								if (c2 > f) { f = c2; fe = 1; }
+							}
+						}
+						if (v == pp + 1) {
+							if (gap == 1) { if (f > best) { best = f; d = 3; } ffin = f; }
+							else if (left_best > best) { best = left_best; d = 3; kk = left_k; }
+							fin = best;
+						}
+					}
+					if (col) {
+						if (gap == 2) H[u * W + v] = best;
+						if (FLOW) {
+							dk[u * W + v] = kk;
+							flags[u * W + v] = (uint8_t)(d | (ee << 2) | (fe << 3));
+						}
+						// start cell: first maximum in row-major order; per column the first row wins (strict >)
+						if (!global && (local || u == len_s || v == len_t) && best > bv) { bv = best; bu = u; }
+					}
+					hprev = best;
+					eprev = e;
+				}
+				wave_lds_fence();
+			}
+			if (global) {
+				raw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hprev), len_t - 1));
+				u_start = len_s; v_start = len_t;
+			} else {
+				raw = 0.0f;
+				for (int j = 0; j < len_t; j++) {
+					const float vj = __shfl(bv, j, 64);
+					const int uj = __shfl(bu, j, 64);
+					if (vj > raw || (vj == raw && vj > 0.0f && uj < u_start)) { raw = vj; u_start = uj; v_start = j + 1; }
+				}
+			}
+		}
+
+		if (!FLOW) {
+			if (lane == 0) {
+				const float boost = p.boost ? p.boost[g] : 1.0f;
+				p.scores[g] = (raw / p.ref_total) * boost;
+				p.raw[g] = raw;
+			}
+			continue;
+		}
+		// ---- FLOW: traceback by lane 0, then the edge similarities from a second sweep over the tiles
+		mapl[lane] = -1;
+		wave_lds_fence();
+		if (lane == 0 && gap != 4) {
+			int u = u_start, v2 = v_start, state = 0;
+			while (u > 0 && v2 > 0) {
+				const int idx = u * W + v2;
+				const uint8_t fl = flags[idx];
+				if (gap == 1 && state == 1) { if (!(fl & 4)) state = 0; u--; continue; }
+				if (gap == 1 && state == 2) { if (!(fl & 8)) state = 0; v2--; continue; }
+				const uint8_t d = fl & 3;
+				if (d == 0) break;
+				if (d == 1) { mapl[v2 - 1] = (int16_t)(u - 1); u--; v2--; }
+				else if (gap == 1) state = (d == 2) ? 1 : 2;
+				else if (d == 2) u -= dk[idx];
+				else v2 -= dk[idx];
+			}
+		}
+		wave_lds_fence();
+		const int mine = mapl[lane];
+		float es = 0.0f;
+		for (int base = base0; base < t_b; base += 16) {
+			fill(base);
+			wave_lds_fence();
+			const int row = t_a + mine - base;
+			if (mine >= 0 && row >= 0 && row < 16) es = Sx[row * LQ + lane];
+			wave_lds_fence();
+		}
+		p.mapping[item * 64 + lane] = (int16_t)mine;
+		p.edge_sim[item * 64 + lane] = es;
+		if (lane == 0) p.raw_out[item] = raw;
+	}
+}
+
+// ---------------------------------------------------------------------------
 // Word Rotator's Distance, stage 2: exact EMD for the candidate sentences.
 // One wave per candidate recomputes the similarity rows (same MFMA sequence as the scoring
 // kernel); lane 0 then runs successive shortest paths with potentials on the bipartite
@@ -1827,6 +2094,33 @@ extern "C" hipError_t vk_launch_topk_wave_batch(const float *scores, const uint6
 	else vk_topk_wave_batch_kernel<0><<<grid, 256, 0, stream>>>(scores, nullptr, n, min_score, k, per_wave, in_stride, out_stride, out);
 	*n_waves_out = nw;
 	return hipGetLastError();
+}
+
+extern "C" hipError_t vk_launch_wide(const VkWideParams *p, int32_t flow_k, hipStream_t stream) {
+	const bool flow = flow_k > 0;
+	const size_t smem = vk_wide_lds_bytes(p->max_len, p->nq, p->gap_mode, p->pos_s != nullptr, flow);
+	if (smem > 160 * 1024) return hipErrorInvalidValue;
+	const void *fn = flow ? reinterpret_cast<const void *>(vk_wide_kernel<true>) : reinterpret_cast<const void *>(vk_wide_kernel<false>);
+	if (smem > 64 * 1024) {
+		hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+		if (e != hipSuccess) return e;
+	}
+	if (flow) {
+		vk_wide_kernel<true><<<flow_k, 64, smem, stream>>>(*p);
+	} else {
+		int occ = 0, dev = 0, cus = 256;
+		hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vk_wide_kernel<false>, 64, smem);
+		if (e != hipSuccess) return e;
+		if (occ < 1) occ = 1;
+		if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+		const int64_t want = p->n_sent, cap = (int64_t)cus * occ;
+		vk_wide_kernel<false><<<(int)(want < cap ? want : cap), 64, smem, stream>>>(*p);
+	}
+	return hipGetLastError();
+}
+
+extern "C" size_t vk_wide_lds_demand(int32_t max_len, int32_t nq, int32_t gap_mode, int32_t tagged, int32_t flow) {
+	return vk_wide_lds_bytes(max_len, nq, gap_mode, tagged != 0, flow != 0);
 }
 
 extern "C" hipError_t vk_launch_flow(const VkFlowParams *p, int32_t k, hipStream_t stream) {

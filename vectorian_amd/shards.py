@@ -12,7 +12,11 @@ import numpy as np
 
 from vectorian_amd import core
 
-_REC_WORDS = 44   # valid, score, raw, sentence(2), mapping i16[16] (8), edge_sim f32[16] (16), pad
+def _layout(len_t):
+	"""int32 words of one record: valid, score, raw, sentence(2), mapping i16[w] (w/2), edge_sim f32[w] (w), padded
+	to a multiple of 4 words; w = query length rounded up to 16 (32 words for queries of at most 16 tokens)."""
+	w = (max(1, len_t) + 15) // 16 * 16
+	return w, (5 + w // 2 + w + 3) // 4 * 4
 
 
 def shard_ranges(n_sentences, world):
@@ -27,23 +31,25 @@ def shard_ranges(n_sentences, world):
 
 
 def pack_topk(top, sentence_offset, k):
-	buf = np.zeros((k, _REC_WORDS), dtype=np.int32)
+	w, words = _layout(top.len_t)
+	buf = np.zeros((k, words), dtype=np.int32)
 	n = top.n
 	buf[:n, 0] = 1
 	buf[:n, 1] = top.score[:n].view(np.int32)
 	buf[:n, 2] = top.raw_score[:n].view(np.int32)
 	buf[:n, 3:5] = (top.sentence[:n] + sentence_offset).astype(np.int64).view(np.int32).reshape(n, 2)
-	m = np.full((n, 16), -1, dtype=np.int16)
+	m = np.full((n, w), -1, dtype=np.int16)
 	m[:, :top.len_t] = top.mapping[:n]
-	buf[:n, 5:13] = m.view(np.int32)
-	e = np.zeros((n, 16), dtype=np.float32)
+	buf[:n, 5:5 + w // 2] = m.view(np.int32)
+	e = np.zeros((n, w), dtype=np.float32)
 	e[:, :top.len_t] = top.edge_sim[:n]
-	buf[:n, 13:29] = e.view(np.int32)
+	buf[:n, 5 + w // 2:5 + w // 2 + w] = e.view(np.int32)
 	return buf
 
 
 def unpack_topk(buf, len_t):
 	k = buf.shape[0]
+	w, _ = _layout(len_t)
 	t = core.TopK(k, len_t)
 	n = int(buf[:, 0].sum())
 	t.n = n
@@ -51,8 +57,8 @@ def unpack_topk(buf, len_t):
 	t.score[:n] = np.ascontiguousarray(b[:, 1]).view(np.float32)
 	t.raw_score[:n] = np.ascontiguousarray(b[:, 2]).view(np.float32)
 	t.sentence[:n] = np.ascontiguousarray(b[:, 3:5]).view(np.int64).reshape(n)
-	t.mapping[:n] = np.ascontiguousarray(b[:, 5:13]).view(np.int16).reshape(n, 16)[:, :len_t]
-	t.edge_sim[:n] = np.ascontiguousarray(b[:, 13:29]).view(np.float32).reshape(n, 16)[:, :len_t]
+	t.mapping[:n] = np.ascontiguousarray(b[:, 5:5 + w // 2]).view(np.int16).reshape(n, w)[:, :len_t]
+	t.edge_sim[:n] = np.ascontiguousarray(b[:, 5 + w // 2:5 + w // 2 + w]).view(np.float32).reshape(n, w)[:, :len_t]
 	return t
 
 
