@@ -83,7 +83,7 @@ def test_all_scores_and_boost(hip, oracle):
 def test_errors_are_loud(hip):
 	corpus = synth.make_contextual_corpus(10, 4, 8, 100, 32)
 	c = hip_contextual_corpus(hip, corpus)
-	q = np.ones((17, 32), dtype=np.float32)
+	q = np.ones((65, 32), dtype=np.float32)
 	with pytest.raises(hip.VkError):
 		c.query(q)
 	with pytest.raises(hip.VkError):
