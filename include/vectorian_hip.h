@@ -97,7 +97,7 @@ typedef struct {
 	int32_t locality;        /* vk_locality (alignment only) */
 	vk_gap gap_s;            /* cost of skipping document tokens */
 	vk_gap gap_t;            /* cost of skipping query tokens   */
-	float submatch_weight;   /* query.cpp:77-79; only 0 is implemented */
+	float submatch_weight;   /* query.cpp:77-79, metric/alignment.h:84-106; >= 0 */
 	int32_t bidirectional;   /* query.cpp:81-83 (parsed, unused upstream); must be 0 */
 	int32_t max_matches;     /* query.cpp:87-89 */
 	float min_score;         /* query.cpp:91-93; admission is score > min_score (metric/alignment.h:284) */

@@ -413,7 +413,7 @@ static int validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_t
 	if (q->max_matches < 1 || q->max_matches > VK_MAX_MATCHES) return fail(VK_ERR_INVALID, "max_matches out of range");
 	if (out->capacity < q->max_matches) return fail(VK_ERR_INVALID, "output capacity smaller than max_matches");
 	if (!out->score || !out->sentence) return fail(VK_ERR_INVALID, "output arrays missing");
-	if (q->submatch_weight != 0.0f) return fail(VK_ERR_UNSUPPORTED, "submatch_weight != 0 is not implemented on the HIP path");
+	if (!(q->submatch_weight >= 0.0f)) return fail(VK_ERR_INVALID, "submatch_weight must be >= 0 (pow of a zero base, metric/alignment.h:97-99)");
 	if (q->bidirectional) return fail(VK_ERR_UNSUPPORTED, "bidirectional is not implemented (unused upstream, query.cpp:81-83)");
 	if (q->algorithm == VK_ALG_ALIGN) {
 		if (q->locality < VK_LOCAL || q->locality > VK_SEMIGLOBAL) return fail(VK_ERR_INVALID, "bad locality");
@@ -719,6 +719,113 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		return VK_OK;
 	}
 
+	// ---- flow (traceback) of `count` slices named by device keys: narrow or wide kernel
+	const int ostride = wide ? 64 : 16;   // row stride of the mapping / edge_sim device arrays
+	auto launch_flow = [&](const uint64_t *d_keys, int count) -> int {
+		if (wide) {
+			wp.keys = d_keys; wp.raw_out = c->d_out_raw; wp.mapping = c->d_out_map; wp.edge_sim = c->d_out_sim;
+			VK_HIP(vk_launch_wide(&wp, count, st));
+			return VK_OK;
+		}
+		VkFlowParams f{};
+		f.tiles = c->d_tiles; f.tok_id = c->d_tok_id; f.table = c->d_table; f.sent_start = c->d_sent_start; f.sent_end = c->d_sent_end;
+		f.layout = p.layout; f.nk32 = c->nk32; f.tail = c->tail; f.tile_bytes = c->tile_bytes;
+		f.qtile = c->d_qtile; f.len_t = q->len_t; f.locality = q->locality; f.gap_mode = (p.gap_mode == 3 || p.gap_mode == 6) ? 2 : p.gap_mode;
+		f.max_len = c->max_len;
+		f.gs = p.gs; f.gt = p.gt; f.a_s = p.a_s; f.a_t = p.a_t; f.open_s = p.open_s; f.open_t = p.open_t;
+		f.ws = c->d_ws; f.wt = c->d_wt;
+		f.pos_s = p.pos_s; f.tw_keep = p.tw_keep; f.tw_threshold = p.tw_threshold;
+		memcpy(f.tw, p.tw, sizeof f.tw);
+		memcpy(f.tpos, p.tpos, sizeof f.tpos);
+		f.keys = d_keys; f.raw_out = c->d_out_raw; f.mapping = c->d_out_map; f.edge_sim = c->d_out_sim;
+		VK_HIP(vk_launch_flow(&f, count, st));
+		return VK_OK;
+	};
+
+	if (is_align && q->submatch_weight != 0.0f) {
+		// ---- submatch_weight: bound from raw, then exact scores of the candidates from their tracebacks, until the
+		// k-th best exact score is above every remaining bound (vk_submatch_bound_kernel)
+		VK_HIP(hipEventRecord(c->ev[2], st));
+		const float wsub = q->submatch_weight, total = p.ref_total;
+		const float m_star = total * (1.0f - powf(1.0f / (wsub + 1.0f), 1.0f / wsub));
+		VK_HIP(vk_launch_submatch_bound(c->d_raw, p.boost, n, total, wsub, m_star, c->d_scores, st));
+		const int M = 512;
+		struct Cand { float val, raw; int64_t row; std::vector<int16_t> map; std::vector<float> sim; };
+		std::vector<Cand> best;
+		std::vector<uint64_t> keys((size_t)M);
+		std::vector<float> raws((size_t)M), sims((size_t)M * ostride);
+		std::vector<int16_t> maps((size_t)M * ostride);
+		for (;;) {
+			int nb = 0, cur = 0;
+			VK_HIP(vk_launch_topk_scores(c->d_scores, n, q->min_score, M, c->d_keys[0], &nb, st));
+			while (nb > 1) {
+				const int64_t nkeys = (int64_t)nb * M;
+				VK_HIP(vk_launch_topk_keys(c->d_keys[cur], nkeys, M, c->d_keys[1 - cur], &nb, st));
+				cur = 1 - cur;
+			}
+			if ((rc = launch_flow(c->d_keys[cur], M))) return rc;
+			VK_HIP(vk_launch_mark(c->d_keys[cur], M, c->d_scores, st));
+			VK_HIP(hipMemcpyAsync(keys.data(), c->d_keys[cur], (size_t)M * 8, hipMemcpyDeviceToHost, st));
+			VK_HIP(hipMemcpyAsync(raws.data(), c->d_out_raw, (size_t)M * 4, hipMemcpyDeviceToHost, st));
+			VK_HIP(hipMemcpyAsync(maps.data(), c->d_out_map, maps.size() * 2, hipMemcpyDeviceToHost, st));
+			VK_HIP(hipMemcpyAsync(sims.data(), c->d_out_sim, sims.size() * 4, hipMemcpyDeviceToHost, st));
+			VK_HIP(hipStreamSynchronize(st));
+			int n_cand = 0;
+			float ub_last = INFINITY;
+			for (int i = 0; i < M; i++) {
+				if (keys[(size_t)i] == 0) break;
+				n_cand++;
+				const uint32_t ob = (uint32_t)(keys[(size_t)i] >> 32);
+				const uint32_t bits = (ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob;
+				memcpy(&ub_last, &bits, 4);
+				const int64_t row = (int64_t)(uint32_t)(keys[(size_t)i] & 0xffffffffu);
+				// reference_score (metric/alignment.h:84-106) with the matched weight of this traceback, in float as upstream
+				float matched = 0.0f;
+				for (int j = 0; j < q->len_t; j++)
+					if (maps[(size_t)i * ostride + j] >= 0) matched += (q->tag_weights && is_align) ? q->tag_weights[j] : 1.0f;
+				const float uw = powf((total - matched) / total, wsub);
+				const float ref = matched + uw * (total - matched);
+				const float boost = q->boost ? q->boost[sentence_of(row)] : 1.0f;
+				const float val = (raws[(size_t)i] / ref) * boost;
+				if (val > q->min_score) {
+					Cand cd{val, raws[(size_t)i], row, {}, {}};
+					cd.map.assign(maps.begin() + (size_t)i * ostride, maps.begin() + (size_t)i * ostride + q->len_t);
+					cd.sim.assign(sims.begin() + (size_t)i * ostride, sims.begin() + (size_t)i * ostride + q->len_t);
+					best.push_back(std::move(cd));
+				}
+			}
+			std::sort(best.begin(), best.end(), [](const Cand &a, const Cand &b) {
+				if (a.val != b.val) return a.val > b.val;
+				return a.row > b.row;
+			});
+			if ((int)best.size() > k) best.resize((size_t)k);
+			if (n_cand < M) break;
+			if ((int)best.size() == k && best.back().val > ub_last) break;
+		}
+		VK_HIP(hipEventRecord(c->ev[3], st));
+		VK_HIP(hipEventRecord(c->ev[4], st));
+		VK_HIP(hipStreamSynchronize(st));
+		for (size_t i = 0; i < best.size(); i++) {
+			out->score[i] = best[i].val;
+			out->sentence[i] = sentence_of(best[i].row);
+			if (out->raw_score) out->raw_score[i] = best[i].raw;
+			if (q->want_flow && out->mapping && out->edge_sim)
+				for (int j = 0; j < q->len_t; j++) {
+					out->mapping[i * (size_t)q->len_t + j] = best[i].map[(size_t)j];
+					out->edge_sim[i * (size_t)q->len_t + j] = best[i].sim[(size_t)j];
+				}
+		}
+		out->n_out = (int)best.size();
+		float ms = 0;
+		vk_timings t{};
+		if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) t.prepare_ms = ms;
+		if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) t.score_ms = ms;
+		if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) t.topk_ms = ms;
+		if (hipEventElapsedTime(&ms, c->ev[0], c->ev[4]) == hipSuccess) t.total_ms = ms;
+		c->last = t;
+		return VK_OK;
+	}
+
 	// ---- bounded result set -------------------------------------------------
 	VK_HIP(hipEventRecord(c->ev[2], st));
 	int cur = 0;
@@ -745,24 +852,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	// ---- flow of the winners ------------------------------------------------
 	VK_HIP(hipEventRecord(c->ev[3], st));
 	const bool do_flow = q->want_flow && is_align;
-	const int ostride = wide ? 64 : 16;   // row stride of the mapping / edge_sim device arrays
-	if (do_flow && wide) {
-		wp.keys = c->d_keys[cur]; wp.raw_out = c->d_out_raw; wp.mapping = c->d_out_map; wp.edge_sim = c->d_out_sim;
-		VK_HIP(vk_launch_wide(&wp, k, st));
-	} else if (do_flow) {
-		VkFlowParams f{};
-		f.tiles = c->d_tiles; f.tok_id = c->d_tok_id; f.table = c->d_table; f.sent_start = c->d_sent_start; f.sent_end = c->d_sent_end;
-		f.layout = p.layout; f.nk32 = c->nk32; f.tail = c->tail; f.tile_bytes = c->tile_bytes;
-		f.qtile = c->d_qtile; f.len_t = q->len_t; f.locality = q->locality; f.gap_mode = (p.gap_mode == 3 || p.gap_mode == 6) ? 2 : p.gap_mode;
-		f.max_len = c->max_len;
-		f.gs = p.gs; f.gt = p.gt; f.a_s = p.a_s; f.a_t = p.a_t; f.open_s = p.open_s; f.open_t = p.open_t;
-		f.ws = c->d_ws; f.wt = c->d_wt;
-		f.pos_s = p.pos_s; f.tw_keep = p.tw_keep; f.tw_threshold = p.tw_threshold;
-		memcpy(f.tw, p.tw, sizeof f.tw);
-		memcpy(f.tpos, p.tpos, sizeof f.tpos);
-		f.keys = c->d_keys[cur]; f.raw_out = c->d_out_raw; f.mapping = c->d_out_map; f.edge_sim = c->d_out_sim;
-		VK_HIP(vk_launch_flow(&f, k, st));
-	}
+	if (do_flow && (rc = launch_flow(c->d_keys[cur], k))) return rc;
 	VK_HIP(hipEventRecord(c->ev[4], st));
 
 	// ---- results to host ------------------------------------------------------

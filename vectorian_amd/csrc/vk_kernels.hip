@@ -1930,6 +1930,41 @@ __global__ void vk_mark_kernel(const uint64_t *__restrict__ keys, int32_t n, flo
 	if (i < n && keys[i] != 0) scores[(uint32_t)(keys[i] & 0xffffffffu)] = VK_NEG_INF;
 }
 
+// submatch_weight != 0 (reference_score, metric/alignment.h:84-106): the score divides the aligner score by
+//   ref(m) = m + ((T - m) / T)^w (T - m),   m = weight of the matched query tokens, T = total weight,
+// and m is known only after a traceback.  Stage 1 turns raw into an upper bound of the score: every matched
+// pair contributes at most its token weight, so m >= raw; ref is convex in m with its minimum at m_star, so
+// ref(m) >= ref(max(raw, m_star)) =: ref_lb(raw) (a margin covers powf).  Negative raw (GLOBAL) is largest
+// over the largest ref = T.  Stage 2 (vk_api.cpp) retraces the candidates with the largest bounds.
+__global__ void vk_submatch_bound_kernel(const float *__restrict__ raw, const float *__restrict__ boost, int64_t n,
+	float total, float w, float m_star, float *__restrict__ scores) {
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const float r = raw[i];
+	if (!(r > VK_NEG_INF)) { scores[i] = VK_NEG_INF; return; }
+	const float b = boost ? boost[i] : 1.0f;
+	float ub;
+	if (r <= 0.0f) ub = r / total;
+	else {
+		float m = fmaxf(r, m_star);
+		m = fminf(m, total);
+		const float ref = m + powf((total - m) / total, w) * (total - m);
+		ub = r / (ref * (1.0f - 4e-6f));
+	}
+	scores[i] = ub * b;
+}
+
+extern "C" hipError_t vk_launch_submatch_bound(const float *raw, const float *boost, int64_t n, float total, float w, float m_star,
+	float *scores, hipStream_t stream) {
+	vk_submatch_bound_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(raw, boost, n, total, w, m_star, scores);
+	return hipGetLastError();
+}
+
+extern "C" hipError_t vk_launch_mark(const uint64_t *keys, int32_t n, float *scores, hipStream_t stream) {
+	vk_mark_kernel<<<(n + 255) / 256, 256, 0, stream>>>(keys, n, scores);
+	return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------
 // host-callable launchers (used by vk_api.cpp; keep all <<< >>> in this file)
 // ---------------------------------------------------------------------------
