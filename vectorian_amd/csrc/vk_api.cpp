@@ -611,6 +611,9 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		}
 		wp.boost = p.boost; wp.scores = c->d_scores; wp.raw = c->d_raw;
 		VK_HIP(vk_launch_wide(&wp, 0, st));
+	} else if (is_align && !is_static && q->len_t == 1 && c->uniform_len == 1 && q->locality == VK_LOCAL && !p.pos_s) {
+		// span-embedding index: one vector per slice, one query vector -> the clipped cosine is the local alignment score
+		VK_HIP(vk_launch_span(&p, st));
 	} else {
 	p.max_short_len = VK_FAST_SENT_LEN;
 	p.s_rows_per_wave = is_static ? (c->max_group_tokens + 15) / 16 * 16 : c->max_group_tiles * 16;

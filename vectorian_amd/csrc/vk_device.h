@@ -172,6 +172,7 @@ hipError_t vk_launch_pack(const void *in, int32_t dtype_bf16, int64_t n_rows, in
 hipError_t vk_launch_table(const uint8_t *etiles, const uint8_t *qtile, int32_t n_tiles, int32_t nk32, int32_t tail,
 	int32_t tile_bytes, float *table, const int32_t *q_ids, int32_t len_t, int32_t V, hipStream_t stream);
 hipError_t vk_launch_score(const VkScoreParams *p, int32_t grid, size_t smem_bytes, hipStream_t stream);
+hipError_t vk_launch_span(const VkScoreParams *p, hipStream_t stream);
 hipError_t vk_launch_topk_scores(const float *scores, int64_t n, float min_score, int32_t k, uint64_t *out,
 	int32_t *n_blocks_out, hipStream_t stream);
 hipError_t vk_launch_topk_keys(const uint64_t *in, int64_t n, int32_t k, uint64_t *out, int32_t *n_blocks_out,
