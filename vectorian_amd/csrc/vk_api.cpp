@@ -96,6 +96,8 @@ struct vk_corpus {
 	uint64_t *d_keys[2] = {nullptr, nullptr};
 	float *d_out_raw = nullptr, *d_out_sim = nullptr;
 	float *d_wrd_raw = nullptr, *d_wrd_val = nullptr;
+	uint32_t *d_counter = nullptr;
+	size_t wrd_cap = 0;          // candidates d_wrd_raw / d_wrd_val (and d_keys[0]) can hold
 	int16_t *d_out_map = nullptr;
 	hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 	vk_timings last{};
@@ -192,7 +194,7 @@ int vk_corpus_free(vk_corpus_t *c) {
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	void *ptrs[] = {c->d_tiles, c->d_mag, c->d_tok_id, c->d_pos, c->d_sent_start, c->d_sent_end, c->d_stage, c->d_qtile, c->d_ws, c->d_wt, c->d_qids,
-		c->d_table, c->d_scores, c->d_raw, c->d_boost, c->d_keys[0], c->d_keys[1], c->d_out_raw, c->d_out_sim, c->d_out_map, c->d_wrd_raw, c->d_wrd_val, c->d_bq, c->d_bqlen, c->d_bscores, c->d_bkeys[0], c->d_bkeys[1], c->d_long_groups};
+		c->d_table, c->d_scores, c->d_raw, c->d_boost, c->d_keys[0], c->d_keys[1], c->d_out_raw, c->d_out_sim, c->d_out_map, c->d_wrd_raw, c->d_wrd_val, c->d_bq, c->d_bqlen, c->d_bscores, c->d_bkeys[0], c->d_bkeys[1], c->d_long_groups, c->d_counter};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -650,16 +652,64 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		// ---- stage 2: exact EMD on the candidates with the largest bounds, until the k-th best
 		// exact score is above every remaining bound (then no unsolved sentence can enter)
 		VK_HIP(hipEventRecord(c->ev[2], st));
+		// Round 1: the M largest bounds.  Its k-th best exact score theta prunes: every row whose bound is below
+		// theta is out; all others are solved in one launch (round 2), which then fills the GPU instead of a
+		// trickle of M-candidate rounds.
 		const int M = 512;
-		if (!c->d_wrd_raw) {
-			rc = alloc_t(c, &c->d_wrd_raw, (size_t)VK_MAX_MATCHES); if (rc) return rc;
-			rc = alloc_t(c, &c->d_wrd_val, (size_t)VK_MAX_MATCHES); if (rc) return rc;
+		const size_t cap = ((size_t)((n + kTopkChunk - 1) / kTopkChunk) + 1) * VK_MAX_MATCHES;   // keys d_keys[0] holds
+		if (c->wrd_cap < cap) {
+			if (c->d_wrd_raw) { VK_HIP(hipFree(c->d_wrd_raw)); VK_HIP(hipFree(c->d_wrd_val)); c->d_wrd_raw = c->d_wrd_val = nullptr; }
+			rc = alloc_t(c, &c->d_wrd_raw, cap); if (rc) return rc;
+			rc = alloc_t(c, &c->d_wrd_val, cap); if (rc) return rc;
+			c->wrd_cap = cap;
 		}
+		if (!c->d_counter) { rc = alloc_t(c, &c->d_counter, 4); if (rc) return rc; }
 		struct Cand { float val, raw; int64_t g; };
 		std::vector<Cand> best;
-		std::vector<uint64_t> keys((size_t)M);
-		std::vector<float> vals((size_t)M), raws((size_t)M);
-		for (;;) {
+		std::vector<uint64_t> keys;
+		std::vector<float> vals, raws;
+		VkWrdParams w{};
+		w.tiles = c->d_tiles; w.tok_id = c->d_tok_id; w.table = c->d_table; w.sent_start = c->d_sent_start; w.sent_end = c->d_sent_end;
+		w.layout = p.layout; w.nk32 = c->nk32; w.tail = c->tail; w.tile_bytes = c->tile_bytes;
+		w.qtile = c->d_qtile; w.len_t = q->len_t; w.mag = c->d_mag;
+		w.mass_mode = q->algorithm == VK_ALG_WRD ? 0 : (q->rwmd_normalize_bow ? 1 : 2);
+		memcpy(w.qmass, p.qmass, sizeof w.qmass);
+		w.boost = p.boost; w.raw_out = c->d_wrd_raw; w.val_out = c->d_wrd_val;
+		// solves the `count` candidates whose keys sit at d_keys, merges them into `best`; returns the smallest bound among them
+		auto solve = [&](const uint64_t *d_keys, int count, float *ub_min, int *n_cand_out) -> int {
+			w.keys = d_keys;
+			VK_HIP(vk_launch_wrd_exact(&w, count, c->d_scores, st));
+			keys.resize((size_t)count); vals.resize((size_t)count); raws.resize((size_t)count);
+			VK_HIP(hipMemcpyAsync(keys.data(), d_keys, (size_t)count * 8, hipMemcpyDeviceToHost, st));
+			VK_HIP(hipMemcpyAsync(vals.data(), c->d_wrd_val, (size_t)count * 4, hipMemcpyDeviceToHost, st));
+			VK_HIP(hipMemcpyAsync(raws.data(), c->d_wrd_raw, (size_t)count * 4, hipMemcpyDeviceToHost, st));
+			VK_HIP(hipStreamSynchronize(st));
+			int n_cand = 0;
+			float ub = INFINITY;
+			for (int i = 0; i < count; i++) {
+				if (keys[(size_t)i] == 0) break;
+				n_cand++;
+				const uint32_t ob = (uint32_t)(keys[(size_t)i] >> 32);
+				const uint32_t bits = (ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob;
+				float u;
+				memcpy(&u, &bits, 4);
+				ub = std::min(ub, u);
+				if (vals[(size_t)i] > q->min_score)
+					best.push_back({vals[(size_t)i], raws[(size_t)i], (int64_t)(uint32_t)(keys[(size_t)i] & 0xffffffffu)});
+			}
+			const auto better = [](const Cand &a, const Cand &b) {
+				if (a.val != b.val) return a.val > b.val;
+				return a.g > b.g;
+			};
+			if ((int)best.size() > k) {
+				std::partial_sort(best.begin(), best.begin() + k, best.end(), better);
+				best.resize((size_t)k);
+			} else std::sort(best.begin(), best.end(), better);
+			*ub_min = ub;
+			*n_cand_out = n_cand;
+			return VK_OK;
+		};
+		{
 			int nb = 0, cur = 0;
 			VK_HIP(vk_launch_topk_scores(c->d_scores, n, q->min_score, M, c->d_keys[0], &nb, st));
 			while (nb > 1) {
@@ -667,36 +717,22 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 				VK_HIP(vk_launch_topk_keys(c->d_keys[cur], nkeys, M, c->d_keys[1 - cur], &nb, st));
 				cur = 1 - cur;
 			}
-			VkWrdParams w{};
-			w.tiles = c->d_tiles; w.tok_id = c->d_tok_id; w.table = c->d_table; w.sent_start = c->d_sent_start; w.sent_end = c->d_sent_end;
-			w.layout = p.layout; w.nk32 = c->nk32; w.tail = c->tail; w.tile_bytes = c->tile_bytes;
-			w.qtile = c->d_qtile; w.len_t = q->len_t; w.mag = c->d_mag;
-			w.mass_mode = q->algorithm == VK_ALG_WRD ? 0 : (q->rwmd_normalize_bow ? 1 : 2);
-			memcpy(w.qmass, p.qmass, sizeof w.qmass);
-			w.boost = p.boost; w.keys = c->d_keys[cur]; w.raw_out = c->d_wrd_raw; w.val_out = c->d_wrd_val;
-			VK_HIP(vk_launch_wrd_exact(&w, M, c->d_scores, st));
-			VK_HIP(hipMemcpyAsync(keys.data(), c->d_keys[cur], (size_t)M * 8, hipMemcpyDeviceToHost, st));
-			VK_HIP(hipMemcpyAsync(vals.data(), c->d_wrd_val, (size_t)M * 4, hipMemcpyDeviceToHost, st));
-			VK_HIP(hipMemcpyAsync(raws.data(), c->d_wrd_raw, (size_t)M * 4, hipMemcpyDeviceToHost, st));
-			VK_HIP(hipStreamSynchronize(st));
-			int n_cand = 0;
 			float ub_last = INFINITY;
-			for (int i = 0; i < M; i++) {
-				if (keys[(size_t)i] == 0) break;
-				n_cand++;
-				const uint32_t ob = (uint32_t)(keys[(size_t)i] >> 32);
-				const uint32_t bits = (ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob;
-				memcpy(&ub_last, &bits, 4);
-				if (vals[(size_t)i] > q->min_score)
-					best.push_back({vals[(size_t)i], raws[(size_t)i], (int64_t)(uint32_t)(keys[(size_t)i] & 0xffffffffu)});
+			int n_cand = 0;
+			if ((rc = solve(c->d_keys[cur], M, &ub_last, &n_cand))) return rc;
+			bool done = n_cand < M || ((int)best.size() == k && best.back().val > ub_last);
+			while (!done) {
+				const float theta = (int)best.size() == k ? best.back().val : -INFINITY;
+				VK_HIP(vk_launch_select_ge(c->d_scores, n, theta, q->min_score, c->d_keys[0], c->d_counter, (uint32_t)cap, st));
+				uint32_t count = 0;
+				VK_HIP(hipMemcpyAsync(&count, c->d_counter, 4, hipMemcpyDeviceToHost, st));
+				VK_HIP(hipStreamSynchronize(st));
+				if (count == 0) break;
+				if (getenv("VK_DEBUG_CANDIDATES")) fprintf(stderr, "[vk] exact transport: round 2 solves %u candidates (theta %.6f, n %lld)\n", count, theta, (long long)n);
+				const int take = (int)std::min<size_t>(count, cap);
+				if ((rc = solve(c->d_keys[0], take, &ub_last, &n_cand))) return rc;
+				done = (size_t)count <= cap;   // every row that could still enter has been solved
 			}
-			std::sort(best.begin(), best.end(), [](const Cand &a, const Cand &b) {
-				if (a.val != b.val) return a.val > b.val;
-				return a.g > b.g;
-			});
-			if ((int)best.size() > k) best.resize((size_t)k);
-			if (n_cand < M) break;                                          // pool exhausted
-			if ((int)best.size() == k && best.back().val > ub_last) break;  // nothing left can enter
 		}
 		VK_HIP(hipEventRecord(c->ev[3], st));
 		VK_HIP(hipEventRecord(c->ev[4], st));

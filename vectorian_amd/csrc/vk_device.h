@@ -166,6 +166,8 @@ hipError_t vk_launch_wide(const VkWideParams *p, int32_t flow_k, hipStream_t str
 hipError_t vk_launch_submatch_bound(const float *raw, const float *boost, int64_t n, float total, float w, float m_star,
 	float *scores, hipStream_t stream);
 hipError_t vk_launch_mark(const uint64_t *keys, int32_t n, float *scores, hipStream_t stream);
+hipError_t vk_launch_select_ge(const float *scores, int64_t n, float theta, float floor_excl, uint64_t *keys_out,
+	uint32_t *counter, uint32_t cap, hipStream_t stream);
 size_t vk_wide_lds_demand(int32_t max_len, int32_t nq, int32_t gap_mode, int32_t tagged, int32_t flow);
 hipError_t vk_launch_pack(const void *in, int32_t dtype_bf16, int64_t n_rows, int32_t d, int32_t d_pad, int64_t row0,
 	uint8_t *tiles, float *mag_out, int32_t normalize, hipStream_t stream);

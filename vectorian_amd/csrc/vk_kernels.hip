@@ -1761,103 +1761,43 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 }
 
 // ---------------------------------------------------------------------------
-// Word Rotator's Distance, stage 2: exact EMD for the candidate sentences.
-// One wave per candidate recomputes the similarity rows (same MFMA sequence as the scoring
-// kernel); lane 0 then runs successive shortest paths with potentials on the bipartite
-// transportation problem in double precision -- statement for statement the oracle's vko_emd /
-// vko_wrd (oracle/vk_oracle.c), which stand in for pyemd's emd_hat_gd_metric<double>
-// (vectorian/core/cpp/alignment/transport.h:70,125-126).
+// Word Rotator's Distance / full WMD, stage 2: exact EMD for the candidate slices.
+// One wave per candidate recomputes the similarity rows (same MFMA sequence as the scoring kernel) and
+// solves the transportation problem (n <= 16 query tokens = supplies, m <= 64 slice tokens = demands) by
+// successive shortest paths with potentials in double precision -- the algorithm of the oracle's vko_emd
+// (oracle/vk_oracle.c), which stands in for pyemd's emd_hat_gd_metric<double>
+// (vectorian/core/cpp/alignment/transport.h:70,125-126) -- with the Dijkstra step spread over the wave:
+//   lane i owns demand i (its distance, potential, predecessor, remaining mass; column i of the costs and
+//   flows in LDS); the supplies live in small LDS arrays read uniformly.
+//   All supplies with remaining mass are sources and are relaxed together.  Demands are never settled
+//   one by one: the next supply to settle is the minimum over (demand i, supply b with flow b -> i) of
+//   dist[i] + reduced cost(i -> b), one in-lane loop over b and ONE wave reduction; it is final because
+//   any shorter path would pass through another unsettled supply first.  The search ends when the
+//   nearest demand with remaining mass is at most that far.
+// The optimal cost is unique, so the score equals the oracle's up to the rounding of the final sums
+// (the path taken among equal-cost alternatives may differ).  A serial one-lane version of the same
+// solver took 8 - 20 ms per round of candidates; this one ~0.1 ms.
 // ---------------------------------------------------------------------------
-
-// Exact EMD of a small transportation problem by successive shortest paths with potentials
-// (dense Dijkstra on reduced costs), double precision, one lane.  sup[n] / dem[m] hold the masses on
-// entry and the unshipped remainders on exit; fl[n x m] receives the flow.  Statement for statement
-// the oracle's vko_emd (oracle/vk_oracle.c).  Kept out of line: inlined into vk_wrd_exact_kernel,
-// ROCm 7.2 hipcc produced a loop that dropped the `target = x` exit (results were wrong while this
-// very function, compiled alone, matches the host bit for bit: tools/probe/ssp_probe.hip).
-__device__ __attribute__((noinline)) void vk_emd_ssp(int n, int m, const double *C, double *fl, double *sup, double *dem,
-	double *pot, double *dist, int *prevn, uint8_t *done) {
-	const int N = n + m;
-	const double EPS = 1e-13;
-	for (int i = 0; i < n * m; i++) fl[i] = 0.0;
-	for (int i = 0; i < N; i++) pot[i] = 0.0;
-	for (int iter = 0; iter < 100000; iter++) {
-		int any = 0;
-		for (int i = 0; i < N; i++) { dist[i] = __builtin_inf(); prevn[i] = -1; done[i] = 0; }
-		for (int i = 0; i < n; i++) if (sup[i] > EPS) { dist[i] = 0.0; any = 1; }
-		if (!any) break;
-		int any_dem = 0;
-		for (int j = 0; j < m; j++) if (dem[j] > EPS) any_dem = 1;
-		if (!any_dem) break;
-
-		int target = -1;
-		bool searching = true;
-		while (searching) {
-			int x = -1;
-			double bd = __builtin_inf();
-			for (int i = 0; i < N; i++) if (!done[i] && dist[i] < bd) { bd = dist[i]; x = i; }
-			if (x < 0) {
-				searching = false;
-			} else {
-				done[x] = 1;
-				if (x >= n && dem[x - n] > EPS) {
-					target = x;
-					searching = false;
-				} else if (x < n) {
-					for (int j = 0; j < m; j++) {
-						if (done[n + j]) continue;
-						double rc = C[x * m + j] + pot[x] - pot[n + j];
-						if (rc < 0) rc = 0;
-						if (dist[x] + rc < dist[n + j]) { dist[n + j] = dist[x] + rc; prevn[n + j] = x; }
-					}
-				} else {
-					const int j = x - n;
-					for (int i = 0; i < n; i++) {
-						if (done[i] || !(fl[i * m + j] > EPS)) continue;
-						double rc = -C[i * m + j] + pot[x] - pot[i];
-						if (rc < 0) rc = 0;
-						if (dist[x] + rc < dist[i]) { dist[i] = dist[x] + rc; prevn[i] = x; }
-					}
-				}
-			}
-		}
-		if (target < 0) break;
-		const double dt = dist[target];
-		for (int i = 0; i < N; i++) pot[i] += (done[i] && dist[i] < dt) ? dist[i] : dt;
-
-		double delta = dem[target - n];
-		int x = target;
-		while (prevn[x] >= 0) {
-			const int pr = prevn[x];
-			if (pr >= n) {
-				const double cap = fl[x * m + (pr - n)];
-				if (cap < delta) delta = cap;
-			}
-			x = pr;
-		}
-		if (sup[x] < delta) delta = sup[x];
-		sup[x] -= delta;
-		dem[target - n] -= delta;
-		x = target;
-		while (prevn[x] >= 0) {
-			const int pr = prevn[x];
-			if (pr < n) fl[pr * m + (x - n)] += delta;
-			else fl[x * m + (pr - n)] -= delta;
-			x = pr;
-		}
-	}
-}
 
 #define VK_WRD_N VK_DEV_MAX_QUERY_LEN
 #define VK_WRD_M VK_DEV_MAX_SENT_LEN
 
+// minimum of x over the wave and a lane holding it (the lowest such lane)
+__device__ __forceinline__ double wave_argmin_f64(double x, int lane, int &at) {
+	double m = x;
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) m = fmin(m, __shfl_xor(m, off, 64));
+	const unsigned long long hit = __ballot(x == m);
+	at = hit ? __builtin_ctzll(hit) : 0;
+	return m;
+}
+
 __global__ __launch_bounds__(64) void vk_wrd_exact_kernel(VkWrdParams p) {
 	__shared__ __attribute__((aligned(16))) float S[(VK_DEV_MAX_SENT_LEN + 32) * 16];
-	__shared__ double Cm[VK_WRD_N * VK_WRD_M];
-	__shared__ double fl[VK_WRD_N * VK_WRD_M];
-	__shared__ double sup[VK_WRD_N], dem[VK_WRD_M], pot[VK_WRD_N + VK_WRD_M], dist[VK_WRD_N + VK_WRD_M];
-	__shared__ int prevn[VK_WRD_N + VK_WRD_M];
-	__shared__ uint8_t done[VK_WRD_N + VK_WRD_M];
+	__shared__ double Cm[VK_WRD_N * 64];     // Cm[j * 64 + i]: cost supply j -> demand i
+	__shared__ double fl[VK_WRD_N * 64];     // flow
+	__shared__ double sup[VK_WRD_N], pot_s[VK_WRD_N], dist_s[VK_WRD_N];
+	__shared__ int pred_s[VK_WRD_N], settled[VK_WRD_N];
 
 	const int lane = threadIdx.x;
 	const int w = blockIdx.x;
@@ -1887,41 +1827,134 @@ __global__ __launch_bounds__(64) void vk_wrd_exact_kernel(VkWrdParams p) {
 		}
 		rowbase = t_a - tile0 * 16;
 	}
-	__syncthreads();
-	if (lane != 0) return;
+	wave_lds_fence();
 	const float *Sm = S + rowbase * 16;
+	const bool has = lane < m;
+	const double EPS = 1e-13, INF = __builtin_inf();
 
 	// masses (wrd.h:99-102) and costs (:104-109)
+	double dem = 0.0;
 	if (p.mass_mode == 0) {
 		float sum_s = 0.0f;
-		for (int i = 0; i < m; i++) sum_s += p.mag[t_a + i];
-		for (int j = 0; j < n; j++) sup[j] = (double)p.qmass[j];
-		for (int i = 0; i < m; i++) dem[i] = (double)(p.mag[t_a + i] / sum_s);
+		for (int i = 0; i < m; i++) sum_s += p.mag[t_a + i];       // in position order, as upstream
+		if (has) dem = (double)(p.mag[t_a + lane] / sum_s);
+		if (lane < VK_WRD_N) sup[lane] = lane < n ? (double)p.qmass[lane] : 0.0;
 	} else {
 		// bags of words over positions: 1 per token (bow), or 1/len (nbow, bow.h:262-270)
 		const float wt = p.mass_mode == 1 ? 1.0f / (float)n : 1.0f;
 		const float wsn = p.mass_mode == 1 ? 1.0f / (float)m : 1.0f;
-		for (int j = 0; j < n; j++) sup[j] = (double)wt;
-		for (int i = 0; i < m; i++) dem[i] = (double)wsn;
+		if (has) dem = (double)wsn;
+		if (lane < VK_WRD_N) sup[lane] = lane < n ? (double)wt : 0.0;
 	}
-	for (int j = 0; j < n; j++)
-		for (int i = 0; i < m; i++) {
-			float d = 1.0f - Sm[i * 16 + j];
-			if (!(d > 0.0f)) d = 0.0f;
-			Cm[j * m + i] = (double)d;
+	if (lane < VK_WRD_N) pot_s[lane] = 0.0;
+	for (int j = 0; j < n; j++) {
+		float d = has ? 1.0f - Sm[lane * 16 + j] : 0.0f;
+		if (!(d > 0.0f)) d = 0.0f;
+		Cm[j * 64 + lane] = (double)d;
+		fl[j * 64 + lane] = 0.0;
+	}
+	double pot_d = 0.0;
+	wave_lds_fence();
+
+	for (int iter = 0; iter < 4000; iter++) {
+		// ---- sources: every supply with remaining mass; relax them all
+		bool any_sup = false;
+		double dist_d = INF;
+		int pred_d = -1;
+		for (int j = 0; j < n; j++) {
+			const bool src = sup[j] > EPS;
+			any_sup |= src;
+			if (lane == 0) { settled[j] = src ? 1 : 0; dist_s[j] = src ? 0.0 : INF; pred_s[j] = -1; }
+			if (src) {
+				double rc = Cm[j * 64 + lane] + pot_s[j] - pot_d;
+				if (rc < 0) rc = 0;
+				if (rc < dist_d) { dist_d = rc; pred_d = j; }
+			}
 		}
-	vk_emd_ssp(n, m, Cm, fl, sup, dem, pot, dist, prevn, done);
+		if (!has) dist_d = INF;
+		const bool any_dem = __ballot(has && dem > EPS) != 0;
+		if (!any_sup || !any_dem) break;
+		wave_lds_fence();
+
+		int target = -1;
+		double dt = INF;
+		for (int round = 0; round <= n; round++) {
+			int fd_lane, c_lane;
+			const double fd = wave_argmin_f64((has && dem > EPS) ? dist_d : INF, lane, fd_lane);
+			double best = INF;
+			int bb = -1;
+			if (dist_d < INF) {
+				for (int b = 0; b < n; b++) {
+					if (settled[b]) continue;
+					if (!(fl[b * 64 + lane] > EPS)) continue;
+					double rc = pot_d - pot_s[b] - Cm[b * 64 + lane];
+					if (rc < 0) rc = 0;
+					const double cand = dist_d + rc;
+					if (cand < best) { best = cand; bb = b; }
+				}
+			}
+			const double cmin = wave_argmin_f64(best, lane, c_lane);
+			if (fd <= cmin) {
+				if (fd < INF) { target = fd_lane; dt = fd; }
+				break;
+			}
+			const int cb = __shfl(bb, c_lane, 64);
+			if (lane == 0) { settled[cb] = 1; dist_s[cb] = cmin; pred_s[cb] = c_lane; }
+			wave_lds_fence();
+			double rc = Cm[cb * 64 + lane] + pot_s[cb] - pot_d;
+			if (rc < 0) rc = 0;
+			const double nd = cmin + rc;
+			if (has && nd < dist_d) { dist_d = nd; pred_d = cb; }
+		}
+		if (target < 0) break;
+
+		// ---- potentials: pot += min(dist, dt)
+		pot_d += dist_d < dt ? dist_d : dt;
+		if (lane < n) pot_s[lane] += (settled[lane] && dist_s[lane] < dt) ? dist_s[lane] : dt;
+		wave_lds_fence();
+
+		// ---- bottleneck along target <- supply <- demand <- ... <- source, then augment
+		double delta = __shfl(dem, target, 64);
+		int x = target;
+		for (int hop = 0; hop <= n; hop++) {
+			const int a = __shfl(pred_d, x, 64);
+			const int ps = pred_s[a];
+			if (ps < 0) { delta = fmin(delta, sup[a]); break; }
+			delta = fmin(delta, fl[a * 64 + ps]);
+			x = ps;
+		}
+		if (lane == target) dem -= delta;
+		x = target;
+		for (int hop = 0; hop <= n; hop++) {
+			const int a = __shfl(pred_d, x, 64);
+			const int ps = pred_s[a];
+			if (lane == 0) {
+				fl[a * 64 + x] += delta;
+				if (ps < 0) sup[a] -= delta;
+				else fl[a * 64 + ps] -= delta;
+			}
+			if (ps < 0) break;
+			x = ps;
+		}
+		wave_lds_fence();
+	}
+
 	// score = sum((1 - D) * G) / sum(G) (wrd.h:139), G as float
 	double num = 0.0, den = 0.0;
-	for (int i = 0; i < n * m; i++) {
-		const float gq = (float)fl[i];
-		num += (double)((1.0f - (float)Cm[i]) * gq);
-		den += (double)gq;
+	if (has)
+		for (int j = 0; j < n; j++) {
+			const float gq = (float)fl[j * 64 + lane];
+			num += (double)((1.0f - (float)Cm[j * 64 + lane]) * gq);
+			den += (double)gq;
+		}
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) { num += __shfl_xor(num, off, 64); den += __shfl_xor(den, off, 64); }
+	if (lane == 0) {
+		const float raw = den > 0.0 ? (float)(num / den) : 0.0f;
+		const float boost = p.boost ? p.boost[g] : 1.0f;
+		p.raw_out[w] = raw;
+		p.val_out[w] = (raw / (float)n) * boost;
 	}
-	const float raw = den > 0.0 ? (float)(num / den) : 0.0f;
-	const float boost = p.boost ? p.boost[g] : 1.0f;
-	p.raw_out[w] = raw;
-	p.val_out[w] = (raw / (float)n) * boost;
 }
 
 // processed candidates leave the pool: their bound becomes -inf
@@ -1957,6 +1990,27 @@ __global__ void vk_submatch_bound_kernel(const float *__restrict__ raw, const fl
 extern "C" hipError_t vk_launch_submatch_bound(const float *raw, const float *boost, int64_t n, float total, float w, float m_star,
 	float *scores, hipStream_t stream) {
 	vk_submatch_bound_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(raw, boost, n, total, w, m_star, scores);
+	return hipGetLastError();
+}
+
+// all slices whose bound can still enter the result set: keys (bound, row) of the rows with
+// theta <= bound and bound > floor, appended in no particular order; *counter = how many qualify
+__global__ void vk_select_ge_kernel(const float *__restrict__ scores, int64_t n, float theta, float floor_excl,
+	uint64_t *__restrict__ keys_out, uint32_t *__restrict__ counter, uint32_t cap) {
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const float sc = scores[i];
+	if (sc >= theta && sc > floor_excl) {
+		const uint32_t at = atomicAdd(counter, 1u);
+		if (at < cap) keys_out[at] = ((uint64_t)float_orderable(sc) << 32) | (uint32_t)i;
+	}
+}
+
+extern "C" hipError_t vk_launch_select_ge(const float *scores, int64_t n, float theta, float floor_excl, uint64_t *keys_out,
+	uint32_t *counter, uint32_t cap, hipStream_t stream) {
+	hipError_t e = hipMemsetAsync(counter, 0, 4, stream);
+	if (e != hipSuccess) return e;
+	vk_select_ge_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(scores, n, theta, floor_excl, keys_out, counter, cap);
 	return hipGetLastError();
 }
 
