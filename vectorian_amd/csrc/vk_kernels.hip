@@ -574,10 +574,11 @@ __device__ __forceinline__ float wrd_bound_rows(const float *__restrict__ S, int
 	const DpArgs &a, const float *__restrict__ mag, float q_mass) {
 	const int len_t = a.len_t;
 	const bool col_ok = v < len_t;
+	// one sweep: sum of the slice's magnitudes and sum of magnitude x nearest distance (the quotient is the
+	// bound of the s -> t direction; it is only a bound, so the order of the float operations is free)
 	float sum_s = 0.0f;
-	for (int u = 1; u <= maxlen; u++) if (u <= len) sum_s += mag[u - 1];
 	float colmin = 3.402823466e+38F;
-	float lb1 = 0.0f;
+	float lb1n = 0.0f;
 	for (int u = 1; u <= maxlen; u++) {
 		const bool act = u <= len;
 		const float s = S[(rowbase + (act ? u - 1 : 0)) * 16 + v];
@@ -588,8 +589,11 @@ __device__ __forceinline__ float wrd_bound_rows(const float *__restrict__ S, int
 		m = fminf(m, dpp_f<DPP_ROW_SHR2>(m, m));
 		m = fminf(m, dpp_f<DPP_ROW_SHR4>(m, m));
 		m = fminf(m, dpp_f<DPP_ROW_SHR8>(m, m));
-		if (act) lb1 += (mag[u - 1] / sum_s) * m;
+		const float mg = act ? mag[u - 1] : 0.0f;
+		sum_s += mg;
+		lb1n += mg * m;
 	}
+	const float lb1 = lb1n / sum_s * (1.0f - 2e-6f);
 	float x = col_ok ? q_mass * colmin : 0.0f;      // sum over lanes, any order: it is only a bound
 	x += dpp_f<DPP_ROW_SHR1>(0.0f, x);
 	x += dpp_f<DPP_ROW_SHR2>(0.0f, x);
