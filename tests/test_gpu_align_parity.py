@@ -87,7 +87,7 @@ def test_errors_are_loud(hip):
 	with pytest.raises(hip.VkError):
 		c.query(q)
 	with pytest.raises(hip.VkError):
-		c.query(q[:3], submatch_weight=0.5)
+		c.query(q[:3], submatch_weight=-0.5)
 	with pytest.raises(hip.VkError):
 		c.query(q[:3], algorithm=hip.VK_ALG_WRD)
 	c.close()

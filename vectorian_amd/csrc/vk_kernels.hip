@@ -684,20 +684,34 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 		int rowbase;
 		if (MODE == 2) {
 			// gather: lane handles token (lane >> 2) + 16*it, 4 query columns (lane & 3)
+			// two dependent loads per token (id, then the table row): issue them four tokens deep so that the
+			// L2 latencies overlap instead of adding up
 			const int ntok = g_b - g_a;
-			for (int it = 0; it * 16 < ntok; it++) {
-				const int tk = it * 16 + (lane >> 2);
-				if (tk < ntok) {
-					const int id = p.tok_id[g_a + tk];
-					float4 val = *reinterpret_cast<const float4 *>(p.table + (int64_t)id * 16 + (lane & 3) * 4);
-					if (p.pos_s) {
-						const int ps = p.pos_s[g_a + tk];
-						val.x = tag_weighted(val.x, twl[0], ps, tposl[0], p.tw_keep, p.tw_threshold);
-						val.y = tag_weighted(val.y, twl[1], ps, tposl[1], p.tw_keep, p.tw_threshold);
-						val.z = tag_weighted(val.z, twl[2], ps, tposl[2], p.tw_keep, p.tw_threshold);
-						val.w = tag_weighted(val.w, twl[3], ps, tposl[3], p.tw_keep, p.tw_threshold);
+			for (int it0 = 0; it0 * 16 < ntok; it0 += 4) {
+				int id[4];
+				float4 val[4];
+#pragma unroll
+				for (int q4 = 0; q4 < 4; q4++) {
+					const int tk = (it0 + q4) * 16 + (lane >> 2);
+					id[q4] = p.tok_id[g_a + (tk < ntok ? tk : 0)];
+				}
+#pragma unroll
+				for (int q4 = 0; q4 < 4; q4++)
+					val[q4] = *reinterpret_cast<const float4 *>(p.table + (int64_t)id[q4] * 16 + (lane & 3) * 4);
+#pragma unroll
+				for (int q4 = 0; q4 < 4; q4++) {
+					const int tk = (it0 + q4) * 16 + (lane >> 2);
+					if (tk < ntok) {
+						float4 vq = val[q4];
+						if (p.pos_s) {
+							const int ps = p.pos_s[g_a + tk];
+							vq.x = tag_weighted(vq.x, twl[0], ps, tposl[0], p.tw_keep, p.tw_threshold);
+							vq.y = tag_weighted(vq.y, twl[1], ps, tposl[1], p.tw_keep, p.tw_threshold);
+							vq.z = tag_weighted(vq.z, twl[2], ps, tposl[2], p.tw_keep, p.tw_threshold);
+							vq.w = tag_weighted(vq.w, twl[3], ps, tposl[3], p.tw_keep, p.tw_threshold);
+						}
+						*reinterpret_cast<float4 *>(S + tk * 16 + (lane & 3) * 4) = vq;
 					}
-					*reinterpret_cast<float4 *>(S + tk * 16 + (lane & 3) * 4) = val;
 				}
 			}
 			rowbase = t_a - g_a;
