@@ -528,12 +528,12 @@ static int cmp_ref_token(const void *a, const void *b) {
 	return (x->pos > y->pos) - (x->pos < y->pos);
 }
 
-typedef struct { float d; int32_t j; } dist_ref;
+typedef struct { float d; int32_t j; int32_t pos; } dist_ref;
 
 static int cmp_dist_ref(const void *a, const void *b) {
 	const dist_ref *x = (const dist_ref *)a, *y = (const dist_ref *)b;
 	if (x->d != y->d) return x->d < y->d ? -1 : 1;
-	return (x->j > y->j) - (x->j < y->j);
+	return (x->pos > y->pos) - (x->pos < y->pos);
 }
 
 double vko_emd(const double *a, int32_t n, const double *b, int32_t m, const double *C, double *flow);
@@ -663,22 +663,25 @@ float vko_wmd(const float *S, int32_t ld, int32_t len_s, int32_t len_t,
 					const int32_t j = vocab[d2][bidx];
 					cand[nc].d = D[(size_t)i * vocab_size + j];
 					cand[nc].j = j;
+					cand[nc].pos = first_pos[d2][j];
 					nc++;
 				}
+				/* upstream pops a binary heap keyed on the distance alone (wmd.h:29-37,352-358): the order among
+				 * equal distances is whatever std::pop_heap yields.  Defined here: by first position in the document. */
 				qsort(cand, (size_t)nc, sizeof(dist_ref), cmp_dist_ref);
-				int done = 0;
 				for (int32_t r = 0; r < nc; r++) {
 					const int32_t target = cand[r].j;
 					if (remaining <= w2[target]) {
 						acc += remaining * cand[r].d;
-						done = 1;
 						break;
 					} else {
 						remaining -= w2[target];
 						acc += w2[target] * cand[r].d;
 					}
 				}
-				if (!done && remaining > 0.0f) acc += remaining * 1.0f;
+				/* wmd.h:373-375 as written: `remaining` keeps its value when the loop above breaks, so the
+				 * last partial shipment is charged a second time at the maximum distance.  Restated as is. */
+				if (remaining > 0.0f) acc += remaining * 1.0f;
 			}
 		}
 		if (!normalize_bow) acc /= (float)w_sum[d1];

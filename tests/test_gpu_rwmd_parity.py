@@ -14,6 +14,10 @@ VARIANTS = {
 	"nbow": (True, True, True),        # rwmd('nbow'): injective, symmetric, normalised (vectorian/alignment.py:232-233)
 	"bow/fast": (True, False, False),  # rwmd('bow/fast') (:236-237)
 	"nbow-onesided": (True, False, True),
+	# 1:n forms (RelaxedSolver with injective = false, alignment/wmd.h:339-376)
+	"nbow/distributed": (False, True, True),   # rwmd('nbow/distributed') (:234-235)
+	"distributed-onesided": (False, False, True),
+	"distributed-bow": (False, False, False),
 }
 
 
@@ -37,7 +41,7 @@ def test_contextual_rwmd(hip, oracle, variant, shape):
 	c.close()
 
 
-@pytest.mark.parametrize("variant", ["nbow", "bow/fast"])
+@pytest.mark.parametrize("variant", ["nbow", "bow/fast", "nbow/distributed", "distributed-bow"])
 def test_static_rwmd(hip, oracle, variant):
 	# query vectors are the vocabulary's own vectors (the regime of Index.find); repeated tokens in
 	# sentences and tokens shared between query and sentence exercise the joint-vocabulary BOW builder
@@ -48,6 +52,7 @@ def test_static_rwmd(hip, oracle, variant):
 	flags = VARIANTS[variant]
 	for _ in range(3):
 		qids = rng.integers(0, 40, size=6).astype(np.int32)      # frequent ids: overlap with sentences is common
+		qids[4] = qids[1]                                         # a repeated query token: one vocabulary entry of mass 2
 		Qb = Eb[qids]
 		ref = oracle.find(layout=oracle.LAYOUT_STATIC, d=300, sent_off=corpus["sent_off"], tok_id=corpus["tok_id"], E=Eb,
 			Q=Qb, q_ids=qids, algorithm=oracle.ALG_RWMD, rwmd=flags, max_matches=20, want_all_scores=True)
@@ -57,11 +62,26 @@ def test_static_rwmd(hip, oracle, variant):
 	c.close()
 
 
-def test_non_injective_is_rejected(hip):
-	corpus = synth.make_contextual_corpus(10, 4, 8, 100, 32)
-	c = hip_contextual_corpus(hip, corpus)
-	with pytest.raises(hip.VkError):
-		c.query(np.ones((3, 32), np.float32), algorithm=hip.VK_ALG_RWMD, rwmd=(False, True, True))
+def test_distributed_rwmd_long_slices_and_short_queries(hip, oracle):
+	# one query token must be spread over every token of the slice; slices of more than 64 tokens take the second launch
+	lens = np.array([3, 70, 12, 1, 33, 200, 64, 5, 9])
+	off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+	rng = np.random.default_rng(5)
+	Xb = synth.to_bf16_bits(synth.normalize_rows(rng.standard_normal((int(off[-1]), 64)).astype(np.float32)))
+	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=64, n_tokens=Xb.shape[0], n_sentences=len(lens))
+	c.append_vectors(Xb, normalize=False)
+	c.set_sentences(off)
+	c.finalize()
+	for len_t in (1, 2, 16):
+		Qb = synth.to_bf16_bits(synth.normalize_rows(rng.standard_normal((len_t, 64)).astype(np.float32)))
+		for flags in ((False, True, True), (False, False, False)):
+			ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=64, sent_off=off, X=Xb, Q=Qb, algorithm=oracle.ALG_RWMD, rwmd=flags,
+				max_matches=9, min_score=-1.0, want_all_scores=True)
+			got = c.query(Qb, algorithm=hip.VK_ALG_RWMD, rwmd=flags, q_normalize=False, max_matches=9, min_score=-1.0)
+			np.testing.assert_allclose(c.last_scores(), ref["all_scores"], atol=1e-5, rtol=0)
+			assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=1e-5, tie_tol=1e-5)
+	with pytest.raises(hip.VkError):   # the 1:n form is built for queries of at most 16 tokens
+		c.query(np.ones((17, 64), np.float32), algorithm=hip.VK_ALG_RWMD, rwmd=(False, True, True))
 	c.close()
 
 

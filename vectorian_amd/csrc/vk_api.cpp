@@ -439,8 +439,8 @@ static int validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_t
 			if (c->max_len > VK_FAST_SENT_LEN) return fail(VK_ERR_UNSUPPORTED, "full WMD needs every slice <= VK_FAST_SENT_LEN (64) tokens");
 			if (q->rwmd_injective) return fail(VK_ERR_INVALID, "non-relaxed WMD with injective mapping is not supported");      // wmd.h:201-204
 			if (q->rwmd_symmetric) return fail(VK_ERR_INVALID, "non-relaxed WMD with symmetric computation is not supported");  // wmd.h:206-209
-		} else if (!q->rwmd_injective)
-			return fail(VK_ERR_UNSUPPORTED, "non-injective RWMD (rwmd('nbow/distributed')) is not implemented on the HIP path");
+		} else if (!q->rwmd_injective && q->len_t > VK_FAST_QUERY_LEN)
+			return fail(VK_ERR_UNSUPPORTED, "non-injective RWMD (rwmd('nbow/distributed')) is implemented for queries of at most 16 tokens");
 		if (q->want_flow && (!out->mapping || !out->edge_sim)) return fail(VK_ERR_INVALID, "want_flow needs mapping and edge_sim arrays");
 	} else if (q->algorithm == VK_ALG_WRD) {
 		if (c->max_len > VK_FAST_SENT_LEN) return fail(VK_ERR_UNSUPPORTED, "VK_ALG_WRD needs every slice <= VK_FAST_SENT_LEN (64) tokens");
@@ -524,6 +524,23 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		p.rwmd_symmetric = q->rwmd_symmetric;
 		p.rwmd_normalize_bow = q->rwmd_normalize_bow;
 		if (q->wmd_full) p.wmd_bound = q->rwmd_normalize_bow ? 1 : 2;
+		else if (!q->rwmd_injective) {
+			// 1:n form: masses of the query's vocabulary entries (count / len at the first occurrence of a token id)
+			p.gap_mode = 7;
+			const bool ids = c->desc.layout == VK_LAYOUT_STATIC && q->q_token_ids;
+			for (int j = 0; j < VK_FAST_QUERY_LEN; j++) {
+				float mass = 0.0f;
+				if (j < q->len_t) {
+					int cnt = 1;
+					bool first = true;
+					if (ids && q->q_token_ids[j] >= 0)
+						for (int i = 0; i < q->len_t; i++)
+							if (i != j && q->q_token_ids[i] == q->q_token_ids[j]) { cnt++; if (i < j) first = false; }
+					mass = first ? (q->rwmd_normalize_bow ? (float)cnt / (float)q->len_t : (float)cnt) : 0.0f;
+				}
+				p.qmass[j] = mass;
+			}
+		}
 	} else if (ks == VK_GAP_LINEAR && kt == VK_GAP_LINEAR) {
 		p.gap_mode = 0;
 		p.gs = q->gap_s.u; p.gt = q->gap_t.u;
@@ -622,6 +639,8 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	p.h_rows = c->max_short_len + 1;
 	int lds_floats = p.s_rows_per_wave * 16;
 	if (p.gap_mode == 2) lds_floats += 4 * p.h_rows * 16;   // column history of dp_general
+	p.m_rows = (c->max_short_len + 4) / 4 * 4;
+	if (p.gap_mode == 7) lds_floats += 4 * p.m_rows;       // vocabulary masses of the 4 slices (static layout)
 	p.lds_floats_per_wave = lds_floats;
 	size_t smem = (size_t)lds_floats * 4 * 4;   // 4 waves per block
 	const size_t qlds = (!is_static && c->nk32 == 24 && c->tail == 0) ? (size_t)c->nk32 * 1024 : 0;   // MODE 3: query tile in LDS
@@ -640,6 +659,8 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		pl.h_rows = 0;
 		int lf = pl.s_rows_per_wave * 16;
 		if (pl.gap_mode == 2) lf += (c->max_len + 1) * 16;
+		pl.m_rows = 0;
+		if (pl.gap_mode == 7) lf += (c->max_len + 4) / 4 * 4;
 		pl.lds_floats_per_wave = lf;
 		const size_t smem_l = (size_t)lf * 4 + qlds;
 		if (smem_l > 160 * 1024) return fail(VK_ERR_UNSUPPORTED, "LDS demand of the long-slice pass exceeds 160 KiB");

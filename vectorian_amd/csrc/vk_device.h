@@ -61,6 +61,7 @@ struct VkScoreParams {
 	int32_t lds_floats_per_wave;
 	int32_t s_rows_per_wave;   // rows of the similarity staging area
 	int32_t h_rows;            // general gap: history rows per sentence (max_len + 1)
+	int32_t m_rows;            // GAP 7, static layout: floats per sentence of the mass scratch (after the S strip)
 };
 
 struct VkRwmdBatchParams {

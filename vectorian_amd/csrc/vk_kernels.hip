@@ -563,6 +563,99 @@ __device__ __forceinline__ float rwmd_rows(const float *__restrict__ S, int rowb
 	return (max_cost - cost) / max_cost;
 }
 
+// Relaxed Word Mover's Distance, 1:n form (rwmd('nbow/distributed'); RelaxedSolver with injective = false,
+// vectorian/core/cpp/alignment/wmd.h:339-376): every source ships its mass to the targets in order of
+// ascending distance, each target taking at most its own mass; as upstream is written, whatever the last
+// (partial) shipment carried is charged once more at the maximum distance 1 (wmd.h:373-375 keeps
+// `remaining` after the break).  Sources and targets are vocabulary entries: q_mass / smass hold count / len
+// at the first occurrence of a token and 0 at its repetitions, which then neither ship nor receive
+// (contextual layout: every position is an entry of its own).
+//   direction 0 (t -> s): lane = source (query token); its column is consumed in ascending (distance, row)
+//     order, one selection sweep over the rows per target taken;
+//   direction 1 (s -> t): row = source; the 16 lanes of the DPP row are the targets, selected by a row
+//     minimum over keys (distance bits with the lane in the low 4 bits: distances closer than 2^-19
+//     relative may swap, which moves the cost by less than 1e-7).
+template <int LT>
+__device__ __forceinline__ float rwmd_fill_rows(const float *__restrict__ S, const float *__restrict__ smass, int rowbase, int len, int maxlen,
+	int lane, const DpArgs &a, float q_mass) {
+	const int v = lane & 15, sigma = lane >> 4;
+	const int len_t = a.len_t;
+	const bool nbow = a.rwmd_normalize_bow != 0;
+	const bool col_ok = v < len_t;
+	const float cap_s = nbow ? 1.0f / (float)(len > 0 ? len : 1) : 1.0f;   // capacity of a slice position
+	const float INF = __builtin_inff();
+
+	// ---- direction 0
+	float rem = col_ok ? q_mass : 0.0f, cost0 = 0.0f, last_d = -1.0f;
+	int last_i = -1;
+	bool fin = !(rem > 0.0f) || len < 1;
+	for (int round = 0; round < maxlen && __any(!fin); round++) {
+		float bd = INF;
+		int bi = -1;
+		for (int u = 1; u <= maxlen; u++) {
+			const bool act = u <= len;
+			const float dist = fmaxf(1.0f - S[(rowbase + (act ? u - 1 : 0)) * 16 + v], 0.0f);
+			const bool later = dist > last_d || (dist == last_d && u - 1 > last_i);
+			if (act && later && dist < bd) { bd = dist; bi = u - 1; }
+		}
+		if (!fin) {
+			// capacity of the target: the mass of its vocabulary entry (0 at the repetitions of a token)
+			const float cap = (smass && bi >= 0) ? smass[bi] : cap_s;
+			if (bi < 0) fin = true;
+			else if (rem <= cap) { cost0 += rem * bd; fin = true; }
+			else { rem -= cap; cost0 += cap * bd; last_d = bd; last_i = bi; }
+		}
+	}
+	if (rem > 0.0f) cost0 += rem;
+	// sum over the query columns in order, lane by lane (as rwmd_rows)
+	float sum = cost0;
+#pragma unroll
+	for (int i = 1; i < LT; i++) {
+		const float t = dpp_f<DPP_ROW_SHR1>(0.0f, sum);
+		if (v == i) sum = t + cost0;
+	}
+	float acc0 = (v == len_t - 1) ? sum : VK_NEG_INF;
+	acc0 = row_max_to_lane15(acc0);
+
+	// ---- direction 1
+	float acc1 = 0.0f;
+	if (a.rwmd_symmetric) {
+		for (int u = 1; u <= maxlen; u++) {
+			const bool act = u <= len;
+			const float dist = fmaxf(1.0f - S[(rowbase + (act ? u - 1 : 0)) * 16 + v], 0.0f);
+			float r1 = act ? (smass ? smass[u - 1] : cap_s) : 0.0f;
+			float cost = 0.0f;
+			bool used = !col_ok, done = !(r1 > 0.0f);
+			for (int r = 0; r < LT && __any(!done); r++) {
+				int key = used ? 0x7fffffff : ((__builtin_bit_cast(int, dist) & ~15) | v);
+				key = min(key, __builtin_amdgcn_update_dpp(key, key, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+				key = min(key, __builtin_amdgcn_update_dpp(key, key, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+				key = min(key, __builtin_amdgcn_update_dpp(key, key, 0x141, 0xf, 0xf, false));   // row_half_mirror
+				key = min(key, __builtin_amdgcn_update_dpp(key, key, 0x140, 0xf, 0xf, false));   // row_mirror
+				const int tl = key & 15;
+				const float td = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((sigma * 16 + tl) * 4, __builtin_bit_cast(int, dist)));
+				const float tc = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((sigma * 16 + tl) * 4, __builtin_bit_cast(int, q_mass)));
+				if (!done) {
+					if (key == 0x7fffffff) done = true;
+					else if (r1 <= tc) { cost += r1 * td; done = true; }
+					else { r1 -= tc; cost += tc * td; }
+				}
+				if (v == tl) used = true;
+			}
+			if (r1 > 0.0f) cost += r1;
+			acc1 += cost;
+		}
+	}
+	if (!nbow) {
+		acc0 = acc0 / (float)len_t;
+		acc1 = acc1 / (float)(len > 0 ? len : 1);
+	}
+	float cost = acc0;
+	if (a.rwmd_symmetric) { cost = 0.0f; if (acc0 > cost) cost = acc0; if (acc1 > cost) cost = acc1; }
+	const float max_cost = nbow ? 1.0f : (float)len_t;
+	return (max_cost - cost) / max_cost;
+}
+
 // Word Rotator's Distance, stage 1: an upper bound of the score for every sentence.
 // WRD = 1 - EMD of the transport problem with masses |x| / sum|x| and costs max(0, 1 - S)
 // (vectorian/core/cpp/alignment/wrd.h:62-146).  Every unit of mass travels at least to its nearest
@@ -613,7 +706,8 @@ __device__ __forceinline__ float wrd_bound_rows(const float *__restrict__ S, int
 //      3 general, sentences <= 32 tokens, strictly subadditive w_t (register history),
 //      4 relaxed word mover's distance (no DP: row / column minima of 1 - S),
 //      5 word rotator's distance, upper bound of the score (stage 1),
-//      6 as 3 for sentences <= 64 tokens.
+//      6 as 3 for sentences <= 64 tokens,
+//      7 relaxed word mover's distance, 1:n form (greedy fill by ascending distance).
 // LT: padded query length (4, 8, 12, 16).
 // ---------------------------------------------------------------------------
 
@@ -745,6 +839,28 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 		else if constexpr (GAP == 3) raw = dp_general_reg<LT, 32>(S, rb, lenc, maxlen, v, a, wsr, wtr);
 		else if constexpr (GAP == 6) raw = dp_general_reg<LT, 64>(S, rb, lenc, maxlen, v, a, wsr, wtr);
 		else if constexpr (GAP == 4) raw = rwmd_rows<LT>(S, rb, lenc, maxlen, v, a);
+		else if constexpr (GAP == 7) {
+			// masses of the slice's vocabulary entries (static layout: repeated token ids count once, at their
+			// first position); stride 0 in the pass over long slices, where only DPP row 0 holds a slice
+			float *sm = nullptr;
+			if (MODE == 2) {
+				sm = Hh + sigma * p.m_rows;
+				const float unit = p.rwmd_normalize_bow ? 1.0f / (float)(lenc > 0 ? lenc : 1) : 1.0f;
+				for (int u = v; u < lenc; u += 16) {
+					const int id = p.tok_id[t_a + u];
+					int cnt = 0;
+					bool first = true;
+					for (int i = 0; i < lenc; i++) {
+						const bool same = p.tok_id[t_a + i] == id;
+						cnt += same ? 1 : 0;
+						first = first && !(same && i < u);
+					}
+					sm[u] = first ? (float)cnt * unit : 0.0f;
+				}
+				wave_lds_fence();
+			}
+			raw = rwmd_fill_rows<LT>(S, sm, rb, lenc, maxlen, lane, a, p.qmass[v]);
+		}
 		else raw = wrd_bound_rows<LT>(S, rb, lenc, maxlen, v, a, p.mag + (len > 0 ? t_a : 0), p.qmass[v]);
 
 		if (v == 15 && s_idx < p.n_sent) {
@@ -2158,6 +2274,7 @@ static hipError_t launch_score_gap(const VkScoreParams &p, int grid, size_t smem
 	case 4: return launch_score_lt<MODE, NK32, TAIL, 4>(p, grid, smem, stream);
 	case 5: return launch_score_lt<MODE, NK32, TAIL, 5>(p, grid, smem, stream);
 	case 6: return launch_score_lt<MODE, NK32, TAIL, 6>(p, grid, smem, stream);
+	case 7: return launch_score_lt<MODE, NK32, TAIL, 7>(p, grid, smem, stream);
 	default: return launch_score_lt<MODE, NK32, TAIL, 2>(p, grid, smem, stream);
 	}
 }
