@@ -11,8 +11,9 @@ from helpers import assert_same_results
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("normalize", [True, False])
 @pytest.mark.parametrize("shape", ["q10_len32", "q5_ragged", "q16_ragged64"])
-def test_contextual_wrd(hip, oracle, shape):
+def test_contextual_wrd(hip, oracle, shape, normalize):
 	n, lo, hi, len_t, d = {"q10_len32": (1500, 32, 32, 10, 128), "q5_ragged": (1200, 1, 40, 5, 96),
 		"q16_ragged64": (600, 8, 64, 16, 768)}[shape]
 	corpus = synth.make_contextual_corpus(n, lo, hi, 2000, d, noise=0.3, norm_sigma=0.25)
@@ -27,8 +28,8 @@ def test_contextual_wrd(hip, oracle, shape):
 		qv = (q["vectors"] * rng.lognormal(0, 0.25, size=(len_t, 1))).astype(np.float32)
 		Qb, qmag = oracle.normalize_rows_bf16(qv)
 		ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=corpus["sent_off"], X=Xb, X_mag=mag, Q=Qb, Q_mag=qmag,
-			algorithm=oracle.ALG_WRD, max_matches=10, min_score=0.0, n_threads=8)
-		got = c.query(qv, algorithm=hip.VK_ALG_WRD, q_normalize=True, max_matches=10, min_score=0.0)
+			algorithm=oracle.ALG_WRD, max_matches=10, min_score=0.0, n_threads=8, wrd_normalize=normalize)
+		got = c.query(qv, algorithm=hip.VK_ALG_WRD, q_normalize=True, max_matches=10, min_score=0.0, wrd_normalize=normalize)
 		assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=1e-5)
 	c.close()
 

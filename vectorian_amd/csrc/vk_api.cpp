@@ -448,8 +448,6 @@ static int validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_t
 		if (c->desc.layout != VK_LAYOUT_CONTEXTUAL)
 			return fail(VK_ERR_UNSUPPORTED, "VK_ALG_WRD is implemented for the contextual layout only");
 		if (!c->d_mag) return fail(VK_ERR_STATE, "VK_ALG_WRD needs a corpus created with keep_magnitudes = 1");
-		if (!q->wrd_normalize_magnitudes)
-			return fail(VK_ERR_UNSUPPORTED, "WordRotatorsDistance(normalize_magnitudes=False) is not implemented on the HIP path");
 		if (q->want_flow && (!out->mapping || !out->edge_sim)) return fail(VK_ERR_INVALID, "want_flow needs mapping and edge_sim arrays");
 	} else {
 		return fail(VK_ERR_INVALID, "bad algorithm");
@@ -517,7 +515,9 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		p.gap_mode = 5;
 		float sum_t = 0.0f;
 		for (int j = 0; j < q->len_t; j++) sum_t += qmags[j];           // wrd.h:99-102, float sum in order
-		for (int j = 0; j < VK_FAST_QUERY_LEN; j++) p.qmass[j] = j < q->len_t ? qmags[j] / sum_t : 0.0f;
+		const bool rawm = !q->wrd_normalize_magnitudes;   // wrd.h:99-102: masses stay the magnitudes
+		for (int j = 0; j < VK_FAST_QUERY_LEN; j++) p.qmass[j] = j < q->len_t ? (rawm ? qmags[j] : qmags[j] / sum_t) : 0.0f;
+		p.wrd_raw_total = rawm ? sum_t : 0.0f;
 		p.mag = c->d_mag;
 	} else if (q->algorithm == VK_ALG_RWMD) {
 		p.gap_mode = 4;
@@ -695,6 +695,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		w.qtile = c->d_qtile; w.len_t = q->len_t; w.mag = c->d_mag;
 		w.mass_mode = q->algorithm == VK_ALG_WRD ? 0 : (q->rwmd_normalize_bow ? 1 : 2);
 		memcpy(w.qmass, p.qmass, sizeof w.qmass);
+		w.raw_masses = (q->algorithm == VK_ALG_WRD && !q->wrd_normalize_magnitudes) ? 1 : 0;
 		w.boost = p.boost; w.raw_out = c->d_wrd_raw; w.val_out = c->d_wrd_val;
 		// solves the `count` candidates whose keys sit at d_keys, merges them into `best`; returns the smallest bound among them
 		auto solve = [&](const uint64_t *d_keys, int count, float *ub_min, int *n_cand_out) -> int {

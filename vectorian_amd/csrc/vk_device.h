@@ -53,7 +53,8 @@ struct VkScoreParams {
 	float tw_threshold;
 	float ref_total;           // reference_score: len_t, or sum(tw)
 	const float *mag;          // WRD: token magnitudes (contextual) / vocabulary magnitudes (static)
-	float qmass[VK_DEV_MAX_QUERY_LEN];   // WRD: query masses |q_j| / sum |q|
+	float qmass[VK_DEV_MAX_QUERY_LEN];   // WRD: query masses |q_j| / sum |q| (or |q_j| when wrd_raw_total > 0)
+	float wrd_raw_total;       // WRD with normalize_magnitudes = false: sum |q_j|; 0 otherwise
 	// outputs
 	float *scores;             // Score::value per sentence (-inf: empty slice)
 	float *raw;                // aligner score per sentence
@@ -94,6 +95,7 @@ struct VkWrdParams {
 	const float *mag;
 	float qmass[VK_DEV_MAX_QUERY_LEN];
 	int32_t mass_mode;         // 0: magnitudes (WRD); 1: 1/len per token (nbow); 2: 1 per token (bow)
+	int32_t raw_masses;        // mass_mode 0: magnitudes as they are (normalize_magnitudes = false)
 	const float *boost;
 	const uint64_t *keys;      // candidates (0 = empty slot)
 	float *raw_out;            // [n_cand]

@@ -283,6 +283,7 @@ struct DpArgs {
 	const float *ws;       // general: w_s[0..max_len]
 	const float *wt;       // general: w_t[0..16]
 	int32_t rwmd_symmetric, rwmd_normalize_bow, wmd_bound;
+	float wrd_raw_total;   // WRD on raw magnitudes: sum of the query's magnitudes (0: masses are normalised)
 };
 
 // In-row dependency of the linear recurrence H[u][j] = max(c[j], H[u][j-1] - gt): because
@@ -692,7 +693,14 @@ __device__ __forceinline__ float wrd_bound_rows(const float *__restrict__ S, int
 	x += dpp_f<DPP_ROW_SHR2>(0.0f, x);
 	x += dpp_f<DPP_ROW_SHR4>(0.0f, x);
 	x += dpp_f<DPP_ROW_SHR8>(0.0f, x);
-	const float lb = fmaxf(x, lb1);
+	float lb;
+	if (a.wrd_raw_total > 0.0f) {
+		// magnitudes as they are (normalize_magnitudes = false): min(sum_t, sum_s) units are shipped and the score
+		// is 1 - cost / shipped; only the lighter side ships everything, so only its relaxed cost is a bound
+		const float sum_t = a.wrd_raw_total;
+		lb = (sum_t <= sum_s ? x / sum_t : lb1) * (1.0f - 2e-6f);
+		if (!(sum_s > 0.0f)) lb = 0.0f;
+	} else lb = fmaxf(x, lb1);
 	return fminf(1.0f - lb + 3e-5f, 1.0f);
 }
 
@@ -737,6 +745,7 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 	a.gs = p.gs; a.gt = p.gt; a.a_s = p.a_s; a.a_t = p.a_t; a.open_s = p.open_s; a.open_t = p.open_t;
 	a.ws = p.ws; a.wt = p.wt;
 	a.rwmd_symmetric = p.rwmd_symmetric; a.rwmd_normalize_bow = p.rwmd_normalize_bow; a.wmd_bound = p.wmd_bound;
+	a.wrd_raw_total = p.wrd_raw_total;
 	const float inv_ref = p.ref_total;
 	// tag-weighted modifier: this lane's four query columns (MFMA layout: 4*(lane>>4) + r)
 	float twl[4] = {1.0f, 1.0f, 1.0f, 1.0f};
@@ -1971,7 +1980,7 @@ __global__ __launch_bounds__(64) void vk_wrd_exact_kernel(VkWrdParams p) {
 	if (p.mass_mode == 0) {
 		float sum_s = 0.0f;
 		for (int i = 0; i < m; i++) sum_s += p.mag[t_a + i];       // in position order, as upstream
-		if (has) dem = (double)(p.mag[t_a + lane] / sum_s);
+		if (has) dem = (double)(p.raw_masses ? p.mag[t_a + lane] : p.mag[t_a + lane] / sum_s);
 		if (lane < VK_WRD_N) sup[lane] = lane < n ? (double)p.qmass[lane] : 0.0;
 	} else {
 		// bags of words over positions: 1 per token (bow), or 1/len (nbow, bow.h:262-270)
