@@ -76,7 +76,7 @@ typedef struct {
 	int64_t n_tokens;      /* total tokens of this shard (< 2^31) */
 	int64_t n_sentences;   /* slices of this shard */
 	int32_t vocab_size;    /* VK_LAYOUT_STATIC: rows of the vocabulary table */
-	int32_t keep_magnitudes; /* keep |x| per token (needed by VK_ALG_WRD, metric/contextual.cpp:49-54) */
+	int32_t keep_magnitudes; /* keep |x| per appended row (needed by VK_ALG_WRD; metric/contextual.cpp:49-54, metric/static.cpp:69-73) */
 } vk_corpus_desc;
 
 typedef struct {

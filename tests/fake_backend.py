@@ -76,7 +76,7 @@ class OracleCorpus:
 			pos_s=self._pos, tag_weights=tag_weights, q_pos=q_pos, pos_mismatch_penalty=pos_mismatch_penalty,
 			similarity_threshold=similarity_threshold, wmd_full=wmd_full)
 		if self.layout == core.VK_LAYOUT_STATIC:
-			kw.update(tok_id=self._ids, E=self._X, q_ids=q_token_ids)
+			kw.update(tok_id=self._ids, E=self._X, q_ids=q_token_ids, X_mag=self._mag[self._ids], Q_mag=qmag)
 		else:
 			kw.update(X=self._X, X_mag=self._mag, Q_mag=qmag)
 		r = vo.find(**kw)

@@ -34,6 +34,28 @@ def test_contextual_wrd(hip, oracle, shape, normalize):
 	c.close()
 
 
+def test_static_layout_wrd(hip, oracle):
+	# static embeddings carry magnitudes too (metric/static.cpp:69-73, 80-120): mass of a token = magnitude of its vocabulary vector
+	corpus = synth.make_static_corpus(900, 1, 40, 400, 64, seed=21)
+	rng = np.random.default_rng(22)
+	E = (corpus["E"] * rng.lognormal(0, 0.3, size=(400, 1))).astype(np.float32)
+	Eb, emag = oracle.normalize_rows_bf16(E)
+	off, ids = corpus["sent_off"], corpus["tok_id"]
+	c = hip.Corpus(layout=hip.VK_LAYOUT_STATIC, d=64, n_tokens=len(ids), n_sentences=len(off) - 1, vocab_size=400, keep_magnitudes=True)
+	c.append_vectors(E, normalize=True)
+	c.set_token_ids(ids)
+	c.set_sentences(off)
+	c.finalize()
+	for normalize in (True, False):
+		for _ in range(2):
+			q_ids = rng.integers(0, 60, size=7).astype(np.int32)
+			ref = oracle.find(layout=oracle.LAYOUT_STATIC, d=64, sent_off=off, tok_id=ids, E=Eb, X_mag=emag[ids], Q=Eb[q_ids], q_ids=q_ids,
+				Q_mag=emag[q_ids], algorithm=oracle.ALG_WRD, max_matches=10, min_score=0.0, wrd_normalize=normalize)
+			got = c.query(E[q_ids], q_token_ids=q_ids, algorithm=hip.VK_ALG_WRD, q_normalize=True, max_matches=10, min_score=0.0, wrd_normalize=normalize)
+			assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=1e-5)
+	c.close()
+
+
 def test_wrd_needs_magnitudes(hip):
 	corpus = synth.make_contextual_corpus(10, 4, 8, 100, 32)
 	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=32, n_tokens=corpus["X"].shape[0], n_sentences=10)

@@ -157,6 +157,25 @@ def test_contextual_embedding_and_boost():
 	assert len(r) == 3
 
 
+def test_transport_strategies_over_static_embedding():
+	"""WordRotatorsDistance and the named RWMD variants through Index.find on a static embedding (vocabulary magnitudes)."""
+	session, emb, words, rng = toy_session(n_docs=2, sents_per_doc=40, V=120, d=24)
+	ts = EmbeddingTokenSim(emb, CosineSim())
+	doc = session.documents[1]
+	st = doc.spans["sentence"]["start"][5]
+	planted = " ".join(doc.tokens[st:st + 4])
+	for strategy in (alignment.WordRotatorsDistance(), alignment.WordRotatorsDistance(normalize_magnitudes=False),
+			alignment.WordMoversDistance.rwmd("nbow"), alignment.WordMoversDistance.rwmd("nbow/distributed"),
+			alignment.WordMoversDistance.rwmd("bow/fast")):
+		index = session.index(OptimizedSpanSim(ts, strategy), corpus_factory=OracleCorpus)
+		result = index.find(planted, n=3, options={"submatch_weight": 1.0})   # transport: reference stays len_t
+		assert len(result) == 3
+		scores = [m.score for m in result]
+		assert scores == sorted(scores, reverse=True) and scores[0] > 0
+		if isinstance(strategy, alignment.WordRotatorsDistance):
+			assert (1, 5) in [(m.doc_index, m.slice_id) for m in result]
+
+
 def test_unsupported_options_are_explicit():
 	session, emb, words, rng = toy_session(n_docs=1, sents_per_doc=3, V=50, d=16)
 	ts = EmbeddingTokenSim(emb, CosineSim())

@@ -150,7 +150,6 @@ int vk_corpus_create(const vk_corpus_desc *desc, vk_corpus_t **out) {
 	if (desc->n_tokens < 0 || desc->n_tokens >= (1ll << 31) - 64) return fail(VK_ERR_INVALID, "n_tokens must be < 2^31 per shard");
 	if (desc->n_sentences < 0 || desc->n_sentences >= (1ll << 31) - 8) return fail(VK_ERR_INVALID, "n_sentences out of range");
 	if (desc->layout == VK_LAYOUT_STATIC && desc->vocab_size < 1) return fail(VK_ERR_INVALID, "static layout needs vocab_size >= 1");
-	if (desc->layout == VK_LAYOUT_STATIC && desc->keep_magnitudes) return fail(VK_ERR_UNSUPPORTED, "magnitudes are kept for the contextual layout only");
 
 	int dev = 0;
 	VK_HIP(hipGetDevice(&dev));
@@ -445,8 +444,6 @@ static int validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_t
 	} else if (q->algorithm == VK_ALG_WRD) {
 		if (c->max_len > VK_FAST_SENT_LEN) return fail(VK_ERR_UNSUPPORTED, "VK_ALG_WRD needs every slice <= VK_FAST_SENT_LEN (64) tokens");
 		if (q->tag_weights) return fail(VK_ERR_UNSUPPORTED, "tag-weighted similarity is implemented for alignments only");
-		if (c->desc.layout != VK_LAYOUT_CONTEXTUAL)
-			return fail(VK_ERR_UNSUPPORTED, "VK_ALG_WRD is implemented for the contextual layout only");
 		if (!c->d_mag) return fail(VK_ERR_STATE, "VK_ALG_WRD needs a corpus created with keep_magnitudes = 1");
 		if (q->want_flow && (!out->mapping || !out->edge_sim)) return fail(VK_ERR_INVALID, "want_flow needs mapping and edge_sim arrays");
 	} else {

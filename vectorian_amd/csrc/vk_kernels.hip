@@ -665,7 +665,7 @@ __device__ __forceinline__ float rwmd_fill_rows(const float *__restrict__ S, con
 // Stage 2 (vk_wrd_exact_kernel) solves the survivors exactly.
 template <int LT>
 __device__ __forceinline__ float wrd_bound_rows(const float *__restrict__ S, int rowbase, int len, int maxlen, int v,
-	const DpArgs &a, const float *__restrict__ mag, float q_mass) {
+	const DpArgs &a, const float *__restrict__ mag, const int32_t *__restrict__ ids, float q_mass) {
 	const int len_t = a.len_t;
 	const bool col_ok = v < len_t;
 	// one sweep: sum of the slice's magnitudes and sum of magnitude x nearest distance (the quotient is the
@@ -683,7 +683,7 @@ __device__ __forceinline__ float wrd_bound_rows(const float *__restrict__ S, int
 		m = fminf(m, dpp_f<DPP_ROW_SHR2>(m, m));
 		m = fminf(m, dpp_f<DPP_ROW_SHR4>(m, m));
 		m = fminf(m, dpp_f<DPP_ROW_SHR8>(m, m));
-		const float mg = act ? mag[u - 1] : 0.0f;
+		const float mg = act ? (ids ? mag[ids[u - 1]] : mag[u - 1]) : 0.0f;   // static layout: magnitude of the vocabulary entry
 		sum_s += mg;
 		lb1n += mg * m;
 	}
@@ -870,7 +870,8 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 			}
 			raw = rwmd_fill_rows<LT>(S, sm, rb, lenc, maxlen, lane, a, p.qmass[v]);
 		}
-		else raw = wrd_bound_rows<LT>(S, rb, lenc, maxlen, v, a, p.mag + (len > 0 ? t_a : 0), p.qmass[v]);
+		else if constexpr (MODE == 2) raw = wrd_bound_rows<LT>(S, rb, lenc, maxlen, v, a, p.mag, p.tok_id + (len > 0 ? t_a : 0), p.qmass[v]);
+		else raw = wrd_bound_rows<LT>(S, rb, lenc, maxlen, v, a, p.mag + (len > 0 ? t_a : 0), nullptr, p.qmass[v]);
 
 		if (v == 15 && s_idx < p.n_sent) {
 			// Score::value = raw / reference_score * boost; reference_score == len_t for
@@ -1978,9 +1979,11 @@ __global__ __launch_bounds__(64) void vk_wrd_exact_kernel(VkWrdParams p) {
 	// masses (wrd.h:99-102) and costs (:104-109)
 	double dem = 0.0;
 	if (p.mass_mode == 0) {
+		const bool by_id = p.layout == VK_DEV_LAYOUT_STATIC;       // static layout: magnitudes of the vocabulary entries
 		float sum_s = 0.0f;
-		for (int i = 0; i < m; i++) sum_s += p.mag[t_a + i];       // in position order, as upstream
-		if (has) dem = (double)(p.raw_masses ? p.mag[t_a + lane] : p.mag[t_a + lane] / sum_s);
+		for (int i = 0; i < m; i++) sum_s += by_id ? p.mag[p.tok_id[t_a + i]] : p.mag[t_a + i];       // in position order, as upstream
+		const float mine = has ? (by_id ? p.mag[p.tok_id[t_a + lane]] : p.mag[t_a + lane]) : 0.0f;
+		if (has) dem = (double)(p.raw_masses ? mine : mine / sum_s);
 		if (lane < VK_WRD_N) sup[lane] = lane < n ? (double)p.qmass[lane] : 0.0;
 	} else {
 		// bags of words over positions: 1 per token (bow), or 1/len (nbow, bow.h:262-270)

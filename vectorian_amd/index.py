@@ -430,10 +430,11 @@ class HipBruteForceIndex(Index):
 		emb = self._embedding
 		if emb.is_static:
 			vocab_vectors = emb.encode_tokens(session.vocab.tokens)
+			# magnitudes are kept for WordRotatorsDistance (metric/static.cpp:69-73, 80-120); rows are normalised on upload
 			self._corpus = make(layout=core.VK_LAYOUT_STATIC, d=emb.dimension, n_tokens=n_tokens, n_sentences=n_slices,
-				vocab_size=max(1, session.vocab.size), device=device)
-			E = vocab_vectors.normalized if session.vocab.size else np.zeros((1, emb.dimension), np.float32)
-			self._corpus.append_vectors(E, normalize=False)
+				vocab_size=max(1, session.vocab.size), keep_magnitudes=True, device=device)
+			E = vocab_vectors.unmodified if session.vocab.size else np.zeros((1, emb.dimension), np.float32)
+			self._corpus.append_vectors(E, normalize=True)
 			ids = np.concatenate([session.doc_token_ids(i) for i in range(len(session.documents))]) if n_tokens else np.zeros(0, np.int32)
 			self._corpus.set_token_ids(ids)
 		elif emb.is_contextual:
@@ -525,7 +526,7 @@ class HipBruteForceIndex(Index):
 		emb = self._embedding
 		qv = emb.encode_tokens(p_query.tokens)
 		if emb.is_static:
-			top = self._corpus.query(qv.normalized, q_normalize=False, q_token_ids=p_query.token_ids,
+			top = self._corpus.query(qv.unmodified, q_normalize=True, q_token_ids=p_query.token_ids,
 				boost=self._boost, want_flow=True, **args)
 		else:
 			top = self._corpus.query(qv.unmodified, q_normalize=True, boost=self._boost, want_flow=True, **args)
