@@ -165,15 +165,28 @@ def main():
 
 	from vectorian_amd import shards
 
+	pending = [None]   # exchange of the previous query, in flight while this one is scored
+
+	def drain():
+		if pending[0] is not None:
+			merged = shards.allgather_finish(pending[0])   # global top-k of the previous query on every rank
+			pending[0] = None
+			return merged
+		return None
+
 	def step(q):
 		top = corpus.query(q, locality=core.Locality.LOCAL, gap_s=gs, gap_t=gt, q_normalize=True,
 			max_matches=K_MATCHES, min_score=0.0, want_flow=True)
 		if world == 1:
 			return top
-		# per-rank result sets -> all ranks (RCCL all-gather over xGMI), then ResultSet.extend
-		return shards.allgather_merge(top, rank * n_sent, K_MATCHES, device=xdev)
+		# per-rank result sets -> all ranks (RCCL all-gather over xGMI), then ResultSet.extend; the collective of
+		# query i overlaps the scoring of query i + 1, every query's merged result is produced inside the timed region
+		merged = drain()
+		pending[0] = shards.allgather_start(top, rank * n_sent, K_MATCHES, device=xdev)
+		return merged
 
 	def sync():
+		drain()
 		torch.cuda.synchronize()
 		if dist is not None:
 			dist.barrier()

@@ -32,7 +32,10 @@ def main(outdir):
 		for name, loc in (("local", 0), ("global", 1)):
 			top = shard.query(q["vectors"], locality=loc, gap_s=0.1, gap_t=0.1, max_matches=12,
 				min_score=0.0 if loc == 0 else -100.0)
-			merged = shards.allgather_merge(top, a, 12)
+			if qi % 2 == 0:
+				merged = shards.allgather_merge(top, a, 12)
+			else:   # the pipelined form bench.py uses
+				merged = shards.allgather_finish(shards.allgather_start(top, a, 12))
 			out[f"{qi}_{name}_score"] = merged.score[:merged.n]
 			out[f"{qi}_{name}_sentence"] = merged.sentence[:merged.n]
 			out[f"{qi}_{name}_mapping"] = merged.mapping[:merged.n]

@@ -62,6 +62,29 @@ def unpack_topk(buf, len_t):
 	return t
 
 
+def allgather_start(top, sentence_offset, k, group=None, device=None):
+	"""starts the exchange of this rank's result set and returns a handle for allgather_finish; the collective
+	runs while the caller scores the next query (one query of latency hidden per step)"""
+	import torch
+	import torch.distributed as dist
+
+	world = dist.get_world_size(group)
+	if device is None:
+		device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+	send = torch.from_numpy(pack_topk(top, sentence_offset, k)).to(device, non_blocking=True)
+	recv = torch.empty((world * k, send.shape[1]), dtype=send.dtype, device=device)   # concatenated along dim 0
+	work = dist.all_gather_into_tensor(recv, send, group=group, async_op=True)
+	return work, recv, send, world, k, top.len_t
+
+
+def allgather_finish(handle):
+	work, recv, send, world, k, len_t = handle
+	work.wait()
+	allr = recv.cpu().numpy().reshape(world, k, send.shape[1])
+	sets = [unpack_topk(allr[r], len_t) for r in range(world)]
+	return core.merge_topk(sets, len_t, k)
+
+
 def allgather_merge(top, sentence_offset, k, group=None, device=None):
 	"""all ranks contribute their local result set; every rank returns the merged global one"""
 	import torch
