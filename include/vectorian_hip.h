@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 1
+#define VK_ABI_VERSION 2
 #define VK_MAX_QUERY_LEN 64   /* query tokens */
 #define VK_FAST_QUERY_LEN 16  /* queries up to this length run in the fused kernels (one 16-wide MFMA column block); longer ones
                                  (alignments and injective RWMD only) take a one-wave-per-slice kernel, ~10x slower */
@@ -134,6 +134,14 @@ typedef struct {
 	                            (metric/alignment.h:194-196); NULL if !want_flow */
 	float *edge_sim;         /* [capacity x len_t] S[mapping[j]][j] (ScoreComputer, metric/alignment.h:335-345
 	                            reports distance = 1 - this); NULL if !want_flow */
+	/* transport algorithms (VK_ALG_RWMD, VK_ALG_WRD) with want_flow: what the host needs to state the flow of a
+	 * winner as SparseFlow / DenseFlow (match/match.h:140-260; alignment/wmd.h:392-408, 228-248; wrd.h:120-135).
+	 * Optional (NULL: not produced); filled for corpora whose slices have at most VK_FAST_SENT_LEN tokens and
+	 * queries of at most VK_FAST_QUERY_LEN tokens. */
+	float *sim_rows;         /* [capacity x VK_FAST_SENT_LEN x 16] similarity S[i][j] of slice token i and query token j
+	                            (clipped, static layout: sim[id(t_j)][j] = 1); rows >= the slice's length are zero */
+	float *plan;             /* [capacity x 16 x VK_FAST_SENT_LEN] exact transport only (VK_ALG_WRD, wmd_full): the optimal
+	                            plan G[j][i], mass moved from query token j to slice token i (positions) */
 } vk_topk_out;
 
 /* kernel timings of the last vk_query on a handle, milliseconds, from HIP events

@@ -81,7 +81,8 @@ class OracleCorpus:
 			kw.update(X=self._X, X_mag=self._mag, Q_mag=qmag)
 		r = vo.find(**kw)
 		self._all = r["all_scores"]
-		top = core.TopK(max_matches, len(q))
+		transport = algorithm != core.VK_ALG_ALIGN and want_flow
+		top = core.TopK(max_matches, len(q), transport=transport)
 		n = len(r["score"])
 		top.n = n
 		top.score[:n], top.raw_score[:n], top.sentence[:n] = r["score"], r["raw"], r["sentence"]
@@ -98,6 +99,22 @@ class OracleCorpus:
 			for j in range(len(q)):
 				if r["mapping"][i][j] >= 0:
 					top.edge_sim[i, j] = S[r["mapping"][i][j], j]
+			if transport and b - a <= core.VK_FAST_SENT_LEN and len(q) <= core.VK_FAST_QUERY_LEN:
+				# what the HIP backend returns for the host to state transport flows: rows, and the plan of exact transports
+				top.sim_rows[i, :b - a, :len(q)] = S
+				exact = algorithm == core.VK_ALG_WRD or wmd_full
+				if exact:
+					if algorithm == core.VK_ALG_WRD:
+						ms = self._mag[self._ids[a:b]] if self.layout == core.VK_LAYOUT_STATIC else self._mag[a:b]
+						mt = qmag
+						if wrd_normalize:
+							ms, mt = ms / ms.sum(dtype=np.float32), mt / mt.sum(dtype=np.float32)
+					else:
+						nb = rwmd[2]
+						ms = np.full(b - a, 1.0 / (b - a) if nb else 1.0, np.float32)
+						mt = np.full(len(q), 1.0 / len(q) if nb else 1.0, np.float32)
+					_, G = vo.emd(mt, ms, np.maximum(1.0 - S.T, 0.0))
+					top.plan[i, :len(q), :b - a] = G
 		return top
 
 	def last_scores(self):

@@ -65,3 +65,39 @@ def test_wrd_needs_magnitudes(hip):
 	with pytest.raises(hip.VkError):
 		c.query(np.ones((3, 32), np.float32), algorithm=hip.VK_ALG_WRD)
 	c.close()
+
+
+def test_transport_flow_outputs(hip, oracle):
+	"""want_flow on transport metrics: similarity rows of the winners, and for exact transport the optimal plan
+	(its marginals are the masses, its value the score)"""
+	corpus = synth.make_contextual_corpus(400, 3, 50, 800, 96, noise=0.3, norm_sigma=0.25)
+	X = corpus["X"]
+	Xb, mag = oracle.normalize_rows_bf16(X)
+	off = corpus["sent_off"]
+	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=96, n_tokens=X.shape[0], n_sentences=400, keep_magnitudes=True)
+	c.append_vectors(X, normalize=True)
+	c.set_sentences(off)
+	c.finalize()
+	qv = synth.make_queries(corpus, 1, 7)[0]["vectors"]
+	Qb, qmag = oracle.normalize_rows_bf16(qv)
+	for alg, kw in ((hip.VK_ALG_WRD, {}), (hip.VK_ALG_RWMD, dict(rwmd=(False, False, True), wmd_full=True)), (hip.VK_ALG_RWMD, {})):
+		got = c.query(qv, algorithm=alg, q_normalize=True, max_matches=6, min_score=0.0, want_flow=True, **kw)
+		assert got.n == 6 and got.sim_rows is not None
+		for i in range(got.n):
+			s = int(got.sentence[i])
+			a, b = int(off[s]), int(off[s + 1])
+			S = oracle.sim_bf16(Xb[a:b], Qb)
+			np.testing.assert_allclose(got.sim_rows[i, :b - a, :7], S, atol=2e-6)
+			assert not got.sim_rows[i, b - a:].any()
+			if alg == hip.VK_ALG_RWMD and not kw:
+				continue
+			G = got.plan[i, :7, :b - a].astype(np.float64)
+			if alg == hip.VK_ALG_WRD:
+				mt, ms = qmag / qmag.sum(), mag[a:b] / mag[a:b].sum()
+			else:
+				mt, ms = np.full(7, 1 / 7), np.full(b - a, 1 / (b - a))
+			np.testing.assert_allclose(G.sum(axis=1), mt, atol=1e-6)
+			np.testing.assert_allclose(G.sum(axis=0), ms, atol=1e-6)
+			raw = ((1.0 - np.maximum(1.0 - S.T, 0.0)) * G).sum() / G.sum()
+			assert abs(raw - got.raw_score[i]) < 1e-5
+	c.close()

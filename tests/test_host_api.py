@@ -174,6 +174,17 @@ def test_transport_strategies_over_static_embedding():
 		assert scores == sorted(scores, reverse=True)
 		if isinstance(strategy, alignment.WordRotatorsDistance):
 			assert (1, 5) in [(m.doc_index, m.slice_id) for m in result]
+		# flows as the reference states them (match/flow.cpp:226-290): dense for exact transport, sparse for the relaxed one
+		flow = result[0].flow
+		len_t = len(planted.split())
+		if isinstance(strategy, alignment.WordRotatorsDistance):
+			assert flow["type"] == "dense" and flow["flow"].shape[0] == len_t
+			np.testing.assert_allclose(flow["flow"].sum(axis=1), 1.0, atol=1e-4)   # every query token ships all of its mass
+		else:
+			assert flow["type"] == "sparse" and set(flow["source"]) <= set(range(len_t))
+			assert len(flow["source"]) == len(flow["target"]) == len(flow["flow"]) == len(flow["dist"]) >= 1
+		j = result[0].to_json()
+		assert any("edges" in r for r in j["regions"])
 
 
 def test_unsupported_options_are_explicit():

@@ -17,6 +17,8 @@ LIB_PATH = os.environ.get("VECTORIAN_HIP_LIB", os.path.join(_HERE, "lib", "libve
 
 VK_MAX_QUERY_LEN = 64
 VK_MAX_SENT_LEN = 512
+VK_FAST_SENT_LEN = 64
+VK_FAST_QUERY_LEN = 16
 VK_MAX_MATCHES = 1024
 
 VK_F32, VK_BF16 = 0, 1
@@ -72,7 +74,8 @@ class _TopkOut(C.Structure):
 	_fields_ = [
 		("capacity", C.c_int32), ("n_out", C.c_int32),
 		("score", C.c_void_p), ("raw_score", C.c_void_p), ("sentence", C.c_void_p),
-		("mapping", C.c_void_p), ("edge_sim", C.c_void_p)]
+		("mapping", C.c_void_p), ("edge_sim", C.c_void_p),
+		("sim_rows", C.c_void_p), ("plan", C.c_void_p)]
 
 
 class _Timings(C.Structure):
@@ -114,7 +117,7 @@ def lib():
 		L.vk_last_scores.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 		L.vk_last_timings.argtypes = [C.c_void_p, C.POINTER(_Timings)]
 		L.vk_merge_topk.argtypes = [C.POINTER(_TopkOut), C.c_int32, C.c_int32, C.c_int32, C.POINTER(_TopkOut)]
-		if L.vk_abi_version() != 1:
+		if L.vk_abi_version() != 2:
 			raise RuntimeError("libvectorian_hip.so ABI version mismatch")
 		_lib = L
 	return _lib
@@ -179,13 +182,16 @@ def gap_to_struct(gap, keep, n_table):
 class TopK:
 	"""Bounded result set as plain arrays (ResultSet, vectorian/core/cpp/result_set.h:17-153)."""
 
-	def __init__(self, k, len_t):
+	def __init__(self, k, len_t, transport=False):
 		self.k, self.len_t = k, len_t
 		self.score = np.zeros(k, dtype=np.float32)
 		self.raw_score = np.zeros(k, dtype=np.float32)
 		self.sentence = np.zeros(k, dtype=np.int64)
 		self.mapping = np.full((k, len_t), -1, dtype=np.int16)
 		self.edge_sim = np.zeros((k, len_t), dtype=np.float32)
+		# transport algorithms: similarity rows S[i][j] and (exact transport) the plan G[j][i] of each winner
+		self.sim_rows = np.zeros((k, VK_FAST_SENT_LEN, 16), dtype=np.float32) if transport else None
+		self.plan = np.zeros((k, 16, VK_FAST_SENT_LEN), dtype=np.float32) if transport else None
 		self.n = 0
 
 	def _struct(self):
@@ -193,6 +199,8 @@ class TopK:
 		s.capacity, s.n_out = self.k, self.n
 		s.score, s.raw_score, s.sentence = _np_ptr(self.score), _np_ptr(self.raw_score), _np_ptr(self.sentence)
 		s.mapping, s.edge_sim = _np_ptr(self.mapping), _np_ptr(self.edge_sim)
+		if self.sim_rows is not None:
+			s.sim_rows, s.plan = _np_ptr(self.sim_rows), _np_ptr(self.plan)
 		return s
 
 	def trimmed(self):
@@ -320,7 +328,7 @@ class Corpus:
 		"""One query against the shard (vk_query).  Returns a TopK."""
 		keep = []
 		q, len_t = self._desc(q_vectors, keep, **options)
-		out = TopK(max(1, q.max_matches), len_t)
+		out = TopK(max(1, q.max_matches), len_t, transport=bool(q.want_flow) and q.algorithm != VK_ALG_ALIGN)
 		so = out._struct()
 		_check(lib().vk_query(self._h, C.byref(q), C.byref(so)))
 		out.n = so.n_out

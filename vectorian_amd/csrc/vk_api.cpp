@@ -97,6 +97,7 @@ struct vk_corpus {
 	float *d_out_raw = nullptr, *d_out_sim = nullptr;
 	float *d_wrd_raw = nullptr, *d_wrd_val = nullptr;
 	uint32_t *d_counter = nullptr;
+	float *d_rows_out = nullptr, *d_plan_out = nullptr;   // transport flows of the winners
 	size_t wrd_cap = 0;          // candidates d_wrd_raw / d_wrd_val (and d_keys[0]) can hold
 	int16_t *d_out_map = nullptr;
 	hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -193,7 +194,7 @@ int vk_corpus_free(vk_corpus_t *c) {
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	void *ptrs[] = {c->d_tiles, c->d_mag, c->d_tok_id, c->d_pos, c->d_sent_start, c->d_sent_end, c->d_stage, c->d_qtile, c->d_ws, c->d_wt, c->d_qids,
-		c->d_table, c->d_scores, c->d_raw, c->d_boost, c->d_keys[0], c->d_keys[1], c->d_out_raw, c->d_out_sim, c->d_out_map, c->d_wrd_raw, c->d_wrd_val, c->d_bq, c->d_bqlen, c->d_bscores, c->d_bkeys[0], c->d_bkeys[1], c->d_long_groups, c->d_counter};
+		c->d_table, c->d_scores, c->d_raw, c->d_boost, c->d_keys[0], c->d_keys[1], c->d_out_raw, c->d_out_sim, c->d_out_map, c->d_wrd_raw, c->d_wrd_val, c->d_bq, c->d_bqlen, c->d_bscores, c->d_bkeys[0], c->d_bkeys[1], c->d_long_groups, c->d_counter, c->d_rows_out, c->d_plan_out};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -494,6 +495,43 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	c->have_scores = false;
 	if (n == 0) return VK_OK;
 	auto sentence_of = [c](int64_t row) { return c->entry_sent.empty() ? row : (int64_t)c->entry_sent[(size_t)row]; };
+	const bool is_static_l = c->desc.layout == VK_LAYOUT_STATIC;
+	// transport algorithms: similarity rows (and, for exact transport, the optimal plan) of the winners, from which
+	// the host states their SparseFlow / DenseFlow.  rows_idx: rows of the slice table, best first.
+	auto transport_flows = [&](const std::vector<int64_t> &rows_idx, bool exact, const float *qmass, int mass_mode, int raw_masses) -> int {
+		if (!q->want_flow || !out->sim_rows || rows_idx.empty()) return VK_OK;
+		if (c->max_len > VK_FAST_SENT_LEN || q->len_t > VK_FAST_QUERY_LEN) return VK_OK;
+		int rc2;
+		if (!c->d_rows_out) {
+			if ((rc2 = alloc_t(c, &c->d_rows_out, (size_t)VK_MAX_MATCHES * 64 * 16))) return rc2;
+			if ((rc2 = alloc_t(c, &c->d_plan_out, (size_t)VK_MAX_MATCHES * 16 * 64))) return rc2;
+		}
+		if (!c->d_wrd_raw) {
+			if ((rc2 = alloc_t(c, &c->d_wrd_raw, (size_t)VK_MAX_MATCHES))) return rc2;
+			if ((rc2 = alloc_t(c, &c->d_wrd_val, (size_t)VK_MAX_MATCHES))) return rc2;
+			c->wrd_cap = VK_MAX_MATCHES;
+		}
+		const int cnt = (int)rows_idx.size();
+		std::vector<uint64_t> hk((size_t)cnt);
+		for (int i = 0; i < cnt; i++) hk[(size_t)i] = (1ull << 32) | (uint64_t)(uint32_t)rows_idx[(size_t)i];
+		VK_HIP(hipMemcpyAsync(c->d_keys[1], hk.data(), hk.size() * 8, hipMemcpyHostToDevice, c->stream));
+		VkWrdParams w{};
+		w.tiles = c->d_tiles; w.tok_id = c->d_tok_id; w.table = c->d_table; w.sent_start = c->d_sent_start; w.sent_end = c->d_sent_end;
+		w.layout = is_static_l ? VK_DEV_LAYOUT_STATIC : VK_DEV_LAYOUT_CONTEXTUAL; w.nk32 = c->nk32; w.tail = c->tail; w.tile_bytes = c->tile_bytes;
+		w.qtile = c->d_qtile; w.len_t = q->len_t; w.mag = c->d_mag;
+		w.keys = c->d_keys[1]; w.rows_out = c->d_rows_out;
+		VK_HIP(vk_launch_rows(&w, cnt, c->stream));
+		VK_HIP(hipMemcpyAsync(out->sim_rows, c->d_rows_out, (size_t)cnt * 64 * 16 * 4, hipMemcpyDeviceToHost, c->stream));
+		if (exact && out->plan) {
+			w.mass_mode = mass_mode; w.raw_masses = raw_masses;
+			memcpy(w.qmass, qmass, sizeof w.qmass);
+			w.raw_out = c->d_wrd_raw; w.val_out = c->d_wrd_val; w.plan_out = c->d_plan_out;
+			VK_HIP(vk_launch_wrd_exact(&w, cnt, nullptr, c->stream));
+			VK_HIP(hipMemcpyAsync(out->plan, c->d_plan_out, (size_t)cnt * 16 * 64 * 4, hipMemcpyDeviceToHost, c->stream));
+		}
+		VK_HIP(hipStreamSynchronize(c->stream));
+		return VK_OK;
+	};
 
 	// ---- prepare: query tile, gap tables, boost, static table -------------
 	VK_HIP(hipEventRecord(c->ev[0], st));
@@ -754,6 +792,11 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 			}
 		}
 		VK_HIP(hipEventRecord(c->ev[3], st));
+		{
+			std::vector<int64_t> rows_idx;
+			for (const Cand &b : best) rows_idx.push_back(b.g);
+			if ((rc = transport_flows(rows_idx, true, w.qmass, w.mass_mode, w.raw_masses))) return rc;
+		}
 		VK_HIP(hipEventRecord(c->ev[4], st));
 		VK_HIP(hipStreamSynchronize(st));
 		for (size_t i = 0; i < best.size(); i++) {
@@ -963,6 +1006,12 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	}
 	out->n_out = n_out;
 	c->have_scores = true;
+	if (q->algorithm == VK_ALG_RWMD && n_out > 0) {
+		std::vector<int64_t> rows_idx;
+		for (int i = 0; i < n_out; i++) rows_idx.push_back((int64_t)(uint32_t)(keys[(size_t)i] & 0xffffffffu));
+		float no_mass[VK_FAST_QUERY_LEN] = {0};
+		if ((rc = transport_flows(rows_idx, false, no_mass, 0, 0))) return rc;
+	}
 
 	float ms = 0;
 	vk_timings t{};

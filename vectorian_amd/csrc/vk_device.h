@@ -100,6 +100,8 @@ struct VkWrdParams {
 	const uint64_t *keys;      // candidates (0 = empty slot)
 	float *raw_out;            // [n_cand]
 	float *val_out;            // [n_cand]
+	float *plan_out;           // optional [n_cand x 16 x 64]: the optimal plan G[j][i]
+	float *rows_out;           // vk_rows_kernel: [n_cand x 64 x 16] similarity rows
 };
 
 struct VkFlowParams {
@@ -190,6 +192,7 @@ hipError_t vk_launch_rwmd_batch32(const VkRwmdBatchParams *p, hipStream_t stream
 hipError_t vk_launch_topk_wave_batch(const float *scores, const uint64_t *keys_in, int64_t n, float min_score, int32_t k,
 	int64_t per_wave, int32_t n_queries, int64_t in_stride, int64_t out_stride, uint64_t *out, int64_t *n_waves_out, hipStream_t stream);
 hipError_t vk_launch_wrd_exact(const VkWrdParams *p, int32_t n_cand, float *scores_to_mark, hipStream_t stream);
+hipError_t vk_launch_rows(const VkWrdParams *p, int32_t n_cand, hipStream_t stream);
 #ifdef __cplusplus
 }
 #endif

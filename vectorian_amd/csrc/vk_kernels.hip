@@ -2101,6 +2101,42 @@ __global__ __launch_bounds__(64) void vk_wrd_exact_kernel(VkWrdParams p) {
 		p.raw_out[w] = raw;
 		p.val_out[w] = (raw / (float)n) * boost;
 	}
+	if (p.plan_out)
+		for (int j = 0; j < VK_WRD_N; j++)
+			p.plan_out[((int64_t)w * VK_WRD_N + j) * 64 + lane] = (has && j < n) ? (float)fl[j * 64 + lane] : 0.0f;
+}
+
+// similarity rows of the winners of a transport query, for the host to state their flows
+__global__ __launch_bounds__(64) void vk_rows_kernel(VkWrdParams p) {
+	const int lane = threadIdx.x;
+	const int w = blockIdx.x;
+	float *out = p.rows_out + (int64_t)w * 64 * 16;
+	for (int i = lane; i < 64 * 16; i += 64) out[i] = 0.0f;
+	const uint64_t key = p.keys[w];
+	if (key == 0) return;
+	const int64_t g = (int64_t)(uint32_t)(key & 0xffffffffu);
+	const int t_a = p.sent_start[g], t_b = p.sent_end[g];
+	const int m = t_b - t_a;
+	if (m < 1 || m > 64) return;
+	__builtin_amdgcn_s_waitcnt(0);
+	if (p.layout == VK_DEV_LAYOUT_STATIC) {
+		for (int it = 0; it * 16 < m; it++) {
+			const int tk = it * 16 + (lane >> 2);
+			if (tk < m) {
+				const int id = p.tok_id[t_a + tk];
+				*reinterpret_cast<float4 *>(out + tk * 16 + (lane & 3) * 4) =
+					*reinterpret_cast<const float4 *>(p.table + (int64_t)id * 16 + (lane & 3) * 4);
+			}
+		}
+	} else {
+		const int tile0 = t_a >> 4;
+		const int ntiles = ((t_b + 15) >> 4) - tile0;
+		for (int ti = 0; ti < ntiles; ti++) {
+			const f32x4 acc = sim_tile_generic(p.qtile, p.tiles + (int64_t)(tile0 + ti) * p.tile_bytes, p.nk32, p.tail, lane);
+			const int row = (tile0 + ti) * 16 + (lane & 15) - t_a;      // token of this lane relative to the slice
+			if (row >= 0 && row < m) *reinterpret_cast<f32x4 *>(out + row * 16 + (lane >> 4) * 4) = acc;
+		}
+	}
 }
 
 // processed candidates leave the pool: their bound becomes -inf
@@ -2318,6 +2354,11 @@ extern "C" hipError_t vk_launch_topk_keys(const uint64_t *in, int64_t n, int32_t
 extern "C" hipError_t vk_launch_wrd_exact(const VkWrdParams *p, int32_t n_cand, float *scores_to_mark, hipStream_t stream) {
 	vk_wrd_exact_kernel<<<n_cand, 64, 0, stream>>>(*p);
 	if (scores_to_mark) vk_mark_kernel<<<(n_cand + 255) / 256, 256, 0, stream>>>(p->keys, n_cand, scores_to_mark);
+	return hipGetLastError();
+}
+
+extern "C" hipError_t vk_launch_rows(const VkWrdParams *p, int32_t n_cand, hipStream_t stream) {
+	vk_rows_kernel<<<n_cand, 64, 0, stream>>>(*p);
 	return hipGetLastError();
 }
 

@@ -188,11 +188,96 @@ class Match:
 			level=self.level)
 
 
+def _vocab_entries(ids, n):
+	"""joint-vocabulary view of one document of a slice (BOWBuilder, vectorian/core/cpp/alignment/bow.h:204-275):
+	entries in ascending token id with their positions; without ids every position is an entry of its own
+	(UniqueTokensBOWBuilder, :281-333)"""
+	if ids is None:
+		return [[i] for i in range(n)]
+	groups = {}
+	for i, t in enumerate(ids):
+		groups.setdefault(int(t), []).append(i)
+	return [groups[t] for t in sorted(groups)]
+
+
+def rwmd_sparse_flow(S, ids_s, ids_t, injective, symmetric, normalize_bow):
+	"""SparseFlow of the relaxed WMD (RelaxedSolver, vectorian/core/cpp/alignment/wmd.h:287-416): the edges of the
+	tighter direction, expanded to positions.  S[i][j]: similarity of slice token i and query token j."""
+	len_s, len_t = S.shape
+	docs = [_vocab_entries(ids_s, len_s), _vocab_entries(ids_t, len_t)]       # 0 = s, 1 = t
+	lens = (len_s, len_t)
+	bow = [[float(len(e)) / (lens[c] if normalize_bow else 1.0) for e in docs[c]] for c in (0, 1)]
+	def dist(es, et):   # first positions stand for the entry (wmd.h:107-135)
+		return max(1.0 - float(S[es[0], et[0]]), 0.0)
+	cost, tighter, edges_by_dir = 0.0, 0, [[], []]
+	for c, (d1, d2) in enumerate(((1, 0), (0, 1))):          # c = 0 moves t -> s first (wmd.h:303-306)
+		acc = 0.0
+		for a, src in enumerate(docs[d1]):
+			ds = [dist(tgt, src) if d1 == 1 else dist(src, tgt) for tgt in docs[d2]]
+			if injective:
+				b = int(np.argmin(ds)) if ds else -1
+				d = ds[b] if b >= 0 else 1.0
+				acc += bow[d1][a] * d
+				edges_by_dir[c].append((a, b, bow[d1][a], d))
+			else:
+				remaining = bow[d1][a]
+				for b in sorted(range(len(ds)), key=lambda x: (ds[x], docs[d2][x][0])):
+					if remaining <= bow[d2][b]:
+						acc += remaining * ds[b]
+						edges_by_dir[c].append((a, b, remaining, ds[b]))
+						break
+					remaining -= bow[d2][b]
+					acc += bow[d2][b] * ds[b]
+					edges_by_dir[c].append((a, b, bow[d2][b], ds[b]))
+				if remaining > 0.0:
+					acc += remaining   # wmd.h:373-375 as written
+		if not normalize_bow:
+			acc /= float(lens[d1])
+		if not symmetric:
+			tighter, cost = 0, acc
+			break
+		if acc > cost:
+			tighter, cost = c, acc
+	source, target, flow, distv = [], [], [], []
+	d1 = 1 if tighter == 0 else 0
+	for a, b, f, d in edges_by_dir[tighter]:
+		if b < 0:
+			continue
+		s_entry = docs[0][b] if tighter == 0 else docs[0][a]
+		t_entry = docs[1][a] if tighter == 0 else docs[1][b]
+		nf = f / (1.0 if normalize_bow else bow[d1][a])
+		for t in t_entry:
+			for s_ in s_entry:
+				source.append(t); target.append(s_); flow.append(nf); distv.append(d)
+	return {"type": "sparse", "source": np.array(source, dtype=np.int16), "target": np.array(target, dtype=np.int16),
+		"flow": np.array(flow, dtype=np.float32), "dist": np.array(distv, dtype=np.float32)}
+
+
+def dense_flow(S, G, ids_s, ids_t, mass_t):
+	"""DenseFlow of an exact transport (FullSolver, wmd.h:228-248; WRD::compute, wrd.h:120-135): flow[t][s] = plan of
+	the vocabulary pair / mass of the query entry, dist[t][s] = their distance.  G[j][i]: plan between positions."""
+	len_s, len_t = S.shape
+	es, et = _vocab_entries(ids_s, len_s), _vocab_entries(ids_t, len_t)
+	flow = np.zeros((len_t, len_s), dtype=np.float32)
+	distv = np.ones((len_t, len_s), dtype=np.float32)
+	for a, te in enumerate(et):
+		m = float(sum(mass_t[t] for t in te))
+		for b, se in enumerate(es):
+			g = float(sum(G[t, s_] for t in te for s_ in se))
+			d = max(1.0 - float(S[se[0], te[0]]), 0.0)
+			for t in te:
+				for s_ in se:
+					flow[t, s_] = g / m if m > 0 else 0.0
+					distv[t, s_] = d
+	return {"type": "dense", "flow": flow, "dist": distv}
+
+
 class HipMatch(Match):
 	"""one winner of a search; what CoreMatch (vectorian/index.py:295-379) exposes, computed
 	from the C-ABI result arrays"""
 
-	def __init__(self, index, query, doc_index, slice_id, token_at, len_s, score, raw_score, mapping, edge_sim, gaps):
+	def __init__(self, index, query, doc_index, slice_id, token_at, len_s, score, raw_score, mapping, edge_sim, gaps, transport_flow=None):
+		self._transport_flow = transport_flow   # callable -> flow dict of a transport metric (sparse / dense), or None
 		self._index = index
 		self._query = query
 		self._doc_index = doc_index
@@ -249,6 +334,10 @@ class HipMatch(Match):
 	def flow(self):
 		"""InjectiveFlow::to_py (vectorian/core/cpp/match/flow.cpp:190-216); per-edge values as
 		ScoreComputer fills them (metric/alignment.h:335-345)"""
+		if self._transport_flow is not None:
+			if callable(self._transport_flow):
+				self._transport_flow = self._transport_flow()
+			return self._transport_flow
 		target = self._mapping.astype(np.int16)
 		matched = target >= 0
 		return {
@@ -257,10 +346,22 @@ class HipMatch(Match):
 			"flow": matched.astype(np.float32),
 			"dist": np.where(matched, 1.0 - self._edge_sim, 1.0).astype(np.float32)}
 
+	def _edges(self):
+		"""(target s, source t, flow, distance) of the flow, as Flow::to_edges (match/match.h:61-73,151-153,202-218)"""
+		flow = self.flow
+		if flow["type"] == "injective":
+			return [(int(flow["target"][j]), j, float(flow["flow"][j]), float(flow["dist"][j]))
+				for j in range(len(self._query)) if flow["target"][j] >= 0]
+		if flow["type"] == "sparse":
+			return [(int(s_), int(t), float(f), float(d)) for t, s_, f, d in zip(flow["source"], flow["target"], flow["flow"], flow["dist"])]
+		ts, ss = np.nonzero(flow["flow"] > 0.0)
+		return [(int(s_), int(t), float(flow["flow"][t, s_]), float(flow["dist"][t, s_])) for t, s_ in zip(ts, ss)]
+
 	@property
 	def omitted(self):
-		# Flow::py_omitted (match/flow.cpp:170-188): query tokens without a partner
-		return [self._query.tokens[j] for j in range(len(self._query)) if self._mapping[j] < 0]
+		# Flow::py_omitted (match/flow.cpp:170-188) over to_injective(): query tokens without a partner
+		have = {t for _, t, f, _ in self._edges() if f > 0.0}
+		return [self._query.tokens[j] for j in range(len(self._query)) if j not in have]
 
 	def regions(self, context_size=10):
 		"""Flow::py_regions (vectorian/core/cpp/match/flow.cpp:9-167) in token units: unmatched
@@ -268,9 +369,10 @@ class HipMatch(Match):
 		doc_tokens = self.prepared_doc.tokens
 		gap_s, gap_t = self._gaps
 		token_at = self._token_at
-		flow = self.flow
-		edges = [(int(flow["target"][j]), j) for j in range(len(self._query)) if flow["target"][j] >= 0]
-		edges.sort()
+		all_edges = self._edges()
+		all_edges.sort(key=lambda e: (e[0], -e[2]))      # by target, biggest flow first (flow.cpp:32-41)
+		edges = [(e[0], e[1]) for e in all_edges]
+		weight = {(e[0], e[1]): (e[2], e[3]) for e in all_edges}
 		text = lambda a, b: " ".join(doc_tokens[a:b])
 		regions = []
 		if not edges:
@@ -296,8 +398,8 @@ class HipMatch(Match):
 				last_source = source
 				region_edges.append(TokenMatchEdge(
 					t=TokenMatchT(text=self._query.tokens[source], index=source, pos=None),
-					flow=float(flow["flow"][source]),
-					distance=float(flow["dist"][source]),
+					flow=weight[(target, source)][0],
+					distance=weight[(target, source)][1],
 					metric=self.metric))
 				k += 1
 			regions.append(Region(s=doc_tokens[pos], match=TokenMatch(pos_s=None, edges=region_edges), gap_penalty=0.0))
@@ -428,6 +530,7 @@ class HipBruteForceIndex(Index):
 
 		make = corpus_factory or core.Corpus
 		emb = self._embedding
+		self._token_ids = None   # static layout: token id per corpus token (joint vocabularies of the transport flows)
 		if emb.is_static:
 			vocab_vectors = emb.encode_tokens(session.vocab.tokens)
 			# magnitudes are kept for WordRotatorsDistance (metric/static.cpp:69-73, 80-120); rows are normalised on upload
@@ -437,6 +540,7 @@ class HipBruteForceIndex(Index):
 			self._corpus.append_vectors(E, normalize=True)
 			ids = np.concatenate([session.doc_token_ids(i) for i in range(len(session.documents))]) if n_tokens else np.zeros(0, np.int32)
 			self._corpus.set_token_ids(ids)
+			self._token_ids = np.asarray(ids, dtype=np.int32)
 		elif emb.is_contextual:
 			from vectorian_amd.embedding import Vectors
 			self._corpus = make(layout=core.VK_LAYOUT_CONTEXTUAL, d=emb.dimension, n_tokens=n_tokens, n_sentences=n_slices,
@@ -532,17 +636,40 @@ class HipBruteForceIndex(Index):
 			top = self._corpus.query(qv.unmodified, q_normalize=True, boost=self._boost, want_flow=True, **args)
 		if progress:
 			progress(1.0)
-		return self._matches_from_topk(p_query, top, gaps)
+		return self._matches_from_topk(p_query, top, gaps, args, np.asarray(qv.magnitudes, dtype=np.float32))
 
-	def _matches_from_topk(self, p_query, top, gaps):
+	def _transport_flow(self, p_query, top, i, g, args, qmag):
+		"""flow of winner i of a transport query, stated from the similarity rows / plan the backend returned"""
+		if getattr(top, "sim_rows", None) is None:
+			return None
+		a, b = int(self._slice_start[g]), int(self._slice_end[g])
+		len_s, len_t = b - a, len(p_query)
+		if len_s > core.VK_FAST_SENT_LEN or len_t > core.VK_FAST_QUERY_LEN:
+			return None
+		S = top.sim_rows[i][:len_s, :len_t].copy()
+		G = top.plan[i][:len_t, :len_s].copy()
+		ids_s = self._token_ids[a:b] if self._token_ids is not None else None
+		ids_t = p_query.token_ids if self._token_ids is not None else None
+		if args["algorithm"] == core.VK_ALG_WRD:
+			mass = qmag / qmag.sum() if args.get("wrd_normalize", True) else qmag
+			return lambda: dense_flow(S, G, None, None, mass)   # WRD works on positions (wrd.h:91-109)
+		injective, symmetric, nbow = args["rwmd"]
+		if args.get("wmd_full"):
+			unit = 1.0 / len_t if nbow else 1.0
+			return lambda: dense_flow(S, G, ids_s, ids_t, np.full(len_t, unit, dtype=np.float32))
+		return lambda: rwmd_sparse_flow(S, ids_s, ids_t, injective, symmetric, nbow)
+
+	def _matches_from_topk(self, p_query, top, gaps, args=None, qmag=None):
 		matches = []
+		transport = args is not None and args.get("algorithm", core.VK_ALG_ALIGN) != core.VK_ALG_ALIGN
 		for i in range(top.n):
 			g = int(top.sentence[i])
 			di = int(self._slice_doc[g])
 			matches.append(HipMatch(
 				self, p_query, di, self._slice_id[g], self._slice_token_at[g],
 				int(self._slice_end[g] - self._slice_start[g]),
-				top.score[i], top.raw_score[i], top.mapping[i].copy(), top.edge_sim[i].copy(), gaps))
+				top.score[i], top.raw_score[i], top.mapping[i].copy(), top.edge_sim[i].copy(), gaps,
+				transport_flow=self._transport_flow(p_query, top, i, g, args, qmag) if transport else None))
 		return matches
 
 	def close(self):
