@@ -316,7 +316,18 @@ class HipMatch(Match):
 
 	@property
 	def score_max(self):
-		return float(len(self._query))   # reference_score with submatch_weight 0 (metric/alignment.h:84-106)
+		"""reference_score (metric/alignment.h:84-106): matched weight + unmatched weight scaled by the share of
+		unmatched weight to the power submatch_weight; len(query) for submatch_weight 0 and for transport metrics"""
+		w = float(self._query.options.get("submatch_weight", 0.0))
+		metric = self._query.options.get("metric", {})
+		weights = np.ones(len(self._query), dtype=np.float32)
+		if isinstance(metric, dict) and metric.get("metric") == "alignment-tag-weighted":
+			weights = np.array([float(metric["tag_weights"].get(t, 1.0)) for t in self._query.tags], dtype=np.float32)
+		total = float(weights.sum())
+		if self._transport_flow is not None or w == 0.0 or total <= 0.0:
+			return total
+		matched = float(weights[np.asarray(self._mapping[:len(weights)]) >= 0].sum())
+		return matched + ((total - matched) / total) ** w * (total - matched)
 
 	@property
 	def raw_score(self):
