@@ -39,6 +39,9 @@ typedef __attribute__((ext_vector_type(4))) short bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #define VK_NEG_INF (-__builtin_inff())
+#ifndef VK_RUN
+#define VK_RUN 4   // consecutive groups of 4 slices per wave turn (vk_score_kernel)
+#endif
 #ifdef VK_DBG_NOINLINE
 #define VK_DP_INLINE __attribute__((noinline))
 #else
@@ -769,8 +772,17 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 	// groups of 4 consecutive slices; slices longer than max_short_len sit alone in their group (the host
 	// pads the slice table, vk_api.cpp set_slices_impl) and are left to a second launch that walks
 	// group_list with one wave per workgroup and a larger LDS strip
+	// A wave takes runs of VK_RUN consecutive groups: when sentences are not tile-aligned, the tile that
+	// straddles two groups is then computed once and its rows are carried over in the strip (ragged corpora:
+	// one tile in ten).
 	const int n_groups = p.group_list ? p.n_list : (p.n_sent + 3) >> 2;
-	for (int gi = blockIdx.x * nwaves + wv; gi < n_groups; gi += gridDim.x * nwaves) {
+	const int run = p.group_list ? 1 : VK_RUN;
+	const int n_runs = (n_groups + run - 1) / run;
+	for (int ri = blockIdx.x * nwaves + wv; ri < n_runs; ri += gridDim.x * nwaves) {
+	int prev_tile = -1, prev_row = 0;   // last tile of the previous group of this run, and its place in the strip
+	for (int gg = 0; gg < run; gg++) {
+		const int gi = ri * run + gg;
+		if (gi >= n_groups) break;
 		const int grp = p.group_list ? p.group_list[gi] : gi;
 		const int s_idx = grp * 4 + sigma;
 		const int i0 = s_idx < p.n_sent ? s_idx : p.n_sent;       // entries >= n_sent are empty slices
@@ -782,7 +794,7 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 		maxlen = max(maxlen, __builtin_amdgcn_readlane(len, 16));
 		maxlen = max(maxlen, __builtin_amdgcn_readlane(len, 32));
 		maxlen = max(maxlen, __builtin_amdgcn_readlane(len, 48));
-		if (!p.group_list && maxlen > p.max_short_len) continue;
+		if (!p.group_list && maxlen > p.max_short_len) { prev_tile = -1; continue; }
 
 		int rowbase;
 		if (MODE == 2) {
@@ -822,7 +834,19 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 			const int tile0 = g_a >> 4;
 			const int ntiles = ((g_b + 15) >> 4) - tile0;
 			const uint8_t *tp = p.tiles + (int64_t)tile0 * p.tile_bytes;
-			for (int ti = 0; ti < ntiles; ti++) {
+			int ti0 = 0;
+			if (ntiles > 0 && tile0 == prev_tile) {
+				// the previous group ended inside this tile: its 16 rows are in the strip already
+				if (prev_row != 0) {
+					const float4 keep = reinterpret_cast<const float4 *>(S)[prev_row * 64 + lane];
+					wave_lds_fence();
+					reinterpret_cast<float4 *>(S)[lane] = keep;
+				}
+				ti0 = 1;
+				tp += p.tile_bytes;
+			}
+			if (ntiles > 0) { prev_tile = tile0 + ntiles - 1; prev_row = ntiles - 1; }
+			for (int ti = ti0; ti < ntiles; ti++) {
 				f32x4 acc;
 				if constexpr (MODE == 0) acc = sim_tile<NK32, TAIL>(qf, tp, lane);
 				else if constexpr (MODE == 3) acc = sim_tile_qlds<NK32, TAIL>(qlds, tp, lane);
@@ -886,6 +910,7 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 			p.raw[s_idx] = r;
 		}
 		wave_lds_fence();
+	}
 	}
 }
 
