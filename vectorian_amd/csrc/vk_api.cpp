@@ -672,7 +672,8 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	p.max_short_len = VK_FAST_SENT_LEN;
 	p.s_rows_per_wave = is_static ? (c->max_group_tokens + 15) / 16 * 16 : c->max_group_tiles * 16;
 	p.h_rows = c->max_short_len + 1;
-	int lds_floats = p.s_rows_per_wave * 16;
+	const int lt = q->len_t <= 4 ? 4 : q->len_t <= 8 ? 8 : q->len_t <= 12 ? 12 : 16;   // strip rows hold the padded query columns (launch_score_lt)
+	int lds_floats = p.s_rows_per_wave * lt + 16;
 	if (p.gap_mode == 2) lds_floats += 4 * p.h_rows * 16;   // column history of dp_general
 	p.m_rows = (c->max_short_len + 4) / 4 * 4;
 	if (p.gap_mode == 7) lds_floats += 4 * p.m_rows;       // vocabulary masses of the 4 slices (static layout)
@@ -692,7 +693,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		if (pl.gap_mode == 3 || pl.gap_mode == 6) pl.gap_mode = 2;
 		pl.s_rows_per_wave = is_static ? (c->long_group_tokens + 15) / 16 * 16 : c->long_group_tiles * 16;
 		pl.h_rows = 0;
-		int lf = pl.s_rows_per_wave * 16;
+		int lf = pl.s_rows_per_wave * lt + 16;
 		if (pl.gap_mode == 2) lf += (c->max_len + 1) * 16;
 		pl.m_rows = 0;
 		if (pl.gap_mode == 7) lf += (c->max_len + 4) / 4 * 4;

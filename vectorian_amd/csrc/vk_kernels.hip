@@ -273,7 +273,8 @@ __device__ __forceinline__ float tag_weighted(float s, float w, int pos_s, int p
 // on DPP row_shr:1, which reproduces the sequential recurrence bit for bit (max is
 // exact and x -> x - g is monotone).
 //
-// S: wave-private LDS [rows][16]; sentence sigma's token i is row rowbase + i.
+// S: wave-private LDS [rows][LT] (the LT = 4/8/12/16 padded query columns); sentence sigma's token i is row rowbase + i.
+// Lanes v >= LT read into the next row: their values never reach a lower lane.
 // Returns the aligner score (raw) in lane 15 of each DPP row.
 // ---------------------------------------------------------------------------
 
@@ -324,7 +325,7 @@ __device__ __forceinline__ float dp_linear(const float *__restrict__ S, int rowb
 	float best = 0.0f;
 	for (int u = 1; u <= maxlen; u++) {
 		const bool act = u <= len;
-		const float s = S[(rowbase + (act ? u - 1 : 0)) * 16 + v];
+		const float s = S[(rowbase + (act ? u - 1 : 0)) * LT + v];
 		const float bprev = -(gsb * (float)(u - 1));
 		const float bcur = -(gsb * (float)u);
 		const float diag = dpp_f<DPP_ROW_SHR1>(bprev, h);
@@ -362,7 +363,7 @@ __device__ VK_DP_INLINE float dp_affine(const float *__restrict__ S, int rowbase
 	float best = 0.0f;
 	for (int u = 1; u <= maxlen; u++) {
 		const bool act = u <= len;
-		const float s = S[(rowbase + (act ? u - 1 : 0)) * 16 + v];
+		const float s = S[(rowbase + (act ? u - 1 : 0)) * LT + v];
 		const float bprev = (is_global && u > 1) ? -(a_s + bs * (float)(u - 1)) : 0.0f;
 		const float bcur = is_global ? -(a_s + bs * (float)u) : 0.0f;
 		const float diag = dpp_f<DPP_ROW_SHR1>(bprev, h);
@@ -412,7 +413,7 @@ __device__ __forceinline__ float dp_general(const float *__restrict__ S, float *
 	float best = 0.0f;
 	for (int u = 1; u <= maxlen; u++) {
 		const bool act = u <= len;
-		const float s = S[(rowbase + (act ? u - 1 : 0)) * 16 + v];
+		const float s = S[(rowbase + (act ? u - 1 : 0)) * LT + v];
 		const float bprev = is_global ? -a.ws[u - 1] : 0.0f;    // ws[0] = 0
 		const float bcur = is_global ? -a.ws[u] : 0.0f;
 		const float diag = dpp_f<DPP_ROW_SHR1>(bprev, h);
@@ -465,7 +466,7 @@ __device__ __forceinline__ float dp_general_reg(const float *__restrict__ S, int
 	for (int u = 1; u <= MAXLEN; u++) {
 		if (u <= maxlen) {
 			const bool act = u <= len;
-			const float s = S[(rowbase + (act ? u - 1 : 0)) * 16 + v];
+			const float s = S[(rowbase + (act ? u - 1 : 0)) * LT + v];
 			const float bprev = is_global ? -wsr[u - 1] : 0.0f;
 			const float bcur = is_global ? -wsr[u] : 0.0f;
 			const float diag = dpp_f<DPP_ROW_SHR1>(bprev, hreg[u - 1]);
@@ -521,7 +522,7 @@ __device__ __forceinline__ float rwmd_rows(const float *__restrict__ S, int rowb
 	float acc1 = 0.0f;
 	for (int u = 1; u <= maxlen; u++) {
 		const bool act = u <= len;
-		const float s = S[(rowbase + (act ? u - 1 : 0)) * 16 + v];
+		const float s = S[(rowbase + (act ? u - 1 : 0)) * LT + v];
 		const float dist = fmaxf(1.0f - s, 0.0f);
 		if (act) colmin = fminf(colmin, dist);
 		// min over the query columns of this row -> lane 15
@@ -598,7 +599,7 @@ __device__ __forceinline__ float rwmd_fill_rows(const float *__restrict__ S, con
 		int bi = -1;
 		for (int u = 1; u <= maxlen; u++) {
 			const bool act = u <= len;
-			const float dist = fmaxf(1.0f - S[(rowbase + (act ? u - 1 : 0)) * 16 + v], 0.0f);
+			const float dist = fmaxf(1.0f - S[(rowbase + (act ? u - 1 : 0)) * LT + v], 0.0f);
 			const bool later = dist > last_d || (dist == last_d && u - 1 > last_i);
 			if (act && later && dist < bd) { bd = dist; bi = u - 1; }
 		}
@@ -626,7 +627,7 @@ __device__ __forceinline__ float rwmd_fill_rows(const float *__restrict__ S, con
 	if (a.rwmd_symmetric) {
 		for (int u = 1; u <= maxlen; u++) {
 			const bool act = u <= len;
-			const float dist = fmaxf(1.0f - S[(rowbase + (act ? u - 1 : 0)) * 16 + v], 0.0f);
+			const float dist = fmaxf(1.0f - S[(rowbase + (act ? u - 1 : 0)) * LT + v], 0.0f);
 			float r1 = act ? (smass ? smass[u - 1] : cap_s) : 0.0f;
 			float cost = 0.0f;
 			bool used = !col_ok, done = !(r1 > 0.0f);
@@ -678,7 +679,7 @@ __device__ __forceinline__ float wrd_bound_rows(const float *__restrict__ S, int
 	float lb1n = 0.0f;
 	for (int u = 1; u <= maxlen; u++) {
 		const bool act = u <= len;
-		const float s = S[(rowbase + (act ? u - 1 : 0)) * 16 + v];
+		const float s = S[(rowbase + (act ? u - 1 : 0)) * LT + v];
 		const float dist = fmaxf(1.0f - s, 0.0f);
 		if (act) colmin = fminf(colmin, dist);
 		float m = col_ok ? dist : 3.402823466e+38F;
@@ -737,7 +738,7 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 		smem += NK32 * 256;
 	}
 	float *S = smem + wv * p.lds_floats_per_wave;
-	float *Hh = S + p.s_rows_per_wave * 16;
+	float *Hh = S + p.s_rows_per_wave * LT + 16;   // strip rows hold the LT query columns only; 16 floats of slack for lanes >= LT
 	const int sigma = lane >> 4, v = lane & 15;
 
 	QFrag<NK32, TAIL> qf;
@@ -825,7 +826,7 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 							vq.z = tag_weighted(vq.z, twl[2], ps, tposl[2], p.tw_keep, p.tw_threshold);
 							vq.w = tag_weighted(vq.w, twl[3], ps, tposl[3], p.tw_keep, p.tw_threshold);
 						}
-						*reinterpret_cast<float4 *>(S + tk * 16 + (lane & 3) * 4) = vq;
+						if ((lane & 3) * 4 < LT) *reinterpret_cast<float4 *>(S + tk * LT + (lane & 3) * 4) = vq;
 					}
 				}
 			}
@@ -838,9 +839,10 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 			if (ntiles > 0 && tile0 == prev_tile) {
 				// the previous group ended inside this tile: its 16 rows are in the strip already
 				if (prev_row != 0) {
-					const float4 keep = reinterpret_cast<const float4 *>(S)[prev_row * 64 + lane];
+					float4 keep = {0.0f, 0.0f, 0.0f, 0.0f};
+					if (lane < 4 * LT) keep = reinterpret_cast<const float4 *>(S)[prev_row * 4 * LT + lane];   // 16 rows of LT floats
 					wave_lds_fence();
-					reinterpret_cast<float4 *>(S)[lane] = keep;
+					if (lane < 4 * LT) reinterpret_cast<float4 *>(S)[lane] = keep;
 				}
 				ti0 = 1;
 				tp += p.tile_bytes;
@@ -856,7 +858,7 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 #pragma unroll
 					for (int r = 0; r < 4; r++) acc[r] = tag_weighted(acc[r], twl[r], ps, tposl[r], p.tw_keep, p.tw_threshold);
 				}
-				*reinterpret_cast<f32x4 *>(S + (ti * 16 + (lane & 15)) * 16 + (lane >> 4) * 4) = acc;
+				if ((lane >> 4) * 4 < LT) *reinterpret_cast<f32x4 *>(S + (ti * 16 + (lane & 15)) * LT + (lane >> 4) * 4) = acc;
 				tp += p.tile_bytes;
 			}
 			rowbase = t_a - tile0 * 16;
@@ -2266,6 +2268,9 @@ static hipError_t launch_sized(K kernel, const VkScoreParams &p, int want_blocks
 	// measured on MI355X (1M x 32 x 300-d): 3 workgroups (12 waves) per CU stream HBM fastest --
 	// 2.90 ms vs 3.51 ms at 5 per CU for the linear-gap kernel, 2.95 ms at 4; more concurrent streams cost bandwidth
 	if (occ > 3 && p.layout != VK_DEV_LAYOUT_STATIC) occ = 3;   // the static layout is DP-bound, not a stream: keep full residency
+	// 768-d rows: a wave already keeps 24 KiB of loads in flight per tile; one workgroup per CU measured fastest
+	// (ragged 8..64 tokens, 400 k sentences: 3.37 ms at 1, 3.45 ms at 2 per CU)
+	if (p.nk32 >= 24 && p.layout != VK_DEV_LAYOUT_STATIC) occ = 1;
 	static const char *ov = getenv("VK_BLOCKS_PER_CU");
 	if (ov && atoi(ov) > 0) occ = atoi(ov);
 	int dev = 0, cus = 256;
