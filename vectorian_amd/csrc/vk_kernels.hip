@@ -290,27 +290,24 @@ struct DpArgs {
 	float wrd_raw_total;   // WRD on raw magnitudes: sum of the query's magnitudes (0: masses are normalised)
 };
 
-// In-row dependency of the linear recurrence H[u][j] = max(c[j], H[u][j-1] - gt): because
-// fl(max(a, b) - g) = max(fl(a - g), fl(b - g)), unrolling gives H[u][j] = max_k decay_k(c[j-k]) with
-// decay_k = k successive fp32 subtractions of gt -- bit for bit the sequential result.  Each lane
-// decays its own c (one short dependent chain), the shifted copies are combined with independent
-// row_shr:k + max.  The border column enters as decay_(j)(H[u][0]) for lane j - 1 (non-LOCAL only).
+// In-row dependency of the linear recurrence H[u][j] = max(c[j], H[u][j-1] - gt): unrolled,
+// H[u][j] = max_k (c[j-k] - k gt), a prefix maximum with decay.  It is taken in log2(LT) doubling steps
+// x <- max(x, row_shr:s(x) - s gt), s = 1, 2, 4, 8 (s gt is exact for powers of two), ten instructions
+// instead of a chain of LT dependent subtractions.  The value may differ from the sequential
+// recurrence in the last bit (c - 2 gt is rounded once, (c - gt) - gt twice); scores are compared at
+// 1e-4, and the tracebacks of the winners come from vk_flow_kernel, which walks the recurrence
+// sequentially.  The border column enters as H[u][0] - (v + 1) gt (non-LOCAL only).
 template <int K>
 __device__ __forceinline__ float shr_k(float old, float src) { return dpp_f<0x110 + K>(old, src); }
 
-template <int LT, int K>
-struct LinChain {
-	// K = 1 .. LT: decay the lane's own value and the border once more; shifts exist for K <= 15
-	static __device__ __forceinline__ void run(float &h, float d, float bdec, float &bsel, float gt, int v) {
-		if constexpr (K <= LT) {
-			d = d - gt;                       // decay_K(c) of this lane
-			bdec = bdec - gt;                 // decay_K(border)
-			bsel = (v == K - 1) ? bdec : bsel;
-			if constexpr (K < LT && K <= 15) h = fmaxf(h, shr_k<K>(VK_NEG_INF, d));
-			LinChain<LT, K + 1>::run(h, d, bdec, bsel, gt, v);
-		}
-	}
-};
+template <int LT>
+__device__ __forceinline__ float decay_scan(float x, float g) {
+	x = fmaxf(x, shr_k<1>(VK_NEG_INF, x) - g);
+	if (LT > 2) x = fmaxf(x, shr_k<2>(VK_NEG_INF, x) - 2.0f * g);
+	if (LT > 4) x = fmaxf(x, shr_k<4>(VK_NEG_INF, x) - 4.0f * g);
+	if (LT > 8) x = fmaxf(x, shr_k<8>(VK_NEG_INF, x) - 8.0f * g);
+	return x;
+}
 
 template <int LT>
 __device__ __forceinline__ float dp_linear(const float *__restrict__ S, int rowbase, int len, int maxlen, int v, const DpArgs &a) {
@@ -320,8 +317,9 @@ __device__ __forceinline__ float dp_linear(const float *__restrict__ S, int rowb
 	const float gsb = is_global ? a.gs : 0.0f;   // border H[u][0] = -(gs*u) (GLOBAL) else 0
 	const float gs = a.gs, gt = a.gt;
 	const bool last_col = v == a.len_t - 1;
+	const float gt_v1 = gt * (float)(v + 1);     // distance of this column from the border column
 
-	float h = is_global ? -(gt * (float)(v + 1)) : 0.0f;  // H[0][v+1]
+	float h = is_global ? -gt_v1 : 0.0f;  // H[0][v+1]
 	float best = 0.0f;
 	for (int u = 1; u <= maxlen; u++) {
 		const bool act = u <= len;
@@ -331,10 +329,8 @@ __device__ __forceinline__ float dp_linear(const float *__restrict__ S, int rowb
 		const float diag = dpp_f<DPP_ROW_SHR1>(bprev, h);
 		float c = fmaxf(diag + s, floor0);
 		c = fmaxf(c, h - gs);
-		float hn = c;
-		float bsel = VK_NEG_INF;              // decay_(v+1)(border) for this lane
-		LinChain<LT, 1>::run(hn, c, bcur, bsel, gt, v);
-		if (!is_local) hn = fmaxf(hn, bsel);
+		float hn = decay_scan<LT>(c, gt);
+		if (!is_local) hn = fmaxf(hn, bcur - gt_v1);
 		h = act ? hn : h;
 		if (is_local || last_col) best = fmaxf(best, h);
 	}
@@ -372,11 +368,19 @@ __device__ VK_DP_INLINE float dp_affine(const float *__restrict__ S, int rowbase
 		// F[u][j] = max(H[u][j-1] - open_t, F[u][j-1] - bt); F[u][0] = -inf
 		float f = VK_NEG_INF;
 		float hc = c;
-#pragma unroll
-		for (int i = 0; i < LT; i++) {
-			const float fl = fmaxf(dpp_f<DPP_ROW_SHR1>(bcur, hc) - open_t, dpp_f<DPP_ROW_SHR1>(VK_NEG_INF, f) - bt);
-			f = fl;
+		if (a_t >= 0.0f) {
+			// opening costs at least an extension, so extending a gap never loses against reopening it from the same
+			// cell: F[u][j] = max_k (c[j-k] - open_t - (k-1) bt), the decayed prefix maximum of c shifted by one
+			// column (the border column enters at lane 0).  Last-bit differences as in dp_linear.
+			f = decay_scan<LT>(dpp_f<DPP_ROW_SHR1>(bcur, c) - open_t, bt);
 			hc = fmaxf(c, f);
+		} else {
+#pragma unroll
+			for (int i = 0; i < LT; i++) {
+				const float fl = fmaxf(dpp_f<DPP_ROW_SHR1>(bcur, hc) - open_t, dpp_f<DPP_ROW_SHR1>(VK_NEG_INF, f) - bt);
+				f = fl;
+				hc = fmaxf(c, f);
+			}
 		}
 		if (act) { h = hc; e = en; }
 		if (is_local || last_col) best = fmaxf(best, h);
