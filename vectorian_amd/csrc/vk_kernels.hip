@@ -678,14 +678,19 @@ __device__ __forceinline__ float wrd_bound_rows(const float *__restrict__ S, int
 	const bool col_ok = v < len_t;
 	// one sweep: sum of the slice's magnitudes and sum of magnitude x nearest distance (the quotient is the
 	// bound of the s -> t direction; it is only a bound, so the order of the float operations is free)
+	// t -> s direction: a query token's mass cannot all go to its nearest slice token -- that one takes at most its
+	// own mass.  The lane keeps the four nearest (distance, mass) pairs of its column; filling them in order and
+	// charging what is left at the fourth distance bounds the cost of any feasible plan from below (a capacity-
+	// constrained relaxation, ICT / ACT of Atasu & Mittelholzer): far tighter than the nearest-neighbour bound when a
+	// query token weighs several slice tokens (10 against 32 tokens), and the exact stage sees that many fewer rows.
 	float sum_s = 0.0f;
-	float colmin = 3.402823466e+38F;
 	float lb1n = 0.0f;
+	const float BIG = 3.402823466e+38F;
+	float d1 = BIG, d2 = BIG, d3 = BIG, d4 = BIG, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f, c4 = 0.0f;
 	for (int u = 1; u <= maxlen; u++) {
 		const bool act = u <= len;
 		const float s = S[(rowbase + (act ? u - 1 : 0)) * LT + v];
 		const float dist = fmaxf(1.0f - s, 0.0f);
-		if (act) colmin = fminf(colmin, dist);
 		float m = col_ok ? dist : 3.402823466e+38F;
 		m = fminf(m, dpp_f<DPP_ROW_SHR1>(m, m));
 		m = fminf(m, dpp_f<DPP_ROW_SHR2>(m, m));
@@ -694,9 +699,27 @@ __device__ __forceinline__ float wrd_bound_rows(const float *__restrict__ S, int
 		const float mg = act ? (ids ? mag[ids[u - 1]] : mag[u - 1]) : 0.0f;   // static layout: magnitude of the vocabulary entry
 		sum_s += mg;
 		lb1n += mg * m;
+		// insert (dist, mg) into the sorted four
+		float nd = act ? dist : BIG, nc = mg;
+		bool sw;
+		sw = nd < d4; d4 = sw ? nd : d4; c4 = sw ? nc : c4;
+		sw = d4 < d3; nd = d3; nc = c3; d3 = sw ? d4 : d3; c3 = sw ? c4 : c3; d4 = sw ? nd : d4; c4 = sw ? nc : c4;
+		sw = d3 < d2; nd = d2; nc = c2; d2 = sw ? d3 : d2; c2 = sw ? c3 : c2; d3 = sw ? nd : d3; c3 = sw ? nc : c3;
+		sw = d2 < d1; nd = d1; nc = c1; d1 = sw ? d2 : d1; c1 = sw ? c2 : c1; d2 = sw ? nd : d2; c2 = sw ? nc : c2;
 	}
 	const float lb1 = lb1n / sum_s * (1.0f - 2e-6f);
-	float x = col_ok ? q_mass * colmin : 0.0f;      // sum over lanes, any order: it is only a bound
+	// masses on the scale of q_mass: normalised (shares of sum_s) unless the magnitudes are used as they are
+	const float scale = a.wrd_raw_total > 0.0f ? 1.0f : 1.0f / sum_s;
+	float rem = col_ok ? q_mass : 0.0f, x = 0.0f, last = 0.0f;
+	{
+		float amt;
+		if (d1 < BIG) { amt = fminf(rem, c1 * scale * (1.0f + 2e-6f)); x += amt * d1; rem -= amt; last = d1; }
+		if (d2 < BIG) { amt = fminf(rem, c2 * scale * (1.0f + 2e-6f)); x += amt * d2; rem -= amt; last = d2; }
+		if (d3 < BIG) { amt = fminf(rem, c3 * scale * (1.0f + 2e-6f)); x += amt * d3; rem -= amt; last = d3; }
+		if (d4 < BIG) { amt = fminf(rem, c4 * scale * (1.0f + 2e-6f)); x += amt * d4; rem -= amt; last = d4; }
+		x += fmaxf(rem, 0.0f) * last;
+	}
+	// sum over lanes, any order: it is only a bound
 	x += dpp_f<DPP_ROW_SHR1>(0.0f, x);
 	x += dpp_f<DPP_ROW_SHR2>(0.0f, x);
 	x += dpp_f<DPP_ROW_SHR4>(0.0f, x);
