@@ -696,7 +696,8 @@ __device__ __forceinline__ float wrd_bound_rows(const float *__restrict__ S, int
 		m = fminf(m, dpp_f<DPP_ROW_SHR2>(m, m));
 		m = fminf(m, dpp_f<DPP_ROW_SHR4>(m, m));
 		m = fminf(m, dpp_f<DPP_ROW_SHR8>(m, m));
-		const float mg = act ? (ids ? mag[ids[u - 1]] : mag[u - 1]) : 0.0f;   // static layout: magnitude of the vocabulary entry
+		// static layout: magnitude of the vocabulary entry; no magnitudes: unit masses (bags of words, full WMD)
+		const float mg = act ? (mag ? (ids ? mag[ids[u - 1]] : mag[u - 1]) : 1.0f) : 0.0f;
 		sum_s += mg;
 		lb1n += mg * m;
 		// insert (dist, mg) into the sorted four
@@ -900,7 +901,11 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 		else if constexpr (GAP == 2) raw = dp_general<LT>(S, Hh, p.h_rows, rb, lenc, maxlen, lane, a);
 		else if constexpr (GAP == 3) raw = dp_general_reg<LT, 32>(S, rb, lenc, maxlen, v, a, wsr, wtr);
 		else if constexpr (GAP == 6) raw = dp_general_reg<LT, 64>(S, rb, lenc, maxlen, v, a, wsr, wtr);
-		else if constexpr (GAP == 4) raw = rwmd_rows<LT>(S, rb, lenc, maxlen, v, a);
+		else if constexpr (GAP == 4) {
+			// stage 1 of the full WMD over normalised bags of words = the WRD bound with unit magnitudes
+			if (a.wmd_bound == 1) raw = wrd_bound_rows<LT>(S, rb, lenc, maxlen, v, a, nullptr, nullptr, 1.0f / (float)a.len_t);
+			else raw = rwmd_rows<LT>(S, rb, lenc, maxlen, v, a);
+		}
 		else if constexpr (GAP == 7) {
 			// masses of the slice's vocabulary entries (static layout: repeated token ids count once, at their
 			// first position); stride 0 in the pass over long slices, where only DPP row 0 holds a slice
