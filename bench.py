@@ -122,6 +122,7 @@ def main():
 	ap.add_argument("--gap", choices=["exp5", "linear"], default="exp5")
 	ap.add_argument("--sentences", type=int, default=1000000, help="sentences per GPU")
 	ap.add_argument("--no-cpu-baseline", action="store_true")
+	ap.add_argument("--no-pipeline", action="store_true", help="one handle, one query at a time")
 	args = ap.parse_args()
 
 	import torch
@@ -165,27 +166,50 @@ def main():
 
 	from vectorian_amd import shards
 
-	pending = [None]   # exchange of the previous query, in flight while this one is scored
+	# Two handles on the resident shard (vk_corpus_view: shared arrays, own stream and workspaces), two host threads:
+	# query i + 1 is scored while the result set of query i is selected, retraced and copied out.  Every query is
+	# complete (top-k with flow on the host; with several ranks: merged across ranks) inside the timed region.
+	from concurrent.futures import ThreadPoolExecutor
+	handles = [corpus] if args.no_pipeline else [corpus, corpus.view()]
+	pool = ThreadPoolExecutor(max_workers=len(handles))
+	inflight = []      # futures of submitted queries, oldest first
+	pending = [None]   # exchange of an earlier query, in flight while later ones are scored
+	submitted = [0]
+	score_ms = []
+
+	def run_query(h, q):
+		top = h.query(q, locality=core.Locality.LOCAL, gap_s=gs, gap_t=gt, q_normalize=True,
+			max_matches=K_MATCHES, min_score=0.0, want_flow=True)
+		return top, h.last_timings()["score_ms"]
 
 	def drain():
 		if pending[0] is not None:
-			merged = shards.allgather_finish(pending[0])   # global top-k of the previous query on every rank
+			merged = shards.allgather_finish(pending[0])   # global top-k of an earlier query on every rank
 			pending[0] = None
 			return merged
 		return None
 
-	def step(q):
-		top = corpus.query(q, locality=core.Locality.LOCAL, gap_s=gs, gap_t=gt, q_normalize=True,
-			max_matches=K_MATCHES, min_score=0.0, want_flow=True)
+	def retire():
+		top, ms = inflight.pop(0).result()
+		score_ms.append(ms)
 		if world == 1:
 			return top
-		# per-rank result sets -> all ranks (RCCL all-gather over xGMI), then ResultSet.extend; the collective of
-		# query i overlaps the scoring of query i + 1, every query's merged result is produced inside the timed region
+		# per-rank result sets -> all ranks (RCCL all-gather over xGMI), then ResultSet.extend
 		merged = drain()
 		pending[0] = shards.allgather_start(top, rank * n_sent, K_MATCHES, device=xdev)
 		return merged
 
+	def step(q):
+		h = handles[submitted[0] % len(handles)]
+		submitted[0] += 1
+		inflight.append(pool.submit(run_query, h, q))
+		if len(inflight) >= len(handles):
+			return retire()
+		return None
+
 	def sync():
+		while inflight:
+			retire()
 		drain()
 		torch.cuda.synchronize()
 		if dist is not None:
@@ -195,11 +219,10 @@ def main():
 	for i in range(args.warmup):
 		step(queries[i])
 	sync()
-	score_ms = []
+	score_ms.clear()
 	t0 = time.perf_counter()
 	for i in range(args.steps):
 		step(queries[args.warmup + i])
-		score_ms.append(corpus.last_timings()["score_ms"])
 	sync()
 	elapsed = time.perf_counter() - t0
 	timings = corpus.last_timings()

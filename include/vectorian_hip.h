@@ -180,6 +180,11 @@ int vk_corpus_set_sentences(vk_corpus_t *c, const int64_t *sent_off, int64_t n_s
  * at most VK_MAX_SENT_LEN tokens each; slices may overlap or leave gaps.  host arrays [n_sentences]. */
 int vk_corpus_set_slices(vk_corpus_t *c, const int64_t *start, const int64_t *end, int64_t n_sentences);
 int vk_corpus_finalize(vk_corpus_t *c);
+/* A second handle on the same resident corpus (read-only arrays shared, own stream and workspaces): two handles serve
+ * two queries at a time from two host threads, so that selection, traceback and the host part of one query overlap the
+ * scoring kernel of the next.  Free the views before the owning handle.  (The reference runs one ThreadPool task per
+ * document, vectorian/index.py:544-558; here the unit of concurrency is the query.) */
+int vk_corpus_view(vk_corpus_t *src, vk_corpus_t **out);
 int vk_corpus_free(vk_corpus_t *c);
 int vk_corpus_device_bytes(const vk_corpus_t *c, int64_t *bytes);
 

@@ -133,3 +133,35 @@ def test_overlapping_slices(hip, oracle):
 	got = c.query(Qb, q_normalize=False, algorithm=hip.VK_ALG_RWMD, max_matches=12).trimmed()
 	assert_same_results(got, ref, check_mapping=False, score_tol=1e-5)
 	c.close()
+
+
+def test_views_serve_queries_from_two_threads(hip):
+	"""vk_corpus_view: a second handle on the same resident corpus; two host threads, results as from one handle"""
+	import threading
+	corpus = synth.make_contextual_corpus(5000, 2, 40, 800, 64)
+	X = corpus["X"]
+	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=64, n_tokens=X.shape[0], n_sentences=5000)
+	c.append_vectors(X)
+	c.set_sentences(corpus["sent_off"])
+	c.finalize()
+	v = c.view()
+	qs = [q["vectors"] for q in synth.make_queries(corpus, 12, 6)]
+	kw = dict(gap_s=EXP5, gap_t=EXP5, max_matches=7)
+	ref = [c.query(q, **kw).trimmed() for q in qs]
+	out = [None] * len(qs)
+
+	def work(h, idx):
+		for i in idx:
+			out[i] = h.query(qs[i], **kw).trimmed()
+	threads = [threading.Thread(target=work, args=(c, range(0, 12, 2))), threading.Thread(target=work, args=(v, range(1, 12, 2)))]
+	for t in threads:
+		t.start()
+	for t in threads:
+		t.join()
+	for a, b in zip(ref, out):
+		assert (a["sentence"] == b["sentence"]).all() and (a["score"] == b["score"]).all() and (a["mapping"] == b["mapping"]).all()
+	with pytest.raises(hip.VkError):
+		v.view()   # views are taken from the owning handle
+	v.close()
+	assert c.query(qs[0], **kw).n == 7   # the owner keeps working after its view is gone
+	c.close()

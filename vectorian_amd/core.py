@@ -85,7 +85,7 @@ class _Timings(C.Structure):
 
 
 EXPORTS = [
-	"vk_abi_version", "vk_last_error", "vk_init", "vk_device_count",
+	"vk_abi_version", "vk_last_error", "vk_init", "vk_device_count", "vk_corpus_view",
 	"vk_corpus_create", "vk_corpus_append_vectors", "vk_corpus_set_token_ids", "vk_corpus_set_token_pos",
 	"vk_corpus_set_sentences", "vk_corpus_set_slices", "vk_corpus_finalize", "vk_corpus_free", "vk_corpus_device_bytes",
 	"vk_query", "vk_query_batch", "vk_last_scores", "vk_last_timings", "vk_merge_topk"]
@@ -363,6 +363,15 @@ class Corpus:
 		t = _Timings()
 		_check(lib().vk_last_timings(self._h, C.byref(t)))
 		return {k: getattr(t, k) for k, _ in _Timings._fields_}
+
+	def view(self):
+		"""a second handle on the same resident corpus (vk_corpus_view): own stream and workspaces, shared arrays.
+		Queries on different handles may run from different threads at the same time."""
+		v = Corpus.__new__(Corpus)
+		v.__dict__.update({k: val for k, val in self.__dict__.items() if k != "_h"})
+		v._h = C.c_void_p()
+		_check(lib().vk_corpus_view(self._h, C.byref(v._h)))
+		return v
 
 	def close(self):
 		if self._h:

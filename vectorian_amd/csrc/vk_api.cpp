@@ -103,6 +103,9 @@ struct vk_corpus {
 	hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 	vk_timings last{};
 	bool have_scores = false;
+	bool is_view = false;        // shares the corpus arrays of another handle (vk_corpus_view): does not free them
+	vk_corpus *peer = nullptr;   // ring of the handles on one corpus: a handle's scoring kernel starts after its peer's
+	bool ev2_recorded = false;   // (device-side wait on ev[2]), so that scoring kernels run back to back, never queued inside each other
 };
 
 namespace {
@@ -189,10 +192,65 @@ int vk_corpus_create(const vk_corpus_desc *desc, vk_corpus_t **out) {
 	return VK_OK;
 }
 
+// A second handle on the same resident corpus: shares the read-only arrays (tiles, magnitudes, token ids, POS codes,
+// slice table) and owns a stream, events and workspaces.  Two handles serve two queries at a time from two host
+// threads: the selection, traceback and host part of one query overlap the scoring kernel of the next.
+int vk_corpus_view(vk_corpus_t *src, vk_corpus_t **out) {
+	if (!src || !out) return fail(VK_ERR_INVALID, "null argument");
+	if (!src->finalized) return fail(VK_ERR_STATE, "corpus not finalized");
+	if (src->is_view) return fail(VK_ERR_INVALID, "views are taken from the owning handle");
+	VK_HIP(hipSetDevice(src->device));
+	vk_corpus *c = new vk_corpus();
+	c->desc = src->desc; c->device = src->device;
+	c->d_pad = src->d_pad; c->nk32 = src->nk32; c->tail = src->tail; c->tile_bytes = src->tile_bytes;
+	c->rows_total = src->rows_total; c->rows_appended = src->rows_appended; c->n_tiles = src->n_tiles;
+	c->d_tiles = src->d_tiles; c->d_mag = src->d_mag; c->d_tok_id = src->d_tok_id; c->d_pos = src->d_pos;
+	c->d_sent_start = src->d_sent_start; c->d_sent_end = src->d_sent_end; c->d_long_groups = src->d_long_groups;
+	c->contiguous = src->contiguous; c->have_ids = src->have_ids; c->have_sent = src->have_sent; c->finalized = true;
+	c->max_len = src->max_len; c->max_group_tiles = src->max_group_tiles; c->max_group_tokens = src->max_group_tokens;
+	c->n_entries = src->n_entries; c->entry_sent = src->entry_sent;
+	c->n_long_groups = src->n_long_groups; c->max_short_len = src->max_short_len;
+	c->long_group_tiles = src->long_group_tiles; c->long_group_tokens = src->long_group_tokens;
+	c->uniform_len = src->uniform_len;
+	c->is_view = true;
+	c->peer = src->peer ? src->peer : src;
+	src->peer = c;
+	int rc = VK_OK;
+	do {
+		if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = fail(VK_ERR_HIP, "hipStreamCreate failed"); break; }
+		for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { rc = fail(VK_ERR_HIP, "hipEventCreate failed"); break; }
+		if (rc) break;
+		if (c->desc.layout == VK_LAYOUT_STATIC && (rc = alloc_t(c, &c->d_table, (size_t)c->n_tiles * 16 * 16 * 4))) break;
+		if ((rc = alloc_t(c, &c->d_qtile, (size_t)c->tile_bytes * 4))) break;
+		if ((rc = alloc_t(c, &c->d_ws, kGapTable))) break;
+		if ((rc = alloc_t(c, &c->d_wt, 80))) break;
+		if ((rc = alloc_t(c, &c->d_qids, 80))) break;
+		if ((rc = alloc_t(c, &c->d_out_raw, VK_MAX_MATCHES))) break;
+		if ((rc = alloc_t(c, &c->d_out_sim, (size_t)VK_MAX_MATCHES * 64))) break;
+		if ((rc = alloc_t(c, &c->d_out_map, (size_t)VK_MAX_MATCHES * 64))) break;
+		if ((rc = alloc_t(c, &c->d_scores, (size_t)c->n_entries + 8))) break;
+		if ((rc = alloc_t(c, &c->d_raw, (size_t)c->n_entries + 8))) break;
+		const size_t nblk = (size_t)((c->n_entries + kTopkChunk - 1) / kTopkChunk) + 1;
+		if ((rc = alloc_t(c, &c->d_keys[0], nblk * VK_MAX_MATCHES + kTopkChunk))) break;
+		if ((rc = alloc_t(c, &c->d_keys[1], (nblk * VK_MAX_MATCHES) / 2 + 2 * kTopkChunk))) break;
+	} while (0);
+	if (rc) { vk_corpus_free(c); return rc; }
+	*out = c;
+	return VK_OK;
+}
+
 int vk_corpus_free(vk_corpus_t *c) {
 	if (!c) return VK_OK;
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	if (c->peer) {   // unlink from the ring of handles
+		vk_corpus *p = c->peer;
+		while (p->peer != c) p = p->peer;
+		p->peer = c->peer == p ? nullptr : c->peer;
+		c->peer = nullptr;
+	}
+	if (c->is_view) c->d_tiles = nullptr, c->d_mag = nullptr, c->d_tok_id = nullptr, c->d_pos = nullptr,
+		c->d_sent_start = c->d_sent_end = nullptr, c->d_long_groups = nullptr;
 	void *ptrs[] = {c->d_tiles, c->d_mag, c->d_tok_id, c->d_pos, c->d_sent_start, c->d_sent_end, c->d_stage, c->d_qtile, c->d_ws, c->d_wt, c->d_qids,
 		c->d_table, c->d_scores, c->d_raw, c->d_boost, c->d_keys[0], c->d_keys[1], c->d_out_raw, c->d_out_sim, c->d_out_map, c->d_wrd_raw, c->d_wrd_val, c->d_bq, c->d_bqlen, c->d_bscores, c->d_bkeys[0], c->d_bkeys[1], c->d_long_groups, c->d_counter, c->d_rows_out, c->d_plan_out};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -259,6 +317,7 @@ int vk_corpus_set_token_ids(vk_corpus_t *c, const int32_t *ids, int64_t n, int32
 int vk_corpus_set_token_pos(vk_corpus_t *c, const int8_t *pos, int64_t n, int32_t mem) {
 	if (!c || !pos) return fail(VK_ERR_INVALID, "null argument");
 	if (n != c->desc.n_tokens) return fail(VK_ERR_INVALID, "POS count differs from n_tokens");
+	if (c->is_view) return fail(VK_ERR_STATE, "set POS codes on the owning handle, before taking views");
 	VK_HIP(hipSetDevice(c->device));
 	if (!c->d_pos) {
 		int rc = alloc_t(c, &c->d_pos, (size_t)n + 64);
@@ -628,6 +687,9 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	}
 
 	// ---- the fused scoring kernel ------------------------------------------
+	// handles on one corpus take turns: this scoring kernel starts when the peer's has finished (its selection and
+	// traceback then run beside this kernel); the wait is on the device, the host does not block
+	if (c->peer && c->peer->ev2_recorded) VK_HIP(hipStreamWaitEvent(st, c->peer->ev[2], 0));
 	VK_HIP(hipEventRecord(c->ev[1], st));
 	p.tiles = c->d_tiles; p.tok_id = c->d_tok_id; p.table = c->d_table; p.sent_start = c->d_sent_start; p.sent_end = c->d_sent_end;
 	p.n_sent = (int32_t)n; p.layout = is_static ? VK_DEV_LAYOUT_STATIC : VK_DEV_LAYOUT_CONTEXTUAL;
@@ -930,6 +992,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 
 	// ---- bounded result set -------------------------------------------------
 	VK_HIP(hipEventRecord(c->ev[2], st));
+	c->ev2_recorded = true;
 	int cur = 0;
 	if (k <= 64) {
 		// wave-streaming selection: n -> ceil(n/4096) * k keys -> ... -> k keys
