@@ -54,3 +54,26 @@ def test_two_rank_gloo_matches_unsharded(tmp_path, oracle):
 				assert (g[f"{qi}_{name}_sentence"] == ref["sentence"]).all()
 				assert (g[f"{qi}_{name}_score"] == ref["score"]).all()
 				assert (g[f"{qi}_{name}_mapping"] == ref["mapping"]).all()
+
+
+def test_sharded_index(tmp_path):
+	"""HipBruteForceIndex(shard=(rank, world)): two gloo ranks, each with half of the slices in its backend; Index.find
+	returns on both ranks exactly what the unsharded index returns"""
+	import json
+	sys.path.insert(0, os.path.join(ROOT, "tests"))
+	import shard_index_worker
+	with socket.socket() as s:
+		s.bind(("127.0.0.1", 0))
+		port = s.getsockname()[1]
+	env = dict(os.environ, OMP_NUM_THREADS="1")
+	cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+		"--master-addr", "127.0.0.1", "--master-port", str(port),
+		os.path.join(ROOT, "tests", "shard_index_worker.py"), str(tmp_path)]
+	r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+	assert r.returncode == 0, r.stderr[-3000:]
+	index, queries = shard_index_worker.build(None)
+	ref = shard_index_worker.answers(index, queries)
+	assert ref[0][0][:2] == [1, 3] and abs(ref[0][0][2] - 1.0) < 1e-2
+	for k in range(2):
+		got = json.load(open(tmp_path / f"index_rank{k}.json"))
+		assert got == ref

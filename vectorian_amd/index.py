@@ -493,9 +493,14 @@ class HipBruteForceIndex(Index):
 	(partition, sim, *, nlp, saliency=None); `device` selects the GPU.  The whole corpus is
 	uploaded once (token tiles in HBM); every `find` is one vk_query."""
 
-	def __init__(self, partition, sim, *, nlp=None, saliency=None, device=0, corpus_factory=None):
+	def __init__(self, partition, sim, *, nlp=None, saliency=None, device=0, corpus_factory=None, shard=None, group=None):
+		"""shard = (rank, world): this process keeps only its contiguous range of the slices in HBM (one process per
+		GPU, every process holds the same Session); `find` then merges the ranks' result sets with one all-gather
+		of k records over `group` (torch.distributed; backend "nccl" = RCCL over xGMI) and returns the same matches
+		on every rank (the reference merges per-document ResultSets, result_set.h:70-93)."""
 		super().__init__(partition, sim)
 		self._nlp = nlp
+		self._shard, self._group = shard, group
 		if not isinstance(sim, OptimizedSpanSim):
 			raise TypeError(f"{type(sim).__name__}: the HIP index implements OptimizedSpanSim")
 		token_sim = sim.token_sim
@@ -539,35 +544,57 @@ class HipBruteForceIndex(Index):
 			if self._boost.shape != (n_slices,):
 				raise ValueError("saliency must hold one float per slice")
 
+		# this process's part of the corpus: slices [sa, sb), tokens [t0, t1)
+		self._slice_off, t0, t1 = 0, 0, n_tokens
+		dev_start, dev_end, dev_off, dev_boost = self._slice_start, self._slice_end, self._sent_off, self._boost
+		if shard is not None:
+			from vectorian_amd import shards
+			rank, world = shard
+			sa, sb = shards.shard_ranges(n_slices, world)[rank]
+			self._slice_off = sa
+			t0 = int(self._slice_start[sa]) if sb > sa else 0
+			t1 = int(self._slice_end[sb - 1]) if sb > sa else 0
+			dev_start, dev_end = self._slice_start[sa:sb] - t0, self._slice_end[sa:sb] - t0
+			dev_off = np.concatenate(([0], dev_end)).astype(np.int64) if self._sent_off is not None else None
+			dev_boost = None if self._boost is None else np.ascontiguousarray(self._boost[sa:sb])
+			n_slices_dev, n_tokens_dev = sb - sa, t1 - t0
+		else:
+			n_slices_dev, n_tokens_dev = n_slices, n_tokens
+		self._dev_boost = dev_boost
+
 		make = corpus_factory or core.Corpus
 		emb = self._embedding
 		self._token_ids = None   # static layout: token id per corpus token (joint vocabularies of the transport flows)
 		if emb.is_static:
 			vocab_vectors = emb.encode_tokens(session.vocab.tokens)
 			# magnitudes are kept for WordRotatorsDistance (metric/static.cpp:69-73, 80-120); rows are normalised on upload
-			self._corpus = make(layout=core.VK_LAYOUT_STATIC, d=emb.dimension, n_tokens=n_tokens, n_sentences=n_slices,
+			self._corpus = make(layout=core.VK_LAYOUT_STATIC, d=emb.dimension, n_tokens=n_tokens_dev, n_sentences=n_slices_dev,
 				vocab_size=max(1, session.vocab.size), keep_magnitudes=True, device=device)
 			E = vocab_vectors.unmodified if session.vocab.size else np.zeros((1, emb.dimension), np.float32)
 			self._corpus.append_vectors(E, normalize=True)
 			ids = np.concatenate([session.doc_token_ids(i) for i in range(len(session.documents))]) if n_tokens else np.zeros(0, np.int32)
-			self._corpus.set_token_ids(ids)
+			self._corpus.set_token_ids(np.ascontiguousarray(ids[t0:t1]))
 			self._token_ids = np.asarray(ids, dtype=np.int32)
 		elif emb.is_contextual:
 			from vectorian_amd.embedding import Vectors
-			self._corpus = make(layout=core.VK_LAYOUT_CONTEXTUAL, d=emb.dimension, n_tokens=n_tokens, n_sentences=n_slices,
+			self._corpus = make(layout=core.VK_LAYOUT_CONTEXTUAL, d=emb.dimension, n_tokens=n_tokens_dev, n_sentences=n_slices_dev,
 				keep_magnitudes=True, device=device)
+			doc_base = 0
 			for doc in session.documents:
-				self._corpus.append_vectors(Vectors(doc.contextual_vectors(emb.name)).unmodified, normalize=True)
+				a, b = max(t0, doc_base), min(t1, doc_base + doc.n_tokens)   # this document's tokens inside the shard
+				if b > a:
+					self._corpus.append_vectors(Vectors(doc.contextual_vectors(emb.name)).unmodified[a - doc_base:b - doc_base], normalize=True)
+				doc_base += doc.n_tokens
 		else:
 			raise TypeError(emb)
 		self._has_pos = all(doc.pos is not None for doc in session.documents) and len(session.documents) > 0
-		if self._has_pos and n_tokens:
+		if self._has_pos and n_tokens_dev:
 			self._corpus.set_token_pos(np.array(
-				[session.pos_code(x) for doc in session.documents for x in doc.pos], dtype=np.int8))
-		if self._sent_off is not None:
-			self._corpus.set_sentences(self._sent_off)
+				[session.pos_code(x) for doc in session.documents for x in doc.pos], dtype=np.int8)[t0:t1])
+		if dev_off is not None:
+			self._corpus.set_sentences(dev_off)
 		else:
-			self._corpus.set_slices(self._slice_start, self._slice_end)
+			self._corpus.set_slices(dev_start, dev_end)
 		self._corpus.finalize()
 
 	@property
@@ -642,9 +669,14 @@ class HipBruteForceIndex(Index):
 		qv = emb.encode_tokens(p_query.tokens)
 		if emb.is_static:
 			top = self._corpus.query(qv.unmodified, q_normalize=True, q_token_ids=p_query.token_ids,
-				boost=self._boost, want_flow=True, **args)
+				boost=self._dev_boost, want_flow=True, **args)
 		else:
-			top = self._corpus.query(qv.unmodified, q_normalize=True, boost=self._boost, want_flow=True, **args)
+			top = self._corpus.query(qv.unmodified, q_normalize=True, boost=self._dev_boost, want_flow=True, **args)
+		if self._shard is not None:
+			# local slice ids -> global, then ResultSet.extend across the ranks; every rank gets the same set
+			# (the rows / plans of transport winners stay on their rank: their flows are not stated in sharded mode)
+			from vectorian_amd import shards
+			top = shards.allgather_merge(top, self._slice_off, args["max_matches"], group=self._group)
 		if progress:
 			progress(1.0)
 		return self._matches_from_topk(p_query, top, gaps, args, np.asarray(qv.magnitudes, dtype=np.float32))
