@@ -61,6 +61,45 @@ def test_rwmd_batch_32_token_sentences(hip, oracle, d, len_t, n_q, flags):
 	c.close()
 
 
+EXP5 = ("table", (1 - 2.0 ** (-np.arange(0, 65) / 5)).astype(np.float32))
+
+
+@pytest.mark.parametrize("d,lo,hi", [(300, 32, 32), (64, 1, 64), (768, 8, 40)])
+def test_shared_pass_alignment_batch(hip, oracle, d, lo, hi):
+	"""queries with common options share one pass over the token tiles (vk_score_batch_kernel): results as from
+	single queries and as the oracle's"""
+	n = 901
+	corpus = synth.make_contextual_corpus(n, lo, hi, 1500, d)
+	Xb = prep_contextual(corpus)
+	c = hip_contextual_corpus(hip, corpus, Xb)
+	qs = [prep_query(q) for q in synth.make_queries(corpus, 7, 11)]
+	qs[1], qs[4], qs[6] = qs[1][:3], qs[4][:8], qs[6][:1]     # different lengths in one batch
+	boost = np.random.default_rng(1).uniform(0.5, 1.5, size=n).astype(np.float32)
+	for loc, ms, gaps, bst in ((0, 0.0, (0.1, 0.1), None), (0, 0.0, (EXP5, EXP5), boost), (1, -1e9, (EXP5, EXP5), None),
+			(2, -1e9, (("affine", 0.2, 0.05),) * 2, None), (1, -1e9, (0.05, 0.2), boost)):
+		kw = dict(locality=loc, gap_s=gaps[0], gap_t=gaps[1], max_matches=9, min_score=ms, boost=bst)
+		outs = c.query_batch(qs, q_normalize=False, **kw)
+		assert c.last_timings()["score_ms"] > 0
+		for Qb, got in zip(qs, outs):
+			ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=corpus["sent_off"], X=Xb, Q=Qb, **kw)
+			assert_same_results(got.trimmed(), ref)
+			single = c.query(Qb, q_normalize=False, **kw)
+			assert (got.sentence[:got.n] == single.sentence[:single.n]).all()
+			np.testing.assert_array_equal(got.score[:got.n], single.score[:single.n])
+			np.testing.assert_array_equal(got.mapping[:got.n], single.mapping[:single.n])
+	# relaxed WMD over ragged sentences takes the same shared pass
+	for flags in ((True, True, True), (True, False, False)):
+		outs = c.query_batch(qs, algorithm=hip.VK_ALG_RWMD, rwmd=flags, q_normalize=False, max_matches=9)
+		for Qb, got in zip(qs, outs):
+			single = c.query(Qb, algorithm=hip.VK_ALG_RWMD, rwmd=flags, q_normalize=False, max_matches=9)
+			if d == 300:   # uniform 32-token sentences: the GEMM kernel, other summation order
+				np.testing.assert_allclose(got.score[:got.n], single.score[:single.n], atol=2e-6)
+			else:
+				np.testing.assert_array_equal(got.score[:got.n], single.score[:single.n])
+				assert (got.sentence[:got.n] == single.sentence[:single.n]).all()
+	c.close()
+
+
 def test_batch_fallback_for_alignment_and_ragged(hip, oracle):
 	corpus = synth.make_contextual_corpus(400, 2, 30, 800, 64)
 	Xb = prep_contextual(corpus)

@@ -130,6 +130,31 @@ struct VkFlowParams {
 	float *edge_sim;           // [k x 16]
 };
 
+// a batch of at most 4 queries with common options over one pass of a contextual corpus (vk_score_batch_kernel)
+struct VkScoreBatchParams {
+	const uint8_t *tiles;
+	const int32_t *sent_start;
+	const int32_t *sent_end;
+	int32_t n_sent;
+	int32_t nk32, tail, tile_bytes;
+	const uint8_t *qtiles;     // n_queries query tiles (16 rows each), tile_bytes apart
+	int32_t n_queries;
+	int32_t n_strips;          // strips per wave in the LDS carve-up (>= n_queries)
+	int32_t len_t[4];
+	int32_t locality;
+	int32_t gap_mode;          // 0 linear, 1 affine, 2 general, 3 / 6 general (register history), 4 RWMD (injective)
+	int32_t rwmd_symmetric, rwmd_normalize_bow;
+	float gs, gt, a_s, a_t, open_s, open_t;
+	const float *ws;
+	const float *wt;
+	const float *boost;
+	float *scores;             // [n_queries x n_sent]
+	float *raw;                // [n_queries x n_sent]
+	int32_t lds_floats_per_wave;
+	int32_t s_rows_per_wave;
+	int32_t h_rows;
+};
+
 // queries of 17 .. 64 tokens (vk_wide_kernel): one wave per slice
 struct VkWideParams {
 	const uint8_t *tiles;
@@ -180,6 +205,7 @@ hipError_t vk_launch_table(const uint8_t *etiles, const uint8_t *qtile, int32_t 
 	int32_t tile_bytes, float *table, const int32_t *q_ids, int32_t len_t, int32_t V, hipStream_t stream);
 hipError_t vk_launch_score(const VkScoreParams *p, int32_t grid, size_t smem_bytes, hipStream_t stream);
 hipError_t vk_launch_span(const VkScoreParams *p, hipStream_t stream);
+hipError_t vk_launch_score_batch(const VkScoreBatchParams *p, int32_t lt, size_t smem, hipStream_t stream);
 hipError_t vk_launch_topk_scores(const float *scores, int64_t n, float min_score, int32_t k, uint64_t *out,
 	int32_t *n_blocks_out, hipStream_t stream);
 hipError_t vk_launch_topk_keys(const uint64_t *in, int64_t n, int32_t k, uint64_t *out, int32_t *n_blocks_out,
