@@ -370,6 +370,7 @@ class Corpus:
 		v = Corpus.__new__(Corpus)
 		v.__dict__.update({k: val for k, val in self.__dict__.items() if k != "_h"})
 		v._h = C.c_void_p()
+		v._owner = self   # the shared arrays live as long as the owning handle: keep it alive
 		_check(lib().vk_corpus_view(self._h, C.byref(v._h)))
 		return v
 
