@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 2
+#define VK_ABI_VERSION 3
 #define VK_MAX_QUERY_LEN 64   /* query tokens */
 #define VK_FAST_QUERY_LEN 16  /* queries up to this length run in the fused kernels (one 16-wide MFMA column block); longer ones
                                  (alignments and injective RWMD only) take a one-wave-per-slice kernel, ~10x slower */
@@ -68,6 +68,13 @@ typedef enum { VK_MEM_HOST = 0, VK_MEM_DEVICE = 1 } vk_mem;
  *   slice/static.h:71-75; metric/static.cpp:9-78). */
 typedef enum { VK_LAYOUT_CONTEXTUAL = 0, VK_LAYOUT_STATIC = 1 } vk_layout;
 
+/* VK_PREC_BF16 (default): unit rows rounded to bf16, cosines on v_mfma_f32_16x16x32_bf16 -- the fast path
+ * (north star); scores follow the reference's algorithm on the ROUNDED vectors and can differ from its fp32
+ * results by a few 1e-4.  VK_PREC_F32: unit rows in fp32, cosines on v_mfma_f32_16x16x4_f32 (exact fp32
+ * products, fp32 accumulation) -- the reference's own precision (CosineSim = fp32 sgemm, vectorian/sim/vector.py:
+ * 66-78) at twice the bytes per token; scores within 1e-6 of the fp32 CPU path. */
+typedef enum { VK_PREC_BF16 = 0, VK_PREC_F32 = 1 } vk_precision;
+
 typedef struct vk_corpus vk_corpus_t;
 
 typedef struct {
@@ -77,6 +84,7 @@ typedef struct {
 	int64_t n_sentences;   /* slices of this shard */
 	int32_t vocab_size;    /* VK_LAYOUT_STATIC: rows of the vocabulary table */
 	int32_t keep_magnitudes; /* keep |x| per appended row (needed by VK_ALG_WRD; metric/contextual.cpp:49-54, metric/static.cpp:69-73) */
+	int32_t precision;       /* vk_precision: how the unit rows are kept in HBM */
 } vk_corpus_desc;
 
 typedef struct {

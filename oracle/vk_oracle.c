@@ -881,9 +881,11 @@ static int score_sentence(const work *w, int64_t s, float *Sbuf, float *xbuf, fl
 
 	if (c->layout == VKO_LAYOUT_CONTEXTUAL) {
 		for (int32_t i = 0; i < len_s; i++) {
-			widen_rows(c->X + (t0 + i) * (int64_t)c->d, c->d, xbuf);
+			const float *xr = xbuf;
+			if (c->X_f32) xr = c->X_f32 + (t0 + i) * (int64_t)c->d;
+			else widen_rows(c->X + (t0 + i) * (int64_t)c->d, c->d, xbuf);
 			for (int32_t j = 0; j < len_t; j++)
-				Sbuf[i * len_t + j] = clip01(dot_f32(xbuf, w->qf + (int64_t)j * c->d, c->d));
+				Sbuf[i * len_t + j] = clip01(dot_f32(xr, w->qf + (int64_t)j * c->d, c->d));
 		}
 	} else {
 		for (int32_t i = 0; i < len_s; i++) {
@@ -983,10 +985,20 @@ int vko_find_many(const vko_corpus *c, const vko_query *qs, int32_t n_queries, v
 	float **table = (float **)calloc((size_t)n_queries, sizeof(float *));
 	for (int32_t i = 0; i < n_queries; i++) {
 		qf[i] = (float *)malloc(sizeof(float) * (size_t)qs[i].len_t * c->d);
-		widen_rows(qs[i].Q, (int64_t)qs[i].len_t * c->d, qf[i]);
+		if (qs[i].Q_f32) memcpy(qf[i], qs[i].Q_f32, sizeof(float) * (size_t)qs[i].len_t * c->d);
+		else widen_rows(qs[i].Q, (int64_t)qs[i].len_t * c->d, qf[i]);
 		if (c->layout == VKO_LAYOUT_STATIC) {
 			table[i] = (float *)malloc(sizeof(float) * (size_t)c->V * qs[i].len_t);
-			vko_sim_table_static_bf16(c->E, c->V, c->d, qs[i].Q, qs[i].len_t, qs[i].q_ids, table[i]);
+			if (c->E_f32) {
+				/* static.cpp:9-78 on fp32 rows: sim = E . Q^T, sim[id(t_j)][j] = 1, clip */
+				for (int32_t v = 0; v < c->V; v++)
+					for (int32_t j = 0; j < qs[i].len_t; j++)
+						table[i][(int64_t)v * qs[i].len_t + j] = dot_f32(c->E_f32 + (int64_t)v * c->d, qf[i] + (int64_t)j * c->d, c->d);
+				if (qs[i].q_ids)
+					for (int32_t j = 0; j < qs[i].len_t; j++)
+						if (qs[i].q_ids[j] >= 0 && qs[i].q_ids[j] < c->V) table[i][(int64_t)qs[i].q_ids[j] * qs[i].len_t + j] = 1.0f;
+				for (int64_t e = 0; e < (int64_t)c->V * qs[i].len_t; e++) table[i][e] = clip01(table[i][e]);
+			} else vko_sim_table_static_bf16(c->E, c->V, c->d, qs[i].Q, qs[i].len_t, qs[i].q_ids, table[i]);
 		}
 	}
 

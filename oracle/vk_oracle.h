@@ -125,6 +125,9 @@ typedef struct {
 	const int64_t *sent_off;  /* [n_sentences+1], token units, contiguous (document.h:147-169, B8) */
 	const int64_t *sent_end;  /* optional [n_sentences]: slice s = [sent_off[s], sent_end[s]) (sliding windows) */
 	const int8_t *pos_s;      /* optional [n_tokens]: universal POS code per token (TagWeightedSlice) */
+	/* fp32 unit rows instead of the bf16 ones (the reference's own precision, vectorian/sim/vector.py:66-78) */
+	const float *X_f32;       /* contextual: [n_tokens x d], used when non-NULL */
+	const float *E_f32;       /* static: [V x d], used when non-NULL */
 } vko_corpus;
 
 typedef struct {
@@ -147,6 +150,7 @@ typedef struct {
 	float pos_mismatch_penalty;
 	float similarity_threshold;
 	int32_t wmd_full;         /* VKO_ALG_RWMD with relaxed = False: full WMD */
+	const float *Q_f32;       /* fp32 unit rows [len_t x d], used when non-NULL */
 } vko_query;
 
 typedef struct {

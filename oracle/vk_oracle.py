@@ -40,7 +40,8 @@ class Corpus(C.Structure):
 		("n_tokens", C.c_int64), ("n_sentences", C.c_int64),
 		("X", C.c_void_p), ("X_mag", C.c_void_p),
 		("tok_id", C.c_void_p), ("E", C.c_void_p), ("V", C.c_int32),
-		("sent_off", C.c_void_p), ("sent_end", C.c_void_p), ("pos_s", C.c_void_p)]
+		("sent_off", C.c_void_p), ("sent_end", C.c_void_p), ("pos_s", C.c_void_p),
+		("X_f32", C.c_void_p), ("E_f32", C.c_void_p)]
 
 
 class Query(C.Structure):
@@ -55,7 +56,8 @@ class Query(C.Structure):
 		("rwmd_injective", C.c_int32), ("rwmd_symmetric", C.c_int32), ("rwmd_normalize_bow", C.c_int32),
 		("wrd_normalize_magnitudes", C.c_int32),
 		("tag_weights", C.c_void_p), ("q_pos", C.c_void_p),
-		("pos_mismatch_penalty", C.c_float), ("similarity_threshold", C.c_float), ("wmd_full", C.c_int32)]
+		("pos_mismatch_penalty", C.c_float), ("similarity_threshold", C.c_float), ("wmd_full", C.c_int32),
+		("Q_f32", C.c_void_p)]
 
 
 class Result(C.Structure):
@@ -274,13 +276,18 @@ def find_many(*, layout, d, sent_off, Qs, sent_end=None, X=None, X_mag=None, tok
 		c.sent_end = _ptr(sent_end)
 	c.layout, c.d = layout, d
 	c.n_tokens, c.n_sentences = int(max(sent_off[-1], sent_end[-1] if sent_end is not None and len(sent_end) else 0)), n_sent
-	if X is not None:
+	# rows of dtype float32 are taken as fp32 unit rows (the reference's own precision), uint16 as bf16 bits
+	if X is not None and np.asarray(X).dtype == np.float32:
+		X = np.ascontiguousarray(X, dtype=np.float32); c.X_f32 = _ptr(X)
+	elif X is not None:
 		X = np.ascontiguousarray(X, dtype=np.uint16); c.X = _ptr(X)
 	if X_mag is not None:
 		X_mag = _f32(X_mag); c.X_mag = _ptr(X_mag)
 	if tok_id is not None:
 		tok_id = np.ascontiguousarray(tok_id, dtype=np.int32); c.tok_id = _ptr(tok_id)
-	if E is not None:
+	if E is not None and np.asarray(E).dtype == np.float32:
+		E = np.ascontiguousarray(E, dtype=np.float32); c.E_f32 = _ptr(E); c.V = E.shape[0]
+	elif E is not None:
 		E = np.ascontiguousarray(E, dtype=np.uint16); c.E = _ptr(E); c.V = E.shape[0]
 	c.sent_off = _ptr(sent_off)
 	if pos_s is not None:
@@ -294,10 +301,15 @@ def find_many(*, layout, d, sent_off, Qs, sent_end=None, X=None, X_mag=None, tok
 	bufs = []
 	k = max_matches
 	for i in range(nq):
-		Q = np.ascontiguousarray(Qs[i], dtype=np.uint16)
-		keep.append(Q)
 		q = qs[i]
-		q.algorithm, q.len_t, q.Q = algorithm, Q.shape[0], _ptr(Q)
+		if np.asarray(Qs[i]).dtype == np.float32:
+			Q = np.ascontiguousarray(Qs[i], dtype=np.float32)
+			q.Q_f32 = _ptr(Q)
+		else:
+			Q = np.ascontiguousarray(Qs[i], dtype=np.uint16)
+			q.Q = _ptr(Q)
+		keep.append(Q)
+		q.algorithm, q.len_t = algorithm, Q.shape[0]
 		if Q_mags is not None and Q_mags[i] is not None:
 			m = _f32(Q_mags[i]); keep.append(m); q.Q_mag = _ptr(m)
 		if q_ids is not None and q_ids[i] is not None:

@@ -20,8 +20,9 @@ def _gap(g, n=65):
 
 
 class OracleCorpus:
-	def __init__(self, *, layout, d, n_tokens, n_sentences, vocab_size=0, keep_magnitudes=False, device=None):
+	def __init__(self, *, layout, d, n_tokens, n_sentences, vocab_size=0, keep_magnitudes=False, device=None, precision="bf16"):
 		self.layout, self.d = layout, d
+		self.precision = precision
 		self.n_tokens, self.n_sentences, self.vocab_size = n_tokens, n_sentences, vocab_size
 		self._rows, self._mags = [], []
 		self._ids = None
@@ -33,7 +34,9 @@ class OracleCorpus:
 		rows = np.ascontiguousarray(rows)
 		if rows.dtype == np.uint16:
 			rows = synth.bf16_bits_to_f32(rows)
-		if normalize:
+		if self.precision == "f32":
+			b, m = (vo.normalize_rows(rows), vo.magnitudes(rows)) if normalize else (rows.astype(np.float32), np.ones(len(rows), np.float32))
+		elif normalize:
 			b, m = vo.normalize_rows_bf16(rows)
 		else:
 			b, m = synth.to_bf16_bits(rows), np.ones(len(rows), np.float32)
@@ -55,7 +58,7 @@ class OracleCorpus:
 		self._end = np.ascontiguousarray(end, dtype=np.int64)
 
 	def finalize(self):
-		self._X = np.concatenate(self._rows) if self._rows else np.zeros((0, self.d), np.uint16)
+		self._X = np.concatenate(self._rows) if self._rows else np.zeros((0, self.d), np.float32 if self.precision == "f32" else np.uint16)
 		self._mag = np.concatenate(self._mags) if self._mags else np.zeros(0, np.float32)
 
 	def query(self, q_vectors, *, locality=0, gap_s=0.0, gap_t=0.0, algorithm=0, q_token_ids=None, q_normalize=True,
@@ -66,7 +69,9 @@ class OracleCorpus:
 		if q.dtype == np.uint16:
 			q = synth.bf16_bits_to_f32(q)
 		q = q.astype(np.float32)
-		if q_normalize:
+		if self.precision == "f32":
+			Qb, qmag = (vo.normalize_rows(q), vo.magnitudes(q)) if q_normalize else (q, np.ones(len(q), np.float32))
+		elif q_normalize:
 			Qb, qmag = vo.normalize_rows_bf16(q)
 		else:
 			Qb, qmag = synth.to_bf16_bits(q), np.ones(len(q), np.float32)
@@ -91,7 +96,13 @@ class OracleCorpus:
 		for i in range(n):
 			s = int(r["sentence"][i])
 			a, b = int(self._off[s]), int(self._end[s] if self._end is not None else self._off[s + 1])
-			if self.layout == core.VK_LAYOUT_STATIC:
+			if self.precision == "f32":
+				rows = self._X[self._ids[a:b]] if self.layout == core.VK_LAYOUT_STATIC else self._X[a:b]
+				S = vo.sim_f32(rows, Qb)
+				if self.layout == core.VK_LAYOUT_STATIC and q_token_ids is not None:
+					for j, qid in enumerate(q_token_ids):
+						S[self._ids[a:b] == qid, j] = 1.0
+			elif self.layout == core.VK_LAYOUT_STATIC:
 				table = vo.sim_table_static_bf16(self._X, Qb, q_token_ids)
 				S = table[self._ids[a:b]]
 			else:

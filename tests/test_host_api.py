@@ -187,6 +187,22 @@ def test_transport_strategies_over_static_embedding():
 		assert any("edges" in r for r in j["regions"])
 
 
+def test_f32_precision_index(oracle):
+	"""precision="f32": the index keeps fp32 unit vectors (the reference's own precision); scores move by a few 1e-4 at most"""
+	session, emb, words, rng = toy_session(n_docs=3, sents_per_doc=40, V=300, d=32)
+	sim = OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), alignment.LocalAlignment(gap=alignment.smooth_gap_cost(5)))
+	doc = session.documents[2]
+	st = doc.spans["sentence"]["start"][9]
+	query = " ".join(doc.tokens[st:st + 6])
+	res = {}
+	for prec in ("bf16", "f32"):
+		index = session.partition("sentence").index(sim, corpus_factory=OracleCorpus, precision=prec)
+		res[prec] = index.find(query, n=8)
+	assert [(m.doc_index, m.slice_id) for m in res["f32"]][:1] == [(2, 9)]
+	a, b = np.array([m.score for m in res["bf16"]]), np.array([m.score for m in res["f32"]])
+	assert 0 < np.abs(a - b).max() < 3e-3
+
+
 def test_unsupported_options_are_explicit():
 	session, emb, words, rng = toy_session(n_docs=1, sents_per_doc=3, V=50, d=16)
 	ts = EmbeddingTokenSim(emb, CosineSim())

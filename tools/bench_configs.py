@@ -34,6 +34,7 @@ def main():
 	ap.add_argument("--k", type=int, default=10)
 	ap.add_argument("--layout", choices=["contextual", "static"], default="contextual")
 	ap.add_argument("--batch", type=int, default=0, help="queries per vk_query_batch call (config 4: 256)")
+	ap.add_argument("--precision", choices=["bf16", "f32"], default="bf16", help="how the unit rows are kept in HBM")
 	args = ap.parse_args()
 
 	import torch
@@ -86,7 +87,7 @@ def main():
 		corpus.close()
 		return
 	corpus = core.Corpus(layout=core.VK_LAYOUT_CONTEXTUAL, d=args.d, n_tokens=n_tok, n_sentences=args.sentences,
-		keep_magnitudes=args.alg == "wrd")
+		keep_magnitudes=args.alg == "wrd", precision=args.precision)
 	E_dev = torch.from_numpy(E).to(device)
 	gen = torch.Generator(device=device)
 	gen.manual_seed(7)

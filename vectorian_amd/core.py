@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("VECTORIAN_HIP_LIB", os.path.join(_HERE, "lib", "libve
 VK_MAX_QUERY_LEN = 64
 VK_MAX_SENT_LEN = 512
 VK_FAST_SENT_LEN = 64
+VK_PREC_BF16, VK_PREC_F32 = 0, 1
 VK_FAST_QUERY_LEN = 16
 VK_MAX_MATCHES = 1024
 
@@ -45,7 +46,7 @@ class _CorpusDesc(C.Structure):
 	_fields_ = [
 		("layout", C.c_int32), ("d", C.c_int32),
 		("n_tokens", C.c_int64), ("n_sentences", C.c_int64),
-		("vocab_size", C.c_int32), ("keep_magnitudes", C.c_int32)]
+		("vocab_size", C.c_int32), ("keep_magnitudes", C.c_int32), ("precision", C.c_int32)]
 
 
 class _Gap(C.Structure):
@@ -117,7 +118,7 @@ def lib():
 		L.vk_last_scores.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 		L.vk_last_timings.argtypes = [C.c_void_p, C.POINTER(_Timings)]
 		L.vk_merge_topk.argtypes = [C.POINTER(_TopkOut), C.c_int32, C.c_int32, C.c_int32, C.POINTER(_TopkOut)]
-		if L.vk_abi_version() != 2:
+		if L.vk_abi_version() != 3:
 			raise RuntimeError("libvectorian_hip.so ABI version mismatch")
 		_lib = L
 	return _lib
@@ -223,11 +224,12 @@ def merge_topk(sets, len_t, max_matches):
 class Corpus:
 	"""A corpus shard resident in HBM (opaque vk_corpus_t handle)."""
 
-	def __init__(self, *, layout, d, n_tokens, n_sentences, vocab_size=0, keep_magnitudes=False, device=None):
+	def __init__(self, *, layout, d, n_tokens, n_sentences, vocab_size=0, keep_magnitudes=False, device=None, precision="bf16"):
+		"""precision: "bf16" (unit rows rounded to bf16, the fast path) or "f32" (the reference's own precision, twice the bytes)"""
 		if device is not None:
 			init(device)
 		self._h = C.c_void_p()
-		desc = _CorpusDesc(layout, d, n_tokens, n_sentences, vocab_size, int(keep_magnitudes))
+		desc = _CorpusDesc(layout, d, n_tokens, n_sentences, vocab_size, int(keep_magnitudes), {"bf16": VK_PREC_BF16, "f32": VK_PREC_F32}[precision])
 		_check(lib().vk_corpus_create(C.byref(desc), C.byref(self._h)))
 		self.layout, self.d = layout, d
 		self.n_tokens, self.n_sentences, self.vocab_size = n_tokens, n_sentences, vocab_size

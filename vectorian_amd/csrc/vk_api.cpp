@@ -67,6 +67,7 @@ struct vk_corpus {
 	int device = 0;
 	hipStream_t stream = nullptr;
 	int d_pad = 0, nk32 = 0, tail = 0, tile_bytes = 0;
+	int prec = 0;                // vk_precision: 1 = fp32 tiles (nk32 then counts blocks of 16 features, tail = 0)
 	int64_t rows_total = 0, rows_appended = 0, n_tiles = 0;
 	uint8_t *d_tiles = nullptr;
 	float *d_mag = nullptr;
@@ -155,6 +156,7 @@ int vk_corpus_create(const vk_corpus_desc *desc, vk_corpus_t **out) {
 	if (desc->n_tokens < 0 || desc->n_tokens >= (1ll << 31) - 64) return fail(VK_ERR_INVALID, "n_tokens must be < 2^31 per shard");
 	if (desc->n_sentences < 0 || desc->n_sentences >= (1ll << 31) - 8) return fail(VK_ERR_INVALID, "n_sentences out of range");
 	if (desc->layout == VK_LAYOUT_STATIC && desc->vocab_size < 1) return fail(VK_ERR_INVALID, "static layout needs vocab_size >= 1");
+	if (desc->precision != VK_PREC_BF16 && desc->precision != VK_PREC_F32) return fail(VK_ERR_INVALID, "bad precision");
 
 	int dev = 0;
 	VK_HIP(hipGetDevice(&dev));
@@ -162,9 +164,16 @@ int vk_corpus_create(const vk_corpus_desc *desc, vk_corpus_t **out) {
 	c->desc = *desc;
 	c->device = dev;
 	c->d_pad = (desc->d + 15) / 16 * 16;
-	c->nk32 = (c->d_pad + 31) / 32;   // K=32 steps; the last one is half filled when tail
-	c->tail = (c->d_pad % 32) ? 1 : 0;
-	c->tile_bytes = c->d_pad * 32;
+	c->prec = desc->precision == VK_PREC_F32 ? 1 : 0;
+	if (c->prec) {
+		c->nk32 = c->d_pad / 16;          // fp32 tiles: blocks of 16 features, 1 KiB each
+		c->tail = 0;
+		c->tile_bytes = c->d_pad * 64;
+	} else {
+		c->nk32 = (c->d_pad + 31) / 32;   // K=32 steps; the last one is half filled when tail
+		c->tail = (c->d_pad % 32) ? 1 : 0;
+		c->tile_bytes = c->d_pad * 32;
+	}
 	c->rows_total = desc->layout == VK_LAYOUT_STATIC ? desc->vocab_size : desc->n_tokens;
 	c->n_tiles = (c->rows_total + 15) / 16 + 1;   // + one zero tile: waves may read one tile past the end
 
@@ -203,7 +212,7 @@ int vk_corpus_view(vk_corpus_t *src, vk_corpus_t **out) {
 	VK_HIP(hipSetDevice(src->device));
 	vk_corpus *c = new vk_corpus();
 	c->desc = src->desc; c->device = src->device;
-	c->d_pad = src->d_pad; c->nk32 = src->nk32; c->tail = src->tail; c->tile_bytes = src->tile_bytes;
+	c->d_pad = src->d_pad; c->nk32 = src->nk32; c->tail = src->tail; c->tile_bytes = src->tile_bytes; c->prec = src->prec;
 	c->rows_total = src->rows_total; c->rows_appended = src->rows_appended; c->n_tiles = src->n_tiles;
 	c->d_tiles = src->d_tiles; c->d_mag = src->d_mag; c->d_tok_id = src->d_tok_id; c->d_pos = src->d_pos;
 	c->d_sent_start = src->d_sent_start; c->d_sent_end = src->d_sent_end; c->d_long_groups = src->d_long_groups;
@@ -277,7 +286,7 @@ int vk_corpus_append_vectors(vk_corpus_t *c, const void *rows, int64_t n_rows, i
 	const size_t row_bytes = esz * (size_t)c->desc.d;
 	if (mem == VK_MEM_DEVICE) {
 		VK_HIP(vk_launch_pack(rows, dtype == VK_BF16, n_rows, c->desc.d, c->d_pad, c->rows_appended, c->d_tiles, c->d_mag,
-			normalize, c->stream));
+			normalize, c->prec, c->stream));
 		VK_HIP(hipStreamSynchronize(c->stream));
 		c->rows_appended += n_rows;
 		return VK_OK;
@@ -292,7 +301,7 @@ int vk_corpus_append_vectors(vk_corpus_t *c, const void *rows, int64_t n_rows, i
 		const int64_t nr = std::min(rows_per_chunk, n_rows - r);
 		VK_HIP(hipMemcpyAsync(c->d_stage, (const uint8_t *)rows + (size_t)r * row_bytes, (size_t)nr * row_bytes, hipMemcpyHostToDevice, c->stream));
 		VK_HIP(vk_launch_pack(c->d_stage, dtype == VK_BF16, nr, c->desc.d, c->d_pad, c->rows_appended + r, c->d_tiles, c->d_mag,
-			normalize, c->stream));
+			normalize, c->prec, c->stream));
 		VK_HIP(hipStreamSynchronize(c->stream));
 	}
 	c->rows_appended += n_rows;
@@ -536,6 +545,11 @@ static void pack_query(const vk_corpus *c, const vk_query_desc *q, std::vector<u
 			}
 		}
 		for (int k = 0; k < d; k++) {
+			if (c->prec) {   // fp32 tile: block k >> 4, lane 16 (k & 3) + row, element (k & 15) >> 2
+				const size_t off = (size_t)(i >> 4) * c->tile_bytes + (size_t)(k >> 4) * 1024 + (size_t)((k & 3) * 16 + (i & 15)) * 16 + (size_t)((k & 15) >> 2) * 4;
+				memcpy(&tile[off], &row[(size_t)k], 4);
+				continue;
+			}
 			const uint16_t b = f32_to_bf16(row[(size_t)k]);
 			const int t = k >> 5, g = (k & 31) >> 3, j = k & 7;
 			const size_t off = (size_t)(i >> 4) * c->tile_bytes + (size_t)t * 1024 + (size_t)(g * 16 + (i & 15)) * 16 + (size_t)j * 2;
@@ -577,7 +591,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		VK_HIP(hipMemcpyAsync(c->d_keys[1], hk.data(), hk.size() * 8, hipMemcpyHostToDevice, c->stream));
 		VkWrdParams w{};
 		w.tiles = c->d_tiles; w.tok_id = c->d_tok_id; w.table = c->d_table; w.sent_start = c->d_sent_start; w.sent_end = c->d_sent_end;
-		w.layout = is_static_l ? VK_DEV_LAYOUT_STATIC : VK_DEV_LAYOUT_CONTEXTUAL; w.nk32 = c->nk32; w.tail = c->tail; w.tile_bytes = c->tile_bytes;
+		w.layout = is_static_l ? VK_DEV_LAYOUT_STATIC : VK_DEV_LAYOUT_CONTEXTUAL; w.nk32 = c->nk32; w.tail = c->tail; w.tile_bytes = c->tile_bytes; w.prec = c->prec;
 		w.qtile = c->d_qtile; w.len_t = q->len_t; w.mag = c->d_mag;
 		w.keys = c->d_keys[1]; w.rows_out = c->d_rows_out;
 		VK_HIP(vk_launch_rows(&w, cnt, c->stream));
@@ -684,7 +698,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		VK_HIP(hipMemcpyAsync(c->d_qids, ids, sizeof ids, hipMemcpyHostToDevice, st));
 		for (int t = 0; t < nq; t++)   // one [V_pad x 16] table per 16 query tokens
 			VK_HIP(vk_launch_table(c->d_tiles, c->d_qtile + (size_t)t * c->tile_bytes, (int32_t)c->n_tiles, c->nk32, c->tail, c->tile_bytes,
-				c->d_table + t * table_stride, q->q_token_ids ? c->d_qids + t * 16 : nullptr, std::min(16, q->len_t - t * 16), c->desc.vocab_size, st));
+				c->d_table + t * table_stride, q->q_token_ids ? c->d_qids + t * 16 : nullptr, std::min(16, q->len_t - t * 16), c->desc.vocab_size, c->prec, st));
 	}
 
 	// ---- the fused scoring kernel ------------------------------------------
@@ -694,7 +708,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	VK_HIP(hipEventRecord(c->ev[1], st));
 	p.tiles = c->d_tiles; p.tok_id = c->d_tok_id; p.table = c->d_table; p.sent_start = c->d_sent_start; p.sent_end = c->d_sent_end;
 	p.n_sent = (int32_t)n; p.layout = is_static ? VK_DEV_LAYOUT_STATIC : VK_DEV_LAYOUT_CONTEXTUAL;
-	p.nk32 = c->nk32; p.tail = c->tail; p.tile_bytes = c->tile_bytes;
+	p.nk32 = c->nk32; p.tail = c->tail; p.tile_bytes = c->tile_bytes; p.prec = c->prec;
 	p.qtile = c->d_qtile; p.len_t = q->len_t; p.locality = q->locality;
 	p.ws = c->d_ws; p.wt = c->d_wt;
 	p.boost = q->boost ? c->d_boost : nullptr;
@@ -716,7 +730,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	if (wide) {
 		wp.tiles = c->d_tiles; wp.tok_id = c->d_tok_id; wp.table = c->d_table; wp.table_stride = table_stride;
 		wp.sent_start = c->d_sent_start; wp.sent_end = c->d_sent_end; wp.n_sent = (int32_t)n; wp.layout = p.layout;
-		wp.nk32 = c->nk32; wp.tail = c->tail; wp.tile_bytes = c->tile_bytes;
+		wp.nk32 = c->nk32; wp.tail = c->tail; wp.tile_bytes = c->tile_bytes; wp.prec = c->prec;
 		wp.qtile = c->d_qtile; wp.nq = nq; wp.len_t = q->len_t; wp.locality = q->locality; wp.gap_mode = p.gap_mode; wp.max_len = c->max_len;
 		wp.rwmd_symmetric = p.rwmd_symmetric; wp.rwmd_normalize_bow = p.rwmd_normalize_bow;
 		wp.gs = p.gs; wp.gt = p.gt; wp.a_s = p.a_s; wp.a_t = p.a_t; wp.open_s = p.open_s; wp.open_t = p.open_t;
@@ -742,7 +756,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	if (p.gap_mode == 7) lds_floats += 4 * p.m_rows;       // vocabulary masses of the 4 slices (static layout)
 	p.lds_floats_per_wave = lds_floats;
 	size_t smem = (size_t)lds_floats * 4 * 4;   // 4 waves per block
-	const size_t qlds = (!is_static && c->nk32 == 24 && c->tail == 0) ? (size_t)c->nk32 * 1024 : 0;   // MODE 3: query tile in LDS
+	const size_t qlds = (!is_static && c->prec == 0 && c->nk32 == 24 && c->tail == 0) ? (size_t)c->nk32 * 1024 : 0;   // MODE 3: query tile in LDS
 	smem += qlds;
 	if (smem > 160 * 1024) return fail(VK_ERR_UNSUPPORTED, "LDS demand exceeds 160 KiB per workgroup");
 	const int64_t n_groups = (n + 3) / 4;
@@ -790,7 +804,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		std::vector<float> vals, raws;
 		VkWrdParams w{};
 		w.tiles = c->d_tiles; w.tok_id = c->d_tok_id; w.table = c->d_table; w.sent_start = c->d_sent_start; w.sent_end = c->d_sent_end;
-		w.layout = p.layout; w.nk32 = c->nk32; w.tail = c->tail; w.tile_bytes = c->tile_bytes;
+		w.layout = p.layout; w.nk32 = c->nk32; w.tail = c->tail; w.tile_bytes = c->tile_bytes; w.prec = c->prec;
 		w.qtile = c->d_qtile; w.len_t = q->len_t; w.mag = c->d_mag;
 		w.mass_mode = q->algorithm == VK_ALG_WRD ? 0 : (q->rwmd_normalize_bow ? 1 : 2);
 		memcpy(w.qmass, p.qmass, sizeof w.qmass);
@@ -894,7 +908,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		}
 		VkFlowParams f{};
 		f.tiles = c->d_tiles; f.tok_id = c->d_tok_id; f.table = c->d_table; f.sent_start = c->d_sent_start; f.sent_end = c->d_sent_end;
-		f.layout = p.layout; f.nk32 = c->nk32; f.tail = c->tail; f.tile_bytes = c->tile_bytes;
+		f.layout = p.layout; f.nk32 = c->nk32; f.tail = c->tail; f.tile_bytes = c->tile_bytes; f.prec = c->prec;
 		f.qtile = c->d_qtile; f.len_t = q->len_t; f.locality = q->locality; f.gap_mode = (p.gap_mode == 3 || p.gap_mode == 6) ? 2 : p.gap_mode;
 		f.max_len = c->max_len;
 		f.gs = p.gs; f.gt = p.gt; f.a_s = p.a_s; f.a_t = p.a_t; f.open_s = p.open_s; f.open_t = p.open_t;
@@ -1101,7 +1115,7 @@ static bool same_gap(const vk_gap &a, const vk_gap &b, int upto) {
 // (vk_score_batch_kernel).  Returns VK_ERR_UNSUPPORTED (without setting an error) when the batch does not qualify;
 // the caller then runs the queries one by one.
 static int query_batch_shared_pass(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, vk_topk_out *outs) {
-	if (n_queries < 2 || !c->finalized || c->desc.layout != VK_LAYOUT_CONTEXTUAL || c->n_long_groups > 0 || c->desc.n_sentences < 1) return VK_ERR_UNSUPPORTED;
+	if (n_queries < 2 || !c->finalized || c->prec != 0 || c->desc.layout != VK_LAYOUT_CONTEXTUAL || c->n_long_groups > 0 || c->desc.n_sentences < 1) return VK_ERR_UNSUPPORTED;
 	if (c->nk32 > 10 && !getenv("VK_BATCH_QB")) return VK_ERR_UNSUPPORTED;   // measured: no gain over single queries for 768-d rows (the kernel pipelines tiles of <= 10 K-steps)
 	const vk_query_desc &q0 = qs[0];
 	if (q0.max_matches > 64) return VK_ERR_UNSUPPORTED;
@@ -1301,7 +1315,7 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 	if (!c || !qs || !outs || n_queries < 0) return fail(VK_ERR_INVALID, "null argument");
 	if (n_queries == 0) return VK_OK;
 	// the GEMM path: injective RWMD, contextual layout, one sentence length (multiple of 16), common options
-	bool gemm = c->finalized && c->contiguous && c->desc.layout == VK_LAYOUT_CONTEXTUAL && c->uniform_len > 0 && c->uniform_len % 16 == 0 &&
+	bool gemm = c->finalized && c->prec == 0 && c->contiguous && c->desc.layout == VK_LAYOUT_CONTEXTUAL && c->uniform_len > 0 && c->uniform_len % 16 == 0 &&
 		c->uniform_len <= 64 && c->desc.n_sentences > 0 && qs[0].max_matches <= 64 &&
 		((c->nk32 == 10 && c->tail == 1) || (c->nk32 == 4 && c->tail == 0));
 	for (int i = 0; i < n_queries && gemm; i++) {

@@ -29,6 +29,7 @@ struct VkScoreParams {
 	int32_t n_sent;
 	int32_t layout;
 	int32_t nk32, tail, tile_bytes;
+	int32_t prec;              // 0: bf16 tiles (nk32 K-steps of 32); 1: fp32 tiles (nk32 blocks of 16 features)
 	const int32_t *group_list; // null: all groups of 4 slices; else the groups holding one long slice each (64-thread blocks)
 	int32_t n_list;
 	int32_t max_short_len;     // main launch: groups with a longer slice are skipped
@@ -90,6 +91,7 @@ struct VkWrdParams {
 	const int32_t *sent_end;
 	int32_t layout;
 	int32_t nk32, tail, tile_bytes;
+	int32_t prec;
 	const uint8_t *qtile;
 	int32_t len_t;
 	const float *mag;
@@ -112,6 +114,7 @@ struct VkFlowParams {
 	const int32_t *sent_end;
 	int32_t layout;
 	int32_t nk32, tail, tile_bytes;
+	int32_t prec;
 	const uint8_t *qtile;
 	int32_t len_t;
 	int32_t locality;
@@ -166,6 +169,7 @@ struct VkWideParams {
 	int32_t n_sent;
 	int32_t layout;
 	int32_t nk32, tail, tile_bytes;
+	int32_t prec;
 	const uint8_t *qtile;      // nq query tiles of 16 rows, tile_bytes apart
 	int32_t nq, len_t;
 	int32_t locality;
@@ -200,9 +204,9 @@ hipError_t vk_launch_select_ge(const float *scores, int64_t n, float theta, floa
 	uint32_t *counter, uint32_t cap, hipStream_t stream);
 size_t vk_wide_lds_demand(int32_t max_len, int32_t nq, int32_t gap_mode, int32_t tagged, int32_t flow);
 hipError_t vk_launch_pack(const void *in, int32_t dtype_bf16, int64_t n_rows, int32_t d, int32_t d_pad, int64_t row0,
-	uint8_t *tiles, float *mag_out, int32_t normalize, hipStream_t stream);
+	uint8_t *tiles, float *mag_out, int32_t normalize, int32_t prec, hipStream_t stream);
 hipError_t vk_launch_table(const uint8_t *etiles, const uint8_t *qtile, int32_t n_tiles, int32_t nk32, int32_t tail,
-	int32_t tile_bytes, float *table, const int32_t *q_ids, int32_t len_t, int32_t V, hipStream_t stream);
+	int32_t tile_bytes, float *table, const int32_t *q_ids, int32_t len_t, int32_t V, int32_t prec, hipStream_t stream);
 hipError_t vk_launch_score(const VkScoreParams *p, int32_t grid, size_t smem_bytes, hipStream_t stream);
 hipError_t vk_launch_span(const VkScoreParams *p, hipStream_t stream);
 hipError_t vk_launch_score_batch(const VkScoreBatchParams *p, int32_t lt, size_t smem, hipStream_t stream);

@@ -106,7 +106,7 @@ template <> __device__ __forceinline__ float load_elem<uint16_t>(const uint16_t 
 template <typename T>
 __global__ __launch_bounds__(256) void vk_pack_rows_kernel(
 	const T *__restrict__ in, int64_t n_rows, int32_t d, int32_t d_pad, int64_t row0,
-	uint8_t *__restrict__ tiles, float *__restrict__ mag_out, int32_t normalize) {
+	uint8_t *__restrict__ tiles, float *__restrict__ mag_out, int32_t normalize, int32_t prec) {
 
 	const int lane = threadIdx.x & 63;
 	const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -130,8 +130,25 @@ __global__ __launch_bounds__(256) void vk_pack_rows_kernel(
 	const int64_t tile = grow >> 4;
 	const int i = (int)(grow & 15);
 	const int nk32 = d_pad >> 5;
-	const int tile_bytes = d_pad * 32;
+	const int tile_bytes = prec ? d_pad * 64 : d_pad * 32;
 	uint8_t *tp = tiles + tile * (int64_t)tile_bytes;
+	if (prec) {
+		// fp32 tiles (operand order of v_mfma_f32_16x16x4_f32): a block of 16 features is 1 KiB; lane 16 g + i owns
+		// row i, features 16 b + 4 s + g for s = 0..3 (element s feeds MFMA step s)
+		for (int k = lane; k < d_pad; k += 64) {
+			float x = 0.0f;
+			if (k < d) {
+				x = load_elem<T>(row + k);
+				if (normalize) {
+					x = x / m;
+					if (x != x) x = 0.0f;
+				}
+			}
+			const int b = k >> 4, sidx = (k & 15) >> 2, g = k & 3;
+			*reinterpret_cast<float *>(tp + b * 1024 + (g * 16 + i) * 16 + sidx * 4) = x;
+		}
+		return;
+	}
 
 	const int n8 = d_pad >> 3;                  // 8-element chunks; chunk c: K-step c>>2, lane group c&3
 	(void)nk32;
@@ -229,8 +246,33 @@ __device__ __forceinline__ f32x4 sim_tile_qlds(const uint8_t *__restrict__ qlds,
 // any d: query fragments re-read per K-step (L1/L2 resident), runtime trip count.
 // Same MFMA sequence as sim_tile, hence bit-identical similarities.
 __device__ __forceinline__ f32x4 sim_tile_generic(const uint8_t *__restrict__ qtile, const uint8_t *__restrict__ tile,
-	int nk, int half, int lane) {
+	int nk, int half, int lane, int prec = 0) {
 	f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+	if (prec) {
+		// fp32 rows (the reference's own precision): nk blocks of 16 features, four v_mfma_f32_16x16x4_f32 per block
+		int b = 0;
+		for (; b + 4 <= nk; b += 4) {   // four blocks in flight
+			f32x4 q[4], x[4];
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				x[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(tile + (b + i) * 1024 + lane * 16));
+				q[i] = *reinterpret_cast<const f32x4 *>(qtile + (b + i) * 1024 + lane * 16);
+			}
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+#pragma unroll
+				for (int e = 0; e < 4; e++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q[i][e], x[i][e], acc, 0, 0, 0);
+			}
+		}
+		for (; b < nk; b++) {
+			const f32x4 x = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(tile + b * 1024 + lane * 16));
+			const f32x4 q = *reinterpret_cast<const f32x4 *>(qtile + b * 1024 + lane * 16);
+#pragma unroll
+			for (int e = 0; e < 4; e++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q[e], x[e], acc, 0, 0, 0);
+		}
+		acc[0] = clip01(acc[0]); acc[1] = clip01(acc[1]); acc[2] = clip01(acc[2]); acc[3] = clip01(acc[3]);
+		return acc;
+	}
 	const int nfull = half ? nk - 1 : nk;
 	int t = 0;
 	for (; t + 4 <= nfull; t += 4) {   // four K-steps in flight
@@ -880,7 +922,7 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 				f32x4 acc;
 				if constexpr (MODE == 0) acc = sim_tile<NK32, TAIL>(qf, tp, lane);
 				else if constexpr (MODE == 3) acc = sim_tile_qlds<NK32, TAIL>(qlds, tp, lane);
-				else acc = sim_tile_generic(p.qtile, tp, p.nk32, p.tail, lane);
+				else acc = sim_tile_generic(p.qtile, tp, p.nk32, p.tail, lane, p.prec);
 				if (p.pos_s) {
 					const int ps = p.pos_s[(tile0 + ti) * 16 + (lane & 15)];
 #pragma unroll
@@ -953,11 +995,11 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 // ---------------------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void vk_table_kernel(const uint8_t *__restrict__ etiles, const uint8_t *__restrict__ qtile,
-	int32_t n_tiles, int32_t nk32, int32_t tail, int32_t tile_bytes, float *__restrict__ table) {
+	int32_t n_tiles, int32_t nk32, int32_t tail, int32_t tile_bytes, float *__restrict__ table, int32_t prec) {
 	const int lane = threadIdx.x & 63;
 	const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
 	if (tile >= n_tiles) return;
-	const f32x4 acc = sim_tile_generic(qtile, etiles + (int64_t)tile * tile_bytes, nk32, tail, lane);
+	const f32x4 acc = sim_tile_generic(qtile, etiles + (int64_t)tile * tile_bytes, nk32, tail, lane, prec);
 	*reinterpret_cast<f32x4 *>(table + ((int64_t)tile * 16 + (lane & 15)) * 16 + (lane >> 4) * 4) = acc;
 }
 
@@ -1549,7 +1591,7 @@ __global__ __launch_bounds__(64) void vk_flow_kernel(VkFlowParams p) {
 		const int tile0 = t_a >> 4;
 		const int ntiles = ((t_b + 15) >> 4) - tile0;
 		for (int ti = 0; ti < ntiles; ti++) {
-			f32x4 acc = sim_tile_generic(p.qtile, p.tiles + (int64_t)(tile0 + ti) * p.tile_bytes, p.nk32, p.tail, lane);
+			f32x4 acc = sim_tile_generic(p.qtile, p.tiles + (int64_t)(tile0 + ti) * p.tile_bytes, p.nk32, p.tail, lane, p.prec);
 			*reinterpret_cast<f32x4 *>(S + (ti * 16 + (lane & 15)) * 16 + (lane >> 4) * 4) = acc;
 			if (p.pos_s) {
 				const int ps = p.pos_s[(tile0 + ti) * 16 + (lane & 15)], cb = (lane >> 4) * 4;
@@ -1784,7 +1826,7 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 			} else {
 				const uint8_t *tp = p.tiles + (int64_t)(base >> 4) * p.tile_bytes;
 				for (int qt = 0; qt < p.nq; qt++) {
-					f32x4 acc = sim_tile_generic(p.qtile + (int64_t)qt * p.tile_bytes, tp, p.nk32, p.tail, lane);
+					f32x4 acc = sim_tile_generic(p.qtile + (int64_t)qt * p.tile_bytes, tp, p.nk32, p.tail, lane, p.prec);
 					const int c0 = qt * 16 + (lane >> 4) * 4;
 					*reinterpret_cast<f32x4 *>(Sx + (lane & 15) * LQ + c0) = acc;
 					if (p.pos_s) {
@@ -2025,7 +2067,7 @@ __global__ __launch_bounds__(64) void vk_wrd_exact_kernel(VkWrdParams p) {
 		const int tile0 = t_a >> 4;
 		const int ntiles = ((t_b + 15) >> 4) - tile0;
 		for (int ti = 0; ti < ntiles; ti++) {
-			const f32x4 acc = sim_tile_generic(p.qtile, p.tiles + (int64_t)(tile0 + ti) * p.tile_bytes, p.nk32, p.tail, lane);
+			const f32x4 acc = sim_tile_generic(p.qtile, p.tiles + (int64_t)(tile0 + ti) * p.tile_bytes, p.nk32, p.tail, lane, p.prec);
 			*reinterpret_cast<f32x4 *>(S + (ti * 16 + (lane & 15)) * 16 + (lane >> 4) * 4) = acc;
 		}
 		rowbase = t_a - tile0 * 16;
@@ -2191,7 +2233,7 @@ __global__ __launch_bounds__(64) void vk_rows_kernel(VkWrdParams p) {
 		const int tile0 = t_a >> 4;
 		const int ntiles = ((t_b + 15) >> 4) - tile0;
 		for (int ti = 0; ti < ntiles; ti++) {
-			const f32x4 acc = sim_tile_generic(p.qtile, p.tiles + (int64_t)(tile0 + ti) * p.tile_bytes, p.nk32, p.tail, lane);
+			const f32x4 acc = sim_tile_generic(p.qtile, p.tiles + (int64_t)(tile0 + ti) * p.tile_bytes, p.nk32, p.tail, lane, p.prec);
 			const int row = (tile0 + ti) * 16 + (lane & 15) - t_a;      // token of this lane relative to the slice
 			if (row >= 0 && row < m) *reinterpret_cast<f32x4 *>(out + row * 16 + (lane >> 4) * 4) = acc;
 		}
@@ -2265,19 +2307,19 @@ extern "C" hipError_t vk_launch_mark(const uint64_t *keys, int32_t n, float *sco
 // ---------------------------------------------------------------------------
 
 extern "C" hipError_t vk_launch_pack(const void *in, int32_t dtype_bf16, int64_t n_rows, int32_t d, int32_t d_pad, int64_t row0,
-	uint8_t *tiles, float *mag_out, int32_t normalize, hipStream_t stream) {
+	uint8_t *tiles, float *mag_out, int32_t normalize, int32_t prec, hipStream_t stream) {
 	if (n_rows <= 0) return hipSuccess;
 	const unsigned grid = (unsigned)((n_rows + 3) / 4);
 	if (dtype_bf16)
-		vk_pack_rows_kernel<uint16_t><<<grid, 256, 0, stream>>>((const uint16_t *)in, n_rows, d, d_pad, row0, tiles, mag_out, normalize);
+		vk_pack_rows_kernel<uint16_t><<<grid, 256, 0, stream>>>((const uint16_t *)in, n_rows, d, d_pad, row0, tiles, mag_out, normalize, prec);
 	else
-		vk_pack_rows_kernel<float><<<grid, 256, 0, stream>>>((const float *)in, n_rows, d, d_pad, row0, tiles, mag_out, normalize);
+		vk_pack_rows_kernel<float><<<grid, 256, 0, stream>>>((const float *)in, n_rows, d, d_pad, row0, tiles, mag_out, normalize, prec);
 	return hipGetLastError();
 }
 
 extern "C" hipError_t vk_launch_table(const uint8_t *etiles, const uint8_t *qtile, int32_t n_tiles, int32_t nk32, int32_t tail,
-	int32_t tile_bytes, float *table, const int32_t *q_ids, int32_t len_t, int32_t V, hipStream_t stream) {
-	vk_table_kernel<<<(n_tiles + 3) / 4, 256, 0, stream>>>(etiles, qtile, n_tiles, nk32, tail, tile_bytes, table);
+	int32_t tile_bytes, float *table, const int32_t *q_ids, int32_t len_t, int32_t V, int32_t prec, hipStream_t stream) {
+	vk_table_kernel<<<(n_tiles + 3) / 4, 256, 0, stream>>>(etiles, qtile, n_tiles, nk32, tail, tile_bytes, table, prec);
 	if (q_ids) vk_table_fix_kernel<<<1, 64, 0, stream>>>(table, q_ids, len_t, V);
 	return hipGetLastError();
 }
@@ -2302,7 +2344,7 @@ static hipError_t launch_sized(K kernel, const VkScoreParams &p, int want_blocks
 	if (occ > 3 && p.layout != VK_DEV_LAYOUT_STATIC) occ = 3;   // the static layout is DP-bound, not a stream: keep full residency
 	// 768-d rows: a wave already keeps 24 KiB of loads in flight per tile; one workgroup per CU measured fastest
 	// (ragged 8..64 tokens, 400 k sentences: 3.37 ms at 1, 3.45 ms at 2 per CU)
-	if (p.nk32 >= 24 && p.layout != VK_DEV_LAYOUT_STATIC) occ = 1;
+	if (p.nk32 >= 24 && p.prec == 0 && p.layout != VK_DEV_LAYOUT_STATIC) occ = 1;
 	static const char *ov = getenv("VK_BLOCKS_PER_CU");
 	if (ov && atoi(ov) > 0) occ = atoi(ov);
 	int dev = 0, cus = 256;
@@ -2527,7 +2569,7 @@ __global__ __launch_bounds__(256) void vk_span_kernel(VkScoreParams p) {
 		const uint8_t *tp = p.tiles + tile * p.tile_bytes;
 		f32x4 acc;
 		if constexpr (NK32 > 0) acc = sim_tile<NK32, TAIL>(qf, tp, lane);
-		else acc = sim_tile_generic(p.qtile, tp, p.nk32, p.tail, lane);
+		else acc = sim_tile_generic(p.qtile, tp, p.nk32, p.tail, lane, p.prec);
 		const int64_t s_idx = tile * 16 + lane;
 		if (lane < 16 && s_idx < p.n_sent) {
 			const float raw = acc[0];                       // query column 0, token lane
@@ -2555,6 +2597,7 @@ static hipError_t launch_span(const VkScoreParams &p, hipStream_t stream) {
 
 extern "C" hipError_t vk_launch_span(const VkScoreParams *pp, hipStream_t stream) {
 	const VkScoreParams &p = *pp;
+	if (p.prec) return launch_span<0, false>(p, stream);
 	if (p.nk32 == 10 && p.tail == 1) return launch_span<10, true>(p, stream);
 	if (p.nk32 == 24 && p.tail == 0) return launch_span<24, false>(p, stream);
 	if (p.nk32 == 12 && p.tail == 0) return launch_span<12, false>(p, stream);
@@ -2579,8 +2622,8 @@ static hipError_t launch_score_gap(const VkScoreParams &p, int grid, size_t smem
 extern "C" hipError_t vk_launch_score(const VkScoreParams *pp, int32_t grid, size_t smem_bytes, hipStream_t stream) {
 	const VkScoreParams &p = *pp;
 	if (p.layout == VK_DEV_LAYOUT_STATIC) return launch_score_gap<2, 0, false>(p, grid, smem_bytes, stream);
-	if (p.nk32 == 10 && p.tail == 1) return launch_score_gap<0, 10, true>(p, grid, smem_bytes, stream);
-	if (p.nk32 == 24 && p.tail == 0) return launch_score_gap<3, 24, false>(p, grid, smem_bytes, stream);
+	if (p.prec == 0 && p.nk32 == 10 && p.tail == 1) return launch_score_gap<0, 10, true>(p, grid, smem_bytes, stream);
+	if (p.prec == 0 && p.nk32 == 24 && p.tail == 0) return launch_score_gap<3, 24, false>(p, grid, smem_bytes, stream);
 	return launch_score_gap<1, 0, false>(p, grid, smem_bytes, stream);
 }
 

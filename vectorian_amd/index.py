@@ -493,11 +493,13 @@ class HipBruteForceIndex(Index):
 	(partition, sim, *, nlp, saliency=None); `device` selects the GPU.  The whole corpus is
 	uploaded once (token tiles in HBM); every `find` is one vk_query."""
 
-	def __init__(self, partition, sim, *, nlp=None, saliency=None, device=0, corpus_factory=None, shard=None, group=None):
+	def __init__(self, partition, sim, *, nlp=None, saliency=None, device=0, corpus_factory=None, shard=None, group=None, precision="bf16"):
 		"""shard = (rank, world): this process keeps only its contiguous range of the slices in HBM (one process per
 		GPU, every process holds the same Session); `find` then merges the ranks' result sets with one all-gather
 		of k records over `group` (torch.distributed; backend "nccl" = RCCL over xGMI) and returns the same matches
-		on every rank (the reference merges per-document ResultSets, result_set.h:70-93)."""
+		on every rank (the reference merges per-document ResultSets, result_set.h:70-93).
+		precision = "bf16": unit vectors rounded to bf16 in HBM (the fast path); "f32": the reference's own
+		precision (CosineSim is an fp32 sgemm, vectorian/sim/vector.py:66-78), twice the bytes per token."""
 		super().__init__(partition, sim)
 		self._nlp = nlp
 		self._shard, self._group = shard, group
@@ -569,7 +571,7 @@ class HipBruteForceIndex(Index):
 			vocab_vectors = emb.encode_tokens(session.vocab.tokens)
 			# magnitudes are kept for WordRotatorsDistance (metric/static.cpp:69-73, 80-120); rows are normalised on upload
 			self._corpus = make(layout=core.VK_LAYOUT_STATIC, d=emb.dimension, n_tokens=n_tokens_dev, n_sentences=n_slices_dev,
-				vocab_size=max(1, session.vocab.size), keep_magnitudes=True, device=device)
+				vocab_size=max(1, session.vocab.size), keep_magnitudes=True, device=device, precision=precision)
 			E = vocab_vectors.unmodified if session.vocab.size else np.zeros((1, emb.dimension), np.float32)
 			self._corpus.append_vectors(E, normalize=True)
 			ids = np.concatenate([session.doc_token_ids(i) for i in range(len(session.documents))]) if n_tokens else np.zeros(0, np.int32)
@@ -578,7 +580,7 @@ class HipBruteForceIndex(Index):
 		elif emb.is_contextual:
 			from vectorian_amd.embedding import Vectors
 			self._corpus = make(layout=core.VK_LAYOUT_CONTEXTUAL, d=emb.dimension, n_tokens=n_tokens_dev, n_sentences=n_slices_dev,
-				keep_magnitudes=True, device=device)
+				keep_magnitudes=True, device=device, precision=precision)
 			doc_base = 0
 			for doc in session.documents:
 				a, b = max(t0, doc_base), min(t1, doc_base + doc.n_tokens)   # this document's tokens inside the shard
