@@ -1340,6 +1340,35 @@ __device__ __forceinline__ int row_imax_to_lane15(int x) {
 }
 __device__ __forceinline__ float clip01_bits(int x) { return __builtin_amdgcn_fmed3f(__builtin_bit_cast(float, x), 0.0f, 1.0f); }
 
+// Maxima of 16 registers over the 16 lanes of each DPP row, transposed: lane v of the row ends up with the row
+// maximum of register v.  Halving exchange: at the step for lane bit b a lane keeps the registers whose index bit
+// equals its own lane bit and hands the others to its partner (lane ^ (1 << b)), so the register count halves while
+// the lane span doubles: 8 + 4 + 2 + 1 exchanges (47 instructions) instead of 16 four-step DPP reductions (64+).
+__device__ __forceinline__ int row_transpose_imax16(const int (&v)[16], int lane) {
+	const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+	const int NEG = (int)0x80000000;
+	int w[8], x[4], y[2];
+#pragma unroll
+	for (int k = 0; k < 8; k++) {
+		const int keep = b0 ? v[2 * k + 1] : v[2 * k], send = b0 ? v[2 * k] : v[2 * k + 1];
+		w[k] = imax(keep, __builtin_amdgcn_update_dpp(NEG, send, 0xB1, 0xf, 0xf, false));     // quad_perm [1,0,3,2]: lane ^ 1
+	}
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		const int keep = b1 ? w[2 * k + 1] : w[2 * k], send = b1 ? w[2 * k] : w[2 * k + 1];
+		x[k] = imax(keep, __builtin_amdgcn_update_dpp(NEG, send, 0x4E, 0xf, 0xf, false));     // quad_perm [2,3,0,1]: lane ^ 2
+	}
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		const int keep = b2 ? x[2 * k + 1] : x[2 * k], send = b2 ? x[2 * k] : x[2 * k + 1];
+		int t = __builtin_amdgcn_update_dpp(NEG, send, 0x104, 0xf, 0x5, false);                // row_shl:4 into banks 0, 2: lane + 4
+		t = __builtin_amdgcn_update_dpp(t, send, 0x114, 0xf, 0xa, false);                      // row_shr:4 into banks 1, 3: lane - 4
+		y[k] = imax(keep, t);
+	}
+	const int keep = b3 ? y[1] : y[0], send = b3 ? y[0] : y[1];
+	return imax(keep, __builtin_amdgcn_update_dpp(NEG, send, 0x128, 0xf, 0xf, false));          // row_ror:8: lane ^ 8
+}
+
 // S tiles of one query tile against the wave's two sentences: 2 x NK16 MFMAs, A fragments DEPTH steps ahead
 template <int NK16>
 __device__ __forceinline__ void batch32_mfma(const uint8_t *cur, const bf16x8 (&x)[2][NK16], f32x16 &acc0, f32x16 &acc1) {
@@ -1398,14 +1427,17 @@ __device__ __forceinline__ void batch32_epilogue(const VkRwmdBatchParams &p, int
 	// (b) per query row: max over the sentence's tokens -> lane 15 of the DPP row
 	const int q_main = qt * QPT + h, q_third = qt * 3 + 2;
 	float s_main = 0.0f, s_third = 0.0f;
+	{
+		int m[16];
 #pragma unroll
-	for (int i = 0; i < NMAIN; i++)
-		s_main += clip01_bits(row_imax_to_lane15(imax(fbits(acc0[i]), fbits(acc1[i]))));
-	if (QPT == 3) {
-#pragma unroll
-		for (int i = 10; i < 15; i++)
-			s_third += clip01_bits(row_imax_to_lane15(imax(fbits(acc0[i]), fbits(acc1[i]))));
-		s_third += xor32_f(s_third, lane);
+		for (int i = 0; i < 16; i++) m[i] = imax(fbits(acc0[i]), fbits(acc1[i]));
+		const float z = clip01_bits(row_transpose_imax16(m, lane));    // lane v of the row: maximum of query row v over the sentence
+		const int v = lane & 15;
+		s_main = row_sum_to_lane15(v < NMAIN ? z : 0.0f);
+		if (QPT == 3) {
+			s_third = row_sum_to_lane15((v >= 10 && v < 15) ? z : 0.0f);
+			s_third += xor32_f(s_third, lane);
+		}
 	}
 	// (c) scores (the expressions of vk_rwmd_batch_kernel; sum (1 - x) over len rows = len - sum x)
 	if ((lane & 15) == 15 && sent < p.n_sent) {
