@@ -345,10 +345,26 @@ class Corpus:
 		outs = []
 		if options.get("boost") is not None:
 			options = dict(options, boost=np.ascontiguousarray(options["boost"], dtype=np.float32))
+		# the options are common: build one descriptor and copy it, only the vectors differ (tag weights, token ids
+		# and POS codes are per query and take the full path)
+		per_query = any(options.get(k) is not None for k in ("q_token_ids", "tag_weights", "q_pos"))
+		first = None
 		for i, qv in enumerate(queries):
-			q, len_t = self._desc(qv, keep, **options)
+			if first is None or per_query:
+				q, len_t = self._desc(qv, keep, **options)
+				first = first or q
+			else:
+				qv = np.ascontiguousarray(qv)
+				if qv.dtype != np.uint16:
+					qv = np.ascontiguousarray(qv, dtype=np.float32)
+				if qv.ndim != 2 or qv.shape[1] != self.d:
+					raise ValueError(f"expected [len_t x {self.d}] query vectors, got {qv.shape}")
+				keep.append(qv)
+				q = _QueryDesc.from_buffer_copy(first)
+				q.q_vectors, q.q_dtype, q.len_t = _np_ptr(qv), (VK_BF16 if qv.dtype == np.uint16 else VK_F32), qv.shape[0]
+				len_t = qv.shape[0]
 			qs[i] = q
-			t = TopK(max(1, q.max_matches), len_t)
+			t = TopK(max(1, q.max_matches), len_t, transport=bool(q.want_flow) and q.algorithm != VK_ALG_ALIGN and n <= 16)
 			outs.append(t)
 			sos[i] = t._struct()
 		_check(lib().vk_query_batch(self._h, qs, n, sos))

@@ -1396,10 +1396,10 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 			else if (slot < 2) { hd = slot; acc = j; }
 			else { hd = j / 5; acc = 10 + j % 5; }
 			const int M = 8 * (acc >> 2) + 4 * hd + (acc & 3);
-			for (int k = 0; k < c->d_pad; k++) {
-				const size_t src = (size_t)(k >> 5) * 1024 + (size_t)(((k & 31) >> 3) * 16 + j) * 16 + (size_t)(k & 7) * 2;
-				const size_t off = (size_t)(k >> 4) * 1024 + (size_t)(((k >> 3) & 1) * 32 + M) * 16 + (size_t)(k & 7) * 2;
-				memcpy(dst + off, one.data() + src, 2);
+			for (int k = 0; k < c->d_pad; k += 8) {   // 8 features = one 16-byte piece in both layouts
+				const size_t src = (size_t)(k >> 5) * 1024 + (size_t)(((k & 31) >> 3) * 16 + j) * 16;
+				const size_t off = (size_t)(k >> 4) * 1024 + (size_t)(((k >> 3) & 1) * 32 + M) * 16;
+				memcpy(dst + off, one.data() + src, 16);
 			}
 		}
 	}
