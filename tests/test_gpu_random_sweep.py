@@ -78,3 +78,65 @@ def test_random_problem(hip, oracle, seed):
 	# slice may hold one word twice, and which of the two equal cells the traceback takes can flip with the last bit
 	assert_same_results(got.trimmed(), ref, score_tol=2e-5, tie_tol=2e-6, check_mapping=not static)
 	c.close()
+
+
+@pytest.mark.parametrize("seed", range(80))
+def test_random_transport_and_modifiers(hip, oracle, seed):
+	"""the other strategies on random small problems: RWMD (all forms), full WMD, WRD (both mass conventions),
+	submatch_weight, tag-weighted alignment"""
+	rng = np.random.default_rng(5000 + seed)
+	d = int(rng.choice([24, 64, 300]))
+	n = int(rng.integers(2, 250))
+	lens = rng.integers(1, 41, size=n)
+	off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+	T = int(off[-1])
+	len_t = int(rng.integers(1, 17))
+	X = (rng.standard_normal((T, d)) * rng.lognormal(0, 0.3, size=(T, 1))).astype(np.float32)
+	qv = (rng.standard_normal((len_t, d)) * rng.lognormal(0, 0.3, size=(len_t, 1))).astype(np.float32)
+	s = int(rng.integers(0, n))
+	m = min(len_t, int(lens[s]))
+	qv[:m] = X[off[s]:off[s] + m] * rng.uniform(0.5, 2.0) + 0.2 * rng.standard_normal((m, d)).astype(np.float32)
+	Xn, mag = oracle.normalize_rows_bf16(X)
+	Qn, qmag = oracle.normalize_rows_bf16(qv)
+	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=d, n_tokens=T, n_sentences=n, keep_magnitudes=True)
+	c.append_vectors(X, normalize=True)
+	c.set_sentences(off)
+	pos = rng.integers(0, 5, size=T).astype(np.int8)
+	c.set_token_pos(pos)
+	c.finalize()
+	k = int(rng.choice([1, 6, 20]))
+	mode = int(rng.integers(0, 5))
+	base = dict(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=off, X=Xn, Q=Qn, max_matches=k)
+	if mode == 0:      # relaxed WMD, any legal form
+		inj, sym, nbow = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+		if sym and not nbow:
+			nbow = True
+		kw = dict(rwmd=(inj, sym, nbow), min_score=-10.0)
+		ref = oracle.find(algorithm=oracle.ALG_RWMD, **base, **kw)
+		got = c.query(qv, q_normalize=True, algorithm=hip.VK_ALG_RWMD, max_matches=k, **kw)
+		assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=2e-5, tie_tol=2e-5)
+	elif mode == 1:    # full WMD
+		nbow = bool(rng.integers(0, 2))
+		ref = oracle.find(algorithm=oracle.ALG_RWMD, rwmd=(False, False, nbow), wmd_full=True, min_score=0.0, **base)
+		got = c.query(qv, q_normalize=True, algorithm=hip.VK_ALG_RWMD, rwmd=(False, False, nbow), wmd_full=True, max_matches=k, min_score=0.0)
+		assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=2e-5, tie_tol=2e-5)
+	elif mode == 2:    # WRD
+		norm = bool(rng.integers(0, 2))
+		ref = oracle.find(algorithm=oracle.ALG_WRD, X_mag=mag, Q_mag=qmag, wrd_normalize=norm, min_score=0.0, **base)
+		got = c.query(qv, q_normalize=True, algorithm=hip.VK_ALG_WRD, wrd_normalize=norm, max_matches=k, min_score=0.0)
+		assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=2e-5, tie_tol=2e-5)
+	elif mode == 3:    # submatch weight
+		kw = dict(locality=int(rng.integers(0, 3)), gap_s=float(rng.uniform(0, 0.3)), gap_t=float(rng.uniform(0, 0.3)),
+			submatch_weight=float(rng.choice([0.5, 1.0, 2.0])), min_score=0.0)
+		ref = oracle.find(**base, **kw)
+		got = c.query(qv, q_normalize=True, max_matches=k, **kw)
+		assert_same_results(got.trimmed(), ref, score_tol=2e-5)
+	else:              # tag-weighted alignment
+		tw = rng.uniform(0.2, 1.5, size=len_t).astype(np.float32)
+		qp = rng.integers(0, 5, size=len_t).astype(np.int8)
+		kw = dict(locality=0, gap_s=0.1, gap_t=0.1, min_score=0.0, tag_weights=tw, q_pos=qp,
+			pos_mismatch_penalty=float(rng.uniform(0, 0.5)), similarity_threshold=float(rng.uniform(0, 0.3)))
+		ref = oracle.find(pos_s=pos, **base, **kw)
+		got = c.query(qv, q_normalize=True, max_matches=k, **kw)
+		assert_same_results(got.trimmed(), ref, score_tol=2e-5)
+	c.close()
