@@ -1,0 +1,114 @@
+"""-m gpu: BASELINE.json configs[1] at full size -- 1,000,000 sentences x 32 tokens x 300-d, 10-token query -- checked
+through properties that do not need the oracle to score a million sentences:
+  * a sample of 3,000 sentences (their vectors are kept on the host while the shard is generated on the device) scores
+    exactly as the oracle scores them;
+  * the returned top-k equals the top-k of the full score vector under the result order (score desc, sentence desc);
+  * planted copies of the query come out first with score ~ 1 and the identity traceback;
+  * the same query twice gives the same bytes; a boost of c scales every score by c;
+  * two half shards merged (vk_merge_topk with offsets) give the result of the whole."""
+
+import numpy as np
+import pytest
+
+# torch generates the shard on the device (as bench.py does).  It must be imported before the HIP library is loaded:
+# torch brings its own HIP runtime, and the process can only initialise one.
+try:
+	import torch
+except Exception:   # pragma: no cover
+	torch = None
+
+from vectorian_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+N_SENT, LEN_S, D, LEN_T, V = 1_000_000, 32, 300, 10, 50_000
+EXP5 = ("table", (1 - 2.0 ** (-np.arange(0, 65) / 5)).astype(np.float32))
+
+
+def build(hip, torch, ids, E, lo, hi, sample, planted):
+	"""sentences [lo, hi) of the synthetic corpus as one device corpus; returns it and the fp32 vectors of `sample`"""
+	device = torch.device("cuda", 0)
+	n_tok = (hi - lo) * LEN_S
+	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=D, n_tokens=n_tok, n_sentences=hi - lo)
+	E_dev = torch.from_numpy(E).to(device)
+	kept = {}
+	chunk_s = 1 << 15                                   # sentences per chunk
+	for a in range(lo, hi, chunk_s):
+		b = min(a + chunk_s, hi)
+		gen = torch.Generator(device=device)
+		gen.manual_seed(77 + a)                         # per chunk: the same vectors whatever the shard bounds (multiples of the chunk)
+		idx = torch.from_numpy(ids[a * LEN_S:b * LEN_S].astype(np.int64)).to(device)
+		x = E_dev[idx] + 0.1 * torch.randn(((b - a) * LEN_S, D), device=device, generator=gen, dtype=torch.float32)
+		for s, qv in planted.items():                   # exact copies of the query inside chosen sentences
+			if a <= s < b:
+				x[(s - a) * LEN_S + 5:(s - a) * LEN_S + 5 + LEN_T] = torch.from_numpy(qv).to(device)
+		x = x.contiguous()
+		for s in sample[(sample >= a) & (sample < b)]:
+			kept[int(s)] = x[(s - a) * LEN_S:(s - a + 1) * LEN_S].cpu().numpy()
+		torch.cuda.synchronize()
+		c.append_vectors_device(x.data_ptr(), x.shape[0], hip.VK_F32, normalize=True)
+		del x, idx
+	c.set_sentences(np.arange(hi - lo + 1, dtype=np.int64) * LEN_S)
+	c.finalize()
+	del E_dev
+	torch.cuda.empty_cache()
+	return c, kept
+
+
+def test_config2_full_size_properties(hip, oracle):
+	if torch is None:
+		pytest.skip("torch is needed to generate the shard on the device")
+	rng = np.random.default_rng(11)
+	E = synth.make_vocab(V, D)
+	ids = synth.zipf_ids(N_SENT * LEN_S, V, rng)
+	qv = np.ascontiguousarray(E[rng.integers(0, V, size=LEN_T)] + 0.05 * rng.standard_normal((LEN_T, D)).astype(np.float32))
+	planted = {int(s): qv for s in (123_456, 999_999, 0)}
+	sample = np.unique(np.concatenate((rng.integers(0, N_SENT, size=3000), list(planted))))
+	c, kept = build(hip, torch, ids, E, 0, N_SENT, sample, planted)
+	kw = dict(q_normalize=True, locality=0, gap_s=EXP5, gap_t=EXP5, max_matches=10, min_score=0.0)
+
+	top = c.query(qv, **kw)
+	scores = c.last_scores()
+	assert scores.shape == (N_SENT,) and np.isfinite(scores).all()
+
+	# (1) sampled sentences against the oracle
+	Xs = np.concatenate([kept[int(s)] for s in sample])
+	Xb, _ = oracle.normalize_rows_bf16(Xs)
+	Qb, _ = oracle.normalize_rows_bf16(qv)
+	ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=D, sent_off=np.arange(len(sample) + 1, dtype=np.int64) * LEN_S, X=Xb, Q=Qb,
+		locality=0, gap_s=EXP5, gap_t=EXP5, max_matches=10, min_score=0.0, want_all_scores=True, n_threads=8)
+	np.testing.assert_allclose(scores[sample], ref["all_scores"], atol=1e-4, rtol=0)
+
+	# (2) selection: top-k of the full score vector under (score desc, sentence desc)
+	order = np.lexsort((-np.arange(N_SENT), -scores.astype(np.float64)))[:10]
+	assert list(top.sentence[:top.n]) == list(order)
+	np.testing.assert_array_equal(top.score[:top.n], scores[order])
+
+	# (3) planted copies first, score ~ 1, identity traceback at offset 5
+	assert set(top.sentence[:3]) == set(planted)
+	assert (top.score[:3] > 0.999).all()
+	for i in range(3):
+		assert list(top.mapping[i]) == list(range(5, 5 + LEN_T))
+
+	# (4) idempotence; boost scales
+	again = c.query(qv, **kw)
+	np.testing.assert_array_equal(again.score, top.score)
+	np.testing.assert_array_equal(again.mapping, top.mapping)
+	boosted = c.query(qv, boost=np.full(N_SENT, 0.5, np.float32), **kw)
+	np.testing.assert_allclose(boosted.score[:10], 0.5 * top.score[:10], rtol=1e-6)
+	assert list(boosted.sentence[:10]) == list(top.sentence[:10])
+	c.close()
+
+	# (5) two half shards merged == the whole
+	half = N_SENT // 2 // (1 << 15) * (1 << 15)
+	parts = []
+	for lo, hi in ((0, half), (half, N_SENT)):
+		ch, _ = build(hip, torch, ids, E, lo, hi, np.zeros(0, np.int64), planted)
+		t = ch.query(qv, **kw)
+		t.sentence[:t.n] += lo
+		parts.append(t)
+		ch.close()
+	merged = hip.merge_topk(parts, LEN_T, 10)
+	assert list(merged.sentence[:10]) == list(top.sentence[:10])
+	np.testing.assert_array_equal(merged.score[:10], top.score[:10])
+	np.testing.assert_array_equal(merged.mapping[:10], top.mapping[:10])
