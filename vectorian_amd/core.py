@@ -94,6 +94,28 @@ EXPORTS = [
 _lib = None
 
 
+def _prefer_torch_hip_runtime():
+	"""PyTorch-ROCm wheels bundle their own HIP runtime and a process can initialise only one.  If torch is installed
+	but not imported yet, its libamdhip64 is loaded first, so that a later `import torch` (shards.py over RCCL, bench.py)
+	still finds the GPU; this library then binds to the same runtime.  Without torch nothing happens."""
+	import importlib.util
+	import sys
+	if "torch" in sys.modules or os.environ.get("VECTORIAN_HIP_NO_TORCH_PRELOAD"):
+		return
+	try:
+		spec = importlib.util.find_spec("torch")
+	except (ImportError, ValueError):
+		return
+	for d in (spec.submodule_search_locations or []) if spec else []:
+		path = os.path.join(d, "lib", "libamdhip64.so")
+		if os.path.exists(path):
+			try:
+				C.CDLL(path, mode=C.RTLD_GLOBAL)
+			except OSError:
+				pass
+			return
+
+
 def lib():
 	"""Loads the shared library (no GPU needed to load it)."""
 	global _lib
@@ -102,6 +124,7 @@ def lib():
 			raise RuntimeError(
 				f"{LIB_PATH} is missing: build it with `make -C vectorian_amd/csrc` "
 				"(or __graft_entry__.build()); there is no CPU fallback")
+		_prefer_torch_hip_runtime()
 		L = C.CDLL(LIB_PATH)
 		L.vk_last_error.restype = C.c_char_p
 		L.vk_corpus_create.argtypes = [C.POINTER(_CorpusDesc), C.POINTER(C.c_void_p)]
@@ -112,6 +135,7 @@ def lib():
 		L.vk_corpus_set_slices.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
 		L.vk_corpus_finalize.argtypes = [C.c_void_p]
 		L.vk_corpus_free.argtypes = [C.c_void_p]
+		L.vk_corpus_view.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
 		L.vk_corpus_device_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
 		L.vk_query.argtypes = [C.c_void_p, C.POINTER(_QueryDesc), C.POINTER(_TopkOut)]
 		L.vk_query_batch.argtypes = [C.c_void_p, C.POINTER(_QueryDesc), C.c_int32, C.POINTER(_TopkOut)]
