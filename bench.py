@@ -85,6 +85,32 @@ def make_queries(E, ids, n_queries, seed):
 	return qs
 
 
+def usable_cores():
+	"""host cores this process may actually run on: the affinity mask and the cgroup CPU quota, not the machine's count"""
+	n = os.cpu_count() or 1
+	try:
+		n = min(n, len(os.sched_getaffinity(0)))
+	except (AttributeError, OSError):
+		pass
+	for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+		try:
+			with open(path) as f:
+				parts = f.read().split()
+			if path.endswith("cpu.max"):
+				if parts[0] != "max":
+					n = min(n, max(1, int(round(int(parts[0]) / int(parts[1])))))
+			else:
+				quota = int(parts[0])
+				with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+					period = int(f.read().split()[0])
+				if quota > 0:
+					n = min(n, max(1, int(round(quota / period))))
+			break
+		except (OSError, ValueError, IndexError):
+			continue
+	return max(1, n)
+
+
 def cpu_baseline(gap_name, budget_s=12.0):
 	"""The CPU restatement of the reference algorithm (oracle/, kind "port": the reference's
 	own C++ path cannot be built offline) on a bounded sample of the same workload:
@@ -92,7 +118,7 @@ def cpu_baseline(gap_name, budget_s=12.0):
 	thread-per-document pool, vectorian/index.py:544-558), threads started once per batch."""
 	from oracle import vk_oracle as vo
 	from vectorian_amd import synth
-	cores = os.cpu_count() or 1
+	cores = usable_cores()
 	n = 8192
 	corpus = synth.make_contextual_corpus(n, LEN_S, LEN_S, VOCAB, D)
 	Xb = synth.to_bf16_bits(synth.normalize_rows(corpus["X"]))
