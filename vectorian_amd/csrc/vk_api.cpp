@@ -668,7 +668,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	for (int i = 0; i < 80; i++) wt[i] = (is_align && i <= q->len_t) ? gap_cost(q->gap_t, i) : 0.0f;
 	if (p.gap_mode == 2) {
 		// register-history kernel: needs w_t strictly subadditive over the query length
-		// (see dp_general_reg in vk_kernels.hip); margin far above fp32 rounding of the DP values
+		// (see dp_general_reg in vk_common.cuh); margin far above fp32 rounding of the DP values
 		bool sub = true;
 		for (int x = 1; x < q->len_t && sub; x++)
 			for (int y = 1; x + y <= q->len_t; y++)

@@ -1,4 +1,4 @@
-// vk_device.h -- structures shared between the kernels (vk_kernels.hip) and the
+// vk_device.h -- structures shared between the kernels (vk_*.hip) and the
 // C-ABI implementation (vk_api.cpp).  Internal; the public interface is
 // include/vectorian_hip.h.
 #ifndef VK_DEVICE_H

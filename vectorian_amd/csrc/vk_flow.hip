@@ -1,0 +1,519 @@
+// vk_flow.hip -- traceback of the winners (vk_flow_kernel) and the one-wave-per-slice kernel for long queries.
+#include "vk_common.cuh"
+
+// ---------------------------------------------------------------------------
+// flow of the winners: one wave per winner recomputes the similarity rows with the
+// same MFMA sequence as the scoring kernel, then lane 0 runs the sequential DP with
+// traceback exactly as the oracle states it (vko_align in oracle/vk_oracle.c):
+// candidates zero (LOCAL), diagonal, gap in s (k = 1..), gap in t (k = 1..), replace
+// on strictly greater; start cell = first maximum in row-major order.
+// Output: mapping[j] = matched sentence token or -1 (InjectiveFlow,
+// metric/alignment.h:194-196), edge_sim[j] = S[mapping[j]][j] (metric/alignment.h:335-345).
+// ---------------------------------------------------------------------------
+
+#define VK_TB_W 17
+
+// dynamic LDS of vk_flow_kernel for slices of at most max_len tokens (bytes); the carve-up below must match
+static inline size_t vk_flow_lds_bytes(int max_len, bool tagged) {
+	const size_t rows = (size_t)max_len + 1, srows = (size_t)max_len + 32;
+	size_t b = srows * 16 * 4 * (tagged ? 2 : 1);      // S (+ SW)
+	b += rows * VK_TB_W * 4;                           // H
+	b += (rows + 3) / 4 * 4 * 4 + 32 * 4;              // wsl, wtl
+	b += rows * VK_TB_W * 2;                           // dk
+	b += rows * VK_TB_W;                               // flags
+	return (b + 15) / 16 * 16;
+}
+
+__global__ __launch_bounds__(64) void vk_flow_kernel(VkFlowParams p) {
+	extern __shared__ float4 vk_smem4[];
+	const int rows = p.max_len + 1, srows = p.max_len + 32;
+	float *S = reinterpret_cast<float *>(vk_smem4);
+	float *SW = p.pos_s ? S + srows * 16 : S;            // tag-weighted copy the DP runs on (else S itself)
+	float *H = SW + srows * 16;
+	float *wsl = H + rows * VK_TB_W;
+	float *wtl = wsl + (rows + 3) / 4 * 4;
+	int16_t *dk = reinterpret_cast<int16_t *>(wtl + 32);
+	uint8_t *flags = reinterpret_cast<uint8_t *>(dk + rows * VK_TB_W);   // bits 0-1 direction, 2 E extended, 3 F extended
+
+	const int lane = threadIdx.x;
+	const int w = blockIdx.x;
+	const uint64_t key = p.keys[w];
+	if (key == 0) return;   // fewer than k admitted
+	const int64_t g = (int64_t)(uint32_t)(key & 0xffffffffu);
+	const int t_a = p.sent_start[g], t_b = p.sent_end[g];
+	const int len_s = t_b - t_a, len_t = p.len_t;
+
+	// S: unmodified similarities (reported per edge, metric/alignment.h:339); SW: what the DP runs on
+	int rowbase;
+	if (p.layout == VK_DEV_LAYOUT_STATIC) {
+		for (int it = 0; it * 16 < len_s; it++) {
+			const int tk = it * 16 + (lane >> 2);
+			if (tk < len_s) {
+				const int id = p.tok_id[t_a + tk];
+				float4 val = *reinterpret_cast<const float4 *>(p.table + (int64_t)id * 16 + (lane & 3) * 4);
+				*reinterpret_cast<float4 *>(S + tk * 16 + (lane & 3) * 4) = val;
+				if (p.pos_s) {
+					const int ps = p.pos_s[t_a + tk], cb = (lane & 3) * 4;
+					val.x = tag_weighted(val.x, p.tw[cb + 0], ps, p.tpos[cb + 0], p.tw_keep, p.tw_threshold);
+					val.y = tag_weighted(val.y, p.tw[cb + 1], ps, p.tpos[cb + 1], p.tw_keep, p.tw_threshold);
+					val.z = tag_weighted(val.z, p.tw[cb + 2], ps, p.tpos[cb + 2], p.tw_keep, p.tw_threshold);
+					val.w = tag_weighted(val.w, p.tw[cb + 3], ps, p.tpos[cb + 3], p.tw_keep, p.tw_threshold);
+					*reinterpret_cast<float4 *>(SW + tk * 16 + (lane & 3) * 4) = val;
+				}
+			}
+		}
+		rowbase = 0;
+	} else {
+		const int tile0 = t_a >> 4;
+		const int ntiles = ((t_b + 15) >> 4) - tile0;
+		for (int ti = 0; ti < ntiles; ti++) {
+			f32x4 acc = sim_tile_generic(p.qtile, p.tiles + (int64_t)(tile0 + ti) * p.tile_bytes, p.nk32, p.tail, lane, p.prec);
+			*reinterpret_cast<f32x4 *>(S + (ti * 16 + (lane & 15)) * 16 + (lane >> 4) * 4) = acc;
+			if (p.pos_s) {
+				const int ps = p.pos_s[(tile0 + ti) * 16 + (lane & 15)], cb = (lane >> 4) * 4;
+#pragma unroll
+				for (int r = 0; r < 4; r++) acc[r] = tag_weighted(acc[r], p.tw[cb + r], ps, p.tpos[cb + r], p.tw_keep, p.tw_threshold);
+				*reinterpret_cast<f32x4 *>(SW + (ti * 16 + (lane & 15)) * 16 + (lane >> 4) * 4) = acc;
+			}
+		}
+		rowbase = t_a - tile0 * 16;
+	}
+	// gap tables into LDS (uniform broadcast reads in the candidate loops)
+	for (int i = lane; i <= p.max_len; i += 64) wsl[i] = p.ws[i];
+	if (lane <= VK_DEV_MAX_QUERY_LEN) wtl[lane] = p.wt[lane];
+	__syncthreads();
+
+	const float *Sm = SW + rowbase * 16;      // DP input
+	const float *Su = S + rowbase * 16;       // unmodified, for the edges
+	const int W = VK_TB_W;
+	const bool local = p.locality == VK_DEV_LOCAL, global = p.locality == VK_DEV_GLOBAL;
+	const int gap = p.gap_mode;
+	const float gs = p.gs, gt = p.gt, open_s = p.open_s, open_t = p.open_t, a_s = p.a_s, a_t = p.a_t;
+
+	// ---- fill: lane l owns query column v = l + 1 (lanes 0..len_t-1, one DPP row).  Per row the
+	// zero / diagonal / gap-in-s candidates of all columns are evaluated in parallel; the gap-in-t
+	// candidates need the final cells to the left, which become final one column per step and are
+	// broadcast with v_readlane (the wave holds ONE sentence, so the column index is wave-uniform).
+	// Candidate order and strict-greater replacement are the oracle's (vko_align): zero, diagonal,
+	// gap in s with k = 1, 2, .., gap in t with k = 1, 2, ..  In-row candidates arrive with k
+	// descending, so among them ">=" keeps the smallest k of the maximum, and the winner replaces
+	// the earlier candidates only if strictly greater.
+	const int v = lane + 1;
+	const bool col = v <= len_t;
+	float wrel[16];   // general: w_t(v - p) for source column p < v
+#pragma unroll
+	for (int pp = 0; pp < 16; pp++) wrel[pp] = (col && pp < v) ? wtl[v - pp] : __builtin_inff();
+
+	float hprev = 0.0f, eprev = VK_NEG_INF;
+	if (global && col) hprev = gap == 0 ? -(gt * (float)v) : gap == 1 ? -(a_t + gt * (float)v) : -wtl[v];
+	if (col) H[v] = hprev;
+	for (int u = 1; u <= len_s; u++) {
+		float bprev = 0.0f, bcur = 0.0f;
+		if (global) {
+			bprev = u == 1 ? 0.0f : (gap == 0 ? -(gs * (float)(u - 1)) : gap == 1 ? -(a_s + gs * (float)(u - 1)) : -wsl[u - 1]);
+			bcur = gap == 0 ? -(gs * (float)u) : gap == 1 ? -(a_s + gs * (float)u) : -wsl[u];
+		}
+		const float sv = Sm[(u - 1) * 16 + (col ? v - 1 : 0)];
+		const float diag = dpp_f<DPP_ROW_SHR1>(bprev, hprev);
+		float best, e = VK_NEG_INF;
+		uint8_t d, ee = 0, fe = 0;
+		int16_t kk = 0;
+		float c = diag + sv;
+		if (local) { best = 0.0f; d = 0; if (c > best) { best = c; d = 1; } }
+		else { best = c; d = 1; }
+		if (gap == 0) {
+			c = hprev - gs;
+			if (c > best) { best = c; d = 2; kk = 1; }
+		} else if (gap == 1) {
+			e = hprev - open_s;
+			c = eprev - gs;
+			if (c > e) { e = c; ee = 1; }
+			if (e > best) { best = e; d = 2; }
+		} else {
+			for (int k = 1; k <= u; k++) {
+				c = H[(u - k) * W + (col ? v : 1)] - wsl[k];
+				if (c > best) { best = c; d = 2; kk = (int16_t)k; }
+			}
+		}
+		// in-row candidates
+		float left_best = VK_NEG_INF, f = VK_NEG_INF, fin = best, ffin = VK_NEG_INF;
+		int16_t left_k = 0;
+#pragma unroll
+		for (int pp = 0; pp < 16; pp++) {
+			if (pp < len_t) {
+				const float sp = pp == 0 ? bcur : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fin), pp - 1));
+				const float fp = pp == 0 ? VK_NEG_INF : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ffin), pp - 1));
+				if (gap == 2) {
+					const float cc = sp - wrel[pp];
+					if (v > pp && cc >= left_best) { left_best = cc; left_k = (int16_t)(v - pp); }
+				} else if (v == pp + 1) {
+					if (gap == 0) { left_best = sp - gt; left_k = 1; }
+					else {
+						f = sp - open_t;
+						const float c2 = fp - gt;
+						if (c2 > f) { f = c2; fe = 1; }
+					}
+				}
+				if (v == pp + 1) {   // all sources of this column are in: finalise it
+					if (gap == 1) { if (f > best) { best = f; d = 3; } ffin = f; }
+					else if (left_best > best) { best = left_best; d = 3; kk = left_k; }
+					fin = best;
+				}
+			}
+		}
+		if (col) {
+			H[u * W + v] = best;
+			dk[u * W + v] = kk;
+			flags[u * W + v] = (uint8_t)(d | (ee << 2) | (fe << 3));
+		}
+		hprev = best;
+		eprev = e;
+	}
+
+	// ---- start cell: first maximum in row-major order (u outer, v inner), borders (0) first
+	float bv = 0.0f;
+	int bu = 0;
+	if (col && !global) {
+		for (int uu = 1; uu <= len_s; uu++) {
+			if (!local && !(uu == len_s || v == len_t)) continue;
+			const float hv = H[uu * W + v];
+			if (hv > bv) { bv = hv; bu = uu; }
+		}
+	}
+	wave_lds_fence();
+	int u = len_s, vq = len_t;
+	float raw;
+	if (global) {
+		raw = H[len_s * W + len_t];
+	} else {
+		raw = 0.0f; u = 0; vq = 0;
+		for (int j = 0; j < len_t; j++) {
+			const float vj = __shfl(bv, j, 64);
+			const int uj = __shfl(bu, j, 64);
+			if (vj > raw || (vj == raw && vj > 0.0f && uj < u)) { raw = vj; u = uj; vq = j + 1; }
+		}
+	}
+	if (lane != 0) return;
+	int v2 = vq;
+	int16_t *mp = p.mapping + (int64_t)w * 16;
+	float *es = p.edge_sim + (int64_t)w * 16;
+	for (int j = 0; j < 16; j++) { mp[j] = -1; es[j] = 0.0f; }
+	int state = 0;
+	while (u > 0 && v2 > 0) {
+		const int idx = u * W + v2;
+		const uint8_t fl = flags[idx];
+		if (gap == 1 && state == 1) { if (!(fl & 4)) state = 0; u--; continue; }
+		if (gap == 1 && state == 2) { if (!(fl & 8)) state = 0; v2--; continue; }
+		const uint8_t d = fl & 3;
+		if (d == 0) break;
+		if (d == 1) { mp[v2 - 1] = (int16_t)(u - 1); es[v2 - 1] = Su[(u - 1) * 16 + v2 - 1]; u--; v2--; }
+		else if (gap == 1) state = (d == 2) ? 1 : 2;
+		else if (d == 2) u -= dk[idx];
+		else v2 -= dk[idx];
+	}
+	p.raw_out[w] = raw;
+}
+
+// ---------------------------------------------------------------------------
+// Queries of 17 .. 64 tokens: one wave per slice, lane = query column (the fill of vk_flow_kernel
+// widened to the whole wave).  SCORE mode walks all slices and writes Score::value / raw like
+// vk_score_kernel; FLOW mode retraces the k winners.  The similarity rows are produced 16 tokens at
+// a time (one MFMA tile per 16 query rows) into a small LDS strip and consumed by the row-serial DP
+// at once, so LDS holds only the column history (general gaps) and, in FLOW mode, the traceback.
+// Candidate order, strict-greater replacement and start-cell rule: as vk_flow_kernel / the oracle.
+// Roughly 10 us of issue time per (32-token slice, 32-token query): a fallback that keeps long
+// queries on the device, not a roofline kernel.
+// ---------------------------------------------------------------------------
+
+static inline size_t vk_wide_lds_bytes(int max_len, int nq, int gap_mode, bool tagged, bool flow) {
+	const size_t LQ = (size_t)nq * 16, W = LQ + 1, rows = (size_t)max_len + 1;
+	size_t fl = 16 * LQ * (tagged ? 2 : 1);            // Sx (+ SWx)
+	fl += (rows + 3) / 4 * 4 + LQ + 4;                 // wsl, wtl
+	fl += 64 + 64;                                     // twl, tposl
+	if (gap_mode == 2) fl += rows * W;                 // H
+	size_t b = fl * 4;
+	if (flow) b += 64 * 2 + rows * W * 2 + rows * W;   // mapl, dk, flags
+	return (b + 15) / 16 * 16;
+}
+
+__device__ __forceinline__ float wave_min64(float m) {
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
+	return m;
+}
+
+template <bool FLOW>
+__global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
+	extern __shared__ float4 vk_smem4[];
+	const int lane = threadIdx.x;
+	const int LQ = p.nq * 16, W = LQ + 1, rows = p.max_len + 1;
+	float *Sx = reinterpret_cast<float *>(vk_smem4);       // [16][LQ] similarities of the current 16 tokens
+	float *SWx = p.pos_s ? Sx + 16 * LQ : Sx;              // tag-weighted copy the DP runs on
+	float *wsl = SWx + 16 * LQ;
+	float *wtl = wsl + (rows + 3) / 4 * 4;
+	float *twl = wtl + LQ + 4;
+	int *tposl = reinterpret_cast<int *>(twl + 64);
+	float *H = reinterpret_cast<float *>(tposl + 64);      // general gaps: H[u][v], row stride W
+	float *after = p.gap_mode == 2 ? H + rows * W : H;
+	int16_t *mapl = reinterpret_cast<int16_t *>(after);    // FLOW: mapping of the winner
+	int16_t *dk = mapl + 64;
+	uint8_t *flags = reinterpret_cast<uint8_t *>(dk + rows * W);
+
+	for (int i = lane; i <= p.max_len; i += 64) wsl[i] = p.ws[i];
+	if (lane <= LQ) wtl[lane] = p.wt[lane];
+	if (lane == 0) wtl[LQ] = p.wt[LQ <= 64 ? LQ : 64];
+	twl[lane] = p.tw[lane]; tposl[lane] = p.tpos[lane];
+	wave_lds_fence();
+
+	const int len_t = p.len_t;
+	const int v = lane + 1;
+	const bool col = v <= len_t;
+	const bool local = p.locality == VK_DEV_LOCAL, global = p.locality == VK_DEV_GLOBAL;
+	const int gap = p.gap_mode;
+	const float gs = p.gs, gt = p.gt, open_s = p.open_s, open_t = p.open_t, a_s = p.a_s, a_t = p.a_t;
+	const bool is_static = p.layout == VK_DEV_LAYOUT_STATIC;
+
+	const int64_t n_items = FLOW ? (int64_t)gridDim.x : (int64_t)p.n_sent;
+	for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+		int64_t g = item;
+		if (FLOW) {
+			const uint64_t key = p.keys[item];
+			if (key == 0) return;   // fewer than k admitted
+			g = (int64_t)(uint32_t)(key & 0xffffffffu);
+		}
+		const int t_a = p.sent_start[g], t_b = p.sent_end[g];
+		const int len_s = t_b - t_a;
+		if (len_s < 1) {
+			if (!FLOW && lane == 0) { p.scores[g] = VK_NEG_INF; p.raw[g] = VK_NEG_INF; }
+			continue;
+		}
+		// similarities of tokens base .. base + 15 (contextual: one tile, 16-aligned; static: gather)
+		auto fill = [&](int base) {
+			if (is_static) {
+				for (int r = 0; r < 16; r++) {
+					const int tok = base + r;
+					if (tok < t_b && lane < LQ) {
+						const int id = p.tok_id[tok];
+						const float sv = p.table[(int64_t)(lane >> 4) * p.table_stride + (int64_t)id * 16 + (lane & 15)];
+						Sx[r * LQ + lane] = sv;
+						if (p.pos_s) SWx[r * LQ + lane] = tag_weighted(sv, twl[lane], p.pos_s[tok], tposl[lane], p.tw_keep, p.tw_threshold);
+					}
+				}
+			} else {
+				const uint8_t *tp = p.tiles + (int64_t)(base >> 4) * p.tile_bytes;
+				for (int qt = 0; qt < p.nq; qt++) {
+					f32x4 acc = sim_tile_generic(p.qtile + (int64_t)qt * p.tile_bytes, tp, p.nk32, p.tail, lane, p.prec);
+					const int c0 = qt * 16 + (lane >> 4) * 4;
+					*reinterpret_cast<f32x4 *>(Sx + (lane & 15) * LQ + c0) = acc;
+					if (p.pos_s) {
+						const int ps = p.pos_s[base + (lane & 15)];
+#pragma unroll
+						for (int r = 0; r < 4; r++) acc[r] = tag_weighted(acc[r], twl[c0 + r], ps, tposl[c0 + r], p.tw_keep, p.tw_threshold);
+						*reinterpret_cast<f32x4 *>(SWx + (lane & 15) * LQ + c0) = acc;
+					}
+				}
+			}
+		};
+		const int base0 = is_static ? t_a : (t_a >> 4) * 16;
+
+		float raw;
+		int u_start = 0, v_start = 0;
+		if (gap == 4) {
+			// ---- relaxed word mover's distance (rwmd_rows of vk_score_kernel over <= 64 columns)
+			const bool nbow = p.rwmd_normalize_bow != 0;
+			const float w_t = nbow ? 1.0f / (float)len_t : 1.0f, w_s = nbow ? 1.0f / (float)len_s : 1.0f;
+			float colmin = 3.402823466e+38F, acc1 = 0.0f;
+			for (int base = base0; base < t_b; base += 16) {
+				fill(base);
+				wave_lds_fence();
+				const int r0 = t_a > base ? t_a - base : 0, r1 = t_b - base < 16 ? t_b - base : 16;
+				for (int r = r0; r < r1; r++) {
+					const float dist = fmaxf(1.0f - Sx[r * LQ + (col ? v - 1 : 0)], 0.0f);
+					colmin = fminf(colmin, dist);
+					acc1 += w_s * wave_min64(col ? dist : 3.402823466e+38F);
+				}
+				wave_lds_fence();
+			}
+			const float x = col ? w_t * colmin : 0.0f;
+			float acc0 = 0.0f;
+			for (int j = 0; j < len_t; j++) {
+				const float xj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), j));
+				acc0 = j == 0 ? xj : acc0 + xj;
+			}
+			if (!nbow) { acc0 = acc0 / (float)len_t; acc1 = acc1 / (float)len_s; }
+			float cost = 0.0f;
+			if (p.rwmd_symmetric) { if (acc0 > cost) cost = acc0; if (acc1 > cost) cost = acc1; }
+			else cost = acc0;
+			const float max_cost = nbow ? 1.0f : (float)len_t;
+			raw = (max_cost - cost) / max_cost;
+		} else {
+			// ---- alignment: fill, lane = column
+			float hprev = 0.0f, eprev = VK_NEG_INF;
+			if (global && col) hprev = gap == 0 ? -(gt * (float)v) : gap == 1 ? -(a_t + gt * (float)v) : -wtl[v];
+			if (gap == 2 && col) H[v] = hprev;
+			float bv = 0.0f;
+			int bu = 0, u = 0;
+			for (int base = base0; base < t_b; base += 16) {
+				fill(base);
+				wave_lds_fence();
+				const int r0 = t_a > base ? t_a - base : 0, r1 = t_b - base < 16 ? t_b - base : 16;
+				for (int r = r0; r < r1; r++) {
+					u++;
+					float bprev = 0.0f, bcur = 0.0f;
+					if (global) {
+						bprev = u == 1 ? 0.0f : (gap == 0 ? -(gs * (float)(u - 1)) : gap == 1 ? -(a_s + gs * (float)(u - 1)) : -wsl[u - 1]);
+						bcur = gap == 0 ? -(gs * (float)u) : gap == 1 ? -(a_s + gs * (float)u) : -wsl[u];
+					}
+					const float sv = SWx[r * LQ + (col ? v - 1 : 0)];
+					const float up = __shfl_up(hprev, 1, 64);
+					const float diag = lane == 0 ? bprev : up;
+					float best, e = VK_NEG_INF;
+					uint8_t d, ee = 0, fe = 0;
+					int16_t kk = 0;
+					float c = diag + sv;
+					if (local) { best = 0.0f; d = 0; if (c > best) { best = c; d = 1; } }
+					else { best = c; d = 1; }
+					if (gap == 0) {
+						c = hprev - gs;
+						if (c > best) { best = c; d = 2; kk = 1; }
+					} else if (gap == 1) {
+						e = hprev - open_s;
+						c = eprev - gs;
+						if (c > e) { e = c; ee = 1; }
+						if (e > best) { best = e; d = 2; }
+					} else {
+						for (int k = 1; k <= u; k++) {
+							c = H[(u - k) * W + (col ? v : 1)] - wsl[k];
+							if (c > best) { best = c; d = 2; kk = (int16_t)k; }
+						}
+					}
+					// in-row candidates: columns become final left to right
+					float left_best = VK_NEG_INF, f = VK_NEG_INF, fin = best, ffin = VK_NEG_INF;
+					int16_t left_k = 0;
+					for (int pp = 0; pp < len_t; pp++) {
+						const float sp = pp == 0 ? bcur : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fin), pp - 1));
+						const float fp = pp == 0 ? VK_NEG_INF : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ffin), pp - 1));
+						if (gap == 2) {
+							if (col && v > pp) {
+								const float cc = sp - wtl[v - pp];
+								if (cc >= left_best) { left_best = cc; left_k = (int16_t)(v - pp); }
+							}
+						} else if (v == pp + 1) {
+							if (gap == 0) { left_best = sp - gt; left_k = 1; }
+							else {
+								f = sp - open_t;
+								const float c2 = fp - gt;
+								if (c2 > f) { f = c2; fe = 1; }
+							}
+						}
+						if (v == pp + 1) {
+							if (gap == 1) { if (f > best) { best = f; d = 3; } ffin = f; }
+							else if (left_best > best) { best = left_best; d = 3; kk = left_k; }
+							fin = best;
+						}
+					}
+					if (col) {
+						if (gap == 2) H[u * W + v] = best;
+						if (FLOW) {
+							dk[u * W + v] = kk;
+							flags[u * W + v] = (uint8_t)(d | (ee << 2) | (fe << 3));
+						}
+						// start cell: first maximum in row-major order; per column the first row wins (strict >)
+						if (!global && (local || u == len_s || v == len_t) && best > bv) { bv = best; bu = u; }
+					}
+					hprev = best;
+					eprev = e;
+				}
+				wave_lds_fence();
+			}
+			if (global) {
+				raw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hprev), len_t - 1));
+				u_start = len_s; v_start = len_t;
+			} else {
+				raw = 0.0f;
+				for (int j = 0; j < len_t; j++) {
+					const float vj = __shfl(bv, j, 64);
+					const int uj = __shfl(bu, j, 64);
+					if (vj > raw || (vj == raw && vj > 0.0f && uj < u_start)) { raw = vj; u_start = uj; v_start = j + 1; }
+				}
+			}
+		}
+
+		if (!FLOW) {
+			if (lane == 0) {
+				const float boost = p.boost ? p.boost[g] : 1.0f;
+				p.scores[g] = (raw / p.ref_total) * boost;
+				p.raw[g] = raw;
+			}
+			continue;
+		}
+		// ---- FLOW: traceback by lane 0, then the edge similarities from a second sweep over the tiles
+		mapl[lane] = -1;
+		wave_lds_fence();
+		if (lane == 0 && gap != 4) {
+			int u = u_start, v2 = v_start, state = 0;
+			while (u > 0 && v2 > 0) {
+				const int idx = u * W + v2;
+				const uint8_t fl = flags[idx];
+				if (gap == 1 && state == 1) { if (!(fl & 4)) state = 0; u--; continue; }
+				if (gap == 1 && state == 2) { if (!(fl & 8)) state = 0; v2--; continue; }
+				const uint8_t d = fl & 3;
+				if (d == 0) break;
+				if (d == 1) { mapl[v2 - 1] = (int16_t)(u - 1); u--; v2--; }
+				else if (gap == 1) state = (d == 2) ? 1 : 2;
+				else if (d == 2) u -= dk[idx];
+				else v2 -= dk[idx];
+			}
+		}
+		wave_lds_fence();
+		const int mine = mapl[lane];
+		float es = 0.0f;
+		for (int base = base0; base < t_b; base += 16) {
+			fill(base);
+			wave_lds_fence();
+			const int row = t_a + mine - base;
+			if (mine >= 0 && row >= 0 && row < 16) es = Sx[row * LQ + lane];
+			wave_lds_fence();
+		}
+		p.mapping[item * 64 + lane] = (int16_t)mine;
+		p.edge_sim[item * 64 + lane] = es;
+		if (lane == 0) p.raw_out[item] = raw;
+	}
+}
+
+extern "C" hipError_t vk_launch_wide(const VkWideParams *p, int32_t flow_k, hipStream_t stream) {
+	const bool flow = flow_k > 0;
+	const size_t smem = vk_wide_lds_bytes(p->max_len, p->nq, p->gap_mode, p->pos_s != nullptr, flow);
+	if (smem > 160 * 1024) return hipErrorInvalidValue;
+	const void *fn = flow ? reinterpret_cast<const void *>(vk_wide_kernel<true>) : reinterpret_cast<const void *>(vk_wide_kernel<false>);
+	if (smem > 64 * 1024) {
+		hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+		if (e != hipSuccess) return e;
+	}
+	if (flow) {
+		vk_wide_kernel<true><<<flow_k, 64, smem, stream>>>(*p);
+	} else {
+		int occ = 0, dev = 0, cus = 256;
+		hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vk_wide_kernel<false>, 64, smem);
+		if (e != hipSuccess) return e;
+		if (occ < 1) occ = 1;
+		if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+		const int64_t want = p->n_sent, cap = (int64_t)cus * occ;
+		vk_wide_kernel<false><<<(int)(want < cap ? want : cap), 64, smem, stream>>>(*p);
+	}
+	return hipGetLastError();
+}
+
+extern "C" size_t vk_wide_lds_demand(int32_t max_len, int32_t nq, int32_t gap_mode, int32_t tagged, int32_t flow) {
+	return vk_wide_lds_bytes(max_len, nq, gap_mode, tagged != 0, flow != 0);
+}
+
+extern "C" hipError_t vk_launch_flow(const VkFlowParams *p, int32_t k, hipStream_t stream) {
+	const size_t smem = vk_flow_lds_bytes(p->max_len, p->pos_s != nullptr);
+	if (smem > 64 * 1024) {
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(vk_flow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+		if (e != hipSuccess) return e;
+	}
+	vk_flow_kernel<<<k, 64, smem, stream>>>(*p);
+	return hipGetLastError();
+}

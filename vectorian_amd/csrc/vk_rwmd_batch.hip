@@ -1,0 +1,448 @@
+// vk_rwmd_batch.hip -- batched relaxed WMD as an MFMA GEMM (BASELINE config 4).
+#include "vk_common.cuh"
+
+// ---------------------------------------------------------------------------
+// Batched relaxed Word Mover's Distance (BASELINE config 4: 256 queries x 1M sentences):
+// a GEMM [T x d] . [d x (B * 16)] on MFMA with the row / column minima and the RWMD score as
+// epilogue.  MFMA-bound (intensity ~2.5 kFLOP per corpus byte), so the corpus tokens stay in
+// registers and the queries stream past them:
+//   workgroup = 4 waves; each wave loads TPW token tiles (64 tokens for TPW = 4) ONCE into
+//   registers as MFMA B operands; the B query tiles (A operands, one 16-row tile per query) are
+//   staged one after the other into a double-buffered LDS slot shared by the 4 waves
+//   (global -> registers -> LDS while the previous query's MFMAs run), so every query byte is
+//   fetched from L2 once per 256 tokens and every corpus byte from HBM once per batch.
+// Requires sentences of one length L = 16 * TPS (the config's shape); other corpora take the
+// per-query path.  Scores: scores[q * n_sent + s] = Score::value as in rwmd_rows.
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ float xor16_f(float x) {
+	return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), (0x10 << 10) | 0x1f));
+}
+
+// DPP row broadcast used by wave reductions: CTRL 0x142 = row_bcast:15 (lane 15 of each row to the next
+// row), 0x143 = row_bcast:31; ROWS = row_mask of the rows that receive.  Lanes outside get 0.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float dpp_bcast(float x) {
+	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROWS, 0xf, false));
+}
+
+// partner lane l ^ 32 through ds_bpermute.  (v_permlane32_swap would be cheaper, but the builtin's
+// second result did not deliver the upper halves here -- tools/probe/xlane_probe.hip -- so it is not used.)
+__device__ __forceinline__ float xor32_f(float x, int lane) {
+	return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, x)));
+}
+
+template <int NK, bool HALF, int TPS>
+__global__ __launch_bounds__(256, 2) void vk_rwmd_batch_kernel(VkRwmdBatchParams p) {
+	constexpr int TPW = TPS == 3 ? 3 : 4;          // token tiles per wave
+	constexpr int SPW = TPW / TPS;                 // sentences per wave
+	extern __shared__ float4 vk_smem4[];
+	uint8_t *qbuf = reinterpret_cast<uint8_t *>(vk_smem4);   // 2 x tile_bytes
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int g4 = lane >> 4;
+	const int n16 = p.tile_bytes >> 4;             // 16-byte pieces of one query tile
+	const int64_t n_chunks = (p.n_tiles + TPW * 4 - 1) / (TPW * 4);
+
+	for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+		const int64_t tile0 = chunk * (TPW * 4) + (int64_t)wv * TPW;
+		// ---- corpus tiles of this wave -> registers (read once per batch)
+		bf16x8 x[TPW][NK];
+#pragma unroll
+		for (int tt = 0; tt < TPW; tt++) {
+			const int64_t tile = tile0 + tt < p.n_tiles ? tile0 + tt : p.n_tiles;   // one zero tile follows the corpus
+			const uint8_t *tp = p.tiles + tile * p.tile_bytes;
+#pragma unroll
+			for (int t = 0; t < NK; t++) {
+				if (HALF && t == NK - 1) x[tt][t] = load_half_block(tp + t * 1024, lane, true);
+				else x[tt][t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(tp + t * 1024 + lane * 16));
+			}
+		}
+		// ---- stage query 0
+		__syncthreads();   // previous chunk's readers are done with the LDS slots
+		for (int i = threadIdx.x; i < n16; i += 256)
+			vk_smem4[i] = *reinterpret_cast<const float4 *>(p.qtiles + i * 16);
+		__syncthreads();
+
+		for (int q = 0; q < p.n_queries; q++) {
+			const uint8_t *cur = qbuf + (q & 1) * p.tile_bytes;
+			float4 *nxt = vk_smem4 + ((q + 1) & 1) * n16;
+			// prefetch the next query tile into registers (<= 3 pieces per thread for d <= 384)
+			float4 st0 = {0, 0, 0, 0}, st1 = st0, st2 = st0;
+			const bool more = q + 1 < p.n_queries;
+			if (more) {
+				const uint8_t *src = p.qtiles + (int64_t)(q + 1) * p.tile_bytes;
+				const int i0 = threadIdx.x, i1 = threadIdx.x + 256, i2 = threadIdx.x + 512;
+				if (i0 < n16) st0 = *reinterpret_cast<const float4 *>(src + i0 * 16);
+				if (i1 < n16) st1 = *reinterpret_cast<const float4 *>(src + i1 * 16);
+				if (i2 < n16) st2 = *reinterpret_cast<const float4 *>(src + i2 * 16);
+			}
+			// ---- S^T = Q X^T for TPW tiles
+			f32x4 acc[TPW];
+#pragma unroll
+			for (int tt = 0; tt < TPW; tt++) acc[tt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+			// query fragments: all NK ds_read_b128 are issued up front (40 VGPRs for d = 300) so the MFMAs
+			// of step t never wait for the LDS latency of step t
+			bf16x8 af[NK];
+#pragma unroll
+			for (int t = 0; t < NK; t++) {
+				af[t] = *reinterpret_cast<const bf16x8 *>(cur + t * 1024 + ((HALF && t == NK - 1) ? (lane & 31) : lane) * 16);
+				if (HALF && t == NK - 1) {
+					const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+					af[t] = lane < 32 ? af[t] : z;
+				}
+			}
+#pragma unroll
+			for (int t = 0; t < NK; t++) {
+#pragma unroll
+				for (int tt = 0; tt < TPW; tt++) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t], x[tt][t], acc[tt], 0, 0, 0);
+			}
+			if (more) {
+				const int i0 = threadIdx.x, i1 = threadIdx.x + 256, i2 = threadIdx.x + 512;
+				if (i0 < n16) nxt[i0] = st0;
+				if (i1 < n16) nxt[i1] = st1;
+				if (i2 < n16) nxt[i2] = st2;
+			}
+			// ---- epilogue: D = 1 - clip(S); lane holds token (lane & 15) x query columns 4*g4 .. +3.
+			// Lane exchanges across the four 16-lane rows go through the LDS crossbar (ds_swizzle /
+			// ds_bpermute); the exchanges of all tiles are issued back to back so their latencies overlap.
+			// (reciprocals instead of the oracle's divisions: a batch epilogue runs per (query, sentence) and
+			// is VALU-bound; the results differ from the per-query kernel by <= 1 ulp, far inside 1e-4)
+			const int len_t = p.q_len[q];
+			const float inv_t = 1.0f / (float)len_t;
+			const float inv_s = 1.0f / (float)(TPS * 16);
+			float rm[TPW], cm[SPW][4];
+#pragma unroll
+			for (int sw = 0; sw < SPW; sw++)
+#pragma unroll
+				for (int r = 0; r < 4; r++) cm[sw][r] = 3.0f;
+#pragma unroll
+			for (int tt = 0; tt < TPW; tt++) {
+				const f32x4 a4 = acc[tt];
+				float dd[4];
+#pragma unroll
+				for (int r = 0; r < 4; r++) {
+					dd[r] = 1.0f - clip01(a4[r]);
+					cm[tt / TPS][r] = fminf(cm[tt / TPS][r], dd[r]);
+				}
+				// padded query columns have S = 0, D = 1: they never lower a minimum
+				rm[tt] = fminf(fminf(dd[0], dd[1]), fminf(dd[2], dd[3]));
+			}
+			float ex[TPW];
+#pragma unroll
+			for (int tt = 0; tt < TPW; tt++) ex[tt] = xor16_f(rm[tt]);
+#pragma unroll
+			for (int tt = 0; tt < TPW; tt++) rm[tt] = fminf(rm[tt], ex[tt]);
+#pragma unroll
+			for (int tt = 0; tt < TPW; tt++) ex[tt] = xor32_f(rm[tt], lane);
+#pragma unroll
+			for (int tt = 0; tt < TPW; tt++) rm[tt] = fminf(rm[tt], ex[tt]);   // row minimum of token (lane & 15) of tile tt
+#pragma unroll
+			for (int sw = 0; sw < SPW; sw++) {
+				float rsum = 0.0f;
+#pragma unroll
+				for (int ts = 0; ts < TPS; ts++) rsum += rm[sw * TPS + ts];
+				// column minima over the sentence's tokens: reduce over the 16 lanes of the DPP row
+#pragma unroll
+				for (int r = 0; r < 4; r++) {
+					float x = cm[sw][r];
+					x = fminf(x, dpp_f<DPP_ROW_SHR1>(x, x));
+					x = fminf(x, dpp_f<DPP_ROW_SHR2>(x, x));
+					x = fminf(x, dpp_f<DPP_ROW_SHR4>(x, x));
+					x = fminf(x, dpp_f<DPP_ROW_SHR8>(x, x));
+					cm[sw][r] = x;
+				}
+				float c0 = 0.0f;
+#pragma unroll
+				for (int r = 0; r < 4; r++) c0 += (4 * g4 + r < len_t) ? cm[sw][r] : 0.0f;   // valid in lane 15 of each row
+				// sum of the four rows' lane 15 -> lane 63 (row_bcast:15 into rows 1, 3; row_bcast:31 into rows 2, 3)
+				c0 += dpp_bcast<0x142, 0xa>(c0);
+				c0 += dpp_bcast<0x143, 0xc>(c0);
+				rsum += dpp_f<DPP_ROW_SHR1>(0.0f, rsum);
+				rsum += dpp_f<DPP_ROW_SHR2>(0.0f, rsum);
+				rsum += dpp_f<DPP_ROW_SHR4>(0.0f, rsum);
+				rsum += dpp_f<DPP_ROW_SHR8>(0.0f, rsum);   // lane 15 of every row: sum over the sentence's tokens
+				const float acc0 = inv_t * c0, acc1 = inv_s * rsum;      // nbow and bow/len agree up to rounding
+				const float cost = p.symmetric ? fmaxf(0.0f, fmaxf(acc0, acc1)) : acc0;
+				const float raw = p.nbow ? 1.0f - cost : ((float)len_t - cost) * inv_t;
+				const int64_t sent = (tile0 + sw * TPS) / TPS;
+				if (lane == 63 && sent < p.n_sent) {
+					const float boost = p.boost ? p.boost[sent] : 1.0f;
+					p.scores[(int64_t)q * p.n_sent + sent] = (raw * inv_t) * boost;
+				}
+			}
+			__syncthreads();   // next query tile is in place; this one may be overwritten
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------
+// Batched RWMD for 32-token sentences (the shape of BASELINE config 4) on v_mfma_f32_32x32x16_bf16.
+// Two inefficiencies of the 16-row kernel above go away: a 10-token query no longer occupies a
+// 16-row tile (QPT = 3 queries share the 32 rows of one A tile: 30 / 32 rows used, 10 / 16 before)
+// and K is padded to 16, not 32 (d = 300: 19 steps of 16 = 304, not 320).
+//   workgroup = 8 waves; a wave keeps its 2 sentences (4 token tiles) in registers as B operands of
+//   two MFMA chains: chain 0 takes tokens 0..15 of both sentences (columns 0..15 = sentence 0,
+//   16..31 = sentence 1), chain 1 tokens 16..31.  So a lane (n = lane & 31, h = lane >> 5) holds, in
+//   acc0[i] and acc1[i], the similarities of ONE query row with tokens n & 15 and 16 + (n & 15) of
+//   sentence n >> 4: the maximum over a sentence's tokens is one in-lane max and a reduction over the
+//   16 lanes of a DPP row, never across rows.
+//   A rows: M = 8 (i >> 2) + 4 h + (i & 3) for accumulator register i of half h (hardware layout of
+//   the 32x32 result).  QPT = 3: half h, i < 10 = token i of query 3 qt + h; 10 <= i < 15 = token
+//   5 h + i - 10 of query 3 qt + 2.  QPT = 2: half h = query 2 qt + h, i = token.  The host packs the
+//   A tiles accordingly (vk_api.cpp pack_query_tiles32).
+//   The query tiles stream through a double-buffered LDS slot shared by the 8 waves.
+// ---------------------------------------------------------------------------
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8n;
+typedef __attribute__((address_space(3))) void *vk_lds_ptr;
+typedef __attribute__((address_space(1))) const void *vk_glb_ptr;
+
+__device__ __forceinline__ float row_sum_to_lane15(float x) {
+	x += dpp_f<DPP_ROW_SHR1>(0.0f, x);
+	x += dpp_f<DPP_ROW_SHR2>(0.0f, x);
+	x += dpp_f<DPP_ROW_SHR4>(0.0f, x);
+	x += dpp_f<DPP_ROW_SHR8>(0.0f, x);
+	return x;
+}
+
+// Maxima of similarities that end in clip01() may be taken on the raw bit patterns as signed integers:
+// non-negative floats order like their bits, negative floats are negative integers and lose against any
+// non-negative one, and a maximum that stays negative is clipped to 0 whichever negative value it is.
+// Integer maxima need no canonicalisation of their inputs and fuse with DPP (v_max_i32_dpp).
+__device__ __forceinline__ int fbits(float x) { return __builtin_bit_cast(int, x); }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+template <int CTRL>
+__device__ __forceinline__ int dpp_imax(int x) {
+	return imax(x, __builtin_amdgcn_update_dpp((int)0x80000000, x, CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ int row_imax_to_lane15(int x) {
+	x = dpp_imax<DPP_ROW_SHR1>(x);
+	x = dpp_imax<DPP_ROW_SHR2>(x);
+	x = dpp_imax<DPP_ROW_SHR4>(x);
+	x = dpp_imax<DPP_ROW_SHR8>(x);
+	return x;
+}
+__device__ __forceinline__ float clip01_bits(int x) { return __builtin_amdgcn_fmed3f(__builtin_bit_cast(float, x), 0.0f, 1.0f); }
+
+// Maxima of 16 registers over the 16 lanes of each DPP row, transposed: lane v of the row ends up with the row
+// maximum of register v.  Halving exchange: at the step for lane bit b a lane keeps the registers whose index bit
+// equals its own lane bit and hands the others to its partner (lane ^ (1 << b)), so the register count halves while
+// the lane span doubles: 8 + 4 + 2 + 1 exchanges (47 instructions) instead of 16 four-step DPP reductions (64+).
+__device__ __forceinline__ int row_transpose_imax16(const int (&v)[16], int lane) {
+	const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+	const int NEG = (int)0x80000000;
+	int w[8], x[4], y[2];
+#pragma unroll
+	for (int k = 0; k < 8; k++) {
+		const int keep = b0 ? v[2 * k + 1] : v[2 * k], send = b0 ? v[2 * k] : v[2 * k + 1];
+		w[k] = imax(keep, __builtin_amdgcn_update_dpp(NEG, send, 0xB1, 0xf, 0xf, false));     // quad_perm [1,0,3,2]: lane ^ 1
+	}
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		const int keep = b1 ? w[2 * k + 1] : w[2 * k], send = b1 ? w[2 * k] : w[2 * k + 1];
+		x[k] = imax(keep, __builtin_amdgcn_update_dpp(NEG, send, 0x4E, 0xf, 0xf, false));     // quad_perm [2,3,0,1]: lane ^ 2
+	}
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		const int keep = b2 ? x[2 * k + 1] : x[2 * k], send = b2 ? x[2 * k] : x[2 * k + 1];
+		int t = __builtin_amdgcn_update_dpp(NEG, send, 0x104, 0xf, 0x5, false);                // row_shl:4 into banks 0, 2: lane + 4
+		t = __builtin_amdgcn_update_dpp(t, send, 0x114, 0xf, 0xa, false);                      // row_shr:4 into banks 1, 3: lane - 4
+		y[k] = imax(keep, t);
+	}
+	const int keep = b3 ? y[1] : y[0], send = b3 ? y[0] : y[1];
+	return imax(keep, __builtin_amdgcn_update_dpp(NEG, send, 0x128, 0xf, 0xf, false));          // row_ror:8: lane ^ 8
+}
+
+// S tiles of one query tile against the wave's two sentences: 2 x NK16 MFMAs, A fragments DEPTH steps ahead
+template <int NK16>
+__device__ __forceinline__ void batch32_mfma(const uint8_t *cur, const bf16x8 (&x)[2][NK16], f32x16 &acc0, f32x16 &acc1) {
+	constexpr int DEPTH = 4;                           // A fragments in flight (ds_read_b128 ahead of their MFMAs)
+#pragma unroll
+	for (int i = 0; i < 16; i++) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
+	bf16x8 a[DEPTH];
+#pragma unroll
+	for (int t = 0; t < DEPTH && t < NK16; t++) a[t] = *reinterpret_cast<const bf16x8 *>(cur + t * 1024);
+#pragma unroll
+	for (int t = 0; t < NK16; t++) {
+		const bf16x8 at = a[t % DEPTH];
+#if defined(VK_ABL) && VK_ABL == 3
+		if (t > 0) { acc0[t & 15] += (float)at[0]; acc1[t & 15] += (float)x[1][t][0] + (float)x[0][t][0]; continue; }
+#endif
+		acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8n, at), __builtin_bit_cast(bf16x8n, x[0][t]), acc0, 0, 0, 0);
+		acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8n, at), __builtin_bit_cast(bf16x8n, x[1][t]), acc1, 0, 0, 0);
+		if (t + DEPTH < NK16) a[t % DEPTH] = *reinterpret_cast<const bf16x8 *>(cur + (t + DEPTH) * 1024);
+		__builtin_amdgcn_sched_barrier(0);
+	}
+}
+
+// RWMD scores of query tile qt for the wave's two sentences from the accumulators.
+// D = 1 - clip(S) is monotone in S: reduce S (as integers, see above), convert the reduced values only.
+// Rows of absent query tokens are zero: S = 0, clip = 0, no masks.
+template <int QPT>
+__device__ __forceinline__ void batch32_epilogue(const VkRwmdBatchParams &p, int qt, int64_t sent, int lane, const f32x16 &acc0, const f32x16 &acc1) {
+	constexpr int NMAIN = QPT == 3 ? 10 : 16;          // rows of the half's own query
+	const int h = lane >> 5;
+	const float inv_s = 1.0f / 32.0f;
+#if defined(VK_ABL) && VK_ABL == 1
+	{
+		float z = 0.0f;
+#pragma unroll
+		for (int i = 0; i < 16; i++) z += acc0[i] + acc1[i];
+		if (z == 12345.0f) p.scores[0] = z;
+		return;
+	}
+#endif
+	// (a) per token: max over the query's rows (in-lane) -> this lane's two tokens' distances -> sum
+	//     over the sentence's 32 tokens = 16 lanes x 2 chains
+	int ca0 = fbits(acc0[0]), ca1 = fbits(acc1[0]);
+#pragma unroll
+	for (int i = 1; i < NMAIN; i++) { ca0 = imax(ca0, fbits(acc0[i])); ca1 = imax(ca1, fbits(acc1[i])); }
+	const float ts_main = row_sum_to_lane15((2.0f - clip01_bits(ca0)) - clip01_bits(ca1));
+	float ts_third = 0.0f;
+	if (QPT == 3) {
+		int cb0 = fbits(acc0[10]), cb1 = fbits(acc1[10]);
+#pragma unroll
+		for (int i = 11; i < 15; i++) { cb0 = imax(cb0, fbits(acc0[i])); cb1 = imax(cb1, fbits(acc1[i])); }
+		const int e0 = __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, cb0);
+		const int e1 = __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, cb1);
+		cb0 = imax(cb0, e0); cb1 = imax(cb1, e1);
+		ts_third = row_sum_to_lane15((2.0f - clip01_bits(cb0)) - clip01_bits(cb1));
+	}
+	// (b) per query row: max over the sentence's tokens -> lane 15 of the DPP row
+	const int q_main = qt * QPT + h, q_third = qt * 3 + 2;
+	float s_main = 0.0f, s_third = 0.0f;
+	{
+		int m[16];
+#pragma unroll
+		for (int i = 0; i < 16; i++) m[i] = imax(fbits(acc0[i]), fbits(acc1[i]));
+		const float z = clip01_bits(row_transpose_imax16(m, lane));    // lane v of the row: maximum of query row v over the sentence
+		const int v = lane & 15;
+		s_main = row_sum_to_lane15(v < NMAIN ? z : 0.0f);
+		if (QPT == 3) {
+			s_third = row_sum_to_lane15((v >= 10 && v < 15) ? z : 0.0f);
+			s_third += xor32_f(s_third, lane);
+		}
+	}
+	// (c) scores (the expressions of vk_rwmd_batch_kernel; sum (1 - x) over len rows = len - sum x)
+	if ((lane & 15) == 15 && sent < p.n_sent) {
+		const float boost = p.boost ? p.boost[sent] : 1.0f;
+		const int len_main = q_main < p.n_queries ? p.q_len[q_main] : 0;
+		if (len_main > 0) {
+			const float inv_t = p.q_inv_len[q_main];
+			const float a0 = inv_t * ((float)len_main - s_main), a1 = inv_s * ts_main;
+			const float cost = p.symmetric ? fmaxf(0.0f, fmaxf(a0, a1)) : a0;
+			const float raw = p.nbow ? 1.0f - cost : ((float)len_main - cost) * inv_t;
+			p.scores[(int64_t)q_main * p.n_sent + sent] = (raw * inv_t) * boost;
+		}
+		const int len_third = (QPT == 3 && h == 0 && q_third < p.n_queries) ? p.q_len[q_third] : 0;
+		if (len_third > 0) {
+			const float inv_t = p.q_inv_len[q_third];
+			const float a0 = inv_t * ((float)len_third - s_third), a1 = inv_s * ts_third;
+			const float cost = p.symmetric ? fmaxf(0.0f, fmaxf(a0, a1)) : a0;
+			const float raw = p.nbow ? 1.0f - cost : ((float)len_third - cost) * inv_t;
+			p.scores[(int64_t)q_third * p.n_sent + sent] = (raw * inv_t) * boost;
+		}
+	}
+}
+
+template <int NK16, int QPT>
+__global__ __launch_bounds__(512) void vk_rwmd_batch32_kernel(VkRwmdBatchParams p) {
+	constexpr int QT_BYTES = NK16 * 1024;
+	extern __shared__ float4 vk_smem4[];
+	const uint8_t *qbuf = reinterpret_cast<const uint8_t *>(vk_smem4);
+	const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int n32 = lane & 31, h = lane >> 5;
+	const int64_t n_chunks = ((int64_t)p.n_sent + 15) / 16;
+	// The two waves that share a SIMD (w and w + 4 of the workgroup) run the two halves of an interval in
+	// opposite order: the "late" wave first finishes the epilogue of the previous tile (VALU) while the
+	// other one issues its MFMAs, then they swap.  Barriers would otherwise keep all waves in phase:
+	// every matrix core idle during the epilogues, every VALU idle during the MFMAs.
+	const bool late = (wv & p.late_mask) != 0;
+
+	for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+		const int64_t sent = chunk * 16 + wv * 2 + (n32 >> 4);   // this lane's sentence
+		// ---- the wave's token tiles -> registers (read once per batch)
+		bf16x8 x[2][NK16];
+#pragma unroll
+		for (int m = 0; m < 2; m++) {
+			const int64_t tile = sent < p.n_sent ? sent * 2 + m : p.n_tiles;   // one zero tile follows the corpus
+			const uint8_t *tp = p.tiles + tile * p.tile_bytes + (n32 & 15) * 16;
+#pragma unroll
+			for (int t = 0; t < NK16; t++)
+				x[m][t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(tp + (t >> 1) * 1024 + (2 * (t & 1) + h) * 256));
+		}
+		__syncthreads();   // previous chunk's readers are done with the LDS slots
+#pragma unroll
+		for (int b = wv; b < NK16; b += 8)
+			__builtin_amdgcn_global_load_lds((vk_glb_ptr)(p.qtiles + b * 1024 + lane * 16), (vk_lds_ptr)(qbuf + b * 1024), 16, 0, 0);
+		__syncthreads();
+
+		f32x16 acc0, acc1;
+		for (int qt = 0; qt < p.n_qtiles; qt++) {
+			const uint8_t *cur = qbuf + (qt & 1) * QT_BYTES + lane * 16;
+			// next query tile: LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, no staging
+			// registers -- the kernel sits at the VGPR cap), in flight during this tile's MFMAs and retired by
+			// the barrier at the end of the iteration.  The tile after the last one is zero padding.
+			{
+				const uint8_t *src = p.qtiles + (int64_t)(qt + 1) * QT_BYTES + lane * 16;
+				const uint8_t *nxt = qbuf + ((qt + 1) & 1) * QT_BYTES;
+#pragma unroll
+				for (int b = wv; b < NK16; b += 8)
+					__builtin_amdgcn_global_load_lds((vk_glb_ptr)(src + b * 1024), (vk_lds_ptr)(nxt + b * 1024), 16, 0, 0);
+			}
+			if (!late) {
+				batch32_mfma<NK16>(cur, x, acc0, acc1);
+				batch32_epilogue<QPT>(p, qt, sent, lane, acc0, acc1);
+			} else {
+				if (qt > 0) batch32_epilogue<QPT>(p, qt - 1, sent, lane, acc0, acc1);
+				batch32_mfma<NK16>(cur, x, acc0, acc1);
+			}
+			__syncthreads();   // next query tile is in place; this one may be overwritten
+		}
+		if (late) batch32_epilogue<QPT>(p, p.n_qtiles - 1, sent, lane, acc0, acc1);
+	}
+}
+
+template <int NK, bool HALF>
+static hipError_t launch_rwmd_batch_tps(const VkRwmdBatchParams &p, size_t smem, hipStream_t stream) {
+	int dev = 0, cus = 256;
+	if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+	const int tpw = p.tiles_per_sent == 3 ? 3 : 4;
+	const int64_t n_chunks = (p.n_tiles + tpw * 4 - 1) / (tpw * 4);
+	const int grid = (int)(n_chunks < (int64_t)cus * 2 ? n_chunks : (int64_t)cus * 2);
+	switch (p.tiles_per_sent) {
+	case 1: vk_rwmd_batch_kernel<NK, HALF, 1><<<grid, 256, smem, stream>>>(p); break;
+	case 2: vk_rwmd_batch_kernel<NK, HALF, 2><<<grid, 256, smem, stream>>>(p); break;
+	case 3: vk_rwmd_batch_kernel<NK, HALF, 3><<<grid, 256, smem, stream>>>(p); break;
+	default: vk_rwmd_batch_kernel<NK, HALF, 4><<<grid, 256, smem, stream>>>(p); break;
+	}
+	return hipGetLastError();
+}
+
+// 32-token sentences: p->qtiles holds p->n_qtiles A tiles of 32 rows (p->qpt queries each)
+extern "C" hipError_t vk_launch_rwmd_batch32(const VkRwmdBatchParams *p, hipStream_t stream) {
+	int dev = 0, cus = 256;
+	if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+	if (p->tiles_per_sent != 2 || (p->qpt != 2 && p->qpt != 3)) return hipErrorNotSupported;
+	const int64_t n_chunks = ((int64_t)p->n_sent + 15) / 16;
+	const int grid = (int)(n_chunks < (int64_t)cus ? n_chunks : (int64_t)cus);
+	if (p->nk == 10 && p->half == 1) {
+		const size_t smem = 2 * 19 * 1024;
+		if (p->qpt == 3) vk_rwmd_batch32_kernel<19, 3><<<grid, 512, smem, stream>>>(*p);
+		else vk_rwmd_batch32_kernel<19, 2><<<grid, 512, smem, stream>>>(*p);
+	} else if (p->nk == 4 && p->half == 0) {
+		const size_t smem = 2 * 8 * 1024;
+		if (p->qpt == 3) vk_rwmd_batch32_kernel<8, 3><<<grid, 512, smem, stream>>>(*p);
+		else vk_rwmd_batch32_kernel<8, 2><<<grid, 512, smem, stream>>>(*p);
+	} else return hipErrorNotSupported;
+	return hipGetLastError();
+}
+
+// returns hipErrorNotSupported when no batched kernel exists for this corpus shape
+extern "C" hipError_t vk_launch_rwmd_batch(const VkRwmdBatchParams *p, hipStream_t stream) {
+	const size_t smem = (size_t)p->tile_bytes * 2;
+	if (p->nk == 10 && p->half == 1) return launch_rwmd_batch_tps<10, true>(*p, smem, stream);
+	if (p->nk == 4 && p->half == 0) return launch_rwmd_batch_tps<4, false>(*p, smem, stream);
+	return hipErrorNotSupported;
+}
