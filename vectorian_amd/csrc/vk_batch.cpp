@@ -1,0 +1,386 @@
+// vk_batch.cpp -- C-ABI: several queries per call (the RWMD GEMM pass, queries sharing a pass over the tiles,
+// or one by one).
+// No CPU compute fallback exists: without a HIP device every entry point that
+// would compute returns VK_ERR_NO_DEVICE / VK_ERR_HIP.
+
+#include "vk_internal.h"
+
+static bool same_gap(const vk_gap &a, const vk_gap &b, int upto) {
+	if (a.kind != b.kind) return false;
+	if (a.kind != VK_GAP_TABLE) return a.u == b.u && (a.kind == VK_GAP_LINEAR || a.v == b.v);
+	if (a.table == b.table && a.n_table == b.n_table) return true;
+	for (int k = 0; k <= upto; k++) if (gap_cost(a, k) != gap_cost(b, k)) return false;
+	return true;
+}
+
+// Queries with common options over a contextual corpus: up to 4 queries share one pass over the token tiles
+// (vk_score_batch_kernel).  Returns VK_ERR_UNSUPPORTED (without setting an error) when the batch does not qualify;
+// the caller then runs the queries one by one.
+static int query_batch_shared_pass(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, vk_topk_out *outs) {
+	if (n_queries < 2 || !c->finalized || c->prec != 0 || c->desc.layout != VK_LAYOUT_CONTEXTUAL || c->n_long_groups > 0 || c->desc.n_sentences < 1) return VK_ERR_UNSUPPORTED;
+	if (c->nk32 > 10 && !getenv("VK_BATCH_QB")) return VK_ERR_UNSUPPORTED;   // measured: no gain over single queries for 768-d rows (the kernel pipelines tiles of <= 10 K-steps)
+	const vk_query_desc &q0 = qs[0];
+	if (q0.max_matches > 64) return VK_ERR_UNSUPPORTED;
+	int max_len_t = 0;
+	for (int i = 0; i < n_queries; i++) {
+		const vk_query_desc &q = qs[i];
+		const bool alg_ok = q.algorithm == VK_ALG_ALIGN || (q.algorithm == VK_ALG_RWMD && q.rwmd_injective && !q.wmd_full);
+		if (!alg_ok || q.algorithm != q0.algorithm || q.len_t > VK_FAST_QUERY_LEN || q.len_t < 1 || q.tag_weights || q.submatch_weight != 0.0f ||
+			q.locality != q0.locality || q.max_matches != q0.max_matches || q.min_score != q0.min_score || q.boost != q0.boost ||
+			q.want_flow != q0.want_flow || q.rwmd_symmetric != q0.rwmd_symmetric || q.rwmd_normalize_bow != q0.rwmd_normalize_bow)
+			return VK_ERR_UNSUPPORTED;
+		if (q.algorithm == VK_ALG_ALIGN && (!same_gap(q.gap_s, q0.gap_s, c->max_len) || !same_gap(q.gap_t, q0.gap_t, VK_FAST_QUERY_LEN)))
+			return VK_ERR_UNSUPPORTED;
+		max_len_t = std::max(max_len_t, (int)q.len_t);
+	}
+	int rc;
+	for (int i = 0; i < n_queries; i++)
+		if ((rc = vk_validate_query(c, &qs[i], &outs[i]))) return rc;
+	VK_HIP(hipSetDevice(c->device));
+	hipStream_t st = c->stream;
+	const int64_t n = c->n_entries;
+	const int k = q0.max_matches;
+	const bool is_align = q0.algorithm == VK_ALG_ALIGN;
+
+	// ---- common options: gap tables, DP form
+	VkScoreBatchParams p{};
+	const int ks = q0.gap_s.kind, kt = q0.gap_t.kind;
+	float ws[kGapTable], wt[80];
+	if (!is_align) {
+		p.gap_mode = 4; p.rwmd_symmetric = q0.rwmd_symmetric; p.rwmd_normalize_bow = q0.rwmd_normalize_bow;
+	} else if (ks == VK_GAP_LINEAR && kt == VK_GAP_LINEAR) {
+		p.gap_mode = 0; p.gs = q0.gap_s.u; p.gt = q0.gap_t.u;
+	} else if ((ks == VK_GAP_LINEAR || ks == VK_GAP_AFFINE) && (kt == VK_GAP_LINEAR || kt == VK_GAP_AFFINE)) {
+		p.gap_mode = 1;
+		p.a_s = ks == VK_GAP_AFFINE ? q0.gap_s.u : 0.0f; p.gs = ks == VK_GAP_AFFINE ? q0.gap_s.v : q0.gap_s.u;
+		p.a_t = kt == VK_GAP_AFFINE ? q0.gap_t.u : 0.0f; p.gt = kt == VK_GAP_AFFINE ? q0.gap_t.v : q0.gap_t.u;
+		p.open_s = p.a_s + p.gs; p.open_t = p.a_t + p.gt;
+	} else p.gap_mode = 2;
+	for (int i = 0; i < kGapTable; i++) ws[i] = (is_align && i <= c->max_len) ? gap_cost(q0.gap_s, i) : 0.0f;
+	for (int i = 0; i < 80; i++) wt[i] = (is_align && i <= max_len_t) ? gap_cost(q0.gap_t, i) : 0.0f;
+	if (p.gap_mode == 2) {
+		bool sub = true;   // see vk_query: register-history DP needs w_t strictly subadditive
+		for (int x = 1; x < max_len_t && sub; x++)
+			for (int y = 1; x + y <= max_len_t; y++)
+				if (!(wt[x] + wt[y] > wt[x + y] + 1e-4f)) { sub = false; break; }
+		if (sub) p.gap_mode = c->max_short_len <= 32 ? 3 : 6;
+	}
+	const int lt = max_len_t <= 4 ? 4 : max_len_t <= 8 ? 8 : max_len_t <= 12 ? 12 : 16;
+	p.s_rows_per_wave = c->max_group_tiles * 16;
+	p.h_rows = c->max_short_len + 1;
+	const int strip = p.s_rows_per_wave * lt + 16;
+	const int hist = p.gap_mode == 2 ? 4 * p.h_rows * 16 : 0;
+	auto smem_of = [&](int qb) { return (size_t)qb * c->tile_bytes + ((size_t)qb * strip + hist) * 4 * 4; };   // query tiles + 4 waves x (qb strips + history)
+	// measured (12 queries x 1 M x 32 x 300-d): 2 queries per pass with two workgroups per CU and 4 per pass with one
+	// take the same time (22 ms linear, 30 ms WSB); 2 leaves LDS for ragged corpora
+	int qb_max = 2;
+	if (const char *e = getenv("VK_BATCH_QB")) qb_max = std::max(2, std::min(4, atoi(e)));   // tuning aid
+	while (qb_max > 1 && smem_of(qb_max) > 160 * 1024) qb_max--;
+	if (qb_max < 2) return VK_ERR_UNSUPPORTED;
+	p.n_strips = qb_max;
+	p.lds_floats_per_wave = qb_max * strip + hist;
+	auto smem_for = [&](int qb) { return (size_t)qb * c->tile_bytes + (size_t)p.lds_floats_per_wave * 4 * 4; };
+
+	// ---- buffers
+	const size_t need_q = (size_t)4 * c->tile_bytes;
+	if (c->bq_cap < need_q) {
+		if (c->d_bq) { VK_HIP(hipFree(c->d_bq)); VK_HIP(hipFree(c->d_bqlen)); }
+		if ((rc = alloc_t(c, &c->d_bq, need_q))) return rc;
+		if ((rc = alloc_t(c, &c->d_bqlen, 2 * ((size_t)4 + 4)))) return rc;
+		c->bq_cap = need_q;
+	}
+	const size_t need_s = (size_t)4 * (size_t)n;
+	if (c->bscores_cap < need_s) {
+		if (c->d_bscores) VK_HIP(hipFree(c->d_bscores));
+		if ((rc = alloc_t(c, &c->d_bscores, need_s))) return rc;
+		c->bscores_cap = need_s;
+	}
+	if (c->braw_cap < need_s) {
+		if (c->d_braw) VK_HIP(hipFree(c->d_braw));
+		if ((rc = alloc_t(c, &c->d_braw, need_s))) return rc;
+		c->braw_cap = need_s;
+	}
+	const int64_t nw1 = (n + 4095) / 4096;
+	const size_t need_k = (size_t)4 * (size_t)nw1 * (size_t)k;
+	if (c->bkeys_cap < need_k) {
+		for (auto &b : c->d_bkeys) if (b) VK_HIP(hipFree(b));
+		if ((rc = alloc_t(c, &c->d_bkeys[0], need_k))) return rc;
+		if ((rc = alloc_t(c, &c->d_bkeys[1], need_k))) return rc;
+		c->bkeys_cap = need_k;
+	}
+	VK_HIP(hipMemcpyAsync(c->d_ws, ws, sizeof ws, hipMemcpyHostToDevice, st));
+	VK_HIP(hipMemcpyAsync(c->d_wt, wt, sizeof wt, hipMemcpyHostToDevice, st));
+	std::vector<float> boost_rows;
+	if (q0.boost) {
+		if (!c->d_boost) { rc = alloc_t(c, &c->d_boost, (size_t)n + 8); if (rc) return rc; }
+		VK_HIP(hipMemcpyAsync(c->d_boost, q0.boost, (size_t)n * 4, hipMemcpyHostToDevice, st));   // no long slices: rows == slices
+	}
+	p.tiles = c->d_tiles; p.sent_start = c->d_sent_start; p.sent_end = c->d_sent_end; p.n_sent = (int32_t)n;
+	p.nk32 = c->nk32; p.tail = c->tail; p.tile_bytes = c->tile_bytes;
+	p.qtiles = c->d_bq; p.locality = q0.locality; p.ws = c->d_ws; p.wt = c->d_wt;
+	p.boost = q0.boost ? c->d_boost : nullptr; p.scores = c->d_bscores; p.raw = c->d_braw;
+
+	float score_ms_total = 0.0f, total_ms = 0.0f;
+	std::vector<uint8_t> all(need_q), one;
+	float mags[VK_MAX_QUERY_LEN];
+	for (int base = 0; base < n_queries; base += qb_max) {
+		const int qb = std::min(qb_max, n_queries - base);
+		VK_HIP(hipEventRecord(c->ev[0], st));
+		std::fill(all.begin(), all.end(), 0);
+		for (int i = 0; i < qb; i++) {
+			vk_pack_query(c, &qs[base + i], one, mags);
+			memcpy(all.data() + (size_t)i * c->tile_bytes, one.data(), (size_t)c->tile_bytes);
+			p.len_t[i] = qs[base + i].len_t;
+		}
+		for (int i = qb; i < 4; i++) p.len_t[i] = 1;
+		p.n_queries = qb;
+		VK_HIP(hipMemcpyAsync(c->d_bq, all.data(), (size_t)qb * c->tile_bytes, hipMemcpyHostToDevice, st));
+		VK_HIP(hipEventRecord(c->ev[1], st));
+		VK_HIP(vk_launch_score_batch(&p, lt, smem_for(qb), st));
+		VK_HIP(hipEventRecord(c->ev[2], st));
+		int64_t nw = 0;
+		int cur = 0;
+		VK_HIP(vk_launch_topk_wave_batch(c->d_bscores, nullptr, n, q0.min_score, k, 4096, qb, n, nw1 * k, c->d_bkeys[0], &nw, st));
+		const int64_t stride = nw1 * k;
+		while (nw > 1) {
+			const int64_t nkeys = nw * k;
+			const int64_t per_wave = nkeys <= 16384 ? nkeys : 4096;
+			VK_HIP(vk_launch_topk_wave_batch(nullptr, c->d_bkeys[cur], nkeys, 0.0f, k, per_wave, qb, stride, stride, c->d_bkeys[1 - cur], &nw, st));
+			cur = 1 - cur;
+		}
+		VK_HIP(hipEventRecord(c->ev[3], st));
+		const bool do_flow = q0.want_flow && is_align;
+		if (do_flow) {
+			for (int i = 0; i < qb; i++) {
+				VkFlowParams f{};
+				f.tiles = c->d_tiles; f.sent_start = c->d_sent_start; f.sent_end = c->d_sent_end;
+				f.layout = VK_DEV_LAYOUT_CONTEXTUAL; f.nk32 = c->nk32; f.tail = c->tail; f.tile_bytes = c->tile_bytes;
+				f.qtile = c->d_bq + (size_t)i * c->tile_bytes; f.len_t = qs[base + i].len_t; f.locality = q0.locality;
+				f.gap_mode = (p.gap_mode == 3 || p.gap_mode == 6) ? 2 : p.gap_mode; f.max_len = c->max_len;
+				f.gs = p.gs; f.gt = p.gt; f.a_s = p.a_s; f.a_t = p.a_t; f.open_s = p.open_s; f.open_t = p.open_t;
+				f.ws = c->d_ws; f.wt = c->d_wt;
+				f.keys = c->d_bkeys[cur] + (size_t)i * stride;
+				f.raw_out = c->d_out_raw + (size_t)i * k; f.mapping = c->d_out_map + (size_t)i * k * 16; f.edge_sim = c->d_out_sim + (size_t)i * k * 16;
+				VK_HIP(vk_launch_flow(&f, k, st));
+			}
+		}
+		VK_HIP(hipEventRecord(c->ev[4], st));
+		std::vector<uint64_t> keys((size_t)qb * k);
+		std::vector<float> raw((size_t)qb * k), sim((size_t)qb * k * 16);
+		std::vector<int16_t> map((size_t)qb * k * 16);
+		VK_HIP(hipMemcpy2DAsync(keys.data(), (size_t)k * 8, c->d_bkeys[cur], (size_t)stride * 8, (size_t)k * 8, (size_t)qb, hipMemcpyDeviceToHost, st));
+		if (do_flow) {
+			VK_HIP(hipMemcpyAsync(raw.data(), c->d_out_raw, raw.size() * 4, hipMemcpyDeviceToHost, st));
+			VK_HIP(hipMemcpyAsync(map.data(), c->d_out_map, map.size() * 2, hipMemcpyDeviceToHost, st));
+			VK_HIP(hipMemcpyAsync(sim.data(), c->d_out_sim, sim.size() * 4, hipMemcpyDeviceToHost, st));
+		}
+		VK_HIP(hipStreamSynchronize(st));
+		for (int i = 0; i < qb; i++) {
+			const vk_query_desc &q = qs[base + i];
+			vk_topk_out *out = &outs[base + i];
+			int n_out = 0;
+			for (int j = 0; j < k; j++) {
+				const uint64_t key = keys[(size_t)i * k + j];
+				if (key == 0) break;
+				const uint32_t ob = (uint32_t)(key >> 32);
+				const uint32_t bits = (ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob;
+				float sc;
+				memcpy(&sc, &bits, 4);
+				const int64_t g = (int64_t)(uint32_t)(key & 0xffffffffu);
+				out->score[j] = sc;
+				out->sentence[j] = g;
+				if (out->raw_score) {
+					if (do_flow) out->raw_score[j] = raw[(size_t)i * k + j];
+					else VK_HIP(hipMemcpy(&out->raw_score[j], c->d_braw + (size_t)i * n + g, 4, hipMemcpyDeviceToHost));
+				}
+				if (q.want_flow && out->mapping && out->edge_sim)
+					for (int t = 0; t < q.len_t; t++) {
+						out->mapping[(size_t)j * q.len_t + t] = do_flow ? map[((size_t)i * k + j) * 16 + t] : (int16_t)-1;
+						out->edge_sim[(size_t)j * q.len_t + t] = do_flow ? sim[((size_t)i * k + j) * 16 + t] : 0.0f;
+					}
+				n_out++;
+			}
+			out->n_out = n_out;
+		}
+		float ms = 0;
+		if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) score_ms_total += ms;
+		if (hipEventElapsedTime(&ms, c->ev[0], c->ev[4]) == hipSuccess) total_ms += ms;
+	}
+	c->have_scores = false;
+	vk_timings t{};
+	t.score_ms = score_ms_total; t.total_ms = total_ms;
+	c->last = t;
+	return VK_OK;
+}
+
+extern "C" {
+
+int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, vk_topk_out *outs) {
+	if (!c || !qs || !outs || n_queries < 0) return fail(VK_ERR_INVALID, "null argument");
+	if (n_queries == 0) return VK_OK;
+	// the GEMM path: injective RWMD, contextual layout, one sentence length (multiple of 16), common options
+	bool gemm = c->finalized && c->prec == 0 && c->contiguous && c->desc.layout == VK_LAYOUT_CONTEXTUAL && c->uniform_len > 0 && c->uniform_len % 16 == 0 &&
+		c->uniform_len <= 64 && c->desc.n_sentences > 0 && qs[0].max_matches <= 64 &&
+		((c->nk32 == 10 && c->tail == 1) || (c->nk32 == 4 && c->tail == 0));
+	for (int i = 0; i < n_queries && gemm; i++) {
+		const vk_query_desc &q = qs[i];
+		gemm = q.len_t <= VK_FAST_QUERY_LEN && q.algorithm == VK_ALG_RWMD && q.rwmd_injective && !q.wmd_full && q.rwmd_symmetric == qs[0].rwmd_symmetric &&
+			q.rwmd_normalize_bow == qs[0].rwmd_normalize_bow && q.max_matches == qs[0].max_matches &&
+			q.min_score == qs[0].min_score && q.boost == qs[0].boost && !q.tag_weights;
+	}
+	if (!gemm) {
+		const int rcb = query_batch_shared_pass(c, qs, n_queries, outs);
+		if (rcb != VK_ERR_UNSUPPORTED) return rcb;
+		for (int i = 0; i < n_queries; i++) {
+			const int rc = vk_query(c, &qs[i], &outs[i]);
+			if (rc) return rc;
+		}
+		return VK_OK;
+	}
+	for (int i = 0; i < n_queries; i++) {
+		const int rc = vk_validate_query(c, &qs[i], &outs[i]);
+		if (rc) return rc;
+	}
+	VK_HIP(hipSetDevice(c->device));
+	hipStream_t st = c->stream;
+	const int64_t n = c->desc.n_sentences;
+	const int k = qs[0].max_matches;
+	int rc;
+
+	// 32-token sentences take the 32x32x16 kernel: 3 queries of <= 10 tokens (else 2 of <= 16) share one 32-row A tile
+	const bool b32 = c->uniform_len == 32;
+	int qpt = 3;
+	for (int i = 0; i < n_queries; i++) if (qs[i].len_t > 10) qpt = 2;
+	const int nk16 = c->d_pad / 16;
+	const int n_qtiles = (n_queries + qpt - 1) / qpt;
+
+	// ---- device buffers (kept for the next batch)
+	// (+1: the kernel prefetches one tile past the last)
+	const size_t need_q = std::max((size_t)n_queries * c->tile_bytes, b32 ? (size_t)(n_qtiles + 1) * nk16 * 1024 : (size_t)0);
+	if (c->bq_cap < need_q) {
+		if (c->d_bq) { VK_HIP(hipFree(c->d_bq)); VK_HIP(hipFree(c->d_bqlen)); }
+		if ((rc = alloc_t(c, &c->d_bq, need_q))) return rc;
+		if ((rc = alloc_t(c, &c->d_bqlen, 2 * ((size_t)n_queries + 4)))) return rc;   // lengths, then their reciprocals
+		c->bq_cap = need_q;
+	}
+	const size_t need_s = (size_t)n_queries * (size_t)n;
+	if (c->bscores_cap < need_s) {
+		if (c->d_bscores) VK_HIP(hipFree(c->d_bscores));
+		if ((rc = alloc_t(c, &c->d_bscores, need_s))) return rc;
+		c->bscores_cap = need_s;
+	}
+	const int64_t nw1 = (n + 4095) / 4096;
+	const size_t need_k = (size_t)n_queries * (size_t)nw1 * (size_t)k;
+	if (c->bkeys_cap < need_k) {
+		for (auto &b : c->d_bkeys) if (b) VK_HIP(hipFree(b));
+		if ((rc = alloc_t(c, &c->d_bkeys[0], need_k))) return rc;
+		if ((rc = alloc_t(c, &c->d_bkeys[1], need_k))) return rc;
+		c->bkeys_cap = need_k;
+	}
+
+	VK_HIP(hipEventRecord(c->ev[0], st));
+	std::vector<uint8_t> all((size_t)need_q, 0), one;
+	std::vector<int32_t> qlen((size_t)n_queries);
+	float mags[VK_MAX_QUERY_LEN];
+	for (int i = 0; i < n_queries; i++) {
+		vk_pack_query(c, &qs[i], one, mags);
+		qlen[(size_t)i] = qs[i].len_t;
+		if (!b32) {
+			memcpy(all.data() + (size_t)i * c->tile_bytes, one.data(), one.size());
+			continue;
+		}
+		// A tile of v_mfma_f32_32x32x16_bf16: K-step t = 1 KiB, lane l = 32 (k >> 3 & 1) + M owns row M, 8 features.
+		// Row M of the result lands in accumulator register acc = 4 (M >> 3) + (M & 3) of lane half hd = M >> 2 & 1;
+		// the kernel (vk_rwmd_batch32_kernel) expects query tokens at (hd, acc) as laid out below.
+		uint8_t *dst = all.data() + (size_t)(i / qpt) * nk16 * 1024;
+		const int slot = i % qpt;
+		for (int j = 0; j < qs[i].len_t; j++) {
+			int hd, acc;
+			if (qpt == 2) { hd = slot; acc = j; }
+			else if (slot < 2) { hd = slot; acc = j; }
+			else { hd = j / 5; acc = 10 + j % 5; }
+			const int M = 8 * (acc >> 2) + 4 * hd + (acc & 3);
+			for (int k = 0; k < c->d_pad; k += 8) {   // 8 features = one 16-byte piece in both layouts
+				const size_t src = (size_t)(k >> 5) * 1024 + (size_t)(((k & 31) >> 3) * 16 + j) * 16;
+				const size_t off = (size_t)(k >> 4) * 1024 + (size_t)(((k >> 3) & 1) * 32 + M) * 16;
+				memcpy(dst + off, one.data() + src, 16);
+			}
+		}
+	}
+	VK_HIP(hipMemcpyAsync(c->d_bq, all.data(), all.size(), hipMemcpyHostToDevice, st));
+	VK_HIP(hipMemcpyAsync(c->d_bqlen, qlen.data(), qlen.size() * 4, hipMemcpyHostToDevice, st));
+	std::vector<float> qinv((size_t)n_queries);
+	for (int i = 0; i < n_queries; i++) qinv[(size_t)i] = 1.0f / (float)qs[i].len_t;
+	float *d_qinv = reinterpret_cast<float *>(c->d_bqlen + n_queries + 4);
+	VK_HIP(hipMemcpyAsync(d_qinv, qinv.data(), qinv.size() * 4, hipMemcpyHostToDevice, st));
+	if (qs[0].boost) {
+		if (!c->d_boost) { rc = alloc_t(c, &c->d_boost, (size_t)n + 8); if (rc) return rc; }
+		VK_HIP(hipMemcpyAsync(c->d_boost, qs[0].boost, (size_t)n * 4, hipMemcpyHostToDevice, st));
+	}
+
+	VK_HIP(hipEventRecord(c->ev[1], st));
+	VkRwmdBatchParams p{};
+	p.tiles = c->d_tiles; p.n_tiles = (c->desc.n_tokens + 15) / 16;
+	p.tile_bytes = c->tile_bytes; p.nk = c->nk32; p.half = c->tail;
+	p.qtiles = c->d_bq; p.q_len = c->d_bqlen; p.n_queries = n_queries; p.n_sent = (int32_t)n;
+	p.tiles_per_sent = c->uniform_len / 16;
+	p.symmetric = qs[0].rwmd_symmetric; p.nbow = qs[0].rwmd_normalize_bow;
+	p.boost = qs[0].boost ? c->d_boost : nullptr;
+	p.scores = c->d_bscores;
+	p.n_qtiles = n_qtiles; p.qpt = qpt; p.q_inv_len = d_qinv;
+	p.late_mask = 4;   // waves w and w + 4 of a workgroup share a SIMD
+	if (const char *e = getenv("VK_BATCH32_LATE_MASK")) p.late_mask = atoi(e);   // tuning aid
+	if (b32) VK_HIP(vk_launch_rwmd_batch32(&p, st));
+	else VK_HIP(vk_launch_rwmd_batch(&p, st));
+
+	VK_HIP(hipEventRecord(c->ev[2], st));
+	int64_t nw = 0;
+	int cur = 0;
+	VK_HIP(vk_launch_topk_wave_batch(c->d_bscores, nullptr, n, qs[0].min_score, k, 4096, n_queries, n, nw1 * k, c->d_bkeys[0], &nw, st));
+	int64_t stride = nw1 * k;
+	while (nw > 1) {
+		const int64_t nkeys = nw * k;
+		const int64_t per_wave = nkeys <= 16384 ? nkeys : 4096;
+		VK_HIP(vk_launch_topk_wave_batch(nullptr, c->d_bkeys[cur], nkeys, 0.0f, k, per_wave, n_queries, stride, stride, c->d_bkeys[1 - cur], &nw, st));
+		cur = 1 - cur;
+	}
+	VK_HIP(hipEventRecord(c->ev[3], st));
+	VK_HIP(hipEventRecord(c->ev[4], st));
+	std::vector<uint64_t> keys((size_t)n_queries * (size_t)k);
+	VK_HIP(hipMemcpy2DAsync(keys.data(), (size_t)k * 8, c->d_bkeys[cur], (size_t)stride * 8, (size_t)k * 8, (size_t)n_queries, hipMemcpyDeviceToHost, st));
+	VK_HIP(hipStreamSynchronize(st));
+	for (int i = 0; i < n_queries; i++) {
+		vk_topk_out *out = &outs[i];
+		int n_out = 0;
+		for (int j = 0; j < k; j++) {
+			const uint64_t key = keys[(size_t)i * k + j];
+			if (key == 0) break;
+			const uint32_t ob = (uint32_t)(key >> 32);
+			const uint32_t bits = (ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob;
+			float s;
+			memcpy(&s, &bits, 4);
+			const int64_t g = (int64_t)(uint32_t)(key & 0xffffffffu);
+			out->score[j] = s;
+			out->sentence[j] = g;
+			if (out->raw_score) out->raw_score[j] = (qs[i].boost ? s / qs[i].boost[g] : s) * (float)qs[i].len_t;
+			if (qs[i].want_flow && out->mapping && out->edge_sim)
+				for (int t = 0; t < qs[i].len_t; t++) {
+					out->mapping[(size_t)j * qs[i].len_t + t] = -1;
+					out->edge_sim[(size_t)j * qs[i].len_t + t] = 0.0f;
+				}
+			n_out++;
+		}
+		out->n_out = n_out;
+	}
+	c->have_scores = false;
+	float ms = 0;
+	vk_timings t{};
+	if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) t.prepare_ms = ms;
+	if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) t.score_ms = ms;
+	if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) t.topk_ms = ms;
+	if (hipEventElapsedTime(&ms, c->ev[0], c->ev[4]) == hipSuccess) t.total_ms = ms;
+	c->last = t;
+	return VK_OK;
+}
+
+} // extern "C"

@@ -417,7 +417,7 @@ __device__ __forceinline__ float dp_general(const float *__restrict__ S, float *
 // w_t is strictly subadditive (w(a) + w(b) > w(a+b) by a margin far above fp32 rounding):
 // two consecutive in-row gaps are then always beaten by the single gap of the summed
 // length, so replacing H[j-k] by c[j-k] drops only dominated candidates.  The host
-// checks the margin (vk_api.cpp) and otherwise selects dp_general.
+// checks the margin (vk_query.cpp) and otherwise selects dp_general.
 template <int LT, int MAXLEN>
 __device__ __forceinline__ float dp_general_reg(const float *__restrict__ S, int rowbase, int len, int maxlen, int v,
 	const DpArgs &a, const float (&wsr)[MAXLEN + 1], const float (&wtr)[LT]) {

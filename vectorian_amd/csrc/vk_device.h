@@ -1,5 +1,5 @@
 // vk_device.h -- structures shared between the kernels (vk_*.hip) and the
-// C-ABI implementation (vk_api.cpp).  Internal; the public interface is
+// C-ABI implementation (vk_corpus.cpp, vk_query.cpp, vk_batch.cpp).  Internal; the public interface is
 // include/vectorian_hip.h.
 #ifndef VK_DEVICE_H
 #define VK_DEVICE_H

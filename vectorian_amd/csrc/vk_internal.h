@@ -1,0 +1,129 @@
+// vk_internal.h -- shared by the host-side units of the C-ABI (vk_corpus.cpp, vk_query.cpp, vk_batch.cpp):
+// error reporting, small conversions, the corpus handle.  Internal; the public interface is include/vectorian_hip.h.
+#ifndef VK_INTERNAL_H
+#define VK_INTERNAL_H
+
+#include "../../include/vectorian_hip.h"
+#include "vk_device.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+std::string &vk_error_slot();   // the calling thread's last error message (vk_corpus.cpp)
+
+namespace {
+
+int fail(int code, const std::string &msg) {
+	vk_error_slot() = msg;
+	return code;
+}
+
+#define VK_HIP(call) \
+	do { \
+		hipError_t e_ = (call); \
+		if (e_ != hipSuccess) { \
+			char buf_[512]; \
+			snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+			return fail(VK_ERR_HIP, buf_); \
+		} \
+	} while (0)
+
+uint16_t f32_to_bf16(float x) {
+	uint32_t u;
+	memcpy(&u, &x, 4);
+	if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
+	u += 0x7fffu + ((u >> 16) & 1u);
+	return (uint16_t)(u >> 16);
+}
+
+float bf16_to_f32(uint16_t b) {
+	uint32_t u = ((uint32_t)b) << 16;
+	float f;
+	memcpy(&f, &u, 4);
+	return f;
+}
+
+float gap_cost(const vk_gap &g, int k) {
+	if (k <= 0) return 0.0f;
+	switch (g.kind) {
+	case VK_GAP_LINEAR: return g.u * (float)k;
+	case VK_GAP_AFFINE: return g.u + g.v * (float)k;
+	default: return (g.table && k < g.n_table) ? g.table[k] : INFINITY;
+	}
+}
+
+constexpr int kTopkChunk = 2048;
+constexpr int kGapTable = 640;   // entries of the gap tables sent to the device (> VK_MAX_SENT_LEN)
+constexpr int64_t kStageBytes = 64ll << 20;
+
+} // namespace
+
+struct vk_corpus {
+	vk_corpus_desc desc{};
+	int device = 0;
+	hipStream_t stream = nullptr;
+	int d_pad = 0, nk32 = 0, tail = 0, tile_bytes = 0;
+	int prec = 0;                // vk_precision: 1 = fp32 tiles (nk32 then counts blocks of 16 features, tail = 0)
+	int64_t rows_total = 0, rows_appended = 0, n_tiles = 0;
+	uint8_t *d_tiles = nullptr;
+	float *d_mag = nullptr;
+	int32_t *d_tok_id = nullptr;
+	int8_t *d_pos = nullptr;   // POS code per token (tag-weighted queries)
+	int32_t *d_sent_start = nullptr, *d_sent_end = nullptr;
+	bool contiguous = false;   // slices are the CSR partition of the token stream
+	bool have_ids = false, have_sent = false, finalized = false;
+	int max_len = 0, max_group_tiles = 0, max_group_tokens = 0;
+	// slice table on the device: n_entries >= n_sentences rows.  Slices longer than VK_FAST_SENT_LEN sit alone in
+	// their group of 4 (padded with empty rows) and are scored by a second launch over d_long_groups.
+	int64_t n_entries = 0;
+	std::vector<int32_t> entry_sent;   // [n_entries] sentence of a row, -1 = padding; empty when the table is the identity
+	int32_t *d_long_groups = nullptr;
+	int n_long_groups = 0, max_short_len = 0, long_group_tiles = 0, long_group_tokens = 0;
+	int uniform_len = 0;       // > 0: every sentence has exactly this many tokens
+	uint8_t *d_bq = nullptr; int32_t *d_bqlen = nullptr; float *d_bscores = nullptr; uint64_t *d_bkeys[2] = {nullptr, nullptr};
+	float *d_braw = nullptr; size_t braw_cap = 0;   // aligner scores of a batch of alignment queries
+	size_t bq_cap = 0, bscores_cap = 0, bkeys_cap = 0;
+	int64_t device_bytes = 0;
+	// workspaces
+	void *d_stage = nullptr;
+	uint8_t *d_qtile = nullptr;
+	float *d_ws = nullptr, *d_wt = nullptr;
+	int32_t *d_qids = nullptr;
+	float *d_table = nullptr;
+	float *d_scores = nullptr, *d_raw = nullptr, *d_boost = nullptr;
+	uint64_t *d_keys[2] = {nullptr, nullptr};
+	float *d_out_raw = nullptr, *d_out_sim = nullptr;
+	float *d_wrd_raw = nullptr, *d_wrd_val = nullptr;
+	uint32_t *d_counter = nullptr;
+	float *d_rows_out = nullptr, *d_plan_out = nullptr;   // transport flows of the winners
+	size_t wrd_cap = 0;          // candidates d_wrd_raw / d_wrd_val (and d_keys[0]) can hold
+	int16_t *d_out_map = nullptr;
+	hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+	vk_timings last{};
+	bool have_scores = false;
+	bool is_view = false;        // shares the corpus arrays of another handle (vk_corpus_view): does not free them
+	vk_corpus *peer = nullptr;   // ring of the handles on one corpus: a handle's scoring kernel starts after its peer's
+	bool ev2_recorded = false;   // (device-side wait on ev[2]), so that scoring kernels run back to back, never queued inside each other
+};
+
+namespace {
+
+int alloc(vk_corpus *c, void **p, size_t bytes) {
+	VK_HIP(hipMalloc(p, bytes ? bytes : 16));
+	c->device_bytes += (int64_t)bytes;
+	return VK_OK;
+}
+
+template <typename T> int alloc_t(vk_corpus *c, T **p, size_t n) { return alloc(c, (void **)p, n * sizeof(T)); }
+
+} // namespace
+
+// units
+int vk_validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_topk_out *out);
+void vk_pack_query(const vk_corpus *c, const vk_query_desc *q, std::vector<uint8_t> &tile, float *mags);
+
+#endif

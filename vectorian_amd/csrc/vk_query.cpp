@@ -1,0 +1,673 @@
+// vk_query.cpp -- C-ABI: one query against a resident corpus (validation, launches, result assembly) and the
+// merge of result sets.
+// No CPU compute fallback exists: without a HIP device every entry point that
+// would compute returns VK_ERR_NO_DEVICE / VK_ERR_HIP.
+
+#include "vk_internal.h"
+
+int vk_validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_topk_out *out) {
+	if (!c || !q || !out) return fail(VK_ERR_INVALID, "null argument");
+	if (!c->finalized) return fail(VK_ERR_STATE, "corpus not finalized");
+	if (q->len_t < 1) return fail(VK_ERR_INVALID, "empty query");
+	if (q->len_t > VK_MAX_QUERY_LEN) return fail(VK_ERR_UNSUPPORTED, "query longer than VK_MAX_QUERY_LEN (64) tokens");
+	if (q->len_t > VK_FAST_QUERY_LEN) {
+		if (q->algorithm == VK_ALG_WRD || (q->algorithm == VK_ALG_RWMD && q->wmd_full))
+			return fail(VK_ERR_UNSUPPORTED, "exact transport (WRD, full WMD) is implemented for queries of at most 16 tokens");
+		const int gm = q->algorithm == VK_ALG_RWMD ? 4 : (q->gap_s.kind == VK_GAP_TABLE || q->gap_t.kind == VK_GAP_TABLE) ? 2 : 1;
+		if (vk_wide_lds_demand(c->max_len, (q->len_t + 15) / 16, gm, q->tag_weights != nullptr, q->want_flow) > 160 * 1024)
+			return fail(VK_ERR_UNSUPPORTED, "query of more than 16 tokens over slices this long exceeds the LDS of a workgroup");
+	}
+	if (!q->q_vectors) return fail(VK_ERR_INVALID, "q_vectors is null");
+	if (q->q_dtype != VK_F32 && q->q_dtype != VK_BF16) return fail(VK_ERR_INVALID, "bad q_dtype");
+	if (q->max_matches < 1 || q->max_matches > VK_MAX_MATCHES) return fail(VK_ERR_INVALID, "max_matches out of range");
+	if (out->capacity < q->max_matches) return fail(VK_ERR_INVALID, "output capacity smaller than max_matches");
+	if (!out->score || !out->sentence) return fail(VK_ERR_INVALID, "output arrays missing");
+	if (!(q->submatch_weight >= 0.0f)) return fail(VK_ERR_INVALID, "submatch_weight must be >= 0 (pow of a zero base, metric/alignment.h:97-99)");
+	if (q->bidirectional) return fail(VK_ERR_UNSUPPORTED, "bidirectional is not implemented (unused upstream, query.cpp:81-83)");
+	if (q->algorithm == VK_ALG_ALIGN) {
+		if (q->locality < VK_LOCAL || q->locality > VK_SEMIGLOBAL) return fail(VK_ERR_INVALID, "bad locality");
+		for (const vk_gap *g : {&q->gap_s, &q->gap_t}) {
+			if (g->kind < VK_GAP_LINEAR || g->kind > VK_GAP_TABLE) return fail(VK_ERR_INVALID, "bad gap kind");
+			if (g->kind == VK_GAP_TABLE && (!g->table || g->n_table < 1)) return fail(VK_ERR_INVALID, "gap table missing");
+		}
+		if (q->gap_s.kind == VK_GAP_TABLE && q->gap_s.n_table <= c->max_len) return fail(VK_ERR_INVALID, "gap_s table shorter than the longest sentence");
+		if (q->gap_t.kind == VK_GAP_TABLE && q->gap_t.n_table <= q->len_t) return fail(VK_ERR_INVALID, "gap_t table shorter than the query");
+		if (q->want_flow && (!out->mapping || !out->edge_sim)) return fail(VK_ERR_INVALID, "want_flow needs mapping and edge_sim arrays");
+		if (q->tag_weights) {
+			if (!q->q_pos) return fail(VK_ERR_INVALID, "tag-weighted query without q_pos");
+			if (!c->d_pos) return fail(VK_ERR_STATE, "tag-weighted query needs vk_corpus_set_token_pos");
+			if (q->similarity_threshold < 0.0f) return fail(VK_ERR_INVALID, "similarity_threshold must be >= 0 (slice/static.h:209)");
+		}
+	} else if (q->algorithm == VK_ALG_RWMD) {
+		if (q->tag_weights) return fail(VK_ERR_UNSUPPORTED, "tag-weighted similarity is implemented for alignments only");
+		if (q->rwmd_symmetric && !q->rwmd_normalize_bow)
+			return fail(VK_ERR_INVALID, "cannot run symmetric mode WMD with bow (needs nbow)");   // wmd.h:441-449
+		if (q->wmd_full) {
+			if (c->max_len > VK_FAST_SENT_LEN) return fail(VK_ERR_UNSUPPORTED, "full WMD needs every slice <= VK_FAST_SENT_LEN (64) tokens");
+			if (q->rwmd_injective) return fail(VK_ERR_INVALID, "non-relaxed WMD with injective mapping is not supported");      // wmd.h:201-204
+			if (q->rwmd_symmetric) return fail(VK_ERR_INVALID, "non-relaxed WMD with symmetric computation is not supported");  // wmd.h:206-209
+		} else if (!q->rwmd_injective && q->len_t > VK_FAST_QUERY_LEN)
+			return fail(VK_ERR_UNSUPPORTED, "non-injective RWMD (rwmd('nbow/distributed')) is implemented for queries of at most 16 tokens");
+		if (q->want_flow && (!out->mapping || !out->edge_sim)) return fail(VK_ERR_INVALID, "want_flow needs mapping and edge_sim arrays");
+	} else if (q->algorithm == VK_ALG_WRD) {
+		if (c->max_len > VK_FAST_SENT_LEN) return fail(VK_ERR_UNSUPPORTED, "VK_ALG_WRD needs every slice <= VK_FAST_SENT_LEN (64) tokens");
+		if (q->tag_weights) return fail(VK_ERR_UNSUPPORTED, "tag-weighted similarity is implemented for alignments only");
+		if (!c->d_mag) return fail(VK_ERR_STATE, "VK_ALG_WRD needs a corpus created with keep_magnitudes = 1");
+		if (q->want_flow && (!out->mapping || !out->edge_sim)) return fail(VK_ERR_INVALID, "want_flow needs mapping and edge_sim arrays");
+	} else {
+		return fail(VK_ERR_INVALID, "bad algorithm");
+	}
+	return VK_OK;
+}
+
+// Vectors.normalized for the query rows, then bf16 (RNE), then tile order (16 rows,
+// rows >= len_t zero).  Same arithmetic as oracle/vk_oracle.c vko_normalize_rows_bf16.
+void vk_pack_query(const vk_corpus *c, const vk_query_desc *q, std::vector<uint8_t> &tile, float *mags) {
+	const int d = c->desc.d;
+	tile.assign((size_t)c->tile_bytes * (size_t)((q->len_t + 15) / 16), 0);   // tile i / 16 holds row i % 16
+	std::vector<float> row((size_t)d);
+	for (int i = 0; i < q->len_t; i++) {
+		for (int k = 0; k < d; k++)
+			row[(size_t)k] = q->q_dtype == VK_F32 ? ((const float *)q->q_vectors)[(size_t)i * d + k]
+			                                       : bf16_to_f32(((const uint16_t *)q->q_vectors)[(size_t)i * d + k]);
+		double acc = 0.0;
+		for (int k = 0; k < d; k++) acc += (double)row[(size_t)k] * (double)row[(size_t)k];
+		float m = (float)std::sqrt(acc);
+		if (m != m) m = 0.0f;
+		mags[i] = m;
+		if (q->q_normalize) {
+			for (int k = 0; k < d; k++) {
+				float v = row[(size_t)k] / m;
+				if (v != v) v = 0.0f;
+				row[(size_t)k] = v;
+			}
+		}
+		for (int k = 0; k < d; k++) {
+			if (c->prec) {   // fp32 tile: block k >> 4, lane 16 (k & 3) + row, element (k & 15) >> 2
+				const size_t off = (size_t)(i >> 4) * c->tile_bytes + (size_t)(k >> 4) * 1024 + (size_t)((k & 3) * 16 + (i & 15)) * 16 + (size_t)((k & 15) >> 2) * 4;
+				memcpy(&tile[off], &row[(size_t)k], 4);
+				continue;
+			}
+			const uint16_t b = f32_to_bf16(row[(size_t)k]);
+			const int t = k >> 5, g = (k & 31) >> 3, j = k & 7;
+			const size_t off = (size_t)(i >> 4) * c->tile_bytes + (size_t)t * 1024 + (size_t)(g * 16 + (i & 15)) * 16 + (size_t)j * 2;
+			memcpy(&tile[off], &b, 2);
+		}
+	}
+}
+
+extern "C" {
+
+int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
+	int rc = vk_validate_query(c, q, out);
+	if (rc) return rc;
+	VK_HIP(hipSetDevice(c->device));
+	hipStream_t st = c->stream;
+	const int64_t n = c->n_entries;           // rows of the slice table (== n_sentences unless long slices were padded)
+	const int k = q->max_matches;
+	out->n_out = 0;
+	c->have_scores = false;
+	if (n == 0) return VK_OK;
+	auto sentence_of = [c](int64_t row) { return c->entry_sent.empty() ? row : (int64_t)c->entry_sent[(size_t)row]; };
+	const bool is_static_l = c->desc.layout == VK_LAYOUT_STATIC;
+	// transport algorithms: similarity rows (and, for exact transport, the optimal plan) of the winners, from which
+	// the host states their SparseFlow / DenseFlow.  rows_idx: rows of the slice table, best first.
+	auto transport_flows = [&](const std::vector<int64_t> &rows_idx, bool exact, const float *qmass, int mass_mode, int raw_masses) -> int {
+		if (!q->want_flow || !out->sim_rows || rows_idx.empty()) return VK_OK;
+		if (c->max_len > VK_FAST_SENT_LEN || q->len_t > VK_FAST_QUERY_LEN) return VK_OK;
+		int rc2;
+		if (!c->d_rows_out) {
+			if ((rc2 = alloc_t(c, &c->d_rows_out, (size_t)VK_MAX_MATCHES * 64 * 16))) return rc2;
+			if ((rc2 = alloc_t(c, &c->d_plan_out, (size_t)VK_MAX_MATCHES * 16 * 64))) return rc2;
+		}
+		if (!c->d_wrd_raw) {
+			if ((rc2 = alloc_t(c, &c->d_wrd_raw, (size_t)VK_MAX_MATCHES))) return rc2;
+			if ((rc2 = alloc_t(c, &c->d_wrd_val, (size_t)VK_MAX_MATCHES))) return rc2;
+			c->wrd_cap = VK_MAX_MATCHES;
+		}
+		const int cnt = (int)rows_idx.size();
+		std::vector<uint64_t> hk((size_t)cnt);
+		for (int i = 0; i < cnt; i++) hk[(size_t)i] = (1ull << 32) | (uint64_t)(uint32_t)rows_idx[(size_t)i];
+		VK_HIP(hipMemcpyAsync(c->d_keys[1], hk.data(), hk.size() * 8, hipMemcpyHostToDevice, c->stream));
+		VkWrdParams w{};
+		w.tiles = c->d_tiles; w.tok_id = c->d_tok_id; w.table = c->d_table; w.sent_start = c->d_sent_start; w.sent_end = c->d_sent_end;
+		w.layout = is_static_l ? VK_DEV_LAYOUT_STATIC : VK_DEV_LAYOUT_CONTEXTUAL; w.nk32 = c->nk32; w.tail = c->tail; w.tile_bytes = c->tile_bytes; w.prec = c->prec;
+		w.qtile = c->d_qtile; w.len_t = q->len_t; w.mag = c->d_mag;
+		w.keys = c->d_keys[1]; w.rows_out = c->d_rows_out;
+		VK_HIP(vk_launch_rows(&w, cnt, c->stream));
+		VK_HIP(hipMemcpyAsync(out->sim_rows, c->d_rows_out, (size_t)cnt * 64 * 16 * 4, hipMemcpyDeviceToHost, c->stream));
+		if (exact && out->plan) {
+			w.mass_mode = mass_mode; w.raw_masses = raw_masses;
+			memcpy(w.qmass, qmass, sizeof w.qmass);
+			w.raw_out = c->d_wrd_raw; w.val_out = c->d_wrd_val; w.plan_out = c->d_plan_out;
+			VK_HIP(vk_launch_wrd_exact(&w, cnt, nullptr, c->stream));
+			VK_HIP(hipMemcpyAsync(out->plan, c->d_plan_out, (size_t)cnt * 16 * 64 * 4, hipMemcpyDeviceToHost, c->stream));
+		}
+		VK_HIP(hipStreamSynchronize(c->stream));
+		return VK_OK;
+	};
+
+	// ---- prepare: query tile, gap tables, boost, static table -------------
+	VK_HIP(hipEventRecord(c->ev[0], st));
+	std::vector<uint8_t> qtile;
+	float qmags[VK_MAX_QUERY_LEN] = {0};
+	const bool wide = q->len_t > VK_FAST_QUERY_LEN;
+	const int nq = (q->len_t + 15) / 16;
+	vk_pack_query(c, q, qtile, qmags);
+	VK_HIP(hipMemcpyAsync(c->d_qtile, qtile.data(), qtile.size(), hipMemcpyHostToDevice, st));
+
+	VkScoreParams p{};
+	const int ks = q->gap_s.kind, kt = q->gap_t.kind;
+	float ws[kGapTable], wt[80];
+	const bool is_align = q->algorithm == VK_ALG_ALIGN;
+	if (q->algorithm == VK_ALG_WRD) {
+		p.gap_mode = 5;
+		float sum_t = 0.0f;
+		for (int j = 0; j < q->len_t; j++) sum_t += qmags[j];           // wrd.h:99-102, float sum in order
+		const bool rawm = !q->wrd_normalize_magnitudes;   // wrd.h:99-102: masses stay the magnitudes
+		for (int j = 0; j < VK_FAST_QUERY_LEN; j++) p.qmass[j] = j < q->len_t ? (rawm ? qmags[j] : qmags[j] / sum_t) : 0.0f;
+		p.wrd_raw_total = rawm ? sum_t : 0.0f;
+		p.mag = c->d_mag;
+	} else if (q->algorithm == VK_ALG_RWMD) {
+		p.gap_mode = 4;
+		p.rwmd_symmetric = q->rwmd_symmetric;
+		p.rwmd_normalize_bow = q->rwmd_normalize_bow;
+		if (q->wmd_full) p.wmd_bound = q->rwmd_normalize_bow ? 1 : 2;
+		else if (!q->rwmd_injective) {
+			// 1:n form: masses of the query's vocabulary entries (count / len at the first occurrence of a token id)
+			p.gap_mode = 7;
+			const bool ids = c->desc.layout == VK_LAYOUT_STATIC && q->q_token_ids;
+			for (int j = 0; j < VK_FAST_QUERY_LEN; j++) {
+				float mass = 0.0f;
+				if (j < q->len_t) {
+					int cnt = 1;
+					bool first = true;
+					if (ids && q->q_token_ids[j] >= 0)
+						for (int i = 0; i < q->len_t; i++)
+							if (i != j && q->q_token_ids[i] == q->q_token_ids[j]) { cnt++; if (i < j) first = false; }
+					mass = first ? (q->rwmd_normalize_bow ? (float)cnt / (float)q->len_t : (float)cnt) : 0.0f;
+				}
+				p.qmass[j] = mass;
+			}
+		}
+	} else if (ks == VK_GAP_LINEAR && kt == VK_GAP_LINEAR) {
+		p.gap_mode = 0;
+		p.gs = q->gap_s.u; p.gt = q->gap_t.u;
+	} else if ((ks == VK_GAP_LINEAR || ks == VK_GAP_AFFINE) && (kt == VK_GAP_LINEAR || kt == VK_GAP_AFFINE)) {
+		p.gap_mode = 1;
+		p.a_s = ks == VK_GAP_AFFINE ? q->gap_s.u : 0.0f;
+		p.gs = ks == VK_GAP_AFFINE ? q->gap_s.v : q->gap_s.u;
+		p.a_t = kt == VK_GAP_AFFINE ? q->gap_t.u : 0.0f;
+		p.gt = kt == VK_GAP_AFFINE ? q->gap_t.v : q->gap_t.u;
+		p.open_s = p.a_s + p.gs;
+		p.open_t = p.a_t + p.gt;
+	} else {
+		p.gap_mode = 2;
+	}
+	for (int i = 0; i < kGapTable; i++) ws[i] = (is_align && i <= c->max_len) ? gap_cost(q->gap_s, i) : 0.0f;
+	for (int i = 0; i < 80; i++) wt[i] = (is_align && i <= q->len_t) ? gap_cost(q->gap_t, i) : 0.0f;
+	if (p.gap_mode == 2) {
+		// register-history kernel: needs w_t strictly subadditive over the query length
+		// (see dp_general_reg in vk_common.cuh); margin far above fp32 rounding of the DP values
+		bool sub = true;
+		for (int x = 1; x < q->len_t && sub; x++)
+			for (int y = 1; x + y <= q->len_t; y++)
+				if (!(wt[x] + wt[y] > wt[x + y] + 1e-4f)) { sub = false; break; }
+		if (sub && !wide) p.gap_mode = c->max_short_len <= 32 ? 3 : 6;
+	}
+	VK_HIP(hipMemcpyAsync(c->d_ws, ws, sizeof ws, hipMemcpyHostToDevice, st));
+	VK_HIP(hipMemcpyAsync(c->d_wt, wt, sizeof wt, hipMemcpyHostToDevice, st));
+
+	std::vector<float> boost_rows;
+	if (q->boost) {
+		if (!c->d_boost) { rc = alloc_t(c, &c->d_boost, (size_t)n + 8); if (rc) return rc; }
+		const float *src = q->boost;
+		if (!c->entry_sent.empty()) {
+			boost_rows.resize((size_t)n);
+			for (int64_t e = 0; e < n; e++) boost_rows[(size_t)e] = c->entry_sent[(size_t)e] >= 0 ? q->boost[c->entry_sent[(size_t)e]] : 1.0f;
+			src = boost_rows.data();
+		}
+		VK_HIP(hipMemcpyAsync(c->d_boost, src, (size_t)n * 4, hipMemcpyHostToDevice, st));
+	}
+
+	const bool is_static = c->desc.layout == VK_LAYOUT_STATIC;
+	const int64_t table_stride = (int64_t)c->n_tiles * 16 * 16;
+	if (is_static) {
+		int32_t ids[80];
+		for (int j = 0; j < 80; j++) ids[j] = (q->q_token_ids && j < q->len_t) ? q->q_token_ids[j] : -1;
+		VK_HIP(hipMemcpyAsync(c->d_qids, ids, sizeof ids, hipMemcpyHostToDevice, st));
+		for (int t = 0; t < nq; t++)   // one [V_pad x 16] table per 16 query tokens
+			VK_HIP(vk_launch_table(c->d_tiles, c->d_qtile + (size_t)t * c->tile_bytes, (int32_t)c->n_tiles, c->nk32, c->tail, c->tile_bytes,
+				c->d_table + t * table_stride, q->q_token_ids ? c->d_qids + t * 16 : nullptr, std::min(16, q->len_t - t * 16), c->desc.vocab_size, c->prec, st));
+	}
+
+	// ---- the fused scoring kernel ------------------------------------------
+	// handles on one corpus take turns: this scoring kernel starts when the peer's has finished (its selection and
+	// traceback then run beside this kernel); the wait is on the device, the host does not block
+	if (c->peer && c->peer->ev2_recorded) VK_HIP(hipStreamWaitEvent(st, c->peer->ev[2], 0));
+	VK_HIP(hipEventRecord(c->ev[1], st));
+	p.tiles = c->d_tiles; p.tok_id = c->d_tok_id; p.table = c->d_table; p.sent_start = c->d_sent_start; p.sent_end = c->d_sent_end;
+	p.n_sent = (int32_t)n; p.layout = is_static ? VK_DEV_LAYOUT_STATIC : VK_DEV_LAYOUT_CONTEXTUAL;
+	p.nk32 = c->nk32; p.tail = c->tail; p.tile_bytes = c->tile_bytes; p.prec = c->prec;
+	p.qtile = c->d_qtile; p.len_t = q->len_t; p.locality = q->locality;
+	p.ws = c->d_ws; p.wt = c->d_wt;
+	p.boost = q->boost ? c->d_boost : nullptr;
+	p.scores = c->d_scores; p.raw = c->d_raw;
+	p.ref_total = (float)q->len_t;
+	if (q->tag_weights && is_align) {
+		float total = 0.0f;
+		for (int j = 0; j < q->len_t; j++) total += q->tag_weights[j];
+		for (int j = 0; j < VK_FAST_QUERY_LEN; j++) {
+			p.tw[j] = j < q->len_t ? q->tag_weights[j] : 0.0f;
+			p.tpos[j] = j < q->len_t ? (int32_t)q->q_pos[j] : -1;
+		}
+		p.pos_s = c->d_pos;
+		p.tw_keep = 1.0f - q->pos_mismatch_penalty;
+		p.tw_threshold = q->similarity_threshold;
+		p.ref_total = total;   // reference_score with max_similarity_for_t = t_pos_weights (slice/static.h:280-286)
+	}
+	VkWideParams wp{};
+	if (wide) {
+		wp.tiles = c->d_tiles; wp.tok_id = c->d_tok_id; wp.table = c->d_table; wp.table_stride = table_stride;
+		wp.sent_start = c->d_sent_start; wp.sent_end = c->d_sent_end; wp.n_sent = (int32_t)n; wp.layout = p.layout;
+		wp.nk32 = c->nk32; wp.tail = c->tail; wp.tile_bytes = c->tile_bytes; wp.prec = c->prec;
+		wp.qtile = c->d_qtile; wp.nq = nq; wp.len_t = q->len_t; wp.locality = q->locality; wp.gap_mode = p.gap_mode; wp.max_len = c->max_len;
+		wp.rwmd_symmetric = p.rwmd_symmetric; wp.rwmd_normalize_bow = p.rwmd_normalize_bow;
+		wp.gs = p.gs; wp.gt = p.gt; wp.a_s = p.a_s; wp.a_t = p.a_t; wp.open_s = p.open_s; wp.open_t = p.open_t;
+		wp.ws = c->d_ws; wp.wt = c->d_wt;
+		wp.pos_s = p.pos_s; wp.tw_keep = p.tw_keep; wp.tw_threshold = p.tw_threshold; wp.ref_total = p.ref_total;
+		for (int j = 0; j < VK_MAX_QUERY_LEN; j++) {
+			wp.tw[j] = (p.pos_s && j < q->len_t) ? q->tag_weights[j] : 0.0f;
+			wp.tpos[j] = (p.pos_s && j < q->len_t) ? (int32_t)q->q_pos[j] : -1;
+		}
+		wp.boost = p.boost; wp.scores = c->d_scores; wp.raw = c->d_raw;
+		VK_HIP(vk_launch_wide(&wp, 0, st));
+	} else if (is_align && !is_static && q->len_t == 1 && c->uniform_len == 1 && q->locality == VK_LOCAL && !p.pos_s) {
+		// span-embedding index: one vector per slice, one query vector -> the clipped cosine is the local alignment score
+		VK_HIP(vk_launch_span(&p, st));
+	} else {
+	p.max_short_len = VK_FAST_SENT_LEN;
+	p.s_rows_per_wave = is_static ? (c->max_group_tokens + 15) / 16 * 16 : c->max_group_tiles * 16;
+	p.h_rows = c->max_short_len + 1;
+	const int lt = q->len_t <= 4 ? 4 : q->len_t <= 8 ? 8 : q->len_t <= 12 ? 12 : 16;   // strip rows hold the padded query columns (launch_score_lt)
+	int lds_floats = p.s_rows_per_wave * lt + 16;
+	if (p.gap_mode == 2) lds_floats += 4 * p.h_rows * 16;   // column history of dp_general
+	p.m_rows = (c->max_short_len + 4) / 4 * 4;
+	if (p.gap_mode == 7) lds_floats += 4 * p.m_rows;       // vocabulary masses of the 4 slices (static layout)
+	p.lds_floats_per_wave = lds_floats;
+	size_t smem = (size_t)lds_floats * 4 * 4;   // 4 waves per block
+	const size_t qlds = (!is_static && c->prec == 0 && c->nk32 == 24 && c->tail == 0) ? (size_t)c->nk32 * 1024 : 0;   // MODE 3: query tile in LDS
+	smem += qlds;
+	if (smem > 160 * 1024) return fail(VK_ERR_UNSUPPORTED, "LDS demand exceeds 160 KiB per workgroup");
+	const int64_t n_groups = (n + 3) / 4;
+	const int grid = (int)std::min<int64_t>((n_groups + 3) / 4, (int64_t)1 << 20);   // capped to residency by the launcher
+	VK_HIP(vk_launch_score(&p, grid, smem, st));
+	if (c->n_long_groups > 0) {
+		// slices longer than VK_FAST_SENT_LEN: one per wave, one wave per workgroup, LDS strip for the longest;
+		// general gaps take the LDS-history form (the four DPP rows share one history: only row 0 is active)
+		VkScoreParams pl = p;
+		pl.group_list = c->d_long_groups; pl.n_list = c->n_long_groups;
+		if (pl.gap_mode == 3 || pl.gap_mode == 6) pl.gap_mode = 2;
+		pl.s_rows_per_wave = is_static ? (c->long_group_tokens + 15) / 16 * 16 : c->long_group_tiles * 16;
+		pl.h_rows = 0;
+		int lf = pl.s_rows_per_wave * lt + 16;
+		if (pl.gap_mode == 2) lf += (c->max_len + 1) * 16;
+		pl.m_rows = 0;
+		if (pl.gap_mode == 7) lf += (c->max_len + 4) / 4 * 4;
+		pl.lds_floats_per_wave = lf;
+		const size_t smem_l = (size_t)lf * 4 + qlds;
+		if (smem_l > 160 * 1024) return fail(VK_ERR_UNSUPPORTED, "LDS demand of the long-slice pass exceeds 160 KiB");
+		VK_HIP(vk_launch_score(&pl, c->n_long_groups, smem_l, st));
+	}
+	}
+
+	const bool exact_transport = q->algorithm == VK_ALG_WRD || (q->algorithm == VK_ALG_RWMD && q->wmd_full);
+	if (exact_transport) {
+		// ---- stage 2: exact EMD on the candidates with the largest bounds, until the k-th best
+		// exact score is above every remaining bound (then no unsolved sentence can enter)
+		VK_HIP(hipEventRecord(c->ev[2], st));
+		// Round 1: the M largest bounds.  Its k-th best exact score theta prunes: every row whose bound is below
+		// theta is out; all others are solved in one launch (round 2), which then fills the GPU instead of a
+		// trickle of M-candidate rounds.
+		const int M = 512;
+		const size_t cap = ((size_t)((n + kTopkChunk - 1) / kTopkChunk) + 1) * VK_MAX_MATCHES;   // keys d_keys[0] holds
+		if (c->wrd_cap < cap) {
+			if (c->d_wrd_raw) { VK_HIP(hipFree(c->d_wrd_raw)); VK_HIP(hipFree(c->d_wrd_val)); c->d_wrd_raw = c->d_wrd_val = nullptr; }
+			rc = alloc_t(c, &c->d_wrd_raw, cap); if (rc) return rc;
+			rc = alloc_t(c, &c->d_wrd_val, cap); if (rc) return rc;
+			c->wrd_cap = cap;
+		}
+		if (!c->d_counter) { rc = alloc_t(c, &c->d_counter, 4); if (rc) return rc; }
+		struct Cand { float val, raw; int64_t g; };
+		std::vector<Cand> best;
+		std::vector<uint64_t> keys;
+		std::vector<float> vals, raws;
+		VkWrdParams w{};
+		w.tiles = c->d_tiles; w.tok_id = c->d_tok_id; w.table = c->d_table; w.sent_start = c->d_sent_start; w.sent_end = c->d_sent_end;
+		w.layout = p.layout; w.nk32 = c->nk32; w.tail = c->tail; w.tile_bytes = c->tile_bytes; w.prec = c->prec;
+		w.qtile = c->d_qtile; w.len_t = q->len_t; w.mag = c->d_mag;
+		w.mass_mode = q->algorithm == VK_ALG_WRD ? 0 : (q->rwmd_normalize_bow ? 1 : 2);
+		memcpy(w.qmass, p.qmass, sizeof w.qmass);
+		w.raw_masses = (q->algorithm == VK_ALG_WRD && !q->wrd_normalize_magnitudes) ? 1 : 0;
+		w.boost = p.boost; w.raw_out = c->d_wrd_raw; w.val_out = c->d_wrd_val;
+		// solves the `count` candidates whose keys sit at d_keys, merges them into `best`; returns the smallest bound among them
+		auto solve = [&](const uint64_t *d_keys, int count, float *ub_min, int *n_cand_out) -> int {
+			w.keys = d_keys;
+			VK_HIP(vk_launch_wrd_exact(&w, count, c->d_scores, st));
+			keys.resize((size_t)count); vals.resize((size_t)count); raws.resize((size_t)count);
+			VK_HIP(hipMemcpyAsync(keys.data(), d_keys, (size_t)count * 8, hipMemcpyDeviceToHost, st));
+			VK_HIP(hipMemcpyAsync(vals.data(), c->d_wrd_val, (size_t)count * 4, hipMemcpyDeviceToHost, st));
+			VK_HIP(hipMemcpyAsync(raws.data(), c->d_wrd_raw, (size_t)count * 4, hipMemcpyDeviceToHost, st));
+			VK_HIP(hipStreamSynchronize(st));
+			int n_cand = 0;
+			float ub = INFINITY;
+			for (int i = 0; i < count; i++) {
+				if (keys[(size_t)i] == 0) break;
+				n_cand++;
+				const uint32_t ob = (uint32_t)(keys[(size_t)i] >> 32);
+				const uint32_t bits = (ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob;
+				float u;
+				memcpy(&u, &bits, 4);
+				ub = std::min(ub, u);
+				if (vals[(size_t)i] > q->min_score)
+					best.push_back({vals[(size_t)i], raws[(size_t)i], (int64_t)(uint32_t)(keys[(size_t)i] & 0xffffffffu)});
+			}
+			const auto better = [](const Cand &a, const Cand &b) {
+				if (a.val != b.val) return a.val > b.val;
+				return a.g > b.g;
+			};
+			if ((int)best.size() > k) {
+				std::partial_sort(best.begin(), best.begin() + k, best.end(), better);
+				best.resize((size_t)k);
+			} else std::sort(best.begin(), best.end(), better);
+			*ub_min = ub;
+			*n_cand_out = n_cand;
+			return VK_OK;
+		};
+		{
+			int nb = 0, cur = 0;
+			VK_HIP(vk_launch_topk_scores(c->d_scores, n, q->min_score, M, c->d_keys[0], &nb, st));
+			while (nb > 1) {
+				const int64_t nkeys = (int64_t)nb * M;
+				VK_HIP(vk_launch_topk_keys(c->d_keys[cur], nkeys, M, c->d_keys[1 - cur], &nb, st));
+				cur = 1 - cur;
+			}
+			float ub_last = INFINITY;
+			int n_cand = 0;
+			if ((rc = solve(c->d_keys[cur], M, &ub_last, &n_cand))) return rc;
+			bool done = n_cand < M || ((int)best.size() == k && best.back().val > ub_last);
+			while (!done) {
+				const float theta = (int)best.size() == k ? best.back().val : -INFINITY;
+				VK_HIP(vk_launch_select_ge(c->d_scores, n, theta, q->min_score, c->d_keys[0], c->d_counter, (uint32_t)cap, st));
+				uint32_t count = 0;
+				VK_HIP(hipMemcpyAsync(&count, c->d_counter, 4, hipMemcpyDeviceToHost, st));
+				VK_HIP(hipStreamSynchronize(st));
+				if (count == 0) break;
+				if (getenv("VK_DEBUG_CANDIDATES")) fprintf(stderr, "[vk] exact transport: round 2 solves %u candidates (theta %.6f, n %lld)\n", count, theta, (long long)n);
+				const int take = (int)std::min<size_t>(count, cap);
+				if ((rc = solve(c->d_keys[0], take, &ub_last, &n_cand))) return rc;
+				done = (size_t)count <= cap;   // every row that could still enter has been solved
+			}
+		}
+		VK_HIP(hipEventRecord(c->ev[3], st));
+		{
+			std::vector<int64_t> rows_idx;
+			for (const Cand &b : best) rows_idx.push_back(b.g);
+			if ((rc = transport_flows(rows_idx, true, w.qmass, w.mass_mode, w.raw_masses))) return rc;
+		}
+		VK_HIP(hipEventRecord(c->ev[4], st));
+		VK_HIP(hipStreamSynchronize(st));
+		for (size_t i = 0; i < best.size(); i++) {
+			out->score[i] = best[i].val;
+			out->sentence[i] = sentence_of(best[i].g);
+			if (out->raw_score) out->raw_score[i] = best[i].raw;
+			if (q->want_flow && out->mapping && out->edge_sim)
+				for (int j = 0; j < q->len_t; j++) {
+					out->mapping[i * (size_t)q->len_t + j] = -1;
+					out->edge_sim[i * (size_t)q->len_t + j] = 0.0f;
+				}
+		}
+		out->n_out = (int)best.size();
+		float ms = 0;
+		vk_timings t{};
+		if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) t.prepare_ms = ms;
+		if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) t.score_ms = ms;
+		if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) t.topk_ms = ms;
+		if (hipEventElapsedTime(&ms, c->ev[0], c->ev[4]) == hipSuccess) t.total_ms = ms;
+		c->last = t;
+		return VK_OK;
+	}
+
+	// ---- flow (traceback) of `count` slices named by device keys: narrow or wide kernel
+	const int ostride = wide ? 64 : 16;   // row stride of the mapping / edge_sim device arrays
+	auto launch_flow = [&](const uint64_t *d_keys, int count) -> int {
+		if (wide) {
+			wp.keys = d_keys; wp.raw_out = c->d_out_raw; wp.mapping = c->d_out_map; wp.edge_sim = c->d_out_sim;
+			VK_HIP(vk_launch_wide(&wp, count, st));
+			return VK_OK;
+		}
+		VkFlowParams f{};
+		f.tiles = c->d_tiles; f.tok_id = c->d_tok_id; f.table = c->d_table; f.sent_start = c->d_sent_start; f.sent_end = c->d_sent_end;
+		f.layout = p.layout; f.nk32 = c->nk32; f.tail = c->tail; f.tile_bytes = c->tile_bytes; f.prec = c->prec;
+		f.qtile = c->d_qtile; f.len_t = q->len_t; f.locality = q->locality; f.gap_mode = (p.gap_mode == 3 || p.gap_mode == 6) ? 2 : p.gap_mode;
+		f.max_len = c->max_len;
+		f.gs = p.gs; f.gt = p.gt; f.a_s = p.a_s; f.a_t = p.a_t; f.open_s = p.open_s; f.open_t = p.open_t;
+		f.ws = c->d_ws; f.wt = c->d_wt;
+		f.pos_s = p.pos_s; f.tw_keep = p.tw_keep; f.tw_threshold = p.tw_threshold;
+		memcpy(f.tw, p.tw, sizeof f.tw);
+		memcpy(f.tpos, p.tpos, sizeof f.tpos);
+		f.keys = d_keys; f.raw_out = c->d_out_raw; f.mapping = c->d_out_map; f.edge_sim = c->d_out_sim;
+		VK_HIP(vk_launch_flow(&f, count, st));
+		return VK_OK;
+	};
+
+	if (is_align && q->submatch_weight != 0.0f) {
+		// ---- submatch_weight: bound from raw, then exact scores of the candidates from their tracebacks, until the
+		// k-th best exact score is above every remaining bound (vk_submatch_bound_kernel)
+		VK_HIP(hipEventRecord(c->ev[2], st));
+		const float wsub = q->submatch_weight, total = p.ref_total;
+		const float m_star = total * (1.0f - powf(1.0f / (wsub + 1.0f), 1.0f / wsub));
+		VK_HIP(vk_launch_submatch_bound(c->d_raw, p.boost, n, total, wsub, m_star, c->d_scores, st));
+		const int M = 512;
+		struct Cand { float val, raw; int64_t row; std::vector<int16_t> map; std::vector<float> sim; };
+		std::vector<Cand> best;
+		std::vector<uint64_t> keys((size_t)M);
+		std::vector<float> raws((size_t)M), sims((size_t)M * ostride);
+		std::vector<int16_t> maps((size_t)M * ostride);
+		for (;;) {
+			int nb = 0, cur = 0;
+			VK_HIP(vk_launch_topk_scores(c->d_scores, n, q->min_score, M, c->d_keys[0], &nb, st));
+			while (nb > 1) {
+				const int64_t nkeys = (int64_t)nb * M;
+				VK_HIP(vk_launch_topk_keys(c->d_keys[cur], nkeys, M, c->d_keys[1 - cur], &nb, st));
+				cur = 1 - cur;
+			}
+			if ((rc = launch_flow(c->d_keys[cur], M))) return rc;
+			VK_HIP(vk_launch_mark(c->d_keys[cur], M, c->d_scores, st));
+			VK_HIP(hipMemcpyAsync(keys.data(), c->d_keys[cur], (size_t)M * 8, hipMemcpyDeviceToHost, st));
+			VK_HIP(hipMemcpyAsync(raws.data(), c->d_out_raw, (size_t)M * 4, hipMemcpyDeviceToHost, st));
+			VK_HIP(hipMemcpyAsync(maps.data(), c->d_out_map, maps.size() * 2, hipMemcpyDeviceToHost, st));
+			VK_HIP(hipMemcpyAsync(sims.data(), c->d_out_sim, sims.size() * 4, hipMemcpyDeviceToHost, st));
+			VK_HIP(hipStreamSynchronize(st));
+			int n_cand = 0;
+			float ub_last = INFINITY;
+			for (int i = 0; i < M; i++) {
+				if (keys[(size_t)i] == 0) break;
+				n_cand++;
+				const uint32_t ob = (uint32_t)(keys[(size_t)i] >> 32);
+				const uint32_t bits = (ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob;
+				memcpy(&ub_last, &bits, 4);
+				const int64_t row = (int64_t)(uint32_t)(keys[(size_t)i] & 0xffffffffu);
+				// reference_score (metric/alignment.h:84-106) with the matched weight of this traceback, in float as upstream
+				float matched = 0.0f;
+				for (int j = 0; j < q->len_t; j++)
+					if (maps[(size_t)i * ostride + j] >= 0) matched += (q->tag_weights && is_align) ? q->tag_weights[j] : 1.0f;
+				const float uw = powf((total - matched) / total, wsub);
+				const float ref = matched + uw * (total - matched);
+				const float boost = q->boost ? q->boost[sentence_of(row)] : 1.0f;
+				const float val = (raws[(size_t)i] / ref) * boost;
+				if (val > q->min_score) {
+					Cand cd{val, raws[(size_t)i], row, {}, {}};
+					cd.map.assign(maps.begin() + (size_t)i * ostride, maps.begin() + (size_t)i * ostride + q->len_t);
+					cd.sim.assign(sims.begin() + (size_t)i * ostride, sims.begin() + (size_t)i * ostride + q->len_t);
+					best.push_back(std::move(cd));
+				}
+			}
+			std::sort(best.begin(), best.end(), [](const Cand &a, const Cand &b) {
+				if (a.val != b.val) return a.val > b.val;
+				return a.row > b.row;
+			});
+			if ((int)best.size() > k) best.resize((size_t)k);
+			if (n_cand < M) break;
+			if ((int)best.size() == k && best.back().val > ub_last) break;
+		}
+		VK_HIP(hipEventRecord(c->ev[3], st));
+		VK_HIP(hipEventRecord(c->ev[4], st));
+		VK_HIP(hipStreamSynchronize(st));
+		for (size_t i = 0; i < best.size(); i++) {
+			out->score[i] = best[i].val;
+			out->sentence[i] = sentence_of(best[i].row);
+			if (out->raw_score) out->raw_score[i] = best[i].raw;
+			if (q->want_flow && out->mapping && out->edge_sim)
+				for (int j = 0; j < q->len_t; j++) {
+					out->mapping[i * (size_t)q->len_t + j] = best[i].map[(size_t)j];
+					out->edge_sim[i * (size_t)q->len_t + j] = best[i].sim[(size_t)j];
+				}
+		}
+		out->n_out = (int)best.size();
+		float ms = 0;
+		vk_timings t{};
+		if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) t.prepare_ms = ms;
+		if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) t.score_ms = ms;
+		if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) t.topk_ms = ms;
+		if (hipEventElapsedTime(&ms, c->ev[0], c->ev[4]) == hipSuccess) t.total_ms = ms;
+		c->last = t;
+		return VK_OK;
+	}
+
+	// ---- bounded result set -------------------------------------------------
+	VK_HIP(hipEventRecord(c->ev[2], st));
+	c->ev2_recorded = true;
+	int cur = 0;
+	if (k <= 64) {
+		// wave-streaming selection: n -> ceil(n/4096) * k keys -> ... -> k keys
+		int64_t nw = 0;
+		VK_HIP(vk_launch_topk_wave(c->d_scores, nullptr, n, q->min_score, k, 4096, c->d_keys[0], &nw, st));
+		while (nw > 1) {
+			const int64_t nkeys = nw * k;
+			const int64_t per_wave = nkeys <= 16384 ? nkeys : 4096;
+			VK_HIP(vk_launch_topk_wave(nullptr, c->d_keys[cur], nkeys, 0.0f, k, per_wave, c->d_keys[1 - cur], &nw, st));
+			cur = 1 - cur;
+		}
+	} else {
+		int nb = 0;
+		VK_HIP(vk_launch_topk_scores(c->d_scores, n, q->min_score, k, c->d_keys[0], &nb, st));
+		while (nb > 1) {
+			const int64_t nkeys = (int64_t)nb * k;
+			VK_HIP(vk_launch_topk_keys(c->d_keys[cur], nkeys, k, c->d_keys[1 - cur], &nb, st));
+			cur = 1 - cur;
+		}
+	}
+
+	// ---- flow of the winners ------------------------------------------------
+	VK_HIP(hipEventRecord(c->ev[3], st));
+	const bool do_flow = q->want_flow && is_align;
+	if (do_flow && (rc = launch_flow(c->d_keys[cur], k))) return rc;
+	VK_HIP(hipEventRecord(c->ev[4], st));
+
+	// ---- results to host ------------------------------------------------------
+	std::vector<uint64_t> keys((size_t)k);
+	std::vector<float> raw((size_t)k), sim((size_t)k * ostride);
+	std::vector<int16_t> map((size_t)k * ostride);
+	VK_HIP(hipMemcpyAsync(keys.data(), c->d_keys[cur], (size_t)k * 8, hipMemcpyDeviceToHost, st));
+	if (do_flow) {
+		VK_HIP(hipMemcpyAsync(raw.data(), c->d_out_raw, (size_t)k * 4, hipMemcpyDeviceToHost, st));
+		VK_HIP(hipMemcpyAsync(map.data(), c->d_out_map, map.size() * 2, hipMemcpyDeviceToHost, st));
+		VK_HIP(hipMemcpyAsync(sim.data(), c->d_out_sim, sim.size() * 4, hipMemcpyDeviceToHost, st));
+	}
+	VK_HIP(hipStreamSynchronize(st));
+
+	int n_out = 0;
+	for (int i = 0; i < k; i++) {
+		if (keys[(size_t)i] == 0) break;
+		n_out++;
+	}
+	std::vector<float> raw_sel((size_t)std::max(n_out, 1));
+	if (!do_flow && out->raw_score && n_out > 0) {
+		// gather the aligner scores of the winners
+		for (int i = 0; i < n_out; i++) {
+			const int64_t g = (int64_t)(uint32_t)(keys[(size_t)i] & 0xffffffffu);
+			VK_HIP(hipMemcpyAsync(&raw_sel[(size_t)i], c->d_raw + g, 4, hipMemcpyDeviceToHost, st));
+		}
+		VK_HIP(hipStreamSynchronize(st));
+	}
+	for (int i = 0; i < n_out; i++) {
+		const uint64_t key = keys[(size_t)i];
+		const uint32_t ob = (uint32_t)(key >> 32);
+		const uint32_t bits = (ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob;
+		float s;
+		memcpy(&s, &bits, 4);
+		out->score[i] = s;
+		out->sentence[i] = sentence_of((int64_t)(uint32_t)(key & 0xffffffffu));
+		if (out->raw_score) out->raw_score[i] = do_flow ? raw[(size_t)i] : raw_sel[(size_t)i];
+		if (do_flow) {
+			for (int j = 0; j < q->len_t; j++) {
+				out->mapping[(size_t)i * q->len_t + j] = map[(size_t)i * ostride + j];
+				out->edge_sim[(size_t)i * q->len_t + j] = sim[(size_t)i * ostride + j];
+			}
+		} else if (q->want_flow && out->mapping && out->edge_sim) {
+			// transport flows of the winners (SparseFlow / DenseFlow) are not produced yet
+			for (int j = 0; j < q->len_t; j++) {
+				out->mapping[(size_t)i * q->len_t + j] = -1;
+				out->edge_sim[(size_t)i * q->len_t + j] = 0.0f;
+			}
+		}
+	}
+	out->n_out = n_out;
+	c->have_scores = true;
+	if (q->algorithm == VK_ALG_RWMD && n_out > 0) {
+		std::vector<int64_t> rows_idx;
+		for (int i = 0; i < n_out; i++) rows_idx.push_back((int64_t)(uint32_t)(keys[(size_t)i] & 0xffffffffu));
+		float no_mass[VK_FAST_QUERY_LEN] = {0};
+		if ((rc = transport_flows(rows_idx, false, no_mass, 0, 0))) return rc;
+	}
+
+	float ms = 0;
+	vk_timings t{};
+	if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) t.prepare_ms = ms;
+	if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) t.score_ms = ms;
+	if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) t.topk_ms = ms;
+	if (hipEventElapsedTime(&ms, c->ev[3], c->ev[4]) == hipSuccess) t.flow_ms = ms;
+	if (hipEventElapsedTime(&ms, c->ev[0], c->ev[4]) == hipSuccess) t.total_ms = ms;
+	c->last = t;
+	return VK_OK;
+}
+
+int vk_merge_topk(const vk_topk_out *sets, int32_t n_sets, int32_t len_t, int32_t max_matches, vk_topk_out *out) {
+	if (!sets || !out || n_sets < 0) return fail(VK_ERR_INVALID, "null argument");
+	if (max_matches < 1 || out->capacity < max_matches) return fail(VK_ERR_INVALID, "output capacity smaller than max_matches");
+	struct Ref { float score; int64_t sent; int set, idx; };
+	std::vector<Ref> all;
+	for (int s = 0; s < n_sets; s++)
+		for (int i = 0; i < sets[s].n_out; i++) all.push_back({sets[s].score[i], sets[s].sentence[i], s, i});
+	std::sort(all.begin(), all.end(), [](const Ref &a, const Ref &b) {
+		if (a.score != b.score) return a.score > b.score;
+		return a.sent > b.sent;
+	});
+	const int n_out = (int)std::min<size_t>(all.size(), (size_t)max_matches);
+	for (int i = 0; i < n_out; i++) {
+		const Ref &r = all[(size_t)i];
+		const vk_topk_out &src = sets[r.set];
+		out->score[i] = r.score;
+		out->sentence[i] = r.sent;
+		if (out->raw_score) out->raw_score[i] = src.raw_score ? src.raw_score[r.idx] : 0.0f;
+		if (out->mapping && src.mapping)
+			memcpy(out->mapping + (size_t)i * len_t, src.mapping + (size_t)r.idx * len_t, (size_t)len_t * 2);
+		if (out->edge_sim && src.edge_sim)
+			memcpy(out->edge_sim + (size_t)i * len_t, src.edge_sim + (size_t)r.idx * len_t, (size_t)len_t * 4);
+	}
+	out->n_out = n_out;
+	return VK_OK;
+}
+
+} // extern "C"

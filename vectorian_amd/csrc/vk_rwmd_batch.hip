@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void vk_rwmd_batch_kernel(VkRwmdBatchParams
 //   A rows: M = 8 (i >> 2) + 4 h + (i & 3) for accumulator register i of half h (hardware layout of
 //   the 32x32 result).  QPT = 3: half h, i < 10 = token i of query 3 qt + h; 10 <= i < 15 = token
 //   5 h + i - 10 of query 3 qt + 2.  QPT = 2: half h = query 2 qt + h, i = token.  The host packs the
-//   A tiles accordingly (vk_api.cpp pack_query_tiles32).
+//   A tiles accordingly (vk_query_batch in vk_batch.cpp).
 //   The query tiles stream through a double-buffered LDS slot shared by the 8 waves.
 // ---------------------------------------------------------------------------
 

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 	}
 
 	// groups of 4 consecutive slices; slices longer than max_short_len sit alone in their group (the host
-	// pads the slice table, vk_api.cpp set_slices_impl) and are left to a second launch that walks
+	// pads the slice table, vk_corpus.cpp set_slices_impl) and are left to a second launch that walks
 	// group_list with one wave per workgroup and a larger LDS strip
 	// A wave takes runs of VK_RUN consecutive groups: when sentences are not tile-aligned, the tile that
 	// straddles two groups is then computed once and its rows are carried over in the strip (ragged corpora:

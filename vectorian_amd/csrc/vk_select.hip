@@ -154,7 +154,7 @@ __global__ void vk_mark_kernel(const uint64_t *__restrict__ keys, int32_t n, flo
 // and m is known only after a traceback.  Stage 1 turns raw into an upper bound of the score: every matched
 // pair contributes at most its token weight, so m >= raw; ref is convex in m with its minimum at m_star, so
 // ref(m) >= ref(max(raw, m_star)) =: ref_lb(raw) (a margin covers powf).  Negative raw (GLOBAL) is largest
-// over the largest ref = T.  Stage 2 (vk_api.cpp) retraces the candidates with the largest bounds.
+// over the largest ref = T.  Stage 2 (vk_query.cpp) retraces the candidates with the largest bounds.
 __global__ void vk_submatch_bound_kernel(const float *__restrict__ raw, const float *__restrict__ boost, int64_t n,
 	float total, float w, float m_star, float *__restrict__ scores) {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
