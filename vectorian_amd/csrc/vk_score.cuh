@@ -232,14 +232,18 @@ static hipError_t launch_sized(K kernel, const VkScoreParams &p, int want_blocks
 	e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, threads, smem);
 	if (e != hipSuccess) return e;
 	if (occ < 1) occ = 1;
+	const int real_occ = occ;
 	// measured on MI355X (1M x 32 x 300-d): 3 workgroups (12 waves) per CU stream HBM fastest --
 	// 2.90 ms vs 3.51 ms at 5 per CU for the linear-gap kernel, 2.95 ms at 4; more concurrent streams cost bandwidth
-	if (occ > 3 && p.layout != VK_DEV_LAYOUT_STATIC) occ = 3;   // the static layout is DP-bound, not a stream: keep full residency
+	// the transport bound (WRD / full WMD stage 1) has the longest epilogue per group and wants every wave it can get to
+	// hide it: 1 M x 32 x 300-d 3.54 ms at 3 per CU, 3.08 at 4; 768-d 4.31 ms at 1, 3.37 at 2
+	const bool bound_pass = p.gap_mode == 5 || (p.gap_mode == 4 && p.wmd_bound == 1);
+	if (occ > 3 && p.layout != VK_DEV_LAYOUT_STATIC && !bound_pass) occ = 3;   // the static layout is DP-bound, not a stream: keep full residency
 	// 768-d rows: a wave already keeps 24 KiB of loads in flight per tile; one workgroup per CU measured fastest
 	// (ragged 8..64 tokens, 400 k sentences: 3.37 ms at 1, 3.45 ms at 2 per CU)
-	if (p.nk32 >= 24 && p.prec == 0 && p.layout != VK_DEV_LAYOUT_STATIC) occ = 1;
+	if (p.nk32 >= 24 && p.prec == 0 && p.layout != VK_DEV_LAYOUT_STATIC && !bound_pass) occ = 1;
 	static const char *ov = getenv("VK_BLOCKS_PER_CU");
-	if (ov && atoi(ov) > 0) occ = atoi(ov);
+	if (ov && atoi(ov) > 0) occ = atoi(ov) < real_occ ? atoi(ov) : real_occ;
 	int dev = 0, cus = 256;
 	if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
 	const int grid = want_blocks < cus * occ ? want_blocks : cus * occ;
