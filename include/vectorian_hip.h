@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 3
+#define VK_ABI_VERSION 4
 #define VK_MAX_QUERY_LEN 64   /* query tokens */
 #define VK_FAST_QUERY_LEN 16  /* queries up to this length run in the fused kernels (one 16-wide MFMA column block); longer ones
                                  (alignments and injective RWMD only) take a one-wave-per-slice kernel, ~10x slower */
@@ -180,6 +180,8 @@ int vk_corpus_append_vectors(vk_corpus_t *c, const void *rows, int64_t n_rows, i
 int vk_corpus_set_token_ids(vk_corpus_t *c, const int32_t *ids, int64_t n, int32_t mem);
 /* universal POS code per token occurrence (Token.pos, common.h:34-42); only needed by tag-weighted queries */
 int vk_corpus_set_token_pos(vk_corpus_t *c, const int8_t *pos, int64_t n, int32_t mem);
+/* fine-grained tag code per token occurrence (Token.tag, common.h:34-42); only needed by tag filters */
+int vk_corpus_set_token_tags(vk_corpus_t *c, const int8_t *tags, int64_t n, int32_t mem);
 /* sentence spans as CSR offsets in token units, contiguous from 0
  * (Spans::iterate, document.h:147-169).  sent_off: host [n_sentences + 1]. */
 int vk_corpus_set_sentences(vk_corpus_t *c, const int64_t *sent_off, int64_t n_sentences);
@@ -193,6 +195,14 @@ int vk_corpus_finalize(vk_corpus_t *c);
  * scoring kernel of the next.  Free the views before the owning handle.  (The reference runs one ThreadPool task per
  * document, vectorian/index.py:544-558; here the unit of concurrency is the query.) */
 int vk_corpus_view(vk_corpus_t *src, vk_corpus_t **out);
+/* Token filter (TokenFilter::pass, vectorian/core/cpp/query.h:8-28; options pos_filter / tag_filter of
+ * Query::initialize, query.cpp:220-228): a token is dropped when bit Token.pos of pos_mask or bit Token.tag of tag_mask
+ * is set (codes 0..63).  The reference compacts every slice per query and document (FilteredSliceFactory,
+ * slice/static.h:366-416); here the filtered corpus is built once on the device -- rows of the dropped tokens removed,
+ * slices re-indexed, same slice ids -- and queried like any other corpus; traceback positions count the tokens that
+ * passed, as upstream's do (flow.cpp:49-60 maps them back).  The static layout shares the vocabulary vectors with
+ * `src`: free the filtered corpus first. */
+int vk_corpus_filter(vk_corpus_t *src, uint64_t pos_mask, uint64_t tag_mask, vk_corpus_t **out);
 int vk_corpus_free(vk_corpus_t *c);
 int vk_corpus_device_bytes(const vk_corpus_t *c, int64_t *bytes);
 

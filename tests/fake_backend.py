@@ -27,6 +27,7 @@ class OracleCorpus:
 		self._rows, self._mags = [], []
 		self._ids = None
 		self._pos = None
+		self._tags = None
 		self._off = None
 		self._all = None
 
@@ -48,6 +49,35 @@ class OracleCorpus:
 
 	def set_token_pos(self, pos):
 		self._pos = np.ascontiguousarray(pos, dtype=np.int8)
+
+	def set_token_tags(self, tags):
+		self._tags = np.ascontiguousarray(tags, dtype=np.int8)
+
+	def filtered(self, pos_mask=0, tag_mask=0):
+		"""the corpus without the tokens the filter drops, slices re-indexed: restated on the host, array by array"""
+		n = self.n_tokens
+		drop = np.zeros(n, dtype=bool)
+		for mask, codes in ((pos_mask, self._pos), (tag_mask, self._tags)):
+			if mask:
+				if codes is None:
+					raise core.VkError(4, "filter needs token codes")
+				cd = codes.astype(np.int64)
+				bits = np.array([(int(mask) >> b) & 1 for b in range(64)], dtype=bool)
+				drop |= (cd >= 0) & (cd < 64) & bits[np.clip(cd, 0, 63)]
+		keep = ~drop
+		new_index = np.concatenate(([0], np.cumsum(keep))).astype(np.int64)
+		f = OracleCorpus(layout=self.layout, d=self.d, n_tokens=int(keep.sum()), n_sentences=self.n_sentences,
+			vocab_size=self.vocab_size, precision=self.precision)
+		f._X, f._mag = self._X, self._mag
+		if self.layout == core.VK_LAYOUT_STATIC:
+			f._ids = self._ids[keep]
+		else:
+			f._X, f._mag = self._X[keep], self._mag[keep]
+		f._pos = None if self._pos is None else self._pos[keep]
+		f._tags = None if self._tags is None else self._tags[keep]
+		f._off = new_index[self._off]
+		f._end = None if self._end is None else new_index[self._end]
+		return f
 
 	def set_sentences(self, off):
 		self._off = np.ascontiguousarray(off, dtype=np.int64)

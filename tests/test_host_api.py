@@ -131,6 +131,44 @@ def test_regions_report_gap_penalties_like_the_reference_docs():
 	assert j["omitted"] == []
 
 
+def test_pos_filter_drops_document_tokens_for_one_query():
+	# options pos_filter / tag_filter (Query::make_token_filter, vectorian/core/cpp/query.cpp:220-228): tokens with
+	# these POS / tags are removed from every slice for this query; flow targets count the passing tokens, regions
+	# are reported in document positions (Flow::py_regions index_map, match/flow.cpp:49-60,96-97)
+	words = ["get", "our", "jewels", "and", "wealth", "together", "jewelry", "riches", "x"]
+	rng = np.random.default_rng(0)
+	base = rng.standard_normal((len(words), 64)).astype(np.float32)
+	base[6] = base[2] + 0.3 * rng.standard_normal(64)
+	base[7] = base[4] + 0.3 * rng.standard_normal(64)
+	emb = StaticEmbedding("toy", words, base)
+	sent = ["get", "our", "jewels", "and", "our", "wealth", "together", "x"]
+	pos = ["VERB", "PRON", "NOUN", "CCONJ", "PRON", "NOUN", "ADV", "X"]
+	tags = ["VB", "PRP$", "NNS", "CC", "PRP$", "NN", "RB", "XX"]
+	session = Session([Document([sent, ["x", "x"]], pos=[pos, ["X", "X"]], tags=[tags, ["XX", "XX"]])], embeddings=[emb])
+	sim = OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), alignment.LocalAlignment(gap=alignment.smooth_gap_cost(5)))
+	index = session.index(sim, corpus_factory=OracleCorpus)
+	plain = index.find("jewelry and riches", n=1)[0]
+	assert list(plain.flow["target"]) == [2, 3, 5]
+	# without the pronouns the slice reads get jewels and wealth together x: no gap left between "and" and "wealth"
+	m = index.find("jewelry and riches", n=1, options={"pos_filter": ["PRON"]})[0]
+	assert list(m.flow["target"]) == [1, 2, 3]
+	assert abs(m.score - (plain.score + 0.12944944202899933 / 3)) < 1e-6
+	reg = m.to_json(context_size=2)["regions"]
+	assert [r["s"] for r in reg if "edges" in r] == ["jewels", "and", "wealth"]
+	# tag filter, both at once, and the cache of filtered corpora
+	m2 = index.find("jewelry and riches", n=1, options={"tag_filter": ["PRP$", "CC"]})[0]
+	assert list(m2.flow["target"]) == [1, -1, 2] and m2.omitted == ["and"]
+	m3 = index.find("jewelry and riches", n=1, options={"pos_filter": ["PRON"], "tag_filter": ["CC"]})[0]
+	assert list(m3.flow["target"]) == [1, -1, 2]
+	assert [r["s"] for r in m3.to_json(context_size=1)["regions"] if "edges" in r] == ["jewels", "wealth"]
+	assert len(index._filtered) == 2
+	again = index.find("jewelry and riches", n=1, options={"pos_filter": ["PRON"], "tag_filter": ["CC"]})[0]
+	assert again.score == m3.score
+	with pytest.raises(RuntimeError, match="illegal value"):
+		index.find("jewelry", options={"pos_filter": ["NO_SUCH_POS"]})      # query.h:45-49
+	index.close()
+
+
 def test_contextual_embedding_and_boost():
 	rng = np.random.default_rng(4)
 	d = 48

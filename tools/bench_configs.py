@@ -35,6 +35,7 @@ def main():
 	ap.add_argument("--layout", choices=["contextual", "static"], default="contextual")
 	ap.add_argument("--batch", type=int, default=0, help="queries per vk_query_batch call (config 4: 256)")
 	ap.add_argument("--precision", choices=["bf16", "f32"], default="bf16", help="how the unit rows are kept in HBM")
+	ap.add_argument("--filter", type=float, default=0.0, help="share of tokens a pos_filter drops: times vk_corpus_filter, then queries the filtered corpus")
 	args = ap.parse_args()
 
 	import torch
@@ -104,6 +105,16 @@ def main():
 		del x, idx
 	corpus.set_sentences(off)
 	corpus.finalize()
+
+	filter_ms = None
+	if args.filter > 0.0:
+		source = corpus
+		source.set_token_pos((rng.random(n_tok) < args.filter).astype(np.int8))
+		source.filtered(pos_mask=2).close()   # warm-up (first use of the scan)
+		torch.cuda.synchronize()
+		t0 = time.perf_counter()
+		corpus = source.filtered(pos_mask=2)
+		filter_ms = (time.perf_counter() - t0) * 1e3
 
 	w = (1 - 2.0 ** (-np.arange(0, 65) / 5)).astype(np.float32)
 	gap = {"exp5": ("table", w), "linear": 0.1, "affine": ("affine", 0.2, 0.05)}[args.gap]
@@ -182,7 +193,7 @@ def main():
 		"score_kernel_ms": score_ms, "score_kernel_GBps": bytes_alg / (score_ms * 1e-3) / 1e9,
 		"hbm_frac_of_8TBps": bytes_alg / (score_ms * 1e-3) / 8e12,
 		"phases_ms_mean": {k: float(np.mean([p[k] for p in phases])) for k in phases[0]},
-		"top_score": float(top.score[0]) if top.n else None}))
+		"top_score": float(top.score[0]) if top.n else None, "filter_build_ms": filter_ms}))
 	corpus.close()
 
 

@@ -87,7 +87,7 @@ class _Timings(C.Structure):
 
 EXPORTS = [
 	"vk_abi_version", "vk_last_error", "vk_init", "vk_device_count", "vk_corpus_view",
-	"vk_corpus_create", "vk_corpus_append_vectors", "vk_corpus_set_token_ids", "vk_corpus_set_token_pos",
+	"vk_corpus_create", "vk_corpus_append_vectors", "vk_corpus_set_token_ids", "vk_corpus_set_token_pos", "vk_corpus_set_token_tags", "vk_corpus_filter",
 	"vk_corpus_set_sentences", "vk_corpus_set_slices", "vk_corpus_finalize", "vk_corpus_free", "vk_corpus_device_bytes",
 	"vk_query", "vk_query_batch", "vk_last_scores", "vk_last_timings", "vk_merge_topk"]
 
@@ -131,18 +131,20 @@ def lib():
 		L.vk_corpus_append_vectors.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32]
 		L.vk_corpus_set_token_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
 		L.vk_corpus_set_token_pos.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
+		L.vk_corpus_set_token_tags.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
 		L.vk_corpus_set_sentences.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 		L.vk_corpus_set_slices.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
 		L.vk_corpus_finalize.argtypes = [C.c_void_p]
 		L.vk_corpus_free.argtypes = [C.c_void_p]
 		L.vk_corpus_view.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+		L.vk_corpus_filter.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]
 		L.vk_corpus_device_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
 		L.vk_query.argtypes = [C.c_void_p, C.POINTER(_QueryDesc), C.POINTER(_TopkOut)]
 		L.vk_query_batch.argtypes = [C.c_void_p, C.POINTER(_QueryDesc), C.c_int32, C.POINTER(_TopkOut)]
 		L.vk_last_scores.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 		L.vk_last_timings.argtypes = [C.c_void_p, C.POINTER(_Timings)]
 		L.vk_merge_topk.argtypes = [C.POINTER(_TopkOut), C.c_int32, C.c_int32, C.c_int32, C.POINTER(_TopkOut)]
-		if L.vk_abi_version() != 3:
+		if L.vk_abi_version() != 4:
 			raise RuntimeError("libvectorian_hip.so ABI version mismatch")
 		_lib = L
 	return _lib
@@ -284,6 +286,11 @@ class Corpus:
 		pos = np.ascontiguousarray(pos, dtype=np.int8)
 		_check(lib().vk_corpus_set_token_pos(self._h, _np_ptr(pos), len(pos), VK_MEM_HOST))
 
+	def set_token_tags(self, tags):
+		"""fine-grained tag code per token occurrence (int8), for tag filters"""
+		tags = np.ascontiguousarray(tags, dtype=np.int8)
+		_check(lib().vk_corpus_set_token_tags(self._h, _np_ptr(tags), len(tags), VK_MEM_HOST))
+
 	def set_sentences(self, sent_off):
 		sent_off = np.ascontiguousarray(sent_off, dtype=np.int64)
 		_check(lib().vk_corpus_set_sentences(self._h, _np_ptr(sent_off), len(sent_off) - 1))
@@ -415,6 +422,16 @@ class Corpus:
 		v._owner = self   # the shared arrays live as long as the owning handle: keep it alive
 		_check(lib().vk_corpus_view(self._h, C.byref(v._h)))
 		return v
+
+	def filtered(self, pos_mask=0, tag_mask=0):
+		"""the corpus without the tokens whose POS / tag code has its bit set in the masks (vk_corpus_filter;
+		TokenFilter, vectorian/core/cpp/query.h:8-28): same slices, re-indexed; built once on the device"""
+		f = Corpus.__new__(Corpus)
+		f.__dict__.update({k: val for k, val in self.__dict__.items() if k != "_h"})
+		f._h = C.c_void_p()
+		f._owner = self   # static layout: the vocabulary vectors stay the source's
+		_check(lib().vk_corpus_filter(self._h, C.c_uint64(int(pos_mask)), C.c_uint64(int(tag_mask)), C.byref(f._h)))
+		return f
 
 	def close(self):
 		if self._h:

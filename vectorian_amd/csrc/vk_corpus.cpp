@@ -101,7 +101,7 @@ int vk_corpus_view(vk_corpus_t *src, vk_corpus_t **out) {
 	c->desc = src->desc; c->device = src->device;
 	c->d_pad = src->d_pad; c->nk32 = src->nk32; c->tail = src->tail; c->tile_bytes = src->tile_bytes; c->prec = src->prec;
 	c->rows_total = src->rows_total; c->rows_appended = src->rows_appended; c->n_tiles = src->n_tiles;
-	c->d_tiles = src->d_tiles; c->d_mag = src->d_mag; c->d_tok_id = src->d_tok_id; c->d_pos = src->d_pos;
+	c->d_tiles = src->d_tiles; c->d_mag = src->d_mag; c->d_tok_id = src->d_tok_id; c->d_pos = src->d_pos; c->d_tag = src->d_tag;
 	c->d_sent_start = src->d_sent_start; c->d_sent_end = src->d_sent_end; c->d_long_groups = src->d_long_groups;
 	c->contiguous = src->contiguous; c->have_ids = src->have_ids; c->have_sent = src->have_sent; c->finalized = true;
 	c->max_len = src->max_len; c->max_group_tiles = src->max_group_tiles; c->max_group_tokens = src->max_group_tokens;
@@ -146,9 +146,10 @@ int vk_corpus_free(vk_corpus_t *c) {
 		p->peer = c->peer == p ? nullptr : c->peer;
 		c->peer = nullptr;
 	}
-	if (c->is_view) c->d_tiles = nullptr, c->d_mag = nullptr, c->d_tok_id = nullptr, c->d_pos = nullptr,
+	if (c->is_view) c->d_tiles = nullptr, c->d_mag = nullptr, c->d_tok_id = nullptr, c->d_pos = nullptr, c->d_tag = nullptr,
 		c->d_sent_start = c->d_sent_end = nullptr, c->d_long_groups = nullptr;
-	void *ptrs[] = {c->d_tiles, c->d_mag, c->d_tok_id, c->d_pos, c->d_sent_start, c->d_sent_end, c->d_stage, c->d_qtile, c->d_ws, c->d_wt, c->d_qids,
+	if (c->shares_vectors) c->d_tiles = nullptr, c->d_mag = nullptr;
+	void *ptrs[] = {c->d_tiles, c->d_mag, c->d_tok_id, c->d_pos, c->d_tag, c->d_sent_start, c->d_sent_end, c->d_stage, c->d_qtile, c->d_ws, c->d_wt, c->d_qids,
 		c->d_table, c->d_scores, c->d_raw, c->d_boost, c->d_keys[0], c->d_keys[1], c->d_out_raw, c->d_out_sim, c->d_out_map, c->d_wrd_raw, c->d_wrd_val, c->d_bq, c->d_bqlen, c->d_bscores, c->d_bkeys[0], c->d_bkeys[1], c->d_long_groups, c->d_counter, c->d_rows_out, c->d_plan_out, c->d_braw};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -211,19 +212,27 @@ int vk_corpus_set_token_ids(vk_corpus_t *c, const int32_t *ids, int64_t n, int32
 	return VK_OK;
 }
 
-int vk_corpus_set_token_pos(vk_corpus_t *c, const int8_t *pos, int64_t n, int32_t mem) {
-	if (!c || !pos) return fail(VK_ERR_INVALID, "null argument");
-	if (n != c->desc.n_tokens) return fail(VK_ERR_INVALID, "POS count differs from n_tokens");
-	if (c->is_view) return fail(VK_ERR_STATE, "set POS codes on the owning handle, before taking views");
+static int set_token_codes(vk_corpus_t *c, int8_t **slot, const int8_t *codes, int64_t n, int32_t mem, const char *what) {
+	if (!c || !codes) return fail(VK_ERR_INVALID, "null argument");
+	if (n != c->desc.n_tokens) return fail(VK_ERR_INVALID, std::string(what) + " count differs from n_tokens");
+	if (c->is_view) return fail(VK_ERR_STATE, std::string("set ") + what + " codes on the owning handle, before taking views");
 	VK_HIP(hipSetDevice(c->device));
-	if (!c->d_pos) {
-		int rc = alloc_t(c, &c->d_pos, (size_t)n + 64);
+	if (!*slot) {
+		int rc = alloc_t(c, slot, (size_t)n + 64);
 		if (rc) return rc;
-		VK_HIP(hipMemsetAsync(c->d_pos, 0, (size_t)n + 64, c->stream));
+		VK_HIP(hipMemsetAsync(*slot, 0, (size_t)n + 64, c->stream));
 	}
-	VK_HIP(hipMemcpyAsync(c->d_pos, pos, (size_t)n, mem == VK_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+	VK_HIP(hipMemcpyAsync(*slot, codes, (size_t)n, mem == VK_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
 	VK_HIP(hipStreamSynchronize(c->stream));
 	return VK_OK;
+}
+
+int vk_corpus_set_token_pos(vk_corpus_t *c, const int8_t *pos, int64_t n, int32_t mem) {
+	return set_token_codes(c, c ? &c->d_pos : nullptr, pos, n, mem, "POS");
+}
+
+int vk_corpus_set_token_tags(vk_corpus_t *c, const int8_t *tags, int64_t n, int32_t mem) {
+	return set_token_codes(c, c ? &c->d_tag : nullptr, tags, n, mem, "tag");
 }
 
 static int set_slices_impl(vk_corpus_t *c, const int64_t *start, const int64_t *end, int64_t n_sentences, bool contiguous) {
@@ -351,6 +360,104 @@ int vk_corpus_finalize(vk_corpus_t *c) {
 	if (c->d_stage) { VK_HIP(hipFree(c->d_stage)); c->d_stage = nullptr; c->device_bytes -= kStageBytes; }
 	VK_HIP(hipStreamSynchronize(c->stream));
 	c->finalized = true;
+	return VK_OK;
+}
+
+// The filtered corpus: keep flags and their scan on the device, slice table re-indexed, token rows / ids / codes /
+// magnitudes gathered.  A handle of its own (stream, workspaces); the static layout shares the vocabulary arrays.
+int vk_corpus_filter(vk_corpus_t *src, uint64_t pos_mask, uint64_t tag_mask, vk_corpus_t **out) {
+	if (!src || !out) return fail(VK_ERR_INVALID, "null argument");
+	if (!src->finalized) return fail(VK_ERR_STATE, "corpus not finalized");
+	if (pos_mask && !src->d_pos) return fail(VK_ERR_STATE, "pos filter needs vk_corpus_set_token_pos");
+	if (tag_mask && !src->d_tag) return fail(VK_ERR_STATE, "tag filter needs vk_corpus_set_token_tags");
+	VK_HIP(hipSetDevice(src->device));
+	hipStream_t st = src->stream;
+	const int64_t n = src->desc.n_tokens, ne = src->n_entries, ns = src->desc.n_sentences;
+	const bool is_static = src->desc.layout == VK_LAYOUT_STATIC;
+
+	int32_t *keep = nullptr, *new_index = nullptr, *src_of = nullptr, *fs = nullptr, *fe = nullptr;
+	void *temp = nullptr;
+	vk_corpus *c = nullptr;
+	int rc = VK_OK;
+	auto body = [&]() -> int {
+		VK_HIP(hipMalloc((void **)&keep, ((size_t)n + 1) * 4));
+		VK_HIP(hipMalloc((void **)&new_index, ((size_t)n + 1) * 4));
+		VK_HIP(hipMalloc((void **)&src_of, ((size_t)n + 1) * 4));
+		VK_HIP(hipMalloc((void **)&fs, ((size_t)ne + 1) * 4));
+		VK_HIP(hipMalloc((void **)&fe, ((size_t)ne + 1) * 4));
+		size_t temp_bytes = 0;
+		VK_HIP(vk_launch_filter_scan(nullptr, nullptr, 0, 0, n, keep, new_index, nullptr, &temp_bytes, st));
+		VK_HIP(hipMalloc(&temp, temp_bytes ? temp_bytes : 16));
+		VK_HIP(vk_launch_filter_scan(src->d_pos, src->d_tag, pos_mask, tag_mask, n, keep, new_index, temp, &temp_bytes, st));
+		VK_HIP(vk_launch_filter_maps(keep, new_index, n, src_of, src->d_sent_start, src->d_sent_end, ne, fs, fe, st));
+		int32_t n_kept32 = 0;
+		std::vector<int32_t> hs((size_t)ne), he((size_t)ne);
+		VK_HIP(hipMemcpyAsync(&n_kept32, new_index + n, 4, hipMemcpyDeviceToHost, st));
+		if (ne > 0) {
+			VK_HIP(hipMemcpyAsync(hs.data(), fs, (size_t)ne * 4, hipMemcpyDeviceToHost, st));
+			VK_HIP(hipMemcpyAsync(he.data(), fe, (size_t)ne * 4, hipMemcpyDeviceToHost, st));
+		}
+		VK_HIP(hipStreamSynchronize(st));
+		const int64_t n_kept = n_kept32;
+
+		// slices of the filtered stream, per sentence (rows of the source's table that are padding carry no sentence)
+		std::vector<int64_t> start((size_t)ns), end((size_t)ns);
+		for (int64_t e = 0; e < ne; e++) {
+			const int64_t sent = src->entry_sent.empty() ? e : src->entry_sent[(size_t)e];
+			if (sent >= 0 && sent < ns) { start[(size_t)sent] = hs[(size_t)e]; end[(size_t)sent] = he[(size_t)e]; }
+		}
+
+		vk_corpus_desc desc = src->desc;
+		desc.n_tokens = n_kept;
+		if (is_static) {
+			// token ids and slices are this handle's, the vocabulary (tiles, magnitudes) stays the source's
+			c = new vk_corpus();
+			c->desc = desc; c->device = src->device;
+			c->d_pad = src->d_pad; c->nk32 = src->nk32; c->tail = src->tail; c->tile_bytes = src->tile_bytes; c->prec = src->prec;
+			c->rows_total = c->rows_appended = src->rows_total; c->n_tiles = src->n_tiles;
+			c->d_tiles = src->d_tiles; c->d_mag = src->d_mag; c->shares_vectors = true;
+			if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(VK_ERR_HIP, "hipStreamCreate failed");
+			for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) return fail(VK_ERR_HIP, "hipEventCreate failed");
+			int r;
+			if ((r = alloc_t(c, &c->d_tok_id, (size_t)n_kept + 64))) return r;
+			if ((r = alloc_t(c, &c->d_table, (size_t)c->n_tiles * 16 * 16 * 4))) return r;
+			if ((r = alloc_t(c, &c->d_qtile, (size_t)c->tile_bytes * 4))) return r;
+			if ((r = alloc_t(c, &c->d_ws, kGapTable))) return r;
+			if ((r = alloc_t(c, &c->d_wt, 80))) return r;
+			if ((r = alloc_t(c, &c->d_qids, 80))) return r;
+			if ((r = alloc_t(c, &c->d_out_raw, VK_MAX_MATCHES))) return r;
+			if ((r = alloc_t(c, &c->d_out_sim, (size_t)VK_MAX_MATCHES * 64))) return r;
+			if ((r = alloc_t(c, &c->d_out_map, (size_t)VK_MAX_MATCHES * 64))) return r;
+			VK_HIP(hipMemsetAsync(c->d_tok_id, 0, ((size_t)n_kept + 64) * 4, st));
+			VK_HIP(vk_launch_filter_gather(src->d_tok_id, c->d_tok_id, 4, src_of, n_kept, st));
+			c->have_ids = true;
+		} else {
+			int r = vk_corpus_create(&desc, &c);
+			if (r) return r;
+			VK_HIP(hipStreamSynchronize(c->stream));   // the zero fill of the new tiles
+			VK_HIP(vk_launch_filter_rows(src->d_tiles, c->d_tiles, src_of, n_kept, src->tile_bytes, st));
+			if (src->d_mag && c->d_mag) VK_HIP(vk_launch_filter_gather(src->d_mag, c->d_mag, 4, src_of, n_kept, st));
+			c->rows_appended = c->rows_total;
+		}
+		for (int which = 0; which < 2; which++) {
+			int8_t *from = which ? src->d_tag : src->d_pos;
+			int8_t **to = which ? &c->d_tag : &c->d_pos;
+			if (!from) continue;
+			int r = alloc_t(c, to, (size_t)n_kept + 64);
+			if (r) return r;
+			VK_HIP(hipMemsetAsync(*to, 0, (size_t)n_kept + 64, st));
+			VK_HIP(vk_launch_filter_gather(from, *to, 1, src_of, n_kept, st));
+		}
+		VK_HIP(hipStreamSynchronize(st));
+		int r = set_slices_impl(c, start.data(), end.data(), ns, src->contiguous);
+		if (r) return r;
+		c->finalized = true;
+		return VK_OK;
+	};
+	rc = body();
+	for (void *p : {(void *)keep, (void *)new_index, (void *)src_of, (void *)fs, (void *)fe, temp}) if (p) (void)hipFree(p);
+	if (rc) { if (c) vk_corpus_free(c); return rc; }
+	*out = c;
 	return VK_OK;
 }
 

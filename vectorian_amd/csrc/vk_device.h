@@ -205,6 +205,15 @@ hipError_t vk_launch_select_ge(const float *scores, int64_t n, float theta, floa
 size_t vk_wide_lds_demand(int32_t max_len, int32_t nq, int32_t gap_mode, int32_t tagged, int32_t flow);
 hipError_t vk_launch_pack(const void *in, int32_t dtype_bf16, int64_t n_rows, int32_t d, int32_t d_pad, int64_t row0,
 	uint8_t *tiles, float *mag_out, int32_t normalize, int32_t prec, hipStream_t stream);
+// token filters (vk_filter.hip): temp == nullptr only sizes the scan's workspace
+hipError_t vk_launch_filter_scan(const int8_t *pos, const int8_t *tag, uint64_t pos_mask, uint64_t tag_mask, int64_t n,
+	int32_t *keep, int32_t *new_index, void *temp, size_t *temp_bytes, hipStream_t stream);
+hipError_t vk_launch_filter_maps(const int32_t *keep, const int32_t *new_index, int64_t n, int32_t *src_of,
+	const int32_t *start, const int32_t *end, int64_t n_entries, int32_t *out_start, int32_t *out_end, hipStream_t stream);
+hipError_t vk_launch_filter_rows(const uint8_t *src, uint8_t *dst, const int32_t *src_of, int64_t n_kept, int32_t tile_bytes,
+	hipStream_t stream);
+hipError_t vk_launch_filter_gather(const void *src, void *dst, int32_t elem_bytes, const int32_t *src_of, int64_t n_kept,
+	hipStream_t stream);
 hipError_t vk_launch_table(const uint8_t *etiles, const uint8_t *qtile, int32_t n_tiles, int32_t nk32, int32_t tail,
 	int32_t tile_bytes, float *table, const int32_t *q_ids, int32_t len_t, int32_t V, int32_t prec, hipStream_t stream);
 hipError_t vk_launch_score(const VkScoreParams *p, int32_t grid, size_t smem_bytes, hipStream_t stream);

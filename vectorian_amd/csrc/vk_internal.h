@@ -72,7 +72,8 @@ struct vk_corpus {
 	uint8_t *d_tiles = nullptr;
 	float *d_mag = nullptr;
 	int32_t *d_tok_id = nullptr;
-	int8_t *d_pos = nullptr;   // POS code per token (tag-weighted queries)
+	int8_t *d_pos = nullptr;   // POS code per token (tag-weighted queries, token filters)
+	int8_t *d_tag = nullptr;   // tag code per token (token filters)
 	int32_t *d_sent_start = nullptr, *d_sent_end = nullptr;
 	bool contiguous = false;   // slices are the CSR partition of the token stream
 	bool have_ids = false, have_sent = false, finalized = false;
@@ -106,6 +107,7 @@ struct vk_corpus {
 	vk_timings last{};
 	bool have_scores = false;
 	bool is_view = false;        // shares the corpus arrays of another handle (vk_corpus_view): does not free them
+	bool shares_vectors = false; // a filtered corpus of the static layout: vocabulary tiles and magnitudes belong to its source
 	vk_corpus *peer = nullptr;   // ring of the handles on one corpus: a handle's scoring kernel starts after its peer's
 	bool ev2_recorded = false;   // (device-side wait on ev[2]), so that scoring kernels run back to back, never queued inside each other
 };

@@ -57,9 +57,6 @@ class PreparedQuery:
 	def __init__(self, query, vocab, nlp):
 		self._query = query
 		raw = list((nlp or default_tokenizer)(query.text))
-		for attr in ("pos_filter", "tag_filter"):
-			if query.options.get(attr):
-				raise NotImplementedError(f"{attr} is not implemented on the HIP path")
 		# nlp may return plain strings, or dicts with 'text' / 'pos' / 'tag' (as spaCy's doc.to_json()["tokens"])
 		tokens, self._pos, self._tags = [], [], []
 		for t in raw:
@@ -276,7 +273,8 @@ class HipMatch(Match):
 	"""one winner of a search; what CoreMatch (vectorian/index.py:295-379) exposes, computed
 	from the C-ABI result arrays"""
 
-	def __init__(self, index, query, doc_index, slice_id, token_at, len_s, score, raw_score, mapping, edge_sim, gaps, transport_flow=None):
+	def __init__(self, index, query, doc_index, slice_id, token_at, len_s, score, raw_score, mapping, edge_sim, gaps, transport_flow=None, index_map=None):
+		self._index_map = index_map   # token filter: position among the slice's passing tokens -> position in the slice
 		self._transport_flow = transport_flow   # callable -> flow dict of a transport metric (sparse / dense), or None
 		self._index = index
 		self._query = query
@@ -381,6 +379,9 @@ class HipMatch(Match):
 		gap_s, gap_t = self._gaps
 		token_at = self._token_at
 		all_edges = self._edges()
+		if self._index_map is not None:
+			# targets count the tokens that pass the query's token filter; back to slice positions (flow.cpp:49-60,96-97)
+			all_edges = [(int(self._index_map[e[0]]),) + tuple(e[1:]) for e in all_edges]
 		all_edges.sort(key=lambda e: (e[0], -e[2]))      # by target, biggest flow first (flow.cpp:32-41)
 		edges = [(e[0], e[1]) for e in all_edges]
 		weight = {(e[0], e[1]): (e[2], e[3]) for e in all_edges}
@@ -590,9 +591,17 @@ class HipBruteForceIndex(Index):
 		else:
 			raise TypeError(emb)
 		self._has_pos = all(doc.pos is not None for doc in session.documents) and len(session.documents) > 0
-		if self._has_pos and n_tokens_dev:
-			self._corpus.set_token_pos(np.array(
-				[session.pos_code(x) for doc in session.documents for x in doc.pos], dtype=np.int8)[t0:t1])
+		self._has_tags = all(doc.tags is not None for doc in session.documents) and len(session.documents) > 0
+		self._pos_codes = self._tag_codes = None   # per corpus token, host copies (token filters: index maps of the winners)
+		if self._has_pos:
+			self._pos_codes = np.array([session.pos_code(x) for doc in session.documents for x in doc.pos], dtype=np.int8)
+			if n_tokens_dev:
+				self._corpus.set_token_pos(self._pos_codes[t0:t1])
+		if self._has_tags:
+			self._tag_codes = np.array([session.tag_code(x) for doc in session.documents for x in doc.tags], dtype=np.int8)
+			if n_tokens_dev:
+				self._corpus.set_token_tags(self._tag_codes[t0:t1])
+		self._filtered = collections.OrderedDict()   # (pos_mask, tag_mask) -> filtered corpus; the last two filters stay resident
 		if dev_off is not None:
 			self._corpus.set_sentences(dev_off)
 		else:
@@ -669,11 +678,13 @@ class HipBruteForceIndex(Index):
 			args["similarity_threshold"] = tw["similarity_threshold"]
 		emb = self._embedding
 		qv = emb.encode_tokens(p_query.tokens)
+		masks = self._filter_masks(query.options)
+		corpus = self._filtered_corpus(masks) if masks else self._corpus
 		if emb.is_static:
-			top = self._corpus.query(qv.unmodified, q_normalize=True, q_token_ids=p_query.token_ids,
+			top = corpus.query(qv.unmodified, q_normalize=True, q_token_ids=p_query.token_ids,
 				boost=self._dev_boost, want_flow=True, **args)
 		else:
-			top = self._corpus.query(qv.unmodified, q_normalize=True, boost=self._dev_boost, want_flow=True, **args)
+			top = corpus.query(qv.unmodified, q_normalize=True, boost=self._dev_boost, want_flow=True, **args)
 		if self._shard is not None:
 			# local slice ids -> global, then ResultSet.extend across the ranks; every rank gets the same set
 			# (the rows / plans of transport winners stay on their rank: their flows are not stated in sharded mode)
@@ -681,19 +692,56 @@ class HipBruteForceIndex(Index):
 			top = shards.allgather_merge(top, self._slice_off, args["max_matches"], group=self._group)
 		if progress:
 			progress(1.0)
-		return self._matches_from_topk(p_query, top, gaps, args, np.asarray(qv.magnitudes, dtype=np.float32))
+		return self._matches_from_topk(p_query, top, gaps, args, np.asarray(qv.magnitudes, dtype=np.float32), masks)
 
-	def _transport_flow(self, p_query, top, i, g, args, qmag):
+	def _filter_masks(self, options):
+		"""pos_filter / tag_filter: lists of POS / tag names whose tokens are dropped from every slice for this query
+		(Query::make_token_filter, vectorian/core/cpp/query.cpp:220-228; parse_filter_mask, query.h:33-55).
+		Returns (pos_mask, tag_mask) or None."""
+		masks = []
+		for name, lookup, have in (("pos_filter", self.session.pos_id, self._has_pos), ("tag_filter", self.session.tag_id, self._has_tags)):
+			m = 0
+			for x in options.get(name) or ():
+				i = lookup(str(x)) if have else -1
+				if i < 0 or i > 63:
+					raise RuntimeError(f"illegal value {x} for {name}")   # query.h:45-49
+				m |= 1 << i
+			masks.append(m)
+		return tuple(masks) if any(masks) else None
+
+	def _filtered_corpus(self, masks):
+		c = self._filtered.pop(masks, None)
+		if c is None:
+			c = self._corpus.filtered(*masks)
+			while len(self._filtered) >= 2:
+				self._filtered.popitem(last=False)[1].close()
+		self._filtered[masks] = c
+		return c
+
+	def _index_map(self, g, masks):
+		"""positions of the tokens of slice g that pass the filter (the index_map of Flow::py_regions, flow.cpp:49-60)"""
+		a, b = int(self._slice_start[g]), int(self._slice_end[g])
+		drop = np.zeros(b - a, dtype=bool)
+		for mask, codes in zip(masks, (self._pos_codes, self._tag_codes)):
+			if mask and codes is not None:
+				cd = codes[a:b].astype(np.int64)
+				bits = np.array([(mask >> b) & 1 for b in range(64)], dtype=bool)   # codes 0..63 have a bit (query.h:13-14)
+				drop |= (cd >= 0) & (cd < 64) & bits[np.clip(cd, 0, 63)]
+		return np.nonzero(~drop)[0]
+
+	def _transport_flow(self, p_query, top, i, g, args, qmag, index_map=None):
 		"""flow of winner i of a transport query, stated from the similarity rows / plan the backend returned"""
 		if getattr(top, "sim_rows", None) is None:
 			return None
 		a, b = int(self._slice_start[g]), int(self._slice_end[g])
-		len_s, len_t = b - a, len(p_query)
+		len_s, len_t = (b - a if index_map is None else len(index_map)), len(p_query)
 		if len_s > core.VK_FAST_SENT_LEN or len_t > core.VK_FAST_QUERY_LEN:
 			return None
 		S = top.sim_rows[i][:len_s, :len_t].copy()
 		G = top.plan[i][:len_t, :len_s].copy()
 		ids_s = self._token_ids[a:b] if self._token_ids is not None else None
+		if ids_s is not None and index_map is not None:
+			ids_s = ids_s[index_map]
 		ids_t = p_query.token_ids if self._token_ids is not None else None
 		if args["algorithm"] == core.VK_ALG_WRD:
 			mass = qmag / qmag.sum() if args.get("wrd_normalize", True) else qmag
@@ -704,20 +752,25 @@ class HipBruteForceIndex(Index):
 			return lambda: dense_flow(S, G, ids_s, ids_t, np.full(len_t, unit, dtype=np.float32))
 		return lambda: rwmd_sparse_flow(S, ids_s, ids_t, injective, symmetric, nbow)
 
-	def _matches_from_topk(self, p_query, top, gaps, args=None, qmag=None):
+	def _matches_from_topk(self, p_query, top, gaps, args=None, qmag=None, masks=None):
 		matches = []
 		transport = args is not None and args.get("algorithm", core.VK_ALG_ALIGN) != core.VK_ALG_ALIGN
 		for i in range(top.n):
 			g = int(top.sentence[i])
 			di = int(self._slice_doc[g])
+			index_map = self._index_map(g, masks) if masks else None
 			matches.append(HipMatch(
 				self, p_query, di, self._slice_id[g], self._slice_token_at[g],
 				int(self._slice_end[g] - self._slice_start[g]),
 				top.score[i], top.raw_score[i], top.mapping[i].copy(), top.edge_sim[i].copy(), gaps,
-				transport_flow=self._transport_flow(p_query, top, i, g, args, qmag) if transport else None))
+				transport_flow=self._transport_flow(p_query, top, i, g, args, qmag, index_map) if transport else None,
+				index_map=index_map))
 		return matches
 
 	def close(self):
+		for c in self._filtered.values():
+			c.close()
+		self._filtered.clear()
 		self._corpus.close()
 
 

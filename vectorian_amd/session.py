@@ -151,6 +151,7 @@ class Session:
 						raise RuntimeError(f"doc {doc.unique_id or i} misses contextual embedding {embedding.name}")
 		self._embedding_encoders = collections.OrderedDict((e.name, e) for e in self._token_embeddings)
 		self._pos_codes = {}
+		self._tag_codes = {}
 		self._vocab = Vocabulary()
 		self._doc_token_ids = []
 		for doc in corpus:
@@ -184,6 +185,23 @@ class Session:
 				raise ValueError("more than 127 distinct POS values")
 			self._pos_codes[pos] = c
 		return c
+
+	def tag_code(self, tag):
+		"""small integer per fine-grained tag string (Token.tag, int8, common.h:34-42)"""
+		c = self._tag_codes.get(tag)
+		if c is None:
+			c = len(self._tag_codes) + 1
+			if c > 127:
+				raise ValueError("more than 127 distinct tag values")
+			self._tag_codes[tag] = c
+		return c
+
+	def pos_id(self, pos):
+		"""code of a POS string seen in the documents, -1 otherwise (Vocabulary::unsafe_pos_id, vocabulary.h:392-394)"""
+		return self._pos_codes.get(pos, -1)
+
+	def tag_id(self, tag):
+		return self._tag_codes.get(tag, -1)
 
 	@property
 	def encoders(self):
