@@ -64,6 +64,11 @@ __device__ __forceinline__ float dpp_f(float old, float src) {
 	return __builtin_bit_cast(float,
 		__builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL, 0xf, 0xf, false));
 }
+// lanes without a source lane read zero (bound_ctrl): lets the compiler fold the move into the consuming VALU op
+template <int CTRL>
+__device__ __forceinline__ float dpp_zero(float src) {
+	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), CTRL, 0xf, 0xf, true));
+}
 #define DPP_ROW_SHR1 0x111
 #define DPP_ROW_SHR2 0x112
 #define DPP_ROW_SHR4 0x114
@@ -263,15 +268,21 @@ struct DpArgs {
 // recurrence in the last bit (c - 2 gt is rounded once, (c - gt) - gt twice); scores are compared at
 // 1e-4, and the tracebacks of the winners come from vk_flow_kernel, which walks the recurrence
 // sequentially.  The border column enters as H[u][0] - (v + 1) gt (non-LOCAL only).
-template <int K>
-__device__ __forceinline__ float shr_k(float old, float src) { return dpp_f<0x110 + K>(old, src); }
+// The decays per lane: s g where column v - s exists, +inf where it does not, so that each step is one
+// v_sub_f32_dpp with zero fill (0 - inf = -inf drops out of the maximum) and one v_max_f32.
+struct DecaySteps { float g1, g2, g4, g8; };
+
+__device__ __forceinline__ DecaySteps decay_steps(float g, int v) {
+	const float inf = __builtin_inff();
+	return {v >= 1 ? g : inf, v >= 2 ? 2.0f * g : inf, v >= 4 ? 4.0f * g : inf, v >= 8 ? 8.0f * g : inf};
+}
 
 template <int LT>
-__device__ __forceinline__ float decay_scan(float x, float g) {
-	x = fmaxf(x, shr_k<1>(VK_NEG_INF, x) - g);
-	if (LT > 2) x = fmaxf(x, shr_k<2>(VK_NEG_INF, x) - 2.0f * g);
-	if (LT > 4) x = fmaxf(x, shr_k<4>(VK_NEG_INF, x) - 4.0f * g);
-	if (LT > 8) x = fmaxf(x, shr_k<8>(VK_NEG_INF, x) - 8.0f * g);
+__device__ __forceinline__ float decay_scan(float x, const DecaySteps &d) {
+	x = fmaxf(x, dpp_zero<0x111>(x) - d.g1);
+	if (LT > 2) x = fmaxf(x, dpp_zero<0x112>(x) - d.g2);
+	if (LT > 4) x = fmaxf(x, dpp_zero<0x114>(x) - d.g4);
+	if (LT > 8) x = fmaxf(x, dpp_zero<0x118>(x) - d.g8);
 	return x;
 }
 
@@ -285,6 +296,8 @@ __device__ __forceinline__ float dp_linear(const float *__restrict__ S, int rowb
 	const bool last_col = v == a.len_t - 1;
 	const float gt_v1 = gt * (float)(v + 1);     // distance of this column from the border column
 
+	const DecaySteps dt = decay_steps(gt, v);
+
 	float h = is_global ? -gt_v1 : 0.0f;  // H[0][v+1]
 	float best = 0.0f;
 	for (int u = 1; u <= maxlen; u++) {
@@ -295,7 +308,7 @@ __device__ __forceinline__ float dp_linear(const float *__restrict__ S, int rowb
 		const float diag = dpp_f<DPP_ROW_SHR1>(bprev, h);
 		float c = fmaxf(diag + s, floor0);
 		c = fmaxf(c, h - gs);
-		float hn = decay_scan<LT>(c, gt);
+		float hn = decay_scan<LT>(c, dt);
 		if (!is_local) hn = fmaxf(hn, bcur - gt_v1);
 		h = act ? hn : h;
 		if (is_local || last_col) best = fmaxf(best, h);
@@ -323,6 +336,7 @@ __device__ VK_DP_INLINE float dp_affine(const float *__restrict__ S, int rowbase
 	float h = is_global ? -(a_t + bt * (float)(v + 1)) : 0.0f;
 	float e = VK_NEG_INF;                       // E[0][j]
 	float best = 0.0f;
+	const DecaySteps dt = decay_steps(bt, v);
 	for (int u = 1; u <= maxlen; u++) {
 		const bool act = u <= len;
 		const float s = S[(rowbase + (act ? u - 1 : 0)) * LT + v];
@@ -338,7 +352,7 @@ __device__ VK_DP_INLINE float dp_affine(const float *__restrict__ S, int rowbase
 			// opening costs at least an extension, so extending a gap never loses against reopening it from the same
 			// cell: F[u][j] = max_k (c[j-k] - open_t - (k-1) bt), the decayed prefix maximum of c shifted by one
 			// column (the border column enters at lane 0).  Last-bit differences as in dp_linear.
-			f = decay_scan<LT>(dpp_f<DPP_ROW_SHR1>(bcur, c) - open_t, bt);
+			f = decay_scan<LT>(dpp_f<DPP_ROW_SHR1>(bcur, c) - open_t, dt);
 			hc = fmaxf(c, f);
 		} else {
 #pragma unroll
@@ -428,6 +442,13 @@ __device__ __forceinline__ float dp_general_reg(const float *__restrict__ S, int
 	const bool last_col = v == a.len_t - 1;
 	const float wt_border = a.wt[v + 1];             // distance from the border column to column v + 1
 
+	// in-row gap costs per lane: w_t(k) where column v - k exists, +inf where it does not.  The candidate is then ONE
+	// v_sub_f32_dpp (zero fill for the missing source lanes: 0 - inf = -inf drops out of the maximum) instead of a
+	// preset, a DPP move and a subtract.
+	float wtv[LT];
+#pragma unroll
+	for (int k = 1; k < LT; k++) wtv[k] = v >= k ? wtr[k] : __builtin_inff();
+
 	float hreg[MAXLEN + 1];
 	float h = is_global ? -wt_border : 0.0f;
 	hreg[0] = h;
@@ -444,21 +465,21 @@ __device__ __forceinline__ float dp_general_reg(const float *__restrict__ S, int
 #pragma unroll
 			for (int k = 1; k <= u; k++) c = fmaxf(c, hreg[u - k] - wsr[k]);
 			float hc = fmaxf(c, bcur - wt_border);
-			if (LT > 1) hc = fmaxf(hc, dpp_f<0x111>(VK_NEG_INF, c) - wtr[1]);
-			if (LT > 2) hc = fmaxf(hc, dpp_f<0x112>(VK_NEG_INF, c) - wtr[2]);
-			if (LT > 3) hc = fmaxf(hc, dpp_f<0x113>(VK_NEG_INF, c) - wtr[3]);
-			if (LT > 4) hc = fmaxf(hc, dpp_f<0x114>(VK_NEG_INF, c) - wtr[4]);
-			if (LT > 5) hc = fmaxf(hc, dpp_f<0x115>(VK_NEG_INF, c) - wtr[5]);
-			if (LT > 6) hc = fmaxf(hc, dpp_f<0x116>(VK_NEG_INF, c) - wtr[6]);
-			if (LT > 7) hc = fmaxf(hc, dpp_f<0x117>(VK_NEG_INF, c) - wtr[7]);
-			if (LT > 8) hc = fmaxf(hc, dpp_f<0x118>(VK_NEG_INF, c) - wtr[8]);
-			if (LT > 9) hc = fmaxf(hc, dpp_f<0x119>(VK_NEG_INF, c) - wtr[9]);
-			if (LT > 10) hc = fmaxf(hc, dpp_f<0x11a>(VK_NEG_INF, c) - wtr[10]);
-			if (LT > 11) hc = fmaxf(hc, dpp_f<0x11b>(VK_NEG_INF, c) - wtr[11]);
-			if (LT > 12) hc = fmaxf(hc, dpp_f<0x11c>(VK_NEG_INF, c) - wtr[12]);
-			if (LT > 13) hc = fmaxf(hc, dpp_f<0x11d>(VK_NEG_INF, c) - wtr[13]);
-			if (LT > 14) hc = fmaxf(hc, dpp_f<0x11e>(VK_NEG_INF, c) - wtr[14]);
-			if (LT > 15) hc = fmaxf(hc, dpp_f<0x11f>(VK_NEG_INF, c) - wtr[15]);
+			if (LT > 1) hc = fmaxf(hc, dpp_zero<0x111>(c) - wtv[1]);
+			if (LT > 2) hc = fmaxf(hc, dpp_zero<0x112>(c) - wtv[2]);
+			if (LT > 3) hc = fmaxf(hc, dpp_zero<0x113>(c) - wtv[3]);
+			if (LT > 4) hc = fmaxf(hc, dpp_zero<0x114>(c) - wtv[4]);
+			if (LT > 5) hc = fmaxf(hc, dpp_zero<0x115>(c) - wtv[5]);
+			if (LT > 6) hc = fmaxf(hc, dpp_zero<0x116>(c) - wtv[6]);
+			if (LT > 7) hc = fmaxf(hc, dpp_zero<0x117>(c) - wtv[7]);
+			if (LT > 8) hc = fmaxf(hc, dpp_zero<0x118>(c) - wtv[8]);
+			if (LT > 9) hc = fmaxf(hc, dpp_zero<0x119>(c) - wtv[9]);
+			if (LT > 10) hc = fmaxf(hc, dpp_zero<0x11a>(c) - wtv[10]);
+			if (LT > 11) hc = fmaxf(hc, dpp_zero<0x11b>(c) - wtv[11]);
+			if (LT > 12) hc = fmaxf(hc, dpp_zero<0x11c>(c) - wtv[12]);
+			if (LT > 13) hc = fmaxf(hc, dpp_zero<0x11d>(c) - wtv[13]);
+			if (LT > 14) hc = fmaxf(hc, dpp_zero<0x11e>(c) - wtv[14]);
+			if (LT > 15) hc = fmaxf(hc, dpp_zero<0x11f>(c) - wtv[15]);
 			hreg[u] = hc;
 			h = act ? hc : h;
 			if (is_local || last_col) best = fmaxf(best, h);
