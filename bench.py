@@ -260,6 +260,9 @@ def main():
 
 	for i in range(args.warmup):
 		step(queries[i])
+		if i < len(handles):
+			sync()   # the first query of a handle has no predecessor to queue behind: one at a time, so that no two
+			         # scoring kernels share the GPU (afterwards a handle's kernel waits for its peer's on the device)
 	sync()
 	score_ms.clear()
 	t0 = time.perf_counter()
