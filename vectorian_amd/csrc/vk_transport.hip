@@ -23,11 +23,34 @@
 #define VK_WRD_N VK_DEV_MAX_QUERY_LEN
 #define VK_WRD_M VK_DEV_MAX_SENT_LEN
 
-// minimum of x over the wave and a lane holding it (the lowest such lane)
+// minimum of x over the wave and a lane holding it (the lowest such lane).  The 16 lanes of a DPP row are folded with
+// four cross-lane moves (quad swaps, half mirror, mirror: every lane ends with its row's minimum), the four rows through
+// v_readlane -- no LDS round trips (a ds_bpermute butterfly on doubles costs twelve of them per reduction, and the solver
+// below is one dependent chain of such reductions).
+template <int CTRL>
+__device__ __forceinline__ double dpp_min_f64(double x) {
+	const long long b = __builtin_bit_cast(long long, x);
+	const int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+	const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+	const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+	const long long b2 = ((long long)hi2 << 32) | (long long)(unsigned)lo2;
+	return fmin(x, __builtin_bit_cast(double, b2));
+}
+
+__device__ __forceinline__ double readlane_f64(double x, int src) {
+	const long long b = __builtin_bit_cast(long long, x);
+	const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
+	const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+	return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+
 __device__ __forceinline__ double wave_argmin_f64(double x, int lane, int &at) {
 	double m = x;
-#pragma unroll
-	for (int off = 32; off >= 1; off >>= 1) m = fmin(m, __shfl_xor(m, off, 64));
+	m = dpp_min_f64<0xB1>(m);    // quad_perm [1,0,3,2]
+	m = dpp_min_f64<0x4E>(m);    // quad_perm [2,3,0,1]
+	m = dpp_min_f64<0x141>(m);   // row_half_mirror
+	m = dpp_min_f64<0x140>(m);   // row_mirror
+	m = fmin(fmin(readlane_f64(m, 0), readlane_f64(m, 16)), fmin(readlane_f64(m, 32), readlane_f64(m, 48)));
 	const unsigned long long hit = __ballot(x == m);
 	at = hit ? __builtin_ctzll(hit) : 0;
 	return m;
@@ -77,9 +100,10 @@ __global__ __launch_bounds__(64) void vk_wrd_exact_kernel(VkWrdParams p) {
 	double dem = 0.0;
 	if (p.mass_mode == 0) {
 		const bool by_id = p.layout == VK_DEV_LAYOUT_STATIC;       // static layout: magnitudes of the vocabulary entries
-		float sum_s = 0.0f;
-		for (int i = 0; i < m; i++) sum_s += by_id ? p.mag[p.tok_id[t_a + i]] : p.mag[t_a + i];       // in position order, as upstream
+		// one load per lane; the sum runs in position order, as upstream (the wave holds one slice: m is uniform)
 		const float mine = has ? (by_id ? p.mag[p.tok_id[t_a + lane]] : p.mag[t_a + lane]) : 0.0f;
+		float sum_s = 0.0f;
+		for (int i = 0; i < m; i++) sum_s += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), i));
 		if (has) dem = (double)(p.raw_masses ? mine : mine / sum_s);
 		if (lane < VK_WRD_N) sup[lane] = lane < n ? (double)p.qmass[lane] : 0.0;
 	} else {
@@ -98,20 +122,62 @@ __global__ __launch_bounds__(64) void vk_wrd_exact_kernel(VkWrdParams p) {
 	}
 	double pot_d = 0.0;
 	wave_lds_fence();
+	// this lane's column of the costs stays in registers; its column of the flows and the supplies' potentials are
+	// refreshed from LDS once per augmentation (LDS holds the copies that are indexed dynamically)
+	double Cr[VK_WRD_N], Fr[VK_WRD_N], Ps[VK_WRD_N];
+#pragma unroll
+	for (int j = 0; j < VK_WRD_N; j++) Cr[j] = j < n ? Cm[j * 64 + lane] : 0.0;
+
+	// ---- start: dual potentials pot_d[i] = min_j C[j][i] (all reduced costs stay >= 0, the nearest supply's arc is
+	// tight) and as much flow on the tight arcs as the supplies allow, demands served in lane order.  Flow on tight
+	// arcs keeps the optimality conditions of successive shortest paths, and most of the mass is placed here: the
+	// augmentations that remain are the ones that actually reroute.
+	// (balanced problems only: with unequal totals the side in excess is served selectively, which a greedy start cannot know)
+	if (p.raw_masses == 0 && p.mass_mode != 2) {
+		double cmin = INF;
+		int jmin = -1;
+		for (int j = 0; j < n; j++) {
+			const double cj = Cm[j * 64 + lane];
+			if (cj < cmin) { cmin = cj; jmin = j; }
+		}
+		if (has && jmin >= 0) pot_d = cmin;
+		for (int j = 0; j < n; j++) {
+			const double want = (has && jmin == j) ? dem : 0.0;
+			double incl = want;
+#pragma unroll
+			for (int off = 1; off < 64; off <<= 1) {
+				const double t = __shfl_up(incl, off, 64);
+				if (lane >= off) incl += t;
+			}
+			const double sj = sup[j];
+			const double room = sj - (incl - want);
+			const double give = fmin(want, room > 0.0 ? room : 0.0);
+			if (give > 0.0) { fl[j * 64 + lane] = give; dem -= give; }
+			const double total = __shfl(incl, 63, 64);
+			wave_lds_fence();
+			if (lane == 0) sup[j] = sj > total ? sj - total : 0.0;
+		}
+		wave_lds_fence();
+	}
 
 	for (int iter = 0; iter < 4000; iter++) {
 		// ---- sources: every supply with remaining mass; relax them all
 		bool any_sup = false;
 		double dist_d = INF;
 		int pred_d = -1;
-		for (int j = 0; j < n; j++) {
-			const bool src = sup[j] > EPS;
-			any_sup |= src;
-			if (lane == 0) { settled[j] = src ? 1 : 0; dist_s[j] = src ? 0.0 : INF; pred_s[j] = -1; }
-			if (src) {
-				double rc = Cm[j * 64 + lane] + pot_s[j] - pot_d;
+		unsigned smask = 0;   // settled supplies (uniform)
+#pragma unroll
+		for (int j = 0; j < VK_WRD_N; j++) {
+			if (j < n) {
+				Fr[j] = fl[j * 64 + lane];
+				Ps[j] = pot_s[j];
+				const bool src = sup[j] > EPS;
+				any_sup |= src;
+				if (src) smask |= 1u << j;
+				if (lane == 0) { settled[j] = src ? 1 : 0; dist_s[j] = src ? 0.0 : INF; pred_s[j] = -1; }
+				double rc = Cr[j] + Ps[j] - pot_d;
 				if (rc < 0) rc = 0;
-				if (rc < dist_d) { dist_d = rc; pred_d = j; }
+				if (src && rc < dist_d) { dist_d = rc; pred_d = j; }
 			}
 		}
 		if (!has) dist_d = INF;
@@ -126,14 +192,15 @@ __global__ __launch_bounds__(64) void vk_wrd_exact_kernel(VkWrdParams p) {
 			const double fd = wave_argmin_f64((has && dem > EPS) ? dist_d : INF, lane, fd_lane);
 			double best = INF;
 			int bb = -1;
-			if (dist_d < INF) {
-				for (int b = 0; b < n; b++) {
-					if (settled[b]) continue;
-					if (!(fl[b * 64 + lane] > EPS)) continue;
-					double rc = pot_d - pot_s[b] - Cm[b * 64 + lane];
+#pragma unroll
+			for (int b = 0; b < VK_WRD_N; b++) {
+				if (b < n) {
+					double rc = pot_d - Ps[b] - Cr[b];
 					if (rc < 0) rc = 0;
 					const double cand = dist_d + rc;
-					if (cand < best) { best = cand; bb = b; }
+					const bool ok = !((smask >> b) & 1) && Fr[b] > EPS && cand < best;   // dist_d = inf gives cand = inf: never < best
+					best = ok ? cand : best;
+					bb = ok ? b : bb;
 				}
 			}
 			const double cmin = wave_argmin_f64(best, lane, c_lane);
@@ -141,7 +208,8 @@ __global__ __launch_bounds__(64) void vk_wrd_exact_kernel(VkWrdParams p) {
 				if (fd < INF) { target = fd_lane; dt = fd; }
 				break;
 			}
-			const int cb = __shfl(bb, c_lane, 64);
+			const int cb = __builtin_amdgcn_readlane(bb, c_lane);
+			smask |= 1u << cb;
 			if (lane == 0) { settled[cb] = 1; dist_s[cb] = cmin; pred_s[cb] = c_lane; }
 			wave_lds_fence();
 			double rc = Cm[cb * 64 + lane] + pot_s[cb] - pot_d;
