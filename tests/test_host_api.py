@@ -276,6 +276,45 @@ def test_sliding_windows_overlap():
 		assert r[0].to_json()["location"]["start"] == st[r[0].slice_id]
 
 
+def test_token_mask_and_span_levels():
+	# PreparedDocument (vectorian/corpus/document.py:626-662): masked tokens disappear from the token table, every span
+	# table is re-indexed with the cumulative sum of the mask; "token" is a partition level of its own (document.cpp:52-53)
+	rng = np.random.default_rng(12)
+	words = [f"w{i}" for i in range(40)]
+	emb = StaticEmbedding("toy", words, rng.standard_normal((40, 32)).astype(np.float32))
+	sents = [[words[int(i)] for i in rng.integers(0, 40, size=int(n))] for n in (6, 9, 4, 7)]
+	n_raw = sum(len(s) for s in sents)
+	mask = rng.random(n_raw) > 0.3
+	ctx = rng.standard_normal((n_raw, 8)).astype(np.float32)
+	masked = Document(sents, token_mask=mask, contextual_embeddings={"c": ctx},
+		spans={"stanza": {"start": [0, 15], "end": [15, n_raw], "label": ["a", "b"]}})
+	# the same document written down without the dropped tokens
+	it = iter(mask)
+	kept = [[t for t in s if next(it)] for s in sents]
+	plain = Document(kept)
+	assert masked.tokens == plain.tokens and masked.n_tokens == int(mask.sum())
+	for k in ("start", "end"):
+		assert (masked.spans["sentence"][k] == plain.spans["sentence"][k]).all()
+	assert (masked.contextual_vectors("c") == ctx[mask]).all()
+	assert masked.spans["stanza"]["end"][-1] == masked.n_tokens and list(masked.spans["stanza"]["label"]) == ["a", "b"]
+	assert masked.spans["stanza"]["start"][1] == int(mask[:15].sum())
+	assert (masked.spans["token"]["end"] - masked.spans["token"]["start"] == 1).all()
+	sim = OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), alignment.LocalAlignment(gap=alignment.LinearGapCost(0.1)))
+	q = " ".join(plain.tokens[5:9])
+	res = [Session([d], embeddings=[emb]).index(sim, corpus_factory=OracleCorpus).find(q, n=4) for d in (masked, plain)]
+	assert [(m.slice_id, m.score) for m in res[0]] == [(m.slice_id, m.score) for m in res[1]]
+	# windows of 5 tokens every 2 tokens, and the two stanzas as slices
+	session = Session([masked], embeddings=[emb])
+	index = session.partition("token", 5, 2).index(sim, corpus_factory=OracleCorpus)
+	assert index.n_slices == (masked.n_tokens + 1) // 2
+	top = index.find(q, n=1)[0]
+	assert top.slice_id == 4 and abs(top.score - 1.0) < 1e-2       # tokens 5..8 lie inside the window [4, 9) only
+	index = session.partition("stanza").index(sim, corpus_factory=OracleCorpus)
+	assert index.n_slices == 2 and index.find(q, n=1)[0].slice_id == 0
+	with pytest.raises(ValueError):
+		Document(sents, spans={"token": {"start": [0], "end": [1]}})
+
+
 def test_tag_weighted_metric():
 	# 'alignment-tag-weighted' (vectorian/sim/span.py:63-71): noun matches count double, a POS mismatch is
 	# penalised, and the score is divided by the sum of the query's tag weights

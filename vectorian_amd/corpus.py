@@ -9,30 +9,62 @@ import numpy as np
 
 
 class Document:
-	def __init__(self, sentences, unique_id=None, metadata=None, contextual_embeddings=None, pos=None, tags=None):
+	def __init__(self, sentences, unique_id=None, metadata=None, contextual_embeddings=None, pos=None, tags=None,
+			spans=None, token_mask=None):
 		"""sentences: list of sentences, each a list of token strings.
 		contextual_embeddings: {embedding name: float32 [n_tokens x d]}
 		pos / tags: optional universal POS / Penn treebank tags, same nesting as `sentences`
-		(Token.pos, Token.tag of the reference, vectorian/core/cpp/common.h:34-42)"""
+		(Token.pos, Token.tag of the reference, vectorian/core/cpp/common.h:34-42)
+		spans: further partition levels, {level: {"start": int[], "end": int[]}} in token units of the unmasked text
+		(the span tables of the stored document, vectorian/corpus/document.py:641-649); the levels "sentence" (from
+		`sentences`) and "token" (one span per token, document.cpp:52-53) always exist.
+		token_mask: bool per token; False drops the token as the session's text normalisation does
+		(`flavor_record.token_mask`, document.py:636-649): tokens, tags and contextual vectors are masked and every
+		span table is re-indexed with the cumulative sum of the mask."""
 		self._sentences = [list(s) for s in sentences]
-		self._tokens = [t for s in self._sentences for t in s]
-		self._pos = [t for s in pos for t in s] if pos is not None else None
-		self._tags = [t for s in tags for t in s] if tags is not None else None
-		for name, seq in (("pos", self._pos), ("tags", self._tags)):
-			if seq is not None and len(seq) != len(self._tokens):
+		tokens = [t for s in self._sentences for t in s]
+		n_raw = len(tokens)
+		flat_pos = [t for s in pos for t in s] if pos is not None else None
+		flat_tags = [t for s in tags for t in s] if tags is not None else None
+		for name, seq in (("pos", flat_pos), ("tags", flat_tags)):
+			if seq is not None and len(seq) != n_raw:
 				raise ValueError(f"{name}: one entry per token expected")
 		lens = np.array([len(s) for s in self._sentences], dtype=np.int64)
-		self._spans = {"sentence": {
+		tables = {"sentence": {
 			"start": np.concatenate(([0], np.cumsum(lens)[:-1])).astype(np.int32) if len(lens) else np.zeros(0, np.int32),
 			"end": np.cumsum(lens).astype(np.int32)}}
-		self._unique_id = unique_id
-		self._metadata = metadata or {}
-		self._contextual = {}
+		for level, table in (spans or {}).items():
+			if level in ("sentence", "token"):
+				raise ValueError(f"span level {level} is built in")
+			st, en = np.asarray(table["start"], dtype=np.int32), np.asarray(table["end"], dtype=np.int32)
+			if st.shape != en.shape or (len(st) and (st.min() < 0 or en.max() > n_raw or (en < st).any())):
+				raise ValueError(f"span level {level}: spans outside the document")
+			tables[level] = dict((k, np.asarray(v)) for k, v in table.items())
+			tables[level]["start"], tables[level]["end"] = st, en
+		contextual = {}
 		for name, v in (contextual_embeddings or {}).items():
 			v = np.ascontiguousarray(v, dtype=np.float32)
-			if v.shape[0] != len(self._tokens):
-				raise ValueError(f"contextual embedding {name}: {v.shape[0]} vectors for {len(self._tokens)} tokens")
-			self._contextual[name] = v
+			if v.shape[0] != n_raw:
+				raise ValueError(f"contextual embedding {name}: {v.shape[0]} vectors for {n_raw} tokens")
+			contextual[name] = v
+		if token_mask is not None:
+			mask = np.asarray(token_mask, dtype=bool)
+			if mask.shape != (n_raw,):
+				raise ValueError("token_mask: one entry per token expected")
+			reindex = np.cumsum(np.concatenate(([False], mask)), dtype=np.int32)       # document.py:641
+			for table in tables.values():
+				table["start"], table["end"] = reindex[table["start"]], reindex[table["end"]]
+			tokens = [t for t, m in zip(tokens, mask) if m]
+			flat_pos = None if flat_pos is None else [t for t, m in zip(flat_pos, mask) if m]
+			flat_tags = None if flat_tags is None else [t for t, m in zip(flat_tags, mask) if m]
+			contextual = dict((k, np.ascontiguousarray(v[mask])) for k, v in contextual.items())      # MaskedVectorsRef
+		n = len(tokens)
+		tables["token"] = {"start": np.arange(n, dtype=np.int32), "end": np.arange(1, n + 1, dtype=np.int32)}
+		self._tokens, self._pos, self._tags = tokens, flat_pos, flat_tags
+		self._spans = tables
+		self._unique_id = unique_id
+		self._metadata = metadata or {}
+		self._contextual = contextual
 
 	@property
 	def unique_id(self):
