@@ -134,10 +134,26 @@ def cpu_baseline(gap_name, budget_s=12.0):
 	t0 = time.perf_counter()
 	vo.find_many(Qs=Qs, **kw)
 	el = time.perf_counter() - t0
+	# beside it: one thread, and the reference's own static layout (token ids + per-query table [V x |q|])
+	def rate(budget, n_sent, **over):
+		k2 = dict(kw, **over)
+		t1 = time.perf_counter()
+		vo.find_many(Qs=qs[:1], **k2)
+		b = int(max(1, min(1024, budget / max(time.perf_counter() - t1, 1e-6))))
+		t1 = time.perf_counter()
+		vo.find_many(Qs=[qs[i % len(qs)] for i in range(b)], **k2)
+		return n_sent * b / (time.perf_counter() - t1)
+	single = rate(3.0, n, n_threads=1)
+	n_st = 16 * n      # the per-query table over the vocabulary is amortised over the slices, as in the full workload
+	st = synth.make_static_corpus(n_st, LEN_S, LEN_S, VOCAB, D)
+	Eb = synth.to_bf16_bits(synth.normalize_rows(st["E"]))
+	static = rate(3.0, n_st, layout=vo.LAYOUT_STATIC, X=None, sent_off=st["sent_off"], tok_id=st["tok_id"], E=Eb)
 	return {
 		"value": n * batch / el, "unit": "sentence-alignments/sec", "cores": cores, "kind": "port",
+		"single_thread_value": single, "static_layout_value": static,
 		"sample": f"{batch} queries x {n} sentences x {LEN_S} tokens x {D}-d (same generator as the GPU workload), "
-			f"{cores} threads, {el:.1f} s; CPU restatement of the reference algorithm (reference not runnable offline)"}
+			f"{cores} threads, {el:.1f} s; CPU restatement of the reference algorithm (reference not runnable offline); "
+			f"single_thread_value: the same on one thread; static_layout_value: token ids + per-query table over {n_st} slices, {cores} threads"}
 
 
 def main():
