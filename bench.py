@@ -192,6 +192,9 @@ def main():
 	if world > 1 or force_dist:
 		import torch.distributed as dist
 		os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+		if force_dist and world == 1:   # no launcher in the one-rank rehearsal
+			for k_, v_ in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_PORT", "29533")):
+				os.environ.setdefault(k_, v_)
 		if backend == "nccl":
 			opts = None
 			try:   # the records are tiny and latency-bound: let the collective's kernel pass the scoring kernel in the queue
@@ -225,7 +228,9 @@ def main():
 	pool = ThreadPoolExecutor(max_workers=len(handles))
 	inflight = []      # futures of submitted queries, oldest first
 	pending = []       # exchanges of earlier queries, in flight while later ones are scored (oldest first)
-	GATHER_DEPTH = int(os.environ.get("VK_BENCH_GATHER_DEPTH", "3"))   # a collective gets this many steps to complete before anyone waits for it
+	GATHER_BATCH = max(1, int(os.environ.get("VK_BENCH_GATHER_BATCH", "4")))   # result sets of this many queries travel in one all-gather
+	GATHER_DEPTH = int(os.environ.get("VK_BENCH_GATHER_DEPTH", "1"))   # a collective gets this many further exchanges to complete before anyone waits for it
+	unsent = []        # result sets of finished queries, waiting for their exchange
 	submitted = [0]
 	score_ms = []
 
@@ -234,10 +239,16 @@ def main():
 			max_matches=K_MATCHES, min_score=0.0, want_flow=True)
 		return top, h.last_timings()["score_ms"]
 
+	def exchange():
+		if unsent:
+			# per-rank result sets -> all ranks (RCCL all-gather over xGMI), then ResultSet.extend
+			pending.append(shards.allgather_start(list(unsent), rank * n_sent, K_MATCHES, device=xdev))
+			unsent.clear()
+
 	def drain(keep=0):
 		merged = None
 		while len(pending) > keep:
-			merged = shards.allgather_finish(pending.pop(0))   # global top-k of an earlier query on every rank
+			merged = shards.allgather_finish(pending.pop(0))[-1]   # global top-k of earlier queries on every rank
 		return merged
 
 	prof = {"wait": 0.0, "start": 0.0, "finish": 0.0} if os.environ.get("VK_BENCH_PROFILE") else None
@@ -248,9 +259,10 @@ def main():
 		score_ms.append(ms)
 		if dist is None:
 			return top
-		# per-rank result sets -> all ranks (RCCL all-gather over xGMI), then ResultSet.extend
 		t_b = time.perf_counter()
-		pending.append(shards.allgather_start(top, rank * n_sent, K_MATCHES, device=xdev))
+		unsent.append(top)
+		if len(unsent) >= GATHER_BATCH:
+			exchange()
 		t_c = time.perf_counter()
 		merged = drain(keep=GATHER_DEPTH)
 		if prof is not None:
@@ -268,6 +280,7 @@ def main():
 	def sync():
 		while inflight:
 			retire()
+		exchange()
 		drain()
 		torch.cuda.synchronize()
 		if dist is not None:

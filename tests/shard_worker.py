@@ -39,6 +39,13 @@ def main(outdir):
 			out[f"{qi}_{name}_score"] = merged.score[:merged.n]
 			out[f"{qi}_{name}_sentence"] = merged.sentence[:merged.n]
 			out[f"{qi}_{name}_mapping"] = merged.mapping[:merged.n]
+	# several result sets in one exchange (bench.py: one all-gather per few queries) == one exchange each
+	tops = [shard.query(q["vectors"], locality=0, gap_s=0.1, gap_t=0.1, max_matches=12, min_score=0.0) for q in queries]
+	for qi, merged in enumerate(shards.allgather_finish(shards.allgather_start(tops, a, 12))):
+		one = shards.allgather_finish(shards.allgather_start(tops[qi], a, 12))
+		assert merged.n == one.n and (merged.sentence[:one.n] == one.sentence[:one.n]).all() and (merged.score[:one.n] == one.score[:one.n]).all()
+		out[f"{qi}_batched_sentence"] = merged.sentence[:merged.n]
+		out[f"{qi}_batched_mapping"] = merged.mapping[:merged.n]
 	np.savez(os.path.join(outdir, f"rank{rank}.npz"), **out)
 	dist.barrier()
 	dist.destroy_process_group()

@@ -54,6 +54,9 @@ def test_two_rank_gloo_matches_unsharded(tmp_path, oracle):
 				assert (g[f"{qi}_{name}_sentence"] == ref["sentence"]).all()
 				assert (g[f"{qi}_{name}_score"] == ref["score"]).all()
 				assert (g[f"{qi}_{name}_mapping"] == ref["mapping"]).all()
+				if loc == 0:   # the same queries exchanged together in one all-gather
+					assert (g[f"{qi}_batched_sentence"] == ref["sentence"]).all()
+					assert (g[f"{qi}_batched_mapping"] == ref["mapping"]).all()
 
 
 def test_sharded_index(tmp_path):

@@ -62,27 +62,68 @@ def unpack_topk(buf, len_t):
 	return t
 
 
-def allgather_start(top, sentence_offset, k, group=None, device=None):
-	"""starts the exchange of this rank's result set and returns a handle for allgather_finish; the collective
-	runs while the caller scores the next query (one query of latency hidden per step)"""
+def allgather_start(tops, sentence_offset, k, group=None, device=None):
+	"""starts the exchange of this rank's result set(s) and returns a handle for allgather_finish; the collective runs
+	while the caller scores the next queries.  `tops` may be a list: the result sets of several queries then travel
+	in ONE all-gather (the records are tiny -- 1.3 KB per query at k = 10 -- and the exchange is latency-bound: per
+	collective there is a launch, a kernel that has to find room beside the scoring kernel, and two small copies, so
+	exchanging every few queries instead of every query divides that cost)."""
 	import torch
 	import torch.distributed as dist
 
+	single = not isinstance(tops, (list, tuple))
+	if single:
+		tops = [tops]
 	world = dist.get_world_size(group)
 	if device is None:
 		device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-	send = torch.from_numpy(pack_topk(top, sentence_offset, k)).to(device, non_blocking=True)
-	recv = torch.empty((world * k, send.shape[1]), dtype=send.dtype, device=device)   # concatenated along dim 0
+	rows = np.concatenate([pack_topk(t, sentence_offset, k) for t in tops])     # [len(tops) * k, words]
+	on_gpu = torch.device(device).type == "cuda"
+	if on_gpu:
+		# pinned staging on both sides and a stream of its own: no pageable copies, nothing on the default stream
+		stream = _exchange_stream(device)
+		host = torch.empty(rows.shape, dtype=torch.int32, pin_memory=True)
+		host.numpy()[:] = rows
+		back = torch.empty((world * rows.shape[0], rows.shape[1]), dtype=torch.int32, pin_memory=True)
+		with torch.cuda.stream(stream):
+			send = host.to(device, non_blocking=True)
+			recv = torch.empty((world * rows.shape[0], rows.shape[1]), dtype=torch.int32, device=device)   # concatenated along dim 0
+			work = dist.all_gather_into_tensor(recv, send, group=group, async_op=True)
+			work.wait()                          # orders the side stream behind the collective; does not block the host
+			back.copy_(recv, non_blocking=True)
+			done = torch.cuda.Event()
+			done.record(stream)
+		return dict(done=done, back=back, keep=(host, send, recv, work), world=world, k=k, n=len(tops), len_t=[t.len_t for t in tops], single=single)
+	send = torch.from_numpy(rows)
+	recv = torch.empty((world * rows.shape[0], rows.shape[1]), dtype=send.dtype)
 	work = dist.all_gather_into_tensor(recv, send, group=group, async_op=True)
-	return work, recv, send, world, k, top.len_t
+	return dict(work=work, back=recv, keep=(send,), world=world, k=k, n=len(tops), len_t=[t.len_t for t in tops], single=single)
+
+
+_streams = {}
+
+
+def _exchange_stream(device):
+	import torch
+	key = str(torch.device(device))
+	if key not in _streams:
+		_streams[key] = torch.cuda.Stream(device=device)
+	return _streams[key]
 
 
 def allgather_finish(handle):
-	work, recv, send, world, k, len_t = handle
-	work.wait()
-	allr = recv.cpu().numpy().reshape(world, k, send.shape[1])
-	sets = [unpack_topk(allr[r], len_t) for r in range(world)]
-	return core.merge_topk(sets, len_t, k)
+	"""the merged global result set of every query of the exchange (one TopK, or a list if a list was started)"""
+	if "done" in handle:
+		handle["done"].synchronize()
+	else:
+		handle["work"].wait()
+	world, k, n = handle["world"], handle["k"], handle["n"]
+	allr = handle["back"].numpy().reshape(world, n, k, -1)
+	out = []
+	for i in range(n):
+		sets = [unpack_topk(allr[r, i], handle["len_t"][i]) for r in range(world)]
+		out.append(core.merge_topk(sets, handle["len_t"][i], k))
+	return out[0] if handle["single"] else out
 
 
 def allgather_merge(top, sentence_offset, k, group=None, device=None):
