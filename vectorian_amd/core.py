@@ -221,6 +221,15 @@ class TopK:
 		self.plan = np.zeros((k, 16, VK_FAST_SENT_LEN), dtype=np.float32) if transport else None
 		self.n = 0
 
+	@classmethod
+	def over(cls, k, len_t, score, raw_score, sentence, mapping, edge_sim):
+		"""a result set over rows of arrays allocated for a whole batch"""
+		t = cls.__new__(cls)
+		t.k, t.len_t, t.n = k, len_t, 0
+		t.score, t.raw_score, t.sentence, t.mapping, t.edge_sim = score, raw_score, sentence, mapping, edge_sim
+		t.sim_rows = t.plan = None
+		return t
+
 	def _struct(self):
 		s = _TopkOut()
 		s.capacity, s.n_out = self.k, self.n
@@ -380,6 +389,10 @@ class Corpus:
 		# and POS codes are per query and take the full path)
 		per_query = any(options.get(k) is not None for k in ("q_token_ids", "tag_weights", "q_pos"))
 		first = None
+		fast = self._batch_fast(queries, per_query, options, qs, sos, keep)
+		if fast is not None:
+			outs = fast
+			queries = ()
 		for i, qv in enumerate(queries):
 			if first is None or per_query:
 				q, len_t = self._desc(qv, keep, **options)
@@ -402,6 +415,45 @@ class Corpus:
 		for t, so in zip(outs, sos):
 			t.n = so.n_out
 		return outs
+
+	def _batch_fast(self, queries, per_query, options, qs, sos, keep):
+		"""large batches of equally shaped queries: one stacked query array and one allocation per result field, the
+		descriptors filled by pointer arithmetic (256 queries: 6 ms of per-query numpy / ctypes work otherwise)"""
+		n = len(queries)
+		if per_query or n < 8:
+			return None
+		arrs = [np.asarray(q) for q in queries]
+		if any(a.ndim != 2 or a.shape != arrs[0].shape or a.dtype != arrs[0].dtype for a in arrs) or arrs[0].shape[1] != self.d:
+			return None
+		if arrs[0].dtype != np.uint16:
+			arrs = [np.asarray(a, dtype=np.float32) for a in arrs]
+		Q = np.ascontiguousarray(np.stack(arrs))
+		keep.append(Q)
+		first, len_t = self._desc(Q[0], keep, **options)
+		if bool(first.want_flow) and first.algorithm != VK_ALG_ALIGN and n <= 16:
+			return None    # transport flows: per-query row / plan buffers (the general path)
+		k = max(1, first.max_matches)
+		score, raw = np.zeros((n, k), np.float32), np.zeros((n, k), np.float32)
+		sentence = np.zeros((n, k), np.int64)
+		mapping, edge = np.full((n, k, len_t), -1, np.int16), np.zeros((n, k, len_t), np.float32)
+		keep.extend((score, raw, sentence, mapping, edge))
+		# the descriptor arrays as bytes: every row a copy of the first descriptor, the pointer fields patched in one go
+		idx = np.arange(n, dtype=np.uint64)
+
+		def patch(rows, field, arr):
+			rows[:, field.offset:field.offset + 8].view(np.uint64)[:, 0] = np.uint64(arr.ctypes.data) + idx * np.uint64(arr.strides[0])
+
+		qrows = np.frombuffer(qs, dtype=np.uint8).reshape(n, C.sizeof(_QueryDesc))
+		qrows[:] = np.frombuffer(first, dtype=np.uint8)
+		patch(qrows, _QueryDesc.q_vectors, Q)
+		proto = _TopkOut()
+		proto.capacity, proto.n_out = k, 0
+		orows = np.frombuffer(sos, dtype=np.uint8).reshape(n, C.sizeof(_TopkOut))
+		orows[:] = np.frombuffer(proto, dtype=np.uint8)
+		for field, arr in ((_TopkOut.score, score), (_TopkOut.raw_score, raw), (_TopkOut.sentence, sentence),
+				(_TopkOut.mapping, mapping), (_TopkOut.edge_sim, edge)):
+			patch(orows, field, arr)
+		return [TopK.over(k, len_t, score[i], raw[i], sentence[i], mapping[i], edge[i]) for i in range(n)]
 
 	def last_scores(self):
 		s = np.empty(self.n_sentences, dtype=np.float32)

@@ -5,6 +5,8 @@
 
 #include "vk_internal.h"
 
+#include <thread>
+
 static bool same_gap(const vk_gap &a, const vk_gap &b, int upto) {
 	if (a.kind != b.kind) return false;
 	if (a.kind != VK_GAP_TABLE) return a.u == b.u && (a.kind == VK_GAP_LINEAR || a.v == b.v);
@@ -279,10 +281,13 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 	}
 
 	VK_HIP(hipEventRecord(c->ev[0], st));
-	std::vector<uint8_t> all((size_t)need_q, 0), one;
+	std::vector<uint8_t> all((size_t)need_q, 0);
 	std::vector<int32_t> qlen((size_t)n_queries);
+	// normalise, round and lay out the queries: a few host threads over disjoint query ranges (256 queries: 1.6 ms on one)
+	auto pack_range = [&](int i0, int i1) {
+	std::vector<uint8_t> one;
 	float mags[VK_MAX_QUERY_LEN];
-	for (int i = 0; i < n_queries; i++) {
+	for (int i = i0; i < i1; i++) {
 		vk_pack_query(c, &qs[i], one, mags);
 		qlen[(size_t)i] = qs[i].len_t;
 		if (!b32) {
@@ -306,6 +311,16 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 				memcpy(dst + off, one.data() + src, 16);
 			}
 		}
+	}
+	};
+	{
+		const int n_thr = n_queries >= 32 ? std::min<int>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
+		std::vector<std::thread> pool;
+		const int per = (n_queries + n_thr - 1) / n_thr;
+		for (int t = 1; t < n_thr; t++)
+			if (t * per < n_queries) pool.emplace_back(pack_range, t * per, std::min(n_queries, (t + 1) * per));
+		pack_range(0, std::min(n_queries, per));
+		for (auto &th : pool) th.join();
 	}
 	VK_HIP(hipMemcpyAsync(c->d_bq, all.data(), all.size(), hipMemcpyHostToDevice, st));
 	VK_HIP(hipMemcpyAsync(c->d_bqlen, qlen.data(), qlen.size() * 4, hipMemcpyHostToDevice, st));
