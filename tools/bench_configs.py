@@ -35,6 +35,7 @@ def main():
 	ap.add_argument("--layout", choices=["contextual", "static"], default="contextual")
 	ap.add_argument("--batch", type=int, default=0, help="queries per vk_query_batch call (config 4: 256)")
 	ap.add_argument("--precision", choices=["bf16", "f32"], default="bf16", help="how the unit rows are kept in HBM")
+	ap.add_argument("--handles", type=int, default=1, help="queries in flight (vk_corpus_view handles, one host thread each), as bench.py keeps them")
 	ap.add_argument("--filter", type=float, default=0.0, help="share of tokens a pos_filter drops: times vk_corpus_filter, then queries the filtered corpus")
 	args = ap.parse_args()
 
@@ -179,11 +180,38 @@ def main():
 		step(qs[i])
 	torch.cuda.synchronize()
 	phases = []
-	t0 = time.perf_counter()
-	for i in range(args.steps):
-		top = step(qs[args.warmup + i])
-		phases.append(corpus.last_timings())
-	el = time.perf_counter() - t0
+	if args.handles > 1:
+		# several queries in flight: the selection / exact stage / traceback of one query beside the scoring kernel of the next
+		from concurrent.futures import ThreadPoolExecutor
+		handles = [corpus] + [corpus.view() for _ in range(args.handles - 1)]
+
+		def run(h, q):
+			r = h.query(q, algorithm=alg, locality=loc, gap_s=gap, gap_t=gap, q_normalize=True, max_matches=args.k,
+				min_score=0.0 if loc != 1 else -1e9, want_flow=args.alg == "align")
+			return r, h.last_timings()
+		with ThreadPoolExecutor(max_workers=len(handles)) as pool:
+			for h in handles:
+				run(h, qs[0])          # one at a time first: a handle's kernel queues behind its peer's from the second query on
+			torch.cuda.synchronize()
+			t0 = time.perf_counter()
+			futs = []
+			for i in range(args.steps):
+				if len(futs) >= len(handles):
+					top, ph = futs.pop(0).result()
+					phases.append(ph)
+				futs.append(pool.submit(run, handles[i % len(handles)], qs[args.warmup + i]))
+			for f in futs:
+				top, ph = f.result()
+				phases.append(ph)
+			el = time.perf_counter() - t0
+		for h in handles[1:]:
+			h.close()
+	else:
+		t0 = time.perf_counter()
+		for i in range(args.steps):
+			top = step(qs[args.warmup + i])
+			phases.append(corpus.last_timings())
+		el = time.perf_counter() - t0
 	score_ms = float(np.mean([p["score_ms"] for p in phases]))
 	bytes_alg = n_tok * args.d * 2
 	print(json.dumps({
@@ -193,7 +221,7 @@ def main():
 		"score_kernel_ms": score_ms, "score_kernel_GBps": bytes_alg / (score_ms * 1e-3) / 1e9,
 		"hbm_frac_of_8TBps": bytes_alg / (score_ms * 1e-3) / 8e12,
 		"phases_ms_mean": {k: float(np.mean([p[k] for p in phases])) for k in phases[0]},
-		"top_score": float(top.score[0]) if top.n else None, "filter_build_ms": filter_ms}))
+		"top_score": float(top.score[0]) if top.n else None, "filter_build_ms": filter_ms, "handles": args.handles}))
 	corpus.close()
 
 

@@ -326,6 +326,8 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		// ---- stage 2: exact EMD on the candidates with the largest bounds, until the k-th best
 		// exact score is above every remaining bound (then no unsolved sentence can enter)
 		VK_HIP(hipEventRecord(c->ev[2], st));
+		// (no turn-taking between handles here: ev2_recorded stays unset.  Two bound passes sharing the chip, each with its
+		// long epilogue, fill each other's gaps: 336 M pairs/s with three handles against 302 M/s when they queue)
 		// Round 1: the M largest bounds.  Its k-th best exact score theta prunes: every row whose bound is below
 		// theta is out; all others are solved in one launch (round 2), which then fills the GPU instead of a
 		// trickle of M-candidate rounds.
@@ -465,6 +467,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		// ---- submatch_weight: bound from raw, then exact scores of the candidates from their tracebacks, until the
 		// k-th best exact score is above every remaining bound (vk_submatch_bound_kernel)
 		VK_HIP(hipEventRecord(c->ev[2], st));
+		c->ev2_recorded = true;
 		const float wsub = q->submatch_weight, total = p.ref_total;
 		const float m_star = total * (1.0f - powf(1.0f / (wsub + 1.0f), 1.0f / wsub));
 		VK_HIP(vk_launch_submatch_bound(c->d_raw, p.boost, n, total, wsub, m_star, c->d_scores, st));
