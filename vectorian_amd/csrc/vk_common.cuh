@@ -445,7 +445,7 @@ __device__ __forceinline__ float dp_general_reg(const float *__restrict__ S, int
 	// in-row gap costs per lane: w_t(k) where column v - k exists, +inf where it does not.  The candidate is then ONE
 	// v_sub_f32_dpp (zero fill for the missing source lanes: 0 - inf = -inf drops out of the maximum) instead of a
 	// preset, a DPP move and a subtract.
-	float wtv[LT];
+	float wtv[16];
 #pragma unroll
 	for (int k = 1; k < LT; k++) wtv[k] = v >= k ? wtr[k] : __builtin_inff();
 
