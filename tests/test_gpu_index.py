@@ -54,3 +54,42 @@ def test_span_embedding_index_on_hip(hip):
 	assert [docs.index(m.prepared_doc) * 1000 + m.slice_id for m in r] == [int(i) for i in order]
 	np.testing.assert_allclose([m.score for m in r], cos[order], atol=2e-3)     # bf16 vectors
 	index.close()
+
+
+def test_filters_and_token_windows_on_hip_equal_oracle_double(hip):
+	"""pos_filter / tag_filter (vk_corpus_filter on the device against the host-side compaction of the double), a
+	token-level partition with overlapping windows, a masked document, alignment and transport strategies"""
+	from test_host_api import Corpus, Document, Session, StaticEmbedding
+	from vectorian_amd import synth
+	rng = np.random.default_rng(31)
+	V, d = 600, 96
+	words = [f"w{i}" for i in range(V)]
+	emb = StaticEmbedding("toy-96", words, synth.make_vocab(V, d))
+	pos_names, tag_names = ["NOUN", "VERB", "DET", "ADJ", "PUNCT"], ["NN", "VBZ", "DT", "JJ", ".", "NNS", "VBD"]
+	docs = []
+	for di in range(6):
+		sents, pos, tags = [], [], []
+		for _ in range(40):
+			n = int(rng.integers(3, 30))
+			sents.append([words[i] for i in synth.zipf_ids(n, V, rng)])
+			pos.append([pos_names[int(i)] for i in rng.integers(0, len(pos_names), size=n)])
+			tags.append([tag_names[int(i)] for i in rng.integers(0, len(tag_names), size=n)])
+		n_raw = sum(len(s) for s in sents)
+		docs.append(Document(sents, pos=pos, tags=tags, token_mask=(rng.random(n_raw) > 0.1) if di % 2 else None))
+	session = Session(Corpus(docs), embeddings=[emb])
+	doc = session.documents[2]
+	query = " ".join(doc.tokens[100:106])
+	for strategy in (alignment.LocalAlignment(gap=alignment.smooth_gap_cost(5)), alignment.WordMoversDistance.rwmd("nbow"),
+			alignment.WordRotatorsDistance()):
+		sim = OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), strategy)
+		for part in (session.partition("sentence"), session.partition("token", 12, 5)):
+			gpu, cpu = part.index(sim), part.index(sim, corpus_factory=OracleCorpus)
+			for options in ({}, {"pos_filter": ["DET", "PUNCT"]}, {"tag_filter": ["NN", "."], "pos_filter": ["ADJ"]}):
+				a, b = gpu.find(query, n=8, options=options), cpu.find(query, n=8, options=options)
+				assert [(m.doc_index, m.slice_id) for m in a] == [(m.doc_index, m.slice_id) for m in b], (type(strategy).__name__, options)
+				np.testing.assert_allclose([m.score for m in a], [m.score for m in b], atol=1e-4)
+				if isinstance(strategy, alignment.LocalAlignment):
+					for x, y in zip(a, b):
+						assert (x.flow["target"] == y.flow["target"]).all()
+					assert a[0].to_json()["regions"] == b[0].to_json()["regions"]
+			gpu.close()
