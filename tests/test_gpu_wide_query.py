@@ -78,3 +78,43 @@ def test_wide_query_limits(hip):
 	with pytest.raises(hip.VkError):   # exact transport stays at 16 query tokens
 		c.query(Q65[:20], algorithm=hip.VK_ALG_WRD, max_matches=3)
 	c.close()
+
+
+@pytest.mark.parametrize("len_t", [17, 19, 23, 28, 31, 32])
+def test_two_block_kernel_shapes(hip, oracle, len_t):
+	"""vk_score32_kernel (17..32 query tokens, linear / affine gaps, two slices per wave): odd slice counts, empty and
+	one-token slices, overlapping windows, every locality; scores of ALL slices against the oracle"""
+	rng = np.random.default_rng(len_t)
+	d = int(rng.choice([48, 300, 320]))
+	n = 2 * int(rng.integers(120, 200)) + 1                       # odd: the last pair has one slice
+	corpus = synth.make_contextual_corpus(n, 1, 64, 1200, d)
+	Xb = prep_contextual(corpus)
+	qs = [prep_query(q) for q in synth.make_queries(corpus, 2, len_t)]
+	# (a) the sentence partition with some empty sentences, (b) windows of three sentences (capped at 64 tokens)
+	at = np.arange(5, n, 16)
+	at = at[:len(at) // 2 * 2]                                     # an even number of empty sentences: n stays odd
+	off = np.insert(corpus["sent_off"], at, corpus["sent_off"][at])
+	n = len(off) - 1
+	assert n % 2 == 1 and (np.diff(off) == 0).sum() > 5
+	start_w = off[:-1].copy()
+	end_w = np.minimum(off[np.minimum(np.arange(n) + 3, n)], start_w + 64)
+	for windows in (False, True):
+		c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=d, n_tokens=Xb.shape[0], n_sentences=n)
+		c.append_vectors(Xb, normalize=False)
+		if windows:
+			c.set_slices(start_w, end_w)
+		else:
+			c.set_sentences(off)
+		c.finalize()
+		geo = dict(sent_off=start_w, sent_end=end_w) if windows else dict(sent_off=off)
+		for Qb in qs:
+			for loc, ms, gaps in ((0, 0.0, (0.1, 0.1)), (1, -1e9, (0.05, 0.2)), (2, -1e9, (AFF, AFF)), (0, 0.0, (AFF, 0.15)), (1, -1e9, (0.3, AFF))):
+				ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, X=Xb, Q=Qb, locality=loc, gap_s=gaps[0], gap_t=gaps[1],
+					max_matches=9, min_score=ms, want_all_scores=True, **geo)
+				got = c.query(Qb, q_normalize=False, locality=loc, gap_s=gaps[0], gap_t=gaps[1], max_matches=9, min_score=ms)
+				assert_same_results(got.trimmed(), ref)
+				lens = (end_w - start_w) if windows else np.diff(off)
+				every = c.last_scores()
+				np.testing.assert_allclose(every[lens > 0], ref["all_scores"][lens > 0], atol=1e-4)
+				assert np.isneginf(every[lens == 0]).all()
+		c.close()

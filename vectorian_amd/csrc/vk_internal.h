@@ -78,6 +78,7 @@ struct vk_corpus {
 	bool contiguous = false;   // slices are the CSR partition of the token stream
 	bool have_ids = false, have_sent = false, finalized = false;
 	int max_len = 0, max_group_tiles = 0, max_group_tokens = 0;
+	int max_pair_tiles = 0;    // tiles spanned by two consecutive rows of the slice table (vk_score32_kernel)
 	// slice table on the device: n_entries >= n_sentences rows.  Slices longer than VK_FAST_SENT_LEN sit alone in
 	// their group of 4 (padded with empty rows) and are scored by a second launch over d_long_groups.
 	int64_t n_entries = 0;

@@ -1,0 +1,193 @@
+// vk_score32.hip -- the fused scoring kernel for queries of 17..32 tokens (a whole sentence as the query) with linear
+// or affine gap costs, contextual bf16 layout, slices of at most 64 tokens.  Same plan as vk_score_kernel, two column
+// blocks wide: a wave holds TWO slices at a time, 32 lanes each (lane = query column); every token tile is loaded once
+// and multiplied with both query tiles (staged in LDS), the similarity strip has 32 columns per row, and the in-row
+// recurrence is the decayed prefix maximum of dp_linear / dp_affine carried across the two 16-lane DPP rows of a slice
+// with one row_bcast:15.  vk_wide_kernel (one wave per slice, serial in-row chain) remains the path for general gaps,
+// longer queries and the tracebacks of the winners: 29 ms per 1 M x 32-token slices there, HBM-bound here.
+#include "vk_common.cuh"
+
+// lane 15 of every 16-lane row, handed to all lanes of the NEXT row (rows 1 and 3 are the right blocks of the two slices)
+__device__ __forceinline__ float from_left_block(float x) {
+	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x142, 0xa, 0xf, false));   // row_bcast:15
+}
+
+// value of the column to the left (col - 1) of the same slice; `edge` enters at column 0
+__device__ __forceinline__ float left_neighbour(float x, float edge, int v16, int blk) {
+	const float in_row = dpp_f<DPP_ROW_SHR1>(edge, x);      // lanes 1..15 of each row; lane 0 keeps `edge`
+	const float across = from_left_block(x);                  // column 15 of the left block
+	return (blk == 1 && v16 == 0) ? across : in_row;
+}
+
+struct Decay32 { DecaySteps d; float far; };
+
+__device__ __forceinline__ Decay32 decay32_steps(float g, int v16, int blk) {
+	// within a block as decay_steps; `far`: distance in gap units from column 15 to this column of the right block
+	return {decay_steps(g, v16), blk == 1 ? (float)(v16 + 1) * g : __builtin_inff()};
+}
+
+// H[j] = max_k (x[j-k] - k g) over the 32 columns of a slice
+__device__ __forceinline__ float decay_scan32(float x, const Decay32 &s) {
+	x = decay_scan<16>(x, s.d);
+	return fmaxf(x, from_left_block(x) - s.far);              // left blocks: far = inf, candidate -inf
+}
+
+// maximum over the 32 lanes of a slice -> its lane 31
+__device__ __forceinline__ float slice_max_to_lane31(float x, int blk) {
+	x = row_max_to_lane15(x);
+	const float l = from_left_block(x);
+	return blk == 1 ? fmaxf(x, l) : x;
+}
+
+template <int GAP>
+__device__ __forceinline__ float dp32(const float *__restrict__ S, int stride, int rowbase, int len, int maxlen, int col, const VkWideParams &p) {
+	const int v16 = col & 15, blk = col >> 4;
+	const bool is_local = p.locality == VK_DEV_LOCAL, is_global = p.locality == VK_DEV_GLOBAL;
+	const float floor0 = is_local ? 0.0f : VK_NEG_INF;
+	const bool last_col = col == p.len_t - 1;
+	const float gs = p.gs, gt = p.gt;
+	const Decay32 dt = decay32_steps(gt, v16, blk);
+	float h, e = VK_NEG_INF, best = 0.0f;
+	if (GAP == 0) h = is_global ? -(gt * (float)(col + 1)) : 0.0f;
+	else h = is_global ? -(p.a_t + gt * (float)(col + 1)) : 0.0f;
+	for (int u = 1; u <= maxlen; u++) {
+		const bool act = u <= len;
+		const float s = S[(rowbase + (act ? u - 1 : 0)) * stride + (col < stride ? col : 0)];   // columns >= stride hold no query token
+		float bprev, bcur;   // border column H[u-1][0], H[u][0]
+		if (GAP == 0) {
+			const float gsb = is_global ? gs : 0.0f;
+			bprev = -(gsb * (float)(u - 1)); bcur = -(gsb * (float)u);
+		} else {
+			bprev = (is_global && u > 1) ? -(p.a_s + gs * (float)(u - 1)) : 0.0f;
+			bcur = is_global ? -(p.a_s + gs * (float)u) : 0.0f;
+		}
+		const float diag = left_neighbour(h, bprev, v16, blk);
+		float c = fmaxf(diag + s, floor0), hn;
+		if (GAP == 0) {
+			c = fmaxf(c, h - gs);
+			hn = decay_scan32(c, dt);
+			if (!is_local) hn = fmaxf(hn, bcur - gt * (float)(col + 1));
+		} else {
+			// Gotoh with open_t >= extend_t (checked by the host): F is the decayed prefix maximum of c shifted by one column
+			const float en = fmaxf(h - p.open_s, e - gs);
+			c = fmaxf(c, en);
+			const float f = decay_scan32(left_neighbour(c, bcur, v16, blk) - p.open_t, dt);
+			hn = fmaxf(c, f);
+			e = act ? en : e;
+		}
+		h = act ? hn : h;
+		if (is_local || last_col) best = fmaxf(best, h);
+	}
+	float m;
+	if (is_local) m = col < p.len_t ? best : 0.0f;
+	else if (is_global) m = last_col ? h : VK_NEG_INF;
+	else m = col < p.len_t ? fmaxf(h, last_col ? best : 0.0f) : 0.0f;
+	m = slice_max_to_lane31(m, blk);
+	return is_global ? m : fmaxf(m, 0.0f);
+}
+
+template <int GAP>
+__global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t rows_per_wave, int32_t stride) {
+	extern __shared__ float4 vk_smem32[];
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	// the two query tiles (tokens 0..15, 16..31) in LDS, shared by the block's waves
+	const int qbytes = p.nk32 * 1024;
+	for (int i = threadIdx.x; i < 2 * p.nk32 * 64; i += blockDim.x) {
+		const int t = i / (p.nk32 * 64), o = i - t * p.nk32 * 64;
+		float4 x = {0.0f, 0.0f, 0.0f, 0.0f};
+		if (!(p.tail && o >= (p.nk32 - 1) * 64 + 32)) x = *reinterpret_cast<const float4 *>(p.qtile + (int64_t)t * p.tile_bytes + o * 16);   // the half block has 32 slots
+		vk_smem32[i] = x;
+	}
+	__syncthreads();
+	const uint8_t *q0 = reinterpret_cast<const uint8_t *>(vk_smem32), *q1 = q0 + qbytes;
+	// strip rows hold the query columns padded to a multiple of 4 (stride floats), not 32: a third workgroup per CU for 20 tokens
+	float *S = reinterpret_cast<float *>(vk_smem32) + 2 * (qbytes / 4) + wv * (rows_per_wave * stride + 32);
+
+	const int half = lane >> 5, col = lane & 31;
+	const int n_pairs = (p.n_sent + 1) >> 1;
+	const int nfull = p.tail ? p.nk32 - 1 : p.nk32;
+	for (int pi = blockIdx.x * 4 + wv; pi < n_pairs; pi += gridDim.x * 4) {
+		const int s_idx = pi * 2 + half;
+		const int i0 = s_idx < p.n_sent ? s_idx : p.n_sent;      // entries >= n_sent are empty slices (padding of the table)
+		const int t_a = p.sent_start[i0], t_b = p.sent_end[i0];
+		const int len = t_b - t_a;
+		const int g_a = __builtin_amdgcn_readlane(t_a, 0), g_b = __builtin_amdgcn_readlane(t_b, 32);
+		const int maxlen = max(__builtin_amdgcn_readlane(len, 0), __builtin_amdgcn_readlane(len, 32));
+		const int tile0 = g_a >> 4;
+		const int ntiles = ((g_b + 15) >> 4) - tile0;
+		const uint8_t *tp = p.tiles + (int64_t)tile0 * p.tile_bytes;
+		for (int ti = 0; ti < ntiles; ti++) {
+			f32x4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = {0.0f, 0.0f, 0.0f, 0.0f};
+			int t = 0;
+			for (; t + 4 <= nfull; t += 4) {   // four K-steps of the token tile in flight, each feeding both query tiles
+				bf16x8 x[4];
+#pragma unroll
+				for (int i = 0; i < 4; i++) x[i] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(tp + (t + i) * 1024 + lane * 16));
+#pragma unroll
+				for (int i = 0; i < 4; i++) {
+					a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(q0 + (t + i) * 1024 + lane * 16), x[i], a0, 0, 0, 0);
+					a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(q1 + (t + i) * 1024 + lane * 16), x[i], a1, 0, 0, 0);
+				}
+			}
+			for (; t < nfull; t++) {
+				const bf16x8 x = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(tp + t * 1024 + lane * 16));
+				a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(q0 + t * 1024 + lane * 16), x, a0, 0, 0, 0);
+				a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(q1 + t * 1024 + lane * 16), x, a1, 0, 0, 0);
+			}
+			if (p.tail) {   // half-filled last K-step: lanes 32..63 contribute zeros (their LDS slots hold zeros, the token side is masked)
+				const bf16x8 x = load_half_block(tp + nfull * 1024, lane, true);
+				a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(q0 + nfull * 1024 + lane * 16), x, a0, 0, 0, 0);
+				a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(q1 + nfull * 1024 + lane * 16), x, a1, 0, 0, 0);
+			}
+#pragma unroll
+			for (int r = 0; r < 4; r++) { a0[r] = clip01(a0[r]); a1[r] = clip01(a1[r]); }
+			float *row = S + (ti * 16 + (lane & 15)) * stride + (lane >> 4) * 4;
+			*reinterpret_cast<f32x4 *>(row) = a0;
+			if (16 + (lane >> 4) * 4 < stride) *reinterpret_cast<f32x4 *>(row + 16) = a1;
+			tp += p.tile_bytes;
+		}
+		wave_lds_fence();
+		const int lenc = len > 0 ? len : 0;
+		const int rb = len > 0 ? t_a - tile0 * 16 : 0;
+		const float raw = dp32<GAP>(S, stride, rb, lenc, maxlen, col, p);
+		if (col == 31 && s_idx < p.n_sent) {
+			float val = VK_NEG_INF, r = VK_NEG_INF;
+			if (len >= 1) {   // document.h:160 skips empty slices
+				const float boost = p.boost ? p.boost[s_idx] : 1.0f;
+				r = raw;
+				val = (raw / p.ref_total) * boost;
+			}
+			p.scores[s_idx] = val;
+			p.raw[s_idx] = r;
+		}
+		wave_lds_fence();
+	}
+}
+
+static inline int strip_stride(int len_t) { return (len_t + 3) / 4 * 4; }
+
+extern "C" size_t vk_score32_lds_bytes(int32_t nk32, int32_t max_pair_tiles, int32_t len_t) {
+	return (size_t)2 * nk32 * 1024 + (size_t)4 * ((size_t)max_pair_tiles * 16 * strip_stride(len_t) + 32) * 4;
+}
+
+extern "C" hipError_t vk_launch_score32(const VkWideParams *p, int32_t max_pair_tiles, hipStream_t stream) {
+	const size_t smem = vk_score32_lds_bytes(p->nk32, max_pair_tiles, p->len_t);
+	auto kernel = p->gap_mode == 0 ? vk_score32_kernel<0> : vk_score32_kernel<1>;
+	hipError_t e;
+	if (smem > 64 * 1024) {
+		e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+		if (e != hipSuccess) return e;
+	}
+	int occ = 0;
+	e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, smem);
+	if (e != hipSuccess) return e;
+	if (occ < 1) occ = 1;
+	static const char *ov = getenv("VK_BLOCKS_PER_CU");
+	if (ov && atoi(ov) > 0 && atoi(ov) < occ) occ = atoi(ov);
+	int dev = 0, cus = 256;
+	if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+	const int want = (int)(((int64_t)(p->n_sent + 1) / 2 + 3) / 4);
+	const int grid = want < cus * occ ? (want > 0 ? want : 1) : cus * occ;
+	kernel<<<grid, 256, smem, stream>>>(*p, max_pair_tiles * 16, strip_stride(p->len_t));
+	return hipGetLastError();
+}
