@@ -118,3 +118,25 @@ def test_two_block_kernel_shapes(hip, oracle, len_t):
 				np.testing.assert_allclose(every[lens > 0], ref["all_scores"][lens > 0], atol=1e-4)
 				assert np.isneginf(every[lens == 0]).all()
 		c.close()
+
+
+@pytest.mark.parametrize("len_t", [17, 24, 32])
+def test_two_block_kernel_static_layout(hip, oracle, len_t):
+	"""the static layout (token ids + two per-query tables) on vk_score32_kernel; general gaps keep to vk_wide_kernel"""
+	corpus = synth.make_static_corpus(701, 1, 64, 900, 100, seed=40 + len_t)
+	off, ids = corpus["sent_off"], corpus["tok_id"]
+	c, Eb = hip_static_corpus(hip, corpus)
+	rng = np.random.default_rng(len_t)
+	for rep in range(2):
+		s = int(rng.integers(0, 700))
+		q_ids = ids[off[s]:off[s] + len_t].astype(np.int32)
+		if len(q_ids) < len_t:
+			q_ids = np.concatenate((q_ids, rng.integers(0, 900, size=len_t - len(q_ids)).astype(np.int32)))
+		Qb = Eb[q_ids]
+		for loc, ms, gaps in ((0, 0.0, (AFF, AFF)), (1, -1e9, (AFF, 0.1)), (2, -1e9, (0.2, AFF)), (0, 0.0, (EXP5L, EXP5L))):
+			ref = oracle.find(layout=oracle.LAYOUT_STATIC, d=100, sent_off=off, tok_id=ids, E=Eb, Q=Qb, q_ids=q_ids,
+				locality=loc, gap_s=gaps[0], gap_t=gaps[1], max_matches=10, min_score=ms, want_all_scores=True)
+			got = c.query(Qb, q_token_ids=q_ids, q_normalize=False, locality=loc, gap_s=gaps[0], gap_t=gaps[1], max_matches=10, min_score=ms)
+			assert_same_results(got.trimmed(), ref, check_mapping=False)   # repeated words: co-optimal tracebacks (DESIGN 7)
+			np.testing.assert_allclose(c.last_scores(), ref["all_scores"], atol=1e-4)
+	c.close()

@@ -1,5 +1,5 @@
 // vk_score32.hip -- the fused scoring kernel for queries of 17..32 tokens (a whole sentence as the query) with linear
-// or affine gap costs, contextual bf16 layout, slices of at most 64 tokens.  Same plan as vk_score_kernel, two column
+// or affine gap costs, slices of at most 64 tokens; bf16 contextual layout, or the static layout (token ids + tables).  Same plan as vk_score_kernel, two column
 // blocks wide: a wave holds TWO slices at a time, 32 lanes each (lane = query column); every token tile is loaded once
 // and multiplied with both query tiles (staged in LDS), the similarity strip has 32 columns per row, and the in-row
 // recurrence is the decayed prefix maximum of dp_linear / dp_affine carried across the two 16-lane DPP rows of a slice
@@ -86,13 +86,14 @@ __device__ __forceinline__ float dp32(const float *__restrict__ S, int stride, i
 	return is_global ? m : fmaxf(m, 0.0f);
 }
 
-template <int GAP>
+// STATIC: token ids + the two per-query tables [V x 16] (columns 0..15 and 16..31) instead of token tiles
+template <int GAP, bool STATIC>
 __global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t rows_per_wave, int32_t stride) {
 	extern __shared__ float4 vk_smem32[];
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	// the two query tiles (tokens 0..15, 16..31) in LDS, shared by the block's waves
-	const int qbytes = p.nk32 * 1024;
-	for (int i = threadIdx.x; i < 2 * p.nk32 * 64; i += blockDim.x) {
+	const int qbytes = STATIC ? 0 : p.nk32 * 1024;
+	for (int i = threadIdx.x; !STATIC && i < 2 * p.nk32 * 64; i += blockDim.x) {
 		const int t = i / (p.nk32 * 64), o = i - t * p.nk32 * 64;
 		float4 x = {0.0f, 0.0f, 0.0f, 0.0f};
 		if (!(p.tail && o >= (p.nk32 - 1) * 64 + 32)) x = *reinterpret_cast<const float4 *>(p.qtile + (int64_t)t * p.tile_bytes + o * 16);   // the half block has 32 slots
@@ -113,8 +114,30 @@ __global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t
 		const int len = t_b - t_a;
 		const int g_a = __builtin_amdgcn_readlane(t_a, 0), g_b = __builtin_amdgcn_readlane(t_b, 32);
 		const int maxlen = max(__builtin_amdgcn_readlane(len, 0), __builtin_amdgcn_readlane(len, 32));
-		const int tile0 = g_a >> 4;
-		const int ntiles = ((g_b + 15) >> 4) - tile0;
+		const int tile0 = STATIC ? 0 : g_a >> 4;
+		const int ntiles = STATIC ? 0 : ((g_b + 15) >> 4) - tile0;
+		if (STATIC) {
+			// gather: lane handles token (lane >> 3) + 8 it, query columns 4 (lane & 7) ..+3; id, then table row: four deep
+			const int ntok = g_b - g_a;
+			const int cb = (lane & 7) * 4;
+			const float *tab = p.table + (cb >> 4) * p.table_stride + (cb & 15);
+			for (int it0 = 0; it0 * 8 < ntok; it0 += 4) {
+				int id[4];
+				float4 val[4];
+#pragma unroll
+				for (int q4 = 0; q4 < 4; q4++) {
+					const int tk = (it0 + q4) * 8 + (lane >> 3);
+					id[q4] = p.tok_id[g_a + (tk < ntok ? tk : 0)];
+				}
+#pragma unroll
+				for (int q4 = 0; q4 < 4; q4++) val[q4] = *reinterpret_cast<const float4 *>(tab + (int64_t)id[q4] * 16);
+#pragma unroll
+				for (int q4 = 0; q4 < 4; q4++) {
+					const int tk = (it0 + q4) * 8 + (lane >> 3);
+					if (tk < ntok && cb < stride) *reinterpret_cast<float4 *>(S + tk * stride + cb) = val[q4];
+				}
+			}
+		}
 		const uint8_t *tp = p.tiles + (int64_t)tile0 * p.tile_bytes;
 		for (int ti = 0; ti < ntiles; ti++) {
 			f32x4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -148,7 +171,7 @@ __global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t
 		}
 		wave_lds_fence();
 		const int lenc = len > 0 ? len : 0;
-		const int rb = len > 0 ? t_a - tile0 * 16 : 0;
+		const int rb = len > 0 ? (STATIC ? t_a - g_a : t_a - tile0 * 16) : 0;
 		const float raw = dp32<GAP>(S, stride, rb, lenc, maxlen, col, p);
 		if (col == 31 && s_idx < p.n_sent) {
 			float val = VK_NEG_INF, r = VK_NEG_INF;
@@ -166,13 +189,16 @@ __global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t
 
 static inline int strip_stride(int len_t) { return (len_t + 3) / 4 * 4; }
 
+// nk32 = 0: static layout (no query tiles in LDS)
 extern "C" size_t vk_score32_lds_bytes(int32_t nk32, int32_t max_pair_tiles, int32_t len_t) {
 	return (size_t)2 * nk32 * 1024 + (size_t)4 * ((size_t)max_pair_tiles * 16 * strip_stride(len_t) + 32) * 4;
 }
 
 extern "C" hipError_t vk_launch_score32(const VkWideParams *p, int32_t max_pair_tiles, hipStream_t stream) {
-	const size_t smem = vk_score32_lds_bytes(p->nk32, max_pair_tiles, p->len_t);
-	auto kernel = p->gap_mode == 0 ? vk_score32_kernel<0> : vk_score32_kernel<1>;
+	const bool is_static = p->layout == VK_DEV_LAYOUT_STATIC;
+	const size_t smem = vk_score32_lds_bytes(is_static ? 0 : p->nk32, max_pair_tiles, p->len_t);
+	auto kernel = is_static ? (p->gap_mode == 0 ? vk_score32_kernel<0, true> : vk_score32_kernel<1, true>)
+		: (p->gap_mode == 0 ? vk_score32_kernel<0, false> : vk_score32_kernel<1, false>);
 	hipError_t e;
 	if (smem > 64 * 1024) {
 		e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
