@@ -108,7 +108,8 @@ def test_two_block_kernel_shapes(hip, oracle, len_t):
 		c.finalize()
 		geo = dict(sent_off=start_w, sent_end=end_w) if windows else dict(sent_off=off)
 		for Qb in qs:
-			for loc, ms, gaps in ((0, 0.0, (0.1, 0.1)), (1, -1e9, (0.05, 0.2)), (2, -1e9, (AFF, AFF)), (0, 0.0, (AFF, 0.15)), (1, -1e9, (0.3, AFF))):
+			for loc, ms, gaps in ((0, 0.0, (0.1, 0.1)), (1, -1e9, (0.05, 0.2)), (2, -1e9, (AFF, AFF)), (0, 0.0, (AFF, 0.15)), (1, -1e9, (0.3, AFF)),
+					(0, 0.0, (EXP5L, EXP5L)), (1, -1e9, (EXP5L, EXP5L)), (2, -1e9, (0.1, EXP5L))):
 				ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, X=Xb, Q=Qb, locality=loc, gap_s=gaps[0], gap_t=gaps[1],
 					max_matches=9, min_score=ms, want_all_scores=True, **geo)
 				got = c.query(Qb, q_normalize=False, locality=loc, gap_s=gaps[0], gap_t=gaps[1], max_matches=9, min_score=ms)

@@ -206,6 +206,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	}
 	for (int i = 0; i < kGapTable; i++) ws[i] = (is_align && i <= c->max_len) ? gap_cost(q->gap_s, i) : 0.0f;
 	for (int i = 0; i < 80; i++) wt[i] = (is_align && i <= q->len_t) ? gap_cost(q->gap_t, i) : 0.0f;
+	bool wide_sub = false;   // a long query whose w_t is strictly subadditive: the two-block kernel may take it
 	if (p.gap_mode == 2) {
 		// register-history kernel: needs w_t strictly subadditive over the query length
 		// (see dp_general_reg in vk_common.cuh); margin far above fp32 rounding of the DP values
@@ -214,6 +215,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 			for (int y = 1; x + y <= q->len_t; y++)
 				if (!(wt[x] + wt[y] > wt[x + y] + 1e-4f)) { sub = false; break; }
 		if (sub && !wide) p.gap_mode = c->max_short_len <= 32 ? 3 : 6;
+		wide_sub = sub && wide;
 	}
 	VK_HIP(hipMemcpyAsync(c->d_ws, ws, sizeof ws, hipMemcpyHostToDevice, st));
 	VK_HIP(hipMemcpyAsync(c->d_wt, wt, sizeof wt, hipMemcpyHostToDevice, st));
@@ -284,9 +286,13 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		// 17..32 tokens with linear / affine gaps over a bf16 contextual corpus of short slices: the fused two-block kernel
 		// (affine: the prefix-scan form of F needs open_t >= extend_t, as dp_affine)
 		const bool two_blocks = is_align && q->len_t <= 32 && (is_static || c->prec == 0) && c->n_long_groups == 0 && !p.pos_s &&
-			c->max_len <= VK_FAST_SENT_LEN && (p.gap_mode == 0 || (p.gap_mode == 1 && p.a_t >= 0.0f)) &&
+			c->max_len <= VK_FAST_SENT_LEN && (p.gap_mode == 0 || (p.gap_mode == 1 && p.a_t >= 0.0f) || (p.gap_mode == 2 && wide_sub)) &&
 			vk_score32_lds_bytes(is_static ? 0 : c->nk32, c->max_pair_tiles, q->len_t) <= 160 * 1024 && !getenv("VK_NO_SCORE32");
-		if (two_blocks) VK_HIP(vk_launch_score32(&wp, c->max_pair_tiles, st));
+		if (two_blocks) {
+			if (p.gap_mode == 2) wp.gap_mode = c->max_len <= 32 ? 3 : 6;   // register history of 32 / 64 rows
+			VK_HIP(vk_launch_score32(&wp, c->max_pair_tiles, st));
+			wp.gap_mode = p.gap_mode;                                        // the traceback kernel knows 0 / 1 / 2
+		}
 		else VK_HIP(vk_launch_wide(&wp, 0, st));
 	} else if (is_align && !is_static && q->len_t == 1 && c->uniform_len == 1 && q->locality == VK_LOCAL && !p.pos_s) {
 		// span-embedding index: one vector per slice, one query vector -> the clipped cosine is the local alignment score

@@ -3,8 +3,9 @@
 // blocks wide: a wave holds TWO slices at a time, 32 lanes each (lane = query column); every token tile is loaded once
 // and multiplied with both query tiles (staged in LDS), the similarity strip has 32 columns per row, and the in-row
 // recurrence is the decayed prefix maximum of dp_linear / dp_affine carried across the two 16-lane DPP rows of a slice
-// with one row_bcast:15.  vk_wide_kernel (one wave per slice, serial in-row chain) remains the path for general gaps,
-// longer queries and the tracebacks of the winners: 29 ms per 1 M x 32-token slices there, HBM-bound here.
+// with one row_bcast:15 (general gaps: dp32_general).  vk_wide_kernel (one wave per slice, serial in-row chain) remains
+// the path for longer queries, gap costs that are not subadditive, and the tracebacks of the winners: 29 ms per
+// 1 M x 32-token slices there (linear gap), 3.5 ms here.
 #include "vk_common.cuh"
 
 // lane 15 of every 16-lane row, handed to all lanes of the NEXT row (rows 1 and 3 are the right blocks of the two slices)
@@ -86,6 +87,78 @@ __device__ __forceinline__ float dp32(const float *__restrict__ S, int stride, i
 	return is_global ? m : fmaxf(m, 0.0f);
 }
 
+// General gap costs (Waterman-Smith-Beyer), w_t strictly subadditive (checked by the host, as for dp_general_reg): the
+// column history of each lane in registers; in-row candidates c[col - k] - w_t(k) from the lane's own block by
+// row_shr:k, and for the right block also from the 16 columns of the left block, which pass through a 64-float slot of
+// wave-private LDS (one write, four broadcast b128 reads per row) and meet per-lane costs w_t(16 + v - i).
+template <int MAXLEN>
+__device__ __forceinline__ float dp32_general(const float *__restrict__ S, int stride, int rowbase, int len, int maxlen, int col, int lane,
+	const VkWideParams &p, const float (&wsr)[MAXLEN + 1], float *__restrict__ xch) {
+	const int v16 = col & 15, blk = col >> 4;
+	const bool is_local = p.locality == VK_DEV_LOCAL, is_global = p.locality == VK_DEV_GLOBAL;
+	const float floor0 = is_local ? 0.0f : VK_NEG_INF;
+	const bool last_col = col == p.len_t - 1;
+	const float inf = __builtin_inff();
+	const float wt_border = p.wt[col + 1];
+	float wtv[16], wfar[16];
+#pragma unroll
+	for (int k = 1; k < 16; k++) wtv[k] = v16 >= k ? p.wt[k] : inf;
+#pragma unroll
+	for (int i = 0; i < 16; i++) wfar[i] = blk == 1 ? p.wt[16 + v16 - i] : inf;
+	const f32x4 *left = reinterpret_cast<const f32x4 *>(xch + (lane & 32));   // c of columns 0..15 of this slice
+
+	float hreg[MAXLEN + 1];
+	float h = is_global ? -wt_border : 0.0f;
+	hreg[0] = h;
+	float best = 0.0f;
+#pragma unroll
+	for (int u = 1; u <= MAXLEN; u++) {
+		if (u <= maxlen) {
+			const bool act = u <= len;
+			const float s = S[(rowbase + (act ? u - 1 : 0)) * stride + (col < stride ? col : 0)];
+			const float bprev = is_global ? -wsr[u - 1] : 0.0f;
+			const float bcur = is_global ? -wsr[u] : 0.0f;
+			const float diag = left_neighbour(hreg[u - 1], bprev, v16, blk);
+			float c = fmaxf(diag + s, floor0);
+#pragma unroll
+			for (int k = 1; k <= u; k++) c = fmaxf(c, hreg[u - k] - wsr[k]);
+			xch[lane] = c;
+			float hc = fmaxf(c, bcur - wt_border);
+			hc = fmaxf(hc, dpp_zero<0x111>(c) - wtv[1]);
+			hc = fmaxf(hc, dpp_zero<0x112>(c) - wtv[2]);
+			hc = fmaxf(hc, dpp_zero<0x113>(c) - wtv[3]);
+			hc = fmaxf(hc, dpp_zero<0x114>(c) - wtv[4]);
+			hc = fmaxf(hc, dpp_zero<0x115>(c) - wtv[5]);
+			hc = fmaxf(hc, dpp_zero<0x116>(c) - wtv[6]);
+			hc = fmaxf(hc, dpp_zero<0x117>(c) - wtv[7]);
+			hc = fmaxf(hc, dpp_zero<0x118>(c) - wtv[8]);
+			hc = fmaxf(hc, dpp_zero<0x119>(c) - wtv[9]);
+			hc = fmaxf(hc, dpp_zero<0x11a>(c) - wtv[10]);
+			hc = fmaxf(hc, dpp_zero<0x11b>(c) - wtv[11]);
+			hc = fmaxf(hc, dpp_zero<0x11c>(c) - wtv[12]);
+			hc = fmaxf(hc, dpp_zero<0x11d>(c) - wtv[13]);
+			hc = fmaxf(hc, dpp_zero<0x11e>(c) - wtv[14]);
+			hc = fmaxf(hc, dpp_zero<0x11f>(c) - wtv[15]);
+			wave_lds_fence();
+#pragma unroll
+			for (int g = 0; g < 4; g++) {
+				const f32x4 l = left[g];
+#pragma unroll
+				for (int r = 0; r < 4; r++) hc = fmaxf(hc, l[r] - wfar[g * 4 + r]);
+			}
+			hreg[u] = hc;
+			h = act ? hc : h;
+			if (is_local || last_col) best = fmaxf(best, h);
+		}
+	}
+	float m;
+	if (is_local) m = col < p.len_t ? best : 0.0f;
+	else if (is_global) m = last_col ? h : VK_NEG_INF;
+	else m = col < p.len_t ? fmaxf(h, last_col ? best : 0.0f) : 0.0f;
+	m = slice_max_to_lane31(m, blk);
+	return is_global ? m : fmaxf(m, 0.0f);
+}
+
 // STATIC: token ids + the two per-query tables [V x 16] (columns 0..15 and 16..31) instead of token tiles
 template <int GAP, bool STATIC>
 __global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t rows_per_wave, int32_t stride) {
@@ -102,7 +175,15 @@ __global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t
 	__syncthreads();
 	const uint8_t *q0 = reinterpret_cast<const uint8_t *>(vk_smem32), *q1 = q0 + qbytes;
 	// strip rows hold the query columns padded to a multiple of 4 (stride floats), not 32: a third workgroup per CU for 20 tokens
-	float *S = reinterpret_cast<float *>(vk_smem32) + 2 * (qbytes / 4) + wv * (rows_per_wave * stride + 32);
+	float *S = reinterpret_cast<float *>(vk_smem32) + 2 * (qbytes / 4) + wv * (rows_per_wave * stride + 64);
+
+	float *xch = S + rows_per_wave * stride;   // 64 floats behind the strip: the in-row exchange of dp32_general
+	constexpr int WSN = GAP == 6 ? 65 : 33;
+	float wsr[WSN];
+	if (GAP == 3 || GAP == 6) {
+#pragma unroll
+		for (int k = 0; k < WSN; k++) wsr[k] = p.ws[k];
+	}
 
 	const int half = lane >> 5, col = lane & 31;
 	const int n_pairs = (p.n_sent + 1) >> 1;
@@ -172,7 +253,10 @@ __global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t
 		wave_lds_fence();
 		const int lenc = len > 0 ? len : 0;
 		const int rb = len > 0 ? (STATIC ? t_a - g_a : t_a - tile0 * 16) : 0;
-		const float raw = dp32<GAP>(S, stride, rb, lenc, maxlen, col, p);
+		float raw;
+		if constexpr (GAP == 3) raw = dp32_general<32>(S, stride, rb, lenc, maxlen, col, lane, p, wsr, xch);
+		else if constexpr (GAP == 6) raw = dp32_general<64>(S, stride, rb, lenc, maxlen, col, lane, p, wsr, xch);
+		else raw = dp32<GAP>(S, stride, rb, lenc, maxlen, col, p);
 		if (col == 31 && s_idx < p.n_sent) {
 			float val = VK_NEG_INF, r = VK_NEG_INF;
 			if (len >= 1) {   // document.h:160 skips empty slices
@@ -191,14 +275,19 @@ static inline int strip_stride(int len_t) { return (len_t + 3) / 4 * 4; }
 
 // nk32 = 0: static layout (no query tiles in LDS)
 extern "C" size_t vk_score32_lds_bytes(int32_t nk32, int32_t max_pair_tiles, int32_t len_t) {
-	return (size_t)2 * nk32 * 1024 + (size_t)4 * ((size_t)max_pair_tiles * 16 * strip_stride(len_t) + 32) * 4;
+	return (size_t)2 * nk32 * 1024 + (size_t)4 * ((size_t)max_pair_tiles * 16 * strip_stride(len_t) + 64) * 4;
 }
 
 extern "C" hipError_t vk_launch_score32(const VkWideParams *p, int32_t max_pair_tiles, hipStream_t stream) {
 	const bool is_static = p->layout == VK_DEV_LAYOUT_STATIC;
 	const size_t smem = vk_score32_lds_bytes(is_static ? 0 : p->nk32, max_pair_tiles, p->len_t);
-	auto kernel = is_static ? (p->gap_mode == 0 ? vk_score32_kernel<0, true> : vk_score32_kernel<1, true>)
-		: (p->gap_mode == 0 ? vk_score32_kernel<0, false> : vk_score32_kernel<1, false>);
+	void (*kernel)(VkWideParams, int32_t, int32_t);
+	switch (p->gap_mode) {
+	case 0: kernel = is_static ? vk_score32_kernel<0, true> : vk_score32_kernel<0, false>; break;
+	case 1: kernel = is_static ? vk_score32_kernel<1, true> : vk_score32_kernel<1, false>; break;
+	case 3: kernel = is_static ? vk_score32_kernel<3, true> : vk_score32_kernel<3, false>; break;
+	default: kernel = is_static ? vk_score32_kernel<6, true> : vk_score32_kernel<6, false>; break;
+	}
 	hipError_t e;
 	if (smem > 64 * 1024) {
 		e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
