@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 EXP5 = ("table", (1 - 2.0 ** (-np.arange(0, 65) / 5)).astype(np.float32))
 
 
-@pytest.mark.parametrize("d,lo,hi,len_t", [(300, 32, 32, 10), (300, 1, 40, 5), (768, 8, 64, 16), (64, 2, 20, 3)])
+@pytest.mark.parametrize("d,lo,hi,len_t", [(300, 32, 32, 10), (300, 1, 40, 5), (768, 8, 64, 16), (64, 2, 20, 3), (300, 1, 40, 20), (64, 2, 64, 32)])
 @pytest.mark.parametrize("gap", [(0.1, 0.1), (EXP5, EXP5), (("affine", 0.2, 0.05), 0.1)])
 def test_contextual_tag_weighted(hip, oracle, d, lo, hi, len_t, gap):
 	n = 400
@@ -43,16 +43,17 @@ def test_contextual_tag_weighted(hip, oracle, d, lo, hi, len_t, gap):
 	c.close()
 
 
-def test_static_tag_weighted(hip, oracle):
+@pytest.mark.parametrize("len_t", [7, 24])
+def test_static_tag_weighted(hip, oracle, len_t):
 	corpus = synth.make_static_corpus(500, 1, 40, 2000, 300)
 	c, Eb = hip_static_corpus(hip, corpus)
 	rng = np.random.default_rng(22)
 	pos_s = rng.integers(1, 4, size=len(corpus["tok_id"])).astype(np.int8)
 	c.set_token_pos(pos_s)
-	for q in synth.make_queries(corpus, 2, 7):
+	for q in synth.make_queries(corpus, 2, len_t):
 		Qb = prep_query(q)
-		tw = rng.choice([0.5, 1.0, 3.0], size=7).astype(np.float32)
-		q_pos = rng.integers(1, 4, size=7).astype(np.int8)
+		tw = rng.choice([0.5, 1.0, 3.0], size=len_t).astype(np.float32)
+		q_pos = rng.integers(1, 4, size=len_t).astype(np.int8)
 		kw = dict(tag_weights=tw, q_pos=q_pos, pos_mismatch_penalty=0.25, similarity_threshold=0.05)
 		ref = oracle.find(layout=oracle.LAYOUT_STATIC, d=300, sent_off=corpus["sent_off"], tok_id=corpus["tok_id"], E=Eb, Q=Qb,
 			q_ids=q["ids"], pos_s=pos_s, gap_s=EXP5, gap_t=EXP5, max_matches=15, **kw)

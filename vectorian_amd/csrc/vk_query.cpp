@@ -285,7 +285,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		wp.boost = p.boost; wp.scores = c->d_scores; wp.raw = c->d_raw;
 		// 17..32 tokens with linear / affine gaps over a bf16 contextual corpus of short slices: the fused two-block kernel
 		// (affine: the prefix-scan form of F needs open_t >= extend_t, as dp_affine)
-		const bool two_blocks = is_align && q->len_t <= 32 && (is_static || c->prec == 0) && c->n_long_groups == 0 && !p.pos_s &&
+		const bool two_blocks = is_align && q->len_t <= 32 && (is_static || c->prec == 0) && c->n_long_groups == 0 &&
 			c->max_len <= VK_FAST_SENT_LEN && (p.gap_mode == 0 || (p.gap_mode == 1 && p.a_t >= 0.0f) || (p.gap_mode == 2 && wide_sub)) &&
 			vk_score32_lds_bytes(is_static ? 0 : c->nk32, c->max_pair_tiles, q->len_t) <= 160 * 1024 && !getenv("VK_NO_SCORE32");
 		if (two_blocks) {

@@ -215,7 +215,17 @@ __global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t
 #pragma unroll
 				for (int q4 = 0; q4 < 4; q4++) {
 					const int tk = (it0 + q4) * 8 + (lane >> 3);
-					if (tk < ntok && cb < stride) *reinterpret_cast<float4 *>(S + tk * stride + cb) = val[q4];
+					if (tk < ntok && cb < stride) {
+						float4 vq = val[q4];
+						if (p.pos_s) {   // tag-weighted modifier (TagWeightedSlice, slice/static.h:237-264)
+							const int ps = p.pos_s[g_a + tk];
+							vq.x = tag_weighted(vq.x, p.tw[cb + 0], ps, p.tpos[cb + 0], p.tw_keep, p.tw_threshold);
+							vq.y = tag_weighted(vq.y, p.tw[cb + 1], ps, p.tpos[cb + 1], p.tw_keep, p.tw_threshold);
+							vq.z = tag_weighted(vq.z, p.tw[cb + 2], ps, p.tpos[cb + 2], p.tw_keep, p.tw_threshold);
+							vq.w = tag_weighted(vq.w, p.tw[cb + 3], ps, p.tpos[cb + 3], p.tw_keep, p.tw_threshold);
+						}
+						*reinterpret_cast<float4 *>(S + tk * stride + cb) = vq;
+					}
 				}
 			}
 		}
@@ -245,6 +255,14 @@ __global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t
 			}
 #pragma unroll
 			for (int r = 0; r < 4; r++) { a0[r] = clip01(a0[r]); a1[r] = clip01(a1[r]); }
+			if (p.pos_s) {
+				const int ps = p.pos_s[(tile0 + ti) * 16 + (lane & 15)], cq = (lane >> 4) * 4;
+#pragma unroll
+				for (int r = 0; r < 4; r++) {
+					a0[r] = tag_weighted(a0[r], p.tw[cq + r], ps, p.tpos[cq + r], p.tw_keep, p.tw_threshold);
+					a1[r] = tag_weighted(a1[r], p.tw[16 + cq + r], ps, p.tpos[16 + cq + r], p.tw_keep, p.tw_threshold);
+				}
+			}
 			float *row = S + (ti * 16 + (lane & 15)) * stride + (lane >> 4) * 4;
 			*reinterpret_cast<f32x4 *>(row) = a0;
 			if (16 + (lane >> 4) * 4 < stride) *reinterpret_cast<f32x4 *>(row + 16) = a1;
