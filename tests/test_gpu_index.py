@@ -25,7 +25,8 @@ def test_index_find_on_hip_equals_oracle_double(hip, optimizer):
 	cpu = session.partition("sentence").index(sim, corpus_factory=OracleCorpus)
 	doc = session.documents[5]
 	st = doc.spans["sentence"]["start"][11]
-	for text in (" ".join(doc.tokens[st:st + 5]), "w3 w17 w4 w900 w2", "w1"):
+	long_query = " ".join(doc.tokens[st:st + 22])                      # a whole sentence as the query: vk_score32_kernel
+	for text in (" ".join(doc.tokens[st:st + 5]), "w3 w17 w4 w900 w2", "w1", long_query):
 		a = gpu.find(text, n=10, min_score=-100.0)
 		b = cpu.find(text, n=10, min_score=-100.0)
 		assert [(m.doc_index, m.slice_id) for m in a] == [(m.doc_index, m.slice_id) for m in b]

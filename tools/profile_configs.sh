@@ -23,3 +23,5 @@ run wrd --alg wrd --steps 6 --warmup 1
 run d768 --d 768 --min-len 8 --max-len 64 --sentences 400000 --steps 10 --warmup 2
 run span --min-len 1 --max-len 1 --len-t 1 --d 768 --sentences 8000000 --gap linear --steps 10 --warmup 2
 run static --layout static --sentences 4000000 --steps 10 --warmup 2
+run q20 --len-t 20 --gap linear --steps 10 --warmup 2
+run q20wsb --len-t 20 --gap exp5 --steps 10 --warmup 2
