@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 EXP5 = ("table", (1 - 2.0 ** (-np.arange(0, 65) / 5)).astype(np.float32))
 
 
-@pytest.mark.parametrize("d,lo,hi,len_t", [(300, 32, 32, 10), (300, 1, 40, 5), (768, 8, 64, 16), (64, 2, 20, 3), (300, 1, 40, 20), (64, 2, 64, 32)])
+@pytest.mark.parametrize("d,lo,hi,len_t", [(300, 32, 32, 10), (300, 1, 40, 5), (768, 8, 64, 16), (64, 2, 20, 3), (300, 1, 40, 20), (64, 2, 64, 32), (96, 2, 50, 45)])
 @pytest.mark.parametrize("gap", [(0.1, 0.1), (EXP5, EXP5), (("affine", 0.2, 0.05), 0.1)])
 def test_contextual_tag_weighted(hip, oracle, d, lo, hi, len_t, gap):
 	n = 400
@@ -43,7 +43,7 @@ def test_contextual_tag_weighted(hip, oracle, d, lo, hi, len_t, gap):
 	c.close()
 
 
-@pytest.mark.parametrize("len_t", [7, 24])
+@pytest.mark.parametrize("len_t", [7, 24, 40])
 def test_static_tag_weighted(hip, oracle, len_t):
 	corpus = synth.make_static_corpus(500, 1, 40, 2000, 300)
 	c, Eb = hip_static_corpus(hip, corpus)

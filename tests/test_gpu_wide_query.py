@@ -80,7 +80,7 @@ def test_wide_query_limits(hip):
 	c.close()
 
 
-@pytest.mark.parametrize("len_t", [17, 19, 23, 28, 31, 32])
+@pytest.mark.parametrize("len_t", [17, 19, 23, 28, 31, 32, 33, 40, 47, 49, 64])
 def test_two_block_kernel_shapes(hip, oracle, len_t):
 	"""vk_score32_kernel (17..32 query tokens, linear / affine gaps, two slices per wave): odd slice counts, empty and
 	one-token slices, overlapping windows, every locality; scores of ALL slices against the oracle"""
@@ -121,7 +121,7 @@ def test_two_block_kernel_shapes(hip, oracle, len_t):
 		c.close()
 
 
-@pytest.mark.parametrize("len_t", [17, 24, 32])
+@pytest.mark.parametrize("len_t", [17, 24, 32, 36, 48, 61])
 def test_two_block_kernel_static_layout(hip, oracle, len_t):
 	"""the static layout (token ids + two per-query tables) on vk_score32_kernel; general gaps keep to vk_wide_kernel"""
 	corpus = synth.make_static_corpus(701, 1, 64, 900, 100, seed=40 + len_t)

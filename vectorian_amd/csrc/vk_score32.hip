@@ -8,39 +8,56 @@
 // 1 M x 32-token slices there (linear gap), 3.5 ms here.
 #include "vk_common.cuh"
 
-// lane 15 of every 16-lane row, handed to all lanes of the NEXT row (rows 1 and 3 are the right blocks of the two slices)
+// NB = column blocks of 16 per slice: 2 (two slices per wave, queries of 17..32 tokens) or 4 (one slice, 33..64).
+// lane 15 of every 16-lane row, handed to all lanes of the NEXT row of the same slice (rows 1 and 3 for NB = 2,
+// rows 1, 2, 3 for NB = 4); the other rows read 0.
+template <int NB>
 __device__ __forceinline__ float from_left_block(float x) {
-	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x142, 0xa, 0xf, false));   // row_bcast:15
+	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x142, NB == 2 ? 0xa : 0xe, 0xf, false));   // row_bcast:15
 }
 
 // value of the column to the left (col - 1) of the same slice; `edge` enters at column 0
+template <int NB>
 __device__ __forceinline__ float left_neighbour(float x, float edge, int v16, int blk) {
 	const float in_row = dpp_f<DPP_ROW_SHR1>(edge, x);      // lanes 1..15 of each row; lane 0 keeps `edge`
-	const float across = from_left_block(x);                  // column 15 of the left block
-	return (blk == 1 && v16 == 0) ? across : in_row;
+	const float across = from_left_block<NB>(x);              // column 15 of the block to the left
+	return (blk >= 1 && v16 == 0) ? across : in_row;
 }
 
 struct Decay32 { DecaySteps d; float far; };
 
 __device__ __forceinline__ Decay32 decay32_steps(float g, int v16, int blk) {
-	// within a block as decay_steps; `far`: distance in gap units from column 15 to this column of the right block
-	return {decay_steps(g, v16), blk == 1 ? (float)(v16 + 1) * g : __builtin_inff()};
+	// within a block as decay_steps; `far`: distance in gap units from the last column of the block to the left
+	return {decay_steps(g, v16), blk >= 1 ? (float)(v16 + 1) * g : __builtin_inff()};
 }
 
-// H[j] = max_k (x[j-k] - k g) over the 32 columns of a slice
-__device__ __forceinline__ float decay_scan32(float x, const Decay32 &s) {
+// H[j] = max_k (x[j-k] - k g) over the 16 NB columns of a slice: the scan inside the blocks, then the carry from
+// block to block (one step for NB = 2; for NB = 4 three steps, each seeing the block to its left already complete)
+template <int NB>
+__device__ __forceinline__ float decay_scan32(float x, const Decay32 &s, int blk) {
 	x = decay_scan<16>(x, s.d);
-	return fmaxf(x, from_left_block(x) - s.far);              // left blocks: far = inf, candidate -inf
+	if (NB == 2) return fmaxf(x, from_left_block<NB>(x) - s.far);   // left blocks: far = inf, candidate -inf
+#pragma unroll
+	for (int r = 1; r < NB; r++) {
+		const float t = from_left_block<NB>(x) - s.far;
+		x = blk == r ? fmaxf(x, t) : x;
+	}
+	return x;
 }
 
-// maximum over the 32 lanes of a slice -> its lane 31
-__device__ __forceinline__ float slice_max_to_lane31(float x, int blk) {
+// maximum over the lanes of a slice -> its last lane
+template <int NB>
+__device__ __forceinline__ float slice_max_to_last_lane(float x, int blk) {
 	x = row_max_to_lane15(x);
-	const float l = from_left_block(x);
-	return blk == 1 ? fmaxf(x, l) : x;
+#pragma unroll
+	for (int r = 1; r < NB; r++) {
+		const float l = from_left_block<NB>(x);
+		x = blk == r ? fmaxf(x, l) : x;
+	}
+	return x;
 }
 
-template <int GAP>
+template <int GAP, int NB>
 __device__ __forceinline__ float dp32(const float *__restrict__ S, int stride, int rowbase, int len, int maxlen, int col, const VkWideParams &p) {
 	const int v16 = col & 15, blk = col >> 4;
 	const bool is_local = p.locality == VK_DEV_LOCAL, is_global = p.locality == VK_DEV_GLOBAL;
@@ -62,17 +79,17 @@ __device__ __forceinline__ float dp32(const float *__restrict__ S, int stride, i
 			bprev = (is_global && u > 1) ? -(p.a_s + gs * (float)(u - 1)) : 0.0f;
 			bcur = is_global ? -(p.a_s + gs * (float)u) : 0.0f;
 		}
-		const float diag = left_neighbour(h, bprev, v16, blk);
+		const float diag = left_neighbour<NB>(h, bprev, v16, blk);
 		float c = fmaxf(diag + s, floor0), hn;
 		if (GAP == 0) {
 			c = fmaxf(c, h - gs);
-			hn = decay_scan32(c, dt);
+			hn = decay_scan32<NB>(c, dt, blk);
 			if (!is_local) hn = fmaxf(hn, bcur - gt * (float)(col + 1));
 		} else {
 			// Gotoh with open_t >= extend_t (checked by the host): F is the decayed prefix maximum of c shifted by one column
 			const float en = fmaxf(h - p.open_s, e - gs);
 			c = fmaxf(c, en);
-			const float f = decay_scan32(left_neighbour(c, bcur, v16, blk) - p.open_t, dt);
+			const float f = decay_scan32<NB>(left_neighbour<NB>(c, bcur, v16, blk) - p.open_t, dt, blk);
 			hn = fmaxf(c, f);
 			e = act ? en : e;
 		}
@@ -83,7 +100,7 @@ __device__ __forceinline__ float dp32(const float *__restrict__ S, int stride, i
 	if (is_local) m = col < p.len_t ? best : 0.0f;
 	else if (is_global) m = last_col ? h : VK_NEG_INF;
 	else m = col < p.len_t ? fmaxf(h, last_col ? best : 0.0f) : 0.0f;
-	m = slice_max_to_lane31(m, blk);
+	m = slice_max_to_last_lane<NB>(m, blk);
 	return is_global ? m : fmaxf(m, 0.0f);
 }
 
@@ -118,7 +135,7 @@ __device__ __forceinline__ float dp32_general(const float *__restrict__ S, int s
 			const float s = S[(rowbase + (act ? u - 1 : 0)) * stride + (col < stride ? col : 0)];
 			const float bprev = is_global ? -wsr[u - 1] : 0.0f;
 			const float bcur = is_global ? -wsr[u] : 0.0f;
-			const float diag = left_neighbour(hreg[u - 1], bprev, v16, blk);
+			const float diag = left_neighbour<2>(hreg[u - 1], bprev, v16, blk);
 			float c = fmaxf(diag + s, floor0);
 #pragma unroll
 			for (int k = 1; k <= u; k++) c = fmaxf(c, hreg[u - k] - wsr[k]);
@@ -155,27 +172,28 @@ __device__ __forceinline__ float dp32_general(const float *__restrict__ S, int s
 	if (is_local) m = col < p.len_t ? best : 0.0f;
 	else if (is_global) m = last_col ? h : VK_NEG_INF;
 	else m = col < p.len_t ? fmaxf(h, last_col ? best : 0.0f) : 0.0f;
-	m = slice_max_to_lane31(m, blk);
+	m = slice_max_to_last_lane<2>(m, blk);
 	return is_global ? m : fmaxf(m, 0.0f);
 }
 
 // STATIC: token ids + the two per-query tables [V x 16] (columns 0..15 and 16..31) instead of token tiles
-template <int GAP, bool STATIC>
+template <int GAP, bool STATIC, int NB>
 __global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t rows_per_wave, int32_t stride) {
+	constexpr int LPS = 16 * NB, PER = 64 / LPS;   // lanes per slice, slices per wave
 	extern __shared__ float4 vk_smem32[];
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	// the two query tiles (tokens 0..15, 16..31) in LDS, shared by the block's waves
+	// the NB query tiles (tokens 0..15, 16..31, ..) in LDS, shared by the block's waves
 	const int qbytes = STATIC ? 0 : p.nk32 * 1024;
-	for (int i = threadIdx.x; !STATIC && i < 2 * p.nk32 * 64; i += blockDim.x) {
+	for (int i = threadIdx.x; !STATIC && i < NB * p.nk32 * 64; i += blockDim.x) {
 		const int t = i / (p.nk32 * 64), o = i - t * p.nk32 * 64;
 		float4 x = {0.0f, 0.0f, 0.0f, 0.0f};
 		if (!(p.tail && o >= (p.nk32 - 1) * 64 + 32)) x = *reinterpret_cast<const float4 *>(p.qtile + (int64_t)t * p.tile_bytes + o * 16);   // the half block has 32 slots
 		vk_smem32[i] = x;
 	}
 	__syncthreads();
-	const uint8_t *q0 = reinterpret_cast<const uint8_t *>(vk_smem32), *q1 = q0 + qbytes;
+	const uint8_t *q0 = reinterpret_cast<const uint8_t *>(vk_smem32);
 	// strip rows hold the query columns padded to a multiple of 4 (stride floats), not 32: a third workgroup per CU for 20 tokens
-	float *S = reinterpret_cast<float *>(vk_smem32) + 2 * (qbytes / 4) + wv * (rows_per_wave * stride + 64);
+	float *S = reinterpret_cast<float *>(vk_smem32) + NB * (qbytes / 4) + wv * (rows_per_wave * stride + 64);
 
 	float *xch = S + rows_per_wave * stride;   // 64 floats behind the strip: the in-row exchange of dp32_general
 	constexpr int WSN = GAP == 6 ? 65 : 33;
@@ -185,36 +203,37 @@ __global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t
 		for (int k = 0; k < WSN; k++) wsr[k] = p.ws[k];
 	}
 
-	const int half = lane >> 5, col = lane & 31;
-	const int n_pairs = (p.n_sent + 1) >> 1;
+	const int half = lane / LPS, col = lane & (LPS - 1);
+	const int n_pairs = (p.n_sent + PER - 1) / PER;
 	const int nfull = p.tail ? p.nk32 - 1 : p.nk32;
 	for (int pi = blockIdx.x * 4 + wv; pi < n_pairs; pi += gridDim.x * 4) {
-		const int s_idx = pi * 2 + half;
+		const int s_idx = pi * PER + half;
 		const int i0 = s_idx < p.n_sent ? s_idx : p.n_sent;      // entries >= n_sent are empty slices (padding of the table)
 		const int t_a = p.sent_start[i0], t_b = p.sent_end[i0];
 		const int len = t_b - t_a;
-		const int g_a = __builtin_amdgcn_readlane(t_a, 0), g_b = __builtin_amdgcn_readlane(t_b, 32);
-		const int maxlen = max(__builtin_amdgcn_readlane(len, 0), __builtin_amdgcn_readlane(len, 32));
+		const int g_a = __builtin_amdgcn_readlane(t_a, 0), g_b = __builtin_amdgcn_readlane(t_b, 64 - LPS);
+		const int maxlen = max(__builtin_amdgcn_readlane(len, 0), __builtin_amdgcn_readlane(len, 64 - LPS));
 		const int tile0 = STATIC ? 0 : g_a >> 4;
 		const int ntiles = STATIC ? 0 : ((g_b + 15) >> 4) - tile0;
 		if (STATIC) {
-			// gather: lane handles token (lane >> 3) + 8 it, query columns 4 (lane & 7) ..+3; id, then table row: four deep
+			// gather: 4 NB lanes per token, 4 query columns each; id, then table row: four deep
 			const int ntok = g_b - g_a;
-			const int cb = (lane & 7) * 4;
+			constexpr int CPL = 4 * NB, TPI = 64 / CPL;   // lanes per token, tokens per iteration
+			const int cb = (lane % CPL) * 4;
 			const float *tab = p.table + (cb >> 4) * p.table_stride + (cb & 15);
-			for (int it0 = 0; it0 * 8 < ntok; it0 += 4) {
+			for (int it0 = 0; it0 * TPI < ntok; it0 += 4) {
 				int id[4];
 				float4 val[4];
 #pragma unroll
 				for (int q4 = 0; q4 < 4; q4++) {
-					const int tk = (it0 + q4) * 8 + (lane >> 3);
+					const int tk = (it0 + q4) * TPI + lane / CPL;
 					id[q4] = p.tok_id[g_a + (tk < ntok ? tk : 0)];
 				}
 #pragma unroll
 				for (int q4 = 0; q4 < 4; q4++) val[q4] = *reinterpret_cast<const float4 *>(tab + (int64_t)id[q4] * 16);
 #pragma unroll
 				for (int q4 = 0; q4 < 4; q4++) {
-					const int tk = (it0 + q4) * 8 + (lane >> 3);
+					const int tk = (it0 + q4) * TPI + lane / CPL;
 					if (tk < ntok && cb < stride) {
 						float4 vq = val[q4];
 						if (p.pos_s) {   // tag-weighted modifier (TagWeightedSlice, slice/static.h:237-264)
@@ -231,41 +250,44 @@ __global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t
 		}
 		const uint8_t *tp = p.tiles + (int64_t)tile0 * p.tile_bytes;
 		for (int ti = 0; ti < ntiles; ti++) {
-			f32x4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = {0.0f, 0.0f, 0.0f, 0.0f};
+			f32x4 acc[NB];
+#pragma unroll
+			for (int b = 0; b < NB; b++) acc[b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 			int t = 0;
-			for (; t + 4 <= nfull; t += 4) {   // four K-steps of the token tile in flight, each feeding both query tiles
+			for (; t + 4 <= nfull; t += 4) {   // four K-steps of the token tile in flight, each feeding all query tiles
 				bf16x8 x[4];
 #pragma unroll
 				for (int i = 0; i < 4; i++) x[i] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(tp + (t + i) * 1024 + lane * 16));
 #pragma unroll
 				for (int i = 0; i < 4; i++) {
-					a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(q0 + (t + i) * 1024 + lane * 16), x[i], a0, 0, 0, 0);
-					a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(q1 + (t + i) * 1024 + lane * 16), x[i], a1, 0, 0, 0);
+#pragma unroll
+					for (int b = 0; b < NB; b++)
+						acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(q0 + b * qbytes + (t + i) * 1024 + lane * 16), x[i], acc[b], 0, 0, 0);
 				}
 			}
 			for (; t < nfull; t++) {
 				const bf16x8 x = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(tp + t * 1024 + lane * 16));
-				a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(q0 + t * 1024 + lane * 16), x, a0, 0, 0, 0);
-				a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(q1 + t * 1024 + lane * 16), x, a1, 0, 0, 0);
+#pragma unroll
+				for (int b = 0; b < NB; b++)
+					acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(q0 + b * qbytes + t * 1024 + lane * 16), x, acc[b], 0, 0, 0);
 			}
 			if (p.tail) {   // half-filled last K-step: lanes 32..63 contribute zeros (their LDS slots hold zeros, the token side is masked)
 				const bf16x8 x = load_half_block(tp + nfull * 1024, lane, true);
-				a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(q0 + nfull * 1024 + lane * 16), x, a0, 0, 0, 0);
-				a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(q1 + nfull * 1024 + lane * 16), x, a1, 0, 0, 0);
-			}
 #pragma unroll
-			for (int r = 0; r < 4; r++) { a0[r] = clip01(a0[r]); a1[r] = clip01(a1[r]); }
-			if (p.pos_s) {
-				const int ps = p.pos_s[(tile0 + ti) * 16 + (lane & 15)], cq = (lane >> 4) * 4;
+				for (int b = 0; b < NB; b++)
+					acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(q0 + b * qbytes + nfull * 1024 + lane * 16), x, acc[b], 0, 0, 0);
+			}
+			const int ps = p.pos_s ? p.pos_s[(tile0 + ti) * 16 + (lane & 15)] : 0, cq = (lane >> 4) * 4;
+			float *row = S + (ti * 16 + (lane & 15)) * stride + cq;
+#pragma unroll
+			for (int b = 0; b < NB; b++) {
 #pragma unroll
 				for (int r = 0; r < 4; r++) {
-					a0[r] = tag_weighted(a0[r], p.tw[cq + r], ps, p.tpos[cq + r], p.tw_keep, p.tw_threshold);
-					a1[r] = tag_weighted(a1[r], p.tw[16 + cq + r], ps, p.tpos[16 + cq + r], p.tw_keep, p.tw_threshold);
+					acc[b][r] = clip01(acc[b][r]);
+					if (p.pos_s) acc[b][r] = tag_weighted(acc[b][r], p.tw[16 * b + cq + r], ps, p.tpos[16 * b + cq + r], p.tw_keep, p.tw_threshold);
 				}
+				if (16 * b + cq < stride) *reinterpret_cast<f32x4 *>(row + 16 * b) = acc[b];
 			}
-			float *row = S + (ti * 16 + (lane & 15)) * stride + (lane >> 4) * 4;
-			*reinterpret_cast<f32x4 *>(row) = a0;
-			if (16 + (lane >> 4) * 4 < stride) *reinterpret_cast<f32x4 *>(row + 16) = a1;
 			tp += p.tile_bytes;
 		}
 		wave_lds_fence();
@@ -274,8 +296,8 @@ __global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t
 		float raw;
 		if constexpr (GAP == 3) raw = dp32_general<32>(S, stride, rb, lenc, maxlen, col, lane, p, wsr, xch);
 		else if constexpr (GAP == 6) raw = dp32_general<64>(S, stride, rb, lenc, maxlen, col, lane, p, wsr, xch);
-		else raw = dp32<GAP>(S, stride, rb, lenc, maxlen, col, p);
-		if (col == 31 && s_idx < p.n_sent) {
+		else raw = dp32<GAP, NB>(S, stride, rb, lenc, maxlen, col, p);
+		if (col == LPS - 1 && s_idx < p.n_sent) {
 			float val = VK_NEG_INF, r = VK_NEG_INF;
 			if (len >= 1) {   // document.h:160 skips empty slices
 				const float boost = p.boost ? p.boost[s_idx] : 1.0f;
@@ -291,20 +313,25 @@ __global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t
 
 static inline int strip_stride(int len_t) { return (len_t + 3) / 4 * 4; }
 
-// nk32 = 0: static layout (no query tiles in LDS)
-extern "C" size_t vk_score32_lds_bytes(int32_t nk32, int32_t max_pair_tiles, int32_t len_t) {
-	return (size_t)2 * nk32 * 1024 + (size_t)4 * ((size_t)max_pair_tiles * 16 * strip_stride(len_t) + 64) * 4;
+// nk32 = 0: static layout (no query tiles in LDS); tiles: token tiles a wave's slices span (two consecutive slices for
+// queries of at most 32 tokens, one slice beyond)
+extern "C" size_t vk_score32_lds_bytes(int32_t nk32, int32_t tiles, int32_t len_t) {
+	const int nb = len_t <= 32 ? 2 : 4;
+	return (size_t)nb * nk32 * 1024 + (size_t)4 * ((size_t)tiles * 16 * strip_stride(len_t) + 64) * 4;
 }
 
-extern "C" hipError_t vk_launch_score32(const VkWideParams *p, int32_t max_pair_tiles, hipStream_t stream) {
+extern "C" hipError_t vk_launch_score32(const VkWideParams *p, int32_t tiles, hipStream_t stream) {
 	const bool is_static = p->layout == VK_DEV_LAYOUT_STATIC;
-	const size_t smem = vk_score32_lds_bytes(is_static ? 0 : p->nk32, max_pair_tiles, p->len_t);
+	const bool four = p->len_t > 32;   // 33..64 tokens: one slice per wave, four column blocks (linear / affine gaps)
+	const size_t smem = vk_score32_lds_bytes(is_static ? 0 : p->nk32, tiles, p->len_t);
 	void (*kernel)(VkWideParams, int32_t, int32_t);
 	switch (p->gap_mode) {
-	case 0: kernel = is_static ? vk_score32_kernel<0, true> : vk_score32_kernel<0, false>; break;
-	case 1: kernel = is_static ? vk_score32_kernel<1, true> : vk_score32_kernel<1, false>; break;
-	case 3: kernel = is_static ? vk_score32_kernel<3, true> : vk_score32_kernel<3, false>; break;
-	default: kernel = is_static ? vk_score32_kernel<6, true> : vk_score32_kernel<6, false>; break;
+	case 0: kernel = four ? (is_static ? vk_score32_kernel<0, true, 4> : vk_score32_kernel<0, false, 4>)
+		: (is_static ? vk_score32_kernel<0, true, 2> : vk_score32_kernel<0, false, 2>); break;
+	case 1: kernel = four ? (is_static ? vk_score32_kernel<1, true, 4> : vk_score32_kernel<1, false, 4>)
+		: (is_static ? vk_score32_kernel<1, true, 2> : vk_score32_kernel<1, false, 2>); break;
+	case 3: kernel = is_static ? vk_score32_kernel<3, true, 2> : vk_score32_kernel<3, false, 2>; break;
+	default: kernel = is_static ? vk_score32_kernel<6, true, 2> : vk_score32_kernel<6, false, 2>; break;
 	}
 	hipError_t e;
 	if (smem > 64 * 1024) {
@@ -319,8 +346,9 @@ extern "C" hipError_t vk_launch_score32(const VkWideParams *p, int32_t max_pair_
 	if (ov && atoi(ov) > 0 && atoi(ov) < occ) occ = atoi(ov);
 	int dev = 0, cus = 256;
 	if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-	const int want = (int)(((int64_t)(p->n_sent + 1) / 2 + 3) / 4);
+	const int per = four ? 1 : 2;
+	const int want = (int)((((int64_t)p->n_sent + per - 1) / per + 3) / 4);
 	const int grid = want < cus * occ ? (want > 0 ? want : 1) : cus * occ;
-	kernel<<<grid, 256, smem, stream>>>(*p, max_pair_tiles * 16, strip_stride(p->len_t));
+	kernel<<<grid, 256, smem, stream>>>(*p, tiles * 16, strip_stride(p->len_t));
 	return hipGetLastError();
 }
