@@ -69,6 +69,23 @@ def test_wide_query_static_and_long_slices(hip, oracle):
 	c.close()
 
 
+@pytest.mark.parametrize("len_t", [33, 48, 64])
+def test_four_block_kernel_general_gaps(hip, oracle, len_t):
+	"""33..64 query tokens with general gaps over slices of at most 32 tokens: vk_score32_kernel<3, ., 4>"""
+	d = 128
+	corpus = synth.make_contextual_corpus(401, 1, 32, 900, d)
+	Xb = prep_contextual(corpus)
+	c = hip_contextual_corpus(hip, corpus, Xb)
+	for Qb in [prep_query(q) for q in synth.make_queries(corpus, 2, len_t)]:
+		for loc, ms in ((0, 0.0), (1, -1e9), (2, -1e9)):
+			ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=corpus["sent_off"], X=Xb, Q=Qb, locality=loc,
+				gap_s=EXP5L, gap_t=EXP5L, max_matches=10, min_score=ms, want_all_scores=True)
+			got = c.query(Qb, q_normalize=False, locality=loc, gap_s=EXP5L, gap_t=EXP5L, max_matches=10, min_score=ms)
+			assert_same_results(got.trimmed(), ref)
+			np.testing.assert_allclose(c.last_scores(), ref["all_scores"], atol=1e-4)
+	c.close()
+
+
 def test_wide_query_limits(hip):
 	corpus = synth.make_contextual_corpus(20, 4, 20, 100, 32, norm_sigma=0.2)
 	c = hip_contextual_corpus(hip, corpus, keep_magnitudes=True)

@@ -106,9 +106,10 @@ __device__ __forceinline__ float dp32(const float *__restrict__ S, int stride, i
 
 // General gap costs (Waterman-Smith-Beyer), w_t strictly subadditive (checked by the host, as for dp_general_reg): the
 // column history of each lane in registers; in-row candidates c[col - k] - w_t(k) from the lane's own block by
-// row_shr:k, and for the right block also from the 16 columns of the left block, which pass through a 64-float slot of
-// wave-private LDS (one write, four broadcast b128 reads per row) and meet per-lane costs w_t(16 + v - i).
-template <int MAXLEN>
+// row_shr:k, and for the blocks further right also from the columns of the blocks to their left, which pass through a
+// 64-float slot of wave-private LDS (one write, four broadcast b128 reads per block and row) and meet per-lane costs
+// w_t(col - i).
+template <int MAXLEN, int NB>
 __device__ __forceinline__ float dp32_general(const float *__restrict__ S, int stride, int rowbase, int len, int maxlen, int col, int lane,
 	const VkWideParams &p, const float (&wsr)[MAXLEN + 1], float *__restrict__ xch) {
 	const int v16 = col & 15, blk = col >> 4;
@@ -117,12 +118,13 @@ __device__ __forceinline__ float dp32_general(const float *__restrict__ S, int s
 	const bool last_col = col == p.len_t - 1;
 	const float inf = __builtin_inff();
 	const float wt_border = p.wt[col + 1];
-	float wtv[16], wfar[16];
+	constexpr int NL = 16 * (NB - 1);   // columns that can lie in blocks to the left
+	float wtv[16], wfar[NL];
 #pragma unroll
 	for (int k = 1; k < 16; k++) wtv[k] = v16 >= k ? p.wt[k] : inf;
 #pragma unroll
-	for (int i = 0; i < 16; i++) wfar[i] = blk == 1 ? p.wt[16 + v16 - i] : inf;
-	const f32x4 *left = reinterpret_cast<const f32x4 *>(xch + (lane & 32));   // c of columns 0..15 of this slice
+	for (int i = 0; i < NL; i++) wfar[i] = (i >> 4) < blk ? p.wt[col - i] : inf;   // column i of the slice, in a block left of this lane's
+	const f32x4 *left = reinterpret_cast<const f32x4 *>(xch + (lane & ~(16 * NB - 1)));   // c of columns 0.. of this slice
 
 	float hreg[MAXLEN + 1];
 	float h = is_global ? -wt_border : 0.0f;
@@ -135,7 +137,7 @@ __device__ __forceinline__ float dp32_general(const float *__restrict__ S, int s
 			const float s = S[(rowbase + (act ? u - 1 : 0)) * stride + (col < stride ? col : 0)];
 			const float bprev = is_global ? -wsr[u - 1] : 0.0f;
 			const float bcur = is_global ? -wsr[u] : 0.0f;
-			const float diag = left_neighbour<2>(hreg[u - 1], bprev, v16, blk);
+			const float diag = left_neighbour<NB>(hreg[u - 1], bprev, v16, blk);
 			float c = fmaxf(diag + s, floor0);
 #pragma unroll
 			for (int k = 1; k <= u; k++) c = fmaxf(c, hreg[u - k] - wsr[k]);
@@ -158,7 +160,7 @@ __device__ __forceinline__ float dp32_general(const float *__restrict__ S, int s
 			hc = fmaxf(hc, dpp_zero<0x11f>(c) - wtv[15]);
 			wave_lds_fence();
 #pragma unroll
-			for (int g = 0; g < 4; g++) {
+			for (int g = 0; g < NL / 4; g++) {
 				const f32x4 l = left[g];
 #pragma unroll
 				for (int r = 0; r < 4; r++) hc = fmaxf(hc, l[r] - wfar[g * 4 + r]);
@@ -172,7 +174,7 @@ __device__ __forceinline__ float dp32_general(const float *__restrict__ S, int s
 	if (is_local) m = col < p.len_t ? best : 0.0f;
 	else if (is_global) m = last_col ? h : VK_NEG_INF;
 	else m = col < p.len_t ? fmaxf(h, last_col ? best : 0.0f) : 0.0f;
-	m = slice_max_to_last_lane<2>(m, blk);
+	m = slice_max_to_last_lane<NB>(m, blk);
 	return is_global ? m : fmaxf(m, 0.0f);
 }
 
@@ -294,8 +296,8 @@ __global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t
 		const int lenc = len > 0 ? len : 0;
 		const int rb = len > 0 ? (STATIC ? t_a - g_a : t_a - tile0 * 16) : 0;
 		float raw;
-		if constexpr (GAP == 3) raw = dp32_general<32>(S, stride, rb, lenc, maxlen, col, lane, p, wsr, xch);
-		else if constexpr (GAP == 6) raw = dp32_general<64>(S, stride, rb, lenc, maxlen, col, lane, p, wsr, xch);
+		if constexpr (GAP == 3) raw = dp32_general<32, NB>(S, stride, rb, lenc, maxlen, col, lane, p, wsr, xch);
+		else if constexpr (GAP == 6) raw = dp32_general<64, NB>(S, stride, rb, lenc, maxlen, col, lane, p, wsr, xch);
 		else raw = dp32<GAP, NB>(S, stride, rb, lenc, maxlen, col, p);
 		if (col == LPS - 1 && s_idx < p.n_sent) {
 			float val = VK_NEG_INF, r = VK_NEG_INF;
@@ -330,8 +332,11 @@ extern "C" hipError_t vk_launch_score32(const VkWideParams *p, int32_t tiles, hi
 		: (is_static ? vk_score32_kernel<0, true, 2> : vk_score32_kernel<0, false, 2>); break;
 	case 1: kernel = four ? (is_static ? vk_score32_kernel<1, true, 4> : vk_score32_kernel<1, false, 4>)
 		: (is_static ? vk_score32_kernel<1, true, 2> : vk_score32_kernel<1, false, 2>); break;
-	case 3: kernel = is_static ? vk_score32_kernel<3, true, 2> : vk_score32_kernel<3, false, 2>; break;
-	default: kernel = is_static ? vk_score32_kernel<6, true, 2> : vk_score32_kernel<6, false, 2>; break;
+	case 3: kernel = four ? (is_static ? vk_score32_kernel<3, true, 4> : vk_score32_kernel<3, false, 4>)
+		: (is_static ? vk_score32_kernel<3, true, 2> : vk_score32_kernel<3, false, 2>); break;
+	default:   // 64-row history: two blocks only (the four-block form spills: the host keeps such queries on vk_wide_kernel)
+		if (four) return hipErrorInvalidValue;
+		kernel = is_static ? vk_score32_kernel<6, true, 2> : vk_score32_kernel<6, false, 2>; break;
 	}
 	hipError_t e;
 	if (smem > 64 * 1024) {
