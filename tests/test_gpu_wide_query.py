@@ -135,6 +135,12 @@ def test_two_block_kernel_shapes(hip, oracle, len_t):
 				every = c.last_scores()
 				np.testing.assert_allclose(every[lens > 0], ref["all_scores"][lens > 0], atol=1e-4)
 				assert np.isneginf(every[lens == 0]).all()
+			for flags in ((True, True, True), (True, False, False), (True, False, True)):
+				ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, X=Xb, Q=Qb, algorithm=oracle.ALG_RWMD, rwmd=flags, max_matches=9,
+					want_all_scores=True, **geo)
+				got = c.query(Qb, q_normalize=False, algorithm=hip.VK_ALG_RWMD, rwmd=flags, max_matches=9)
+				assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=2e-5, tie_tol=2e-5)
+				np.testing.assert_allclose(c.last_scores()[lens > 0], ref["all_scores"][lens > 0], atol=2e-5)
 		c.close()
 
 
@@ -157,4 +163,10 @@ def test_two_block_kernel_static_layout(hip, oracle, len_t):
 			got = c.query(Qb, q_token_ids=q_ids, q_normalize=False, locality=loc, gap_s=gaps[0], gap_t=gaps[1], max_matches=10, min_score=ms)
 			assert_same_results(got.trimmed(), ref, check_mapping=False)   # repeated words: co-optimal tracebacks
 			np.testing.assert_allclose(c.last_scores(), ref["all_scores"], atol=1e-4)
+		for flags in ((True, True, True), (True, False, False)):
+			ref = oracle.find(layout=oracle.LAYOUT_STATIC, d=100, sent_off=off, tok_id=ids, E=Eb, Q=Qb, q_ids=q_ids, algorithm=oracle.ALG_RWMD,
+				rwmd=flags, max_matches=10, want_all_scores=True)
+			got = c.query(Qb, q_token_ids=q_ids, q_normalize=False, algorithm=hip.VK_ALG_RWMD, rwmd=flags, max_matches=10)
+			assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=2e-5, tie_tol=2e-5)
+			np.testing.assert_allclose(c.last_scores(), ref["all_scores"], atol=2e-5)
 	c.close()

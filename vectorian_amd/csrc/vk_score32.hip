@@ -104,6 +104,41 @@ __device__ __forceinline__ float dp32(const float *__restrict__ S, int stride, i
 	return is_global ? m : fmaxf(m, 0.0f);
 }
 
+// Relaxed word mover's distance, injective form (rwmd_rows of vk_score_kernel over 16 NB columns): column minima in
+// the lanes, row minima folded to the slice's last lane, the sum over the query columns in column order.
+template <int NB>
+__device__ __forceinline__ float rwmd32(const float *__restrict__ S, int stride, int rowbase, int len, int maxlen, int col, int lane,
+	const VkWideParams &p) {
+	constexpr int LPS = 16 * NB;
+	const int blk = col >> 4;
+	const bool nbow = p.rwmd_normalize_bow != 0, col_ok = col < p.len_t;
+	const float w_t = nbow ? 1.0f / (float)p.len_t : 1.0f, w_s = nbow ? 1.0f / (float)(len > 0 ? len : 1) : 1.0f;
+	const float BIG = 3.402823466e+38F;
+	float colmin = BIG, acc1 = 0.0f;
+	for (int u = 1; u <= maxlen; u++) {
+		const bool act = u <= len;
+		const float dist = fmaxf(1.0f - S[(rowbase + (act ? u - 1 : 0)) * stride + (col < stride ? col : 0)], 0.0f);
+		if (act) colmin = fminf(colmin, dist);
+		const float m = -slice_max_to_last_lane<NB>(col_ok ? -dist : -BIG, blk);   // min = -max(-x), exact
+		if (act) acc1 += w_s * m;
+	}
+	const float x = col_ok ? w_t * colmin : 0.0f;
+	float acc0 = 0.0f;
+	for (int j = 0; j < p.len_t; j++) {   // in column order, as the oracle sums (the wave holds 64 / LPS slices)
+		float xj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), j));
+		if (NB == 2) {
+			const float xb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), LPS + j));
+			xj = lane >= LPS ? xb : xj;
+		}
+		acc0 = j == 0 ? xj : acc0 + xj;
+	}
+	if (!nbow) { acc0 = acc0 / (float)p.len_t; acc1 = acc1 / (float)(len > 0 ? len : 1); }
+	float cost = acc0;
+	if (p.rwmd_symmetric) { cost = 0.0f; if (acc0 > cost) cost = acc0; if (acc1 > cost) cost = acc1; }
+	const float max_cost = nbow ? 1.0f : (float)p.len_t;
+	return (max_cost - cost) / max_cost;
+}
+
 // General gap costs (Waterman-Smith-Beyer), w_t strictly subadditive (checked by the host, as for dp_general_reg): the
 // column history of each lane in registers; in-row candidates c[col - k] - w_t(k) from the lane's own block by
 // row_shr:k, and for the blocks further right also from the columns of the blocks to their left, which pass through a
@@ -298,6 +333,7 @@ __global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t
 		float raw;
 		if constexpr (GAP == 3) raw = dp32_general<32, NB>(S, stride, rb, lenc, maxlen, col, lane, p, wsr, xch);
 		else if constexpr (GAP == 6) raw = dp32_general<64, NB>(S, stride, rb, lenc, maxlen, col, lane, p, wsr, xch);
+		else if constexpr (GAP == 4) raw = rwmd32<NB>(S, stride, rb, lenc, maxlen, col, lane, p);
 		else raw = dp32<GAP, NB>(S, stride, rb, lenc, maxlen, col, p);
 		if (col == LPS - 1 && s_idx < p.n_sent) {
 			float val = VK_NEG_INF, r = VK_NEG_INF;
@@ -332,6 +368,8 @@ extern "C" hipError_t vk_launch_score32(const VkWideParams *p, int32_t tiles, hi
 		: (is_static ? vk_score32_kernel<0, true, 2> : vk_score32_kernel<0, false, 2>); break;
 	case 1: kernel = four ? (is_static ? vk_score32_kernel<1, true, 4> : vk_score32_kernel<1, false, 4>)
 		: (is_static ? vk_score32_kernel<1, true, 2> : vk_score32_kernel<1, false, 2>); break;
+	case 4: kernel = four ? (is_static ? vk_score32_kernel<4, true, 4> : vk_score32_kernel<4, false, 4>)
+		: (is_static ? vk_score32_kernel<4, true, 2> : vk_score32_kernel<4, false, 2>); break;
 	case 3: kernel = four ? (is_static ? vk_score32_kernel<3, true, 4> : vk_score32_kernel<3, false, 4>)
 		: (is_static ? vk_score32_kernel<3, true, 2> : vk_score32_kernel<3, false, 2>); break;
 	default:   // 64-row history: two blocks only (the four-block form spills: the host keeps such queries on vk_wide_kernel)
