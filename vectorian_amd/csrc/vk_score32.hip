@@ -1,11 +1,14 @@
-// vk_score32.hip -- the fused scoring kernel for queries of 17..32 tokens (a whole sentence as the query) with linear
-// or affine gap costs, slices of at most 64 tokens; bf16 contextual layout, or the static layout (token ids + tables).  Same plan as vk_score_kernel, two column
-// blocks wide: a wave holds TWO slices at a time, 32 lanes each (lane = query column); every token tile is loaded once
-// and multiplied with both query tiles (staged in LDS), the similarity strip has 32 columns per row, and the in-row
-// recurrence is the decayed prefix maximum of dp_linear / dp_affine carried across the two 16-lane DPP rows of a slice
-// with one row_bcast:15 (general gaps: dp32_general).  vk_wide_kernel (one wave per slice, serial in-row chain) remains
-// the path for longer queries, gap costs that are not subadditive, and the tracebacks of the winners: 29 ms per
-// 1 M x 32-token slices there (linear gap), 3.5 ms here.
+// vk_score32.hip -- the fused scoring kernel for queries of 17..64 tokens (a whole sentence as the query) over slices
+// of at most 64 tokens; bf16 contextual layout, or the static layout (token ids + per-query tables).  Same plan as
+// vk_score_kernel, NB column blocks of 16 wide:
+//   NB = 2 (17..32 tokens): a wave holds TWO slices at a time, 32 lanes each (lane = query column);
+//   NB = 4 (33..64 tokens): one slice per wave, 64 lanes.
+// Every token tile is loaded once and multiplied with all NB query tiles (staged in LDS), the similarity strip has up to
+// 16 NB columns per row, and the in-row recurrence of dp_linear / dp_affine -- a decayed prefix maximum -- is carried
+// from block to block with row_bcast:15; general gaps (strictly subadditive w_t): dp32_general; injective RWMD: rwmd32.
+// vk_wide_kernel (one wave per slice, serial in-row chain) remains the path for gap costs that are not subadditive, fp32
+// tiles, long slices, and the tracebacks of the winners: 29 ms per 1 M x 32-token slices there (20 tokens, linear gap),
+// 3.5 ms here.
 #include "vk_common.cuh"
 
 // NB = column blocks of 16 per slice: 2 (two slices per wave, queries of 17..32 tokens) or 4 (one slice, 33..64).
