@@ -311,7 +311,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	if (p.gap_mode == 7) lds_floats += 4 * p.m_rows;       // vocabulary masses of the 4 slices (static layout)
 	p.lds_floats_per_wave = lds_floats;
 	size_t smem = (size_t)lds_floats * 4 * 4;   // 4 waves per block
-	const size_t qlds = (!is_static && c->prec == 0 && c->nk32 == 24 && c->tail == 0) ? (size_t)c->nk32 * 1024 : 0;   // MODE 3: query tile in LDS
+	const size_t qlds = (!is_static && c->prec == 0 && ((c->nk32 == 24 && c->tail == 0) || (getenv("VK_QLDS") && c->nk32 == 10 && c->tail == 1))) ? (size_t)c->nk32 * 1024 : 0;   // MODE 3: query tile in LDS
 	smem += qlds;
 	if (smem > 160 * 1024) return fail(VK_ERR_UNSUPPORTED, "LDS demand exceeds 160 KiB per workgroup");
 	const int64_t n_groups = (n + 3) / 4;
