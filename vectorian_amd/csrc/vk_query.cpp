@@ -313,6 +313,12 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	size_t smem = (size_t)lds_floats * 4 * 4;   // 4 waves per block
 	const size_t qlds = (!is_static && c->prec == 0 && ((c->nk32 == 24 && c->tail == 0) || (getenv("VK_QLDS") && c->nk32 == 10 && c->tail == 1))) ? (size_t)c->nk32 * 1024 : 0;   // MODE 3: query tile in LDS
 	smem += qlds;
+	// the generic contextual kernel (MODE 1: fp32 tiles, or a d without a specialised form) stages the query tile in LDS when it fits
+	// beside the strips of at least two workgroups per CU
+	if (!is_static && qlds == 0 && !(c->prec == 0 && c->nk32 == 10 && c->tail == 1)) {
+		const size_t qb = ((size_t)c->tile_bytes + 1023) / 1024 * 1024;
+		if (2 * (smem + qb) <= 160 * 1024 && !getenv("VK_NO_QLDS1")) { p.q_lds = (int32_t)qb; smem += qb; }
+	}
 	if (smem > 160 * 1024) return fail(VK_ERR_UNSUPPORTED, "LDS demand exceeds 160 KiB per workgroup");
 	const int64_t n_groups = (n + 3) / 4;
 	const int grid = (int)std::min<int64_t>((n_groups + 3) / 4, (int64_t)1 << 20);   // capped to residency by the launcher
@@ -330,7 +336,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		pl.m_rows = 0;
 		if (pl.gap_mode == 7) lf += (c->max_len + 4) / 4 * 4;
 		pl.lds_floats_per_wave = lf;
-		const size_t smem_l = (size_t)lf * 4 + qlds;
+		const size_t smem_l = (size_t)lf * 4 + qlds + (size_t)pl.q_lds;
 		if (smem_l > 160 * 1024) return fail(VK_ERR_UNSUPPORTED, "LDS demand of the long-slice pass exceeds 160 KiB");
 		VK_HIP(vk_launch_score(&pl, c->n_long_groups, smem_l, st));
 	}

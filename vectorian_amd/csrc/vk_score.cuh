@@ -34,6 +34,16 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 		__syncthreads();
 		smem += NK32 * 256;
 	}
+	// MODE 1 (any d, fp32 tiles): the same staging with a runtime size; the K loop then reads the query with ds_read instead of
+	// going through L1 for every token tile
+	if constexpr (MODE == 1) {
+		if (p.q_lds > 0) {
+			for (int i = threadIdx.x; i * 16 < p.q_lds; i += blockDim.x)
+				vk_smem4[i] = i * 16 < p.tile_bytes ? *reinterpret_cast<const float4 *>(p.qtile + i * 16) : float4{0.0f, 0.0f, 0.0f, 0.0f};
+			__syncthreads();
+			smem += p.q_lds / 4;
+		}
+	}
 	float *S = smem + wv * p.lds_floats_per_wave;
 	float *Hh = S + p.s_rows_per_wave * LT + 16;   // strip rows hold the LT query columns only; 16 floats of slack for lanes >= LT
 	const int sigma = lane >> 4, v = lane & 15;
@@ -149,6 +159,7 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 				f32x4 acc;
 				if constexpr (MODE == 0) acc = sim_tile<NK32, TAIL>(qf, tp, lane);
 				else if constexpr (MODE == 3) acc = sim_tile_qlds<NK32, TAIL>(qlds, tp, lane);
+				else if (MODE == 1 && p.q_lds > 0) acc = sim_tile_generic(qlds, tp, p.nk32, p.tail, lane, p.prec);
 				else acc = sim_tile_generic(p.qtile, tp, p.nk32, p.tail, lane, p.prec);
 				if (p.pos_s) {
 					const int ps = p.pos_s[(tile0 + ti) * 16 + (lane & 15)];
