@@ -71,9 +71,9 @@ def test_wide_query_static_and_long_slices(hip, oracle):
 
 @pytest.mark.parametrize("len_t", [33, 48, 64])
 def test_four_block_kernel_general_gaps(hip, oracle, len_t):
-	"""33..64 query tokens with general gaps over slices of at most 32 tokens: vk_score32_kernel<3, ., 4>"""
+	"""33..64 query tokens with general gaps: vk_score32_kernel<3 or 6, ., 4>"""
 	d = 128
-	corpus = synth.make_contextual_corpus(401, 1, 32, 900, d)
+	corpus = synth.make_contextual_corpus(401, 1, 32 if len_t != 48 else 64, 900, d)   # 48: slices up to 64 tokens (64-row history)
 	Xb = prep_contextual(corpus)
 	c = hip_contextual_corpus(hip, corpus, Xb)
 	for Qb in [prep_query(q) for q in synth.make_queries(corpus, 2, len_t)]:

@@ -157,11 +157,17 @@ __device__ __forceinline__ float dp32_general(const float *__restrict__ S, int s
 	const float inf = __builtin_inff();
 	const float wt_border = p.wt[col + 1];
 	constexpr int NL = 16 * (NB - 1);   // columns that can lie in blocks to the left
-	float wtv[16], wfar[NL];
+	// their costs w_t(col - i) per lane: in registers, except beside the 64-row history of the four-block form, where 48 more
+	// registers spill -- there they are read from the wave's copy of w_t in LDS (xch + 64), one ds_read_b32 per candidate
+	constexpr bool FAR_LDS = MAXLEN == 64 && NB == 4;
+	float wtv[16], wfar[FAR_LDS ? 1 : NL];
 #pragma unroll
 	for (int k = 1; k < 16; k++) wtv[k] = v16 >= k ? p.wt[k] : inf;
+	if constexpr (!FAR_LDS) {
 #pragma unroll
-	for (int i = 0; i < NL; i++) wfar[i] = (i >> 4) < blk ? p.wt[col - i] : inf;   // column i of the slice, in a block left of this lane's
+		for (int i = 0; i < NL; i++) wfar[i] = (i >> 4) < blk ? p.wt[col - i] : inf;   // column i of the slice, in a block left of this lane's
+	}
+	const float *wtl = xch + 64;
 	const f32x4 *left = reinterpret_cast<const f32x4 *>(xch + (lane & ~(16 * NB - 1)));   // c of columns 0.. of this slice
 
 	float hreg[MAXLEN + 1];
@@ -201,7 +207,16 @@ __device__ __forceinline__ float dp32_general(const float *__restrict__ S, int s
 			for (int g = 0; g < NL / 4; g++) {
 				const f32x4 l = left[g];
 #pragma unroll
-				for (int r = 0; r < 4; r++) hc = fmaxf(hc, l[r] - wfar[g * 4 + r]);
+				for (int r = 0; r < 4; r++) {
+					const int i = g * 4 + r;
+					float w;
+					if constexpr (FAR_LDS) {
+						const bool ok = (i >> 4) < blk;
+						w = wtl[ok ? col - i : 0];
+						w = ok ? w : inf;
+					} else w = wfar[i];
+					hc = fmaxf(hc, l[r] - w);
+				}
 			}
 			hreg[u] = hc;
 			h = act ? hc : h;
@@ -233,9 +248,14 @@ __global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t
 	__syncthreads();
 	const uint8_t *q0 = reinterpret_cast<const uint8_t *>(vk_smem32);
 	// strip rows hold the query columns padded to a multiple of 4 (stride floats), not 32: a third workgroup per CU for 20 tokens
-	float *S = reinterpret_cast<float *>(vk_smem32) + NB * (qbytes / 4) + wv * (rows_per_wave * stride + 64);
+	float *S = reinterpret_cast<float *>(vk_smem32) + NB * (qbytes / 4) + wv * (rows_per_wave * stride + 144);
 
-	float *xch = S + rows_per_wave * stride;   // 64 floats behind the strip: the in-row exchange of dp32_general
+	float *xch = S + rows_per_wave * stride;   // 64 floats behind the strip: the in-row exchange of dp32_general; then the wave's copy of w_t
+	if (GAP == 6 && NB == 4) {
+		xch[64 + lane] = p.wt[lane];
+		if (lane == 0) xch[128] = p.wt[64];
+		wave_lds_fence();
+	}
 	constexpr int WSN = GAP == 6 ? 65 : 33;
 	float wsr[WSN];
 	if (GAP == 3 || GAP == 6) {
@@ -358,7 +378,7 @@ static inline int strip_stride(int len_t) { return (len_t + 3) / 4 * 4; }
 // queries of at most 32 tokens, one slice beyond)
 extern "C" size_t vk_score32_lds_bytes(int32_t nk32, int32_t tiles, int32_t len_t) {
 	const int nb = len_t <= 32 ? 2 : 4;
-	return (size_t)nb * nk32 * 1024 + (size_t)4 * ((size_t)tiles * 16 * strip_stride(len_t) + 64) * 4;
+	return (size_t)nb * nk32 * 1024 + (size_t)4 * ((size_t)tiles * 16 * strip_stride(len_t) + 144) * 4;
 }
 
 extern "C" hipError_t vk_launch_score32(const VkWideParams *p, int32_t tiles, hipStream_t stream) {
@@ -375,9 +395,8 @@ extern "C" hipError_t vk_launch_score32(const VkWideParams *p, int32_t tiles, hi
 		: (is_static ? vk_score32_kernel<4, true, 2> : vk_score32_kernel<4, false, 2>); break;
 	case 3: kernel = four ? (is_static ? vk_score32_kernel<3, true, 4> : vk_score32_kernel<3, false, 4>)
 		: (is_static ? vk_score32_kernel<3, true, 2> : vk_score32_kernel<3, false, 2>); break;
-	default:   // 64-row history: two blocks only (the four-block form spills: the host keeps such queries on vk_wide_kernel)
-		if (four) return hipErrorInvalidValue;
-		kernel = is_static ? vk_score32_kernel<6, true, 2> : vk_score32_kernel<6, false, 2>; break;
+	default: kernel = four ? (is_static ? vk_score32_kernel<6, true, 4> : vk_score32_kernel<6, false, 4>)
+		: (is_static ? vk_score32_kernel<6, true, 2> : vk_score32_kernel<6, false, 2>); break;
 	}
 	hipError_t e;
 	if (smem > 64 * 1024) {
