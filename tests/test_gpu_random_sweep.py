@@ -25,7 +25,18 @@ def random_gap(rng, n):
 
 @pytest.mark.parametrize("seed", range(200))
 def test_random_problem(hip, oracle, seed):
-	rng = np.random.default_rng(1000 + seed)
+	run_random_problem(hip, oracle, 1000 + seed, 1, 25)
+
+
+@pytest.mark.parametrize("seed", range(100))
+def test_random_problem_long_query(hip, oracle, seed):
+	"""queries of 17..64 tokens: the multi-block kernel (vk_score32_kernel) and its fallbacks (long slices, fp32 tiles,
+	gap costs that are not subadditive)"""
+	run_random_problem(hip, oracle, 5000 + seed, 17, 65)
+
+
+def run_random_problem(hip, oracle, seed, len_lo, len_hi):
+	rng = np.random.default_rng(seed)
 	static = bool(rng.integers(0, 2))
 	d = int(rng.choice([16, 50, 64, 100, 300, 320]))
 	n = int(rng.integers(1, 300))
@@ -36,7 +47,7 @@ def test_random_problem(hip, oracle, seed):
 	T = int(off[-1])
 	if T == 0:
 		pytest.skip("empty corpus")
-	len_t = int(rng.integers(1, 25))
+	len_t = int(rng.integers(len_lo, len_hi))
 	precision = "f32" if rng.random() < 0.25 else "bf16"
 	loc = int(rng.integers(0, 3))
 	gs, gt = random_gap(rng, 513), random_gap(rng, 65)
