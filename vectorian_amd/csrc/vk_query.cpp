@@ -288,7 +288,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		// (33..64 tokens: one slice per wave and four column blocks)
 		const int wave_tiles = q->len_t <= 32 ? c->max_pair_tiles : (c->max_len + 15) / 16 + 1;
 		const bool rwmd_inj = q->algorithm == VK_ALG_RWMD && p.gap_mode == 4 && !q->wmd_full;
-		const bool two_blocks = (is_align || rwmd_inj) && (is_static || c->prec == 0) && c->n_long_groups == 0 &&
+		const bool two_blocks = (is_align || rwmd_inj) && c->n_long_groups == 0 &&
 			c->max_len <= VK_FAST_SENT_LEN && (rwmd_inj || p.gap_mode == 0 || (p.gap_mode == 1 && p.a_t >= 0.0f) || (p.gap_mode == 2 && wide_sub)) &&
 			vk_score32_lds_bytes(is_static ? 0 : c->nk32, wave_tiles, q->len_t) <= 160 * 1024 && !getenv("VK_NO_SCORE32");
 		if (two_blocks) {

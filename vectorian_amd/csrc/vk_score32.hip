@@ -1,13 +1,13 @@
 // vk_score32.hip -- the fused scoring kernel for queries of 17..64 tokens (a whole sentence as the query) over slices
-// of at most 64 tokens; bf16 contextual layout, or the static layout (token ids + per-query tables).  Same plan as
+// of at most 64 tokens; contextual layout (bf16 or fp32 tiles), or the static layout (token ids + per-query tables).  Same plan as
 // vk_score_kernel, NB column blocks of 16 wide:
 //   NB = 2 (17..32 tokens): a wave holds TWO slices at a time, 32 lanes each (lane = query column);
 //   NB = 4 (33..64 tokens): one slice per wave, 64 lanes.
 // Every token tile is loaded once and multiplied with all NB query tiles (staged in LDS), the similarity strip has up to
 // 16 NB columns per row, and the in-row recurrence of dp_linear / dp_affine -- a decayed prefix maximum -- is carried
 // from block to block with row_bcast:15; general gaps (strictly subadditive w_t): dp32_general; injective RWMD: rwmd32.
-// vk_wide_kernel (one wave per slice, serial in-row chain) remains the path for gap costs that are not subadditive, fp32
-// tiles, long slices, and the tracebacks of the winners: 29 ms per 1 M x 32-token slices there (20 tokens, linear gap),
+// vk_wide_kernel (one wave per slice, serial in-row chain) remains the path for gap costs that are not subadditive,
+// long slices, and the tracebacks of the winners: 29 ms per 1 M x 32-token slices there (20 tokens, linear gap),
 // 3.5 ms here.
 #include "vk_common.cuh"
 
@@ -314,6 +314,34 @@ __global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t
 #pragma unroll
 			for (int b = 0; b < NB; b++) acc[b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 			int t = 0;
+			if (p.prec) {
+				// fp32 tiles (the reference's own precision): nk32 blocks of 16 features, four v_mfma_f32_16x16x4_f32 per block and query tile
+				int bk = 0;
+				for (; bk + 4 <= p.nk32; bk += 4) {
+					f32x4 x[4];
+#pragma unroll
+					for (int i = 0; i < 4; i++) x[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(tp + (bk + i) * 1024 + lane * 16));
+#pragma unroll
+					for (int i = 0; i < 4; i++) {
+#pragma unroll
+						for (int b = 0; b < NB; b++) {
+							const f32x4 q = *reinterpret_cast<const f32x4 *>(q0 + b * qbytes + (bk + i) * 1024 + lane * 16);
+#pragma unroll
+							for (int e = 0; e < 4; e++) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[e], x[i][e], acc[b], 0, 0, 0);
+						}
+					}
+				}
+				for (; bk < p.nk32; bk++) {
+					const f32x4 x = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(tp + bk * 1024 + lane * 16));
+#pragma unroll
+					for (int b = 0; b < NB; b++) {
+						const f32x4 q = *reinterpret_cast<const f32x4 *>(q0 + b * qbytes + bk * 1024 + lane * 16);
+#pragma unroll
+						for (int e = 0; e < 4; e++) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[e], x[e], acc[b], 0, 0, 0);
+					}
+				}
+				t = nfull;   // nothing left for the bf16 loops (fp32 tiles have no half block)
+			}
 			for (; t + 4 <= nfull; t += 4) {   // four K-steps of the token tile in flight, each feeding all query tiles
 				bf16x8 x[4];
 #pragma unroll
@@ -331,7 +359,7 @@ __global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t
 				for (int b = 0; b < NB; b++)
 					acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(q0 + b * qbytes + t * 1024 + lane * 16), x, acc[b], 0, 0, 0);
 			}
-			if (p.tail) {   // half-filled last K-step: lanes 32..63 contribute zeros (their LDS slots hold zeros, the token side is masked)
+			if (p.tail && !p.prec) {   // half-filled last K-step: lanes 32..63 contribute zeros (their LDS slots hold zeros, the token side is masked)
 				const bf16x8 x = load_half_block(tp + nfull * 1024, lane, true);
 #pragma unroll
 				for (int b = 0; b < NB; b++)
