@@ -5,7 +5,8 @@ through properties that do not need the oracle to score a million sentences:
   * the returned top-k equals the top-k of the full score vector under the result order (score desc, sentence desc);
   * planted copies of the query come out first with score ~ 1 and the identity traceback;
   * the same query twice gives the same bytes; a boost of c scales every score by c;
-  * two half shards merged (vk_merge_topk with offsets) give the result of the whole."""
+  * two half shards merged (vk_merge_topk with offsets) give the result of the whole;
+  * queries of 24 and 40 tokens over the same shard: the sample against the oracle, the selection against the score vector."""
 
 import numpy as np
 import pytest
@@ -97,6 +98,21 @@ def test_config2_full_size_properties(hip, oracle):
 	boosted = c.query(qv, boost=np.full(N_SENT, 0.5, np.float32), **kw)
 	np.testing.assert_allclose(boosted.score[:10], 0.5 * top.score[:10], rtol=1e-6)
 	assert list(boosted.sentence[:10]) == list(top.sentence[:10])
+
+	# (4b) the same shard under queries of 24 and 40 tokens (vk_score32_kernel, two and four column blocks): sampled
+	# sentences against the oracle, and the selection against the full score vector
+	for len_t, gaps in ((24, (0.1, 0.1)), (24, (EXP5, EXP5)), (40, (("affine", 0.2, 0.05), 0.1))):
+		ql = np.ascontiguousarray(E[rng.integers(0, V, size=len_t)] + 0.05 * rng.standard_normal((len_t, D)).astype(np.float32))
+		kwl = dict(q_normalize=True, locality=0, gap_s=gaps[0], gap_t=gaps[1], max_matches=10, min_score=0.0)
+		topl = c.query(ql, **kwl)
+		sl = c.last_scores()
+		Ql, _ = oracle.normalize_rows_bf16(ql)
+		refl = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=D, sent_off=np.arange(len(sample) + 1, dtype=np.int64) * LEN_S, X=Xb, Q=Ql,
+			locality=0, gap_s=gaps[0], gap_t=gaps[1], max_matches=10, min_score=0.0, want_all_scores=True, n_threads=8)
+		np.testing.assert_allclose(sl[sample], refl["all_scores"], atol=1e-4, rtol=0)
+		orderl = np.lexsort((-np.arange(N_SENT), -sl.astype(np.float64)))[:10]
+		assert list(topl.sentence[:topl.n]) == list(orderl)
+		np.testing.assert_array_equal(topl.score[:topl.n], sl[orderl])
 	c.close()
 
 	# (5) two half shards merged == the whole
