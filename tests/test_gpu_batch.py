@@ -114,3 +114,24 @@ def test_batch_fallback_for_alignment_and_ragged(hip, oracle):
 		ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=64, sent_off=corpus["sent_off"], X=Xb, Q=Qb, algorithm=oracle.ALG_RWMD, max_matches=7)
 		assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=1e-5)
 	c.close()
+
+
+def test_batch_with_long_queries(hip, oracle):
+	"""a batch that mixes short and long queries: the long ones fall out of the shared pass onto the multi-block kernel,
+	each result set as from a single query and as the oracle's"""
+	n, d = 777, 300
+	corpus = synth.make_contextual_corpus(n, 1, 64, 1500, d)
+	Xb = prep_contextual(corpus)
+	c = hip_contextual_corpus(hip, corpus, Xb)
+	qs = [prep_query(q) for q in synth.make_queries(corpus, 10, 40)]
+	qs = [q[:m] for q, m in zip(qs, (7, 24, 40, 16, 17, 33, 3, 32, 12, 20))]
+	for loc, ms, gaps in ((0, 0.0, (0.1, 0.1)), (1, -1e9, (EXP5, EXP5))):
+		kw = dict(locality=loc, gap_s=gaps[0], gap_t=gaps[1], max_matches=8, min_score=ms)
+		outs = c.query_batch(qs, q_normalize=False, **kw)
+		for Qb, got in zip(qs, outs):
+			ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=corpus["sent_off"], X=Xb, Q=Qb, **kw)
+			assert_same_results(got.trimmed(), ref)
+			single = c.query(Qb, q_normalize=False, **kw)
+			np.testing.assert_array_equal(got.score[:got.n], single.score[:single.n])
+			np.testing.assert_array_equal(got.mapping[:got.n], single.mapping[:single.n])
+	c.close()
