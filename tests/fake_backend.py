@@ -158,6 +158,9 @@ class OracleCorpus:
 					top.plan[i, :len(q), :b - a] = G
 		return top
 
+	def view(self):
+		return self          # the double keeps no per-query state a second handle would need
+
 	def last_scores(self):
 		return self._all
 

@@ -94,3 +94,18 @@ def test_filters_and_token_windows_on_hip_equal_oracle_double(hip):
 						assert (x.flow["target"] == y.flow["target"]).all()
 					assert a[0].to_json()["regions"] == b[0].to_json()["regions"]
 			gpu.close()
+
+
+def test_find_many_on_hip_equals_find(hip):
+	"""Index.find_many: three queries in flight on views of the resident corpus; every Result as from find()"""
+	session, emb, words, rng = toy_session()
+	sim = OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), alignment.LocalAlignment(gap=alignment.smooth_gap_cost(5)))
+	index = session.partition("sentence").index(sim)
+	texts = [" ".join(session.documents[i % 20].tokens[11 * i:11 * i + 3 + i % 20]) for i in range(40)]
+	many = index.find_many(texts, n=10)
+	for text, res in zip(texts, many):
+		one = index.find(text, n=10)
+		assert [(m.doc_index, m.slice_id) for m in res] == [(m.doc_index, m.slice_id) for m in one]
+		np.testing.assert_array_equal([m.score for m in res], [m.score for m in one])
+		assert all((a.flow["target"] == b.flow["target"]).all() for a, b in zip(res, one))
+	index.close()

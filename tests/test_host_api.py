@@ -102,6 +102,20 @@ def test_find_over_toy_corpus_static_wsb(oracle):
 	np.testing.assert_allclose([m.score for m in result], ref["score"], atol=1e-6)
 
 
+def test_find_many_equals_find():
+	session, emb, words, rng = toy_session(n_docs=4, sents_per_doc=30, V=400, d=48)
+	sim = OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), alignment.LocalAlignment(gap=alignment.smooth_gap_cost(5)))
+	index = session.index(sim, corpus_factory=OracleCorpus)
+	texts = [" ".join(session.documents[i % 4].tokens[7 * i:7 * i + 4 + i % 3]) for i in range(7)] + [""]
+	many = index.find_many(texts, n=5)
+	assert len(many) == len(texts) and many[-1].matches == []
+	for text, res in zip(texts, many):
+		one = index.find(text, n=5)
+		assert [(m.doc_index, m.slice_id, m.score) for m in res] == [(m.doc_index, m.slice_id, m.score) for m in one]
+		assert all((a.flow["target"] == b.flow["target"]).all() for a, b in zip(res, one))
+	index.close()
+
+
 def test_regions_report_gap_penalties_like_the_reference_docs():
 	# the shape of mkdocs/docs/introduction.md:150-184: one skipped document token between
 	# the 2nd and 3rd match costs gap_cost_s(1) = 1 - 2^(-1/5)

@@ -602,6 +602,7 @@ class HipBruteForceIndex(Index):
 			if n_tokens_dev:
 				self._corpus.set_token_tags(self._tag_codes[t0:t1])
 		self._filtered = collections.OrderedDict()   # (pos_mask, tag_mask) -> filtered corpus; the last two filters stay resident
+		self._views = []   # further handles on the resident corpus (find_many)
 		if dev_off is not None:
 			self._corpus.set_sentences(dev_off)
 		else:
@@ -662,7 +663,36 @@ class HipBruteForceIndex(Index):
 				similarity_threshold=float(metric.get("similarity_threshold", 0)))
 		return args, gaps
 
-	def _find(self, query, progress=None):
+	def find_many(self, texts, n=10, min_score=0.0, options: dict = dict(), in_flight=3):
+		"""Several queries, `in_flight` of them at a time on as many handles of the resident corpus (vk_corpus_view:
+		shared arrays, own stream and workspaces) from as many host threads: the selection, traceback and host part of
+		one query run beside the scoring kernel of the next (bench.py measures the path this way).  Returns one Result
+		per text, in order; each equals what `find` returns.  Not part of the reference's Index (which has one
+		ThreadPool task per document inside a single find, vectorian/index.py:544-558)."""
+		from concurrent.futures import ThreadPoolExecutor
+		session = self.session
+		queries = [self.make_query(t, n=n, min_score=min_score, options=options) for t in texts]
+		sequential = self._shard is not None or self._filter_masks(options) is not None or in_flight < 2 or not hasattr(self._corpus, "view")
+		if sequential:
+			return [self.find(t, n=n, min_score=min_score, options=options) for t in texts]
+		while len(self._views) < in_flight - 1:
+			self._views.append(self._corpus.view())
+		handles = [self._corpus] + self._views[:in_flight - 1]
+		start = time.time()
+
+		def run(i):
+			return self._find(queries[i], corpus=handles[i % len(handles)])
+		# query i goes to handle i % in_flight; a handle serves its queries in order (one worker thread per handle)
+		results = [None] * len(queries)
+		with ThreadPoolExecutor(max_workers=len(handles)) as pool:
+			def lane(h):
+				for i in range(h, len(queries), len(handles)):
+					results[i] = run(i)
+			list(pool.map(lane, range(len(handles))))
+		duration = (time.time() - start) / max(1, len(queries))
+		return [session.make_result(self, m, duration=duration) for m in results]
+
+	def _find(self, query, progress=None, corpus=None):
 		p_query = query.prepare(self._nlp)
 		if len(p_query) == 0:
 			return []
@@ -679,7 +709,8 @@ class HipBruteForceIndex(Index):
 		emb = self._embedding
 		qv = emb.encode_tokens(p_query.tokens)
 		masks = self._filter_masks(query.options)
-		corpus = self._filtered_corpus(masks) if masks else self._corpus
+		if corpus is None:
+			corpus = self._filtered_corpus(masks) if masks else self._corpus
 		if emb.is_static:
 			top = corpus.query(qv.unmodified, q_normalize=True, q_token_ids=p_query.token_ids,
 				boost=self._dev_boost, want_flow=True, **args)
@@ -768,9 +799,10 @@ class HipBruteForceIndex(Index):
 		return matches
 
 	def close(self):
-		for c in self._filtered.values():
+		for c in list(self._filtered.values()) + self._views:
 			c.close()
 		self._filtered.clear()
+		self._views = []
 		self._corpus.close()
 
 
