@@ -342,6 +342,9 @@ def main():
 		if not args.no_cpu_baseline and world == 1:
 			out["cpu_baseline"] = cpu_baseline(args.gap)
 		print(json.dumps(out))
+	pool.shutdown()
+	for h in handles[1:]:   # views first, then the handle that owns the arrays
+		h.close()
 	corpus.close()
 	if dist is not None:
 		dist.barrier()
