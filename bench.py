@@ -195,16 +195,30 @@ def main():
 		if force_dist and world == 1:   # no launcher in the one-rank rehearsal
 			for k_, v_ in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_PORT", "29533")):
 				os.environ.setdefault(k_, v_)
-		if backend == "nccl":
-			opts = None
-			try:   # the records are tiny and latency-bound: let the collective's kernel pass the scoring kernel in the queue
-				opts = dist.ProcessGroupNCCL.Options()
-				opts.is_high_priority_stream = True
-			except Exception:
+		# RCCL writes a version banner to stdout (fd 1) when its communicator comes up; stdout is for the ONE JSON line:
+		# fd 1 points at stderr until the first collective has run
+		sys.stdout.flush()
+		saved_fd1 = os.dup(1)
+		os.dup2(2, 1)
+		try:
+			if backend == "nccl":
 				opts = None
-			dist.init_process_group(backend="nccl", device_id=device, pg_options=opts)
-		else:
-			dist.init_process_group(backend=backend)
+				try:   # the records are tiny and latency-bound: let the collective's kernel pass the scoring kernel in the queue
+					opts = dist.ProcessGroupNCCL.Options()
+					opts.is_high_priority_stream = True
+				except Exception:
+					opts = None
+				dist.init_process_group(backend="nccl", device_id=device, pg_options=opts)
+			else:
+				dist.init_process_group(backend=backend)
+			warm = torch.zeros(1, device=device if backend == "nccl" else "cpu")
+			dist.all_reduce(warm)
+			if backend == "nccl":
+				torch.cuda.synchronize()
+		finally:
+			sys.stdout.flush()
+			os.dup2(saved_fd1, 1)
+			os.close(saved_fd1)
 	xdev = device if backend == "nccl" else torch.device("cpu")   # where the exchanged records live
 
 	n_sent = args.sentences
