@@ -1,18 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- sentence-alignments/sec of the brute-force alignment search on MI355X.
 
-Workload (BASELINE.json configs[1], SURVEY 8d "Config 2"): per GPU 1,000,000 sentences x 32
+Headline workload (BASELINE.json configs[1], SURVEY 8d "Config 2"): per GPU 1,000,000 sentences x 32
 tokens x 300-d bf16 (contextual layout, one vector per token occurrence), 10-token query,
 local alignment, k = 10, min_score = 0.  A "step" is one query against the resident shard:
 query upload -> fused similarity (MFMA) + DP kernel -> bounded result set -> flow of the
 winners -> results on the host (N > 1: + all-gather of the per-rank result sets + merge).
 
-  python bench.py --gpus N --steps K --warmup W [--gap exp5|linear] [--sentences n]
+  python bench.py --gpus N --steps K --warmup W [--config 2|3|4|5|5wrd|2f32] [--gap exp5|linear]
+                  [--locality local|global|semiglobal] [--sentences n] [--no-extra]
 
 N > 1 is launched by the driver as
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 Rank 0 prints ONE JSON line.  The corpus is sharded by sentence range (weak scaling: every
-rank holds its own 1M-sentence shard); the only exchange is the all-gather of k records.
+rank holds its own shard of the workload's per-GPU size); the only exchange is the all-gather of k records.
+
+--config picks the workload of the headline `value` (default 2); at N = 1 the other SURVEY 8(d)
+configurations are then timed as well, each on its own resident corpus at its per-GPU shape, and reported
+under "configs" in the same JSON line (per entry: workload, value, kernel, kernel_ms, roofline):
+  3     1.25 M x 32 x 300-d per GPU, global alignment (Needleman-Wunsch), linear gap 0.1   (config 3 = 10 M over 8 GPUs)
+  4     256 queries x 1 M x 32 x 300-d, relaxed WMD rwmd('nbow'), one GEMM-shaped pass     (MFMA-bound)
+  5     1 M sentences of 8..64 tokens x 768-d per GPU, WSB local alignment                  (config 5 = 4 M over 4 GPUs)
+  5wrd  the same corpus, Word Rotator's Distance (bound pass + exact EMD of the survivors)
+  2f32  config 2 with fp32 unit rows (VK_PREC_F32: the reference's own precision, twice the bytes)
 """
 
 import argparse
@@ -26,62 +36,106 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-D = 300
-LEN_S = 32
-LEN_T = 10
 VOCAB = 50000
 K_MATCHES = 10
+LEN_T = 10
 HBM_PEAK = 8.0e12          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-ALG_BYTES_PER_PAIR = LEN_S * D * 2   # |s| * d * 2 bytes (bf16 token vectors, read once)
+MFMA_BF16_PEAK = 2.5e15    # MI355X_MICROARCH.md: dense bf16 MFMA (the 5 PF headline includes 2:1 sparsity)
+
+# the per-GPU shape of each configuration
+WORKLOADS = {
+	"2": dict(name="config2", n_sent=1000000, min_len=32, max_len=32, d=300, alg="align", locality="local", gap="exp5", prec="bf16"),
+	"3": dict(name="config3", n_sent=1250000, min_len=32, max_len=32, d=300, alg="align", locality="global", gap="linear", prec="bf16"),
+	"4": dict(name="config4", n_sent=1000000, min_len=32, max_len=32, d=300, alg="rwmd", locality="local", gap="linear", prec="bf16", batch=256),
+	"5": dict(name="config5_wsb", n_sent=1000000, min_len=8, max_len=64, d=768, alg="align", locality="local", gap="exp5", prec="bf16",
+		noise=0.3, norm_sigma=0.25, magnitudes=True),
+	"5wrd": dict(name="config5_wrd", n_sent=1000000, min_len=8, max_len=64, d=768, alg="wrd", locality="local", gap="linear", prec="bf16",
+		noise=0.3, norm_sigma=0.25, magnitudes=True),
+	"2f32": dict(name="config2_f32", n_sent=1000000, min_len=32, max_len=32, d=300, alg="align", locality="local", gap="exp5", prec="f32"),
+}
+LOCALITIES = {"local": 0, "global": 1, "semiglobal": 2}
 
 
 def gap_spec(name):
 	if name == "linear":
-		return 0.1, 0.1, "local alignment, linear gap u=0.1 (Smith-Waterman)"
+		return 0.1, 0.1, "linear gap u=0.1"
 	w = (1 - 2.0 ** (-np.arange(0, 65) / 5)).astype(np.float32)   # smooth_gap_cost(5)
-	return ("table", w), ("table", w), "local alignment, general gap w(k)=1-2^(-k/5) (Waterman-Smith-Beyer)"
+	return ("table", w), ("table", w), "general gap w(k)=1-2^(-k/5) (Waterman-Smith-Beyer)"
 
 
-def build_shard(core, torch, n_sent, rank, device):
-	"""synthetic shard generated on the GPU in chunks, handed to the library by device pointer"""
+def describe(spec, n_sent):
+	lens = f"{spec['min_len']}" if spec["min_len"] == spec["max_len"] else f"{spec['min_len']}..{spec['max_len']}"
+	rows = f"{n_sent} x {lens}-token synthetic sentences per GPU, {spec['d']}-d {spec['prec']} per-token vectors (contextual layout)"
+	if spec["alg"] == "rwmd":
+		return f"batch of {spec.get('batch', 1)} {LEN_T}-token queries over {rows}, relaxed Word Mover's Distance rwmd('nbow'), top-{K_MATCHES} per query"
+	if spec["alg"] == "wrd":
+		return f"{LEN_T}-token query over {rows}, Word Rotator's Distance (bound pass + exact EMD of the survivors), top-{K_MATCHES}"
+	return f"{LEN_T}-token query over {rows}, {spec['locality']} alignment, {gap_spec(spec['gap'])[2]}, top-{K_MATCHES} with flow"
+
+
+def build_shard(core, torch, spec, n_sent, rank, device):
+	"""synthetic shard generated on the GPU in chunks (clustered vocabulary, Zipf(1.1) token ids, per-token
+	noise), handed to the library by device pointer.  Returns the corpus handle, the vocabulary, the token ids (device) and
+	the sentence offsets."""
 	from vectorian_amd import synth
-	E = synth.make_vocab(VOCAB, D)                                   # seeded, shared by all ranks
+	d = spec["d"]
+	E = synth.make_vocab(VOCAB, d)                                   # seeded, shared by all ranks
 	rng = np.random.default_rng(synth.SEED_CORPUS + 7919 * rank)
-	n_tok = n_sent * LEN_S
-	ids = synth.zipf_ids(n_tok, VOCAB, rng)
-	off = np.arange(n_sent + 1, dtype=np.int64) * LEN_S
-	corpus = core.Corpus(layout=core.VK_LAYOUT_CONTEXTUAL, d=D, n_tokens=n_tok, n_sentences=n_sent)
+	if spec["max_len"] > spec["min_len"]:
+		lens = rng.integers(spec["min_len"], spec["max_len"] + 1, size=n_sent)
+	else:
+		lens = np.full(n_sent, spec["min_len"])
+	off = np.zeros(n_sent + 1, dtype=np.int64)
+	np.cumsum(lens, out=off[1:])
+	n_tok = int(off[-1])
+	corpus = core.Corpus(layout=core.VK_LAYOUT_CONTEXTUAL, d=d, n_tokens=n_tok, n_sentences=n_sent,
+		keep_magnitudes=bool(spec.get("magnitudes")), precision=spec["prec"])
 	E_dev = torch.from_numpy(E).to(device)
 	gen = torch.Generator(device=device)
 	gen.manual_seed(1000 + rank)
-	chunk = 1 << 20
+	p = 1.0 / np.arange(1, VOCAB + 1) ** 1.1
+	cdf = np.cumsum(p)
+	cdf_dev = torch.from_numpy(cdf / cdf[-1]).to(device)
+	ids = torch.empty(n_tok, dtype=torch.int32, device=device)
+	chunk = 1 << 20 if d <= 320 else 1 << 19
+	noise, sigma = spec.get("noise", 0.1), spec.get("norm_sigma", 0.0)
 	for a in range(0, n_tok, chunk):
 		b = min(a + chunk, n_tok)
-		idx = torch.from_numpy(ids[a:b].astype(np.int64)).to(device)
-		x = E_dev[idx] + 0.1 * torch.randn((b - a, D), device=device, generator=gen, dtype=torch.float32)
+		idx = torch.searchsorted(cdf_dev, torch.rand(b - a, device=device, generator=gen, dtype=torch.float64)).clamp_(max=VOCAB - 1)
+		ids[a:b] = idx.to(torch.int32)
+		x = E_dev[idx] + noise * torch.randn((b - a, d), device=device, generator=gen, dtype=torch.float32)
+		if sigma > 0:
+			x = x * torch.exp(sigma * torch.randn((b - a, 1), device=device, generator=gen, dtype=torch.float32))
 		x = x.contiguous()
 		torch.cuda.synchronize()
 		corpus.append_vectors_device(x.data_ptr(), b - a, core.VK_F32, normalize=True)
 		del x, idx
 	corpus.set_sentences(off)
 	corpus.finalize()
-	del E_dev
+	del E_dev, cdf_dev
 	torch.cuda.empty_cache()
-	return corpus, E, ids
+	return corpus, E, ids, off
 
 
-def make_queries(E, ids, n_queries, seed):
+def make_queries(E, ids, off, n_queries, seed):
+	"""half of the queries are noisy copies of LEN_T consecutive tokens of a corpus sentence (planted hits), half random"""
 	rng = np.random.default_rng(seed)
-	n_sent = len(ids) // LEN_S
+	n_sent = len(off) - 1
+	d = E.shape[1]
 	qs = []
 	for i in range(n_queries):
-		if i % 2 == 0:   # planted: noisy copy of 10 consecutive tokens of a corpus sentence
-			s = int(rng.integers(0, n_sent))
-			st = s * LEN_S + int(rng.integers(0, LEN_S - LEN_T + 1))
-			qi = ids[st:st + LEN_T]
-		else:
+		qi = None
+		if i % 2 == 0:
+			for _ in range(64):
+				s = int(rng.integers(0, n_sent))
+				ln = int(off[s + 1] - off[s])
+				if ln >= LEN_T:
+					st = int(off[s]) + int(rng.integers(0, ln - LEN_T + 1))
+					qi = ids[st:st + LEN_T].cpu().numpy().astype(np.int64)
+					break
+		if qi is None:
 			qi = rng.integers(0, VOCAB, size=LEN_T)
-		qs.append(np.ascontiguousarray(E[qi] + 0.05 * rng.standard_normal((LEN_T, D)).astype(np.float32), dtype=np.float32))
+		qs.append(np.ascontiguousarray(E[qi] + 0.05 * rng.standard_normal((LEN_T, d)).astype(np.float32), dtype=np.float32))
 	return qs
 
 
@@ -111,49 +165,195 @@ def usable_cores():
 	return max(1, n)
 
 
-def cpu_baseline(gap_name, budget_s=12.0):
+def cpu_baseline(spec, budget_s=10.0):
 	"""The CPU restatement of the reference algorithm (oracle/, kind "port": the reference's
 	own C++ path cannot be built offline) on a bounded sample of the same workload:
 	all host cores, static sentence ranges per thread (the analogue of the reference's
-	thread-per-document pool, vectorian/index.py:544-558), threads started once per batch."""
+	thread-per-document pool, vectorian/index.py:544-558), threads started once per batch.
+	`value` computes every cosine with the port's scalar dot products; `blas_value` is the form closest to the
+	reference's contextual path: ONE fp32 sgemm per query for the similarity matrix of the whole sample
+	(numpy @ = BLAS, as vectorian/sim/vector.py:66-78 via metric/contextual.cpp:26-63), then the port's DP over its rows."""
 	from oracle import vk_oracle as vo
 	from vectorian_amd import synth
 	cores = usable_cores()
 	n = 8192
-	corpus = synth.make_contextual_corpus(n, LEN_S, LEN_S, VOCAB, D)
-	Xb = synth.to_bf16_bits(synth.normalize_rows(corpus["X"]))
-	qs = [synth.to_bf16_bits(synth.normalize_rows(q["vectors"])) for q in synth.make_queries(corpus, 16, LEN_T)]
-	gs, gt, _ = gap_spec(gap_name)
-	kw = dict(layout=vo.LAYOUT_CONTEXTUAL, d=D, sent_off=corpus["sent_off"], X=Xb, locality=vo.LOCAL,
+	d, ls0, ls1 = spec["d"], spec["min_len"], spec["max_len"]
+	corpus = synth.make_contextual_corpus(n, ls0, ls1, VOCAB, d, noise=spec.get("noise", 0.1), norm_sigma=spec.get("norm_sigma", 0.0))
+	Xn = synth.normalize_rows(corpus["X"])
+	Xb = synth.to_bf16_bits(Xn)
+	qraw = synth.make_queries(corpus, 16, LEN_T)
+	qs = [synth.to_bf16_bits(synth.normalize_rows(q["vectors"])) for q in qraw]
+	gs, gt, _ = gap_spec(spec["gap"])
+	alg = {"align": vo.ALG_ALIGN, "rwmd": vo.ALG_RWMD, "wrd": vo.ALG_WRD}[spec["alg"]]
+	kw = dict(layout=vo.LAYOUT_CONTEXTUAL, d=d, sent_off=corpus["sent_off"], X=Xb, algorithm=alg, locality=LOCALITIES[spec["locality"]],
 		gap_s=gs, gap_t=gt, max_matches=K_MATCHES, min_score=0.0, n_threads=cores)
-	t0 = time.perf_counter()
-	vo.find_many(Qs=qs[:2], **kw)                      # calibrate the batch size to the budget
-	per_q = (time.perf_counter() - t0) / 2
-	batch = int(max(2, min(4096, budget_s / max(per_q, 1e-6))))
-	Qs = [qs[i % len(qs)] for i in range(batch)]
-	t0 = time.perf_counter()
-	vo.find_many(Qs=Qs, **kw)
-	el = time.perf_counter() - t0
-	# beside it (SURVEY 8d): one thread, and the reference's own static layout (token ids + per-query table [V x |q|])
-	def rate(budget, n_sent, **over):
+	if spec["alg"] == "wrd":
+		kw["X_mag"] = vo.magnitudes(corpus["X"])
+		kw["Q_mags"] = None
+	def rate(budget, n_sent, cap, **over):
 		k2 = dict(kw, **over)
+		mags = (lambda m: [vo.magnitudes(qraw[i % len(qraw)]["vectors"]) for i in range(m)]) if spec["alg"] == "wrd" else (lambda m: None)
 		t1 = time.perf_counter()
-		vo.find_many(Qs=qs[:1], **k2)
-		b = int(max(1, min(1024, budget / max(time.perf_counter() - t1, 1e-6))))
+		vo.find_many(Qs=qs[:2], **dict(k2, Q_mags=mags(2)))          # calibrate the batch size to the budget
+		per_q = (time.perf_counter() - t1) / 2
+		b = int(max(2, min(cap, budget / max(per_q, 1e-6))))
 		t1 = time.perf_counter()
-		vo.find_many(Qs=[qs[i % len(qs)] for i in range(b)], **k2)
-		return n_sent * b / (time.perf_counter() - t1)
-	single = rate(3.0, n, n_threads=1)
-	n_st = 16 * n      # the per-query table over the vocabulary is amortised over the slices, as in the full workload
-	st = synth.make_static_corpus(n_st, LEN_S, LEN_S, VOCAB, D)
-	Eb = synth.to_bf16_bits(synth.normalize_rows(st["E"]))
-	static = rate(3.0, n_st, layout=vo.LAYOUT_STATIC, X=None, sent_off=st["sent_off"], tok_id=st["tok_id"], E=Eb)
-	return {
-		"value": n * batch / el, "unit": "sentence-alignments/sec", "cores": cores, "kind": "port",
-		"single_thread_value": single, "static_layout_value": static,
-		"sample": f"{batch} queries x {n} sentences x {LEN_S} tokens x {D}-d (same generator as the GPU workload), "
-			f"{cores} threads, {el:.1f} s; CPU restatement of the reference algorithm (reference not runnable offline); "
-			f"single_thread_value: the same on one thread; static_layout_value: token ids + per-query table over {n_st} slices, {cores} threads"}
+		vo.find_many(Qs=[qs[i % len(qs)] for i in range(b)], **dict(k2, Q_mags=mags(b)))
+		el = time.perf_counter() - t1
+		return n_sent * b / el, b, el
+	value, batch, el = rate(budget_s, n, 4096)
+	out = {
+		"value": value, "unit": "sentence-alignments/sec", "cores": cores, "kind": "port",
+		"sample": f"{batch} queries x {n} sentences x {ls0 if ls0 == ls1 else str(ls0) + '..' + str(ls1)} tokens x {d}-d (same generator as the GPU workload), "
+			f"{cores} threads, {el:.1f} s; CPU restatement of the reference algorithm (reference not runnable offline)"}
+	# beside it (SURVEY 8d): one thread
+	out["single_thread_value"] = rate(2.5, n, 1024, n_threads=1)[0]
+	out["sample"] += "; single_thread_value: the same on one thread"
+	if spec["alg"] == "align":
+		# BLAS leg: S = X . Q^T by sgemm (fp32 unit rows, as the reference computes it), clip, then the port's DP
+		def blas_run(b):
+			S = [np.clip(Xn @ synth.normalize_rows(qraw[i % len(qraw)]["vectors"]).T, 0.0, 1.0) for i in range(b)]
+			vo.find_many(Qs=[qs[i % len(qs)] for i in range(b)], S_rows=S, **kw)
+		t1 = time.perf_counter()
+		blas_run(2)
+		per_q = (time.perf_counter() - t1) / 2
+		b = int(max(2, min(2048, 4.0 / max(per_q, 1e-6))))
+		t1 = time.perf_counter()
+		blas_run(b)
+		out["blas_value"] = n * b / (time.perf_counter() - t1)
+		out["sample"] += f"; blas_value: {b} queries, one numpy sgemm [{Xn.shape[0]} x {d}] x [{d} x {LEN_T}] per query (BLAS threads: numpy's default) + the port's DP on {cores} threads"
+		# the reference's own static layout (token ids + per-query table [V x |q|])
+		n_st = 16 * n      # the per-query table over the vocabulary is amortised over the slices, as in the full workload
+		st = synth.make_static_corpus(n_st, ls0, ls1, VOCAB, d)
+		Eb = synth.to_bf16_bits(synth.normalize_rows(st["E"]))
+		out["static_layout_value"] = rate(2.5, n_st, 1024, layout=vo.LAYOUT_STATIC, X=None, sent_off=st["sent_off"], tok_id=st["tok_id"], E=Eb)[0]
+		out["sample"] += f"; static_layout_value: token ids + per-query table over {n_st} slices, {cores} threads"
+	return out
+
+
+class Runner:
+	"""Keeps queries in flight on one resident shard: three handles (vk_corpus_view: shared arrays, own stream and
+	workspaces), one host thread each: query i + 1 is scored while the result set of query i is selected, retraced and
+	copied out (measured in round 1: 331 M/s with two handles, 342 M/s with three, 337 M/s with four).  Every query is
+	complete (top-k with flow on the host; with several ranks: merged across ranks) inside the timed region."""
+
+	def __init__(self, core, torch, corpus, spec, n_sent, dist, xdev, rank, n_handles, gap_name=None, locality=None):
+		from concurrent.futures import ThreadPoolExecutor
+		from vectorian_amd import shards
+		self.core, self.torch, self.corpus, self.spec, self.n_sent = core, torch, corpus, spec, n_sent
+		self.dist, self.xdev, self.rank, self.shards = dist, xdev, rank, shards
+		self.batch = int(spec.get("batch", 0))
+		self.handles = [corpus] + [corpus.view() for _ in range((1 if self.batch else n_handles) - 1)]
+		self.pool = ThreadPoolExecutor(max_workers=len(self.handles))
+		self.inflight, self.pending, self.unsent = [], [], []
+		self.gather_batch = max(1, int(os.environ.get("VK_BENCH_GATHER_BATCH", "4")))   # result sets of this many queries travel in one all-gather
+		self.gather_depth = int(os.environ.get("VK_BENCH_GATHER_DEPTH", "1"))   # a collective gets this many further exchanges to complete before anyone waits for it
+		self.submitted = 0
+		self.score_ms, self.phases = [], []
+		gs, gt, _ = gap_spec(gap_name or spec["gap"])
+		alg = {"align": core.VK_ALG_ALIGN, "rwmd": core.VK_ALG_RWMD, "wrd": core.VK_ALG_WRD}[spec["alg"]]
+		self.options = dict(algorithm=alg, locality=LOCALITIES[locality or spec["locality"]], gap_s=gs, gap_t=gt, q_normalize=True,
+			max_matches=K_MATCHES, min_score=0.0, want_flow=spec["alg"] == "align")
+
+	def _run(self, h, q):
+		if self.batch:
+			tops = h.query_batch(q, **self.options)
+			return tops, h.last_timings()
+		top = h.query(q, **self.options)
+		return [top], h.last_timings()
+
+	def _exchange(self):
+		if self.unsent:
+			# per-rank result sets -> all ranks (RCCL all-gather over xGMI), then ResultSet.extend
+			self.pending.append(self.shards.allgather_start(list(self.unsent), self.rank * self.n_sent, K_MATCHES, device=self.xdev))
+			self.unsent.clear()
+
+	def _drain(self, keep=0):
+		while len(self.pending) > keep:
+			self.shards.allgather_finish(self.pending.pop(0))   # global top-k of earlier queries on every rank
+
+	def _retire(self):
+		tops, ph = self.inflight.pop(0).result()
+		self.score_ms.append(ph["score_ms"])
+		self.phases.append(ph)
+		if self.dist is None:
+			return
+		self.unsent.extend(tops)
+		if len(self.unsent) >= self.gather_batch:
+			self._exchange()
+		self._drain(keep=self.gather_depth)
+
+	def step(self, q):
+		h = self.handles[self.submitted % len(self.handles)]
+		self.submitted += 1
+		self.inflight.append(self.pool.submit(self._run, h, q))
+		if len(self.inflight) >= len(self.handles):
+			self._retire()
+
+	def sync(self):
+		while self.inflight:
+			self._retire()
+		self._exchange()
+		self._drain()
+		self.torch.cuda.synchronize()
+		if self.dist is not None:
+			self.dist.barrier()
+			self.torch.cuda.synchronize()
+
+	def run(self, queries, warmup, steps):
+		"""queries: warmup + steps entries (an entry = one query, or the list of a batch).  Returns the elapsed seconds of the
+		timed steps."""
+		for i in range(warmup):
+			self.step(queries[i])
+			if i < len(self.handles):
+				self.sync()   # the first query of a handle has no predecessor to queue behind: one at a time, so that no two
+				              # scoring kernels share the GPU (afterwards a handle's kernel waits for its peer's on the device)
+		self.sync()
+		self.score_ms.clear()
+		self.phases.clear()
+		t0 = time.perf_counter()
+		for i in range(steps):
+			self.step(queries[warmup + i])
+		self.sync()
+		return time.perf_counter() - t0
+
+	def close(self):
+		self.pool.shutdown()
+		for h in self.handles[1:]:   # views first, then the handle that owns the arrays (the caller closes that one)
+			h.close()
+
+
+def roofline_of(spec, n_sent, n_tok, kern_s):
+	"""the dominant kernel against the roofline that bounds it: algorithmic bytes = |s| * d * 2 per (query,
+	sentence) pair (bf16 token vectors read once; fp32 rows: * 4; WRD: + 4 bytes of magnitude per token), padding not
+	counted; config 4: 2 * |s| * |q| * d flops per pair against the dense bf16 MFMA peak"""
+	d = spec["d"]
+	if spec.get("batch"):
+		flops = 2.0 * n_tok * spec["batch"] * LEN_T * d
+		ach = flops / kern_s
+		return {"bound": "mfma", "achieved": ach / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK,
+			"kernel": "vk_rwmd_batch32_kernel", "kernel_ms": kern_s * 1e3, "algorithmic_flops_per_launch": flops}
+	nbytes = n_tok * d * (4 if spec["prec"] == "f32" else 2) + (4 * n_tok if spec["alg"] == "wrd" else 0)
+	ach = nbytes / kern_s
+	return {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
+		"kernel": "vk_score_kernel" + (" (WRD bound pass)" if spec["alg"] == "wrd" else ""), "kernel_ms": kern_s * 1e3,
+		"algorithmic_bytes_per_launch": nbytes}
+
+
+def traffic_of(name, gap, n_sent, nominal):
+	"""HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/traffic.json: rocprofv3 --pmc
+	FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this script, gfx950 correction applied) -- not measured in this run"""
+	path = os.path.join(ROOT, "profiles", "traffic.json")
+	if n_sent != nominal or not os.path.exists(path):
+		return None, None
+	try:
+		t = json.load(open(path))
+	except Exception:
+		return None, None
+	e = t.get(name + ":" + gap) or (t.get(gap) if name == "config2" else None)
+	if not e:
+		return None, None
+	return e.get("hbm_bytes_per_launch"), "profiles/traffic.json (" + e.get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, round 1") + "); not measured in this run"
 
 
 def main():
@@ -161,10 +361,17 @@ def main():
 	ap.add_argument("--gpus", type=int, default=1)
 	ap.add_argument("--steps", type=int, default=40)
 	ap.add_argument("--warmup", type=int, default=5)
-	ap.add_argument("--gap", choices=["exp5", "linear"], default="exp5")
-	ap.add_argument("--sentences", type=int, default=1000000, help="sentences per GPU")
+	ap.add_argument("--config", choices=sorted(WORKLOADS), default="2", help="workload of the headline value")
+	ap.add_argument("--gap", choices=["exp5", "linear"], default=None, help="gap costs of the headline alignment workload (default: the config's)")
+	ap.add_argument("--locality", choices=sorted(LOCALITIES), default=None, help="locality of the headline alignment workload (default: the config's)")
+	ap.add_argument("--sentences", type=int, default=0, help="sentences per GPU of the headline workload (default: the config's per-GPU size)")
 	ap.add_argument("--no-cpu-baseline", action="store_true")
 	ap.add_argument("--no-pipeline", action="store_true", help="one handle, one query at a time")
+	ap.add_argument("--no-extra", action="store_true", help="headline workload only (no \"configs\" object)")
+	ap.add_argument("--extra", default="4,3,2f32,5,5wrd", help="the other configurations timed at N = 1 after the headline")
+	ap.add_argument("--extra-steps", type=int, default=12)
+	ap.add_argument("--extra-warmup", type=int, default=4)
+	ap.add_argument("--extra-scale", type=float, default=1.0, help="scales the sentence counts of the extra configurations (rehearsals)")
 	args = ap.parse_args()
 
 	import torch
@@ -221,145 +428,108 @@ def main():
 			os.close(saved_fd1)
 	xdev = device if backend == "nccl" else torch.device("cpu")   # where the exchanged records live
 
-	n_sent = args.sentences
-	corpus, E, ids = build_shard(core, torch, n_sent, rank, device)
-	queries = make_queries(E, ids, args.steps + args.warmup, seed=3456)
-	if dist is not None:   # one query stream for the whole job: rank 0's
-		qt = torch.from_numpy(np.stack(queries)).to(xdev)
-		dist.broadcast(qt, src=0)
-		queries = list(qt.cpu().numpy())
-	gs, gt, gap_desc = gap_spec(args.gap)
-
-	from vectorian_amd import shards
-
-	# Three handles on the resident shard (vk_corpus_view: shared arrays, own stream and workspaces), one host thread each:
-	# query i + 1 is scored while the result set of query i is selected, retraced and copied out (measured: 331 M/s with
-	# two handles, 342 M/s with three, 337 M/s with four).  Every query is
-	# complete (top-k with flow on the host; with several ranks: merged across ranks) inside the timed region.
-	from concurrent.futures import ThreadPoolExecutor
 	n_handles = 1 if args.no_pipeline else max(1, int(os.environ.get("VK_BENCH_HANDLES", "3")))
-	handles = [corpus] + [corpus.view() for _ in range(n_handles - 1)]
-	pool = ThreadPoolExecutor(max_workers=len(handles))
-	inflight = []      # futures of submitted queries, oldest first
-	pending = []       # exchanges of earlier queries, in flight while later ones are scored (oldest first)
-	GATHER_BATCH = max(1, int(os.environ.get("VK_BENCH_GATHER_BATCH", "4")))   # result sets of this many queries travel in one all-gather
-	GATHER_DEPTH = int(os.environ.get("VK_BENCH_GATHER_DEPTH", "1"))   # a collective gets this many further exchanges to complete before anyone waits for it
-	unsent = []        # result sets of finished queries, waiting for their exchange
-	submitted = [0]
-	score_ms = []
 
-	def run_query(h, q):
-		top = h.query(q, locality=core.Locality.LOCAL, gap_s=gs, gap_t=gt, q_normalize=True,
-			max_matches=K_MATCHES, min_score=0.0, want_flow=True)
-		return top, h.last_timings()["score_ms"]
+	def measure(key, n_sent, warmup, steps, use_dist, gap=None, locality=None, keep=None):
+		"""builds (or takes over) the resident shard of a workload, runs warmup + steps, returns the report entry"""
+		spec = dict(WORKLOADS[key])
+		if gap and spec["alg"] == "align":
+			spec["gap"] = gap
+		if locality and spec["alg"] == "align":
+			spec["locality"] = locality
+		if keep is not None and keep.get("shape") == (n_sent, spec["min_len"], spec["max_len"], spec["d"], spec["prec"], bool(spec.get("magnitudes"))):
+			corpus, E, ids, off = keep["shard"]
+		else:
+			if keep is not None and keep.get("shard"):
+				keep["shard"][0].close()
+				keep.clear()
+				torch.cuda.empty_cache()
+			corpus, E, ids, off = build_shard(core, torch, spec, n_sent, rank, device)
+			if keep is not None:
+				keep["shape"] = (n_sent, spec["min_len"], spec["max_len"], spec["d"], spec["prec"], bool(spec.get("magnitudes")))
+				keep["shard"] = (corpus, E, ids, off)
+		n_tok = int(off[-1])
+		batch = int(spec.get("batch", 0))
+		if batch:
+			pool_q = make_queries(E, ids, off, batch + 8, seed=3456)
+			queries = [[pool_q[(i + j) % len(pool_q)] for j in range(batch)] for i in range(warmup + steps)]
+		else:
+			queries = make_queries(E, ids, off, warmup + steps, seed=3456)
+			if use_dist is not None:   # one query stream for the whole job: rank 0's
+				qt = torch.from_numpy(np.stack(queries)).to(xdev)
+				use_dist.broadcast(qt, src=0)
+				queries = list(qt.cpu().numpy())
+		r = Runner(core, torch, corpus, spec, n_sent, use_dist, xdev, rank, n_handles)
+		try:
+			elapsed = r.run(queries, warmup, steps)
+		finally:
+			r.close()
+		if keep is None:
+			corpus.close()
+		if use_dist is not None:
+			t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
+			use_dist.all_reduce(t, op=use_dist.ReduceOp.MAX)
+			elapsed = float(t.item())
+		pairs = n_sent * max(1, batch) * (world if use_dist is not None else 1) * steps
+		kern_s = float(np.mean(r.score_ms)) * 1e-3
+		entry = {
+			"workload": describe(spec, n_sent), "value": pairs / elapsed, "unit": "sentence-alignments/sec",
+			"steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "dtype": spec["prec"],
+			"sentences_per_gpu": n_sent, "tokens_per_gpu": n_tok, "d": spec["d"],
+			"roofline": roofline_of(spec, n_sent, n_tok, kern_s),
+			"phases_ms_mean": {k: float(np.mean([p[k] for p in r.phases])) for k in r.phases[0]} if r.phases else {},
+		}
+		entry["kernel"], entry["kernel_ms"] = entry["roofline"]["kernel"], entry["roofline"]["kernel_ms"]
+		return spec, entry
 
-	def exchange():
-		if unsent:
-			# per-rank result sets -> all ranks (RCCL all-gather over xGMI), then ResultSet.extend
-			pending.append(shards.allgather_start(list(unsent), rank * n_sent, K_MATCHES, device=xdev))
-			unsent.clear()
+	keep = {}
+	head = WORKLOADS[args.config]
+	n_sent = args.sentences or head["n_sent"]
+	spec, entry = measure(args.config, n_sent, args.warmup, args.steps, dist, gap=args.gap, locality=args.locality, keep=keep)
+	traffic, traffic_source = traffic_of(spec["name"], spec["gap"], n_sent, head["n_sent"])
 
-	def drain(keep=0):
-		merged = None
-		while len(pending) > keep:
-			merged = shards.allgather_finish(pending.pop(0))[-1]   # global top-k of earlier queries on every rank
-		return merged
-
-	prof = {"wait": 0.0, "start": 0.0, "finish": 0.0} if os.environ.get("VK_BENCH_PROFILE") else None
-
-	def retire():
-		t_a = time.perf_counter()
-		top, ms = inflight.pop(0).result()
-		score_ms.append(ms)
-		if dist is None:
-			return top
-		t_b = time.perf_counter()
-		unsent.append(top)
-		if len(unsent) >= GATHER_BATCH:
-			exchange()
-		t_c = time.perf_counter()
-		merged = drain(keep=GATHER_DEPTH)
-		if prof is not None:
-			prof["wait"] += t_b - t_a; prof["start"] += t_c - t_b; prof["finish"] += time.perf_counter() - t_c
-		return merged
-
-	def step(q):
-		h = handles[submitted[0] % len(handles)]
-		submitted[0] += 1
-		inflight.append(pool.submit(run_query, h, q))
-		if len(inflight) >= len(handles):
-			return retire()
-		return None
-
-	def sync():
-		while inflight:
-			retire()
-		exchange()
-		drain()
-		torch.cuda.synchronize()
-		if dist is not None:
-			dist.barrier()
-			torch.cuda.synchronize()
-
-	for i in range(args.warmup):
-		step(queries[i])
-		if i < len(handles):
-			sync()   # the first query of a handle has no predecessor to queue behind: one at a time, so that no two
-			         # scoring kernels share the GPU (afterwards a handle's kernel waits for its peer's on the device)
-	sync()
-	score_ms.clear()
-	t0 = time.perf_counter()
-	for i in range(args.steps):
-		step(queries[args.warmup + i])
-	sync()
-	elapsed = time.perf_counter() - t0
-	timings = corpus.last_timings()
-	if prof is not None and rank == 0:
-		print("bench.py host profile (s, warmup included):", prof, file=sys.stderr)
-
-	if dist is not None:
-		t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
-		dist.all_reduce(t, op=dist.ReduceOp.MAX)
-		elapsed = float(t.item())
-
+	out = None
 	if rank == 0:
-		total_pairs = n_sent * world * args.steps
-		value = total_pairs / elapsed
-		kern_s = float(np.mean(score_ms)) * 1e-3
-		achieved = n_sent * ALG_BYTES_PER_PAIR / kern_s
-		traffic = None
-		prof = os.path.join(ROOT, "profiles", "traffic.json")
-		if os.path.exists(prof):
-			try:
-				traffic = json.load(open(prof)).get(args.gap, {}).get("hbm_bytes_per_launch") if n_sent == 1000000 else None
-			except Exception:
-				traffic = None
+		roof = dict(entry["roofline"])
+		roof["traffic"] = traffic
+		roof["traffic_source"] = traffic_source
 		out = {
 			"metric": "sentence-alignments/sec at d=300, |q|=10, |s|<=64; 1/2/4/8 GPU + %HBM roofline",
-			"value": value, "unit": "sentence-alignments/sec",
+			"value": entry["value"], "unit": "sentence-alignments/sec",
 			"n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-			"ms_per_step": elapsed / args.steps * 1e3,
+			"ms_per_step": entry["ms_per_step"],
 			"higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-			"dtype": "bf16", "data": "synthetic",
+			"dtype": spec["prec"], "data": "synthetic",
 			"config": {
-				"workload": f"{LEN_T}-token query over {n_sent} x {LEN_S}-token synthetic sentences per GPU, "
-					f"{D}-d bf16 per-token vectors (contextual layout), {gap_desc}, top-{K_MATCHES} with flow",
-				"sentences_per_gpu": n_sent, "len_s": LEN_S, "len_t": LEN_T, "d": D, "k": K_MATCHES,
-				"gap": args.gap, "parallelism": f"corpus shards x{world}, RCCL all-gather of k records"},
-			"roofline": {
-				"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-				"frac": achieved / HBM_PEAK, "traffic": traffic,
-				"kernel": "vk_score_kernel", "kernel_ms": kern_s * 1e3,
-				"algorithmic_bytes_per_launch": n_sent * ALG_BYTES_PER_PAIR},
-			"phases_ms_last_step": timings,
+				"workload": entry["workload"], "name": spec["name"],
+				"sentences_per_gpu": n_sent, "len_s": [spec["min_len"], spec["max_len"]], "len_t": LEN_T, "d": spec["d"], "k": K_MATCHES,
+				"algorithm": spec["alg"], "locality": spec["locality"], "gap": spec["gap"], "queries_per_step": max(1, int(spec.get("batch", 0))),
+				"parallelism": f"corpus shards x{world}, RCCL all-gather of k records"},
+			"roofline": roof,
+			"phases_ms_mean": entry["phases_ms_mean"],
 		}
+
+	# ---- the other SURVEY 8(d) configurations, one GPU, each on its own resident corpus --------------------------
+	if world == 1 and dist is None and not args.no_extra:
+		configs = {}
+		for key in [k for k in args.extra.split(",") if k and k in WORKLOADS and k != args.config]:
+			w = WORKLOADS[key]
+			n_x = max(4096, int(w["n_sent"] * args.extra_scale))
+			try:
+				_, e = measure(key, n_x, args.extra_warmup, args.extra_steps, None, keep=keep)
+			except Exception as ex:   # a configuration that fails is reported, the headline stands
+				e = {"workload": describe(w, n_x), "error": f"{type(ex).__name__}: {ex}"}
+			configs[w["name"]] = e
+		out["configs"] = configs
+	if keep.get("shard"):
+		keep["shard"][0].close()
+		keep.clear()
+		torch.cuda.empty_cache()
+
+	if rank == 0:
 		if not args.no_cpu_baseline and world == 1:
-			out["cpu_baseline"] = cpu_baseline(args.gap)
+			out["cpu_baseline"] = cpu_baseline(spec)
 		print(json.dumps(out))
-	pool.shutdown()
-	for h in handles[1:]:   # views first, then the handle that owns the arrays
-		h.close()
-	corpus.close()
 	if dist is not None:
 		dist.barrier()
 		dist.destroy_process_group()

@@ -879,7 +879,10 @@ static int score_sentence(const work *w, int64_t s, float *Sbuf, float *xbuf, fl
 	if (len_s < 1) return 1; /* document.h:160 */
 	if (len_s > VKO_MAX_LEN_S) return 2;
 
-	if (c->layout == VKO_LAYOUT_CONTEXTUAL) {
+	if (c->layout == VKO_LAYOUT_CONTEXTUAL && q->S_rows) {
+		/* slice/contextual.h:65-67: rows of the matrix the caller's sgemm produced (metric/contextual.cpp:26-63) */
+		memcpy(Sbuf, q->S_rows + t0 * (int64_t)len_t, sizeof(float) * (size_t)len_s * len_t);
+	} else if (c->layout == VKO_LAYOUT_CONTEXTUAL) {
 		for (int32_t i = 0; i < len_s; i++) {
 			const float *xr = xbuf;
 			if (c->X_f32) xr = c->X_f32 + (t0 + i) * (int64_t)c->d;

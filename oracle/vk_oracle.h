@@ -151,6 +151,11 @@ typedef struct {
 	float similarity_threshold;
 	int32_t wmd_full;         /* VKO_ALG_RWMD with relaxed = False: full WMD */
 	const float *Q_f32;       /* fp32 unit rows [len_t x d], used when non-NULL */
+	/* contextual layout: the per-document similarity matrix already computed by the caller, clipped,
+	 * [n_tokens x len_t] -- how the reference itself proceeds (metric/contextual.cpp:26-63 fills the matrix with ONE
+	 * sgemm per document through vectorian/sim/vector.py:66-78, slice/contextual.h:65-67 then reads S[offset + i][j]);
+	 * used when non-NULL (bench.py's BLAS leg of the CPU baseline) */
+	const float *S_rows;
 } vko_query;
 
 typedef struct {

@@ -57,7 +57,7 @@ class Query(C.Structure):
 		("wrd_normalize_magnitudes", C.c_int32),
 		("tag_weights", C.c_void_p), ("q_pos", C.c_void_p),
 		("pos_mismatch_penalty", C.c_float), ("similarity_threshold", C.c_float), ("wmd_full", C.c_int32),
-		("Q_f32", C.c_void_p)]
+		("Q_f32", C.c_void_p), ("S_rows", C.c_void_p)]
 
 
 class Result(C.Structure):
@@ -263,9 +263,12 @@ def find_many(*, layout, d, sent_off, Qs, sent_end=None, X=None, X_mag=None, tok
 		algorithm=ALG_ALIGN, locality=LOCAL, gap_s=0.0, gap_t=0.0, q_ids=None, Q_mags=None,
 		max_matches=10, min_score=0.0, boost=None, submatch_weight=0.0,
 		rwmd=(True, True, True), wrd_normalize=True, n_threads=1, want_all_scores=False,
-		pos_s=None, tag_weights=None, q_pos=None, pos_mismatch_penalty=0.0, similarity_threshold=0.0, wmd_full=False):
+		pos_s=None, tag_weights=None, q_pos=None, pos_mismatch_penalty=0.0, similarity_threshold=0.0, wmd_full=False,
+		S_rows=None):
 	"""Runs vko_find_many over a batch of queries (Qs: list of uint16 bf16 [len_t x d]); q_ids / Q_mags
-	are per-query lists or None.  Returns a list of dict(score, raw, sentence, mapping[, all_scores])."""
+	are per-query lists or None.  S_rows: per-query list of float32 [n_tokens x len_t] similarity matrices the caller
+	computed itself (contextual layout; the reference's one-sgemm-per-document form).  Returns a list of
+	dict(score, raw, sentence, mapping[, all_scores])."""
 	keep = []
 	c = Corpus()
 	sent_off = np.ascontiguousarray(sent_off, dtype=np.int64)
@@ -323,6 +326,11 @@ def find_many(*, layout, d, sent_off, Qs, sent_end=None, X=None, X_mag=None, tok
 		q.rwmd_injective, q.rwmd_symmetric, q.rwmd_normalize_bow = [int(x) for x in rwmd]
 		q.wrd_normalize_magnitudes = int(wrd_normalize)
 		q.wmd_full = int(bool(wmd_full))
+		if S_rows is not None and S_rows[i] is not None:
+			sr = np.ascontiguousarray(S_rows[i], dtype=np.float32)
+			if sr.shape != (c.n_tokens, Q.shape[0]):
+				raise ValueError("S_rows must be [n_tokens x len_t]")
+			keep.append(sr); q.S_rows = _ptr(sr)
 		if tag_weights is not None and tag_weights[i] is not None:
 			tw = _f32(tag_weights[i]); keep.append(tw); q.tag_weights = _ptr(tw)
 			if q_pos is not None and q_pos[i] is not None:

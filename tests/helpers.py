@@ -39,10 +39,11 @@ def hip_static_corpus(core, corpus):
 	return c, Eb
 
 
-def assert_same_results(got, ref, *, score_tol=1e-4, tie_tol=2e-6, check_mapping=True):
+def assert_same_results(got, ref, *, score_tol=1e-4, tie_tol=2e-6, check_mapping=True, mapping_filter=None):
 	"""got: core.TopK.trimmed(); ref: oracle.find() dict.
 	Scores within score_tol; identical sentence ids and mappings, except where the
-	oracle's own scores are closer than tie_tol (fp32 accumulation-order ties)."""
+	oracle's own scores are closer than tie_tol (fp32 accumulation-order ties).
+	mapping_filter(sentence) -> bool: compare the mapping of that winner (default: all of them)."""
 	n = len(ref["score"])
 	assert len(got["score"]) == n, (len(got["score"]), n)
 	np.testing.assert_allclose(got["score"], ref["score"], atol=score_tol, rtol=0)
@@ -51,5 +52,21 @@ def assert_same_results(got, ref, *, score_tol=1e-4, tie_tol=2e-6, check_mapping
 			near = np.abs(ref["score"] - ref["score"][i]) <= tie_tol
 			assert near.sum() > 1, (i, got["sentence"][i], ref["sentence"][i], ref["score"][:n])
 			continue
-		if check_mapping:
+		if check_mapping and (mapping_filter is None or mapping_filter(int(ref["sentence"][i]))):
 			assert (got["mapping"][i] == ref["mapping"][i]).all(), (i, got["mapping"][i], ref["mapping"][i])
+
+
+def assert_json_close(a, b, tol, path="$"):
+	"""two JSON-like structures: same shape, keys and non-float leaves; floats within tol"""
+	if isinstance(a, dict):
+		assert isinstance(b, dict) and set(a) == set(b), (path, a, b)
+		for k in a:
+			assert_json_close(a[k], b[k], tol, f"{path}.{k}")
+	elif isinstance(a, (list, tuple)):
+		assert isinstance(b, (list, tuple)) and len(a) == len(b), (path, a, b)
+		for i, (x, y) in enumerate(zip(a, b)):
+			assert_json_close(x, y, tol, f"{path}[{i}]")
+	elif isinstance(a, (float, np.floating)):
+		assert abs(float(a) - float(b)) <= tol, (path, a, b)
+	else:
+		assert a == b, (path, a, b)

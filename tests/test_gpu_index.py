@@ -4,6 +4,8 @@ return what the same surface returns on the oracle-backed double."""
 import numpy as np
 import pytest
 
+from helpers import assert_json_close
+
 from fake_backend import OracleCorpus
 from test_host_api import toy_session
 from vectorian_amd import alignment
@@ -34,7 +36,7 @@ def test_index_find_on_hip_equals_oracle_double(hip, optimizer):
 		for x, y in zip(a, b):
 			assert (x.flow["target"] == y.flow["target"]).all()
 			np.testing.assert_allclose(x.flow["dist"], y.flow["dist"], atol=1e-4)
-		assert a[0].to_json()["regions"] == b[0].to_json()["regions"] or True
+		assert_json_close(a[0].to_json()["regions"], b[0].to_json()["regions"], 1e-4)   # same pieces of text and matched tokens; numbers at the parity tolerance
 	gpu.close()
 
 

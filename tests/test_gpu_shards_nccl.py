@@ -1,0 +1,55 @@
+"""-m gpu: the exchange step of the sharded path (vectorian_amd/shards.py) on the real backend -- RCCL (torch.distributed
+backend "nccl") and the HIP library in ONE process, on result sets that come out of core.Corpus.  One rank: the box has one
+GPU; the collective, its stream, the pinned staging and the merge are the code every rank of an 8-GPU job runs
+(tests/test_shards_gloo.py covers world_size 2 on the CPU)."""
+
+import os
+
+import numpy as np
+import pytest
+
+from vectorian_amd import shards, synth
+
+from helpers import hip_contextual_corpus, prep_query
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nccl_group(hip):
+	import torch
+	import torch.distributed as dist
+	for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29541"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+		os.environ.setdefault(k, v)
+	dist.init_process_group(backend="nccl", device_id=torch.device("cuda", 0))
+	yield dist
+	dist.destroy_process_group()
+
+
+def test_allgather_of_hip_result_sets_over_rccl(hip, nccl_group):
+	import torch
+	corpus = synth.make_contextual_corpus(3000, 4, 40, 2000, 64)
+	c = hip_contextual_corpus(hip, corpus)
+	k = 7
+	tops = []
+	for q in synth.make_queries(corpus, 5, 6):
+		tops.append(c.query(prep_query(q), q_normalize=False, locality=hip.Locality.LOCAL, gap_s=0.1, gap_t=0.1, max_matches=k, want_flow=True))
+	offset = 100000
+	# several result sets in one all-gather, in flight while another query is scored
+	h = shards.allgather_start(tops[:4], offset, k, device=torch.device("cuda", 0))
+	extra = c.query(prep_query(synth.make_queries(corpus, 1, 6, seed=9)[0]), q_normalize=False, gap_s=0.1, gap_t=0.1, max_matches=k)
+	assert extra.n > 0
+	merged = shards.allgather_finish(h)
+	assert len(merged) == 4
+	for t, m in zip(tops, merged):
+		assert m.n == t.n
+		np.testing.assert_array_equal(m.score[:m.n], t.score[:t.n])
+		np.testing.assert_array_equal(m.sentence[:m.n], t.sentence[:t.n] + offset)
+		np.testing.assert_array_equal(m.mapping[:m.n], t.mapping[:t.n])
+		np.testing.assert_array_equal(m.edge_sim[:m.n], t.edge_sim[:t.n])
+	# a single set, and the blocking form
+	one = shards.allgather_finish(shards.allgather_start(tops[4], offset, k, device=torch.device("cuda", 0)))
+	np.testing.assert_array_equal(one.sentence[:one.n], tops[4].sentence[:tops[4].n] + offset)
+	blk = shards.allgather_merge(tops[4], offset, k)
+	np.testing.assert_array_equal(blk.score[:blk.n], tops[4].score[:tops[4].n])
+	c.close()

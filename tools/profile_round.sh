@@ -1,18 +1,31 @@
 #!/bin/bash
-# Run on the GPU box from the repo root: rocprofv3 kernel statistics and the two HBM counter passes for bench.py.
-# Usage: tools/profile_round.sh r01   ->  gpurun_out/prof_r01/{stats_exp5,stats_linear,pmc_fetch,pmc_write}
+# Run on the GPU box from the repo root: rocprofv3 kernel statistics of every bench.py configuration (one process per
+# configuration, so that each kernel_stats.csv holds one workload), the two HBM counter passes of the headline workload and
+# the MFMA-busy pass of config 4.  Counters are collected in passes of their own (--kernel-trace + --pmc only).
+# Usage: tools/profile_round.sh r02 [configs...]  ->  gpurun_out/prof_r02/summary/{r02_kernel_stats_<config>.csv, traffic.json, ...}
 set -e
-tag=${1:-r01}
+tag=${1:-r02}
+shift || true
+configs=${@:-"2 3 4 5 5wrd 2f32"}
 root=$(pwd)
 out=$root/gpurun_out/prof_$tag
-mkdir -p "$out"
+mkdir -p "$out/summary"
 export TMPDIR=/tmp
 cd /tmp
-for gap in exp5 linear; do
-	rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_$gap" -- python3 "$root/bench.py" --steps 20 --warmup 3 --gap $gap --no-cpu-baseline > "$out/bench_$gap.log" 2>&1
-	tail -n 1 "$out/bench_$gap.log"
+for c in $configs; do
+	rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_$c" -- python3 "$root/bench.py" --config $c --steps 12 --warmup 4 --no-extra --no-cpu-baseline > "$out/bench_$c.log" 2>&1
+	tail -n 1 "$out/bench_$c.log" | cut -c1-600
+	f=$(find "$out/stats_$c" -name "*kernel_stats.csv" | head -n 1)
+	head -n 8 "$f" > "$out/summary/${tag}_kernel_stats_config$c.csv"
+	cp "$out/bench_$c.log" "$out/summary/${tag}_bench_config$c.log"
 done
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python3 "$root/bench.py" --steps 4 --warmup 1 --gap exp5 --no-cpu-baseline > "$out/pmc_fetch.log" 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python3 "$root/bench.py" --steps 4 --warmup 1 --gap exp5 --no-cpu-baseline > "$out/pmc_write.log" 2>&1
+if echo " $configs " | grep -q " 2 "; then
+	rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python3 "$root/bench.py" --steps 4 --warmup 2 --no-extra --no-cpu-baseline > "$out/pmc_fetch.log" 2>&1
+	rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python3 "$root/bench.py" --steps 4 --warmup 2 --no-extra --no-cpu-baseline > "$out/pmc_write.log" 2>&1
+fi
+if echo " $configs " | grep -q " 4 "; then
+	rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d "$out/pmc_mfma" -- python3 "$root/bench.py" --config 4 --steps 3 --warmup 2 --no-extra --no-cpu-baseline > "$out/pmc_mfma.log" 2>&1
+	python3 "$root/tools/summarize_mfma.py" "$out/pmc_mfma" "$out/summary/${tag}_pmc_config4_mfma.csv"
+fi
 cd "$root"
 python3 tools/summarize_profile.py "$out" "$tag"
