@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 4
+#define VK_ABI_VERSION 5
 #define VK_MAX_QUERY_LEN 64   /* query tokens */
 #define VK_FAST_QUERY_LEN 16  /* queries up to this length run in the fused kernels (one 16-wide MFMA column block); longer ones
                                  (alignments and injective RWMD only) take a one-wave-per-slice kernel, ~10x slower */
@@ -159,7 +159,9 @@ typedef struct {
 	float score_ms;     /* the fused similarity + DP kernel (dominant) */
 	float topk_ms;      /* bounded result set selection */
 	float flow_ms;      /* traceback of the winners */
-	float total_ms;     /* first to last event */
+	float total_ms;     /* first to last event, without queue_ms: the device time this query took once it had its turn */
+	float queue_ms;     /* several handles on one corpus (vk_corpus_view): time this query's scoring kernel waited on the
+	                       device for the kernel of the handle before it (the kernels take turns; 0 with one handle) */
 } vk_timings;
 
 int vk_abi_version(void);

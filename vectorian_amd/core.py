@@ -82,7 +82,7 @@ class _TopkOut(C.Structure):
 class _Timings(C.Structure):
 	_fields_ = [
 		("prepare_ms", C.c_float), ("score_ms", C.c_float), ("topk_ms", C.c_float),
-		("flow_ms", C.c_float), ("total_ms", C.c_float)]
+		("flow_ms", C.c_float), ("total_ms", C.c_float), ("queue_ms", C.c_float)]
 
 
 EXPORTS = [
@@ -144,7 +144,7 @@ def lib():
 		L.vk_last_scores.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 		L.vk_last_timings.argtypes = [C.c_void_p, C.POINTER(_Timings)]
 		L.vk_merge_topk.argtypes = [C.POINTER(_TopkOut), C.c_int32, C.c_int32, C.c_int32, C.POINTER(_TopkOut)]
-		if L.vk_abi_version() != 4:
+		if L.vk_abi_version() != 5:
 			raise RuntimeError("libvectorian_hip.so ABI version mismatch")
 		_lib = L
 	return _lib

@@ -246,6 +246,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	// ---- the fused scoring kernel ------------------------------------------
 	// handles on one corpus take turns: this scoring kernel starts when the peer's has finished (its selection and
 	// traceback then run beside this kernel); the wait is on the device, the host does not block
+	VK_HIP(hipEventRecord(c->ev[5], st));
 	if (c->peer && c->peer->ev2_recorded) VK_HIP(hipStreamWaitEvent(st, c->peer->ev[2], 0));
 	VK_HIP(hipEventRecord(c->ev[1], st));
 	p.tiles = c->d_tiles; p.tok_id = c->d_tok_id; p.table = c->d_table; p.sent_start = c->d_sent_start; p.sent_end = c->d_sent_end;
@@ -311,7 +312,14 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	if (p.gap_mode == 7) lds_floats += 4 * p.m_rows;       // vocabulary masses of the 4 slices (static layout)
 	p.lds_floats_per_wave = lds_floats;
 	size_t smem = (size_t)lds_floats * 4 * 4;   // 4 waves per block
-	const size_t qlds = (!is_static && c->prec == 0 && ((c->nk32 == 24 && c->tail == 0) || (getenv("VK_QLDS") && c->nk32 == 10 && c->tail == 1))) ? (size_t)c->nk32 * 1024 : 0;   // MODE 3: query tile in LDS
+	// 300-d rows with general gaps (register history): the register form of the kernel takes 160 VGPRs, three waves per SIMD
+	// leave 32, and the traceback kernel of the previous query has to wait until this kernel has drained (2.3 - 2.8 ms); with
+	// the query tile in LDS the kernel takes 136 and runs at the same speed, the neighbours beside it.
+	// Linear / affine gaps take 112 registers in the register form.  VK_QREG=1 / VK_QLDS=1 force one or the other.
+	const bool reg_history = p.gap_mode == 3 || p.gap_mode == 6;
+	if (!is_static && c->prec == 0 && c->nk32 == 10 && c->tail == 1)
+		p.q_mode3 = getenv("VK_QLDS") ? 1 : getenv("VK_QREG") ? 0 : (reg_history ? 1 : 0);
+	const size_t qlds = (!is_static && c->prec == 0 && ((c->nk32 == 24 && c->tail == 0) || p.q_mode3)) ? (size_t)c->nk32 * 1024 : 0;   // MODE 3: query tile in LDS
 	smem += qlds;
 	// the generic contextual kernel (MODE 1: fp32 tiles, or a d without a specialised form) stages the query tile in LDS when it fits
 	// beside the strips of at least two workgroups per CU
@@ -453,10 +461,11 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		out->n_out = (int)best.size();
 		float ms = 0;
 		vk_timings t{};
-		if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) t.prepare_ms = ms;
+		if (hipEventElapsedTime(&ms, c->ev[0], c->ev[5]) == hipSuccess) t.prepare_ms = ms;
+	if (hipEventElapsedTime(&ms, c->ev[5], c->ev[1]) == hipSuccess) t.queue_ms = ms;
 		if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) t.score_ms = ms;
 		if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) t.topk_ms = ms;
-		if (hipEventElapsedTime(&ms, c->ev[0], c->ev[4]) == hipSuccess) t.total_ms = ms;
+		if (hipEventElapsedTime(&ms, c->ev[0], c->ev[4]) == hipSuccess) t.total_ms = ms - t.queue_ms;
 		c->last = t;
 		return VK_OK;
 	}
@@ -561,10 +570,11 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		out->n_out = (int)best.size();
 		float ms = 0;
 		vk_timings t{};
-		if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) t.prepare_ms = ms;
+		if (hipEventElapsedTime(&ms, c->ev[0], c->ev[5]) == hipSuccess) t.prepare_ms = ms;
+	if (hipEventElapsedTime(&ms, c->ev[5], c->ev[1]) == hipSuccess) t.queue_ms = ms;
 		if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) t.score_ms = ms;
 		if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) t.topk_ms = ms;
-		if (hipEventElapsedTime(&ms, c->ev[0], c->ev[4]) == hipSuccess) t.total_ms = ms;
+		if (hipEventElapsedTime(&ms, c->ev[0], c->ev[4]) == hipSuccess) t.total_ms = ms - t.queue_ms;
 		c->last = t;
 		return VK_OK;
 	}
@@ -658,11 +668,12 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 
 	float ms = 0;
 	vk_timings t{};
-	if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) t.prepare_ms = ms;
+	if (hipEventElapsedTime(&ms, c->ev[0], c->ev[5]) == hipSuccess) t.prepare_ms = ms;
+	if (hipEventElapsedTime(&ms, c->ev[5], c->ev[1]) == hipSuccess) t.queue_ms = ms;
 	if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) t.score_ms = ms;
 	if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) t.topk_ms = ms;
 	if (hipEventElapsedTime(&ms, c->ev[3], c->ev[4]) == hipSuccess) t.flow_ms = ms;
-	if (hipEventElapsedTime(&ms, c->ev[0], c->ev[4]) == hipSuccess) t.total_ms = ms;
+	if (hipEventElapsedTime(&ms, c->ev[0], c->ev[4]) == hipSuccess) t.total_ms = ms - t.queue_ms;
 	c->last = t;
 	return VK_OK;
 }
