@@ -43,9 +43,12 @@ def test_rwmd_gemm_batch(hip, oracle, length, d, len_t, flags):
 	(300, 16, 5, (True, True, True)),       # longer than 10 tokens: 2 queries per tile
 	(128, 10, 7, (True, True, True)),
 	(128, 13, 4, (True, False, False)),
+	(300, 10, 53, (True, True, True)),      # >= 32 queries of <= 10 tokens: 16 queries per five tiles (vk_rwmd_batch32d_kernel), last super tile partly empty
+	(300, 9, 32, (True, False, True)),
+	(128, 10, 40, (True, True, False)),
 ])
 def test_rwmd_batch_32_token_sentences(hip, oracle, d, len_t, n_q, flags):
-	"""32-token sentences run on the 32x32x16 MFMA kernel (queries share A tiles)."""
+	"""32-token sentences run on the 32x32x16 MFMA kernels (queries share A tiles)."""
 	n = 1000 + 13
 	corpus = synth.make_contextual_corpus(n, 32, 32, 2000, d)
 	Xb = prep_contextual(corpus)
@@ -53,6 +56,10 @@ def test_rwmd_batch_32_token_sentences(hip, oracle, d, len_t, n_q, flags):
 	qs = [prep_query(q) for q in synth.make_queries(corpus, n_q, len_t)]
 	qs[1] = qs[1][:max(1, len_t - 3)]
 	qs[-1] = qs[-1][:1]
+	for i in range(5, n_q, 7):              # queries of every length in one batch: whole and split rows of the dense layout
+		qs[i] = qs[i][:1 + (i * 3) % len_t]
+	if flags[1] and not flags[2]:
+		flags = (flags[0], True, True)       # symmetric needs nbow (wmd.h:441-449)
 	outs = c.query_batch(qs, algorithm=hip.VK_ALG_RWMD, rwmd=flags, q_normalize=False, max_matches=12, min_score=0.0)
 	for Qb, got in zip(qs, outs):
 		ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=corpus["sent_off"], X=Xb, Q=Qb,

@@ -86,10 +86,14 @@ static int query_batch_shared_pass(vk_corpus_t *c, const vk_query_desc *qs, int3
 	// ---- buffers
 	const size_t need_q = (size_t)4 * c->tile_bytes;
 	if (c->bq_cap < need_q) {
-		if (c->d_bq) { VK_HIP(hipFree(c->d_bq)); VK_HIP(hipFree(c->d_bqlen)); }
+		if (c->d_bq) VK_HIP(hipFree(c->d_bq));
 		if ((rc = alloc_t(c, &c->d_bq, need_q))) return rc;
-		if ((rc = alloc_t(c, &c->d_bqlen, 2 * ((size_t)4 + 4)))) return rc;
 		c->bq_cap = need_q;
+	}
+	if (c->bqlen_cap < 16) {
+		if (c->d_bqlen) VK_HIP(hipFree(c->d_bqlen));
+		if ((rc = alloc_t(c, &c->d_bqlen, 16))) return rc;
+		c->bqlen_cap = 16;
 	}
 	const size_t need_s = (size_t)4 * (size_t)n;
 	if (c->bscores_cap < need_s) {
@@ -254,18 +258,27 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 	int qpt = 3;
 	for (int i = 0; i < n_queries; i++) if (qs[i].len_t > 10) qpt = 2;
 	const int nk16 = c->d_pad / 16;
-	const int n_qtiles = (n_queries + qpt - 1) / qpt;
+	// batches of ten-token queries: 16 queries fill five A tiles exactly (vk_rwmd_batch32d_kernel); small batches keep 3 per tile
+	const bool dense = b32 && qpt == 3 && n_queries >= 32 && !getenv("VK_BATCH32_NO_DENSE");
+	const int n_super = (n_queries + 15) / 16;
+	const int n_qtiles = dense ? 5 * n_super : (n_queries + qpt - 1) / qpt;
+	const int score_rows = !b32 ? n_queries : dense ? 16 * n_super : n_qtiles * qpt;   // the 32-token kernels write whole tiles of queries
 
 	// ---- device buffers (kept for the next batch)
 	// (+1: the kernel prefetches one tile past the last)
 	const size_t need_q = std::max((size_t)n_queries * c->tile_bytes, b32 ? (size_t)(n_qtiles + 1) * nk16 * 1024 : (size_t)0);
 	if (c->bq_cap < need_q) {
-		if (c->d_bq) { VK_HIP(hipFree(c->d_bq)); VK_HIP(hipFree(c->d_bqlen)); }
+		if (c->d_bq) VK_HIP(hipFree(c->d_bq));
 		if ((rc = alloc_t(c, &c->d_bq, need_q))) return rc;
-		if ((rc = alloc_t(c, &c->d_bqlen, 2 * ((size_t)n_queries + 4)))) return rc;   // lengths, then their reciprocals
 		c->bq_cap = need_q;
 	}
-	const size_t need_s = (size_t)n_queries * (size_t)n;
+	const size_t need_len = 2 * ((size_t)n_queries + 4) + std::max(8 * ((size_t)n_qtiles + 2), 32 * ((size_t)n_super + 1));   // lengths, their reciprocals, kernel parameters
+	if (c->bqlen_cap < need_len) {
+		if (c->d_bqlen) VK_HIP(hipFree(c->d_bqlen));
+		if ((rc = alloc_t(c, &c->d_bqlen, need_len))) return rc;
+		c->bqlen_cap = need_len;
+	}
+	const size_t need_s = (size_t)score_rows * (size_t)n;
 	if (c->bscores_cap < need_s) {
 		if (c->d_bscores) VK_HIP(hipFree(c->d_bscores));
 		if ((rc = alloc_t(c, &c->d_bscores, need_s))) return rc;
@@ -301,7 +314,20 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 		const int slot = i % qpt;
 		for (int j = 0; j < qs[i].len_t; j++) {
 			int hd, acc;
-			if (qpt == 2) { hd = slot; acc = j; }
+			if (dense) {
+				// super tile i / 16; lane half hd serves its queries 8 hd .. 8 hd + 7: five whole ones (registers 0..9 of tile k) and
+				// three in the registers 10..15 of the five tiles, in slot order (vk_rwmd_batch32d_kernel)
+				const int idx = i % 16, r = idx % 8;
+				int k;
+				hd = idx / 8;
+				if (r < 5) { k = r; acc = j; }
+				else {
+					const int lin = (r - 5) * 10 + j;   // 0..29 over the 30 spare slots of the half
+					k = lin / 6; acc = 10 + lin % 6;
+				}
+				dst = all.data() + ((size_t)(i / 16) * 5 + (size_t)k) * nk16 * 1024;
+			}
+			else if (qpt == 2) { hd = slot; acc = j; }
 			else if (slot < 2) { hd = slot; acc = j; }
 			else { hd = j / 5; acc = 10 + j % 5; }
 			const int M = 8 * (acc >> 2) + 4 * hd + (acc & 3);
@@ -328,6 +354,20 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 	for (int i = 0; i < n_queries; i++) qinv[(size_t)i] = 1.0f / (float)qs[i].len_t;
 	float *d_qinv = reinterpret_cast<float *>(c->d_bqlen + n_queries + 4);
 	VK_HIP(hipMemcpyAsync(d_qinv, qinv.data(), qinv.size() * 4, hipMemcpyHostToDevice, st));
+	// vk_rwmd_batch32_kernel: per A tile the lengths of its queries (as floats) and their reciprocals, 0 for an absent query
+	float *d_qparam = d_qinv + n_queries + 4;
+	std::vector<float> qparam((size_t)(n_qtiles + 1) * 8, 0.0f);
+	if (dense) qparam.assign((size_t)(n_super + 1) * 32, 0.0f);
+	for (int i = 0; i < n_queries; i++) {
+		if (dense) {   // [query][2]
+			qparam[(size_t)i * 2] = (float)qs[i].len_t;
+			qparam[(size_t)i * 2 + 1] = qinv[(size_t)i];
+			continue;
+		}
+		qparam[(size_t)(i / qpt) * 8 + (size_t)(i % qpt)] = (float)qs[i].len_t;
+		qparam[(size_t)(i / qpt) * 8 + 4 + (size_t)(i % qpt)] = qinv[(size_t)i];
+	}
+	if (b32) VK_HIP(hipMemcpyAsync(d_qparam, qparam.data(), qparam.size() * 4, hipMemcpyHostToDevice, st));
 	if (qs[0].boost) {
 		if (!c->d_boost) { rc = alloc_t(c, &c->d_boost, (size_t)n + 8); if (rc) return rc; }
 		VK_HIP(hipMemcpyAsync(c->d_boost, qs[0].boost, (size_t)n * 4, hipMemcpyHostToDevice, st));
@@ -342,7 +382,7 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 	p.symmetric = qs[0].rwmd_symmetric; p.nbow = qs[0].rwmd_normalize_bow;
 	p.boost = qs[0].boost ? c->d_boost : nullptr;
 	p.scores = c->d_bscores;
-	p.n_qtiles = n_qtiles; p.qpt = qpt; p.q_inv_len = d_qinv;
+	p.n_qtiles = n_qtiles; p.qpt = qpt; p.q_inv_len = d_qinv; p.q_param = d_qparam; p.dense = dense ? 1 : 0;
 	p.late_mask = 4;   // waves w and w + 4 of a workgroup share a SIMD
 	if (const char *e = getenv("VK_BATCH32_LATE_MASK")) p.late_mask = atoi(e);   // tuning aid
 	if (b32) VK_HIP(vk_launch_rwmd_batch32(&p, st));

@@ -74,9 +74,11 @@ struct VkRwmdBatchParams {
 	int32_t tile_bytes, nk, half;
 	const uint8_t *qtiles;     // [n_queries] query tiles, back to back (batch32: [n_qtiles] 32-row tiles)
 	int32_t n_qtiles, qpt;     // batch32: tiles and queries per tile (2 or 3)
+	int32_t dense;             // batch32: 1 = 16 ten-token queries per 5 tiles (vk_rwmd_batch32d_kernel); q_param then [queries][2]
 	int32_t late_mask;         // batch32: waves with (wave & late_mask) != 0 run epilogue-then-MFMA (0: none)
 	const int32_t *q_len;      // [n_queries]
-	const float *q_inv_len;    // [n_queries] 1 / q_len (batch32)
+	const float *q_inv_len;    // [n_queries] 1 / q_len
+	const float *q_param;      // batch32: [n_qtiles + 1][8] per tile: length (as float) of its 3 queries, pad, reciprocals, pad; 0 = absent
 	int32_t n_queries;
 	int32_t n_sent;
 	int32_t tiles_per_sent;    // every sentence has 16 * tiles_per_sent tokens

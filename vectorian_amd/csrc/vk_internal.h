@@ -88,7 +88,7 @@ struct vk_corpus {
 	int uniform_len = 0;       // > 0: every sentence has exactly this many tokens
 	uint8_t *d_bq = nullptr; int32_t *d_bqlen = nullptr; float *d_bscores = nullptr; uint64_t *d_bkeys[2] = {nullptr, nullptr};
 	float *d_braw = nullptr; size_t braw_cap = 0;   // aligner scores of a batch of alignment queries
-	size_t bq_cap = 0, bscores_cap = 0, bkeys_cap = 0;
+	size_t bq_cap = 0, bqlen_cap = 0, bscores_cap = 0, bkeys_cap = 0;
 	int64_t device_bytes = 0;
 	// workspaces
 	void *d_stage = nullptr;

@@ -254,10 +254,23 @@ __device__ __forceinline__ int row_transpose_imax16(const int (&v)[16], int lane
 	return imax(keep, __builtin_amdgcn_update_dpp(NEG, send, 0x128, 0xf, 0xf, false));          // row_ror:8: lane ^ 8
 }
 
-// S tiles of one query tile against the wave's two sentences: 2 x NK16 MFMAs, A fragments DEPTH steps ahead
+// S tiles of one query tile against the wave's two sentences: 2 x NK16 MFMAs, A fragments DEPTH steps ahead.
+// The wave's share of the NEXT query tile (1 KiB pieces wv, wv + 8, wv + 16) leaves as LDS-DMA right after the first MFMA
+// pair (global_load_lds_dwordx4: no staging registers -- the kernel sits at the VGPR cap), in flight during this tile's MFMAs
+// and retired by the barrier that ends the iteration.  (Fetched into registers after the first MFMA pairs and written with
+// ds_write_b128 before the last ones, the same bytes cost the same time and 8 registers: measured, not kept.  Without the
+// staging at all the kernel takes 10 % less: what costs is moving 100 GB per batch from L2 into the CUs, not issuing it.)
 template <int NK16>
-__device__ __forceinline__ void batch32_mfma(const uint8_t *cur, const bf16x8 (&x)[2][NK16], f32x16 &acc0, f32x16 &acc1) {
-	constexpr int DEPTH = 4;                           // A fragments in flight (ds_read_b128 ahead of their MFMAs)
+__device__ __forceinline__ void batch32_mfma(const uint8_t *cur, const bf16x8 (&x)[2][NK16], f32x16 &acc0, f32x16 &acc1,
+	const uint8_t *next_src /* wave-uniform */, unsigned lane16, const uint8_t *next_dst, int wv) {
+#ifdef VK_DEPTH
+	constexpr int DEPTH = VK_DEPTH;
+#else
+	constexpr int DEPTH = 2;                           // A fragments in flight (ds_read_b128 ahead of their MFMAs)
+#endif
+#ifdef VK_PRIO
+	__builtin_amdgcn_s_setprio(VK_PRIO);
+#endif
 #pragma unroll
 	for (int i = 0; i < 16; i++) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
 	bf16x8 a[DEPTH];
@@ -271,26 +284,50 @@ __device__ __forceinline__ void batch32_mfma(const uint8_t *cur, const bf16x8 (&
 #endif
 		acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8n, at), __builtin_bit_cast(bf16x8n, x[0][t]), acc0, 0, 0, 0);
 		acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8n, at), __builtin_bit_cast(bf16x8n, x[1][t]), acc1, 0, 0, 0);
+#if defined(VK_ABL) && VK_ABL >= 5
+		if (t + DEPTH < NK16) a[t % DEPTH] = a[(t + 1) % DEPTH];
+#else
 		if (t + DEPTH < NK16) a[t % DEPTH] = *reinterpret_cast<const bf16x8 *>(cur + (t + DEPTH) * 1024);
+#endif
+#if !defined(VK_ABL) || VK_ABL < 4
+		if (t == 0) {
+#pragma unroll
+			for (int b = wv; b < NK16; b += 8)   // wave-uniform piece base (scalar registers) + the lane's 32-bit offset: no 64-bit vector addresses
+				__builtin_amdgcn_global_load_lds((vk_glb_ptr)(next_src + b * 1024 + lane16), (vk_lds_ptr)(next_dst + b * 1024), 16, 0, 0);
+		}
+#endif
+#ifndef VK_NO_SCHED_BARRIER
 		__builtin_amdgcn_sched_barrier(0);
+#endif
 	}
+#ifdef VK_PRIO
+	__builtin_amdgcn_s_setprio(0);
+#endif
 }
 
-// RWMD scores of query tile qt for the wave's two sentences from the accumulators.
+// RWMD scores of one query tile for the wave's two sentences from the accumulators.
 // D = 1 - clip(S) is monotone in S: reduce S (as integers, see above), convert the reduced values only.
 // Rows of absent query tokens are zero: S = 0, clip = 0, no masks.
+// The parameters of the tile's queries (length as float, its reciprocal; 0 for an absent query) sit in LDS, staged once per
+// workgroup: four ds_read_b32 at the top of the epilogue, consumed at its end.  (Fetched from global memory under the
+// lane-15 branch, each tile paid the latency of two dependent vector loads inside its epilogue.)
+struct B32Vals { float main, third; };
+constexpr int B32_MAX_QTILES = 256;   // query tiles per launch (their parameters: 8 KiB of LDS); larger batches take several launches
+
 template <int QPT>
-__device__ __forceinline__ void batch32_epilogue(const VkRwmdBatchParams &p, int qt, int64_t sent, int lane, const f32x16 &acc0, const f32x16 &acc1) {
+__device__ __forceinline__ B32Vals batch32_epilogue(const VkRwmdBatchParams &p, int lane, const f32x16 &acc0, const f32x16 &acc1,
+	const float *tile_param, float boost) {
 	constexpr int NMAIN = QPT == 3 ? 10 : 16;          // rows of the half's own query
 	const int h = lane >> 5;
 	const float inv_s = 1.0f / 32.0f;
-#if defined(VK_ABL) && VK_ABL == 1
+	const float len_main = tile_param[h], inv_main = tile_param[4 + h];
+	const float len_third = tile_param[2], inv_third = tile_param[6];
+#if defined(VK_ABL) && (VK_ABL == 1 || VK_ABL >= 4)
 	{
-		float z = 0.0f;
+		// no epilogue: the accumulators stay live, nothing is computed from them
 #pragma unroll
-		for (int i = 0; i < 16; i++) z += acc0[i] + acc1[i];
-		if (z == 12345.0f) p.scores[0] = z;
-		return;
+		for (int i = 0; i < 16; i++) asm volatile("" :: "v"(acc0[i]), "v"(acc1[i]));
+		return {0.0f, 0.0f};
 	}
 #endif
 	// (a) per token: max over the query's rows (in-lane) -> this lane's two tokens' distances -> sum
@@ -310,7 +347,6 @@ __device__ __forceinline__ void batch32_epilogue(const VkRwmdBatchParams &p, int
 		ts_third = row_sum_to_lane15((2.0f - clip01_bits(cb0)) - clip01_bits(cb1));
 	}
 	// (b) per query row: max over the sentence's tokens -> lane 15 of the DPP row
-	const int q_main = qt * QPT + h, q_third = qt * 3 + 2;
 	float s_main = 0.0f, s_third = 0.0f;
 	{
 		int m[16];
@@ -324,25 +360,35 @@ __device__ __forceinline__ void batch32_epilogue(const VkRwmdBatchParams &p, int
 			s_third += xor32_f(s_third, lane);
 		}
 	}
-	// (c) scores (the expressions of vk_rwmd_batch_kernel; sum (1 - x) over len rows = len - sum x)
-	if ((lane & 15) == 15 && sent < p.n_sent) {
-		const float boost = p.boost ? p.boost[sent] : 1.0f;
-		const int len_main = q_main < p.n_queries ? p.q_len[q_main] : 0;
-		if (len_main > 0) {
-			const float inv_t = p.q_inv_len[q_main];
-			const float a0 = inv_t * ((float)len_main - s_main), a1 = inv_s * ts_main;
-			const float cost = p.symmetric ? fmaxf(0.0f, fmaxf(a0, a1)) : a0;
-			const float raw = p.nbow ? 1.0f - cost : ((float)len_main - cost) * inv_t;
-			p.scores[(int64_t)q_main * p.n_sent + sent] = (raw * inv_t) * boost;
-		}
-		const int len_third = (QPT == 3 && h == 0 && q_third < p.n_queries) ? p.q_len[q_third] : 0;
-		if (len_third > 0) {
-			const float inv_t = p.q_inv_len[q_third];
-			const float a0 = inv_t * ((float)len_third - s_third), a1 = inv_s * ts_third;
-			const float cost = p.symmetric ? fmaxf(0.0f, fmaxf(a0, a1)) : a0;
-			const float raw = p.nbow ? 1.0f - cost : ((float)len_third - cost) * inv_t;
-			p.scores[(int64_t)q_third * p.n_sent + sent] = (raw * inv_t) * boost;
-		}
+	// (c) scores (the expressions of vk_rwmd_batch_kernel; sum (1 - x) over len rows = len - sum x); valid in lane 15 of each row
+	B32Vals out;
+	{
+		const float len_t = len_main, inv_t = inv_main;
+		const float a0 = inv_t * (len_t - s_main), a1 = inv_s * ts_main;
+		const float cost = p.symmetric ? fmaxf(0.0f, fmaxf(a0, a1)) : a0;
+		const float raw = p.nbow ? 1.0f - cost : (len_t - cost) * inv_t;
+		out.main = (raw * inv_t) * boost;
+	}
+	out.third = 0.0f;
+	if (QPT == 3) {
+		const float len_t = len_third, inv_t = inv_third;
+		const float a0 = inv_t * (len_t - s_third), a1 = inv_s * ts_third;
+		const float cost = p.symmetric ? fmaxf(0.0f, fmaxf(a0, a1)) : a0;
+		const float raw = p.nbow ? 1.0f - cost : (len_t - cost) * inv_t;
+		out.third = (raw * inv_t) * boost;
+	}
+	return out;
+}
+
+// the scores of tile qt: lane 15 of each DPP row holds them (row = sentence x lane half).  Rows of absent queries (the
+// last tile may hold fewer than QPT) are written too: the score array has n_qtiles * QPT rows.
+template <int QPT>
+__device__ __forceinline__ void batch32_store(const VkRwmdBatchParams &p, int qt, bool store_lane, unsigned lane_off, int lane, const B32Vals &v) {
+	// row base wave-uniform (scalar registers), the lane's part a 32-bit offset: no 64-bit address arithmetic in vector registers
+	float *row = p.scores + (int64_t)(qt * QPT) * p.n_sent;
+	if (store_lane) {
+		row[lane_off] = v.main;
+		if (QPT == 3 && lane < 32) (row + (int64_t)2 * p.n_sent)[lane_off] = v.third;
 	}
 }
 
@@ -351,9 +397,11 @@ __global__ __launch_bounds__(512) void vk_rwmd_batch32_kernel(VkRwmdBatchParams 
 	constexpr int QT_BYTES = NK16 * 1024;
 	extern __shared__ float4 vk_smem4[];
 	const uint8_t *qbuf = reinterpret_cast<const uint8_t *>(vk_smem4);
+	float *param = reinterpret_cast<float *>(vk_smem4) + 2 * QT_BYTES / 4;   // [n_qtiles][8]: len of the tile's 3 queries, pad, 1 / len, pad
 	const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int n32 = lane & 31, h = lane >> 5;
 	const int64_t n_chunks = ((int64_t)p.n_sent + 15) / 16;
+	for (int i = threadIdx.x; i < p.n_qtiles * 8; i += 512) param[i] = p.q_param[i];
 	// The two waves that share a SIMD (w and w + 4 of the workgroup) run the two halves of an interval in
 	// opposite order: the "late" wave first finishes the epilogue of the previous tile (VALU) while the
 	// other one issues its MFMAs, then they swap.  Barriers would otherwise keep all waves in phase:
@@ -362,6 +410,9 @@ __global__ __launch_bounds__(512) void vk_rwmd_batch32_kernel(VkRwmdBatchParams 
 
 	for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
 		const int64_t sent = chunk * 16 + wv * 2 + (n32 >> 4);   // this lane's sentence
+		const float boost = (p.boost && sent < p.n_sent) ? p.boost[sent] : 1.0f;
+		const bool store_lane = (lane & 15) == 15 && sent < p.n_sent;                 // lane 15 of each DPP row holds the row's scores
+		const unsigned lane_off = (unsigned)h * (unsigned)p.n_sent + (unsigned)sent;   // its place in the score rows of its half's query
 		// ---- the wave's token tiles -> registers (read once per batch)
 		bf16x8 x[2][NK16];
 #pragma unroll
@@ -379,28 +430,192 @@ __global__ __launch_bounds__(512) void vk_rwmd_batch32_kernel(VkRwmdBatchParams 
 		__syncthreads();
 
 		f32x16 acc0, acc1;
+		B32Vals pend{0.0f, 0.0f};
 		for (int qt = 0; qt < p.n_qtiles; qt++) {
 			const uint8_t *cur = qbuf + (qt & 1) * QT_BYTES + lane * 16;
-			// next query tile: LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, no staging
-			// registers -- the kernel sits at the VGPR cap), in flight during this tile's MFMAs and retired by
-			// the barrier at the end of the iteration.  The tile after the last one is zero padding.
-			{
-				const uint8_t *src = p.qtiles + (int64_t)(qt + 1) * QT_BYTES + lane * 16;
-				const uint8_t *nxt = qbuf + ((qt + 1) & 1) * QT_BYTES;
-#pragma unroll
-				for (int b = wv; b < NK16; b += 8)
-					__builtin_amdgcn_global_load_lds((vk_glb_ptr)(src + b * 1024), (vk_lds_ptr)(nxt + b * 1024), 16, 0, 0);
-			}
+			// next query tile: LDS-DMA from inside the MFMA sequence (batch32_mfma) into the other slot, complete at the barrier
+			// that ends the iteration.  The tile after the last one is zero padding.
+			const uint8_t *next_src = p.qtiles + (int64_t)(qt + 1) * QT_BYTES;
+			const uint8_t *next_dst = qbuf + ((qt + 1) & 1) * QT_BYTES;
 			if (!late) {
-				batch32_mfma<NK16>(cur, x, acc0, acc1);
-				batch32_epilogue<QPT>(p, qt, sent, lane, acc0, acc1);
+				// the scores of the previous tile leave now, not at the end of its iteration: the barrier there waits for
+				// every outstanding memory operation of the wave (vmcnt(0) for the LDS-DMA), stores to HBM included
+				if (qt > 0) batch32_store<QPT>(p, qt - 1, store_lane, lane_off, lane, pend);
+				batch32_mfma<NK16>(cur, x, acc0, acc1, next_src, (unsigned)lane * 16u, next_dst, wv);
+				pend = batch32_epilogue<QPT>(p, lane, acc0, acc1, param + qt * 8, boost);
 			} else {
-				if (qt > 0) batch32_epilogue<QPT>(p, qt - 1, sent, lane, acc0, acc1);
-				batch32_mfma<NK16>(cur, x, acc0, acc1);
+				if (qt > 0) batch32_store<QPT>(p, qt - 1, store_lane, lane_off, lane, batch32_epilogue<QPT>(p, lane, acc0, acc1, param + (qt - 1) * 8, boost));
+				batch32_mfma<NK16>(cur, x, acc0, acc1, next_src, (unsigned)lane * 16u, next_dst, wv);
 			}
+#if !defined(VK_ABL) || VK_ABL < 6
 			__syncthreads();   // next query tile is in place; this one may be overwritten
+#endif
 		}
-		if (late) batch32_epilogue<QPT>(p, p.n_qtiles - 1, sent, lane, acc0, acc1);
+		if (late) pend = batch32_epilogue<QPT>(p, lane, acc0, acc1, param + (p.n_qtiles - 1) * 8, boost);
+		batch32_store<QPT>(p, p.n_qtiles - 1, store_lane, lane_off, lane, pend);
+	}
+}
+
+// ---------------------------------------------------------------------------
+// Dense form of the 32-token kernel for batches of ten-token queries: 16 queries = 160 rows = FIVE A tiles exactly (3 queries
+// per tile leave 2 of 32 rows empty: 86 tiles per 256 queries against 80 here, 7 % fewer MFMAs, query bytes and epilogues).
+// A lane half h (rows 8 (i >> 2) + 4 h + (i & 3), i = accumulator register) serves 8 of the 16 queries of a super tile and
+// every query stays inside one half, so the maxima over a query's rows are in-lane, with no exchange across the halves:
+//   registers 0..9 of tile k: query F_k = 8 h + k of the super tile (tokens 0..9);
+//   registers 10..15 of the five tiles (30 slots): queries G_0..G_2 = 8 h + 5 + g, ten tokens each, in slot order --
+//     G_0: tile 0 slots 10..15, tile 1 slots 10..13;  G_1: tile 1 slots 14, 15, tile 2 slots 10..15, tile 3 slots 10, 11;
+//     G_2: tile 3 slots 12..15, tile 4 slots 10..15.
+// A split query carries its in-lane maxima (both chains) and its per-lane sum of row maxima from tile to tile (3 registers).
+// Shorter queries leave zero rows (S = 0, clip 0, no masks); the host packs the tiles (vk_batch.cpp).
+// ---------------------------------------------------------------------------
+
+struct B32DState { int cb0, cb1; float zg; };
+
+template <int K>
+__device__ __forceinline__ B32Vals batch32d_epilogue(const VkRwmdBatchParams &p, int lane, const f32x16 &acc0, const f32x16 &acc1,
+	const float *super_param /* [16][2]: len, 1 / len of the super tile's queries */, float boost, B32DState &st) {
+	constexpr int C_HI = K == 0 ? 10 : K == 1 ? 14 : K == 3 ? 12 : 16;   // slots [10, C_HI) continue the split query in progress
+	constexpr bool CLOSES = K == 1 || K == 3 || K == 4;                  // ... and complete it
+	constexpr bool STARTS = K == 0 || K == 1 || K == 3;                  // slots [C_HI, 16) start the next one
+	constexpr int G = K == 1 ? 0 : K == 3 ? 1 : 2;
+	const int h = lane >> 5, v = lane & 15;
+	const float inv_s = 1.0f / 32.0f;
+	const float len_f = super_param[2 * (8 * h + K)], inv_f = super_param[2 * (8 * h + K) + 1];
+	float len_g = 0.0f, inv_g = 0.0f;
+	if (CLOSES) { len_g = super_param[2 * (8 * h + 5 + G)]; inv_g = super_param[2 * (8 * h + 5 + G) + 1]; }
+#if defined(VK_ABL) && (VK_ABL == 1 || VK_ABL >= 4)
+	{
+#pragma unroll
+		for (int i = 0; i < 16; i++) asm volatile("" :: "v"(acc0[i]), "v"(acc1[i]));
+		return {0.0f, 0.0f};
+	}
+#endif
+	// (a) per token: maximum over the query's rows, in-lane; distances of this lane's two tokens; sum over the sentence
+	int ca0 = fbits(acc0[0]), ca1 = fbits(acc1[0]);
+#pragma unroll
+	for (int i = 1; i < 10; i++) { ca0 = imax(ca0, fbits(acc0[i])); ca1 = imax(ca1, fbits(acc1[i])); }
+	const float ts_f = row_sum_to_lane15((2.0f - clip01_bits(ca0)) - clip01_bits(ca1));
+#pragma unroll
+	for (int i = 10; i < C_HI; i++) { st.cb0 = imax(st.cb0, fbits(acc0[i])); st.cb1 = imax(st.cb1, fbits(acc1[i])); }
+	float ts_g = 0.0f;
+	if (CLOSES) ts_g = row_sum_to_lane15((2.0f - clip01_bits(st.cb0)) - clip01_bits(st.cb1));
+	if (STARTS) {
+		st.cb0 = fbits(acc0[C_HI]); st.cb1 = fbits(acc1[C_HI]);
+#pragma unroll
+		for (int i = C_HI + 1; i < 16; i++) { st.cb0 = imax(st.cb0, fbits(acc0[i])); st.cb1 = imax(st.cb1, fbits(acc1[i])); }
+	}
+	// (b) per query row: maximum over the sentence's tokens, transposed: lane v of the DPP row holds the one of register v
+	__builtin_amdgcn_sched_barrier(0);   // (a) is done with the accumulators: m[] may take their registers (the kernel sits at the VGPR cap)
+	int m[16];
+#pragma unroll
+	for (int i = 0; i < 16; i++) m[i] = imax(fbits(acc0[i]), fbits(acc1[i]));
+	const float z = clip01_bits(row_transpose_imax16(m, lane));
+	const float s_f = row_sum_to_lane15(v < 10 ? z : 0.0f);
+	if (C_HI > 10) st.zg += (v >= 10 && v < C_HI) ? z : 0.0f;
+	float s_g = 0.0f;
+	if (CLOSES) s_g = row_sum_to_lane15(st.zg);
+	if (STARTS) st.zg = v >= C_HI ? z : 0.0f;
+	// (c) scores, valid in lane 15 of each row (the expressions of batch32_epilogue)
+	B32Vals out;
+	{
+		const float a0 = inv_f * (len_f - s_f), a1 = inv_s * ts_f;
+		const float cost = p.symmetric ? fmaxf(0.0f, fmaxf(a0, a1)) : a0;
+		const float raw = p.nbow ? 1.0f - cost : (len_f - cost) * inv_f;
+		out.main = (raw * inv_f) * boost;
+	}
+	out.third = 0.0f;
+	if (CLOSES) {
+		const float a0 = inv_g * (len_g - s_g), a1 = inv_s * ts_g;
+		const float cost = p.symmetric ? fmaxf(0.0f, fmaxf(a0, a1)) : a0;
+		const float raw = p.nbow ? 1.0f - cost : (len_g - cost) * inv_g;
+		out.third = (raw * inv_g) * boost;
+	}
+	return out;
+}
+
+constexpr int B32D_MAX_SUPER = 48;   // super tiles per launch: 768 queries, their parameters 6 KiB of LDS
+
+// epilogue / store of tile K (0..4) of a super tile; K is wave-uniform, the five forms are the arms of one switch (unrolling the
+// five tiles into the loop body instead let hipcc hoist their addresses and parameters: 30 more registers, scratch)
+__device__ __forceinline__ B32Vals batch32d_epilogue_k(int K, const VkRwmdBatchParams &p, int lane, const f32x16 &acc0, const f32x16 &acc1,
+	const float *super_param, float boost, B32DState &st) {
+	switch (K) {
+	case 0: return batch32d_epilogue<0>(p, lane, acc0, acc1, super_param, boost, st);
+	case 1: return batch32d_epilogue<1>(p, lane, acc0, acc1, super_param, boost, st);
+	case 2: return batch32d_epilogue<2>(p, lane, acc0, acc1, super_param, boost, st);
+	case 3: return batch32d_epilogue<3>(p, lane, acc0, acc1, super_param, boost, st);
+	default: return batch32d_epilogue<4>(p, lane, acc0, acc1, super_param, boost, st);
+	}
+}
+
+__device__ __forceinline__ void batch32d_store_k(int K, const VkRwmdBatchParams &p, int super, bool store_lane, unsigned lane_off, const B32Vals &v) {
+	// tiles 1, 3 and 4 complete a split query: G = 0, 1, 2; its row is 5 + G - K rows below the tile's own
+	const bool closes = K == 1 || K == 3 || K == 4;
+	const int g_row = K == 1 ? 4 : K == 3 ? 3 : 3;   // 5 + G - K
+	float *row = p.scores + (int64_t)(super * 16 + K) * p.n_sent;   // wave-uniform; lane_off = (8 h) n_sent + sentence
+	if (store_lane) {
+		row[lane_off] = v.main;
+		if (closes) (row + (int64_t)g_row * p.n_sent)[lane_off] = v.third;
+	}
+}
+
+template <int NK16>
+__global__ __launch_bounds__(512) void vk_rwmd_batch32d_kernel(VkRwmdBatchParams p) {
+	constexpr int QT_BYTES = NK16 * 1024;
+	extern __shared__ float4 vk_smem4[];
+	const uint8_t *qbuf = reinterpret_cast<const uint8_t *>(vk_smem4);
+	float *param = reinterpret_cast<float *>(vk_smem4) + 2 * QT_BYTES / 4;   // [n_super * 16][2]: len, 1 / len per query
+	const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int n32 = lane & 31, h = lane >> 5;
+	const int n_super = p.n_qtiles / 5;
+	const int64_t n_chunks = ((int64_t)p.n_sent + 15) / 16;
+	for (int i = threadIdx.x; i < n_super * 32; i += 512) param[i] = p.q_param[i];
+	const bool late = (wv & p.late_mask) != 0;   // see vk_rwmd_batch32_kernel
+
+	for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+		const int64_t sent = chunk * 16 + wv * 2 + (n32 >> 4);   // this lane's sentence
+		const float boost = (p.boost && sent < p.n_sent) ? p.boost[sent] : 1.0f;
+		const bool store_lane = (lane & 15) == 15 && sent < p.n_sent;
+		const unsigned lane_off = (unsigned)(8 * h) * (unsigned)p.n_sent + (unsigned)sent;
+		bf16x8 x[2][NK16];
+#pragma unroll
+		for (int m = 0; m < 2; m++) {
+			const int64_t tile = sent < p.n_sent ? sent * 2 + m : p.n_tiles;   // one zero tile follows the corpus
+			const uint8_t *tp = p.tiles + tile * p.tile_bytes + (n32 & 15) * 16;
+#pragma unroll
+			for (int t = 0; t < NK16; t++)
+				x[m][t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(tp + (t >> 1) * 1024 + (2 * (t & 1) + h) * 256));
+		}
+		__syncthreads();   // previous chunk's readers are done with the LDS slots
+#pragma unroll
+		for (int b = wv; b < NK16; b += 8)
+			__builtin_amdgcn_global_load_lds((vk_glb_ptr)(p.qtiles + b * 1024 + lane * 16), (vk_lds_ptr)(qbuf + b * 1024), 16, 0, 0);
+		__syncthreads();
+
+		f32x16 acc0, acc1;
+		B32Vals pend{0.0f, 0.0f};
+		B32DState st{0, 0, 0.0f};
+		int K = 0, super = 0;          // tile qt = 5 * super + K
+		for (int qt = 0; qt < p.n_qtiles; qt++) {
+			const int KP = K == 0 ? 4 : K - 1, super_p = K == 0 ? super - 1 : super;   // the tile before
+			const uint8_t *cur = qbuf + (qt & 1) * QT_BYTES + lane * 16;
+			const uint8_t *next_src = p.qtiles + (int64_t)(qt + 1) * QT_BYTES;
+			const uint8_t *next_dst = qbuf + ((qt + 1) & 1) * QT_BYTES;
+			if (!late) {
+				if (qt > 0) batch32d_store_k(KP, p, super_p, store_lane, lane_off, pend);
+				batch32_mfma<NK16>(cur, x, acc0, acc1, next_src, (unsigned)lane * 16u, next_dst, wv);
+				pend = batch32d_epilogue_k(K, p, lane, acc0, acc1, param + super * 32, boost, st);
+			} else {
+				if (qt > 0) batch32d_store_k(KP, p, super_p, store_lane, lane_off, batch32d_epilogue_k(KP, p, lane, acc0, acc1, param + super_p * 32, boost, st));
+				batch32_mfma<NK16>(cur, x, acc0, acc1, next_src, (unsigned)lane * 16u, next_dst, wv);
+			}
+#if !defined(VK_ABL) || VK_ABL < 6
+			__syncthreads();   // next query tile is in place; this one may be overwritten
+#endif
+			if (++K == 5) { K = 0; super++; }
+		}
+		if (late) pend = batch32d_epilogue<4>(p, lane, acc0, acc1, param + (n_super - 1) * 32, boost, st);
+		batch32d_store_k(4, p, n_super - 1, store_lane, lane_off, pend);
 	}
 }
 
@@ -420,23 +635,53 @@ static hipError_t launch_rwmd_batch_tps(const VkRwmdBatchParams &p, size_t smem,
 	return hipGetLastError();
 }
 
-// 32-token sentences: p->qtiles holds p->n_qtiles A tiles of 32 rows (p->qpt queries each)
-extern "C" hipError_t vk_launch_rwmd_batch32(const VkRwmdBatchParams *p, hipStream_t stream) {
+// 32-token sentences: p->qtiles holds p->n_qtiles A tiles of 32 rows (p->qpt queries each); p->scores has n_qtiles * qpt rows
+extern "C" hipError_t vk_launch_rwmd_batch32(const VkRwmdBatchParams *pp, hipStream_t stream) {
 	int dev = 0, cus = 256;
 	if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-	if (p->tiles_per_sent != 2 || (p->qpt != 2 && p->qpt != 3)) return hipErrorNotSupported;
-	const int64_t n_chunks = ((int64_t)p->n_sent + 15) / 16;
+	if (pp->tiles_per_sent != 2 || (pp->qpt != 2 && pp->qpt != 3)) return hipErrorNotSupported;
+	const int64_t n_chunks = ((int64_t)pp->n_sent + 15) / 16;
 	const int grid = (int)(n_chunks < (int64_t)cus ? n_chunks : (int64_t)cus);
-	if (p->nk == 10 && p->half == 1) {
-		const size_t smem = 2 * 19 * 1024;
-		if (p->qpt == 3) vk_rwmd_batch32_kernel<19, 3><<<grid, 512, smem, stream>>>(*p);
-		else vk_rwmd_batch32_kernel<19, 2><<<grid, 512, smem, stream>>>(*p);
-	} else if (p->nk == 4 && p->half == 0) {
-		const size_t smem = 2 * 8 * 1024;
-		if (p->qpt == 3) vk_rwmd_batch32_kernel<8, 3><<<grid, 512, smem, stream>>>(*p);
-		else vk_rwmd_batch32_kernel<8, 2><<<grid, 512, smem, stream>>>(*p);
-	} else return hipErrorNotSupported;
-	return hipGetLastError();
+	int nk16;
+	if (pp->nk == 10 && pp->half == 1) nk16 = 19;
+	else if (pp->nk == 4 && pp->half == 0) nk16 = 8;
+	else return hipErrorNotSupported;
+	if (pp->dense) {
+		// p->n_qtiles = 5 x super tiles of 16 queries; q_param [n_super * 16][2]; scores n_super * 16 rows
+		const int n_super = pp->n_qtiles / 5;
+		for (int s0 = 0; s0 < n_super; s0 += B32D_MAX_SUPER) {
+			VkRwmdBatchParams p = *pp;
+			const int ns = n_super - s0 < B32D_MAX_SUPER ? n_super - s0 : B32D_MAX_SUPER;
+			p.n_qtiles = ns * 5;
+			p.qtiles = pp->qtiles + (size_t)s0 * 5 * nk16 * 1024;
+			p.q_param = pp->q_param + (size_t)s0 * 32;
+			p.scores = pp->scores + (size_t)s0 * 16 * pp->n_sent;
+			const size_t smem = (size_t)2 * nk16 * 1024 + (size_t)B32D_MAX_SUPER * 128;
+			if (nk16 == 19) vk_rwmd_batch32d_kernel<19><<<grid, 512, smem, stream>>>(p);
+			else vk_rwmd_batch32d_kernel<8><<<grid, 512, smem, stream>>>(p);
+			const hipError_t e = hipGetLastError();
+			if (e != hipSuccess) return e;
+		}
+		return hipSuccess;
+	}
+	for (int t0 = 0; t0 < pp->n_qtiles; t0 += B32_MAX_QTILES) {
+		VkRwmdBatchParams p = *pp;
+		p.n_qtiles = pp->n_qtiles - t0 < B32_MAX_QTILES ? pp->n_qtiles - t0 : B32_MAX_QTILES;
+		p.qtiles = pp->qtiles + (size_t)t0 * nk16 * 1024;
+		p.q_param = pp->q_param + (size_t)t0 * 8;
+		p.scores = pp->scores + (size_t)t0 * pp->qpt * pp->n_sent;
+		const size_t smem = (size_t)2 * nk16 * 1024 + (size_t)B32_MAX_QTILES * 32;
+		if (nk16 == 19) {
+			if (p.qpt == 3) vk_rwmd_batch32_kernel<19, 3><<<grid, 512, smem, stream>>>(p);
+			else vk_rwmd_batch32_kernel<19, 2><<<grid, 512, smem, stream>>>(p);
+		} else {
+			if (p.qpt == 3) vk_rwmd_batch32_kernel<8, 3><<<grid, 512, smem, stream>>>(p);
+			else vk_rwmd_batch32_kernel<8, 2><<<grid, 512, smem, stream>>>(p);
+		}
+		const hipError_t e = hipGetLastError();
+		if (e != hipSuccess) return e;
+	}
+	return hipSuccess;
 }
 
 // returns hipErrorNotSupported when no batched kernel exists for this corpus shape
