@@ -34,7 +34,8 @@ extern "C" {
 #define VK_ABI_VERSION 5
 #define VK_MAX_QUERY_LEN 64   /* query tokens */
 #define VK_FAST_QUERY_LEN 16  /* queries up to this length run in the fused kernels (one 16-wide MFMA column block); longer ones
-                                 (alignments and injective RWMD only) take a one-wave-per-slice kernel, ~10x slower */
+                                 take the multi-block kernel (2 or 4 column blocks) or, where that does not apply, a
+                                 one-wave-per-slice kernel, ~10x slower; the 1:n form of RWMD stops at this length */
 #define VK_MAX_SENT_LEN 512   /* tokens per sentence (slice) */
 #define VK_FAST_SENT_LEN 64   /* slices up to this length run 4 per wave in the fused kernel (|s| <= 64); longer
                                  ones take a second launch, one slice per wave; VK_ALG_WRD and full WMD need all slices <= 64 */
@@ -118,7 +119,8 @@ typedef struct {
 	/* 'alignment-tag-weighted' (vectorian/sim/span.py:63-71; TagWeightedSlice, slice/static.h:186-288):
 	 * S'[i][j] = S[i][j] * tag_weights[j] * (pos_s[i] != q_pos[j] ? 1 - pos_mismatch_penalty : 1), set to 0
 	 * when <= similarity_threshold; the score is divided by sum(tag_weights) instead of len_t.
-	 * tag_weights NULL = 'alignment-isolated'.  Alignment only; needs vk_corpus_set_token_pos. */
+	 * tag_weights NULL = 'alignment-isolated'.  Any algorithm (TagWeightedSlice wraps every slice, match/instantiate.cpp:
+	 * 173-189) except the 1:n form of RWMD over the static layout; needs vk_corpus_set_token_pos. */
 	const float *tag_weights;  /* host [len_t] t_pos_weights (match/instantiate.cpp:10-38) */
 	const int8_t *q_pos;       /* host [len_t] universal POS code per query token */
 	float pos_mismatch_penalty;
@@ -144,11 +146,11 @@ typedef struct {
 	                            reports distance = 1 - this); NULL if !want_flow */
 	/* transport algorithms (VK_ALG_RWMD, VK_ALG_WRD) with want_flow: what the host needs to state the flow of a
 	 * winner as SparseFlow / DenseFlow (match/match.h:140-260; alignment/wmd.h:392-408, 228-248; wrd.h:120-135).
-	 * Optional (NULL: not produced); filled for corpora whose slices have at most VK_FAST_SENT_LEN tokens and
-	 * queries of at most VK_FAST_QUERY_LEN tokens. */
-	float *sim_rows;         /* [capacity x VK_FAST_SENT_LEN x 16] similarity S[i][j] of slice token i and query token j
-	                            (clipped, static layout: sim[id(t_j)][j] = 1); rows >= the slice's length are zero */
-	float *plan;             /* [capacity x 16 x VK_FAST_SENT_LEN] exact transport only (VK_ALG_WRD, wmd_full): the optimal
+	 * Optional (NULL: not produced); filled for corpora whose slices have at most VK_FAST_SENT_LEN tokens.
+	 * W = the query length rounded up to a multiple of 16 (16 for queries of at most VK_FAST_QUERY_LEN tokens). */
+	float *sim_rows;         /* [capacity x VK_FAST_SENT_LEN x W] similarity S[i][j] of slice token i and query token j
+	                            (clipped, tag weights applied, static layout: sim[id(t_j)][j] = 1); rows >= the slice's length are zero */
+	float *plan;             /* [capacity x W x VK_FAST_SENT_LEN] exact transport only (VK_ALG_WRD, wmd_full): the optimal
 	                            plan G[j][i], mass moved from query token j to slice token i (positions) */
 } vk_topk_out;
 

@@ -932,17 +932,34 @@ static int score_sentence(const work *w, int64_t s, float *Sbuf, float *xbuf, fl
 	} else if (q->algorithm == VKO_ALG_RWMD) {
 		const int32_t *ids_s = c->layout == VKO_LAYOUT_STATIC ? c->tok_id + t0 : NULL;
 		const int32_t *ids_t = c->layout == VKO_LAYOUT_STATIC ? q->q_ids : NULL;
+		int32_t key_s[VKO_MAX_LEN_S], key_t[VKO_MAX_LEN_T];
+		if (q->tag_weights && ids_s && ids_t && c->tag_s && q->q_tag) {
+			/* TagWeightedSlice::similarity_dependency() == TAGS (slice/static.h:233-235) selects the tagged BOW builder
+			 * (metric/alignment.h:551-576): vocabulary entries are (token id, tag) pairs (bow.h:106-127, 150-176) */
+			for (int32_t i = 0; i < len_s; i++) key_s[i] = ids_s[i] * 256 + (int32_t)(uint8_t)c->tag_s[t0 + i];
+			for (int32_t j = 0; j < len_t; j++) key_t[j] = ids_t[j] * 256 + (int32_t)(uint8_t)q->q_tag[j];
+			ids_s = key_s; ids_t = key_t;
+		}
 		raw = vko_wmd(Sbuf, len_t, len_s, len_t, ids_s, ids_t, !q->wmd_full, q->rwmd_injective, q->rwmd_symmetric, q->rwmd_normalize_bow);
 		if (raw != raw) return 2;
-		/* SparseFlow::max_score -> matched = len_t (match.h:165-176) => ref = len_t */
-		*value_out = vko_score(raw, len_t, len_t, q->submatch_weight, boost);
+		/* SparseFlow::max_score -> matched = sum of max_similarity_for_t = len_t (match.h:165-176) => ref = len_t;
+		 * tag-weighted: max_similarity_for_t = t_pos_weights (slice/static.h:280-286) => matched = total = their sum */
+		if (q->tag_weights) {
+			float total = 0.0f;
+			for (int32_t j = 0; j < len_t; j++) total += q->tag_weights[j];
+			*value_out = (raw / total) * boost;
+		} else *value_out = vko_score(raw, len_t, len_t, q->submatch_weight, boost);
 	} else {
 		float mag_s[VKO_MAX_LEN_S];
 		for (int32_t i = 0; i < len_s; i++) mag_s[i] = c->X_mag ? c->X_mag[t0 + i] : 1.0f;
 		float mag_t[VKO_MAX_LEN_T];
 		for (int32_t j = 0; j < len_t; j++) mag_t[j] = q->Q_mag ? q->Q_mag[j] : 1.0f;
 		raw = vko_wrd(Sbuf, len_t, len_s, len_t, mag_s, mag_t, q->wrd_normalize_magnitudes);
-		*value_out = vko_score(raw, len_t, len_t, q->submatch_weight, boost);
+		if (q->tag_weights) {   /* DenseFlow::max_score (match.h:227-237): matched = total = sum of t_pos_weights */
+			float total = 0.0f;
+			for (int32_t j = 0; j < len_t; j++) total += q->tag_weights[j];
+			*value_out = (raw / total) * boost;
+		} else *value_out = vko_score(raw, len_t, len_t, q->submatch_weight, boost);
 	}
 	*raw_out = raw;
 	return 0;

@@ -128,6 +128,8 @@ typedef struct {
 	/* fp32 unit rows instead of the bf16 ones (the reference's own precision, vectorian/sim/vector.py:66-78) */
 	const float *X_f32;       /* contextual: [n_tokens x d], used when non-NULL */
 	const float *E_f32;       /* static: [V x d], used when non-NULL */
+	const int8_t *tag_s;      /* optional [n_tokens]: fine-grained tag code per token (Token.tag): with tag-weighted similarity the
+	                             vocabulary of the bags of words is keyed by (token id, tag) (TaggedTokenFactory, alignment/bow.h:150-176) */
 } vko_corpus;
 
 typedef struct {
@@ -156,6 +158,7 @@ typedef struct {
 	 * sgemm per document through vectorian/sim/vector.py:66-78, slice/contextual.h:65-67 then reads S[offset + i][j]);
 	 * used when non-NULL (bench.py's BLAS leg of the CPU baseline) */
 	const float *S_rows;
+	const int8_t *q_tag;      /* optional [len_t]: fine-grained tag code per query token (see vko_corpus.tag_s) */
 } vko_query;
 
 typedef struct {

@@ -41,7 +41,7 @@ class Corpus(C.Structure):
 		("X", C.c_void_p), ("X_mag", C.c_void_p),
 		("tok_id", C.c_void_p), ("E", C.c_void_p), ("V", C.c_int32),
 		("sent_off", C.c_void_p), ("sent_end", C.c_void_p), ("pos_s", C.c_void_p),
-		("X_f32", C.c_void_p), ("E_f32", C.c_void_p)]
+		("X_f32", C.c_void_p), ("E_f32", C.c_void_p), ("tag_s", C.c_void_p)]
 
 
 class Query(C.Structure):
@@ -57,7 +57,7 @@ class Query(C.Structure):
 		("wrd_normalize_magnitudes", C.c_int32),
 		("tag_weights", C.c_void_p), ("q_pos", C.c_void_p),
 		("pos_mismatch_penalty", C.c_float), ("similarity_threshold", C.c_float), ("wmd_full", C.c_int32),
-		("Q_f32", C.c_void_p), ("S_rows", C.c_void_p)]
+		("Q_f32", C.c_void_p), ("S_rows", C.c_void_p), ("q_tag", C.c_void_p)]
 
 
 class Result(C.Structure):
@@ -264,7 +264,7 @@ def find_many(*, layout, d, sent_off, Qs, sent_end=None, X=None, X_mag=None, tok
 		max_matches=10, min_score=0.0, boost=None, submatch_weight=0.0,
 		rwmd=(True, True, True), wrd_normalize=True, n_threads=1, want_all_scores=False,
 		pos_s=None, tag_weights=None, q_pos=None, pos_mismatch_penalty=0.0, similarity_threshold=0.0, wmd_full=False,
-		S_rows=None):
+		S_rows=None, tag_s=None, q_tags=None):
 	"""Runs vko_find_many over a batch of queries (Qs: list of uint16 bf16 [len_t x d]); q_ids / Q_mags
 	are per-query lists or None.  S_rows: per-query list of float32 [n_tokens x len_t] similarity matrices the caller
 	computed itself (contextual layout; the reference's one-sgemm-per-document form).  Returns a list of
@@ -297,6 +297,8 @@ def find_many(*, layout, d, sent_off, Qs, sent_end=None, X=None, X_mag=None, tok
 		pos_s = np.ascontiguousarray(pos_s, dtype=np.int8); c.pos_s = _ptr(pos_s)
 	if boost is not None:
 		boost = _f32(boost)
+	if tag_s is not None:
+		tag_s = np.ascontiguousarray(tag_s, dtype=np.int8); c.tag_s = _ptr(tag_s)
 
 	nq = len(Qs)
 	qs = (Query * nq)()
@@ -326,6 +328,8 @@ def find_many(*, layout, d, sent_off, Qs, sent_end=None, X=None, X_mag=None, tok
 		q.rwmd_injective, q.rwmd_symmetric, q.rwmd_normalize_bow = [int(x) for x in rwmd]
 		q.wrd_normalize_magnitudes = int(wrd_normalize)
 		q.wmd_full = int(bool(wmd_full))
+		if q_tags is not None and q_tags[i] is not None:
+			qt = np.ascontiguousarray(q_tags[i], dtype=np.int8); keep.append(qt); q.q_tag = _ptr(qt)
 		if S_rows is not None and S_rows[i] is not None:
 			sr = np.ascontiguousarray(S_rows[i], dtype=np.float32)
 			if sr.shape != (c.n_tokens, Q.shape[0]):
@@ -360,7 +364,8 @@ def find_many(*, layout, d, sent_off, Qs, sent_end=None, X=None, X_mag=None, tok
 	return outs
 
 
-def find(*, Q, q_ids=None, Q_mag=None, len_t=None, tag_weights=None, q_pos=None, **kw):
+def find(*, Q, q_ids=None, Q_mag=None, len_t=None, tag_weights=None, q_pos=None, q_tag=None, **kw):
 	"""one query (vko_find); see find_many"""
 	return find_many(Qs=[Q], q_ids=None if q_ids is None else [q_ids], Q_mags=None if Q_mag is None else [Q_mag],
-		tag_weights=None if tag_weights is None else [tag_weights], q_pos=None if q_pos is None else [q_pos], **kw)[0]
+		tag_weights=None if tag_weights is None else [tag_weights], q_pos=None if q_pos is None else [q_pos],
+		q_tags=None if q_tag is None else [q_tag], **kw)[0]

@@ -20,6 +20,8 @@ def _gap(g, n=65):
 
 
 class OracleCorpus:
+	takes_q_tags = True   # tag-weighted transport: the oracle keys the bags of words by (token id, tag), as the reference does
+
 	def __init__(self, *, layout, d, n_tokens, n_sentences, vocab_size=0, keep_magnitudes=False, device=None, precision="bf16"):
 		self.layout, self.d = layout, d
 		self.precision = precision
@@ -94,7 +96,7 @@ class OracleCorpus:
 	def query(self, q_vectors, *, locality=0, gap_s=0.0, gap_t=0.0, algorithm=0, q_token_ids=None, q_normalize=True,
 			max_matches=10, min_score=0.0, boost=None, want_flow=True, submatch_weight=0.0, bidirectional=False,
 			rwmd=(True, True, True), wrd_normalize=True, tag_weights=None, q_pos=None, pos_mismatch_penalty=0.0,
-			similarity_threshold=0.0, wmd_full=False):
+			similarity_threshold=0.0, wmd_full=False, q_tags=None):
 		q = np.ascontiguousarray(q_vectors)
 		if q.dtype == np.uint16:
 			q = synth.bf16_bits_to_f32(q)
@@ -110,6 +112,8 @@ class OracleCorpus:
 			submatch_weight=submatch_weight, rwmd=rwmd, wrd_normalize=wrd_normalize, want_all_scores=True,
 			pos_s=self._pos, tag_weights=tag_weights, q_pos=q_pos, pos_mismatch_penalty=pos_mismatch_penalty,
 			similarity_threshold=similarity_threshold, wmd_full=wmd_full)
+		if tag_weights is not None and q_tags is not None and self._tags is not None:
+			kw.update(tag_s=self._tags, q_tag=q_tags)
 		if self.layout == core.VK_LAYOUT_STATIC:
 			kw.update(tok_id=self._ids, E=self._X, q_ids=q_token_ids, X_mag=self._mag[self._ids], Q_mag=qmag)
 		else:
@@ -140,7 +144,13 @@ class OracleCorpus:
 			for j in range(len(q)):
 				if r["mapping"][i][j] >= 0:
 					top.edge_sim[i, j] = S[r["mapping"][i][j], j]
-			if transport and b - a <= core.VK_FAST_SENT_LEN and len(q) <= core.VK_FAST_QUERY_LEN:
+			if transport and tag_weights is not None:
+				# the solvers (and the flows stated from these rows) see the modified similarity (TagWeightedSlice::similarity, slice/static.h:237-264)
+				wgt = np.asarray(tag_weights, dtype=np.float32)[None, :] * np.where(
+					self._pos[a:b, None] != np.asarray(q_pos, dtype=np.int8)[None, :], np.float32(1.0 - pos_mismatch_penalty), np.float32(1.0))
+				S = (S * wgt).astype(np.float32)
+				S[S <= similarity_threshold] = 0.0
+			if transport and b - a <= core.VK_FAST_SENT_LEN:
 				# what the HIP backend returns for the host to state transport flows: rows, and the plan of exact transports
 				top.sim_rows[i, :b - a, :len(q)] = S
 				exact = algorithm == core.VK_ALG_WRD or wmd_full

@@ -111,3 +111,52 @@ def test_find_many_on_hip_equals_find(hip):
 		np.testing.assert_array_equal([m.score for m in res], [m.score for m in one])
 		assert all((a.flow["target"] == b.flow["target"]).all() for a, b in zip(res, one))
 	index.close()
+
+
+def test_tag_weighted_transport_and_long_queries_on_hip_equal_oracle_double(hip):
+	"""'alignment-tag-weighted' with the transport strategies (any matcher takes the modifier, match/instantiate.cpp:173-189) and
+	transport queries of more than 16 tokens, through Session / Index.find: ids, scores and the stated flows as the double's"""
+	from test_host_api import Corpus, Document, Session, StaticEmbedding
+	from vectorian_amd import synth
+	rng = np.random.default_rng(41)
+	V, d = 500, 64
+	words = [f"w{i}" for i in range(V)]
+	emb = StaticEmbedding("toy-64", words, synth.make_vocab(V, d) * rng.lognormal(0, 0.3, size=(V, 1)).astype(np.float32))
+	tag_names = ["NN", "VBZ", "DT", "JJ", ".", "NNS", "VBD"]
+	pos_of_tag = {"NN": "NOUN", "NNS": "NOUN", "VBZ": "VERB", "VBD": "VERB", "DT": "DET", "JJ": "ADJ", ".": "PUNCT"}
+	tag_of = lambda w: tag_names[(int(w[1:]) * 7919) % len(tag_names)]      # one tag per word, the universal POS a function of it
+	docs = []
+	for di in range(5):
+		sents = [[words[i] for i in synth.zipf_ids(int(rng.integers(3, 40)), V, rng)] for _ in range(40)]
+		docs.append(Document(sents, pos=[[pos_of_tag[tag_of(w)] for w in s] for s in sents], tags=[[tag_of(w) for w in s] for s in sents]))
+	session = Session(Corpus(docs), embeddings=[emb])
+	nlp = lambda text: [{"text": w, "pos": pos_of_tag[tag_of(w)], "tag": tag_of(w)} for w in text.split()]
+	doc = session.documents[3]
+	short, long_q = " ".join(doc.tokens[50:57]), " ".join(doc.tokens[200:227])
+	cases = [
+		(alignment.WordMoversDistance.rwmd("nbow"), True, short), (alignment.WordMoversDistance.wmd("nbow"), True, short),
+		(alignment.WordRotatorsDistance(), True, short), (alignment.WordRotatorsDistance(), False, long_q),
+		(alignment.WordMoversDistance.wmd("bow"), False, long_q), (alignment.WordRotatorsDistance(), True, long_q),
+	]
+	for strategy, tagged, text in cases:
+		kw = dict(tag_weights={"NN": 2.0, "VBZ": 1.5, "DT": 0.25}, pos_mismatch_penalty=0.3, similarity_threshold=0.1) if tagged else {}
+		sim = OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), strategy, **kw)
+		gpu = session.partition("sentence").index(sim, nlp=nlp)
+		cpu = session.partition("sentence").index(sim, nlp=nlp, corpus_factory=OracleCorpus)
+		a, b = gpu.find(text, n=6, min_score=0.0), cpu.find(text, n=6, min_score=0.0)
+		assert len(a) == len(b) == 6
+		assert [(m.doc_index, m.slice_id) for m in a] == [(m.doc_index, m.slice_id) for m in b], (type(strategy).__name__, tagged, len(text.split()))
+		np.testing.assert_allclose([m.score for m in a], [m.score for m in b], atol=2e-5)
+		for x, y in zip(a[:3], b[:3]):
+			fx, fy = x.flow, y.flow
+			assert fx["type"] == fy["type"]
+			if fx["type"] == "dense":
+				# an optimal plan need not be unique (repeated words give equal rows): same mass moved at the same cost
+				assert fx["flow"].shape == fy["flow"].shape == fx["dist"].shape
+				np.testing.assert_allclose(fx["dist"], fy["dist"], atol=2e-5)
+				assert abs(float(np.sum(fx["flow"])) - float(np.sum(fy["flow"]))) < 1e-4
+				assert abs(float(np.sum(fx["flow"] * fx["dist"])) - float(np.sum(fy["flow"] * fy["dist"]))) < 1e-4
+			else:
+				assert_json_close({k: np.asarray(v).tolist() for k, v in fx.items() if k != "type"},
+					{k: np.asarray(v).tolist() for k, v in fy.items() if k != "type"}, 2e-5)
+		gpu.close()

@@ -62,14 +62,91 @@ def test_static_tag_weighted(hip, oracle, len_t):
 	c.close()
 
 
-def test_tag_weighted_needs_pos_and_alignment(hip):
+def test_tag_weighted_needs_pos(hip):
 	corpus = synth.make_contextual_corpus(10, 4, 8, 100, 32)
 	c = hip_contextual_corpus(hip, corpus)
 	q = np.ones((3, 32), np.float32)
 	with pytest.raises(hip.VkError):
 		c.query(q, tag_weights=[1, 1, 1], q_pos=[1, 1, 1])           # no POS uploaded
 	c.set_token_pos(np.ones(corpus["X"].shape[0], np.int8))
-	with pytest.raises(hip.VkError):
-		c.query(q, algorithm=hip.VK_ALG_RWMD, tag_weights=[1, 1, 1], q_pos=[1, 1, 1])
+	c.query(q, algorithm=hip.VK_ALG_RWMD, tag_weights=[1, 1, 1], q_pos=[1, 1, 1])   # any matcher takes the modifier
 	c.query(q, tag_weights=[1, 1, 1], q_pos=[1, 1, 1])
+	c.close()
+
+
+TRANSPORTS = [
+	("rwmd", dict(rwmd=(True, True, True))), ("rwmd", dict(rwmd=(True, False, False))),
+	("rwmd", dict(rwmd=(False, True, True))), ("rwmd", dict(rwmd=(False, False, False))),      # 1:n form
+	("wmd", dict(rwmd=(False, False, True), wmd_full=True)), ("wmd", dict(rwmd=(False, False, False), wmd_full=True)),
+	("wrd", dict(wrd_normalize=True)), ("wrd", dict(wrd_normalize=False)),
+]
+
+
+@pytest.mark.parametrize("shape", [(96, 1, 40, 6), (300, 32, 32, 10), (64, 2, 64, 16), (96, 3, 50, 23), (64, 2, 64, 50)])
+@pytest.mark.parametrize("alg,opts", TRANSPORTS)
+def test_contextual_tag_weighted_transport(hip, oracle, shape, alg, opts):
+	"""the tag-weighted modifier with the transport metrics (TagWeightedSlice wraps any slice, match/instantiate.cpp:173-189):
+	modified similarities drive the solver, the score is divided by sum(tag_weights) (slice/static.h:280-286)"""
+	d, lo, hi, len_t = shape
+	if len_t > 16 and alg == "rwmd" and not opts["rwmd"][0]:
+		pytest.skip("the 1:n form stops at 16 query tokens")
+	n = 300
+	corpus = synth.make_contextual_corpus(n, lo, hi, 1500, d, noise=0.3, norm_sigma=0.25)
+	X = corpus["X"]
+	Xb, mag = oracle.normalize_rows_bf16(X)
+	rng = np.random.default_rng(31)
+	pos_s = rng.integers(1, 5, size=X.shape[0]).astype(np.int8)
+	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=d, n_tokens=X.shape[0], n_sentences=n, keep_magnitudes=True)
+	c.append_vectors(X, normalize=True)
+	c.set_sentences(corpus["sent_off"])
+	c.set_token_pos(pos_s)
+	c.finalize()
+	for q in synth.make_queries(corpus, 2, len_t):
+		qv = (q["vectors"] * rng.lognormal(0, 0.25, size=(len_t, 1))).astype(np.float32)
+		Qb, qmag = oracle.normalize_rows_bf16(qv)
+		tw = rng.choice([0.5, 1.0, 2.0], size=len_t).astype(np.float32)
+		q_pos = rng.integers(1, 5, size=len_t).astype(np.int8)
+		kw = dict(tag_weights=tw, q_pos=q_pos, pos_mismatch_penalty=0.4, similarity_threshold=0.15, max_matches=10, min_score=0.0, **opts)
+		o_alg = oracle.ALG_WRD if alg == "wrd" else oracle.ALG_RWMD
+		h_alg = hip.VK_ALG_WRD if alg == "wrd" else hip.VK_ALG_RWMD
+		ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=corpus["sent_off"], X=Xb, X_mag=mag, Q=Qb, Q_mag=qmag, pos_s=pos_s,
+			algorithm=o_alg, n_threads=8, **kw)
+		got = c.query(qv, q_normalize=True, algorithm=h_alg, **kw)
+		assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=2e-5, tie_tol=2e-5)
+	c.close()
+
+
+@pytest.mark.parametrize("len_t", [7, 20])
+@pytest.mark.parametrize("alg,opts", [t for t in TRANSPORTS if t[0] != "rwmd" or t[1]["rwmd"][0]])
+def test_static_tag_weighted_transport(hip, oracle, len_t, alg, opts):
+	"""static layout: the bags of words are keyed by (token id, tag) (TaggedTokenFactory, alignment/bow.h:150-176); the universal POS
+	is a function of the tag, as in spaCy's tag map, so equal keys have equal similarity rows"""
+	V, d = 300, 64
+	corpus = synth.make_static_corpus(400, 1, 40, V, d, seed=41)
+	rng = np.random.default_rng(42)
+	E = (corpus["E"] * rng.lognormal(0, 0.3, size=(V, 1))).astype(np.float32)
+	Eb, emag = oracle.normalize_rows_bf16(E)
+	off, ids = corpus["sent_off"], corpus["tok_id"]
+	tag_s = rng.integers(1, 9, size=len(ids)).astype(np.int8)
+	pos_s = (tag_s % 3 + 1).astype(np.int8)
+	c = hip.Corpus(layout=hip.VK_LAYOUT_STATIC, d=d, n_tokens=len(ids), n_sentences=len(off) - 1, vocab_size=V, keep_magnitudes=True)
+	c.append_vectors(E, normalize=True)
+	c.set_token_ids(ids)
+	c.set_sentences(off)
+	c.set_token_pos(pos_s)
+	c.finalize()
+	for _ in range(2):
+		q_ids = rng.integers(0, 40, size=len_t).astype(np.int32)
+		q_tag = rng.integers(1, 9, size=len_t).astype(np.int8)
+		q_pos = (q_tag % 3 + 1).astype(np.int8)
+		tw = np.array([0.5, 1.0, 3.0, 1.5, 0.75, 2.0, 1.0, 0.25, 1.25], dtype=np.float32)[q_tag]   # weights go by tag (parse_tag_weights, instantiate.cpp:10-38)
+		kw = dict(tag_weights=tw, q_pos=q_pos, pos_mismatch_penalty=0.25, similarity_threshold=0.05, max_matches=10, min_score=0.0, **opts)
+		o_alg = oracle.ALG_WRD if alg == "wrd" else oracle.ALG_RWMD
+		h_alg = hip.VK_ALG_WRD if alg == "wrd" else hip.VK_ALG_RWMD
+		ref = oracle.find(layout=oracle.LAYOUT_STATIC, d=d, sent_off=off, tok_id=ids, E=Eb, X_mag=emag[ids], Q=Eb[q_ids], q_ids=q_ids, Q_mag=emag[q_ids],
+			pos_s=pos_s, tag_s=tag_s, q_tag=q_tag, algorithm=o_alg, **kw)
+		got = c.query(E[q_ids], q_token_ids=q_ids, q_normalize=True, algorithm=h_alg, **kw)
+		assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=2e-5, tie_tol=2e-5)
+	with pytest.raises(hip.VkError):   # the 1:n form needs the (id, tag) vocabulary on the device: rejected, not approximated
+		c.query(E[q_ids], q_token_ids=q_ids, algorithm=hip.VK_ALG_RWMD, rwmd=(False, False, True), tag_weights=tw, q_pos=q_pos)
 	c.close()

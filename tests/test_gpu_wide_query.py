@@ -92,8 +92,9 @@ def test_wide_query_limits(hip):
 	Q65 = np.random.default_rng(1).standard_normal((65, 32)).astype(np.float32)
 	with pytest.raises(hip.VkError):
 		c.query(Q65, max_matches=3)
-	with pytest.raises(hip.VkError):   # exact transport stays at 16 query tokens
-		c.query(Q65[:20], algorithm=hip.VK_ALG_WRD, max_matches=3)
+	assert c.query(Q65[:20], algorithm=hip.VK_ALG_WRD, max_matches=3).n == 3   # exact transport runs up to 64 query tokens
+	with pytest.raises(hip.VkError):   # the 1:n form of RWMD stays at 16
+		c.query(Q65[:20], algorithm=hip.VK_ALG_RWMD, rwmd=(False, False, True), max_matches=3)
 	c.close()
 
 

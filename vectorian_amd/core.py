@@ -217,8 +217,9 @@ class TopK:
 		self.mapping = np.full((k, len_t), -1, dtype=np.int16)
 		self.edge_sim = np.zeros((k, len_t), dtype=np.float32)
 		# transport algorithms: similarity rows S[i][j] and (exact transport) the plan G[j][i] of each winner
-		self.sim_rows = np.zeros((k, VK_FAST_SENT_LEN, 16), dtype=np.float32) if transport else None
-		self.plan = np.zeros((k, 16, VK_FAST_SENT_LEN), dtype=np.float32) if transport else None
+		w = (len_t + 15) // 16 * 16     # columns of a similarity row: the query length padded to a multiple of 16
+		self.sim_rows = np.zeros((k, VK_FAST_SENT_LEN, w), dtype=np.float32) if transport else None
+		self.plan = np.zeros((k, w, VK_FAST_SENT_LEN), dtype=np.float32) if transport else None
 		self.n = 0
 
 	@classmethod

@@ -90,24 +90,32 @@ struct VkRwmdBatchParams {
 struct VkWrdParams {
 	const uint8_t *tiles;
 	const int32_t *tok_id;
-	const float *table;
+	const float *table;        // static: nq tables [V_pad x 16], table_stride floats apart
+	int64_t table_stride;
 	const int32_t *sent_start;
 	const int32_t *sent_end;
 	int32_t layout;
 	int32_t nk32, tail, tile_bytes;
 	int32_t prec;
-	const uint8_t *qtile;
+	const uint8_t *qtile;      // nq query tiles of 16 rows, tile_bytes apart
+	int32_t nq;                // 16-column blocks of the query: 1 (<= 16 tokens) .. 4 (<= 64)
 	int32_t len_t;
 	const float *mag;
-	float qmass[VK_DEV_MAX_QUERY_LEN];
+	float qmass[VK_DEV_MAX_WIDE_QUERY_LEN];
 	int32_t mass_mode;         // 0: magnitudes (WRD); 1: 1/len per token (nbow); 2: 1 per token (bow)
 	int32_t raw_masses;        // mass_mode 0: magnitudes as they are (normalize_magnitudes = false)
+	// tag-weighted similarity modifier (pos_s == nullptr: off), as in VkScoreParams
+	const int8_t *pos_s;
+	float tw[VK_DEV_MAX_WIDE_QUERY_LEN];
+	int32_t tpos[VK_DEV_MAX_WIDE_QUERY_LEN];
+	float tw_keep, tw_threshold;
+	float ref_total;           // reference_score: len_t, or sum(tw)
 	const float *boost;
 	const uint64_t *keys;      // candidates (0 = empty slot)
 	float *raw_out;            // [n_cand]
 	float *val_out;            // [n_cand]
-	float *plan_out;           // optional [n_cand x 16 x 64]: the optimal plan G[j][i]
-	float *rows_out;           // vk_rows_kernel: [n_cand x 64 x 16] similarity rows
+	float *plan_out;           // optional [n_cand x 16 nq x 64]: the optimal plan G[j][i]
+	float *rows_out;           // vk_rows_kernel: [n_cand x 64 x 16 nq] similarity rows
 };
 
 struct VkFlowParams {
@@ -188,6 +196,11 @@ struct VkWideParams {
 	int32_t tpos[VK_DEV_MAX_WIDE_QUERY_LEN];
 	float tw_keep, tw_threshold;
 	float ref_total;
+	// transport bound (vk_score32_kernel, GAP 5): upper bound of the WRD / full WMD score of every slice
+	const float *mag;          // token magnitudes (contextual) / vocabulary magnitudes (static); null: unit masses (bags of words)
+	float qmass[VK_DEV_MAX_WIDE_QUERY_LEN];   // query masses: |q_j| / sum |q|, |q_j| (wrd_raw_total > 0), 1 / len_t (nbow) or 1 (bow)
+	float wrd_raw_total;       // WRD on the magnitudes as they are: sum |q_j|; 0 otherwise
+	int32_t wmd_bound;         // 0: WRD; 1: full WMD over normalised bags; 2: full WMD over unit masses
 	const float *boost;
 	float *scores;
 	float *raw;

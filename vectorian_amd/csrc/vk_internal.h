@@ -102,6 +102,7 @@ struct vk_corpus {
 	float *d_wrd_raw = nullptr, *d_wrd_val = nullptr;
 	uint32_t *d_counter = nullptr;
 	float *d_rows_out = nullptr, *d_plan_out = nullptr;   // transport flows of the winners
+	int rows_w = 0;              // columns per similarity row they are sized for (16, 32, 48 or 64)
 	size_t wrd_cap = 0;          // candidates d_wrd_raw / d_wrd_val (and d_keys[0]) can hold
 	int16_t *d_out_map = nullptr;
 	hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // 0 start, 5 before / 1 after the wait for the peer's kernel, 2 scored, 3 selected, 4 done

@@ -11,8 +11,6 @@ int vk_validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_topk_
 	if (q->len_t < 1) return fail(VK_ERR_INVALID, "empty query");
 	if (q->len_t > VK_MAX_QUERY_LEN) return fail(VK_ERR_UNSUPPORTED, "query longer than VK_MAX_QUERY_LEN (64) tokens");
 	if (q->len_t > VK_FAST_QUERY_LEN) {
-		if (q->algorithm == VK_ALG_WRD || (q->algorithm == VK_ALG_RWMD && q->wmd_full))
-			return fail(VK_ERR_UNSUPPORTED, "exact transport (WRD, full WMD) is implemented for queries of at most 16 tokens");
 		const int gm = q->algorithm == VK_ALG_RWMD ? 4 : (q->gap_s.kind == VK_GAP_TABLE || q->gap_t.kind == VK_GAP_TABLE) ? 2 : 1;
 		if (vk_wide_lds_demand(c->max_len, (q->len_t + 15) / 16, gm, q->tag_weights != nullptr, q->want_flow) > 160 * 1024)
 			return fail(VK_ERR_UNSUPPORTED, "query of more than 16 tokens over slices this long exceeds the LDS of a workgroup");
@@ -39,7 +37,13 @@ int vk_validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_topk_
 			if (q->similarity_threshold < 0.0f) return fail(VK_ERR_INVALID, "similarity_threshold must be >= 0 (slice/static.h:209)");
 		}
 	} else if (q->algorithm == VK_ALG_RWMD) {
-		if (q->tag_weights) return fail(VK_ERR_UNSUPPORTED, "tag-weighted similarity is implemented for alignments only");
+		if (q->tag_weights) {   // TagWeightedSlice wraps any slice, whatever the matcher (match/instantiate.cpp:173-189)
+			if (!q->q_pos) return fail(VK_ERR_INVALID, "tag-weighted query without q_pos");
+			if (!c->d_pos) return fail(VK_ERR_STATE, "tag-weighted query needs vk_corpus_set_token_pos");
+			if (q->similarity_threshold < 0.0f) return fail(VK_ERR_INVALID, "similarity_threshold must be >= 0 (slice/static.h:209)");
+			if (!q->rwmd_injective && !q->wmd_full && c->desc.layout == VK_LAYOUT_STATIC)
+				return fail(VK_ERR_UNSUPPORTED, "tag-weighted 1:n RWMD over the static layout is not implemented (its vocabulary is keyed by (token, tag), bow.h:150-176)");
+		}
 		if (q->rwmd_symmetric && !q->rwmd_normalize_bow)
 			return fail(VK_ERR_INVALID, "cannot run symmetric mode WMD with bow (needs nbow)");   // wmd.h:441-449
 		if (q->wmd_full) {
@@ -51,7 +55,11 @@ int vk_validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_topk_
 		if (q->want_flow && (!out->mapping || !out->edge_sim)) return fail(VK_ERR_INVALID, "want_flow needs mapping and edge_sim arrays");
 	} else if (q->algorithm == VK_ALG_WRD) {
 		if (c->max_len > VK_FAST_SENT_LEN) return fail(VK_ERR_UNSUPPORTED, "VK_ALG_WRD needs every slice <= VK_FAST_SENT_LEN (64) tokens");
-		if (q->tag_weights) return fail(VK_ERR_UNSUPPORTED, "tag-weighted similarity is implemented for alignments only");
+		if (q->tag_weights) {
+			if (!q->q_pos) return fail(VK_ERR_INVALID, "tag-weighted query without q_pos");
+			if (!c->d_pos) return fail(VK_ERR_STATE, "tag-weighted query needs vk_corpus_set_token_pos");
+			if (q->similarity_threshold < 0.0f) return fail(VK_ERR_INVALID, "similarity_threshold must be >= 0 (slice/static.h:209)");
+		}
 		if (!c->d_mag) return fail(VK_ERR_STATE, "VK_ALG_WRD needs a corpus created with keep_magnitudes = 1");
 		if (q->want_flow && (!out->mapping || !out->edge_sim)) return fail(VK_ERR_INVALID, "want_flow needs mapping and edge_sim arrays");
 	} else {
@@ -112,13 +120,34 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	const bool is_static_l = c->desc.layout == VK_LAYOUT_STATIC;
 	// transport algorithms: similarity rows (and, for exact transport, the optimal plan) of the winners, from which
 	// the host states their SparseFlow / DenseFlow.  rows_idx: rows of the slice table, best first.
+	// what vk_wrd_exact_kernel / vk_rows_kernel need to restate the similarity rows of a slice (tag weights included)
+	auto fill_transport = [&](VkWrdParams &w) {
+		w.tiles = c->d_tiles; w.tok_id = c->d_tok_id; w.table = c->d_table; w.table_stride = (int64_t)c->n_tiles * 16 * 16;
+		w.sent_start = c->d_sent_start; w.sent_end = c->d_sent_end;
+		w.layout = is_static_l ? VK_DEV_LAYOUT_STATIC : VK_DEV_LAYOUT_CONTEXTUAL; w.nk32 = c->nk32; w.tail = c->tail; w.tile_bytes = c->tile_bytes; w.prec = c->prec;
+		w.qtile = c->d_qtile; w.nq = (q->len_t + 15) / 16; w.len_t = q->len_t; w.mag = c->d_mag;
+		w.ref_total = (float)q->len_t;
+		if (q->tag_weights) {
+			float total = 0.0f;
+			for (int j = 0; j < q->len_t; j++) total += q->tag_weights[j];
+			for (int j = 0; j < VK_MAX_QUERY_LEN; j++) {
+				w.tw[j] = j < q->len_t ? q->tag_weights[j] : 0.0f;
+				w.tpos[j] = j < q->len_t ? (int32_t)q->q_pos[j] : -1;
+			}
+			w.pos_s = c->d_pos; w.tw_keep = 1.0f - q->pos_mismatch_penalty; w.tw_threshold = q->similarity_threshold;
+			w.ref_total = total;   // reference_score with max_sum_of_similarities = sum of t_pos_weights (slice/static.h:280-286)
+		}
+	};
 	auto transport_flows = [&](const std::vector<int64_t> &rows_idx, bool exact, const float *qmass, int mass_mode, int raw_masses) -> int {
 		if (!q->want_flow || !out->sim_rows || rows_idx.empty()) return VK_OK;
-		if (c->max_len > VK_FAST_SENT_LEN || q->len_t > VK_FAST_QUERY_LEN) return VK_OK;
+		if (c->max_len > VK_FAST_SENT_LEN) return VK_OK;
+		const int nqw = (q->len_t + 15) / 16, W = 16 * nqw;   // columns of a similarity row: the query length padded to 16
 		int rc2;
-		if (!c->d_rows_out) {
-			if ((rc2 = alloc_t(c, &c->d_rows_out, (size_t)VK_MAX_MATCHES * 64 * 16))) return rc2;
-			if ((rc2 = alloc_t(c, &c->d_plan_out, (size_t)VK_MAX_MATCHES * 16 * 64))) return rc2;
+		if (c->rows_w < W) {
+			if (c->d_rows_out) { VK_HIP(hipFree(c->d_rows_out)); VK_HIP(hipFree(c->d_plan_out)); c->d_rows_out = c->d_plan_out = nullptr; }
+			if ((rc2 = alloc_t(c, &c->d_rows_out, (size_t)VK_MAX_MATCHES * 64 * W))) return rc2;
+			if ((rc2 = alloc_t(c, &c->d_plan_out, (size_t)VK_MAX_MATCHES * W * 64))) return rc2;
+			c->rows_w = W;
 		}
 		if (!c->d_wrd_raw) {
 			if ((rc2 = alloc_t(c, &c->d_wrd_raw, (size_t)VK_MAX_MATCHES))) return rc2;
@@ -130,18 +159,16 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		for (int i = 0; i < cnt; i++) hk[(size_t)i] = (1ull << 32) | (uint64_t)(uint32_t)rows_idx[(size_t)i];
 		VK_HIP(hipMemcpyAsync(c->d_keys[1], hk.data(), hk.size() * 8, hipMemcpyHostToDevice, c->stream));
 		VkWrdParams w{};
-		w.tiles = c->d_tiles; w.tok_id = c->d_tok_id; w.table = c->d_table; w.sent_start = c->d_sent_start; w.sent_end = c->d_sent_end;
-		w.layout = is_static_l ? VK_DEV_LAYOUT_STATIC : VK_DEV_LAYOUT_CONTEXTUAL; w.nk32 = c->nk32; w.tail = c->tail; w.tile_bytes = c->tile_bytes; w.prec = c->prec;
-		w.qtile = c->d_qtile; w.len_t = q->len_t; w.mag = c->d_mag;
+		fill_transport(w);
 		w.keys = c->d_keys[1]; w.rows_out = c->d_rows_out;
 		VK_HIP(vk_launch_rows(&w, cnt, c->stream));
-		VK_HIP(hipMemcpyAsync(out->sim_rows, c->d_rows_out, (size_t)cnt * 64 * 16 * 4, hipMemcpyDeviceToHost, c->stream));
+		VK_HIP(hipMemcpyAsync(out->sim_rows, c->d_rows_out, (size_t)cnt * 64 * W * 4, hipMemcpyDeviceToHost, c->stream));
 		if (exact && out->plan) {
 			w.mass_mode = mass_mode; w.raw_masses = raw_masses;
 			memcpy(w.qmass, qmass, sizeof w.qmass);
 			w.raw_out = c->d_wrd_raw; w.val_out = c->d_wrd_val; w.plan_out = c->d_plan_out;
 			VK_HIP(vk_launch_wrd_exact(&w, cnt, nullptr, c->stream));
-			VK_HIP(hipMemcpyAsync(out->plan, c->d_plan_out, (size_t)cnt * 16 * 64 * 4, hipMemcpyDeviceToHost, c->stream));
+			VK_HIP(hipMemcpyAsync(out->plan, c->d_plan_out, (size_t)cnt * W * 64 * 4, hipMemcpyDeviceToHost, c->stream));
 		}
 		VK_HIP(hipStreamSynchronize(c->stream));
 		return VK_OK;
@@ -157,6 +184,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	VK_HIP(hipMemcpyAsync(c->d_qtile, qtile.data(), qtile.size(), hipMemcpyHostToDevice, st));
 
 	VkScoreParams p{};
+	float qmass_all[VK_MAX_QUERY_LEN] = {0};   // masses of the query tokens (transport algorithms), all 64 columns
 	const int ks = q->gap_s.kind, kt = q->gap_t.kind;
 	float ws[kGapTable], wt[80];
 	const bool is_align = q->algorithm == VK_ALG_ALIGN;
@@ -165,14 +193,18 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		float sum_t = 0.0f;
 		for (int j = 0; j < q->len_t; j++) sum_t += qmags[j];           // wrd.h:99-102, float sum in order
 		const bool rawm = !q->wrd_normalize_magnitudes;   // wrd.h:99-102: masses stay the magnitudes
-		for (int j = 0; j < VK_FAST_QUERY_LEN; j++) p.qmass[j] = j < q->len_t ? (rawm ? qmags[j] : qmags[j] / sum_t) : 0.0f;
+		for (int j = 0; j < VK_MAX_QUERY_LEN; j++) qmass_all[j] = j < q->len_t ? (rawm ? qmags[j] : qmags[j] / sum_t) : 0.0f;
+		memcpy(p.qmass, qmass_all, sizeof p.qmass);
 		p.wrd_raw_total = rawm ? sum_t : 0.0f;
 		p.mag = c->d_mag;
 	} else if (q->algorithm == VK_ALG_RWMD) {
 		p.gap_mode = 4;
 		p.rwmd_symmetric = q->rwmd_symmetric;
 		p.rwmd_normalize_bow = q->rwmd_normalize_bow;
-		if (q->wmd_full) p.wmd_bound = q->rwmd_normalize_bow ? 1 : 2;
+		if (q->wmd_full) {
+			p.wmd_bound = q->rwmd_normalize_bow ? 1 : 2;
+			for (int j = 0; j < q->len_t; j++) qmass_all[j] = q->rwmd_normalize_bow ? 1.0f / (float)q->len_t : 1.0f;
+		}
 		else if (!q->rwmd_injective) {
 			// 1:n form: masses of the query's vocabulary entries (count / len at the first occurrence of a token id)
 			p.gap_mode = 7;
@@ -257,7 +289,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	p.boost = q->boost ? c->d_boost : nullptr;
 	p.scores = c->d_scores; p.raw = c->d_raw;
 	p.ref_total = (float)q->len_t;
-	if (q->tag_weights && is_align) {
+	if (q->tag_weights) {
 		float total = 0.0f;
 		for (int j = 0; j < q->len_t; j++) total += q->tag_weights[j];
 		for (int j = 0; j < VK_FAST_QUERY_LEN; j++) {
@@ -289,10 +321,19 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		// (33..64 tokens: one slice per wave and four column blocks)
 		const int wave_tiles = q->len_t <= 32 ? c->max_pair_tiles : (c->max_len + 15) / 16 + 1;
 		const bool rwmd_inj = q->algorithm == VK_ALG_RWMD && p.gap_mode == 4 && !q->wmd_full;
-		const bool two_blocks = (is_align || rwmd_inj) && c->n_long_groups == 0 &&
-			c->max_len <= VK_FAST_SENT_LEN && (rwmd_inj || p.gap_mode == 0 || (p.gap_mode == 1 && p.a_t >= 0.0f) || (p.gap_mode == 2 && wide_sub)) &&
-			vk_score32_lds_bytes(is_static ? 0 : c->nk32, wave_tiles, q->len_t) <= 160 * 1024 && !getenv("VK_NO_SCORE32");
+		const bool bound_pass = q->algorithm == VK_ALG_WRD || (q->algorithm == VK_ALG_RWMD && q->wmd_full);   // exact transport: stage 1
+		const bool two_blocks = (is_align || rwmd_inj || bound_pass) && c->n_long_groups == 0 &&
+			c->max_len <= VK_FAST_SENT_LEN && (rwmd_inj || bound_pass || p.gap_mode == 0 || (p.gap_mode == 1 && p.a_t >= 0.0f) || (p.gap_mode == 2 && wide_sub)) &&
+			vk_score32_lds_bytes(is_static ? 0 : c->nk32, wave_tiles, q->len_t) <= 160 * 1024 && (bound_pass || !getenv("VK_NO_SCORE32"));
+		if (bound_pass && !two_blocks)
+			return fail(VK_ERR_UNSUPPORTED, "exact transport with a query of more than 16 tokens: the multi-block kernel does not fit this corpus (LDS)");
 		if (two_blocks) {
+			if (bound_pass) {
+				wp.gap_mode = 5;
+				wp.mag = q->algorithm == VK_ALG_WRD ? c->d_mag : nullptr;
+				memcpy(wp.qmass, qmass_all, sizeof wp.qmass);
+				wp.wrd_raw_total = p.wrd_raw_total; wp.wmd_bound = q->algorithm == VK_ALG_WRD ? 0 : p.wmd_bound;
+			}
 			if (p.gap_mode == 2) wp.gap_mode = c->max_len <= 32 ? 3 : 6;   // register history of 32 / 64 rows
 			VK_HIP(vk_launch_score32(&wp, wave_tiles, st));
 			wp.gap_mode = p.gap_mode;                                        // the traceback kernel knows 0 / 1 / 2
@@ -374,11 +415,9 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		std::vector<uint64_t> keys;
 		std::vector<float> vals, raws;
 		VkWrdParams w{};
-		w.tiles = c->d_tiles; w.tok_id = c->d_tok_id; w.table = c->d_table; w.sent_start = c->d_sent_start; w.sent_end = c->d_sent_end;
-		w.layout = p.layout; w.nk32 = c->nk32; w.tail = c->tail; w.tile_bytes = c->tile_bytes; w.prec = c->prec;
-		w.qtile = c->d_qtile; w.len_t = q->len_t; w.mag = c->d_mag;
+		fill_transport(w);
 		w.mass_mode = q->algorithm == VK_ALG_WRD ? 0 : (q->rwmd_normalize_bow ? 1 : 2);
-		memcpy(w.qmass, p.qmass, sizeof w.qmass);
+		memcpy(w.qmass, qmass_all, sizeof w.qmass);
 		w.raw_masses = (q->algorithm == VK_ALG_WRD && !q->wrd_normalize_magnitudes) ? 1 : 0;
 		w.boost = p.boost; w.raw_out = c->d_wrd_raw; w.val_out = c->d_wrd_val;
 		// solves the `count` candidates whose keys sit at d_keys, merges them into `best`; returns the smallest bound among them
@@ -662,7 +701,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	if (q->algorithm == VK_ALG_RWMD && n_out > 0) {
 		std::vector<int64_t> rows_idx;
 		for (int i = 0; i < n_out; i++) rows_idx.push_back((int64_t)(uint32_t)(keys[(size_t)i] & 0xffffffffu));
-		float no_mass[VK_FAST_QUERY_LEN] = {0};
+		float no_mass[VK_MAX_QUERY_LEN] = {0};
 		if ((rc = transport_flows(rows_idx, false, no_mass, 0, 0))) return rc;
 	}
 

@@ -142,6 +142,68 @@ __device__ __forceinline__ float rwmd32(const float *__restrict__ S, int stride,
 	return (max_cost - cost) / max_cost;
 }
 
+// sum over the lanes of a slice -> its last lane (any order: used for bounds only)
+template <int NB>
+__device__ __forceinline__ float slice_sum_to_last_lane(float x, int blk) {
+	x += dpp_f<DPP_ROW_SHR1>(0.0f, x);
+	x += dpp_f<DPP_ROW_SHR2>(0.0f, x);
+	x += dpp_f<DPP_ROW_SHR4>(0.0f, x);
+	x += dpp_f<DPP_ROW_SHR8>(0.0f, x);
+#pragma unroll
+	for (int r = 1; r < NB; r++) {
+		const float l = from_left_block<NB>(x);
+		x = blk == r ? x + l : x;
+	}
+	return x;
+}
+
+// Exact transport (Word Rotator's Distance, full WMD) with queries of 17..64 tokens, stage 1: an upper bound of the score of every
+// slice (stage 2, vk_wrd_exact_kernel, solves the survivors).  Every unit of mass travels at least to its nearest partner, so
+//   sum_j m_t[j] min_i C[j][i]   and   sum_i m_s[i] min_j C[j][i],   C = max(0, 1 - S)   (wrd.h:104-109, wmd.h:107-135)
+// bound the cost of any feasible plan from below whenever that side ships all its mass (the nearest-neighbour relaxation; the
+// 16-column kernel adds capacity constraints, wrd_bound_rows).  Masses: magnitudes (WRD; normalised to 1 per side unless
+// wrd_raw_total > 0) or the unit / 1 / len masses of bags of words (mag == null).  Only a bound: float order is free.
+template <int NB>
+__device__ __forceinline__ float transport_bound32(const float *__restrict__ S, int stride, int rowbase, int len, int maxlen, int col, int lane,
+	const VkWideParams &p, const float *__restrict__ mag, const int32_t *__restrict__ ids) {
+	constexpr int LPS = 16 * NB, REGS = 64 / LPS;   // lanes per slice; registers that hold a slice's (at most 64) masses
+	const int blk = col >> 4;
+	const bool col_ok = col < p.len_t;
+	const float BIG = 3.402823466e+38F;
+	// the slice's masses, fetched once: lane `col` of the slice holds tokens col, col + LPS
+	float mreg[REGS];
+#pragma unroll
+	for (int c = 0; c < REGS; c++) {
+		const int u0 = c * LPS + col;
+		float mg = 0.0f;
+		if (u0 < len) mg = mag ? (ids ? mag[ids[u0]] : mag[u0]) : 1.0f;
+		mreg[c] = mg;
+	}
+	const int slice_lane0 = lane & ~(LPS - 1);
+	float colmin = BIG, sum_s = 0.0f, lb1n = 0.0f;
+#pragma unroll
+	for (int c = 0; c < REGS; c++) {
+		const int u_end = maxlen < (c + 1) * LPS ? maxlen : (c + 1) * LPS;
+		for (int u = c * LPS + 1; u <= u_end; u++) {
+			const bool act = u <= len;
+			const float dist = fmaxf(1.0f - S[(rowbase + (act ? u - 1 : 0)) * stride + (col < stride ? col : 0)], 0.0f);
+			if (act) colmin = fminf(colmin, dist);
+			const float m = -slice_max_to_last_lane<NB>(col_ok ? -dist : -BIG, blk);   // nearest query token of this slice token
+			const float mg = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((slice_lane0 | ((u - 1) & (LPS - 1))) * 4, __builtin_bit_cast(int, mreg[c])));
+			sum_s += mg;            // 0 beyond the slice's length
+			lb1n += mg * m;         // complete in the slice's last lane
+		}
+	}
+	const float x = slice_sum_to_last_lane<NB>(col_ok ? p.qmass[col < VK_DEV_MAX_WIDE_QUERY_LEN ? col : 0] * colmin : 0.0f, blk);
+	const float lb1 = sum_s > 0.0f ? lb1n / sum_s : 0.0f;
+	float lb;
+	if (p.wmd_bound == 2) lb = p.len_t <= len ? x / (float)p.len_t : lb1;            // unit masses: the shorter side ships everything
+	else if (p.wrd_raw_total > 0.0f) lb = p.wrd_raw_total <= sum_s ? x / p.wrd_raw_total : lb1;   // magnitudes as they are: the lighter side
+	else lb = fmaxf(x, lb1);                                                         // both sides ship 1
+	if (!(sum_s > 0.0f)) lb = 0.0f;
+	return fminf(1.0f - lb * (1.0f - 4e-6f) + 3e-5f, 1.0f);
+}
+
 // General gap costs (Waterman-Smith-Beyer), w_t strictly subadditive (checked by the host, as for dp_general_reg): the
 // column history of each lane in registers; in-row candidates c[col - k] - w_t(k) from the lane's own block by
 // row_shr:k, and for the blocks further right also from the columns of the blocks to their left, which pass through a
@@ -385,6 +447,8 @@ __global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t
 		if constexpr (GAP == 3) raw = dp32_general<32, NB>(S, stride, rb, lenc, maxlen, col, lane, p, wsr, xch);
 		else if constexpr (GAP == 6) raw = dp32_general<64, NB>(S, stride, rb, lenc, maxlen, col, lane, p, wsr, xch);
 		else if constexpr (GAP == 4) raw = rwmd32<NB>(S, stride, rb, lenc, maxlen, col, lane, p);
+		else if constexpr (GAP == 5) raw = transport_bound32<NB>(S, stride, rb, lenc, maxlen, col, lane, p,
+			p.mag ? (STATIC ? p.mag : p.mag + (len > 0 ? t_a : 0)) : nullptr, (STATIC && p.mag) ? p.tok_id + (len > 0 ? t_a : 0) : nullptr);
 		else raw = dp32<GAP, NB>(S, stride, rb, lenc, maxlen, col, p);
 		if (col == LPS - 1 && s_idx < p.n_sent) {
 			float val = VK_NEG_INF, r = VK_NEG_INF;
@@ -421,6 +485,8 @@ extern "C" hipError_t vk_launch_score32(const VkWideParams *p, int32_t tiles, hi
 		: (is_static ? vk_score32_kernel<1, true, 2> : vk_score32_kernel<1, false, 2>); break;
 	case 4: kernel = four ? (is_static ? vk_score32_kernel<4, true, 4> : vk_score32_kernel<4, false, 4>)
 		: (is_static ? vk_score32_kernel<4, true, 2> : vk_score32_kernel<4, false, 2>); break;
+	case 5: kernel = four ? (is_static ? vk_score32_kernel<5, true, 4> : vk_score32_kernel<5, false, 4>)
+		: (is_static ? vk_score32_kernel<5, true, 2> : vk_score32_kernel<5, false, 2>); break;
 	case 3: kernel = four ? (is_static ? vk_score32_kernel<3, true, 4> : vk_score32_kernel<3, false, 4>)
 		: (is_static ? vk_score32_kernel<3, true, 2> : vk_score32_kernel<3, false, 2>); break;
 	default: kernel = four ? (is_static ? vk_score32_kernel<6, true, 4> : vk_score32_kernel<6, false, 4>)

@@ -9,7 +9,7 @@
 // (oracle/vk_oracle.c), which stands in for pyemd's emd_hat_gd_metric<double>
 // (vectorian/core/cpp/alignment/transport.h:70,125-126) -- with the Dijkstra step spread over the wave:
 //   lane i owns demand i (its distance, potential, predecessor, remaining mass; column i of the costs and
-//   flows in LDS); the supplies live in small LDS arrays read uniformly.
+//   flows in LDS); the supplies live in small LDS arrays read uniformly.  Queries of up to 64 tokens: 16 NQ supplies.
 //   All supplies with remaining mass are sources and are relaxed together.  Demands are never settled
 //   one by one: the next supply to settle is the minimum over (demand i, supply b with flow b -> i) of
 //   dist[i] + reduced cost(i -> b), one in-lane loop over b and ONE wave reduction; it is final because
@@ -20,8 +20,6 @@
 // solver took 8 - 20 ms per round of candidates; this one ~0.1 ms.
 // ---------------------------------------------------------------------------
 
-#define VK_WRD_N VK_DEV_MAX_QUERY_LEN
-#define VK_WRD_M VK_DEV_MAX_SENT_LEN
 
 // minimum of x over the wave and a lane holding it (the lowest such lane).  The 16 lanes of a DPP row are folded with
 // four cross-lane moves (quad swaps, half mirror, mirror: every lane ends with its row's minimum), the four rows through
@@ -56,12 +54,64 @@ __device__ __forceinline__ double wave_argmin_f64(double x, int lane, int &at) {
 	return m;
 }
 
+// similarity rows of one slice against the nq query tiles -> S[row][16 nq] (row 0 = first token of the slice's first tile or,
+// static layout, of the slice); returns the row of the slice's first token.  Tag-weighted modifier applied when p.pos_s.
+template <int NQ>
+__device__ __forceinline__ int transport_sim_rows(const VkWrdParams &p, float *S, int t_a, int t_b, int lane) {
+	constexpr int N = 16 * NQ;
+	const int m = t_b - t_a;
+	if (p.layout == VK_DEV_LAYOUT_STATIC) {
+		for (int it = 0; it * 16 < m; it++) {
+			const int tk = it * 16 + (lane >> 2);
+			if (tk < m) {
+				const int id = p.tok_id[t_a + tk];
+				const int ps = p.pos_s ? p.pos_s[t_a + tk] : 0;
+#pragma unroll
+				for (int b = 0; b < NQ; b++) {
+					float4 vq = *reinterpret_cast<const float4 *>(p.table + b * p.table_stride + (int64_t)id * 16 + (lane & 3) * 4);
+					if (p.pos_s) {
+						const int c0 = 16 * b + (lane & 3) * 4;
+						vq.x = tag_weighted(vq.x, p.tw[c0 + 0], ps, p.tpos[c0 + 0], p.tw_keep, p.tw_threshold);
+						vq.y = tag_weighted(vq.y, p.tw[c0 + 1], ps, p.tpos[c0 + 1], p.tw_keep, p.tw_threshold);
+						vq.z = tag_weighted(vq.z, p.tw[c0 + 2], ps, p.tpos[c0 + 2], p.tw_keep, p.tw_threshold);
+						vq.w = tag_weighted(vq.w, p.tw[c0 + 3], ps, p.tpos[c0 + 3], p.tw_keep, p.tw_threshold);
+					}
+					*reinterpret_cast<float4 *>(S + tk * N + 16 * b + (lane & 3) * 4) = vq;
+				}
+			}
+		}
+		return 0;
+	}
+	const int tile0 = t_a >> 4;
+	const int ntiles = ((t_b + 15) >> 4) - tile0;
+	for (int ti = 0; ti < ntiles; ti++) {
+		const int ps = p.pos_s ? p.pos_s[(tile0 + ti) * 16 + (lane & 15)] : 0;
+#pragma unroll
+		for (int b = 0; b < NQ; b++) {
+			f32x4 acc = sim_tile_generic(p.qtile + (int64_t)b * p.tile_bytes, p.tiles + (int64_t)(tile0 + ti) * p.tile_bytes, p.nk32, p.tail, lane, p.prec);
+			if (p.pos_s) {
+				const int c0 = 16 * b + (lane >> 4) * 4;
+#pragma unroll
+				for (int r = 0; r < 4; r++) acc[r] = tag_weighted(acc[r], p.tw[c0 + r], ps, p.tpos[c0 + r], p.tw_keep, p.tw_threshold);
+			}
+			*reinterpret_cast<f32x4 *>(S + (ti * 16 + (lane & 15)) * N + 16 * b + (lane >> 4) * 4) = acc;
+		}
+	}
+	return t_a - tile0 * 16;
+}
+
+// NQ = 16-column blocks of the query (1: at most 16 tokens .. 4: at most 64).  NQ = 1 keeps the lane's cost and flow columns and
+// the supplies' potentials in registers; the wider forms read them from LDS (3 x 16 NQ doubles per lane do not fit).
+template <int NQ>
 __global__ __launch_bounds__(64) void vk_wrd_exact_kernel(VkWrdParams p) {
-	__shared__ __attribute__((aligned(16))) float S[(VK_DEV_MAX_SENT_LEN + 32) * 16];
-	__shared__ double Cm[VK_WRD_N * 64];     // Cm[j * 64 + i]: cost supply j -> demand i
-	__shared__ double fl[VK_WRD_N * 64];     // flow
-	__shared__ double sup[VK_WRD_N], pot_s[VK_WRD_N], dist_s[VK_WRD_N];
-	__shared__ int pred_s[VK_WRD_N], settled[VK_WRD_N];
+	constexpr int N = 16 * NQ;
+	constexpr bool REG = NQ == 1;
+	extern __shared__ double vk_smem_f64[];
+	double *Cm = vk_smem_f64;               // Cm[j * 64 + i]: cost supply j -> demand i
+	double *fl = Cm + N * 64;               // flow
+	double *sup = fl + N * 64, *pot_s = sup + N, *dist_s = pot_s + N;
+	int *pred_s = reinterpret_cast<int *>(dist_s + N), *settled = pred_s + N;
+	float *S = reinterpret_cast<float *>(settled + N);   // [(VK_DEV_MAX_SENT_LEN + 32)][N]
 
 	const int lane = threadIdx.x;
 	const int w = blockIdx.x;
@@ -71,28 +121,9 @@ __global__ __launch_bounds__(64) void vk_wrd_exact_kernel(VkWrdParams p) {
 	const int t_a = p.sent_start[g], t_b = p.sent_end[g];
 	const int m = t_b - t_a, n = p.len_t;
 
-	int rowbase;
-	if (p.layout == VK_DEV_LAYOUT_STATIC) {
-		for (int it = 0; it * 16 < m; it++) {
-			const int tk = it * 16 + (lane >> 2);
-			if (tk < m) {
-				const int id = p.tok_id[t_a + tk];
-				*reinterpret_cast<float4 *>(S + tk * 16 + (lane & 3) * 4) =
-					*reinterpret_cast<const float4 *>(p.table + (int64_t)id * 16 + (lane & 3) * 4);
-			}
-		}
-		rowbase = 0;
-	} else {
-		const int tile0 = t_a >> 4;
-		const int ntiles = ((t_b + 15) >> 4) - tile0;
-		for (int ti = 0; ti < ntiles; ti++) {
-			const f32x4 acc = sim_tile_generic(p.qtile, p.tiles + (int64_t)(tile0 + ti) * p.tile_bytes, p.nk32, p.tail, lane, p.prec);
-			*reinterpret_cast<f32x4 *>(S + (ti * 16 + (lane & 15)) * 16 + (lane >> 4) * 4) = acc;
-		}
-		rowbase = t_a - tile0 * 16;
-	}
+	const int rowbase = transport_sim_rows<NQ>(p, S, t_a, t_b, lane);
 	wave_lds_fence();
-	const float *Sm = S + rowbase * 16;
+	const float *Sm = S + rowbase * N;
 	const bool has = lane < m;
 	const double EPS = 1e-13, INF = __builtin_inf();
 
@@ -105,28 +136,30 @@ __global__ __launch_bounds__(64) void vk_wrd_exact_kernel(VkWrdParams p) {
 		float sum_s = 0.0f;
 		for (int i = 0; i < m; i++) sum_s += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), i));
 		if (has) dem = (double)(p.raw_masses ? mine : mine / sum_s);
-		if (lane < VK_WRD_N) sup[lane] = lane < n ? (double)p.qmass[lane] : 0.0;
+		if (lane < N) sup[lane] = lane < n ? (double)p.qmass[lane] : 0.0;
 	} else {
 		// bags of words over positions: 1 per token (bow), or 1/len (nbow, bow.h:262-270)
 		const float wt = p.mass_mode == 1 ? 1.0f / (float)n : 1.0f;
 		const float wsn = p.mass_mode == 1 ? 1.0f / (float)m : 1.0f;
 		if (has) dem = (double)wsn;
-		if (lane < VK_WRD_N) sup[lane] = lane < n ? (double)wt : 0.0;
+		if (lane < N) sup[lane] = lane < n ? (double)wt : 0.0;
 	}
-	if (lane < VK_WRD_N) pot_s[lane] = 0.0;
+	if (lane < N) pot_s[lane] = 0.0;
 	for (int j = 0; j < n; j++) {
-		float d = has ? 1.0f - Sm[lane * 16 + j] : 0.0f;
+		float d = has ? 1.0f - Sm[lane * N + j] : 0.0f;
 		if (!(d > 0.0f)) d = 0.0f;
 		Cm[j * 64 + lane] = (double)d;
 		fl[j * 64 + lane] = 0.0;
 	}
 	double pot_d = 0.0;
 	wave_lds_fence();
-	// this lane's column of the costs stays in registers; its column of the flows and the supplies' potentials are
+	// REG: this lane's column of the costs stays in registers; its column of the flows and the supplies' potentials are
 	// refreshed from LDS once per augmentation (LDS holds the copies that are indexed dynamically)
-	double Cr[VK_WRD_N], Fr[VK_WRD_N], Ps[VK_WRD_N];
+	double Cr[REG ? N : 1], Fr[REG ? N : 1], Ps[REG ? N : 1];
+	if constexpr (REG) {
 #pragma unroll
-	for (int j = 0; j < VK_WRD_N; j++) Cr[j] = j < n ? Cm[j * 64 + lane] : 0.0;
+		for (int j = 0; j < N; j++) Cr[j] = j < n ? Cm[j * 64 + lane] : 0.0;
+	}
 
 	// ---- start: dual potentials pot_d[i] = min_j C[j][i] (all reduced costs stay >= 0, the nearest supply's arc is
 	// tight) and as much flow on the tight arcs as the supplies allow, demands served in lane order.  Flow on tight
@@ -160,25 +193,32 @@ __global__ __launch_bounds__(64) void vk_wrd_exact_kernel(VkWrdParams p) {
 		wave_lds_fence();
 	}
 
-	for (int iter = 0; iter < 4000; iter++) {
+	for (int iter = 0; iter < 4000 * NQ; iter++) {
 		// ---- sources: every supply with remaining mass; relax them all
 		bool any_sup = false;
 		double dist_d = INF;
 		int pred_d = -1;
-		unsigned smask = 0;   // settled supplies (uniform)
+		uint64_t smask = 0;   // settled supplies (uniform)
+		auto relax_source = [&](int j, double cj, double psj) {
+			const bool src = sup[j] > EPS;
+			any_sup |= src;
+			if (src) smask |= 1ull << j;
+			if (lane == 0) { settled[j] = src ? 1 : 0; dist_s[j] = src ? 0.0 : INF; pred_s[j] = -1; }
+			double rc = cj + psj - pot_d;
+			if (rc < 0) rc = 0;
+			if (src && rc < dist_d) { dist_d = rc; pred_d = j; }
+		};
+		if constexpr (REG) {
 #pragma unroll
-		for (int j = 0; j < VK_WRD_N; j++) {
-			if (j < n) {
-				Fr[j] = fl[j * 64 + lane];
-				Ps[j] = pot_s[j];
-				const bool src = sup[j] > EPS;
-				any_sup |= src;
-				if (src) smask |= 1u << j;
-				if (lane == 0) { settled[j] = src ? 1 : 0; dist_s[j] = src ? 0.0 : INF; pred_s[j] = -1; }
-				double rc = Cr[j] + Ps[j] - pot_d;
-				if (rc < 0) rc = 0;
-				if (src && rc < dist_d) { dist_d = rc; pred_d = j; }
+			for (int j = 0; j < N; j++) {
+				if (j < n) {
+					Fr[j] = fl[j * 64 + lane];
+					Ps[j] = pot_s[j];
+					relax_source(j, Cr[j], Ps[j]);
+				}
 			}
+		} else {
+			for (int j = 0; j < n; j++) relax_source(j, Cm[j * 64 + lane], pot_s[j]);
 		}
 		if (!has) dist_d = INF;
 		const bool any_dem = __ballot(has && dem > EPS) != 0;
@@ -192,16 +232,21 @@ __global__ __launch_bounds__(64) void vk_wrd_exact_kernel(VkWrdParams p) {
 			const double fd = wave_argmin_f64((has && dem > EPS) ? dist_d : INF, lane, fd_lane);
 			double best = INF;
 			int bb = -1;
+			auto candidate = [&](int b, double cb_, double fb, double psb) {
+				double rc = pot_d - psb - cb_;
+				if (rc < 0) rc = 0;
+				const double cand = dist_d + rc;
+				const bool ok = !((smask >> b) & 1) && fb > EPS && cand < best;   // dist_d = inf gives cand = inf: never < best
+				best = ok ? cand : best;
+				bb = ok ? b : bb;
+			};
+			if constexpr (REG) {
 #pragma unroll
-			for (int b = 0; b < VK_WRD_N; b++) {
-				if (b < n) {
-					double rc = pot_d - Ps[b] - Cr[b];
-					if (rc < 0) rc = 0;
-					const double cand = dist_d + rc;
-					const bool ok = !((smask >> b) & 1) && Fr[b] > EPS && cand < best;   // dist_d = inf gives cand = inf: never < best
-					best = ok ? cand : best;
-					bb = ok ? b : bb;
+				for (int b = 0; b < N; b++) {
+					if (b < n) candidate(b, Cr[b], Fr[b], Ps[b]);
 				}
+			} else {
+				for (int b = 0; b < n; b++) candidate(b, Cm[b * 64 + lane], fl[b * 64 + lane], pot_s[b]);
 			}
 			const double cmin = wave_argmin_f64(best, lane, c_lane);
 			if (fd <= cmin) {
@@ -209,7 +254,7 @@ __global__ __launch_bounds__(64) void vk_wrd_exact_kernel(VkWrdParams p) {
 				break;
 			}
 			const int cb = __builtin_amdgcn_readlane(bb, c_lane);
-			smask |= 1u << cb;
+			smask |= 1ull << cb;
 			if (lane == 0) { settled[cb] = 1; dist_s[cb] = cmin; pred_s[cb] = c_lane; }
 			wave_lds_fence();
 			double rc = Cm[cb * 64 + lane] + pot_s[cb] - pot_d;
@@ -264,53 +309,55 @@ __global__ __launch_bounds__(64) void vk_wrd_exact_kernel(VkWrdParams p) {
 		const float raw = den > 0.0 ? (float)(num / den) : 0.0f;
 		const float boost = p.boost ? p.boost[g] : 1.0f;
 		p.raw_out[w] = raw;
-		p.val_out[w] = (raw / (float)n) * boost;
+		p.val_out[w] = (raw / p.ref_total) * boost;
 	}
 	if (p.plan_out)
-		for (int j = 0; j < VK_WRD_N; j++)
-			p.plan_out[((int64_t)w * VK_WRD_N + j) * 64 + lane] = (has && j < n) ? (float)fl[j * 64 + lane] : 0.0f;
+		for (int j = 0; j < N; j++)
+			p.plan_out[((int64_t)w * N + j) * 64 + lane] = (has && j < n) ? (float)fl[j * 64 + lane] : 0.0f;
 }
 
-// similarity rows of the winners of a transport query, for the host to state their flows
+// similarity rows of the winners of a transport query, for the host to state their flows: [64][16 nq] per winner
+template <int NQ>
 __global__ __launch_bounds__(64) void vk_rows_kernel(VkWrdParams p) {
+	constexpr int N = 16 * NQ;
+	extern __shared__ double vk_smem_f64[];
+	float *S = reinterpret_cast<float *>(vk_smem_f64);   // [(VK_DEV_MAX_SENT_LEN + 32)][N]
 	const int lane = threadIdx.x;
 	const int w = blockIdx.x;
-	float *out = p.rows_out + (int64_t)w * 64 * 16;
-	for (int i = lane; i < 64 * 16; i += 64) out[i] = 0.0f;
+	float *out = p.rows_out + (int64_t)w * 64 * N;
 	const uint64_t key = p.keys[w];
-	if (key == 0) return;
-	const int64_t g = (int64_t)(uint32_t)(key & 0xffffffffu);
-	const int t_a = p.sent_start[g], t_b = p.sent_end[g];
-	const int m = t_b - t_a;
-	if (m < 1 || m > 64) return;
-	__builtin_amdgcn_s_waitcnt(0);
-	if (p.layout == VK_DEV_LAYOUT_STATIC) {
-		for (int it = 0; it * 16 < m; it++) {
-			const int tk = it * 16 + (lane >> 2);
-			if (tk < m) {
-				const int id = p.tok_id[t_a + tk];
-				*reinterpret_cast<float4 *>(out + tk * 16 + (lane & 3) * 4) =
-					*reinterpret_cast<const float4 *>(p.table + (int64_t)id * 16 + (lane & 3) * 4);
-			}
-		}
-	} else {
-		const int tile0 = t_a >> 4;
-		const int ntiles = ((t_b + 15) >> 4) - tile0;
-		for (int ti = 0; ti < ntiles; ti++) {
-			const f32x4 acc = sim_tile_generic(p.qtile, p.tiles + (int64_t)(tile0 + ti) * p.tile_bytes, p.nk32, p.tail, lane, p.prec);
-			const int row = (tile0 + ti) * 16 + (lane & 15) - t_a;      // token of this lane relative to the slice
-			if (row >= 0 && row < m) *reinterpret_cast<f32x4 *>(out + row * 16 + (lane >> 4) * 4) = acc;
-		}
+	int m = 0, rowbase = 0;
+	if (key != 0) {
+		const int64_t g = (int64_t)(uint32_t)(key & 0xffffffffu);
+		const int t_a = p.sent_start[g], t_b = p.sent_end[g];
+		m = t_b - t_a;
+		if (m < 1 || m > 64) m = 0;
+		else rowbase = transport_sim_rows<NQ>(p, S, t_a, t_b, lane);
 	}
+	wave_lds_fence();
+	for (int i = lane; i < 64 * N; i += 64) out[i] = i / N < m ? S[rowbase * N + i] : 0.0f;
+}
+
+static size_t transport_lds_bytes(int nq, bool solver) {
+	const size_t n = 16 * (size_t)nq;
+	return (solver ? n * 64 * 8 * 2 + n * 8 * 3 + n * 4 * 2 : 0) + (size_t)(VK_DEV_MAX_SENT_LEN + 32) * n * 4;
 }
 
 extern "C" hipError_t vk_launch_wrd_exact(const VkWrdParams *p, int32_t n_cand, float *scores_to_mark, hipStream_t stream) {
-	vk_wrd_exact_kernel<<<n_cand, 64, 0, stream>>>(*p);
+	const size_t smem = transport_lds_bytes(p->nq, true);
+	void (*kernel)(VkWrdParams) = p->nq <= 1 ? vk_wrd_exact_kernel<1> : p->nq == 2 ? vk_wrd_exact_kernel<2> : p->nq == 3 ? vk_wrd_exact_kernel<3> : vk_wrd_exact_kernel<4>;
+	if (smem > 64 * 1024) {
+		const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+		if (e != hipSuccess) return e;
+	}
+	kernel<<<n_cand, 64, smem, stream>>>(*p);
 	if (scores_to_mark) return vk_launch_mark(p->keys, n_cand, scores_to_mark, stream);   // vk_select.hip
 	return hipGetLastError();
 }
 
 extern "C" hipError_t vk_launch_rows(const VkWrdParams *p, int32_t n_cand, hipStream_t stream) {
-	vk_rows_kernel<<<n_cand, 64, 0, stream>>>(*p);
+	const size_t smem = transport_lds_bytes(p->nq, false);
+	void (*kernel)(VkWrdParams) = p->nq <= 1 ? vk_rows_kernel<1> : p->nq == 2 ? vk_rows_kernel<2> : p->nq == 3 ? vk_rows_kernel<3> : vk_rows_kernel<4>;
+	kernel<<<n_cand, 64, smem, stream>>>(*p);
 	return hipGetLastError();
 }

@@ -654,9 +654,7 @@ class HipBruteForceIndex(Index):
 			gaps = (lambda k: 0.0, lambda k: 0.0)
 		else:
 			raise RuntimeError(f"unknown alignment algorithm {algorithm}")   # metric/alignment.h:914-919
-		if metric["metric"] == "alignment-tag-weighted":
-			if algorithm != "pyalign":
-				raise NotImplementedError("tag-weighted similarity is implemented for alignments only")
+		if metric["metric"] == "alignment-tag-weighted":   # any matcher: TagWeightedSlice wraps the slice (match/instantiate.cpp:173-189)
 			args["tag_weighted"] = dict(
 				tag_weights=metric["tag_weights"],
 				pos_mismatch_penalty=float(metric.get("pos_mismatch_penalty", 0)),
@@ -711,6 +709,15 @@ class HipBruteForceIndex(Index):
 		masks = self._filter_masks(query.options)
 		if corpus is None:
 			corpus = self._filtered_corpus(masks) if masks else self._corpus
+		q_tag_codes = None
+		if tw is not None and self._has_tags:
+			# tag-weighted transport: the vocabulary of the bags of words is keyed by (token id, tag) (TaggedTokenFactory,
+			# vectorian/core/cpp/alignment/bow.h:150-176).  The device works on positions, which is the same problem as long as
+			# equal (id, tag) pairs have equal similarity rows, i.e. the universal POS is a function of the fine-grained tag (as
+			# in spaCy's tag map); the host states the flows of the winners over that vocabulary.
+			q_tag_codes = np.array([self.session.tag_code(t) if t is not None else 0 for t in p_query.tags], dtype=np.int8)
+			if getattr(corpus, "takes_q_tags", False):
+				args["q_tags"] = q_tag_codes
 		if emb.is_static:
 			top = corpus.query(qv.unmodified, q_normalize=True, q_token_ids=p_query.token_ids,
 				boost=self._dev_boost, want_flow=True, **args)
@@ -723,7 +730,7 @@ class HipBruteForceIndex(Index):
 			top = shards.allgather_merge(top, self._slice_off, args["max_matches"], group=self._group)
 		if progress:
 			progress(1.0)
-		return self._matches_from_topk(p_query, top, gaps, args, np.asarray(qv.magnitudes, dtype=np.float32), masks)
+		return self._matches_from_topk(p_query, top, gaps, args, np.asarray(qv.magnitudes, dtype=np.float32), masks, q_tag_codes)
 
 	def _filter_masks(self, options):
 		"""pos_filter / tag_filter: lists of POS / tag names whose tokens are dropped from every slice for this query
@@ -760,13 +767,13 @@ class HipBruteForceIndex(Index):
 				drop |= (cd >= 0) & (cd < 64) & bits[np.clip(cd, 0, 63)]
 		return np.nonzero(~drop)[0]
 
-	def _transport_flow(self, p_query, top, i, g, args, qmag, index_map=None):
+	def _transport_flow(self, p_query, top, i, g, args, qmag, index_map=None, q_tag_codes=None):
 		"""flow of winner i of a transport query, stated from the similarity rows / plan the backend returned"""
 		if getattr(top, "sim_rows", None) is None:
 			return None
 		a, b = int(self._slice_start[g]), int(self._slice_end[g])
 		len_s, len_t = (b - a if index_map is None else len(index_map)), len(p_query)
-		if len_s > core.VK_FAST_SENT_LEN or len_t > core.VK_FAST_QUERY_LEN:
+		if len_s > core.VK_FAST_SENT_LEN:
 			return None
 		S = top.sim_rows[i][:len_s, :len_t].copy()
 		G = top.plan[i][:len_t, :len_s].copy()
@@ -774,6 +781,11 @@ class HipBruteForceIndex(Index):
 		if ids_s is not None and index_map is not None:
 			ids_s = ids_s[index_map]
 		ids_t = p_query.token_ids if self._token_ids is not None else None
+		if ids_s is not None and q_tag_codes is not None and self._tag_codes is not None:
+			# tag-weighted: vocabulary entries are (token id, tag) pairs
+			tags_s = self._tag_codes[a:b] if index_map is None else self._tag_codes[a:b][index_map]
+			ids_s = np.asarray(ids_s, dtype=np.int64) * 256 + (np.asarray(tags_s, dtype=np.int64) & 255)
+			ids_t = np.asarray(ids_t, dtype=np.int64) * 256 + (np.asarray(q_tag_codes, dtype=np.int64) & 255)
 		if args["algorithm"] == core.VK_ALG_WRD:
 			mass = qmag / qmag.sum() if args.get("wrd_normalize", True) else qmag
 			return lambda: dense_flow(S, G, None, None, mass)   # WRD works on positions (wrd.h:91-109)
@@ -783,7 +795,7 @@ class HipBruteForceIndex(Index):
 			return lambda: dense_flow(S, G, ids_s, ids_t, np.full(len_t, unit, dtype=np.float32))
 		return lambda: rwmd_sparse_flow(S, ids_s, ids_t, injective, symmetric, nbow)
 
-	def _matches_from_topk(self, p_query, top, gaps, args=None, qmag=None, masks=None):
+	def _matches_from_topk(self, p_query, top, gaps, args=None, qmag=None, masks=None, q_tag_codes=None):
 		matches = []
 		transport = args is not None and args.get("algorithm", core.VK_ALG_ALIGN) != core.VK_ALG_ALIGN
 		for i in range(top.n):
@@ -794,7 +806,7 @@ class HipBruteForceIndex(Index):
 				self, p_query, di, self._slice_id[g], self._slice_token_at[g],
 				int(self._slice_end[g] - self._slice_start[g]),
 				top.score[i], top.raw_score[i], top.mapping[i].copy(), top.edge_sim[i].copy(), gaps,
-				transport_flow=self._transport_flow(p_query, top, i, g, args, qmag, index_map) if transport else None,
+				transport_flow=self._transport_flow(p_query, top, i, g, args, qmag, index_map, q_tag_codes) if transport else None,
 				index_map=index_map))
 		return matches
 
