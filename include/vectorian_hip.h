@@ -47,7 +47,9 @@ typedef enum {
 	VK_ERR_UNSUPPORTED = 2,  /* option the HIP path does not implement: explicit, never a fallback */
 	VK_ERR_HIP = 3,          /* HIP runtime error */
 	VK_ERR_NO_DEVICE = 4,
-	VK_ERR_STATE = 5         /* call order violated (e.g. query before finalize) */
+	VK_ERR_STATE = 5,        /* call order violated (e.g. query before finalize) */
+	VK_ERR_ABORTED = 6       /* the caller raised the query's abort flag (Query::abort, query.h:183-189): nothing, or only the
+	                            queries of a batch before the poll, was computed */
 } vk_status;
 
 /* pyalign::enums::Locality (metric/alignment.h:363-364; vectorian/alignment.py:97,130,187) */
@@ -129,6 +131,10 @@ typedef struct {
 	 * exact EMD between the two bags of words (FullSolver, alignment/wmd.h:194-270); needs
 	 * rwmd_injective = rwmd_symmetric = 0 as upstream (wmd.h:201-209) */
 	int32_t wmd_full;
+	/* Query::abort (module.cpp:120, query.h:183-189; polled per slice at match/matcher_impl.h:105): optional host flag the caller
+	 * may raise from another thread.  Polled when vk_query starts and between the queries / launches of vk_query_batch (a query
+	 * is a few milliseconds of device time and is not interrupted); a raised flag ends the call with VK_ERR_ABORTED. */
+	const volatile int32_t *abort;
 } vk_query_desc;
 
 /* Bounded result set, best first.  Order: score descending, then sentence index
@@ -146,6 +152,8 @@ typedef struct {
 	                            reports distance = 1 - this); NULL if !want_flow */
 	/* transport algorithms (VK_ALG_RWMD, VK_ALG_WRD) with want_flow: what the host needs to state the flow of a
 	 * winner as SparseFlow / DenseFlow (match/match.h:140-260; alignment/wmd.h:392-408, 228-248; wrd.h:120-135).
+	 * Alignments fill sim_rows too when the array is given: the 'similarity' matrix of the debug hook
+	 * (call_debug_hook, metric/alignment.h:145-173), for the winners.
 	 * Optional (NULL: not produced); filled for corpora whose slices have at most VK_FAST_SENT_LEN tokens.
 	 * W = the query length rounded up to a multiple of 16 (16 for queries of at most VK_FAST_QUERY_LEN tokens). */
 	float *sim_rows;         /* [capacity x VK_FAST_SENT_LEN x W] similarity S[i][j] of slice token i and query token j

@@ -96,7 +96,9 @@ class OracleCorpus:
 	def query(self, q_vectors, *, locality=0, gap_s=0.0, gap_t=0.0, algorithm=0, q_token_ids=None, q_normalize=True,
 			max_matches=10, min_score=0.0, boost=None, want_flow=True, submatch_weight=0.0, bidirectional=False,
 			rwmd=(True, True, True), wrd_normalize=True, tag_weights=None, q_pos=None, pos_mismatch_penalty=0.0,
-			similarity_threshold=0.0, wmd_full=False, q_tags=None):
+			similarity_threshold=0.0, wmd_full=False, q_tags=None, abort_flag=None, want_rows=False):
+		if abort_flag is not None and abort_flag[0]:
+			raise core.VkError(core.VK_ERR_ABORTED, "query aborted by the caller")
 		q = np.ascontiguousarray(q_vectors)
 		if q.dtype == np.uint16:
 			q = synth.bf16_bits_to_f32(q)
@@ -120,7 +122,7 @@ class OracleCorpus:
 			kw.update(X=self._X, X_mag=self._mag, Q_mag=qmag)
 		r = vo.find(**kw)
 		self._all = r["all_scores"]
-		transport = algorithm != core.VK_ALG_ALIGN and want_flow
+		transport = (algorithm != core.VK_ALG_ALIGN or want_rows) and want_flow
 		top = core.TopK(max_matches, len(q), transport=transport)
 		n = len(r["score"])
 		top.n = n
@@ -153,7 +155,7 @@ class OracleCorpus:
 			if transport and b - a <= core.VK_FAST_SENT_LEN:
 				# what the HIP backend returns for the host to state transport flows: rows, and the plan of exact transports
 				top.sim_rows[i, :b - a, :len(q)] = S
-				exact = algorithm == core.VK_ALG_WRD or wmd_full
+				exact = algorithm == core.VK_ALG_WRD or (algorithm == core.VK_ALG_RWMD and wmd_full)
 				if exact:
 					if algorithm == core.VK_ALG_WRD:
 						ms = self._mag[self._ids[a:b]] if self.layout == core.VK_LAYOUT_STATIC else self._mag[a:b]

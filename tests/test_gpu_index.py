@@ -160,3 +160,34 @@ def test_tag_weighted_transport_and_long_queries_on_hip_equal_oracle_double(hip)
 				assert_json_close({k: np.asarray(v).tolist() for k, v in fx.items() if k != "type"},
 					{k: np.asarray(v).tolist() for k, v in fy.items() if k != "type"}, 2e-5)
 		gpu.close()
+
+
+def test_debug_hook_and_abort_on_hip(hip):
+	"""the debug hook on the real backend (similarity rows of the winners from vk_rows_kernel) and Query.abort / find_many(abort=)
+	through vk_query_desc.abort"""
+	session, emb, words, rng = toy_session()
+	sim = OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), alignment.LocalAlignment(gap=alignment.smooth_gap_cost(5)))
+	gpu = session.partition("sentence").index(sim)
+	cpu = session.partition("sentence").index(sim, corpus_factory=OracleCorpus)
+	doc = session.documents[7]
+	text = " ".join(doc.tokens[40:46])
+	got, want = [], []
+	a = gpu.find(text, n=5, debug=lambda name, data: got.append((name, data)))
+	b = cpu.find(text, n=5, debug=lambda name, data: want.append((name, data)))
+	assert len(got) == len(want) == 5 and [m.slice_id for m in a] == [m.slice_id for m in b]
+	for (n1, d1), (n2, d2) in zip(got, want):
+		assert n1 == n2 == "alignment" and d1["slice"] == d2["slice"] and abs(d1["score"] - d2["score"]) < 1e-4
+		np.testing.assert_allclose(d1["similarity"], d2["similarity"], atol=2e-6)
+		assert (d1["flow"]["target"] == d2["flow"]["target"]).all()
+	q = gpu.make_query(text, n=5)
+	q.abort()
+	assert gpu._find(q) == [] and len(gpu.find(text, n=5)) == 5
+	flag = np.zeros(1, dtype=np.int32)
+	texts = [" ".join(session.documents[i % 20].tokens[5 * i:5 * i + 4]) for i in range(12)]
+	assert all(len(r) > 0 for r in gpu.find_many(texts, n=3, abort=flag))
+	flag[0] = 1
+	assert all(len(r) == 0 for r in gpu.find_many(texts, n=3, abort=flag))
+	with pytest.raises(hip.VkError) as e:   # the C-ABI: VK_ERR_ABORTED from vk_query and vk_query_batch
+		gpu.corpus.query(np.ones((3, emb.dimension), np.float32), q_token_ids=np.zeros(3, np.int32), abort_flag=flag)
+	assert e.value.status == hip.VK_ERR_ABORTED
+	gpu.close()

@@ -376,3 +376,38 @@ def test_span_embedding_index():
 	qv = enc([" ".join(target)])[0]
 	cos = (allv @ qv) / (np.linalg.norm(allv, axis=1) * np.linalg.norm(qv))
 	assert [int(np.argsort(-cos)[i]) for i in range(3)] == [12 * docs.index(m.prepared_doc) + m.slice_id for m in r]
+
+
+def test_debug_hook_and_abort():
+	"""options['debug'] (Index.find(debug=...), vectorian/index.py:468-469; call_debug_hook, metric/alignment.h:145-173): the hook
+	is called with the reference's keys for the winners; Query.abort (module.cpp:120) ends a search before its device work"""
+	session, emb, words, rng = toy_session()
+	doc = session.documents[2]
+	text = " ".join(doc.tokens[30:35])
+	calls = []
+	hook = lambda name, data: calls.append((name, data))
+	sim = OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), alignment.LocalAlignment(gap=alignment.LinearGapCost(0.2)))
+	index = session.partition("sentence").index(sim, corpus_factory=OracleCorpus)
+	r = index.find(text, n=4, debug=hook)
+	assert [c[0] for c in calls] == ["alignment"] * 4
+	for m, (_, data) in zip(r, calls):
+		assert set(data) == {"slice", "similarity", "flow", "score"}
+		assert data["slice"] == m.slice_id and abs(data["score"] - m.raw_score) < 1e-6
+		S = data["similarity"]
+		assert S.shape == (m._len_s, 5) and (data["flow"]["target"] == m.flow["target"]).all()
+		for j, i in enumerate(m.flow["target"]):
+			if i >= 0:
+				assert abs((1.0 - S[i, j]) - m.flow["dist"][j]) < 1e-6
+	with pytest.raises(TypeError):
+		index.find(text, n=4, debug="not callable")
+	calls.clear()
+	wmd = session.partition("sentence").index(OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), alignment.WordMoversDistance.rwmd("nbow")),
+		corpus_factory=OracleCorpus)
+	r = wmd.find(text, n=3, debug=hook)
+	assert [c[0] for c in calls] == ["alignment/word-movers-distance/make"] * 3
+	assert abs(calls[0][1]["score"] - r[0].score) < 1e-7 and abs(calls[0][1]["worst_score"] - r[-1].score) < 1e-7
+	# abort: raised before the search starts -> no matches; a fresh query is unaffected
+	q = index.make_query(text, n=4)
+	q.abort()
+	assert q.aborted and index._find(q) == []
+	assert len(index.find(text, n=4)) == 4

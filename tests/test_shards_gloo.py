@@ -74,9 +74,12 @@ def test_sharded_index(tmp_path):
 		os.path.join(ROOT, "tests", "shard_index_worker.py"), str(tmp_path)]
 	r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
 	assert r.returncode == 0, r.stderr[-3000:]
-	index, queries = shard_index_worker.build(None)
-	ref = shard_index_worker.answers(index, queries)
-	assert ref[0][0][:2] == [1, 3] and abs(ref[0][0][2] - 1.0) < 1e-2
+	ref = {}
+	for strategy in ("align", "wrd", "rwmd"):   # the transport strategies: the flows of the merged winners are stated on every rank
+		index, queries = shard_index_worker.build(None, strategy)
+		ref[strategy] = shard_index_worker.answers(index, queries)
+	assert ref["align"][0][0][:2] == [1, 3] and abs(ref["align"][0][0][2] - 1.0) < 1e-2
+	assert ref["wrd"][0][0][3] == "dense" and ref["rwmd"][0][0][3] == "sparse"
 	for k in range(2):
 		got = json.load(open(tmp_path / f"index_rank{k}.json"))
 		assert got == ref

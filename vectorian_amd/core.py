@@ -27,6 +27,7 @@ VK_MEM_HOST, VK_MEM_DEVICE = 0, 1
 VK_LAYOUT_CONTEXTUAL, VK_LAYOUT_STATIC = 0, 1
 VK_ALG_ALIGN, VK_ALG_RWMD, VK_ALG_WRD = 0, 1, 2
 VK_GAP_LINEAR, VK_GAP_AFFINE, VK_GAP_TABLE = 0, 1, 2
+VK_ERR_ABORTED = 6
 
 
 class Locality(enum.IntEnum):
@@ -68,7 +69,8 @@ class _QueryDesc(C.Structure):
 		("rwmd_injective", C.c_int32), ("rwmd_symmetric", C.c_int32), ("rwmd_normalize_bow", C.c_int32),
 		("wrd_normalize_magnitudes", C.c_int32),
 		("tag_weights", C.c_void_p), ("q_pos", C.c_void_p),
-		("pos_mismatch_penalty", C.c_float), ("similarity_threshold", C.c_float), ("wmd_full", C.c_int32)]
+		("pos_mismatch_penalty", C.c_float), ("similarity_threshold", C.c_float), ("wmd_full", C.c_int32),
+		("abort", C.c_void_p)]
 
 
 class _TopkOut(C.Structure):
@@ -323,7 +325,10 @@ class Corpus:
 	def _desc(self, q_vectors, keep, *, locality=Locality.LOCAL, gap_s=0.0, gap_t=0.0, algorithm=VK_ALG_ALIGN,
 			q_token_ids=None, q_normalize=True, max_matches=10, min_score=0.0, boost=None, want_flow=True,
 			submatch_weight=0.0, bidirectional=False, rwmd=(True, True, True), wrd_normalize=True,
-			tag_weights=None, q_pos=None, pos_mismatch_penalty=0.0, similarity_threshold=0.0, wmd_full=False):
+			tag_weights=None, q_pos=None, pos_mismatch_penalty=0.0, similarity_threshold=0.0, wmd_full=False,
+			abort_flag=None, want_rows=False):
+		"""abort_flag: int32 array of one element another thread may set to 1 (Query.abort); want_rows: similarity rows of the
+		winners of an alignment query too (the debug hook's 'similarity')"""
 		q_vectors = np.ascontiguousarray(q_vectors)
 		if q_vectors.dtype == np.uint16:
 			qdt = VK_BF16
@@ -357,6 +362,11 @@ class Corpus:
 		q.rwmd_injective, q.rwmd_symmetric, q.rwmd_normalize_bow = [int(bool(x)) for x in rwmd]
 		q.wrd_normalize_magnitudes = int(bool(wrd_normalize))
 		q.wmd_full = int(bool(wmd_full))
+		if abort_flag is not None:
+			if not (isinstance(abort_flag, np.ndarray) and abort_flag.dtype == np.int32 and abort_flag.size >= 1):
+				raise TypeError("abort_flag must be an int32 array")
+			keep.append(abort_flag)
+			q.abort = _np_ptr(abort_flag)
 		if tag_weights is not None:
 			tw = np.ascontiguousarray(tag_weights, dtype=np.float32)
 			qp = np.ascontiguousarray(q_pos if q_pos is not None else np.zeros(len_t), dtype=np.int8)
@@ -371,7 +381,7 @@ class Corpus:
 		"""One query against the shard (vk_query).  Returns a TopK."""
 		keep = []
 		q, len_t = self._desc(q_vectors, keep, **options)
-		out = TopK(max(1, q.max_matches), len_t, transport=bool(q.want_flow) and q.algorithm != VK_ALG_ALIGN)
+		out = TopK(max(1, q.max_matches), len_t, transport=bool(q.want_flow) and (q.algorithm != VK_ALG_ALIGN or bool(options.get("want_rows"))))
 		so = out._struct()
 		_check(lib().vk_query(self._h, C.byref(q), C.byref(so)))
 		out.n = so.n_out

@@ -131,6 +131,11 @@ static int query_batch_shared_pass(vk_corpus_t *c, const vk_query_desc *qs, int3
 	float mags[VK_MAX_QUERY_LEN];
 	for (int base = 0; base < n_queries; base += qb_max) {
 		const int qb = std::min(qb_max, n_queries - base);
+		// Query::abort (query.h:183-189): polled between the passes; the queries before `base` are complete
+		if (qs[base].abort && *qs[base].abort) {
+			for (int i = base; i < n_queries; i++) outs[i].n_out = 0;
+			return fail(VK_ERR_ABORTED, "batch aborted by the caller");
+		}
 		VK_HIP(hipEventRecord(c->ev[0], st));
 		std::fill(all.begin(), all.end(), 0);
 		for (int i = 0; i < qb; i++) {
@@ -224,6 +229,10 @@ extern "C" {
 int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, vk_topk_out *outs) {
 	if (!c || !qs || !outs || n_queries < 0) return fail(VK_ERR_INVALID, "null argument");
 	if (n_queries == 0) return VK_OK;
+	if (qs[0].abort && *qs[0].abort) {
+		for (int i = 0; i < n_queries; i++) outs[i].n_out = 0;
+		return fail(VK_ERR_ABORTED, "batch aborted by the caller");
+	}
 	// the GEMM path: injective RWMD, contextual layout, one sentence length (multiple of 16), common options
 	bool gemm = c->finalized && c->prec == 0 && c->contiguous && c->desc.layout == VK_LAYOUT_CONTEXTUAL && c->uniform_len > 0 && c->uniform_len % 16 == 0 &&
 		c->uniform_len <= 64 && c->desc.n_sentences > 0 && qs[0].max_matches <= 64 &&
@@ -238,8 +247,11 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 		const int rcb = query_batch_shared_pass(c, qs, n_queries, outs);
 		if (rcb != VK_ERR_UNSUPPORTED) return rcb;
 		for (int i = 0; i < n_queries; i++) {
-			const int rc = vk_query(c, &qs[i], &outs[i]);
-			if (rc) return rc;
+			const int rc = vk_query(c, &qs[i], &outs[i]);   // polls the query's abort flag
+			if (rc) {
+				for (int r = i; r < n_queries; r++) outs[r].n_out = 0;
+				return rc;
+			}
 		}
 		return VK_OK;
 	}

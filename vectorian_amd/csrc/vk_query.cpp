@@ -109,6 +109,7 @@ extern "C" {
 int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	int rc = vk_validate_query(c, q, out);
 	if (rc) return rc;
+	if (q->abort && *q->abort) { out->n_out = 0; return fail(VK_ERR_ABORTED, "query aborted by the caller"); }
 	VK_HIP(hipSetDevice(c->device));
 	hipStream_t st = c->stream;
 	const int64_t n = c->n_entries;           // rows of the slice table (== n_sentences unless long slices were padded)
@@ -621,6 +622,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	// ---- bounded result set -------------------------------------------------
 	VK_HIP(hipEventRecord(c->ev[2], st));
 	c->ev2_recorded = true;
+	const bool rows_on_request = out->sim_rows != nullptr;   // alignments: similarity rows of the winners only on request (debug hook)
 	int cur = 0;
 	if (k <= 64) {
 		// wave-streaming selection: n -> ceil(n/4096) * k keys -> ... -> k keys
@@ -698,7 +700,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	}
 	out->n_out = n_out;
 	c->have_scores = true;
-	if (q->algorithm == VK_ALG_RWMD && n_out > 0) {
+	if ((q->algorithm == VK_ALG_RWMD || (is_align && rows_on_request)) && n_out > 0) {
 		std::vector<int64_t> rows_idx;
 		for (int i = 0; i < n_out; i++) rows_idx.push_back((int64_t)(uint32_t)(keys[(size_t)i] & 0xffffffffu));
 		float no_mass[VK_MAX_QUERY_LEN] = {0};

@@ -34,6 +34,16 @@ class Query:
 		self._vocab = vocab
 		self._text = text
 		self._options = options
+		self._abort = np.zeros(1, dtype=np.int32)   # the flag the native side polls (vk_query_desc.abort)
+
+	def abort(self):
+		"""core.Query.abort (vectorian/core/cpp/module.cpp:120, query.h:183-189): may be called from another thread; a search that
+		has not started its device work yet (or the rest of a batch) is dropped and returns no matches"""
+		self._abort[0] = 1
+
+	@property
+	def aborted(self):
+		return bool(self._abort[0])
 
 	@property
 	def index(self):
@@ -608,6 +618,7 @@ class HipBruteForceIndex(Index):
 		else:
 			self._corpus.set_slices(dev_start, dev_end)
 		self._corpus.finalize()
+		self._max_slice_len = int((np.asarray(dev_end) - np.asarray(dev_start)).max()) if len(dev_start) else 0   # of the resident part
 
 	@property
 	def metric_name(self):
@@ -661,7 +672,7 @@ class HipBruteForceIndex(Index):
 				similarity_threshold=float(metric.get("similarity_threshold", 0)))
 		return args, gaps
 
-	def find_many(self, texts, n=10, min_score=0.0, options: dict = dict(), in_flight=3):
+	def find_many(self, texts, n=10, min_score=0.0, options: dict = dict(), in_flight=3, abort=None):
 		"""Several queries, `in_flight` of them at a time on as many handles of the resident corpus (vk_corpus_view:
 		shared arrays, own stream and workspaces) from as many host threads: the selection, traceback and host part of
 		one query run beside the scoring kernel of the next (bench.py measures the path this way).  Returns one Result
@@ -670,9 +681,17 @@ class HipBruteForceIndex(Index):
 		from concurrent.futures import ThreadPoolExecutor
 		session = self.session
 		queries = [self.make_query(t, n=n, min_score=min_score, options=options) for t in texts]
+		if abort is not None:
+			# one flag for the whole call (an int32 array of one element, as Query._abort): raising it from another thread drops
+			# the queries that have not started yet -- they return no matches (Query::abort polled between the queries)
+			if not (isinstance(abort, np.ndarray) and abort.dtype == np.int32 and abort.size >= 1):
+				raise TypeError("abort must be an int32 numpy array")
+			for q in queries:
+				q._abort = abort
 		sequential = self._shard is not None or self._filter_masks(options) is not None or in_flight < 2 or not hasattr(self._corpus, "view")
 		if sequential:
-			return [self.find(t, n=n, min_score=min_score, options=options) for t in texts]
+			start = time.time()
+			return [session.make_result(self, self._find(q), duration=time.time() - start) for q in queries]
 		while len(self._views) < in_flight - 1:
 			self._views.append(self._corpus.view())
 		handles = [self._corpus] + self._views[:in_flight - 1]
@@ -718,19 +737,51 @@ class HipBruteForceIndex(Index):
 			q_tag_codes = np.array([self.session.tag_code(t) if t is not None else 0 for t in p_query.tags], dtype=np.int8)
 			if getattr(corpus, "takes_q_tags", False):
 				args["q_tags"] = q_tag_codes
-		if emb.is_static:
-			top = corpus.query(qv.unmodified, q_normalize=True, q_token_ids=p_query.token_ids,
-				boost=self._dev_boost, want_flow=True, **args)
-		else:
-			top = corpus.query(qv.unmodified, q_normalize=True, boost=self._dev_boost, want_flow=True, **args)
+		hook = query.options.get("debug")
+		if hook is not None and not callable(hook):
+			raise TypeError("debug must be callable: hook(name, data)")   # query.cpp:73-75 casts to a py::object it later calls
+		if hook is not None:
+			args["want_rows"] = True
+		args["abort_flag"] = query._abort
+		try:
+			if emb.is_static:
+				top = corpus.query(qv.unmodified, q_normalize=True, q_token_ids=p_query.token_ids,
+					boost=self._dev_boost, want_flow=True, **args)
+			else:
+				top = corpus.query(qv.unmodified, q_normalize=True, boost=self._dev_boost, want_flow=True, **args)
+		except core.VkError as e:
+			if e.status == core.VK_ERR_ABORTED:   # Query.abort: the matcher loop ends (match/matcher_impl.h:105), nothing was added
+				return []
+			raise
+		args.pop("abort_flag"); args.pop("want_rows", None)
 		if self._shard is not None:
-			# local slice ids -> global, then ResultSet.extend across the ranks; every rank gets the same set
-			# (the rows / plans of transport winners stay on their rank: their flows are not stated in sharded mode)
+			# local slice ids -> global, then ResultSet.extend across the ranks; every rank gets the same set, the similarity
+			# rows / plans of transport winners travelling with their records, so that flows are stated as on one GPU
 			from vectorian_amd import shards
 			top = shards.allgather_merge(top, self._slice_off, args["max_matches"], group=self._group)
 		if progress:
 			progress(1.0)
-		return self._matches_from_topk(p_query, top, gaps, args, np.asarray(qv.magnitudes, dtype=np.float32), masks, q_tag_codes)
+		matches = self._matches_from_topk(p_query, top, gaps, args, np.asarray(qv.magnitudes, dtype=np.float32), masks, q_tag_codes)
+		if hook is not None:
+			self._call_debug_hook(hook, p_query, top, matches, args)
+		return matches
+
+	def _call_debug_hook(self, hook, p_query, top, matches, args):
+		"""the reference calls hook(name, data) for EVERY slice it scores (call_debug_hook, metric/alignment.h:145-173: slice,
+		similarity [len_s x len_t], flow, score = the aligner's score; WMD: 'alignment/word-movers-distance/make' with score and
+		worst_score, :600-607).  Here the scoring kernel keeps no per-slice matrices: the hook is called for the k winners, best
+		first, with the same keys; `similarity` is None for winners of corpora with slices of more than 64 tokens (their rows are
+		not produced)."""
+		alg = args.get("algorithm", core.VK_ALG_ALIGN)
+		worst = float(matches[-1].score) if len(matches) >= args["max_matches"] else float(args["min_score"])
+		for i, m in enumerate(matches):
+			if alg == core.VK_ALG_RWMD:
+				hook("alignment/word-movers-distance/make", {"score": m.score, "worst_score": worst, "slice": m.slice_id, "flow": m.flow})
+				continue
+			sim = None
+			if getattr(top, "sim_rows", None) is not None and m._len_s <= core.VK_FAST_SENT_LEN and self._max_slice_len <= core.VK_FAST_SENT_LEN:
+				sim = top.sim_rows[i][:m._len_s if m._index_map is None else len(m._index_map), :len(p_query)].copy()
+			hook("alignment", {"slice": m.slice_id, "similarity": sim, "flow": m.flow, "score": m.raw_score})
 
 	def _filter_masks(self, options):
 		"""pos_filter / tag_filter: lists of POS / tag names whose tokens are dropped from every slice for this query

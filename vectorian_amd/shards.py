@@ -139,4 +139,25 @@ def allgather_merge(top, sentence_offset, k, group=None, device=None):
 	dist.all_gather_into_tensor(recv, send, group=group)
 	allr = recv.cpu().numpy().reshape(world, k, send.shape[1])
 	sets = [unpack_topk(allr[r], top.len_t) for r in range(world)]
-	return core.merge_topk(sets, top.len_t, k)
+	merged = core.merge_topk(sets, top.len_t, k)
+	if getattr(top, "sim_rows", None) is not None:
+		# transport winners (and the rows the debug hook asked for): their similarity rows [64 x W] and optimal plans [W x 64]
+		# follow in a second all-gather (k x 2 x 64 W floats per rank: 80 KB at k = 10, W = 16), so that the merged winners
+		# carry what the host states their SparseFlow / DenseFlow from (wmd.h:392-408, 228-248; wrd.h:120-135), whichever rank
+		# scored them
+		w = top.sim_rows.shape[2]
+		pay = np.zeros((k, 2, core.VK_FAST_SENT_LEN * w), dtype=np.float32)
+		pay[:top.n, 0] = top.sim_rows[:top.n].reshape(top.n, -1)
+		pay[:top.n, 1] = top.plan[:top.n].reshape(top.n, -1)
+		send2 = torch.from_numpy(pay).to(device)
+		recv2 = torch.empty((world * k,) + pay.shape[1:], dtype=send2.dtype, device=device)
+		dist.all_gather_into_tensor(recv2, send2, group=group)
+		allp = recv2.cpu().numpy().reshape(world, k, 2, -1)
+		where = {int(sets[r].sentence[j]): (r, j) for r in range(world) for j in range(sets[r].n)}
+		merged.sim_rows = np.zeros((k, core.VK_FAST_SENT_LEN, w), dtype=np.float32)
+		merged.plan = np.zeros((k, w, core.VK_FAST_SENT_LEN), dtype=np.float32)
+		for i in range(merged.n):
+			r, j = where[int(merged.sentence[i])]
+			merged.sim_rows[i] = allp[r, j, 0].reshape(core.VK_FAST_SENT_LEN, w)
+			merged.plan[i] = allp[r, j, 1].reshape(w, core.VK_FAST_SENT_LEN)
+	return merged
