@@ -99,11 +99,8 @@ def test_shared_pass_alignment_batch(hip, oracle, d, lo, hi):
 		outs = c.query_batch(qs, algorithm=hip.VK_ALG_RWMD, rwmd=flags, q_normalize=False, max_matches=9)
 		for Qb, got in zip(qs, outs):
 			single = c.query(Qb, algorithm=hip.VK_ALG_RWMD, rwmd=flags, q_normalize=False, max_matches=9)
-			if d == 300:   # uniform 32-token sentences: the GEMM kernel, other summation order
-				np.testing.assert_allclose(got.score[:got.n], single.score[:single.n], atol=2e-6)
-			else:
-				np.testing.assert_array_equal(got.score[:got.n], single.score[:single.n])
-				assert (got.sentence[:got.n] == single.sentence[:single.n]).all()
+			# the GEMM kernels (uniform 32-token sentences; since round 2 ragged corpora and 768-d rows too): other summation order
+			np.testing.assert_allclose(got.score[:got.n], single.score[:single.n], atol=2e-6)
 	c.close()
 
 
@@ -141,4 +138,42 @@ def test_batch_with_long_queries(hip, oracle):
 			single = c.query(Qb, q_normalize=False, **kw)
 			np.testing.assert_array_equal(got.score[:got.n], single.score[:single.n])
 			np.testing.assert_array_equal(got.mapping[:got.n], single.mapping[:single.n])
+	c.close()
+
+
+@pytest.mark.parametrize("d,lo,hi,len_t,n_q,flags", [
+	(300, 1, 64, 10, 19, (True, True, True)),       # every bucket (16 / 32 / 48 / 64 padded tokens), lengths of all residues
+	(300, 8, 64, 7, 12, (True, False, False)),
+	(128, 3, 40, 16, 9, (True, True, True)),
+	(768, 8, 64, 10, 11, (True, True, True)),       # config 5's rows: 24 K-steps, one wave per SIMD
+	(768, 32, 32, 10, 6, (True, False, True)),      # uniform 32-token sentences at 768-d: the 16-row kernel on the resident tiles
+	(768, 48, 48, 12, 5, (True, True, True)),
+])
+def test_rwmd_gemm_batch_ragged_and_768(hip, oracle, d, lo, hi, len_t, n_q, flags):
+	"""the GEMM-shaped RWMD over corpora the round-1 kernels refused: ragged sentence lengths (padded length buckets of a copy
+	of the corpus, scores back at the original sentence indices, empty slices left out) and 768-d rows (wmd.h:287-416 has no
+	shape restriction)"""
+	n = 700
+	corpus = synth.make_contextual_corpus(n, lo, hi, 2000, d)
+	off = corpus["sent_off"].copy()
+	if lo < hi:                       # a few empty slices too: sliding windows over them would be skipped upstream (document.h:160)
+		start, end = off[:-1].copy(), off[1:].copy()
+		end[[5, 77, n - 1]] = start[[5, 77, n - 1]]
+	else:
+		start, end = off[:-1], off[1:]
+	Xb = prep_contextual(corpus)
+	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=d, n_tokens=Xb.shape[0], n_sentences=n)
+	c.append_vectors(Xb, normalize=False)
+	c.set_slices(start, end)
+	c.finalize()
+	qs = [prep_query(q) for q in synth.make_queries(corpus, n_q, len_t)]
+	qs[1] = qs[1][:max(1, len_t - 3)]
+	qs[-1] = qs[-1][:1]
+	boost = np.random.default_rng(2).uniform(0.5, 1.5, size=n).astype(np.float32) if d == 300 else None
+	for rep in range(2):              # the second call runs on the layout the first one built
+		outs = c.query_batch(qs, algorithm=hip.VK_ALG_RWMD, rwmd=flags, q_normalize=False, max_matches=9, min_score=0.0, boost=boost)
+		for Qb, got in zip(qs, outs):
+			ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=start, sent_end=end, X=Xb, Q=Qb,
+				algorithm=oracle.ALG_RWMD, rwmd=flags, max_matches=9, min_score=0.0, boost=boost)
+			assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=2e-5, tie_tol=2e-5)
 	c.close()

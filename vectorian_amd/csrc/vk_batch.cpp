@@ -224,6 +224,45 @@ static int query_batch_shared_pass(vk_corpus_t *c, const vk_query_desc *qs, int3
 	return VK_OK;
 }
 
+// The padded copy of a ragged corpus the batched GEMM runs on: sentences sorted into buckets by their length rounded up to
+// 16, 32, 48 or 64 tokens, every sentence padded with zero rows to its bucket's length (tile aligned: a wave's token tiles
+// then belong to whole sentences, as in a corpus of one sentence length), with the real length and the original index of
+// each.  Built once per handle, on the device from the resident tiles.
+static int build_batch_layout(vk_corpus *c) {
+	if (c->bl_built) return VK_OK;
+	const int64_t n = c->desc.n_sentences;
+	std::vector<int32_t> start((size_t)n), end((size_t)n);
+	VK_HIP(hipMemcpy(start.data(), c->d_sent_start, (size_t)n * 4, hipMemcpyDeviceToHost));
+	VK_HIP(hipMemcpy(end.data(), c->d_sent_end, (size_t)n * 4, hipMemcpyDeviceToHost));
+	std::vector<int32_t> ids[4], lens[4];
+	c->bl_empty = 0;
+	for (int64_t s = 0; s < n; s++) {
+		const int len = end[(size_t)s] - start[(size_t)s];
+		if (len < 1) { c->bl_empty++; continue; }
+		const int b = (len + 15) / 16 - 1;
+		ids[b].push_back((int32_t)s);
+		lens[b].push_back(len);
+	}
+	for (int b = 0; b < 4; b++) {
+		auto &B = c->bl[b];
+		B.n = (int64_t)ids[b].size();
+		if (B.n == 0) continue;
+		const int tps = b + 1;
+		int rc;
+		const size_t bytes = ((size_t)B.n * tps + 1) * (size_t)c->tile_bytes;   // one zero tile follows (the kernel reads it for the last, partly filled chunk)
+		if ((rc = alloc_t(c, &B.tiles, bytes))) return rc;
+		if ((rc = alloc_t(c, &B.len, (size_t)B.n))) return rc;
+		if ((rc = alloc_t(c, &B.id, (size_t)B.n))) return rc;
+		VK_HIP(hipMemsetAsync(B.tiles + (size_t)B.n * tps * c->tile_bytes, 0, (size_t)c->tile_bytes, c->stream));
+		VK_HIP(hipMemcpyAsync(B.len, lens[b].data(), (size_t)B.n * 4, hipMemcpyHostToDevice, c->stream));
+		VK_HIP(hipMemcpyAsync(B.id, ids[b].data(), (size_t)B.n * 4, hipMemcpyHostToDevice, c->stream));
+		VK_HIP(vk_launch_batch_pack(c->d_tiles, B.tiles, B.id, c->d_sent_start, c->d_sent_end, B.n, tps, c->tile_bytes, c->stream));
+		VK_HIP(hipStreamSynchronize(c->stream));   // the host vectors go out of scope
+	}
+	c->bl_built = true;
+	return VK_OK;
+}
+
 extern "C" {
 
 int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, vk_topk_out *outs) {
@@ -234,9 +273,11 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 		return fail(VK_ERR_ABORTED, "batch aborted by the caller");
 	}
 	// the GEMM path: injective RWMD, contextual layout, one sentence length (multiple of 16), common options
-	bool gemm = c->finalized && c->prec == 0 && c->contiguous && c->desc.layout == VK_LAYOUT_CONTEXTUAL && c->uniform_len > 0 && c->uniform_len % 16 == 0 &&
-		c->uniform_len <= 64 && c->desc.n_sentences > 0 && qs[0].max_matches <= 64 &&
-		((c->nk32 == 10 && c->tail == 1) || (c->nk32 == 4 && c->tail == 0));
+	// (uniform corpora of 16 / 32 / 48 / 64-token sentences run on the resident tiles; any other corpus of slices of at most 64
+	// tokens on a padded copy, bucket by bucket)
+	const bool uniform16 = c->contiguous && c->uniform_len > 0 && c->uniform_len % 16 == 0 && c->uniform_len <= 64;
+	bool gemm = c->finalized && c->prec == 0 && c->desc.layout == VK_LAYOUT_CONTEXTUAL && c->desc.n_sentences > 0 && qs[0].max_matches <= 64 &&
+		vk_rwmd_batch_supported(c->nk32, c->tail) && (uniform16 || (c->max_len <= VK_FAST_SENT_LEN && c->entry_sent.empty() && !getenv("VK_BATCH_NO_RAGGED")));
 	for (int i = 0; i < n_queries && gemm; i++) {
 		const vk_query_desc &q = qs[i];
 		gemm = q.len_t <= VK_FAST_QUERY_LEN && q.algorithm == VK_ALG_RWMD && q.rwmd_injective && !q.wmd_full && q.rwmd_symmetric == qs[0].rwmd_symmetric &&
@@ -266,7 +307,8 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 	int rc;
 
 	// 32-token sentences take the 32x32x16 kernel: 3 queries of <= 10 tokens (else 2 of <= 16) share one 32-row A tile
-	const bool b32 = c->uniform_len == 32;
+	const bool b32 = uniform16 && c->uniform_len == 32 && c->nk32 <= 10;   // (768-d rows: the 16-row kernel, one wave per SIMD)
+	if (!uniform16 && (rc = build_batch_layout(c))) return rc;
 	int qpt = 3;
 	for (int i = 0; i < n_queries; i++) if (qs[i].len_t > 10) qpt = 2;
 	const int nk16 = c->d_pad / 16;
@@ -398,7 +440,18 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 	p.late_mask = 4;   // waves w and w + 4 of a workgroup share a SIMD
 	if (const char *e = getenv("VK_BATCH32_LATE_MASK")) p.late_mask = atoi(e);   // tuning aid
 	if (b32) VK_HIP(vk_launch_rwmd_batch32(&p, st));
-	else VK_HIP(vk_launch_rwmd_batch(&p, st));
+	else if (uniform16) VK_HIP(vk_launch_rwmd_batch(&p, st));
+	else {
+		if (c->bl_empty > 0) VK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->d_bscores), (int)0xff800000u, (size_t)n_queries * (size_t)n, st));   // -inf: empty slices
+		for (int b = 0; b < 4; b++) {
+			const auto &B = c->bl[b];
+			if (B.n == 0) continue;
+			VkRwmdBatchParams pb = p;
+			pb.tiles = B.tiles; pb.n_tiles = B.n * (b + 1); pb.n_sent = (int32_t)B.n; pb.tiles_per_sent = b + 1;
+			pb.sent_len = B.len; pb.sent_id = B.id; pb.score_stride = n;
+			VK_HIP(vk_launch_rwmd_batch(&pb, st));
+		}
+	}
 
 	VK_HIP(hipEventRecord(c->ev[2], st));
 	int64_t nw = 0;

@@ -85,6 +85,11 @@ struct VkRwmdBatchParams {
 	int32_t symmetric, nbow;
 	const float *boost;
 	float *scores;             // [n_queries x n_sent]
+	// ragged corpora (vk_rwmd_batch_kernel over one length bucket of the padded batch layout): real length and original index of
+	// each of the bucket's n_sent sentences; null for uniform corpora.  score_stride: sentences of the whole corpus (row stride)
+	const int32_t *sent_len;
+	const int32_t *sent_id;
+	int64_t score_stride;
 };
 
 struct VkWrdParams {
@@ -248,6 +253,10 @@ hipError_t vk_launch_topk_wave(const float *scores, const uint64_t *keys_in, int
 hipError_t vk_launch_flow(const VkFlowParams *p, int32_t k, hipStream_t stream);
 hipError_t vk_launch_rwmd_batch(const VkRwmdBatchParams *p, hipStream_t stream);
 hipError_t vk_launch_rwmd_batch32(const VkRwmdBatchParams *p, hipStream_t stream);
+// padded copy of the sentences `ids` (n of them, each `tps` tiles long) for the batched GEMM over a ragged corpus
+hipError_t vk_launch_batch_pack(const uint8_t *src_tiles, uint8_t *dst_tiles, const int32_t *ids, const int32_t *sent_start, const int32_t *sent_end,
+	int64_t n, int32_t tps, int32_t tile_bytes, hipStream_t stream);
+int vk_rwmd_batch_supported(int32_t nk, int32_t half);
 hipError_t vk_launch_topk_wave_batch(const float *scores, const uint64_t *keys_in, int64_t n, float min_score, int32_t k,
 	int64_t per_wave, int32_t n_queries, int64_t in_stride, int64_t out_stride, uint64_t *out, int64_t *n_waves_out, hipStream_t stream);
 hipError_t vk_launch_wrd_exact(const VkWrdParams *p, int32_t n_cand, float *scores_to_mark, hipStream_t stream);

@@ -103,6 +103,12 @@ struct vk_corpus {
 	uint32_t *d_counter = nullptr;
 	float *d_rows_out = nullptr, *d_plan_out = nullptr;   // transport flows of the winners
 	int rows_w = 0;              // columns per similarity row they are sized for (16, 32, 48 or 64)
+	// batched GEMM over a ragged corpus (vk_query_batch): a padded copy of the sentences, one bucket per padded length
+	// 16 / 32 / 48 / 64 tokens, built on the first such batch (this handle's; about 1.2 x the corpus for lengths 8..64)
+	struct batch_bucket { uint8_t *tiles = nullptr; int32_t *len = nullptr, *id = nullptr; int64_t n = 0; };
+	batch_bucket bl[4];
+	bool bl_built = false;
+	int64_t bl_empty = 0;        // slices without tokens (in no bucket: their scores stay -inf)
 	size_t wrd_cap = 0;          // candidates d_wrd_raw / d_wrd_val (and d_keys[0]) can hold
 	int16_t *d_out_map = nullptr;
 	hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // 0 start, 5 before / 1 after the wait for the peer's kernel, 2 scored, 3 selected, 4 done

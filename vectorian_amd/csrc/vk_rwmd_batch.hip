@@ -32,8 +32,12 @@ __device__ __forceinline__ float xor32_f(float x, int lane) {
 	return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, x)));
 }
 
+// Ragged corpora take the same kernel once per length bucket of a padded copy of the corpus (vk_batch.cpp: sentences of 1..16,
+// 17..32, 33..48, 49..64 tokens, each padded with zero rows to 16 TPS tokens): p.sent_len masks the padding out of the sums over
+// a sentence's tokens (a zero row gives D = 1: it never lowers a column minimum), p.sent_id sends the score to the sentence's own
+// place.  NK > 12 (768-d rows): one wave per SIMD -- the 64 tokens of a wave then take 384 registers.
 template <int NK, bool HALF, int TPS>
-__global__ __launch_bounds__(256, 2) void vk_rwmd_batch_kernel(VkRwmdBatchParams p) {
+__global__ __launch_bounds__(256, NK > 12 ? 1 : 2) void vk_rwmd_batch_kernel(VkRwmdBatchParams p) {
 	constexpr int TPW = TPS == 3 ? 3 : 4;          // token tiles per wave
 	constexpr int SPW = TPW / TPS;                 // sentences per wave
 	extern __shared__ float4 vk_smem4[];
@@ -42,6 +46,7 @@ __global__ __launch_bounds__(256, 2) void vk_rwmd_batch_kernel(VkRwmdBatchParams
 	const int g4 = lane >> 4;
 	const int n16 = p.tile_bytes >> 4;             // 16-byte pieces of one query tile
 	const int64_t n_chunks = (p.n_tiles + TPW * 4 - 1) / (TPW * 4);
+	const int64_t stride = p.score_stride > 0 ? p.score_stride : p.n_sent;
 
 	for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
 		const int64_t tile0 = chunk * (TPW * 4) + (int64_t)wv * TPW;
@@ -57,6 +62,16 @@ __global__ __launch_bounds__(256, 2) void vk_rwmd_batch_kernel(VkRwmdBatchParams
 				else x[tt][t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(tp + t * 1024 + lane * 16));
 			}
 		}
+		// this wave's sentences: length (ragged corpora) and where their scores go
+		int slen[SPW];
+		int64_t sout[SPW];
+#pragma unroll
+		for (int sw = 0; sw < SPW; sw++) {
+			const int64_t sent = (tile0 + sw * TPS) / TPS;
+			const bool ok = sent < p.n_sent;
+			slen[sw] = ok ? (p.sent_len ? p.sent_len[sent] : TPS * 16) : 0;
+			sout[sw] = ok ? (p.sent_id ? (int64_t)p.sent_id[sent] : sent) : -1;
+		}
 		// ---- stage query 0
 		__syncthreads();   // previous chunk's readers are done with the LDS slots
 		for (int i = threadIdx.x; i < n16; i += 256)
@@ -66,41 +81,57 @@ __global__ __launch_bounds__(256, 2) void vk_rwmd_batch_kernel(VkRwmdBatchParams
 		for (int q = 0; q < p.n_queries; q++) {
 			const uint8_t *cur = qbuf + (q & 1) * p.tile_bytes;
 			float4 *nxt = vk_smem4 + ((q + 1) & 1) * n16;
-			// prefetch the next query tile into registers (<= 3 pieces per thread for d <= 384)
-			float4 st0 = {0, 0, 0, 0}, st1 = st0, st2 = st0;
+			// prefetch the next query tile into registers (<= 3 pieces per thread for d <= 384, 6 for d = 768)
+			// (named registers: an array indexed in two separately unrolled loops stays in scratch with hipcc)
+			constexpr bool WIDE = NK > 12;
+			const float4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
+			float4 st0 = z4, st1 = z4, st2 = z4, st3 = z4, st4 = z4, st5 = z4;
 			const bool more = q + 1 < p.n_queries;
 			if (more) {
 				const uint8_t *src = p.qtiles + (int64_t)(q + 1) * p.tile_bytes;
-				const int i0 = threadIdx.x, i1 = threadIdx.x + 256, i2 = threadIdx.x + 512;
-				if (i0 < n16) st0 = *reinterpret_cast<const float4 *>(src + i0 * 16);
-				if (i1 < n16) st1 = *reinterpret_cast<const float4 *>(src + i1 * 16);
-				if (i2 < n16) st2 = *reinterpret_cast<const float4 *>(src + i2 * 16);
+				const int i0 = threadIdx.x;
+				auto piece = [&](int i) { return *reinterpret_cast<const float4 *>(src + (i < n16 ? i : 0) * 16); };   // clamped: no branch around a load
+				st0 = piece(i0); st1 = piece(i0 + 256); st2 = piece(i0 + 512);
+				if (WIDE) { st3 = piece(i0 + 768); st4 = piece(i0 + 1024); st5 = piece(i0 + 1280); }
 			}
-			// ---- S^T = Q X^T for TPW tiles
+			// ---- S^T = Q X^T for TPW tiles; query fragments DEPTH steps ahead of their MFMAs
 			f32x4 acc[TPW];
 #pragma unroll
 			for (int tt = 0; tt < TPW; tt++) acc[tt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-			// query fragments: all NK ds_read_b128 are issued up front (40 VGPRs for d = 300) so the MFMAs
-			// of step t never wait for the LDS latency of step t
-			bf16x8 af[NK];
+			// query fragments: the ds_read_b128 of a chunk of K-steps (all of them for d <= 384: 40 VGPRs at d = 300) are issued up
+			// front, so that the MFMAs of step t never wait for the LDS latency of step t
+			constexpr int KC = NK > 12 ? 12 : NK;          // K-steps per chunk
 #pragma unroll
-			for (int t = 0; t < NK; t++) {
-				af[t] = *reinterpret_cast<const bf16x8 *>(cur + t * 1024 + ((HALF && t == NK - 1) ? (lane & 31) : lane) * 16);
-				if (HALF && t == NK - 1) {
-					const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-					af[t] = lane < 32 ? af[t] : z;
+			for (int t0 = 0; t0 < NK; t0 += KC) {
+				bf16x8 af[KC];
+#pragma unroll
+				for (int t = 0; t < KC; t++) {
+					if (t0 + t < NK) {
+						af[t] = *reinterpret_cast<const bf16x8 *>(cur + (t0 + t) * 1024 + ((HALF && t0 + t == NK - 1) ? (lane & 31) : lane) * 16);
+						if (HALF && t0 + t == NK - 1) {
+							const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+							af[t] = lane < 32 ? af[t] : z;
+						}
+					}
+				}
+#pragma unroll
+				for (int t = 0; t < KC; t++) {
+					if (t0 + t < NK) {
+#pragma unroll
+						for (int tt = 0; tt < TPW; tt++) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t], x[tt][t0 + t], acc[tt], 0, 0, 0);
+					}
 				}
 			}
-#pragma unroll
-			for (int t = 0; t < NK; t++) {
-#pragma unroll
-				for (int tt = 0; tt < TPW; tt++) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t], x[tt][t], acc[tt], 0, 0, 0);
-			}
 			if (more) {
-				const int i0 = threadIdx.x, i1 = threadIdx.x + 256, i2 = threadIdx.x + 512;
+				const int i0 = threadIdx.x;
 				if (i0 < n16) nxt[i0] = st0;
-				if (i1 < n16) nxt[i1] = st1;
-				if (i2 < n16) nxt[i2] = st2;
+				if (i0 + 256 < n16) nxt[i0 + 256] = st1;
+				if (i0 + 512 < n16) nxt[i0 + 512] = st2;
+				if (WIDE) {
+					if (i0 + 768 < n16) nxt[i0 + 768] = st3;
+					if (i0 + 1024 < n16) nxt[i0 + 1024] = st4;
+					if (i0 + 1280 < n16) nxt[i0 + 1280] = st5;
+				}
 			}
 			// ---- epilogue: D = 1 - clip(S); lane holds token (lane & 15) x query columns 4*g4 .. +3.
 			// Lane exchanges across the four 16-lane rows go through the LDS crossbar (ds_swizzle /
@@ -109,7 +140,6 @@ __global__ __launch_bounds__(256, 2) void vk_rwmd_batch_kernel(VkRwmdBatchParams
 			// is VALU-bound; the results differ from the per-query kernel by <= 1 ulp, far inside 1e-4)
 			const int len_t = p.q_len[q];
 			const float inv_t = 1.0f / (float)len_t;
-			const float inv_s = 1.0f / (float)(TPS * 16);
 			float rm[TPW], cm[SPW][4];
 #pragma unroll
 			for (int sw = 0; sw < SPW; sw++)
@@ -140,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void vk_rwmd_batch_kernel(VkRwmdBatchParams
 			for (int sw = 0; sw < SPW; sw++) {
 				float rsum = 0.0f;
 #pragma unroll
-				for (int ts = 0; ts < TPS; ts++) rsum += rm[sw * TPS + ts];
+				for (int ts = 0; ts < TPS; ts++) rsum += (ts * 16 + (lane & 15) < slen[sw]) ? rm[sw * TPS + ts] : 0.0f;   // padding rows stay out
 				// column minima over the sentence's tokens: reduce over the 16 lanes of the DPP row
 #pragma unroll
 				for (int r = 0; r < 4; r++) {
@@ -161,18 +191,45 @@ __global__ __launch_bounds__(256, 2) void vk_rwmd_batch_kernel(VkRwmdBatchParams
 				rsum += dpp_f<DPP_ROW_SHR2>(0.0f, rsum);
 				rsum += dpp_f<DPP_ROW_SHR4>(0.0f, rsum);
 				rsum += dpp_f<DPP_ROW_SHR8>(0.0f, rsum);   // lane 15 of every row: sum over the sentence's tokens
+				const float inv_s = 1.0f / (float)(slen[sw] > 0 ? slen[sw] : 1);
 				const float acc0 = inv_t * c0, acc1 = inv_s * rsum;      // nbow and bow/len agree up to rounding
 				const float cost = p.symmetric ? fmaxf(0.0f, fmaxf(acc0, acc1)) : acc0;
 				const float raw = p.nbow ? 1.0f - cost : ((float)len_t - cost) * inv_t;
-				const int64_t sent = (tile0 + sw * TPS) / TPS;
-				if (lane == 63 && sent < p.n_sent) {
-					const float boost = p.boost ? p.boost[sent] : 1.0f;
-					p.scores[(int64_t)q * p.n_sent + sent] = (raw * inv_t) * boost;
+				if (lane == 63 && sout[sw] >= 0) {
+					const float boost = p.boost ? p.boost[sout[sw]] : 1.0f;
+					p.scores[(int64_t)q * stride + sout[sw]] = (raw * inv_t) * boost;
 				}
 			}
 			__syncthreads();   // next query tile is in place; this one may be overwritten
 		}
 	}
+}
+
+// padded copy of a length bucket: destination row j = token j % (16 tps) of the bucket's sentence j / (16 tps), a zero row
+// beyond the sentence's length.  One 16-lane group per row, the row's 16-byte pieces (4 per K-step block) spread over 16 groups.
+__global__ __launch_bounds__(256) void vk_batch_pack_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, const int32_t *__restrict__ ids,
+	const int32_t *__restrict__ sent_start, const int32_t *__restrict__ sent_end, int64_t n, int32_t tps, int32_t tile_bytes) {
+	const int64_t tile = blockIdx.x;
+	const int i = threadIdx.x & 15;
+	const int64_t j = tile * 16 + i;
+	const int64_t sb = j / (16 * tps);
+	if (sb >= n) return;
+	const int t = (int)(j - sb * 16 * tps);
+	const int32_t id = ids[sb];
+	const int64_t s = (int64_t)sent_start[id] + t;
+	const bool real = s < sent_end[id];
+	const uint8_t *sp = src + (s >> 4) * (int64_t)tile_bytes + (s & 15) * 16;
+	uint8_t *dp = dst + tile * (int64_t)tile_bytes + i * 16;
+	const int n_slabs = tile_bytes >> 8;
+	const uint4 zero = {0u, 0u, 0u, 0u};
+	for (int q = threadIdx.x >> 4; q < n_slabs; q += 16)
+		*reinterpret_cast<uint4 *>(dp + q * 256) = real ? *reinterpret_cast<const uint4 *>(sp + q * 256) : zero;
+}
+
+extern "C" hipError_t vk_launch_batch_pack(const uint8_t *src_tiles, uint8_t *dst_tiles, const int32_t *ids, const int32_t *sent_start, const int32_t *sent_end,
+	int64_t n, int32_t tps, int32_t tile_bytes, hipStream_t stream) {
+	if (n > 0) vk_batch_pack_kernel<<<(unsigned)(n * tps), 256, 0, stream>>>(src_tiles, dst_tiles, ids, sent_start, sent_end, n, tps, tile_bytes);
+	return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------
@@ -624,8 +681,10 @@ static hipError_t launch_rwmd_batch_tps(const VkRwmdBatchParams &p, size_t smem,
 	int dev = 0, cus = 256;
 	if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
 	const int tpw = p.tiles_per_sent == 3 ? 3 : 4;
+	const int per_cu = NK > 12 ? 1 : 2;     // workgroups of 4 waves per CU (768-d rows: one wave per SIMD)
 	const int64_t n_chunks = (p.n_tiles + tpw * 4 - 1) / (tpw * 4);
-	const int grid = (int)(n_chunks < (int64_t)cus * 2 ? n_chunks : (int64_t)cus * 2);
+	const int grid = (int)(n_chunks < (int64_t)cus * per_cu ? n_chunks : (int64_t)cus * per_cu);
+	if (grid < 1) return hipSuccess;
 	switch (p.tiles_per_sent) {
 	case 1: vk_rwmd_batch_kernel<NK, HALF, 1><<<grid, 256, smem, stream>>>(p); break;
 	case 2: vk_rwmd_batch_kernel<NK, HALF, 2><<<grid, 256, smem, stream>>>(p); break;
@@ -684,10 +743,16 @@ extern "C" hipError_t vk_launch_rwmd_batch32(const VkRwmdBatchParams *pp, hipStr
 	return hipSuccess;
 }
 
+// row widths the batched kernels are built for: 300-d (10 K-steps, the last half filled), 128-d, 768-d
+extern "C" int vk_rwmd_batch_supported(int32_t nk, int32_t half) {
+	return (nk == 10 && half == 1) || (nk == 4 && half == 0) || (nk == 24 && half == 0);
+}
+
 // returns hipErrorNotSupported when no batched kernel exists for this corpus shape
 extern "C" hipError_t vk_launch_rwmd_batch(const VkRwmdBatchParams *p, hipStream_t stream) {
 	const size_t smem = (size_t)p->tile_bytes * 2;
 	if (p->nk == 10 && p->half == 1) return launch_rwmd_batch_tps<10, true>(*p, smem, stream);
 	if (p->nk == 4 && p->half == 0) return launch_rwmd_batch_tps<4, false>(*p, smem, stream);
+	if (p->nk == 24 && p->half == 0) return launch_rwmd_batch_tps<24, false>(*p, smem, stream);
 	return hipErrorNotSupported;
 }
