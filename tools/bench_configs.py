@@ -163,8 +163,12 @@ def main():
 		if args.min_len == 32 and args.max_len == 32:   # vk_rwmd_batch32_kernel: 3 (len_t <= 10) or 2 queries per 32-row tile, K padded to 16
 			qpt = 3 if args.len_t <= 10 else 2
 			flops_padded = 2.0 * n_tok * ((args.batch + qpt - 1) // qpt) * 32 * ((args.d + 15) // 16 * 16)
+		elif args.max_len > args.min_len and args.d <= 320:   # ragged: sentences padded to 32 / 64 tokens on the 32x32x16 kernels, 16 queries per 5 tiles
+			padded = float(np.sum((lens + 31) // 32 * 32))
+			flops_padded = 2.0 * padded * ((args.batch + 15) // 16 * 5) * 32 * ((args.d + 15) // 16 * 16)
 		else:
-			flops_padded = 2.0 * n_tok * args.batch * 16 * ((args.d + 31) // 32 * 32)
+			padded = float(np.sum((lens + 15) // 16 * 16))
+			flops_padded = 2.0 * padded * args.batch * 16 * ((args.d + 31) // 32 * 32)
 		print(json.dumps({
 			"alg": args.alg, "batch": args.batch, "d": args.d, "len_t": args.len_t, "len_s": [args.min_len, args.max_len],
 			"sentences": args.sentences, "pairs_per_s": args.sentences * args.batch * args.steps / el,

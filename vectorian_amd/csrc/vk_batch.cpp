@@ -228,7 +228,9 @@ static int query_batch_shared_pass(vk_corpus_t *c, const vk_query_desc *qs, int3
 // 16, 32, 48 or 64 tokens, every sentence padded with zero rows to its bucket's length (tile aligned: a wave's token tiles
 // then belong to whole sentences, as in a corpus of one sentence length), with the real length and the original index of
 // each.  Built once per handle, on the device from the resident tiles.
-static int build_batch_layout(vk_corpus *c) {
+// gran: tiles per bucket step -- 2 (buckets of 32 and 64 padded tokens: the 32x32x16 kernels, 300-d and 128-d rows) or 1 (16, 32,
+// 48, 64: the 16-row kernel, 768-d rows)
+static int build_batch_layout(vk_corpus *c, int gran) {
 	if (c->bl_built) return VK_OK;
 	const int64_t n = c->desc.n_sentences;
 	std::vector<int32_t> start((size_t)n), end((size_t)n);
@@ -239,7 +241,7 @@ static int build_batch_layout(vk_corpus *c) {
 	for (int64_t s = 0; s < n; s++) {
 		const int len = end[(size_t)s] - start[(size_t)s];
 		if (len < 1) { c->bl_empty++; continue; }
-		const int b = (len + 15) / 16 - 1;
+		const int b = (len + 16 * gran - 1) / (16 * gran) - 1;
 		ids[b].push_back((int32_t)s);
 		lens[b].push_back(len);
 	}
@@ -247,7 +249,7 @@ static int build_batch_layout(vk_corpus *c) {
 		auto &B = c->bl[b];
 		B.n = (int64_t)ids[b].size();
 		if (B.n == 0) continue;
-		const int tps = b + 1;
+		const int tps = (b + 1) * gran;
 		int rc;
 		const size_t bytes = ((size_t)B.n * tps + 1) * (size_t)c->tile_bytes;   // one zero tile follows (the kernel reads it for the last, partly filled chunk)
 		if ((rc = alloc_t(c, &B.tiles, bytes))) return rc;
@@ -307,8 +309,11 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 	int rc;
 
 	// 32-token sentences take the 32x32x16 kernel: 3 queries of <= 10 tokens (else 2 of <= 16) share one 32-row A tile
-	const bool b32 = uniform16 && c->uniform_len == 32 && c->nk32 <= 10;   // (768-d rows: the 16-row kernel, one wave per SIMD)
-	if (!uniform16 && (rc = build_batch_layout(c))) return rc;
+	bool b32 = uniform16 && c->uniform_len == 32 && c->nk32 <= 10;   // (768-d rows: the 16-row kernel, one wave per SIMD)
+	const int gran = c->nk32 <= 10 ? 2 : 1;   // ragged corpora: bucket step in tiles
+	if (!uniform16 && (rc = build_batch_layout(c, gran))) return rc;
+	const bool r32 = !uniform16 && gran == 2;   // ragged, on the 32x32x16 kernels
+	b32 = b32 || r32;                           // query tiles packed for them
 	int qpt = 3;
 	for (int i = 0; i < n_queries; i++) if (qs[i].len_t > 10) qpt = 2;
 	const int nk16 = c->d_pad / 16;
@@ -439,7 +444,7 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 	p.n_qtiles = n_qtiles; p.qpt = qpt; p.q_inv_len = d_qinv; p.q_param = d_qparam; p.dense = dense ? 1 : 0;
 	p.late_mask = 4;   // waves w and w + 4 of a workgroup share a SIMD
 	if (const char *e = getenv("VK_BATCH32_LATE_MASK")) p.late_mask = atoi(e);   // tuning aid
-	if (b32) VK_HIP(vk_launch_rwmd_batch32(&p, st));
+	if (b32 && !r32) VK_HIP(vk_launch_rwmd_batch32(&p, st));
 	else if (uniform16) VK_HIP(vk_launch_rwmd_batch(&p, st));
 	else {
 		if (c->bl_empty > 0) VK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->d_bscores), (int)0xff800000u, (size_t)n_queries * (size_t)n, st));   // -inf: empty slices
@@ -447,9 +452,10 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 			const auto &B = c->bl[b];
 			if (B.n == 0) continue;
 			VkRwmdBatchParams pb = p;
-			pb.tiles = B.tiles; pb.n_tiles = B.n * (b + 1); pb.n_sent = (int32_t)B.n; pb.tiles_per_sent = b + 1;
+			pb.tiles = B.tiles; pb.n_tiles = B.n * (b + 1) * gran; pb.n_sent = (int32_t)B.n; pb.tiles_per_sent = (b + 1) * gran;
 			pb.sent_len = B.len; pb.sent_id = B.id; pb.score_stride = n;
-			VK_HIP(vk_launch_rwmd_batch(&pb, st));
+			if (r32) VK_HIP(vk_launch_rwmd_batch32(&pb, st));
+			else VK_HIP(vk_launch_rwmd_batch(&pb, st));
 		}
 	}
 

@@ -369,14 +369,26 @@ __device__ __forceinline__ void batch32_mfma(const uint8_t *cur, const bf16x8 (&
 // workgroup: four ds_read_b32 at the top of the epilogue, consumed at its end.  (Fetched from global memory under the
 // lane-15 branch, each tile paid the latency of two dependent vector loads inside its epilogue.)
 struct B32Vals { float main, third; };
+// the lane's sentence: 1 / its real length and the number of padding tokens (ragged corpora run on a padded copy, vk_batch.cpp:
+// a zero row has S = 0 exactly, so each padding token adds exactly 1 to the sum of the token distances and nothing to a maximum)
+struct B32Sent { float inv_s, pad; };
+// W64: the wave holds ONE sentence of 64 (padded) tokens instead of two of 32 -- columns 0..15 of the two MFMA chains are its
+// tokens 0..31, columns 16..31 its tokens 32..63; sums over its tokens add the two DPP rows of a lane half (row_bcast:15),
+// maxima over its tokens meet through one ds_swizzle (lane ^ 16); its scores sit in lanes 31 and 63.
+template <bool W64>
+__device__ __forceinline__ float tokens_sum(float x) {
+	x = row_sum_to_lane15(x);
+	if (W64) x += dpp_bcast<0x142, 0xa>(x);
+	return x;
+}
 constexpr int B32_MAX_QTILES = 256;   // query tiles per launch (their parameters: 8 KiB of LDS); larger batches take several launches
 
-template <int QPT>
+template <int QPT, bool W64>
 __device__ __forceinline__ B32Vals batch32_epilogue(const VkRwmdBatchParams &p, int lane, const f32x16 &acc0, const f32x16 &acc1,
-	const float *tile_param, float boost) {
+	const float *tile_param, float boost, const B32Sent &sn) {
 	constexpr int NMAIN = QPT == 3 ? 10 : 16;          // rows of the half's own query
 	const int h = lane >> 5;
-	const float inv_s = 1.0f / 32.0f;
+	const float inv_s = sn.inv_s;
 	const float len_main = tile_param[h], inv_main = tile_param[4 + h];
 	const float len_third = tile_param[2], inv_third = tile_param[6];
 #if defined(VK_ABL) && (VK_ABL == 1 || VK_ABL >= 4)
@@ -392,7 +404,7 @@ __device__ __forceinline__ B32Vals batch32_epilogue(const VkRwmdBatchParams &p, 
 	int ca0 = fbits(acc0[0]), ca1 = fbits(acc1[0]);
 #pragma unroll
 	for (int i = 1; i < NMAIN; i++) { ca0 = imax(ca0, fbits(acc0[i])); ca1 = imax(ca1, fbits(acc1[i])); }
-	const float ts_main = row_sum_to_lane15((2.0f - clip01_bits(ca0)) - clip01_bits(ca1));
+	const float ts_main = tokens_sum<W64>((2.0f - clip01_bits(ca0)) - clip01_bits(ca1)) - sn.pad;
 	float ts_third = 0.0f;
 	if (QPT == 3) {
 		int cb0 = fbits(acc0[10]), cb1 = fbits(acc1[10]);
@@ -401,7 +413,7 @@ __device__ __forceinline__ B32Vals batch32_epilogue(const VkRwmdBatchParams &p, 
 		const int e0 = __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, cb0);
 		const int e1 = __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, cb1);
 		cb0 = imax(cb0, e0); cb1 = imax(cb1, e1);
-		ts_third = row_sum_to_lane15((2.0f - clip01_bits(cb0)) - clip01_bits(cb1));
+		ts_third = tokens_sum<W64>((2.0f - clip01_bits(cb0)) - clip01_bits(cb1)) - sn.pad;
 	}
 	// (b) per query row: max over the sentence's tokens -> lane 15 of the DPP row
 	float s_main = 0.0f, s_third = 0.0f;
@@ -409,7 +421,8 @@ __device__ __forceinline__ B32Vals batch32_epilogue(const VkRwmdBatchParams &p, 
 		int m[16];
 #pragma unroll
 		for (int i = 0; i < 16; i++) m[i] = imax(fbits(acc0[i]), fbits(acc1[i]));
-		const float z = clip01_bits(row_transpose_imax16(m, lane));    // lane v of the row: maximum of query row v over the sentence
+		float z = clip01_bits(row_transpose_imax16(m, lane));    // lane v of the row: maximum of query row v over the sentence
+		if (W64) z = fmaxf(z, xor16_f(z));                          // ... over both halves of a 64-token sentence
 		const int v = lane & 15;
 		s_main = row_sum_to_lane15(v < NMAIN ? z : 0.0f);
 		if (QPT == 3) {
@@ -440,16 +453,16 @@ __device__ __forceinline__ B32Vals batch32_epilogue(const VkRwmdBatchParams &p, 
 // the scores of tile qt: lane 15 of each DPP row holds them (row = sentence x lane half).  Rows of absent queries (the
 // last tile may hold fewer than QPT) are written too: the score array has n_qtiles * QPT rows.
 template <int QPT>
-__device__ __forceinline__ void batch32_store(const VkRwmdBatchParams &p, int qt, bool store_lane, unsigned lane_off, int lane, const B32Vals &v) {
+__device__ __forceinline__ void batch32_store(const VkRwmdBatchParams &p, int qt, bool store_lane, unsigned lane_off, int lane, const B32Vals &v, int64_t stride) {
 	// row base wave-uniform (scalar registers), the lane's part a 32-bit offset: no 64-bit address arithmetic in vector registers
-	float *row = p.scores + (int64_t)(qt * QPT) * p.n_sent;
+	float *row = p.scores + (int64_t)(qt * QPT) * stride;
 	if (store_lane) {
 		row[lane_off] = v.main;
-		if (QPT == 3 && lane < 32) (row + (int64_t)2 * p.n_sent)[lane_off] = v.third;
+		if (QPT == 3 && lane < 32) (row + (int64_t)2 * stride)[lane_off] = v.third;
 	}
 }
 
-template <int NK16, int QPT>
+template <int NK16, int QPT, bool W64>
 __global__ __launch_bounds__(512) void vk_rwmd_batch32_kernel(VkRwmdBatchParams p) {
 	constexpr int QT_BYTES = NK16 * 1024;
 	extern __shared__ float4 vk_smem4[];
@@ -457,7 +470,9 @@ __global__ __launch_bounds__(512) void vk_rwmd_batch32_kernel(VkRwmdBatchParams 
 	float *param = reinterpret_cast<float *>(vk_smem4) + 2 * QT_BYTES / 4;   // [n_qtiles][8]: len of the tile's 3 queries, pad, 1 / len, pad
 	const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int n32 = lane & 31, h = lane >> 5;
-	const int64_t n_chunks = ((int64_t)p.n_sent + 15) / 16;
+	constexpr int SPC = W64 ? 8 : 16;              // sentences per chunk (workgroup)
+	const int64_t n_chunks = ((int64_t)p.n_sent + SPC - 1) / SPC;
+	const int64_t stride = p.score_stride > 0 ? p.score_stride : p.n_sent;
 	for (int i = threadIdx.x; i < p.n_qtiles * 8; i += 512) param[i] = p.q_param[i];
 	// The two waves that share a SIMD (w and w + 4 of the workgroup) run the two halves of an interval in
 	// opposite order: the "late" wave first finishes the epilogue of the previous tile (VALU) while the
@@ -466,15 +481,19 @@ __global__ __launch_bounds__(512) void vk_rwmd_batch32_kernel(VkRwmdBatchParams 
 	const bool late = (wv & p.late_mask) != 0;
 
 	for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-		const int64_t sent = chunk * 16 + wv * 2 + (n32 >> 4);   // this lane's sentence
-		const float boost = (p.boost && sent < p.n_sent) ? p.boost[sent] : 1.0f;
-		const bool store_lane = (lane & 15) == 15 && sent < p.n_sent;                 // lane 15 of each DPP row holds the row's scores
-		const unsigned lane_off = (unsigned)h * (unsigned)p.n_sent + (unsigned)sent;   // its place in the score rows of its half's query
+		const int64_t sent = W64 ? chunk * 8 + wv : chunk * 16 + wv * 2 + (n32 >> 4);   // this lane's sentence
+		const bool have = sent < p.n_sent;
+		const int slen = have ? (p.sent_len ? p.sent_len[sent] : (W64 ? 64 : 32)) : 1;
+		const int64_t sout = have ? (p.sent_id ? (int64_t)p.sent_id[sent] : sent) : 0;   // where its scores go
+		const B32Sent sn{1.0f / (float)slen, (float)((W64 ? 64 : 32) - slen)};
+		const float boost = (p.boost && have) ? p.boost[sout] : 1.0f;
+		const bool store_lane = (W64 ? (lane & 31) == 31 : (lane & 15) == 15) && have;   // the last lane of a sentence's lanes holds its scores
+		const unsigned lane_off = (unsigned)h * (unsigned)stride + (unsigned)sout;       // its place in the score rows of its half's query
 		// ---- the wave's token tiles -> registers (read once per batch)
 		bf16x8 x[2][NK16];
 #pragma unroll
 		for (int m = 0; m < 2; m++) {
-			const int64_t tile = sent < p.n_sent ? sent * 2 + m : p.n_tiles;   // one zero tile follows the corpus
+			const int64_t tile = have ? (W64 ? sent * 4 + 2 * (n32 >> 4) + m : sent * 2 + m) : p.n_tiles;   // one zero tile follows the corpus
 			const uint8_t *tp = p.tiles + tile * p.tile_bytes + (n32 & 15) * 16;
 #pragma unroll
 			for (int t = 0; t < NK16; t++)
@@ -497,19 +516,19 @@ __global__ __launch_bounds__(512) void vk_rwmd_batch32_kernel(VkRwmdBatchParams 
 			if (!late) {
 				// the scores of the previous tile leave now, not at the end of its iteration: the barrier there waits for
 				// every outstanding memory operation of the wave (vmcnt(0) for the LDS-DMA), stores to HBM included
-				if (qt > 0) batch32_store<QPT>(p, qt - 1, store_lane, lane_off, lane, pend);
+				if (qt > 0) batch32_store<QPT>(p, qt - 1, store_lane, lane_off, lane, pend, stride);
 				batch32_mfma<NK16>(cur, x, acc0, acc1, next_src, (unsigned)lane * 16u, next_dst, wv);
-				pend = batch32_epilogue<QPT>(p, lane, acc0, acc1, param + qt * 8, boost);
+				pend = batch32_epilogue<QPT, W64>(p, lane, acc0, acc1, param + qt * 8, boost, sn);
 			} else {
-				if (qt > 0) batch32_store<QPT>(p, qt - 1, store_lane, lane_off, lane, batch32_epilogue<QPT>(p, lane, acc0, acc1, param + (qt - 1) * 8, boost));
+				if (qt > 0) batch32_store<QPT>(p, qt - 1, store_lane, lane_off, lane, batch32_epilogue<QPT, W64>(p, lane, acc0, acc1, param + (qt - 1) * 8, boost, sn), stride);
 				batch32_mfma<NK16>(cur, x, acc0, acc1, next_src, (unsigned)lane * 16u, next_dst, wv);
 			}
 #if !defined(VK_ABL) || VK_ABL < 6
 			__syncthreads();   // next query tile is in place; this one may be overwritten
 #endif
 		}
-		if (late) pend = batch32_epilogue<QPT>(p, lane, acc0, acc1, param + (p.n_qtiles - 1) * 8, boost);
-		batch32_store<QPT>(p, p.n_qtiles - 1, store_lane, lane_off, lane, pend);
+		if (late) pend = batch32_epilogue<QPT, W64>(p, lane, acc0, acc1, param + (p.n_qtiles - 1) * 8, boost, sn);
+		batch32_store<QPT>(p, p.n_qtiles - 1, store_lane, lane_off, lane, pend, stride);
 	}
 }
 
@@ -528,15 +547,15 @@ __global__ __launch_bounds__(512) void vk_rwmd_batch32_kernel(VkRwmdBatchParams 
 
 struct B32DState { int cb0, cb1; float zg; };
 
-template <int K>
+template <int K, bool W64>
 __device__ __forceinline__ B32Vals batch32d_epilogue(const VkRwmdBatchParams &p, int lane, const f32x16 &acc0, const f32x16 &acc1,
-	const float *super_param /* [16][2]: len, 1 / len of the super tile's queries */, float boost, B32DState &st) {
+	const float *super_param /* [16][2]: len, 1 / len of the super tile's queries */, float boost, B32DState &st, const B32Sent &sn) {
 	constexpr int C_HI = K == 0 ? 10 : K == 1 ? 14 : K == 3 ? 12 : 16;   // slots [10, C_HI) continue the split query in progress
 	constexpr bool CLOSES = K == 1 || K == 3 || K == 4;                  // ... and complete it
 	constexpr bool STARTS = K == 0 || K == 1 || K == 3;                  // slots [C_HI, 16) start the next one
 	constexpr int G = K == 1 ? 0 : K == 3 ? 1 : 2;
 	const int h = lane >> 5, v = lane & 15;
-	const float inv_s = 1.0f / 32.0f;
+	const float inv_s = sn.inv_s;
 	const float len_f = super_param[2 * (8 * h + K)], inv_f = super_param[2 * (8 * h + K) + 1];
 	float len_g = 0.0f, inv_g = 0.0f;
 	if (CLOSES) { len_g = super_param[2 * (8 * h + 5 + G)]; inv_g = super_param[2 * (8 * h + 5 + G) + 1]; }
@@ -551,11 +570,11 @@ __device__ __forceinline__ B32Vals batch32d_epilogue(const VkRwmdBatchParams &p,
 	int ca0 = fbits(acc0[0]), ca1 = fbits(acc1[0]);
 #pragma unroll
 	for (int i = 1; i < 10; i++) { ca0 = imax(ca0, fbits(acc0[i])); ca1 = imax(ca1, fbits(acc1[i])); }
-	const float ts_f = row_sum_to_lane15((2.0f - clip01_bits(ca0)) - clip01_bits(ca1));
+	const float ts_f = tokens_sum<W64>((2.0f - clip01_bits(ca0)) - clip01_bits(ca1)) - sn.pad;
 #pragma unroll
 	for (int i = 10; i < C_HI; i++) { st.cb0 = imax(st.cb0, fbits(acc0[i])); st.cb1 = imax(st.cb1, fbits(acc1[i])); }
 	float ts_g = 0.0f;
-	if (CLOSES) ts_g = row_sum_to_lane15((2.0f - clip01_bits(st.cb0)) - clip01_bits(st.cb1));
+	if (CLOSES) ts_g = tokens_sum<W64>((2.0f - clip01_bits(st.cb0)) - clip01_bits(st.cb1)) - sn.pad;
 	if (STARTS) {
 		st.cb0 = fbits(acc0[C_HI]); st.cb1 = fbits(acc1[C_HI]);
 #pragma unroll
@@ -566,7 +585,8 @@ __device__ __forceinline__ B32Vals batch32d_epilogue(const VkRwmdBatchParams &p,
 	int m[16];
 #pragma unroll
 	for (int i = 0; i < 16; i++) m[i] = imax(fbits(acc0[i]), fbits(acc1[i]));
-	const float z = clip01_bits(row_transpose_imax16(m, lane));
+	float z = clip01_bits(row_transpose_imax16(m, lane));
+	if (W64) z = fmaxf(z, xor16_f(z));
 	const float s_f = row_sum_to_lane15(v < 10 ? z : 0.0f);
 	if (C_HI > 10) st.zg += (v >= 10 && v < C_HI) ? z : 0.0f;
 	float s_g = 0.0f;
@@ -594,29 +614,30 @@ constexpr int B32D_MAX_SUPER = 48;   // super tiles per launch: 768 queries, the
 
 // epilogue / store of tile K (0..4) of a super tile; K is wave-uniform, the five forms are the arms of one switch (unrolling the
 // five tiles into the loop body instead let hipcc hoist their addresses and parameters: 30 more registers, scratch)
+template <bool W64>
 __device__ __forceinline__ B32Vals batch32d_epilogue_k(int K, const VkRwmdBatchParams &p, int lane, const f32x16 &acc0, const f32x16 &acc1,
-	const float *super_param, float boost, B32DState &st) {
+	const float *super_param, float boost, B32DState &st, const B32Sent &sn) {
 	switch (K) {
-	case 0: return batch32d_epilogue<0>(p, lane, acc0, acc1, super_param, boost, st);
-	case 1: return batch32d_epilogue<1>(p, lane, acc0, acc1, super_param, boost, st);
-	case 2: return batch32d_epilogue<2>(p, lane, acc0, acc1, super_param, boost, st);
-	case 3: return batch32d_epilogue<3>(p, lane, acc0, acc1, super_param, boost, st);
-	default: return batch32d_epilogue<4>(p, lane, acc0, acc1, super_param, boost, st);
+	case 0: return batch32d_epilogue<0, W64>(p, lane, acc0, acc1, super_param, boost, st, sn);
+	case 1: return batch32d_epilogue<1, W64>(p, lane, acc0, acc1, super_param, boost, st, sn);
+	case 2: return batch32d_epilogue<2, W64>(p, lane, acc0, acc1, super_param, boost, st, sn);
+	case 3: return batch32d_epilogue<3, W64>(p, lane, acc0, acc1, super_param, boost, st, sn);
+	default: return batch32d_epilogue<4, W64>(p, lane, acc0, acc1, super_param, boost, st, sn);
 	}
 }
 
-__device__ __forceinline__ void batch32d_store_k(int K, const VkRwmdBatchParams &p, int super, bool store_lane, unsigned lane_off, const B32Vals &v) {
+__device__ __forceinline__ void batch32d_store_k(int K, const VkRwmdBatchParams &p, int super, bool store_lane, unsigned lane_off, const B32Vals &v, int64_t stride) {
 	// tiles 1, 3 and 4 complete a split query: G = 0, 1, 2; its row is 5 + G - K rows below the tile's own
 	const bool closes = K == 1 || K == 3 || K == 4;
 	const int g_row = K == 1 ? 4 : K == 3 ? 3 : 3;   // 5 + G - K
-	float *row = p.scores + (int64_t)(super * 16 + K) * p.n_sent;   // wave-uniform; lane_off = (8 h) n_sent + sentence
+	float *row = p.scores + (int64_t)(super * 16 + K) * stride;   // wave-uniform; lane_off = (8 h) stride + sentence
 	if (store_lane) {
 		row[lane_off] = v.main;
-		if (closes) (row + (int64_t)g_row * p.n_sent)[lane_off] = v.third;
+		if (closes) (row + (int64_t)g_row * stride)[lane_off] = v.third;
 	}
 }
 
-template <int NK16>
+template <int NK16, bool W64>
 __global__ __launch_bounds__(512) void vk_rwmd_batch32d_kernel(VkRwmdBatchParams p) {
 	constexpr int QT_BYTES = NK16 * 1024;
 	extern __shared__ float4 vk_smem4[];
@@ -625,19 +646,25 @@ __global__ __launch_bounds__(512) void vk_rwmd_batch32d_kernel(VkRwmdBatchParams
 	const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int n32 = lane & 31, h = lane >> 5;
 	const int n_super = p.n_qtiles / 5;
-	const int64_t n_chunks = ((int64_t)p.n_sent + 15) / 16;
+	constexpr int SPC = W64 ? 8 : 16;              // sentences per chunk (workgroup)
+	const int64_t n_chunks = ((int64_t)p.n_sent + SPC - 1) / SPC;
+	const int64_t stride = p.score_stride > 0 ? p.score_stride : p.n_sent;
 	for (int i = threadIdx.x; i < n_super * 32; i += 512) param[i] = p.q_param[i];
 	const bool late = (wv & p.late_mask) != 0;   // see vk_rwmd_batch32_kernel
 
 	for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-		const int64_t sent = chunk * 16 + wv * 2 + (n32 >> 4);   // this lane's sentence
-		const float boost = (p.boost && sent < p.n_sent) ? p.boost[sent] : 1.0f;
-		const bool store_lane = (lane & 15) == 15 && sent < p.n_sent;
-		const unsigned lane_off = (unsigned)(8 * h) * (unsigned)p.n_sent + (unsigned)sent;
+		const int64_t sent = W64 ? chunk * 8 + wv : chunk * 16 + wv * 2 + (n32 >> 4);   // this lane's sentence
+		const bool have = sent < p.n_sent;
+		const int slen = have ? (p.sent_len ? p.sent_len[sent] : (W64 ? 64 : 32)) : 1;
+		const int64_t sout = have ? (p.sent_id ? (int64_t)p.sent_id[sent] : sent) : 0;
+		const B32Sent sn{1.0f / (float)slen, (float)((W64 ? 64 : 32) - slen)};
+		const float boost = (p.boost && have) ? p.boost[sout] : 1.0f;
+		const bool store_lane = (W64 ? (lane & 31) == 31 : (lane & 15) == 15) && have;
+		const unsigned lane_off = (unsigned)(8 * h) * (unsigned)stride + (unsigned)sout;
 		bf16x8 x[2][NK16];
 #pragma unroll
 		for (int m = 0; m < 2; m++) {
-			const int64_t tile = sent < p.n_sent ? sent * 2 + m : p.n_tiles;   // one zero tile follows the corpus
+			const int64_t tile = have ? (W64 ? sent * 4 + 2 * (n32 >> 4) + m : sent * 2 + m) : p.n_tiles;   // one zero tile follows the corpus
 			const uint8_t *tp = p.tiles + tile * p.tile_bytes + (n32 & 15) * 16;
 #pragma unroll
 			for (int t = 0; t < NK16; t++)
@@ -659,11 +686,11 @@ __global__ __launch_bounds__(512) void vk_rwmd_batch32d_kernel(VkRwmdBatchParams
 			const uint8_t *next_src = p.qtiles + (int64_t)(qt + 1) * QT_BYTES;
 			const uint8_t *next_dst = qbuf + ((qt + 1) & 1) * QT_BYTES;
 			if (!late) {
-				if (qt > 0) batch32d_store_k(KP, p, super_p, store_lane, lane_off, pend);
+				if (qt > 0) batch32d_store_k(KP, p, super_p, store_lane, lane_off, pend, stride);
 				batch32_mfma<NK16>(cur, x, acc0, acc1, next_src, (unsigned)lane * 16u, next_dst, wv);
-				pend = batch32d_epilogue_k(K, p, lane, acc0, acc1, param + super * 32, boost, st);
+				pend = batch32d_epilogue_k<W64>(K, p, lane, acc0, acc1, param + super * 32, boost, st, sn);
 			} else {
-				if (qt > 0) batch32d_store_k(KP, p, super_p, store_lane, lane_off, batch32d_epilogue_k(KP, p, lane, acc0, acc1, param + super_p * 32, boost, st));
+				if (qt > 0) batch32d_store_k(KP, p, super_p, store_lane, lane_off, batch32d_epilogue_k<W64>(KP, p, lane, acc0, acc1, param + super_p * 32, boost, st, sn), stride);
 				batch32_mfma<NK16>(cur, x, acc0, acc1, next_src, (unsigned)lane * 16u, next_dst, wv);
 			}
 #if !defined(VK_ABL) || VK_ABL < 6
@@ -671,8 +698,8 @@ __global__ __launch_bounds__(512) void vk_rwmd_batch32d_kernel(VkRwmdBatchParams
 #endif
 			if (++K == 5) { K = 0; super++; }
 		}
-		if (late) pend = batch32d_epilogue<4>(p, lane, acc0, acc1, param + (n_super - 1) * 32, boost, st);
-		batch32d_store_k(4, p, n_super - 1, store_lane, lane_off, pend);
+		if (late) pend = batch32d_epilogue<4, W64>(p, lane, acc0, acc1, param + (n_super - 1) * 32, boost, st, sn);
+		batch32d_store_k(4, p, n_super - 1, store_lane, lane_off, pend, stride);
 	}
 }
 
@@ -698,9 +725,12 @@ static hipError_t launch_rwmd_batch_tps(const VkRwmdBatchParams &p, size_t smem,
 extern "C" hipError_t vk_launch_rwmd_batch32(const VkRwmdBatchParams *pp, hipStream_t stream) {
 	int dev = 0, cus = 256;
 	if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-	if (pp->tiles_per_sent != 2 || (pp->qpt != 2 && pp->qpt != 3)) return hipErrorNotSupported;
-	const int64_t n_chunks = ((int64_t)pp->n_sent + 15) / 16;
+	if ((pp->tiles_per_sent != 2 && pp->tiles_per_sent != 4) || (pp->qpt != 2 && pp->qpt != 3)) return hipErrorNotSupported;
+	const bool w64 = pp->tiles_per_sent == 4;   // 64-token (padded) sentences: one per wave
+	const int spc = w64 ? 8 : 16;
+	const int64_t n_chunks = ((int64_t)pp->n_sent + spc - 1) / spc;
 	const int grid = (int)(n_chunks < (int64_t)cus ? n_chunks : (int64_t)cus);
+	if (grid < 1) return hipSuccess;
 	int nk16;
 	if (pp->nk == 10 && pp->half == 1) nk16 = 19;
 	else if (pp->nk == 4 && pp->half == 0) nk16 = 8;
@@ -708,35 +738,34 @@ extern "C" hipError_t vk_launch_rwmd_batch32(const VkRwmdBatchParams *pp, hipStr
 	if (pp->dense) {
 		// p->n_qtiles = 5 x super tiles of 16 queries; q_param [n_super * 16][2]; scores n_super * 16 rows
 		const int n_super = pp->n_qtiles / 5;
+		const int64_t stride = pp->score_stride > 0 ? pp->score_stride : pp->n_sent;
 		for (int s0 = 0; s0 < n_super; s0 += B32D_MAX_SUPER) {
 			VkRwmdBatchParams p = *pp;
 			const int ns = n_super - s0 < B32D_MAX_SUPER ? n_super - s0 : B32D_MAX_SUPER;
 			p.n_qtiles = ns * 5;
 			p.qtiles = pp->qtiles + (size_t)s0 * 5 * nk16 * 1024;
 			p.q_param = pp->q_param + (size_t)s0 * 32;
-			p.scores = pp->scores + (size_t)s0 * 16 * pp->n_sent;
+			p.scores = pp->scores + (size_t)s0 * 16 * stride;
 			const size_t smem = (size_t)2 * nk16 * 1024 + (size_t)B32D_MAX_SUPER * 128;
-			if (nk16 == 19) vk_rwmd_batch32d_kernel<19><<<grid, 512, smem, stream>>>(p);
-			else vk_rwmd_batch32d_kernel<8><<<grid, 512, smem, stream>>>(p);
+			if (nk16 == 19) { if (w64) vk_rwmd_batch32d_kernel<19, true><<<grid, 512, smem, stream>>>(p); else vk_rwmd_batch32d_kernel<19, false><<<grid, 512, smem, stream>>>(p); }
+			else { if (w64) vk_rwmd_batch32d_kernel<8, true><<<grid, 512, smem, stream>>>(p); else vk_rwmd_batch32d_kernel<8, false><<<grid, 512, smem, stream>>>(p); }
 			const hipError_t e = hipGetLastError();
 			if (e != hipSuccess) return e;
 		}
 		return hipSuccess;
 	}
+	const int64_t stride = pp->score_stride > 0 ? pp->score_stride : pp->n_sent;
 	for (int t0 = 0; t0 < pp->n_qtiles; t0 += B32_MAX_QTILES) {
 		VkRwmdBatchParams p = *pp;
 		p.n_qtiles = pp->n_qtiles - t0 < B32_MAX_QTILES ? pp->n_qtiles - t0 : B32_MAX_QTILES;
 		p.qtiles = pp->qtiles + (size_t)t0 * nk16 * 1024;
 		p.q_param = pp->q_param + (size_t)t0 * 8;
-		p.scores = pp->scores + (size_t)t0 * pp->qpt * pp->n_sent;
+		p.scores = pp->scores + (size_t)t0 * pp->qpt * stride;
 		const size_t smem = (size_t)2 * nk16 * 1024 + (size_t)B32_MAX_QTILES * 32;
-		if (nk16 == 19) {
-			if (p.qpt == 3) vk_rwmd_batch32_kernel<19, 3><<<grid, 512, smem, stream>>>(p);
-			else vk_rwmd_batch32_kernel<19, 2><<<grid, 512, smem, stream>>>(p);
-		} else {
-			if (p.qpt == 3) vk_rwmd_batch32_kernel<8, 3><<<grid, 512, smem, stream>>>(p);
-			else vk_rwmd_batch32_kernel<8, 2><<<grid, 512, smem, stream>>>(p);
-		}
+		void (*kernel)(VkRwmdBatchParams);
+		if (nk16 == 19) kernel = p.qpt == 3 ? (w64 ? vk_rwmd_batch32_kernel<19, 3, true> : vk_rwmd_batch32_kernel<19, 3, false>) : (w64 ? vk_rwmd_batch32_kernel<19, 2, true> : vk_rwmd_batch32_kernel<19, 2, false>);
+		else kernel = p.qpt == 3 ? (w64 ? vk_rwmd_batch32_kernel<8, 3, true> : vk_rwmd_batch32_kernel<8, 3, false>) : (w64 ? vk_rwmd_batch32_kernel<8, 2, true> : vk_rwmd_batch32_kernel<8, 2, false>);
+		kernel<<<grid, 512, smem, stream>>>(p);
 		const hipError_t e = hipGetLastError();
 		if (e != hipSuccess) return e;
 	}
