@@ -91,3 +91,24 @@ def test_errors_are_loud(hip):
 	with pytest.raises(hip.VkError):
 		c.query(q[:3], algorithm=hip.VK_ALG_WRD)
 	c.close()
+
+
+@pytest.mark.parametrize("len_t", [3, 10, 16, 20, 32, 45])
+@pytest.mark.parametrize("table", ["linear_as_table", "convex", "steps"])
+def test_general_gaps_that_are_not_subadditive(hip, oracle, len_t, table):
+	"""gap tables for which two gaps in a row are cheaper than (or as cheap as) one of the summed length: the sequential
+	recurrence composes them, the register-history kernels take the subadditive closure of the table (vk_query.cpp)"""
+	k = np.arange(0, 513, dtype=np.float64)
+	w = {"linear_as_table": 0.1 * k, "convex": np.minimum(0.02 * k ** 2, 1.5), "steps": 0.15 * np.ceil(k / 3.0) ** 1.5}[table].astype(np.float32)
+	corpus = synth.make_contextual_corpus(600, 1, 40, 1500, 64)
+	Xb = prep_contextual(corpus)
+	c = hip_contextual_corpus(hip, corpus, Xb)
+	for q in synth.make_queries(corpus, 2, len_t):
+		Qb = prep_query(q)
+		for loc, ms in ((0, 0.0), (1, -1e9), (2, -1e9)):
+			kw = dict(locality=loc, gap_s=("table", w), gap_t=("table", w), max_matches=10, min_score=ms)
+			ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=64, sent_off=corpus["sent_off"], X=Xb, Q=Qb, want_all_scores=True, **kw)
+			got = c.query(Qb, q_normalize=False, **kw)
+			assert_same_results(got.trimmed(), ref, score_tol=2e-5, tie_tol=2e-6)
+			np.testing.assert_allclose(c.last_scores(), ref["all_scores"], atol=2e-5, rtol=0)
+	c.close()

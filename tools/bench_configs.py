@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 def main():
 	ap = argparse.ArgumentParser()
 	ap.add_argument("--alg", choices=["align", "rwmd", "wrd"], default="align")
-	ap.add_argument("--gap", choices=["exp5", "linear", "affine"], default="exp5")
+	ap.add_argument("--gap", choices=["exp5", "linear", "affine", "lintable", "convex"], default="exp5", help="lintable: the linear cost 0.1 k handed over as a table (not strictly subadditive); convex: 0.02 k^2 capped at 1 (superadditive at short gaps)")
 	ap.add_argument("--locality", choices=["local", "global", "semiglobal"], default="local")
 	ap.add_argument("--d", type=int, default=300)
 	ap.add_argument("--len-t", type=int, default=10)
@@ -118,7 +118,9 @@ def main():
 		filter_ms = (time.perf_counter() - t0) * 1e3
 
 	w = (1 - 2.0 ** (-np.arange(0, 65) / 5)).astype(np.float32)
-	gap = {"exp5": ("table", w), "linear": 0.1, "affine": ("affine", 0.2, 0.05)}[args.gap]
+	gap = {"exp5": ("table", w), "linear": 0.1, "affine": ("affine", 0.2, 0.05),
+		"lintable": ("table", (0.1 * np.arange(0, 65)).astype(np.float32)),
+		"convex": ("table", np.minimum(0.02 * np.arange(0, 65) ** 2, 1.0).astype(np.float32))}[args.gap]
 	loc = {"local": 0, "global": 1, "semiglobal": 2}[args.locality]
 	alg = {"align": core.VK_ALG_ALIGN, "rwmd": core.VK_ALG_RWMD, "wrd": core.VK_ALG_WRD}[args.alg]
 	qs = []

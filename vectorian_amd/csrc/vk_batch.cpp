@@ -47,7 +47,7 @@ static int query_batch_shared_pass(vk_corpus_t *c, const vk_query_desc *qs, int3
 	// ---- common options: gap tables, DP form
 	VkScoreBatchParams p{};
 	const int ks = q0.gap_s.kind, kt = q0.gap_t.kind;
-	float ws[kGapTable], wt[80];
+	float ws[kGapTable], wt[160] = {0};   // wt[80..159]: the subadditive closure of w_t
 	if (!is_align) {
 		p.gap_mode = 4; p.rwmd_symmetric = q0.rwmd_symmetric; p.rwmd_normalize_bow = q0.rwmd_normalize_bow;
 	} else if (ks == VK_GAP_LINEAR && kt == VK_GAP_LINEAR) {
@@ -60,13 +60,10 @@ static int query_batch_shared_pass(vk_corpus_t *c, const vk_query_desc *qs, int3
 	} else p.gap_mode = 2;
 	for (int i = 0; i < kGapTable; i++) ws[i] = (is_align && i <= c->max_len) ? gap_cost(q0.gap_s, i) : 0.0f;
 	for (int i = 0; i < 80; i++) wt[i] = (is_align && i <= max_len_t) ? gap_cost(q0.gap_t, i) : 0.0f;
-	if (p.gap_mode == 2) {
-		bool sub = true;   // see vk_query: register-history DP needs w_t strictly subadditive
-		for (int x = 1; x < max_len_t && sub; x++)
-			for (int y = 1; x + y <= max_len_t; y++)
-				if (!(wt[x] + wt[y] > wt[x + y] + 1e-4f)) { sub = false; break; }
-		if (sub) p.gap_mode = c->max_short_len <= 32 ? 3 : 6;
-	}
+	for (int k = 0; k < 80; k++) wt[80 + k] = wt[k];   // the subadditive closure of w_t for the in-row candidates (vk_query.cpp)
+	for (int k = 2; k <= max_len_t && k < 80; k++)
+		for (int a = 1; a < k; a++) wt[80 + k] = std::min(wt[80 + k], wt[80 + a] + wt[80 + k - a]);
+	if (p.gap_mode == 2) p.gap_mode = c->max_short_len <= 32 ? 3 : 6;
 	const int lt = max_len_t <= 4 ? 4 : max_len_t <= 8 ? 8 : max_len_t <= 12 ? 12 : 16;
 	p.s_rows_per_wave = c->max_group_tiles * 16;
 	p.h_rows = c->max_short_len + 1;
@@ -123,7 +120,7 @@ static int query_batch_shared_pass(vk_corpus_t *c, const vk_query_desc *qs, int3
 	}
 	p.tiles = c->d_tiles; p.sent_start = c->d_sent_start; p.sent_end = c->d_sent_end; p.n_sent = (int32_t)n;
 	p.nk32 = c->nk32; p.tail = c->tail; p.tile_bytes = c->tile_bytes;
-	p.qtiles = c->d_bq; p.locality = q0.locality; p.ws = c->d_ws; p.wt = c->d_wt;
+	p.qtiles = c->d_bq; p.locality = q0.locality; p.ws = c->d_ws; p.wt = c->d_wt + 80; p.wt0 = c->d_wt;
 	p.boost = q0.boost ? c->d_boost : nullptr; p.scores = c->d_bscores; p.raw = c->d_braw;
 
 	float score_ms_total = 0.0f, total_ms = 0.0f;

@@ -256,7 +256,8 @@ struct DpArgs {
 	float a_s, a_t;        // affine: a
 	float open_s, open_t;  // affine: a + b
 	const float *ws;       // general: w_s[0..max_len]
-	const float *wt;       // general: w_t[0..16]
+	const float *wt;       // general: w_t[0..16] for the in-row candidates (the closure of the caller's table, vk_query.cpp)
+	const float *wt0;      // general: the caller's table (border row H[0][j] = -w_t(j), set directly, never chained)
 	int32_t rwmd_symmetric, rwmd_normalize_bow, wmd_bound;
 	float wrd_raw_total;   // WRD on raw magnitudes: sum of the query's magnitudes (0: masses are normalised)
 };
@@ -392,7 +393,7 @@ __device__ __forceinline__ float dp_general(const float *__restrict__ S, float *
 #pragma unroll
 	for (int p = 0; p < LT; p++) wtl[p] = (p <= v) ? a.wt[v + 1 - p] : __builtin_inff();
 
-	float h = is_global ? -a.wt[v + 1] : 0.0f;
+	float h = is_global ? -a.wt0[v + 1] : 0.0f;
 	hist[0] = h;
 	float best = 0.0f;
 	for (int u = 1; u <= maxlen; u++) {
@@ -427,11 +428,13 @@ __device__ __forceinline__ float dp_general(const float *__restrict__ S, float *
 // H[0..u-1][j] lives in registers (rows fully unrolled, w_s in scalar registers), and
 // the in-row step takes its candidates from the row's values *before* in-row gaps,
 //     H[u][j] = max(c[j], max_k c[j-k] - w_t(k)),   c = max(zero, diagonal, gaps over s tokens)
-// which needs no serial chain.  This equals the sequential recurrence bit for bit when
-// w_t is strictly subadditive (w(a) + w(b) > w(a+b) by a margin far above fp32 rounding):
-// two consecutive in-row gaps are then always beaten by the single gap of the summed
-// length, so replacing H[j-k] by c[j-k] drops only dominated candidates.  The host
-// checks the margin (vk_query.cpp) and otherwise selects dp_general.
+// which needs no serial chain.  In the sequential recurrence an in-row candidate H[u][j-k] - w_t(k) may itself end in an in-row
+// gap: two gaps in a row cost w_t(a) + w_t(b), so the recurrence works with the cheapest way of composing a gap,
+//     w*(k) = min(w_t(k), min_{a+b=k} w*(a) + w*(b))    (the subadditive closure of w_t),
+// and H[u][j] = max(c[j], max_k c[j-k] - w*(k)) exactly.  The host hands over w* as `wt` (vk_query.cpp; it equals w_t for
+// subadditive costs such as 1 - 2^(-k/c)); a composed gap is rounded once here and twice in the chain, a difference of an ulp,
+// far inside the 1e-4 of the scores -- the tracebacks of the winners walk the caller's table sequentially (vk_flow_kernel).
+// The border row is set directly: H[0][j] = -w_t(j), one gap, from `wt0`.
 template <int LT, int MAXLEN>
 __device__ __forceinline__ float dp_general_reg(const float *__restrict__ S, int rowbase, int len, int maxlen, int v,
 	const DpArgs &a, const float (&wsr)[MAXLEN + 1], const float (&wtr)[LT]) {
@@ -440,7 +443,8 @@ __device__ __forceinline__ float dp_general_reg(const float *__restrict__ S, int
 	const bool is_global = a.locality == VK_DEV_GLOBAL;
 	const float floor0 = is_local ? 0.0f : VK_NEG_INF;
 	const bool last_col = v == a.len_t - 1;
-	const float wt_border = a.wt[v + 1];             // distance from the border column to column v + 1
+	const float wt_border = a.wt[v + 1];             // distance from the border column to column v + 1 (chains of gaps allowed: closure)
+	const float wt_border0 = a.wt0[v + 1];           // ... as one gap: the border row
 
 	// in-row gap costs per lane: w_t(k) where column v - k exists, +inf where it does not.  The candidate is then ONE
 	// v_sub_f32_dpp (zero fill for the missing source lanes: 0 - inf = -inf drops out of the maximum) instead of a
@@ -450,7 +454,7 @@ __device__ __forceinline__ float dp_general_reg(const float *__restrict__ S, int
 	for (int k = 1; k < LT; k++) wtv[k] = v >= k ? wtr[k] : __builtin_inff();
 
 	float hreg[MAXLEN + 1];
-	float h = is_global ? -wt_border : 0.0f;
+	float h = is_global ? -wt_border0 : 0.0f;
 	hreg[0] = h;
 	float best = 0.0f;
 #pragma unroll

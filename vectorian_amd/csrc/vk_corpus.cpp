@@ -78,7 +78,7 @@ int vk_corpus_create(const vk_corpus_desc *desc, vk_corpus_t **out) {
 		}
 		if ((rc = alloc_t(c, &c->d_qtile, (size_t)c->tile_bytes * 4))) break;   // up to 4 tiles of 16 query rows
 		if ((rc = alloc_t(c, &c->d_ws, kGapTable))) break;
-		if ((rc = alloc_t(c, &c->d_wt, 80))) break;
+		if ((rc = alloc_t(c, &c->d_wt, 160))) break;
 		if ((rc = alloc_t(c, &c->d_qids, 80))) break;
 		if ((rc = alloc_t(c, &c->d_out_raw, VK_MAX_MATCHES))) break;
 		if ((rc = alloc_t(c, &c->d_out_sim, (size_t)VK_MAX_MATCHES * 64))) break;
@@ -120,7 +120,7 @@ int vk_corpus_view(vk_corpus_t *src, vk_corpus_t **out) {
 		if (c->desc.layout == VK_LAYOUT_STATIC && (rc = alloc_t(c, &c->d_table, (size_t)c->n_tiles * 16 * 16 * 4))) break;
 		if ((rc = alloc_t(c, &c->d_qtile, (size_t)c->tile_bytes * 4))) break;
 		if ((rc = alloc_t(c, &c->d_ws, kGapTable))) break;
-		if ((rc = alloc_t(c, &c->d_wt, 80))) break;
+		if ((rc = alloc_t(c, &c->d_wt, 160))) break;
 		if ((rc = alloc_t(c, &c->d_qids, 80))) break;
 		if ((rc = alloc_t(c, &c->d_out_raw, VK_MAX_MATCHES))) break;
 		if ((rc = alloc_t(c, &c->d_out_sim, (size_t)VK_MAX_MATCHES * 64))) break;
@@ -430,7 +430,7 @@ int vk_corpus_filter(vk_corpus_t *src, uint64_t pos_mask, uint64_t tag_mask, vk_
 			if ((r = alloc_t(c, &c->d_table, (size_t)c->n_tiles * 16 * 16 * 4))) return r;
 			if ((r = alloc_t(c, &c->d_qtile, (size_t)c->tile_bytes * 4))) return r;
 			if ((r = alloc_t(c, &c->d_ws, kGapTable))) return r;
-			if ((r = alloc_t(c, &c->d_wt, 80))) return r;
+			if ((r = alloc_t(c, &c->d_wt, 160))) return r;
 			if ((r = alloc_t(c, &c->d_qids, 80))) return r;
 			if ((r = alloc_t(c, &c->d_out_raw, VK_MAX_MATCHES))) return r;
 			if ((r = alloc_t(c, &c->d_out_sim, (size_t)VK_MAX_MATCHES * 64))) return r;

@@ -46,7 +46,8 @@ struct VkScoreParams {
 	float a_s, a_t;            // affine: a
 	float open_s, open_t;      // affine: a + b
 	const float *ws;           // general: [max_len + 1]
-	const float *wt;           // general: [17]
+	const float *wt;           // general: [17]; for the in-row candidates: the subadditive closure of the caller's table (vk_query.cpp)
+	const float *wt0;          // general: the caller's table itself: the border row H[0][j] = -w_t(j)
 	const float *boost;        // [n_sent] or null
 	// tag-weighted similarity modifier (pos_s == nullptr: off)
 	const int8_t *pos_s;       // [n_tokens + pad] POS code per token
@@ -166,7 +167,8 @@ struct VkScoreBatchParams {
 	int32_t rwmd_symmetric, rwmd_normalize_bow;
 	float gs, gt, a_s, a_t, open_s, open_t;
 	const float *ws;
-	const float *wt;
+	const float *wt;           // closure of w_t (see VkScoreParams)
+	const float *wt0;          // w_t as given
 	const float *boost;
 	float *scores;             // [n_queries x n_sent]
 	float *raw;                // [n_queries x n_sent]
@@ -195,7 +197,8 @@ struct VkWideParams {
 	int32_t rwmd_symmetric, rwmd_normalize_bow;
 	float gs, gt, a_s, a_t, open_s, open_t;
 	const float *ws;
-	const float *wt;           // [65]
+	const float *wt;           // [65]; vk_score32_kernel: the closure of w_t (see VkScoreParams); vk_wide_kernel: w_t as given
+	const float *wt0;          // vk_score32_kernel: w_t as given (border row)
 	const int8_t *pos_s;
 	float tw[VK_DEV_MAX_WIDE_QUERY_LEN];
 	int32_t tpos[VK_DEV_MAX_WIDE_QUERY_LEN];

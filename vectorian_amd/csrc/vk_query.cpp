@@ -187,7 +187,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	VkScoreParams p{};
 	float qmass_all[VK_MAX_QUERY_LEN] = {0};   // masses of the query tokens (transport algorithms), all 64 columns
 	const int ks = q->gap_s.kind, kt = q->gap_t.kind;
-	float ws[kGapTable], wt[80];
+	float ws[kGapTable], wt[160];   // wt[0..79]: w_t as given; wt[80..159]: its subadditive closure
 	const bool is_align = q->algorithm == VK_ALG_ALIGN;
 	if (q->algorithm == VK_ALG_WRD) {
 		p.gap_mode = 5;
@@ -239,16 +239,18 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	}
 	for (int i = 0; i < kGapTable; i++) ws[i] = (is_align && i <= c->max_len) ? gap_cost(q->gap_s, i) : 0.0f;
 	for (int i = 0; i < 80; i++) wt[i] = (is_align && i <= q->len_t) ? gap_cost(q->gap_t, i) : 0.0f;
-	bool wide_sub = false;   // a long query whose w_t is strictly subadditive: the two-block kernel may take it
+	for (int i = 80; i < 160; i++) wt[i] = 0.0f;
+	// The register-history kernels take their in-row candidates from the row's values before in-row gaps, which is the
+	// sequential recurrence with w_t replaced by its subadditive closure w* (dp_general_reg in vk_common.cuh): wt[80..159].
+	// (Round 1 sent every table that was not strictly subadditive -- a linear cost handed over as a table, a convex one -- to the
+	// LDS-history kernel with its serial in-row chain: 12.7 ms per 1 M x 32 tokens against 2.9 ms.)
+	bool wide_sub = false;   // a long query with general gaps: the multi-block kernel takes it
+	for (int k = 0; k < 80; k++) wt[80 + k] = wt[k];
+	for (int k = 2; k <= q->len_t && k < 80; k++)
+		for (int a = 1; a < k; a++) wt[80 + k] = std::min(wt[80 + k], wt[80 + a] + wt[80 + k - a]);
 	if (p.gap_mode == 2) {
-		// register-history kernel: needs w_t strictly subadditive over the query length
-		// (see dp_general_reg in vk_common.cuh); margin far above fp32 rounding of the DP values
-		bool sub = true;
-		for (int x = 1; x < q->len_t && sub; x++)
-			for (int y = 1; x + y <= q->len_t; y++)
-				if (!(wt[x] + wt[y] > wt[x + y] + 1e-4f)) { sub = false; break; }
-		if (sub && !wide) p.gap_mode = c->max_short_len <= 32 ? 3 : 6;
-		wide_sub = sub && wide;
+		if (!wide) p.gap_mode = c->max_short_len <= 32 ? 3 : 6;
+		wide_sub = wide;
 	}
 	VK_HIP(hipMemcpyAsync(c->d_ws, ws, sizeof ws, hipMemcpyHostToDevice, st));
 	VK_HIP(hipMemcpyAsync(c->d_wt, wt, sizeof wt, hipMemcpyHostToDevice, st));
@@ -286,7 +288,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	p.n_sent = (int32_t)n; p.layout = is_static ? VK_DEV_LAYOUT_STATIC : VK_DEV_LAYOUT_CONTEXTUAL;
 	p.nk32 = c->nk32; p.tail = c->tail; p.tile_bytes = c->tile_bytes; p.prec = c->prec;
 	p.qtile = c->d_qtile; p.len_t = q->len_t; p.locality = q->locality;
-	p.ws = c->d_ws; p.wt = c->d_wt;
+	p.ws = c->d_ws; p.wt = c->d_wt + 80; p.wt0 = c->d_wt;
 	p.boost = q->boost ? c->d_boost : nullptr;
 	p.scores = c->d_scores; p.raw = c->d_raw;
 	p.ref_total = (float)q->len_t;
@@ -310,7 +312,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		wp.qtile = c->d_qtile; wp.nq = nq; wp.len_t = q->len_t; wp.locality = q->locality; wp.gap_mode = p.gap_mode; wp.max_len = c->max_len;
 		wp.rwmd_symmetric = p.rwmd_symmetric; wp.rwmd_normalize_bow = p.rwmd_normalize_bow;
 		wp.gs = p.gs; wp.gt = p.gt; wp.a_s = p.a_s; wp.a_t = p.a_t; wp.open_s = p.open_s; wp.open_t = p.open_t;
-		wp.ws = c->d_ws; wp.wt = c->d_wt;
+		wp.ws = c->d_ws; wp.wt = c->d_wt; wp.wt0 = c->d_wt;
 		wp.pos_s = p.pos_s; wp.tw_keep = p.tw_keep; wp.tw_threshold = p.tw_threshold; wp.ref_total = p.ref_total;
 		for (int j = 0; j < VK_MAX_QUERY_LEN; j++) {
 			wp.tw[j] = (p.pos_s && j < q->len_t) ? q->tag_weights[j] : 0.0f;
@@ -335,9 +337,10 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 				memcpy(wp.qmass, qmass_all, sizeof wp.qmass);
 				wp.wrd_raw_total = p.wrd_raw_total; wp.wmd_bound = q->algorithm == VK_ALG_WRD ? 0 : p.wmd_bound;
 			}
-			if (p.gap_mode == 2) wp.gap_mode = c->max_len <= 32 ? 3 : 6;   // register history of 32 / 64 rows
+			if (p.gap_mode == 2) { wp.gap_mode = c->max_len <= 32 ? 3 : 6; wp.wt = c->d_wt + 80; }   // register history of 32 / 64 rows, closure of w_t
 			VK_HIP(vk_launch_score32(&wp, wave_tiles, st));
 			wp.gap_mode = p.gap_mode;                                        // the traceback kernel knows 0 / 1 / 2
+			wp.wt = c->d_wt;                                                 // ... and walks the caller's table
 		}
 		else VK_HIP(vk_launch_wide(&wp, 0, st));
 	} else if (is_align && !is_static && q->len_t == 1 && c->uniform_len == 1 && q->locality == VK_LOCAL && !p.pos_s) {

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 	DpArgs a;
 	a.locality = p.locality; a.len_t = p.len_t;
 	a.gs = p.gs; a.gt = p.gt; a.a_s = p.a_s; a.a_t = p.a_t; a.open_s = p.open_s; a.open_t = p.open_t;
-	a.ws = p.ws; a.wt = p.wt;
+	a.ws = p.ws; a.wt = p.wt; a.wt0 = p.wt0;
 	a.rwmd_symmetric = p.rwmd_symmetric; a.rwmd_normalize_bow = p.rwmd_normalize_bow; a.wmd_bound = p.wmd_bound;
 	a.wrd_raw_total = p.wrd_raw_total;
 	const float inv_ref = p.ref_total;

@@ -217,7 +217,7 @@ __device__ __forceinline__ float dp32_general(const float *__restrict__ S, int s
 	const float floor0 = is_local ? 0.0f : VK_NEG_INF;
 	const bool last_col = col == p.len_t - 1;
 	const float inf = __builtin_inff();
-	const float wt_border = p.wt[col + 1];
+	const float wt_border = p.wt[col + 1], wt_border0 = p.wt0[col + 1];   // chains of gaps from the border column / one gap (border row)
 	constexpr int NL = 16 * (NB - 1);   // columns that can lie in blocks to the left
 	// their costs w_t(col - i) per lane: in registers, except beside the 64-row history of the four-block form, where 48 more
 	// registers spill -- there they are read from the wave's copy of w_t in LDS (xch + 64), one ds_read_b32 per candidate
@@ -233,7 +233,7 @@ __device__ __forceinline__ float dp32_general(const float *__restrict__ S, int s
 	const f32x4 *left = reinterpret_cast<const f32x4 *>(xch + (lane & ~(16 * NB - 1)));   // c of columns 0.. of this slice
 
 	float hreg[MAXLEN + 1];
-	float h = is_global ? -wt_border : 0.0f;
+	float h = is_global ? -wt_border0 : 0.0f;
 	hreg[0] = h;
 	float best = 0.0f;
 #pragma unroll
