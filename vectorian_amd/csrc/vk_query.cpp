@@ -327,7 +327,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		const bool bound_pass = q->algorithm == VK_ALG_WRD || (q->algorithm == VK_ALG_RWMD && q->wmd_full);   // exact transport: stage 1
 		const bool two_blocks = (is_align || rwmd_inj || bound_pass) && c->n_long_groups == 0 &&
 			c->max_len <= VK_FAST_SENT_LEN && (rwmd_inj || bound_pass || p.gap_mode == 0 || (p.gap_mode == 1 && p.a_t >= 0.0f) || (p.gap_mode == 2 && wide_sub)) &&
-			vk_score32_lds_bytes(is_static ? 0 : c->nk32, wave_tiles, q->len_t) <= 160 * 1024 && (bound_pass || !getenv("VK_NO_SCORE32"));
+			vk_score32_lds_bytes(is_static ? 0 : c->nk32, c->tail, wave_tiles, q->len_t, 6) <= 160 * 1024 && (bound_pass || !getenv("VK_NO_SCORE32"));
 		if (bound_pass && !two_blocks)
 			return fail(VK_ERR_UNSUPPORTED, "exact transport with a query of more than 16 tokens: the multi-block kernel does not fit this corpus (LDS)");
 		if (two_blocks) {

@@ -295,22 +295,23 @@ __device__ __forceinline__ float dp32_general(const float *__restrict__ S, int s
 
 // STATIC: token ids + the two per-query tables [V x 16] (columns 0..15 and 16..31) instead of token tiles
 template <int GAP, bool STATIC, int NB>
-__global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t rows_per_wave, int32_t stride) {
+__global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t rows_per_wave, int32_t stride, int32_t slack) {
 	constexpr int LPS = 16 * NB, PER = 64 / LPS;   // lanes per slice, slices per wave
 	extern __shared__ float4 vk_smem32[];
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	// the NB query tiles (tokens 0..15, 16..31, ..) in LDS, shared by the block's waves
-	const int qbytes = STATIC ? 0 : p.nk32 * 1024;
-	for (int i = threadIdx.x; !STATIC && i < NB * p.nk32 * 64; i += blockDim.x) {
-		const int t = i / (p.nk32 * 64), o = i - t * p.nk32 * 64;
-		float4 x = {0.0f, 0.0f, 0.0f, 0.0f};
-		if (!(p.tail && o >= (p.nk32 - 1) * 64 + 32)) x = *reinterpret_cast<const float4 *>(p.qtile + (int64_t)t * p.tile_bytes + o * 16);   // the half block has 32 slots
-		vk_smem32[i] = x;
+	// (a half-filled last K-step takes 512 bytes, as in HBM: its lanes 32..63 re-read the slots of lanes 0..31 and meet zeros on the
+	// token side -- 1 KiB per workgroup that decides, at 32 query tokens, whether a third workgroup fits the CU)
+	const int qbytes = STATIC ? 0 : (p.tail ? p.nk32 * 1024 - 512 : p.nk32 * 1024);
+	const int qpieces = qbytes / 16;
+	for (int i = threadIdx.x; !STATIC && i < NB * qpieces; i += blockDim.x) {
+		const int t = i / qpieces, o = i - t * qpieces;
+		vk_smem32[i] = *reinterpret_cast<const float4 *>(p.qtile + (int64_t)t * p.tile_bytes + o * 16);
 	}
 	__syncthreads();
 	const uint8_t *q0 = reinterpret_cast<const uint8_t *>(vk_smem32);
 	// strip rows hold the query columns padded to a multiple of 4 (stride floats), not 32: a third workgroup per CU for 20 tokens
-	float *S = reinterpret_cast<float *>(vk_smem32) + NB * (qbytes / 4) + wv * (rows_per_wave * stride + 144);
+	float *S = reinterpret_cast<float *>(vk_smem32) + NB * (qbytes / 4) + wv * (rows_per_wave * stride + slack);   // 16-byte aligned: qbytes is a multiple of 512
 
 	float *xch = S + rows_per_wave * stride;   // 64 floats behind the strip: the in-row exchange of dp32_general; then the wave's copy of w_t
 	if (GAP == 6 && NB == 4) {
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t
 				const bf16x8 x = load_half_block(tp + nfull * 1024, lane, true);
 #pragma unroll
 				for (int b = 0; b < NB; b++)
-					acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(q0 + b * qbytes + nfull * 1024 + lane * 16), x, acc[b], 0, 0, 0);
+					acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(q0 + b * qbytes + nfull * 1024 + (lane & 31) * 16), x, acc[b], 0, 0, 0);
 			}
 			const int ps = p.pos_s ? p.pos_s[(tile0 + ti) * 16 + (lane & 15)] : 0, cq = (lane >> 4) * 4;
 			float *row = S + (ti * 16 + (lane & 15)) * stride + cq;
@@ -465,19 +466,26 @@ __global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t
 }
 
 static inline int strip_stride(int len_t) { return (len_t + 3) / 4 * 4; }
+// floats behind a wave's strip: the 64-float exchange slot of dp32_general (general gaps), followed, in the four-block form with
+// the 64-row history, by the wave's copy of w_t (65); 16 otherwise (lanes beyond the strip's columns read into it).  Exact sizes
+// matter: at 32 query tokens and 300-d rows 1,280 bytes decide between two and three workgroups per CU (5.4 -> 4.3 ms).
+static inline int strip_slack(int gap_mode, int len_t) {
+	if (gap_mode == 6 && len_t > 32) return 144;
+	return (gap_mode == 3 || gap_mode == 6) ? 64 : 16;
+}
 
 // nk32 = 0: static layout (no query tiles in LDS); tiles: token tiles a wave's slices span (two consecutive slices for
 // queries of at most 32 tokens, one slice beyond)
-extern "C" size_t vk_score32_lds_bytes(int32_t nk32, int32_t tiles, int32_t len_t) {
+extern "C" size_t vk_score32_lds_bytes(int32_t nk32, int32_t tail, int32_t tiles, int32_t len_t, int32_t gap_mode) {
 	const int nb = len_t <= 32 ? 2 : 4;
-	return (size_t)nb * nk32 * 1024 + (size_t)4 * ((size_t)tiles * 16 * strip_stride(len_t) + 144) * 4;
+	return (size_t)nb * (nk32 * 1024 - (tail && nk32 > 0 ? 512 : 0)) + (size_t)4 * ((size_t)tiles * 16 * strip_stride(len_t) + strip_slack(gap_mode, len_t)) * 4;
 }
 
 extern "C" hipError_t vk_launch_score32(const VkWideParams *p, int32_t tiles, hipStream_t stream) {
 	const bool is_static = p->layout == VK_DEV_LAYOUT_STATIC;
 	const bool four = p->len_t > 32;   // 33..64 tokens: one slice per wave, four column blocks (linear / affine gaps)
-	const size_t smem = vk_score32_lds_bytes(is_static ? 0 : p->nk32, tiles, p->len_t);
-	void (*kernel)(VkWideParams, int32_t, int32_t);
+	const size_t smem = vk_score32_lds_bytes(is_static ? 0 : p->nk32, p->tail, tiles, p->len_t, p->gap_mode);
+	void (*kernel)(VkWideParams, int32_t, int32_t, int32_t);
 	switch (p->gap_mode) {
 	case 0: kernel = four ? (is_static ? vk_score32_kernel<0, true, 4> : vk_score32_kernel<0, false, 4>)
 		: (is_static ? vk_score32_kernel<0, true, 2> : vk_score32_kernel<0, false, 2>); break;
@@ -508,6 +516,6 @@ extern "C" hipError_t vk_launch_score32(const VkWideParams *p, int32_t tiles, hi
 	const int per = four ? 1 : 2;
 	const int want = (int)((((int64_t)p->n_sent + per - 1) / per + 3) / 4);
 	const int grid = want < cus * occ ? (want > 0 ? want : 1) : cus * occ;
-	kernel<<<grid, 256, smem, stream>>>(*p, tiles * 16, strip_stride(p->len_t));
+	kernel<<<grid, 256, smem, stream>>>(*p, tiles * 16, strip_stride(p->len_t), strip_slack(p->gap_mode, p->len_t));
 	return hipGetLastError();
 }
