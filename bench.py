@@ -333,7 +333,7 @@ def roofline_of(spec, n_sent, n_tok, kern_s):
 		flops = 2.0 * n_tok * spec["batch"] * LEN_T * d
 		ach = flops / kern_s
 		return {"bound": "mfma", "achieved": ach / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK,
-			"kernel": "vk_rwmd_batch32_kernel", "kernel_ms": kern_s * 1e3, "algorithmic_flops_per_launch": flops}
+			"kernel": "vk_rwmd_batch32d_kernel", "kernel_ms": kern_s * 1e3, "algorithmic_flops_per_launch": flops}
 	nbytes = n_tok * d * (4 if spec["prec"] == "f32" else 2) + (4 * n_tok if spec["alg"] == "wrd" else 0)
 	ach = nbytes / kern_s
 	return {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,

@@ -80,8 +80,36 @@ def test_distributed_rwmd_long_slices_and_short_queries(hip, oracle):
 			got = c.query(Qb, algorithm=hip.VK_ALG_RWMD, rwmd=flags, q_normalize=False, max_matches=9, min_score=-1.0)
 			np.testing.assert_allclose(c.last_scores(), ref["all_scores"], atol=1e-5, rtol=0)
 			assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=1e-5, tie_tol=1e-5)
-	with pytest.raises(hip.VkError):   # the 1:n form is built for queries of at most 16 tokens
+	with pytest.raises(hip.VkError):   # the 1:n form with more than 16 query tokens needs slices of at most 64 tokens
 		c.query(np.ones((17, 64), np.float32), algorithm=hip.VK_ALG_RWMD, rwmd=(False, True, True))
+	c.close()
+
+
+@pytest.mark.parametrize("layout", ["contextual", "static"])
+@pytest.mark.parametrize("len_t", [17, 24, 32, 33, 50, 64])
+def test_distributed_rwmd_long_queries(hip, oracle, layout, len_t):
+	"""the 1:n form (rwmd('nbow/distributed'), wmd.h:339-376) with queries of 17..64 tokens: rwmd_fill32 of the multi-block kernel"""
+	rng = np.random.default_rng(7 + len_t)
+	if layout == "static":
+		V, d = 60, 64                                   # a small vocabulary: words repeat inside slices and queries
+		corpus = synth.make_static_corpus(300, 1, 64, V, d, seed=5)
+		c, Eb = hip_static_corpus(hip, corpus)
+		q_ids = rng.integers(0, V, size=len_t).astype(np.int32)
+		base = dict(layout=oracle.LAYOUT_STATIC, d=d, sent_off=corpus["sent_off"], tok_id=corpus["tok_id"], E=Eb, Q=Eb[q_ids], q_ids=q_ids)
+		qargs = dict(q_token_ids=q_ids)
+		Qb = Eb[q_ids]
+	else:
+		corpus = synth.make_contextual_corpus(300, 1, 64, 500, 96)
+		Xb = prep_contextual(corpus)
+		c = hip_contextual_corpus(hip, corpus, Xb)
+		Qb = prep_query(synth.make_queries(corpus, 1, len_t)[0])
+		base = dict(layout=oracle.LAYOUT_CONTEXTUAL, d=96, sent_off=corpus["sent_off"], X=Xb, Q=Qb)
+		qargs = {}
+	for flags in ((False, True, True), (False, False, True), (False, False, False)):
+		ref = oracle.find(algorithm=oracle.ALG_RWMD, rwmd=flags, max_matches=9, min_score=-1.0, want_all_scores=True, **base)
+		got = c.query(Qb, algorithm=hip.VK_ALG_RWMD, rwmd=flags, q_normalize=False, max_matches=9, min_score=-1.0, **qargs)
+		np.testing.assert_allclose(c.last_scores(), ref["all_scores"], atol=1e-5, rtol=0)
+		assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=1e-5, tie_tol=1e-5)
 	c.close()
 
 

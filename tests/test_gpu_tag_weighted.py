@@ -88,8 +88,6 @@ def test_contextual_tag_weighted_transport(hip, oracle, shape, alg, opts):
 	"""the tag-weighted modifier with the transport metrics (TagWeightedSlice wraps any slice, match/instantiate.cpp:173-189):
 	modified similarities drive the solver, the score is divided by sum(tag_weights) (slice/static.h:280-286)"""
 	d, lo, hi, len_t = shape
-	if len_t > 16 and alg == "rwmd" and not opts["rwmd"][0]:
-		pytest.skip("the 1:n form stops at 16 query tokens")
 	n = 300
 	corpus = synth.make_contextual_corpus(n, lo, hi, 1500, d, noise=0.3, norm_sigma=0.25)
 	X = corpus["X"]

@@ -93,8 +93,7 @@ def test_wide_query_limits(hip):
 	with pytest.raises(hip.VkError):
 		c.query(Q65, max_matches=3)
 	assert c.query(Q65[:20], algorithm=hip.VK_ALG_WRD, max_matches=3).n == 3   # exact transport runs up to 64 query tokens
-	with pytest.raises(hip.VkError):   # the 1:n form of RWMD stays at 16
-		c.query(Q65[:20], algorithm=hip.VK_ALG_RWMD, rwmd=(False, False, True), max_matches=3)
+	assert c.query(Q65[:20], algorithm=hip.VK_ALG_RWMD, rwmd=(False, False, True), max_matches=3, min_score=-1.0).n == 3   # ... and the 1:n form of RWMD
 	c.close()
 
 

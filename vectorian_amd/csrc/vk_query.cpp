@@ -50,8 +50,8 @@ int vk_validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_topk_
 			if (c->max_len > VK_FAST_SENT_LEN) return fail(VK_ERR_UNSUPPORTED, "full WMD needs every slice <= VK_FAST_SENT_LEN (64) tokens");
 			if (q->rwmd_injective) return fail(VK_ERR_INVALID, "non-relaxed WMD with injective mapping is not supported");      // wmd.h:201-204
 			if (q->rwmd_symmetric) return fail(VK_ERR_INVALID, "non-relaxed WMD with symmetric computation is not supported");  // wmd.h:206-209
-		} else if (!q->rwmd_injective && q->len_t > VK_FAST_QUERY_LEN)
-			return fail(VK_ERR_UNSUPPORTED, "non-injective RWMD (rwmd('nbow/distributed')) is implemented for queries of at most 16 tokens");
+		} else if (!q->rwmd_injective && q->len_t > VK_FAST_QUERY_LEN && c->max_len > VK_FAST_SENT_LEN)
+			return fail(VK_ERR_UNSUPPORTED, "non-injective RWMD (rwmd('nbow/distributed')) with a query of more than 16 tokens needs every slice <= VK_FAST_SENT_LEN (64) tokens");
 		if (q->want_flow && (!out->mapping || !out->edge_sim)) return fail(VK_ERR_INVALID, "want_flow needs mapping and edge_sim arrays");
 	} else if (q->algorithm == VK_ALG_WRD) {
 		if (c->max_len > VK_FAST_SENT_LEN) return fail(VK_ERR_UNSUPPORTED, "VK_ALG_WRD needs every slice <= VK_FAST_SENT_LEN (64) tokens");
@@ -210,7 +210,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 			// 1:n form: masses of the query's vocabulary entries (count / len at the first occurrence of a token id)
 			p.gap_mode = 7;
 			const bool ids = c->desc.layout == VK_LAYOUT_STATIC && q->q_token_ids;
-			for (int j = 0; j < VK_FAST_QUERY_LEN; j++) {
+			for (int j = 0; j < VK_MAX_QUERY_LEN; j++) {
 				float mass = 0.0f;
 				if (j < q->len_t) {
 					int cnt = 1;
@@ -220,8 +220,9 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 							if (i != j && q->q_token_ids[i] == q->q_token_ids[j]) { cnt++; if (i < j) first = false; }
 					mass = first ? (q->rwmd_normalize_bow ? (float)cnt / (float)q->len_t : (float)cnt) : 0.0f;
 				}
-				p.qmass[j] = mass;
+				qmass_all[j] = mass;
 			}
+			memcpy(p.qmass, qmass_all, sizeof p.qmass);
 		}
 	} else if (ks == VK_GAP_LINEAR && kt == VK_GAP_LINEAR) {
 		p.gap_mode = 0;
@@ -323,13 +324,14 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		// (affine: the prefix-scan form of F needs open_t >= extend_t, as dp_affine)
 		// (33..64 tokens: one slice per wave and four column blocks)
 		const int wave_tiles = q->len_t <= 32 ? c->max_pair_tiles : (c->max_len + 15) / 16 + 1;
-		const bool rwmd_inj = q->algorithm == VK_ALG_RWMD && p.gap_mode == 4 && !q->wmd_full;
+		const bool rwmd_inj = q->algorithm == VK_ALG_RWMD && (p.gap_mode == 4 || p.gap_mode == 7) && !q->wmd_full;
 		const bool bound_pass = q->algorithm == VK_ALG_WRD || (q->algorithm == VK_ALG_RWMD && q->wmd_full);   // exact transport: stage 1
 		const bool two_blocks = (is_align || rwmd_inj || bound_pass) && c->n_long_groups == 0 &&
 			c->max_len <= VK_FAST_SENT_LEN && (rwmd_inj || bound_pass || p.gap_mode == 0 || (p.gap_mode == 1 && p.a_t >= 0.0f) || (p.gap_mode == 2 && wide_sub)) &&
 			vk_score32_lds_bytes(is_static ? 0 : c->nk32, c->tail, wave_tiles, q->len_t, 6) <= 160 * 1024 && (bound_pass || !getenv("VK_NO_SCORE32"));
-		if (bound_pass && !two_blocks)
-			return fail(VK_ERR_UNSUPPORTED, "exact transport with a query of more than 16 tokens: the multi-block kernel does not fit this corpus (LDS)");
+		if ((bound_pass || p.gap_mode == 7) && !two_blocks)
+			return fail(VK_ERR_UNSUPPORTED, "exact transport / 1:n RWMD with a query of more than 16 tokens: the multi-block kernel does not fit this corpus (LDS)");
+		if (p.gap_mode == 7) memcpy(wp.qmass, qmass_all, sizeof wp.qmass);
 		if (two_blocks) {
 			if (bound_pass) {
 				wp.gap_mode = 5;
@@ -400,6 +402,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		// ---- stage 2: exact EMD on the candidates with the largest bounds, until the k-th best
 		// exact score is above every remaining bound (then no unsolved sentence can enter)
 		VK_HIP(hipEventRecord(c->ev[2], st));
+		if (getenv("VK_WRD_TURNS")) c->ev2_recorded = true;   // experiment: bound passes take turns like the alignment kernels
 		// (no turn-taking between handles here: ev2_recorded stays unset.  Two bound passes sharing the chip, each with its
 		// long epilogue, fill each other's gaps: 336 M pairs/s with three handles against 302 M/s when they queue)
 		// Round 1: the M largest bounds.  Its k-th best exact score theta prunes: every row whose bound is below

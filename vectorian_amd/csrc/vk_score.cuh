@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 			float *sm = nullptr;
 			if (MODE == 2) {
 				sm = Hh + sigma * p.m_rows;
-				const float unit = p.rwmd_normalize_bow ? 1.0f / (float)(lenc > 0 ? lenc : 1) : 1.0f;
+				const float wsum = p.rwmd_normalize_bow ? (float)(lenc > 0 ? lenc : 1) : 1.0f;   // bow[i] /= w_sum (bow.h:262-270): a division, as upstream -- a mass that ties with a capacity must tie here too
 				for (int u = v; u < lenc; u += 16) {
 					const int id = p.tok_id[t_a + u];
 					int cnt = 0;
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 						cnt += same ? 1 : 0;
 						first = first && !(same && i < u);
 					}
-					sm[u] = first ? (float)cnt * unit : 0.0f;
+					sm[u] = first ? (float)cnt / wsum : 0.0f;
 				}
 				wave_lds_fence();
 			}

@@ -142,6 +142,96 @@ __device__ __forceinline__ float rwmd32(const float *__restrict__ S, int stride,
 	return (max_cost - cost) / max_cost;
 }
 
+// Relaxed word mover's distance, 1:n form (rwmd_fill_rows of vk_score_kernel over 16 NB columns; RelaxedSolver with injective =
+// false, vectorian/core/cpp/alignment/wmd.h:339-376, restated as upstream is written incl. the re-charged last shipment, :373-375).
+//   direction 0 (t -> s): lane = source (query token): its column is consumed in ascending (distance, row) order;
+//   direction 1 (s -> t): row = source; the lanes of the slice are the targets, the nearest unused one found by a minimum over
+//     keys (distance bits with the column in the low 6 bits) folded to the slice's last lane and read back with v_readlane.
+// smass: masses of the slice's vocabulary entries (static layout: count / len at a token's first occurrence, 0 at its
+// repetitions; null: every position an entry of its own), in wave-private LDS, one segment per slice of the wave.
+template <int NB>
+__device__ __forceinline__ float rwmd_fill32(const float *__restrict__ S, int stride, const float *__restrict__ smass, int rowbase, int len, int maxlen,
+	int col, int lane, const VkWideParams &p) {
+	constexpr int LPS = 16 * NB;
+	const int blk = col >> 4;
+	const int len_t = p.len_t;
+	const bool nbow = p.rwmd_normalize_bow != 0, col_ok = col < len_t;
+	const float cap_s = nbow ? 1.0f / (float)(len > 0 ? len : 1) : 1.0f;   // capacity of a slice position
+	const float INF = __builtin_inff();
+	const float q_mass = col_ok ? p.qmass[col < VK_DEV_MAX_WIDE_QUERY_LEN ? col : 0] : 0.0f;
+	const int sc = col < stride ? col : 0;
+	// ---- direction 0
+	float rem = q_mass, cost0 = 0.0f, last_d = -1.0f;
+	int last_i = -1;
+	bool fin = !(rem > 0.0f) || len < 1;
+	for (int round = 0; round < maxlen && __any(!fin); round++) {
+		float bd = INF;
+		int bi = -1;
+		for (int u = 1; u <= maxlen; u++) {
+			const bool act = u <= len;
+			const float dist = fmaxf(1.0f - S[(rowbase + (act ? u - 1 : 0)) * stride + sc], 0.0f);
+			const bool later = dist > last_d || (dist == last_d && u - 1 > last_i);
+			if (act && later && dist < bd) { bd = dist; bi = u - 1; }
+		}
+		if (!fin) {
+			const float cap = (smass && bi >= 0) ? smass[bi] : cap_s;
+			if (bi < 0) fin = true;
+			else if (rem <= cap) { cost0 += rem * bd; fin = true; }
+			else { rem -= cap; cost0 += cap * bd; last_d = bd; last_i = bi; }
+		}
+	}
+	if (rem > 0.0f) cost0 += rem;
+	float acc0 = 0.0f;
+	for (int j = 0; j < len_t; j++) {   // in column order, as the oracle sums
+		float xj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cost0), j));
+		if (NB == 2) {
+			const float xb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cost0), LPS + j));
+			xj = lane >= LPS ? xb : xj;
+		}
+		acc0 = j == 0 ? xj : acc0 + xj;
+	}
+	// ---- direction 1
+	float acc1 = 0.0f;
+	if (p.rwmd_symmetric) {
+		for (int u = 1; u <= maxlen; u++) {
+			const bool act = u <= len;
+			const float dist = fmaxf(1.0f - S[(rowbase + (act ? u - 1 : 0)) * stride + sc], 0.0f);
+			float r1 = act ? (smass ? smass[u - 1] : cap_s) : 0.0f;
+			float cost = 0.0f;
+			bool used = !col_ok, done = !(r1 > 0.0f);
+			for (int r = 0; r < len_t && __any(!done); r++) {
+				// nearest unused target: distances are >= 0, their bit patterns order like the values; ties go to the lower column
+				const float key = used ? INF : __builtin_bit_cast(float, (__builtin_bit_cast(int, dist) & ~63) | col);
+				const float best = -slice_max_to_last_lane<NB>(-key, blk);
+				float kb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, best), LPS - 1));
+				int tl = __builtin_bit_cast(int, kb) & 63;
+				float td = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dist), tl));
+				float tc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q_mass), tl));
+				if (NB == 2) {
+					const float kb2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, best), 63));
+					const int tl2 = __builtin_bit_cast(int, kb2) & 63;
+					const float td2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dist), LPS + (tl2 & (LPS - 1))));
+					const float tc2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q_mass), LPS + (tl2 & (LPS - 1))));
+					if (lane >= LPS) { kb = kb2; tl = tl2; td = td2; tc = tc2; }
+				}
+				if (!done) {
+					if (!(kb < INF)) done = true;
+					else if (r1 <= tc) { cost += r1 * td; done = true; }
+					else { r1 -= tc; cost += tc * td; }
+				}
+				if (col == tl && kb < INF) used = true;
+			}
+			if (r1 > 0.0f) cost += r1;
+			acc1 += cost;
+		}
+	}
+	if (!nbow) { acc0 = acc0 / (float)len_t; acc1 = acc1 / (float)(len > 0 ? len : 1); }
+	float cost = acc0;
+	if (p.rwmd_symmetric) { cost = 0.0f; if (acc0 > cost) cost = acc0; if (acc1 > cost) cost = acc1; }
+	const float max_cost = nbow ? 1.0f : (float)len_t;
+	return (max_cost - cost) / max_cost;
+}
+
 // sum over the lanes of a slice -> its last lane (any order: used for bounds only)
 template <int NB>
 __device__ __forceinline__ float slice_sum_to_last_lane(float x, int blk) {
@@ -448,6 +538,28 @@ __global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t
 		if constexpr (GAP == 3) raw = dp32_general<32, NB>(S, stride, rb, lenc, maxlen, col, lane, p, wsr, xch);
 		else if constexpr (GAP == 6) raw = dp32_general<64, NB>(S, stride, rb, lenc, maxlen, col, lane, p, wsr, xch);
 		else if constexpr (GAP == 4) raw = rwmd32<NB>(S, stride, rb, lenc, maxlen, col, lane, p);
+		else if constexpr (GAP == 7) {
+			// masses of the slice's vocabulary entries (static layout: repeated token ids count once, at their first position),
+			// kept behind the strip: LPS lanes fill the slice's (at most 64) entries
+			float *sm = nullptr;
+			if (STATIC) {
+				sm = xch + half * 64;
+				const float wsum = p.rwmd_normalize_bow ? (float)(lenc > 0 ? lenc : 1) : 1.0f;   // bow[i] /= w_sum (bow.h:262-270): a division, as upstream -- a mass that ties with a capacity must tie here too
+				for (int u = col; u < lenc; u += LPS) {
+					const int id = p.tok_id[t_a + u];
+					int cnt = 0;
+					bool first = true;
+					for (int i = 0; i < lenc; i++) {
+						const bool same = p.tok_id[t_a + i] == id;
+						cnt += same ? 1 : 0;
+						first = first && !(same && i < u);
+					}
+					sm[u] = first ? (float)cnt / wsum : 0.0f;
+				}
+				wave_lds_fence();
+			}
+			raw = rwmd_fill32<NB>(S, stride, sm, rb, lenc, maxlen, col, lane, p);
+		}
 		else if constexpr (GAP == 5) raw = transport_bound32<NB>(S, stride, rb, lenc, maxlen, col, lane, p,
 			p.mag ? (STATIC ? p.mag : p.mag + (len > 0 ? t_a : 0)) : nullptr, (STATIC && p.mag) ? p.tok_id + (len > 0 ? t_a : 0) : nullptr);
 		else raw = dp32<GAP, NB>(S, stride, rb, lenc, maxlen, col, p);
@@ -470,7 +582,7 @@ static inline int strip_stride(int len_t) { return (len_t + 3) / 4 * 4; }
 // the 64-row history, by the wave's copy of w_t (65); 16 otherwise (lanes beyond the strip's columns read into it).  Exact sizes
 // matter: at 32 query tokens and 300-d rows 1,280 bytes decide between two and three workgroups per CU (5.4 -> 4.3 ms).
 static inline int strip_slack(int gap_mode, int len_t) {
-	if (gap_mode == 6 && len_t > 32) return 144;
+	if ((gap_mode == 6 && len_t > 32) || gap_mode == 7) return 144;   // gap_mode 7: 2 x 64 vocabulary masses
 	return (gap_mode == 3 || gap_mode == 6) ? 64 : 16;
 }
 
@@ -493,6 +605,8 @@ extern "C" hipError_t vk_launch_score32(const VkWideParams *p, int32_t tiles, hi
 		: (is_static ? vk_score32_kernel<1, true, 2> : vk_score32_kernel<1, false, 2>); break;
 	case 4: kernel = four ? (is_static ? vk_score32_kernel<4, true, 4> : vk_score32_kernel<4, false, 4>)
 		: (is_static ? vk_score32_kernel<4, true, 2> : vk_score32_kernel<4, false, 2>); break;
+	case 7: kernel = four ? (is_static ? vk_score32_kernel<7, true, 4> : vk_score32_kernel<7, false, 4>)
+		: (is_static ? vk_score32_kernel<7, true, 2> : vk_score32_kernel<7, false, 2>); break;
 	case 5: kernel = four ? (is_static ? vk_score32_kernel<5, true, 4> : vk_score32_kernel<5, false, 4>)
 		: (is_static ? vk_score32_kernel<5, true, 2> : vk_score32_kernel<5, false, 2>); break;
 	case 3: kernel = four ? (is_static ? vk_score32_kernel<3, true, 4> : vk_score32_kernel<3, false, 4>)
