@@ -1,4 +1,4 @@
-// vk_common.cuh -- gfx950 (MI355X, CDNA4) kernels of the brute-force alignment search.
+// vk_common.hip.h -- gfx950 (MI355X, CDNA4) kernels of the brute-force alignment search.
 //
 // Written for wave64 / MFMA / LDS of gfx950 only (no portability layer).
 // Compiled with -ffp-contract=off: the DP recurrences must be the literal fp32
@@ -31,8 +31,8 @@
 // Shared by the translation units vk_*.hip: wave helpers, the similarity tile (MFMA) and the DP / transport row
 // sweeps.  Everything here is a template or __forceinline__ device function; the kernels live in the .hip files.
 
-#ifndef VK_COMMON_CUH
-#define VK_COMMON_CUH
+#ifndef VK_COMMON_HIP_H
+#define VK_COMMON_HIP_H
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -2,7 +2,7 @@
 // slice/static.h:366-416): a filtered corpus is the source corpus with the tokens that do not pass removed and the
 // slices re-indexed, built on the device once per distinct filter.  Every scoring kernel then runs on it unchanged
 // (the reference compacts each slice again for every query and document).
-#include "vk_common.cuh"
+#include "vk_common.hip.h"
 
 #include <hipcub/hipcub.hpp>
 

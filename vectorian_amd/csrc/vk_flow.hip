@@ -1,5 +1,5 @@
 // vk_flow.hip -- traceback of the winners (vk_flow_kernel) and the one-wave-per-slice kernel for long queries.
-#include "vk_common.cuh"
+#include "vk_common.hip.h"
 
 // ---------------------------------------------------------------------------
 // flow of the winners: one wave per winner recomputes the similarity rows with the

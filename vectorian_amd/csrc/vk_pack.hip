@@ -1,5 +1,5 @@
 // vk_pack.hip -- corpus upload (normalise, round, tile order) and the per-query table of the static layout.
-#include "vk_common.cuh"
+#include "vk_common.hip.h"
 
 // ---------------------------------------------------------------------------
 // corpus upload: L2-normalise rows (Vectors.normalized, vectorian/embedding/vectors.py:71-86),

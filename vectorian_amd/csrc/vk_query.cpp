@@ -242,7 +242,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	for (int i = 0; i < 80; i++) wt[i] = (is_align && i <= q->len_t) ? gap_cost(q->gap_t, i) : 0.0f;
 	for (int i = 80; i < 160; i++) wt[i] = 0.0f;
 	// The register-history kernels take their in-row candidates from the row's values before in-row gaps, which is the
-	// sequential recurrence with w_t replaced by its subadditive closure w* (dp_general_reg in vk_common.cuh): wt[80..159].
+	// sequential recurrence with w_t replaced by its subadditive closure w* (dp_general_reg in vk_common.hip.h): wt[80..159].
 	// (Round 1 sent every table that was not strictly subadditive -- a linear cost handed over as a table, a convex one -- to the
 	// LDS-history kernel with its serial in-row chain: 12.7 ms per 1 M x 32 tokens against 2.9 ms.)
 	bool wide_sub = false;   // a long query with general gaps: the multi-block kernel takes it

@@ -1,5 +1,5 @@
 // vk_rwmd_batch.hip -- batched relaxed WMD as an MFMA GEMM (BASELINE config 4).
-#include "vk_common.cuh"
+#include "vk_common.hip.h"
 
 // ---------------------------------------------------------------------------
 // Batched relaxed Word Mover's Distance (BASELINE config 4: 256 queries x 1M sentences):

@@ -1,5 +1,5 @@
 // vk_score.hip -- dispatch of the scoring kernel over its MODE translation units, and the span kernel.
-#include "vk_common.cuh"
+#include "vk_common.hip.h"
 
 extern "C" hipError_t vk_launch_score_m0(const VkScoreParams *p, int32_t grid, size_t smem_bytes, hipStream_t stream);
 extern "C" hipError_t vk_launch_score_m1(const VkScoreParams *p, int32_t grid, size_t smem_bytes, hipStream_t stream);

@@ -1,9 +1,9 @@
-// vk_score.cuh -- the fused scoring kernel and its launcher templates.  The instantiations are spread over
+// vk_score.hip.h -- the fused scoring kernel and its launcher templates.  The instantiations are spread over
 // vk_score_m0..m3.hip (one per similarity MODE) so that they compile in parallel.
-#ifndef VK_SCORE_CUH
-#define VK_SCORE_CUH
+#ifndef VK_SCORE_HIP_H
+#define VK_SCORE_HIP_H
 
-#include "vk_common.cuh"
+#include "vk_common.hip.h"
 
 // ---------------------------------------------------------------------------
 // the fused scoring kernel: one wave = 4 sentences at a time, grid-stride over groups.

@@ -9,7 +9,7 @@
 // vk_wide_kernel (one wave per slice, serial in-row chain) remains the path for gap costs that are not subadditive,
 // long slices, and the tracebacks of the winners: 29 ms per 1 M x 32-token slices there (20 tokens, linear gap),
 // 3.5 ms here.
-#include "vk_common.cuh"
+#include "vk_common.hip.h"
 
 // NB = column blocks of 16 per slice: 2 (two slices per wave, queries of 17..32 tokens) or 4 (one slice, 33..64).
 // lane 15 of every 16-lane row, handed to all lanes of the NEXT row of the same slice (rows 1 and 3 for NB = 2,

@@ -1,5 +1,5 @@
 // vk_score_batch.hip -- queries with common options sharing one pass over the token tiles.
-#include "vk_common.cuh"
+#include "vk_common.hip.h"
 
 // ---------------------------------------------------------------------------
 // A batch of queries with common options over one pass of the corpus (contextual layout): every token tile is

@@ -1,5 +1,5 @@
 // vk_select.hip -- bounded result sets (top-k), candidate selection and the small per-row kernels around them.
-#include "vk_common.cuh"
+#include "vk_common.hip.h"
 
 // ---------------------------------------------------------------------------
 // bounded result set: keys = (orderable(score) << 32) | sentence, descending.

@@ -1,5 +1,5 @@
 // vk_transport.hip -- exact transport of candidate slices (WRD, full WMD) and the similarity rows of winners.
-#include "vk_common.cuh"
+#include "vk_common.hip.h"
 
 // ---------------------------------------------------------------------------
 // Word Rotator's Distance / full WMD, stage 2: exact EMD for the candidate slices.
