@@ -59,12 +59,17 @@ def test_long_slices_contextual(hip, oracle, d):
 				assert sent in got.sentence[:got.n]
 			sc = c.last_scores()
 			np.testing.assert_allclose(sc, ref["all_scores"], atol=1e-4)
-	# transport: the relaxed distance has no length limit, the exact ones do
+	# transport: the relaxed distance and (since round 2, for queries of at most 16 tokens) the exact ones have no length limit
 	ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=off, X=Xb, Q=Qb, algorithm=oracle.ALG_RWMD, max_matches=15)
 	got = c.query(Qb, q_normalize=False, algorithm=hip.VK_ALG_RWMD, max_matches=15).trimmed()
 	assert_same_results(got, ref, check_mapping=False, score_tol=2e-5, tie_tol=2e-5)
-	with pytest.raises(hip.VkError):
-		c.query(Qb, q_normalize=False, algorithm=hip.VK_ALG_RWMD, rwmd=(False, False, True), wmd_full=True, max_matches=5)
+	if len(Qb) <= 16:
+		ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=off, X=Xb, Q=Qb, algorithm=oracle.ALG_RWMD, rwmd=(False, False, True), wmd_full=True, max_matches=5)
+		got = c.query(Qb, q_normalize=False, algorithm=hip.VK_ALG_RWMD, rwmd=(False, False, True), wmd_full=True, max_matches=5).trimmed()
+		assert_same_results(got, ref, check_mapping=False, score_tol=2e-5, tie_tol=2e-5)
+	else:
+		with pytest.raises(hip.VkError):
+			c.query(Qb, q_normalize=False, algorithm=hip.VK_ALG_RWMD, rwmd=(False, False, True), wmd_full=True, max_matches=5)
 	c.close()
 
 
@@ -127,4 +132,56 @@ def test_only_long_slices_and_limit(hip, oracle):
 	c.append_vectors(np.ones((513, 16), np.float32))
 	with pytest.raises(hip.VkError):
 		c.set_sentences(np.array([0, 513], dtype=np.int64))
+	c.close()
+
+
+@pytest.mark.parametrize("alg,opts", [
+	("wrd", dict(wrd_normalize=True)), ("wrd", dict(wrd_normalize=False)),
+	("wmd", dict(rwmd=(False, False, True), wmd_full=True)), ("wmd", dict(rwmd=(False, False, False), wmd_full=True)),
+])
+@pytest.mark.parametrize("layout", ["contextual", "static"])
+def test_exact_transport_over_long_slices(hip, oracle, layout, alg, opts):
+	"""Word Rotator's Distance and the full WMD over a corpus with sentences of 65..400 tokens (upstream sizes its transport problems
+	by the longest sentence, metric/alignment.h:357-358): bound pass of the one-slice-per-wave launch + vk_wrd_exact_long_kernel"""
+	rng = np.random.default_rng(12)
+	n = 260
+	lens = rng.integers(1, 50, size=n)
+	lens[rng.integers(0, n, size=40)] = rng.integers(65, 400, size=40)
+	lens[7] = 512
+	off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+	T, d, len_t = int(off[-1]), 64, 9
+	o_alg = oracle.ALG_WRD if alg == "wrd" else oracle.ALG_RWMD
+	h_alg = hip.VK_ALG_WRD if alg == "wrd" else hip.VK_ALG_RWMD
+	if layout == "static":
+		V = 300
+		E = (synth.make_vocab(V, d) * rng.lognormal(0, 0.3, size=(V, 1))).astype(np.float32)
+		Eb, emag = oracle.normalize_rows_bf16(E)
+		ids = synth.zipf_ids(T, V, rng)
+		c = hip.Corpus(layout=hip.VK_LAYOUT_STATIC, d=d, n_tokens=T, n_sentences=n, vocab_size=V, keep_magnitudes=True)
+		c.append_vectors(E, normalize=True)
+		c.set_token_ids(ids)
+	else:
+		X = (rng.standard_normal((T, d)) * rng.lognormal(0, 0.3, size=(T, 1))).astype(np.float32)
+		Xb, mag = oracle.normalize_rows_bf16(X)
+		c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=d, n_tokens=T, n_sentences=n, keep_magnitudes=True)
+		c.append_vectors(X, normalize=True)
+	c.set_sentences(off)
+	c.finalize()
+	for qi in range(3):
+		s = int(np.argsort(-lens)[qi * 5])                 # plant part of a long sentence
+		if layout == "static":
+			q_ids = ids[off[s] + 3:off[s] + 3 + len_t].astype(np.int32)
+			ref = oracle.find(layout=oracle.LAYOUT_STATIC, d=d, sent_off=off, tok_id=ids, E=Eb, X_mag=emag[ids], Q=Eb[q_ids], q_ids=q_ids, Q_mag=emag[q_ids],
+				algorithm=o_alg, max_matches=n, min_score=-1.0, **opts)
+			got = c.query(E[q_ids], q_token_ids=q_ids, q_normalize=True, algorithm=h_alg, max_matches=n, min_score=-1.0, **opts)
+		else:
+			qv = (X[off[s] + 3:off[s] + 3 + len_t] + 0.3 * rng.standard_normal((len_t, d))).astype(np.float32)
+			Qb, qmag = oracle.normalize_rows_bf16(qv)
+			ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=off, X=Xb, X_mag=mag, Q=Qb, Q_mag=qmag,
+				algorithm=o_alg, max_matches=n, min_score=-1.0, n_threads=8, **opts)
+			got = c.query(qv, q_normalize=True, algorithm=h_alg, max_matches=n, min_score=-1.0, **opts)
+		assert len(ref["sentence"]) == n   # every sentence is ranked: all the long ones are solved exactly
+		assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=2e-5, tie_tol=2e-5)
+	with pytest.raises(hip.VkError):   # queries of more than 16 tokens: the solver's wide form needs slices of at most 64 tokens
+		c.query(np.ones((20, d), np.float32), q_token_ids=np.zeros(20, np.int32) if layout == "static" else None, algorithm=hip.VK_ALG_WRD)
 	c.close()

@@ -682,40 +682,43 @@ __device__ __forceinline__ float wrd_bound_rows(const float *__restrict__ S, int
 	// v + 32, v + 48, and handed out row by row with ds_bpermute: a global load per row inside the sweep left the wave
 	// waiting on memory latency 64 times per group (static layout: magnitude of the vocabulary entry; no magnitudes:
 	// unit masses -- bags of words, full WMD)
-	float mreg[4];
-#pragma unroll
-	for (int c = 0; c < 4; c++) {
-		const int u0 = c * 16 + v;
-		float mg = 0.0f;
-		if (u0 < len) mg = mag ? (ids ? mag[ids[u0]] : mag[u0]) : 1.0f;
-		mreg[c] = mg;
-	}
+	// (slices of more than 64 tokens -- the one-slice-per-wave pass -- go through the same sweep 64 rows at a time)
 	const int lane_row = (int)(threadIdx.x & 48);
+	for (int base = 0; base < maxlen; base += 64) {
+		float mreg[4];
 #pragma unroll
-	for (int c = 0; c < 4; c++) {
-		const int u_end = maxlen < c * 16 + 16 ? maxlen : c * 16 + 16;
-		for (int u = c * 16 + 1; u <= u_end; u++) {
-			const bool act = u <= len;
-			const float s = S[(rowbase + (act ? u - 1 : 0)) * LT + v];
-			const float dist = fmaxf(1.0f - s, 0.0f);
-			// minimum over the query columns -> lane 15; distances are >= 0, so the integer order of the bits is theirs
-			// (v_min_i32 takes the DPP operand directly, fminf would canonicalise first)
-			int mi = __builtin_bit_cast(int, col_ok ? dist : BIG);
-			mi = min(mi, __builtin_amdgcn_update_dpp(mi, mi, DPP_ROW_SHR1, 0xf, 0xf, false));
-			mi = min(mi, __builtin_amdgcn_update_dpp(mi, mi, DPP_ROW_SHR2, 0xf, 0xf, false));
-			mi = min(mi, __builtin_amdgcn_update_dpp(mi, mi, DPP_ROW_SHR4, 0xf, 0xf, false));
-			mi = min(mi, __builtin_amdgcn_update_dpp(mi, mi, DPP_ROW_SHR8, 0xf, 0xf, false));
-			const float m = __builtin_bit_cast(float, mi);
-			const float mg = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane_row | ((u - 1) & 15)) * 4, __builtin_bit_cast(int, mreg[c])));
-			sum_s += mg;
-			lb1n += mg * m;
-			// insert (dist, mg) into the sorted four
-			float nd = act ? dist : BIG, nc = mg;
-			bool sw;
-			sw = nd < d4; d4 = sw ? nd : d4; c4 = sw ? nc : c4;
-			sw = d4 < d3; nd = d3; nc = c3; d3 = sw ? d4 : d3; c3 = sw ? c4 : c3; d4 = sw ? nd : d4; c4 = sw ? nc : c4;
-			sw = d3 < d2; nd = d2; nc = c2; d2 = sw ? d3 : d2; c2 = sw ? c3 : c2; d3 = sw ? nd : d3; c3 = sw ? nc : c3;
-			sw = d2 < d1; nd = d1; nc = c1; d1 = sw ? d2 : d1; c1 = sw ? c2 : c1; d2 = sw ? nd : d2; c2 = sw ? nc : c2;
+		for (int c = 0; c < 4; c++) {
+			const int u0 = base + c * 16 + v;
+			float mg = 0.0f;
+			if (u0 < len) mg = mag ? (ids ? mag[ids[u0]] : mag[u0]) : 1.0f;
+			mreg[c] = mg;
+		}
+#pragma unroll
+		for (int c = 0; c < 4; c++) {
+			const int u_end = maxlen < base + c * 16 + 16 ? maxlen : base + c * 16 + 16;
+			for (int u = base + c * 16 + 1; u <= u_end; u++) {
+				const bool act = u <= len;
+				const float s = S[(rowbase + (act ? u - 1 : 0)) * LT + v];
+				const float dist = fmaxf(1.0f - s, 0.0f);
+				// minimum over the query columns -> lane 15; distances are >= 0, so the integer order of the bits is theirs
+				// (v_min_i32 takes the DPP operand directly, fminf would canonicalise first)
+				int mi = __builtin_bit_cast(int, col_ok ? dist : BIG);
+				mi = min(mi, __builtin_amdgcn_update_dpp(mi, mi, DPP_ROW_SHR1, 0xf, 0xf, false));
+				mi = min(mi, __builtin_amdgcn_update_dpp(mi, mi, DPP_ROW_SHR2, 0xf, 0xf, false));
+				mi = min(mi, __builtin_amdgcn_update_dpp(mi, mi, DPP_ROW_SHR4, 0xf, 0xf, false));
+				mi = min(mi, __builtin_amdgcn_update_dpp(mi, mi, DPP_ROW_SHR8, 0xf, 0xf, false));
+				const float m = __builtin_bit_cast(float, mi);
+				const float mg = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane_row | ((u - 1) & 15)) * 4, __builtin_bit_cast(int, mreg[c])));
+				sum_s += mg;
+				lb1n += mg * m;
+				// insert (dist, mg) into the sorted four
+				float nd = act ? dist : BIG, nc = mg;
+				bool sw;
+				sw = nd < d4; d4 = sw ? nd : d4; c4 = sw ? nc : c4;
+				sw = d4 < d3; nd = d3; nc = c3; d3 = sw ? d4 : d3; c3 = sw ? c4 : c3; d4 = sw ? nd : d4; c4 = sw ? nc : c4;
+				sw = d3 < d2; nd = d2; nc = c2; d2 = sw ? d3 : d2; c2 = sw ? c3 : c2; d3 = sw ? nd : d3; c3 = sw ? nc : c3;
+				sw = d2 < d1; nd = d1; nc = c1; d1 = sw ? d2 : d1; c1 = sw ? c2 : c1; d2 = sw ? nd : d2; c2 = sw ? nc : c2;
+			}
 		}
 	}
 	const float lb1 = lb1n / sum_s * (1.0f - 2e-6f);

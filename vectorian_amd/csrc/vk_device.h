@@ -264,6 +264,7 @@ hipError_t vk_launch_topk_wave_batch(const float *scores, const uint64_t *keys_i
 	int64_t per_wave, int32_t n_queries, int64_t in_stride, int64_t out_stride, uint64_t *out, int64_t *n_waves_out, hipStream_t stream);
 hipError_t vk_launch_wrd_exact(const VkWrdParams *p, int32_t n_cand, float *scores_to_mark, hipStream_t stream);
 hipError_t vk_launch_rows(const VkWrdParams *p, int32_t n_cand, hipStream_t stream);
+hipError_t vk_launch_wrd_exact_long(const VkWrdParams *p, int32_t n_cand, hipStream_t stream);
 #ifdef __cplusplus
 }
 #endif

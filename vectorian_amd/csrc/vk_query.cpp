@@ -47,14 +47,16 @@ int vk_validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_topk_
 		if (q->rwmd_symmetric && !q->rwmd_normalize_bow)
 			return fail(VK_ERR_INVALID, "cannot run symmetric mode WMD with bow (needs nbow)");   // wmd.h:441-449
 		if (q->wmd_full) {
-			if (c->max_len > VK_FAST_SENT_LEN) return fail(VK_ERR_UNSUPPORTED, "full WMD needs every slice <= VK_FAST_SENT_LEN (64) tokens");
+			if (c->max_len > VK_FAST_SENT_LEN && q->len_t > VK_FAST_QUERY_LEN)
+				return fail(VK_ERR_UNSUPPORTED, "full WMD with a query of more than 16 tokens needs every slice <= VK_FAST_SENT_LEN (64) tokens");
 			if (q->rwmd_injective) return fail(VK_ERR_INVALID, "non-relaxed WMD with injective mapping is not supported");      // wmd.h:201-204
 			if (q->rwmd_symmetric) return fail(VK_ERR_INVALID, "non-relaxed WMD with symmetric computation is not supported");  // wmd.h:206-209
 		} else if (!q->rwmd_injective && q->len_t > VK_FAST_QUERY_LEN && c->max_len > VK_FAST_SENT_LEN)
 			return fail(VK_ERR_UNSUPPORTED, "non-injective RWMD (rwmd('nbow/distributed')) with a query of more than 16 tokens needs every slice <= VK_FAST_SENT_LEN (64) tokens");
 		if (q->want_flow && (!out->mapping || !out->edge_sim)) return fail(VK_ERR_INVALID, "want_flow needs mapping and edge_sim arrays");
 	} else if (q->algorithm == VK_ALG_WRD) {
-		if (c->max_len > VK_FAST_SENT_LEN) return fail(VK_ERR_UNSUPPORTED, "VK_ALG_WRD needs every slice <= VK_FAST_SENT_LEN (64) tokens");
+		if (c->max_len > VK_FAST_SENT_LEN && q->len_t > VK_FAST_QUERY_LEN)
+			return fail(VK_ERR_UNSUPPORTED, "VK_ALG_WRD with a query of more than 16 tokens needs every slice <= VK_FAST_SENT_LEN (64) tokens");
 		if (q->tag_weights) {
 			if (!q->q_pos) return fail(VK_ERR_INVALID, "tag-weighted query without q_pos");
 			if (!c->d_pos) return fail(VK_ERR_STATE, "tag-weighted query needs vk_corpus_set_token_pos");
@@ -141,8 +143,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	};
 	auto transport_flows = [&](const std::vector<int64_t> &rows_idx, bool exact, const float *qmass, int mass_mode, int raw_masses) -> int {
 		if (!q->want_flow || !out->sim_rows || rows_idx.empty()) return VK_OK;
-		if (c->max_len > VK_FAST_SENT_LEN) return VK_OK;
-		const int nqw = (q->len_t + 15) / 16, W = 16 * nqw;   // columns of a similarity row: the query length padded to 16
+		const int nqw = (q->len_t + 15) / 16, W = 16 * nqw;   // (winners of more than 64 tokens get zero rows: their flows are not stated)   // columns of a similarity row: the query length padded to 16
 		int rc2;
 		if (c->rows_w < W) {
 			if (c->d_rows_out) { VK_HIP(hipFree(c->d_rows_out)); VK_HIP(hipFree(c->d_plan_out)); c->d_rows_out = c->d_plan_out = nullptr; }
@@ -431,6 +432,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		auto solve = [&](const uint64_t *d_keys, int count, float *ub_min, int *n_cand_out) -> int {
 			w.keys = d_keys;
 			VK_HIP(vk_launch_wrd_exact(&w, count, c->d_scores, st));
+			if (c->max_len > VK_FAST_SENT_LEN) VK_HIP(vk_launch_wrd_exact_long(&w, count, st));   // candidates of 65 .. 512 tokens
 			keys.resize((size_t)count); vals.resize((size_t)count); raws.resize((size_t)count);
 			VK_HIP(hipMemcpyAsync(keys.data(), d_keys, (size_t)count * 8, hipMemcpyDeviceToHost, st));
 			VK_HIP(hipMemcpyAsync(vals.data(), c->d_wrd_val, (size_t)count * 4, hipMemcpyDeviceToHost, st));

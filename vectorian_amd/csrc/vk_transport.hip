@@ -120,6 +120,7 @@ __global__ __launch_bounds__(64) void vk_wrd_exact_kernel(VkWrdParams p) {
 	const int64_t g = (int64_t)(uint32_t)(key & 0xffffffffu);
 	const int t_a = p.sent_start[g], t_b = p.sent_end[g];
 	const int m = t_b - t_a, n = p.len_t;
+	if (m > VK_DEV_MAX_SENT_LEN) return;   // long slices: vk_wrd_exact_long_kernel
 
 	const int rowbase = transport_sim_rows<NQ>(p, S, t_a, t_b, lane);
 	wave_lds_fence();
@@ -314,6 +315,200 @@ __global__ __launch_bounds__(64) void vk_wrd_exact_kernel(VkWrdParams p) {
 	if (p.plan_out)
 		for (int j = 0; j < N; j++)
 			p.plan_out[((int64_t)w * N + j) * 64 + lane] = (has && j < n) ? (float)fl[j * 64 + lane] : 0.0f;
+}
+
+// ---------------------------------------------------------------------------
+// The same solver for slices of 65 .. VK_DEV_MAX_LONG_LEN tokens (long sentences, sliding windows; queries of at most 16
+// tokens): upstream sizes its transport problems by the document's longest sentence (metric/alignment.h:357-358,
+// alignment/wrd.h:76-85).  A demand no longer has a lane of its own: lane l owns demands l, l + 64, ..; distances, potentials,
+// predecessors and remaining masses live in LDS arrays, every per-demand step is a strided loop.  No greedy start (plain
+// successive shortest paths from the zero flow; the optimal cost is unique).  Such slices are rare: a fallback that keeps
+// corpora with a long sentence on the device, one wave per candidate, not a tuned kernel.  Costs are kept as floats (they
+// are floats: 1 - S), flows and potentials in double.
+// ---------------------------------------------------------------------------
+constexpr int VK_WRDL_N = 16;                         // supplies (query tokens)
+constexpr int VK_WRDL_M = VK_DEV_MAX_LONG_LEN;        // demands (slice tokens)
+
+__global__ __launch_bounds__(64) void vk_wrd_exact_long_kernel(VkWrdParams p) {
+	constexpr int N = VK_WRDL_N, M = VK_WRDL_M;
+	extern __shared__ double vk_smem_f64[];
+	double *fl = vk_smem_f64;                          // [N][M] flow
+	double *dem = fl + N * M, *pot_d = dem + M, *dist_d = pot_d + M;   // [M] each
+	double *sup = dist_d + M, *pot_s = sup + N, *dist_s = pot_s + N;  // [N] each
+	int *pred_d = reinterpret_cast<int *>(dist_s + N);                // [M]
+	int *pred_s = pred_d + M, *settled = pred_s + N;                   // [N]
+	float *Cm = reinterpret_cast<float *>(settled + N);                // [N][M] cost supply j -> demand i
+	float *S = Cm + N * M;                                             // [(M + 32)][16] similarity rows
+
+	const int lane = threadIdx.x;
+	const int w = blockIdx.x;
+	const uint64_t key = p.keys[w];
+	if (key == 0) return;
+	const int64_t g = (int64_t)(uint32_t)(key & 0xffffffffu);
+	const int t_a = p.sent_start[g], t_b = p.sent_end[g];
+	const int m = t_b - t_a, n = p.len_t;
+	if (m <= VK_DEV_MAX_SENT_LEN || m > M) return;   // short slices are vk_wrd_exact_kernel's
+
+	const int rowbase = transport_sim_rows<1>(p, S, t_a, t_b, lane);
+	wave_lds_fence();
+	const float *Sm = S + rowbase * 16;
+	const double EPS = 1e-13, INF = __builtin_inf();
+
+	// masses (wrd.h:99-102) and costs (:104-109)
+	if (p.mass_mode == 0) {
+		const bool by_id = p.layout == VK_DEV_LAYOUT_STATIC;
+		float sum_s = 0.0f;
+		for (int i = 0; i < m; i++) sum_s += by_id ? p.mag[p.tok_id[t_a + i]] : p.mag[t_a + i];   // position order, as upstream (uniform loop)
+		for (int i = lane; i < m; i += 64) {
+			const float mine = by_id ? p.mag[p.tok_id[t_a + i]] : p.mag[t_a + i];
+			dem[i] = (double)(p.raw_masses ? mine : mine / sum_s);
+		}
+		if (lane < N) sup[lane] = lane < n ? (double)p.qmass[lane] : 0.0;
+	} else {
+		const float wt = p.mass_mode == 1 ? 1.0f / (float)n : 1.0f;
+		const float wsn = p.mass_mode == 1 ? 1.0f / (float)m : 1.0f;
+		for (int i = lane; i < m; i += 64) dem[i] = (double)wsn;
+		if (lane < N) sup[lane] = lane < n ? (double)wt : 0.0;
+	}
+	if (lane < N) pot_s[lane] = 0.0;
+	for (int i = lane; i < m; i += 64) {
+		pot_d[i] = 0.0;
+		for (int j = 0; j < n; j++) {
+			float d = 1.0f - Sm[i * 16 + j];
+			if (!(d > 0.0f)) d = 0.0f;
+			Cm[j * M + i] = d;
+			fl[j * M + i] = 0.0;
+		}
+	}
+	wave_lds_fence();
+
+	for (int iter = 0; iter < 40000; iter++) {
+		// ---- sources: every supply with remaining mass; relax them all
+		bool any_sup = false;
+		uint32_t smask = 0;   // settled supplies (uniform)
+		for (int j = 0; j < n; j++) {
+			const bool src = sup[j] > EPS;
+			any_sup |= src;
+			if (src) smask |= 1u << j;
+			if (lane == 0) { settled[j] = src ? 1 : 0; dist_s[j] = src ? 0.0 : INF; pred_s[j] = -1; }
+		}
+		bool any_dem = false;
+		for (int i = lane; i < m; i += 64) {
+			double dd = INF;
+			int pd = -1;
+			for (int j = 0; j < n; j++) {
+				if (!((smask >> j) & 1)) continue;
+				double rc = (double)Cm[j * M + i] + pot_s[j] - pot_d[i];
+				if (rc < 0) rc = 0;
+				if (rc < dd) { dd = rc; pd = j; }
+			}
+			dist_d[i] = dd; pred_d[i] = pd;
+			any_dem |= dem[i] > EPS;
+		}
+		if (!any_sup || !__any(any_dem)) break;
+		wave_lds_fence();
+
+		int target = -1;
+		double dt = INF;
+		for (int round = 0; round <= n; round++) {
+			// nearest demand with remaining mass, and the cheapest way back into an unsettled supply
+			double fd_l = INF, best = INF;
+			int fd_i = -1, bb = -1, bi = -1;
+			for (int i = lane; i < m; i += 64) {
+				const double di = dist_d[i];
+				if (dem[i] > EPS && di < fd_l) { fd_l = di; fd_i = i; }
+				for (int b = 0; b < n; b++) {
+					if ((smask >> b) & 1) continue;
+					if (!(fl[b * M + i] > EPS)) continue;
+					double rc = pot_d[i] - pot_s[b] - (double)Cm[b * M + i];
+					if (rc < 0) rc = 0;
+					const double cand = di + rc;
+					if (cand < best) { best = cand; bb = b; bi = i; }
+				}
+			}
+			int fd_lane, c_lane;
+			const double fd = wave_argmin_f64(fd_l, lane, fd_lane);
+			const double cmin = wave_argmin_f64(best, lane, c_lane);
+			if (fd <= cmin) {
+				if (fd < INF) { target = __builtin_amdgcn_readlane(fd_i, fd_lane); dt = fd; }
+				break;
+			}
+			const int cb = __builtin_amdgcn_readlane(bb, c_lane);
+			const int ci = __builtin_amdgcn_readlane(bi, c_lane);
+			smask |= 1u << cb;
+			if (lane == 0) { settled[cb] = 1; dist_s[cb] = cmin; pred_s[cb] = ci; }
+			wave_lds_fence();
+			for (int i = lane; i < m; i += 64) {
+				double rc = (double)Cm[cb * M + i] + pot_s[cb] - pot_d[i];
+				if (rc < 0) rc = 0;
+				const double nd = cmin + rc;
+				if (nd < dist_d[i]) { dist_d[i] = nd; pred_d[i] = cb; }
+			}
+			wave_lds_fence();
+		}
+		if (target < 0) break;
+
+		// ---- potentials: pot += min(dist, dt)
+		for (int i = lane; i < m; i += 64) { const double di = dist_d[i]; pot_d[i] += di < dt ? di : dt; }
+		if (lane < n) pot_s[lane] += (settled[lane] && dist_s[lane] < dt) ? dist_s[lane] : dt;
+		wave_lds_fence();
+
+		// ---- bottleneck along target <- supply <- demand <- ... <- source, then augment (uniform walk over LDS)
+		double delta = dem[target];
+		int x = target;
+		for (int hop = 0; hop <= n; hop++) {
+			const int a = pred_d[x];
+			const int ps = pred_s[a];
+			if (ps < 0) { delta = fmin(delta, sup[a]); break; }
+			delta = fmin(delta, fl[a * M + ps]);
+			x = ps;
+		}
+		wave_lds_fence();
+		if (lane == 0) {
+			dem[target] -= delta;
+			x = target;
+			for (int hop = 0; hop <= n; hop++) {
+				const int a = pred_d[x];
+				const int ps = pred_s[a];
+				fl[a * M + x] += delta;
+				if (ps < 0) { sup[a] -= delta; break; }
+				fl[a * M + ps] -= delta;
+				x = ps;
+			}
+		}
+		wave_lds_fence();
+	}
+
+	// score = sum((1 - D) * G) / sum(G) (wrd.h:139), G as float
+	double num = 0.0, den = 0.0;
+	for (int i = lane; i < m; i += 64)
+		for (int j = 0; j < n; j++) {
+			const float gq = (float)fl[j * M + i];
+			num += (double)((1.0f - Cm[j * M + i]) * gq);
+			den += (double)gq;
+		}
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) { num += __shfl_xor(num, off, 64); den += __shfl_xor(den, off, 64); }
+	if (lane == 0) {
+		const float raw = den > 0.0 ? (float)(num / den) : 0.0f;
+		const float boost = p.boost ? p.boost[g] : 1.0f;
+		p.raw_out[w] = raw;
+		p.val_out[w] = (raw / p.ref_total) * boost;
+	}
+}
+
+static size_t transport_long_lds_bytes() {
+	const size_t N = VK_WRDL_N, M = VK_WRDL_M;
+	return N * M * 8 + 3 * M * 8 + 3 * N * 8 + M * 4 + 2 * N * 4 + N * M * 4 + (M + 32) * 16 * 4;
+}
+
+// candidates whose slice has more than VK_DEV_MAX_SENT_LEN tokens (the others return at once); queries of at most 16 tokens
+extern "C" hipError_t vk_launch_wrd_exact_long(const VkWrdParams *p, int32_t n_cand, hipStream_t stream) {
+	const size_t smem = transport_long_lds_bytes();
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(vk_wrd_exact_long_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+	if (e != hipSuccess) return e;
+	vk_wrd_exact_long_kernel<<<n_cand, 64, smem, stream>>>(*p);
+	return hipGetLastError();
 }
 
 // similarity rows of the winners of a transport query, for the host to state their flows: [64][16 nq] per winner

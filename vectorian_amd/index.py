@@ -770,8 +770,7 @@ class HipBruteForceIndex(Index):
 		"""the reference calls hook(name, data) for EVERY slice it scores (call_debug_hook, metric/alignment.h:145-173: slice,
 		similarity [len_s x len_t], flow, score = the aligner's score; WMD: 'alignment/word-movers-distance/make' with score and
 		worst_score, :600-607).  Here the scoring kernel keeps no per-slice matrices: the hook is called for the k winners, best
-		first, with the same keys; `similarity` is None for winners of corpora with slices of more than 64 tokens (their rows are
-		not produced)."""
+		first, with the same keys; `similarity` is None for winners of more than 64 tokens (their rows are not produced)."""
 		alg = args.get("algorithm", core.VK_ALG_ALIGN)
 		worst = float(matches[-1].score) if len(matches) >= args["max_matches"] else float(args["min_score"])
 		for i, m in enumerate(matches):
@@ -779,7 +778,7 @@ class HipBruteForceIndex(Index):
 				hook("alignment/word-movers-distance/make", {"score": m.score, "worst_score": worst, "slice": m.slice_id, "flow": m.flow})
 				continue
 			sim = None
-			if getattr(top, "sim_rows", None) is not None and m._len_s <= core.VK_FAST_SENT_LEN and self._max_slice_len <= core.VK_FAST_SENT_LEN:
+			if getattr(top, "sim_rows", None) is not None and m._len_s <= core.VK_FAST_SENT_LEN:
 				sim = top.sim_rows[i][:m._len_s if m._index_map is None else len(m._index_map), :len(p_query)].copy()
 			hook("alignment", {"slice": m.slice_id, "similarity": sim, "flow": m.flow, "score": m.raw_score})
 
