@@ -128,3 +128,153 @@ def test_config2_full_size_properties(hip, oracle):
 	assert list(merged.sentence[:10]) == list(top.sentence[:10])
 	np.testing.assert_array_equal(merged.score[:10], top.score[:10])
 	np.testing.assert_array_equal(merged.mapping[:10], top.mapping[:10])
+
+
+def test_config3_and_config4_full_size_properties(hip, oracle):
+	"""BASELINE configs[2] at its per-GPU size (1,250,000 sentences x 32 x 300-d, global alignment, linear gap 0.1) and configs[3]
+	(256 queries x the same kind of corpus, relaxed WMD as one GEMM-shaped pass), through properties:
+	  * config 3: a sample against the oracle, the selection against the full score vector, a planted copy first;
+	  * config 4: every query of the batch against the single-query path (same sentences, scores to 2e-6), a sample against the
+	    oracle."""
+	if torch is None:
+		pytest.skip("torch is needed to generate the shard on the device")
+	n3 = 1_250_000 // (1 << 15) * (1 << 15)            # whole chunks of the generator
+	rng = np.random.default_rng(12)
+	E = synth.make_vocab(V, D)
+	ids = synth.zipf_ids(n3 * LEN_S, V, rng)
+	qv = np.ascontiguousarray(E[rng.integers(0, V, size=LEN_T)] + 0.05 * rng.standard_normal((LEN_T, D)).astype(np.float32))
+	planted = {int(s): qv for s in (77_777, n3 - 1)}
+	sample = np.unique(np.concatenate((rng.integers(0, n3, size=2000), list(planted))))
+	c, kept = build(hip, torch, ids, E, 0, n3, sample, planted)
+	Xs = np.concatenate([kept[int(s)] for s in sample])
+	Xb, _ = oracle.normalize_rows_bf16(Xs)
+	soff = np.arange(len(sample) + 1, dtype=np.int64) * LEN_S
+
+	# ---- config 3: global alignment (Needleman-Wunsch), linear gap 0.1 on both axes
+	kw = dict(q_normalize=True, locality=1, gap_s=0.1, gap_t=0.1, max_matches=10, min_score=-1e9)
+	top = c.query(qv, **kw)
+	scores = c.last_scores()
+	assert scores.shape == (n3,) and np.isfinite(scores).all()
+	Qb, _ = oracle.normalize_rows_bf16(qv)
+	ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=D, sent_off=soff, X=Xb, Q=Qb, locality=1, gap_s=0.1, gap_t=0.1,
+		max_matches=10, min_score=-1e9, want_all_scores=True, n_threads=8)
+	np.testing.assert_allclose(scores[sample], ref["all_scores"], atol=1e-4, rtol=0)
+	order = np.lexsort((-np.arange(n3), -scores.astype(np.float64)))[:10]
+	assert list(top.sentence[:top.n]) == list(order)
+	np.testing.assert_array_equal(top.score[:top.n], scores[order])
+	assert set(top.sentence[:2]) == set(planted)
+	for i in range(2):                                   # the copy sits at tokens 5..14: the ten matches, 22 skipped tokens
+		assert list(top.mapping[i]) == list(range(5, 5 + LEN_T))
+		assert abs(top.score[i] - (LEN_T - 0.1 * (LEN_S - LEN_T)) / LEN_T) < 2e-3
+
+	# ---- config 4: 256 queries, rwmd('nbow') = relaxed, injective, symmetric, normalised
+	B = 256
+	qs = [np.ascontiguousarray(E[rng.integers(0, V, size=LEN_T)] + 0.05 * rng.standard_normal((LEN_T, D)).astype(np.float32)) for _ in range(B)]
+	targets = rng.integers(0, n3, size=B)
+	for i in range(0, B, 4):                             # every fourth query: a noisy copy of ten tokens of a sampled sentence
+		s = int(sample[int(rng.integers(0, len(sample)))])
+		qs[i] = np.ascontiguousarray(kept[s][3:3 + LEN_T] + 0.02 * rng.standard_normal((LEN_T, D)).astype(np.float32))
+		targets[i] = s
+	qs[5] = qs[5][:7]                                    # shorter queries in the same batch
+	qs[6] = qs[6][:1]
+	flags = (True, True, True)
+	outs = c.query_batch(qs, algorithm=hip.VK_ALG_RWMD, rwmd=flags, q_normalize=True, max_matches=10, min_score=0.0)
+	assert len(outs) == B
+	# (a noisy copy of part of a sentence need not win under the symmetric relaxed distance: the sentence's other 22 tokens count too)
+	for i in (0, 1, 4, 5, 6, 17, 100, 255):
+		single = c.query(qs[i], algorithm=hip.VK_ALG_RWMD, rwmd=flags, q_normalize=True, max_matches=10, min_score=0.0)
+		np.testing.assert_allclose(outs[i].score[:outs[i].n], single.score[:single.n], atol=2e-6, rtol=0)
+		diff = outs[i].sentence[:outs[i].n] != single.sentence[:single.n]
+		assert not diff.any() or np.abs(np.diff(single.score[:single.n]))[np.nonzero(diff)[0].clip(max=single.n - 2)].max() < 2e-6
+		Qi, _ = oracle.normalize_rows_bf16(qs[i])
+		r = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=D, sent_off=soff, X=Xb, Q=Qi, algorithm=oracle.ALG_RWMD, rwmd=flags,
+			max_matches=10, min_score=0.0, want_all_scores=True, n_threads=8)
+		np.testing.assert_allclose(c.last_scores()[sample], r["all_scores"], atol=2e-5, rtol=0)   # scores of the single-query pass
+	c.close()
+
+
+def test_config5_full_size_properties(hip, oracle):
+	"""BASELINE configs[4] at its per-GPU size: 1,000,000 sentences of 8..64 tokens x 768-d with their magnitudes (55 GB resident), WSB
+	local alignment and Word Rotator's Distance.  Alignment: a sample against the oracle, the selection against the score vector.
+	WRD (bound pass + exact EMD of the survivors): the winners' scores against the oracle on their regenerated vectors, no sampled
+	sentence above the k-th winner, a planted copy first."""
+	if torch is None:
+		pytest.skip("torch is needed to generate the shard on the device")
+	device = torch.device("cuda", 0)
+	n, d, len_t = 1_000_000, 768, 10
+	rng = np.random.default_rng(13)
+	lens = rng.integers(8, 65, size=n)
+	off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+	n_tok = int(off[-1])
+	E = synth.make_vocab(V, d)
+	E_dev = torch.from_numpy(E).to(device)
+	chunk_s = 1 << 14                                   # sentences per generator chunk
+
+	def chunk_vectors(a):
+		"""fp32 vectors of sentences [a, a + chunk_s): the same on every call (seeded per chunk), magnitudes spread by LogNormal(0, 0.25)"""
+		b = min(a + chunk_s, n)
+		gen = torch.Generator(device=device)
+		gen.manual_seed(500 + a)
+		nt = int(off[b] - off[a])
+		idx = torch.randint(0, V, (nt,), device=device, generator=gen)
+		x = E_dev[idx] + 0.3 * torch.randn((nt, d), device=device, generator=gen, dtype=torch.float32)
+		return (x * torch.exp(0.25 * torch.randn((nt, 1), device=device, generator=gen, dtype=torch.float32))).contiguous()
+
+	def sentence_vectors(s):
+		a = s // chunk_s * chunk_s
+		x = chunk_vectors(a)
+		return x[int(off[s] - off[a]):int(off[s + 1] - off[a])].cpu().numpy()
+
+	sample = np.unique(rng.integers(0, n, size=1500))
+	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=d, n_tokens=n_tok, n_sentences=n, keep_magnitudes=True)
+	kept = {}
+	for a in range(0, n, chunk_s):
+		x = chunk_vectors(a)
+		for s in sample[(sample >= a) & (sample < a + chunk_s)]:
+			kept[int(s)] = x[int(off[s] - off[a]):int(off[s + 1] - off[a])].cpu().numpy()
+		torch.cuda.synchronize()
+		c.append_vectors_device(x.data_ptr(), x.shape[0], hip.VK_F32, normalize=True)
+		del x
+	c.set_sentences(off)
+	c.finalize()
+	assert c.device_bytes > 55e9
+	src = int(sample[len(sample) // 2])
+	while lens[src] < len_t + 2:
+		src += 1
+	base = sentence_vectors(src)
+	qv = np.ascontiguousarray(base[1:1 + len_t] + 0.02 * rng.standard_normal((len_t, d)).astype(np.float32) * np.linalg.norm(base[1:1 + len_t], axis=1, keepdims=True) / np.sqrt(d))
+	Xs = np.concatenate([kept[int(s)] for s in sample])
+	Xb, mag = oracle.normalize_rows_bf16(Xs)
+	soff = np.concatenate(([0], np.cumsum(lens[sample]))).astype(np.int64)
+	Qb, qmag = oracle.normalize_rows_bf16(qv)
+
+	# ---- WSB local alignment
+	kw = dict(q_normalize=True, locality=0, gap_s=EXP5, gap_t=EXP5, max_matches=10, min_score=0.0)
+	top = c.query(qv, **kw)
+	scores = c.last_scores()
+	ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=soff, X=Xb, Q=Qb, locality=0, gap_s=EXP5, gap_t=EXP5,
+		max_matches=10, min_score=0.0, want_all_scores=True, n_threads=8)
+	np.testing.assert_allclose(scores[sample], ref["all_scores"], atol=1e-4, rtol=0)
+	order = np.lexsort((-np.arange(n), -scores.astype(np.float64)))[:10]
+	assert list(top.sentence[:top.n]) == list(order)
+	assert top.sentence[0] == src and list(top.mapping[0]) == list(range(1, 1 + len_t))
+
+	# ---- Word Rotator's Distance
+	for normalize in (True, False):
+		wrd = c.query(qv, algorithm=hip.VK_ALG_WRD, q_normalize=True, wrd_normalize=normalize, max_matches=10, min_score=0.0)
+		assert wrd.n == 10 and (np.diff(wrd.score[:10]) <= 0).all()
+		r = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=soff, X=Xb, X_mag=mag, Q=Qb, Q_mag=qmag, algorithm=oracle.ALG_WRD,
+			wrd_normalize=normalize, max_matches=10, min_score=0.0, want_all_scores=True, n_threads=8)
+		# no sampled sentence beats the k-th winner unless it is a winner itself
+		better = sample[r["all_scores"] > wrd.score[9] + 2e-5]
+		assert set(int(s) for s in better) <= set(int(s) for s in wrd.sentence[:10])
+		# the winners' scores, exactly: their vectors regenerated, the oracle solving each
+		for i in (0, 1, 4, 9):
+			xv = sentence_vectors(int(wrd.sentence[i]))
+			xb, xm = oracle.normalize_rows_bf16(xv)
+			one = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=np.array([0, len(xv)], dtype=np.int64), X=xb, X_mag=xm, Q=Qb, Q_mag=qmag,
+				algorithm=oracle.ALG_WRD, wrd_normalize=normalize, max_matches=1, min_score=-1.0)
+			assert abs(one["score"][0] - wrd.score[i]) < 2e-5
+		if normalize:
+			assert wrd.sentence[0] == src
+	c.close()
