@@ -23,6 +23,7 @@ under "configs" in the same JSON line (per entry: workload, value, kernel, kerne
   5     1 M sentences of 8..64 tokens x 768-d per GPU, WSB local alignment                  (config 5 = 4 M over 4 GPUs)
   5wrd  the same corpus, Word Rotator's Distance (bound pass + exact EMD of the survivors)
   2f32  config 2 with fp32 unit rows (VK_PREC_F32: the reference's own precision, twice the bytes)
+  2static  config 2's query over 4 M sentences in the reference's static layout (token ids + per-query table; DP-issue bound)
 """
 
 import argparse
@@ -52,6 +53,9 @@ WORKLOADS = {
 	"5wrd": dict(name="config5_wrd", n_sent=1000000, min_len=8, max_len=64, d=768, alg="wrd", locality="local", gap="linear", prec="bf16",
 		noise=0.3, norm_sigma=0.25, magnitudes=True),
 	"2f32": dict(name="config2_f32", n_sent=1000000, min_len=32, max_len=32, d=300, alg="align", locality="local", gap="exp5", prec="f32"),
+	# the reference's own layout for static embeddings (fastText / GloVe: token ids + vocabulary table, per-query table [V x |q|],
+	# StaticEmbeddingSlice, slice/static.h:71-75): no vectors are streamed, the kernel is bound by the DP's instruction issue
+	"2static": dict(name="config2_static", n_sent=4000000, min_len=32, max_len=32, d=300, alg="align", locality="local", gap="exp5", prec="bf16", layout="static"),
 }
 LOCALITIES = {"local": 0, "global": 1, "semiglobal": 2}
 
@@ -66,6 +70,8 @@ def gap_spec(name):
 def describe(spec, n_sent):
 	lens = f"{spec['min_len']}" if spec["min_len"] == spec["max_len"] else f"{spec['min_len']}..{spec['max_len']}"
 	rows = f"{n_sent} x {lens}-token synthetic sentences per GPU, {spec['d']}-d {spec['prec']} per-token vectors (contextual layout)"
+	if spec.get("layout") == "static":
+		rows = f"{n_sent} x {lens}-token synthetic sentences per GPU as token ids over a {VOCAB}-word {spec['d']}-d vocabulary (static layout: per-query table [V x |q|] + gather)"
 	if spec["alg"] == "rwmd":
 		return f"batch of {spec.get('batch', 1)} {LEN_T}-token queries over {rows}, relaxed Word Mover's Distance rwmd('nbow'), top-{K_MATCHES} per query"
 	if spec["alg"] == "wrd":
@@ -88,8 +94,13 @@ def build_shard(core, torch, spec, n_sent, rank, device):
 	off = np.zeros(n_sent + 1, dtype=np.int64)
 	np.cumsum(lens, out=off[1:])
 	n_tok = int(off[-1])
-	corpus = core.Corpus(layout=core.VK_LAYOUT_CONTEXTUAL, d=d, n_tokens=n_tok, n_sentences=n_sent,
-		keep_magnitudes=bool(spec.get("magnitudes")), precision=spec["prec"])
+	static = spec.get("layout") == "static"
+	if static:
+		corpus = core.Corpus(layout=core.VK_LAYOUT_STATIC, d=d, n_tokens=n_tok, n_sentences=n_sent, vocab_size=VOCAB, precision=spec["prec"])
+		corpus.append_vectors(E, normalize=True)
+	else:
+		corpus = core.Corpus(layout=core.VK_LAYOUT_CONTEXTUAL, d=d, n_tokens=n_tok, n_sentences=n_sent,
+			keep_magnitudes=bool(spec.get("magnitudes")), precision=spec["prec"])
 	E_dev = torch.from_numpy(E).to(device)
 	gen = torch.Generator(device=device)
 	gen.manual_seed(1000 + rank)
@@ -103,6 +114,8 @@ def build_shard(core, torch, spec, n_sent, rank, device):
 		b = min(a + chunk, n_tok)
 		idx = torch.searchsorted(cdf_dev, torch.rand(b - a, device=device, generator=gen, dtype=torch.float64)).clamp_(max=VOCAB - 1)
 		ids[a:b] = idx.to(torch.int32)
+		if static:
+			continue
 		x = E_dev[idx] + noise * torch.randn((b - a, d), device=device, generator=gen, dtype=torch.float32)
 		if sigma > 0:
 			x = x * torch.exp(sigma * torch.randn((b - a, 1), device=device, generator=gen, dtype=torch.float32))
@@ -110,6 +123,8 @@ def build_shard(core, torch, spec, n_sent, rank, device):
 		torch.cuda.synchronize()
 		corpus.append_vectors_device(x.data_ptr(), b - a, core.VK_F32, normalize=True)
 		del x, idx
+	if static:
+		corpus.set_token_ids(ids.cpu().numpy())
 	corpus.set_sentences(off)
 	corpus.finalize()
 	del E_dev, cdf_dev
@@ -117,8 +132,9 @@ def build_shard(core, torch, spec, n_sent, rank, device):
 	return corpus, E, ids, off
 
 
-def make_queries(E, ids, off, n_queries, seed):
-	"""half of the queries are noisy copies of LEN_T consecutive tokens of a corpus sentence (planted hits), half random"""
+def make_queries(E, ids, off, n_queries, seed, static=False):
+	"""half of the queries are noisy copies of LEN_T consecutive tokens of a corpus sentence (planted hits), half random;
+	static layout: the words themselves (their vectors and vocabulary ids)"""
 	rng = np.random.default_rng(seed)
 	n_sent = len(off) - 1
 	d = E.shape[1]
@@ -135,6 +151,9 @@ def make_queries(E, ids, off, n_queries, seed):
 					break
 		if qi is None:
 			qi = rng.integers(0, VOCAB, size=LEN_T)
+		if static:
+			qs.append((np.ascontiguousarray(E[qi], dtype=np.float32), np.asarray(qi, dtype=np.int32)))
+			continue
 		qs.append(np.ascontiguousarray(E[qi] + 0.05 * rng.standard_normal((LEN_T, d)).astype(np.float32), dtype=np.float32))
 	return qs
 
@@ -260,7 +279,10 @@ class Runner:
 		if self.batch:
 			tops = h.query_batch(q, **self.options)
 			return tops, h.last_timings()
-		top = h.query(q, **self.options)
+		if isinstance(q, tuple):   # static layout: vectors and vocabulary ids of the query's words
+			top = h.query(q[0], q_token_ids=q[1], **self.options)
+		else:
+			top = h.query(q, **self.options)
 		return [top], h.last_timings()
 
 	def _exchange(self):
@@ -334,6 +356,14 @@ def roofline_of(spec, n_sent, n_tok, kern_s):
 		ach = flops / kern_s
 		return {"bound": "mfma", "achieved": ach / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK,
 			"kernel": "vk_rwmd_batch32d_kernel", "kernel_ms": kern_s * 1e3, "algorithmic_flops_per_launch": flops}
+	if spec.get("layout") == "static":
+		# neither roofline binds this layout (SURVEY 8d "Mode B"): 4 bytes of token id per token are all that is streamed; the
+		# honest figures are cell updates per second and the (small) share of HBM bandwidth
+		nbytes = 4 * n_tok
+		ach = nbytes / kern_s
+		return {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
+			"kernel": "vk_score_kernel (static layout)", "kernel_ms": kern_s * 1e3, "algorithmic_bytes_per_launch": nbytes,
+			"gcups": n_tok * LEN_T / kern_s / 1e9, "note": "DP-issue bound: token ids + an L2-resident per-query table; GCUPS is the figure of merit"}
 	nbytes = n_tok * d * (4 if spec["prec"] == "f32" else 2) + (4 * n_tok if spec["alg"] == "wrd" else 0)
 	ach = nbytes / kern_s
 	return {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
@@ -369,7 +399,7 @@ def main():
 	ap.add_argument("--no-cpu-baseline", action="store_true")
 	ap.add_argument("--no-pipeline", action="store_true", help="one handle, one query at a time")
 	ap.add_argument("--no-extra", action="store_true", help="headline workload only (no \"configs\" object)")
-	ap.add_argument("--extra", default="4,3,2f32,5,5wrd", help="the other configurations timed at N = 1 after the headline")
+	ap.add_argument("--extra", default="4,3,2f32,2static,5,5wrd", help="the other configurations timed at N = 1 after the headline")
 	ap.add_argument("--extra-steps", type=int, default=12)
 	ap.add_argument("--extra-warmup", type=int, default=4)
 	ap.add_argument("--extra-scale", type=float, default=1.0, help="scales the sentence counts of the extra configurations (rehearsals)")
@@ -438,7 +468,8 @@ def main():
 			spec["gap"] = gap
 		if locality and spec["alg"] == "align":
 			spec["locality"] = locality
-		if keep is not None and keep.get("shape") == (n_sent, spec["min_len"], spec["max_len"], spec["d"], spec["prec"], bool(spec.get("magnitudes"))):
+		shape = (n_sent, spec["min_len"], spec["max_len"], spec["d"], spec["prec"], bool(spec.get("magnitudes")), spec.get("layout"))
+		if keep is not None and keep.get("shape") == shape:
 			corpus, E, ids, off = keep["shard"]
 		else:
 			if keep is not None and keep.get("shard"):
@@ -447,7 +478,7 @@ def main():
 				torch.cuda.empty_cache()
 			corpus, E, ids, off = build_shard(core, torch, spec, n_sent, rank, device)
 			if keep is not None:
-				keep["shape"] = (n_sent, spec["min_len"], spec["max_len"], spec["d"], spec["prec"], bool(spec.get("magnitudes")))
+				keep["shape"] = shape
 				keep["shard"] = (corpus, E, ids, off)
 		n_tok = int(off[-1])
 		batch = int(spec.get("batch", 0))
@@ -455,8 +486,8 @@ def main():
 			pool_q = make_queries(E, ids, off, batch + 8, seed=3456)
 			queries = [[pool_q[(i + j) % len(pool_q)] for j in range(batch)] for i in range(warmup + steps)]
 		else:
-			queries = make_queries(E, ids, off, warmup + steps, seed=3456)
-			if use_dist is not None:   # one query stream for the whole job: rank 0's
+			queries = make_queries(E, ids, off, warmup + steps, seed=3456, static=spec.get("layout") == "static")
+			if use_dist is not None and spec.get("layout") != "static":   # one query stream for the whole job: rank 0's
 				qt = torch.from_numpy(np.stack(queries)).to(xdev)
 				use_dist.broadcast(qt, src=0)
 				queries = list(qt.cpu().numpy())
