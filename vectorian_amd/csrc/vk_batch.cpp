@@ -275,7 +275,8 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 	// (uniform corpora of 16 / 32 / 48 / 64-token sentences run on the resident tiles; any other corpus of slices of at most 64
 	// tokens on a padded copy, bucket by bucket)
 	const bool uniform16 = c->contiguous && c->uniform_len > 0 && c->uniform_len % 16 == 0 && c->uniform_len <= 64;
-	bool gemm = c->finalized && c->prec == 0 && c->desc.layout == VK_LAYOUT_CONTEXTUAL && c->desc.n_sentences > 0 && qs[0].max_matches <= 64 &&
+	// (the kernels address a score row by a 32-bit sentence offset: 9 x n_sentences must stay below 2^31)
+	bool gemm = c->finalized && c->prec == 0 && c->desc.layout == VK_LAYOUT_CONTEXTUAL && c->desc.n_sentences > 0 && c->desc.n_sentences < (1ll << 27) && qs[0].max_matches <= 64 &&
 		vk_rwmd_batch_supported(c->nk32, c->tail) && (uniform16 || (c->max_len <= VK_FAST_SENT_LEN && c->entry_sent.empty() && !getenv("VK_BATCH_NO_RAGGED")));
 	for (int i = 0; i < n_queries && gemm; i++) {
 		const vk_query_desc &q = qs[i];
