@@ -172,6 +172,26 @@ __device__ __forceinline__ f32x4 sim_tile_qlds(const uint8_t *__restrict__ qlds,
 	return acc;
 }
 
+// fp32 unit rows (VK_PREC_F32, the reference's own precision), NB16 blocks of 16 features known at compile time: all the
+// tile's loads are issued up front (NB16 KiB in flight per wave, as the bf16 form keeps its whole tile in flight; the generic
+// loop below holds 4 KiB), the query tile is read from LDS block by block, four v_mfma_f32_16x16x4_f32 per block -- exact fp32
+// products, fp32 accumulation in k order.  Same MFMA sequence as sim_tile_generic(prec = 1): bit-identical similarities.
+template <int NB16>
+__device__ __forceinline__ f32x4 sim_tile_f32_qlds(const uint8_t *__restrict__ qlds, const uint8_t *__restrict__ tile, int lane) {
+	f32x4 x[NB16];
+#pragma unroll
+	for (int b = 0; b < NB16; b++) x[b] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(tile + b * 1024 + lane * 16));
+	f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+	for (int b = 0; b < NB16; b++) {
+		const f32x4 q = *reinterpret_cast<const f32x4 *>(qlds + b * 1024 + lane * 16);
+#pragma unroll
+		for (int e = 0; e < 4; e++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q[e], x[b][e], acc, 0, 0, 0);
+	}
+	acc[0] = clip01(acc[0]); acc[1] = clip01(acc[1]); acc[2] = clip01(acc[2]); acc[3] = clip01(acc[3]);
+	return acc;
+}
+
 // any d: query fragments re-read per K-step (L1/L2 resident), runtime trip count.
 // Same MFMA sequence as sim_tile, hence bit-identical similarities.
 __device__ __forceinline__ f32x4 sim_tile_generic(const uint8_t *__restrict__ qtile, const uint8_t *__restrict__ tile,

@@ -31,7 +31,8 @@ struct VkScoreParams {
 	int32_t nk32, tail, tile_bytes;
 	int32_t prec;              // 0: bf16 tiles (nk32 K-steps of 32); 1: fp32 tiles (nk32 blocks of 16 features)
 	int32_t q_lds;             // MODE 1: bytes of the query tile staged at the start of the dynamic LDS (0: read through L1 / L2)
-	int32_t q_mode3;           // 300-d bf16 rows: 1 = query tile in LDS (MODE 3, 136 VGPRs with general gaps), 0 = in registers (MODE 0, 160)
+	int32_t q_mode3;           // 300-d bf16 rows: 1 = query tile in LDS (MODE 3, 136 VGPRs with general gaps), 0 = in registers (MODE 0, 160);
+	                           // 300-d fp32 rows: 1 = the specialised form (MODE 4), 0 = the generic loop (MODE 1)
 	const int32_t *group_list; // null: all groups of 4 slices; else the groups holding one long slice each (64-thread blocks)
 	int32_t n_list;
 	int32_t max_short_len;     // main launch: groups with a longer slice are skipped

@@ -367,7 +367,8 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	const bool reg_history = p.gap_mode == 3 || p.gap_mode == 6;
 	if (!is_static && c->prec == 0 && c->nk32 == 10 && c->tail == 1)
 		p.q_mode3 = getenv("VK_QLDS") ? 1 : getenv("VK_QREG") ? 0 : (reg_history ? 1 : 0);
-	const size_t qlds = (!is_static && c->prec == 0 && ((c->nk32 == 24 && c->tail == 0) || p.q_mode3)) ? (size_t)c->nk32 * 1024 : 0;   // MODE 3: query tile in LDS
+	if (!is_static && c->prec == 1 && c->nk32 == 19 && !getenv("VK_NO_F32_SPECIAL")) p.q_mode3 = 1;   // fp32 rows at 300-d: MODE 4 (all 19 blocks of a tile in flight)
+	const size_t qlds = (!is_static && ((c->prec == 0 && c->nk32 == 24 && c->tail == 0) || p.q_mode3)) ? (size_t)c->nk32 * 1024 : 0;   // MODE 3 / 4: query tile in LDS
 	smem += qlds;
 	// the generic contextual kernel (MODE 1: fp32 tiles, or a d without a specialised form) stages the query tile in LDS when it fits
 	// beside the strips of at least two workgroups per CU

@@ -6,12 +6,14 @@ extern "C" hipError_t vk_launch_score_m1(const VkScoreParams *p, int32_t grid, s
 extern "C" hipError_t vk_launch_score_m2(const VkScoreParams *p, int32_t grid, size_t smem_bytes, hipStream_t stream);
 extern "C" hipError_t vk_launch_score_m3(const VkScoreParams *p, int32_t grid, size_t smem_bytes, hipStream_t stream);
 extern "C" hipError_t vk_launch_score_m3_300(const VkScoreParams *p, int32_t grid, size_t smem_bytes, hipStream_t stream);
+extern "C" hipError_t vk_launch_score_m4(const VkScoreParams *p, int32_t grid, size_t smem_bytes, hipStream_t stream);
 
 extern "C" hipError_t vk_launch_score(const VkScoreParams *pp, int32_t grid, size_t smem_bytes, hipStream_t stream) {
 	const VkScoreParams &p = *pp;
 	if (p.layout == VK_DEV_LAYOUT_STATIC) return vk_launch_score_m2(pp, grid, smem_bytes, stream);
 	if (p.prec == 0 && p.nk32 == 10 && p.tail == 1) return p.q_mode3 ? vk_launch_score_m3_300(pp, grid, smem_bytes, stream) : vk_launch_score_m0(pp, grid, smem_bytes, stream);
 	if (p.prec == 0 && p.nk32 == 24 && p.tail == 0) return vk_launch_score_m3(pp, grid, smem_bytes, stream);
+	if (p.prec == 1 && p.nk32 == 19 && p.q_mode3) return vk_launch_score_m4(pp, grid, smem_bytes, stream);   // fp32 rows, 300-d
 	return vk_launch_score_m1(pp, grid, smem_bytes, stream);
 }
 

@@ -11,6 +11,7 @@
 //   MODE 1: contextual layout, any d (runtime K loop)
 //   MODE 2: static layout: gather rows of the per-query table by token id
 //   MODE 3: contextual layout, NK32 K-steps, query tile staged in LDS (large d)
+//   MODE 4: contextual layout, fp32 tiles of NK32 blocks of 16 features (compile time), query tile staged in LDS
 // GAP: 0 linear, 1 affine, 2 general (LDS history, serial in-row chain),
 //      3 general, sentences <= 32 tokens, strictly subadditive w_t (register history),
 //      4 relaxed word mover's distance (no DP: row / column minima of 1 - S),
@@ -28,7 +29,7 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 	const int nwaves = blockDim.x >> 6;      // 4; 1 in the pass over long slices (group_list)
 	// MODE 3: the first NK32 KiB of the dynamic LDS hold the query tile (shared by the block's waves)
 	const uint8_t *qlds = reinterpret_cast<const uint8_t *>(smem);
-	if constexpr (MODE == 3) {
+	if constexpr (MODE == 3 || MODE == 4) {
 		for (int i = threadIdx.x; i < NK32 * 64; i += blockDim.x)
 			vk_smem4[i] = *reinterpret_cast<const float4 *>(p.qtile + i * 16);
 		__syncthreads();
@@ -159,6 +160,7 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 				f32x4 acc;
 				if constexpr (MODE == 0) acc = sim_tile<NK32, TAIL>(qf, tp, lane);
 				else if constexpr (MODE == 3) acc = sim_tile_qlds<NK32, TAIL>(qlds, tp, lane);
+				else if constexpr (MODE == 4) acc = sim_tile_f32_qlds<NK32>(qlds, tp, lane);
 				else if (MODE == 1 && p.q_lds > 0) acc = sim_tile_generic(qlds, tp, p.nk32, p.tail, lane, p.prec);
 				else acc = sim_tile_generic(p.qtile, tp, p.nk32, p.tail, lane, p.prec);
 				if (p.pos_s) {
