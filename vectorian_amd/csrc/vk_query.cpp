@@ -511,7 +511,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		float ms = 0;
 		vk_timings t{};
 		if (hipEventElapsedTime(&ms, c->ev[0], c->ev[5]) == hipSuccess) t.prepare_ms = ms;
-	if (hipEventElapsedTime(&ms, c->ev[5], c->ev[1]) == hipSuccess) t.queue_ms = ms;
+		if (hipEventElapsedTime(&ms, c->ev[5], c->ev[1]) == hipSuccess) t.queue_ms = ms;
 		if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) t.score_ms = ms;
 		if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) t.topk_ms = ms;
 		if (hipEventElapsedTime(&ms, c->ev[0], c->ev[4]) == hipSuccess) t.total_ms = ms - t.queue_ms;
@@ -617,10 +617,16 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 				}
 		}
 		out->n_out = (int)best.size();
+		if (out->sim_rows && !best.empty()) {   // similarity rows of the winners on request (debug hook)
+			std::vector<int64_t> rows_idx;
+			for (const Cand &b : best) rows_idx.push_back(b.row);
+			float no_mass[VK_MAX_QUERY_LEN] = {0};
+			if ((rc = transport_flows(rows_idx, false, no_mass, 0, 0))) return rc;
+		}
 		float ms = 0;
 		vk_timings t{};
 		if (hipEventElapsedTime(&ms, c->ev[0], c->ev[5]) == hipSuccess) t.prepare_ms = ms;
-	if (hipEventElapsedTime(&ms, c->ev[5], c->ev[1]) == hipSuccess) t.queue_ms = ms;
+		if (hipEventElapsedTime(&ms, c->ev[5], c->ev[1]) == hipSuccess) t.queue_ms = ms;
 		if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) t.score_ms = ms;
 		if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) t.topk_ms = ms;
 		if (hipEventElapsedTime(&ms, c->ev[0], c->ev[4]) == hipSuccess) t.total_ms = ms - t.queue_ms;
