@@ -1,3 +1,7 @@
+"""Probe kept from round 2: the 1:n RWMD (rwmd_fill32 / rwmd_fill_rows) over a static corpus of few distinct words against the oracle,
+slice by slice.  It found that a vocabulary mass computed as cnt * (1 / len) instead of cnt / len breaks exact ties between a mass and
+a capacity (1/17 against 3/51), which upstream's re-charged last shipment (wmd.h:373-375) turns into differences of up to 7e-3
+(DESIGN.md section 7).  Run on a GPU box from the repo root: python tools/probe/dbg_fill.py"""
 import sys, numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from vectorian_amd import core as hip, synth
