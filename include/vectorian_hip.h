@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 5
+#define VK_ABI_VERSION 6
 #define VK_MAX_QUERY_LEN 64   /* query tokens */
 #define VK_FAST_QUERY_LEN 16  /* queries up to this length run in the fused kernels (one 16-wide MFMA column block); longer ones
                                  take the multi-block kernel (2 or 4 column blocks) or, where that does not apply, a
@@ -238,6 +238,17 @@ int vk_last_timings(const vk_corpus_t *c, vk_timings *t);
  * sets (e.g. one per GPU rank after the all-gather) into one bounded set.
  * sentence indices must already be global. Pure host code. */
 int vk_merge_topk(const vk_topk_out *sets, int32_t n_sets, int32_t len_t, int32_t max_matches, vk_topk_out *out);
+
+/* The exchange records of the sharded path (one process per GPU; the only traffic per query is an all-gather of every
+ * rank's k records, vectorian_amd/shards.py): a result set as k fixed-size records of int32 words, so that the host
+ * part of the exchange -- packing before the collective, ResultSet::extend over all ranks' records after it -- is two
+ * calls whatever the number of ranks.  One record: valid, score, raw score, global slice index (2 words), mapping
+ * i16[W], edge_sim f32[W], padded to a multiple of 4 words; W = len_t rounded up to a multiple of 16. */
+int32_t vk_record_words(int32_t len_t);
+/* records: [k x vk_record_words(len_t)], rows >= set->n_out zeroed; slice indices become sentence_offset + local index */
+int vk_pack_records(const vk_topk_out *set, int32_t len_t, int32_t k, int64_t sentence_offset, int32_t *records);
+/* records: [n_sets x k x words] as the all-gather delivers them; out as for vk_merge_topk (capacity >= k) */
+int vk_merge_records(const int32_t *records, int32_t n_sets, int32_t len_t, int32_t k, vk_topk_out *out);
 
 #ifdef __cplusplus
 }

@@ -24,7 +24,7 @@ def test_every_declared_symbol_is_exported():
 	missing = [s for s in syms if not hasattr(lib, s)]
 	assert not missing, missing
 	assert sorted(core.EXPORTS) == syms
-	assert lib.vk_abi_version() == 5
+	assert lib.vk_abi_version() == 6
 
 
 def test_no_gpu_means_loud_failure():
@@ -54,3 +54,35 @@ def test_merge_topk_is_resultset_extend():
 	assert list(m.sentence[:4]) == [7, 100, 101, 12]
 	assert list(m.mapping[1]) == [5, 6, 7] and list(m.mapping[3]) == [1, -1, 2]
 	np.testing.assert_array_equal(m.score[:4], np.array([0.9, 0.7, 0.5, 0.5], np.float32))
+
+
+@pytest.mark.parametrize("len_t", [1, 10, 16, 17, 40, 64])
+def test_exchange_records_native_against_numpy(len_t):
+	# vk_pack_records writes the layout shards.pack_topk_numpy spells out; vk_merge_records over the records of several
+	# sets is vk_merge_topk over the sets
+	from vectorian_amd import core, shards
+	rng = np.random.default_rng(len_t)
+	k, world = 6, 5
+	sets, recs = [], []
+	for r in range(world):
+		t = core.TopK(k, len_t)
+		t.n = int(rng.integers(0, k + 1))
+		t.score[:t.n] = np.sort(rng.integers(0, 8, size=t.n).astype(np.float32) / 8)[::-1]   # ties across sets
+		t.raw_score[:t.n] = rng.random(t.n)
+		t.sentence[:t.n] = rng.integers(0, 1 << 40, size=t.n)
+		t.mapping[:t.n] = rng.integers(-1, 64, size=(t.n, len_t))
+		t.edge_sim[:t.n] = rng.random((t.n, len_t))
+		rec = shards.pack_topk(t, 1000 * r, k)
+		assert rec.shape == (k, core.record_words(len_t))
+		np.testing.assert_array_equal(rec, shards.pack_topk_numpy(t, 1000 * r, k))
+		back = shards.unpack_topk(rec, len_t)
+		assert back.n == t.n
+		np.testing.assert_array_equal(back.sentence[:t.n], t.sentence[:t.n] + 1000 * r)
+		np.testing.assert_array_equal(back.mapping[:t.n], t.mapping[:t.n])
+		sets.append(back)
+		recs.append(rec)
+	ref = core.merge_topk(sets, len_t, k)
+	got = core.merge_records(np.stack(recs), world, len_t, k)
+	assert got.n == ref.n
+	for f in ("score", "raw_score", "sentence", "mapping", "edge_sim"):
+		np.testing.assert_array_equal(getattr(got, f)[:got.n], getattr(ref, f)[:ref.n])

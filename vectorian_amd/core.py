@@ -91,7 +91,8 @@ EXPORTS = [
 	"vk_abi_version", "vk_last_error", "vk_init", "vk_device_count", "vk_corpus_view",
 	"vk_corpus_create", "vk_corpus_append_vectors", "vk_corpus_set_token_ids", "vk_corpus_set_token_pos", "vk_corpus_set_token_tags", "vk_corpus_filter",
 	"vk_corpus_set_sentences", "vk_corpus_set_slices", "vk_corpus_finalize", "vk_corpus_free", "vk_corpus_device_bytes",
-	"vk_query", "vk_query_batch", "vk_last_scores", "vk_last_timings", "vk_merge_topk"]
+	"vk_query", "vk_query_batch", "vk_last_scores", "vk_last_timings", "vk_merge_topk",
+	"vk_record_words", "vk_pack_records", "vk_merge_records"]
 
 _lib = None
 
@@ -146,7 +147,10 @@ def lib():
 		L.vk_last_scores.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 		L.vk_last_timings.argtypes = [C.c_void_p, C.POINTER(_Timings)]
 		L.vk_merge_topk.argtypes = [C.POINTER(_TopkOut), C.c_int32, C.c_int32, C.c_int32, C.POINTER(_TopkOut)]
-		if L.vk_abi_version() != 5:
+		L.vk_record_words.argtypes = [C.c_int32]
+		L.vk_pack_records.argtypes = [C.POINTER(_TopkOut), C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
+		L.vk_merge_records.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_TopkOut)]
+		if L.vk_abi_version() != 6:
 			raise RuntimeError("libvectorian_hip.so ABI version mismatch")
 		_lib = L
 	return _lib
@@ -255,6 +259,30 @@ def merge_topk(sets, len_t, max_matches):
 	out = TopK(max_matches, len_t)
 	so = out._struct()
 	_check(lib().vk_merge_topk(arr, len(sets), len_t, max_matches, C.byref(so)))
+	out.n = so.n_out
+	return out
+
+
+def record_words(len_t):
+	return int(lib().vk_record_words(len_t))
+
+
+def pack_records(top, sentence_offset, k, out=None):
+	"""the result set as k exchange records (vk_pack_records): int32 [k x record_words(len_t)]"""
+	if out is None:
+		out = np.empty((k, record_words(top.len_t)), dtype=np.int32)
+	s = top._struct()
+	_check(lib().vk_pack_records(C.byref(s), top.len_t, k, int(sentence_offset), _np_ptr(out)))
+	return out
+
+
+def merge_records(records, n_sets, len_t, k):
+	"""ResultSet.extend over the records of n_sets result sets (vk_merge_records); records: contiguous int32
+	[n_sets x k x words]"""
+	assert records.dtype == np.int32 and records.flags.c_contiguous and records.size == n_sets * k * record_words(len_t)
+	out = TopK(k, len_t)
+	so = out._struct()
+	_check(lib().vk_merge_records(_np_ptr(records), n_sets, len_t, k, C.byref(so)))
 	out.n = so.n_out
 	return out
 

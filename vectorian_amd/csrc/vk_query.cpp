@@ -761,4 +761,65 @@ int vk_merge_topk(const vk_topk_out *sets, int32_t n_sets, int32_t len_t, int32_
 	return VK_OK;
 }
 
+static inline int record_w(int len_t) { return (std::max(1, len_t) + 15) / 16 * 16; }
+
+int32_t vk_record_words(int32_t len_t) {
+	const int w = record_w(len_t);
+	return (5 + w / 2 + w + 3) / 4 * 4;
+}
+
+int vk_pack_records(const vk_topk_out *set, int32_t len_t, int32_t k, int64_t sentence_offset, int32_t *records) {
+	if (!set || !records || k < 0 || len_t < 1) return fail(VK_ERR_INVALID, "null argument");
+	if (set->n_out > k) return fail(VK_ERR_INVALID, "result set larger than k records");
+	const int w = record_w(len_t), words = vk_record_words(len_t);
+	memset(records, 0, (size_t)k * words * 4);
+	for (int i = 0; i < set->n_out; i++) {
+		int32_t *r = records + (size_t)i * words;
+		r[0] = 1;
+		memcpy(r + 1, set->score + i, 4);
+		if (set->raw_score) memcpy(r + 2, set->raw_score + i, 4);
+		const int64_t g = set->sentence[i] + sentence_offset;
+		memcpy(r + 3, &g, 8);
+		int16_t *m = (int16_t *)(r + 5);
+		for (int j = 0; j < w; j++) m[j] = -1;
+		if (set->mapping) memcpy(m, set->mapping + (size_t)i * len_t, (size_t)len_t * 2);
+		if (set->edge_sim) memcpy(r + 5 + w / 2, set->edge_sim + (size_t)i * len_t, (size_t)len_t * 4);
+	}
+	return VK_OK;
+}
+
+int vk_merge_records(const int32_t *records, int32_t n_sets, int32_t len_t, int32_t k, vk_topk_out *out) {
+	if (!records || !out || n_sets < 0 || k < 1 || len_t < 1) return fail(VK_ERR_INVALID, "null argument");
+	if (out->capacity < k) return fail(VK_ERR_INVALID, "output capacity smaller than k");
+	const int w = record_w(len_t), words = vk_record_words(len_t);
+	struct Ref { float score; int64_t sent; const int32_t *rec; };
+	std::vector<Ref> all;
+	all.reserve((size_t)n_sets * k);
+	for (size_t i = 0; i < (size_t)n_sets * k; i++) {
+		const int32_t *r = records + i * words;
+		if (!r[0]) continue;
+		Ref e;
+		memcpy(&e.score, r + 1, 4);
+		memcpy(&e.sent, r + 3, 8);
+		e.rec = r;
+		all.push_back(e);
+	}
+	// the order of vk_merge_topk (and of the selection on one GPU): score descending, ties by slice index descending
+	std::sort(all.begin(), all.end(), [](const Ref &a, const Ref &b) {
+		if (a.score != b.score) return a.score > b.score;
+		return a.sent > b.sent;
+	});
+	const int n_out = (int)std::min<size_t>(all.size(), (size_t)k);
+	for (int i = 0; i < n_out; i++) {
+		const int32_t *r = all[(size_t)i].rec;
+		out->score[i] = all[(size_t)i].score;
+		out->sentence[i] = all[(size_t)i].sent;
+		if (out->raw_score) memcpy(out->raw_score + i, r + 2, 4);
+		if (out->mapping) memcpy(out->mapping + (size_t)i * len_t, r + 5, (size_t)len_t * 2);
+		if (out->edge_sim) memcpy(out->edge_sim + (size_t)i * len_t, r + 5 + w / 2, (size_t)len_t * 4);
+	}
+	out->n_out = n_out;
+	return VK_OK;
+}
+
 } // extern "C"

@@ -31,6 +31,12 @@ def shard_ranges(n_sentences, world):
 
 
 def pack_topk(top, sentence_offset, k):
+	"""the k exchange records of a result set (native: vk_pack_records; the layout is _layout's)"""
+	return core.pack_records(top, sentence_offset, k)
+
+
+def pack_topk_numpy(top, sentence_offset, k):
+	"""the record layout written out in numpy: the tests hold vk_pack_records against it"""
 	w, words = _layout(top.len_t)
 	buf = np.zeros((k, words), dtype=np.int32)
 	n = top.n
@@ -77,7 +83,11 @@ def allgather_start(tops, sentence_offset, k, group=None, device=None):
 	world = dist.get_world_size(group)
 	if device is None:
 		device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-	rows = np.concatenate([pack_topk(t, sentence_offset, k) for t in tops])     # [len(tops) * k, words]
+	if len({_layout(t.len_t) for t in tops}) != 1:
+		raise ValueError("the result sets of one exchange must have the same record size (query lengths in the same multiple of 16)")
+	rows = np.empty((len(tops) * k, _layout(tops[0].len_t)[1]), dtype=np.int32)
+	for i, t in enumerate(tops):
+		core.pack_records(t, sentence_offset, k, out=rows[i * k:(i + 1) * k])
 	on_gpu = torch.device(device).type == "cuda"
 	if on_gpu:
 		# pinned staging on both sides and a stream of its own: no pageable copies, nothing on the default stream
@@ -119,10 +129,8 @@ def allgather_finish(handle):
 		handle["work"].wait()
 	world, k, n = handle["world"], handle["k"], handle["n"]
 	allr = handle["back"].numpy().reshape(world, n, k, -1)
-	out = []
-	for i in range(n):
-		sets = [unpack_topk(allr[r, i], handle["len_t"][i]) for r in range(world)]
-		out.append(core.merge_topk(sets, handle["len_t"][i], k))
+	# ResultSet.extend over every rank's records, one native call per query (vk_merge_records)
+	out = [core.merge_records(np.ascontiguousarray(allr[:, i]), world, handle["len_t"][i], k) for i in range(n)]
 	return out[0] if handle["single"] else out
 
 
