@@ -18,6 +18,22 @@ def test_shard_ranges():
 	assert shards.shard_ranges(2, 4) == [(0, 1), (1, 2), (2, 2), (2, 2)]
 
 
+def test_shard_ranges_by_tokens():
+	# equal slices: the cuts of shard_ranges; ragged slices: token counts within one slice of the ideal; always a partition
+	assert shards.shard_ranges_by_tokens([4] * 12, 3) == [(0, 4), (4, 8), (8, 12)]
+	assert shards.shard_ranges_by_tokens([], 3) == [(0, 0)] * 3
+	r = shards.shard_ranges_by_tokens([5, 5], 4)      # more ranks than slices: some ranks hold nothing
+	assert r[0][0] == 0 and r[-1][1] == 2 and all(r[i][1] == r[i + 1][0] for i in range(3)) and max(b - a for a, b in r) == 1
+	rng = np.random.default_rng(0)
+	for world in (2, 3, 8):
+		lens = rng.integers(1, 65, size=5000)
+		lens[:1000] = 64      # long slices first: equal slice counts would give rank 0 far more tokens
+		r = shards.shard_ranges_by_tokens(lens, world)
+		assert r[0][0] == 0 and r[-1][1] == len(lens) and all(r[i][1] == r[i + 1][0] for i in range(world - 1))
+		tok = [int(lens[a:b].sum()) for a, b in r]
+		assert max(tok) - min(tok) <= 2 * 64, tok
+
+
 def test_pack_roundtrip():
 	from vectorian_amd import core
 	t = core.TopK(5, 3)

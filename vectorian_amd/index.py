@@ -563,7 +563,7 @@ class HipBruteForceIndex(Index):
 		if shard is not None:
 			from vectorian_amd import shards
 			rank, world = shard
-			sa, sb = shards.shard_ranges(n_slices, world)[rank]
+			sa, sb = shards.shard_ranges_by_tokens(self._slice_end - self._slice_start, world)[rank]   # equal token counts per rank
 			self._slice_off = sa
 			t0 = int(self._slice_start[sa]) if sb > sa else 0
 			t1 = int(self._slice_end[sb - 1]) if sb > sa else 0

@@ -30,6 +30,28 @@ def shard_ranges(n_sentences, world):
 	return out
 
 
+def shard_ranges_by_tokens(slice_len, world):
+	"""contiguous slice ranges of (nearly) equal TOKEN counts (the work of a rank is the tokens it streams, so a
+	corpus of ragged slices is cut where the running token count crosses r / world of the total, not at equal slice
+	counts).  slice_len: tokens per slice; every rank computes the same cuts from the same array."""
+	slice_len = np.asarray(slice_len, dtype=np.int64)
+	n = len(slice_len)
+	if n == 0:
+		return [(0, 0)] * world
+	cum = np.cumsum(slice_len)
+	total = int(cum[-1])
+	cuts = [0]
+	for r in range(1, world):
+		target = total * r / world
+		i = int(np.searchsorted(cum, target, side="left"))      # first slice whose end reaches the target
+		# the cut after slice i or before it, whichever leaves the running count closer to the target
+		if i < n and (i == 0 or abs(int(cum[i]) - target) <= abs(int(cum[i - 1]) - target)):
+			i += 1
+		cuts.append(min(n, max(cuts[-1], i)))
+	cuts.append(n)
+	return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
 def pack_topk(top, sentence_offset, k):
 	"""the k exchange records of a result set (native: vk_pack_records; the layout is _layout's)"""
 	return core.pack_records(top, sentence_offset, k)
