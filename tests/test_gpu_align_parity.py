@@ -25,13 +25,18 @@ GAPS = {
 
 @pytest.mark.parametrize("locality", [0, 1, 2])
 @pytest.mark.parametrize("gap", list(GAPS))
-@pytest.mark.parametrize("shape", ["fixed32_q10", "ragged_q5", "ragged64_q16", "tiny_q1"])
+@pytest.mark.parametrize("shape", ["fixed32_q10", "ragged_q5", "ragged64_q16", "tiny_q1", "ragged_q7_d1040", "ragged_q12_d272", "ragged_q9_d160"])
 def test_contextual_parity(hip, oracle, locality, gap, shape):
 	n, lo, hi, len_t, d = {
 		"fixed32_q10": (600, 32, 32, 10, 300),
 		"ragged_q5": (500, 1, 40, 5, 300),
 		"ragged64_q16": (300, 8, 64, 16, 768),
 		"tiny_q1": (37, 1, 3, 1, 50),
+		# widths without a specialised kernel: the runtime K loop, eight K-steps deep from 256 features (32.5 / 8.5 K-steps: a
+		# full eight, the four-step remainder, single steps and the half block), four deep below
+		"ragged_q7_d1040": (250, 4, 64, 7, 1040),
+		"ragged_q12_d272": (300, 1, 50, 12, 272),
+		"ragged_q9_d160": (300, 1, 50, 9, 160),
 	}[shape]
 	corpus = synth.make_contextual_corpus(n, lo, hi, 2000, d)
 	Xb = prep_contextual(corpus)

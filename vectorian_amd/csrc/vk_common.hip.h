@@ -194,6 +194,10 @@ __device__ __forceinline__ f32x4 sim_tile_f32_qlds(const uint8_t *__restrict__ q
 
 // any d: query fragments re-read per K-step (L1/L2 resident), runtime trip count.
 // Same MFMA sequence as sim_tile, hence bit-identical similarities.
+// DEEP: eight K-steps (8 KiB per wave) in flight instead of four -- rows of 256 features and more, where the tile loop of a
+// ragged corpus otherwise runs out of loads in flight (1024-d, U{8..64} tokens: 4.9 -> 5.5 TB/s; tools/sweep_dims.py); costs
+// 24 VGPRs, so the narrower rows keep the four-deep form and their occupancy.
+template <bool DEEP = false>
 __device__ __forceinline__ f32x4 sim_tile_generic(const uint8_t *__restrict__ qtile, const uint8_t *__restrict__ tile,
 	int nk, int half, int lane, int prec = 0) {
 	f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -224,6 +228,16 @@ __device__ __forceinline__ f32x4 sim_tile_generic(const uint8_t *__restrict__ qt
 	}
 	const int nfull = half ? nk - 1 : nk;
 	int t = 0;
+	if constexpr (DEEP)
+	for (; t + 8 <= nfull; t += 8) {
+		bf16x8 q[8], x[8];
+#pragma unroll
+		for (int i = 0; i < 8; i++) x[i] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(tile + (t + i) * 1024 + lane * 16));
+#pragma unroll
+		for (int i = 0; i < 8; i++) q[i] = *reinterpret_cast<const bf16x8 *>(qtile + (t + i) * 1024 + lane * 16);
+#pragma unroll
+		for (int i = 0; i < 8; i++) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q[i], x[i], acc, 0, 0, 0);
+	}
 	for (; t + 4 <= nfull; t += 4) {   // four K-steps in flight
 		bf16x8 q[4], x[4];
 #pragma unroll

@@ -3,6 +3,7 @@
 
 extern "C" hipError_t vk_launch_score_m0(const VkScoreParams *p, int32_t grid, size_t smem_bytes, hipStream_t stream);
 extern "C" hipError_t vk_launch_score_m1(const VkScoreParams *p, int32_t grid, size_t smem_bytes, hipStream_t stream);
+extern "C" hipError_t vk_launch_score_m5(const VkScoreParams *p, int32_t grid, size_t smem_bytes, hipStream_t stream);
 extern "C" hipError_t vk_launch_score_m2(const VkScoreParams *p, int32_t grid, size_t smem_bytes, hipStream_t stream);
 extern "C" hipError_t vk_launch_score_m3(const VkScoreParams *p, int32_t grid, size_t smem_bytes, hipStream_t stream);
 extern "C" hipError_t vk_launch_score_m3_300(const VkScoreParams *p, int32_t grid, size_t smem_bytes, hipStream_t stream);
@@ -14,6 +15,7 @@ extern "C" hipError_t vk_launch_score(const VkScoreParams *pp, int32_t grid, siz
 	if (p.prec == 0 && p.nk32 == 10 && p.tail == 1) return p.q_mode3 ? vk_launch_score_m3_300(pp, grid, smem_bytes, stream) : vk_launch_score_m0(pp, grid, smem_bytes, stream);
 	if (p.prec == 0 && p.nk32 == 24 && p.tail == 0) return vk_launch_score_m3(pp, grid, smem_bytes, stream);
 	if (p.prec == 1 && p.nk32 == 19 && p.q_mode3) return vk_launch_score_m4(pp, grid, smem_bytes, stream);   // fp32 rows, 300-d
+	if (p.prec == 0 && p.nk32 >= 8) return vk_launch_score_m5(pp, grid, smem_bytes, stream);   // wide rows: deeper load pipeline
 	return vk_launch_score_m1(pp, grid, smem_bytes, stream);
 }
 
@@ -52,7 +54,7 @@ static hipError_t launch_span(const VkScoreParams &p, hipStream_t stream) {
 	if (e != hipSuccess) return e;
 	if (occ < 1) occ = 1;
 	if (occ > 3) occ = 3;   // as vk_score_kernel: 12 waves per CU stream HBM fastest
-	static const char *ov = getenv("VK_BLOCKS_PER_CU");
+	const char *ov = getenv("VK_BLOCKS_PER_CU");   // read per launch: tools/sweep_dims.py varies it inside one process
 	if (ov && atoi(ov) > 0) occ = atoi(ov);
 	if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
 	const int64_t want = (((int64_t)p.n_sent + 15) / 16 + 3) / 4, cap = (int64_t)cus * occ;

@@ -12,6 +12,7 @@
 //   MODE 2: static layout: gather rows of the per-query table by token id
 //   MODE 3: contextual layout, NK32 K-steps, query tile staged in LDS (large d)
 //   MODE 4: contextual layout, fp32 tiles of NK32 blocks of 16 features (compile time), query tile staged in LDS
+//   MODE 5: MODE 1 for bf16 rows of 256 features and more: eight K-steps in flight instead of four
 // GAP: 0 linear, 1 affine, 2 general (LDS history, serial in-row chain),
 //      3 general, sentences <= 32 tokens, strictly subadditive w_t (register history),
 //      4 relaxed word mover's distance (no DP: row / column minima of 1 - S),
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 	}
 	// MODE 1 (any d, fp32 tiles): the same staging with a runtime size; the K loop then reads the query with ds_read instead of
 	// going through L1 for every token tile
-	if constexpr (MODE == 1) {
+	if constexpr (MODE == 1 || MODE == 5) {
 		if (p.q_lds > 0) {
 			for (int i = threadIdx.x; i * 16 < p.q_lds; i += blockDim.x)
 				vk_smem4[i] = i * 16 < p.tile_bytes ? *reinterpret_cast<const float4 *>(p.qtile + i * 16) : float4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -161,6 +162,8 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 				if constexpr (MODE == 0) acc = sim_tile<NK32, TAIL>(qf, tp, lane);
 				else if constexpr (MODE == 3) acc = sim_tile_qlds<NK32, TAIL>(qlds, tp, lane);
 				else if constexpr (MODE == 4) acc = sim_tile_f32_qlds<NK32>(qlds, tp, lane);
+				else if (MODE == 5 && p.q_lds > 0) acc = sim_tile_generic<true>(qlds, tp, p.nk32, p.tail, lane, p.prec);
+				else if (MODE == 5) acc = sim_tile_generic<true>(p.qtile, tp, p.nk32, p.tail, lane, p.prec);
 				else if (MODE == 1 && p.q_lds > 0) acc = sim_tile_generic(qlds, tp, p.nk32, p.tail, lane, p.prec);
 				else acc = sim_tile_generic(p.qtile, tp, p.nk32, p.tail, lane, p.prec);
 				if (p.pos_s) {
@@ -251,11 +254,18 @@ static hipError_t launch_sized(K kernel, const VkScoreParams &p, int want_blocks
 	// the transport bound (WRD / full WMD stage 1) has the longest epilogue per group and wants every wave it can get to
 	// hide it: 1 M x 32 x 300-d 3.54 ms at 3 per CU, 3.08 at 4; 768-d 4.31 ms at 1, 3.37 at 2
 	const bool bound_pass = p.gap_mode == 5 || (p.gap_mode == 4 && p.wmd_bound == 1);
-	if (occ > 3 && p.layout != VK_DEV_LAYOUT_STATIC && !bound_pass) occ = 3;   // the static layout is DP-bound, not a stream: keep full residency
+	// narrow rows (d <= 96) are not a stream either: a slice is 6 KB or less and the DP dominates -- 64-d, 32 tokens: 3.4 TB/s at
+	// 3 per CU, 4.8 TB/s at 5; 96-d: 3.7 against 5.4 TB/s.  129..224-d: 4 per CU stream 4-8 % faster than 3 (6.4 against
+	// 6.0 TB/s); 128-d and 256..1536-d: 3 per CU within 2 % of the best setting (tools/sweep_dims.py, profiles/r02_sweep_dims*.jsonl)
+	const bool dp_bound = p.layout == VK_DEV_LAYOUT_STATIC || p.nk32 <= 3;
+	const int stream_cap = (p.nk32 >= 5 && p.nk32 <= 7) ? 4 : 3;
+	if (occ > stream_cap && !dp_bound && !bound_pass) occ = stream_cap;   // the static layout is DP-bound, not a stream: keep full residency
 	// 768-d rows: a wave already keeps 24 KiB of loads in flight per tile; one workgroup per CU measured fastest
 	// (ragged 8..64 tokens, 400 k sentences: 3.37 ms at 1, 3.45 ms at 2 per CU)
-	if (p.nk32 >= 24 && p.prec == 0 && p.layout != VK_DEV_LAYOUT_STATIC && !bound_pass) occ = 1;
-	static const char *ov = getenv("VK_BLOCKS_PER_CU");
+	// -- the 768-d specialisation only: the generic kernel at 1024-d loses 20 % (32 tokens) to 38 % (ragged) with one group
+	// per CU (tools/sweep_dims.py)
+	if (p.nk32 == 24 && p.tail == 0 && p.prec == 0 && p.layout != VK_DEV_LAYOUT_STATIC && !bound_pass) occ = 1;
+	const char *ov = getenv("VK_BLOCKS_PER_CU");   // read per launch: tools/sweep_dims.py varies it inside one process
 	if (ov && atoi(ov) > 0) occ = atoi(ov) < real_occ ? atoi(ov) : real_occ;
 	int dev = 0, cus = 256;
 	if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);

@@ -623,7 +623,7 @@ extern "C" hipError_t vk_launch_score32(const VkWideParams *p, int32_t tiles, hi
 	e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, smem);
 	if (e != hipSuccess) return e;
 	if (occ < 1) occ = 1;
-	static const char *ov = getenv("VK_BLOCKS_PER_CU");
+	const char *ov = getenv("VK_BLOCKS_PER_CU");   // read per launch: tools/sweep_dims.py varies it inside one process
 	if (ov && atoi(ov) > 0 && atoi(ov) < occ) occ = atoi(ov);
 	int dev = 0, cus = 256;
 	if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
