@@ -26,6 +26,7 @@ def main():
 	ap.add_argument("--ragged", action="store_true", help="slice lengths U{8..64} instead of --len-s")
 	ap.add_argument("--reps", type=int, default=5)
 	ap.add_argument("--max-setting", type=int, default=5)
+	ap.add_argument("--precision", choices=["bf16", "f32"], default="bf16", help="how the unit rows are kept in HBM")
 	args = ap.parse_args()
 
 	import torch
@@ -38,14 +39,15 @@ def main():
 	for d in [int(x) for x in args.dims.split(",")]:
 		rng = np.random.default_rng(d)
 		mean_len = 36 if args.ragged else args.len_s
-		n_sent = int(args.gbytes * 1e9 / (mean_len * d * 2))
+		esz = 4 if args.precision == "f32" else 2
+		n_sent = int(args.gbytes * 1e9 / (mean_len * d * esz))
 		lens = rng.integers(8, 65, size=n_sent) if args.ragged else np.full(n_sent, args.len_s)
 		off = np.zeros(n_sent + 1, dtype=np.int64)
 		np.cumsum(lens, out=off[1:])
 		n_tok = int(off[-1])
 		E = synth.make_vocab(V, d)
 		E_dev = torch.from_numpy(E).to(device)
-		corpus = core.Corpus(layout=core.VK_LAYOUT_CONTEXTUAL, d=d, n_tokens=n_tok, n_sentences=n_sent)
+		corpus = core.Corpus(layout=core.VK_LAYOUT_CONTEXTUAL, d=d, n_tokens=n_tok, n_sentences=n_sent, precision=args.precision)
 		gen = torch.Generator(device=device)
 		gen.manual_seed(7)
 		chunk = 1 << 20
@@ -60,7 +62,7 @@ def main():
 		corpus.finalize()
 		qs = [np.ascontiguousarray(E[rng.integers(0, V, size=10)] + 0.05 * rng.standard_normal((10, d)).astype(np.float32)) for _ in range(args.reps + 1)]
 		for gname, gap in gaps.items():
-			row = {"d": d, "gap": gname, "sentences": n_sent, "len_s": "U{8..64}" if args.ragged else args.len_s, "bytes": n_tok * d * 2, "GBps": {}, "ms": {}}
+			row = {"d": d, "gap": gname, "sentences": n_sent, "len_s": "U{8..64}" if args.ragged else args.len_s, "precision": args.precision, "bytes": n_tok * d * esz, "GBps": {}, "ms": {}}
 			for setting in ["default"] + [str(i) for i in range(1, args.max_setting + 1)]:
 				if setting == "default":
 					os.environ.pop("VK_BLOCKS_PER_CU", None)
@@ -73,7 +75,7 @@ def main():
 						ms.append(corpus.last_timings()["score_ms"])
 				t = float(np.median(ms))
 				row["ms"][setting] = round(t, 4)
-				row["GBps"][setting] = round(n_tok * d * 2 / (t * 1e-3) / 1e9, 1)
+				row["GBps"][setting] = round(n_tok * d * esz / (t * 1e-3) / 1e9, 1)
 			os.environ.pop("VK_BLOCKS_PER_CU", None)
 			best = max((k for k in row["GBps"] if k != "default"), key=lambda k: row["GBps"][k])
 			row["best_forced"] = best

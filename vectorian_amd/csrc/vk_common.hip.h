@@ -181,6 +181,8 @@ __device__ __forceinline__ f32x4 sim_tile_f32_qlds(const uint8_t *__restrict__ q
 	f32x4 x[NB16];
 #pragma unroll
 	for (int b = 0; b < NB16; b++) x[b] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(tile + b * 1024 + lane * 16));
+	// without the barrier the machine scheduler sinks every load to its MFMAs to save registers and leaves 2 - 3 KiB in flight
+	__builtin_amdgcn_sched_barrier(0);
 	f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
 	for (int b = 0; b < NB16; b++) {
@@ -197,20 +199,36 @@ __device__ __forceinline__ f32x4 sim_tile_f32_qlds(const uint8_t *__restrict__ q
 // DEEP: eight K-steps (8 KiB per wave) in flight instead of four -- rows of 256 features and more, where the tile loop of a
 // ragged corpus otherwise runs out of loads in flight (1024-d, U{8..64} tokens: 4.9 -> 5.5 TB/s; tools/sweep_dims.py); costs
 // 24 VGPRs, so the narrower rows keep the four-deep form and their occupancy.
-template <bool DEEP = false>
+// PREC: -1 the row type is the runtime argument `prec`; 0 / 1: bf16 / fp32 rows known at compile time (the scoring kernel
+// instantiates one form per row type, so that the registers of the fp32 batches do not count against the bf16 kernels).
+template <bool DEEP = false, int PREC = -1>
 __device__ __forceinline__ f32x4 sim_tile_generic(const uint8_t *__restrict__ qtile, const uint8_t *__restrict__ tile,
 	int nk, int half, int lane, int prec = 0) {
 	f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-	if (prec) {
+	if (PREC == 1 || (PREC < 0 && prec)) {
 		// fp32 rows (the reference's own precision): nk blocks of 16 features, four v_mfma_f32_16x16x4_f32 per block
 		int b = 0;
+		if constexpr (DEEP)
+		for (; b + 8 <= nk; b += 8) {   // eight blocks (8 KiB per wave) in flight
+			f32x4 q[8], x[8];
+#pragma unroll
+			for (int i = 0; i < 8; i++) x[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(tile + (b + i) * 1024 + lane * 16));
+#pragma unroll
+			for (int i = 0; i < 8; i++) q[i] = *reinterpret_cast<const f32x4 *>(qtile + (b + i) * 1024 + lane * 16);
+			__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+			for (int i = 0; i < 8; i++) {
+#pragma unroll
+				for (int e = 0; e < 4; e++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q[i][e], x[i][e], acc, 0, 0, 0);
+			}
+		}
 		for (; b + 4 <= nk; b += 4) {   // four blocks in flight
 			f32x4 q[4], x[4];
 #pragma unroll
-			for (int i = 0; i < 4; i++) {
-				x[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(tile + (b + i) * 1024 + lane * 16));
-				q[i] = *reinterpret_cast<const f32x4 *>(qtile + (b + i) * 1024 + lane * 16);
-			}
+			for (int i = 0; i < 4; i++) x[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(tile + (b + i) * 1024 + lane * 16));
+#pragma unroll
+			for (int i = 0; i < 4; i++) q[i] = *reinterpret_cast<const f32x4 *>(qtile + (b + i) * 1024 + lane * 16);
+			__builtin_amdgcn_sched_barrier(0);   // keep the batch of loads in front of its MFMAs (the scheduler sinks them otherwise)
 #pragma unroll
 			for (int i = 0; i < 4; i++) {
 #pragma unroll
@@ -235,6 +253,7 @@ __device__ __forceinline__ f32x4 sim_tile_generic(const uint8_t *__restrict__ qt
 		for (int i = 0; i < 8; i++) x[i] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(tile + (t + i) * 1024 + lane * 16));
 #pragma unroll
 		for (int i = 0; i < 8; i++) q[i] = *reinterpret_cast<const bf16x8 *>(qtile + (t + i) * 1024 + lane * 16);
+		__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 		for (int i = 0; i < 8; i++) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q[i], x[i], acc, 0, 0, 0);
 	}

@@ -4,6 +4,7 @@
 extern "C" hipError_t vk_launch_score_m0(const VkScoreParams *p, int32_t grid, size_t smem_bytes, hipStream_t stream);
 extern "C" hipError_t vk_launch_score_m1(const VkScoreParams *p, int32_t grid, size_t smem_bytes, hipStream_t stream);
 extern "C" hipError_t vk_launch_score_m5(const VkScoreParams *p, int32_t grid, size_t smem_bytes, hipStream_t stream);
+extern "C" hipError_t vk_launch_score_m6(const VkScoreParams *p, int32_t grid, size_t smem_bytes, hipStream_t stream);
 extern "C" hipError_t vk_launch_score_m2(const VkScoreParams *p, int32_t grid, size_t smem_bytes, hipStream_t stream);
 extern "C" hipError_t vk_launch_score_m3(const VkScoreParams *p, int32_t grid, size_t smem_bytes, hipStream_t stream);
 extern "C" hipError_t vk_launch_score_m3_300(const VkScoreParams *p, int32_t grid, size_t smem_bytes, hipStream_t stream);
@@ -15,6 +16,7 @@ extern "C" hipError_t vk_launch_score(const VkScoreParams *pp, int32_t grid, siz
 	if (p.prec == 0 && p.nk32 == 10 && p.tail == 1) return p.q_mode3 ? vk_launch_score_m3_300(pp, grid, smem_bytes, stream) : vk_launch_score_m0(pp, grid, smem_bytes, stream);
 	if (p.prec == 0 && p.nk32 == 24 && p.tail == 0) return vk_launch_score_m3(pp, grid, smem_bytes, stream);
 	if (p.prec == 1 && p.nk32 == 19 && p.q_mode3) return vk_launch_score_m4(pp, grid, smem_bytes, stream);   // fp32 rows, 300-d
+	if (p.prec == 1) return vk_launch_score_m6(pp, grid, smem_bytes, stream);
 	if (p.prec == 0 && p.nk32 >= 8) return vk_launch_score_m5(pp, grid, smem_bytes, stream);   // wide rows: deeper load pipeline
 	return vk_launch_score_m1(pp, grid, smem_bytes, stream);
 }

@@ -8,11 +8,12 @@
 // ---------------------------------------------------------------------------
 // the fused scoring kernel: one wave = 4 sentences at a time, grid-stride over groups.
 //   MODE 0: contextual layout, NK32 K-steps (last one half filled when TAIL), query fragments in registers
-//   MODE 1: contextual layout, any d (runtime K loop)
+//   MODE 1: contextual layout, bf16 rows of any d (runtime K loop)
 //   MODE 2: static layout: gather rows of the per-query table by token id
 //   MODE 3: contextual layout, NK32 K-steps, query tile staged in LDS (large d)
 //   MODE 4: contextual layout, fp32 tiles of NK32 blocks of 16 features (compile time), query tile staged in LDS
 //   MODE 5: MODE 1 for bf16 rows of 256 features and more: eight K-steps in flight instead of four
+//   MODE 6: MODE 1 for fp32 rows (any d but the 300 of MODE 4)
 // GAP: 0 linear, 1 affine, 2 general (LDS history, serial in-row chain),
 //      3 general, sentences <= 32 tokens, strictly subadditive w_t (register history),
 //      4 relaxed word mover's distance (no DP: row / column minima of 1 - S),
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 	}
 	// MODE 1 (any d, fp32 tiles): the same staging with a runtime size; the K loop then reads the query with ds_read instead of
 	// going through L1 for every token tile
-	if constexpr (MODE == 1 || MODE == 5) {
+	if constexpr (MODE == 1 || MODE == 5 || MODE == 6) {
 		if (p.q_lds > 0) {
 			for (int i = threadIdx.x; i * 16 < p.q_lds; i += blockDim.x)
 				vk_smem4[i] = i * 16 < p.tile_bytes ? *reinterpret_cast<const float4 *>(p.qtile + i * 16) : float4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -162,10 +163,14 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 				if constexpr (MODE == 0) acc = sim_tile<NK32, TAIL>(qf, tp, lane);
 				else if constexpr (MODE == 3) acc = sim_tile_qlds<NK32, TAIL>(qlds, tp, lane);
 				else if constexpr (MODE == 4) acc = sim_tile_f32_qlds<NK32>(qlds, tp, lane);
-				else if (MODE == 5 && p.q_lds > 0) acc = sim_tile_generic<true>(qlds, tp, p.nk32, p.tail, lane, p.prec);
-				else if (MODE == 5) acc = sim_tile_generic<true>(p.qtile, tp, p.nk32, p.tail, lane, p.prec);
-				else if (MODE == 1 && p.q_lds > 0) acc = sim_tile_generic(qlds, tp, p.nk32, p.tail, lane, p.prec);
-				else acc = sim_tile_generic(p.qtile, tp, p.nk32, p.tail, lane, p.prec);
+				else {
+					// two calls, not one with a selected pointer: an LDS-or-global pointer is a flat pointer, and flat loads count
+					// on both wait counters -- every batch of tile loads would be waited for in full
+					constexpr bool DEEP = MODE == 5 || MODE == 6;
+					constexpr int PREC = MODE == 6 ? 1 : 0;
+					if (p.q_lds > 0) acc = sim_tile_generic<DEEP, PREC>(qlds, tp, p.nk32, p.tail, lane);
+					else acc = sim_tile_generic<DEEP, PREC>(p.qtile, tp, p.nk32, p.tail, lane);
+				}
 				if (p.pos_s) {
 					const int ps = p.pos_s[(tile0 + ti) * 16 + (lane & 15)];
 #pragma unroll
