@@ -132,6 +132,8 @@ __device__ __forceinline__ void load_qfrag(QFrag<NK, HALF> &f, const uint8_t *__
 	}
 }
 
+// (The scheduler keeps a rolling four of the NK loads in flight here, not all of them; with 12 waves per CU that is enough for
+// bf16 rows -- a sched_barrier that forces all ten costs 1.5 % at 300-d, DESIGN 5.0 -- unlike the fp32 form below.)
 template <int NK, bool HALF>
 __device__ __forceinline__ f32x4 sim_tile(const QFrag<NK, HALF> &f, const uint8_t *__restrict__ tile, int lane) {
 	bf16x8 x[NK > 0 ? NK : 1];
