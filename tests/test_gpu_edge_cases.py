@@ -166,3 +166,26 @@ def test_views_serve_queries_from_two_threads(hip):
 	v.close()
 	assert c.query(qs[0], **kw).n == 7   # the owner keeps working after its view is gone
 	c.close()
+
+
+@pytest.mark.parametrize("d,n", [(300, 16 * 4 * 4 * 3 + 5), (768, 4099), (384, 63), (1024, 16 * 4 * 4), (100, 1000), (300, 1)])
+def test_span_kernel_every_slice(hip, oracle, d, n):
+	"""one vector per slice against a one-token query (vk_span_kernel: runs of four tiles per wave, a last partial run, a last
+	partial tile): every slice's score is the clipped cosine of the bf16-rounded unit rows, the result set their top k"""
+	rng = np.random.default_rng(d + n)
+	V = rng.standard_normal((n, d)).astype(np.float32)
+	V[n // 2] = -V[0]                # a negative cosine: clipped to 0
+	Vb, _ = oracle.normalize_rows_bf16(V)
+	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=d, n_tokens=n, n_sentences=n)
+	c.append_vectors(Vb, normalize=False)
+	c.set_sentences(np.arange(n + 1, dtype=np.int64))
+	c.finalize()
+	q = V[0:1] + 0.1 * rng.standard_normal((1, d)).astype(np.float32)
+	Qb, _ = oracle.normalize_rows_bf16(q)
+	got = c.query(Qb, q_normalize=False, max_matches=min(n, 20), min_score=-1.0)
+	cos = oracle.sim_bf16(Vb, Qb)[:, 0]
+	np.testing.assert_allclose(c.last_scores(), cos, atol=2e-6)
+	order = np.argsort(-cos, kind="stable")[:got.n]
+	np.testing.assert_allclose(got.score[:got.n], cos[order], atol=2e-6)
+	assert got.n == min(n, 20) and int(got.sentence[0]) == 0
+	c.close()

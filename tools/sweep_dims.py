@@ -24,6 +24,7 @@ def main():
 	ap.add_argument("--gbytes", type=float, default=8.0)
 	ap.add_argument("--len-s", type=int, default=32)
 	ap.add_argument("--ragged", action="store_true", help="slice lengths U{8..64} instead of --len-s")
+	ap.add_argument("--len-t", type=int, default=10, help="query tokens (1 with --len-s 1: the span-embedding index, vk_span_kernel)")
 	ap.add_argument("--reps", type=int, default=5)
 	ap.add_argument("--max-setting", type=int, default=5)
 	ap.add_argument("--precision", choices=["bf16", "f32"], default="bf16", help="how the unit rows are kept in HBM")
@@ -60,7 +61,7 @@ def main():
 			del x, idx
 		corpus.set_sentences(off)
 		corpus.finalize()
-		qs = [np.ascontiguousarray(E[rng.integers(0, V, size=10)] + 0.05 * rng.standard_normal((10, d)).astype(np.float32)) for _ in range(args.reps + 1)]
+		qs = [np.ascontiguousarray(E[rng.integers(0, V, size=args.len_t)] + 0.05 * rng.standard_normal((args.len_t, d)).astype(np.float32)) for _ in range(args.reps + 1)]
 		for gname, gap in gaps.items():
 			row = {"d": d, "gap": gname, "sentences": n_sent, "len_s": "U{8..64}" if args.ragged else args.len_s, "precision": args.precision, "bytes": n_tok * d * esz, "GBps": {}, "ms": {}}
 			for setting in ["default"] + [str(i) for i in range(1, args.max_setting + 1)]:

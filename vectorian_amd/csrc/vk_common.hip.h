@@ -134,7 +134,7 @@ __device__ __forceinline__ void load_qfrag(QFrag<NK, HALF> &f, const uint8_t *__
 
 // (The scheduler keeps a rolling four of the NK loads in flight here, not all of them; with 12 waves per CU that is enough for
 // bf16 rows -- a sched_barrier that forces all ten costs 1.5 % at 300-d, DESIGN 5.0 -- unlike the fp32 form below.)
-template <int NK, bool HALF>
+template <int NK, bool HALF, bool BARRIER = false>
 __device__ __forceinline__ f32x4 sim_tile(const QFrag<NK, HALF> &f, const uint8_t *__restrict__ tile, int lane) {
 	bf16x8 x[NK > 0 ? NK : 1];
 #pragma unroll
@@ -142,6 +142,7 @@ __device__ __forceinline__ f32x4 sim_tile(const QFrag<NK, HALF> &f, const uint8_
 		if (HALF && t == NK - 1) x[t] = load_half_block(tile + t * 1024, lane, true);
 		else x[t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(tile + t * 1024 + lane * 16));
 	}
+	if constexpr (BARRIER) __builtin_amdgcn_sched_barrier(0);
 	f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
 	for (int t = 0; t < NK; t++) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.q[t], x[t], acc, 0, 0, 0);

@@ -28,16 +28,21 @@ extern "C" hipError_t vk_launch_score(const VkScoreParams *pp, int32_t grid, siz
 // time.  HBM-bound: d * 2 bytes per slice.
 // ---------------------------------------------------------------------------
 
+// A wave takes runs of VK_SPAN_RUN consecutive tiles (one tile per wave in turn left 300-d spans at 5.9 TB/s; runs: 6.4 - 6.6) and
+// keeps all of a tile's loads in front of its MFMAs (sched_barrier in sim_tile).
+constexpr int VK_SPAN_RUN = 4;
+
 template <int NK32, bool TAIL>
 __global__ __launch_bounds__(256) void vk_span_kernel(VkScoreParams p) {
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	QFrag<NK32, TAIL> qf;
 	if constexpr (NK32 > 0) load_qfrag<NK32, TAIL>(qf, p.qtile, lane);
 	const int64_t n_tiles = ((int64_t)p.n_sent + 15) >> 4;
-	for (int64_t tile = (int64_t)blockIdx.x * 4 + wv; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+	for (int64_t run = (int64_t)blockIdx.x * 4 + wv; run * VK_SPAN_RUN < n_tiles; run += (int64_t)gridDim.x * 4)
+	for (int64_t tile = run * VK_SPAN_RUN; tile < (run + 1) * VK_SPAN_RUN && tile < n_tiles; tile++) {
 		const uint8_t *tp = p.tiles + tile * p.tile_bytes;
 		f32x4 acc;
-		if constexpr (NK32 > 0) acc = sim_tile<NK32, TAIL>(qf, tp, lane);
+		if constexpr (NK32 > 0) acc = sim_tile<NK32, TAIL, true>(qf, tp, lane);
 		else acc = sim_tile_generic(p.qtile, tp, p.nk32, p.tail, lane, p.prec);
 		const int64_t s_idx = tile * 16 + lane;
 		if (lane < 16 && s_idx < p.n_sent) {
@@ -59,7 +64,8 @@ static hipError_t launch_span(const VkScoreParams &p, hipStream_t stream) {
 	const char *ov = getenv("VK_BLOCKS_PER_CU");   // read per launch: tools/sweep_dims.py varies it inside one process
 	if (ov && atoi(ov) > 0) occ = atoi(ov);
 	if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-	const int64_t want = (((int64_t)p.n_sent + 15) / 16 + 3) / 4, cap = (int64_t)cus * occ;
+	const int64_t runs = (((int64_t)p.n_sent + 15) / 16 + VK_SPAN_RUN - 1) / VK_SPAN_RUN;
+	const int64_t want = (runs + 3) / 4 > 0 ? (runs + 3) / 4 : 1, cap = (int64_t)cus * occ;
 	vk_span_kernel<NK32, TAIL><<<(int)(want < cap ? want : cap), 256, 0, stream>>>(p);
 	return hipGetLastError();
 }
