@@ -563,6 +563,8 @@ def main():
 			n_x = max(4096, int(w["n_sent"] * args.extra_scale))
 			try:
 				_, e = measure(key, n_x, args.extra_warmup, args.extra_steps, None, keep=keep)
+				if e["roofline"]["bound"] == "hbm" and w.get("layout") != "static":
+					e["roofline"]["traffic"], e["roofline"]["traffic_source"] = traffic_of(w["name"], w["gap"], n_x, w["n_sent"])
 			except Exception as ex:   # a configuration that fails is reported, the headline stands
 				e = {"workload": describe(w, n_x), "error": f"{type(ex).__name__}: {ex}"}
 			configs[w["name"]] = e
