@@ -269,7 +269,7 @@ class Runner:
 		self.gather_batch = max(1, int(os.environ.get("VK_BENCH_GATHER_BATCH", "4")))   # result sets of this many queries travel in one all-gather
 		self.gather_depth = int(os.environ.get("VK_BENCH_GATHER_DEPTH", "1"))   # a collective gets this many further exchanges to complete before anyone waits for it
 		self.submitted = 0
-		self.score_ms, self.phases = [], []
+		self.score_ms, self.phases, self.retired_at, self.median_gap_ms = [], [], [], None
 		gs, gt, _ = gap_spec(gap_name or spec["gap"])
 		alg = {"align": core.VK_ALG_ALIGN, "rwmd": core.VK_ALG_RWMD, "wrd": core.VK_ALG_WRD}[spec["alg"]]
 		self.options = dict(algorithm=alg, locality=LOCALITIES[locality or spec["locality"]], gap_s=gs, gap_t=gt, q_normalize=True,
@@ -297,6 +297,7 @@ class Runner:
 
 	def _retire(self):
 		tops, ph = self.inflight.pop(0).result()
+		self.retired_at.append(time.perf_counter())
 		self.score_ms.append(ph["score_ms"])
 		self.phases.append(ph)
 		if self.dist is None:
@@ -334,11 +335,19 @@ class Runner:
 		self.sync()
 		self.score_ms.clear()
 		self.phases.clear()
+		self.retired_at.clear()
 		t0 = time.perf_counter()
 		for i in range(steps):
 			self.step(queries[warmup + i])
 		self.sync()
-		return time.perf_counter() - t0
+		elapsed = time.perf_counter() - t0
+		self.median_gap_ms = float(np.median(np.diff(np.array([t0] + self.retired_at)))) * 1e3 if self.retired_at else None
+		if os.environ.get("VK_BENCH_TRACE"):   # where the time between completed queries went (stalls show as single long gaps)
+			gaps = np.diff(np.array([t0] + self.retired_at)) * 1e3
+			top = np.argsort(-gaps)[:4]
+			print(f"[trace] {self.spec['name']}: {steps} steps, median gap {np.median(gaps):.2f} ms, longest " +
+				", ".join(f"{gaps[i]:.1f} ms at step {i}" for i in top), file=sys.stderr)
+		return elapsed
 
 	def close(self):
 		self.pool.shutdown()
@@ -402,6 +411,7 @@ def main():
 	ap.add_argument("--extra", default="4,3,2f32,2static,5,5wrd", help="the other configurations timed at N = 1 after the headline")
 	ap.add_argument("--extra-steps", type=int, default=12)
 	ap.add_argument("--extra-warmup", type=int, default=4)
+	ap.add_argument("--extra-min-ms", type=float, default=300.0, help="the extra configurations run at least this long inside their timed region")
 	ap.add_argument("--extra-scale", type=float, default=1.0, help="scales the sentence counts of the extra configurations (rehearsals)")
 	args = ap.parse_args()
 
@@ -518,6 +528,7 @@ def main():
 		entry = {
 			"workload": describe(spec, n_sent), "value": pairs / elapsed, "unit": "sentence-alignments/sec",
 			"steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "dtype": spec["prec"],
+			"ms_per_step_median": r.median_gap_ms,   # median time between completed steps: a host stall shows in ms_per_step, not here
 			"sentences_per_gpu": n_sent, "tokens_per_gpu": n_tok, "d": spec["d"],
 			"roofline": roofline_of(spec, n_sent, n_tok, kern_s),
 			"phases_ms_mean": {k: float(np.mean([p[k] for p in r.phases])) for k in r.phases[0]} if r.phases else {},
@@ -543,7 +554,7 @@ def main():
 			"metric": "sentence-alignments/sec at d=300, |q|=10, |s|<=64; 1/2/4/8 GPU + %HBM roofline",
 			"value": entry["value"], "unit": "sentence-alignments/sec",
 			"n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-			"ms_per_step": entry["ms_per_step"],
+			"ms_per_step": entry["ms_per_step"], "ms_per_step_median": entry["ms_per_step_median"],
 			"higher_is_better": True, "scaling": "weak", "vs_baseline": None,
 			"dtype": spec["prec"], "data": "synthetic",
 			"config": {
@@ -561,8 +572,20 @@ def main():
 		for key in [k for k in args.extra.split(",") if k and k in WORKLOADS and k != args.config]:
 			w = WORKLOADS[key]
 			n_x = max(4096, int(w["n_sent"] * args.extra_scale))
+			# a timed region of a few steps of 3.5 ms is at the mercy of whatever the previous configuration left running in the
+			# driver (freed corpora: the static layout once showed 9 ms per step over 12 steps, 3.44 over 60): at least
+			# --extra-min-ms of timed steps, a third of that as warm-up
+			avg_len = (w["min_len"] + w["max_len"]) / 2
+			if w.get("batch"):
+				est_ms = 2.0 * n_x * avg_len * w["batch"] * LEN_T * w["d"] / (0.5 * MFMA_BF16_PEAK) * 1e3
+			elif w.get("layout") == "static":
+				est_ms = n_x * avg_len * LEN_T / 370e9 * 1e3
+			else:
+				est_ms = n_x * avg_len * w["d"] * (4 if w["prec"] == "f32" else 2) / (0.8 * HBM_PEAK) * 1e3
+			x_steps = max(args.extra_steps, int(np.ceil(args.extra_min_ms / est_ms)))
+			x_warmup = max(args.extra_warmup, int(np.ceil(args.extra_min_ms / 3 / est_ms)))
 			try:
-				_, e = measure(key, n_x, args.extra_warmup, args.extra_steps, None, keep=keep)
+				_, e = measure(key, n_x, x_warmup, x_steps, None, keep=keep)
 				if e["roofline"]["bound"] == "hbm" and w.get("layout") != "static":
 					e["roofline"]["traffic"], e["roofline"]["traffic_source"] = traffic_of(w["name"], w["gap"], n_x, w["n_sent"])
 			except Exception as ex:   # a configuration that fails is reported, the headline stands
