@@ -247,7 +247,9 @@ int vk_merge_topk(const vk_topk_out *sets, int32_t n_sets, int32_t len_t, int32_
 int32_t vk_record_words(int32_t len_t);
 /* records: [k x vk_record_words(len_t)], rows >= set->n_out zeroed; slice indices become sentence_offset + local index */
 int vk_pack_records(const vk_topk_out *set, int32_t len_t, int32_t k, int64_t sentence_offset, int32_t *records);
-/* records: [n_sets x k x words] as the all-gather delivers them; out as for vk_merge_topk (capacity >= k) */
+/* ResultSet::extend (vectorian/core/cpp/result_set.h:70-93) + best_n (result_set.cpp:3-21) over the records of n_sets
+ * result sets.  records: [n_sets x k x words] as the all-gather delivers them; out as for vk_merge_topk (capacity >= k);
+ * order: score descending, ties by slice index descending (Match::compare_by_score, match/match_impl.h:8-42). */
 int vk_merge_records(const int32_t *records, int32_t n_sets, int32_t len_t, int32_t k, vk_topk_out *out);
 
 #ifdef __cplusplus
