@@ -470,6 +470,21 @@ __global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t
 			if (p.prec) {
 				// fp32 tiles (the reference's own precision): nk32 blocks of 16 features, four v_mfma_f32_16x16x4_f32 per block and query tile
 				int bk = 0;
+				for (; bk + 8 <= p.nk32; bk += 8) {   // eight blocks in flight, in front of their MFMAs (20 tokens, fp32 rows: 9.6 -> 7.8 ms)
+					f32x4 x[8];
+#pragma unroll
+					for (int i = 0; i < 8; i++) x[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(tp + (bk + i) * 1024 + lane * 16));
+					__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+					for (int i = 0; i < 8; i++) {
+#pragma unroll
+						for (int b = 0; b < NB; b++) {
+							const f32x4 q = *reinterpret_cast<const f32x4 *>(q0 + b * qbytes + (bk + i) * 1024 + lane * 16);
+#pragma unroll
+							for (int e = 0; e < 4; e++) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[e], x[i][e], acc[b], 0, 0, 0);
+						}
+					}
+				}
 				for (; bk + 4 <= p.nk32; bk += 4) {
 					f32x4 x[4];
 #pragma unroll
