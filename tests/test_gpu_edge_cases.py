@@ -189,3 +189,57 @@ def test_span_kernel_every_slice(hip, oracle, d, n):
 	np.testing.assert_allclose(got.score[:got.n], cos[order], atol=2e-6)
 	assert got.n == min(n, 20) and int(got.sentence[0]) == 0
 	c.close()
+
+
+def test_different_corpora_from_different_threads(hip):
+	"""the boundary's threading contract: concurrent calls on DIFFERENT corpus handles are safe -- three corpora of
+	different layout / width / algorithm, one host thread each, every result as from the same handle used alone"""
+	import threading
+	ctx = synth.make_contextual_corpus(4000, 2, 40, 800, 96, noise=0.3, norm_sigma=0.25)
+	a = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=96, n_tokens=ctx["X"].shape[0], n_sentences=4000, keep_magnitudes=True)
+	a.append_vectors(ctx["X"], normalize=True)
+	a.set_sentences(ctx["sent_off"])
+	a.finalize()
+	st = synth.make_static_corpus(6000, 1, 40, 500, 300, seed=5)
+	b = hip.Corpus(layout=hip.VK_LAYOUT_STATIC, d=300, n_tokens=len(st["tok_id"]), n_sentences=6000, vocab_size=500)
+	b.append_vectors(st["E"], normalize=True)
+	b.set_token_ids(st["tok_id"])
+	b.set_sentences(st["sent_off"])
+	b.finalize()
+	f32 = synth.make_contextual_corpus(3000, 8, 32, 800, 160)
+	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=160, n_tokens=f32["X"].shape[0], n_sentences=3000, precision="f32")
+	c.append_vectors(f32["X"], normalize=True)
+	c.set_sentences(f32["sent_off"])
+	c.finalize()
+	rng = np.random.default_rng(3)
+	qa = [q["vectors"] for q in synth.make_queries(ctx, 10, 7)]
+	qb = [rng.integers(0, 500, size=9).astype(np.int32) for _ in range(10)]
+	qc = [q["vectors"] for q in synth.make_queries(f32, 10, 20)]    # the long-query kernel
+	jobs = [
+		(a, [lambda h, q=q: h.query(q, algorithm=hip.VK_ALG_WRD, q_normalize=True, max_matches=6).trimmed() for q in qa]),
+		(b, [lambda h, q=q: h.query(st["E"][q], q_token_ids=q, q_normalize=True, gap_s=EXP5, gap_t=EXP5, max_matches=9).trimmed() for q in qb]),
+		(c, [lambda h, q=q: h.query(q, q_normalize=True, gap_s=0.1, gap_t=0.1, locality=hip.Locality.SEMIGLOBAL, max_matches=5, min_score=-10.0).trimmed() for q in qc]),
+	]
+	ref = [[f(h) for f in fs] for h, fs in jobs]
+	out = [[None] * len(fs) for _, fs in jobs]
+	errors = []
+
+	def work(k):
+		h, fs = jobs[k]
+		try:
+			for rep in range(3):
+				for i, f in enumerate(fs):
+					out[k][i] = f(h)
+		except Exception as e:   # surfaced below: a thread's exception would otherwise vanish
+			errors.append(e)
+	threads = [threading.Thread(target=work, args=(k,)) for k in range(len(jobs))]
+	for t in threads:
+		t.start()
+	for t in threads:
+		t.join()
+	assert not errors, errors
+	for rs, os_ in zip(ref, out):
+		for r, o in zip(rs, os_):
+			assert (r["sentence"] == o["sentence"]).all() and (r["score"] == o["score"]).all() and (r["mapping"] == o["mapping"]).all()
+	for h in (a, b, c):
+		h.close()
