@@ -38,8 +38,9 @@ extern "C" {
                                  one-wave-per-slice kernel, ~10x slower; the 1:n form of RWMD stops at this length */
 #define VK_MAX_SENT_LEN 512   /* tokens per sentence (slice) */
 #define VK_FAST_SENT_LEN 64   /* slices up to this length run 4 per wave in the fused kernel (|s| <= 64); longer
-                                 ones take a second launch, one slice per wave (exact transport: a slower solver); queries of
-                                 more than VK_FAST_QUERY_LEN tokens with VK_ALG_WRD, full WMD or the 1:n RWMD need all slices <= 64 */
+                                 ones take a second launch, one slice per wave (exact transport: a slower solver; with a query of
+                                 more than VK_FAST_QUERY_LEN tokens its state lives in global memory); the 1:n RWMD of a query of
+                                 more than VK_FAST_QUERY_LEN tokens needs all slices <= 64 */
 #define VK_MAX_MATCHES 1024
 
 typedef enum {

@@ -140,16 +140,19 @@ def test_only_long_slices_and_limit(hip, oracle):
 	("wmd", dict(rwmd=(False, False, True), wmd_full=True)), ("wmd", dict(rwmd=(False, False, False), wmd_full=True)),
 ])
 @pytest.mark.parametrize("layout", ["contextual", "static"])
-def test_exact_transport_over_long_slices(hip, oracle, layout, alg, opts):
+@pytest.mark.parametrize("len_t", [9, 20, 40, 64])
+def test_exact_transport_over_long_slices(hip, oracle, layout, alg, opts, len_t):
 	"""Word Rotator's Distance and the full WMD over a corpus with sentences of 65..400 tokens (upstream sizes its transport problems
-	by the longest sentence, metric/alignment.h:357-358): bound pass of the one-slice-per-wave launch + vk_wrd_exact_long_kernel"""
+	by the longest sentence, metric/alignment.h:357-358).  Queries of at most 16 tokens: bound pass of the one-slice-per-wave launch
+	+ vk_wrd_exact_long_kernel<1> (state in LDS); 17..64 tokens: the multi-block kernel bounds the short slices, vk_long_bound_kernel
+	the long ones, vk_wrd_exact_long_kernel<4> solves long candidates with its (supply, demand) arrays in global scratch"""
 	rng = np.random.default_rng(12)
 	n = 260
 	lens = rng.integers(1, 50, size=n)
 	lens[rng.integers(0, n, size=40)] = rng.integers(65, 400, size=40)
 	lens[7] = 512
 	off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
-	T, d, len_t = int(off[-1]), 64, 9
+	T, d = int(off[-1]), 64
 	o_alg = oracle.ALG_WRD if alg == "wrd" else oracle.ALG_RWMD
 	h_alg = hip.VK_ALG_WRD if alg == "wrd" else hip.VK_ALG_RWMD
 	if layout == "static":
@@ -182,6 +185,4 @@ def test_exact_transport_over_long_slices(hip, oracle, layout, alg, opts):
 			got = c.query(qv, q_normalize=True, algorithm=h_alg, max_matches=n, min_score=-1.0, **opts)
 		assert len(ref["sentence"]) == n   # every sentence is ranked: all the long ones are solved exactly
 		assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=2e-5, tie_tol=2e-5)
-	with pytest.raises(hip.VkError):   # queries of more than 16 tokens: the solver's wide form needs slices of at most 64 tokens
-		c.query(np.ones((20, d), np.float32), q_token_ids=np.zeros(20, np.int32) if layout == "static" else None, algorithm=hip.VK_ALG_WRD)
 	c.close()

@@ -104,7 +104,7 @@ int vk_corpus_view(vk_corpus_t *src, vk_corpus_t **out) {
 	c->d_tiles = src->d_tiles; c->d_mag = src->d_mag; c->d_tok_id = src->d_tok_id; c->d_pos = src->d_pos; c->d_tag = src->d_tag;
 	c->d_sent_start = src->d_sent_start; c->d_sent_end = src->d_sent_end; c->d_long_groups = src->d_long_groups;
 	c->contiguous = src->contiguous; c->have_ids = src->have_ids; c->have_sent = src->have_sent; c->finalized = true;
-	c->max_len = src->max_len; c->max_group_tiles = src->max_group_tiles; c->max_group_tokens = src->max_group_tokens; c->max_pair_tiles = src->max_pair_tiles;
+	c->max_len = src->max_len; c->max_group_tiles = src->max_group_tiles; c->max_group_tokens = src->max_group_tokens; c->max_pair_tiles = src->max_pair_tiles; c->max_short_pair_tiles = src->max_short_pair_tiles;
 	c->n_entries = src->n_entries; c->entry_sent = src->entry_sent;
 	c->n_long_groups = src->n_long_groups; c->max_short_len = src->max_short_len;
 	c->long_group_tiles = src->long_group_tiles; c->long_group_tokens = src->long_group_tokens;
@@ -150,7 +150,7 @@ int vk_corpus_free(vk_corpus_t *c) {
 		c->d_sent_start = c->d_sent_end = nullptr, c->d_long_groups = nullptr;
 	if (c->shares_vectors) c->d_tiles = nullptr, c->d_mag = nullptr;
 	void *ptrs[] = {c->d_tiles, c->d_mag, c->d_tok_id, c->d_pos, c->d_tag, c->d_sent_start, c->d_sent_end, c->d_stage, c->d_qtile, c->d_ws, c->d_wt, c->d_qids,
-		c->d_table, c->d_scores, c->d_raw, c->d_boost, c->d_keys[0], c->d_keys[1], c->d_out_raw, c->d_out_sim, c->d_out_map, c->d_wrd_raw, c->d_wrd_val, c->d_bq, c->d_bqlen, c->d_bscores, c->d_bkeys[0], c->d_bkeys[1], c->d_long_groups, c->d_counter, c->d_rows_out, c->d_plan_out, c->d_braw};
+		c->d_table, c->d_scores, c->d_raw, c->d_boost, c->d_keys[0], c->d_keys[1], c->d_out_raw, c->d_out_sim, c->d_out_map, c->d_wrd_raw, c->d_wrd_val, c->d_bq, c->d_bqlen, c->d_bscores, c->d_bkeys[0], c->d_bkeys[1], c->d_long_groups, c->d_counter, c->d_rows_out, c->d_plan_out, c->d_braw, c->d_wrdl_scratch};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	for (auto &b : c->bl) for (void *p : {(void *)b.tiles, (void *)b.len, (void *)b.id}) if (p) (void)hipFree(p);
 	for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -326,12 +326,17 @@ static int set_slices_impl(vk_corpus_t *c, const int64_t *start, const int64_t *
 			mtok = std::max(mtok, (int)(b - a));
 		}
 	}
-	int pt = 1;
+	int pt = 1, spt = 1;
+	li = 0;
 	for (int64_t g = 0; g * 2 < n_entries; g++) {
 		const int64_t a = st32[(size_t)(g * 2)], b = en32[(size_t)std::min<int64_t>(g * 2 + 1, n_entries - 1)];
-		pt = std::max(pt, (int)(((b + 15) >> 4) - (a >> 4)));
+		const int tiles = (int)(((b + 15) >> 4) - (a >> 4));
+		pt = std::max(pt, tiles);
+		while (li < long_groups.size() && long_groups[li] < g / 2) li++;
+		if (!(li < long_groups.size() && long_groups[li] == g / 2)) spt = std::max(spt, tiles);
 	}
 	c->max_pair_tiles = pt;
+	c->max_short_pair_tiles = spt;
 	c->max_group_tiles = mt;
 	c->max_group_tokens = mtok;
 	c->long_group_tiles = lt;

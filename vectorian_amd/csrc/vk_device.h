@@ -123,6 +123,16 @@ struct VkWrdParams {
 	float *val_out;            // [n_cand]
 	float *plan_out;           // optional [n_cand x 16 nq x 64]: the optimal plan G[j][i]
 	float *rows_out;           // vk_rows_kernel: [n_cand x 64 x 16 nq] similarity rows
+	// queries of more than 16 tokens over slices of more than VK_DEV_MAX_SENT_LEN tokens
+	const int32_t *group_list; // vk_long_bound_kernel: groups of the slice table that hold one long slice (row 4 g)
+	int32_t n_list;
+	int32_t n_entries;         // rows of the slice table
+	float *scores, *raw;       // vk_long_bound_kernel: per row of the slice table
+	float wrd_raw_total;       // > 0: magnitudes as they are, the query's total
+	int32_t wmd_bound;         // 0: WRD; 1: nbow; 2: bow (as VkWideParams)
+	uint8_t *scratch;          // vk_wrd_exact_long_kernel, nq > 1: flows, costs and similarity rows of one candidate per workgroup
+	int64_t scratch_stride;
+	int32_t n_cand;
 };
 
 struct VkFlowParams {
@@ -266,6 +276,11 @@ hipError_t vk_launch_topk_wave_batch(const float *scores, const uint64_t *keys_i
 hipError_t vk_launch_wrd_exact(const VkWrdParams *p, int32_t n_cand, float *scores_to_mark, hipStream_t stream);
 hipError_t vk_launch_rows(const VkWrdParams *p, int32_t n_cand, hipStream_t stream);
 hipError_t vk_launch_wrd_exact_long(const VkWrdParams *p, int32_t n_cand, hipStream_t stream);
+// queries of 17..64 tokens over long slices: workgroups of the exact solver (each with its own scratch) and bytes per workgroup
+int vk_wrd_long_blocks(void);
+size_t vk_wrd_long_scratch_bytes(void);
+// upper bound of the transport score of every long slice (p->group_list), queries of 17..64 tokens
+hipError_t vk_launch_long_bound(const VkWrdParams *p, hipStream_t stream);
 #ifdef __cplusplus
 }
 #endif

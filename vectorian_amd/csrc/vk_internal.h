@@ -79,6 +79,7 @@ struct vk_corpus {
 	bool have_ids = false, have_sent = false, finalized = false;
 	int max_len = 0, max_group_tiles = 0, max_group_tokens = 0;
 	int max_pair_tiles = 0;    // tiles spanned by two consecutive rows of the slice table (vk_score32_kernel)
+	int max_short_pair_tiles = 0;   // ... leaving out the groups that hold a long slice
 	// slice table on the device: n_entries >= n_sentences rows.  Slices longer than VK_FAST_SENT_LEN sit alone in
 	// their group of 4 (padded with empty rows) and are scored by a second launch over d_long_groups.
 	int64_t n_entries = 0;
@@ -102,6 +103,7 @@ struct vk_corpus {
 	float *d_wrd_raw = nullptr, *d_wrd_val = nullptr;
 	uint32_t *d_counter = nullptr;
 	float *d_rows_out = nullptr, *d_plan_out = nullptr;   // transport flows of the winners
+	uint8_t *d_wrdl_scratch = nullptr;   // exact transport, queries of 17..64 tokens over long slices: per-workgroup state
 	int rows_w = 0;              // columns per similarity row they are sized for (16, 32, 48 or 64)
 	// batched GEMM over a ragged corpus (vk_query_batch): a padded copy of the sentences, one bucket per padded length
 	// 16 / 32 / 48 / 64 tokens, built on the first such batch (this handle's; about 1.2 x the corpus for lengths 8..64)

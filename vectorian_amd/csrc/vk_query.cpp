@@ -10,7 +10,8 @@ int vk_validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_topk_
 	if (!c->finalized) return fail(VK_ERR_STATE, "corpus not finalized");
 	if (q->len_t < 1) return fail(VK_ERR_INVALID, "empty query");
 	if (q->len_t > VK_MAX_QUERY_LEN) return fail(VK_ERR_UNSUPPORTED, "query longer than VK_MAX_QUERY_LEN (64) tokens");
-	if (q->len_t > VK_FAST_QUERY_LEN) {
+	const bool exact_tr = q->algorithm == VK_ALG_WRD || (q->algorithm == VK_ALG_RWMD && q->wmd_full);   // bound pass + exact solver: no wide kernel
+	if (q->len_t > VK_FAST_QUERY_LEN && !exact_tr) {
 		const int gm = q->algorithm == VK_ALG_RWMD ? 4 : (q->gap_s.kind == VK_GAP_TABLE || q->gap_t.kind == VK_GAP_TABLE) ? 2 : 1;
 		if (vk_wide_lds_demand(c->max_len, (q->len_t + 15) / 16, gm, q->tag_weights != nullptr, q->want_flow) > 160 * 1024)
 			return fail(VK_ERR_UNSUPPORTED, "query of more than 16 tokens over slices this long exceeds the LDS of a workgroup");
@@ -47,16 +48,12 @@ int vk_validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_topk_
 		if (q->rwmd_symmetric && !q->rwmd_normalize_bow)
 			return fail(VK_ERR_INVALID, "cannot run symmetric mode WMD with bow (needs nbow)");   // wmd.h:441-449
 		if (q->wmd_full) {
-			if (c->max_len > VK_FAST_SENT_LEN && q->len_t > VK_FAST_QUERY_LEN)
-				return fail(VK_ERR_UNSUPPORTED, "full WMD with a query of more than 16 tokens needs every slice <= VK_FAST_SENT_LEN (64) tokens");
 			if (q->rwmd_injective) return fail(VK_ERR_INVALID, "non-relaxed WMD with injective mapping is not supported");      // wmd.h:201-204
 			if (q->rwmd_symmetric) return fail(VK_ERR_INVALID, "non-relaxed WMD with symmetric computation is not supported");  // wmd.h:206-209
 		} else if (!q->rwmd_injective && q->len_t > VK_FAST_QUERY_LEN && c->max_len > VK_FAST_SENT_LEN)
 			return fail(VK_ERR_UNSUPPORTED, "non-injective RWMD (rwmd('nbow/distributed')) with a query of more than 16 tokens needs every slice <= VK_FAST_SENT_LEN (64) tokens");
 		if (q->want_flow && (!out->mapping || !out->edge_sim)) return fail(VK_ERR_INVALID, "want_flow needs mapping and edge_sim arrays");
 	} else if (q->algorithm == VK_ALG_WRD) {
-		if (c->max_len > VK_FAST_SENT_LEN && q->len_t > VK_FAST_QUERY_LEN)
-			return fail(VK_ERR_UNSUPPORTED, "VK_ALG_WRD with a query of more than 16 tokens needs every slice <= VK_FAST_SENT_LEN (64) tokens");
 		if (q->tag_weights) {
 			if (!q->q_pos) return fail(VK_ERR_INVALID, "tag-weighted query without q_pos");
 			if (!c->d_pos) return fail(VK_ERR_STATE, "tag-weighted query needs vk_corpus_set_token_pos");
@@ -324,11 +321,15 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		// 17..32 tokens with linear / affine gaps over a bf16 contextual corpus of short slices: the fused two-block kernel
 		// (affine: the prefix-scan form of F needs open_t >= extend_t, as dp_affine)
 		// (33..64 tokens: one slice per wave and four column blocks)
-		const int wave_tiles = q->len_t <= 32 ? c->max_pair_tiles : (c->max_len + 15) / 16 + 1;
 		const bool rwmd_inj = q->algorithm == VK_ALG_RWMD && (p.gap_mode == 4 || p.gap_mode == 7) && !q->wmd_full;
 		const bool bound_pass = q->algorithm == VK_ALG_WRD || (q->algorithm == VK_ALG_RWMD && q->wmd_full);   // exact transport: stage 1
-		const bool two_blocks = (is_align || rwmd_inj || bound_pass) && c->n_long_groups == 0 &&
-			c->max_len <= VK_FAST_SENT_LEN && (rwmd_inj || bound_pass || p.gap_mode == 0 || (p.gap_mode == 1 && p.a_t >= 0.0f) || (p.gap_mode == 2 && wide_sub)) &&
+		// exact transport over a corpus with long slices: the multi-block kernel skips them (their groups are padded, vk_corpus.cpp),
+		// vk_long_bound_kernel bounds them
+		const bool long_apart = bound_pass && c->n_long_groups > 0;
+		const int wave_tiles = long_apart ? (q->len_t <= 32 ? c->max_short_pair_tiles : (c->max_short_len + 15) / 16 + 1)
+			: (q->len_t <= 32 ? c->max_pair_tiles : (c->max_len + 15) / 16 + 1);
+		const bool two_blocks = (is_align || rwmd_inj || bound_pass) && (long_apart || (c->n_long_groups == 0 &&
+			c->max_len <= VK_FAST_SENT_LEN)) && (rwmd_inj || bound_pass || p.gap_mode == 0 || (p.gap_mode == 1 && p.a_t >= 0.0f) || (p.gap_mode == 2 && wide_sub)) &&
 			vk_score32_lds_bytes(is_static ? 0 : c->nk32, c->tail, wave_tiles, q->len_t, 6) <= 160 * 1024 && (bound_pass || !getenv("VK_NO_SCORE32"));
 		if ((bound_pass || p.gap_mode == 7) && !two_blocks)
 			return fail(VK_ERR_UNSUPPORTED, "exact transport / 1:n RWMD with a query of more than 16 tokens: the multi-block kernel does not fit this corpus (LDS)");
@@ -342,6 +343,16 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 			}
 			if (p.gap_mode == 2) { wp.gap_mode = c->max_len <= 32 ? 3 : 6; wp.wt = c->d_wt + 80; }   // register history of 32 / 64 rows, closure of w_t
 			VK_HIP(vk_launch_score32(&wp, wave_tiles, st));
+			if (long_apart) {
+				VkWrdParams lw{};
+				fill_transport(lw);
+				lw.mag = q->algorithm == VK_ALG_WRD ? c->d_mag : nullptr;
+				memcpy(lw.qmass, qmass_all, sizeof lw.qmass);
+				lw.wrd_raw_total = p.wrd_raw_total; lw.wmd_bound = wp.wmd_bound;
+				lw.group_list = c->d_long_groups; lw.n_list = c->n_long_groups; lw.n_entries = (int32_t)n;
+				lw.scores = c->d_scores; lw.raw = c->d_raw; lw.boost = p.boost;
+				VK_HIP(vk_launch_long_bound(&lw, st));
+			}
 			wp.gap_mode = p.gap_mode;                                        // the traceback kernel knows 0 / 1 / 2
 			wp.wt = c->d_wt;                                                 // ... and walks the caller's table
 		}
@@ -433,7 +444,14 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		auto solve = [&](const uint64_t *d_keys, int count, float *ub_min, int *n_cand_out) -> int {
 			w.keys = d_keys;
 			VK_HIP(vk_launch_wrd_exact(&w, count, c->d_scores, st));
-			if (c->max_len > VK_FAST_SENT_LEN) VK_HIP(vk_launch_wrd_exact_long(&w, count, st));   // candidates of 65 .. 512 tokens
+			if (c->max_len > VK_FAST_SENT_LEN) {   // candidates of 65 .. 512 tokens
+				if (w.nq > 1 && !c->d_wrdl_scratch) {
+					int rc3 = alloc_t(c, &c->d_wrdl_scratch, (size_t)vk_wrd_long_blocks() * vk_wrd_long_scratch_bytes());
+					if (rc3) return rc3;
+				}
+				w.scratch = c->d_wrdl_scratch; w.scratch_stride = (int64_t)vk_wrd_long_scratch_bytes();
+				VK_HIP(vk_launch_wrd_exact_long(&w, count, st));
+			}
 			keys.resize((size_t)count); vals.resize((size_t)count); raws.resize((size_t)count);
 			VK_HIP(hipMemcpyAsync(keys.data(), d_keys, (size_t)count * 8, hipMemcpyDeviceToHost, st));
 			VK_HIP(hipMemcpyAsync(vals.data(), c->d_wrd_val, (size_t)count * 4, hipMemcpyDeviceToHost, st));

@@ -426,6 +426,7 @@ __global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t
 		const int len = t_b - t_a;
 		const int g_a = __builtin_amdgcn_readlane(t_a, 0), g_b = __builtin_amdgcn_readlane(t_b, 64 - LPS);
 		const int maxlen = max(__builtin_amdgcn_readlane(len, 0), __builtin_amdgcn_readlane(len, 64 - LPS));
+		if (maxlen > VK_DEV_MAX_SENT_LEN) continue;   // a long slice (alone in its padded group): bounded by vk_long_bound_kernel
 		const int tile0 = STATIC ? 0 : g_a >> 4;
 		const int ntiles = STATIC ? 0 : ((g_b + 15) >> 4) - tile0;
 		if (STATIC) {

@@ -56,9 +56,10 @@ __device__ __forceinline__ double wave_argmin_f64(double x, int lane, int &at) {
 
 // similarity rows of one slice against the nq query tiles -> S[row][16 nq] (row 0 = first token of the slice's first tile or,
 // static layout, of the slice); returns the row of the slice's first token.  Tag-weighted modifier applied when p.pos_s.
-template <int NQ>
+// (STRIDE: floats per row of S, at least 16 NQ.)
+template <int NQ, int STRIDE = 16 * NQ>
 __device__ __forceinline__ int transport_sim_rows(const VkWrdParams &p, float *S, int t_a, int t_b, int lane) {
-	constexpr int N = 16 * NQ;
+	constexpr int N = STRIDE;
 	const int m = t_b - t_a;
 	if (p.layout == VK_DEV_LAYOUT_STATIC) {
 		for (int it = 0; it * 16 < m; it++) {
@@ -326,33 +327,59 @@ __global__ __launch_bounds__(64) void vk_wrd_exact_kernel(VkWrdParams p) {
 // corpora with a long sentence on the device, one wave per candidate, not a tuned kernel.  Costs are kept as floats (they
 // are floats: 1 - S), flows and potentials in double.
 // ---------------------------------------------------------------------------
-constexpr int VK_WRDL_N = 16;                         // supplies (query tokens)
 constexpr int VK_WRDL_M = VK_DEV_MAX_LONG_LEN;        // demands (slice tokens)
 
+// GLOBAL: the arrays indexed by (supply, demand) live in a scratch region of global memory (a query of up to 64 tokens against
+// 512 demands: 256 KB of flows alone); lanes then exchange them through L1 / L2, so the fence is a workgroup-scope one
+template <bool GLOBAL>
+__device__ __forceinline__ void wrdl_fence() {
+	if constexpr (GLOBAL) {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+	} else wave_lds_fence();
+}
+
+// NQ = 1: queries of at most 16 tokens, everything in LDS (148 KB).  NQ = 4: queries of 17..64 tokens; flows, costs and
+// similarity rows in the workgroup's scratch region (p.scratch), the per-demand and per-supply vectors in LDS; a workgroup
+// walks the candidates with a grid stride.
+template <int NQ>
 __global__ __launch_bounds__(64) void vk_wrd_exact_long_kernel(VkWrdParams p) {
-	constexpr int N = VK_WRDL_N, M = VK_WRDL_M;
+	constexpr int N = 16 * NQ, M = VK_WRDL_M;
+	constexpr bool GLOBAL = NQ > 1;
 	extern __shared__ double vk_smem_f64[];
-	double *fl = vk_smem_f64;                          // [N][M] flow
-	double *dem = fl + N * M, *pot_d = dem + M, *dist_d = pot_d + M;   // [M] each
-	double *sup = dist_d + M, *pot_s = sup + N, *dist_s = pot_s + N;  // [N] each
-	int *pred_d = reinterpret_cast<int *>(dist_s + N);                // [M]
-	int *pred_s = pred_d + M, *settled = pred_s + N;                   // [N]
-	float *Cm = reinterpret_cast<float *>(settled + N);                // [N][M] cost supply j -> demand i
-	float *S = Cm + N * M;                                             // [(M + 32)][16] similarity rows
+	double *dem = vk_smem_f64, *pot_d = dem + M, *dist_d = pot_d + M;   // [M] each
+	double *sup = dist_d + M, *pot_s = sup + N, *dist_s = pot_s + N;    // [N] each
+	int *pred_d = reinterpret_cast<int *>(dist_s + N);                  // [M]
+	int *pred_s = pred_d + M, *settled = pred_s + N;                    // [N]
+	double *fl;      // [N][M] flow
+	float *Cm, *S;   // [N][M] cost supply j -> demand i; [(M + 32)][N] similarity rows
+	if constexpr (GLOBAL) {
+		uint8_t *base = p.scratch + (int64_t)blockIdx.x * p.scratch_stride;
+		fl = reinterpret_cast<double *>(base);
+		Cm = reinterpret_cast<float *>(fl + N * M);
+		S = Cm + N * M;
+	} else {
+		fl = reinterpret_cast<double *>(settled + N);   // 8-byte aligned: the ints before it come in even numbers
+		Cm = reinterpret_cast<float *>(fl + N * M);
+		S = Cm + N * M;
+	}
 
 	const int lane = threadIdx.x;
-	const int w = blockIdx.x;
+	const double EPS = 1e-13, INF = __builtin_inf();
+	for (int w = blockIdx.x; w < p.n_cand; w += gridDim.x) {
 	const uint64_t key = p.keys[w];
-	if (key == 0) return;
+	if (key == 0) continue;
 	const int64_t g = (int64_t)(uint32_t)(key & 0xffffffffu);
 	const int t_a = p.sent_start[g], t_b = p.sent_end[g];
 	const int m = t_b - t_a, n = p.len_t;
-	if (m <= VK_DEV_MAX_SENT_LEN || m > M) return;   // short slices are vk_wrd_exact_kernel's
+	if (m <= VK_DEV_MAX_SENT_LEN || m > M) continue;   // short slices are vk_wrd_exact_kernel's
 
-	const int rowbase = transport_sim_rows<1>(p, S, t_a, t_b, lane);
-	wave_lds_fence();
-	const float *Sm = S + rowbase * 16;
-	const double EPS = 1e-13, INF = __builtin_inf();
+	int rowbase;
+	if constexpr (NQ == 1) rowbase = transport_sim_rows<1>(p, S, t_a, t_b, lane);
+	else rowbase = p.nq == 2 ? transport_sim_rows<2, N>(p, S, t_a, t_b, lane) : p.nq == 3 ? transport_sim_rows<3, N>(p, S, t_a, t_b, lane) : transport_sim_rows<4, N>(p, S, t_a, t_b, lane);
+	wrdl_fence<GLOBAL>();
+	const float *Sm = S + rowbase * N;
 
 	// masses (wrd.h:99-102) and costs (:104-109)
 	if (p.mass_mode == 0) {
@@ -374,22 +401,22 @@ __global__ __launch_bounds__(64) void vk_wrd_exact_long_kernel(VkWrdParams p) {
 	for (int i = lane; i < m; i += 64) {
 		pot_d[i] = 0.0;
 		for (int j = 0; j < n; j++) {
-			float d = 1.0f - Sm[i * 16 + j];
+			float d = 1.0f - Sm[i * N + j];
 			if (!(d > 0.0f)) d = 0.0f;
 			Cm[j * M + i] = d;
 			fl[j * M + i] = 0.0;
 		}
 	}
-	wave_lds_fence();
+	wrdl_fence<GLOBAL>();
 
-	for (int iter = 0; iter < 40000; iter++) {
+	for (int iter = 0; iter < 40000 * NQ; iter++) {
 		// ---- sources: every supply with remaining mass; relax them all
 		bool any_sup = false;
-		uint32_t smask = 0;   // settled supplies (uniform)
+		uint64_t smask = 0;   // settled supplies (uniform)
 		for (int j = 0; j < n; j++) {
 			const bool src = sup[j] > EPS;
 			any_sup |= src;
-			if (src) smask |= 1u << j;
+			if (src) smask |= 1ull << j;
 			if (lane == 0) { settled[j] = src ? 1 : 0; dist_s[j] = src ? 0.0 : INF; pred_s[j] = -1; }
 		}
 		bool any_dem = false;
@@ -406,7 +433,7 @@ __global__ __launch_bounds__(64) void vk_wrd_exact_long_kernel(VkWrdParams p) {
 			any_dem |= dem[i] > EPS;
 		}
 		if (!any_sup || !__any(any_dem)) break;
-		wave_lds_fence();
+		wrdl_fence<GLOBAL>();
 
 		int target = -1;
 		double dt = INF;
@@ -435,25 +462,25 @@ __global__ __launch_bounds__(64) void vk_wrd_exact_long_kernel(VkWrdParams p) {
 			}
 			const int cb = __builtin_amdgcn_readlane(bb, c_lane);
 			const int ci = __builtin_amdgcn_readlane(bi, c_lane);
-			smask |= 1u << cb;
+			smask |= 1ull << cb;
 			if (lane == 0) { settled[cb] = 1; dist_s[cb] = cmin; pred_s[cb] = ci; }
-			wave_lds_fence();
+			wrdl_fence<GLOBAL>();
 			for (int i = lane; i < m; i += 64) {
 				double rc = (double)Cm[cb * M + i] + pot_s[cb] - pot_d[i];
 				if (rc < 0) rc = 0;
 				const double nd = cmin + rc;
 				if (nd < dist_d[i]) { dist_d[i] = nd; pred_d[i] = cb; }
 			}
-			wave_lds_fence();
+			wrdl_fence<GLOBAL>();
 		}
 		if (target < 0) break;
 
 		// ---- potentials: pot += min(dist, dt)
 		for (int i = lane; i < m; i += 64) { const double di = dist_d[i]; pot_d[i] += di < dt ? di : dt; }
 		if (lane < n) pot_s[lane] += (settled[lane] && dist_s[lane] < dt) ? dist_s[lane] : dt;
-		wave_lds_fence();
+		wrdl_fence<GLOBAL>();
 
-		// ---- bottleneck along target <- supply <- demand <- ... <- source, then augment (uniform walk over LDS)
+		// ---- bottleneck along target <- supply <- demand <- ... <- source, then augment (uniform walk)
 		double delta = dem[target];
 		int x = target;
 		for (int hop = 0; hop <= n; hop++) {
@@ -463,7 +490,7 @@ __global__ __launch_bounds__(64) void vk_wrd_exact_long_kernel(VkWrdParams p) {
 			delta = fmin(delta, fl[a * M + ps]);
 			x = ps;
 		}
-		wave_lds_fence();
+		wrdl_fence<GLOBAL>();
 		if (lane == 0) {
 			dem[target] -= delta;
 			x = target;
@@ -476,7 +503,7 @@ __global__ __launch_bounds__(64) void vk_wrd_exact_long_kernel(VkWrdParams p) {
 				x = ps;
 			}
 		}
-		wave_lds_fence();
+		wrdl_fence<GLOBAL>();
 	}
 
 	// score = sum((1 - D) * G) / sum(G) (wrd.h:139), G as float
@@ -495,19 +522,107 @@ __global__ __launch_bounds__(64) void vk_wrd_exact_long_kernel(VkWrdParams p) {
 		p.raw_out[w] = raw;
 		p.val_out[w] = (raw / p.ref_total) * boost;
 	}
+	wrdl_fence<GLOBAL>();   // the next candidate reuses the arrays
+	}
 }
 
-static size_t transport_long_lds_bytes() {
-	const size_t N = VK_WRDL_N, M = VK_WRDL_M;
-	return N * M * 8 + 3 * M * 8 + 3 * N * 8 + M * 4 + 2 * N * 4 + N * M * 4 + (M + 32) * 16 * 4;
+static size_t transport_long_lds_bytes(int nq) {
+	const size_t N = 16 * (size_t)nq, M = VK_WRDL_M;
+	const size_t vectors = 3 * M * 8 + 3 * N * 8 + M * 4 + 2 * N * 4;
+	return nq > 1 ? vectors : vectors + N * M * 8 + N * M * 4 + (M + 32) * N * 4;
 }
 
-// candidates whose slice has more than VK_DEV_MAX_SENT_LEN tokens (the others return at once); queries of at most 16 tokens
-extern "C" hipError_t vk_launch_wrd_exact_long(const VkWrdParams *p, int32_t n_cand, hipStream_t stream) {
-	const size_t smem = transport_long_lds_bytes();
-	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(vk_wrd_exact_long_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+extern "C" int vk_wrd_long_blocks(void) { return 256; }
+
+extern "C" size_t vk_wrd_long_scratch_bytes(void) {
+	const size_t N = 64, M = VK_WRDL_M;
+	return (N * M * 8 + N * M * 4 + (M + 32) * N * 4 + 255) / 256 * 256;
+}
+
+// candidates whose slice has more than VK_DEV_MAX_SENT_LEN tokens (the others are skipped at once)
+extern "C" hipError_t vk_launch_wrd_exact_long(const VkWrdParams *pp, int32_t n_cand, hipStream_t stream) {
+	VkWrdParams p = *pp;
+	p.n_cand = n_cand;
+	if (n_cand < 1) return hipSuccess;
+	if (p.nq <= 1) {
+		const size_t smem = transport_long_lds_bytes(1);
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(vk_wrd_exact_long_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+		if (e != hipSuccess) return e;
+		vk_wrd_exact_long_kernel<1><<<n_cand, 64, smem, stream>>>(p);
+		return hipGetLastError();
+	}
+	if (!p.scratch || p.scratch_stride < (int64_t)vk_wrd_long_scratch_bytes()) return hipErrorInvalidValue;
+	const int blocks = n_cand < vk_wrd_long_blocks() ? n_cand : vk_wrd_long_blocks();
+	vk_wrd_exact_long_kernel<4><<<blocks, 64, transport_long_lds_bytes(4), stream>>>(p);
+	return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Exact transport with a query of 17..64 tokens, stage 1 for the slices of more than VK_DEV_MAX_SENT_LEN tokens (the short
+// ones: transport_bound32 in vk_score32_kernel): the nearest-neighbour relaxation in both directions, the same bound with the
+// same combination of the two sides.  One wave per long slice, its similarity rows [m x 64] in LDS (139 KB).  A fallback that
+// keeps such corpora on the device, not a roofline kernel.  The three padding rows of the slice's group get the "empty" score.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void vk_long_bound_kernel(VkWrdParams p) {
+	constexpr int N = 64, M = VK_WRDL_M;
+	extern __shared__ double vk_smem_f64[];
+	float *S = reinterpret_cast<float *>(vk_smem_f64);   // [(M + 32)][N]
+	const int lane = threadIdx.x;
+	const float BIG = 3.402823466e+38F;
+	for (int gi = blockIdx.x; gi < p.n_list; gi += gridDim.x) {
+		const int row = p.group_list[gi] * 4;
+		const int t_a = p.sent_start[row], t_b = p.sent_end[row];
+		const int m = t_b - t_a, n = p.len_t;
+		if (lane >= 1 && lane < 4 && row + lane < p.n_entries) { p.scores[row + lane] = VK_NEG_INF; p.raw[row + lane] = VK_NEG_INF; }
+		if (m < 1 || m > M) {
+			if (lane == 0) { p.scores[row] = VK_NEG_INF; p.raw[row] = VK_NEG_INF; }
+			continue;
+		}
+		const int rowbase = p.nq == 2 ? transport_sim_rows<2, N>(p, S, t_a, t_b, lane) : p.nq == 3 ? transport_sim_rows<3, N>(p, S, t_a, t_b, lane) : transport_sim_rows<4, N>(p, S, t_a, t_b, lane);
+		wave_lds_fence();
+		const float *Sm = S + rowbase * N;
+		const bool by_id = p.layout == VK_DEV_LAYOUT_STATIC;
+		// slice side: every slice token to its nearest query token
+		float sum_s = 0.0f, lb1n = 0.0f;
+		for (int i = lane; i < m; i += 64) {
+			const float mg = p.mag ? (by_id ? p.mag[p.tok_id[t_a + i]] : p.mag[t_a + i]) : 1.0f;
+			float rmin = BIG;
+			for (int j = 0; j < n; j++) rmin = fminf(rmin, fmaxf(1.0f - Sm[i * N + j], 0.0f));
+			sum_s += mg;
+			lb1n += mg * rmin;
+		}
+		// query side: every query token to its nearest slice token
+		float x = 0.0f;
+		if (lane < n) {
+			float cmin = BIG;
+			for (int i = 0; i < m; i++) cmin = fminf(cmin, fmaxf(1.0f - Sm[i * N + lane], 0.0f));
+			x = p.qmass[lane] * cmin;
+		}
+#pragma unroll
+		for (int off = 32; off >= 1; off >>= 1) { sum_s += __shfl_xor(sum_s, off, 64); lb1n += __shfl_xor(lb1n, off, 64); x += __shfl_xor(x, off, 64); }
+		const float lb1 = sum_s > 0.0f ? lb1n / sum_s : 0.0f;
+		float lb;
+		if (p.wmd_bound == 2) lb = n <= m ? x / (float)n : lb1;                                       // unit masses: the shorter side ships everything
+		else if (p.wrd_raw_total > 0.0f) lb = p.wrd_raw_total <= sum_s ? x / p.wrd_raw_total : lb1;  // magnitudes as they are: the lighter side
+		else lb = fmaxf(x, lb1);                                                                      // both sides ship 1
+		if (!(sum_s > 0.0f)) lb = 0.0f;
+		const float raw = fminf(1.0f - lb * (1.0f - 4e-6f) + 3e-5f, 1.0f);
+		if (lane == 0) {
+			const float boost = p.boost ? p.boost[row] : 1.0f;
+			p.scores[row] = (raw / p.ref_total) * boost;
+			p.raw[row] = raw;
+		}
+		wave_lds_fence();
+	}
+}
+
+extern "C" hipError_t vk_launch_long_bound(const VkWrdParams *p, hipStream_t stream) {
+	if (p->n_list < 1) return hipSuccess;
+	const size_t smem = (size_t)(VK_WRDL_M + 32) * 64 * 4;
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(vk_long_bound_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 	if (e != hipSuccess) return e;
-	vk_wrd_exact_long_kernel<<<n_cand, 64, smem, stream>>>(*p);
+	const int blocks = p->n_list < 2048 ? p->n_list : 2048;
+	vk_long_bound_kernel<<<blocks, 64, smem, stream>>>(*p);
 	return hipGetLastError();
 }
 
