@@ -188,6 +188,15 @@ def test_span_kernel_every_slice(hip, oracle, d, n):
 	order = np.argsort(-cos, kind="stable")[:got.n]
 	np.testing.assert_allclose(got.score[:got.n], cos[order], atol=2e-6)
 	assert got.n == min(n, 20) and int(got.sentence[0]) == 0
+	# the aligner scores of the winners, with and without traceback, with and without a booster (the kernel writes its second
+	# output array only in the last case)
+	boost = (0.5 + rng.random(n)).astype(np.float32)
+	for want_flow in (True, False):
+		for b in (None, boost):
+			r = c.query(Qb, q_normalize=False, max_matches=min(n, 20), min_score=-1.0, want_flow=want_flow, boost=b)
+			sel = r.sentence[:r.n]
+			np.testing.assert_allclose(r.raw_score[:r.n], cos[sel], atol=2e-6)
+			np.testing.assert_allclose(r.score[:r.n], cos[sel] * (1.0 if b is None else b[sel]), atol=2e-6)
 	c.close()
 
 

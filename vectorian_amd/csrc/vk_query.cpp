@@ -183,6 +183,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	VK_HIP(hipMemcpyAsync(c->d_qtile, qtile.data(), qtile.size(), hipMemcpyHostToDevice, st));
 
 	VkScoreParams p{};
+	bool span_skip_raw = false;   // span-embedding path without its second output array
 	float qmass_all[VK_MAX_QUERY_LEN] = {0};   // masses of the query tokens (transport algorithms), all 64 columns
 	const int ks = q->gap_s.kind, kt = q->gap_t.kind;
 	float ws[kGapTable], wt[160];   // wt[0..79]: w_t as given; wt[80..159]: its subadditive closure
@@ -358,8 +359,13 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		}
 		else VK_HIP(vk_launch_wide(&wp, 0, st));
 	} else if (is_align && !is_static && q->len_t == 1 && c->uniform_len == 1 && q->locality == VK_LOCAL && !p.pos_s) {
-		// span-embedding index: one vector per slice, one query vector -> the clipped cosine is the local alignment score
-		VK_HIP(vk_launch_span(&p, st));
+		// span-embedding index: one vector per slice, one query vector -> the clipped cosine is the local alignment score.
+		// The aligner scores are written only if something reads them: the traceback kernel restates those of the winners, and
+		// without a booster the score IS the aligner score ((raw / 1) * 1)
+		span_skip_raw = !(q->submatch_weight > 0.0f) && ((q->want_flow && is_align) || !p.boost || !out->raw_score);
+		VkScoreParams ps = p;
+		if (span_skip_raw) ps.raw = nullptr;
+		VK_HIP(vk_launch_span(&ps, st));
 	} else {
 	p.max_short_len = VK_FAST_SENT_LEN;
 	p.s_rows_per_wave = is_static ? (c->max_group_tokens + 15) / 16 * 16 : c->max_group_tiles * 16;
@@ -705,7 +711,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		// gather the aligner scores of the winners
 		for (int i = 0; i < n_out; i++) {
 			const int64_t g = (int64_t)(uint32_t)(keys[(size_t)i] & 0xffffffffu);
-			VK_HIP(hipMemcpyAsync(&raw_sel[(size_t)i], c->d_raw + g, 4, hipMemcpyDeviceToHost, st));
+			if (!span_skip_raw) VK_HIP(hipMemcpyAsync(&raw_sel[(size_t)i], c->d_raw + g, 4, hipMemcpyDeviceToHost, st));
 		}
 		VK_HIP(hipStreamSynchronize(st));
 	}
@@ -717,7 +723,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		memcpy(&s, &bits, 4);
 		out->score[i] = s;
 		out->sentence[i] = sentence_of((int64_t)(uint32_t)(key & 0xffffffffu));
-		if (out->raw_score) out->raw_score[i] = do_flow ? raw[(size_t)i] : raw_sel[(size_t)i];
+		if (out->raw_score) out->raw_score[i] = do_flow ? raw[(size_t)i] : span_skip_raw ? s : raw_sel[(size_t)i];
 		if (do_flow) {
 			for (int j = 0; j < q->len_t; j++) {
 				out->mapping[(size_t)i * q->len_t + j] = map[(size_t)i * ostride + j];
