@@ -368,6 +368,13 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		VK_HIP(vk_launch_span(&ps, st));
 	} else {
 	p.max_short_len = VK_FAST_SENT_LEN;
+	// the aligner scores of all slices: read by the submatch bound and, without traceback, for the winners; with traceback the
+	// flow kernel restates those of the winners
+	// (exact transport: the solver states them); a second output array costs the stream 1 % (2.90 -> 2.87 ms per 1 M x 32 x 300-d)
+	{
+		const bool exact_tr2 = q->algorithm == VK_ALG_WRD || (q->algorithm == VK_ALG_RWMD && q->wmd_full);
+		if (((is_align && q->want_flow) || exact_tr2) && !(q->submatch_weight > 0.0f) && !getenv("VK_KEEP_RAW")) p.raw = nullptr;
+	}
 	p.s_rows_per_wave = is_static ? (c->max_group_tokens + 15) / 16 * 16 : c->max_group_tiles * 16;
 	p.h_rows = c->max_short_len + 1;
 	const int lt = q->len_t <= 4 ? 4 : q->len_t <= 8 ? 8 : q->len_t <= 12 ? 12 : 16;   // strip rows hold the padded query columns (launch_score_lt)

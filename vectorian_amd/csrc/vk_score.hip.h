@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 				val = (raw / inv_ref) * boost;
 			}
 			p.scores[s_idx] = val;
-			p.raw[s_idx] = r;
+			if (p.raw) p.raw[s_idx] = r;
 		}
 		wave_lds_fence();
 	}
