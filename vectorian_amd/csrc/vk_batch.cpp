@@ -430,6 +430,10 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 		VK_HIP(hipMemcpyAsync(c->d_boost, qs[0].boost, (size_t)n * 4, hipMemcpyHostToDevice, st));
 	}
 
+	// handles on one corpus take turns, as in vk_query: this batch's GEMM starts when the peer's has finished, so that the
+	// selection, the copies and the host part of one batch run beside the GEMM of the next (the wait is on the device)
+	VK_HIP(hipEventRecord(c->ev[5], st));
+	if (c->peer && c->peer->ev2_recorded) VK_HIP(hipStreamWaitEvent(st, c->peer->ev[2], 0));
 	VK_HIP(hipEventRecord(c->ev[1], st));
 	VkRwmdBatchParams p{};
 	p.tiles = c->d_tiles; p.n_tiles = (c->desc.n_tokens + 15) / 16;
@@ -457,7 +461,7 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 		}
 	}
 
-	VK_HIP(hipEventRecord(c->ev[2], st));
+	VK_HIP(hipEventRecord(c->ev[6], st));
 	int64_t nw = 0;
 	int cur = 0;
 	VK_HIP(vk_launch_topk_wave_batch(c->d_bscores, nullptr, n, qs[0].min_score, k, 4096, n_queries, n, nw1 * k, c->d_bkeys[0], &nw, st));
@@ -468,6 +472,11 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 		VK_HIP(vk_launch_topk_wave_batch(nullptr, c->d_bkeys[cur], nkeys, 0.0f, k, per_wave, n_queries, stride, stride, c->d_bkeys[1 - cur], &nw, st));
 		cur = 1 - cur;
 	}
+	// the turn passes AFTER the selection: a GEMM fills every CU for 40 ms, and a selection that starts beside the peer's GEMM waits
+	// for it to end (0.5 ms of work returned 20 ms late, the handle's next batch submitted late: 1.6 - 1.9 ms of idle GPU per pair of
+	// batches); behind the selection the peer's GEMM starts 0.5 ms later and this handle's host part runs beside it
+	VK_HIP(hipEventRecord(c->ev[2], st));
+	c->ev2_recorded = true;
 	VK_HIP(hipEventRecord(c->ev[3], st));
 	VK_HIP(hipEventRecord(c->ev[4], st));
 	std::vector<uint64_t> keys((size_t)n_queries * (size_t)k);
@@ -499,10 +508,11 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 	c->have_scores = false;
 	float ms = 0;
 	vk_timings t{};
-	if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) t.prepare_ms = ms;
-	if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) t.score_ms = ms;
-	if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) t.topk_ms = ms;
-	if (hipEventElapsedTime(&ms, c->ev[0], c->ev[4]) == hipSuccess) t.total_ms = ms;
+	if (hipEventElapsedTime(&ms, c->ev[0], c->ev[5]) == hipSuccess) t.prepare_ms = ms;
+	if (hipEventElapsedTime(&ms, c->ev[5], c->ev[1]) == hipSuccess) t.queue_ms = ms;
+	if (hipEventElapsedTime(&ms, c->ev[1], c->ev[6]) == hipSuccess) t.score_ms = ms;
+	if (hipEventElapsedTime(&ms, c->ev[6], c->ev[3]) == hipSuccess) t.topk_ms = ms;
+	if (hipEventElapsedTime(&ms, c->ev[0], c->ev[4]) == hipSuccess) t.total_ms = ms - t.queue_ms;
 	c->last = t;
 	return VK_OK;
 }

@@ -113,7 +113,7 @@ struct vk_corpus {
 	int64_t bl_empty = 0;        // slices without tokens (in no bucket: their scores stay -inf)
 	size_t wrd_cap = 0;          // candidates d_wrd_raw / d_wrd_val (and d_keys[0]) can hold
 	int16_t *d_out_map = nullptr;
-	hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // 0 start, 5 before / 1 after the wait for the peer's kernel, 2 scored, 3 selected, 4 done
+	hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // 0 start, 5 before / 1 after the wait for the peer's kernel, 2 scored (the peer's turn), 3 selected, 4 done; 6: the batched GEMM has ended (its turn ends after the selection)
 	vk_timings last{};
 	bool have_scores = false;
 	bool is_view = false;        // shares the corpus arrays of another handle (vk_corpus_view): does not free them
