@@ -284,7 +284,7 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 		const int t_a = p.sent_start[g], t_b = p.sent_end[g];
 		const int len_s = t_b - t_a;
 		if (len_s < 1) {
-			if (!FLOW && lane == 0) { p.scores[g] = VK_NEG_INF; p.raw[g] = VK_NEG_INF; }
+			if (!FLOW && lane == 0) { p.scores[g] = VK_NEG_INF; if (p.raw) p.raw[g] = VK_NEG_INF; }
 			continue;
 		}
 		// similarities of tokens base .. base + 15 (contextual: one tile, 16-aligned; static: gather)
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 			if (lane == 0) {
 				const float boost = p.boost ? p.boost[g] : 1.0f;
 				p.scores[g] = (raw / p.ref_total) * boost;
-				p.raw[g] = raw;
+				if (p.raw) p.raw[g] = raw;
 			}
 			continue;
 		}

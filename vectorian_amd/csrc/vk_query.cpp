@@ -319,6 +319,10 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 			wp.tpos[j] = (p.pos_s && j < q->len_t) ? (int32_t)q->q_pos[j] : -1;
 		}
 		wp.boost = p.boost; wp.scores = c->d_scores; wp.raw = c->d_raw;
+		{   // as for the 16-column kernel: the aligner scores of all slices only if something reads them
+			const bool exact_tr2 = q->algorithm == VK_ALG_WRD || (q->algorithm == VK_ALG_RWMD && q->wmd_full);
+			if (((is_align && q->want_flow) || exact_tr2) && !(q->submatch_weight > 0.0f) && !getenv("VK_KEEP_RAW")) wp.raw = nullptr;
+		}
 		// 17..32 tokens with linear / affine gaps over a bf16 contextual corpus of short slices: the fused two-block kernel
 		// (affine: the prefix-scan form of F needs open_t >= extend_t, as dp_affine)
 		// (33..64 tokens: one slice per wave and four column blocks)

@@ -602,7 +602,7 @@ __global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t
 				val = (raw / p.ref_total) * boost;
 			}
 			p.scores[s_idx] = val;
-			p.raw[s_idx] = r;
+			if (p.raw) p.raw[s_idx] = r;
 		}
 		wave_lds_fence();
 	}
