@@ -55,6 +55,9 @@ WORKLOADS = {
 	"2f32": dict(name="config2_f32", n_sent=1000000, min_len=32, max_len=32, d=300, alg="align", locality="local", gap="exp5", prec="f32"),
 	# the reference's own layout for static embeddings (fastText / GloVe: token ids + vocabulary table, per-query table [V x |q|],
 	# StaticEmbeddingSlice, slice/static.h:71-75): no vectors are streamed, the kernel is bound by the DP's instruction issue
+	# several queries with the same options in one call (Index.find_many / vk_query_batch): every token tile is read once per PAIR of
+	# queries (vk_score_batch_kernel), so the pairs per second are not bound by |s| d 2 bytes per pair
+	"2shared": dict(name="config2_shared_pass", n_sent=1000000, min_len=32, max_len=32, d=300, alg="align", locality="local", gap="exp5", prec="bf16", batch=8, per_pass=2),
 	"2static": dict(name="config2_static", n_sent=4000000, min_len=32, max_len=32, d=300, alg="align", locality="local", gap="exp5", prec="bf16", layout="static"),
 }
 LOCALITIES = {"local": 0, "global": 1, "semiglobal": 2}
@@ -72,6 +75,9 @@ def describe(spec, n_sent):
 	rows = f"{n_sent} x {lens}-token synthetic sentences per GPU, {spec['d']}-d {spec['prec']} per-token vectors (contextual layout)"
 	if spec.get("layout") == "static":
 		rows = f"{n_sent} x {lens}-token synthetic sentences per GPU as token ids over a {VOCAB}-word {spec['d']}-d vocabulary (static layout: per-query table [V x |q|] + gather)"
+	if spec["alg"] == "align" and spec.get("batch"):
+		return (f"{spec['batch']} {LEN_T}-token queries per call over {rows}, {spec['locality']} alignment, {gap_spec(spec['gap'])[2]}, top-{K_MATCHES} with flow per query; "
+			f"the token tiles are streamed once per {spec.get('per_pass', 2)} queries")
 	if spec["alg"] == "rwmd":
 		return f"batch of {spec.get('batch', 1)} {LEN_T}-token queries over {rows}, relaxed Word Mover's Distance rwmd('nbow'), top-{K_MATCHES} per query"
 	if spec["alg"] == "wrd":
@@ -257,7 +263,7 @@ class Runner:
 	343 M/s with two handles and with three; the register form needed three: 341 against 326 M/s).  Every query is
 	complete (top-k with flow on the host; with several ranks: merged across ranks) inside the timed region."""
 
-	def __init__(self, core, torch, corpus, spec, n_sent, dist, xdev, rank, n_handles, gap_name=None, locality=None):
+	def __init__(self, core, torch, corpus, spec, n_sent, dist, xdev, rank, n_handles, gap_name=None, locality=None, batch_handles=None):
 		from concurrent.futures import ThreadPoolExecutor
 		from vectorian_amd import shards
 		self.core, self.torch, self.corpus, self.spec, self.n_sent = core, torch, corpus, spec, n_sent
@@ -265,7 +271,7 @@ class Runner:
 		self.batch = int(spec.get("batch", 0))
 		# batches: two handles as well -- the selection, the copies and the host part of one batch run beside the GEMM of the next
 		# (the turn passes after the selection, vk_batch.cpp): 40.9 -> 39.1 ms per batch of 256
-		n_batch_handles = max(1, int(os.environ.get("VK_BENCH_BATCH_HANDLES", "2")))
+		n_batch_handles = batch_handles or max(1, int(os.environ.get("VK_BENCH_BATCH_HANDLES", "2")))
 		self.handles = [corpus] + [corpus.view() for _ in range((n_batch_handles if self.batch else n_handles) - 1)]
 		self.pool = ThreadPoolExecutor(max_workers=len(self.handles))
 		self.inflight, self.pending, self.unsent = [], [], []
@@ -369,6 +375,15 @@ def roofline_of(spec, n_sent, n_tok, kern_s):
 	sentence) pair (bf16 token vectors read once; fp32 rows: * 4; WRD: + 4 bytes of magnitude per token), padding not
 	counted; config 4: 2 * |s| * |q| * d flops per pair against the dense bf16 MFMA peak"""
 	d = spec["d"]
+	if spec.get("batch") and spec["alg"] == "align":
+		# shared pass: kern_s is the sum over the call's passes (ceil(batch / per_pass)); one pass streams the corpus once
+		passes = -(-spec["batch"] // spec.get("per_pass", 2))
+		nbytes = n_tok * d * 2
+		ach = nbytes / (kern_s / passes)
+		return {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
+			"kernel": "vk_score_batch_kernel", "kernel_ms": kern_s / passes * 1e3, "algorithmic_bytes_per_launch": nbytes,
+			"queries_per_launch": spec.get("per_pass", 2),
+			"note": "one launch scores the corpus against 2 queries: the DPs of both, not the stream, bound it"}
 	if spec.get("batch"):
 		flops = 2.0 * n_tok * spec["batch"] * LEN_T * d
 		ach = flops / kern_s
@@ -417,7 +432,7 @@ def main():
 	ap.add_argument("--no-cpu-baseline", action="store_true")
 	ap.add_argument("--no-pipeline", action="store_true", help="one handle, one query at a time")
 	ap.add_argument("--no-extra", action="store_true", help="headline workload only (no \"configs\" object)")
-	ap.add_argument("--extra", default="4,3,2f32,2static,5,5wrd", help="the other configurations timed at N = 1 after the headline")
+	ap.add_argument("--extra", default="4,3,2f32,2static,2shared,5,5wrd", help="the other configurations timed at N = 1 after the headline")
 	ap.add_argument("--extra-steps", type=int, default=12)
 	ap.add_argument("--extra-warmup", type=int, default=4)
 	ap.add_argument("--extra-min-ms", type=float, default=300.0, help="the extra configurations run at least this long inside their timed region")
@@ -516,11 +531,13 @@ def main():
 		finally:
 			r.close()
 		kernel_alone_ms = None
-		if spec["alg"] == "wrd" and n_handles > 1:
+		shared_pass = spec["alg"] == "align" and batch > 0
+		if (spec["alg"] == "wrd" and n_handles > 1) or shared_pass:
 			# The bound passes of the queries in flight do not take turns (vk_query.cpp: two passes sharing the chip fill each
 			# other's epilogue gaps), so a launch's own events span the work of its neighbours too.  The kernel's duration for the
 			# roofline is taken one query at a time, in the same process, right after the timed region.
-			r1 = Runner(core, torch, corpus, spec, n_sent, None, xdev, rank, 1)
+			# (the shared passes of two calls in flight overlap in the same way)
+			r1 = Runner(core, torch, corpus, spec, n_sent, None, xdev, rank, 1, batch_handles=1)
 			try:
 				r1.run(queries, 1, min(4, steps))
 			finally:
@@ -544,8 +561,8 @@ def main():
 		}
 		entry["kernel"], entry["kernel_ms"] = entry["roofline"]["kernel"], entry["roofline"]["kernel_ms"]
 		if kernel_alone_ms is not None:
-			entry["roofline"]["kernel_ms_note"] = ("one query at a time (4 launches after the timed region); with three queries in flight the bound passes "
-				f"overlap on the chip and a launch's own events span {float(np.mean(r.score_ms)):.2f} ms")
+			entry["roofline"]["kernel_ms_note"] = ("one call at a time (4 after the timed region); with several in flight the passes "
+				f"overlap on the chip and a call's own events span {float(np.mean(r.score_ms)):.2f} ms")
 		return spec, entry
 
 	keep = {}
@@ -585,7 +602,9 @@ def main():
 			# driver (freed corpora: the static layout once showed 9 ms per step over 12 steps, 3.44 over 60): at least
 			# --extra-min-ms of timed steps, a third of that as warm-up
 			avg_len = (w["min_len"] + w["max_len"]) / 2
-			if w.get("batch"):
+			if w.get("batch") and w["alg"] == "align":
+				est_ms = -(-w["batch"] // w.get("per_pass", 2)) * n_x * avg_len * w["d"] * 2 / (0.6 * HBM_PEAK) * 1e3
+			elif w.get("batch"):
 				est_ms = 2.0 * n_x * avg_len * w["batch"] * LEN_T * w["d"] / (0.5 * MFMA_BF16_PEAK) * 1e3
 			elif w.get("layout") == "static":
 				est_ms = n_x * avg_len * LEN_T / 370e9 * 1e3
