@@ -122,6 +122,7 @@ static int query_batch_shared_pass(vk_corpus_t *c, const vk_query_desc *qs, int3
 	p.nk32 = c->nk32; p.tail = c->tail; p.tile_bytes = c->tile_bytes;
 	p.qtiles = c->d_bq; p.locality = q0.locality; p.ws = c->d_ws; p.wt = c->d_wt + 80; p.wt0 = c->d_wt;
 	p.boost = q0.boost ? c->d_boost : nullptr; p.scores = c->d_bscores; p.raw = c->d_braw;
+	if (q0.want_flow && q0.algorithm == VK_ALG_ALIGN) p.raw = nullptr;   // the flow kernel restates the winners' aligner scores; nothing else reads the array (no submatch weights here)
 
 	float score_ms_total = 0.0f, total_ms = 0.0f;
 	std::vector<uint8_t> all(need_q), one;

@@ -60,9 +60,9 @@ __global__ __launch_bounds__(256) void vk_score_batch_kernel(VkScoreBatchParams 
 		const int tile0 = g_a >> 4;
 		const int ntiles = ((g_b + 15) >> 4) - tile0;
 		const uint8_t *tp = p.tiles + (int64_t)tile0 * p.tile_bytes;
-		// Tiles of at most ten K-steps (d <= 320): the loads of tile ti + 1 are issued before the MFMAs of tile ti.
-		// No branches around the loads (clamped addresses, results zeroed by a select): a branch would make the
-		// compiler wait for all outstanding loads at its join.
+		// Other widths: ten K-steps at a time, no branches around the loads (clamped addresses, results zeroed by a select): a
+		// branch would make the compiler wait for all outstanding loads at its join.  (Round 1 prefetched tile ti + 1 during the
+		// MFMAs of tile ti, with a reload of each group's last tile and 80 registers of staging: 537 against 595 M pairs/s.)
 		const int t_last = p.tail ? nfull : nfull - 1;
 		auto load10 = [&](const uint8_t *tile, int t0, bf16x8 (&x)[10]) {
 #pragma unroll
@@ -89,19 +89,28 @@ __global__ __launch_bounds__(256) void vk_score_batch_kernel(VkScoreBatchParams 
 					}
 				}
 		};
-		const bool one_chunk = p.nk32 <= 10;
-		bf16x8 xa[10], xb[10];
-		if (one_chunk && ntiles > 0) load10(tp, 0, xa);
+		bf16x8 xb[10];
 		for (int ti = 0; ti < ntiles; ti++) {
 			f32x4 acc[VK_QB_MAX];
 #pragma unroll
 			for (int qb = 0; qb < VK_QB_MAX; qb++) acc[qb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-			if (one_chunk) {
-				const uint8_t *nxt = tp + (ti + 1 < ntiles ? p.tile_bytes : 0);   // last tile: a harmless reload
-				load10(nxt, 0, xb);
-				mfma10(0, xa, acc);
+			if (p.nk32 == 10 && p.tail) {
+				// 300-d rows: the tile's nine full K-steps and the half one, loaded once and multiplied with every query tile
+				bf16x8 x[10];
 #pragma unroll
-				for (int i = 0; i < 10; i++) xa[i] = xb[i];
+				for (int t = 0; t < 9; t++) x[t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(tp + t * 1024 + lane * 16));
+				x[9] = load_half_block(tp + 9 * 1024, lane, true);
+#pragma unroll
+				for (int qb = 0; qb < VK_QB_MAX; qb++)
+					if (qb < qb_n) {
+						const uint8_t *qq = qlds + (size_t)qb * p.tile_bytes;
+#pragma unroll
+						for (int t = 0; t < 10; t++) {
+							bf16x8 q = *reinterpret_cast<const bf16x8 *>(qq + t * 1024 + (t == 9 ? (lane & 31) : lane) * 16);
+							if (t == 9) { const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0}; q = lane < 32 ? q : z; }
+							acc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q, x[t], acc[qb], 0, 0, 0);
+						}
+					}
 			} else {
 				for (int t0 = 0; t0 < p.nk32; t0 += 10) {
 					load10(tp, t0, xb);
@@ -140,7 +149,7 @@ __global__ __launch_bounds__(256) void vk_score_batch_kernel(VkScoreBatchParams 
 					val = (raw / (float)p.len_t[qb]) * boost;
 				}
 				p.scores[(int64_t)qb * p.n_sent + s_idx] = val;
-				p.raw[(int64_t)qb * p.n_sent + s_idx] = r;
+				if (p.raw) p.raw[(int64_t)qb * p.n_sent + s_idx] = r;
 			}
 			if (GAP == 2) wave_lds_fence();
 		}
