@@ -170,6 +170,11 @@ class OracleCorpus:
 					top.plan[i, :len(q), :b - a] = G
 		return top
 
+	def query_batch(self, queries, **options):
+		"""vk_query_batch's contract: n_queries calls of vk_query with common options"""
+		self.batch_calls = getattr(self, "batch_calls", 0) + 1
+		return [self.query(q, **options) for q in queries]
+
 	def view(self):
 		return self          # the double keeps no per-query state a second handle would need
 

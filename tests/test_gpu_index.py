@@ -113,6 +113,36 @@ def test_find_many_on_hip_equals_find(hip):
 	index.close()
 
 
+@pytest.mark.parametrize("strategy,uniform,d", [("local", None, 64), ("local", None, 300), ("rwmd", 32, 300), ("rwmd", None, 300), ("rwmd", None, 64), ("rwmd_bow", None, 300)])
+def test_find_many_shares_calls_on_hip(hip, strategy, uniform, d):
+	"""Index.find_many over a contextual embedding: alignment queries share passes over the corpus (vk_score_batch_kernel), relaxed-WMD
+	queries go up to 256 per call through the GEMM kernels (uniform 32-token sentences: on the resident tiles; ragged: padded buckets),
+	with the similarity rows of every query's winners for the flows; every Result as from find()"""
+	from test_host_api import contextual_toy
+	from vectorian_amd.alignment import WordMoversDistance
+	session, emb, docs = contextual_toy(n_docs=6, sents=120, d=d, uniform=uniform)   # 300-d: the GEMM kernels; 64-d: the shared pass
+	al = {"local": alignment.LocalAlignment(gap=alignment.smooth_gap_cost(5)), "rwmd": WordMoversDistance.rwmd("nbow"),
+		"rwmd_bow": WordMoversDistance.rwmd("bow/fast")}[strategy]
+	index = session.partition("sentence").index(OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), al))
+	texts = [" ".join(docs[i % 6].tokens[9 * i:9 * i + 3 + i % 8]) for i in range(45)]
+	many = index.find_many(texts, n=6, batch=True)
+	for text, res in zip(texts, many):
+		one = index.find(text, n=6)
+		assert [(m.doc_index, m.slice_id) for m in res] == [(m.doc_index, m.slice_id) for m in one]
+		np.testing.assert_allclose([m.score for m in res], [m.score for m in one], atol=2e-6)
+		for a, b in zip(res, one):
+			fa, fb = a.flow, b.flow
+			assert fa["type"] == fb["type"]
+			if fa["type"] == "injective":
+				assert (fa["target"] == fb["target"]).all()
+			else:
+				assert set(fa) == set(fb)
+				for key in fa:
+					if key != "type":
+						np.testing.assert_allclose(np.asarray(fa[key], dtype=float), np.asarray(fb[key], dtype=float), atol=1e-6)
+	index.close()
+
+
 def test_tag_weighted_transport_and_long_queries_on_hip_equal_oracle_double(hip):
 	"""'alignment-tag-weighted' with the transport strategies (any matcher takes the modifier, match/instantiate.cpp:173-189) and
 	transport queries of more than 16 tokens, through Session / Index.find: ids, scores and the stated flows as the double's"""

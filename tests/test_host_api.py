@@ -209,6 +209,46 @@ def test_contextual_embedding_and_boost():
 	assert len(r) == 3
 
 
+def contextual_toy(n_docs=4, sents=40, d=48, seed=4, uniform=None):
+	rng = np.random.default_rng(seed)
+	table = {}
+	def vec(tok):
+		if tok not in table:
+			table[tok] = rng.standard_normal(d).astype(np.float32)
+		return table[tok]
+	docs = []
+	for di in range(n_docs):
+		ss = [[f"t{int(rng.integers(0, 60))}" for _ in range(uniform or int(rng.integers(2, 12)))] for _ in range(sents)]
+		toks = [t for s_ in ss for t in s_]
+		X = np.stack([vec(t) + 0.05 * rng.standard_normal(d).astype(np.float32) for t in toks])
+		docs.append(Document(ss, contextual_embeddings={"ctx": X}))
+	emb = ContextualEmbedding("ctx", d, lambda tokens: np.stack([vec(t) for t in tokens]))
+	return Session(docs, embeddings=[emb]), emb, docs
+
+
+@pytest.mark.parametrize("strategy", ["local", "rwmd"])
+def test_find_many_shares_calls_over_contextual_embeddings(strategy):
+	# queries with common options over a contextual embedding go to the backend several per call (query_batch); every Result as from find()
+	session, emb, docs = contextual_toy()
+	al = alignment.LocalAlignment(gap=alignment.smooth_gap_cost(5)) if strategy == "local" else alignment.WordMoversDistance.rwmd("nbow")
+	index = session.index(OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), al), corpus_factory=OracleCorpus)
+	texts = [" ".join(docs[i % 4].tokens[5 * i:5 * i + 3 + i % 4]) for i in range(21)] + [""]
+	many = index.find_many(texts, n=5)
+	assert index._corpus.batch_calls >= 1 and len(many) == len(texts) and many[-1].matches == []
+	for text, res in zip(texts, many):
+		one = index.find(text, n=5)
+		assert [(m.doc_index, m.slice_id, m.score) for m in res] == [(m.doc_index, m.slice_id, m.score) for m in one]
+		for a, b in zip(res, one):
+			assert a.to_json()["regions"] == b.to_json()["regions"]
+	calls = index._corpus.batch_calls
+	assert len(index.find_many(texts, n=5, batch=False)) == len(texts) and index._corpus.batch_calls == calls   # never
+	wrd = session.index(OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), alignment.WordRotatorsDistance()), corpus_factory=OracleCorpus)
+	with pytest.raises(RuntimeError):
+		wrd.find_many(texts[:3], n=5, batch=True)    # exact transport does not share calls
+	assert len(wrd.find_many(texts[:3], n=5)) == 3
+	index.close(); wrd.close()
+
+
 def test_transport_strategies_over_static_embedding():
 	"""WordRotatorsDistance and the named RWMD variants through Index.find on a static embedding (vocabulary magnitudes)."""
 	session, emb, words, rng = toy_session(n_docs=2, sents_per_doc=40, V=120, d=24)

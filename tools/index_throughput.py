@@ -21,36 +21,51 @@ def main():
 	ap.add_argument("--sentences", type=int, default=1000000)
 	ap.add_argument("--queries", type=int, default=60)
 	ap.add_argument("--in-flight", type=int, default=3)
+	ap.add_argument("--contextual", action="store_true", help="per-token vectors (contextual embedding) instead of the static layout: find_many then shares calls (vk_query_batch)")
+	ap.add_argument("--strategy", choices=["local", "rwmd"], default="local")
+	ap.add_argument("--no-batch", action="store_true", help="find_many(batch=False): one query per call")
 	args = ap.parse_args()
 	from vectorian_amd import alignment, synth
 	from vectorian_amd.corpus import Corpus, Document
-	from vectorian_amd.embedding import StaticEmbedding
+	from vectorian_amd.embedding import ContextualEmbedding, StaticEmbedding
 	from vectorian_amd.session import Session
 	from vectorian_amd.sim import CosineSim, EmbeddingTokenSim, OptimizedSpanSim
 	V, d, len_s = 50000, 300, 32
 	rng = np.random.default_rng(5)
 	words = [f"w{i}" for i in range(V)]
-	emb = StaticEmbedding("synthetic-300", words, synth.make_vocab(V, d))
+	E = synth.make_vocab(V, d)
+	word_id = {w: i for i, w in enumerate(words)}
+	if args.contextual:
+		emb = ContextualEmbedding("ctx", d, lambda tokens: E[[word_id[t] for t in tokens]])
+	else:
+		emb = StaticEmbedding("synthetic-300", words, E)
 	per_doc = 10000
 	docs = []
 	for di in range((args.sentences + per_doc - 1) // per_doc):
 		ids = synth.zipf_ids(per_doc * len_s, V, rng).reshape(per_doc, len_s)
-		docs.append(Document([[words[j] for j in row] for row in ids]))
+		sents = [[words[j] for j in row] for row in ids]
+		if args.contextual:
+			X = E[ids.reshape(-1)] + 0.1 * rng.standard_normal((per_doc * len_s, d)).astype(np.float32)
+			docs.append(Document(sents, contextual_embeddings={"ctx": X}))
+		else:
+			docs.append(Document(sents))
 	session = Session(Corpus(docs), embeddings=[emb])
-	sim = OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), alignment.LocalAlignment(gap=alignment.smooth_gap_cost(5)))
+	strategy = alignment.LocalAlignment(gap=alignment.smooth_gap_cost(5)) if args.strategy == "local" else alignment.WordMoversDistance.rwmd("nbow")
+	sim = OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), strategy)
 	t0 = time.perf_counter()
 	index = session.partition("sentence").index(sim)
 	build_s = time.perf_counter() - t0
 	texts = [" ".join(docs[int(rng.integers(0, len(docs)))].tokens[a:a + 10]) for a in rng.integers(0, per_doc * len_s - 10, size=args.queries)]
-	index.find_many(texts[:6], in_flight=args.in_flight)
+	batch = False if args.no_batch else None
+	index.find_many(texts[:max(6, min(len(texts), 32))], in_flight=args.in_flight, batch=batch)
 	t0 = time.perf_counter()
-	results = index.find_many(texts, in_flight=args.in_flight)
+	results = index.find_many(texts, in_flight=args.in_flight, batch=batch)
 	el = time.perf_counter() - t0
 	t0 = time.perf_counter()
 	for t in texts[:10]:
 		index.find(t)
 	one = (time.perf_counter() - t0) / 10
-	print(json.dumps({"surface": "Session / Index.find_many (static layout, WSB)", "sentences": index.n_slices, "queries": len(texts),
+	print(json.dumps({"surface": f"Session / Index.find_many ({'contextual' if args.contextual else 'static'} layout, {args.strategy}, {'one query per call' if args.no_batch or not args.contextual else 'shared calls'})", "sentences": index.n_slices, "queries": len(texts),
 		"in_flight": args.in_flight, "alignments_per_s": index.n_slices * len(texts) / el, "ms_per_query": el / len(texts) * 1e3,
 		"ms_per_find_one_at_a_time": one * 1e3, "index_build_s": build_s, "top_score": results[0][0].score if len(results[0]) else None}))
 	index.close()

@@ -447,7 +447,10 @@ class Corpus:
 				q.q_vectors, q.q_dtype, q.len_t = _np_ptr(qv), (VK_BF16 if qv.dtype == np.uint16 else VK_F32), qv.shape[0]
 				len_t = qv.shape[0]
 			qs[i] = q
-			t = TopK(max(1, q.max_matches), len_t, transport=bool(q.want_flow) and q.algorithm != VK_ALG_ALIGN and n <= 16)
+			# transport flows need the winners' similarity rows: always for the relaxed WMD (the batch path returns them for every
+			# query), for exact transport (answered query by query) only in small batches -- 80 KB of rows and plans per query
+			t = TopK(max(1, q.max_matches), len_t, transport=bool(q.want_flow) and q.algorithm != VK_ALG_ALIGN and
+				(n <= 16 or (q.algorithm == VK_ALG_RWMD and not q.wmd_full)))
 			outs.append(t)
 			sos[i] = t._struct()
 		_check(lib().vk_query_batch(self._h, qs, n, sos))
@@ -489,10 +492,23 @@ class Corpus:
 		proto.capacity, proto.n_out = k, 0
 		orows = np.frombuffer(sos, dtype=np.uint8).reshape(n, C.sizeof(_TopkOut))
 		orows[:] = np.frombuffer(proto, dtype=np.uint8)
-		for field, arr in ((_TopkOut.score, score), (_TopkOut.raw_score, raw), (_TopkOut.sentence, sentence),
-				(_TopkOut.mapping, mapping), (_TopkOut.edge_sim, edge)):
+		fields = [(_TopkOut.score, score), (_TopkOut.raw_score, raw), (_TopkOut.sentence, sentence),
+			(_TopkOut.mapping, mapping), (_TopkOut.edge_sim, edge)]
+		rows = plan = None
+		if bool(first.want_flow) and first.algorithm == VK_ALG_RWMD and not bool(first.wmd_full) and len_t <= VK_FAST_QUERY_LEN:
+			# relaxed WMD: the similarity rows of every query's winners (the host states their SparseFlow from them); no plans
+			# (exact transport only): one zero array stands in for all of them
+			rows = np.zeros((n, k, VK_FAST_SENT_LEN, 16), np.float32)
+			plan = np.zeros((k, 16, VK_FAST_SENT_LEN), np.float32)
+			keep.extend((rows, plan))
+			fields.append((_TopkOut.sim_rows, rows))
+		for field, arr in fields:
 			patch(orows, field, arr)
-		return [TopK.over(k, len_t, score[i], raw[i], sentence[i], mapping[i], edge[i]) for i in range(n)]
+		outs = [TopK.over(k, len_t, score[i], raw[i], sentence[i], mapping[i], edge[i]) for i in range(n)]
+		if rows is not None:
+			for i, t in enumerate(outs):
+				t.sim_rows, t.plan = rows[i], plan
+		return outs
 
 	def last_scores(self):
 		s = np.empty(self.n_sentences, dtype=np.float32)

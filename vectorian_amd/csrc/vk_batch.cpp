@@ -15,6 +15,59 @@ static bool same_gap(const vk_gap &a, const vk_gap &b, int upto) {
 	return true;
 }
 
+// Similarity rows of the winners of a batch of relaxed-WMD queries, from which the host states their flows (SparseFlow,
+// alignment/wmd.h:392-408): one launch for all queries, every winner against its own query's tile.  keys: [n_queries x k] as
+// selected (0 = empty slot); outs[i].n_out set.
+static int batch_winner_rows(vk_corpus *c, const vk_query_desc *qs, int n_queries, vk_topk_out *outs, const uint64_t *keys, int k, hipStream_t st) {
+	int rc;
+	bool any_rows = false;
+	for (int i = 0; i < n_queries; i++) any_rows |= qs[i].algorithm == VK_ALG_RWMD && qs[i].want_flow && outs[i].sim_rows && outs[i].n_out > 0;
+	if (!any_rows || c->max_len > VK_FAST_SENT_LEN) return VK_OK;
+	const size_t n_cand = (size_t)n_queries * (size_t)k;
+	if (c->bqt_cap < (size_t)n_queries) {
+		if (c->d_bqt) { VK_HIP(hipFree(c->d_bqt)); c->d_bqt = nullptr; }
+		if ((rc = alloc_t(c, &c->d_bqt, (size_t)n_queries * c->tile_bytes))) return rc;
+		c->bqt_cap = (size_t)n_queries;
+	}
+	if (c->bcand_cap < n_cand) {
+		for (void *ptr : {(void *)c->d_bcand, (void *)c->d_bcandq, (void *)c->d_brows}) if (ptr) VK_HIP(hipFree(ptr));
+		c->d_bcand = nullptr; c->d_bcandq = nullptr; c->d_brows = nullptr;
+		if ((rc = alloc_t(c, &c->d_bcand, n_cand))) return rc;
+		if ((rc = alloc_t(c, &c->d_bcandq, n_cand))) return rc;
+		if ((rc = alloc_t(c, &c->d_brows, n_cand * 64 * 16))) return rc;
+		c->bcand_cap = n_cand;
+	}
+	std::vector<uint8_t> qt((size_t)n_queries * c->tile_bytes, 0), one;
+	std::vector<uint64_t> hk(n_cand, 0);
+	std::vector<int32_t> hq(n_cand, 0);
+	float mags[VK_MAX_QUERY_LEN];
+	for (int i = 0; i < n_queries; i++) {
+		vk_pack_query(c, &qs[i], one, mags);
+		memcpy(qt.data() + (size_t)i * c->tile_bytes, one.data(), std::min(one.size(), (size_t)c->tile_bytes));
+		for (int j = 0; j < k; j++) {
+			hq[(size_t)i * k + j] = i;
+			if (j < outs[i].n_out && qs[i].want_flow && outs[i].sim_rows)
+				hk[(size_t)i * k + j] = (1ull << 32) | (uint64_t)(uint32_t)(keys[(size_t)i * k + j] & 0xffffffffu);
+		}
+	}
+	VK_HIP(hipMemcpyAsync(c->d_bqt, qt.data(), qt.size(), hipMemcpyHostToDevice, st));
+	VK_HIP(hipMemcpyAsync(c->d_bcand, hk.data(), n_cand * 8, hipMemcpyHostToDevice, st));
+	VK_HIP(hipMemcpyAsync(c->d_bcandq, hq.data(), n_cand * 4, hipMemcpyHostToDevice, st));
+	VkWrdParams w{};
+	w.tiles = c->d_tiles; w.sent_start = c->d_sent_start; w.sent_end = c->d_sent_end;
+	w.layout = VK_DEV_LAYOUT_CONTEXTUAL; w.nk32 = c->nk32; w.tail = c->tail; w.tile_bytes = c->tile_bytes; w.prec = c->prec;
+	w.qtile = c->d_bqt; w.qtile_stride = c->tile_bytes; w.cand_query = c->d_bcandq; w.nq = 1; w.len_t = qs[0].len_t;
+	w.keys = c->d_bcand; w.rows_out = c->d_brows;
+	VK_HIP(vk_launch_rows(&w, (int32_t)n_cand, st));
+	std::vector<float> rows(n_cand * 64 * 16);
+	VK_HIP(hipMemcpyAsync(rows.data(), c->d_brows, rows.size() * 4, hipMemcpyDeviceToHost, st));
+	VK_HIP(hipStreamSynchronize(st));
+	for (int i = 0; i < n_queries; i++)
+		if (qs[i].algorithm == VK_ALG_RWMD && qs[i].want_flow && outs[i].sim_rows && outs[i].n_out > 0)
+			memcpy(outs[i].sim_rows, rows.data() + (size_t)i * k * 64 * 16, (size_t)outs[i].n_out * 64 * 16 * 4);
+	return VK_OK;
+}
+
 // Queries with common options over a contextual corpus: up to 4 queries share one pass over the token tiles
 // (vk_score_batch_kernel).  Returns VK_ERR_UNSUPPORTED (without setting an error) when the batch does not qualify;
 // the caller then runs the queries one by one.
@@ -211,6 +264,7 @@ static int query_batch_shared_pass(vk_corpus_t *c, const vk_query_desc *qs, int3
 			}
 			out->n_out = n_out;
 		}
+		if (!is_align && (rc = batch_winner_rows(c, qs + base, qb, outs + base, keys.data(), k, st))) return rc;
 		float ms = 0;
 		if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) score_ms_total += ms;
 		if (hipEventElapsedTime(&ms, c->ev[0], c->ev[4]) == hipSuccess) total_ms += ms;
@@ -506,6 +560,7 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 		}
 		out->n_out = n_out;
 	}
+	if ((rc = batch_winner_rows(c, qs, n_queries, outs, keys.data(), k, st))) return rc;
 	c->have_scores = false;
 	float ms = 0;
 	vk_timings t{};

@@ -123,6 +123,8 @@ struct VkWrdParams {
 	float *val_out;            // [n_cand]
 	float *plan_out;           // optional [n_cand x 16 nq x 64]: the optimal plan G[j][i]
 	float *rows_out;           // vk_rows_kernel: [n_cand x 64 x 16 nq] similarity rows
+	const int32_t *cand_query; // vk_rows_kernel, batches: candidate w belongs to query cand_query[w], whose tile sits at qtile + that * qtile_stride
+	int64_t qtile_stride;
 	// queries of more than 16 tokens over slices of more than VK_DEV_MAX_SENT_LEN tokens
 	const int32_t *group_list; // vk_long_bound_kernel: groups of the slice table that hold one long slice (row 4 g)
 	int32_t n_list;

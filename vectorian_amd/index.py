@@ -672,12 +672,15 @@ class HipBruteForceIndex(Index):
 				similarity_threshold=float(metric.get("similarity_threshold", 0)))
 		return args, gaps
 
-	def find_many(self, texts, n=10, min_score=0.0, options: dict = dict(), in_flight=3, abort=None):
+	def find_many(self, texts, n=10, min_score=0.0, options: dict = dict(), in_flight=3, abort=None, batch=None):
 		"""Several queries, `in_flight` of them at a time on as many handles of the resident corpus (vk_corpus_view:
 		shared arrays, own stream and workspaces) from as many host threads: the selection, traceback and host part of
 		one query run beside the scoring kernel of the next (bench.py measures the path this way).  Returns one Result
 		per text, in order; each equals what `find` returns.  Not part of the reference's Index (which has one
-		ThreadPool task per document inside a single find, vectorian/index.py:544-558)."""
+		ThreadPool task per document inside a single find, vectorian/index.py:544-558).
+		batch: None (default) -- queries that can share a call do: over contextual embeddings, alignments go to the backend
+		several per call (vk_query_batch: every token tile is read once per pair of queries) and relaxed-WMD queries up to 256
+		per call (one MFMA-bound GEMM pass over the corpus per call, BASELINE config 4); False -- never; True -- or raise."""
 		from concurrent.futures import ThreadPoolExecutor
 		session = self.session
 		queries = [self.make_query(t, n=n, min_score=min_score, options=options) for t in texts]
@@ -688,6 +691,12 @@ class HipBruteForceIndex(Index):
 				raise TypeError("abort must be an int32 numpy array")
 			for q in queries:
 				q._abort = abort
+		batches = self._batch_plan(queries, options) if batch is not False else None
+		if batch is True and batches is None:
+			raise RuntimeError("find_many(batch=True): these queries cannot share a call (static embeddings, filters, tag weights, "
+				"a debug hook, a sharded index, exact transport, or queries that differ in their options)")
+		if batches is not None:
+			return self._find_batches(queries, batches, in_flight)
 		sequential = self._shard is not None or self._filter_masks(options) is not None or in_flight < 2 or not hasattr(self._corpus, "view")
 		if sequential:
 			start = time.time()
@@ -706,6 +715,68 @@ class HipBruteForceIndex(Index):
 				for i in range(h, len(queries), len(handles)):
 					results[i] = run(i)
 			list(pool.map(lane, range(len(handles))))
+		duration = (time.time() - start) / max(1, len(queries))
+		return [session.make_result(self, m, duration=duration) for m in results]
+
+	def _batch_plan(self, queries, options):
+		"""chunks of queries that can go to the backend in one call each, or None"""
+		if (self._shard is not None or self._filter_masks(options) is not None or options.get("debug") is not None
+				or not hasattr(self._corpus, "query_batch") or not self._embedding.is_contextual or len(queries) < 2):
+			return None
+		args, _ = self._backend_args(queries[0].options)
+		if "tag_weighted" in args or args["submatch_weight"] != 0.0:
+			return None
+		alg = args["algorithm"]
+		if alg == core.VK_ALG_ALIGN:
+			per_call = 16
+		elif alg == core.VK_ALG_RWMD and not args.get("wmd_full"):
+			per_call = 256
+		else:
+			return None   # exact transport: per query (bound pass + solver rounds)
+		return [range(a, min(a + per_call, len(queries))) for a in range(0, len(queries), per_call)]
+
+	def _find_batches(self, queries, batches, in_flight):
+		"""find_many through vk_query_batch: the chunks of `batches` on up to two handles of the resident corpus"""
+		from concurrent.futures import ThreadPoolExecutor
+		session = self.session
+		emb = self._embedding
+		args, gaps = self._backend_args(queries[0].options)
+		prepared = [q.prepare(self._nlp) for q in queries]
+		n_handles = max(1, min(2, in_flight, len(batches))) if hasattr(self._corpus, "view") else 1
+		while len(self._views) < n_handles - 1:
+			self._views.append(self._corpus.view())
+		handles = [self._corpus] + self._views[:n_handles - 1]
+		results = [None] * len(queries)
+		start = time.time()
+
+		def run(chunk, corpus):
+			idx = [i for i in chunk if len(prepared[i]) > 0]
+			for i in chunk:
+				if len(prepared[i]) == 0:
+					results[i] = []
+			if not idx:
+				return
+			qvs = [emb.encode_tokens(prepared[i].tokens) for i in idx]
+			try:
+				tops = corpus.query_batch([np.ascontiguousarray(qv.unmodified, dtype=np.float32) for qv in qvs], q_normalize=True,
+					boost=self._dev_boost, want_flow=True, abort_flag=queries[idx[0]]._abort, **args)
+			except core.VkError as e:
+				if e.status == core.VK_ERR_ABORTED:
+					for i in idx:
+						results[i] = []
+					return
+				raise
+			for i, qv, top in zip(idx, qvs, tops):
+				results[i] = self._matches_from_topk(prepared[i], top, gaps, args, np.asarray(qv.magnitudes, dtype=np.float32), None, None)
+
+		def lane(h):
+			for b in range(h, len(batches), len(handles)):
+				run(batches[b], handles[h])
+		if len(handles) == 1:
+			lane(0)
+		else:
+			with ThreadPoolExecutor(max_workers=len(handles)) as pool:
+				list(pool.map(lane, range(len(handles))))
 		duration = (time.time() - start) / max(1, len(queries))
 		return [session.make_result(self, m, duration=duration) for m in results]
 
