@@ -227,7 +227,8 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out);
 /* A batch of queries against the shard (BASELINE config 4: 256 queries per call).  Semantically
  * n_queries calls of vk_query; for injective RWMD over a contextual corpus whose sentences all have
  * the same length 16 / 32 / 48 / 64 it runs as one MFMA-bound GEMM with the row / column minima as
- * epilogue (every corpus byte read once per batch).  outs: [n_queries]. */
+ * epilogue (every corpus byte read once per batch).  outs: [n_queries]; with want_flow, relaxed-WMD queries get the
+ * similarity rows of their winners in outs[i].sim_rows when that array is given (one launch for the whole batch). */
 int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, vk_topk_out *outs);
 
 /* every sentence's Score::value of the last query, for the debug hook
