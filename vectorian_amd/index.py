@@ -896,8 +896,9 @@ class HipBruteForceIndex(Index):
 		len_s, len_t = (b - a if index_map is None else len(index_map)), len(p_query)
 		if len_s > core.VK_FAST_SENT_LEN:
 			return None
-		S = top.sim_rows[i][:len_s, :len_t].copy()
-		G = top.plan[i][:len_t, :len_s].copy()
+		rows, plan = top.sim_rows[i], top.plan[i]   # sliced and copied when the flow is asked for (HipMatch.flow is lazy)
+		S = lambda: rows[:len_s, :len_t].copy()
+		G = lambda: plan[:len_t, :len_s].copy()
 		ids_s = self._token_ids[a:b] if self._token_ids is not None else None
 		if ids_s is not None and index_map is not None:
 			ids_s = ids_s[index_map]
@@ -909,12 +910,12 @@ class HipBruteForceIndex(Index):
 			ids_t = np.asarray(ids_t, dtype=np.int64) * 256 + (np.asarray(q_tag_codes, dtype=np.int64) & 255)
 		if args["algorithm"] == core.VK_ALG_WRD:
 			mass = qmag / qmag.sum() if args.get("wrd_normalize", True) else qmag
-			return lambda: dense_flow(S, G, None, None, mass)   # WRD works on positions (wrd.h:91-109)
+			return lambda: dense_flow(S(), G(), None, None, mass)   # WRD works on positions (wrd.h:91-109)
 		injective, symmetric, nbow = args["rwmd"]
 		if args.get("wmd_full"):
 			unit = 1.0 / len_t if nbow else 1.0
-			return lambda: dense_flow(S, G, ids_s, ids_t, np.full(len_t, unit, dtype=np.float32))
-		return lambda: rwmd_sparse_flow(S, ids_s, ids_t, injective, symmetric, nbow)
+			return lambda: dense_flow(S(), G(), ids_s, ids_t, np.full(len_t, unit, dtype=np.float32))
+		return lambda: rwmd_sparse_flow(S(), ids_s, ids_t, injective, symmetric, nbow)
 
 	def _matches_from_topk(self, p_query, top, gaps, args=None, qmag=None, masks=None, q_tag_codes=None):
 		matches = []
