@@ -459,55 +459,63 @@ class Corpus:
 		return outs
 
 	def _batch_fast(self, queries, per_query, options, qs, sos, keep):
-		"""large batches of equally shaped queries: one stacked query array and one allocation per result field, the
+		"""large batches: the queries in one array (their lengths may differ), one allocation per result field, the
 		descriptors filled by pointer arithmetic (256 queries: 6 ms of per-query numpy / ctypes work otherwise)"""
 		n = len(queries)
 		if per_query or n < 8:
 			return None
 		arrs = [np.asarray(q) for q in queries]
-		if any(a.ndim != 2 or a.shape != arrs[0].shape or a.dtype != arrs[0].dtype for a in arrs) or arrs[0].shape[1] != self.d:
+		if any(a.ndim != 2 or a.shape[1] != self.d or a.shape[0] < 1 or a.dtype != arrs[0].dtype for a in arrs):
 			return None
 		if arrs[0].dtype != np.uint16:
 			arrs = [np.asarray(a, dtype=np.float32) for a in arrs]
-		Q = np.ascontiguousarray(np.stack(arrs))
+		lens = np.array([a.shape[0] for a in arrs], dtype=np.int64)
+		Q = np.ascontiguousarray(np.concatenate(arrs))          # [sum of the lengths x d]
 		keep.append(Q)
-		first, len_t = self._desc(Q[0], keep, **options)
+		first, _ = self._desc(arrs[0], keep, **options)
 		if bool(first.want_flow) and first.algorithm != VK_ALG_ALIGN and n <= 16:
 			return None    # transport flows: per-query row / plan buffers (the general path)
 		k = max(1, first.max_matches)
 		score, raw = np.zeros((n, k), np.float32), np.zeros((n, k), np.float32)
 		sentence = np.zeros((n, k), np.int64)
-		mapping, edge = np.full((n, k, len_t), -1, np.int16), np.zeros((n, k, len_t), np.float32)
+		# mapping / edge_sim of query i: [k x len_t(i)], one after the other in a flat array
+		row_off = np.concatenate(([0], np.cumsum(lens)))                     # in query tokens
+		mapping, edge = np.full(k * int(row_off[-1]), -1, np.int16), np.zeros(k * int(row_off[-1]), np.float32)
 		keep.extend((score, raw, sentence, mapping, edge))
 		# the descriptor arrays as bytes: every row a copy of the first descriptor, the pointer fields patched in one go
 		idx = np.arange(n, dtype=np.uint64)
 
-		def patch(rows, field, arr):
-			rows[:, field.offset:field.offset + 8].view(np.uint64)[:, 0] = np.uint64(arr.ctypes.data) + idx * np.uint64(arr.strides[0])
+		def patch(rows, field, arr, offsets=None):
+			step = idx * np.uint64(arr.strides[0]) if offsets is None else offsets.astype(np.uint64) * np.uint64(arr.itemsize)
+			rows[:, field.offset:field.offset + 8].view(np.uint64)[:, 0] = np.uint64(arr.ctypes.data) + step
 
 		qrows = np.frombuffer(qs, dtype=np.uint8).reshape(n, C.sizeof(_QueryDesc))
 		qrows[:] = np.frombuffer(first, dtype=np.uint8)
-		patch(qrows, _QueryDesc.q_vectors, Q)
+		patch(qrows, _QueryDesc.q_vectors, Q, offsets=row_off[:-1] * self.d)
+		qrows[:, _QueryDesc.len_t.offset:_QueryDesc.len_t.offset + 4].view(np.int32)[:, 0] = lens
 		proto = _TopkOut()
 		proto.capacity, proto.n_out = k, 0
 		orows = np.frombuffer(sos, dtype=np.uint8).reshape(n, C.sizeof(_TopkOut))
 		orows[:] = np.frombuffer(proto, dtype=np.uint8)
-		fields = [(_TopkOut.score, score), (_TopkOut.raw_score, raw), (_TopkOut.sentence, sentence),
-			(_TopkOut.mapping, mapping), (_TopkOut.edge_sim, edge)]
+		for field, arr in ((_TopkOut.score, score), (_TopkOut.raw_score, raw), (_TopkOut.sentence, sentence)):
+			patch(orows, field, arr)
+		patch(orows, _TopkOut.mapping, mapping, offsets=row_off[:-1] * k)
+		patch(orows, _TopkOut.edge_sim, edge, offsets=row_off[:-1] * k)
 		rows = plan = None
-		if bool(first.want_flow) and first.algorithm == VK_ALG_RWMD and not bool(first.wmd_full) and len_t <= VK_FAST_QUERY_LEN:
+		if bool(first.want_flow) and first.algorithm == VK_ALG_RWMD and not bool(first.wmd_full) and int(lens.max()) <= VK_FAST_QUERY_LEN:
 			# relaxed WMD: the similarity rows of every query's winners (the host states their SparseFlow from them); no plans
 			# (exact transport only): one zero array stands in for all of them
 			rows = np.zeros((n, k, VK_FAST_SENT_LEN, 16), np.float32)
 			plan = np.zeros((k, 16, VK_FAST_SENT_LEN), np.float32)
 			keep.extend((rows, plan))
-			fields.append((_TopkOut.sim_rows, rows))
-		for field, arr in fields:
-			patch(orows, field, arr)
-		outs = [TopK.over(k, len_t, score[i], raw[i], sentence[i], mapping[i], edge[i]) for i in range(n)]
-		if rows is not None:
-			for i, t in enumerate(outs):
+			patch(orows, _TopkOut.sim_rows, rows)
+		outs = []
+		for i in range(n):
+			a, b, lt = k * int(row_off[i]), k * int(row_off[i + 1]), int(lens[i])
+			t = TopK.over(k, lt, score[i], raw[i], sentence[i], mapping[a:b].reshape(k, lt), edge[a:b].reshape(k, lt))
+			if rows is not None:
 				t.sim_rows, t.plan = rows[i], plan
+			outs.append(t)
 		return outs
 
 	def last_scores(self):
