@@ -177,3 +177,29 @@ def test_rwmd_gemm_batch_ragged_and_768(hip, oracle, d, lo, hi, len_t, n_q, flag
 				algorithm=oracle.ALG_RWMD, rwmd=flags, max_matches=9, min_score=0.0, boost=boost)
 			assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=2e-5, tie_tol=2e-5)
 	c.close()
+
+
+def test_batch_rows_of_relaxed_wmd_winners(hip):
+	"""want_flow on a batch of relaxed-WMD queries: the similarity rows of every query's winners (one launch for the batch), as the
+	single-query path returns them -- on the GEMM kernels (300-d, ragged), on the shared pass (96-d), with queries of different
+	lengths, queries without winners and fewer winners than k"""
+	for d in (300, 96):
+		corpus = synth.make_contextual_corpus(700, 3, 40, 900, d)
+		X = corpus["X"]
+		c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=d, n_tokens=X.shape[0], n_sentences=700)
+		c.append_vectors(X, normalize=True)
+		c.set_sentences(corpus["sent_off"])
+		c.finalize()
+		rng = np.random.default_rng(d)
+		qs = [q["vectors"] for q in synth.make_queries(corpus, 10, 4)] + [q["vectors"] for q in synth.make_queries(corpus, 11, 9, seed=5)]
+		qs.append(-qs[0])     # nothing above min_score
+		kw = dict(algorithm=hip.VK_ALG_RWMD, rwmd=(True, True, True), q_normalize=True, max_matches=5, min_score=0.35, want_flow=True)
+		outs = c.query_batch(qs, **kw)
+		assert outs[-1].n == 0
+		for q, b in zip(qs, outs):
+			one = c.query(q, **kw)
+			assert b.n == one.n and (b.sentence[:b.n] == one.sentence[:one.n]).all()
+			np.testing.assert_allclose(b.score[:b.n], one.score[:one.n], atol=2e-6)
+			np.testing.assert_array_equal(b.sim_rows[:b.n, :, :one.sim_rows.shape[2]], one.sim_rows[:one.n])
+			assert not b.sim_rows[b.n:].any()
+		c.close()

@@ -22,7 +22,7 @@ static int batch_winner_rows(vk_corpus *c, const vk_query_desc *qs, int n_querie
 	int rc;
 	bool any_rows = false;
 	for (int i = 0; i < n_queries; i++) any_rows |= qs[i].algorithm == VK_ALG_RWMD && qs[i].want_flow && outs[i].sim_rows && outs[i].n_out > 0;
-	if (!any_rows || c->max_len > VK_FAST_SENT_LEN) return VK_OK;
+	if (!any_rows) return VK_OK;   // (winners of more than 64 tokens get zero rows from the kernel: their flows are not stated)
 	const size_t n_cand = (size_t)n_queries * (size_t)k;
 	if (c->bqt_cap < (size_t)n_queries) {
 		if (c->d_bqt) { VK_HIP(hipFree(c->d_bqt)); c->d_bqt = nullptr; }
