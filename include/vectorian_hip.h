@@ -35,12 +35,11 @@ extern "C" {
 #define VK_MAX_QUERY_LEN 64   /* query tokens */
 #define VK_FAST_QUERY_LEN 16  /* queries up to this length run in the fused kernels (one 16-wide MFMA column block); longer ones
                                  take the multi-block kernel (2 or 4 column blocks) or, where that does not apply, a
-                                 one-wave-per-slice kernel, ~10x slower; the 1:n form of RWMD stops at this length */
+                                 one-wave-per-slice kernel, ~10x slower */
 #define VK_MAX_SENT_LEN 512   /* tokens per sentence (slice) */
 #define VK_FAST_SENT_LEN 64   /* slices up to this length run 4 per wave in the fused kernel (|s| <= 64); longer
                                  ones take a second launch, one slice per wave (exact transport: a slower solver; with a query of
-                                 more than VK_FAST_QUERY_LEN tokens its state lives in global memory); the 1:n RWMD of a query of
-                                 more than VK_FAST_QUERY_LEN tokens needs all slices <= 64 */
+                                 more than VK_FAST_QUERY_LEN tokens its state lives in global memory) */
 #define VK_MAX_MATCHES 1024
 
 typedef enum {

@@ -62,26 +62,41 @@ def test_static_rwmd(hip, oracle, variant):
 	c.close()
 
 
-def test_distributed_rwmd_long_slices_and_short_queries(hip, oracle):
+@pytest.mark.parametrize("layout", ["contextual", "static"])
+def test_distributed_rwmd_long_slices(hip, oracle, layout):
 	# one query token must be spread over every token of the slice; slices of more than 64 tokens take the second launch
-	lens = np.array([3, 70, 12, 1, 33, 200, 64, 5, 9])
+	# (17 .. 64 query tokens: the multi-block kernel for the short slices, vk_long_rwmd_fill_kernel for the long ones)
+	lens = np.array([3, 70, 12, 1, 33, 200, 64, 5, 9, 130])
 	off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
 	rng = np.random.default_rng(5)
-	Xb = synth.to_bf16_bits(synth.normalize_rows(rng.standard_normal((int(off[-1]), 64)).astype(np.float32)))
-	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=64, n_tokens=Xb.shape[0], n_sentences=len(lens))
-	c.append_vectors(Xb, normalize=False)
+	if layout == "static":
+		V = 60     # few words: repeated token ids inside the long slices (vocabulary entries with counts)
+		Eb = synth.to_bf16_bits(synth.normalize_rows(rng.standard_normal((V, 64)).astype(np.float32)))
+		ids = rng.integers(0, V, size=int(off[-1])).astype(np.int32)
+		c = hip.Corpus(layout=hip.VK_LAYOUT_STATIC, d=64, n_tokens=len(ids), n_sentences=len(lens), vocab_size=V)
+		c.append_vectors(Eb, normalize=False)
+		c.set_token_ids(ids)
+	else:
+		Xb = synth.to_bf16_bits(synth.normalize_rows(rng.standard_normal((int(off[-1]), 64)).astype(np.float32)))
+		c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=64, n_tokens=Xb.shape[0], n_sentences=len(lens))
+		c.append_vectors(Xb, normalize=False)
 	c.set_sentences(off)
 	c.finalize()
-	for len_t in (1, 2, 16):
-		Qb = synth.to_bf16_bits(synth.normalize_rows(rng.standard_normal((len_t, 64)).astype(np.float32)))
-		for flags in ((False, True, True), (False, False, False)):
-			ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=64, sent_off=off, X=Xb, Q=Qb, algorithm=oracle.ALG_RWMD, rwmd=flags,
-				max_matches=9, min_score=-1.0, want_all_scores=True)
-			got = c.query(Qb, algorithm=hip.VK_ALG_RWMD, rwmd=flags, q_normalize=False, max_matches=9, min_score=-1.0)
+	for len_t in (1, 2, 16, 17, 40, 64):
+		if layout == "static":
+			qids = rng.integers(0, V, size=len_t).astype(np.int32)
+			Qb = Eb[qids]
+			base = dict(layout=oracle.LAYOUT_STATIC, d=64, sent_off=off, tok_id=ids, E=Eb, Q=Qb, q_ids=qids)
+			qargs = dict(q_token_ids=qids)
+		else:
+			Qb = synth.to_bf16_bits(synth.normalize_rows(rng.standard_normal((len_t, 64)).astype(np.float32)))
+			base = dict(layout=oracle.LAYOUT_CONTEXTUAL, d=64, sent_off=off, X=Xb, Q=Qb)
+			qargs = {}
+		for flags in ((False, True, True), (False, False, True), (False, False, False)):
+			ref = oracle.find(algorithm=oracle.ALG_RWMD, rwmd=flags, max_matches=9, min_score=-1.0, want_all_scores=True, **base)
+			got = c.query(Qb, algorithm=hip.VK_ALG_RWMD, rwmd=flags, q_normalize=False, max_matches=9, min_score=-1.0, **qargs)
 			np.testing.assert_allclose(c.last_scores(), ref["all_scores"], atol=1e-5, rtol=0)
 			assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=1e-5, tie_tol=1e-5)
-	with pytest.raises(hip.VkError):   # the 1:n form with more than 16 query tokens needs slices of at most 64 tokens
-		c.query(np.ones((17, 64), np.float32), algorithm=hip.VK_ALG_RWMD, rwmd=(False, True, True))
 	c.close()
 
 

@@ -281,6 +281,8 @@ hipError_t vk_launch_wrd_exact_long(const VkWrdParams *p, int32_t n_cand, hipStr
 // queries of 17..64 tokens over long slices: workgroups of the exact solver (each with its own scratch) and bytes per workgroup
 int vk_wrd_long_blocks(void);
 size_t vk_wrd_long_scratch_bytes(void);
+// 1:n RWMD of the long slices (group_list) for queries of 17..64 tokens
+hipError_t vk_launch_long_rwmd_fill(const VkWideParams *p, const int32_t *group_list, int32_t n_list, int32_t n_entries, hipStream_t stream);
 // upper bound of the transport score of every long slice (p->group_list), queries of 17..64 tokens
 hipError_t vk_launch_long_bound(const VkWrdParams *p, hipStream_t stream);
 #ifdef __cplusplus

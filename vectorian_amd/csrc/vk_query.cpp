@@ -10,7 +10,7 @@ int vk_validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_topk_
 	if (!c->finalized) return fail(VK_ERR_STATE, "corpus not finalized");
 	if (q->len_t < 1) return fail(VK_ERR_INVALID, "empty query");
 	if (q->len_t > VK_MAX_QUERY_LEN) return fail(VK_ERR_UNSUPPORTED, "query longer than VK_MAX_QUERY_LEN (64) tokens");
-	const bool exact_tr = q->algorithm == VK_ALG_WRD || (q->algorithm == VK_ALG_RWMD && q->wmd_full);   // bound pass + exact solver: no wide kernel
+	const bool exact_tr = q->algorithm == VK_ALG_WRD || (q->algorithm == VK_ALG_RWMD && (q->wmd_full || !q->rwmd_injective));   // multi-block kernel + kernels of their own for the long slices: no wide kernel
 	if (q->len_t > VK_FAST_QUERY_LEN && !exact_tr) {
 		const int gm = q->algorithm == VK_ALG_RWMD ? 4 : (q->gap_s.kind == VK_GAP_TABLE || q->gap_t.kind == VK_GAP_TABLE) ? 2 : 1;
 		if (vk_wide_lds_demand(c->max_len, (q->len_t + 15) / 16, gm, q->tag_weights != nullptr, q->want_flow) > 160 * 1024)
@@ -50,8 +50,7 @@ int vk_validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_topk_
 		if (q->wmd_full) {
 			if (q->rwmd_injective) return fail(VK_ERR_INVALID, "non-relaxed WMD with injective mapping is not supported");      // wmd.h:201-204
 			if (q->rwmd_symmetric) return fail(VK_ERR_INVALID, "non-relaxed WMD with symmetric computation is not supported");  // wmd.h:206-209
-		} else if (!q->rwmd_injective && q->len_t > VK_FAST_QUERY_LEN && c->max_len > VK_FAST_SENT_LEN)
-			return fail(VK_ERR_UNSUPPORTED, "non-injective RWMD (rwmd('nbow/distributed')) with a query of more than 16 tokens needs every slice <= VK_FAST_SENT_LEN (64) tokens");
+		}
 		if (q->want_flow && (!out->mapping || !out->edge_sim)) return fail(VK_ERR_INVALID, "want_flow needs mapping and edge_sim arrays");
 	} else if (q->algorithm == VK_ALG_WRD) {
 		if (q->tag_weights) {
@@ -330,7 +329,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		const bool bound_pass = q->algorithm == VK_ALG_WRD || (q->algorithm == VK_ALG_RWMD && q->wmd_full);   // exact transport: stage 1
 		// exact transport over a corpus with long slices: the multi-block kernel skips them (their groups are padded, vk_corpus.cpp),
 		// vk_long_bound_kernel bounds them
-		const bool long_apart = bound_pass && c->n_long_groups > 0;
+		const bool long_apart = (bound_pass || p.gap_mode == 7) && c->n_long_groups > 0;
 		const int wave_tiles = long_apart ? (q->len_t <= 32 ? c->max_short_pair_tiles : (c->max_short_len + 15) / 16 + 1)
 			: (q->len_t <= 32 ? c->max_pair_tiles : (c->max_len + 15) / 16 + 1);
 		const bool two_blocks = (is_align || rwmd_inj || bound_pass) && (long_apart || (c->n_long_groups == 0 &&
@@ -348,7 +347,8 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 			}
 			if (p.gap_mode == 2) { wp.gap_mode = c->max_len <= 32 ? 3 : 6; wp.wt = c->d_wt + 80; }   // register history of 32 / 64 rows, closure of w_t
 			VK_HIP(vk_launch_score32(&wp, wave_tiles, st));
-			if (long_apart) {
+			if (long_apart && p.gap_mode == 7) VK_HIP(vk_launch_long_rwmd_fill(&wp, c->d_long_groups, c->n_long_groups, (int32_t)n, st));
+			else if (long_apart) {
 				VkWrdParams lw{};
 				fill_transport(lw);
 				lw.mag = q->algorithm == VK_ALG_WRD ? c->d_mag : nullptr;

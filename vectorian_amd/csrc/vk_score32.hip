@@ -664,3 +664,96 @@ extern "C" hipError_t vk_launch_score32(const VkWideParams *p, int32_t tiles, hi
 	kernel<<<grid, 256, smem, stream>>>(*p, tiles * 16, strip_stride(p->len_t), strip_slack(p->gap_mode, p->len_t));
 	return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------
+// 1:n RWMD of a query of 17..64 tokens over the slices of more than VK_DEV_MAX_SENT_LEN tokens (the multi-block kernel above skips
+// them; their groups in the slice table are padded, vk_corpus.cpp): one wave per long slice, its similarity rows [m x 64] in LDS
+// (139 KB) like the rows of a short slice in the strip, then the same rwmd_fill32 four blocks wide.  Upstream sizes its problems by
+// the longest sentence (metric/alignment.h:357-358); a fallback that keeps such corpora on the device, not a roofline kernel.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void vk_long_rwmd_fill_kernel(VkWideParams p, const int32_t *__restrict__ group_list, int32_t n_list, int32_t n_entries) {
+	constexpr int N = 64, M = VK_DEV_MAX_LONG_LEN;
+	extern __shared__ float4 vk_smem32[];
+	float *S = reinterpret_cast<float *>(vk_smem32);   // [(M + 32)][N]
+	float *sm = S + (M + 32) * N;                       // [M] masses of the slice's vocabulary entries (static layout)
+	const int lane = threadIdx.x;
+	const bool is_static = p.layout == VK_DEV_LAYOUT_STATIC;
+	for (int gi = blockIdx.x; gi < n_list; gi += gridDim.x) {
+		const int row = group_list[gi] * 4;
+		const int t_a = p.sent_start[row], t_b = p.sent_end[row];
+		const int m = t_b - t_a;
+		if (lane >= 1 && lane < 4 && row + lane < n_entries) { p.scores[row + lane] = VK_NEG_INF; if (p.raw) p.raw[row + lane] = VK_NEG_INF; }
+		if (m < 1 || m > M) {
+			if (lane == 0) { p.scores[row] = VK_NEG_INF; if (p.raw) p.raw[row] = VK_NEG_INF; }
+			continue;
+		}
+		int rowbase = 0;
+		if (is_static) {
+			for (int it = 0; it * 16 < m; it++) {
+				const int tk = it * 16 + (lane >> 2);
+				if (tk < m) {
+					const int id = p.tok_id[t_a + tk];
+					const int ps = p.pos_s ? p.pos_s[t_a + tk] : 0;
+					for (int b = 0; b < p.nq; b++) {
+						float4 vq = *reinterpret_cast<const float4 *>(p.table + b * p.table_stride + (int64_t)id * 16 + (lane & 3) * 4);
+						if (p.pos_s) {
+							const int c0 = 16 * b + (lane & 3) * 4;
+							vq.x = tag_weighted(vq.x, p.tw[c0 + 0], ps, p.tpos[c0 + 0], p.tw_keep, p.tw_threshold);
+							vq.y = tag_weighted(vq.y, p.tw[c0 + 1], ps, p.tpos[c0 + 1], p.tw_keep, p.tw_threshold);
+							vq.z = tag_weighted(vq.z, p.tw[c0 + 2], ps, p.tpos[c0 + 2], p.tw_keep, p.tw_threshold);
+							vq.w = tag_weighted(vq.w, p.tw[c0 + 3], ps, p.tpos[c0 + 3], p.tw_keep, p.tw_threshold);
+						}
+						*reinterpret_cast<float4 *>(S + tk * N + 16 * b + (lane & 3) * 4) = vq;
+					}
+				}
+			}
+			// masses of the vocabulary entries: repeated token ids count once, at their first position (as in the kernel above)
+			const float wsum = p.rwmd_normalize_bow ? (float)m : 1.0f;
+			for (int u = lane; u < m; u += 64) {
+				const int id = p.tok_id[t_a + u];
+				int cnt = 0;
+				bool first = true;
+				for (int i = 0; i < m; i++) {
+					const bool same = p.tok_id[t_a + i] == id;
+					cnt += same ? 1 : 0;
+					first = first && !(same && i < u);
+				}
+				sm[u] = first ? (float)cnt / wsum : 0.0f;
+			}
+		} else {
+			const int tile0 = t_a >> 4;
+			const int ntiles = ((t_b + 15) >> 4) - tile0;
+			for (int ti = 0; ti < ntiles; ti++) {
+				const int ps = p.pos_s ? p.pos_s[(tile0 + ti) * 16 + (lane & 15)] : 0;
+				for (int b = 0; b < p.nq; b++) {
+					f32x4 acc = sim_tile_generic(p.qtile + (int64_t)b * p.tile_bytes, p.tiles + (int64_t)(tile0 + ti) * p.tile_bytes, p.nk32, p.tail, lane, p.prec);
+					if (p.pos_s) {
+						const int c0 = 16 * b + (lane >> 4) * 4;
+#pragma unroll
+						for (int r = 0; r < 4; r++) acc[r] = tag_weighted(acc[r], p.tw[c0 + r], ps, p.tpos[c0 + r], p.tw_keep, p.tw_threshold);
+					}
+					*reinterpret_cast<f32x4 *>(S + (ti * 16 + (lane & 15)) * N + 16 * b + (lane >> 4) * 4) = acc;
+				}
+			}
+			rowbase = t_a - tile0 * 16;
+		}
+		wave_lds_fence();
+		const float raw = rwmd_fill32<4>(S, N, is_static ? sm : nullptr, rowbase, m, m, lane, lane, p);
+		if (lane == 63) {
+			const float boost = p.boost ? p.boost[row] : 1.0f;
+			p.scores[row] = (raw / p.ref_total) * boost;
+			if (p.raw) p.raw[row] = raw;
+		}
+		wave_lds_fence();
+	}
+}
+
+extern "C" hipError_t vk_launch_long_rwmd_fill(const VkWideParams *p, const int32_t *group_list, int32_t n_list, int32_t n_entries, hipStream_t stream) {
+	if (n_list < 1) return hipSuccess;
+	const size_t smem = ((size_t)(VK_DEV_MAX_LONG_LEN + 32) * 64 + VK_DEV_MAX_LONG_LEN) * 4;
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(vk_long_rwmd_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+	if (e != hipSuccess) return e;
+	const int blocks = n_list < 2048 ? n_list : 2048;
+	vk_long_rwmd_fill_kernel<<<blocks, 64, smem, stream>>>(*p, group_list, n_list, n_entries);
+	return hipGetLastError();
+}
