@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 6
+#define VK_ABI_VERSION 7
 #define VK_MAX_QUERY_LEN 64   /* query tokens */
 #define VK_FAST_QUERY_LEN 16  /* queries up to this length run in the fused kernels (one 16-wide MFMA column block); longer ones
                                  take the multi-block kernel (2 or 4 column blocks) or, where that does not apply, a
@@ -123,9 +123,13 @@ typedef struct {
 	 * S'[i][j] = S[i][j] * tag_weights[j] * (pos_s[i] != q_pos[j] ? 1 - pos_mismatch_penalty : 1), set to 0
 	 * when <= similarity_threshold; the score is divided by sum(tag_weights) instead of len_t.
 	 * tag_weights NULL = 'alignment-isolated'.  Any algorithm (TagWeightedSlice wraps every slice, match/instantiate.cpp:
-	 * 173-189) except the 1:n form of RWMD over the static layout; needs vk_corpus_set_token_pos. */
+	 * 173-189); needs vk_corpus_set_token_pos. */
 	const float *tag_weights;  /* host [len_t] t_pos_weights (match/instantiate.cpp:10-38) */
 	const int8_t *q_pos;       /* host [len_t] universal POS code per query token */
+	const int8_t *q_tags;      /* host [len_t] tag code per query token, or NULL: with tag weights the bags of words are keyed by
+	                              (token id, tag) (TaggedTokenFactory, alignment/bow.h:150-176); only the 1:n RWMD over the static
+	                              layout needs the keys on the device (repeated ids count as one entry only if their tags agree;
+	                              needs vk_corpus_set_token_tags) */
 	float pos_mismatch_penalty;
 	float similarity_threshold;
 	/* VK_ALG_RWMD with 'relaxed': False (vectorian/alignment.py:206-218): the full Word Mover's Distance,

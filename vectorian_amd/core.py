@@ -68,7 +68,7 @@ class _QueryDesc(C.Structure):
 		("boost", C.c_void_p), ("want_flow", C.c_int32),
 		("rwmd_injective", C.c_int32), ("rwmd_symmetric", C.c_int32), ("rwmd_normalize_bow", C.c_int32),
 		("wrd_normalize_magnitudes", C.c_int32),
-		("tag_weights", C.c_void_p), ("q_pos", C.c_void_p),
+		("tag_weights", C.c_void_p), ("q_pos", C.c_void_p), ("q_tags", C.c_void_p),
 		("pos_mismatch_penalty", C.c_float), ("similarity_threshold", C.c_float), ("wmd_full", C.c_int32),
 		("abort", C.c_void_p)]
 
@@ -150,7 +150,7 @@ def lib():
 		L.vk_record_words.argtypes = [C.c_int32]
 		L.vk_pack_records.argtypes = [C.POINTER(_TopkOut), C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
 		L.vk_merge_records.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_TopkOut)]
-		if L.vk_abi_version() != 6:
+		if L.vk_abi_version() != 7:
 			raise RuntimeError("libvectorian_hip.so ABI version mismatch")
 		_lib = L
 	return _lib
@@ -290,6 +290,8 @@ def merge_records(records, n_sets, len_t, k):
 class Corpus:
 	"""A corpus shard resident in HBM (opaque vk_corpus_t handle)."""
 
+	takes_q_tags = True   # query(q_tags=...): tag codes of the query tokens (tag-weighted transport over (id, tag) vocabularies)
+
 	def __init__(self, *, layout, d, n_tokens, n_sentences, vocab_size=0, keep_magnitudes=False, device=None, precision="bf16"):
 		"""precision: "bf16" (unit rows rounded to bf16, the fast path) or "f32" (the reference's own precision, twice the bytes)"""
 		if device is not None:
@@ -353,7 +355,7 @@ class Corpus:
 	def _desc(self, q_vectors, keep, *, locality=Locality.LOCAL, gap_s=0.0, gap_t=0.0, algorithm=VK_ALG_ALIGN,
 			q_token_ids=None, q_normalize=True, max_matches=10, min_score=0.0, boost=None, want_flow=True,
 			submatch_weight=0.0, bidirectional=False, rwmd=(True, True, True), wrd_normalize=True,
-			tag_weights=None, q_pos=None, pos_mismatch_penalty=0.0, similarity_threshold=0.0, wmd_full=False,
+			tag_weights=None, q_pos=None, q_tags=None, pos_mismatch_penalty=0.0, similarity_threshold=0.0, wmd_full=False,
 			abort_flag=None, want_rows=False):
 		"""abort_flag: int32 array of one element another thread may set to 1 (Query.abort); want_rows: similarity rows of the
 		winners of an alignment query too (the debug hook's 'similarity')"""
@@ -402,6 +404,12 @@ class Corpus:
 				raise ValueError("tag_weights / q_pos must have one entry per query token")
 			keep.extend([tw, qp])
 			q.tag_weights, q.q_pos = _np_ptr(tw), _np_ptr(qp)
+			if q_tags is not None:
+				qt = np.ascontiguousarray(q_tags, dtype=np.int8)
+				if len(qt) != len_t:
+					raise ValueError("q_tags must have one entry per query token")
+				keep.append(qt)
+				q.q_tags = _np_ptr(qt)
 			q.pos_mismatch_penalty, q.similarity_threshold = float(pos_mismatch_penalty), float(similarity_threshold)
 		return q, len_t
 
@@ -426,7 +434,7 @@ class Corpus:
 			options = dict(options, boost=np.ascontiguousarray(options["boost"], dtype=np.float32))
 		# the options are common: build one descriptor and copy it, only the vectors differ (tag weights, token ids
 		# and POS codes are per query and take the full path)
-		per_query = any(options.get(k) is not None for k in ("q_token_ids", "tag_weights", "q_pos"))
+		per_query = any(options.get(k) is not None for k in ("q_token_ids", "tag_weights", "q_pos", "q_tags"))
 		first = None
 		fast = self._batch_fast(queries, per_query, options, qs, sos, keep)
 		if fast is not None:

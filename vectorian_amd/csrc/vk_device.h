@@ -52,6 +52,7 @@ struct VkScoreParams {
 	const float *boost;        // [n_sent] or null
 	// tag-weighted similarity modifier (pos_s == nullptr: off)
 	const int8_t *pos_s;       // [n_tokens + pad] POS code per token
+	const int8_t *tag_s;       // tagged 1:n RWMD over the static layout: tag code per token (vocabulary entries are (id, tag) pairs); else null
 	float tw[VK_DEV_MAX_QUERY_LEN];      // t_pos_weights
 	int32_t tpos[VK_DEV_MAX_QUERY_LEN];  // POS code per query token
 	float tw_keep;             // 1 - pos_mismatch_penalty
@@ -213,6 +214,7 @@ struct VkWideParams {
 	const float *wt;           // [65]; vk_score32_kernel: the closure of w_t (see VkScoreParams); vk_wide_kernel: w_t as given
 	const float *wt0;          // vk_score32_kernel: w_t as given (border row)
 	const int8_t *pos_s;
+	const int8_t *tag_s;       // tagged 1:n RWMD over the static layout: tag code per token (vocabulary entries are (id, tag) pairs); else null
 	float tw[VK_DEV_MAX_WIDE_QUERY_LEN];
 	int32_t tpos[VK_DEV_MAX_WIDE_QUERY_LEN];
 	float tw_keep, tw_threshold;

@@ -42,8 +42,8 @@ int vk_validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_topk_
 			if (!q->q_pos) return fail(VK_ERR_INVALID, "tag-weighted query without q_pos");
 			if (!c->d_pos) return fail(VK_ERR_STATE, "tag-weighted query needs vk_corpus_set_token_pos");
 			if (q->similarity_threshold < 0.0f) return fail(VK_ERR_INVALID, "similarity_threshold must be >= 0 (slice/static.h:209)");
-			if (!q->rwmd_injective && !q->wmd_full && c->desc.layout == VK_LAYOUT_STATIC)
-				return fail(VK_ERR_UNSUPPORTED, "tag-weighted 1:n RWMD over the static layout is not implemented (its vocabulary is keyed by (token, tag), bow.h:150-176)");
+			if (q->q_tags && !q->rwmd_injective && !q->wmd_full && c->desc.layout == VK_LAYOUT_STATIC && !c->d_tag)
+				return fail(VK_ERR_STATE, "tag-weighted 1:n RWMD over the static layout with q_tags needs vk_corpus_set_token_tags (its vocabulary is keyed by (token, tag), bow.h:150-176)");
 		}
 		if (q->rwmd_symmetric && !q->rwmd_normalize_bow)
 			return fail(VK_ERR_INVALID, "cannot run symmetric mode WMD with bow (needs nbow)");   // wmd.h:441-449
@@ -213,14 +213,17 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 				if (j < q->len_t) {
 					int cnt = 1;
 					bool first = true;
+					// (tag-weighted with q_tags: the entries are (token id, tag) pairs, TaggedTokenFactory, bow.h:150-176)
+					const bool tagged = q->tag_weights && q->q_tags;
 					if (ids && q->q_token_ids[j] >= 0)
 						for (int i = 0; i < q->len_t; i++)
-							if (i != j && q->q_token_ids[i] == q->q_token_ids[j]) { cnt++; if (i < j) first = false; }
+							if (i != j && q->q_token_ids[i] == q->q_token_ids[j] && (!tagged || q->q_tags[i] == q->q_tags[j])) { cnt++; if (i < j) first = false; }
 					mass = first ? (q->rwmd_normalize_bow ? (float)cnt / (float)q->len_t : (float)cnt) : 0.0f;
 				}
 				qmass_all[j] = mass;
 			}
 			memcpy(p.qmass, qmass_all, sizeof p.qmass);
+			if (ids && q->tag_weights && q->q_tags) p.tag_s = c->d_tag;
 		}
 	} else if (ks == VK_GAP_LINEAR && kt == VK_GAP_LINEAR) {
 		p.gap_mode = 0;
@@ -312,7 +315,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		wp.rwmd_symmetric = p.rwmd_symmetric; wp.rwmd_normalize_bow = p.rwmd_normalize_bow;
 		wp.gs = p.gs; wp.gt = p.gt; wp.a_s = p.a_s; wp.a_t = p.a_t; wp.open_s = p.open_s; wp.open_t = p.open_t;
 		wp.ws = c->d_ws; wp.wt = c->d_wt; wp.wt0 = c->d_wt;
-		wp.pos_s = p.pos_s; wp.tw_keep = p.tw_keep; wp.tw_threshold = p.tw_threshold; wp.ref_total = p.ref_total;
+		wp.pos_s = p.pos_s; wp.tag_s = p.tag_s; wp.tw_keep = p.tw_keep; wp.tw_threshold = p.tw_threshold; wp.ref_total = p.ref_total;
 		for (int j = 0; j < VK_MAX_QUERY_LEN; j++) {
 			wp.tw[j] = (p.pos_s && j < q->len_t) ? q->tag_weights[j] : 0.0f;
 			wp.tpos[j] = (p.pos_s && j < q->len_t) ? (int32_t)q->q_pos[j] : -1;

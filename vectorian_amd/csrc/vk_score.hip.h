@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 					int cnt = 0;
 					bool first = true;
 					for (int i = 0; i < lenc; i++) {
-						const bool same = p.tok_id[t_a + i] == id;
+						const bool same = p.tok_id[t_a + i] == id && (!p.tag_s || p.tag_s[t_a + i] == p.tag_s[t_a + u]);
 						cnt += same ? 1 : 0;
 						first = first && !(same && i < u);
 					}
