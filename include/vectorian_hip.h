@@ -127,9 +127,11 @@ typedef struct {
 	const float *tag_weights;  /* host [len_t] t_pos_weights (match/instantiate.cpp:10-38) */
 	const int8_t *q_pos;       /* host [len_t] universal POS code per query token */
 	const int8_t *q_tags;      /* host [len_t] tag code per query token, or NULL: with tag weights the bags of words are keyed by
-	                              (token id, tag) (TaggedTokenFactory, alignment/bow.h:150-176); only the 1:n RWMD over the static
-	                              layout needs the keys on the device (repeated ids count as one entry only if their tags agree;
-	                              needs vk_corpus_set_token_tags) */
+	                              (token id, tag) (TaggedTokenFactory, alignment/bow.h:150-176).  Over the static layout the
+	                              device needs the keys (with vk_corpus_set_token_tags) for the masses of the 1:n RWMD (repeated ids
+	                              are one entry only if their tags agree) and for the cells upstream's distance matrix writes
+	                              twice (entries in both documents, wmd.h:121-133); without them those cells keep the positions'
+	                              own similarity (scores of such slices within 5e-4) */
 	float pos_mismatch_penalty;
 	float similarity_threshold;
 	/* VK_ALG_RWMD with 'relaxed': False (vectorian/alignment.py:206-218): the full Word Mover's Distance,

@@ -150,8 +150,22 @@ class OracleCorpus:
 				# the solvers (and the flows stated from these rows) see the modified similarity (TagWeightedSlice::similarity, slice/static.h:237-264)
 				wgt = np.asarray(tag_weights, dtype=np.float32)[None, :] * np.where(
 					self._pos[a:b, None] != np.asarray(q_pos, dtype=np.int8)[None, :], np.float32(1.0 - pos_mismatch_penalty), np.float32(1.0))
-				S = (S * wgt).astype(np.float32)
+				raw = S
+				S = (raw * wgt).astype(np.float32)
 				S[S <= similarity_threshold] = 0.0
+				if self.layout == core.VK_LAYOUT_STATIC and algorithm == core.VK_ALG_RWMD and q_tags is not None and self._tags is not None and q_token_ids is not None:
+					# upstream's vocabulary distance matrix is written twice for entries that occur in both documents, the later write
+					# wins (wmd.h:121-133): for keys a (slice) < b (query), both in both, the value of (slice's b, query's a) -- this
+					# cell's cosine and POS penalty under the tag weight of a (the device: static_vocab_fixup)
+					ks = self._ids[a:b].astype(np.int64) * 256 + (self._tags[a:b].astype(np.int64) & 255)
+					kt = np.asarray(q_token_ids, dtype=np.int64) * 256 + (np.asarray(q_tags, dtype=np.int64) & 255)
+					in_t, in_s = np.isin(ks, kt), np.isin(kt, ks)
+					for si in np.nonzero(in_t)[0]:
+						ft = int(np.nonzero(kt == ks[si])[0][0])
+						for tj in np.nonzero(in_s & (kt > ks[si]))[0]:
+							w = np.float32(tag_weights[ft]) * (np.float32(1.0 - pos_mismatch_penalty) if self._pos[a + si] != q_pos[tj] else np.float32(1.0))
+							v = np.float32(raw[si, tj] * w)
+							S[si, tj] = 0.0 if v <= similarity_threshold else v
 			if transport and b - a <= core.VK_FAST_SENT_LEN:
 				# what the HIP backend returns for the host to state transport flows: rows, and the plan of exact transports
 				top.sim_rows[i, :b - a, :len(q)] = S

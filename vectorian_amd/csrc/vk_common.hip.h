@@ -291,6 +291,44 @@ __device__ __forceinline__ float tag_weighted(float s, float w, int pos_s, int p
 	return sc <= thr ? 0.0f : sc;
 }
 
+// Vocabulary transports (both RWMD forms, full WMD) with the tag-weighted similarity over the STATIC layout.  Upstream fills its
+// distance matrix over the joint vocabulary with dist(u, v) = dist(v, u) = d, u over the slice's entries, v over the query's
+// (alignment/wmd.h:121-133): a cell whose two entries occur in BOTH documents is written twice, the later write -- the larger u --
+// wins.  The modifier is asymmetric (the tag weight belongs to the query side), so the two values differ: for a slice token with
+// key a and a query token with key b, both keys in both documents and a < b, the surviving value is the similarity of the slice's
+// b with the query's a.  With keys (token id, tag) and the universal POS a function of the tag (TaggedTokenFactory,
+// bow.h:150-176; spaCy's tag map) that is this cell's own cosine and POS penalty under the tag weight of a instead of b.
+// One slice, rows S[u * stride + j] already weighted; the NL lanes l = 0 .. NL - 1 share the rows.  Every lane finds the shared
+// query columns by itself (a bitmap of the query's ids keeps the scan to the few tokens that can match): no exchange.
+template <int NL>
+__device__ __forceinline__ void static_vocab_fixup(float *__restrict__ S, int stride, int len_s, int len_t,
+	const int32_t *__restrict__ tok, const int8_t *__restrict__ tag, const int8_t *__restrict__ pos,
+	const float *__restrict__ table, int64_t table_stride, const uint32_t *__restrict__ bits, const int32_t *qkey,
+	const float *tw, const int32_t *tpos, float keep, float thr, int l) {
+	unsigned long long mask = 0;   // query columns whose key occurs in the slice
+	for (int u = 0; u < len_s; u++) {
+		const int id = tok[u];
+		if (!((bits[id >> 5] >> (id & 31)) & 1u)) continue;
+		const int key = id * 256 + (tag[u] & 255);
+		for (int j = 0; j < len_t; j++) mask |= qkey[j] == key ? 1ull << j : 0ull;
+	}
+	if (!(mask & (mask - 1))) return;   // fewer than two shared columns: nothing is written twice with different values
+	for (int u = l; u < len_s; u += NL) {
+		const int id = tok[u];
+		if (!((bits[id >> 5] >> (id & 31)) & 1u)) continue;
+		const int key = id * 256 + (tag[u] & 255);
+		int ft = -1;
+		for (int j = len_t - 1; j >= 0; j--) ft = qkey[j] == key ? j : ft;
+		if (ft < 0) continue;
+		for (int j = 0; j < len_t; j++)
+			if (((mask >> j) & 1ull) && qkey[j] > key) {
+				const float raw = table[(int64_t)(j >> 4) * table_stride + (int64_t)id * 16 + (j & 15)];
+				S[u * stride + j] = tag_weighted(raw, tw[ft], pos[u], tpos[j], keep, thr);
+			}
+	}
+}
+
+
 // ---------------------------------------------------------------------------
 // DP over a group of 4 sentences: DPP row sigma = lane >> 4 is one sentence, lane
 // v = lane & 15 is query column v + 1.  Rows (sentence tokens) are swept serially;

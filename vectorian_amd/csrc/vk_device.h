@@ -53,6 +53,10 @@ struct VkScoreParams {
 	// tag-weighted similarity modifier (pos_s == nullptr: off)
 	const int8_t *pos_s;       // [n_tokens + pad] POS code per token
 	const int8_t *tag_s;       // tagged 1:n RWMD over the static layout: tag code per token (vocabulary entries are (id, tag) pairs); else null
+	// tag-weighted vocabulary transports over the static layout (static_vocab_fixup, vk_common.hip.h): bitmap of the query's token
+	// ids over the vocabulary (null: off) and the (id, tag) key of every query token
+	const uint32_t *qid_bits;
+	int32_t qkey[VK_DEV_MAX_QUERY_LEN];
 	float tw[VK_DEV_MAX_QUERY_LEN];      // t_pos_weights
 	int32_t tpos[VK_DEV_MAX_QUERY_LEN];  // POS code per query token
 	float tw_keep;             // 1 - pos_mismatch_penalty
@@ -124,6 +128,9 @@ struct VkWrdParams {
 	float *val_out;            // [n_cand]
 	float *plan_out;           // optional [n_cand x 16 nq x 64]: the optimal plan G[j][i]
 	float *rows_out;           // vk_rows_kernel: [n_cand x 64 x 16 nq] similarity rows
+	const int8_t *tag_s;       // static layout, tag-weighted vocabulary transports: tag code per token, bitmap of the query's ids, keys of
+	const uint32_t *qid_bits;  // the query tokens (static_vocab_fixup; qid_bits null: off)
+	int32_t qkey[VK_DEV_MAX_WIDE_QUERY_LEN];
 	const int32_t *cand_query; // vk_rows_kernel, batches: candidate w belongs to query cand_query[w], whose tile sits at qtile + that * qtile_stride
 	int64_t qtile_stride;
 	// queries of more than 16 tokens over slices of more than VK_DEV_MAX_SENT_LEN tokens
@@ -215,6 +222,10 @@ struct VkWideParams {
 	const float *wt0;          // vk_score32_kernel: w_t as given (border row)
 	const int8_t *pos_s;
 	const int8_t *tag_s;       // tagged 1:n RWMD over the static layout: tag code per token (vocabulary entries are (id, tag) pairs); else null
+	// tag-weighted vocabulary transports over the static layout (static_vocab_fixup, vk_common.hip.h): bitmap of the query's token
+	// ids over the vocabulary (null: off) and the (id, tag) key of every query token
+	const uint32_t *qid_bits;
+	int32_t qkey[VK_DEV_MAX_WIDE_QUERY_LEN];
 	float tw[VK_DEV_MAX_WIDE_QUERY_LEN];
 	int32_t tpos[VK_DEV_MAX_WIDE_QUERY_LEN];
 	float tw_keep, tw_threshold;

@@ -287,6 +287,18 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 			if (!FLOW && lane == 0) { p.scores[g] = VK_NEG_INF; if (p.raw) p.raw[g] = VK_NEG_INF; }
 			continue;
 		}
+		// tag-weighted vocabulary transport over the static layout: the query columns whose (id, tag) key occurs in this slice
+		// (cells upstream writes twice take the tag weight of the slice token's key, static_vocab_fixup in vk_common.hip.h)
+		unsigned long long vmask = 0;
+		if (is_static && p.qid_bits && p.pos_s && gap == 4) {
+			for (int tok = t_a; tok < t_b; tok++) {
+				const int id = p.tok_id[tok];
+				if (!((p.qid_bits[id >> 5] >> (id & 31)) & 1u)) continue;
+				const int key = id * 256 + (p.tag_s[tok] & 255);
+				for (int j = 0; j < len_t; j++) vmask |= p.qkey[j] == key ? 1ull << j : 0ull;
+			}
+			if (!(vmask & (vmask - 1))) vmask = 0;
+		}
 		// similarities of tokens base .. base + 15 (contextual: one tile, 16-aligned; static: gather)
 		auto fill = [&](int base) {
 			if (is_static) {
@@ -296,7 +308,16 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 						const int id = p.tok_id[tok];
 						const float sv = p.table[(int64_t)(lane >> 4) * p.table_stride + (int64_t)id * 16 + (lane & 15)];
 						Sx[r * LQ + lane] = sv;
-						if (p.pos_s) SWx[r * LQ + lane] = tag_weighted(sv, twl[lane], p.pos_s[tok], tposl[lane], p.tw_keep, p.tw_threshold);
+						if (p.pos_s) {
+							float w = twl[lane];
+							if (vmask && ((p.qid_bits[id >> 5] >> (id & 31)) & 1u)) {
+								const int key = id * 256 + (p.tag_s[tok] & 255);
+								int ft = -1;
+								for (int j = len_t - 1; j >= 0; j--) ft = p.qkey[j] == key ? j : ft;
+								if (ft >= 0 && lane < len_t && ((vmask >> lane) & 1ull) && p.qkey[lane] > key) w = twl[ft];
+							}
+							SWx[r * LQ + lane] = tag_weighted(sv, w, p.pos_s[tok], tposl[lane], p.tw_keep, p.tw_threshold);
+						}
 					}
 				}
 			} else {

@@ -105,6 +105,7 @@ struct vk_corpus {
 	float *d_rows_out = nullptr, *d_plan_out = nullptr;   // transport flows of the winners
 	uint8_t *d_bqt = nullptr; uint64_t *d_bcand = nullptr; int32_t *d_bcandq = nullptr; float *d_brows = nullptr;   // similarity rows of a batch's winners
 	size_t bqt_cap = 0, bcand_cap = 0;
+	uint32_t *d_qbits = nullptr;   // tag-weighted vocabulary transports over the static layout: bitmap of the query's token ids
 	uint8_t *d_wrdl_scratch = nullptr;   // exact transport, queries of 17..64 tokens over long slices: per-workgroup state
 	int rows_w = 0;              // columns per similarity row they are sized for (16, 32, 48 or 64)
 	// batched GEMM over a ragged corpus (vk_query_batch): a padded copy of the sentences, one bucket per padded length

@@ -135,6 +135,12 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 			}
 			w.pos_s = c->d_pos; w.tw_keep = 1.0f - q->pos_mismatch_penalty; w.tw_threshold = q->similarity_threshold;
 			w.ref_total = total;   // reference_score with max_sum_of_similarities = sum of t_pos_weights (slice/static.h:280-286)
+			if (is_static_l && q->algorithm == VK_ALG_RWMD && q->q_tags && q->q_token_ids && c->d_tag && c->d_qbits) {
+				// the cells upstream writes twice (static_vocab_fixup); d_qbits holds this query's bitmap (set before the scoring launch)
+				w.tag_s = c->d_tag; w.qid_bits = c->d_qbits;
+				for (int j = 0; j < VK_MAX_QUERY_LEN; j++)
+					w.qkey[j] = (j < q->len_t && q->q_token_ids[j] >= 0 && q->q_token_ids[j] < c->desc.vocab_size) ? q->q_token_ids[j] * 256 + ((int32_t)q->q_tags[j] & 255) : -1;
+			}
 		}
 	};
 	auto transport_flows = [&](const std::vector<int64_t> &rows_idx, bool exact, const float *qmass, int mass_mode, int raw_masses) -> int {
@@ -306,6 +312,26 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		p.tw_threshold = q->similarity_threshold;
 		p.ref_total = total;   // reference_score with max_similarity_for_t = t_pos_weights (slice/static.h:280-286)
 	}
+	// vocabulary transports with tag weights over the static layout: the cells upstream writes twice (static_vocab_fixup,
+	// vk_common.hip.h) -- needs the (id, tag) keys of both sides: q_tags and vk_corpus_set_token_tags
+	int32_t qkey_all[VK_MAX_QUERY_LEN];
+	for (int j = 0; j < VK_MAX_QUERY_LEN; j++) qkey_all[j] = -1;
+	const bool vocab_fix = is_static && q->algorithm == VK_ALG_RWMD && q->tag_weights && q->q_tags && q->q_token_ids && c->d_tag && c->d_pos;
+	if (vocab_fix) {
+		const size_t words = ((size_t)c->desc.vocab_size + 31) / 32 + 1;
+		if (!c->d_qbits && (rc = alloc_t(c, &c->d_qbits, words))) return rc;
+		std::vector<uint32_t> bits(words, 0);
+		for (int j = 0; j < q->len_t; j++) {
+			const int32_t id = q->q_token_ids[j];
+			if (id < 0 || id >= c->desc.vocab_size) continue;
+			bits[(size_t)id >> 5] |= 1u << (id & 31);
+			qkey_all[j] = id * 256 + ((int32_t)q->q_tags[j] & 255);
+		}
+		VK_HIP(hipMemcpyAsync(c->d_qbits, bits.data(), words * 4, hipMemcpyHostToDevice, st));
+		VK_HIP(hipStreamSynchronize(st));   // `bits` leaves scope
+		p.qid_bits = c->d_qbits; p.tag_s = c->d_tag;
+		for (int j = 0; j < VK_FAST_QUERY_LEN; j++) p.qkey[j] = qkey_all[j];
+	}
 	VkWideParams wp{};
 	if (wide) {
 		wp.tiles = c->d_tiles; wp.tok_id = c->d_tok_id; wp.table = c->d_table; wp.table_stride = table_stride;
@@ -315,7 +341,8 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		wp.rwmd_symmetric = p.rwmd_symmetric; wp.rwmd_normalize_bow = p.rwmd_normalize_bow;
 		wp.gs = p.gs; wp.gt = p.gt; wp.a_s = p.a_s; wp.a_t = p.a_t; wp.open_s = p.open_s; wp.open_t = p.open_t;
 		wp.ws = c->d_ws; wp.wt = c->d_wt; wp.wt0 = c->d_wt;
-		wp.pos_s = p.pos_s; wp.tag_s = p.tag_s; wp.tw_keep = p.tw_keep; wp.tw_threshold = p.tw_threshold; wp.ref_total = p.ref_total;
+		wp.pos_s = p.pos_s; wp.tag_s = p.tag_s; wp.qid_bits = p.qid_bits; memcpy(wp.qkey, qkey_all, sizeof wp.qkey);
+		wp.tw_keep = p.tw_keep; wp.tw_threshold = p.tw_threshold; wp.ref_total = p.ref_total;
 		for (int j = 0; j < VK_MAX_QUERY_LEN; j++) {
 			wp.tw[j] = (p.pos_s && j < q->len_t) ? q->tag_weights[j] : 0.0f;
 			wp.tpos[j] = (p.pos_s && j < q->len_t) ? (int32_t)q->q_pos[j] : -1;

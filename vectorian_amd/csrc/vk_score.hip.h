@@ -182,6 +182,13 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 			rowbase = t_a - tile0 * 16;
 		}
 		wave_lds_fence();
+		if constexpr (MODE == 2 && (GAP == 4 || GAP == 7)) {
+			if (p.qid_bits && len > 0) {   // tag-weighted vocabulary transport: cells upstream writes twice (static_vocab_fixup)
+				static_vocab_fixup<16>(S + rowbase * LT, LT, len, p.len_t, p.tok_id + t_a, p.tag_s + t_a, p.pos_s + t_a, p.table, 0,
+					p.qid_bits, p.qkey, p.tw, p.tpos, p.tw_keep, p.tw_threshold, v);
+				wave_lds_fence();
+			}
+		}
 
 		float raw;
 		const int lenc = len > 0 ? len : 0;

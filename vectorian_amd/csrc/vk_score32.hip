@@ -565,6 +565,13 @@ __global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t
 		wave_lds_fence();
 		const int lenc = len > 0 ? len : 0;
 		const int rb = len > 0 ? (STATIC ? t_a - g_a : t_a - tile0 * 16) : 0;
+		if constexpr (STATIC && (GAP == 4 || GAP == 7 || GAP == 5)) {
+			if (p.qid_bits && len > 0) {   // tag-weighted vocabulary transport: cells upstream writes twice (static_vocab_fixup, vk_common.hip.h)
+				static_vocab_fixup<LPS>(S + rb * stride, stride, len, p.len_t, p.tok_id + t_a, p.tag_s + t_a, p.pos_s + t_a, p.table, p.table_stride,
+					p.qid_bits, p.qkey, p.tw, p.tpos, p.tw_keep, p.tw_threshold, col);
+				wave_lds_fence();
+			}
+		}
 		float raw;
 		if constexpr (GAP == 3) raw = dp32_general<32, NB>(S, stride, rb, lenc, maxlen, col, lane, p, wsr, xch);
 		else if constexpr (GAP == 6) raw = dp32_general<64, NB>(S, stride, rb, lenc, maxlen, col, lane, p, wsr, xch);
@@ -719,6 +726,11 @@ __global__ __launch_bounds__(64) void vk_long_rwmd_fill_kernel(VkWideParams p, c
 					first = first && !(same && i < u);
 				}
 				sm[u] = first ? (float)cnt / wsum : 0.0f;
+			}
+			if (p.qid_bits) {
+				wave_lds_fence();
+				static_vocab_fixup<64>(S, N, m, p.len_t, p.tok_id + t_a, p.tag_s + t_a, p.pos_s + t_a, p.table, p.table_stride,
+					p.qid_bits, p.qkey, p.tw, p.tpos, p.tw_keep, p.tw_threshold, lane);
 			}
 		} else {
 			const int tile0 = t_a >> 4;

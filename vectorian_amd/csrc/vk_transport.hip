@@ -81,6 +81,11 @@ __device__ __forceinline__ int transport_sim_rows(const VkWrdParams &p, float *S
 				}
 			}
 		}
+		if (p.qid_bits && p.pos_s) {   // tag-weighted vocabulary transport: cells upstream writes twice (static_vocab_fixup, vk_common.hip.h)
+			wave_lds_fence();
+			static_vocab_fixup<64>(S, N, m, p.len_t, p.tok_id + t_a, p.tag_s + t_a, p.pos_s + t_a, p.table, p.table_stride,
+				p.qid_bits, p.qkey, p.tw, p.tpos, p.tw_keep, p.tw_threshold, lane);
+		}
 		return 0;
 	}
 	const int tile0 = t_a >> 4;
