@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 7
+#define VK_ABI_VERSION 8
 #define VK_MAX_QUERY_LEN 64   /* query tokens */
 #define VK_FAST_QUERY_LEN 16  /* queries up to this length run in the fused kernels (one 16-wide MFMA column block); longer ones
                                  take the multi-block kernel (2 or 4 column blocks) or, where that does not apply, a
@@ -161,12 +161,14 @@ typedef struct {
 	 * winner as SparseFlow / DenseFlow (match/match.h:140-260; alignment/wmd.h:392-408, 228-248; wrd.h:120-135).
 	 * Alignments fill sim_rows too when the array is given: the 'similarity' matrix of the debug hook
 	 * (call_debug_hook, metric/alignment.h:145-173), for the winners.
-	 * Optional (NULL: not produced); filled for corpora whose slices have at most VK_FAST_SENT_LEN tokens.
+	 * Optional (NULL: not produced).
 	 * W = the query length rounded up to a multiple of 16 (16 for queries of at most VK_FAST_QUERY_LEN tokens). */
-	float *sim_rows;         /* [capacity x VK_FAST_SENT_LEN x W] similarity S[i][j] of slice token i and query token j
+	float *sim_rows;         /* [capacity x R x W] similarity S[i][j] of slice token i and query token j
 	                            (clipped, tag weights applied, static layout: sim[id(t_j)][j] = 1); rows >= the slice's length are zero */
-	float *plan;             /* [capacity x W x VK_FAST_SENT_LEN] exact transport only (VK_ALG_WRD, wmd_full): the optimal
+	float *plan;             /* [capacity x W x R] exact transport only (VK_ALG_WRD, wmd_full): the optimal
 	                            plan G[j][i], mass moved from query token j to slice token i (positions) */
+	int32_t rows_per_winner; /* R: slice tokens per winner the two arrays hold; 0 = VK_FAST_SENT_LEN.  Winners of more than R tokens
+	                            get zero rows (their flows are not stated); up to VK_MAX_SENT_LEN, a multiple of 64 */
 } vk_topk_out;
 
 /* kernel timings of the last vk_query on a handle, milliseconds, from HIP events

@@ -182,3 +182,50 @@ def test_exact_transport_over_long_slices(hip, oracle, layout, alg, opts, len_t)
 		assert len(ref["sentence"]) == n   # every sentence is ranked: all the long ones are solved exactly
 		assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=2e-5, tie_tol=2e-5)
 	c.close()
+
+
+@pytest.mark.parametrize("len_t", [7, 24])
+def test_transport_flow_outputs_of_long_winners(hip, oracle, len_t):
+	"""want_flow on transport metrics over a corpus with slices of 65..300 tokens: the similarity rows of the winners and, for exact
+	transport, the optimal plan (its marginals are the masses, its value the score) -- vk_topk_out.rows_per_winner sized by the
+	corpus's longest slice, the long solver restating the plans of winners of more than 64 tokens"""
+	rng = np.random.default_rng(8 + len_t)
+	lens = rng.integers(3, 50, size=120)
+	lens[rng.integers(0, 120, size=25)] = rng.integers(65, 300, size=25)
+	off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+	d = 64
+	X = (rng.standard_normal((int(off[-1]), d)) * rng.lognormal(0, 0.3, size=(int(off[-1]), 1))).astype(np.float32)
+	Xb, mag = oracle.normalize_rows_bf16(X)
+	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=d, n_tokens=X.shape[0], n_sentences=len(lens), keep_magnitudes=True)
+	c.append_vectors(X, normalize=True)
+	c.set_sentences(off)
+	c.finalize()
+	s_long = int(np.argmax(lens))
+	qv = (X[off[s_long] + 5:off[s_long] + 5 + len_t] + 0.2 * rng.standard_normal((len_t, d))).astype(np.float32)   # planted in the longest slice
+	Qb, qmag = oracle.normalize_rows_bf16(qv)
+	n_long = 0
+	for alg, kw in ((hip.VK_ALG_WRD, {}), (hip.VK_ALG_RWMD, dict(rwmd=(False, False, True), wmd_full=True)), (hip.VK_ALG_RWMD, {})):
+		got = c.query(qv, algorithm=alg, q_normalize=True, max_matches=len(lens), min_score=-1.0, want_flow=True, **kw)
+		assert got.n == len(lens) and got.sim_rows.shape[1] >= int(lens.max())
+		for i in range(got.n):
+			s = int(got.sentence[i])
+			a, b = int(off[s]), int(off[s + 1])
+			if b - a <= 64 and i > 12:
+				continue
+			n_long += b - a > 64
+			S = oracle.sim_bf16(Xb[a:b], Qb)
+			np.testing.assert_allclose(got.sim_rows[i, :b - a, :len_t], S, atol=2e-6)
+			assert not got.sim_rows[i, b - a:].any()
+			if alg == hip.VK_ALG_RWMD and not kw:
+				continue
+			G = got.plan[i, :len_t, :b - a].astype(np.float64)
+			if alg == hip.VK_ALG_WRD:
+				mt, ms = qmag / qmag.sum(), mag[a:b] / mag[a:b].sum()
+			else:
+				mt, ms = np.full(len_t, 1 / len_t), np.full(b - a, 1 / (b - a))
+			np.testing.assert_allclose(G.sum(axis=1), mt, atol=2e-6)
+			np.testing.assert_allclose(G.sum(axis=0), ms, atol=2e-6)
+			raw = ((1.0 - np.maximum(1.0 - S.T, 0.0)) * G).sum() / G.sum()
+			assert abs(raw - got.raw_score[i]) < 2e-5
+	assert n_long >= 25
+	c.close()

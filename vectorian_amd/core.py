@@ -78,7 +78,7 @@ class _TopkOut(C.Structure):
 		("capacity", C.c_int32), ("n_out", C.c_int32),
 		("score", C.c_void_p), ("raw_score", C.c_void_p), ("sentence", C.c_void_p),
 		("mapping", C.c_void_p), ("edge_sim", C.c_void_p),
-		("sim_rows", C.c_void_p), ("plan", C.c_void_p)]
+		("sim_rows", C.c_void_p), ("plan", C.c_void_p), ("rows_per_winner", C.c_int32)]
 
 
 class _Timings(C.Structure):
@@ -150,7 +150,7 @@ def lib():
 		L.vk_record_words.argtypes = [C.c_int32]
 		L.vk_pack_records.argtypes = [C.POINTER(_TopkOut), C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
 		L.vk_merge_records.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_TopkOut)]
-		if L.vk_abi_version() != 7:
+		if L.vk_abi_version() != 8:
 			raise RuntimeError("libvectorian_hip.so ABI version mismatch")
 		_lib = L
 	return _lib
@@ -215,7 +215,7 @@ def gap_to_struct(gap, keep, n_table):
 class TopK:
 	"""Bounded result set as plain arrays (ResultSet, vectorian/core/cpp/result_set.h:17-153)."""
 
-	def __init__(self, k, len_t, transport=False):
+	def __init__(self, k, len_t, transport=False, rows=VK_FAST_SENT_LEN):
 		self.k, self.len_t = k, len_t
 		self.score = np.zeros(k, dtype=np.float32)
 		self.raw_score = np.zeros(k, dtype=np.float32)
@@ -224,8 +224,9 @@ class TopK:
 		self.edge_sim = np.zeros((k, len_t), dtype=np.float32)
 		# transport algorithms: similarity rows S[i][j] and (exact transport) the plan G[j][i] of each winner
 		w = (len_t + 15) // 16 * 16     # columns of a similarity row: the query length padded to a multiple of 16
-		self.sim_rows = np.zeros((k, VK_FAST_SENT_LEN, w), dtype=np.float32) if transport else None
-		self.plan = np.zeros((k, w, VK_FAST_SENT_LEN), dtype=np.float32) if transport else None
+		# rows: slice tokens per winner the two arrays hold (vk_topk_out.rows_per_winner; winners longer than that: no flow stated)
+		self.sim_rows = np.zeros((k, rows, w), dtype=np.float32) if transport else None
+		self.plan = np.zeros((k, w, rows), dtype=np.float32) if transport else None
 		self.n = 0
 
 	@classmethod
@@ -244,6 +245,7 @@ class TopK:
 		s.mapping, s.edge_sim = _np_ptr(self.mapping), _np_ptr(self.edge_sim)
 		if self.sim_rows is not None:
 			s.sim_rows, s.plan = _np_ptr(self.sim_rows), _np_ptr(self.plan)
+			s.rows_per_winner = self.sim_rows.shape[1]
 		return s
 
 	def trimmed(self):
@@ -336,12 +338,14 @@ class Corpus:
 	def set_sentences(self, sent_off):
 		sent_off = np.ascontiguousarray(sent_off, dtype=np.int64)
 		_check(lib().vk_corpus_set_sentences(self._h, _np_ptr(sent_off), len(sent_off) - 1))
+		self._max_len = int(np.diff(sent_off).max()) if len(sent_off) > 1 else 0
 
 	def set_slices(self, start, end):
 		"""general (possibly overlapping) slices: tokens [start[i], end[i])"""
 		start = np.ascontiguousarray(start, dtype=np.int64)
 		end = np.ascontiguousarray(end, dtype=np.int64)
 		_check(lib().vk_corpus_set_slices(self._h, _np_ptr(start), _np_ptr(end), len(start)))
+		self._max_len = int((end - start).max()) if len(start) else 0
 
 	def finalize(self):
 		_check(lib().vk_corpus_finalize(self._h))
@@ -417,7 +421,9 @@ class Corpus:
 		"""One query against the shard (vk_query).  Returns a TopK."""
 		keep = []
 		q, len_t = self._desc(q_vectors, keep, **options)
-		out = TopK(max(1, q.max_matches), len_t, transport=bool(q.want_flow) and (q.algorithm != VK_ALG_ALIGN or bool(options.get("want_rows"))))
+		# similarity rows / plans of the winners: room for the longest slice of the corpus (a multiple of 64 tokens)
+		rows = min(VK_MAX_SENT_LEN, max(VK_FAST_SENT_LEN, (getattr(self, "_max_len", 0) + 63) // 64 * 64))
+		out = TopK(max(1, q.max_matches), len_t, transport=bool(q.want_flow) and (q.algorithm != VK_ALG_ALIGN or bool(options.get("want_rows"))), rows=rows)
 		so = out._struct()
 		_check(lib().vk_query(self._h, C.byref(q), C.byref(so)))
 		out.n = so.n_out

@@ -126,8 +126,9 @@ struct VkWrdParams {
 	const uint64_t *keys;      // candidates (0 = empty slot)
 	float *raw_out;            // [n_cand]
 	float *val_out;            // [n_cand]
-	float *plan_out;           // optional [n_cand x 16 nq x 64]: the optimal plan G[j][i]
-	float *rows_out;           // vk_rows_kernel: [n_cand x 64 x 16 nq] similarity rows
+	float *plan_out;           // optional [n_cand x 16 nq x rows_len]: the optimal plan G[j][i]
+	float *rows_out;           // vk_rows_kernel: [n_cand x rows_len x 16 nq] similarity rows
+	int32_t rows_len;          // slice tokens per candidate in rows_out / plan_out (0 = 64)
 	const int8_t *tag_s;       // static layout, tag-weighted vocabulary transports: tag code per token, bitmap of the query's ids, keys of
 	const uint32_t *qid_bits;  // the query tokens (static_vocab_fixup; qid_bits null: off)
 	int32_t qkey[VK_DEV_MAX_WIDE_QUERY_LEN];

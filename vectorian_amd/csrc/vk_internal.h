@@ -103,6 +103,7 @@ struct vk_corpus {
 	float *d_wrd_raw = nullptr, *d_wrd_val = nullptr;
 	uint32_t *d_counter = nullptr;
 	float *d_rows_out = nullptr, *d_plan_out = nullptr;   // transport flows of the winners
+	size_t rows_cap = 0;   // floats each of them holds
 	uint8_t *d_bqt = nullptr; uint64_t *d_bcand = nullptr; int32_t *d_bcandq = nullptr; float *d_brows = nullptr;   // similarity rows of a batch's winners
 	size_t bqt_cap = 0, bcand_cap = 0;
 	uint32_t *d_qbits = nullptr;   // tag-weighted vocabulary transports over the static layout: bitmap of the query's token ids

@@ -145,34 +145,45 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	};
 	auto transport_flows = [&](const std::vector<int64_t> &rows_idx, bool exact, const float *qmass, int mass_mode, int raw_masses) -> int {
 		if (!q->want_flow || !out->sim_rows || rows_idx.empty()) return VK_OK;
-		const int nqw = (q->len_t + 15) / 16, W = 16 * nqw;   // (winners of more than 64 tokens get zero rows: their flows are not stated)   // columns of a similarity row: the query length padded to 16
+		const int nqw = (q->len_t + 15) / 16, W = 16 * nqw;   // columns of a similarity row: the query length padded to 16
+		const int R = out->rows_per_winner > 0 ? out->rows_per_winner : VK_FAST_SENT_LEN;   // rows per winner (longer winners: zero rows)
+		if (R % 64 != 0 || R > VK_MAX_SENT_LEN) return fail(VK_ERR_INVALID, "rows_per_winner must be a multiple of 64, at most VK_MAX_SENT_LEN");
 		int rc2;
-		if (c->rows_w < W) {
+		const int cnt = (int)rows_idx.size();
+		const size_t need = (size_t)cnt * R * W;
+		if (c->rows_cap < need) {
 			if (c->d_rows_out) { VK_HIP(hipFree(c->d_rows_out)); VK_HIP(hipFree(c->d_plan_out)); c->d_rows_out = c->d_plan_out = nullptr; }
-			if ((rc2 = alloc_t(c, &c->d_rows_out, (size_t)VK_MAX_MATCHES * 64 * W))) return rc2;
-			if ((rc2 = alloc_t(c, &c->d_plan_out, (size_t)VK_MAX_MATCHES * W * 64))) return rc2;
-			c->rows_w = W;
+			if ((rc2 = alloc_t(c, &c->d_rows_out, need))) return rc2;
+			if ((rc2 = alloc_t(c, &c->d_plan_out, need))) return rc2;
+			c->rows_cap = need;
 		}
 		if (!c->d_wrd_raw) {
 			if ((rc2 = alloc_t(c, &c->d_wrd_raw, (size_t)VK_MAX_MATCHES))) return rc2;
 			if ((rc2 = alloc_t(c, &c->d_wrd_val, (size_t)VK_MAX_MATCHES))) return rc2;
 			c->wrd_cap = VK_MAX_MATCHES;
 		}
-		const int cnt = (int)rows_idx.size();
 		std::vector<uint64_t> hk((size_t)cnt);
 		for (int i = 0; i < cnt; i++) hk[(size_t)i] = (1ull << 32) | (uint64_t)(uint32_t)rows_idx[(size_t)i];
 		VK_HIP(hipMemcpyAsync(c->d_keys[1], hk.data(), hk.size() * 8, hipMemcpyHostToDevice, c->stream));
 		VkWrdParams w{};
 		fill_transport(w);
-		w.keys = c->d_keys[1]; w.rows_out = c->d_rows_out;
+		w.keys = c->d_keys[1]; w.rows_out = c->d_rows_out; w.rows_len = R;
 		VK_HIP(vk_launch_rows(&w, cnt, c->stream));
-		VK_HIP(hipMemcpyAsync(out->sim_rows, c->d_rows_out, (size_t)cnt * 64 * W * 4, hipMemcpyDeviceToHost, c->stream));
+		VK_HIP(hipMemcpyAsync(out->sim_rows, c->d_rows_out, need * 4, hipMemcpyDeviceToHost, c->stream));
 		if (exact && out->plan) {
 			w.mass_mode = mass_mode; w.raw_masses = raw_masses;
 			memcpy(w.qmass, qmass, sizeof w.qmass);
 			w.raw_out = c->d_wrd_raw; w.val_out = c->d_wrd_val; w.plan_out = c->d_plan_out;
+			VK_HIP(hipMemsetAsync(c->d_plan_out, 0, need * 4, c->stream));   // a solver writes the columns of its winner's tokens only
 			VK_HIP(vk_launch_wrd_exact(&w, cnt, nullptr, c->stream));
-			VK_HIP(hipMemcpyAsync(out->plan, c->d_plan_out, (size_t)cnt * W * 64 * 4, hipMemcpyDeviceToHost, c->stream));
+			if (R > VK_FAST_SENT_LEN && c->max_len > VK_FAST_SENT_LEN) {   // winners of 65 .. R tokens: the long solver restates their plans
+				if (w.nq > 1 && !c->d_wrdl_scratch) {
+					if ((rc2 = alloc_t(c, &c->d_wrdl_scratch, (size_t)vk_wrd_long_blocks() * vk_wrd_long_scratch_bytes()))) return rc2;
+				}
+				w.scratch = c->d_wrdl_scratch; w.scratch_stride = (int64_t)vk_wrd_long_scratch_bytes();
+				VK_HIP(vk_launch_wrd_exact_long(&w, cnt, c->stream));
+			}
+			VK_HIP(hipMemcpyAsync(out->plan, c->d_plan_out, need * 4, hipMemcpyDeviceToHost, c->stream));
 		}
 		VK_HIP(hipStreamSynchronize(c->stream));
 		return VK_OK;

@@ -318,9 +318,11 @@ __global__ __launch_bounds__(64) void vk_wrd_exact_kernel(VkWrdParams p) {
 		p.raw_out[w] = raw;
 		p.val_out[w] = (raw / p.ref_total) * boost;
 	}
-	if (p.plan_out)
+	if (p.plan_out) {
+		const int R = p.rows_len > 0 ? p.rows_len : 64;
 		for (int j = 0; j < N; j++)
-			p.plan_out[((int64_t)w * N + j) * 64 + lane] = (has && j < n) ? (float)fl[j * 64 + lane] : 0.0f;
+			p.plan_out[((int64_t)w * N + j) * R + lane] = (has && j < n) ? (float)fl[j * 64 + lane] : 0.0f;
+	}
 }
 
 // ---------------------------------------------------------------------------
@@ -527,6 +529,11 @@ __global__ __launch_bounds__(64) void vk_wrd_exact_long_kernel(VkWrdParams p) {
 		p.raw_out[w] = raw;
 		p.val_out[w] = (raw / p.ref_total) * boost;
 	}
+	if (p.plan_out && p.rows_len >= m) {   // the plan of a winner, for the host to state its flow: [16 nq x rows_len]
+		const int Wp = 16 * p.nq;
+		for (int i = lane; i < m; i += 64)
+			for (int j = 0; j < n; j++) p.plan_out[((int64_t)w * Wp + j) * p.rows_len + i] = (float)fl[j * M + i];
+	}
 	wrdl_fence<GLOBAL>();   // the next candidate reuses the arrays
 	}
 }
@@ -636,10 +643,11 @@ template <int NQ>
 __global__ __launch_bounds__(64) void vk_rows_kernel(VkWrdParams p) {
 	constexpr int N = 16 * NQ;
 	extern __shared__ double vk_smem_f64[];
-	float *S = reinterpret_cast<float *>(vk_smem_f64);   // [(VK_DEV_MAX_SENT_LEN + 32)][N]
+	float *S = reinterpret_cast<float *>(vk_smem_f64);   // [(R + 32)][N]
 	const int lane = threadIdx.x;
 	const int w = blockIdx.x;
-	float *out = p.rows_out + (int64_t)w * 64 * N;
+	const int R = p.rows_len > 0 ? p.rows_len : 64;
+	float *out = p.rows_out + (int64_t)w * R * N;
 	const uint64_t key = p.keys[w];
 	int m = 0, rowbase = 0;
 	if (p.cand_query) p.qtile += (int64_t)p.cand_query[w] * p.qtile_stride;   // a batch: every candidate against its own query
@@ -647,11 +655,11 @@ __global__ __launch_bounds__(64) void vk_rows_kernel(VkWrdParams p) {
 		const int64_t g = (int64_t)(uint32_t)(key & 0xffffffffu);
 		const int t_a = p.sent_start[g], t_b = p.sent_end[g];
 		m = t_b - t_a;
-		if (m < 1 || m > 64) m = 0;
+		if (m < 1 || m > R) m = 0;
 		else rowbase = transport_sim_rows<NQ>(p, S, t_a, t_b, lane);
 	}
 	wave_lds_fence();
-	for (int i = lane; i < 64 * N; i += 64) out[i] = i / N < m ? S[rowbase * N + i] : 0.0f;
+	for (int i = lane; i < R * N; i += 64) out[i] = i / N < m ? S[rowbase * N + i] : 0.0f;
 }
 
 static size_t transport_lds_bytes(int nq, bool solver) {
@@ -672,8 +680,13 @@ extern "C" hipError_t vk_launch_wrd_exact(const VkWrdParams *p, int32_t n_cand, 
 }
 
 extern "C" hipError_t vk_launch_rows(const VkWrdParams *p, int32_t n_cand, hipStream_t stream) {
-	const size_t smem = transport_lds_bytes(p->nq, false);
+	const int R = p->rows_len > 0 ? p->rows_len : 64;
+	const size_t smem = (size_t)(R + 32) * 16 * (size_t)(p->nq < 1 ? 1 : p->nq) * 4;
 	void (*kernel)(VkWrdParams) = p->nq <= 1 ? vk_rows_kernel<1> : p->nq == 2 ? vk_rows_kernel<2> : p->nq == 3 ? vk_rows_kernel<3> : vk_rows_kernel<4>;
+	if (smem > 64 * 1024) {
+		const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+		if (e != hipSuccess) return e;
+	}
 	kernel<<<n_cand, 64, smem, stream>>>(*p);
 	return hipGetLastError();
 }

@@ -619,6 +619,10 @@ class HipBruteForceIndex(Index):
 			self._corpus.set_slices(dev_start, dev_end)
 		self._corpus.finalize()
 		self._max_slice_len = int((np.asarray(dev_end) - np.asarray(dev_start)).max()) if len(dev_start) else 0   # of the resident part
+		if shard is not None and hasattr(self._corpus, "_max_len") and n_slices:
+			# similarity rows / plans of transport winners are sized by the longest slice; the ranks exchange them (shards.allgather_merge),
+			# so every rank sizes them by the longest slice of the WHOLE corpus
+			self._corpus._max_len = int((self._slice_end - self._slice_start).max())
 
 	@property
 	def metric_name(self):
@@ -841,7 +845,7 @@ class HipBruteForceIndex(Index):
 		"""the reference calls hook(name, data) for EVERY slice it scores (call_debug_hook, metric/alignment.h:145-173: slice,
 		similarity [len_s x len_t], flow, score = the aligner's score; WMD: 'alignment/word-movers-distance/make' with score and
 		worst_score, :600-607).  Here the scoring kernel keeps no per-slice matrices: the hook is called for the k winners, best
-		first, with the same keys; `similarity` is None for winners of more than 64 tokens (their rows are not produced)."""
+		first, with the same keys; `similarity` is None for winners longer than the rows the backend returned (the oracle double: 64 tokens)."""
 		alg = args.get("algorithm", core.VK_ALG_ALIGN)
 		worst = float(matches[-1].score) if len(matches) >= args["max_matches"] else float(args["min_score"])
 		for i, m in enumerate(matches):
@@ -849,7 +853,7 @@ class HipBruteForceIndex(Index):
 				hook("alignment/word-movers-distance/make", {"score": m.score, "worst_score": worst, "slice": m.slice_id, "flow": m.flow})
 				continue
 			sim = None
-			if getattr(top, "sim_rows", None) is not None and m._len_s <= core.VK_FAST_SENT_LEN:
+			if getattr(top, "sim_rows", None) is not None and m._len_s <= top.sim_rows.shape[1]:
 				sim = top.sim_rows[i][:m._len_s if m._index_map is None else len(m._index_map), :len(p_query)].copy()
 			hook("alignment", {"slice": m.slice_id, "similarity": sim, "flow": m.flow, "score": m.raw_score})
 
@@ -894,7 +898,7 @@ class HipBruteForceIndex(Index):
 			return None
 		a, b = int(self._slice_start[g]), int(self._slice_end[g])
 		len_s, len_t = (b - a if index_map is None else len(index_map)), len(p_query)
-		if len_s > core.VK_FAST_SENT_LEN:
+		if len_s > top.sim_rows.shape[1]:   # rows per winner the backend was given room for (the corpus's longest slice on the HIP backend)
 			return None
 		rows, plan = top.sim_rows[i], top.plan[i]   # sliced and copied when the flow is asked for (HipMatch.flow is lazy)
 		S = lambda: rows[:len_s, :len_t].copy()

@@ -175,8 +175,8 @@ def allgather_merge(top, sentence_offset, k, group=None, device=None):
 		# follow in a second all-gather (k x 2 x 64 W floats per rank: 80 KB at k = 10, W = 16), so that the merged winners
 		# carry what the host states their SparseFlow / DenseFlow from (wmd.h:392-408, 228-248; wrd.h:120-135), whichever rank
 		# scored them
-		w = top.sim_rows.shape[2]
-		pay = np.zeros((k, 2, core.VK_FAST_SENT_LEN * w), dtype=np.float32)
+		rows, w = top.sim_rows.shape[1], top.sim_rows.shape[2]
+		pay = np.zeros((k, 2, rows * w), dtype=np.float32)
 		pay[:top.n, 0] = top.sim_rows[:top.n].reshape(top.n, -1)
 		pay[:top.n, 1] = top.plan[:top.n].reshape(top.n, -1)
 		send2 = torch.from_numpy(pay).to(device)
@@ -184,10 +184,10 @@ def allgather_merge(top, sentence_offset, k, group=None, device=None):
 		dist.all_gather_into_tensor(recv2, send2, group=group)
 		allp = recv2.cpu().numpy().reshape(world, k, 2, -1)
 		where = {int(sets[r].sentence[j]): (r, j) for r in range(world) for j in range(sets[r].n)}
-		merged.sim_rows = np.zeros((k, core.VK_FAST_SENT_LEN, w), dtype=np.float32)
-		merged.plan = np.zeros((k, w, core.VK_FAST_SENT_LEN), dtype=np.float32)
+		merged.sim_rows = np.zeros((k, rows, w), dtype=np.float32)
+		merged.plan = np.zeros((k, w, rows), dtype=np.float32)
 		for i in range(merged.n):
 			r, j = where[int(merged.sentence[i])]
-			merged.sim_rows[i] = allp[r, j, 0].reshape(core.VK_FAST_SENT_LEN, w)
-			merged.plan[i] = allp[r, j, 1].reshape(w, core.VK_FAST_SENT_LEN)
+			merged.sim_rows[i] = allp[r, j, 0].reshape(rows, w)
+			merged.plan[i] = allp[r, j, 1].reshape(w, rows)
 	return merged
