@@ -53,3 +53,24 @@ def test_allgather_of_hip_result_sets_over_rccl(hip, nccl_group):
 	blk = shards.allgather_merge(tops[4], offset, k)
 	np.testing.assert_array_equal(blk.score[:blk.n], tops[4].score[:tops[4].n])
 	c.close()
+
+
+def test_allgather_merge_carries_rows_of_long_transport_winners(hip, nccl_group):
+	"""the blocking exchange with the flows' payload: similarity rows and plans sized by the longest slice (here 150 tokens)"""
+	rng = np.random.default_rng(3)
+	lens = np.array([12, 150, 30, 7, 64, 90, 20])
+	off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+	X = rng.standard_normal((int(off[-1]), 48)).astype(np.float32)
+	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=48, n_tokens=X.shape[0], n_sentences=len(lens), keep_magnitudes=True)
+	c.append_vectors(X, normalize=True)
+	c.set_sentences(off)
+	c.finalize()
+	top = c.query(X[off[1] + 3:off[1] + 9], algorithm=hip.VK_ALG_WRD, q_normalize=True, max_matches=5, min_score=-1.0, want_flow=True)
+	assert top.sim_rows.shape[1] == 192 and int(top.sentence[0]) == 1
+	merged = shards.allgather_merge(top, 1000, 5)
+	assert merged.n == top.n and merged.sim_rows.shape == top.sim_rows.shape
+	np.testing.assert_array_equal(merged.sentence[:merged.n], top.sentence[:top.n] + 1000)
+	np.testing.assert_array_equal(merged.sim_rows[:merged.n], top.sim_rows[:top.n])
+	np.testing.assert_array_equal(merged.plan[:merged.n], top.plan[:top.n])
+	assert abs(float(merged.plan[0].sum()) - 1.0) < 1e-5      # the plan of the 150-token winner moves all the mass
+	c.close()
