@@ -86,3 +86,30 @@ def test_exchange_records_native_against_numpy(len_t):
 	assert got.n == ref.n
 	for f in ("score", "raw_score", "sentence", "mapping", "edge_sim"):
 		np.testing.assert_array_equal(getattr(got, f)[:got.n], getattr(ref, f)[:ref.n])
+
+
+def test_struct_fields_agree_header_shim_and_integration_stub():
+	# the ctypes structures of the shim and of INTEGRATION.md's stub list the fields of the header's structs, in order
+	from vectorian_amd import core
+	header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "vectorian_hip.h")).read(), flags=re.S)
+	doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+
+	def header_fields(name):
+		end = header.index("} " + name + ";")
+		body = header[header.rindex("typedef struct {", 0, end) + len("typedef struct {"):end]
+		out = []
+		for decl in body.split(";"):
+			for part in decl.split(","):
+				m = re.search(r"(\w+)\s*(\[\w*\])?\s*$", part.strip())
+				if m and part.strip():
+					out.append(m.group(1))
+		return out
+
+	def stub_fields(name):
+		i = doc.index(f"class {name}(C.Structure)")
+		j = min(x for x in (doc.find("\nclass ", i + 10), doc.find("\ndef check", i)) if x > 0)
+		return re.findall(r'\("(\w+)"', doc[i:j])
+	for cname, shim, stub in (("vk_query_desc", core._QueryDesc, "QueryDesc"), ("vk_topk_out", core._TopkOut, "TopkOut"), ("vk_corpus_desc", core._CorpusDesc, "CorpusDesc")):
+		names = [f[0] for f in shim._fields_]
+		assert header_fields(cname) == names, (cname, header_fields(cname), names)
+		assert stub_fields(stub) == names, (stub, stub_fields(stub), names)
