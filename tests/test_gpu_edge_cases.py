@@ -252,3 +252,31 @@ def test_different_corpora_from_different_threads(hip):
 			assert (r["sentence"] == o["sentence"]).all() and (r["score"] == o["score"]).all() and (r["mapping"] == o["mapping"]).all()
 	for h in (a, b, c):
 		h.close()
+
+
+def test_degenerate_vectors(hip, oracle):
+	"""Vectors.normalized (vectorian/embedding/vectors.py:71-80): rows / norm with NaN -> 0 -- an all-zero row, a row with a NaN and a
+	row with an infinity become zero rows (similarity 0 to everything); a zero query token likewise.  Scores stay finite and equal
+	the oracle's on the same rounded rows."""
+	corpus = synth.make_contextual_corpus(300, 2, 30, 500, 64)
+	X = corpus["X"].copy()
+	off = corpus["sent_off"]
+	X[int(off[5])] = 0.0
+	X[int(off[9]) + 1, 3] = np.nan
+	X[int(off[20]), 7] = np.inf
+	Xb, _ = oracle.normalize_rows_bf16(X)
+	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=64, n_tokens=X.shape[0], n_sentences=300)
+	c.append_vectors(X, normalize=True)
+	c.set_sentences(off)
+	c.finalize()
+	q = synth.make_queries(corpus, 1, 6)[0]["vectors"].copy()
+	q[2] = 0.0
+	Qb, _ = oracle.normalize_rows_bf16(q)
+	for kw, okw in ((dict(gap_s=EXP5, gap_t=EXP5), dict(gap_s=EXP5, gap_t=EXP5)), (dict(algorithm=hip.VK_ALG_RWMD), dict(algorithm=oracle.ALG_RWMD))):
+		ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=64, sent_off=off, X=Xb, Q=Qb, max_matches=300, min_score=-1.0, want_all_scores=True, **okw)
+		got = c.query(q, q_normalize=True, max_matches=300, min_score=-1.0, **kw)
+		sc = c.last_scores()
+		assert np.isfinite(sc).all()
+		np.testing.assert_allclose(sc, ref["all_scores"], atol=1e-4)
+		assert got.n == len(ref["score"])
+	c.close()
