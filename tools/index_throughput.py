@@ -24,6 +24,7 @@ def main():
 	ap.add_argument("--contextual", action="store_true", help="per-token vectors (contextual embedding) instead of the static layout: find_many then shares calls (vk_query_batch)")
 	ap.add_argument("--strategy", choices=["local", "rwmd"], default="local")
 	ap.add_argument("--no-batch", action="store_true", help="find_many(batch=False): one query per call")
+	ap.add_argument("--profile", action="store_true", help="cProfile of the timed find_many on stderr")
 	args = ap.parse_args()
 	from vectorian_amd import alignment, synth
 	from vectorian_amd.corpus import Corpus, Document
@@ -58,9 +59,18 @@ def main():
 	texts = [" ".join(docs[int(rng.integers(0, len(docs)))].tokens[a:a + 10]) for a in rng.integers(0, per_doc * len_s - 10, size=args.queries)]
 	batch = False if args.no_batch else None
 	index.find_many(texts[:max(6, min(len(texts), 32))], in_flight=args.in_flight, batch=batch)
+	prof = None
+	if args.profile:
+		import cProfile
+		prof = cProfile.Profile()
+		prof.enable()
 	t0 = time.perf_counter()
 	results = index.find_many(texts, in_flight=args.in_flight, batch=batch)
 	el = time.perf_counter() - t0
+	if prof is not None:
+		import pstats
+		prof.disable()
+		pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(18)
 	t0 = time.perf_counter()
 	for t in texts[:10]:
 		index.find(t)

@@ -771,7 +771,7 @@ class HipBruteForceIndex(Index):
 					return
 				raise
 			for i, qv, top in zip(idx, qvs, tops):
-				results[i] = self._matches_from_topk(prepared[i], top, gaps, args, np.asarray(qv.magnitudes, dtype=np.float32), None, None)
+				results[i] = self._matches_from_topk(prepared[i], top, gaps, args, None, None, None)   # (magnitudes: WRD only, which does not share calls)
 
 		def lane(h):
 			for b in range(h, len(batches), len(handles)):
@@ -836,7 +836,8 @@ class HipBruteForceIndex(Index):
 			top = shards.allgather_merge(top, self._slice_off, args["max_matches"], group=self._group)
 		if progress:
 			progress(1.0)
-		matches = self._matches_from_topk(p_query, top, gaps, args, np.asarray(qv.magnitudes, dtype=np.float32), masks, q_tag_codes)
+		qmag = np.asarray(qv.magnitudes, dtype=np.float32) if args.get("algorithm") == core.VK_ALG_WRD else None   # masses of the WRD flow
+		matches = self._matches_from_topk(p_query, top, gaps, args, qmag, masks, q_tag_codes)
 		if hook is not None:
 			self._call_debug_hook(hook, p_query, top, matches, args)
 		return matches
@@ -892,47 +893,60 @@ class HipBruteForceIndex(Index):
 				drop |= (cd >= 0) & (cd < 64) & bits[np.clip(cd, 0, 63)]
 		return np.nonzero(~drop)[0]
 
-	def _transport_flow(self, p_query, top, i, g, args, qmag, index_map=None, q_tag_codes=None):
-		"""flow of winner i of a transport query, stated from the similarity rows / plan the backend returned"""
+	def _transport_flow(self, p_query, top, i, g, args, qmag, index_map=None, q_tag_codes=None, span=None):
+		"""flow of winner i of a transport query, stated from the similarity rows / plan the backend returned
+		(a callable: HipMatch.flow evaluates it when asked)"""
 		if getattr(top, "sim_rows", None) is None:
 			return None
-		a, b = int(self._slice_start[g]), int(self._slice_end[g])
+		a, b = span if span is not None else (int(self._slice_start[g]), int(self._slice_end[g]))
 		len_s, len_t = (b - a if index_map is None else len(index_map)), len(p_query)
 		if len_s > top.sim_rows.shape[1]:   # rows per winner the backend was given room for (the corpus's longest slice on the HIP backend)
 			return None
-		rows, plan = top.sim_rows[i], top.plan[i]   # sliced and copied when the flow is asked for (HipMatch.flow is lazy)
-		S = lambda: rows[:len_s, :len_t].copy()
-		G = lambda: plan[:len_t, :len_s].copy()
-		ids_s = self._token_ids[a:b] if self._token_ids is not None else None
-		if ids_s is not None and index_map is not None:
-			ids_s = ids_s[index_map]
-		ids_t = p_query.token_ids if self._token_ids is not None else None
-		if ids_s is not None and q_tag_codes is not None and self._tag_codes is not None:
-			# tag-weighted: vocabulary entries are (token id, tag) pairs
-			tags_s = self._tag_codes[a:b] if index_map is None else self._tag_codes[a:b][index_map]
-			ids_s = np.asarray(ids_s, dtype=np.int64) * 256 + (np.asarray(tags_s, dtype=np.int64) & 255)
-			ids_t = np.asarray(ids_t, dtype=np.int64) * 256 + (np.asarray(q_tag_codes, dtype=np.int64) & 255)
-		if args["algorithm"] == core.VK_ALG_WRD:
-			mass = qmag / qmag.sum() if args.get("wrd_normalize", True) else qmag
-			return lambda: dense_flow(S(), G(), None, None, mass)   # WRD works on positions (wrd.h:91-109)
-		injective, symmetric, nbow = args["rwmd"]
-		if args.get("wmd_full"):
-			unit = 1.0 / len_t if nbow else 1.0
-			return lambda: dense_flow(S(), G(), ids_s, ids_t, np.full(len_t, unit, dtype=np.float32))
-		return lambda: rwmd_sparse_flow(S(), ids_s, ids_t, injective, symmetric, nbow)
+		alg = args["algorithm"]
+		token_ids, tag_codes = self._token_ids, self._tag_codes
+
+		def state():
+			S = top.sim_rows[i][:len_s, :len_t].copy()
+			ids_s = token_ids[a:b] if token_ids is not None else None
+			if ids_s is not None and index_map is not None:
+				ids_s = ids_s[index_map]
+			ids_t = p_query.token_ids if token_ids is not None else None
+			if ids_s is not None and q_tag_codes is not None and tag_codes is not None:
+				# tag-weighted: vocabulary entries are (token id, tag) pairs
+				tags_s = tag_codes[a:b] if index_map is None else tag_codes[a:b][index_map]
+				ids_s = np.asarray(ids_s, dtype=np.int64) * 256 + (np.asarray(tags_s, dtype=np.int64) & 255)
+				ids_t = np.asarray(ids_t, dtype=np.int64) * 256 + (np.asarray(q_tag_codes, dtype=np.int64) & 255)
+			if alg == core.VK_ALG_WRD:
+				mass = qmag / qmag.sum() if args.get("wrd_normalize", True) else qmag
+				return dense_flow(S, top.plan[i][:len_t, :len_s].copy(), None, None, mass)   # WRD works on positions (wrd.h:91-109)
+			injective, symmetric, nbow = args["rwmd"]
+			if args.get("wmd_full"):
+				unit = 1.0 / len_t if nbow else 1.0
+				return dense_flow(S, top.plan[i][:len_t, :len_s].copy(), ids_s, ids_t, np.full(len_t, unit, dtype=np.float32))
+			return rwmd_sparse_flow(S, ids_s, ids_t, injective, symmetric, nbow)
+		return state
 
 	def _matches_from_topk(self, p_query, top, gaps, args=None, qmag=None, masks=None, q_tag_codes=None):
-		matches = []
+		n = top.n
+		if n == 0:
+			return []
 		transport = args is not None and args.get("algorithm", core.VK_ALG_ALIGN) != core.VK_ALG_ALIGN
-		for i in range(top.n):
-			g = int(top.sentence[i])
-			di = int(self._slice_doc[g])
+		# one conversion per field for all winners (a batch of 256 queries builds 2,560 matches)
+		sent_a = np.asarray(top.sentence[:n], dtype=np.int64)
+		sent = sent_a.tolist()
+		score, raw = top.score[:n].tolist(), top.raw_score[:n].tolist()
+		mapping, edge = top.mapping[:n].copy(), top.edge_sim[:n].copy()
+		docs = self._slice_doc[sent_a].tolist()
+		starts, ends = self._slice_start[sent_a].tolist(), self._slice_end[sent_a].tolist()
+		slice_id, token_at = self._slice_id, self._slice_token_at
+		matches = []
+		for i in range(n):
+			g = sent[i]
 			index_map = self._index_map(g, masks) if masks else None
 			matches.append(HipMatch(
-				self, p_query, di, self._slice_id[g], self._slice_token_at[g],
-				int(self._slice_end[g] - self._slice_start[g]),
-				top.score[i], top.raw_score[i], top.mapping[i].copy(), top.edge_sim[i].copy(), gaps,
-				transport_flow=self._transport_flow(p_query, top, i, g, args, qmag, index_map, q_tag_codes) if transport else None,
+				self, p_query, docs[i], slice_id[g], token_at[g], ends[i] - starts[i],
+				score[i], raw[i], mapping[i], edge[i], gaps,
+				transport_flow=self._transport_flow(p_query, top, i, g, args, qmag, index_map, q_tag_codes, span=(starts[i], ends[i])) if transport else None,
 				index_map=index_map))
 		return matches
 
