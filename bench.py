@@ -17,7 +17,8 @@ rank holds its own shard of the workload's per-GPU size); the only exchange is t
 
 --config picks the workload of the headline `value` (default 2); at N = 1 the other SURVEY 8(d)
 configurations are then timed as well, each on its own resident corpus at its per-GPU shape, and reported
-under "configs" in the same JSON line (per entry: workload, value, kernel, kernel_ms, roofline):
+in the same JSON line as roofline.by_config = {name: [value, kernel_ms, frac]} (the line stays under 2 KB; the long
+form -- workload texts, phases, traffic sources, every entry's full roofline -- goes to stderr and to $VK_BENCH_FULL):
   3     1.25 M x 32 x 300-d per GPU, global alignment (Needleman-Wunsch), linear gap 0.1   (config 3 = 10 M over 8 GPUs)
   4     256 queries x 1 M x 32 x 300-d, relaxed WMD rwmd('nbow'), one GEMM-shaped pass     (MFMA-bound)
   5     1 M sentences of 8..64 tokens x 768-d per GPU, WSB local alignment                  (config 5 = 4 M over 4 GPUs)
@@ -71,18 +72,17 @@ def gap_spec(name):
 
 
 def describe(spec, n_sent):
+	"""one short line per workload (the whole JSON line has to stay under 2 KB: the driver keeps a 2,000-character tail)"""
 	lens = f"{spec['min_len']}" if spec["min_len"] == spec["max_len"] else f"{spec['min_len']}..{spec['max_len']}"
-	rows = f"{n_sent} x {lens}-token synthetic sentences per GPU, {spec['d']}-d {spec['prec']} per-token vectors (contextual layout)"
-	if spec.get("layout") == "static":
-		rows = f"{n_sent} x {lens}-token synthetic sentences per GPU as token ids over a {VOCAB}-word {spec['d']}-d vocabulary (static layout: per-query table [V x |q|] + gather)"
+	rows = f"{n_sent} x {lens} tok x {spec['d']}-d {spec['prec']}" + (f" static layout (ids over {VOCAB} words)" if spec.get("layout") == "static" else " contextual")
+	gap = "WSB general gap 1-2^(-k/5)" if spec["gap"] == "exp5" else "linear gap 0.1"
 	if spec["alg"] == "align" and spec.get("batch"):
-		return (f"{spec['batch']} {LEN_T}-token queries per call over {rows}, {spec['locality']} alignment, {gap_spec(spec['gap'])[2]}, top-{K_MATCHES} with flow per query; "
-			f"the token tiles are streamed once per {spec.get('per_pass', 2)} queries")
+		return f"{spec['batch']} x {LEN_T}-tok queries/call over {rows} per GPU, {spec['locality']} {gap}, top-{K_MATCHES}+flow, tiles read once per {spec.get('per_pass', 2)} queries"
 	if spec["alg"] == "rwmd":
-		return f"batch of {spec.get('batch', 1)} {LEN_T}-token queries over {rows}, relaxed Word Mover's Distance rwmd('nbow'), top-{K_MATCHES} per query"
+		return f"{spec.get('batch', 1)} x {LEN_T}-tok queries over {rows} per GPU, RWMD rwmd('nbow'), top-{K_MATCHES}"
 	if spec["alg"] == "wrd":
-		return f"{LEN_T}-token query over {rows}, Word Rotator's Distance (bound pass + exact EMD of the survivors), top-{K_MATCHES}"
-	return f"{LEN_T}-token query over {rows}, {spec['locality']} alignment, {gap_spec(spec['gap'])[2]}, top-{K_MATCHES} with flow"
+		return f"{LEN_T}-tok query over {rows} per GPU, WRD (bound pass + exact EMD), top-{K_MATCHES}"
+	return f"{LEN_T}-tok query over {rows} per GPU, {spec['locality']} alignment {gap}, top-{K_MATCHES}+flow"
 
 
 def build_shard(core, torch, spec, n_sent, rank, device):
@@ -229,11 +229,9 @@ def cpu_baseline(spec, budget_s=10.0):
 	value, batch, el = rate(budget_s, n, 4096)
 	out = {
 		"value": value, "unit": "sentence-alignments/sec", "cores": cores, "kind": "port",
-		"sample": f"{batch} queries x {n} sentences x {ls0 if ls0 == ls1 else str(ls0) + '..' + str(ls1)} tokens x {d}-d (same generator as the GPU workload), "
-			f"{cores} threads, {el:.1f} s; CPU restatement of the reference algorithm (reference not runnable offline)"}
+		"sample": f"{batch} queries x {n} sent x {ls0 if ls0 == ls1 else str(ls0) + '..' + str(ls1)} tok x {d}-d, {cores} threads, {el:.1f} s (C restatement; reference not runnable offline)"}
 	# beside it: one thread
 	out["single_thread_value"] = rate(2.5, n, 1024, n_threads=1)[0]
-	out["sample"] += "; single_thread_value: the same on one thread"
 	if spec["alg"] == "align":
 		# BLAS leg: S = X . Q^T by sgemm (fp32 unit rows, as the reference computes it), clip, then the port's DP
 		def blas_run(b):
@@ -246,13 +244,12 @@ def cpu_baseline(spec, budget_s=10.0):
 		t1 = time.perf_counter()
 		blas_run(b)
 		out["blas_value"] = n * b / (time.perf_counter() - t1)
-		out["sample"] += f"; blas_value: {b} queries, one numpy sgemm [{Xn.shape[0]} x {d}] x [{d} x {LEN_T}] per query (BLAS threads: numpy's default) + the port's DP on {cores} threads"
+		out["blas_note"] = f"one numpy sgemm [{Xn.shape[0]}x{d}]x[{d}x{LEN_T}] per query + the port's DP"
 		# the reference's own static layout (token ids + per-query table [V x |q|])
 		n_st = 16 * n      # the per-query table over the vocabulary is amortised over the slices, as in the full workload
 		st = synth.make_static_corpus(n_st, ls0, ls1, VOCAB, d)
 		Eb = synth.to_bf16_bits(synth.normalize_rows(st["E"]))
 		out["static_layout_value"] = rate(2.5, n_st, 1024, layout=vo.LAYOUT_STATIC, X=None, sent_off=st["sent_off"], tok_id=st["tok_id"], E=Eb)[0]
-		out["sample"] += f"; static_layout_value: token ids + per-query table over {n_st} slices, {cores} threads"
 	return out
 
 
@@ -571,26 +568,47 @@ def main():
 	spec, entry = measure(args.config, n_sent, args.warmup, args.steps, dist, gap=args.gap, locality=args.locality, keep=keep)
 	traffic, traffic_source = traffic_of(spec["name"], spec["gap"], n_sent, head["n_sent"])
 
-	out = None
+	# what the collective backend itself saw (the first real multi-GPU run must prove that RCCL ran with N ranks on N devices)
+	ranks = {"launched": world, "backend": backend if dist is not None else None, "world_seen_by_backend": 1, "devices": [dev_index]}
+	if dist is not None:
+		ranks["world_seen_by_backend"] = int(dist.get_world_size())
+		seen = [None] * dist.get_world_size()
+		dist.all_gather_object(seen, (rank, dev_index, os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")))
+		ranks["devices"] = [d_ for _, d_, _ in sorted(seen)]
+		vis = sorted({v_ for _, _, v_ in seen if v_})
+		if vis:
+			ranks["visible"] = vis
+
+	def compact_roofline(e):
+		r = e["roofline"]
+		return {"bound": r["bound"], "achieved": round(r["achieved"], 1), "peak": r["peak"], "unit": r["unit"], "frac": round(r["frac"], 4),
+			"kernel": r["kernel"], "kernel_ms": round(r["kernel_ms"], 4)}
+
+	out = full = None
 	if rank == 0:
-		roof = dict(entry["roofline"])
+		roof = compact_roofline(entry)
 		roof["traffic"] = traffic
-		roof["traffic_source"] = traffic_source
+		# ONE line, under 2 KB (the driver keeps a 2,000-character tail of stdout): the headline, its roofline with every other
+		# configuration as [value, kernel_ms, frac] under roofline.by_config, the CPU baseline.  The long form (workload texts,
+		# phases, notes, traffic sources) goes to stderr and to VK_BENCH_FULL (a file) when set.
 		out = {
 			"metric": "sentence-alignments/sec at d=300, |q|=10, |s|<=64; 1/2/4/8 GPU + %HBM roofline",
-			"value": entry["value"], "unit": "sentence-alignments/sec",
+			"value": round(entry["value"], 1), "unit": "sentence-alignments/sec",
 			"n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-			"ms_per_step": entry["ms_per_step"], "ms_per_step_median": entry["ms_per_step_median"],
+			"ms_per_step": round(entry["ms_per_step"], 4),
 			"higher_is_better": True, "scaling": "weak", "vs_baseline": None,
 			"dtype": spec["prec"], "data": "synthetic",
-			"config": {
-				"workload": entry["workload"], "name": spec["name"],
-				"sentences_per_gpu": n_sent, "len_s": [spec["min_len"], spec["max_len"]], "len_t": LEN_T, "d": spec["d"], "k": K_MATCHES,
-				"algorithm": spec["alg"], "locality": spec["locality"], "gap": spec["gap"], "queries_per_step": max(1, int(spec.get("batch", 0))),
+			"config": {"workload": entry["workload"], "name": spec["name"],
 				"parallelism": f"corpus shards x{world}, RCCL all-gather of k records"},
 			"roofline": roof,
-			"phases_ms_mean": entry["phases_ms_mean"],
+			"ranks": ranks,
 		}
+		full = dict(out)
+		full["config"] = dict(out["config"], sentences_per_gpu=n_sent, len_s=[spec["min_len"], spec["max_len"]], len_t=LEN_T, d=spec["d"], k=K_MATCHES,
+			algorithm=spec["alg"], locality=spec["locality"], gap=spec["gap"], queries_per_step=max(1, int(spec.get("batch", 0))))
+		full["roofline"] = dict(entry["roofline"], traffic=traffic, traffic_source=traffic_source)
+		full["ms_per_step_median"] = entry["ms_per_step_median"]
+		full["phases_ms_mean"] = entry["phases_ms_mean"]
 
 	# ---- the other SURVEY 8(d) configurations, one GPU, each on its own resident corpus --------------------------
 	if world == 1 and dist is None and not args.no_extra:
@@ -619,7 +637,10 @@ def main():
 			except Exception as ex:   # a configuration that fails is reported, the headline stands
 				e = {"workload": describe(w, n_x), "error": f"{type(ex).__name__}: {ex}"}
 			configs[w["name"]] = e
-		out["configs"] = configs
+		full["configs"] = configs
+		# [value, kernel_ms, frac of the roofline that bounds it] per configuration; units as the headline's (config4: pairs/s, MFMA)
+		out["roofline"]["by_config"] = {name: ([round(e["value"], 1), round(e["kernel_ms"], 4), round(e["roofline"]["frac"], 4)] if "error" not in e else "error")
+			for name, e in configs.items()}
 	if keep.get("shard"):
 		keep["shard"][0].close()
 		keep.clear()
@@ -627,8 +648,21 @@ def main():
 
 	if rank == 0:
 		if not args.no_cpu_baseline and world == 1:
-			out["cpu_baseline"] = cpu_baseline(spec)
-		print(json.dumps(out))
+			cb = cpu_baseline(spec)
+			full["cpu_baseline"] = cb
+			out["cpu_baseline"] = {k_: (round(v_, 1) if isinstance(v_, float) else v_) for k_, v_ in cb.items() if k_ != "blas_note"}
+		print("[bench full] " + json.dumps(full), file=sys.stderr)
+		if os.environ.get("VK_BENCH_FULL"):
+			with open(os.environ["VK_BENCH_FULL"], "w") as f:
+				json.dump(full, f, indent=1)
+		line = json.dumps(out, separators=(",", ":"))
+		if len(line) > 1900:   # never let the tail cut the front of the line: drop the least needed parts first
+			for drop in (("ranks", "visible"), ("cpu_baseline", "sample"), ("roofline", "kernel"), ("config", "parallelism")):
+				out.get(drop[0], {}).pop(drop[1], None)
+				line = json.dumps(out, separators=(",", ":"))
+				if len(line) <= 1900:
+					break
+		print(line)
 	if dist is not None:
 		dist.barrier()
 		dist.destroy_process_group()

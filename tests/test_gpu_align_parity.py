@@ -1,6 +1,7 @@
 """-m gpu: the HIP path (through the C-ABI) against the CPU oracle on the same
-seeded inputs.  Scores within 1e-4 (north_star tolerance), sentence ids and
-traceback mappings identical."""
+seeded inputs.  Alignments with traceback: slice ids, scores and traceback mappings
+bit-identical to the oracle's (helpers.assert_same_results, exact); the score vector of
+all slices within 1e-4 (north_star tolerance)."""
 
 import numpy as np
 import pytest
@@ -67,6 +68,42 @@ def test_static_parity(hip, oracle, locality, gap):
 		got = c.query(Qb, q_token_ids=q["ids"], locality=locality, gap_s=gs, gap_t=gt, q_normalize=False,
 			max_matches=20, min_score=0.0 if locality != 1 else -100.0).trimmed()
 		assert_same_results(got, ref)
+	c.close()
+
+
+@pytest.mark.parametrize("locality", [0, 1, 2])
+@pytest.mark.parametrize("gap", ["linear0.1", "linear0", "linear_asym"])
+def test_static_linear_gaps_repeated_words(hip, oracle, locality, gap):
+	"""The case round 2 exempted: static layout, LINEAR gaps, words that repeat inside the slices and inside the query (a small
+	vocabulary: equal similarity rows, co-optimal alignments that tie exactly in real arithmetic, the traceback then decided by
+	the last bit of S).  The winners are restated in the oracle's arithmetic (sim_canon): ids, scores, tracebacks bit for bit,
+	with the query's own token ids (sim[id(t_j)][j] = 1) and without them."""
+	rng = np.random.default_rng(77 + locality)
+	V, d, n = 12, 300, 800
+	E = rng.standard_normal((V, d)).astype(np.float32)
+	lens = rng.integers(1, 41, size=n)
+	off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+	ids = rng.integers(0, V, size=int(off[-1])).astype(np.int32)
+	c = hip.Corpus(layout=hip.VK_LAYOUT_STATIC, d=d, n_tokens=len(ids), n_sentences=n, vocab_size=V)
+	c.append_vectors(E, normalize=True)
+	c.set_token_ids(ids)
+	c.set_sentences(off)
+	c.finalize()
+	En = oracle.normalize_rows_bf16(E)[0]
+	gs, gt = GAPS[gap]
+	ms = 0.0 if locality != 1 else -1e9
+	repeated = 0
+	for len_t in (4, 9, 16):
+		q_ids = rng.integers(0, V, size=len_t).astype(np.int32)
+		q_ids[-1] = q_ids[0]   # the query repeats a word too
+		for with_ids in (True, False):
+			kw = dict(locality=locality, gap_s=gs, gap_t=gt, max_matches=25, min_score=ms)
+			ref = oracle.find(layout=oracle.LAYOUT_STATIC, d=d, sent_off=off, tok_id=ids, E=En, Q=En[q_ids], q_ids=q_ids if with_ids else None, **kw)
+			got = c.query(E[q_ids], q_token_ids=q_ids if with_ids else None, q_normalize=True, **kw)
+			assert_same_results(got.trimmed(), ref)
+			for s in ref["sentence"]:
+				repeated += len(set(ids[off[s]:off[s + 1]].tolist())) < int(off[s + 1] - off[s])
+	assert repeated > 50   # the winners did hold repeated words
 	c.close()
 
 

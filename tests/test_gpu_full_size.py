@@ -2,7 +2,9 @@
 through properties that do not need the oracle to score a million sentences:
   * a sample of 3,000 sentences (their vectors are kept on the host while the shard is generated on the device) scores
     exactly as the oracle scores them;
-  * the returned top-k equals the top-k of the full score vector under the result order (score desc, sentence desc);
+  * the returned top-k equals the top-k of the full score vector under the result order (score desc, sentence desc) up to the
+    rounding between the scoring pass and the winners' canonical restatement, and every winner is bit-exact against the oracle
+    on its regenerated vectors (score and traceback);
   * planted copies of the query come out first with score ~ 1 and the identity traceback;
   * the same query twice gives the same bytes; a boost of c scales every score by c;
   * two half shards merged (vk_merge_topk with offsets) give the result of the whole;
@@ -26,6 +28,37 @@ N_SENT, LEN_S, D, LEN_T, V = 1_000_000, 32, 300, 10, 50_000
 EXP5 = ("table", (1 - 2.0 ** (-np.arange(0, 65) / 5)).astype(np.float32))
 
 
+CHUNK_S = 1 << 15                                       # sentences per generator chunk
+
+
+def chunk_vectors(torch, E_dev, ids, a, b, planted):
+	"""fp32 vectors of sentences [a, b) (a a multiple of CHUNK_S): seeded per chunk, the same on every call"""
+	device = E_dev.device
+	gen = torch.Generator(device=device)
+	gen.manual_seed(77 + a)                             # per chunk: the same vectors whatever the shard bounds (multiples of the chunk)
+	idx = torch.from_numpy(ids[a * LEN_S:b * LEN_S].astype(np.int64)).to(device)
+	x = E_dev[idx] + 0.1 * torch.randn(((b - a) * LEN_S, D), device=device, generator=gen, dtype=torch.float32)
+	for s, qv in planted.items():                       # exact copies of the query inside chosen sentences
+		if a <= s < b:
+			x[(s - a) * LEN_S + 5:(s - a) * LEN_S + 5 + LEN_T] = torch.from_numpy(qv).to(device)
+	return x.contiguous()
+
+
+def regenerate(torch, E, ids, sentences, planted, n_total):
+	"""fp32 vectors of the given sentences, from the generator (one chunk at a time)"""
+	E_dev = torch.from_numpy(E).to(torch.device("cuda", 0))
+	out = {}
+	for a in sorted({int(s) // CHUNK_S * CHUNK_S for s in sentences}):
+		x = chunk_vectors(torch, E_dev, ids, a, min(a + CHUNK_S, n_total), planted)
+		for s in sentences:
+			if a <= int(s) < a + CHUNK_S:
+				out[int(s)] = x[(int(s) - a) * LEN_S:(int(s) - a + 1) * LEN_S].cpu().numpy()
+		del x
+	del E_dev
+	torch.cuda.empty_cache()
+	return out
+
+
 def build(hip, torch, ids, E, lo, hi, sample, planted):
 	"""sentences [lo, hi) of the synthetic corpus as one device corpus; returns it and the fp32 vectors of `sample`"""
 	device = torch.device("cuda", 0)
@@ -33,27 +66,49 @@ def build(hip, torch, ids, E, lo, hi, sample, planted):
 	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=D, n_tokens=n_tok, n_sentences=hi - lo)
 	E_dev = torch.from_numpy(E).to(device)
 	kept = {}
-	chunk_s = 1 << 15                                   # sentences per chunk
-	for a in range(lo, hi, chunk_s):
-		b = min(a + chunk_s, hi)
-		gen = torch.Generator(device=device)
-		gen.manual_seed(77 + a)                         # per chunk: the same vectors whatever the shard bounds (multiples of the chunk)
-		idx = torch.from_numpy(ids[a * LEN_S:b * LEN_S].astype(np.int64)).to(device)
-		x = E_dev[idx] + 0.1 * torch.randn(((b - a) * LEN_S, D), device=device, generator=gen, dtype=torch.float32)
-		for s, qv in planted.items():                   # exact copies of the query inside chosen sentences
-			if a <= s < b:
-				x[(s - a) * LEN_S + 5:(s - a) * LEN_S + 5 + LEN_T] = torch.from_numpy(qv).to(device)
-		x = x.contiguous()
+	for a in range(lo, hi, CHUNK_S):
+		b = min(a + CHUNK_S, hi)
+		x = chunk_vectors(torch, E_dev, ids, a, b, planted)
 		for s in sample[(sample >= a) & (sample < b)]:
 			kept[int(s)] = x[(s - a) * LEN_S:(s - a + 1) * LEN_S].cpu().numpy()
 		torch.cuda.synchronize()
 		c.append_vectors_device(x.data_ptr(), x.shape[0], hip.VK_F32, normalize=True)
-		del x, idx
+		del x
 	c.set_sentences(np.arange(hi - lo + 1, dtype=np.int64) * LEN_S)
 	c.finalize()
 	del E_dev
 	torch.cuda.empty_cache()
 	return c, kept
+
+
+def check_selection(top, scores, k):
+	"""The result set against the score vector of ALL slices.  The vector holds the scoring pass's values (MFMA cosines); the
+	winners' scores are restated in the oracle's arithmetic (sim_canon) and a few runners-up with them, so the two differ by
+	rounding (<= 4e-6): the winners are in result order, each within rounding of its entry in the vector, and no slice
+	outside the result set scores above the k-th winner by more than rounding."""
+	n = top.n
+	sent, sc = top.sentence[:n].astype(np.int64), top.score[:n]
+	assert len(set(sent.tolist())) == n
+	np.testing.assert_allclose(sc, scores[sent], atol=4e-6, rtol=0)
+	for i in range(n - 1):
+		assert sc[i] > sc[i + 1] or (sc[i] == sc[i + 1] and sent[i] > sent[i + 1])
+	if n == k:
+		rest = scores.copy()
+		rest[sent] = -np.inf
+		assert rest.max() <= sc[n - 1] + 4e-6
+
+
+def check_winners_exact(oracle, top, vectors, qv, **kw):
+	"""every winner alone against the oracle on its regenerated vectors: score and traceback bit for bit"""
+	Qb, _ = oracle.normalize_rows_bf16(qv)
+	for i in range(top.n):
+		xv = vectors[int(top.sentence[i])]
+		xb, _ = oracle.normalize_rows_bf16(xv)
+		one = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=xv.shape[1], sent_off=np.array([0, len(xv)], dtype=np.int64), X=xb, Q=Qb,
+			max_matches=1, **kw)
+		assert len(one["score"]) == 1
+		assert np.float32(one["score"][0]).view(np.uint32) == np.float32(top.score[i]).view(np.uint32), (i, one["score"][0], top.score[i])
+		assert list(one["mapping"][0]) == list(top.mapping[i])
 
 
 def test_config2_full_size_properties(hip, oracle):
@@ -80,10 +135,11 @@ def test_config2_full_size_properties(hip, oracle):
 		locality=0, gap_s=EXP5, gap_t=EXP5, max_matches=10, min_score=0.0, want_all_scores=True, n_threads=8)
 	np.testing.assert_allclose(scores[sample], ref["all_scores"], atol=1e-4, rtol=0)
 
-	# (2) selection: top-k of the full score vector under (score desc, sentence desc)
-	order = np.lexsort((-np.arange(N_SENT), -scores.astype(np.float64)))[:10]
-	assert list(top.sentence[:top.n]) == list(order)
-	np.testing.assert_array_equal(top.score[:top.n], scores[order])
+	# (2) selection: top-k of the full score vector under (score desc, sentence desc), up to the rounding between the scoring
+	# pass and the canonical restatement of the winners; (2b) every winner bit-exact against the oracle on its regenerated vectors
+	check_selection(top, scores, 10)
+	check_winners_exact(oracle, top, regenerate(torch, E, ids, top.sentence[:top.n], planted, N_SENT), qv,
+		locality=0, gap_s=EXP5, gap_t=EXP5, min_score=-1.0)
 
 	# (3) planted copies first, score ~ 1, identity traceback at offset 5
 	assert set(top.sentence[:3]) == set(planted)
@@ -110,9 +166,7 @@ def test_config2_full_size_properties(hip, oracle):
 		refl = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=D, sent_off=np.arange(len(sample) + 1, dtype=np.int64) * LEN_S, X=Xb, Q=Ql,
 			locality=0, gap_s=gaps[0], gap_t=gaps[1], max_matches=10, min_score=0.0, want_all_scores=True, n_threads=8)
 		np.testing.assert_allclose(sl[sample], refl["all_scores"], atol=1e-4, rtol=0)
-		orderl = np.lexsort((-np.arange(N_SENT), -sl.astype(np.float64)))[:10]
-		assert list(topl.sentence[:topl.n]) == list(orderl)
-		np.testing.assert_array_equal(topl.score[:topl.n], sl[orderl])
+		check_selection(topl, sl, 10)
 	c.close()
 
 	# (5) two half shards merged == the whole
@@ -159,9 +213,9 @@ def test_config3_and_config4_full_size_properties(hip, oracle):
 	ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=D, sent_off=soff, X=Xb, Q=Qb, locality=1, gap_s=0.1, gap_t=0.1,
 		max_matches=10, min_score=-1e9, want_all_scores=True, n_threads=8)
 	np.testing.assert_allclose(scores[sample], ref["all_scores"], atol=1e-4, rtol=0)
-	order = np.lexsort((-np.arange(n3), -scores.astype(np.float64)))[:10]
-	assert list(top.sentence[:top.n]) == list(order)
-	np.testing.assert_array_equal(top.score[:top.n], scores[order])
+	check_selection(top, scores, 10)
+	check_winners_exact(oracle, top, regenerate(torch, E, ids, top.sentence[:top.n], planted, n3), qv,
+		locality=1, gap_s=0.1, gap_t=0.1, min_score=-1e9)
 	assert set(top.sentence[:2]) == set(planted)
 	for i in range(2):                                   # the copy sits at tokens 5..14: the ten matches, 22 skipped tokens
 		assert list(top.mapping[i]) == list(range(5, 5 + LEN_T))
@@ -255,8 +309,9 @@ def test_config5_full_size_properties(hip, oracle):
 	ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=soff, X=Xb, Q=Qb, locality=0, gap_s=EXP5, gap_t=EXP5,
 		max_matches=10, min_score=0.0, want_all_scores=True, n_threads=8)
 	np.testing.assert_allclose(scores[sample], ref["all_scores"], atol=1e-4, rtol=0)
-	order = np.lexsort((-np.arange(n), -scores.astype(np.float64)))[:10]
-	assert list(top.sentence[:top.n]) == list(order)
+	check_selection(top, scores, 10)
+	check_winners_exact(oracle, top, {int(s_): sentence_vectors(int(s_)) for s_ in top.sentence[:top.n]}, qv,
+		locality=0, gap_s=EXP5, gap_t=EXP5, min_score=-1.0)
 	assert top.sentence[0] == src and list(top.mapping[0]) == list(range(1, 1 + len_t))
 
 	# ---- Word Rotator's Distance

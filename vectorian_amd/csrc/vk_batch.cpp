@@ -57,6 +57,7 @@ static int batch_winner_rows(vk_corpus *c, const vk_query_desc *qs, int n_querie
 	w.tiles = c->d_tiles; w.sent_start = c->d_sent_start; w.sent_end = c->d_sent_end;
 	w.layout = VK_DEV_LAYOUT_CONTEXTUAL; w.nk32 = c->nk32; w.tail = c->tail; w.tile_bytes = c->tile_bytes; w.prec = c->prec;
 	w.qtile = c->d_bqt; w.qtile_stride = c->tile_bytes; w.cand_query = c->d_bcandq; w.nq = 1; w.len_t = qs[0].len_t;
+	w.d = c->desc.d;   // canonical similarity rows (sim_canon)
 	w.keys = c->d_bcand; w.rows_out = c->d_brows;
 	VK_HIP(vk_launch_rows(&w, (int32_t)n_cand, st));
 	std::vector<float> rows(n_cand * 64 * 16);
@@ -221,6 +222,7 @@ static int query_batch_shared_pass(vk_corpus_t *c, const vk_query_desc *qs, int3
 				f.gap_mode = (p.gap_mode == 3 || p.gap_mode == 6) ? 2 : p.gap_mode; f.max_len = c->max_len;
 				f.gs = p.gs; f.gt = p.gt; f.a_s = p.a_s; f.a_t = p.a_t; f.open_s = p.open_s; f.open_t = p.open_t;
 				f.ws = c->d_ws; f.wt = c->d_wt;
+				f.d = c->desc.d;   // canonical similarity rows (sim_canon)
 				f.keys = c->d_bkeys[cur] + (size_t)i * stride;
 				f.raw_out = c->d_out_raw + (size_t)i * k; f.mapping = c->d_out_map + (size_t)i * k * 16; f.edge_sim = c->d_out_sim + (size_t)i * k * 16;
 				VK_HIP(vk_launch_flow(&f, k, st));
@@ -240,25 +242,45 @@ static int query_batch_shared_pass(vk_corpus_t *c, const vk_query_desc *qs, int3
 		for (int i = 0; i < qb; i++) {
 			const vk_query_desc &q = qs[base + i];
 			vk_topk_out *out = &outs[base + i];
-			int n_out = 0;
+			// winners of this query: position in the selection, score.  With traceback the score is restated from the canonical
+			// aligner score of the flow kernel (the oracle's, bit for bit) and the winners are put in that order (vk_query).
+			std::vector<int> order;
+			std::vector<float> val((size_t)k, 0.0f);
 			for (int j = 0; j < k; j++) {
 				const uint64_t key = keys[(size_t)i * k + j];
 				if (key == 0) break;
 				const uint32_t ob = (uint32_t)(key >> 32);
 				const uint32_t bits = (ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob;
-				float sc;
-				memcpy(&sc, &bits, 4);
+				memcpy(&val[(size_t)j], &bits, 4);
+				if (do_flow) {
+					float matched = 0.0f;
+					for (int t = 0; t < q.len_t; t++) matched += map[((size_t)i * k + j) * 16 + t] >= 0 ? 1.0f : 0.0f;
+					const float total = (float)q.len_t, uw = powf((total - matched) / total, 0.0f);
+					const float ref = matched + uw * (total - matched);
+					const float boost = q.boost ? q.boost[(int64_t)(uint32_t)(key & 0xffffffffu)] : 1.0f;
+					val[(size_t)j] = (raw[(size_t)i * k + j] / ref) * boost;
+					if (!(val[(size_t)j] > q.min_score)) continue;
+				}
+				order.push_back(j);
+			}
+			if (do_flow) std::sort(order.begin(), order.end(), [&](int a, int b2) {
+				if (val[(size_t)a] != val[(size_t)b2]) return val[(size_t)a] > val[(size_t)b2];
+				return (uint32_t)(keys[(size_t)i * k + a] & 0xffffffffu) > (uint32_t)(keys[(size_t)i * k + b2] & 0xffffffffu);
+			});
+			int n_out = 0;
+			for (const int j : order) {
+				const uint64_t key = keys[(size_t)i * k + j];
 				const int64_t g = (int64_t)(uint32_t)(key & 0xffffffffu);
-				out->score[j] = sc;
-				out->sentence[j] = g;
+				out->score[n_out] = val[(size_t)j];
+				out->sentence[n_out] = g;
 				if (out->raw_score) {
-					if (do_flow) out->raw_score[j] = raw[(size_t)i * k + j];
-					else VK_HIP(hipMemcpy(&out->raw_score[j], c->d_braw + (size_t)i * n + g, 4, hipMemcpyDeviceToHost));
+					if (do_flow) out->raw_score[n_out] = raw[(size_t)i * k + j];
+					else VK_HIP(hipMemcpy(&out->raw_score[n_out], c->d_braw + (size_t)i * n + g, 4, hipMemcpyDeviceToHost));
 				}
 				if (q.want_flow && out->mapping && out->edge_sim)
 					for (int t = 0; t < q.len_t; t++) {
-						out->mapping[(size_t)j * q.len_t + t] = do_flow ? map[((size_t)i * k + j) * 16 + t] : (int16_t)-1;
-						out->edge_sim[(size_t)j * q.len_t + t] = do_flow ? sim[((size_t)i * k + j) * 16 + t] : 0.0f;
+						out->mapping[(size_t)n_out * q.len_t + t] = do_flow ? map[((size_t)i * k + j) * 16 + t] : (int16_t)-1;
+						out->edge_sim[(size_t)n_out * q.len_t + t] = do_flow ? sim[((size_t)i * k + j) * 16 + t] : 0.0f;
 					}
 				n_out++;
 			}

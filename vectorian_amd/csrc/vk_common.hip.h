@@ -282,6 +282,102 @@ __device__ __forceinline__ f32x4 sim_tile_generic(const uint8_t *__restrict__ qt
 	return acc;
 }
 
+// ---------------------------------------------------------------------------
+// Canonical similarities: what the k winners' tracebacks, flows and exact transport plans are computed from.
+// The million-row scoring pass takes its cosines on MFMA (fp32 accumulation in the matrix pipe's own order); a traceback
+// that must equal the oracle's index for index cannot hang on the last bit of that sum (co-optimal alignments tie exactly
+// in real arithmetic when a word repeats, and the rounding of S then picks the path).  So everything that is computed for
+// the winners only restates the cosine in ONE arithmetic that the oracle shares bit for bit (oracle/vk_oracle.c dot_f32):
+// four partial sums over k mod 4 in double, k ascending, the d % 4 trailing features all into the first, then
+// (s0 + s1) + (s2 + s3) rounded to float once.  Products of two bf16 (or fp32) values are exact in double, so a fused
+// multiply-add and the oracle's multiply-then-add round identically.  Cost: k x |s| x |q| x d double FMAs, microseconds.
+// One lane computes NC consecutive query columns (c0 a multiple of NC <= 4, all inside one 16-row query tile) for row `row`
+// of the token tile; both tiles in operand order (bf16: DESIGN 3; fp32: block of 16 features, lane 16 g + i owns row i,
+// features 16 b + 4 s + g).
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
+
+__device__ __forceinline__ float tile_elem(const uint8_t *__restrict__ tile, int row, int k, int prec) {
+	if (prec) return *reinterpret_cast<const float *>(tile + (int64_t)(k >> 4) * 1024 + ((k & 3) * 16 + row) * 16 + ((k & 15) >> 2) * 4);
+	return bf16_bits_to_f32(*reinterpret_cast<const uint16_t *>(tile + (int64_t)(k >> 5) * 1024 + (((k & 31) >> 3) * 16 + row) * 16 + (k & 7) * 2));
+}
+
+template <int NC>
+__device__ __forceinline__ void sim_canon_cols(const uint8_t *__restrict__ tile, int row, const uint8_t *__restrict__ qtile, int c0,
+	int d, int prec, float *out) {
+	double acc[NC][4];
+#pragma unroll
+	for (int c = 0; c < NC; c++) { acc[c][0] = 0.0; acc[c][1] = 0.0; acc[c][2] = 0.0; acc[c][3] = 0.0; }
+	const int d4 = d & ~3;
+	int k0 = 0;
+	if (prec) {
+#pragma unroll 1
+		for (; k0 + 16 <= d4; k0 += 16) {
+			const int64_t off = (int64_t)(k0 >> 4) * 1024;
+#pragma unroll
+			for (int g = 0; g < 4; g++) {   // lane 16 g + i of the block: features k0 + 4 s + g, s = 0 .. 3 (k mod 4 = g, ascending in s)
+				const f32x4 x = *reinterpret_cast<const f32x4 *>(tile + off + (g * 16 + row) * 16);
+#pragma unroll
+				for (int c = 0; c < NC; c++) {
+					const f32x4 q = *reinterpret_cast<const f32x4 *>(qtile + off + (g * 16 + c0 + c) * 16);
+#pragma unroll
+					for (int s = 0; s < 4; s++) acc[c][g] = __builtin_fma((double)x[s], (double)q[s], acc[c][g]);
+				}
+			}
+		}
+	} else {
+#pragma unroll 1
+		for (; k0 + 8 <= d4; k0 += 8) {
+			const int64_t off = (int64_t)(k0 >> 5) * 1024 + ((k0 & 31) >> 3) * 256;
+			const bf16x8 x = *reinterpret_cast<const bf16x8 *>(tile + off + row * 16);
+#pragma unroll
+			for (int c = 0; c < NC; c++) {
+				const bf16x8 q = *reinterpret_cast<const bf16x8 *>(qtile + off + (c0 + c) * 16);
+#pragma unroll
+				for (int e = 0; e < 8; e++)
+					acc[c][e & 3] = __builtin_fma((double)bf16_bits_to_f32((uint16_t)x[e]), (double)bf16_bits_to_f32((uint16_t)q[e]), acc[c][e & 3]);
+			}
+		}
+	}
+#pragma unroll 1
+	for (int k = k0; k < d; k++) {   // what is left of the last chunk; features from d4 on all go to the first sum
+		const double xv = (double)tile_elem(tile, row, k, prec);
+#pragma unroll
+		for (int c = 0; c < NC; c++) {
+			const double p = xv * (double)tile_elem(qtile, c0 + c, k, prec);
+			const int a = k < d4 ? (k & 3) : 0;
+			acc[c][0] += a == 0 ? p : 0.0;
+			acc[c][1] += a == 1 ? p : 0.0;
+			acc[c][2] += a == 2 ? p : 0.0;
+			acc[c][3] += a == 3 ? p : 0.0;
+		}
+	}
+#pragma unroll
+	for (int c = 0; c < NC; c++) out[c] = (float)((acc[c][0] + acc[c][1]) + (acc[c][2] + acc[c][3]));
+}
+
+// (two columns at a time: eight double accumulators; the kernels that call this run beside the scoring kernel and must stay small)
+template <int NC>
+__device__ __forceinline__ void sim_canon(const uint8_t *__restrict__ tile, int row, const uint8_t *__restrict__ qtile, int c0,
+	int d, int prec, float (&out)[NC]) {
+	if constexpr (NC == 4) {
+		sim_canon_cols<2>(tile, row, qtile, c0, d, prec, out);
+		__builtin_amdgcn_sched_barrier(0);
+		sim_canon_cols<2>(tile, row, qtile, c0 + 2, d, prec, out + 2);
+	} else sim_canon_cols<NC>(tile, row, qtile, c0, d, prec, out);
+}
+
+// static layout: the cell of the per-query table (metric/static.cpp:9-78) for vocabulary entry `id` and query columns
+// c0 .. c0 + NC - 1 in the canonical arithmetic: cosine, then sim[id(t_j)][j] = 1 (:58-67), then the clip (:75)
+template <int NC>
+__device__ __forceinline__ void static_sim_canon(const uint8_t *__restrict__ etiles, int tile_bytes, int id, const uint8_t *__restrict__ qtiles,
+	int c0, int d, int prec, const int32_t *__restrict__ q_ids, float (&out)[NC]) {
+	sim_canon<NC>(etiles + (int64_t)(id >> 4) * tile_bytes, id & 15, qtiles + (int64_t)(c0 >> 4) * tile_bytes, c0 & 15, d, prec, out);
+#pragma unroll
+	for (int c = 0; c < NC; c++) out[c] = (q_ids && q_ids[c0 + c] == id) ? 1.0f : clip01(out[c]);
+}
+
 // TagWeightedSlice::similarity (vectorian/core/cpp/slice/static.h:237-264): S * weight(i, j) with
 // weight = t_pos_weights[j] * (pos_s != pos_t ? 1 - penalty : 1); values <= threshold become 0.
 __device__ __forceinline__ float tag_weighted(float s, float w, int pos_s, int pos_t, float keep, float thr) {
@@ -300,11 +396,14 @@ __device__ __forceinline__ float tag_weighted(float s, float w, int pos_s, int p
 // bow.h:150-176; spaCy's tag map) that is this cell's own cosine and POS penalty under the tag weight of a instead of b.
 // One slice, rows S[u * stride + j] already weighted; the NL lanes l = 0 .. NL - 1 share the rows.  Every lane finds the shared
 // query columns by itself (a bitmap of the query's ids keeps the scan to the few tokens that can match): no exchange.
-template <int NL>
+// CANON: the cell's cosine restated in the canonical arithmetic (the winners' and candidates' rows) instead of read from the table.
+template <int NL, bool CANON = false>
 __device__ __forceinline__ void static_vocab_fixup(float *__restrict__ S, int stride, int len_s, int len_t,
 	const int32_t *__restrict__ tok, const int8_t *__restrict__ tag, const int8_t *__restrict__ pos,
 	const float *__restrict__ table, int64_t table_stride, const uint32_t *__restrict__ bits, const int32_t *qkey,
-	const float *tw, const int32_t *tpos, float keep, float thr, int l) {
+	const float *tw, const int32_t *tpos, float keep, float thr, int l,
+	const uint8_t *__restrict__ etiles = nullptr, int tile_bytes = 0, const uint8_t *__restrict__ qtiles = nullptr, int d = 0, int prec = 0,
+	const int32_t *__restrict__ q_ids = nullptr) {
 	unsigned long long mask = 0;   // query columns whose key occurs in the slice
 	for (int u = 0; u < len_s; u++) {
 		const int id = tok[u];
@@ -322,7 +421,12 @@ __device__ __forceinline__ void static_vocab_fixup(float *__restrict__ S, int st
 		if (ft < 0) continue;
 		for (int j = 0; j < len_t; j++)
 			if (((mask >> j) & 1ull) && qkey[j] > key) {
-				const float raw = table[(int64_t)(j >> 4) * table_stride + (int64_t)id * 16 + (j & 15)];
+				float raw;
+				if constexpr (CANON) {
+					float v1[1];
+					static_sim_canon<1>(etiles, tile_bytes, id, qtiles, j, d, prec, q_ids, v1);
+					raw = v1[0];
+				} else raw = table[(int64_t)(j >> 4) * table_stride + (int64_t)id * 16 + (j & 15)];
 				S[u * stride + j] = tag_weighted(raw, tw[ft], pos[u], tpos[j], keep, thr);
 			}
 	}

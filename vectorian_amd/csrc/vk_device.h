@@ -141,6 +141,8 @@ struct VkWrdParams {
 	float *scores, *raw;       // vk_long_bound_kernel: per row of the slice table
 	float wrd_raw_total;       // > 0: magnitudes as they are, the query's total
 	int32_t wmd_bound;         // 0: WRD; 1: nbow; 2: bow (as VkWideParams)
+	int32_t d;                 // features per row (unpadded) and, static layout, the query's token ids: the similarity rows of candidates
+	const int32_t *q_ids;      // and winners are taken in the canonical arithmetic (sim_canon, vk_common.hip.h)
 	uint8_t *scratch;          // vk_wrd_exact_long_kernel, nq > 1: flows, costs and similarity rows of one candidate per workgroup
 	int64_t scratch_stride;
 	int32_t n_cand;
@@ -167,6 +169,8 @@ struct VkFlowParams {
 	float tw[VK_DEV_MAX_QUERY_LEN];
 	int32_t tpos[VK_DEV_MAX_QUERY_LEN];
 	float tw_keep, tw_threshold;
+	int32_t d;                 // features per row (unpadded): the canonical sums follow the oracle's k order (sim_canon)
+	const int32_t *q_ids;      // static layout: token ids of the query (-1: none), for sim[id(t_j)][j] = 1; null: no ids
 	const uint64_t *keys;      // winners, best first; 0 = empty slot
 	float *raw_out;            // [k]
 	int16_t *mapping;          // [k x 16]
@@ -239,6 +243,8 @@ struct VkWideParams {
 	const float *boost;
 	float *scores;
 	float *raw;
+	int32_t d;                 // FLOW: features per row (unpadded) and, static layout, the query's token ids (sim_canon)
+	const int32_t *q_ids;
 	const uint64_t *keys;      // FLOW: winners
 	float *raw_out;            // [k]
 	int16_t *mapping;          // [k x 64]

@@ -2,9 +2,12 @@
 #include "vk_common.hip.h"
 
 // ---------------------------------------------------------------------------
-// flow of the winners: one wave per winner recomputes the similarity rows with the
-// same MFMA sequence as the scoring kernel, then lane 0 runs the sequential DP with
-// traceback exactly as the oracle states it (vko_align in oracle/vk_oracle.c):
+// flow of the winners: one wave per winner restates the similarity rows in the canonical
+// arithmetic (sim_canon, vk_common.hip.h: the oracle's own sums, bit for bit -- the scoring
+// kernel's MFMA cosines differ from them in the last bit, which is enough to flip the
+// traceback between co-optimal alignments), then runs the sequential DP with traceback
+// exactly as the oracle states it (vko_align in oracle/vk_oracle.c): the aligner score,
+// the mapping and the edge similarities of a winner are the oracle's, bit for bit.
 // candidates zero (LOCAL), diagonal, gap in s (k = 1..), gap in t (k = 1..), replace
 // on strictly greater; start cell = first maximum in row-major order.
 // Output: mapping[j] = matched sentence token or -1 (InjectiveFlow,
@@ -24,7 +27,8 @@ static inline size_t vk_flow_lds_bytes(int max_len, bool tagged) {
 	return (b + 15) / 16 * 16;
 }
 
-__global__ __launch_bounds__(64) void vk_flow_kernel(VkFlowParams p) {
+// (five waves per SIMD asked of the register allocator: at most 96 VGPRs, so that the kernel runs beside the next query's scoring kernel)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void vk_flow_kernel(VkFlowParams p) {
 	extern __shared__ float4 vk_smem4[];
 	const int rows = p.max_len + 1, srows = p.max_len + 32;
 	float *S = reinterpret_cast<float *>(vk_smem4);
@@ -49,16 +53,15 @@ __global__ __launch_bounds__(64) void vk_flow_kernel(VkFlowParams p) {
 		for (int it = 0; it * 16 < len_s; it++) {
 			const int tk = it * 16 + (lane >> 2);
 			if (tk < len_s) {
-				const int id = p.tok_id[t_a + tk];
-				float4 val = *reinterpret_cast<const float4 *>(p.table + (int64_t)id * 16 + (lane & 3) * 4);
-				*reinterpret_cast<float4 *>(S + tk * 16 + (lane & 3) * 4) = val;
+				const int id = p.tok_id[t_a + tk], cb = (lane & 3) * 4;
+				float val[4];
+				static_sim_canon<4>(p.tiles, p.tile_bytes, id, p.qtile, cb, p.d, p.prec, p.q_ids, val);
+				*reinterpret_cast<float4 *>(S + tk * 16 + cb) = make_float4(val[0], val[1], val[2], val[3]);
 				if (p.pos_s) {
-					const int ps = p.pos_s[t_a + tk], cb = (lane & 3) * 4;
-					val.x = tag_weighted(val.x, p.tw[cb + 0], ps, p.tpos[cb + 0], p.tw_keep, p.tw_threshold);
-					val.y = tag_weighted(val.y, p.tw[cb + 1], ps, p.tpos[cb + 1], p.tw_keep, p.tw_threshold);
-					val.z = tag_weighted(val.z, p.tw[cb + 2], ps, p.tpos[cb + 2], p.tw_keep, p.tw_threshold);
-					val.w = tag_weighted(val.w, p.tw[cb + 3], ps, p.tpos[cb + 3], p.tw_keep, p.tw_threshold);
-					*reinterpret_cast<float4 *>(SW + tk * 16 + (lane & 3) * 4) = val;
+					const int ps = p.pos_s[t_a + tk];
+#pragma unroll
+					for (int r = 0; r < 4; r++) val[r] = tag_weighted(val[r], p.tw[cb + r], ps, p.tpos[cb + r], p.tw_keep, p.tw_threshold);
+					*reinterpret_cast<float4 *>(SW + tk * 16 + cb) = make_float4(val[0], val[1], val[2], val[3]);
 				}
 			}
 		}
@@ -67,13 +70,17 @@ __global__ __launch_bounds__(64) void vk_flow_kernel(VkFlowParams p) {
 		const int tile0 = t_a >> 4;
 		const int ntiles = ((t_b + 15) >> 4) - tile0;
 		for (int ti = 0; ti < ntiles; ti++) {
-			f32x4 acc = sim_tile_generic(p.qtile, p.tiles + (int64_t)(tile0 + ti) * p.tile_bytes, p.nk32, p.tail, lane, p.prec);
-			*reinterpret_cast<f32x4 *>(S + (ti * 16 + (lane & 15)) * 16 + (lane >> 4) * 4) = acc;
-			if (p.pos_s) {
-				const int ps = p.pos_s[(tile0 + ti) * 16 + (lane & 15)], cb = (lane >> 4) * 4;
+			const int cb = (lane >> 4) * 4;
+			float val[4];
+			sim_canon<4>(p.tiles + (int64_t)(tile0 + ti) * p.tile_bytes, lane & 15, p.qtile, cb, p.d, p.prec, val);
 #pragma unroll
-				for (int r = 0; r < 4; r++) acc[r] = tag_weighted(acc[r], p.tw[cb + r], ps, p.tpos[cb + r], p.tw_keep, p.tw_threshold);
-				*reinterpret_cast<f32x4 *>(SW + (ti * 16 + (lane & 15)) * 16 + (lane >> 4) * 4) = acc;
+			for (int r = 0; r < 4; r++) val[r] = clip01(val[r]);
+			*reinterpret_cast<float4 *>(S + (ti * 16 + (lane & 15)) * 16 + cb) = make_float4(val[0], val[1], val[2], val[3]);
+			if (p.pos_s) {
+				const int ps = p.pos_s[(tile0 + ti) * 16 + (lane & 15)];
+#pragma unroll
+				for (int r = 0; r < 4; r++) val[r] = tag_weighted(val[r], p.tw[cb + r], ps, p.tpos[cb + r], p.tw_keep, p.tw_threshold);
+				*reinterpret_cast<float4 *>(SW + (ti * 16 + (lane & 15)) * 16 + cb) = make_float4(val[0], val[1], val[2], val[3]);
 			}
 		}
 		rowbase = t_a - tile0 * 16;
@@ -306,7 +313,12 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 					const int tok = base + r;
 					if (tok < t_b && lane < LQ) {
 						const int id = p.tok_id[tok];
-						const float sv = p.table[(int64_t)(lane >> 4) * p.table_stride + (int64_t)id * 16 + (lane & 15)];
+						float sv;
+						if constexpr (FLOW) {   // winners: the canonical arithmetic (sim_canon), as vk_flow_kernel
+							float v1[1];
+							static_sim_canon<1>(p.tiles, p.tile_bytes, id, p.qtile, lane, p.d, p.prec, p.q_ids, v1);
+							sv = v1[0];
+						} else sv = p.table[(int64_t)(lane >> 4) * p.table_stride + (int64_t)id * 16 + (lane & 15)];
 						Sx[r * LQ + lane] = sv;
 						if (p.pos_s) {
 							float w = twl[lane];
@@ -323,7 +335,12 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 			} else {
 				const uint8_t *tp = p.tiles + (int64_t)(base >> 4) * p.tile_bytes;
 				for (int qt = 0; qt < p.nq; qt++) {
-					f32x4 acc = sim_tile_generic(p.qtile + (int64_t)qt * p.tile_bytes, tp, p.nk32, p.tail, lane, p.prec);
+					f32x4 acc;
+					if constexpr (FLOW) {
+						float val[4];
+						sim_canon<4>(tp, lane & 15, p.qtile + (int64_t)qt * p.tile_bytes, (lane >> 4) * 4, p.d, p.prec, val);
+						acc[0] = clip01(val[0]); acc[1] = clip01(val[1]); acc[2] = clip01(val[2]); acc[3] = clip01(val[3]);
+					} else acc = sim_tile_generic(p.qtile + (int64_t)qt * p.tile_bytes, tp, p.nk32, p.tail, lane, p.prec);
 					const int c0 = qt * 16 + (lane >> 4) * 4;
 					*reinterpret_cast<f32x4 *>(Sx + (lane & 15) * LQ + c0) = acc;
 					if (p.pos_s) {

@@ -125,6 +125,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		w.sent_start = c->d_sent_start; w.sent_end = c->d_sent_end;
 		w.layout = is_static_l ? VK_DEV_LAYOUT_STATIC : VK_DEV_LAYOUT_CONTEXTUAL; w.nk32 = c->nk32; w.tail = c->tail; w.tile_bytes = c->tile_bytes; w.prec = c->prec;
 		w.qtile = c->d_qtile; w.nq = (q->len_t + 15) / 16; w.len_t = q->len_t; w.mag = c->d_mag;
+		w.d = c->desc.d; w.q_ids = is_static_l ? c->d_qids : nullptr;   // canonical similarity rows (sim_canon)
 		w.ref_total = (float)q->len_t;
 		if (q->tag_weights) {
 			float total = 0.0f;
@@ -359,6 +360,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 			wp.tpos[j] = (p.pos_s && j < q->len_t) ? (int32_t)q->q_pos[j] : -1;
 		}
 		wp.boost = p.boost; wp.scores = c->d_scores; wp.raw = c->d_raw;
+		wp.d = c->desc.d; wp.q_ids = is_static ? c->d_qids : nullptr;   // FLOW: canonical similarity rows (sim_canon)
 		{   // as for the 16-column kernel: the aligner scores of all slices only if something reads them
 			const bool exact_tr2 = q->algorithm == VK_ALG_WRD || (q->algorithm == VK_ALG_RWMD && q->wmd_full);
 			if (((is_align && q->want_flow) || exact_tr2) && !(q->submatch_weight > 0.0f) && !getenv("VK_KEEP_RAW")) wp.raw = nullptr;
@@ -613,6 +615,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		f.pos_s = p.pos_s; f.tw_keep = p.tw_keep; f.tw_threshold = p.tw_threshold;
 		memcpy(f.tw, p.tw, sizeof f.tw);
 		memcpy(f.tpos, p.tpos, sizeof f.tpos);
+		f.d = c->desc.d; f.q_ids = is_static ? c->d_qids : nullptr;   // canonical similarity rows (sim_canon)
 		f.keys = d_keys; f.raw_out = c->d_out_raw; f.mapping = c->d_out_map; f.edge_sim = c->d_out_sim;
 		VK_HIP(vk_launch_flow(&f, count, st));
 		return VK_OK;
@@ -714,49 +717,88 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	VK_HIP(hipEventRecord(c->ev[2], st));
 	c->ev2_recorded = true;
 	const bool rows_on_request = out->sim_rows != nullptr;   // alignments: similarity rows of the winners only on request (debug hook)
+	// Alignments with traceback: the scores of the scoring pass rest on MFMA cosines and differ from the oracle's in the last
+	// bits; the flow kernel restates every winner in the canonical arithmetic (aligner score, mapping, edge similarities: the
+	// oracle's, bit for bit).  So that the result SET is the oracle's too, a few runners-up are retraced with the winners
+	// (kCanonMargin more slices; the floor of the selection is lowered by the rounding slack likewise) and the k best canonical
+	// scores are kept: exact unless more than kCanonMargin slices sit within rounding (~2e-6) of the k-th score.
+	const bool do_flow = q->want_flow && is_align;
+	constexpr int kCanonMargin = 8;
+	const int kk = !do_flow ? k : k <= 64 ? std::min(k + kCanonMargin, 64) : std::min(k + kCanonMargin, VK_MAX_MATCHES);
+	const float sel_floor = do_flow ? q->min_score - 1e-5f * std::max(1.0f, std::fabs(q->min_score)) : q->min_score;
 	int cur = 0;
-	if (k <= 64) {
+	if (kk <= 64) {
 		// wave-streaming selection: n -> ceil(n/4096) * k keys -> ... -> k keys
 		int64_t nw = 0;
-		VK_HIP(vk_launch_topk_wave(c->d_scores, nullptr, n, q->min_score, k, 4096, c->d_keys[0], &nw, st));
+		VK_HIP(vk_launch_topk_wave(c->d_scores, nullptr, n, sel_floor, kk, 4096, c->d_keys[0], &nw, st));
 		while (nw > 1) {
-			const int64_t nkeys = nw * k;
+			const int64_t nkeys = nw * kk;
 			const int64_t per_wave = nkeys <= 16384 ? nkeys : 4096;
-			VK_HIP(vk_launch_topk_wave(nullptr, c->d_keys[cur], nkeys, 0.0f, k, per_wave, c->d_keys[1 - cur], &nw, st));
+			VK_HIP(vk_launch_topk_wave(nullptr, c->d_keys[cur], nkeys, 0.0f, kk, per_wave, c->d_keys[1 - cur], &nw, st));
 			cur = 1 - cur;
 		}
 	} else {
 		int nb = 0;
-		VK_HIP(vk_launch_topk_scores(c->d_scores, n, q->min_score, k, c->d_keys[0], &nb, st));
+		VK_HIP(vk_launch_topk_scores(c->d_scores, n, sel_floor, kk, c->d_keys[0], &nb, st));
 		while (nb > 1) {
-			const int64_t nkeys = (int64_t)nb * k;
-			VK_HIP(vk_launch_topk_keys(c->d_keys[cur], nkeys, k, c->d_keys[1 - cur], &nb, st));
+			const int64_t nkeys = (int64_t)nb * kk;
+			VK_HIP(vk_launch_topk_keys(c->d_keys[cur], nkeys, kk, c->d_keys[1 - cur], &nb, st));
 			cur = 1 - cur;
 		}
 	}
 
 	// ---- flow of the winners ------------------------------------------------
 	VK_HIP(hipEventRecord(c->ev[3], st));
-	const bool do_flow = q->want_flow && is_align;
-	if (do_flow && (rc = launch_flow(c->d_keys[cur], k))) return rc;
+	if (do_flow && (rc = launch_flow(c->d_keys[cur], kk))) return rc;
 	VK_HIP(hipEventRecord(c->ev[4], st));
 
 	// ---- results to host ------------------------------------------------------
-	std::vector<uint64_t> keys((size_t)k);
-	std::vector<float> raw((size_t)k), sim((size_t)k * ostride);
-	std::vector<int16_t> map((size_t)k * ostride);
-	VK_HIP(hipMemcpyAsync(keys.data(), c->d_keys[cur], (size_t)k * 8, hipMemcpyDeviceToHost, st));
+	std::vector<uint64_t> keys((size_t)kk);
+	std::vector<float> raw((size_t)kk), sim((size_t)kk * ostride);
+	std::vector<int16_t> map((size_t)kk * ostride);
+	VK_HIP(hipMemcpyAsync(keys.data(), c->d_keys[cur], (size_t)kk * 8, hipMemcpyDeviceToHost, st));
 	if (do_flow) {
-		VK_HIP(hipMemcpyAsync(raw.data(), c->d_out_raw, (size_t)k * 4, hipMemcpyDeviceToHost, st));
+		VK_HIP(hipMemcpyAsync(raw.data(), c->d_out_raw, (size_t)kk * 4, hipMemcpyDeviceToHost, st));
 		VK_HIP(hipMemcpyAsync(map.data(), c->d_out_map, map.size() * 2, hipMemcpyDeviceToHost, st));
 		VK_HIP(hipMemcpyAsync(sim.data(), c->d_out_sim, sim.size() * 4, hipMemcpyDeviceToHost, st));
 	}
 	VK_HIP(hipStreamSynchronize(st));
 
-	int n_out = 0;
-	for (int i = 0; i < k; i++) {
+	int n_sel = 0;
+	for (int i = 0; i < kk; i++) {
 		if (keys[(size_t)i] == 0) break;
-		n_out++;
+		n_sel++;
+	}
+	// order[i]: position among the selected slices of the i-th result
+	std::vector<int> order((size_t)n_sel);
+	std::vector<float> val((size_t)std::max(n_sel, 1));
+	for (int i = 0; i < n_sel; i++) {
+		order[(size_t)i] = i;
+		const uint32_t ob = (uint32_t)(keys[(size_t)i] >> 32);
+		const uint32_t bits = (ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob;
+		memcpy(&val[(size_t)i], &bits, 4);
+	}
+	int n_out = n_sel;
+	if (do_flow) {
+		// Score of a winner from its canonical aligner score (match/match.h:295-307, reference_score metric/alignment.h:84-106),
+		// operation by operation as the oracle's vko_score: matched weight of this traceback, pow(., submatch_weight = 0) = 1
+		const float total = p.ref_total;
+		for (int i = 0; i < n_sel; i++) {
+			float matched = 0.0f;
+			for (int j = 0; j < q->len_t; j++)
+				if (map[(size_t)i * ostride + j] >= 0) matched += q->tag_weights ? q->tag_weights[j] : 1.0f;
+			const float uw = powf((total - matched) / total, 0.0f);
+			const float ref = matched + uw * (total - matched);
+			const int64_t row = (int64_t)(uint32_t)(keys[(size_t)i] & 0xffffffffu);
+			const float boost = q->boost ? q->boost[sentence_of(row)] : 1.0f;
+			val[(size_t)i] = (raw[(size_t)i] / ref) * boost;
+		}
+		order.erase(std::remove_if(order.begin(), order.end(), [&](int i) { return !(val[(size_t)i] > q->min_score); }), order.end());
+		std::sort(order.begin(), order.end(), [&](int a, int b) {   // the total order of the result set: score, then slice, descending
+			if (val[(size_t)a] != val[(size_t)b]) return val[(size_t)a] > val[(size_t)b];
+			return (uint32_t)(keys[(size_t)a] & 0xffffffffu) > (uint32_t)(keys[(size_t)b] & 0xffffffffu);
+		});
+		n_out = std::min((int)order.size(), k);
 	}
 	std::vector<float> raw_sel((size_t)std::max(n_out, 1));
 	if (!do_flow && out->raw_score && n_out > 0) {
@@ -768,18 +810,16 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		VK_HIP(hipStreamSynchronize(st));
 	}
 	for (int i = 0; i < n_out; i++) {
-		const uint64_t key = keys[(size_t)i];
-		const uint32_t ob = (uint32_t)(key >> 32);
-		const uint32_t bits = (ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob;
-		float s;
-		memcpy(&s, &bits, 4);
+		const int src = order[(size_t)i];
+		const uint64_t key = keys[(size_t)src];
+		const float s = val[(size_t)src];
 		out->score[i] = s;
 		out->sentence[i] = sentence_of((int64_t)(uint32_t)(key & 0xffffffffu));
-		if (out->raw_score) out->raw_score[i] = do_flow ? raw[(size_t)i] : span_skip_raw ? s : raw_sel[(size_t)i];
+		if (out->raw_score) out->raw_score[i] = do_flow ? raw[(size_t)src] : span_skip_raw ? s : raw_sel[(size_t)i];
 		if (do_flow) {
 			for (int j = 0; j < q->len_t; j++) {
-				out->mapping[(size_t)i * q->len_t + j] = map[(size_t)i * ostride + j];
-				out->edge_sim[(size_t)i * q->len_t + j] = sim[(size_t)i * ostride + j];
+				out->mapping[(size_t)i * q->len_t + j] = map[(size_t)src * ostride + j];
+				out->edge_sim[(size_t)i * q->len_t + j] = sim[(size_t)src * ostride + j];
 			}
 		} else if (q->want_flow && out->mapping && out->edge_sim) {
 			// transport flows of the winners (SparseFlow / DenseFlow) are not produced yet
@@ -793,7 +833,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	c->have_scores = true;
 	if ((q->algorithm == VK_ALG_RWMD || (is_align && rows_on_request)) && n_out > 0) {
 		std::vector<int64_t> rows_idx;
-		for (int i = 0; i < n_out; i++) rows_idx.push_back((int64_t)(uint32_t)(keys[(size_t)i] & 0xffffffffu));
+		for (int i = 0; i < n_out; i++) rows_idx.push_back((int64_t)(uint32_t)(keys[(size_t)order[(size_t)i]] & 0xffffffffu));
 		float no_mass[VK_MAX_QUERY_LEN] = {0};
 		if ((rc = transport_flows(rows_idx, false, no_mass, 0, 0))) return rc;
 	}

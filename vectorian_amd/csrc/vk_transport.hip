@@ -3,7 +3,7 @@
 
 // ---------------------------------------------------------------------------
 // Word Rotator's Distance / full WMD, stage 2: exact EMD for the candidate slices.
-// One wave per candidate recomputes the similarity rows (same MFMA sequence as the scoring kernel) and
+// One wave per candidate restates the similarity rows (canonical arithmetic, transport_sim_rows) and
 // solves the transportation problem (n <= 16 query tokens = supplies, m <= 64 slice tokens = demands) by
 // successive shortest paths with potentials in double precision -- the algorithm of the oracle's vko_emd
 // (oracle/vk_oracle.c), which stands in for pyemd's emd_hat_gd_metric<double>
@@ -57,7 +57,10 @@ __device__ __forceinline__ double wave_argmin_f64(double x, int lane, int &at) {
 // similarity rows of one slice against the nq query tiles -> S[row][16 nq] (row 0 = first token of the slice's first tile or,
 // static layout, of the slice); returns the row of the slice's first token.  Tag-weighted modifier applied when p.pos_s.
 // (STRIDE: floats per row of S, at least 16 NQ.)
-template <int NQ, int STRIDE = 16 * NQ>
+// CANON: the canonical arithmetic (sim_canon, vk_common.hip.h: the oracle's own sums) -- candidates of the exact solvers and
+// winners' rows, whose costs, plans and flows then rest on the same similarities as the oracle's, bit for bit; the bound pass
+// over all long slices (vk_long_bound_kernel) keeps the MFMA form.
+template <int NQ, int STRIDE = 16 * NQ, bool CANON = true>
 __device__ __forceinline__ int transport_sim_rows(const VkWrdParams &p, float *S, int t_a, int t_b, int lane) {
 	constexpr int N = STRIDE;
 	const int m = t_b - t_a;
@@ -69,22 +72,27 @@ __device__ __forceinline__ int transport_sim_rows(const VkWrdParams &p, float *S
 				const int ps = p.pos_s ? p.pos_s[t_a + tk] : 0;
 #pragma unroll
 				for (int b = 0; b < NQ; b++) {
-					float4 vq = *reinterpret_cast<const float4 *>(p.table + b * p.table_stride + (int64_t)id * 16 + (lane & 3) * 4);
+					const int c0 = 16 * b + (lane & 3) * 4;
+					float4 vq;
+					if constexpr (CANON) {
+						float val[4];
+						static_sim_canon<4>(p.tiles, p.tile_bytes, id, p.qtile, c0, p.d, p.prec, p.q_ids, val);
+						vq = make_float4(val[0], val[1], val[2], val[3]);
+					} else vq = *reinterpret_cast<const float4 *>(p.table + b * p.table_stride + (int64_t)id * 16 + (lane & 3) * 4);
 					if (p.pos_s) {
-						const int c0 = 16 * b + (lane & 3) * 4;
 						vq.x = tag_weighted(vq.x, p.tw[c0 + 0], ps, p.tpos[c0 + 0], p.tw_keep, p.tw_threshold);
 						vq.y = tag_weighted(vq.y, p.tw[c0 + 1], ps, p.tpos[c0 + 1], p.tw_keep, p.tw_threshold);
 						vq.z = tag_weighted(vq.z, p.tw[c0 + 2], ps, p.tpos[c0 + 2], p.tw_keep, p.tw_threshold);
 						vq.w = tag_weighted(vq.w, p.tw[c0 + 3], ps, p.tpos[c0 + 3], p.tw_keep, p.tw_threshold);
 					}
-					*reinterpret_cast<float4 *>(S + tk * N + 16 * b + (lane & 3) * 4) = vq;
+					*reinterpret_cast<float4 *>(S + tk * N + c0) = vq;
 				}
 			}
 		}
 		if (p.qid_bits && p.pos_s) {   // tag-weighted vocabulary transport: cells upstream writes twice (static_vocab_fixup, vk_common.hip.h)
 			wave_lds_fence();
-			static_vocab_fixup<64>(S, N, m, p.len_t, p.tok_id + t_a, p.tag_s + t_a, p.pos_s + t_a, p.table, p.table_stride,
-				p.qid_bits, p.qkey, p.tw, p.tpos, p.tw_keep, p.tw_threshold, lane);
+			static_vocab_fixup<64, CANON>(S, N, m, p.len_t, p.tok_id + t_a, p.tag_s + t_a, p.pos_s + t_a, p.table, p.table_stride,
+				p.qid_bits, p.qkey, p.tw, p.tpos, p.tw_keep, p.tw_threshold, lane, p.tiles, p.tile_bytes, p.qtile, p.d, p.prec, p.q_ids);
 		}
 		return 0;
 	}
@@ -94,7 +102,12 @@ __device__ __forceinline__ int transport_sim_rows(const VkWrdParams &p, float *S
 		const int ps = p.pos_s ? p.pos_s[(tile0 + ti) * 16 + (lane & 15)] : 0;
 #pragma unroll
 		for (int b = 0; b < NQ; b++) {
-			f32x4 acc = sim_tile_generic(p.qtile + (int64_t)b * p.tile_bytes, p.tiles + (int64_t)(tile0 + ti) * p.tile_bytes, p.nk32, p.tail, lane, p.prec);
+			f32x4 acc;
+			if constexpr (CANON) {
+				float val[4];
+				sim_canon<4>(p.tiles + (int64_t)(tile0 + ti) * p.tile_bytes, lane & 15, p.qtile + (int64_t)b * p.tile_bytes, (lane >> 4) * 4, p.d, p.prec, val);
+				acc[0] = clip01(val[0]); acc[1] = clip01(val[1]); acc[2] = clip01(val[2]); acc[3] = clip01(val[3]);
+			} else acc = sim_tile_generic(p.qtile + (int64_t)b * p.tile_bytes, p.tiles + (int64_t)(tile0 + ti) * p.tile_bytes, p.nk32, p.tail, lane, p.prec);
 			if (p.pos_s) {
 				const int c0 = 16 * b + (lane >> 4) * 4;
 #pragma unroll
@@ -590,7 +603,7 @@ __global__ __launch_bounds__(64) void vk_long_bound_kernel(VkWrdParams p) {
 			if (lane == 0) { p.scores[row] = VK_NEG_INF; p.raw[row] = VK_NEG_INF; }
 			continue;
 		}
-		const int rowbase = p.nq == 2 ? transport_sim_rows<2, N>(p, S, t_a, t_b, lane) : p.nq == 3 ? transport_sim_rows<3, N>(p, S, t_a, t_b, lane) : transport_sim_rows<4, N>(p, S, t_a, t_b, lane);
+		const int rowbase = p.nq == 2 ? transport_sim_rows<2, N, false>(p, S, t_a, t_b, lane) : p.nq == 3 ? transport_sim_rows<3, N, false>(p, S, t_a, t_b, lane) : transport_sim_rows<4, N, false>(p, S, t_a, t_b, lane);
 		wave_lds_fence();
 		const float *Sm = S + rowbase * N;
 		const bool by_id = p.layout == VK_DEV_LAYOUT_STATIC;
