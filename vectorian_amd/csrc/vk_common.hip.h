@@ -303,6 +303,12 @@ __device__ __forceinline__ float tile_elem(const uint8_t *__restrict__ tile, int
 	return bf16_bits_to_f32(*reinterpret_cast<const uint16_t *>(tile + (int64_t)(k >> 5) * 1024 + (((k & 31) >> 3) * 16 + row) * 16 + (k & 7) * 2));
 }
 
+// element k of a row given by the address of its first 16 bytes in block 0 (canon_row_ptr)
+__device__ __forceinline__ float row_elem(const uint8_t *__restrict__ rowp, int k, int prec) {
+	if (prec) return *reinterpret_cast<const float *>(rowp + (int64_t)(k >> 4) * 1024 + (k & 3) * 256 + ((k & 15) >> 2) * 4);
+	return bf16_bits_to_f32(*reinterpret_cast<const uint16_t *>(rowp + (int64_t)(k >> 5) * 1024 + ((k & 31) >> 3) * 256 + (k & 7) * 2));
+}
+
 template <int NC>
 __device__ __forceinline__ void sim_canon_cols(const uint8_t *__restrict__ tile, int row, const uint8_t *__restrict__ qtile, int c0,
 	int d, int prec, float *out) {
@@ -366,6 +372,103 @@ __device__ __forceinline__ void sim_canon(const uint8_t *__restrict__ tile, int 
 		__builtin_amdgcn_sched_barrier(0);
 		sim_canon_cols<2>(tile, row, qtile, c0 + 2, d, prec, out + 2);
 	} else sim_canon_cols<NC>(tile, row, qtile, c0, d, prec, out);
+}
+
+// The same sums for a whole 16 x 16 block of similarities, one wave: rows = 16 token rows (lane l's row l & 15 given by its own
+// pointer `xrow` -- the address of the row's first 16 bytes in block 0: a tile row of the contextual layout, or a gathered
+// vocabulary row of the static one), columns = the 16 rows of a query tile.  Blocks of both sides are staged through LDS
+// VK_CANON_RB KiB at a time with the coalesced loads of the scoring kernel, all of a round in flight together (the direct form above
+// waits out one memory round trip per 16 bytes: 1.4 ms per query for the winners of config 2 beside a busy scoring kernel, this
+// form 0.2 ms); every lane then reads its row's chunks and its four columns' from LDS.  out[r]: row l & 15 x column 4 (l >> 4) + r,
+// unclipped.  nblk: 1 KiB blocks of a tile (bf16: K-steps of 32 features, the last one a half block when `half`; fp32: blocks of 16).
+// `lds`: VK_CANON_LDS bytes private to the wave.
+#define VK_CANON_RB 4
+#define VK_CANON_LDS (2 * VK_CANON_RB * 1024)
+typedef __attribute__((address_space(3))) void *vk_lds_ptr;
+typedef __attribute__((address_space(1))) const void *vk_glb_ptr;
+
+template <int NC>
+__device__ __forceinline__ void sim_canon16_cols(const uint8_t *__restrict__ xrow, const uint8_t *__restrict__ qtile, int nblk, int half,
+	int d, int prec, uint8_t *__restrict__ lds, int lane, int c0, float *out) {
+	double acc[NC][4];
+#pragma unroll
+	for (int c = 0; c < NC; c++) { acc[c][0] = 0.0; acc[c][1] = 0.0; acc[c][2] = 0.0; acc[c][3] = 0.0; }
+	const int d4 = d & ~3;
+	const int lim = d4;   // features below it take the sums k mod 4 (from d on the rows hold zeros: d4 bounds the copies in a half block too)
+	const int row = lane & 15, g_l = lane >> 4;
+	uint8_t *Xl = lds, *Ql = lds + VK_CANON_RB * 1024;
+#pragma unroll 1
+	for (int t0 = 0; t0 < nblk; t0 += VK_CANON_RB) {
+		const int nb = nblk - t0 < VK_CANON_RB ? nblk - t0 : VK_CANON_RB;
+#pragma unroll
+		for (int i = 0; i < VK_CANON_RB; i++) {
+			// LDS-DMA (global_load_lds_dwordx4: per-lane source, lane l lands at base + 16 l): no staging registers -- the callers run
+			// beside the scoring kernel and must stay under 96 VGPRs.  Addresses clamped to the last block (no loads under branches);
+			// a half block holds chunks 0 and 1 only: lanes of chunks 2, 3 fetch those again, their LDS slots are zeroed below.
+			const int t = t0 + i < nblk ? t0 + i : nblk - 1;
+			const int gl = (half && t == nblk - 1) ? (g_l & 1) : g_l;
+			__builtin_amdgcn_global_load_lds((vk_glb_ptr)(xrow + (int64_t)t * 1024 + gl * 256), (vk_lds_ptr)(Xl + i * 1024), 16, 0, 0);
+			__builtin_amdgcn_global_load_lds((vk_glb_ptr)(qtile + (int64_t)t * 1024 + (gl * 16 + row) * 16), (vk_lds_ptr)(Ql + i * 1024), 16, 0, 0);
+		}
+		__builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): an LDS-DMA is a pending LDS write on the VM counter
+		wave_lds_fence();
+		// Rolled loops on purpose (one 16-byte chunk of the row against the NC columns per trip): unrolled, the compiler widens the
+		// chunks of a whole block to double before the first multiply (64 more registers).  Features from `lim` on (the d % 4
+		// trailing ones, which belong to the first sum) are zeroed here and added after the loop.
+		if (prec) {
+#pragma unroll 1
+			for (int is = 0; is < nb * 4; is++) {   // block i, element s of the lanes' float4: features kb + 4 s + g (k mod 4 = g), s ascending
+				const int i = is >> 2, sidx = is & 3, kb = (t0 + i) * 16;
+				const bool live = kb + 4 * sidx < lim;
+#pragma unroll
+				for (int g = 0; g < 4; g++) {
+					float x = *reinterpret_cast<const float *>(Xl + i * 1024 + (g * 16 + row) * 16 + sidx * 4);
+					x = live ? x : 0.0f;
+#pragma unroll
+					for (int c = 0; c < NC; c++)
+						acc[c][g] = __builtin_fma((double)x, (double)*reinterpret_cast<const float *>(Ql + i * 1024 + (g * 16 + c0 + c) * 16 + sidx * 4), acc[c][g]);
+					__builtin_amdgcn_sched_barrier(0);
+				}
+			}
+		} else {
+#pragma unroll 1
+			for (int ig = 0; ig < nb * 8; ig++) {   // half a 16-byte chunk per trip: features k0 .. k0 + 3 (k mod 4 = e)
+				const int i = ig >> 3, g = (ig >> 1) & 3, hh = ig & 1;
+				const int k0 = (t0 + i) * 32 + g * 8 + hh * 4;   // (chunks 2, 3 of a half block hold copies of chunks 0, 1: k0 >= d_pad >= lim zeroes them)
+				const bf16x4 xb = *reinterpret_cast<const bf16x4 *>(Xl + i * 1024 + (g * 16 + row) * 16 + hh * 8);
+				float xf[4];
+#pragma unroll
+				for (int e = 0; e < 4; e++) xf[e] = k0 < lim ? bf16_bits_to_f32((uint16_t)xb[e]) : 0.0f;   // lim is a multiple of 4
+#pragma unroll
+				for (int c = 0; c < NC; c++) {
+					const bf16x4 q = *reinterpret_cast<const bf16x4 *>(Ql + i * 1024 + (g * 16 + c0 + c) * 16 + hh * 8);
+#pragma unroll
+					for (int e = 0; e < 4; e++)
+						acc[c][e] = __builtin_fma((double)xf[e], (double)bf16_bits_to_f32((uint16_t)q[e]), acc[c][e]);
+				}
+			}
+		}
+		wave_lds_fence();
+	}
+#pragma unroll 1
+	for (int k = d4; k < d; k++) {   // the d % 4 trailing features, in k order, into the first sum (oracle: `for (; k < d; k++) s0 += ..`)
+		const double xv = (double)row_elem(xrow, k, prec);
+#pragma unroll
+		for (int c = 0; c < NC; c++) acc[c][0] += xv * (double)row_elem(qtile + (c0 + c) * 16, k, prec);
+	}
+#pragma unroll
+	for (int c = 0; c < NC; c++) out[c] = (float)((acc[c][0] + acc[c][1]) + (acc[c][2] + acc[c][3]));
+}
+
+__device__ __forceinline__ void sim_canon16(const uint8_t *__restrict__ xrow, const uint8_t *__restrict__ qtile, int nblk, int half,
+	int d, int prec, uint8_t *__restrict__ lds, int lane, float (&out)[4]) {
+	sim_canon16_cols<4>(xrow, qtile, nblk, half, d, prec, lds, lane, (lane >> 4) * 4, out);
+}
+
+// this lane's row pointer for sim_canon16: row (lane & 15) of a contextual tile, or vocabulary entry `id` of the static layout
+__device__ __forceinline__ const uint8_t *canon_row_ptr(const uint8_t *__restrict__ tile, int lane) { return tile + (lane & 15) * 16; }
+__device__ __forceinline__ const uint8_t *canon_row_ptr_static(const uint8_t *__restrict__ etiles, int tile_bytes, int id) {
+	return etiles + (int64_t)(id >> 4) * tile_bytes + (id & 15) * 16;
 }
 
 // static layout: the cell of the per-query table (metric/static.cpp:9-78) for vocabulary entry `id` and query columns

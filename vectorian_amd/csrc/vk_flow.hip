@@ -19,7 +19,8 @@
 // dynamic LDS of vk_flow_kernel for slices of at most max_len tokens (bytes); the carve-up below must match
 static inline size_t vk_flow_lds_bytes(int max_len, bool tagged) {
 	const size_t rows = (size_t)max_len + 1, srows = (size_t)max_len + 32;
-	size_t b = srows * 16 * 4 * (tagged ? 2 : 1);      // S (+ SW)
+	size_t b = VK_CANON_LDS;                           // staging of sim_canon16
+	b += srows * 16 * 4 * (tagged ? 2 : 1);            // S (+ SW)
 	b += rows * VK_TB_W * 4;                           // H
 	b += (rows + 3) / 4 * 4 * 4 + 32 * 4;              // wsl, wtl
 	b += rows * VK_TB_W * 2;                           // dk
@@ -27,11 +28,15 @@ static inline size_t vk_flow_lds_bytes(int max_len, bool tagged) {
 	return (b + 15) / 16 * 16;
 }
 
-// (five waves per SIMD asked of the register allocator: at most 96 VGPRs, so that the kernel runs beside the next query's scoring kernel)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void vk_flow_kernel(VkFlowParams p) {
+// PREC: bf16 / fp32 rows at compile time -- the kernel has to fit into the registers the next query's scoring kernel leaves free
+// (three waves per SIMD of 136 VGPRs leave 104; the fp32 scoring kernel's 126 leave 134): 64 VGPRs for bf16 rows, the fp32 form
+// likewise (five waves per SIMD asked of the register allocator: at most 96).
+template <int PREC>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void vk_flow_kernel(VkFlowParams p) {
 	extern __shared__ float4 vk_smem4[];
 	const int rows = p.max_len + 1, srows = p.max_len + 32;
-	float *S = reinterpret_cast<float *>(vk_smem4);
+	uint8_t *canon = reinterpret_cast<uint8_t *>(vk_smem4);
+	float *S = reinterpret_cast<float *>(canon + VK_CANON_LDS);
 	float *SW = p.pos_s ? S + srows * 16 : S;            // tag-weighted copy the DP runs on (else S itself)
 	float *H = SW + srows * 16;
 	float *wsl = H + rows * VK_TB_W;
@@ -48,43 +53,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void vk
 	const int len_s = t_b - t_a, len_t = p.len_t;
 
 	// S: unmodified similarities (reported per edge, metric/alignment.h:339); SW: what the DP runs on
-	int rowbase;
-	if (p.layout == VK_DEV_LAYOUT_STATIC) {
-		for (int it = 0; it * 16 < len_s; it++) {
-			const int tk = it * 16 + (lane >> 2);
-			if (tk < len_s) {
-				const int id = p.tok_id[t_a + tk], cb = (lane & 3) * 4;
-				float val[4];
-				static_sim_canon<4>(p.tiles, p.tile_bytes, id, p.qtile, cb, p.d, p.prec, p.q_ids, val);
-				*reinterpret_cast<float4 *>(S + tk * 16 + cb) = make_float4(val[0], val[1], val[2], val[3]);
-				if (p.pos_s) {
-					const int ps = p.pos_s[t_a + tk];
+	const int is_static = p.layout == VK_DEV_LAYOUT_STATIC;
+	const int tile0 = is_static ? 0 : t_a >> 4;
+	const int ntiles = is_static ? (len_s + 15) >> 4 : ((t_b + 15) >> 4) - tile0;
+	for (int ti = 0; ti < ntiles; ti++) {
+		// 16 rows x 16 columns per step: lane l -> row l & 15, columns 4 (l >> 4) .. + 3 (static layout: the rows of 16
+		// consecutive tokens of the slice, gathered from the vocabulary; past the end: the slice's first token again, never read)
+		const int tok = is_static ? t_a + (ti * 16 + (lane & 15) < len_s ? ti * 16 + (lane & 15) : 0) : (tile0 + ti) * 16 + (lane & 15);
+		const int id = is_static ? p.tok_id[tok] : 0;
+		const uint8_t *xrow = is_static ? canon_row_ptr_static(p.tiles, p.tile_bytes, id) : canon_row_ptr(p.tiles + (int64_t)(tile0 + ti) * p.tile_bytes, lane);
+		const int cb = (lane >> 4) * 4;
+		float val[4];
+		sim_canon16(xrow, p.qtile, p.nk32, p.tail, p.d, PREC, canon, lane, val);
 #pragma unroll
-					for (int r = 0; r < 4; r++) val[r] = tag_weighted(val[r], p.tw[cb + r], ps, p.tpos[cb + r], p.tw_keep, p.tw_threshold);
-					*reinterpret_cast<float4 *>(SW + tk * 16 + cb) = make_float4(val[0], val[1], val[2], val[3]);
-				}
-			}
+		for (int r = 0; r < 4; r++) val[r] = (is_static && p.q_ids && p.q_ids[cb + r] == id) ? 1.0f : clip01(val[r]);   // sim[id(t_j)][j] = 1 (metric/static.cpp:58-67)
+		*reinterpret_cast<float4 *>(S + (ti * 16 + (lane & 15)) * 16 + cb) = make_float4(val[0], val[1], val[2], val[3]);
+		if (p.pos_s) {
+			const int ps = p.pos_s[tok];
+#pragma unroll
+			for (int r = 0; r < 4; r++) val[r] = tag_weighted(val[r], p.tw[cb + r], ps, p.tpos[cb + r], p.tw_keep, p.tw_threshold);
+			*reinterpret_cast<float4 *>(SW + (ti * 16 + (lane & 15)) * 16 + cb) = make_float4(val[0], val[1], val[2], val[3]);
 		}
-		rowbase = 0;
-	} else {
-		const int tile0 = t_a >> 4;
-		const int ntiles = ((t_b + 15) >> 4) - tile0;
-		for (int ti = 0; ti < ntiles; ti++) {
-			const int cb = (lane >> 4) * 4;
-			float val[4];
-			sim_canon<4>(p.tiles + (int64_t)(tile0 + ti) * p.tile_bytes, lane & 15, p.qtile, cb, p.d, p.prec, val);
-#pragma unroll
-			for (int r = 0; r < 4; r++) val[r] = clip01(val[r]);
-			*reinterpret_cast<float4 *>(S + (ti * 16 + (lane & 15)) * 16 + cb) = make_float4(val[0], val[1], val[2], val[3]);
-			if (p.pos_s) {
-				const int ps = p.pos_s[(tile0 + ti) * 16 + (lane & 15)];
-#pragma unroll
-				for (int r = 0; r < 4; r++) val[r] = tag_weighted(val[r], p.tw[cb + r], ps, p.tpos[cb + r], p.tw_keep, p.tw_threshold);
-				*reinterpret_cast<float4 *>(SW + (ti * 16 + (lane & 15)) * 16 + cb) = make_float4(val[0], val[1], val[2], val[3]);
-			}
-		}
-		rowbase = t_a - tile0 * 16;
 	}
+	const int rowbase = is_static ? 0 : t_a - tile0 * 16;
 	// gap tables into LDS (uniform broadcast reads in the candidate loops)
 	for (int i = lane; i <= p.max_len; i += 64) wsl[i] = p.ws[i];
 	if (lane <= VK_DEV_MAX_QUERY_LEN) wtl[lane] = p.wt[lane];
@@ -240,7 +231,9 @@ static inline size_t vk_wide_lds_bytes(int max_len, int nq, int gap_mode, bool t
 	if (gap_mode == 2) fl += rows * W;                 // H
 	size_t b = fl * 4;
 	if (flow) b += 64 * 2 + rows * W * 2 + rows * W;   // mapl, dk, flags
-	return (b + 15) / 16 * 16;
+	b = (b + 15) / 16 * 16;
+	if (flow) b += VK_CANON_LDS;                       // staging of sim_canon16, behind everything else
+	return b;
 }
 
 __device__ __forceinline__ float wave_min64(float m) {
@@ -265,6 +258,7 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 	int16_t *mapl = reinterpret_cast<int16_t *>(after);    // FLOW: mapping of the winner
 	int16_t *dk = mapl + 64;
 	uint8_t *flags = reinterpret_cast<uint8_t *>(dk + rows * W);
+	uint8_t *canon = FLOW ? reinterpret_cast<uint8_t *>(vk_smem4) + (((size_t)(flags + rows * W - reinterpret_cast<uint8_t *>(vk_smem4)) + 15) / 16 * 16) : nullptr;
 
 	for (int i = lane; i <= p.max_len; i += 64) wsl[i] = p.ws[i];
 	if (lane <= LQ) wtl[lane] = p.wt[lane];
@@ -308,17 +302,34 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 		}
 		// similarities of tokens base .. base + 15 (contextual: one tile, 16-aligned; static: gather)
 		auto fill = [&](int base) {
+			if constexpr (FLOW) {
+				// winners: the canonical arithmetic (sim_canon16), as vk_flow_kernel -- 16 rows x 16 columns per query tile, lane l ->
+				// row l & 15, columns 4 (l >> 4) .. + 3 (static layout: rows gathered from the vocabulary; past the slice's end its
+				// first token again, never read).  (FLOW runs alignments only: no vocabulary fixup here.)
+				const int trow = base + (lane & 15);
+				const int tok = is_static ? (trow < t_b ? trow : t_a) : trow;
+				const int id = is_static ? p.tok_id[tok] : 0;
+				const uint8_t *xrow = is_static ? canon_row_ptr_static(p.tiles, p.tile_bytes, id) : canon_row_ptr(p.tiles + (int64_t)(base >> 4) * p.tile_bytes, lane);
+				const int ps = p.pos_s ? p.pos_s[tok] : 0;
+				for (int qt = 0; qt < p.nq; qt++) {
+					float val[4];
+					sim_canon16(xrow, p.qtile + (int64_t)qt * p.tile_bytes, p.nk32, p.tail, p.d, p.prec, canon, lane, val);
+					const int c0 = qt * 16 + (lane >> 4) * 4;
+#pragma unroll
+					for (int r = 0; r < 4; r++) {
+						val[r] = (is_static && p.q_ids && p.q_ids[c0 + r] == id) ? 1.0f : clip01(val[r]);
+						Sx[(lane & 15) * LQ + c0 + r] = val[r];
+						if (p.pos_s) SWx[(lane & 15) * LQ + c0 + r] = tag_weighted(val[r], twl[c0 + r], ps, tposl[c0 + r], p.tw_keep, p.tw_threshold);
+					}
+				}
+				return;
+			}
 			if (is_static) {
 				for (int r = 0; r < 16; r++) {
 					const int tok = base + r;
 					if (tok < t_b && lane < LQ) {
 						const int id = p.tok_id[tok];
-						float sv;
-						if constexpr (FLOW) {   // winners: the canonical arithmetic (sim_canon), as vk_flow_kernel
-							float v1[1];
-							static_sim_canon<1>(p.tiles, p.tile_bytes, id, p.qtile, lane, p.d, p.prec, p.q_ids, v1);
-							sv = v1[0];
-						} else sv = p.table[(int64_t)(lane >> 4) * p.table_stride + (int64_t)id * 16 + (lane & 15)];
+						const float sv = p.table[(int64_t)(lane >> 4) * p.table_stride + (int64_t)id * 16 + (lane & 15)];
 						Sx[r * LQ + lane] = sv;
 						if (p.pos_s) {
 							float w = twl[lane];
@@ -335,12 +346,7 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 			} else {
 				const uint8_t *tp = p.tiles + (int64_t)(base >> 4) * p.tile_bytes;
 				for (int qt = 0; qt < p.nq; qt++) {
-					f32x4 acc;
-					if constexpr (FLOW) {
-						float val[4];
-						sim_canon<4>(tp, lane & 15, p.qtile + (int64_t)qt * p.tile_bytes, (lane >> 4) * 4, p.d, p.prec, val);
-						acc[0] = clip01(val[0]); acc[1] = clip01(val[1]); acc[2] = clip01(val[2]); acc[3] = clip01(val[3]);
-					} else acc = sim_tile_generic(p.qtile + (int64_t)qt * p.tile_bytes, tp, p.nk32, p.tail, lane, p.prec);
+					f32x4 acc = sim_tile_generic(p.qtile + (int64_t)qt * p.tile_bytes, tp, p.nk32, p.tail, lane, p.prec);
 					const int c0 = qt * 16 + (lane >> 4) * 4;
 					*reinterpret_cast<f32x4 *>(Sx + (lane & 15) * LQ + c0) = acc;
 					if (p.pos_s) {
@@ -549,9 +555,11 @@ extern "C" size_t vk_wide_lds_demand(int32_t max_len, int32_t nq, int32_t gap_mo
 extern "C" hipError_t vk_launch_flow(const VkFlowParams *p, int32_t k, hipStream_t stream) {
 	const size_t smem = vk_flow_lds_bytes(p->max_len, p->pos_s != nullptr);
 	if (smem > 64 * 1024) {
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(vk_flow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+		hipError_t e = hipFuncSetAttribute(p->prec ? reinterpret_cast<const void *>(vk_flow_kernel<1>) : reinterpret_cast<const void *>(vk_flow_kernel<0>),
+			hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 		if (e != hipSuccess) return e;
 	}
-	vk_flow_kernel<<<k, 64, smem, stream>>>(*p);
+	if (p->prec) vk_flow_kernel<1><<<k, 64, smem, stream>>>(*p);
+	else vk_flow_kernel<0><<<k, 64, smem, stream>>>(*p);
 	return hipGetLastError();
 }

@@ -252,8 +252,6 @@ extern "C" hipError_t vk_launch_batch_pack(const uint8_t *src_tiles, uint8_t *ds
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8n;
-typedef __attribute__((address_space(3))) void *vk_lds_ptr;
-typedef __attribute__((address_space(1))) const void *vk_glb_ptr;
 
 __device__ __forceinline__ float row_sum_to_lane15(float x) {
 	x += dpp_f<DPP_ROW_SHR1>(0.0f, x);

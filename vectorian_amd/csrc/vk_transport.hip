@@ -61,10 +61,42 @@ __device__ __forceinline__ double wave_argmin_f64(double x, int lane, int &at) {
 // winners' rows, whose costs, plans and flows then rest on the same similarities as the oracle's, bit for bit; the bound pass
 // over all long slices (vk_long_bound_kernel) keeps the MFMA form.
 template <int NQ, int STRIDE = 16 * NQ, bool CANON = true>
-__device__ __forceinline__ int transport_sim_rows(const VkWrdParams &p, float *S, int t_a, int t_b, int lane) {
+__device__ __forceinline__ int transport_sim_rows(const VkWrdParams &p, float *S, int t_a, int t_b, int lane, uint8_t *canon = nullptr) {
 	constexpr int N = STRIDE;
 	const int m = t_b - t_a;
-	if (p.layout == VK_DEV_LAYOUT_STATIC) {
+	const bool is_static = p.layout == VK_DEV_LAYOUT_STATIC;
+	if constexpr (CANON) {
+		// 16 rows x 16 columns per step (sim_canon16, staged through the wave's `canon` bytes of LDS): lane l -> row l & 15,
+		// columns 4 (l >> 4) .. + 3 of each query tile; static layout: the rows of 16 consecutive tokens gathered from the vocabulary
+		// (past the slice's end its first token again, never read)
+		const int tile0 = is_static ? 0 : t_a >> 4;
+		const int ntiles = is_static ? (m + 15) >> 4 : ((t_b + 15) >> 4) - tile0;
+		for (int ti = 0; ti < ntiles; ti++) {
+			const int tok = is_static ? t_a + (ti * 16 + (lane & 15) < m ? ti * 16 + (lane & 15) : 0) : (tile0 + ti) * 16 + (lane & 15);
+			const int id = is_static ? p.tok_id[tok] : 0;
+			const uint8_t *xrow = is_static ? canon_row_ptr_static(p.tiles, p.tile_bytes, id) : canon_row_ptr(p.tiles + (int64_t)(tile0 + ti) * p.tile_bytes, lane);
+			const int ps = p.pos_s ? p.pos_s[tok] : 0;
+#pragma unroll 1
+			for (int b = 0; b < NQ; b++) {
+				float val[4];
+				sim_canon16(xrow, p.qtile + (int64_t)b * p.tile_bytes, p.nk32, p.tail, p.d, p.prec, canon, lane, val);
+				const int c0 = 16 * b + (lane >> 4) * 4;
+#pragma unroll
+				for (int r = 0; r < 4; r++) {
+					val[r] = (is_static && p.q_ids && p.q_ids[c0 + r] == id) ? 1.0f : clip01(val[r]);   // sim[id(t_j)][j] = 1 (metric/static.cpp:58-67)
+					if (p.pos_s) val[r] = tag_weighted(val[r], p.tw[c0 + r], ps, p.tpos[c0 + r], p.tw_keep, p.tw_threshold);
+				}
+				*reinterpret_cast<float4 *>(S + (ti * 16 + (lane & 15)) * N + c0) = make_float4(val[0], val[1], val[2], val[3]);
+			}
+		}
+		if (is_static && p.qid_bits && p.pos_s) {   // tag-weighted vocabulary transport: cells upstream writes twice (static_vocab_fixup, vk_common.hip.h)
+			wave_lds_fence();
+			static_vocab_fixup<64, true>(S, N, m, p.len_t, p.tok_id + t_a, p.tag_s + t_a, p.pos_s + t_a, p.table, p.table_stride,
+				p.qid_bits, p.qkey, p.tw, p.tpos, p.tw_keep, p.tw_threshold, lane, p.tiles, p.tile_bytes, p.qtile, p.d, p.prec, p.q_ids);
+		}
+		return is_static ? 0 : t_a - tile0 * 16;
+	}
+	if (is_static) {
 		for (int it = 0; it * 16 < m; it++) {
 			const int tk = it * 16 + (lane >> 2);
 			if (tk < m) {
@@ -73,12 +105,7 @@ __device__ __forceinline__ int transport_sim_rows(const VkWrdParams &p, float *S
 #pragma unroll
 				for (int b = 0; b < NQ; b++) {
 					const int c0 = 16 * b + (lane & 3) * 4;
-					float4 vq;
-					if constexpr (CANON) {
-						float val[4];
-						static_sim_canon<4>(p.tiles, p.tile_bytes, id, p.qtile, c0, p.d, p.prec, p.q_ids, val);
-						vq = make_float4(val[0], val[1], val[2], val[3]);
-					} else vq = *reinterpret_cast<const float4 *>(p.table + b * p.table_stride + (int64_t)id * 16 + (lane & 3) * 4);
+					float4 vq = *reinterpret_cast<const float4 *>(p.table + b * p.table_stride + (int64_t)id * 16 + (lane & 3) * 4);
 					if (p.pos_s) {
 						vq.x = tag_weighted(vq.x, p.tw[c0 + 0], ps, p.tpos[c0 + 0], p.tw_keep, p.tw_threshold);
 						vq.y = tag_weighted(vq.y, p.tw[c0 + 1], ps, p.tpos[c0 + 1], p.tw_keep, p.tw_threshold);
@@ -89,10 +116,10 @@ __device__ __forceinline__ int transport_sim_rows(const VkWrdParams &p, float *S
 				}
 			}
 		}
-		if (p.qid_bits && p.pos_s) {   // tag-weighted vocabulary transport: cells upstream writes twice (static_vocab_fixup, vk_common.hip.h)
+		if (p.qid_bits && p.pos_s) {
 			wave_lds_fence();
-			static_vocab_fixup<64, CANON>(S, N, m, p.len_t, p.tok_id + t_a, p.tag_s + t_a, p.pos_s + t_a, p.table, p.table_stride,
-				p.qid_bits, p.qkey, p.tw, p.tpos, p.tw_keep, p.tw_threshold, lane, p.tiles, p.tile_bytes, p.qtile, p.d, p.prec, p.q_ids);
+			static_vocab_fixup<64>(S, N, m, p.len_t, p.tok_id + t_a, p.tag_s + t_a, p.pos_s + t_a, p.table, p.table_stride,
+				p.qid_bits, p.qkey, p.tw, p.tpos, p.tw_keep, p.tw_threshold, lane);
 		}
 		return 0;
 	}
@@ -102,12 +129,7 @@ __device__ __forceinline__ int transport_sim_rows(const VkWrdParams &p, float *S
 		const int ps = p.pos_s ? p.pos_s[(tile0 + ti) * 16 + (lane & 15)] : 0;
 #pragma unroll
 		for (int b = 0; b < NQ; b++) {
-			f32x4 acc;
-			if constexpr (CANON) {
-				float val[4];
-				sim_canon<4>(p.tiles + (int64_t)(tile0 + ti) * p.tile_bytes, lane & 15, p.qtile + (int64_t)b * p.tile_bytes, (lane >> 4) * 4, p.d, p.prec, val);
-				acc[0] = clip01(val[0]); acc[1] = clip01(val[1]); acc[2] = clip01(val[2]); acc[3] = clip01(val[3]);
-			} else acc = sim_tile_generic(p.qtile + (int64_t)b * p.tile_bytes, p.tiles + (int64_t)(tile0 + ti) * p.tile_bytes, p.nk32, p.tail, lane, p.prec);
+			f32x4 acc = sim_tile_generic(p.qtile + (int64_t)b * p.tile_bytes, p.tiles + (int64_t)(tile0 + ti) * p.tile_bytes, p.nk32, p.tail, lane, p.prec);
 			if (p.pos_s) {
 				const int c0 = 16 * b + (lane >> 4) * 4;
 #pragma unroll
@@ -126,7 +148,8 @@ __global__ __launch_bounds__(64) void vk_wrd_exact_kernel(VkWrdParams p) {
 	constexpr int N = 16 * NQ;
 	constexpr bool REG = NQ == 1;
 	extern __shared__ double vk_smem_f64[];
-	double *Cm = vk_smem_f64;               // Cm[j * 64 + i]: cost supply j -> demand i
+	uint8_t *canon = reinterpret_cast<uint8_t *>(vk_smem_f64);   // staging of sim_canon16 (VK_CANON_LDS bytes)
+	double *Cm = reinterpret_cast<double *>(canon + VK_CANON_LDS);   // Cm[j * 64 + i]: cost supply j -> demand i
 	double *fl = Cm + N * 64;               // flow
 	double *sup = fl + N * 64, *pot_s = sup + N, *dist_s = pot_s + N;
 	int *pred_s = reinterpret_cast<int *>(dist_s + N), *settled = pred_s + N;
@@ -141,7 +164,7 @@ __global__ __launch_bounds__(64) void vk_wrd_exact_kernel(VkWrdParams p) {
 	const int m = t_b - t_a, n = p.len_t;
 	if (m > VK_DEV_MAX_SENT_LEN) return;   // long slices: vk_wrd_exact_long_kernel
 
-	const int rowbase = transport_sim_rows<NQ>(p, S, t_a, t_b, lane);
+	const int rowbase = transport_sim_rows<NQ>(p, S, t_a, t_b, lane, canon);
 	wave_lds_fence();
 	const float *Sm = S + rowbase * N;
 	const bool has = lane < m;
@@ -368,7 +391,8 @@ __global__ __launch_bounds__(64) void vk_wrd_exact_long_kernel(VkWrdParams p) {
 	constexpr int N = 16 * NQ, M = VK_WRDL_M;
 	constexpr bool GLOBAL = NQ > 1;
 	extern __shared__ double vk_smem_f64[];
-	double *dem = vk_smem_f64, *pot_d = dem + M, *dist_d = pot_d + M;   // [M] each
+	uint8_t *canon = reinterpret_cast<uint8_t *>(vk_smem_f64);   // staging of sim_canon16 (VK_CANON_LDS bytes)
+	double *dem = reinterpret_cast<double *>(canon + VK_CANON_LDS), *pot_d = dem + M, *dist_d = pot_d + M;   // [M] each
 	double *sup = dist_d + M, *pot_s = sup + N, *dist_s = pot_s + N;    // [N] each
 	int *pred_d = reinterpret_cast<int *>(dist_s + N);                  // [M]
 	int *pred_s = pred_d + M, *settled = pred_s + N;                    // [N]
@@ -396,8 +420,8 @@ __global__ __launch_bounds__(64) void vk_wrd_exact_long_kernel(VkWrdParams p) {
 	if (m <= VK_DEV_MAX_SENT_LEN || m > M) continue;   // short slices are vk_wrd_exact_kernel's
 
 	int rowbase;
-	if constexpr (NQ == 1) rowbase = transport_sim_rows<1>(p, S, t_a, t_b, lane);
-	else rowbase = p.nq == 2 ? transport_sim_rows<2, N>(p, S, t_a, t_b, lane) : p.nq == 3 ? transport_sim_rows<3, N>(p, S, t_a, t_b, lane) : transport_sim_rows<4, N>(p, S, t_a, t_b, lane);
+	if constexpr (NQ == 1) rowbase = transport_sim_rows<1>(p, S, t_a, t_b, lane, canon);
+	else rowbase = p.nq == 2 ? transport_sim_rows<2, N>(p, S, t_a, t_b, lane, canon) : p.nq == 3 ? transport_sim_rows<3, N>(p, S, t_a, t_b, lane, canon) : transport_sim_rows<4, N>(p, S, t_a, t_b, lane, canon);
 	wrdl_fence<GLOBAL>();
 	const float *Sm = S + rowbase * N;
 
@@ -554,7 +578,7 @@ __global__ __launch_bounds__(64) void vk_wrd_exact_long_kernel(VkWrdParams p) {
 static size_t transport_long_lds_bytes(int nq) {
 	const size_t N = 16 * (size_t)nq, M = VK_WRDL_M;
 	const size_t vectors = 3 * M * 8 + 3 * N * 8 + M * 4 + 2 * N * 4;
-	return nq > 1 ? vectors : vectors + N * M * 8 + N * M * 4 + (M + 32) * N * 4;
+	return VK_CANON_LDS + (nq > 1 ? vectors : vectors + N * M * 8 + N * M * 4 + (M + 32) * N * 4);
 }
 
 extern "C" int vk_wrd_long_blocks(void) { return 256; }
@@ -656,7 +680,8 @@ template <int NQ>
 __global__ __launch_bounds__(64) void vk_rows_kernel(VkWrdParams p) {
 	constexpr int N = 16 * NQ;
 	extern __shared__ double vk_smem_f64[];
-	float *S = reinterpret_cast<float *>(vk_smem_f64);   // [(R + 32)][N]
+	uint8_t *canon = reinterpret_cast<uint8_t *>(vk_smem_f64);   // staging of sim_canon16 (VK_CANON_LDS bytes)
+	float *S = reinterpret_cast<float *>(canon + VK_CANON_LDS);   // [(R + 32)][N]
 	const int lane = threadIdx.x;
 	const int w = blockIdx.x;
 	const int R = p.rows_len > 0 ? p.rows_len : 64;
@@ -669,7 +694,7 @@ __global__ __launch_bounds__(64) void vk_rows_kernel(VkWrdParams p) {
 		const int t_a = p.sent_start[g], t_b = p.sent_end[g];
 		m = t_b - t_a;
 		if (m < 1 || m > R) m = 0;
-		else rowbase = transport_sim_rows<NQ>(p, S, t_a, t_b, lane);
+		else rowbase = transport_sim_rows<NQ>(p, S, t_a, t_b, lane, canon);
 	}
 	wave_lds_fence();
 	for (int i = lane; i < R * N; i += 64) out[i] = i / N < m ? S[rowbase * N + i] : 0.0f;
@@ -677,7 +702,7 @@ __global__ __launch_bounds__(64) void vk_rows_kernel(VkWrdParams p) {
 
 static size_t transport_lds_bytes(int nq, bool solver) {
 	const size_t n = 16 * (size_t)nq;
-	return (solver ? n * 64 * 8 * 2 + n * 8 * 3 + n * 4 * 2 : 0) + (size_t)(VK_DEV_MAX_SENT_LEN + 32) * n * 4;
+	return VK_CANON_LDS + (solver ? n * 64 * 8 * 2 + n * 8 * 3 + n * 4 * 2 : 0) + (size_t)(VK_DEV_MAX_SENT_LEN + 32) * n * 4;
 }
 
 extern "C" hipError_t vk_launch_wrd_exact(const VkWrdParams *p, int32_t n_cand, float *scores_to_mark, hipStream_t stream) {
@@ -694,7 +719,7 @@ extern "C" hipError_t vk_launch_wrd_exact(const VkWrdParams *p, int32_t n_cand, 
 
 extern "C" hipError_t vk_launch_rows(const VkWrdParams *p, int32_t n_cand, hipStream_t stream) {
 	const int R = p->rows_len > 0 ? p->rows_len : 64;
-	const size_t smem = (size_t)(R + 32) * 16 * (size_t)(p->nq < 1 ? 1 : p->nq) * 4;
+	const size_t smem = VK_CANON_LDS + (size_t)(R + 32) * 16 * (size_t)(p->nq < 1 ? 1 : p->nq) * 4;
 	void (*kernel)(VkWrdParams) = p->nq <= 1 ? vk_rows_kernel<1> : p->nq == 2 ? vk_rows_kernel<2> : p->nq == 3 ? vk_rows_kernel<3> : vk_rows_kernel<4>;
 	if (smem > 64 * 1024) {
 		const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
