@@ -88,47 +88,54 @@ def describe(spec, n_sent):
 def build_shard(core, torch, spec, n_sent, rank, device):
 	"""synthetic shard generated on the GPU in chunks (clustered vocabulary, Zipf(1.1) token ids, per-token
 	noise), handed to the library by device pointer.  Returns the corpus handle, the vocabulary, the token ids (device) and
-	the sentence offsets."""
+	the sentence offsets.  `rank` may be a list of ranks: their shards one after the other in ONE corpus (the self-check of the
+	sharded path compares the merged result sets with the answer of that corpus)."""
 	from vectorian_amd import synth
+	ranks = list(rank) if isinstance(rank, (list, tuple)) else [rank]
 	d = spec["d"]
 	E = synth.make_vocab(VOCAB, d)                                   # seeded, shared by all ranks
-	rng = np.random.default_rng(synth.SEED_CORPUS + 7919 * rank)
-	if spec["max_len"] > spec["min_len"]:
-		lens = rng.integers(spec["min_len"], spec["max_len"] + 1, size=n_sent)
-	else:
-		lens = np.full(n_sent, spec["min_len"])
-	off = np.zeros(n_sent + 1, dtype=np.int64)
-	np.cumsum(lens, out=off[1:])
+	lens = []
+	for r in ranks:
+		rng = np.random.default_rng(synth.SEED_CORPUS + 7919 * r)
+		if spec["max_len"] > spec["min_len"]:
+			lens.append(rng.integers(spec["min_len"], spec["max_len"] + 1, size=n_sent))
+		else:
+			lens.append(np.full(n_sent, spec["min_len"]))
+	n_all = n_sent * len(ranks)
+	off = np.zeros(n_all + 1, dtype=np.int64)
+	np.cumsum(np.concatenate(lens), out=off[1:])
 	n_tok = int(off[-1])
 	static = spec.get("layout") == "static"
 	if static:
-		corpus = core.Corpus(layout=core.VK_LAYOUT_STATIC, d=d, n_tokens=n_tok, n_sentences=n_sent, vocab_size=VOCAB, precision=spec["prec"])
+		corpus = core.Corpus(layout=core.VK_LAYOUT_STATIC, d=d, n_tokens=n_tok, n_sentences=n_all, vocab_size=VOCAB, precision=spec["prec"])
 		corpus.append_vectors(E, normalize=True)
 	else:
-		corpus = core.Corpus(layout=core.VK_LAYOUT_CONTEXTUAL, d=d, n_tokens=n_tok, n_sentences=n_sent,
+		corpus = core.Corpus(layout=core.VK_LAYOUT_CONTEXTUAL, d=d, n_tokens=n_tok, n_sentences=n_all,
 			keep_magnitudes=bool(spec.get("magnitudes")), precision=spec["prec"])
 	E_dev = torch.from_numpy(E).to(device)
-	gen = torch.Generator(device=device)
-	gen.manual_seed(1000 + rank)
 	p = 1.0 / np.arange(1, VOCAB + 1) ** 1.1
 	cdf = np.cumsum(p)
 	cdf_dev = torch.from_numpy(cdf / cdf[-1]).to(device)
 	ids = torch.empty(n_tok, dtype=torch.int32, device=device)
 	chunk = 1 << 20 if d <= 320 else 1 << 19
 	noise, sigma = spec.get("noise", 0.1), spec.get("norm_sigma", 0.0)
-	for a in range(0, n_tok, chunk):
-		b = min(a + chunk, n_tok)
-		idx = torch.searchsorted(cdf_dev, torch.rand(b - a, device=device, generator=gen, dtype=torch.float64)).clamp_(max=VOCAB - 1)
-		ids[a:b] = idx.to(torch.int32)
-		if static:
-			continue
-		x = E_dev[idx] + noise * torch.randn((b - a, d), device=device, generator=gen, dtype=torch.float32)
-		if sigma > 0:
-			x = x * torch.exp(sigma * torch.randn((b - a, 1), device=device, generator=gen, dtype=torch.float32))
-		x = x.contiguous()
-		torch.cuda.synchronize()
-		corpus.append_vectors_device(x.data_ptr(), b - a, core.VK_F32, normalize=True)
-		del x, idx
+	for i, r in enumerate(ranks):
+		gen = torch.Generator(device=device)
+		gen.manual_seed(1000 + r)
+		t0, t1 = int(off[i * n_sent]), int(off[(i + 1) * n_sent])   # this rank's tokens: generated as if the shard stood alone
+		for a in range(t0, t1, chunk):
+			b = min(a + chunk, t1)
+			idx = torch.searchsorted(cdf_dev, torch.rand(b - a, device=device, generator=gen, dtype=torch.float64)).clamp_(max=VOCAB - 1)
+			ids[a:b] = idx.to(torch.int32)
+			if static:
+				continue
+			x = E_dev[idx] + noise * torch.randn((b - a, d), device=device, generator=gen, dtype=torch.float32)
+			if sigma > 0:
+				x = x * torch.exp(sigma * torch.randn((b - a, 1), device=device, generator=gen, dtype=torch.float32))
+			x = x.contiguous()
+			torch.cuda.synchronize()
+			corpus.append_vectors_device(x.data_ptr(), b - a, core.VK_F32, normalize=True)
+			del x, idx
 	if static:
 		corpus.set_token_ids(ids.cpu().numpy())
 	corpus.set_sentences(off)
@@ -434,6 +441,9 @@ def main():
 	ap.add_argument("--extra-warmup", type=int, default=4)
 	ap.add_argument("--extra-min-ms", type=float, default=300.0, help="the extra configurations run at least this long inside their timed region")
 	ap.add_argument("--extra-scale", type=float, default=1.0, help="scales the sentence counts of the extra configurations (rehearsals)")
+	ap.add_argument("--selfcheck", action="store_true", help="N > 1, small --sentences: after the timed region one fixed query goes through the "
+		"sharded path (per-rank result sets, all-gather, merge) and rank 0 compares the merged result set with the answer of ONE corpus "
+		"holding all ranks' shards (\"selfcheck\" in the JSON line)")
 	args = ap.parse_args()
 
 	import torch
@@ -568,6 +578,30 @@ def main():
 	spec, entry = measure(args.config, n_sent, args.warmup, args.steps, dist, gap=args.gap, locality=args.locality, keep=keep)
 	traffic, traffic_source = traffic_of(spec["name"], spec["gap"], n_sent, head["n_sent"])
 
+	# ---- self-check of the sharded path (tests/test_gpu_bench_ranks.py runs this with two gloo ranks on one GPU)
+	selfcheck = None
+	if args.selfcheck and dist is not None and spec["alg"] == "align" and spec.get("layout") != "static" and not spec.get("batch"):
+		from vectorian_amd import shards as _shards
+		corpus = keep["shard"][0]
+		E = keep["shard"][1]
+		rq = np.random.default_rng(777)
+		qv = np.ascontiguousarray(E[rq.integers(0, VOCAB, size=LEN_T)] + 0.05 * rq.standard_normal((LEN_T, spec["d"])).astype(np.float32), dtype=np.float32)
+		gs_, gt_, _ = gap_spec(spec["gap"])
+		opts = dict(algorithm=core.VK_ALG_ALIGN, locality=LOCALITIES[spec["locality"]], gap_s=gs_, gap_t=gt_, q_normalize=True,
+			max_matches=K_MATCHES, min_score=0.0 if spec["locality"] == "local" else -1e9, want_flow=True)
+		local = corpus.query(qv, **opts)
+		merged = _shards.allgather_finish(_shards.allgather_start([local], rank * n_sent, K_MATCHES, device=xdev))[0]
+		if rank == 0:
+			whole = build_shard(core, torch, spec, n_sent, list(range(world)), device)[0]   # all ranks' shards, one corpus, no exchange
+			one = whole.query(qv, **opts)
+			whole.close()
+			n_ = int(one.n)
+			same = (int(merged.n) == n_ and (merged.sentence[:n_] == one.sentence[:n_]).all()
+				and (merged.score[:n_].view(np.uint32) == one.score[:n_].view(np.uint32)).all() and (merged.mapping[:n_] == one.mapping[:n_]).all())
+			selfcheck = {"ok": bool(same), "n": n_, "merged": [int(x) for x in merged.sentence[:int(merged.n)]], "one_corpus": [int(x) for x in one.sentence[:n_]],
+				"ranks_with_winners": sorted({int(x) // n_sent for x in merged.sentence[:int(merged.n)]})}
+		dist.barrier()
+
 	# what the collective backend itself saw (the first real multi-GPU run must prove that RCCL ran with N ranks on N devices)
 	ranks = {"launched": world, "backend": backend if dist is not None else None, "world_seen_by_backend": 1, "devices": [dev_index]}
 	if dist is not None:
@@ -603,6 +637,8 @@ def main():
 			"roofline": roof,
 			"ranks": ranks,
 		}
+		if selfcheck is not None:
+			out["selfcheck"] = selfcheck
 		full = dict(out)
 		full["config"] = dict(out["config"], sentences_per_gpu=n_sent, len_s=[spec["min_len"], spec["max_len"]], len_t=LEN_T, d=spec["d"], k=K_MATCHES,
 			algorithm=spec["alg"], locality=spec["locality"], gap=spec["gap"], queries_per_step=max(1, int(spec.get("batch", 0))))

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 8
+#define VK_ABI_VERSION 9
 #define VK_MAX_QUERY_LEN 64   /* query tokens */
 #define VK_FAST_QUERY_LEN 16  /* queries up to this length run in the fused kernels (one 16-wide MFMA column block); longer ones
                                  take the multi-block kernel (2 or 4 column blocks) or, where that does not apply, a
@@ -142,6 +142,14 @@ typedef struct {
 	 * may raise from another thread.  Polled when vk_query starts and between the queries / launches of vk_query_batch (a query
 	 * is a few milliseconds of device time and is not interrupted); a raised flag ends the call with VK_ERR_ABORTED. */
 	const volatile int32_t *abort;
+	/* The debug hook of the reference is called for EVERY slice a matcher scores (call_debug_hook, metric/alignment.h:145-173:
+	 * slice, similarity, flow, score), not only for the winners.  only_slices (host, n_only entries, each a slice index of this
+	 * handle, n_only <= min(VK_MAX_MATCHES, capacity); NULL: off) makes vk_query skip the scoring pass and the selection and
+	 * state exactly these slices instead, in the given order: score, raw_score, mapping and edge_sim from the traceback kernel
+	 * (canonical arithmetic), sim_rows when the array is given; no min_score admission, n_out = n_only.  VK_ALG_ALIGN with
+	 * want_flow and submatch_weight = 0 only.  A caller walks the corpus in chunks with it (Index: debug = AllSlices(hook)). */
+	const int64_t *only_slices;
+	int32_t n_only;
 } vk_query_desc;
 
 /* Bounded result set, best first.  Order: score descending, then sentence index

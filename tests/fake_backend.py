@@ -96,9 +96,28 @@ class OracleCorpus:
 	def query(self, q_vectors, *, locality=0, gap_s=0.0, gap_t=0.0, algorithm=0, q_token_ids=None, q_normalize=True,
 			max_matches=10, min_score=0.0, boost=None, want_flow=True, submatch_weight=0.0, bidirectional=False,
 			rwmd=(True, True, True), wrd_normalize=True, tag_weights=None, q_pos=None, pos_mismatch_penalty=0.0,
-			similarity_threshold=0.0, wmd_full=False, q_tags=None, abort_flag=None, want_rows=False):
+			similarity_threshold=0.0, wmd_full=False, q_tags=None, abort_flag=None, want_rows=False, only_slices=None):
 		if abort_flag is not None and abort_flag[0]:
 			raise core.VkError(core.VK_ERR_ABORTED, "query aborted by the caller")
+		if only_slices is not None:
+			# vk_query_desc.only_slices: exactly these slices, in this order, whatever their score (the debug hook's walk)
+			ids = np.asarray(only_slices, dtype=np.int64)
+			sub = OracleCorpus(layout=self.layout, d=self.d, n_tokens=self.n_tokens, n_sentences=len(ids), vocab_size=self.vocab_size, precision=self.precision)
+			sub._X, sub._mag, sub._ids, sub._pos, sub._tags = self._X, self._mag, self._ids, self._pos, self._tags
+			sub._off = self._off[ids]
+			sub._end = (self._end if self._end is not None else self._off[1:])[ids]
+			b = None if boost is None else np.ascontiguousarray(np.asarray(boost, dtype=np.float32)[ids])
+			t = sub.query(q_vectors, locality=locality, gap_s=gap_s, gap_t=gap_t, algorithm=algorithm, q_token_ids=q_token_ids, q_normalize=q_normalize,
+				max_matches=len(ids), min_score=-3.0e38, boost=b, want_flow=want_flow, submatch_weight=submatch_weight, rwmd=rwmd,
+				wrd_normalize=wrd_normalize, tag_weights=tag_weights, q_pos=q_pos, pos_mismatch_penalty=pos_mismatch_penalty,
+				similarity_threshold=similarity_threshold, wmd_full=wmd_full, q_tags=q_tags, want_rows=want_rows)
+			assert t.n == len(ids), (t.n, len(ids))
+			back = np.argsort(t.sentence[:t.n], kind="stable")   # position i of the output = slice ids[i]
+			for name in ("score", "raw_score", "mapping", "edge_sim") + (("sim_rows", "plan") if getattr(t, "sim_rows", None) is not None else ()):
+				arr = getattr(t, name)
+				arr[:t.n] = arr[:t.n][back]
+			t.sentence[:t.n] = ids
+			return t
 		q = np.ascontiguousarray(q_vectors)
 		if q.dtype == np.uint16:
 			q = synth.bf16_bits_to_f32(q)

@@ -44,6 +44,76 @@ def answers(index, queries):
 	return out
 
 
+def summary(r):
+	rows = []
+	for m in r:
+		f = m.flow
+		if f["type"] == "dense":
+			shape = [float(round(float((f["flow"] * f["dist"]).sum()), 4)), float(round(float(f["flow"].sum()), 4))]
+		elif f["type"] == "sparse":
+			shape = [[int(x) for x in f["source"]], [int(x) for x in f["target"]], [float(round(float(x), 5)) for x in f["flow"]]]
+		else:
+			shape = [int(x) for x in f["target"]]
+		rows.append([m.doc_index, int(m.slice_id), float(m.score), f["type"], shape])
+	return rows
+
+
+def many_queries(index, n=37):
+	"""n queries cut from the session's own documents (contextual session: batched calls are possible)"""
+	session = index.session
+	out = []
+	for i in range(n):
+		doc = session.documents[i % len(session.documents)]
+		st = int(doc.spans["sentence"]["start"][(7 * i) % len(doc.spans["sentence"]["start"])])
+		out.append(" ".join(doc.tokens[st:st + 3 + i % 4]))
+	return out
+
+
+def build_contextual(shard, strategy):
+	"""a session with contextual embeddings (find_many shares calls over these: vk_query_batch)"""
+	from fake_backend import OracleCorpus
+	from test_host_api import contextual_toy
+	from vectorian_amd import alignment
+	from vectorian_amd.sim import CosineSim, EmbeddingTokenSim, OptimizedSpanSim
+	session, emb, _ = contextual_toy(n_docs=5, sents=30)
+	optimizer = {"align": alignment.LocalAlignment(gap=alignment.smooth_gap_cost(5)), "rwmd": alignment.WordMoversDistance.rwmd("nbow")}[strategy]
+	sim = OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), optimizer)
+	return session.partition("sentence").index(sim, corpus_factory=OracleCorpus, shard=shard)
+
+
+def find_many_answers(shard):
+	"""find_many over a (sharded) index: alignments (16 per backend call) and relaxed WMD (256 per call), with progress"""
+	out = {}
+	for strategy in ("align", "rwmd"):
+		index = build_contextual(shard, strategy)
+		queries = many_queries(index)
+		seen = []
+		results = index.find_many(queries, n=5, batch=True, progress=seen.append)
+		out[strategy] = [summary(r) for r in results]
+		out[strategy + "_progress"] = seen
+		out[strategy + "_batch_calls"] = index.corpus.batch_calls
+		# one query at a time through the pipelined path as well (no shared calls)
+		out[strategy + "_pipelined"] = [summary(r) for r in index.find_many(queries[:9], n=5, batch=False)]
+	return out
+
+
+def abort_answers(shard):
+	"""Query.abort seen by ONE rank only: every rank still joins the exchange and the query yields no matches anywhere"""
+	import numpy as np
+	index = build_contextual(shard, "align")
+	queries = many_queries(index, 6)
+	flag = np.zeros(1, dtype=np.int32)
+	if shard is not None and shard[0] == 1:
+		flag[0] = 1
+	res = {"batched": [len(r.matches) for r in index.find_many(queries, n=5, abort=flag)],
+		"pipelined": [len(list(r)) for r in index.find_many(queries, n=5, abort=flag, batch=False)]}
+	q = index.make_query(queries[0], n=5)
+	if shard is not None and shard[0] == 1:
+		q.abort()
+	res["find"] = len(index._find(q))
+	return res
+
+
 def main(outdir):
 	import torch.distributed as dist
 	dist.init_process_group(backend="gloo")
@@ -52,6 +122,8 @@ def main(outdir):
 	for strategy in ("align", "wrd", "rwmd"):
 		index, queries = build((rank, world), strategy)
 		res[strategy] = answers(index, queries)
+	res["find_many"] = find_many_answers((rank, world))
+	res["abort"] = abort_answers((rank, world))
 	with open(os.path.join(outdir, f"index_rank{rank}.json"), "w") as f:
 		json.dump(res, f)
 	dist.barrier()

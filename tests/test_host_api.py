@@ -451,3 +451,63 @@ def test_debug_hook_and_abort():
 	q.abort()
 	assert q.aborted and index._find(q) == []
 	assert len(index.find(text, n=4)) == 4
+
+
+def test_debug_hook_for_every_slice_and_progress():
+	"""debug = AllSlices(hook): the hook contract of the reference in full -- one call per scored slice, in slice order, with the
+	keys of call_debug_hook (vectorian/core/cpp/metric/alignment.h:145-173); progress(done / total) per stage of a find and per
+	query / chunk of find_many (vectorian/index.py:541-558)"""
+	from vectorian_amd.index import AllSlices
+	session, emb, words, rng = toy_session(n_docs=3, sents_per_doc=25, V=300, d=32)
+	doc = session.documents[1]
+	text = " ".join(doc.tokens[12:16])
+	sim = OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), alignment.LocalAlignment(gap=alignment.LinearGapCost(0.2)))
+	index = session.partition("sentence").index(sim, corpus_factory=OracleCorpus)
+	calls, seen = [], []
+	hook = AllSlices(lambda name, data: calls.append((name, data)), chunk=20)
+	matches = index._find(index.make_query(text, n=4, debug=hook), progress=seen.append)
+	assert seen == [1.0, 1.0]                      # one GPU: all tokens scored, then the result set complete
+	assert len(calls) == 75 and [c[0] for c in calls] == ["alignment"] * 75
+	assert [c[1]["slice"] for c in calls] == [s for _ in range(3) for s in range(25)]   # every slice, document by document, in order
+	by_slice = {}
+	for k, (_, data) in enumerate(calls):
+		assert set(data) == {"slice", "similarity", "flow", "score"}
+		by_slice[(k // 25, data["slice"])] = data
+	for m in matches:                              # the winners' data as the winners report it
+		data = by_slice[(m.doc_index, m.slice_id)]
+		assert abs(data["score"] - m.raw_score) < 1e-6 and (data["flow"]["target"] == m.flow["target"]).all()
+		assert data["similarity"].shape == (m._len_s, 4)
+	best = max(d["score"] for d in by_slice.values())
+	assert abs(best - matches[0].raw_score) < 1e-6
+	# relaxed WMD: score and the running worst score of a result set filled in slice order (metric/alignment.h:600-607)
+	calls.clear()
+	wmd = session.partition("sentence").index(OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), alignment.WordMoversDistance.rwmd("nbow")),
+		corpus_factory=OracleCorpus)
+	r = wmd.find(text, n=3, debug=hook)
+	assert len(calls) == 75 and calls[0][0] == "alignment/word-movers-distance/make"
+	assert calls[0][1]["worst_score"] == 0.0 and calls[-1][1]["worst_score"] <= r[-1].score + 1e-7
+	admitted = sorted((c[1]["score"] for c in calls if c[1]["score"] > c[1]["worst_score"]), reverse=True)[:3]
+	assert np.allclose(admitted, [m.score for m in r], atol=1e-7)
+	# find_many: progress after every query (pipelined path) and after every chunk (batched calls)
+	seen.clear()
+	res = index.find_many([text] * 5, n=2, progress=seen.append)
+	assert len(res) == 5 and seen == [0.2, 0.4, 0.6, 0.8, 1.0]
+
+
+def test_matches_are_lazy():
+	"""a match holds its place in the result set's arrays; flows, regions and index maps are stated on first access (CoreMatch,
+	vectorian/index.py:295-379)"""
+	session, emb, docs = contextual_toy()
+	index = session.index(OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), alignment.WordMoversDistance.rwmd("nbow")), corpus_factory=OracleCorpus)
+	stated = []
+	orig = index._transport_flow
+	index._transport_flow = lambda *a, **k: (stated.append(1), orig(*a, **k))[1]
+	res = index.find_many([" ".join(docs[i % 4].tokens[4 * i:4 * i + 4]) for i in range(12)], n=5)
+	assert sum(len(r) for r in res) == 60 and stated == []          # nothing stated yet
+	scores = [m.score for r in res for m in r]                     # plain fields: still nothing
+	assert stated == [] and len(scores) == 60
+	f = res[3][0].flow
+	assert f["type"] == "sparse" and len(stated) == 1
+	assert res[3][0].flow is f and len(stated) == 1                 # cached
+	assert res[3][0].to_json()["regions"] and len(stated) == 1
+	index.close()

@@ -96,6 +96,17 @@ def test_sharded_index(tmp_path):
 		ref[strategy] = shard_index_worker.answers(index, queries)
 	assert ref["align"][0][0][:2] == [1, 3] and abs(ref["align"][0][0][2] - 1.0) < 1e-2
 	assert ref["wrd"][0][0][3] == "dense" and ref["rwmd"][0][0][3] == "sparse"
+	# find_many on the sharded index: the batched calls (16 alignment queries / 256 relaxed-WMD queries per backend call, one
+	# all-gather per chunk) and the one-query-at-a-time pipeline (exchanges issued in query order) return what the unsharded
+	# index returns, flows included, on both ranks; progress is reported per chunk
+	ref["find_many"] = shard_index_worker.find_many_answers(None)
+	for strategy in ("align", "rwmd"):
+		assert any(len(rows) == 5 for rows in ref["find_many"][strategy])
+		assert ref["find_many"][strategy + "_pipelined"] == ref["find_many"][strategy][:9]
+		assert ref["find_many"][strategy + "_progress"][-1] == 1.0
+	assert ref["find_many"]["rwmd"][0][0][3] == "sparse"
 	for k in range(2):
 		got = json.load(open(tmp_path / f"index_rank{k}.json"))
+		# Query.abort raised on rank 1 only: no rank hangs in the collective, and the query yields no matches on either rank
+		assert got.pop("abort") == {"batched": [0] * 6, "pipelined": [0] * 6, "find": 0}
 		assert got == ref

@@ -70,7 +70,7 @@ class _QueryDesc(C.Structure):
 		("wrd_normalize_magnitudes", C.c_int32),
 		("tag_weights", C.c_void_p), ("q_pos", C.c_void_p), ("q_tags", C.c_void_p),
 		("pos_mismatch_penalty", C.c_float), ("similarity_threshold", C.c_float), ("wmd_full", C.c_int32),
-		("abort", C.c_void_p)]
+		("abort", C.c_void_p), ("only_slices", C.c_void_p), ("n_only", C.c_int32)]
 
 
 class _TopkOut(C.Structure):
@@ -150,7 +150,7 @@ def lib():
 		L.vk_record_words.argtypes = [C.c_int32]
 		L.vk_pack_records.argtypes = [C.POINTER(_TopkOut), C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
 		L.vk_merge_records.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_TopkOut)]
-		if L.vk_abi_version() != 8:
+		if L.vk_abi_version() != 9:
 			raise RuntimeError("libvectorian_hip.so ABI version mismatch")
 		_lib = L
 	return _lib
@@ -360,9 +360,10 @@ class Corpus:
 			q_token_ids=None, q_normalize=True, max_matches=10, min_score=0.0, boost=None, want_flow=True,
 			submatch_weight=0.0, bidirectional=False, rwmd=(True, True, True), wrd_normalize=True,
 			tag_weights=None, q_pos=None, q_tags=None, pos_mismatch_penalty=0.0, similarity_threshold=0.0, wmd_full=False,
-			abort_flag=None, want_rows=False):
+			abort_flag=None, want_rows=False, only_slices=None):
 		"""abort_flag: int32 array of one element another thread may set to 1 (Query.abort); want_rows: similarity rows of the
-		winners of an alignment query too (the debug hook's 'similarity')"""
+		winners of an alignment query too (the debug hook's 'similarity'); only_slices: state exactly these slices (in order)
+		instead of searching -- the debug hook's walk over every slice (vk_query_desc.only_slices)"""
 		q_vectors = np.ascontiguousarray(q_vectors)
 		if q_vectors.dtype == np.uint16:
 			qdt = VK_BF16
@@ -401,6 +402,11 @@ class Corpus:
 				raise TypeError("abort_flag must be an int32 array")
 			keep.append(abort_flag)
 			q.abort = _np_ptr(abort_flag)
+		if only_slices is not None:
+			only = np.ascontiguousarray(only_slices, dtype=np.int64)
+			keep.append(only)
+			q.only_slices, q.n_only = _np_ptr(only), len(only)
+			q.max_matches = max(1, len(only))
 		if tag_weights is not None:
 			tw = np.ascontiguousarray(tag_weights, dtype=np.float32)
 			qp = np.ascontiguousarray(q_pos if q_pos is not None else np.zeros(len_t), dtype=np.int8)

@@ -258,7 +258,7 @@ static int set_slices_impl(vk_corpus_t *c, const int64_t *start, const int64_t *
 	// of its own ([L, empty, empty, empty]); the group before it is closed with empty rows, so that no group of
 	// the main launch spans the tokens of a long slice.  Rows stay in slice order (ties are broken by row).
 	std::vector<int32_t> st32, en32, long_groups;
-	c->entry_sent.clear();
+	c->entry_sent.clear(); c->sent_entry.clear();
 	if (n_long == 0) {
 		st32.resize((size_t)n_sentences); en32.resize((size_t)n_sentences);
 		for (int64_t s = 0; s < n_sentences; s++) { st32[(size_t)s] = (int32_t)start[s]; en32[(size_t)s] = (int32_t)end[s]; }

@@ -84,6 +84,7 @@ struct vk_corpus {
 	// their group of 4 (padded with empty rows) and are scored by a second launch over d_long_groups.
 	int64_t n_entries = 0;
 	std::vector<int32_t> entry_sent;   // [n_entries] sentence of a row, -1 = padding; empty when the table is the identity
+	std::vector<int32_t> sent_entry;   // its inverse (row of a sentence), built when vk_query_desc.only_slices first needs it
 	int32_t *d_long_groups = nullptr;
 	int n_long_groups = 0, max_short_len = 0, long_group_tiles = 0, long_group_tokens = 0;
 	int uniform_len = 0;       // > 0: every sentence has exactly this many tokens

@@ -22,6 +22,13 @@ int vk_validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_topk_
 	if (out->capacity < q->max_matches) return fail(VK_ERR_INVALID, "output capacity smaller than max_matches");
 	if (!out->score || !out->sentence) return fail(VK_ERR_INVALID, "output arrays missing");
 	if (!(q->submatch_weight >= 0.0f)) return fail(VK_ERR_INVALID, "submatch_weight must be >= 0 (pow of a zero base, metric/alignment.h:97-99)");
+	if (q->only_slices) {
+		if (q->n_only < 1 || q->n_only > VK_MAX_MATCHES || q->n_only > out->capacity) return fail(VK_ERR_INVALID, "only_slices: n_only out of range (1 .. min(VK_MAX_MATCHES, capacity))");
+		if (q->algorithm != VK_ALG_ALIGN || !q->want_flow || q->submatch_weight != 0.0f)
+			return fail(VK_ERR_UNSUPPORTED, "only_slices states alignments with want_flow and submatch_weight = 0");
+		for (int i = 0; i < q->n_only; i++)
+			if (q->only_slices[i] < 0 || q->only_slices[i] >= c->desc.n_sentences) return fail(VK_ERR_INVALID, "only_slices: slice index out of range");
+	}
 	if (q->bidirectional) return fail(VK_ERR_UNSUPPORTED, "bidirectional is not implemented (unused upstream, query.cpp:81-83)");
 	if (q->algorithm == VK_ALG_ALIGN) {
 		if (q->locality < VK_LOCAL || q->locality > VK_SEMIGLOBAL) return fail(VK_ERR_INVALID, "bad locality");
@@ -112,6 +119,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	hipStream_t st = c->stream;
 	const int64_t n = c->n_entries;           // rows of the slice table (== n_sentences unless long slices were padded)
 	const int k = q->max_matches;
+	const bool only = q->only_slices != nullptr;   // state the listed slices: no scoring pass, no selection
 	out->n_out = 0;
 	c->have_scores = false;
 	if (n == 0) return VK_OK;
@@ -293,7 +301,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		int32_t ids[80];
 		for (int j = 0; j < 80; j++) ids[j] = (q->q_token_ids && j < q->len_t) ? q->q_token_ids[j] : -1;
 		VK_HIP(hipMemcpyAsync(c->d_qids, ids, sizeof ids, hipMemcpyHostToDevice, st));
-		for (int t = 0; t < nq; t++)   // one [V_pad x 16] table per 16 query tokens
+		for (int t = 0; t < nq && !only; t++)   // one [V_pad x 16] table per 16 query tokens (the traceback kernels restate their cells themselves)
 			VK_HIP(vk_launch_table(c->d_tiles, c->d_qtile + (size_t)t * c->tile_bytes, (int32_t)c->n_tiles, c->nk32, c->tail, c->tile_bytes,
 				c->d_table + t * table_stride, q->q_token_ids ? c->d_qids + t * 16 : nullptr, std::min(16, q->len_t - t * 16), c->desc.vocab_size, c->prec, st));
 	}
@@ -381,7 +389,8 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		if ((bound_pass || p.gap_mode == 7) && !two_blocks)
 			return fail(VK_ERR_UNSUPPORTED, "exact transport / 1:n RWMD with a query of more than 16 tokens: the multi-block kernel does not fit this corpus (LDS)");
 		if (p.gap_mode == 7) memcpy(wp.qmass, qmass_all, sizeof wp.qmass);
-		if (two_blocks) {
+		if (only) {
+		} else if (two_blocks) {
 			if (bound_pass) {
 				wp.gap_mode = 5;
 				wp.mag = q->algorithm == VK_ALG_WRD ? c->d_mag : nullptr;
@@ -412,7 +421,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		span_skip_raw = !(q->submatch_weight > 0.0f) && ((q->want_flow && is_align) || !p.boost || !out->raw_score);
 		VkScoreParams ps = p;
 		if (span_skip_raw) ps.raw = nullptr;
-		VK_HIP(vk_launch_span(&ps, st));
+		if (!only) VK_HIP(vk_launch_span(&ps, st));
 	} else {
 	p.max_short_len = VK_FAST_SENT_LEN;
 	// the aligner scores of all slices: read by the submatch bound and, without traceback, for the winners; with traceback the
@@ -450,8 +459,8 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	if (smem > 160 * 1024) return fail(VK_ERR_UNSUPPORTED, "LDS demand exceeds 160 KiB per workgroup");
 	const int64_t n_groups = (n + 3) / 4;
 	const int grid = (int)std::min<int64_t>((n_groups + 3) / 4, (int64_t)1 << 20);   // capped to residency by the launcher
-	VK_HIP(vk_launch_score(&p, grid, smem, st));
-	if (c->n_long_groups > 0) {
+	if (!only) VK_HIP(vk_launch_score(&p, grid, smem, st));
+	if (c->n_long_groups > 0 && !only) {
 		// slices longer than VK_FAST_SENT_LEN: one per wave, one wave per workgroup, LDS strip for the longest;
 		// general gaps take the LDS-history form (the four DPP rows share one history: only row 0 is active)
 		VkScoreParams pl = p;
@@ -724,10 +733,23 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	// scores are kept: exact unless more than kCanonMargin slices sit within rounding (~2e-6) of the k-th score.
 	const bool do_flow = q->want_flow && is_align;
 	constexpr int kCanonMargin = 8;
-	const int kk = !do_flow ? k : k <= 64 ? std::min(k + kCanonMargin, 64) : std::min(k + kCanonMargin, VK_MAX_MATCHES);
+	const int kk = only ? q->n_only : !do_flow ? k : k <= 64 ? std::min(k + kCanonMargin, 64) : std::min(k + kCanonMargin, VK_MAX_MATCHES);
 	const float sel_floor = do_flow ? q->min_score - 1e-5f * std::max(1.0f, std::fabs(q->min_score)) : q->min_score;
 	int cur = 0;
-	if (kk <= 64) {
+	if (only) {
+		// keys of the listed slices, in the caller's order (rows of the slice table: long slices sit in padded groups)
+		if (!c->entry_sent.empty() && c->sent_entry.empty()) {
+			c->sent_entry.assign((size_t)c->desc.n_sentences, -1);
+			for (int64_t e = 0; e < n; e++) if (c->entry_sent[(size_t)e] >= 0) c->sent_entry[(size_t)c->entry_sent[(size_t)e]] = (int32_t)e;
+		}
+		std::vector<uint64_t> hk((size_t)q->n_only);
+		for (int i = 0; i < q->n_only; i++) {
+			const int64_t row = c->sent_entry.empty() ? q->only_slices[i] : (int64_t)c->sent_entry[(size_t)q->only_slices[i]];
+			hk[(size_t)i] = (1ull << 32) | (uint64_t)(uint32_t)row;
+		}
+		VK_HIP(hipMemcpyAsync(c->d_keys[0], hk.data(), hk.size() * 8, hipMemcpyHostToDevice, st));
+		VK_HIP(hipStreamSynchronize(st));   // `hk` leaves scope
+	} else if (kk <= 64) {
 		// wave-streaming selection: n -> ceil(n/4096) * k keys -> ... -> k keys
 		int64_t nw = 0;
 		VK_HIP(vk_launch_topk_wave(c->d_scores, nullptr, n, sel_floor, kk, 4096, c->d_keys[0], &nw, st));
@@ -793,12 +815,14 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 			const float boost = q->boost ? q->boost[sentence_of(row)] : 1.0f;
 			val[(size_t)i] = (raw[(size_t)i] / ref) * boost;
 		}
-		order.erase(std::remove_if(order.begin(), order.end(), [&](int i) { return !(val[(size_t)i] > q->min_score); }), order.end());
-		std::sort(order.begin(), order.end(), [&](int a, int b) {   // the total order of the result set: score, then slice, descending
-			if (val[(size_t)a] != val[(size_t)b]) return val[(size_t)a] > val[(size_t)b];
-			return (uint32_t)(keys[(size_t)a] & 0xffffffffu) > (uint32_t)(keys[(size_t)b] & 0xffffffffu);
-		});
-		n_out = std::min((int)order.size(), k);
+		if (!only) {
+			order.erase(std::remove_if(order.begin(), order.end(), [&](int i) { return !(val[(size_t)i] > q->min_score); }), order.end());
+			std::sort(order.begin(), order.end(), [&](int a, int b) {   // the total order of the result set: score, then slice, descending
+				if (val[(size_t)a] != val[(size_t)b]) return val[(size_t)a] > val[(size_t)b];
+				return (uint32_t)(keys[(size_t)a] & 0xffffffffu) > (uint32_t)(keys[(size_t)b] & 0xffffffffu);
+			});
+		}
+		n_out = std::min((int)order.size(), only ? q->n_only : k);
 	}
 	std::vector<float> raw_sel((size_t)std::max(n_out, 1));
 	if (!do_flow && out->raw_score && n_out > 0) {
@@ -830,7 +854,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		}
 	}
 	out->n_out = n_out;
-	c->have_scores = true;
+	c->have_scores = !only;
 	if ((q->algorithm == VK_ALG_RWMD || (is_align && rows_on_request)) && n_out > 0) {
 		std::vector<int64_t> rows_idx;
 		for (int i = 0; i < n_out; i++) rows_idx.push_back((int64_t)(uint32_t)(keys[(size_t)order[(size_t)i]] & 0xffffffffu));

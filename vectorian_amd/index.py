@@ -279,24 +279,96 @@ def dense_flow(S, G, ids_s, ids_t, mass_t):
 	return {"type": "dense", "flow": flow, "dist": distv}
 
 
-class HipMatch(Match):
-	"""one winner of a search; what CoreMatch (vectorian/index.py:295-379) exposes, computed
-	from the C-ABI result arrays"""
+class _Winners:
+	"""the result set of one query as the arrays the backend returned; the HipMatch objects of the query index into it"""
+	__slots__ = ("index", "query", "top", "n", "sent", "docs", "starts", "ends", "gaps", "args", "qmag", "masks", "q_tag_codes", "transport")
 
-	def __init__(self, index, query, doc_index, slice_id, token_at, len_s, score, raw_score, mapping, edge_sim, gaps, transport_flow=None, index_map=None):
-		self._index_map = index_map   # token filter: position among the slice's passing tokens -> position in the slice
-		self._transport_flow = transport_flow   # callable -> flow dict of a transport metric (sparse / dense), or None
-		self._index = index
-		self._query = query
-		self._doc_index = doc_index
-		self._slice_id = slice_id
-		self._token_at = token_at
-		self._len_s = len_s
-		self._score = float(score)
-		self._raw_score = float(raw_score)
-		self._mapping = mapping
-		self._edge_sim = edge_sim
-		self._gaps = gaps
+	def __init__(self, index, query, top, gaps, args, qmag, masks, q_tag_codes):
+		self.index, self.query, self.top, self.gaps, self.args = index, query, top, gaps, args
+		self.qmag, self.masks, self.q_tag_codes = qmag, masks, q_tag_codes
+		self.n = n = top.n
+		self.sent = np.asarray(top.sentence[:n], dtype=np.int64)
+		self.docs = index._slice_doc[self.sent]
+		self.starts, self.ends = index._slice_start[self.sent], index._slice_end[self.sent]
+		self.transport = args is not None and args.get("algorithm", core.VK_ALG_ALIGN) != core.VK_ALG_ALIGN
+
+
+class HipMatch(Match):
+	"""one winner of a search; what CoreMatch (vectorian/index.py:295-379) exposes.  As CoreMatch, it holds a reference to the
+	native result (here: the result set's arrays, `_Winners`, and its place in them) and materialises flow, regions, omitted
+	tokens and the flows of transport metrics when they are asked for -- a batch of 256 queries returns 2,560 matches, and
+	building every flow eagerly cost four fifths of config 4's throughput at the operator level."""
+	__slots__ = ("_w", "_i", "_flow_cache", "_index_map_cache")
+
+	def __init__(self, winners, i):
+		self._w, self._i = winners, i
+		self._flow_cache = None
+		self._index_map_cache = False   # False: not computed yet (None is a value: no filter)
+
+	@property
+	def _index(self):
+		return self._w.index
+
+	@property
+	def _query(self):
+		return self._w.query
+
+	@property
+	def _doc_index(self):
+		return int(self._w.docs[self._i])
+
+	@property
+	def _slice_id(self):
+		return self._w.index._slice_id[int(self._w.sent[self._i])]
+
+	@property
+	def _token_at(self):
+		return self._w.index._slice_token_at[int(self._w.sent[self._i])]
+
+	@property
+	def _len_s(self):
+		return int(self._w.ends[self._i] - self._w.starts[self._i])
+
+	@property
+	def _mapping(self):
+		return self._w.top.mapping[self._i]
+
+	@property
+	def _edge_sim(self):
+		return self._w.top.edge_sim[self._i]
+
+	@property
+	def _gaps(self):
+		return self._w.gaps
+
+	@property
+	def _index_map(self):
+		"""token filter: position among the slice's passing tokens -> position in the slice (None: no filter)"""
+		if self._index_map_cache is False:
+			w = self._w
+			self._index_map_cache = w.index._index_map(int(w.sent[self._i]), w.masks) if w.masks else None
+		return self._index_map_cache
+
+	@property
+	def _transport_flow(self):
+		"""flow dict of a transport metric (sparse / dense), stated on first access; None for alignments"""
+		w = self._w
+		if not w.transport:
+			return None
+		if self._flow_cache is None:
+			i = self._i
+			state = w.index._transport_flow(w.query, w.top, i, int(w.sent[i]), w.args, w.qmag, self._index_map, w.q_tag_codes,
+				span=(int(w.starts[i]), int(w.ends[i])))
+			self._flow_cache = state() if state is not None else False
+		return self._flow_cache if self._flow_cache is not False else None
+
+	@property
+	def _score(self):
+		return float(self._w.top.score[self._i])
+
+	@property
+	def _raw_score(self):
+		return float(self._w.top.raw_score[self._i])
 
 	@property
 	def index(self):
@@ -332,7 +404,7 @@ class HipMatch(Match):
 		if isinstance(metric, dict) and metric.get("metric") == "alignment-tag-weighted":
 			weights = np.array([float(metric["tag_weights"].get(t, 1.0)) for t in self._query.tags], dtype=np.float32)
 		total = float(weights.sum())
-		if self._transport_flow is not None or w == 0.0 or total <= 0.0:
+		if self._w.transport or w == 0.0 or total <= 0.0:
 			return total
 		matched = float(weights[np.asarray(self._mapping[:len(weights)]) >= 0].sum())
 		return matched + ((total - matched) / total) ** w * (total - matched)
@@ -353,9 +425,7 @@ class HipMatch(Match):
 	def flow(self):
 		"""InjectiveFlow::to_py (vectorian/core/cpp/match/flow.cpp:190-216); per-edge values as
 		ScoreComputer fills them (metric/alignment.h:335-345)"""
-		if self._transport_flow is not None:
-			if callable(self._transport_flow):
-				self._transport_flow = self._transport_flow()
+		if self._w.transport:
 			return self._transport_flow
 		target = self._mapping.astype(np.int16)
 		matched = target >= 0
@@ -431,6 +501,22 @@ class HipMatch(Match):
 		if up_to > last_anchor:
 			regions.append(Region(s=text(last_anchor, up_to), match=None, gap_penalty=0.0))
 		return regions
+
+
+class AllSlices:
+	"""debug = AllSlices(hook): call the debug hook for EVERY slice the search scores, as the reference does (call_debug_hook,
+	vectorian/core/cpp/metric/alignment.h:145-173; match/matcher_impl.h:137-170), instead of for the k winners only.  The fused
+	scoring kernel keeps no per-slice matrices, so the slices are restated `chunk` at a time after the search: exact, opt-in, slow."""
+
+	all_slices = True
+
+	def __init__(self, hook, chunk=512):
+		if not callable(hook):
+			raise TypeError("debug must be callable: hook(name, data)")
+		self.hook, self.chunk = hook, int(chunk)
+
+	def __call__(self, name, data):
+		return self.hook(name, data)
 
 
 class Index:
@@ -574,6 +660,8 @@ class HipBruteForceIndex(Index):
 		else:
 			n_slices_dev, n_tokens_dev = n_slices, n_tokens
 		self._dev_boost = dev_boost
+		self._n_local, self._n_local_tokens, self._n_tokens = n_slices_dev, n_tokens_dev, n_tokens
+		self._xdev = None   # where exchanged records live: the process group's own device (RCCL: this GPU; gloo: the host)
 
 		make = corpus_factory or core.Corpus
 		emb = self._embedding
@@ -620,8 +708,8 @@ class HipBruteForceIndex(Index):
 		self._corpus.finalize()
 		self._max_slice_len = int((np.asarray(dev_end) - np.asarray(dev_start)).max()) if len(dev_start) else 0   # of the resident part
 		if shard is not None and hasattr(self._corpus, "_max_len") and n_slices:
-			# similarity rows / plans of transport winners are sized by the longest slice; the ranks exchange them (shards.allgather_merge),
-			# so every rank sizes them by the longest slice of the WHOLE corpus
+			# similarity rows / plans of transport winners are sized by the longest slice; the ranks exchange those of the merged winners
+			# (shards.rows_allreduce), so every rank sizes them by the longest slice of the WHOLE corpus
 			self._corpus._max_len = int((self._slice_end - self._slice_start).max())
 
 	@property
@@ -676,7 +764,7 @@ class HipBruteForceIndex(Index):
 				similarity_threshold=float(metric.get("similarity_threshold", 0)))
 		return args, gaps
 
-	def find_many(self, texts, n=10, min_score=0.0, options: dict = dict(), in_flight=3, abort=None, batch=None):
+	def find_many(self, texts, n=10, min_score=0.0, options: dict = dict(), in_flight=3, abort=None, batch=None, progress=None):
 		"""Several queries, `in_flight` of them at a time on as many handles of the resident corpus (vk_corpus_view:
 		shared arrays, own stream and workspaces) from as many host threads: the selection, traceback and host part of
 		one query run beside the scoring kernel of the next (bench.py measures the path this way).  Returns one Result
@@ -684,8 +772,12 @@ class HipBruteForceIndex(Index):
 		ThreadPool task per document inside a single find, vectorian/index.py:544-558).
 		batch: None (default) -- queries that can share a call do: over contextual embeddings, alignments go to the backend
 		several per call (vk_query_batch: every token tile is read once per pair of queries) and relaxed-WMD queries up to 256
-		per call (one MFMA-bound GEMM pass over the corpus per call, BASELINE config 4); False -- never; True -- or raise."""
-		from concurrent.futures import ThreadPoolExecutor
+		per call (one MFMA-bound GEMM pass over the corpus per call, BASELINE config 4); False -- never; True -- or raise.
+		A sharded index (shard = (rank, world)) takes the same paths: every rank scores its shard (batched calls included), the
+		result sets of a chunk of queries travel in ONE all-gather, issued in query order from the calling thread while the
+		worker threads score the next queries (the exchange bench.py times), and every rank returns the merged matches.
+		progress: called with done / total after every query (every chunk of a batched call) is complete, as the reference
+		reports done / total tokens after every document (vectorian/index.py:541-558)."""
 		session = self.session
 		queries = [self.make_query(t, n=n, min_score=min_score, options=options) for t in texts]
 		if abort is not None:
@@ -698,33 +790,65 @@ class HipBruteForceIndex(Index):
 		batches = self._batch_plan(queries, options) if batch is not False else None
 		if batch is True and batches is None:
 			raise RuntimeError("find_many(batch=True): these queries cannot share a call (static embeddings, filters, tag weights, "
-				"a debug hook, a sharded index, exact transport, or queries that differ in their options)")
-		if batches is not None:
-			return self._find_batches(queries, batches, in_flight)
-		sequential = self._shard is not None or self._filter_masks(options) is not None or in_flight < 2 or not hasattr(self._corpus, "view")
-		if sequential:
-			start = time.time()
-			return [session.make_result(self, self._find(q), duration=time.time() - start) for q in queries]
-		while len(self._views) < in_flight - 1:
-			self._views.append(self._corpus.view())
-		handles = [self._corpus] + self._views[:in_flight - 1]
+				"a debug hook, exact transport, or queries that differ in their options)")
 		start = time.time()
-
-		def run(i):
-			return self._find(queries[i], corpus=handles[i % len(handles)])
-		# query i goes to handle i % in_flight; a handle serves its queries in order (one worker thread per handle)
-		results = [None] * len(queries)
-		with ThreadPoolExecutor(max_workers=len(handles)) as pool:
-			def lane(h):
-				for i in range(h, len(queries), len(handles)):
-					results[i] = run(i)
-			list(pool.map(lane, range(len(handles))))
+		if batches is not None:
+			results = self._find_batches(queries, batches, in_flight, progress)
+		else:
+			results = self._find_pipelined(queries, in_flight, progress)
 		duration = (time.time() - start) / max(1, len(queries))
 		return [session.make_result(self, m, duration=duration) for m in results]
 
+	def _handles(self, n):
+		"""the resident corpus and n - 1 further handles on it (own stream and workspaces each)"""
+		if not hasattr(self._corpus, "view"):
+			return [self._corpus]
+		while len(self._views) < n - 1:
+			self._views.append(self._corpus.view())
+		return [self._corpus] + self._views[:max(0, n - 1)]
+
+	def _in_order(self, n_items, n_lanes, work, finish, group=1):
+		"""work(item, lane) on n_lanes worker threads (lane l serves items l, l + n_lanes, .. in order: a handle is used by one
+		thread); finish(first, outputs) on the CALLING thread for runs of `group` consecutive items, in item order -- the
+		collectives of a sharded index must be issued in the same order on every rank, whatever the threads' timing."""
+		from concurrent.futures import Future, ThreadPoolExecutor
+		futs = [Future() for _ in range(n_items)]
+
+		def lane(l):
+			for i in range(l, n_items, n_lanes):
+				try:
+					futs[i].set_result(work(i, l))
+				except BaseException as e:   # surfaces on the calling thread, in order
+					futs[i].set_exception(e)
+		with ThreadPoolExecutor(max_workers=max(1, n_lanes)) as pool:
+			for l in range(n_lanes):
+				pool.submit(lane, l)
+			for a in range(0, n_items, group):
+				finish(a, [futs[i].result() for i in range(a, min(a + group, n_items))])
+
+	def _find_pipelined(self, queries, in_flight, progress):
+		"""find_many, one vk_query per query: the local part on up to `in_flight` handles, the exchange (sharded) in query order"""
+		filtered = any(self._filter_masks(q.options) is not None for q in queries)
+		handles = self._handles(1 if (filtered or in_flight < 2) else in_flight)
+		results = [None] * len(queries)
+		done = [0]
+
+		def work(i, l):
+			return self._find_local(queries[i], corpus=handles[l] if not filtered else None)
+
+		def finish(first, locals_):
+			merged = self._merge_ranks(locals_)
+			for j, (loc, top) in enumerate(zip(locals_, merged)):
+				results[first + j] = self._finish_find(queries[first + j], loc, top)
+			done[0] += len(locals_)
+			if progress:
+				progress(done[0] / len(queries))
+		self._in_order(len(queries), len(handles), work, finish, group=4 if self._shard is not None else 1)
+		return results
+
 	def _batch_plan(self, queries, options):
 		"""chunks of queries that can go to the backend in one call each, or None"""
-		if (self._shard is not None or self._filter_masks(options) is not None or options.get("debug") is not None
+		if (self._filter_masks(options) is not None or options.get("debug") is not None
 				or not hasattr(self._corpus, "query_batch") or not self._embedding.is_contextual or len(queries) < 2):
 			return None
 		args, _ = self._backend_args(queries[0].options)
@@ -739,55 +863,93 @@ class HipBruteForceIndex(Index):
 			return None   # exact transport: per query (bound pass + solver rounds)
 		return [range(a, min(a + per_call, len(queries))) for a in range(0, len(queries), per_call)]
 
-	def _find_batches(self, queries, batches, in_flight):
-		"""find_many through vk_query_batch: the chunks of `batches` on up to two handles of the resident corpus"""
-		from concurrent.futures import ThreadPoolExecutor
-		session = self.session
+	def _find_batches(self, queries, batches, in_flight, progress=None):
+		"""find_many through vk_query_batch: the chunks of `batches` on up to two handles of the resident corpus; a sharded index
+		exchanges the result sets of a chunk in one all-gather (config 4 sharded: each rank's GEMM, one all-gather of 256 x k records)"""
 		emb = self._embedding
 		args, gaps = self._backend_args(queries[0].options)
 		prepared = [q.prepare(self._nlp) for q in queries]
-		n_handles = max(1, min(2, in_flight, len(batches))) if hasattr(self._corpus, "view") else 1
-		while len(self._views) < n_handles - 1:
-			self._views.append(self._corpus.view())
-		handles = [self._corpus] + self._views[:n_handles - 1]
+		handles = self._handles(max(1, min(2, in_flight, len(batches))))
 		results = [None] * len(queries)
-		start = time.time()
+		k = args["max_matches"]
+		done = [0]
 
-		def run(chunk, corpus):
-			idx = [i for i in chunk if len(prepared[i]) > 0]
-			for i in chunk:
-				if len(prepared[i]) == 0:
-					results[i] = []
-			if not idx:
-				return
+		def work(b, l):
+			"""local result sets of chunk b: (indices of its non-empty queries, their TopKs, aborted)"""
+			idx = [i for i in batches[b] if len(prepared[i]) > 0]
+			if not idx and self._shard is None:
+				return idx, [], False
 			qvs = [emb.encode_tokens(prepared[i].tokens) for i in idx]
 			try:
-				tops = corpus.query_batch([np.ascontiguousarray(qv.unmodified, dtype=np.float32) for qv in qvs], q_normalize=True,
-					boost=self._dev_boost, want_flow=True, abort_flag=queries[idx[0]]._abort, **args)
+				tops = handles[l].query_batch([np.ascontiguousarray(qv.unmodified, dtype=np.float32) for qv in qvs], q_normalize=True,
+					boost=self._dev_boost, want_flow=True, abort_flag=queries[idx[0]]._abort, **args) if idx else []
 			except core.VkError as e:
-				if e.status == core.VK_ERR_ABORTED:
-					for i in idx:
-						results[i] = []
-					return
-				raise
-			for i, qv, top in zip(idx, qvs, tops):
-				results[i] = self._matches_from_topk(prepared[i], top, gaps, args, None, None, None)   # (magnitudes: WRD only, which does not share calls)
+				if e.status != core.VK_ERR_ABORTED:
+					raise
+				# Query.abort: no matches -- on a sharded index this rank still joins the exchange (with empty result sets and the
+				# flag raised), or the ranks that did not see the flag in time would wait for it in the collective forever
+				return idx, [self._empty_top(len(prepared[i]), args) for i in idx], True
+			return idx, tops, False
 
-		def lane(h):
-			for b in range(h, len(batches), len(handles)):
-				run(batches[b], handles[h])
-		if len(handles) == 1:
-			lane(0)
-		else:
-			with ThreadPoolExecutor(max_workers=len(handles)) as pool:
-				list(pool.map(lane, range(len(handles))))
-		duration = (time.time() - start) / max(1, len(queries))
-		return [session.make_result(self, m, duration=duration) for m in results]
+		def finish(b, out):
+			(idx, tops, aborted), = out
+			merged = self._merge_ranks([dict(top=t, aborted=aborted, args=args) for t in tops])
+			for i in batches[b]:
+				results[i] = []
+			for i, top in zip(idx, merged):
+				if top is not None:
+					results[i] = self._matches_from_topk(prepared[i], top, gaps, args, None, None, None)   # (magnitudes: WRD only, which does not share calls)
+			done[0] += len(batches[b])
+			if progress:
+				progress(done[0] / len(queries))
+		self._in_order(len(batches), len(handles), work, finish)
+		return results
+
+	def _empty_top(self, len_t, args):
+		return core.TopK(max(1, args["max_matches"]), len_t)
+
+	def _merge_ranks(self, locals_):
+		"""local results (dicts of _find_local / _find_batches: top, aborted, args) -> the result sets `find` goes on with, None
+		for an aborted query.  One GPU: the local ones.  Sharded: ResultSet.extend across the ranks (result_set.h:70-93) -- ONE
+		all-gather of the k-record result sets of all the queries handed over (local slice ids -> global), every rank ending
+		with the same sets; the similarity rows / plans of transport winners follow in one all-reduce for the merged winners
+		only (shards.rows_allreduce), so that flows are stated as on one GPU.  A rank whose query was aborted joins with an
+		empty set and a flag: the query then yields no matches on any rank."""
+		live = [x for x in locals_ if x is not None]
+		if self._shard is None or not live:
+			return [None if (x is None or x["aborted"]) else x["top"] for x in locals_]
+		from vectorian_amd import shards
+		args = live[0]["args"]
+		k = args["max_matches"]
+		tops = [x["top"] for x in live]
+		h = shards.allgather_start(tops, self._slice_off, k, group=self._group, device=self._xdev,
+			flags=[shards.FLAG_ABORTED if x["aborted"] else 0 for x in live])
+		merged = shards.allgather_finish(h)
+		with_rows = [i for i, t in enumerate(tops) if getattr(t, "sim_rows", None) is not None]
+		if with_rows:
+			lens = [self._slice_end[merged[i].sentence[:merged[i].n]] - self._slice_start[merged[i].sentence[:merged[i].n]] for i in with_rows]
+			exact = args.get("algorithm") == core.VK_ALG_WRD or bool(args.get("wmd_full"))
+			shards.rows_allreduce([tops[i] for i in with_rows], [merged[i] for i in with_rows], self._slice_off, self._n_local, lens,
+				group=self._group, device=self._xdev, with_plan=exact)
+		out = iter(None if (f & shards.FLAG_ABORTED) else m for m, f in zip(merged, h["flags_out"]))
+		return [None if x is None else next(out) for x in locals_]
 
 	def _find(self, query, progress=None, corpus=None):
+		local = self._find_local(query, corpus=corpus)
+		if progress and local is not None:
+			progress(self._n_local_tokens / max(1, self._n_tokens))   # this process's tokens are scored (one GPU: all of them)
+		top, = self._merge_ranks([local])
+		matches = self._finish_find(query, local, top)
+		if progress:
+			progress(1.0)
+		return matches
+
+	def _find_local(self, query, corpus=None):
+		"""this process's part of a search: one vk_query against the resident corpus.  Returns None for an empty query, else a
+		dict with the local result set (`aborted`: Query.abort was seen -- no matches)"""
 		p_query = query.prepare(self._nlp)
 		if len(p_query) == 0:
-			return []
+			return None
 		args, gaps = self._backend_args(query.options)
 		tw = args.pop("tag_weighted", None)
 		if tw is not None:
@@ -815,38 +977,44 @@ class HipBruteForceIndex(Index):
 		hook = query.options.get("debug")
 		if hook is not None and not callable(hook):
 			raise TypeError("debug must be callable: hook(name, data)")   # query.cpp:73-75 casts to a py::object it later calls
+		call = dict(args)
 		if hook is not None:
-			args["want_rows"] = True
-		args["abort_flag"] = query._abort
+			call["want_rows"] = True
+		call["abort_flag"] = query._abort
+		if emb.is_static:
+			call["q_token_ids"] = p_query.token_ids
+		aborted = False
 		try:
-			if emb.is_static:
-				top = corpus.query(qv.unmodified, q_normalize=True, q_token_ids=p_query.token_ids,
-					boost=self._dev_boost, want_flow=True, **args)
-			else:
-				top = corpus.query(qv.unmodified, q_normalize=True, boost=self._dev_boost, want_flow=True, **args)
+			top = corpus.query(qv.unmodified, q_normalize=True, boost=self._dev_boost, want_flow=True, **call)
 		except core.VkError as e:
-			if e.status == core.VK_ERR_ABORTED:   # Query.abort: the matcher loop ends (match/matcher_impl.h:105), nothing was added
-				return []
-			raise
-		args.pop("abort_flag"); args.pop("want_rows", None)
-		if self._shard is not None:
-			# local slice ids -> global, then ResultSet.extend across the ranks; every rank gets the same set, the similarity
-			# rows / plans of transport winners travelling with their records, so that flows are stated as on one GPU
-			from vectorian_amd import shards
-			top = shards.allgather_merge(top, self._slice_off, args["max_matches"], group=self._group)
-		if progress:
-			progress(1.0)
-		qmag = np.asarray(qv.magnitudes, dtype=np.float32) if args.get("algorithm") == core.VK_ALG_WRD else None   # masses of the WRD flow
-		matches = self._matches_from_topk(p_query, top, gaps, args, qmag, masks, q_tag_codes)
+			if e.status != core.VK_ERR_ABORTED:   # Query.abort: the matcher loop ends (match/matcher_impl.h:105), nothing was added
+				raise
+			top, aborted = self._empty_top(len(p_query), args), True
+		call.pop("abort_flag")
+		return dict(p_query=p_query, top=top, aborted=aborted, args=args, call=call, gaps=gaps, qv=qv, masks=masks, q_tag_codes=q_tag_codes,
+			hook=hook, corpus=corpus)
+
+	def _finish_find(self, query, local, top):
+		"""matches of a (merged) result set; the debug hook"""
+		if local is None or top is None:
+			return []
+		args, p_query = local["args"], local["p_query"]
+		qmag = np.asarray(local["qv"].magnitudes, dtype=np.float32) if args.get("algorithm") == core.VK_ALG_WRD else None   # masses of the WRD flow
+		matches = self._matches_from_topk(p_query, top, local["gaps"], args, qmag, local["masks"], local["q_tag_codes"])
+		hook = local["hook"]
 		if hook is not None:
-			self._call_debug_hook(hook, p_query, top, matches, args)
+			if getattr(hook, "all_slices", False):
+				self._call_debug_hook_all_slices(hook, local, matches)
+			else:
+				self._call_debug_hook(hook, p_query, top, matches, args)
 		return matches
 
 	def _call_debug_hook(self, hook, p_query, top, matches, args):
 		"""the reference calls hook(name, data) for EVERY slice it scores (call_debug_hook, metric/alignment.h:145-173: slice,
 		similarity [len_s x len_t], flow, score = the aligner's score; WMD: 'alignment/word-movers-distance/make' with score and
-		worst_score, :600-607).  Here the scoring kernel keeps no per-slice matrices: the hook is called for the k winners, best
-		first, with the same keys; `similarity` is None for winners longer than the rows the backend returned (the oracle double: 64 tokens)."""
+		worst_score, :600-607).  The scoring kernel keeps no per-slice matrices; by default the hook is called for the k winners, best
+		first, with the same keys (`similarity` is None for winners longer than the rows the backend returned).  debug =
+		AllSlices(hook) walks every slice instead (_call_debug_hook_all_slices)."""
 		alg = args.get("algorithm", core.VK_ALG_ALIGN)
 		worst = float(matches[-1].score) if len(matches) >= args["max_matches"] else float(args["min_score"])
 		for i, m in enumerate(matches):
@@ -857,6 +1025,53 @@ class HipBruteForceIndex(Index):
 			if getattr(top, "sim_rows", None) is not None and m._len_s <= top.sim_rows.shape[1]:
 				sim = top.sim_rows[i][:m._len_s if m._index_map is None else len(m._index_map), :len(p_query)].copy()
 			hook("alignment", {"slice": m.slice_id, "similarity": sim, "flow": m.flow, "score": m.raw_score})
+
+	def _call_debug_hook_all_slices(self, hook, local, matches):
+		"""debug = AllSlices(hook): the hook contract of the reference in full -- one call per slice this process scores, in slice
+		order, with the reference's keys.  Alignments ('alignment': slice, similarity, flow, score; metric/alignment.h:145-173): the
+		slices are stated `hook.chunk` at a time by the traceback kernel (vk_query_desc.only_slices: aligner score, mapping, edge
+		similarities and the similarity rows, canonical arithmetic), whatever their score.  Relaxed WMD
+		('alignment/word-movers-distance/make': score, worst_score; :600-607): from the score vector of the search, with the worst
+		score of a result set filled in slice order as upstream fills it.  Opt-in and slow (a Python call per slice); a sharded
+		index walks its own slices on every rank.  Other strategies: the winners (as without AllSlices)."""
+		args, p_query, corpus = local["args"], local["p_query"], local["corpus"]
+		alg = args.get("algorithm", core.VK_ALG_ALIGN)
+		n_loc, off, len_t = self._n_local, self._slice_off, len(p_query)
+		if alg == core.VK_ALG_RWMD and not args.get("wmd_full"):
+			import heapq
+			scores = corpus.last_scores()
+			heap, k, floor = [], args["max_matches"], float(args["min_score"])
+			for g in range(n_loc):
+				sc = float(scores[g])
+				if not np.isfinite(sc):
+					continue   # empty slice: Spans::iterate skips it (document.h:160-162)
+				worst = heap[0] if len(heap) >= k else floor
+				hook("alignment/word-movers-distance/make", {"score": sc, "worst_score": worst, "slice": self._slice_id[off + g]})
+				if sc > worst:
+					heapq.heappush(heap, sc) if len(heap) < k else heapq.heapreplace(heap, sc)
+			return
+		if alg != core.VK_ALG_ALIGN or args.get("submatch_weight", 0.0) != 0.0:
+			return self._call_debug_hook(hook, p_query, local["top"], matches, args)
+		call = dict(local["call"], want_rows=True)
+		masks = local["masks"]
+		for a in range(0, n_loc, max(1, int(getattr(hook, "chunk", 512)))):
+			ids = np.arange(a, min(n_loc, a + max(1, int(getattr(hook, "chunk", 512)))), dtype=np.int64)
+			lens = self._slice_end[off + ids] - self._slice_start[off + ids]
+			ids = ids[lens > 0]   # Spans::iterate skips empty slices
+			if len(ids) == 0:
+				continue
+			top = corpus.query(local["qv"].unmodified, q_normalize=True, boost=self._dev_boost, want_flow=True, only_slices=ids, **call)
+			for i in range(top.n):
+				g = off + int(ids[i])
+				len_s = int(self._slice_end[g] - self._slice_start[g]) if not masks else len(self._index_map(g, masks))
+				if len_s < 1:
+					continue   # every token filtered out: the slice is not scored (FilteredSliceFactory, slice/static.h:366-416)
+				target = top.mapping[i].astype(np.int16)
+				matched = target >= 0
+				flow = {"type": "injective", "target": target, "flow": matched.astype(np.float32),
+					"dist": np.where(matched, 1.0 - top.edge_sim[i], 1.0).astype(np.float32)}
+				sim = top.sim_rows[i][:len_s, :len_t].copy() if len_s <= top.sim_rows.shape[1] else None
+				hook("alignment", {"slice": self._slice_id[g], "similarity": sim, "flow": flow, "score": float(top.raw_score[i])})
 
 	def _filter_masks(self, options):
 		"""pos_filter / tag_filter: lists of POS / tag names whose tokens are dropped from every slice for this query
@@ -927,28 +1142,11 @@ class HipBruteForceIndex(Index):
 		return state
 
 	def _matches_from_topk(self, p_query, top, gaps, args=None, qmag=None, masks=None, q_tag_codes=None):
-		n = top.n
-		if n == 0:
+		"""the matches of a result set: one shared `_Winners` and a two-word object per winner; everything else on access"""
+		if top.n == 0:
 			return []
-		transport = args is not None and args.get("algorithm", core.VK_ALG_ALIGN) != core.VK_ALG_ALIGN
-		# one conversion per field for all winners (a batch of 256 queries builds 2,560 matches)
-		sent_a = np.asarray(top.sentence[:n], dtype=np.int64)
-		sent = sent_a.tolist()
-		score, raw = top.score[:n].tolist(), top.raw_score[:n].tolist()
-		mapping, edge = top.mapping[:n].copy(), top.edge_sim[:n].copy()
-		docs = self._slice_doc[sent_a].tolist()
-		starts, ends = self._slice_start[sent_a].tolist(), self._slice_end[sent_a].tolist()
-		slice_id, token_at = self._slice_id, self._slice_token_at
-		matches = []
-		for i in range(n):
-			g = sent[i]
-			index_map = self._index_map(g, masks) if masks else None
-			matches.append(HipMatch(
-				self, p_query, docs[i], slice_id[g], token_at[g], ends[i] - starts[i],
-				score[i], raw[i], mapping[i], edge[i], gaps,
-				transport_flow=self._transport_flow(p_query, top, i, g, args, qmag, index_map, q_tag_codes, span=(starts[i], ends[i])) if transport else None,
-				index_map=index_map))
-		return matches
+		w = _Winners(self, p_query, top, gaps, args, qmag, masks, q_tag_codes)
+		return [HipMatch(w, i) for i in range(w.n)]
 
 	def close(self):
 		for c in list(self._filtered.values()) + self._views:

@@ -90,7 +90,10 @@ def unpack_topk(buf, len_t):
 	return t
 
 
-def allgather_start(tops, sentence_offset, k, group=None, device=None):
+FLAG_ABORTED = 1   # Query.abort() was seen by a rank: the query yields no matches on ANY rank (the ranks poll their flags at different times)
+
+
+def allgather_start(tops, sentence_offset, k, group=None, device=None, flags=None):
 	"""starts the exchange of this rank's result set(s) and returns a handle for allgather_finish; the collective runs
 	while the caller scores the next queries.  `tops` may be a list: the result sets of several queries then travel
 	in ONE all-gather (the records are tiny -- 1.3 KB per query at k = 10 -- and the exchange is latency-bound: per
@@ -110,6 +113,9 @@ def allgather_start(tops, sentence_offset, k, group=None, device=None):
 	rows = np.empty((len(tops) * k, _layout(tops[0].len_t)[1]), dtype=np.int32)
 	for i, t in enumerate(tops):
 		core.pack_records(t, sentence_offset, k, out=rows[i * k:(i + 1) * k])
+		# per-query flags of this rank ride in the spare last word of the query's first record (a record has three words of
+		# padding behind the edge similarities); allgather_finish ORs them over the ranks into handle["flags_out"]
+		rows[i * k, -1] = int(flags[i]) if flags is not None else 0
 	on_gpu = torch.device(device).type == "cuda"
 	if on_gpu:
 		# pinned staging on both sides and a stream of its own: no pageable copies, nothing on the default stream
@@ -151,6 +157,7 @@ def allgather_finish(handle):
 		handle["work"].wait()
 	world, k, n = handle["world"], handle["k"], handle["n"]
 	allr = handle["back"].numpy().reshape(world, n, k, -1)
+	handle["flags_out"] = [int(np.bitwise_or.reduce(allr[:, i, 0, -1])) for i in range(n)]
 	# ResultSet.extend over every rank's records, one native call per query (vk_merge_records)
 	out = [core.merge_records(np.ascontiguousarray(allr[:, i]), world, handle["len_t"][i], k) for i in range(n)]
 	return out[0] if handle["single"] else out
@@ -191,3 +198,56 @@ def allgather_merge(top, sentence_offset, k, group=None, device=None):
 			merged.sim_rows[i] = allp[r, j, 0].reshape(rows, w)
 			merged.plan[i] = allp[r, j, 1].reshape(w, rows)
 	return merged
+
+
+def rows_allreduce(local_tops, merged_tops, sentence_offset, n_local, lens, group=None, device=None, with_plan=False):
+	"""Second phase of a transport exchange: the similarity rows (and, exact transport, the optimal plans) of the MERGED winners,
+	each contributed by the rank that scored it -- what the host states a winner's SparseFlow / DenseFlow from (wmd.h:392-408,
+	228-248; wrd.h:120-135), so that flows read the same on every rank, whichever rank holds the slice.
+	One all_reduce(SUM) over [queries x k x R x W] floats (x 2 with plans), zeros wherever a rank has nothing to say: k winners
+	per query travel, not k per rank, and R is the longest MERGED winner, not the corpus's longest slice (`lens[i][j]`: tokens of
+	merged winner j of query i -- every rank holds the slice table and computes the same).  (Round 2 all-gathered k x 2 x R_max x W
+	per rank through pageable copies: 26 MB per rank and query at k = 100, R_max = 512.)
+	Sets merged_tops[i].sim_rows [k x R x W] and .plan [k x W x R]."""
+	import torch
+	import torch.distributed as dist
+
+	nq = len(merged_tops)
+	if nq == 0:
+		return
+	if device is None:
+		device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+	k = max(len(m.score) for m in merged_tops)
+	R = max([int(np.max(l)) if len(l) else 0 for l in lens] + [1])
+	W = max([t.sim_rows.shape[2] for t in local_tops if getattr(t, "sim_rows", None) is not None] + [16])
+	Wt = torch.tensor([W, R], dtype=torch.int64, device=device)
+	dist.all_reduce(Wt, op=dist.ReduceOp.MAX, group=group)   # a rank without winners knows no W of its own
+	W, R = int(Wt[0].item()), int(Wt[1].item())
+	buf = np.zeros((nq, k, 2 if with_plan else 1, R * W), dtype=np.float32)
+	for i, (loc, mer) in enumerate(zip(local_tops, merged_tops)):
+		if loc is None or getattr(loc, "sim_rows", None) is None or loc.n == 0:
+			continue
+		where = {int(sid): j for j, sid in enumerate(loc.sentence[:loc.n])}
+		w_l = loc.sim_rows.shape[2]
+		for j in range(mer.n):
+			g = int(mer.sentence[j]) - sentence_offset
+			if not (0 <= g < n_local) or g not in where:
+				continue
+			jl, ln = where[g], min(int(lens[i][j]), loc.sim_rows.shape[1], R)
+			rows = np.zeros((R, W), dtype=np.float32)
+			rows[:ln, :w_l] = loc.sim_rows[jl][:ln]
+			buf[i, j, 0] = rows.reshape(-1)
+			if with_plan and getattr(loc, "plan", None) is not None:
+				plan = np.zeros((W, R), dtype=np.float32)
+				plan[:w_l, :ln] = loc.plan[jl][:, :ln]
+				buf[i, j, 1] = plan.reshape(-1)
+	t = torch.from_numpy(buf)
+	on_gpu = torch.device(device).type == "cuda"
+	if on_gpu:
+		t = t.pin_memory().to(device, non_blocking=True)
+	dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+	allb = t.cpu().numpy() if on_gpu else t.numpy()
+	for i, mer in enumerate(merged_tops):
+		mer.sim_rows = np.ascontiguousarray(allb[i, :, 0]).reshape(k, R, W)
+		mer.plan = np.ascontiguousarray(allb[i, :, 1]).reshape(k, W, R) if with_plan else np.zeros((k, W, R), dtype=np.float32)
+
