@@ -5,6 +5,7 @@
 
 #include "vk_internal.h"
 
+#include <chrono>
 #include <thread>
 
 static bool same_gap(const vk_gap &a, const vk_gap &b, int upto) {
@@ -18,12 +19,20 @@ static bool same_gap(const vk_gap &a, const vk_gap &b, int upto) {
 // Similarity rows of the winners of a batch of relaxed-WMD queries, from which the host states their flows (SparseFlow,
 // alignment/wmd.h:392-408): one launch for all queries, every winner against its own query's tile.  keys: [n_queries x k] as
 // selected (0 = empty slot); outs[i].n_out set.
-static int batch_winner_rows(vk_corpus *c, const vk_query_desc *qs, int n_queries, vk_topk_out *outs, const uint64_t *keys, int k, hipStream_t st) {
+// packed16: the queries' 16-row tiles as vk_pack_query lays them out, tile_bytes apart, when the caller has packed them already
+// (the GEMM path: packing 256 queries a second time, on one thread, cost 12 ms per batch); null: packed here
+static int batch_winner_rows(vk_corpus *c, const vk_query_desc *qs, int n_queries, vk_topk_out *outs, const uint64_t *keys, int k, hipStream_t st,
+	const uint8_t *packed16 = nullptr) {
 	int rc;
 	bool any_rows = false;
 	for (int i = 0; i < n_queries; i++) any_rows |= qs[i].algorithm == VK_ALG_RWMD && qs[i].want_flow && outs[i].sim_rows && outs[i].n_out > 0;
 	if (!any_rows) return VK_OK;   // (winners of more than 64 tokens get zero rows from the kernel: their flows are not stated)
 	const size_t n_cand = (size_t)n_queries * (size_t)k;
+	const bool trace = getenv("VK_TRACE_BATCH") != nullptr;
+	const auto t_begin = std::chrono::steady_clock::now();
+	auto stamp = [&](const char *what) {
+		if (trace) fprintf(stderr, "[vk] batch_winner_rows %s: %.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+	};
 	if (c->bqt_cap < (size_t)n_queries) {
 		if (c->d_bqt) { VK_HIP(hipFree(c->d_bqt)); c->d_bqt = nullptr; }
 		if ((rc = alloc_t(c, &c->d_bqt, (size_t)n_queries * c->tile_bytes))) return rc;
@@ -37,22 +46,26 @@ static int batch_winner_rows(vk_corpus *c, const vk_query_desc *qs, int n_querie
 		if ((rc = alloc_t(c, &c->d_brows, n_cand * 64 * 16))) return rc;
 		c->bcand_cap = n_cand;
 	}
-	std::vector<uint8_t> qt((size_t)n_queries * c->tile_bytes, 0), one;
+	std::vector<uint8_t> qt, one;
 	std::vector<uint64_t> hk(n_cand, 0);
 	std::vector<int32_t> hq(n_cand, 0);
 	float mags[VK_MAX_QUERY_LEN];
+	if (!packed16) qt.assign((size_t)n_queries * c->tile_bytes, 0);
 	for (int i = 0; i < n_queries; i++) {
-		vk_pack_query(c, &qs[i], one, mags);
-		memcpy(qt.data() + (size_t)i * c->tile_bytes, one.data(), std::min(one.size(), (size_t)c->tile_bytes));
+		if (!packed16) {
+			vk_pack_query(c, &qs[i], one, mags);
+			memcpy(qt.data() + (size_t)i * c->tile_bytes, one.data(), std::min(one.size(), (size_t)c->tile_bytes));
+		}
 		for (int j = 0; j < k; j++) {
 			hq[(size_t)i * k + j] = i;
 			if (j < outs[i].n_out && qs[i].want_flow && outs[i].sim_rows)
 				hk[(size_t)i * k + j] = (1ull << 32) | (uint64_t)(uint32_t)(keys[(size_t)i * k + j] & 0xffffffffu);
 		}
 	}
-	VK_HIP(hipMemcpyAsync(c->d_bqt, qt.data(), qt.size(), hipMemcpyHostToDevice, st));
+	VK_HIP(hipMemcpyAsync(c->d_bqt, packed16 ? packed16 : qt.data(), (size_t)n_queries * c->tile_bytes, hipMemcpyHostToDevice, st));
 	VK_HIP(hipMemcpyAsync(c->d_bcand, hk.data(), n_cand * 8, hipMemcpyHostToDevice, st));
 	VK_HIP(hipMemcpyAsync(c->d_bcandq, hq.data(), n_cand * 4, hipMemcpyHostToDevice, st));
+	stamp("uploads issued");
 	VkWrdParams w{};
 	w.tiles = c->d_tiles; w.sent_start = c->d_sent_start; w.sent_end = c->d_sent_end;
 	w.layout = VK_DEV_LAYOUT_CONTEXTUAL; w.nk32 = c->nk32; w.tail = c->tail; w.tile_bytes = c->tile_bytes; w.prec = c->prec;
@@ -60,12 +73,22 @@ static int batch_winner_rows(vk_corpus *c, const vk_query_desc *qs, int n_querie
 	w.d = c->desc.d;   // canonical similarity rows (sim_canon)
 	w.keys = c->d_bcand; w.rows_out = c->d_brows;
 	VK_HIP(vk_launch_rows(&w, (int32_t)n_cand, st));
-	std::vector<float> rows(n_cand * 64 * 16);
-	VK_HIP(hipMemcpyAsync(rows.data(), c->d_brows, rows.size() * 4, hipMemcpyDeviceToHost, st));
+	// one copy into pinned host memory, then into the callers' arrays (copies into pageable memory go through the runtime's
+	// staging: 256 of them, one per query, took 5 - 30 ms; a zero-initialised std::vector as the bounce buffer 3 ms)
+	const size_t bytes = n_cand * 64 * 16 * 4;
+	if (c->h_brows_cap < bytes) {
+		if (c->h_brows) { VK_HIP(hipHostFree(c->h_brows)); c->h_brows = nullptr; c->h_brows_cap = 0; }
+		VK_HIP(hipHostMalloc((void **)&c->h_brows, bytes, hipHostMallocDefault));
+		c->h_brows_cap = bytes;
+	}
+	stamp("kernel issued");
+	VK_HIP(hipMemcpyAsync(c->h_brows, c->d_brows, bytes, hipMemcpyDeviceToHost, st));
 	VK_HIP(hipStreamSynchronize(st));
+	stamp("rows on the host");
 	for (int i = 0; i < n_queries; i++)
 		if (qs[i].algorithm == VK_ALG_RWMD && qs[i].want_flow && outs[i].sim_rows && outs[i].n_out > 0)
-			memcpy(outs[i].sim_rows, rows.data() + (size_t)i * k * 64 * 16, (size_t)outs[i].n_out * 64 * 16 * 4);
+			memcpy(outs[i].sim_rows, c->h_brows + (size_t)i * k * 64 * 16, (size_t)outs[i].n_out * 64 * 16 * 4);
+	stamp("copied out");
 	return VK_OK;
 }
 
@@ -430,6 +453,10 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 	VK_HIP(hipEventRecord(c->ev[0], st));
 	std::vector<uint8_t> all((size_t)need_q, 0);
 	std::vector<int32_t> qlen((size_t)n_queries);
+	// the queries' 16-row tiles are kept when the winners' similarity rows will be asked for (batch_winner_rows)
+	bool rows_wanted = false;
+	for (int i = 0; i < n_queries; i++) rows_wanted |= qs[i].want_flow && outs[i].sim_rows;
+	std::vector<uint8_t> tiles16(rows_wanted ? (size_t)n_queries * c->tile_bytes : 0, 0);
 	// normalise, round and lay out the queries: a few host threads over disjoint query ranges (256 queries: 1.6 ms on one)
 	auto pack_range = [&](int i0, int i1) {
 	std::vector<uint8_t> one;
@@ -437,6 +464,7 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 	for (int i = i0; i < i1; i++) {
 		vk_pack_query(c, &qs[i], one, mags);
 		qlen[(size_t)i] = qs[i].len_t;
+		if (!tiles16.empty()) memcpy(tiles16.data() + (size_t)i * c->tile_bytes, one.data(), std::min(one.size(), (size_t)c->tile_bytes));   // for the winners' rows
 		if (!b32) {
 			memcpy(all.data() + (size_t)i * c->tile_bytes, one.data(), one.size());
 			continue;
@@ -582,7 +610,7 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 		}
 		out->n_out = n_out;
 	}
-	if ((rc = batch_winner_rows(c, qs, n_queries, outs, keys.data(), k, st))) return rc;
+	if ((rc = batch_winner_rows(c, qs, n_queries, outs, keys.data(), k, st, tiles16.empty() ? nullptr : tiles16.data()))) return rc;
 	c->have_scores = false;
 	float ms = 0;
 	vk_timings t{};

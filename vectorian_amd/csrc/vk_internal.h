@@ -107,6 +107,7 @@ struct vk_corpus {
 	size_t rows_cap = 0;   // floats each of them holds
 	uint8_t *d_bqt = nullptr; uint64_t *d_bcand = nullptr; int32_t *d_bcandq = nullptr; float *d_brows = nullptr;   // similarity rows of a batch's winners
 	size_t bqt_cap = 0, bcand_cap = 0;
+	float *h_brows = nullptr; size_t h_brows_cap = 0;   // pinned host staging of the similarity rows of a batch's winners
 	uint32_t *d_qbits = nullptr;   // tag-weighted vocabulary transports over the static layout: bitmap of the query's token ids
 	uint8_t *d_wrdl_scratch = nullptr;   // exact transport, queries of 17..64 tokens over long slices: per-workgroup state
 	int rows_w = 0;              // columns per similarity row they are sized for (16, 32, 48 or 64)
