@@ -88,6 +88,27 @@ def test_exchange_records_native_against_numpy(len_t):
 		np.testing.assert_array_equal(getattr(got, f)[:got.n], getattr(ref, f)[:ref.n])
 
 
+def test_merge_survives_nan_scores_and_carries_flags():
+	# records arrive from other ranks unchecked: a NaN score must not break the sort (it ranks last); the per-query flag word
+	# (shards.allgather_start: the spare last word of a query's first record) is not part of a record's payload
+	from vectorian_amd import core, shards
+	k, len_t = 6, 10
+	recs = []
+	for r, scores in enumerate(([0.9, np.nan, 0.3], [0.8, 0.5], [np.nan])):
+		t = core.TopK(k, len_t)
+		t.n = len(scores)
+		t.score[:t.n] = scores
+		t.sentence[:t.n] = np.arange(t.n) + 10 * r
+		rec = shards.pack_topk(t, 0, k)
+		rec[0, -1] = 5            # a flag word
+		recs.append(rec)
+	for _ in range(20):            # std::sort over a broken order is undefined: run it a few times
+		got = core.merge_records(np.stack(recs), 3, len_t, k)
+	assert got.n == 6
+	assert list(got.score[:4]) == [np.float32(0.9), np.float32(0.8), np.float32(0.5), np.float32(0.3)]
+	assert got.score[4] == -np.inf and got.score[5] == -np.inf and sorted(int(x) for x in got.sentence[4:6]) == [1, 20]
+
+
 def test_struct_fields_agree_header_shim_and_integration_stub():
 	# the ctypes structures of the shim and of INTEGRATION.md's stub list the fields of the header's structs, in order
 	from vectorian_amd import core

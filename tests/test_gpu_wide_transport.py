@@ -16,7 +16,9 @@ pytestmark = pytest.mark.gpu
 	("wrd", dict(wrd_normalize=True)), ("wrd", dict(wrd_normalize=False)),
 	("wmd", dict(rwmd=(False, False, True), wmd_full=True)), ("wmd", dict(rwmd=(False, False, False), wmd_full=True)),
 ])
-@pytest.mark.parametrize("shape", [(128, 32, 32, 20), (96, 1, 40, 17), (64, 8, 64, 32), (300, 3, 50, 40), (64, 2, 64, 64)])
+# (768-d rows: the four query tiles of a 49..64-token query take 96 KB of LDS -- the multi-block kernel then runs two waves or one
+# wave per workgroup instead of four, vk_score32_waves; round 2 returned VK_ERR_UNSUPPORTED for these)
+@pytest.mark.parametrize("shape", [(128, 32, 32, 20), (96, 1, 40, 17), (64, 8, 64, 32), (300, 3, 50, 40), (64, 2, 64, 64), (768, 8, 64, 64), (768, 4, 40, 50)])
 def test_contextual_wide_transport(hip, oracle, shape, opts):
 	d, lo, hi, len_t = shape
 	alg, kw = opts
@@ -46,7 +48,7 @@ def test_contextual_wide_transport(hip, oracle, shape, opts):
 			s = int(got.sentence[i])
 			a, b = int(off[s]), int(off[s + 1])
 			S = oracle.sim_bf16(Xb[a:b], Qb)
-			np.testing.assert_allclose(got.sim_rows[i, :b - a, :len_t], S, atol=2e-6)
+			assert (got.sim_rows[i, :b - a, :len_t] == S).all()   # the winners' rows are restated in the oracle's arithmetic (sim_canon): bit for bit
 			G = got.plan[i, :len_t, :b - a].astype(np.float64)
 			assert not got.plan[i, len_t:].any() and not got.plan[i, :, b - a:].any()
 			raw = ((1.0 - np.maximum(1.0 - S.T, 0.0)) * G).sum() / G.sum()
@@ -76,3 +78,40 @@ def test_static_wide_transport(hip, oracle, len_t):
 		got = c.query(E[q_ids], q_token_ids=q_ids, algorithm=h_alg, q_normalize=True, max_matches=10, min_score=0.0, **kw)
 		assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=2e-5, tie_tol=2e-5)
 	c.close()
+
+
+def test_wide_rows_wide_query_fill_rwmd_and_the_limit(hip, oracle):
+	"""1:n RWMD (rwmd('nbow/distributed')) of a 64-token query over 768-d rows: no other kernel exists for this form, the
+	multi-block kernel runs with fewer waves per workgroup.  Rows too wide for even one wave's strip beside the query tiles are
+	refused by vk_validate_query (VK_ERR_UNSUPPORTED), before anything is enqueued."""
+	d, len_t, n = 768, 64, 400
+	corpus = synth.make_contextual_corpus(n, 8, 64, 1500, d, noise=0.3)
+	X, off = corpus["X"], corpus["sent_off"]
+	Xb, _ = oracle.normalize_rows_bf16(X)
+	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=d, n_tokens=X.shape[0], n_sentences=n, keep_magnitudes=True)
+	c.append_vectors(X, normalize=True)
+	c.set_sentences(off)
+	c.finalize()
+	for q in synth.make_queries(corpus, 2, len_t):
+		Qb, _ = oracle.normalize_rows_bf16(q["vectors"])
+		for flags in ((False, True, True), (False, False, True)):
+			ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=off, X=Xb, Q=Qb, algorithm=oracle.ALG_RWMD, rwmd=flags,
+				max_matches=8, min_score=-10.0, n_threads=8)
+			got = c.query(q["vectors"], algorithm=hip.VK_ALG_RWMD, rwmd=flags, q_normalize=True, max_matches=8, min_score=-10.0)
+			assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=2e-5, tie_tol=2e-5)
+	c.close()
+	# 2048-d fp32 rows: a query tile alone is 128 KB
+	d2 = 2048
+	rng = np.random.default_rng(2)
+	X2 = rng.standard_normal((600, d2)).astype(np.float32)
+	c2 = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=d2, n_tokens=600, n_sentences=20, keep_magnitudes=True, precision="f32")
+	c2.append_vectors(X2, normalize=True)
+	c2.set_sentences(np.arange(21, dtype=np.int64) * 30)
+	c2.finalize()
+	qv = rng.standard_normal((40, d2)).astype(np.float32)
+	with pytest.raises(hip.VkError) as e:
+		c2.query(qv, algorithm=hip.VK_ALG_WRD, q_normalize=True, max_matches=5)
+	assert e.value.status == hip.VK_ERR_UNSUPPORTED
+	assert c2.query(qv[:12], algorithm=hip.VK_ALG_WRD, q_normalize=True, max_matches=5).n == 5   # at most 16 tokens: fine
+	c2.close()
+

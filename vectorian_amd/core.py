@@ -27,6 +27,7 @@ VK_MEM_HOST, VK_MEM_DEVICE = 0, 1
 VK_LAYOUT_CONTEXTUAL, VK_LAYOUT_STATIC = 0, 1
 VK_ALG_ALIGN, VK_ALG_RWMD, VK_ALG_WRD = 0, 1, 2
 VK_GAP_LINEAR, VK_GAP_AFFINE, VK_GAP_TABLE = 0, 1, 2
+VK_ERR_INVALID, VK_ERR_UNSUPPORTED, VK_ERR_HIP, VK_ERR_NO_DEVICE, VK_ERR_STATE = 1, 2, 3, 4, 5
 VK_ERR_ABORTED = 6
 
 

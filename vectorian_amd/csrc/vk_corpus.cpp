@@ -234,6 +234,11 @@ int vk_corpus_set_token_pos(vk_corpus_t *c, const int8_t *pos, int64_t n, int32_
 }
 
 int vk_corpus_set_token_tags(vk_corpus_t *c, const int8_t *tags, int64_t n, int32_t mem) {
+	// The (token id, tag) vocabulary keys of tag-weighted transports are built as id * 256 + tag and must order like upstream's
+	// signed pairs (TaggedTokenFactory, alignment/bow.h:150-176): tag codes have to be 0 .. 127.  Host arrays are checked here.
+	if (c && tags && mem != VK_MEM_DEVICE && n == c->desc.n_tokens)
+		for (int64_t i = 0; i < n; i++)
+			if (tags[i] < 0) return fail(VK_ERR_INVALID, "tag codes must be 0 .. 127 (they key the vocabulary of tag-weighted transports as id * 256 + tag)");
 	return set_token_codes(c, c ? &c->d_tag : nullptr, tags, n, mem, "tag");
 }
 

@@ -264,7 +264,8 @@ size_t vk_wide_lds_demand(int32_t max_len, int32_t nq, int32_t gap_mode, int32_t
 hipError_t vk_launch_pack(const void *in, int32_t dtype_bf16, int64_t n_rows, int32_t d, int32_t d_pad, int64_t row0,
 	uint8_t *tiles, float *mag_out, int32_t normalize, int32_t prec, hipStream_t stream);
 // queries of 17..32 tokens, linear / affine gaps (vk_score32.hip)
-size_t vk_score32_lds_bytes(int32_t nk32, int32_t tail, int32_t max_pair_tiles, int32_t len_t, int32_t gap_mode);
+size_t vk_score32_lds_bytes(int32_t nk32, int32_t tail, int32_t max_pair_tiles, int32_t len_t, int32_t gap_mode, int32_t waves);
+int32_t vk_score32_waves(int32_t nk32, int32_t tail, int32_t max_pair_tiles, int32_t len_t, int32_t gap_mode);   // waves per workgroup that fit the LDS: 4, 2, 1 or 0 (none)
 hipError_t vk_launch_score32(const VkWideParams *p, int32_t max_pair_tiles, hipStream_t stream);
 // token filters (vk_filter.hip): temp == nullptr only sizes the scan's workspace
 hipError_t vk_launch_filter_scan(const int8_t *pos, const int8_t *tag, uint64_t pos_mask, uint64_t tag_mask, int64_t n,

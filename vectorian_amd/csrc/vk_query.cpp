@@ -5,12 +5,39 @@
 
 #include "vk_internal.h"
 
+// The multi-block kernel (vk_score32_kernel) for a query of 17..64 tokens: the gap mode it is launched with, the token tiles a
+// wave's strip spans, and whether the query tiles and at least one wave's strip fit the LDS of a CU (vk_score32_waves).  One
+// place for vk_validate_query and vk_query: exact transport and the 1:n RWMD have no other kernel for such queries, so a shape that
+// does not fit is refused before anything is enqueued -- with the gap mode of the launch, not a stand-in (round 2 tested mode 6 and
+// launched 5 or 7, whose strips are up to 1,280 bytes larger: a borderline shape failed in hipFuncSetAttribute instead).
+struct Score32Plan { int gap_mode, wave_tiles; bool fits, only_kernel; };
+static Score32Plan score32_plan(const vk_corpus *c, const vk_query_desc *q) {
+	const bool is_static = c->desc.layout == VK_LAYOUT_STATIC;
+	const bool bound_pass = q->algorithm == VK_ALG_WRD || (q->algorithm == VK_ALG_RWMD && q->wmd_full);
+	const bool fill = q->algorithm == VK_ALG_RWMD && !q->wmd_full && !q->rwmd_injective;
+	const int ks = q->gap_s.kind, kt = q->gap_t.kind;
+	int gm;
+	if (bound_pass) gm = 5;
+	else if (fill) gm = 7;
+	else if (q->algorithm == VK_ALG_RWMD) gm = 4;
+	else if (ks == VK_GAP_LINEAR && kt == VK_GAP_LINEAR) gm = 0;
+	else if (ks != VK_GAP_TABLE && kt != VK_GAP_TABLE) gm = 1;
+	else gm = c->max_len <= 32 ? 3 : 6;
+	const bool long_apart = (bound_pass || fill) && c->n_long_groups > 0;   // the long slices have kernels of their own
+	const int wave_tiles = long_apart ? (q->len_t <= 32 ? c->max_short_pair_tiles : (c->max_short_len + 15) / 16 + 1)
+		: (q->len_t <= 32 ? c->max_pair_tiles : (c->max_len + 15) / 16 + 1);
+	const bool fits = vk_score32_waves(is_static ? 0 : c->nk32, c->tail, wave_tiles, q->len_t, gm) >= 1;
+	return {gm, wave_tiles, fits, bound_pass || fill};
+}
+
 int vk_validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_topk_out *out) {
 	if (!c || !q || !out) return fail(VK_ERR_INVALID, "null argument");
 	if (!c->finalized) return fail(VK_ERR_STATE, "corpus not finalized");
 	if (q->len_t < 1) return fail(VK_ERR_INVALID, "empty query");
 	if (q->len_t > VK_MAX_QUERY_LEN) return fail(VK_ERR_UNSUPPORTED, "query longer than VK_MAX_QUERY_LEN (64) tokens");
 	const bool exact_tr = q->algorithm == VK_ALG_WRD || (q->algorithm == VK_ALG_RWMD && (q->wmd_full || !q->rwmd_injective));   // multi-block kernel + kernels of their own for the long slices: no wide kernel
+	if (q->len_t > VK_FAST_QUERY_LEN && exact_tr && !score32_plan(c, q).fits)
+		return fail(VK_ERR_UNSUPPORTED, "exact transport / 1:n RWMD with a query of more than 16 tokens: the query tiles of rows this wide and one wave's similarity strip exceed the LDS of a workgroup (160 KiB)");
 	if (q->len_t > VK_FAST_QUERY_LEN && !exact_tr) {
 		const int gm = q->algorithm == VK_ALG_RWMD ? 4 : (q->gap_s.kind == VK_GAP_TABLE || q->gap_t.kind == VK_GAP_TABLE) ? 2 : 1;
 		if (vk_wide_lds_demand(c->max_len, (q->len_t + 15) / 16, gm, q->tag_weights != nullptr, q->want_flow) > 160 * 1024)
@@ -49,6 +76,12 @@ int vk_validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_topk_
 			if (!q->q_pos) return fail(VK_ERR_INVALID, "tag-weighted query without q_pos");
 			if (!c->d_pos) return fail(VK_ERR_STATE, "tag-weighted query needs vk_corpus_set_token_pos");
 			if (q->similarity_threshold < 0.0f) return fail(VK_ERR_INVALID, "similarity_threshold must be >= 0 (slice/static.h:209)");
+			if (q->q_tags && c->desc.layout == VK_LAYOUT_STATIC) {
+				// vocabulary keys (token id, tag) as id * 256 + tag in 32 bits, ordered as upstream's signed pairs: ids below 2^23, tags 0 .. 127
+				if (c->desc.vocab_size > (1 << 23)) return fail(VK_ERR_UNSUPPORTED, "tag-weighted transport with q_tags over the static layout: vocabularies of more than 2^23 entries overflow the (id, tag) keys");
+				for (int j = 0; j < q->len_t; j++)
+					if (q->q_tags[j] < 0) return fail(VK_ERR_INVALID, "q_tags: tag codes must be 0 .. 127");
+			}
 			if (q->q_tags && !q->rwmd_injective && !q->wmd_full && c->desc.layout == VK_LAYOUT_STATIC && !c->d_tag)
 				return fail(VK_ERR_STATE, "tag-weighted 1:n RWMD over the static layout with q_tags needs vk_corpus_set_token_tags (its vocabulary is keyed by (token, tag), bow.h:150-176)");
 		}
@@ -381,11 +414,11 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		// exact transport over a corpus with long slices: the multi-block kernel skips them (their groups are padded, vk_corpus.cpp),
 		// vk_long_bound_kernel bounds them
 		const bool long_apart = (bound_pass || p.gap_mode == 7) && c->n_long_groups > 0;
-		const int wave_tiles = long_apart ? (q->len_t <= 32 ? c->max_short_pair_tiles : (c->max_short_len + 15) / 16 + 1)
-			: (q->len_t <= 32 ? c->max_pair_tiles : (c->max_len + 15) / 16 + 1);
+		const Score32Plan plan32 = score32_plan(c, q);
+		const int wave_tiles = plan32.wave_tiles;
 		const bool two_blocks = (is_align || rwmd_inj || bound_pass) && (long_apart || (c->n_long_groups == 0 &&
 			c->max_len <= VK_FAST_SENT_LEN)) && (rwmd_inj || bound_pass || p.gap_mode == 0 || (p.gap_mode == 1 && p.a_t >= 0.0f) || (p.gap_mode == 2 && wide_sub)) &&
-			vk_score32_lds_bytes(is_static ? 0 : c->nk32, c->tail, wave_tiles, q->len_t, 6) <= 160 * 1024 && (bound_pass || !getenv("VK_NO_SCORE32"));
+			plan32.fits && (bound_pass || p.gap_mode == 7 || !getenv("VK_NO_SCORE32"));
 		if ((bound_pass || p.gap_mode == 7) && !two_blocks)
 			return fail(VK_ERR_UNSUPPORTED, "exact transport / 1:n RWMD with a query of more than 16 tokens: the multi-block kernel does not fit this corpus (LDS)");
 		if (p.gap_mode == 7) memcpy(wp.qmass, qmass_all, sizeof wp.qmass);
@@ -879,8 +912,10 @@ int vk_merge_topk(const vk_topk_out *sets, int32_t n_sets, int32_t len_t, int32_
 	if (max_matches < 1 || out->capacity < max_matches) return fail(VK_ERR_INVALID, "output capacity smaller than max_matches");
 	struct Ref { float score; int64_t sent; int set, idx; };
 	std::vector<Ref> all;
+	// (a NaN score -- records arrive from other ranks unchecked -- would break the strict weak order std::sort needs: it ranks last,
+	// as -inf; the kernels never produce one, degenerate vectors score 0)
 	for (int s = 0; s < n_sets; s++)
-		for (int i = 0; i < sets[s].n_out; i++) all.push_back({sets[s].score[i], sets[s].sentence[i], s, i});
+		for (int i = 0; i < sets[s].n_out; i++) all.push_back({sets[s].score[i] == sets[s].score[i] ? sets[s].score[i] : -INFINITY, sets[s].sentence[i], s, i});
 	std::sort(all.begin(), all.end(), [](const Ref &a, const Ref &b) {
 		if (a.score != b.score) return a.score > b.score;
 		return a.sent > b.sent;
@@ -940,6 +975,7 @@ int vk_merge_records(const int32_t *records, int32_t n_sets, int32_t len_t, int3
 		if (!r[0]) continue;
 		Ref e;
 		memcpy(&e.score, r + 1, 4);
+		if (e.score != e.score) e.score = -INFINITY;   // NaN ranks last (see vk_merge_topk): a strict weak order whatever arrives
 		memcpy(&e.sent, r + 3, 8);
 		e.rec = r;
 		all.push_back(e);

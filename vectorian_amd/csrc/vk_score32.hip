@@ -389,6 +389,7 @@ __global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t
 	constexpr int LPS = 16 * NB, PER = 64 / LPS;   // lanes per slice, slices per wave
 	extern __shared__ float4 vk_smem32[];
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int nwv = blockDim.x >> 6;   // waves per workgroup: 4, or fewer when the query tiles of wide rows leave no room for four strips (vk_launch_score32)
 	// the NB query tiles (tokens 0..15, 16..31, ..) in LDS, shared by the block's waves
 	// (a half-filled last K-step takes 512 bytes, as in HBM: its lanes 32..63 re-read the slots of lanes 0..31 and meet zeros on the
 	// token side -- 1 KiB per workgroup that decides, at 32 query tokens, whether a third workgroup fits the CU)
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t
 	const int half = lane / LPS, col = lane & (LPS - 1);
 	const int n_pairs = (p.n_sent + PER - 1) / PER;
 	const int nfull = p.tail ? p.nk32 - 1 : p.nk32;
-	for (int pi = blockIdx.x * 4 + wv; pi < n_pairs; pi += gridDim.x * 4) {
+	for (int pi = blockIdx.x * nwv + wv; pi < n_pairs; pi += gridDim.x * nwv) {
 		const int s_idx = pi * PER + half;
 		const int i0 = s_idx < p.n_sent ? s_idx : p.n_sent;      // entries >= n_sent are empty slices (padding of the table)
 		const int t_a = p.sent_start[i0], t_b = p.sent_end[i0];
@@ -626,15 +627,27 @@ static inline int strip_slack(int gap_mode, int len_t) {
 
 // nk32 = 0: static layout (no query tiles in LDS); tiles: token tiles a wave's slices span (two consecutive slices for
 // queries of at most 32 tokens, one slice beyond)
-extern "C" size_t vk_score32_lds_bytes(int32_t nk32, int32_t tail, int32_t tiles, int32_t len_t, int32_t gap_mode) {
+// waves: waves per workgroup (each with a strip of its own)
+extern "C" size_t vk_score32_lds_bytes(int32_t nk32, int32_t tail, int32_t tiles, int32_t len_t, int32_t gap_mode, int32_t waves) {
 	const int nb = len_t <= 32 ? 2 : 4;
-	return (size_t)nb * (nk32 * 1024 - (tail && nk32 > 0 ? 512 : 0)) + (size_t)4 * ((size_t)tiles * 16 * strip_stride(len_t) + strip_slack(gap_mode, len_t)) * 4;
+	return (size_t)nb * (nk32 * 1024 - (tail && nk32 > 0 ? 512 : 0)) + (size_t)waves * ((size_t)tiles * 16 * strip_stride(len_t) + strip_slack(gap_mode, len_t)) * 4;
+}
+
+// waves per workgroup of the launch: 4 when the LDS of a CU holds the query tiles and four strips; wide rows (768-d: four query tiles of
+// 24 KB for a query of 49..64 tokens) leave room for 2 or 1 -- slower, but exact transport and the 1:n RWMD have no other kernel for
+// such queries (round 2 returned VK_ERR_UNSUPPORTED there).  0: not even one strip fits.
+extern "C" int32_t vk_score32_waves(int32_t nk32, int32_t tail, int32_t tiles, int32_t len_t, int32_t gap_mode) {
+	for (int w = 4; w >= 1; w >>= 1)
+		if (vk_score32_lds_bytes(nk32, tail, tiles, len_t, gap_mode, w) <= 160 * 1024) return w;
+	return 0;
 }
 
 extern "C" hipError_t vk_launch_score32(const VkWideParams *p, int32_t tiles, hipStream_t stream) {
 	const bool is_static = p->layout == VK_DEV_LAYOUT_STATIC;
 	const bool four = p->len_t > 32;   // 33..64 tokens: one slice per wave, four column blocks (linear / affine gaps)
-	const size_t smem = vk_score32_lds_bytes(is_static ? 0 : p->nk32, p->tail, tiles, p->len_t, p->gap_mode);
+	const int waves = vk_score32_waves(is_static ? 0 : p->nk32, p->tail, tiles, p->len_t, p->gap_mode);
+	if (waves < 1) return hipErrorInvalidValue;
+	const size_t smem = vk_score32_lds_bytes(is_static ? 0 : p->nk32, p->tail, tiles, p->len_t, p->gap_mode, waves);
 	void (*kernel)(VkWideParams, int32_t, int32_t, int32_t);
 	switch (p->gap_mode) {
 	case 0: kernel = four ? (is_static ? vk_score32_kernel<0, true, 4> : vk_score32_kernel<0, false, 4>)
@@ -658,7 +671,7 @@ extern "C" hipError_t vk_launch_score32(const VkWideParams *p, int32_t tiles, hi
 		if (e != hipSuccess) return e;
 	}
 	int occ = 0;
-	e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, smem);
+	e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 64 * waves, smem);
 	if (e != hipSuccess) return e;
 	if (occ < 1) occ = 1;
 	const char *ov = getenv("VK_BLOCKS_PER_CU");   // read per launch: tools/sweep_dims.py varies it inside one process
@@ -666,9 +679,9 @@ extern "C" hipError_t vk_launch_score32(const VkWideParams *p, int32_t tiles, hi
 	int dev = 0, cus = 256;
 	if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
 	const int per = four ? 1 : 2;
-	const int want = (int)((((int64_t)p->n_sent + per - 1) / per + 3) / 4);
+	const int want = (int)((((int64_t)p->n_sent + per - 1) / per + waves - 1) / waves);
 	const int grid = want < cus * occ ? (want > 0 ? want : 1) : cus * occ;
-	kernel<<<grid, 256, smem, stream>>>(*p, tiles * 16, strip_stride(p->len_t), strip_slack(p->gap_mode, p->len_t));
+	kernel<<<grid, 64 * waves, smem, stream>>>(*p, tiles * 16, strip_stride(p->len_t), strip_slack(p->gap_mode, p->len_t));
 	return hipGetLastError();
 }
 
