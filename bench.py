@@ -23,6 +23,7 @@ form -- workload texts, phases, traffic sources, every entry's full roofline -- 
   4     256 queries x 1 M x 32 x 300-d, relaxed WMD rwmd('nbow'), one GEMM-shaped pass     (MFMA-bound)
   5     1 M sentences of 8..64 tokens x 768-d per GPU, WSB local alignment                  (config 5 = 4 M over 4 GPUs)
   5wrd  the same corpus, Word Rotator's Distance (bound pass + exact EMD of the survivors)
+  5rwmd the same corpus, a batch of 256 relaxed-WMD queries (the GEMM-shaped pass over 768-d rows)
   2f32  config 2 with fp32 unit rows (VK_PREC_F32: the reference's own precision, twice the bytes)
   2static  config 2's query over 4 M sentences in the reference's static layout (token ids + per-query table; DP-issue bound)
 """
@@ -53,6 +54,10 @@ WORKLOADS = {
 		noise=0.3, norm_sigma=0.25, magnitudes=True),
 	"5wrd": dict(name="config5_wrd", n_sent=1000000, min_len=8, max_len=64, d=768, alg="wrd", locality="local", gap="linear", prec="bf16",
 		noise=0.3, norm_sigma=0.25, magnitudes=True),
+	# config 5's corpus under a batch of 256 relaxed-WMD queries: the GEMM-shaped pass over 768-d rows (round 3: the 32-row kernels with
+	# one fat wave per SIMD; the 16-row kernel of round 2 ran at 0.64 G pairs/s)
+	"5rwmd": dict(name="config5_rwmd_batch", n_sent=1000000, min_len=8, max_len=64, d=768, alg="rwmd", locality="local", gap="linear", prec="bf16",
+		noise=0.3, norm_sigma=0.25, magnitudes=True, batch=256),
 	"2f32": dict(name="config2_f32", n_sent=1000000, min_len=32, max_len=32, d=300, alg="align", locality="local", gap="exp5", prec="f32"),
 	# the reference's own layout for static embeddings (fastText / GloVe: token ids + vocabulary table, per-query table [V x |q|],
 	# StaticEmbeddingSlice, slice/static.h:71-75): no vectors are streamed, the kernel is bound by the DP's instruction issue
@@ -436,7 +441,7 @@ def main():
 	ap.add_argument("--no-cpu-baseline", action="store_true")
 	ap.add_argument("--no-pipeline", action="store_true", help="one handle, one query at a time")
 	ap.add_argument("--no-extra", action="store_true", help="headline workload only (no \"configs\" object)")
-	ap.add_argument("--extra", default="4,3,2f32,2static,2shared,5,5wrd", help="the other configurations timed at N = 1 after the headline")
+	ap.add_argument("--extra", default="4,3,2f32,2static,2shared,5,5wrd,5rwmd", help="the other configurations timed at N = 1 after the headline")
 	ap.add_argument("--extra-steps", type=int, default=12)
 	ap.add_argument("--extra-warmup", type=int, default=4)
 	ap.add_argument("--extra-min-ms", type=float, default=300.0, help="the extra configurations run at least this long inside their timed region")

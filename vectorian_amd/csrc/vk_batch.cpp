@@ -407,8 +407,11 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 	int rc;
 
 	// 32-token sentences take the 32x32x16 kernel: 3 queries of <= 10 tokens (else 2 of <= 16) share one 32-row A tile
-	bool b32 = uniform16 && c->uniform_len == 32 && c->nk32 <= 10;   // (768-d rows: the 16-row kernel, one wave per SIMD)
-	const int gran = c->nk32 <= 10 ? 2 : 1;   // ragged corpora: bucket step in tiles
+	// (768-d rows, round 3: the same kernels with four waves per workgroup, one per SIMD -- a wave's 64 token columns take 384
+	// registers; the 16-row kernel used 10 of its 16 A rows and ran at 0.64 G pairs/s.  VK_BATCH_WIDE16=1 keeps the old path for A/B runs)
+	const bool wide32 = c->nk32 == 24 && c->tail == 0 && !getenv("VK_BATCH_WIDE16");
+	bool b32 = uniform16 && c->uniform_len == 32 && (c->nk32 <= 10 || wide32);
+	const int gran = (c->nk32 <= 10 || wide32) ? 2 : 1;   // ragged corpora: bucket step in tiles
 	if (!uniform16 && (rc = build_batch_layout(c, gran))) return rc;
 	const bool r32 = !uniform16 && gran == 2;   // ragged, on the 32x32x16 kernels
 	b32 = b32 || r32;                           // query tiles packed for them
@@ -549,7 +552,7 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 	p.boost = qs[0].boost ? c->d_boost : nullptr;
 	p.scores = c->d_bscores;
 	p.n_qtiles = n_qtiles; p.qpt = qpt; p.q_inv_len = d_qinv; p.q_param = d_qparam; p.dense = dense ? 1 : 0;
-	p.late_mask = 4;   // waves w and w + 4 of a workgroup share a SIMD
+	p.late_mask = wide32 ? 0 : 4;   // waves w and w + 4 of a workgroup share a SIMD (768-d rows: one wave per SIMD, nobody to alternate with)
 	if (const char *e = getenv("VK_BATCH32_LATE_MASK")) p.late_mask = atoi(e);   // tuning aid
 	if (b32 && !r32) VK_HIP(vk_launch_rwmd_batch32(&p, st));
 	else if (uniform16) VK_HIP(vk_launch_rwmd_batch(&p, st));

@@ -315,7 +315,7 @@ __device__ __forceinline__ int row_transpose_imax16(const int (&v)[16], int lane
 // and retired by the barrier that ends the iteration.  (Fetched into registers after the first MFMA pairs and written with
 // ds_write_b128 before the last ones, the same bytes cost the same time and 8 registers: measured, not kept.  Without the
 // staging at all the kernel takes 10 % less: what costs is moving 100 GB per batch from L2 into the CUs, not issuing it.)
-template <int NK16>
+template <int NK16, int NW = 8>
 __device__ __forceinline__ void batch32_mfma(const uint8_t *cur, const bf16x8 (&x)[2][NK16], f32x16 &acc0, f32x16 &acc1,
 	const uint8_t *next_src /* wave-uniform */, unsigned lane16, const uint8_t *next_dst, int wv) {
 #ifdef VK_DEPTH
@@ -347,7 +347,7 @@ __device__ __forceinline__ void batch32_mfma(const uint8_t *cur, const bf16x8 (&
 #if !defined(VK_ABL) || VK_ABL < 4
 		if (t == 0) {
 #pragma unroll
-			for (int b = wv; b < NK16; b += 8)   // wave-uniform piece base (scalar registers) + the lane's 32-bit offset: no 64-bit vector addresses
+			for (int b = wv; b < NK16; b += NW)   // wave-uniform piece base (scalar registers) + the lane's 32-bit offset: no 64-bit vector addresses
 				__builtin_amdgcn_global_load_lds((vk_glb_ptr)(next_src + b * 1024 + lane16), (vk_lds_ptr)(next_dst + b * 1024), 16, 0, 0);
 		}
 #endif
@@ -460,18 +460,20 @@ __device__ __forceinline__ void batch32_store(const VkRwmdBatchParams &p, int qt
 	}
 }
 
-template <int NK16, int QPT, bool W64>
-__global__ __launch_bounds__(512) void vk_rwmd_batch32_kernel(VkRwmdBatchParams p) {
+// NW: waves per workgroup -- 8 (two per SIMD, 256 registers each) for rows of up to 304 features; 4 (one per SIMD, up to 512
+// registers) for 768-d rows, whose 64 token columns per wave take 384 registers
+template <int NK16, int QPT, bool W64, int NW = 8>
+__global__ __launch_bounds__(64 * NW) void vk_rwmd_batch32_kernel(VkRwmdBatchParams p) {
 	constexpr int QT_BYTES = NK16 * 1024;
 	extern __shared__ float4 vk_smem4[];
 	const uint8_t *qbuf = reinterpret_cast<const uint8_t *>(vk_smem4);
 	float *param = reinterpret_cast<float *>(vk_smem4) + 2 * QT_BYTES / 4;   // [n_qtiles][8]: len of the tile's 3 queries, pad, 1 / len, pad
 	const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int n32 = lane & 31, h = lane >> 5;
-	constexpr int SPC = W64 ? 8 : 16;              // sentences per chunk (workgroup)
+	constexpr int SPC = W64 ? NW : 2 * NW;         // sentences per chunk (workgroup)
 	const int64_t n_chunks = ((int64_t)p.n_sent + SPC - 1) / SPC;
 	const int64_t stride = p.score_stride > 0 ? p.score_stride : p.n_sent;
-	for (int i = threadIdx.x; i < p.n_qtiles * 8; i += 512) param[i] = p.q_param[i];
+	for (int i = threadIdx.x; i < p.n_qtiles * 8; i += 64 * NW) param[i] = p.q_param[i];
 	// The two waves that share a SIMD (w and w + 4 of the workgroup) run the two halves of an interval in
 	// opposite order: the "late" wave first finishes the epilogue of the previous tile (VALU) while the
 	// other one issues its MFMAs, then they swap.  Barriers would otherwise keep all waves in phase:
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(512) void vk_rwmd_batch32_kernel(VkRwmdBatchParams 
 	const bool late = (wv & p.late_mask) != 0;
 
 	for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-		const int64_t sent = W64 ? chunk * 8 + wv : chunk * 16 + wv * 2 + (n32 >> 4);   // this lane's sentence
+		const int64_t sent = W64 ? chunk * NW + wv : chunk * (2 * NW) + wv * 2 + (n32 >> 4);   // this lane's sentence
 		const bool have = sent < p.n_sent;
 		const int slen = have ? (p.sent_len ? p.sent_len[sent] : (W64 ? 64 : 32)) : 1;
 		const int64_t sout = have ? (p.sent_id ? (int64_t)p.sent_id[sent] : sent) : 0;   // where its scores go
@@ -499,7 +501,7 @@ __global__ __launch_bounds__(512) void vk_rwmd_batch32_kernel(VkRwmdBatchParams 
 		}
 		__syncthreads();   // previous chunk's readers are done with the LDS slots
 #pragma unroll
-		for (int b = wv; b < NK16; b += 8)
+		for (int b = wv; b < NK16; b += NW)
 			__builtin_amdgcn_global_load_lds((vk_glb_ptr)(p.qtiles + b * 1024 + lane * 16), (vk_lds_ptr)(qbuf + b * 1024), 16, 0, 0);
 		__syncthreads();
 
@@ -515,11 +517,11 @@ __global__ __launch_bounds__(512) void vk_rwmd_batch32_kernel(VkRwmdBatchParams 
 				// the scores of the previous tile leave now, not at the end of its iteration: the barrier there waits for
 				// every outstanding memory operation of the wave (vmcnt(0) for the LDS-DMA), stores to HBM included
 				if (qt > 0) batch32_store<QPT>(p, qt - 1, store_lane, lane_off, lane, pend, stride);
-				batch32_mfma<NK16>(cur, x, acc0, acc1, next_src, (unsigned)lane * 16u, next_dst, wv);
+				batch32_mfma<NK16, NW>(cur, x, acc0, acc1, next_src, (unsigned)lane * 16u, next_dst, wv);
 				pend = batch32_epilogue<QPT, W64>(p, lane, acc0, acc1, param + qt * 8, boost, sn);
 			} else {
 				if (qt > 0) batch32_store<QPT>(p, qt - 1, store_lane, lane_off, lane, batch32_epilogue<QPT, W64>(p, lane, acc0, acc1, param + (qt - 1) * 8, boost, sn), stride);
-				batch32_mfma<NK16>(cur, x, acc0, acc1, next_src, (unsigned)lane * 16u, next_dst, wv);
+				batch32_mfma<NK16, NW>(cur, x, acc0, acc1, next_src, (unsigned)lane * 16u, next_dst, wv);
 			}
 #if !defined(VK_ABL) || VK_ABL < 6
 			__syncthreads();   // next query tile is in place; this one may be overwritten
@@ -635,8 +637,8 @@ __device__ __forceinline__ void batch32d_store_k(int K, const VkRwmdBatchParams 
 	}
 }
 
-template <int NK16, bool W64>
-__global__ __launch_bounds__(512) void vk_rwmd_batch32d_kernel(VkRwmdBatchParams p) {
+template <int NK16, bool W64, int NW = 8>
+__global__ __launch_bounds__(64 * NW) void vk_rwmd_batch32d_kernel(VkRwmdBatchParams p) {
 	constexpr int QT_BYTES = NK16 * 1024;
 	extern __shared__ float4 vk_smem4[];
 	const uint8_t *qbuf = reinterpret_cast<const uint8_t *>(vk_smem4);
@@ -644,14 +646,14 @@ __global__ __launch_bounds__(512) void vk_rwmd_batch32d_kernel(VkRwmdBatchParams
 	const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int n32 = lane & 31, h = lane >> 5;
 	const int n_super = p.n_qtiles / 5;
-	constexpr int SPC = W64 ? 8 : 16;              // sentences per chunk (workgroup)
+	constexpr int SPC = W64 ? NW : 2 * NW;         // sentences per chunk (workgroup)
 	const int64_t n_chunks = ((int64_t)p.n_sent + SPC - 1) / SPC;
 	const int64_t stride = p.score_stride > 0 ? p.score_stride : p.n_sent;
-	for (int i = threadIdx.x; i < n_super * 32; i += 512) param[i] = p.q_param[i];
+	for (int i = threadIdx.x; i < n_super * 32; i += 64 * NW) param[i] = p.q_param[i];
 	const bool late = (wv & p.late_mask) != 0;   // see vk_rwmd_batch32_kernel
 
 	for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-		const int64_t sent = W64 ? chunk * 8 + wv : chunk * 16 + wv * 2 + (n32 >> 4);   // this lane's sentence
+		const int64_t sent = W64 ? chunk * NW + wv : chunk * (2 * NW) + wv * 2 + (n32 >> 4);   // this lane's sentence
 		const bool have = sent < p.n_sent;
 		const int slen = have ? (p.sent_len ? p.sent_len[sent] : (W64 ? 64 : 32)) : 1;
 		const int64_t sout = have ? (p.sent_id ? (int64_t)p.sent_id[sent] : sent) : 0;
@@ -670,7 +672,7 @@ __global__ __launch_bounds__(512) void vk_rwmd_batch32d_kernel(VkRwmdBatchParams
 		}
 		__syncthreads();   // previous chunk's readers are done with the LDS slots
 #pragma unroll
-		for (int b = wv; b < NK16; b += 8)
+		for (int b = wv; b < NK16; b += NW)
 			__builtin_amdgcn_global_load_lds((vk_glb_ptr)(p.qtiles + b * 1024 + lane * 16), (vk_lds_ptr)(qbuf + b * 1024), 16, 0, 0);
 		__syncthreads();
 
@@ -685,11 +687,11 @@ __global__ __launch_bounds__(512) void vk_rwmd_batch32d_kernel(VkRwmdBatchParams
 			const uint8_t *next_dst = qbuf + ((qt + 1) & 1) * QT_BYTES;
 			if (!late) {
 				if (qt > 0) batch32d_store_k(KP, p, super_p, store_lane, lane_off, pend, stride);
-				batch32_mfma<NK16>(cur, x, acc0, acc1, next_src, (unsigned)lane * 16u, next_dst, wv);
+				batch32_mfma<NK16, NW>(cur, x, acc0, acc1, next_src, (unsigned)lane * 16u, next_dst, wv);
 				pend = batch32d_epilogue_k<W64>(K, p, lane, acc0, acc1, param + super * 32, boost, st, sn);
 			} else {
 				if (qt > 0) batch32d_store_k(KP, p, super_p, store_lane, lane_off, batch32d_epilogue_k<W64>(KP, p, lane, acc0, acc1, param + super_p * 32, boost, st, sn), stride);
-				batch32_mfma<NK16>(cur, x, acc0, acc1, next_src, (unsigned)lane * 16u, next_dst, wv);
+				batch32_mfma<NK16, NW>(cur, x, acc0, acc1, next_src, (unsigned)lane * 16u, next_dst, wv);
 			}
 #if !defined(VK_ABL) || VK_ABL < 6
 			__syncthreads();   // next query tile is in place; this one may be overwritten
@@ -720,54 +722,67 @@ static hipError_t launch_rwmd_batch_tps(const VkRwmdBatchParams &p, size_t smem,
 }
 
 // 32-token sentences: p->qtiles holds p->n_qtiles A tiles of 32 rows (p->qpt queries each); p->scores has n_qtiles * qpt rows
-extern "C" hipError_t vk_launch_rwmd_batch32(const VkRwmdBatchParams *pp, hipStream_t stream) {
-	int dev = 0, cus = 256;
-	if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-	if ((pp->tiles_per_sent != 2 && pp->tiles_per_sent != 4) || (pp->qpt != 2 && pp->qpt != 3)) return hipErrorNotSupported;
-	const bool w64 = pp->tiles_per_sent == 4;   // 64-token (padded) sentences: one per wave
-	const int spc = w64 ? 8 : 16;
-	const int64_t n_chunks = ((int64_t)pp->n_sent + spc - 1) / spc;
-	const int grid = (int)(n_chunks < (int64_t)cus ? n_chunks : (int64_t)cus);
-	if (grid < 1) return hipSuccess;
-	int nk16;
-	if (pp->nk == 10 && pp->half == 1) nk16 = 19;
-	else if (pp->nk == 4 && pp->half == 0) nk16 = 8;
-	else return hipErrorNotSupported;
+template <int NK16, int NW>
+static hipError_t launch_batch32(const VkRwmdBatchParams *pp, bool w64, int grid, hipStream_t stream) {
 	if (pp->dense) {
 		// p->n_qtiles = 5 x super tiles of 16 queries; q_param [n_super * 16][2]; scores n_super * 16 rows
 		const int n_super = pp->n_qtiles / 5;
 		const int64_t stride = pp->score_stride > 0 ? pp->score_stride : pp->n_sent;
+		const size_t smem = (size_t)2 * NK16 * 1024 + (size_t)B32D_MAX_SUPER * 128;
+		void (*kernel)(VkRwmdBatchParams) = w64 ? vk_rwmd_batch32d_kernel<NK16, true, NW> : vk_rwmd_batch32d_kernel<NK16, false, NW>;
+		if (smem > 64 * 1024) {
+			const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+			if (e != hipSuccess) return e;
+		}
 		for (int s0 = 0; s0 < n_super; s0 += B32D_MAX_SUPER) {
 			VkRwmdBatchParams p = *pp;
 			const int ns = n_super - s0 < B32D_MAX_SUPER ? n_super - s0 : B32D_MAX_SUPER;
 			p.n_qtiles = ns * 5;
-			p.qtiles = pp->qtiles + (size_t)s0 * 5 * nk16 * 1024;
+			p.qtiles = pp->qtiles + (size_t)s0 * 5 * NK16 * 1024;
 			p.q_param = pp->q_param + (size_t)s0 * 32;
 			p.scores = pp->scores + (size_t)s0 * 16 * stride;
-			const size_t smem = (size_t)2 * nk16 * 1024 + (size_t)B32D_MAX_SUPER * 128;
-			if (nk16 == 19) { if (w64) vk_rwmd_batch32d_kernel<19, true><<<grid, 512, smem, stream>>>(p); else vk_rwmd_batch32d_kernel<19, false><<<grid, 512, smem, stream>>>(p); }
-			else { if (w64) vk_rwmd_batch32d_kernel<8, true><<<grid, 512, smem, stream>>>(p); else vk_rwmd_batch32d_kernel<8, false><<<grid, 512, smem, stream>>>(p); }
+			kernel<<<grid, 64 * NW, smem, stream>>>(p);
 			const hipError_t e = hipGetLastError();
 			if (e != hipSuccess) return e;
 		}
 		return hipSuccess;
 	}
 	const int64_t stride = pp->score_stride > 0 ? pp->score_stride : pp->n_sent;
+	const size_t smem = (size_t)2 * NK16 * 1024 + (size_t)B32_MAX_QTILES * 32;
+	void (*kernel)(VkRwmdBatchParams) = pp->qpt == 3 ? (w64 ? vk_rwmd_batch32_kernel<NK16, 3, true, NW> : vk_rwmd_batch32_kernel<NK16, 3, false, NW>)
+		: (w64 ? vk_rwmd_batch32_kernel<NK16, 2, true, NW> : vk_rwmd_batch32_kernel<NK16, 2, false, NW>);
+	if (smem > 64 * 1024) {
+		const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+		if (e != hipSuccess) return e;
+	}
 	for (int t0 = 0; t0 < pp->n_qtiles; t0 += B32_MAX_QTILES) {
 		VkRwmdBatchParams p = *pp;
 		p.n_qtiles = pp->n_qtiles - t0 < B32_MAX_QTILES ? pp->n_qtiles - t0 : B32_MAX_QTILES;
-		p.qtiles = pp->qtiles + (size_t)t0 * nk16 * 1024;
+		p.qtiles = pp->qtiles + (size_t)t0 * NK16 * 1024;
 		p.q_param = pp->q_param + (size_t)t0 * 8;
 		p.scores = pp->scores + (size_t)t0 * pp->qpt * stride;
-		const size_t smem = (size_t)2 * nk16 * 1024 + (size_t)B32_MAX_QTILES * 32;
-		void (*kernel)(VkRwmdBatchParams);
-		if (nk16 == 19) kernel = p.qpt == 3 ? (w64 ? vk_rwmd_batch32_kernel<19, 3, true> : vk_rwmd_batch32_kernel<19, 3, false>) : (w64 ? vk_rwmd_batch32_kernel<19, 2, true> : vk_rwmd_batch32_kernel<19, 2, false>);
-		else kernel = p.qpt == 3 ? (w64 ? vk_rwmd_batch32_kernel<8, 3, true> : vk_rwmd_batch32_kernel<8, 3, false>) : (w64 ? vk_rwmd_batch32_kernel<8, 2, true> : vk_rwmd_batch32_kernel<8, 2, false>);
-		kernel<<<grid, 512, smem, stream>>>(p);
+		kernel<<<grid, 64 * NW, smem, stream>>>(p);
 		const hipError_t e = hipGetLastError();
 		if (e != hipSuccess) return e;
 	}
 	return hipSuccess;
+}
+
+// 32-token sentences: p->qtiles holds p->n_qtiles A tiles of 32 rows (p->qpt queries each); p->scores has n_qtiles * qpt rows
+extern "C" hipError_t vk_launch_rwmd_batch32(const VkRwmdBatchParams *pp, hipStream_t stream) {
+	int dev = 0, cus = 256;
+	if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+	if ((pp->tiles_per_sent != 2 && pp->tiles_per_sent != 4) || (pp->qpt != 2 && pp->qpt != 3)) return hipErrorNotSupported;
+	const bool w64 = pp->tiles_per_sent == 4;   // 64-token (padded) sentences: one per wave
+	const bool wide = pp->nk == 24 && pp->half == 0;   // 768-d rows: four waves per workgroup, one per SIMD
+	const int spc = (w64 ? 1 : 2) * (wide ? 4 : 8);
+	const int64_t n_chunks = ((int64_t)pp->n_sent + spc - 1) / spc;
+	const int grid = (int)(n_chunks < (int64_t)cus ? n_chunks : (int64_t)cus);
+	if (grid < 1) return hipSuccess;
+	if (pp->nk == 10 && pp->half == 1) return launch_batch32<19, 8>(pp, w64, grid, stream);
+	if (pp->nk == 4 && pp->half == 0) return launch_batch32<8, 8>(pp, w64, grid, stream);
+	if (wide) return launch_batch32<48, 4>(pp, w64, grid, stream);
+	return hipErrorNotSupported;
 }
 
 // row widths the batched kernels are built for: 300-d (10 K-steps, the last half filled), 128-d, 768-d

@@ -294,11 +294,26 @@ __device__ __forceinline__ float transport_bound32(const float *__restrict__ S, 
 	return fminf(1.0f - lb * (1.0f - 4e-6f) + 3e-5f, 1.0f);
 }
 
-// General gap costs (Waterman-Smith-Beyer), w_t strictly subadditive (checked by the host, as for dp_general_reg): the
+// General gap costs (Waterman-Smith-Beyer), any table through the closure of w_t (dp_general_reg, vk_common.hip.h): the
 // column history of each lane in registers; in-row candidates c[col - k] - w_t(k) from the lane's own block by
 // row_shr:k, and for the blocks further right also from the columns of the blocks to their left, which pass through a
-// 64-float slot of wave-private LDS (one write, four broadcast b128 reads per block and row) and meet per-lane costs
-// w_t(col - i).
+// 64-float slot of wave-private LDS (one write, broadcast b128 reads) and meet per-lane costs w_t(col - i) held in registers.
+// NB = 4 (queries of 33..64 tokens, one slice per wave): the far candidates are a triangle -- block b has 16 b of them, block 3
+// three times 16 while block 0 idles -- and a wave executes the longest lane's count.  They are dealt out evenly, 24 per lane:
+//   block 0 lanes: sources 24..47 for column 48 + v of block 3;     block 2: its own, sources 0..23 (+ 8 from block 1's lanes)
+//   block 1 lanes: their own 16, then sources 24..31 for column 32 + v;   block 3: its own, sources 0..23 (+ 24 from block 0's)
+// the helpers' partial maxima cross through a second 64-float slot.  (Round 2 walked 48 candidates in every lane and fetched
+// each cost from a copy of w_t in LDS: four to five operations per candidate, 216 of a row's ~300; 40 tokens: 10.4 ms = 0.23 of
+// the HBM roofline.)
+// x[lane - K] - w within the DPP row as ONE v_sub_f32_dpp; lanes without a source lane read 0 (bound_ctrl) and carry w = +inf
+template <int K, bool FIRST = false>
+__device__ __forceinline__ float shr_sub(float x, float w) {
+	float r;
+	if constexpr (FIRST) asm("s_nop 1\n\tv_sub_f32_dpp %0, %1, %2 row_shr:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(x), "v"(w), "n"(K));
+	else asm("v_sub_f32_dpp %0, %1, %2 row_shr:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(x), "v"(w), "n"(K));
+	return r;
+}
+
 template <int MAXLEN, int NB>
 __device__ __forceinline__ float dp32_general(const float *__restrict__ S, int stride, int rowbase, int len, int maxlen, int col, int lane,
 	const VkWideParams &p, const float (&wsr)[MAXLEN + 1], float *__restrict__ xch) {
@@ -308,19 +323,22 @@ __device__ __forceinline__ float dp32_general(const float *__restrict__ S, int s
 	const bool last_col = col == p.len_t - 1;
 	const float inf = __builtin_inff();
 	const float wt_border = p.wt[col + 1], wt_border0 = p.wt0[col + 1];   // chains of gaps from the border column / one gap (border row)
-	constexpr int NL = 16 * (NB - 1);   // columns that can lie in blocks to the left
-	// their costs w_t(col - i) per lane: in registers, except beside the 64-row history of the four-block form, where 48 more
-	// registers spill -- there they are read from the wave's copy of w_t in LDS (xch + 64), one ds_read_b32 per candidate
-	constexpr bool FAR_LDS = MAXLEN == 64 && NB == 4;
-	float wtv[16], wfar[FAR_LDS ? 1 : NL];
+	constexpr bool BAL = NB == 4;
+	constexpr int NFAR = BAL ? 24 : 16 * (NB - 1);   // far candidates a lane walks
+	float wtv[16], wfar[NFAR];
 #pragma unroll
 	for (int k = 1; k < 16; k++) wtv[k] = v16 >= k ? p.wt[k] : inf;
-	if constexpr (!FAR_LDS) {
+	// group g of four source columns this lane reads, and the column it works for there
+	auto far_group = [&](int g) { return !BAL ? g : blk == 0 ? g + 6 : (blk == 1 && g >= 4) ? g + 2 : g; };
+	auto far_target = [&](int g) { return !BAL ? col : blk == 0 ? 48 + v16 : (blk == 1 && g >= 4) ? 32 + v16 : col; };
 #pragma unroll
-		for (int i = 0; i < NL; i++) wfar[i] = (i >> 4) < blk ? p.wt[col - i] : inf;   // column i of the slice, in a block left of this lane's
+	for (int i = 0; i < NFAR; i++) {
+		const int src = 4 * far_group(i >> 2) + (i & 3), tgt = far_target(i >> 2);
+		wfar[i] = (src >> 4) < (tgt >> 4) ? p.wt[tgt - src] : inf;   // a source in a block left of the target's
 	}
-	const float *wtl = xch + 64;
 	const f32x4 *left = reinterpret_cast<const f32x4 *>(xch + (lane & ~(16 * NB - 1)));   // c of columns 0.. of this slice
+	float *help = xch + 64;                           // NB = 4: the helpers' partial maxima
+	const int partner = blk == 3 ? col - 48 : col - 16;   // block 3 <- block 0's lane v, block 2 <- block 1's lane 16 + v
 
 	float hreg[MAXLEN + 1];
 	float h = is_global ? -wt_border0 : 0.0f;
@@ -339,37 +357,43 @@ __device__ __forceinline__ float dp32_general(const float *__restrict__ S, int s
 			for (int k = 1; k <= u; k++) c = fmaxf(c, hreg[u - k] - wsr[k]);
 			xch[lane] = c;
 			float hc = fmaxf(c, bcur - wt_border);
-			hc = fmaxf(hc, dpp_zero<0x111>(c) - wtv[1]);
-			hc = fmaxf(hc, dpp_zero<0x112>(c) - wtv[2]);
-			hc = fmaxf(hc, dpp_zero<0x113>(c) - wtv[3]);
-			hc = fmaxf(hc, dpp_zero<0x114>(c) - wtv[4]);
-			hc = fmaxf(hc, dpp_zero<0x115>(c) - wtv[5]);
-			hc = fmaxf(hc, dpp_zero<0x116>(c) - wtv[6]);
-			hc = fmaxf(hc, dpp_zero<0x117>(c) - wtv[7]);
-			hc = fmaxf(hc, dpp_zero<0x118>(c) - wtv[8]);
-			hc = fmaxf(hc, dpp_zero<0x119>(c) - wtv[9]);
-			hc = fmaxf(hc, dpp_zero<0x11a>(c) - wtv[10]);
-			hc = fmaxf(hc, dpp_zero<0x11b>(c) - wtv[11]);
-			hc = fmaxf(hc, dpp_zero<0x11c>(c) - wtv[12]);
-			hc = fmaxf(hc, dpp_zero<0x11d>(c) - wtv[13]);
-			hc = fmaxf(hc, dpp_zero<0x11e>(c) - wtv[14]);
-			hc = fmaxf(hc, dpp_zero<0x11f>(c) - wtv[15]);
+			// (written as the fused instruction: beside the far candidates hipcc leaves these as v_mov_b32_dpp + v_subrev_f32, 15 more
+			// VALU operations per row of ~160; the first one waits out the two states a DPP read of a fresh VALU result needs)
+			hc = fmaxf(hc, shr_sub<1, true>(c, wtv[1]));
+			hc = fmaxf(hc, shr_sub<2>(c, wtv[2]));
+			hc = fmaxf(hc, shr_sub<3>(c, wtv[3]));
+			hc = fmaxf(hc, shr_sub<4>(c, wtv[4]));
+			hc = fmaxf(hc, shr_sub<5>(c, wtv[5]));
+			hc = fmaxf(hc, shr_sub<6>(c, wtv[6]));
+			hc = fmaxf(hc, shr_sub<7>(c, wtv[7]));
+			hc = fmaxf(hc, shr_sub<8>(c, wtv[8]));
+			hc = fmaxf(hc, shr_sub<9>(c, wtv[9]));
+			hc = fmaxf(hc, shr_sub<10>(c, wtv[10]));
+			hc = fmaxf(hc, shr_sub<11>(c, wtv[11]));
+			hc = fmaxf(hc, shr_sub<12>(c, wtv[12]));
+			hc = fmaxf(hc, shr_sub<13>(c, wtv[13]));
+			hc = fmaxf(hc, shr_sub<14>(c, wtv[14]));
+			hc = fmaxf(hc, shr_sub<15>(c, wtv[15]));
 			wave_lds_fence();
+			float fa = VK_NEG_INF, fb = VK_NEG_INF;   // maxima over the groups 0..3 / 4.. of the lane's list
 #pragma unroll
-			for (int g = 0; g < NL / 4; g++) {
-				const f32x4 l = left[g];
+			for (int g = 0; g < NFAR / 4; g++) {
+				const f32x4 l = left[far_group(g)];
 #pragma unroll
 				for (int r = 0; r < 4; r++) {
-					const int i = g * 4 + r;
-					float w;
-					if constexpr (FAR_LDS) {
-						const bool ok = (i >> 4) < blk;
-						w = wtl[ok ? col - i : 0];
-						w = ok ? w : inf;
-					} else w = wfar[i];
-					hc = fmaxf(hc, l[r] - w);
+					const float cand = l[r] - wfar[g * 4 + r];
+					if (g < 4) fa = fmaxf(fa, cand);
+					else fb = fmaxf(fb, cand);
 				}
 			}
+			if constexpr (BAL) {
+				// block 0: everything it found belongs to block 3's column; block 1: groups 4, 5 belong to block 2's
+				help[lane] = blk == 0 ? fmaxf(fa, fb) : fb;
+				hc = fmaxf(hc, blk == 0 ? VK_NEG_INF : blk == 1 ? fa : fmaxf(fa, fb));
+				wave_lds_fence();
+				const float hv = help[blk >= 2 ? partner : lane];
+				hc = fmaxf(hc, blk >= 2 ? hv : VK_NEG_INF);
+			} else hc = fmaxf(hc, fmaxf(fa, fb));
 			hreg[u] = hc;
 			h = act ? hc : h;
 			if (is_local || last_col) best = fmaxf(best, h);
@@ -384,8 +408,10 @@ __device__ __forceinline__ float dp32_general(const float *__restrict__ S, int s
 }
 
 // STATIC: token ids + the two per-query tables [V x 16] (columns 0..15 and 16..31) instead of token tiles
+// (at least two waves per SIMD asked of the register allocator: the four-block general-gap form took 247 + 24 registers -- ONE wave
+// per SIMD, its tile loads and its DP never overlapping with another wave's)
 template <int GAP, bool STATIC, int NB>
-__global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t rows_per_wave, int32_t stride, int32_t slack) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void vk_score32_kernel(VkWideParams p, int32_t rows_per_wave, int32_t stride, int32_t slack) {
 	constexpr int LPS = 16 * NB, PER = 64 / LPS;   // lanes per slice, slices per wave
 	extern __shared__ float4 vk_smem32[];
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -404,12 +430,7 @@ __global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t
 	// strip rows hold the query columns padded to a multiple of 4 (stride floats), not 32: a third workgroup per CU for 20 tokens
 	float *S = reinterpret_cast<float *>(vk_smem32) + NB * (qbytes / 4) + wv * (rows_per_wave * stride + slack);   // 16-byte aligned: qbytes is a multiple of 512
 
-	float *xch = S + rows_per_wave * stride;   // 64 floats behind the strip: the in-row exchange of dp32_general; then the wave's copy of w_t
-	if (GAP == 6 && NB == 4) {
-		xch[64 + lane] = p.wt[lane];
-		if (lane == 0) xch[128] = p.wt[64];
-		wave_lds_fence();
-	}
+	float *xch = S + rows_per_wave * stride;   // 64 floats behind the strip: the in-row exchange of dp32_general; four-block form: 64 more for the helpers' maxima
 	constexpr int WSN = GAP == 6 ? 65 : 33;
 	float wsr[WSN];
 	if (GAP == 3 || GAP == 6) {
@@ -514,7 +535,7 @@ __global__ __launch_bounds__(256) void vk_score32_kernel(VkWideParams p, int32_t
 			}
 			// nine K-steps in flight (the nine full steps of a 300-d tile), kept in front of their MFMAs: 32 tokens, linear gaps 3.15 -> 2.97 ms
 			// per 1 M x 32 x 300-d (four in flight, and the scheduler sinking the loads), general gaps 4.43 -> 4.26
-			constexpr int VK_S32_DEEP = 9;
+			constexpr int VK_S32_DEEP = (GAP == 6 && NB == 4) ? 4 : 9;   // (the four-block general-gap form sits at the register cap of two waves per SIMD: 272 registers with nine in flight, one wave per SIMD)
 			for (; t + VK_S32_DEEP <= nfull; t += VK_S32_DEEP) {
 				bf16x8 x[VK_S32_DEEP];
 #pragma unroll
@@ -621,8 +642,9 @@ static inline int strip_stride(int len_t) { return (len_t + 3) / 4 * 4; }
 // the 64-row history, by the wave's copy of w_t (65); 16 otherwise (lanes beyond the strip's columns read into it).  Exact sizes
 // matter: at 32 query tokens and 300-d rows 1,280 bytes decide between two and three workgroups per CU (5.4 -> 4.3 ms).
 static inline int strip_slack(int gap_mode, int len_t) {
-	if ((gap_mode == 6 && len_t > 32) || gap_mode == 7) return 144;   // gap_mode 7: 2 x 64 vocabulary masses
-	return (gap_mode == 3 || gap_mode == 6) ? 64 : 16;
+	if (gap_mode == 7) return 144;   // 2 x 64 vocabulary masses
+	if (gap_mode == 3 || gap_mode == 6) return len_t > 32 ? 128 : 64;   // four-block form: the second slot of dp32_general
+	return 16;
 }
 
 // nk32 = 0: static layout (no query tiles in LDS); tiles: token tiles a wave's slices span (two consecutive slices for
