@@ -6,7 +6,7 @@
 set -e
 tag=${1:-r02}
 shift || true
-configs=${@:-"2 3 4 5 5wrd 2f32"}
+configs=${@:-"2 3 4 5 5wrd 5rwmd 2f32"}
 root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 mkdir -p "$out/summary"
@@ -21,7 +21,7 @@ for c in $configs; do
 done
 # HBM traffic of the scoring kernel, every HBM-bound configuration: FETCH_SIZE and WRITE_SIZE in passes of their own
 for c in $configs; do
-	case $c in 4|2static) continue;; esac
+	case $c in 4|2static|5rwmd) continue;; esac
 	rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch_$c" -- python3 "$root/bench.py" --config $c --steps 4 --warmup 2 --no-extra --no-cpu-baseline > "$out/pmc_fetch_$c.log" 2>&1
 	rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write_$c" -- python3 "$root/bench.py" --config $c --steps 4 --warmup 2 --no-extra --no-cpu-baseline > "$out/pmc_write_$c.log" 2>&1
 done

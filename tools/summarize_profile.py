@@ -23,7 +23,14 @@ def bench_line(path):
 	"""the JSON line bench.py printed in that pass"""
 	if not os.path.exists(path):
 		return None
-	for line in reversed(open(path).read().splitlines()):
+	lines = open(path).read().splitlines()
+	for line in reversed(lines):   # round 3: the ONE line on stdout is compact; the long form (config.gap, algorithmic bytes) goes to stderr
+		if line.startswith("[bench full] {"):
+			try:
+				return json.loads(line[len("[bench full] "):])
+			except ValueError:
+				pass
+	for line in reversed(lines):
 		if line.startswith("{") and '"metric"' in line:
 			try:
 				return json.loads(line)
