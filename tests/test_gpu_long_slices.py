@@ -229,3 +229,42 @@ def test_transport_flow_outputs_of_long_winners(hip, oracle, len_t):
 			assert abs(raw - got.raw_score[i]) < 2e-5
 	assert n_long >= 25
 	c.close()
+
+
+@pytest.mark.parametrize("len_t", [9, 24])
+def test_only_slices_states_every_slice_long_ones_included(hip, oracle, len_t):
+	"""vk_query_desc.only_slices (the debug hook's walk over every slice): no scoring pass, no selection -- the listed slices in the
+	caller's order, whatever their score, with the aligner score, the score, the traceback and the similarity rows of the canonical
+	arithmetic.  Over a slice table padded for long slices (sentence -> row of the table), for short and long queries, with a boost."""
+	d = 64
+	off = mixed_lengths(41)
+	n = len(off) - 1
+	X = np.random.default_rng(42).standard_normal((int(off[-1]), d)).astype(np.float32)
+	Xb = synth.to_bf16_bits(synth.normalize_rows(X))
+	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=d, n_tokens=Xb.shape[0], n_sentences=n)
+	c.append_vectors(Xb, normalize=False)
+	c.set_sentences(off)
+	c.finalize()
+	Qb = planted_query(X, off, 18, len_t, 43)
+	boost = np.random.default_rng(44).uniform(0.5, 1.5, size=n).astype(np.float32)
+	kw = dict(locality=0, gap_s=EXP5L, gap_t=EXP5L, boost=boost)
+	ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=off, X=Xb, Q=Qb, max_matches=n, min_score=-1.0, **kw)
+	by_sent = {int(s): i for i, s in enumerate(ref["sentence"])}
+	assert len(by_sent) == n                                   # the oracle states every slice once min_score is out of the way
+	order = np.random.default_rng(45).permutation(n).astype(np.int64)   # any order, any subset
+	for ids in (order[:37], order[37:], np.array([18, 18, 6], dtype=np.int64)):
+		got = c.query(Qb, q_normalize=False, only_slices=ids, want_rows=True, **kw)
+		assert got.n == len(ids) and list(got.sentence[:got.n]) == list(ids)
+		for i, s in enumerate(ids):
+			j = by_sent[int(s)]
+			assert np.float32(got.score[i]).view(np.uint32) == np.float32(ref["score"][j]).view(np.uint32)
+			assert np.float32(got.raw_score[i]).view(np.uint32) == np.float32(ref["raw"][j]).view(np.uint32)
+			assert list(got.mapping[i]) == list(ref["mapping"][j])
+			a, b = int(off[s]), int(off[s + 1])
+			S = oracle.sim_bf16(Xb[a:b], Qb)
+			assert (got.sim_rows[i, :b - a, :len_t] == S).all()
+	with pytest.raises(hip.VkError):
+		c.query(Qb, q_normalize=False, only_slices=np.array([n], dtype=np.int64), **kw)              # out of range
+	with pytest.raises(hip.VkError):
+		c.query(Qb, q_normalize=False, only_slices=ids, algorithm=hip.VK_ALG_RWMD)                    # alignments only
+	c.close()
