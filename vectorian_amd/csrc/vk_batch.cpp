@@ -410,7 +410,7 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 	// (768-d rows, round 3: the same kernels with four waves per workgroup, one per SIMD -- a wave's 64 token columns take 384
 	// registers; the 16-row kernel used 10 of its 16 A rows and ran at 0.64 G pairs/s.  VK_BATCH_WIDE16=1 keeps the old path for A/B runs)
 	const bool wide32 = c->nk32 == 24 && c->tail == 0 && !getenv("VK_BATCH_WIDE16");
-	bool b32 = uniform16 && c->uniform_len == 32 && (c->nk32 <= 10 || wide32);
+	bool b32 = uniform16 && (c->uniform_len == 32 || c->uniform_len == 64) && (c->nk32 <= 10 || wide32);   // 64 tokens: one sentence per wave (W64)
 	const int gran = (c->nk32 <= 10 || wide32) ? 2 : 1;   // ragged corpora: bucket step in tiles
 	if (!uniform16 && (rc = build_batch_layout(c, gran))) return rc;
 	const bool r32 = !uniform16 && gran == 2;   // ragged, on the 32x32x16 kernels
