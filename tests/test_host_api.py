@@ -511,3 +511,35 @@ def test_matches_are_lazy():
 	assert res[3][0].flow is f and len(stated) == 1                 # cached
 	assert res[3][0].to_json()["regions"] and len(stated) == 1
 	index.close()
+
+
+def test_solver_debug_hooks_for_the_winners():
+	"""the exact solvers' debug hooks (WRD::call_debug_hook, vectorian/core/cpp/alignment/wrd.h:31-59; FullSolver, wmd.h:147-181) are
+	called for the winners with the joint problem as upstream lays it out: query masses in the first len_t slots, slice masses behind
+	them, D = 1 except D[t][len_t + s] = max(0, 1 - S[s][t]), the plan G and its cost"""
+	session, emb, words, rng = toy_session(n_docs=2, sents_per_doc=30, V=150, d=24)
+	ts = EmbeddingTokenSim(emb, CosineSim())
+	doc = session.documents[1]
+	st = doc.spans["sentence"]["start"][4]
+	text = " ".join(doc.tokens[st:st + 4])
+	calls = []
+	hook = lambda name, data: calls.append((name, data))
+	wrd = session.index(OptimizedSpanSim(ts, alignment.WordRotatorsDistance()), corpus_factory=OracleCorpus)
+	r = wrd.find(text, n=3, debug=hook)
+	assert [c[0] for c in calls] == ["alignment/word-rotators-distance/solver"] * 3
+	for m, (_, d) in zip(r, calls):
+		n = m._len_s + 4
+		assert d["t"]["text"] == text.split() and len(d["s"]["text"]) == m._len_s and d["s"]["text"] == doc.tokens[m._token_at:m._token_at + m._len_s] or m.doc_index != 1
+		assert d["D"].shape == (n, n) and d["solution"]["G"].shape == (n, n) and d["solution"]["type"] == "optimal"
+		assert abs(d["mag_t"][:4].sum() - 1.0) < 1e-5 and not d["mag_t"][4:].any() and abs(d["mag_s"][4:].sum() - 1.0) < 1e-5 and not d["mag_s"][:4].any()
+		assert (d["D"][4:] == 1.0).all() and (d["D"][:4, :4] == 1.0).all()
+		G = d["solution"]["G"]
+		np.testing.assert_allclose(G[:4, 4:].sum(axis=1), d["mag_t"][:4], atol=1e-5)      # the plan ships every query mass ...
+		np.testing.assert_allclose(G[:4, 4:].sum(axis=0), d["mag_s"][4:], atol=1e-5)      # ... into the slice's masses
+		assert abs((1.0 - d["solution"]["cost"]) - m.raw_score) < 1e-5                    # score = 1 - EMD for normalised masses
+	calls.clear()
+	wmd = session.index(OptimizedSpanSim(ts, alignment.WordMoversDistance.wmd("bow")), corpus_factory=OracleCorpus)   # (upstream's naming: "bow" normalises)
+	r = wmd.find(text, n=2, debug=hook)
+	assert [c[0] for c in calls] == ["alignment/word-movers-distance/solver", "alignment/word-movers-distance/make"] * 2
+	d = calls[0][1]
+	assert abs(d["score"] - r[0].raw_score) < 1e-6 and d["G"].shape == d["D"].shape and abs(d["bow_t"].sum() - 1.0) < 1e-6

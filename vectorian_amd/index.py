@@ -1018,13 +1018,77 @@ class HipBruteForceIndex(Index):
 		alg = args.get("algorithm", core.VK_ALG_ALIGN)
 		worst = float(matches[-1].score) if len(matches) >= args["max_matches"] else float(args["min_score"])
 		for i, m in enumerate(matches):
+			if alg == core.VK_ALG_WRD or (alg == core.VK_ALG_RWMD and args.get("wmd_full")):
+				data = self._solver_debug_data(p_query, top, i, m, args)
+				if data is not None:
+					hook("alignment/word-rotators-distance/solver" if alg == core.VK_ALG_WRD else "alignment/word-movers-distance/solver", data)
 			if alg == core.VK_ALG_RWMD:
 				hook("alignment/word-movers-distance/make", {"score": m.score, "worst_score": worst, "slice": m.slice_id, "flow": m.flow})
+				continue
+			if alg == core.VK_ALG_WRD:
 				continue
 			sim = None
 			if getattr(top, "sim_rows", None) is not None and m._len_s <= top.sim_rows.shape[1]:
 				sim = top.sim_rows[i][:m._len_s if m._index_map is None else len(m._index_map), :len(p_query)].copy()
 			hook("alignment", {"slice": m.slice_id, "similarity": sim, "flow": m.flow, "score": m.raw_score})
+
+	def _token_magnitudes(self, g):
+		"""|x| of the tokens of slice g, as Slice::magnitude_s hands them to WRD (metric/contextual.cpp:49-54, metric/static.cpp:69-73)"""
+		a, b = int(self._slice_start[g]), int(self._slice_end[g])
+		emb = self._embedding
+		if emb.is_static:
+			if getattr(self, "_vocab_mag", None) is None:
+				self._vocab_mag = np.asarray(emb.encode_tokens(self.session.vocab.tokens).magnitudes, dtype=np.float32)
+			return self._vocab_mag[self._token_ids[a:b]]
+		from vectorian_amd.embedding import Vectors
+		doc_base = 0
+		for doc in self.session.documents:
+			if a < doc_base + doc.n_tokens:
+				return np.asarray(Vectors(doc.contextual_vectors(emb.name)[a - doc_base:b - doc_base]).magnitudes, dtype=np.float32)
+			doc_base += doc.n_tokens
+		return None
+
+	def _solver_debug_data(self, p_query, top, i, m, args):
+		"""what the exact solvers hand the debug hook for a slice (WRD::call_debug_hook, vectorian/core/cpp/alignment/wrd.h:31-59;
+		FullSolver::call_debug_hook, alignment/wmd.h:147-181), stated for a WINNER from the similarity rows and the optimal plan the
+		backend returned: tokens of both sides, masses, the distance matrix over the joint problem, the plan G and its cost"""
+		if getattr(top, "sim_rows", None) is None or getattr(top, "plan", None) is None or m._index_map is not None:
+			return None
+		len_s, len_t = m._len_s, len(p_query)
+		if len_s > top.sim_rows.shape[1]:
+			return None
+		g = int(m._w.sent[m._i])
+		a = int(self._slice_start[g])
+		doc_tokens = m.prepared_doc.tokens
+		S = top.sim_rows[i][:len_s, :len_t]
+		G_ts = top.plan[i][:len_t, :len_s]
+		ids_s = self._token_ids[a:a + len_s].tolist() if self._token_ids is not None else list(range(len_s))
+		data = {
+			"s": {"id": ids_s, "text": list(doc_tokens[m._token_at:m._token_at + len_s])},
+			"t": {"id": [int(x) for x in p_query.token_ids], "text": list(p_query.tokens)}}
+		n = len_s + len_t
+		D = np.ones((n, n), dtype=np.float32)
+		D[:len_t, len_t:] = np.maximum(0.0, 1.0 - S.T)
+		G = np.zeros((n, n), dtype=np.float32)
+		G[:len_t, len_t:] = G_ts
+		if args.get("algorithm") == core.VK_ALG_WRD:
+			mag_s, mag_t = np.zeros(n, dtype=np.float32), np.zeros(n, dtype=np.float32)
+			ms = self._token_magnitudes(g)
+			if ms is None:
+				return None
+			mag_t[:len_t] = np.asarray(self._embedding.encode_tokens(p_query.tokens).magnitudes, dtype=np.float32)
+			mag_s[len_t:] = ms
+			if args.get("wrd_normalize", True):
+				mag_t /= mag_t.sum()
+				mag_s /= mag_s.sum()
+			data.update(mag_s=mag_s, mag_t=mag_t, D=D, elapsed_microseconds=0,
+				solution={"G": G, "cost": float((D * G).sum()), "type": "optimal"})
+			return data
+		# full WMD over positions (every position its own vocabulary entry on the device; the host states flows over the joint vocabulary)
+		nbow = args["rwmd"][2]
+		data.update(bow_s=np.full(len_s, 1.0 / len_s if nbow else 1.0, dtype=np.float32), bow_t=np.full(len_t, 1.0 / len_t if nbow else 1.0, dtype=np.float32),
+			D=D, G=G, flow_by_pos=m.flow["flow"], dist_by_pos=m.flow["dist"], score=m.raw_score)
+		return data
 
 	def _call_debug_hook_all_slices(self, hook, local, matches):
 		"""debug = AllSlices(hook): the hook contract of the reference in full -- one call per slice this process scores, in slice
