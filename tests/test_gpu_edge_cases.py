@@ -280,3 +280,31 @@ def test_degenerate_vectors(hip, oracle):
 		np.testing.assert_allclose(sc, ref["all_scores"], atol=1e-4)
 		assert got.n == len(ref["score"])
 	c.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_near_ties_at_the_k_boundary_are_resolved_in_the_oracles_arithmetic(hip, oracle, seed):
+	"""Thirteen near-duplicates of one slice -- each differs from the original in ONE bf16 ulp of one feature of one token, so their
+	scores sit within ~1e-6 of each other, closer than the scoring pass's MFMA cosines can order them -- straddle the k-th place (k =
+	10) of a corpus whose other slices score far below.  The selection hands k + 8 slices to the traceback kernel, which restates them
+	in the oracle's arithmetic; the result set (ids, scores, order, tracebacks) must be the oracle's, bit for bit.  (With more than
+	8 such slices beyond the k-th place the guarantee ends: DESIGN 7.1.)"""
+	rng = np.random.default_rng(900 + seed)
+	d, len_s, len_t, n = 300, 24, 8, 400
+	X = rng.standard_normal((n * len_s, d)).astype(np.float32)
+	base = int(rng.integers(0, n))
+	Xb = synth.to_bf16_bits(synth.normalize_rows(X))
+	dup = rng.choice(np.setdiff1d(np.arange(n), [base]), size=12, replace=False)
+	for j, s in enumerate(dup):
+		Xb[s * len_s:(s + 1) * len_s] = Xb[base * len_s:(base + 1) * len_s]
+		tok, feat = int(rng.integers(3, 3 + len_t)), int(rng.integers(0, d))   # inside the aligned stretch
+		v = int(Xb[s * len_s + tok, feat])
+		if 0 < (v & 0x7fff) < 0x7f00:
+			Xb[s * len_s + tok, feat] = np.uint16(v + 1 if j % 2 == 0 else v - 1)
+	off = np.arange(n + 1, dtype=np.int64) * len_s
+	Qb = Xb[base * len_s + 3:base * len_s + 3 + len_t].copy()
+	for loc, ms, gaps in ((0, 0.0, (0.1, 0.1)), (0, 0.0, (EXP5, EXP5)), (1, -1e9, (0.05, 0.05))):
+		got, ref = both(hip, oracle, Xb, off, Qb, gap_s=gaps[0], gap_t=gaps[1], max_matches=10, locality=loc, min_score=ms)
+		assert set(int(x) for x in ref["sentence"]) <= set(int(x) for x in dup) | {base}
+		assert np.ptp(ref["score"]) < 1e-4 and len(np.unique(ref["score"])) > 1      # near-ties, not exact ties
+		assert_same_results(got, ref)
