@@ -120,6 +120,10 @@ static int query_batch_shared_pass(vk_corpus_t *c, const vk_query_desc *qs, int3
 	const int64_t n = c->n_entries;
 	const int k = q0.max_matches;
 	const bool is_align = q0.algorithm == VK_ALG_ALIGN;
+	// alignments with traceback: k + 8 slices are selected and restated in the canonical arithmetic, the k best of them returned
+	// (vk_query: the result set is then the oracle's, not only its members' numbers); kk slots per query below
+	const int kk = (q0.want_flow && is_align) ? std::min(k + 8, 64) : k;
+	const float sel_floor = (q0.want_flow && is_align) ? q0.min_score - 1e-5f * std::max(1.0f, std::fabs(q0.min_score)) : q0.min_score;
 
 	// ---- common options: gap tables, DP form
 	VkScoreBatchParams p{};
@@ -181,7 +185,7 @@ static int query_batch_shared_pass(vk_corpus_t *c, const vk_query_desc *qs, int3
 		c->braw_cap = need_s;
 	}
 	const int64_t nw1 = (n + 4095) / 4096;
-	const size_t need_k = (size_t)4 * (size_t)nw1 * (size_t)k;
+	const size_t need_k = (size_t)4 * (size_t)nw1 * (size_t)kk;
 	if (c->bkeys_cap < need_k) {
 		for (auto &b : c->d_bkeys) if (b) VK_HIP(hipFree(b));
 		if ((rc = alloc_t(c, &c->d_bkeys[0], need_k))) return rc;
@@ -226,12 +230,12 @@ static int query_batch_shared_pass(vk_corpus_t *c, const vk_query_desc *qs, int3
 		VK_HIP(hipEventRecord(c->ev[2], st));
 		int64_t nw = 0;
 		int cur = 0;
-		VK_HIP(vk_launch_topk_wave_batch(c->d_bscores, nullptr, n, q0.min_score, k, 4096, qb, n, nw1 * k, c->d_bkeys[0], &nw, st));
-		const int64_t stride = nw1 * k;
+		VK_HIP(vk_launch_topk_wave_batch(c->d_bscores, nullptr, n, sel_floor, kk, 4096, qb, n, nw1 * kk, c->d_bkeys[0], &nw, st));
+		const int64_t stride = nw1 * kk;
 		while (nw > 1) {
-			const int64_t nkeys = nw * k;
+			const int64_t nkeys = nw * kk;
 			const int64_t per_wave = nkeys <= 16384 ? nkeys : 4096;
-			VK_HIP(vk_launch_topk_wave_batch(nullptr, c->d_bkeys[cur], nkeys, 0.0f, k, per_wave, qb, stride, stride, c->d_bkeys[1 - cur], &nw, st));
+			VK_HIP(vk_launch_topk_wave_batch(nullptr, c->d_bkeys[cur], nkeys, 0.0f, kk, per_wave, qb, stride, stride, c->d_bkeys[1 - cur], &nw, st));
 			cur = 1 - cur;
 		}
 		VK_HIP(hipEventRecord(c->ev[3], st));
@@ -247,15 +251,15 @@ static int query_batch_shared_pass(vk_corpus_t *c, const vk_query_desc *qs, int3
 				f.ws = c->d_ws; f.wt = c->d_wt;
 				f.d = c->desc.d;   // canonical similarity rows (sim_canon)
 				f.keys = c->d_bkeys[cur] + (size_t)i * stride;
-				f.raw_out = c->d_out_raw + (size_t)i * k; f.mapping = c->d_out_map + (size_t)i * k * 16; f.edge_sim = c->d_out_sim + (size_t)i * k * 16;
-				VK_HIP(vk_launch_flow(&f, k, st));
+				f.raw_out = c->d_out_raw + (size_t)i * kk; f.mapping = c->d_out_map + (size_t)i * kk * 16; f.edge_sim = c->d_out_sim + (size_t)i * kk * 16;
+				VK_HIP(vk_launch_flow(&f, kk, st));
 			}
 		}
 		VK_HIP(hipEventRecord(c->ev[4], st));
-		std::vector<uint64_t> keys((size_t)qb * k);
-		std::vector<float> raw((size_t)qb * k), sim((size_t)qb * k * 16);
-		std::vector<int16_t> map((size_t)qb * k * 16);
-		VK_HIP(hipMemcpy2DAsync(keys.data(), (size_t)k * 8, c->d_bkeys[cur], (size_t)stride * 8, (size_t)k * 8, (size_t)qb, hipMemcpyDeviceToHost, st));
+		std::vector<uint64_t> keys((size_t)qb * kk);
+		std::vector<float> raw((size_t)qb * kk), sim((size_t)qb * kk * 16);
+		std::vector<int16_t> map((size_t)qb * kk * 16);
+		VK_HIP(hipMemcpy2DAsync(keys.data(), (size_t)kk * 8, c->d_bkeys[cur], (size_t)stride * 8, (size_t)kk * 8, (size_t)qb, hipMemcpyDeviceToHost, st));
 		if (do_flow) {
 			VK_HIP(hipMemcpyAsync(raw.data(), c->d_out_raw, raw.size() * 4, hipMemcpyDeviceToHost, st));
 			VK_HIP(hipMemcpyAsync(map.data(), c->d_out_map, map.size() * 2, hipMemcpyDeviceToHost, st));
@@ -268,42 +272,43 @@ static int query_batch_shared_pass(vk_corpus_t *c, const vk_query_desc *qs, int3
 			// winners of this query: position in the selection, score.  With traceback the score is restated from the canonical
 			// aligner score of the flow kernel (the oracle's, bit for bit) and the winners are put in that order (vk_query).
 			std::vector<int> order;
-			std::vector<float> val((size_t)k, 0.0f);
-			for (int j = 0; j < k; j++) {
-				const uint64_t key = keys[(size_t)i * k + j];
+			std::vector<float> val((size_t)kk, 0.0f);
+			for (int j = 0; j < kk; j++) {
+				const uint64_t key = keys[(size_t)i * kk + j];
 				if (key == 0) break;
 				const uint32_t ob = (uint32_t)(key >> 32);
 				const uint32_t bits = (ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob;
 				memcpy(&val[(size_t)j], &bits, 4);
 				if (do_flow) {
 					float matched = 0.0f;
-					for (int t = 0; t < q.len_t; t++) matched += map[((size_t)i * k + j) * 16 + t] >= 0 ? 1.0f : 0.0f;
+					for (int t = 0; t < q.len_t; t++) matched += map[((size_t)i * kk + j) * 16 + t] >= 0 ? 1.0f : 0.0f;
 					const float total = (float)q.len_t, uw = powf((total - matched) / total, 0.0f);
 					const float ref = matched + uw * (total - matched);
 					const float boost = q.boost ? q.boost[(int64_t)(uint32_t)(key & 0xffffffffu)] : 1.0f;
-					val[(size_t)j] = (raw[(size_t)i * k + j] / ref) * boost;
+					val[(size_t)j] = (raw[(size_t)i * kk + j] / ref) * boost;
 					if (!(val[(size_t)j] > q.min_score)) continue;
 				}
 				order.push_back(j);
 			}
 			if (do_flow) std::sort(order.begin(), order.end(), [&](int a, int b2) {
 				if (val[(size_t)a] != val[(size_t)b2]) return val[(size_t)a] > val[(size_t)b2];
-				return (uint32_t)(keys[(size_t)i * k + a] & 0xffffffffu) > (uint32_t)(keys[(size_t)i * k + b2] & 0xffffffffu);
+				return (uint32_t)(keys[(size_t)i * kk + a] & 0xffffffffu) > (uint32_t)(keys[(size_t)i * kk + b2] & 0xffffffffu);
 			});
 			int n_out = 0;
 			for (const int j : order) {
-				const uint64_t key = keys[(size_t)i * k + j];
+				if (n_out >= k) break;
+				const uint64_t key = keys[(size_t)i * kk + j];
 				const int64_t g = (int64_t)(uint32_t)(key & 0xffffffffu);
 				out->score[n_out] = val[(size_t)j];
 				out->sentence[n_out] = g;
 				if (out->raw_score) {
-					if (do_flow) out->raw_score[n_out] = raw[(size_t)i * k + j];
+					if (do_flow) out->raw_score[n_out] = raw[(size_t)i * kk + j];
 					else VK_HIP(hipMemcpy(&out->raw_score[n_out], c->d_braw + (size_t)i * n + g, 4, hipMemcpyDeviceToHost));
 				}
 				if (q.want_flow && out->mapping && out->edge_sim)
 					for (int t = 0; t < q.len_t; t++) {
-						out->mapping[(size_t)n_out * q.len_t + t] = do_flow ? map[((size_t)i * k + j) * 16 + t] : (int16_t)-1;
-						out->edge_sim[(size_t)n_out * q.len_t + t] = do_flow ? sim[((size_t)i * k + j) * 16 + t] : 0.0f;
+						out->mapping[(size_t)n_out * q.len_t + t] = do_flow ? map[((size_t)i * kk + j) * 16 + t] : (int16_t)-1;
+						out->edge_sim[(size_t)n_out * q.len_t + t] = do_flow ? sim[((size_t)i * kk + j) * 16 + t] : 0.0f;
 					}
 				n_out++;
 			}
