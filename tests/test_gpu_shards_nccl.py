@@ -74,3 +74,31 @@ def test_allgather_merge_carries_rows_of_long_transport_winners(hip, nccl_group)
 	np.testing.assert_array_equal(merged.plan[:merged.n], top.plan[:top.n])
 	assert abs(float(merged.plan[0].sum()) - 1.0) < 1e-5      # the plan of the 150-token winner moves all the mass
 	c.close()
+
+
+def test_sharded_index_on_hip_over_rccl_equals_the_unsharded_index(hip, nccl_group):
+	"""HipBruteForceIndex(shard = (0, 1), group = the RCCL group) on the HIP backend: Index.find, the pipelined and the batched
+	find_many (alignments: 16 per vk_query_batch call; relaxed WMD: one GEMM pass per chunk) go through the exchange -- all-gather
+	of the records on the device, the rows of the merged transport winners in one all-reduce -- and return what the unsharded
+	index returns, flows included"""
+	from test_host_api import contextual_toy
+	from vectorian_amd import alignment
+	from vectorian_amd.sim import CosineSim, EmbeddingTokenSim, OptimizedSpanSim
+	session, emb, docs = contextual_toy(n_docs=4, sents=60, d=64)
+	texts = [" ".join(docs[i % 4].tokens[5 * i:5 * i + 3 + i % 4]) for i in range(23)]
+	for strategy in (alignment.LocalAlignment(gap=alignment.smooth_gap_cost(5)), alignment.WordMoversDistance.rwmd("nbow"), alignment.WordRotatorsDistance()):
+		sim = OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), strategy)
+		whole = session.index(sim)
+		shard = session.index(sim, shard=(0, 1), group=None)
+		pairs = [(whole.find(texts[3], n=5), shard.find(texts[3], n=5))]
+		pairs += list(zip(whole.find_many(texts, n=5), shard.find_many(texts, n=5)))
+		pairs += list(zip(whole.find_many(texts[:7], n=5, batch=False), shard.find_many(texts[:7], n=5, batch=False)))
+		for a, b in pairs:
+			assert [(m.doc_index, m.slice_id, m.score) for m in a] == [(m.doc_index, m.slice_id, m.score) for m in b]
+			for x, y in zip(a, b):
+				fx, fy = x.flow, y.flow
+				assert fx["type"] == fy["type"]
+				for key in fx:
+					if key != "type":
+						np.testing.assert_array_equal(fx[key], fy[key])
+		whole.close(); shard.close()
