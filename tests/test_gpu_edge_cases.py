@@ -70,9 +70,10 @@ def test_k_exceeds_admissible_and_min_score(hip, oracle):
 	assert len(got["score"]) == 0 and len(ref["score"]) == 0
 
 
-@pytest.mark.parametrize("k", [1, 64, 65, 128, 200, 512, 1024])
+@pytest.mark.parametrize("k", [1, 56, 57, 64, 65, 128, 200, 512, 1024])
 def test_selection_paths(hip, oracle, k):
-	# k <= 64: wave-streaming selection; k > 64: staged bitonic sort (powers of two: later stages merge sorted runs);
+	# k + 8 <= 64 (with traceback: k + 8 slices are selected): wave-streaming selection; beyond: staged bitonic sort (powers of two:
+	# later stages merge sorted runs);
 	# 9000 slices span several blocks and, for k = 512 / 1024, three stages
 	corpus = synth.make_contextual_corpus(9000, 3, 12, 800, 32)
 	Xb = synth.to_bf16_bits(synth.normalize_rows(corpus["X"]))

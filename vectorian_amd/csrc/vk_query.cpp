@@ -766,7 +766,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	// scores are kept: exact unless more than kCanonMargin slices sit within rounding (~2e-6) of the k-th score.
 	const bool do_flow = q->want_flow && is_align;
 	constexpr int kCanonMargin = 8;
-	const int kk = only ? q->n_only : !do_flow ? k : k <= 64 ? std::min(k + kCanonMargin, 64) : std::min(k + kCanonMargin, VK_MAX_MATCHES);
+	const int kk = only ? q->n_only : !do_flow ? k : std::min(k + kCanonMargin, VK_MAX_MATCHES);   // (57 .. 64 matches: the margin takes the selection to the k > 64 path)
 	const float sel_floor = do_flow ? q->min_score - 1e-5f * std::max(1.0f, std::fabs(q->min_score)) : q->min_score;
 	int cur = 0;
 	if (only) {
