@@ -52,3 +52,22 @@ def test_two_ranks_bench_line_and_selfcheck(config, locality):
 	assert sc["ok"], sc
 	assert sc["n"] == 10 and sc["merged"] == sc["one_corpus"]
 	assert sc["ranks_with_winners"] == [0, 1], sc       # winners from both shards: the merge did merge
+
+
+def test_one_rank_over_rccl_runs_the_multi_rank_code_path():
+	"""VK_BENCH_FORCE_DIST=1: the N > 1 code path of bench.py with the backend the driver's multi-GPU run uses (torch.distributed
+	"nccl" = RCCL: communicator with a high-priority stream, stdout kept clean of RCCL's banner, all_gather_object of the ranks'
+	devices, the batched exchange on the device, all_reduce(MAX) of the elapsed time), one rank on the one GPU"""
+	env = dict(os.environ, VK_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+	for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+		env.pop(k, None)
+	r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--sentences", "65536", "--selfcheck"],
+		cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+	assert r.returncode == 0, r.stderr[-4000:]
+	lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+	assert len(lines) == 1, r.stdout[-2000:]
+	out = json.loads(lines[0])
+	assert out["n_gpus"] == 1 and out["value"] > 0
+	assert out["ranks"]["backend"] == "nccl" and out["ranks"]["world_seen_by_backend"] == 1 and out["ranks"]["devices"] == [0]
+	assert out["selfcheck"]["ok"] and out["selfcheck"]["n"] == 10
+
