@@ -913,7 +913,10 @@ static int score_sentence(const work *w, int64_t s, float *Sbuf, float *xbuf, fl
 	if (q->algorithm == VKO_ALG_ALIGN) {
 		int16_t local_map[VKO_MAX_LEN_T];
 		int16_t *m = mapping ? mapping : local_map;
-		const int need_map = mapping != NULL || q->submatch_weight != 0.0f;
+		/* reference_score takes the matched weight of THIS slice's flow (metric/alignment.h:84-106; InjectiveFlow::max_score,
+		 * match/match.h:112-132) -- upstream always has the flow.  With unit weights matched + (total - matched) is exact whatever
+		 * the flow, so the traceback may be skipped; with tag weights it is not (an ulp), so it is taken. */
+		const int need_map = mapping != NULL || q->submatch_weight != 0.0f || q->tag_weights != NULL;
 		if (vko_align(Sbuf, len_t, len_s, len_t, q->locality, &q->gap_s, &q->gap_t, &raw, need_map ? m : NULL)) return 2;
 		if (q->tag_weights) {
 			/* reference_score with max_similarity_for_t = t_pos_weights (slice/static.h:280-286) */

@@ -23,12 +23,16 @@ def random_gap(rng, n):
 	return ("table", w)
 
 
-@pytest.mark.parametrize("seed", range(200))
+# VK_SWEEP_SCALE=10 runs ten times the seeds (a one-off soak on the GPU box; the committed tier runs the default)
+SCALE = int(__import__("os").environ.get("VK_SWEEP_SCALE", "1"))
+
+
+@pytest.mark.parametrize("seed", range(200 * SCALE))
 def test_random_problem(hip, oracle, seed):
 	run_random_problem(hip, oracle, 1000 + seed, 1, 25)
 
 
-@pytest.mark.parametrize("seed", range(100))
+@pytest.mark.parametrize("seed", range(100 * SCALE))
 def test_random_problem_long_query(hip, oracle, seed):
 	"""queries of 17..64 tokens: the multi-block kernel (vk_score32_kernel) and its fallbacks (long slices, fp32 tiles,
 	gap costs that are not subadditive)"""
@@ -91,7 +95,7 @@ def run_random_problem(hip, oracle, seed, len_lo, len_hi):
 	c.close()
 
 
-@pytest.mark.parametrize("seed", range(80))
+@pytest.mark.parametrize("seed", range(80 * SCALE))
 def test_random_transport_and_modifiers(hip, oracle, seed):
 	"""the other strategies on random small problems: RWMD (all forms), full WMD, WRD (both mass conventions),
 	submatch_weight, tag-weighted alignment"""
