@@ -8,7 +8,7 @@ from oracle import vk_oracle as vo
 from vectorian_amd import core, synth
 
 
-def _gap(g, n=65):
+def _gap(g, n=core.VK_MAX_SENT_LEN + 1):   # (65 entries until round 3: a gap over more than 64 tokens of a long slice cost +inf in the double)
 	if hasattr(g, "to_special_case"):
 		sp = g.to_special_case()
 		if "linear" in sp:

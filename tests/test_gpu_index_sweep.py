@@ -1,0 +1,158 @@
+"""-m gpu: a seeded sweep over the operator surface -- random sessions (static or contextual embedding, POS / tags, token masks),
+partitions (sentence or token level, sliding windows), strategies (alignments of every locality and gap family, the relaxed /
+full word mover's distances, word rotator's distance, each optionally tag-weighted), options (token filters, saliency boost,
+submatch weight, n, min_score) -- through Session / Index.find on the HIP backend and on the oracle-backed double.
+Alignments: documents, slices, scores, flows and the regions of the JSON report equal with `==` (the winners are restated in
+the oracle's arithmetic on the device).  Transport strategies: scores at 2e-5, the same slices unless the double itself scores
+them within that, flows of equal mass and cost.  VK_SWEEP_SCALE multiplies the seeds (soak runs)."""
+
+import os
+
+import numpy as np
+import pytest
+
+from fake_backend import OracleCorpus
+from test_host_api import Corpus, Document, Session, StaticEmbedding
+from vectorian_amd import alignment, synth
+from vectorian_amd.embedding import ContextualEmbedding
+from vectorian_amd.sim import CosineSim, EmbeddingTokenSim, OptimizedSpanSim
+
+pytestmark = pytest.mark.gpu
+
+SCALE = int(os.environ.get("VK_SWEEP_SCALE", "1"))
+TAGS = ["NN", "VBZ", "DT", "JJ", ".", "NNS", "VBD"]
+POS_OF = {"NN": "NOUN", "NNS": "NOUN", "VBZ": "VERB", "VBD": "VERB", "DT": "DET", "JJ": "ADJ", ".": "PUNCT"}
+
+
+def random_gap(rng):
+	kind = int(rng.integers(0, 5))
+	if kind == 0:
+		return alignment.ConstantGapCost(float(rng.uniform(0, 0.3)))
+	if kind == 1:
+		return alignment.LinearGapCost(float(rng.uniform(0, 0.4)))
+	if kind == 2:
+		return alignment.AffineGapCost(float(rng.uniform(0, 0.3)), float(rng.uniform(0, 0.2)))
+	if kind == 3:
+		return alignment.smooth_gap_cost(float(rng.uniform(1, 8)))
+	return alignment.ExponentialGapCost(float(rng.uniform(1.5, 3.0)), float(rng.uniform(0.1, 0.9)))   # w(k) = 1 - base^(-k rate), base > 1
+
+
+def random_strategy(rng):
+	kind = int(rng.integers(0, 8))
+	gap = random_gap(rng) if rng.random() < 0.6 else {"s": random_gap(rng), "t": random_gap(rng)}
+	if kind <= 2:
+		return [alignment.LocalAlignment, alignment.GlobalAlignment, alignment.SemiGlobalAlignment][kind](gap=gap), True
+	if kind == 3:
+		return alignment.LocalAlignment(gap=gap), True
+	if kind == 4:
+		return alignment.WordMoversDistance.rwmd(str(rng.choice(["nbow", "nbow/distributed", "bow/fast"]))), False
+	if kind == 5:
+		return alignment.WordMoversDistance.wmd(str(rng.choice(["nbow", "bow"]))), False
+	return alignment.WordRotatorsDistance(normalize_magnitudes=bool(rng.integers(0, 2))), False
+
+
+def build_session(rng):
+	V, d = int(rng.integers(30, 400)), int(rng.choice([32, 100, 300]))
+	words = [f"w{i}" for i in range(V)]
+	E = (synth.make_vocab(V, d) * rng.lognormal(0, 0.3, size=(V, 1))).astype(np.float32)
+	tag_of = lambda w: TAGS[(int(w[1:]) * 7919) % len(TAGS)]
+	contextual = bool(rng.integers(0, 2))
+	docs = []
+	for di in range(int(rng.integers(2, 6))):
+		sents = []
+		for _ in range(int(rng.integers(8, 40))):
+			n = int(rng.integers(1, 31)) if rng.random() > 0.05 else int(rng.integers(65, 120))   # now and then a long sentence
+			sents.append([words[int(i)] for i in rng.integers(0, V, size=n)])
+		kw = dict(pos=[[POS_OF[tag_of(w)] for w in s] for s in sents], tags=[[tag_of(w) for w in s] for s in sents])
+		n_raw = sum(len(s) for s in sents)
+		if rng.random() < 0.25:
+			kw["token_mask"] = rng.random(n_raw) > 0.1
+		if contextual:
+			ids = [int(w[1:]) for s in sents for w in s]
+			X = (E[ids] + 0.1 * rng.standard_normal((n_raw, d))).astype(np.float32)
+			kw["contextual_embeddings"] = {"ctx": X}
+		docs.append(Document(sents, **kw))
+	if contextual:
+		emb = ContextualEmbedding("ctx", d, lambda tokens: E[[int(t[1:]) for t in tokens]])
+		session = Session(docs, embeddings=[emb])
+	else:
+		emb = StaticEmbedding("toy", words, E)
+		session = Session(Corpus(docs), embeddings=[emb])
+	nlp = lambda text: [{"text": w, "pos": POS_OF[tag_of(w)], "tag": tag_of(w)} for w in text.split()]
+	return session, emb, nlp, words
+
+
+def flows_close(fx, fy, exact):
+	if fy is None:
+		return   # the double states transport flows for winners of at most 64 tokens only
+	assert fx is not None and fx["type"] == fy["type"]
+	if exact:
+		for key in fx:
+			if key != "type":
+				assert (np.asarray(fx[key]) == np.asarray(fy[key])).all(), key
+	elif fx["type"] == "dense":
+		# an optimal plan need not be unique (repeated words give equal rows): same mass moved at the same cost
+		assert fx["flow"].shape == fy["flow"].shape
+		np.testing.assert_allclose(fx["dist"], fy["dist"], atol=2e-5)
+		assert abs(float(np.sum(fx["flow"])) - float(np.sum(fy["flow"]))) < 1e-4
+		assert abs(float(np.sum(fx["flow"] * fx["dist"])) - float(np.sum(fy["flow"] * fy["dist"]))) < 1e-4
+
+
+@pytest.mark.parametrize("seed", range(60 * SCALE))
+def test_random_session_on_hip_equals_oracle_double(hip, seed):
+	rng = np.random.default_rng(77000 + seed)
+	session, emb, nlp, words = build_session(rng)
+	strategy, is_align = random_strategy(rng)
+	kw = {}
+	if rng.random() < 0.3:
+		kw = dict(tag_weights={t: float(rng.uniform(0.25, 2.5)) for t in rng.choice(TAGS, size=3, replace=False)},
+			pos_mismatch_penalty=float(rng.uniform(0, 0.5)), similarity_threshold=float(rng.uniform(0, 0.2)))
+	sim = OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), strategy, **kw)
+	if rng.random() < 0.7:
+		part = session.partition("sentence", int(rng.integers(1, 4)), int(rng.integers(1, 3)))
+	else:
+		part = session.partition("token", int(rng.integers(4, 20)), int(rng.integers(1, 8)))
+	n_slices = None
+	index_kw = {}
+	gpu = part.index(sim, nlp=nlp)
+	n_slices = gpu.n_slices
+	if rng.random() < 0.3:
+		index_kw["saliency"] = rng.uniform(0.5, 1.5, size=n_slices).astype(np.float32)
+		gpu.close()
+		gpu = part.index(sim, nlp=nlp, **index_kw)
+	cpu = part.index(sim, nlp=nlp, corpus_factory=OracleCorpus, **index_kw)
+	for _ in range(2):
+		doc = session.documents[int(rng.integers(0, len(session.documents)))]
+		len_t = int(rng.integers(1, 13)) if rng.random() < 0.8 else int(rng.integers(17, 40))
+		if len(doc.tokens) > len_t and rng.random() < 0.7:
+			a0 = int(rng.integers(0, len(doc.tokens) - len_t))
+			text = " ".join(doc.tokens[a0:a0 + len_t])
+		else:
+			text = " ".join(words[int(i)] for i in rng.integers(0, len(words), size=len_t))
+		options = {}
+		if rng.random() < 0.25:
+			options["pos_filter"] = [str(x) for x in rng.choice(["DET", "PUNCT", "ADJ"], size=int(rng.integers(1, 3)), replace=False)]
+		if is_align and rng.random() < 0.2:
+			options["submatch_weight"] = float(rng.choice([0.5, 1.0, 2.0]))
+		n = int(rng.choice([1, 5, 12]))
+		min_score = 0.0 if rng.random() < 0.7 else -100.0
+		a = gpu.find(text, n=n, min_score=min_score, options=options)
+		b = cpu.find(text, n=n, min_score=min_score, options=options)
+		ctx = (seed, type(strategy).__name__, getattr(strategy, '_options', None), text, options, bool(kw), part.to_args(), type(emb).__name__, n, min_score, bool(index_kw))
+		assert len(a) == len(b), ctx
+		if is_align:
+			assert [(m.doc_index, m.slice_id, m.score) for m in a] == [(m.doc_index, m.slice_id, m.score) for m in b], ctx
+			for x, y in zip(a, b):
+				flows_close(x.flow, y.flow, True)
+			if len(a):
+				assert a[0].to_json() == b[0].to_json(), ctx
+		else:
+			sa, sb = np.array([m.score for m in a]), np.array([m.score for m in b])
+			np.testing.assert_allclose(sa, sb, atol=2e-5, err_msg=str(ctx))
+			for i, (x, y) in enumerate(zip(a, b)):
+				if (x.doc_index, x.slice_id) != (y.doc_index, y.slice_id):
+					assert (np.abs(sb - sb[i]) <= 2e-5).sum() > 1 or abs(sb[i] - sb[-1]) <= 2e-5, ctx   # a tie of the double's own
+					continue
+				if i < 3:
+					flows_close(x.flow, y.flow, False)
+	gpu.close(); cpu.close()

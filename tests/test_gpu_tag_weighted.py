@@ -195,3 +195,36 @@ def test_static_tag_weighted_transport_shared_entries(hip, oracle):
 			worst, affected, total = max(worst, float(diff.max())), affected + int((diff > 2e-5).sum()), total + len(diff)
 	assert 0 < affected < 0.1 * total and worst < 5e-4
 	c.close()
+
+
+@pytest.mark.parametrize("len_t", [20, 40])
+@pytest.mark.parametrize("flags", [(True, True, True), (True, False, False)])
+def test_tag_weighted_injective_rwmd_wide_query_over_a_corpus_with_long_slices(hip, oracle, len_t, flags):
+	"""Queries of more than 16 tokens over a corpus that holds slices of more than 64: the injective RWMD takes the one-wave-per-slice
+	fallback (vk_wide_kernel), which must minimise over the TAG-WEIGHTED similarities (round 2 read the unweighted ones there:
+	found by the Index-level sweep of round 3, tests/test_gpu_index_sweep.py)"""
+	rng = np.random.default_rng(77)
+	d, n = 64, 120
+	lens = rng.integers(2, 41, size=n)
+	lens[[5, 60]] = [90, 130]
+	off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+	X = rng.standard_normal((int(off[-1]), d)).astype(np.float32)
+	Xb, _ = oracle.normalize_rows_bf16(X)
+	pos_s = rng.integers(1, 5, size=X.shape[0]).astype(np.int8)
+	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=d, n_tokens=X.shape[0], n_sentences=n)
+	c.append_vectors(X, normalize=True)
+	c.set_sentences(off)
+	c.set_token_pos(pos_s)
+	c.finalize()
+	for rep in range(2):
+		s = int(rng.integers(0, n))
+		qv = (X[rng.integers(off[s], off[s + 1], size=len_t)] + 0.3 * rng.standard_normal((len_t, d))).astype(np.float32)
+		Qb, _ = oracle.normalize_rows_bf16(qv)
+		tw = rng.choice([0.25, 1.0, 2.5], size=len_t).astype(np.float32)
+		q_pos = rng.integers(1, 5, size=len_t).astype(np.int8)
+		kw = dict(tag_weights=tw, q_pos=q_pos, pos_mismatch_penalty=0.4, similarity_threshold=0.1, max_matches=10, min_score=-10.0, rwmd=flags)
+		ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=off, X=Xb, Q=Qb, pos_s=pos_s, algorithm=oracle.ALG_RWMD, want_all_scores=True, **kw)
+		got = c.query(qv, q_normalize=True, algorithm=hip.VK_ALG_RWMD, **kw)
+		assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=2e-5, tie_tol=2e-5)
+		np.testing.assert_allclose(c.last_scores(), ref["all_scores"], atol=2e-5, rtol=0)
+	c.close()

@@ -543,3 +543,20 @@ def test_solver_debug_hooks_for_the_winners():
 	assert [c[0] for c in calls] == ["alignment/word-movers-distance/solver", "alignment/word-movers-distance/make"] * 2
 	d = calls[0][1]
 	assert abs(d["score"] - r[0].raw_score) < 1e-6 and d["G"].shape == d["D"].shape and abs(d["bow_t"].sum() - 1.0) < 1e-6
+
+
+def test_query_tokens_outside_the_corpus_get_ids_of_their_own():
+	"""QueryVocabulary (vectorian/core/cpp/vocabulary.h:500-541) is an incremental lexicon over the session's: a query token the
+	corpus does not hold gets a new id behind the session's, the same word the same id -- the bags of words of the transport
+	strategies then merge repeated words and only those (one id -1 for every unknown word merged them all: the device, which
+	works on positions, and the double, which keys its vocabulary by id, disagreed; found by the Index-level sweep)"""
+	session, emb, words, rng = toy_session(n_docs=2, sents_per_doc=10, V=400, d=24)
+	V = session.vocab.size
+	unknown = [w for w in words if session.vocab.token_to_id(w) < 0][:3]
+	assert len(unknown) == 3
+	known = session.documents[0].tokens[0]
+	index = session.index(OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), alignment.WordMoversDistance.rwmd("bow/fast")), corpus_factory=OracleCorpus)
+	p = index.make_query(" ".join([unknown[0], known, unknown[1], unknown[0], unknown[2]]), n=3).prepare(None)
+	ids = p.token_ids.tolist()
+	assert ids[1] == session.vocab.token_to_id(known) and ids[0] == ids[3] == V and ids[2] == V + 1 and ids[4] == V + 2
+	assert len(index.find(" ".join(unknown), n=3, min_score=-10.0)) == 3

@@ -372,7 +372,7 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 				wave_lds_fence();
 				const int r0 = t_a > base ? t_a - base : 0, r1 = t_b - base < 16 ? t_b - base : 16;
 				for (int r = r0; r < r1; r++) {
-					const float dist = fmaxf(1.0f - Sx[r * LQ + (col ? v - 1 : 0)], 0.0f);
+					const float dist = fmaxf(1.0f - SWx[r * LQ + (col ? v - 1 : 0)], 0.0f);   // the tag-weighted similarity (SWx == Sx without tag weights); round 2 read Sx here
 					colmin = fminf(colmin, dist);
 					acc1 += w_s * wave_min64(col ? dist : 3.402823466e+38F);
 				}

@@ -75,7 +75,16 @@ class PreparedQuery:
 			else:
 				tokens.append(t); self._pos.append(None); self._tags.append(None)
 		self._tokens = tokens
-		self._token_ids = np.array([vocab.token_to_id(t) for t in tokens], dtype=np.int32)
+		# QueryVocabulary (vectorian/core/cpp/vocabulary.h:500-541) is an incremental lexicon over the session's: a query token the
+		# corpus does not hold gets a NEW id behind the session's, the same word the same id -- so that the bags of words of the
+		# transport strategies merge repeated words, and only those (all unknown words as one id -1 would merge them all)
+		ids, fresh = [], {}
+		for t in tokens:
+			i = vocab.token_to_id(t)
+			if i < 0:
+				i = fresh.setdefault(t, vocab.size + len(fresh))
+			ids.append(i)
+		self._token_ids = np.array(ids, dtype=np.int32)
 
 	@property
 	def index(self):
