@@ -228,3 +228,43 @@ def test_tag_weighted_injective_rwmd_wide_query_over_a_corpus_with_long_slices(h
 		assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=2e-5, tie_tol=2e-5)
 		np.testing.assert_allclose(c.last_scores(), ref["all_scores"], atol=2e-5, rtol=0)
 	c.close()
+
+
+@pytest.mark.parametrize("len_t,window,step", [(12, 11, 4), (9, 16, 1), (24, 30, 7), (40, 20, 5), (12, 64, 16)])
+@pytest.mark.parametrize("flags,full", [((True, True, True), False), ((True, False, False), False), ((True, False, True), False), ((False, False, True), True)])
+def test_static_tag_weighted_transport_over_sliding_windows(hip, oracle, len_t, window, step, flags, full):
+	"""The rewritten cells (static_vocab_fixup) are per slice, but the scoring kernels keep the rows of the slices of a wave in one
+	strip: over sliding windows a row belongs to several slices.  Round 2 rewrote it in place and the neighbours read the rewritten
+	value (found by the Index-level sweep, seed 4480: token windows of 11 every 4 tokens, the query a passage of the document).
+	Queries cut from the token stream, so that the windows around them share many (id, tag) entries with the query."""
+	rng = np.random.default_rng(1000 * len_t + window)
+	V, d, n_tok = 120, 64, 900
+	E = rng.standard_normal((V, d)).astype(np.float32)
+	Eb, emag = oracle.normalize_rows_bf16(E)
+	ids = rng.integers(0, V, size=n_tok).astype(np.int32)
+	tag_of = rng.integers(1, 9, size=V).astype(np.int8)
+	tag_s = tag_of[ids]
+	pos_s = (tag_s % 3 + 1).astype(np.int8)
+	start = np.arange(0, n_tok - window + 1, step, dtype=np.int64)
+	end = start + window
+	c = hip.Corpus(layout=hip.VK_LAYOUT_STATIC, d=d, n_tokens=n_tok, n_sentences=len(start), vocab_size=V, keep_magnitudes=True)
+	c.append_vectors(E, normalize=True)
+	c.set_token_ids(ids)
+	c.set_slices(start, end)
+	c.set_token_pos(pos_s)
+	c.set_token_tags(tag_s)
+	c.finalize()
+	weights = np.array([0.5, 1.0, 3.0, 1.5, 0.75, 2.0, 1.0, 0.25, 1.25], dtype=np.float32)
+	for rep in range(3):
+		a = int(rng.integers(0, n_tok - len_t))
+		q_ids = ids[a:a + len_t].copy()
+		q_tag = tag_of[q_ids]
+		q_pos = (q_tag % 3 + 1).astype(np.int8)
+		kw = dict(tag_weights=weights[q_tag], q_pos=q_pos, pos_mismatch_penalty=0.25, similarity_threshold=0.05, max_matches=10, min_score=-10.0, rwmd=flags, wmd_full=full)
+		ref = oracle.find(layout=oracle.LAYOUT_STATIC, d=d, sent_off=start, sent_end=end, tok_id=ids, E=Eb, X_mag=emag[ids], Q=Eb[q_ids], q_ids=q_ids, Q_mag=emag[q_ids],
+			pos_s=pos_s, tag_s=tag_s, q_tag=q_tag, algorithm=oracle.ALG_RWMD, want_all_scores=True, **kw)
+		got = c.query(E[q_ids], q_token_ids=q_ids, q_normalize=True, algorithm=hip.VK_ALG_RWMD, q_tags=q_tag, **kw)
+		if not full:
+			np.testing.assert_allclose(c.last_scores(), ref["all_scores"], atol=2e-5, rtol=0)
+		assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=2e-5, tie_tol=2e-5)
+	c.close()

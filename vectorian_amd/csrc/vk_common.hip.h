@@ -500,21 +500,33 @@ __device__ __forceinline__ float tag_weighted(float s, float w, int pos_s, int p
 // One slice, rows S[u * stride + j] already weighted; the NL lanes l = 0 .. NL - 1 share the rows.  Every lane finds the shared
 // query columns by itself (a bitmap of the query's ids keeps the scan to the few tokens that can match): no exchange.
 // CANON: the cell's cosine restated in the canonical arithmetic (the winners' and candidates' rows) instead of read from the table.
-template <int NL, bool CANON = false>
-__device__ __forceinline__ void static_vocab_fixup(float *__restrict__ S, int stride, int len_s, int len_t,
-	const int32_t *__restrict__ tok, const int8_t *__restrict__ tag, const int8_t *__restrict__ pos,
-	const float *__restrict__ table, int64_t table_stride, const uint32_t *__restrict__ bits, const int32_t *qkey,
-	const float *tw, const int32_t *tpos, float keep, float thr, int l,
-	const uint8_t *__restrict__ etiles = nullptr, int tile_bytes = 0, const uint8_t *__restrict__ qtiles = nullptr, int d = 0, int prec = 0,
-	const int32_t *__restrict__ q_ids = nullptr) {
-	unsigned long long mask = 0;   // query columns whose key occurs in the slice
+// RESTORE: the inverse -- the same cells under their own tag weight again.  The scoring kernels keep the rows of the slices of one
+// wave in ONE strip: where slices overlap (sliding windows) a row belongs to several slices, and a cell rewritten for one of them
+// must not be seen by the others; those waves take their slices in turns: rewrite, evaluate, restore (static_vocab_turns).
+
+// the query columns whose (id, tag) key occurs in the slice; 0 unless there are at least two (with fewer nothing is written twice
+// with different values)
+__device__ __forceinline__ unsigned long long static_vocab_shared(int len_s, int len_t, const int32_t *__restrict__ tok,
+	const int8_t *__restrict__ tag, const uint32_t *__restrict__ bits, const int32_t *qkey) {
+	unsigned long long mask = 0;
 	for (int u = 0; u < len_s; u++) {
 		const int id = tok[u];
 		if (!((bits[id >> 5] >> (id & 31)) & 1u)) continue;
 		const int key = id * 256 + (tag[u] & 255);
 		for (int j = 0; j < len_t; j++) mask |= qkey[j] == key ? 1ull << j : 0ull;
 	}
-	if (!(mask & (mask - 1))) return;   // fewer than two shared columns: nothing is written twice with different values
+	return (mask & (mask - 1)) ? mask : 0ull;
+}
+
+template <int NL, bool CANON = false, bool RESTORE = false>
+__device__ __forceinline__ void static_vocab_fixup(float *__restrict__ S, int stride, int len_s, int len_t,
+	const int32_t *__restrict__ tok, const int8_t *__restrict__ tag, const int8_t *__restrict__ pos,
+	const float *__restrict__ table, int64_t table_stride, const uint32_t *__restrict__ bits, const int32_t *qkey,
+	const float *tw, const int32_t *tpos, float keep, float thr, int l,
+	const uint8_t *__restrict__ etiles = nullptr, int tile_bytes = 0, const uint8_t *__restrict__ qtiles = nullptr, int d = 0, int prec = 0,
+	const int32_t *__restrict__ q_ids = nullptr) {
+	const unsigned long long mask = static_vocab_shared(len_s, len_t, tok, tag, bits, qkey);
+	if (!mask) return;
 	for (int u = l; u < len_s; u += NL) {
 		const int id = tok[u];
 		if (!((bits[id >> 5] >> (id & 31)) & 1u)) continue;
@@ -530,7 +542,7 @@ __device__ __forceinline__ void static_vocab_fixup(float *__restrict__ S, int st
 					static_sim_canon<1>(etiles, tile_bytes, id, qtiles, j, d, prec, q_ids, v1);
 					raw = v1[0];
 				} else raw = table[(int64_t)(j >> 4) * table_stride + (int64_t)id * 16 + (j & 15)];
-				S[u * stride + j] = tag_weighted(raw, tw[ft], pos[u], tpos[j], keep, thr);
+				S[u * stride + j] = tag_weighted(raw, tw[RESTORE ? j : ft], pos[u], tpos[j], keep, thr);
 			}
 	}
 }

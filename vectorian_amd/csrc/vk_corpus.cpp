@@ -103,7 +103,7 @@ int vk_corpus_view(vk_corpus_t *src, vk_corpus_t **out) {
 	c->rows_total = src->rows_total; c->rows_appended = src->rows_appended; c->n_tiles = src->n_tiles;
 	c->d_tiles = src->d_tiles; c->d_mag = src->d_mag; c->d_tok_id = src->d_tok_id; c->d_pos = src->d_pos; c->d_tag = src->d_tag;
 	c->d_sent_start = src->d_sent_start; c->d_sent_end = src->d_sent_end; c->d_long_groups = src->d_long_groups;
-	c->contiguous = src->contiguous; c->have_ids = src->have_ids; c->have_sent = src->have_sent; c->finalized = true;
+	c->contiguous = src->contiguous; c->overlapping = src->overlapping; c->have_ids = src->have_ids; c->have_sent = src->have_sent; c->finalized = true;
 	c->max_len = src->max_len; c->max_group_tiles = src->max_group_tiles; c->max_group_tokens = src->max_group_tokens; c->max_pair_tiles = src->max_pair_tiles; c->max_short_pair_tiles = src->max_short_pair_tiles;
 	c->n_entries = src->n_entries; c->entry_sent = src->entry_sent;
 	c->n_long_groups = src->n_long_groups; c->max_short_len = src->max_short_len;
@@ -310,6 +310,8 @@ static int set_slices_impl(vk_corpus_t *c, const int64_t *start, const int64_t *
 	c->max_len = max_len;
 	c->max_short_len = max_short;
 	c->contiguous = contiguous;
+	c->overlapping = false;
+	for (int64_t s = 1; s < n_sentences && !c->overlapping; s++) c->overlapping = start[s] < end[s - 1] && end[s] > start[s];
 	c->uniform_len = 0;
 	if (n_sentences > 0 && contiguous) {
 		const int64_t l0 = end[0] - start[0];

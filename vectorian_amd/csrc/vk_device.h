@@ -56,6 +56,7 @@ struct VkScoreParams {
 	// tag-weighted vocabulary transports over the static layout (static_vocab_fixup, vk_common.hip.h): bitmap of the query's token
 	// ids over the vocabulary (null: off) and the (id, tag) key of every query token
 	const uint32_t *qid_bits;
+	int32_t slices_overlap;    // slices share tokens (sliding windows): rewritten cells are per slice, the wave takes its slices in turns
 	int32_t qkey[VK_DEV_MAX_QUERY_LEN];
 	float tw[VK_DEV_MAX_QUERY_LEN];      // t_pos_weights
 	int32_t tpos[VK_DEV_MAX_QUERY_LEN];  // POS code per query token
@@ -230,6 +231,7 @@ struct VkWideParams {
 	// tag-weighted vocabulary transports over the static layout (static_vocab_fixup, vk_common.hip.h): bitmap of the query's token
 	// ids over the vocabulary (null: off) and the (id, tag) key of every query token
 	const uint32_t *qid_bits;
+	int32_t slices_overlap;    // as VkScoreParams
 	int32_t qkey[VK_DEV_MAX_WIDE_QUERY_LEN];
 	float tw[VK_DEV_MAX_WIDE_QUERY_LEN];
 	int32_t tpos[VK_DEV_MAX_WIDE_QUERY_LEN];

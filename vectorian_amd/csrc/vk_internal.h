@@ -76,6 +76,7 @@ struct vk_corpus {
 	int8_t *d_tag = nullptr;   // tag code per token (token filters)
 	int32_t *d_sent_start = nullptr, *d_sent_end = nullptr;
 	bool contiguous = false;   // slices are the CSR partition of the token stream
+	bool overlapping = false;  // some token belongs to more than one slice (sliding windows)
 	bool have_ids = false, have_sent = false, finalized = false;
 	int max_len = 0, max_group_tiles = 0, max_group_tokens = 0;
 	int max_pair_tiles = 0;    // tiles spanned by two consecutive rows of the slice table (vk_score32_kernel)

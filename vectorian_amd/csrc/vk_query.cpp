@@ -382,7 +382,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		}
 		VK_HIP(hipMemcpyAsync(c->d_qbits, bits.data(), words * 4, hipMemcpyHostToDevice, st));
 		VK_HIP(hipStreamSynchronize(st));   // `bits` leaves scope
-		p.qid_bits = c->d_qbits; p.tag_s = c->d_tag;
+		p.qid_bits = c->d_qbits; p.tag_s = c->d_tag; p.slices_overlap = c->overlapping ? 1 : 0;
 		for (int j = 0; j < VK_FAST_QUERY_LEN; j++) p.qkey[j] = qkey_all[j];
 	}
 	VkWideParams wp{};
@@ -394,7 +394,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		wp.rwmd_symmetric = p.rwmd_symmetric; wp.rwmd_normalize_bow = p.rwmd_normalize_bow;
 		wp.gs = p.gs; wp.gt = p.gt; wp.a_s = p.a_s; wp.a_t = p.a_t; wp.open_s = p.open_s; wp.open_t = p.open_t;
 		wp.ws = c->d_ws; wp.wt = c->d_wt; wp.wt0 = c->d_wt;
-		wp.pos_s = p.pos_s; wp.tag_s = p.tag_s; wp.qid_bits = p.qid_bits; memcpy(wp.qkey, qkey_all, sizeof wp.qkey);
+		wp.pos_s = p.pos_s; wp.tag_s = p.tag_s; wp.qid_bits = p.qid_bits; wp.slices_overlap = p.slices_overlap; memcpy(wp.qkey, qkey_all, sizeof wp.qkey);
 		wp.tw_keep = p.tw_keep; wp.tw_threshold = p.tw_threshold; wp.ref_total = p.ref_total;
 		for (int j = 0; j < VK_MAX_QUERY_LEN; j++) {
 			wp.tw[j] = (p.pos_s && j < q->len_t) ? q->tag_weights[j] : 0.0f;

@@ -182,17 +182,24 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 			rowbase = t_a - tile0 * 16;
 		}
 		wave_lds_fence();
+		// tag-weighted vocabulary transport: cells upstream writes twice (static_vocab_fixup).  The four slices of the wave share one
+		// strip of rows: over sliding windows a rewritten cell may belong to a neighbour too, and the slices take turns
+		int turns = 1;
+		bool rewrite = false;
 		if constexpr (MODE == 2 && (GAP == 4 || GAP == 7)) {
-			if (p.qid_bits && len > 0) {   // tag-weighted vocabulary transport: cells upstream writes twice (static_vocab_fixup)
-				static_vocab_fixup<16>(S + rowbase * LT, LT, len, p.len_t, p.tok_id + t_a, p.tag_s + t_a, p.pos_s + t_a, p.table, 0,
+			if (p.qid_bits) {
+				rewrite = len > 0 && static_vocab_shared(len, p.len_t, p.tok_id + t_a, p.tag_s + t_a, p.qid_bits, p.qkey) != 0;
+				if (p.slices_overlap && __builtin_amdgcn_ballot_w64(rewrite) != 0) turns = 4;
+				else if (rewrite) static_vocab_fixup<16>(S + rowbase * LT, LT, len, p.len_t, p.tok_id + t_a, p.tag_s + t_a, p.pos_s + t_a, p.table, 0,
 					p.qid_bits, p.qkey, p.tw, p.tpos, p.tw_keep, p.tw_threshold, v);
 				wave_lds_fence();
 			}
 		}
 
-		float raw;
 		const int lenc = len > 0 ? len : 0;
 		const int rb = len > 0 ? rowbase : 0;
+		auto evaluate = [&]() -> float {
+		float raw;
 		if constexpr (GAP == 0) raw = dp_linear<LT>(S, rb, lenc, maxlen, v, a);
 		else if constexpr (GAP == 1) raw = dp_affine<LT>(S, rb, lenc, maxlen, v, a);
 		else if constexpr (GAP == 2) raw = dp_general<LT>(S, Hh, p.h_rows, rb, lenc, maxlen, lane, a);
@@ -227,6 +234,25 @@ __global__ __launch_bounds__(256) void vk_score_kernel(VkScoreParams p) {
 		}
 		else if constexpr (MODE == 2) raw = wrd_bound_rows<LT>(S, rb, lenc, maxlen, v, a, p.mag, p.tok_id + (len > 0 ? t_a : 0), p.qmass[v]);
 		else raw = wrd_bound_rows<LT>(S, rb, lenc, maxlen, v, a, p.mag + (len > 0 ? t_a : 0), nullptr, p.qmass[v]);
+		return raw;
+		};
+		float raw = 0.0f;
+		if constexpr (MODE == 2 && (GAP == 4 || GAP == 7)) {
+			if (turns > 1) {
+				for (int turn = 0; turn < 4; turn++) {
+					const bool mine = sigma == turn;
+					if (mine && rewrite) static_vocab_fixup<16>(S + rowbase * LT, LT, len, p.len_t, p.tok_id + t_a, p.tag_s + t_a, p.pos_s + t_a, p.table, 0,
+						p.qid_bits, p.qkey, p.tw, p.tpos, p.tw_keep, p.tw_threshold, v);
+					wave_lds_fence();
+					const float r = evaluate();
+					if (mine) raw = r;
+					wave_lds_fence();
+					if (mine && rewrite) static_vocab_fixup<16, false, true>(S + rowbase * LT, LT, len, p.len_t, p.tok_id + t_a, p.tag_s + t_a, p.pos_s + t_a, p.table, 0,
+						p.qid_bits, p.qkey, p.tw, p.tpos, p.tw_keep, p.tw_threshold, v);
+					wave_lds_fence();
+				}
+			} else raw = evaluate();
+		} else raw = evaluate();
 
 		if (v == 15 && s_idx < p.n_sent) {
 			// Score::value = raw / reference_score * boost; reference_score == len_t for

@@ -587,13 +587,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void v
 		wave_lds_fence();
 		const int lenc = len > 0 ? len : 0;
 		const int rb = len > 0 ? (STATIC ? t_a - g_a : t_a - tile0 * 16) : 0;
+		// tag-weighted vocabulary transport: cells upstream writes twice (static_vocab_fixup, vk_common.hip.h).  The slices of the wave
+		// share one strip of rows: over sliding windows a rewritten cell may belong to a neighbour too, and the slices take turns
+		int turns = 1;
+		bool rewrite = false;
 		if constexpr (STATIC && (GAP == 4 || GAP == 7 || GAP == 5)) {
-			if (p.qid_bits && len > 0) {   // tag-weighted vocabulary transport: cells upstream writes twice (static_vocab_fixup, vk_common.hip.h)
-				static_vocab_fixup<LPS>(S + rb * stride, stride, len, p.len_t, p.tok_id + t_a, p.tag_s + t_a, p.pos_s + t_a, p.table, p.table_stride,
+			if (p.qid_bits) {
+				rewrite = len > 0 && static_vocab_shared(len, p.len_t, p.tok_id + t_a, p.tag_s + t_a, p.qid_bits, p.qkey) != 0;
+				if (PER > 1 && p.slices_overlap && __builtin_amdgcn_ballot_w64(rewrite) != 0) turns = PER;
+				else if (rewrite) static_vocab_fixup<LPS>(S + rb * stride, stride, len, p.len_t, p.tok_id + t_a, p.tag_s + t_a, p.pos_s + t_a, p.table, p.table_stride,
 					p.qid_bits, p.qkey, p.tw, p.tpos, p.tw_keep, p.tw_threshold, col);
 				wave_lds_fence();
 			}
 		}
+		auto evaluate = [&]() -> float {
 		float raw;
 		if constexpr (GAP == 3) raw = dp32_general<32, NB>(S, stride, rb, lenc, maxlen, col, lane, p, wsr, xch);
 		else if constexpr (GAP == 6) raw = dp32_general<64, NB>(S, stride, rb, lenc, maxlen, col, lane, p, wsr, xch);
@@ -623,6 +630,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void v
 		else if constexpr (GAP == 5) raw = transport_bound32<NB>(S, stride, rb, lenc, maxlen, col, lane, p,
 			p.mag ? (STATIC ? p.mag : p.mag + (len > 0 ? t_a : 0)) : nullptr, (STATIC && p.mag) ? p.tok_id + (len > 0 ? t_a : 0) : nullptr);
 		else raw = dp32<GAP, NB>(S, stride, rb, lenc, maxlen, col, p);
+		return raw;
+		};
+		float raw = 0.0f;
+		if constexpr (STATIC && (GAP == 4 || GAP == 7 || GAP == 5)) {
+			if (turns > 1) {
+				for (int turn = 0; turn < PER; turn++) {
+					const bool mine = half == turn;
+					if (mine && rewrite) static_vocab_fixup<LPS>(S + rb * stride, stride, len, p.len_t, p.tok_id + t_a, p.tag_s + t_a, p.pos_s + t_a, p.table, p.table_stride,
+						p.qid_bits, p.qkey, p.tw, p.tpos, p.tw_keep, p.tw_threshold, col);
+					wave_lds_fence();
+					const float r = evaluate();
+					if (mine) raw = r;
+					wave_lds_fence();
+					if (mine && rewrite) static_vocab_fixup<LPS, false, true>(S + rb * stride, stride, len, p.len_t, p.tok_id + t_a, p.tag_s + t_a, p.pos_s + t_a, p.table, p.table_stride,
+						p.qid_bits, p.qkey, p.tw, p.tpos, p.tw_keep, p.tw_threshold, col);
+					wave_lds_fence();
+				}
+			} else raw = evaluate();
+		} else raw = evaluate();
 		if (col == LPS - 1 && s_idx < p.n_sent) {
 			float val = VK_NEG_INF, r = VK_NEG_INF;
 			if (len >= 1) {   // document.h:160 skips empty slices
