@@ -156,3 +156,58 @@ def test_random_session_on_hip_equals_oracle_double(hip, seed):
 				if i < 3:
 					flows_close(x.flow, y.flow, False)
 	gpu.close(); cpu.close()
+
+
+@pytest.mark.parametrize("seed", range(30 * SCALE))
+def test_random_session_find_many_equals_find(hip, seed):
+	"""Index.find_many -- queries in flight on handles of the resident corpus; over contextual embeddings alignments 16 per call on
+	the shared pass, relaxed-WMD queries up to 256 per call on the GEMM kernels -- returns what Index.find returns, query by query:
+	alignments with `==` (both restate their winners in the canonical arithmetic); transports at 2e-5 (the batched kernels sum
+	their dot products in another order than the per-query kernel), the same slices unless scores tie within that."""
+	rng = np.random.default_rng(99000 + seed)
+	session, emb, nlp, words = build_session(rng)
+	strategy, is_align = random_strategy(rng)
+	kw = {}
+	if rng.random() < 0.15:
+		kw = dict(tag_weights={t: float(rng.uniform(0.25, 2.5)) for t in rng.choice(TAGS, size=3, replace=False)},
+			pos_mismatch_penalty=float(rng.uniform(0, 0.5)), similarity_threshold=float(rng.uniform(0, 0.2)))
+	sim = OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), strategy, **kw)
+	if rng.random() < 0.7:
+		part = session.partition("sentence", int(rng.integers(1, 4)), int(rng.integers(1, 3)))
+	else:
+		part = session.partition("token", int(rng.integers(4, 20)), int(rng.integers(1, 8)))
+	gpu = part.index(sim, nlp=nlp)
+	texts = []
+	wide = rng.random() < 0.2
+	for _ in range(int(rng.integers(2, 24))):
+		doc = session.documents[int(rng.integers(0, len(session.documents)))]
+		len_t = int(rng.integers(17, 40)) if wide and rng.random() < 0.5 else int(rng.integers(1, 17))
+		if len(doc.tokens) > len_t and rng.random() < 0.7:
+			a0 = int(rng.integers(0, len(doc.tokens) - len_t))
+			texts.append(" ".join(doc.tokens[a0:a0 + len_t]))
+		else:
+			texts.append(" ".join(words[int(i)] for i in rng.integers(0, len(words), size=len_t)))
+	options = {}
+	if rng.random() < 0.15:
+		options["pos_filter"] = ["DET"]
+	if is_align and rng.random() < 0.2:
+		options["submatch_weight"] = float(rng.choice([0.5, 1.0, 2.0]))
+	n = int(rng.choice([1, 5, 12]))
+	min_score = 0.0 if rng.random() < 0.7 else -100.0
+	many = gpu.find_many(texts, n=n, min_score=min_score, options=options, in_flight=int(rng.integers(1, 4)))
+	assert len(many) == len(texts)
+	for text, a in zip(texts, many):
+		b = gpu.find(text, n=n, min_score=min_score, options=options)
+		ctx = (seed, type(strategy).__name__, getattr(strategy, '_options', None), text, options, bool(kw), part.to_args(), type(emb).__name__, n, min_score)
+		assert len(a) == len(b), ctx
+		if is_align:
+			assert [(m.doc_index, m.slice_id, m.score) for m in a] == [(m.doc_index, m.slice_id, m.score) for m in b], ctx
+			for x, y in zip(a, b):
+				flows_close(x.flow, y.flow, True)
+		else:
+			sa, sb = np.array([m.score for m in a]), np.array([m.score for m in b])
+			np.testing.assert_allclose(sa, sb, atol=2e-5, err_msg=str(ctx))
+			for i, (x, y) in enumerate(zip(a, b)):
+				if (x.doc_index, x.slice_id) != (y.doc_index, y.slice_id):
+					assert (np.abs(sb - sb[i]) <= 2e-5).sum() > 1 or abs(sb[i] - sb[-1]) <= 2e-5, ctx
+	gpu.close()
