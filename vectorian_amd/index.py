@@ -930,17 +930,27 @@ class HipBruteForceIndex(Index):
 		from vectorian_amd import shards
 		args = live[0]["args"]
 		k = args["max_matches"]
-		tops = [x["top"] for x in live]
-		h = shards.allgather_start(tops, self._slice_off, k, group=self._group, device=self._xdev,
-			flags=[shards.FLAG_ABORTED if x["aborted"] else 0 for x in live])
-		merged = shards.allgather_finish(h)
-		with_rows = [i for i, t in enumerate(tops) if getattr(t, "sim_rows", None) is not None]
-		if with_rows:
-			lens = [self._slice_end[merged[i].sentence[:merged[i].n]] - self._slice_start[merged[i].sentence[:merged[i].n]] for i in with_rows]
-			exact = args.get("algorithm") == core.VK_ALG_WRD or bool(args.get("wmd_full"))
-			shards.rows_allreduce([tops[i] for i in with_rows], [merged[i] for i in with_rows], self._slice_off, self._n_local, lens,
-				group=self._group, device=self._xdev, with_plan=exact)
-		out = iter(None if (f & shards.FLAG_ABORTED) else m for m, f in zip(merged, h["flags_out"]))
+		# one exchange per record size (a record holds the query's columns rounded up to 16: queries of 5 and of 20 tokens
+		# travel apart), in the order of the sizes -- the same on every rank
+		by_size = {}
+		for i, x in enumerate(live):
+			by_size.setdefault(shards._layout(x["top"].len_t), []).append(i)
+		done = [None] * len(live)
+		for size in sorted(by_size):
+			part = [live[i] for i in by_size[size]]
+			tops = [x["top"] for x in part]
+			h = shards.allgather_start(tops, self._slice_off, k, group=self._group, device=self._xdev,
+				flags=[shards.FLAG_ABORTED if x["aborted"] else 0 for x in part])
+			merged = shards.allgather_finish(h)
+			with_rows = [i for i, t in enumerate(tops) if getattr(t, "sim_rows", None) is not None]
+			if with_rows:
+				lens = [self._slice_end[merged[i].sentence[:merged[i].n]] - self._slice_start[merged[i].sentence[:merged[i].n]] for i in with_rows]
+				exact = args.get("algorithm") == core.VK_ALG_WRD or bool(args.get("wmd_full"))
+				shards.rows_allreduce([tops[i] for i in with_rows], [merged[i] for i in with_rows], self._slice_off, self._n_local, lens,
+					group=self._group, device=self._xdev, with_plan=exact)
+			for i, m, f in zip(by_size[size], merged, h["flags_out"]):
+				done[i] = None if (f & shards.FLAG_ABORTED) else m
+		out = iter(done)
 		return [None if x is None else next(out) for x in locals_]
 
 	def _find(self, query, progress=None, corpus=None):
