@@ -111,6 +111,9 @@ def abort_answers(shard):
 	if shard is not None and shard[0] == 1:
 		q.abort()
 	res["find"] = len(index._find(q))
+	# a transport strategy: the rows of the merged winners follow in an all-reduce every rank must join, the aborted one too
+	index = build_contextual(shard, "rwmd")
+	res["rwmd"] = [len(list(r)) for r in index.find_many(queries, n=5, abort=flag, batch=False)] + [len(r.matches) for r in index.find_many(queries, n=5, abort=flag)]
 	return res
 
 

@@ -19,7 +19,7 @@ def same(a, b, exact_flows):
 	for x, y in zip(a, b):
 		fx, fy = x.flow, y.flow
 		if (fx is None) != (fy is None):
-			return "flow stated on one side only"
+			return "flow stated on one side only (sharded: %s, unsharded: %s; slice of %d tokens)" % (fx is not None, fy is not None, x._len_s)
 		if fx is None:
 			continue
 		if fx["type"] != fy["type"]:

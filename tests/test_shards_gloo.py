@@ -108,5 +108,5 @@ def test_sharded_index(tmp_path):
 	for k in range(2):
 		got = json.load(open(tmp_path / f"index_rank{k}.json"))
 		# Query.abort raised on rank 1 only: no rank hangs in the collective, and the query yields no matches on either rank
-		assert got.pop("abort") == {"batched": [0] * 6, "pipelined": [0] * 6, "find": 0}
+		assert got.pop("abort") == {"batched": [0] * 6, "pipelined": [0] * 6, "find": 0, "rwmd": [0] * 12}
 		assert got == ref

@@ -942,7 +942,10 @@ class HipBruteForceIndex(Index):
 			h = shards.allgather_start(tops, self._slice_off, k, group=self._group, device=self._xdev,
 				flags=[shards.FLAG_ABORTED if x["aborted"] else 0 for x in part])
 			merged = shards.allgather_finish(h)
-			with_rows = [i for i, t in enumerate(tops) if getattr(t, "sim_rows", None) is not None]
+			# (every rank must take the same decision: by the algorithm, not by what this rank's sets happen to hold -- an aborted
+			# or empty local set has no rows)
+			transport = args.get("algorithm", core.VK_ALG_ALIGN) != core.VK_ALG_ALIGN
+			with_rows = [i for i, x in enumerate(part) if transport or x.get("hook") is not None]   # (a debug hook asks for the rows of alignments too)
 			if with_rows:
 				lens = [self._slice_end[merged[i].sentence[:merged[i].n]] - self._slice_start[merged[i].sentence[:merged[i].n]] for i in with_rows]
 				exact = args.get("algorithm") == core.VK_ALG_WRD or bool(args.get("wmd_full"))

@@ -220,9 +220,12 @@ def rows_allreduce(local_tops, merged_tops, sentence_offset, n_local, lens, grou
 	k = max(len(m.score) for m in merged_tops)
 	R = max([int(np.max(l)) if len(l) else 0 for l in lens] + [1])
 	W = max([t.sim_rows.shape[2] for t in local_tops if getattr(t, "sim_rows", None) is not None] + [16])
-	Wt = torch.tensor([W, R], dtype=torch.int64, device=device)
+	# rows per winner the backend returned (batched calls: 64; vk_query: the longest slice): a merged winner longer than that has
+	# no rows anywhere, and must read as one without -- not as rows cut short (the host would state a flow from them)
+	cap = min([t.sim_rows.shape[1] for t in local_tops if getattr(t, "sim_rows", None) is not None and t.n > 0] + [1 << 30])
+	Wt = torch.tensor([W, R, -cap], dtype=torch.int64, device=device)
 	dist.all_reduce(Wt, op=dist.ReduceOp.MAX, group=group)   # a rank without winners knows no W of its own
-	W, R = int(Wt[0].item()), int(Wt[1].item())
+	W, R = int(Wt[0].item()), max(1, min(int(Wt[1].item()), -int(Wt[2].item())))
 	buf = np.zeros((nq, k, 2 if with_plan else 1, R * W), dtype=np.float32)
 	for i, (loc, mer) in enumerate(zip(local_tops, merged_tops)):
 		if loc is None or getattr(loc, "sim_rows", None) is None or loc.n == 0:
