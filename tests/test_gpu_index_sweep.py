@@ -146,6 +146,12 @@ def test_random_session_on_hip_equals_oracle_double(hip, seed):
 				flows_close(x.flow, y.flow, True)
 			if len(a):
 				assert a[0].to_json() == b[0].to_json(), ctx
+		elif (getattr(strategy, "_options", None) or {}).get("relaxed"):
+			# relaxed WMD: the winners' scores are restated on the host from their canonical similarity rows, in the reference's order
+			# of operations (vk_transport_host.h): the oracle's floats, the oracle's result set
+			assert [(m.doc_index, m.slice_id, m.score) for m in a] == [(m.doc_index, m.slice_id, m.score) for m in b], ctx
+			for x, y in list(zip(a, b))[:3]:
+				flows_close(x.flow, y.flow, False)
 		else:
 			sa, sb = np.array([m.score for m in a]), np.array([m.score for m in b])
 			np.testing.assert_allclose(sa, sb, atol=2e-5, err_msg=str(ctx))
@@ -204,6 +210,8 @@ def test_random_session_find_many_equals_find(hip, seed):
 			assert [(m.doc_index, m.slice_id, m.score) for m in a] == [(m.doc_index, m.slice_id, m.score) for m in b], ctx
 			for x, y in zip(a, b):
 				flows_close(x.flow, y.flow, True)
+		elif (getattr(strategy, "_options", None) or {}).get("relaxed"):
+			assert [(m.doc_index, m.slice_id, m.score) for m in a] == [(m.doc_index, m.slice_id, m.score) for m in b], ctx   # canonical on both paths
 		else:
 			sa, sb = np.array([m.score for m in a]), np.array([m.score for m in b])
 			np.testing.assert_allclose(sa, sb, atol=2e-5, err_msg=str(ctx))

@@ -4,6 +4,7 @@
 // would compute returns VK_ERR_NO_DEVICE / VK_ERR_HIP.
 
 #include "vk_internal.h"
+#include "vk_transport_host.h"
 
 #include <chrono>
 #include <thread>
@@ -16,18 +17,17 @@ static bool same_gap(const vk_gap &a, const vk_gap &b, int upto) {
 	return true;
 }
 
-// Similarity rows of the winners of a batch of relaxed-WMD queries, from which the host states their flows (SparseFlow,
-// alignment/wmd.h:392-408): one launch for all queries, every winner against its own query's tile.  keys: [n_queries x k] as
-// selected (0 = empty slot); outs[i].n_out set.
+// The result sets of a batch of relaxed-WMD queries from the kk = k + margin slices selected per query: the similarity rows of
+// every candidate in the canonical arithmetic (one launch for all queries, every candidate against its own query's tile), its score
+// restated from them on the host as the reference computes it (vk_transport_host.h), the k best kept -- scores, slices, aligner
+// scores and the rows the host states the flows from (SparseFlow, alignment/wmd.h:392-408) written to outs[i].
+// keys: [n_queries x kk] as selected (0 = empty slot).
 // packed16: the queries' 16-row tiles as vk_pack_query lays them out, tile_bytes apart, when the caller has packed them already
 // (the GEMM path: packing 256 queries a second time, on one thread, cost 12 ms per batch); null: packed here
-static int batch_winner_rows(vk_corpus *c, const vk_query_desc *qs, int n_queries, vk_topk_out *outs, const uint64_t *keys, int k, hipStream_t st,
+static int batch_winner_rows(vk_corpus *c, const vk_query_desc *qs, int n_queries, vk_topk_out *outs, const uint64_t *keys, int kk, int k, hipStream_t st,
 	const uint8_t *packed16 = nullptr) {
 	int rc;
-	bool any_rows = false;
-	for (int i = 0; i < n_queries; i++) any_rows |= qs[i].algorithm == VK_ALG_RWMD && qs[i].want_flow && outs[i].sim_rows && outs[i].n_out > 0;
-	if (!any_rows) return VK_OK;   // (winners of more than 64 tokens get zero rows from the kernel: their flows are not stated)
-	const size_t n_cand = (size_t)n_queries * (size_t)k;
+	const size_t n_cand = (size_t)n_queries * (size_t)kk;
 	const bool trace = getenv("VK_TRACE_BATCH") != nullptr;
 	const auto t_begin = std::chrono::steady_clock::now();
 	auto stamp = [&](const char *what) {
@@ -56,10 +56,10 @@ static int batch_winner_rows(vk_corpus *c, const vk_query_desc *qs, int n_querie
 			vk_pack_query(c, &qs[i], one, mags);
 			memcpy(qt.data() + (size_t)i * c->tile_bytes, one.data(), std::min(one.size(), (size_t)c->tile_bytes));
 		}
-		for (int j = 0; j < k; j++) {
-			hq[(size_t)i * k + j] = i;
-			if (j < outs[i].n_out && qs[i].want_flow && outs[i].sim_rows)
-				hk[(size_t)i * k + j] = (1ull << 32) | (uint64_t)(uint32_t)(keys[(size_t)i * k + j] & 0xffffffffu);
+		for (int j = 0; j < kk; j++) {
+			hq[(size_t)i * kk + j] = i;
+			if (keys[(size_t)i * kk + j] != 0)
+				hk[(size_t)i * kk + j] = (1ull << 32) | (uint64_t)(uint32_t)(keys[(size_t)i * kk + j] & 0xffffffffu);
 		}
 	}
 	VK_HIP(hipMemcpyAsync(c->d_bqt, packed16 ? packed16 : qt.data(), (size_t)n_queries * c->tile_bytes, hipMemcpyHostToDevice, st));
@@ -85,10 +85,53 @@ static int batch_winner_rows(vk_corpus *c, const vk_query_desc *qs, int n_querie
 	VK_HIP(hipMemcpyAsync(c->h_brows, c->d_brows, bytes, hipMemcpyDeviceToHost, st));
 	VK_HIP(hipStreamSynchronize(st));
 	stamp("rows on the host");
-	for (int i = 0; i < n_queries; i++)
-		if (qs[i].algorithm == VK_ALG_RWMD && qs[i].want_flow && outs[i].sim_rows && outs[i].n_out > 0)
-			memcpy(outs[i].sim_rows, c->h_brows + (size_t)i * k * 64 * 16, (size_t)outs[i].n_out * 64 * 16 * 4);
-	stamp("copied out");
+	// the score of every candidate from its rows, in the reference's order of operations (vk_transport_host.h; contextual layout:
+	// every position is a vocabulary entry); the k best of a query's kk candidates, in the order of the result set
+	auto rank_range = [&](int i0, int i1) {
+		std::vector<int> order;
+		std::vector<float> val((size_t)kk), raw((size_t)kk);
+		for (int i = i0; i < i1; i++) {
+			const vk_query_desc &q = qs[i];
+			vk_topk_out *out = &outs[i];
+			order.clear();
+			for (int j = 0; j < kk; j++) {
+				const uint64_t key = keys[(size_t)i * kk + j];
+				if (key == 0) break;
+				const int64_t g = (int64_t)(uint32_t)(key & 0xffffffffu);
+				const int len_s = (*c->h_end)[(size_t)g] - (*c->h_start)[(size_t)g];
+				raw[(size_t)j] = vk_host::rwmd_from_rows(c->h_brows + ((size_t)i * kk + j) * 64 * 16, 16, len_s, q.len_t, nullptr, nullptr,
+					q.rwmd_injective != 0, q.rwmd_symmetric != 0, q.rwmd_normalize_bow != 0);
+				val[(size_t)j] = (raw[(size_t)j] / (float)q.len_t) * (q.boost ? q.boost[g] : 1.0f);
+				if (val[(size_t)j] > q.min_score) order.push_back(j);
+			}
+			std::sort(order.begin(), order.end(), [&](int a, int b) {
+				if (val[(size_t)a] != val[(size_t)b]) return val[(size_t)a] > val[(size_t)b];
+				return (uint32_t)(keys[(size_t)i * kk + a] & 0xffffffffu) > (uint32_t)(keys[(size_t)i * kk + b] & 0xffffffffu);
+			});
+			const int n_out = std::min((int)order.size(), k);
+			for (int r = 0; r < n_out; r++) {
+				const int j = order[(size_t)r];
+				out->score[r] = val[(size_t)j];
+				out->sentence[r] = (int64_t)(uint32_t)(keys[(size_t)i * kk + j] & 0xffffffffu);
+				if (out->raw_score) out->raw_score[r] = raw[(size_t)j];
+				if (out->mapping && out->edge_sim)
+					for (int t = 0; t < q.len_t; t++) {
+						out->mapping[(size_t)r * q.len_t + t] = -1;
+						out->edge_sim[(size_t)r * q.len_t + t] = 0.0f;
+					}
+				memcpy(out->sim_rows + (size_t)r * 64 * 16, c->h_brows + ((size_t)i * kk + j) * 64 * 16, (size_t)64 * 16 * 4);
+			}
+			out->n_out = n_out;
+		}
+	};
+	const int n_threads = n_queries >= 64 ? 4 : 1;
+	if (n_threads == 1) rank_range(0, n_queries);
+	else {
+		std::vector<std::thread> pool;
+		for (int t = 0; t < n_threads; t++) pool.emplace_back(rank_range, (int)((int64_t)n_queries * t / n_threads), (int)((int64_t)n_queries * (t + 1) / n_threads));
+		for (auto &th : pool) th.join();
+	}
+	stamp("ranked and copied out");
 	return VK_OK;
 }
 
@@ -122,8 +165,12 @@ static int query_batch_shared_pass(vk_corpus_t *c, const vk_query_desc *qs, int3
 	const bool is_align = q0.algorithm == VK_ALG_ALIGN;
 	// alignments with traceback: k + 8 slices are selected and restated in the canonical arithmetic, the k best of them returned
 	// (vk_query: the result set is then the oracle's, not only its members' numbers); kk slots per query below
-	const int kk = (q0.want_flow && is_align) ? std::min(k + 8, 64) : k;
-	const float sel_floor = (q0.want_flow && is_align) ? q0.min_score - 1e-5f * std::max(1.0f, std::fabs(q0.min_score)) : q0.min_score;
+	// relaxed WMD with flows: likewise, restated on the host from the candidates' canonical similarity rows (batch_winner_rows)
+	bool canon_tr = !is_align && q0.want_flow;
+	for (int i = 0; i < n_queries; i++) canon_tr = canon_tr && outs[i].sim_rows != nullptr;
+	const bool margin = (q0.want_flow && is_align) || canon_tr;
+	const int kk = margin ? std::min(k + 8, 64) : k;
+	const float sel_floor = margin ? q0.min_score - 1e-5f * std::max(1.0f, std::fabs(q0.min_score)) : q0.min_score;
 
 	// ---- common options: gap tables, DP form
 	VkScoreBatchParams p{};
@@ -266,7 +313,7 @@ static int query_batch_shared_pass(vk_corpus_t *c, const vk_query_desc *qs, int3
 			VK_HIP(hipMemcpyAsync(sim.data(), c->d_out_sim, sim.size() * 4, hipMemcpyDeviceToHost, st));
 		}
 		VK_HIP(hipStreamSynchronize(st));
-		for (int i = 0; i < qb; i++) {
+		for (int i = 0; i < qb && !canon_tr; i++) {   // (relaxed WMD with flows: batch_winner_rows below writes the result sets)
 			const vk_query_desc &q = qs[base + i];
 			vk_topk_out *out = &outs[base + i];
 			// winners of this query: position in the selection, score.  With traceback the score is restated from the canonical
@@ -314,7 +361,7 @@ static int query_batch_shared_pass(vk_corpus_t *c, const vk_query_desc *qs, int3
 			}
 			out->n_out = n_out;
 		}
-		if (!is_align && (rc = batch_winner_rows(c, qs + base, qb, outs + base, keys.data(), k, st))) return rc;
+		if (canon_tr && (rc = batch_winner_rows(c, qs + base, qb, outs + base, keys.data(), kk, k, st))) return rc;
 		float ms = 0;
 		if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) score_ms_total += ms;
 		if (hipEventElapsedTime(&ms, c->ev[0], c->ev[4]) == hipSuccess) total_ms += ms;
@@ -449,8 +496,13 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 		if ((rc = alloc_t(c, &c->d_bscores, need_s))) return rc;
 		c->bscores_cap = need_s;
 	}
+	// with flows: k + 8 candidates per query, restated on the host from their canonical rows; the k best are kept (batch_winner_rows)
+	bool canon_tr = qs[0].want_flow != 0;
+	for (int i = 0; i < n_queries; i++) canon_tr = canon_tr && outs[i].sim_rows != nullptr;
+	const int kk = canon_tr ? std::min(k + 8, 64) : k;
+	const float sel_floor = canon_tr ? qs[0].min_score - 1e-5f * std::max(1.0f, std::fabs(qs[0].min_score)) : qs[0].min_score;
 	const int64_t nw1 = (n + 4095) / 4096;
-	const size_t need_k = (size_t)n_queries * (size_t)nw1 * (size_t)k;
+	const size_t need_k = (size_t)n_queries * (size_t)nw1 * (size_t)kk;
 	if (c->bkeys_cap < need_k) {
 		for (auto &b : c->d_bkeys) if (b) VK_HIP(hipFree(b));
 		if ((rc = alloc_t(c, &c->d_bkeys[0], need_k))) return rc;
@@ -577,12 +629,12 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 	VK_HIP(hipEventRecord(c->ev[6], st));
 	int64_t nw = 0;
 	int cur = 0;
-	VK_HIP(vk_launch_topk_wave_batch(c->d_bscores, nullptr, n, qs[0].min_score, k, 4096, n_queries, n, nw1 * k, c->d_bkeys[0], &nw, st));
-	int64_t stride = nw1 * k;
+	VK_HIP(vk_launch_topk_wave_batch(c->d_bscores, nullptr, n, sel_floor, kk, 4096, n_queries, n, nw1 * kk, c->d_bkeys[0], &nw, st));
+	int64_t stride = nw1 * kk;
 	while (nw > 1) {
-		const int64_t nkeys = nw * k;
+		const int64_t nkeys = nw * kk;
 		const int64_t per_wave = nkeys <= 16384 ? nkeys : 4096;
-		VK_HIP(vk_launch_topk_wave_batch(nullptr, c->d_bkeys[cur], nkeys, 0.0f, k, per_wave, n_queries, stride, stride, c->d_bkeys[1 - cur], &nw, st));
+		VK_HIP(vk_launch_topk_wave_batch(nullptr, c->d_bkeys[cur], nkeys, 0.0f, kk, per_wave, n_queries, stride, stride, c->d_bkeys[1 - cur], &nw, st));
 		cur = 1 - cur;
 	}
 	// the turn passes AFTER the selection: a GEMM fills every CU for 40 ms, and a selection that starts beside the peer's GEMM waits
@@ -592,10 +644,10 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 	c->ev2_recorded = true;
 	VK_HIP(hipEventRecord(c->ev[3], st));
 	VK_HIP(hipEventRecord(c->ev[4], st));
-	std::vector<uint64_t> keys((size_t)n_queries * (size_t)k);
-	VK_HIP(hipMemcpy2DAsync(keys.data(), (size_t)k * 8, c->d_bkeys[cur], (size_t)stride * 8, (size_t)k * 8, (size_t)n_queries, hipMemcpyDeviceToHost, st));
+	std::vector<uint64_t> keys((size_t)n_queries * (size_t)kk);
+	VK_HIP(hipMemcpy2DAsync(keys.data(), (size_t)kk * 8, c->d_bkeys[cur], (size_t)stride * 8, (size_t)kk * 8, (size_t)n_queries, hipMemcpyDeviceToHost, st));
 	VK_HIP(hipStreamSynchronize(st));
-	for (int i = 0; i < n_queries; i++) {
+	for (int i = 0; i < n_queries && !canon_tr; i++) {   // without flows: the scores of the GEMM pass (kk == k)
 		vk_topk_out *out = &outs[i];
 		int n_out = 0;
 		for (int j = 0; j < k; j++) {
@@ -618,7 +670,7 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 		}
 		out->n_out = n_out;
 	}
-	if ((rc = batch_winner_rows(c, qs, n_queries, outs, keys.data(), k, st, tiles16.empty() ? nullptr : tiles16.data()))) return rc;
+	if (canon_tr && (rc = batch_winner_rows(c, qs, n_queries, outs, keys.data(), kk, k, st, tiles16.empty() ? nullptr : tiles16.data()))) return rc;
 	c->have_scores = false;
 	float ms = 0;
 	vk_timings t{};

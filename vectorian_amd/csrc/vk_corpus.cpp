@@ -106,6 +106,7 @@ int vk_corpus_view(vk_corpus_t *src, vk_corpus_t **out) {
 	c->contiguous = src->contiguous; c->overlapping = src->overlapping; c->have_ids = src->have_ids; c->have_sent = src->have_sent; c->finalized = true;
 	c->max_len = src->max_len; c->max_group_tiles = src->max_group_tiles; c->max_group_tokens = src->max_group_tokens; c->max_pair_tiles = src->max_pair_tiles; c->max_short_pair_tiles = src->max_short_pair_tiles;
 	c->n_entries = src->n_entries; c->entry_sent = src->entry_sent;
+	c->h_start = src->h_start; c->h_end = src->h_end; c->h_tok = src->h_tok; c->h_tag = src->h_tag;
 	c->n_long_groups = src->n_long_groups; c->max_short_len = src->max_short_len;
 	c->long_group_tiles = src->long_group_tiles; c->long_group_tokens = src->long_group_tokens;
 	c->uniform_len = src->uniform_len;
@@ -210,6 +211,9 @@ int vk_corpus_set_token_ids(vk_corpus_t *c, const int32_t *ids, int64_t n, int32
 	}
 	VK_HIP(hipMemcpyAsync(c->d_tok_id, ids, (size_t)n * 4, mem == VK_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
 	VK_HIP(hipStreamSynchronize(c->stream));
+	c->h_tok = std::make_shared<std::vector<int32_t>>((size_t)n);
+	if (mem == VK_MEM_DEVICE) VK_HIP(hipMemcpy(c->h_tok->data(), c->d_tok_id, (size_t)n * 4, hipMemcpyDeviceToHost));
+	else memcpy(c->h_tok->data(), ids, (size_t)n * 4);
 	c->have_ids = true;
 	return VK_OK;
 }
@@ -239,7 +243,12 @@ int vk_corpus_set_token_tags(vk_corpus_t *c, const int8_t *tags, int64_t n, int3
 	if (c && tags && mem != VK_MEM_DEVICE && n == c->desc.n_tokens)
 		for (int64_t i = 0; i < n; i++)
 			if (tags[i] < 0) return fail(VK_ERR_INVALID, "tag codes must be 0 .. 127 (they key the vocabulary of tag-weighted transports as id * 256 + tag)");
-	return set_token_codes(c, c ? &c->d_tag : nullptr, tags, n, mem, "tag");
+	const int rc = set_token_codes(c, c ? &c->d_tag : nullptr, tags, n, mem, "tag");
+	if (rc) return rc;
+	c->h_tag = std::make_shared<std::vector<int8_t>>((size_t)n);
+	if (mem == VK_MEM_DEVICE) VK_HIP(hipMemcpy(c->h_tag->data(), c->d_tag, (size_t)n, hipMemcpyDeviceToHost));
+	else memcpy(c->h_tag->data(), tags, (size_t)n);
+	return VK_OK;
 }
 
 static int set_slices_impl(vk_corpus_t *c, const int64_t *start, const int64_t *end, int64_t n_sentences, bool contiguous) {
@@ -305,6 +314,8 @@ static int set_slices_impl(vk_corpus_t *c, const int64_t *start, const int64_t *
 	}
 	VK_HIP(hipMemcpy(c->d_sent_start, st32.data(), st32.size() * 4, hipMemcpyHostToDevice));
 	VK_HIP(hipMemcpy(c->d_sent_end, en32.data(), en32.size() * 4, hipMemcpyHostToDevice));
+	c->h_start = std::make_shared<std::vector<int32_t>>(st32);
+	c->h_end = std::make_shared<std::vector<int32_t>>(en32);
 	c->n_entries = n_entries;
 	c->n_long_groups = (int)long_groups.size();
 	c->max_len = max_len;
@@ -469,6 +480,14 @@ int vk_corpus_filter(vk_corpus_t *src, uint64_t pos_mask, uint64_t tag_mask, vk_
 			VK_HIP(vk_launch_filter_gather(from, *to, 1, src_of, n_kept, st));
 		}
 		VK_HIP(hipStreamSynchronize(st));
+		if (is_static) {
+			c->h_tok = std::make_shared<std::vector<int32_t>>((size_t)n_kept);
+			if (n_kept > 0) VK_HIP(hipMemcpy(c->h_tok->data(), c->d_tok_id, (size_t)n_kept * 4, hipMemcpyDeviceToHost));
+		}
+		if (c->d_tag) {
+			c->h_tag = std::make_shared<std::vector<int8_t>>((size_t)n_kept);
+			if (n_kept > 0) VK_HIP(hipMemcpy(c->h_tag->data(), c->d_tag, (size_t)n_kept, hipMemcpyDeviceToHost));
+		}
 		int r = set_slices_impl(c, start.data(), end.data(), ns, src->contiguous);
 		if (r) return r;
 		c->finalized = true;

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -75,6 +76,10 @@ struct vk_corpus {
 	int8_t *d_pos = nullptr;   // POS code per token (tag-weighted queries, token filters)
 	int8_t *d_tag = nullptr;   // tag code per token (token filters)
 	int32_t *d_sent_start = nullptr, *d_sent_end = nullptr;
+	// host mirrors, shared by the views of a corpus: rows of the slice table (as on the device, padding included), token ids and tag
+	// codes of the static layout -- what restating a transport winner on the host needs (vk_transport_host.h)
+	std::shared_ptr<std::vector<int32_t>> h_start, h_end, h_tok;
+	std::shared_ptr<std::vector<int8_t>> h_tag;
 	bool contiguous = false;   // slices are the CSR partition of the token stream
 	bool overlapping = false;  // some token belongs to more than one slice (sliding windows)
 	bool have_ids = false, have_sent = false, finalized = false;

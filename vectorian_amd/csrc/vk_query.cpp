@@ -4,6 +4,7 @@
 // would compute returns VK_ERR_NO_DEVICE / VK_ERR_HIP.
 
 #include "vk_internal.h"
+#include "vk_transport_host.h"
 
 // The multi-block kernel (vk_score32_kernel) for a query of 17..64 tokens: the gap mode it is launched with, the token tiles a
 // wave's strip spans, and whether the query tiles and at least one wave's strip fit the LDS of a CU (vk_score32_waves).  One
@@ -185,8 +186,9 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 			}
 		}
 	};
-	auto transport_flows = [&](const std::vector<int64_t> &rows_idx, bool exact, const float *qmass, int mass_mode, int raw_masses) -> int {
+	auto transport_flows = [&](const std::vector<int64_t> &rows_idx, bool exact, const float *qmass, int mass_mode, int raw_masses, float *rows_dst = nullptr) -> int {
 		if (!q->want_flow || !out->sim_rows || rows_idx.empty()) return VK_OK;
+		if (!rows_dst) rows_dst = out->sim_rows;
 		const int nqw = (q->len_t + 15) / 16, W = 16 * nqw;   // columns of a similarity row: the query length padded to 16
 		const int R = out->rows_per_winner > 0 ? out->rows_per_winner : VK_FAST_SENT_LEN;   // rows per winner (longer winners: zero rows)
 		if (R % 64 != 0 || R > VK_MAX_SENT_LEN) return fail(VK_ERR_INVALID, "rows_per_winner must be a multiple of 64, at most VK_MAX_SENT_LEN");
@@ -211,7 +213,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		fill_transport(w);
 		w.keys = c->d_keys[1]; w.rows_out = c->d_rows_out; w.rows_len = R;
 		VK_HIP(vk_launch_rows(&w, cnt, c->stream));
-		VK_HIP(hipMemcpyAsync(out->sim_rows, c->d_rows_out, need * 4, hipMemcpyDeviceToHost, c->stream));
+		VK_HIP(hipMemcpyAsync(rows_dst, c->d_rows_out, need * 4, hipMemcpyDeviceToHost, c->stream));
 		if (exact && out->plan) {
 			w.mass_mode = mass_mode; w.raw_masses = raw_masses;
 			memcpy(w.qmass, qmass, sizeof w.qmass);
@@ -765,9 +767,13 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	// (kCanonMargin more slices; the floor of the selection is lowered by the rounding slack likewise) and the k best canonical
 	// scores are kept: exact unless more than kCanonMargin slices sit within rounding (~2e-6) of the k-th score.
 	const bool do_flow = q->want_flow && is_align;
+	// Relaxed word mover's distance: likewise -- the rows of the winners come back in the canonical arithmetic (vk_rows_kernel) and
+	// the host restates each winner's score from them in the reference's order of operations (vk_transport_host.h): the scores of the
+	// result set are the oracle's floats, whichever kernel ranked the slices (per query, batched GEMM, a shard of the corpus).
+	const bool canon_tr = q->algorithm == VK_ALG_RWMD && !q->wmd_full && q->want_flow && out->sim_rows != nullptr;
 	constexpr int kCanonMargin = 8;
-	const int kk = only ? q->n_only : !do_flow ? k : std::min(k + kCanonMargin, VK_MAX_MATCHES);   // (57 .. 64 matches: the margin takes the selection to the k > 64 path)
-	const float sel_floor = do_flow ? q->min_score - 1e-5f * std::max(1.0f, std::fabs(q->min_score)) : q->min_score;
+	const int kk = only ? q->n_only : !(do_flow || canon_tr) ? k : std::min(k + kCanonMargin, VK_MAX_MATCHES);   // (57 .. 64 matches: the margin takes the selection to the k > 64 path)
+	const float sel_floor = (do_flow || canon_tr) ? q->min_score - 1e-5f * std::max(1.0f, std::fabs(q->min_score)) : q->min_score;
 	int cur = 0;
 	if (only) {
 		// keys of the listed slices, in the caller's order (rows of the slice table: long slices sit in padded groups)
@@ -857,8 +863,52 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		}
 		n_out = std::min((int)order.size(), only ? q->n_only : k);
 	}
+	std::vector<float> rows_all;   // canon_tr: similarity rows of every selected slice
+	const int rows_R = out->rows_per_winner > 0 ? out->rows_per_winner : VK_FAST_SENT_LEN, rows_W = 16 * ((q->len_t + 15) / 16);
+	if (canon_tr && n_sel > 0) {
+		rows_all.resize((size_t)n_sel * rows_R * rows_W);
+		std::vector<int64_t> rows_idx;
+		for (int i = 0; i < n_sel; i++) rows_idx.push_back((int64_t)(uint32_t)(keys[(size_t)i] & 0xffffffffu));
+		float no_mass[VK_MAX_QUERY_LEN] = {0};
+		if ((rc = transport_flows(rows_idx, false, no_mass, 0, 0, rows_all.data()))) return rc;
+		// vocabulary keys (static layout): token ids, or (id, tag) pairs when the similarity is tag-weighted (alignment/bow.h:106-127, 150-176)
+		const bool vocab = is_static && q->q_token_ids && c->h_tok;
+		const bool tagged = vocab && q->tag_weights && q->q_tags && c->h_tag;
+		std::vector<int32_t> key_t((size_t)q->len_t), key_s;
+		for (int j = 0; vocab && j < q->len_t; j++) key_t[(size_t)j] = tagged ? q->q_token_ids[j] * 256 + (int32_t)(uint8_t)q->q_tags[j] : q->q_token_ids[j];
+		float total = (float)q->len_t;
+		if (q->tag_weights) {
+			total = 0.0f;
+			for (int j = 0; j < q->len_t; j++) total += q->tag_weights[j];
+		}
+		for (int i = 0; i < n_sel; i++) {
+			const int64_t row = rows_idx[(size_t)i];
+			const int32_t t_a = (*c->h_start)[(size_t)row], len_s = (*c->h_end)[(size_t)row] - t_a;
+			const float boost = q->boost ? q->boost[sentence_of(row)] : 1.0f;
+			if (len_s < 1 || len_s > rows_R) {   // no rows for this one (longer than the caller's room): it keeps the scoring pass's value
+				VK_HIP(hipMemcpy(&raw[(size_t)i], c->d_raw + row, 4, hipMemcpyDeviceToHost));
+				continue;
+			}
+			if (vocab) {
+				key_s.resize((size_t)len_s);
+				for (int u = 0; u < len_s; u++)
+					key_s[(size_t)u] = tagged ? (*c->h_tok)[(size_t)(t_a + u)] * 256 + (int32_t)(uint8_t)(*c->h_tag)[(size_t)(t_a + u)] : (*c->h_tok)[(size_t)(t_a + u)];
+			}
+			raw[(size_t)i] = vk_host::rwmd_from_rows(rows_all.data() + (size_t)i * rows_R * rows_W, rows_W, len_s, q->len_t,
+				vocab ? key_s.data() : nullptr, vocab ? key_t.data() : nullptr, q->rwmd_injective != 0, q->rwmd_symmetric != 0, q->rwmd_normalize_bow != 0);
+			val[(size_t)i] = (raw[(size_t)i] / total) * boost;   // reference_score with every query token matched: the sum of the weights (match.h:165-176)
+		}
+		if (!only) {
+			order.erase(std::remove_if(order.begin(), order.end(), [&](int i) { return !(val[(size_t)i] > q->min_score); }), order.end());
+			std::sort(order.begin(), order.end(), [&](int a, int b) {
+				if (val[(size_t)a] != val[(size_t)b]) return val[(size_t)a] > val[(size_t)b];
+				return (uint32_t)(keys[(size_t)a] & 0xffffffffu) > (uint32_t)(keys[(size_t)b] & 0xffffffffu);
+			});
+		}
+		n_out = std::min((int)order.size(), only ? q->n_only : k);
+	}
 	std::vector<float> raw_sel((size_t)std::max(n_out, 1));
-	if (!do_flow && out->raw_score && n_out > 0) {
+	if (!do_flow && !(canon_tr && n_sel > 0) && out->raw_score && n_out > 0) {
 		// gather the aligner scores of the winners
 		for (int i = 0; i < n_out; i++) {
 			const int64_t g = (int64_t)(uint32_t)(keys[(size_t)i] & 0xffffffffu);
@@ -872,7 +922,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		const float s = val[(size_t)src];
 		out->score[i] = s;
 		out->sentence[i] = sentence_of((int64_t)(uint32_t)(key & 0xffffffffu));
-		if (out->raw_score) out->raw_score[i] = do_flow ? raw[(size_t)src] : span_skip_raw ? s : raw_sel[(size_t)i];
+		if (out->raw_score) out->raw_score[i] = (do_flow || canon_tr) ? raw[(size_t)src] : span_skip_raw ? s : raw_sel[(size_t)i];
 		if (do_flow) {
 			for (int j = 0; j < q->len_t; j++) {
 				out->mapping[(size_t)i * q->len_t + j] = map[(size_t)src * ostride + j];
@@ -888,7 +938,10 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	}
 	out->n_out = n_out;
 	c->have_scores = !only;
-	if ((q->algorithm == VK_ALG_RWMD || (is_align && rows_on_request)) && n_out > 0) {
+	if (canon_tr && n_out > 0) {
+		for (int i = 0; i < n_out; i++)   // the rows of the winners, in their final order
+			memcpy(out->sim_rows + (size_t)i * rows_R * rows_W, rows_all.data() + (size_t)order[(size_t)i] * rows_R * rows_W, (size_t)rows_R * rows_W * 4);
+	} else if ((q->algorithm == VK_ALG_RWMD || (is_align && rows_on_request)) && n_out > 0) {
 		std::vector<int64_t> rows_idx;
 		for (int i = 0; i < n_out; i++) rows_idx.push_back((int64_t)(uint32_t)(keys[(size_t)order[(size_t)i]] & 0xffffffffu));
 		float no_mass[VK_MAX_QUERY_LEN] = {0};
