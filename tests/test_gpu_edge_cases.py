@@ -133,7 +133,7 @@ def test_overlapping_slices(hip, oracle):
 		assert_same_results(got, ref)
 	ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=64, sent_off=start, sent_end=end, X=Xb, Q=Qb, algorithm=oracle.ALG_RWMD, max_matches=12)
 	got = c.query(Qb, q_normalize=False, algorithm=hip.VK_ALG_RWMD, max_matches=12).trimmed()
-	assert_same_results(got, ref, check_mapping=False, score_tol=1e-5)
+	assert_same_results(got, ref, check_mapping=False, exact=True)
 	c.close()
 
 

@@ -62,7 +62,7 @@ def test_long_slices_contextual(hip, oracle, d):
 	# transport: the relaxed distance and (since round 2, for queries of at most 16 tokens) the exact ones have no length limit
 	ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=off, X=Xb, Q=Qb, algorithm=oracle.ALG_RWMD, max_matches=15)
 	got = c.query(Qb, q_normalize=False, algorithm=hip.VK_ALG_RWMD, max_matches=15).trimmed()
-	assert_same_results(got, ref, check_mapping=False, score_tol=2e-5, tie_tol=2e-5)
+	assert_same_results(got, ref, check_mapping=False, exact=True)
 	ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=off, X=Xb, Q=Qb, algorithm=oracle.ALG_RWMD, rwmd=(False, False, True), wmd_full=True, max_matches=5)
 	got = c.query(Qb, q_normalize=False, algorithm=hip.VK_ALG_RWMD, rwmd=(False, False, True), wmd_full=True, max_matches=5).trimmed()
 	assert_same_results(got, ref, check_mapping=False, score_tol=2e-5, tie_tol=2e-5)

@@ -35,7 +35,7 @@ def test_contextual_rwmd(hip, oracle, variant, shape):
 		ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=corpus["sent_off"], X=Xb, Q=Qb,
 			algorithm=oracle.ALG_RWMD, rwmd=flags, max_matches=15, min_score=0.0, want_all_scores=True)
 		got = c.query(Qb, algorithm=hip.VK_ALG_RWMD, rwmd=flags, q_normalize=False, max_matches=15, min_score=0.0)
-		assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=1e-5)
+		assert_same_results(got.trimmed(), ref, check_mapping=False, exact=True)   # relaxed WMD: the winners are restated on the host from canonical rows (vk_transport_host.h)
 		np.testing.assert_allclose(got.raw_score[:got.n], ref["raw"], atol=1e-4, rtol=0)
 		np.testing.assert_allclose(c.last_scores(), ref["all_scores"], atol=1e-5, rtol=0)
 	c.close()
@@ -58,7 +58,7 @@ def test_static_rwmd(hip, oracle, variant):
 			Q=Qb, q_ids=qids, algorithm=oracle.ALG_RWMD, rwmd=flags, max_matches=20, want_all_scores=True)
 		got = c.query(Qb, q_token_ids=qids, algorithm=hip.VK_ALG_RWMD, rwmd=flags, q_normalize=False, max_matches=20)
 		np.testing.assert_allclose(c.last_scores(), ref["all_scores"], atol=1e-5, rtol=0)
-		assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=1e-5, tie_tol=1e-5)
+		assert_same_results(got.trimmed(), ref, check_mapping=False, exact=True)
 	c.close()
 
 
@@ -96,7 +96,7 @@ def test_distributed_rwmd_long_slices(hip, oracle, layout):
 			ref = oracle.find(algorithm=oracle.ALG_RWMD, rwmd=flags, max_matches=9, min_score=-1.0, want_all_scores=True, **base)
 			got = c.query(Qb, algorithm=hip.VK_ALG_RWMD, rwmd=flags, q_normalize=False, max_matches=9, min_score=-1.0, **qargs)
 			np.testing.assert_allclose(c.last_scores(), ref["all_scores"], atol=1e-5, rtol=0)
-			assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=1e-5, tie_tol=1e-5)
+			assert_same_results(got.trimmed(), ref, check_mapping=False, exact=True)
 	c.close()
 
 
@@ -124,7 +124,7 @@ def test_distributed_rwmd_long_queries(hip, oracle, layout, len_t):
 		ref = oracle.find(algorithm=oracle.ALG_RWMD, rwmd=flags, max_matches=9, min_score=-1.0, want_all_scores=True, **base)
 		got = c.query(Qb, algorithm=hip.VK_ALG_RWMD, rwmd=flags, q_normalize=False, max_matches=9, min_score=-1.0, **qargs)
 		np.testing.assert_allclose(c.last_scores(), ref["all_scores"], atol=1e-5, rtol=0)
-		assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=1e-5, tie_tol=1e-5)
+		assert_same_results(got.trimmed(), ref, check_mapping=False, exact=True)
 	c.close()
 
 

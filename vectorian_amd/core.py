@@ -424,12 +424,15 @@ class Corpus:
 			q.pos_mismatch_penalty, q.similarity_threshold = float(pos_mismatch_penalty), float(similarity_threshold)
 		return q, len_t
 
+	def _winner_rows(self):
+		"""similarity rows / plans of the winners: room for the longest slice of the corpus (a multiple of 64 tokens)"""
+		return min(VK_MAX_SENT_LEN, max(VK_FAST_SENT_LEN, (getattr(self, "_max_len", 0) + 63) // 64 * 64))
+
 	def query(self, q_vectors, **options):
 		"""One query against the shard (vk_query).  Returns a TopK."""
 		keep = []
 		q, len_t = self._desc(q_vectors, keep, **options)
-		# similarity rows / plans of the winners: room for the longest slice of the corpus (a multiple of 64 tokens)
-		rows = min(VK_MAX_SENT_LEN, max(VK_FAST_SENT_LEN, (getattr(self, "_max_len", 0) + 63) // 64 * 64))
+		rows = self._winner_rows()
 		out = TopK(max(1, q.max_matches), len_t, transport=bool(q.want_flow) and (q.algorithm != VK_ALG_ALIGN or bool(options.get("want_rows"))), rows=rows)
 		so = out._struct()
 		_check(lib().vk_query(self._h, C.byref(q), C.byref(so)))
@@ -471,7 +474,7 @@ class Corpus:
 			# transport flows need the winners' similarity rows: always for the relaxed WMD (the batch path returns them for every
 			# query), for exact transport (answered query by query) only in small batches -- 80 KB of rows and plans per query
 			t = TopK(max(1, q.max_matches), len_t, transport=bool(q.want_flow) and q.algorithm != VK_ALG_ALIGN and
-				(n <= 16 or (q.algorithm == VK_ALG_RWMD and not q.wmd_full)))
+				(n <= 16 or (q.algorithm == VK_ALG_RWMD and not q.wmd_full)), rows=self._winner_rows())
 			outs.append(t)
 			sos[i] = t._struct()
 		_check(lib().vk_query_batch(self._h, qs, n, sos))
@@ -494,8 +497,8 @@ class Corpus:
 		Q = np.ascontiguousarray(np.concatenate(arrs))          # [sum of the lengths x d]
 		keep.append(Q)
 		first, _ = self._desc(arrs[0], keep, **options)
-		if bool(first.want_flow) and first.algorithm != VK_ALG_ALIGN and n <= 16:
-			return None    # transport flows: per-query row / plan buffers (the general path)
+		if bool(first.want_flow) and first.algorithm != VK_ALG_ALIGN and (n <= 16 or int(lens.max()) > VK_FAST_QUERY_LEN):
+			return None    # transport flows: per-query row / plan buffers (the general path; queries of more than 16 tokens: wider rows)
 		k = max(1, first.max_matches)
 		score, raw = np.zeros((n, k), np.float32), np.zeros((n, k), np.float32)
 		sentence = np.zeros((n, k), np.int64)
@@ -523,13 +526,16 @@ class Corpus:
 		patch(orows, _TopkOut.mapping, mapping, offsets=row_off[:-1] * k)
 		patch(orows, _TopkOut.edge_sim, edge, offsets=row_off[:-1] * k)
 		rows = plan = None
-		if bool(first.want_flow) and first.algorithm == VK_ALG_RWMD and not bool(first.wmd_full) and int(lens.max()) <= VK_FAST_QUERY_LEN:
+		if bool(first.want_flow) and first.algorithm == VK_ALG_RWMD and not bool(first.wmd_full):
 			# relaxed WMD: the similarity rows of every query's winners (the host states their SparseFlow from them); no plans
 			# (exact transport only): one zero array stands in for all of them
-			rows = np.zeros((n, k, VK_FAST_SENT_LEN, 16), np.float32)
-			plan = np.zeros((k, 16, VK_FAST_SENT_LEN), np.float32)
+			# (a corpus with slices of more than 64 tokens is answered query by query: room for its longest slice, as `query`)
+			R = self._winner_rows()
+			rows = np.zeros((n, k, R, 16), np.float32)
+			plan = np.zeros((k, 16, R), np.float32)
 			keep.extend((rows, plan))
 			patch(orows, _TopkOut.sim_rows, rows)
+			orows[:, _TopkOut.rows_per_winner.offset:_TopkOut.rows_per_winner.offset + 4].view(np.int32)[:, 0] = R
 		outs = []
 		for i in range(n):
 			a, b, lt = k * int(row_off[i]), k * int(row_off[i + 1]), int(lens[i])
