@@ -170,6 +170,10 @@ typedef struct {
 	 * Alignments fill sim_rows too when the array is given: the 'similarity' matrix of the debug hook
 	 * (call_debug_hook, metric/alignment.h:145-173), for the winners.
 	 * Optional (NULL: not produced).
+	 * Relaxed WMD (VK_ALG_RWMD without wmd_full) with want_flow and sim_rows given: score / raw_score of the result set are
+	 * restated on the host from these rows in the reference's order of operations (RelaxedSolver, alignment/wmd.h:287-416) --
+	 * bit-identical to a scalar fp32 run of the reference, whichever kernel ranked the slices; a winner of more than R tokens
+	 * keeps the value of the scoring pass.
 	 * W = the query length rounded up to a multiple of 16 (16 for queries of at most VK_FAST_QUERY_LEN tokens). */
 	float *sim_rows;         /* [capacity x R x W] similarity S[i][j] of slice token i and query token j
 	                            (clipped, tag weights applied, static layout: sim[id(t_j)][j] = 1); rows >= the slice's length are zero */
