@@ -26,7 +26,7 @@ def same(a, b, exact_flows):
 			return "flow types differ"
 		for key in fx:
 			if key != "type" and not (np.asarray(fx[key]) == np.asarray(fy[key])).all():
-				return "flow['%s'] differs" % key
+				return "flow['%s'] differs: %r | %r (slice of %d tokens)" % (key, np.asarray(fx[key]).tolist(), np.asarray(fy[key]).tolist(), x._len_s)
 	return None
 
 

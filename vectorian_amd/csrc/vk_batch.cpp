@@ -119,7 +119,8 @@ static int batch_winner_rows(vk_corpus *c, const vk_query_desc *qs, int n_querie
 						out->mapping[(size_t)r * q.len_t + t] = -1;
 						out->edge_sim[(size_t)r * q.len_t + t] = 0.0f;
 					}
-				memcpy(out->sim_rows + (size_t)r * 64 * 16, c->h_brows + ((size_t)i * kk + j) * 64 * 16, (size_t)64 * 16 * 4);
+				const size_t room = out->rows_per_winner > 0 ? (size_t)out->rows_per_winner : (size_t)VK_FAST_SENT_LEN;   // rows per winner of the caller's array (>= 64)
+				memcpy(out->sim_rows + (size_t)r * room * 16, c->h_brows + ((size_t)i * kk + j) * 64 * 16, (size_t)64 * 16 * 4);
 			}
 			out->n_out = n_out;
 		}

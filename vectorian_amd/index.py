@@ -288,6 +288,13 @@ def dense_flow(S, G, ids_s, ids_t, mass_t):
 	return {"type": "dense", "flow": flow, "dist": distv}
 
 
+def _rows_room(top, i):
+	"""slice tokens the similarity rows of winner i have room for: the rows per winner the backend returned; on a sharded index what
+	the rank that scored the winner returned (shards.rows_allreduce)"""
+	room = getattr(top, "rows_room", None)
+	return top.sim_rows.shape[1] if room is None else int(room[i])
+
+
 class _Winners:
 	"""the result set of one query as the arrays the backend returned; the HipMatch objects of the query index into it"""
 	__slots__ = ("index", "query", "top", "n", "sent", "docs", "starts", "ends", "gaps", "args", "qmag", "masks", "q_tag_codes", "transport")
@@ -716,10 +723,6 @@ class HipBruteForceIndex(Index):
 			self._corpus.set_slices(dev_start, dev_end)
 		self._corpus.finalize()
 		self._max_slice_len = int((np.asarray(dev_end) - np.asarray(dev_start)).max()) if len(dev_start) else 0   # of the resident part
-		if shard is not None and hasattr(self._corpus, "_max_len") and n_slices:
-			# similarity rows / plans of transport winners are sized by the longest slice; the ranks exchange those of the merged winners
-			# (shards.rows_allreduce), so every rank sizes them by the longest slice of the WHOLE corpus
-			self._corpus._max_len = int((self._slice_end - self._slice_start).max())
 
 	@property
 	def metric_name(self):
@@ -1050,7 +1053,7 @@ class HipBruteForceIndex(Index):
 			if alg == core.VK_ALG_WRD:
 				continue
 			sim = None
-			if getattr(top, "sim_rows", None) is not None and m._len_s <= top.sim_rows.shape[1]:
+			if getattr(top, "sim_rows", None) is not None and m._len_s <= _rows_room(top, i):
 				sim = top.sim_rows[i][:m._len_s if m._index_map is None else len(m._index_map), :len(p_query)].copy()
 			hook("alignment", {"slice": m.slice_id, "similarity": sim, "flow": m.flow, "score": m.raw_score})
 
@@ -1077,7 +1080,7 @@ class HipBruteForceIndex(Index):
 		if getattr(top, "sim_rows", None) is None or getattr(top, "plan", None) is None or m._index_map is not None:
 			return None
 		len_s, len_t = m._len_s, len(p_query)
-		if len_s > top.sim_rows.shape[1]:
+		if len_s > _rows_room(top, i):
 			return None
 		g = int(m._w.sent[m._i])
 		a = int(self._slice_start[g])
@@ -1201,7 +1204,7 @@ class HipBruteForceIndex(Index):
 			return None
 		a, b = span if span is not None else (int(self._slice_start[g]), int(self._slice_end[g]))
 		len_s, len_t = (b - a if index_map is None else len(index_map)), len(p_query)
-		if len_s > top.sim_rows.shape[1]:   # rows per winner the backend was given room for (the corpus's longest slice on the HIP backend)
+		if len_s > _rows_room(top, i):   # rows per winner the backend was given room for (the corpus's longest slice on the HIP backend)
 			return None
 		alg = args["algorithm"]
 		token_ids, tag_codes = self._token_ids, self._tag_codes

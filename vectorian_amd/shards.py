@@ -208,7 +208,7 @@ def rows_allreduce(local_tops, merged_tops, sentence_offset, n_local, lens, grou
 	per query travel, not k per rank, and R is the longest MERGED winner, not the corpus's longest slice (`lens[i][j]`: tokens of
 	merged winner j of query i -- every rank holds the slice table and computes the same).  (Round 2 all-gathered k x 2 x R_max x W
 	per rank through pageable copies: 26 MB per rank and query at k = 100, R_max = 512.)
-	Sets merged_tops[i].sim_rows [k x R x W] and .plan [k x W x R]."""
+	Sets merged_tops[i].sim_rows [k x R x W], .plan [k x W x R] and .rows_room [k]."""
 	import torch
 	import torch.distributed as dist
 
@@ -220,13 +220,16 @@ def rows_allreduce(local_tops, merged_tops, sentence_offset, n_local, lens, grou
 	k = max(len(m.score) for m in merged_tops)
 	R = max([int(np.max(l)) if len(l) else 0 for l in lens] + [1])
 	W = max([t.sim_rows.shape[2] for t in local_tops if getattr(t, "sim_rows", None) is not None] + [16])
-	# rows per winner the backend returned (batched calls: 64; vk_query: the longest slice): a merged winner longer than that has
-	# no rows anywhere, and must read as one without -- not as rows cut short (the host would state a flow from them)
-	cap = min([t.sim_rows.shape[1] for t in local_tops if getattr(t, "sim_rows", None) is not None and t.n > 0] + [1 << 30])
-	Wt = torch.tensor([W, R, -cap], dtype=torch.int64, device=device)
+	# rows per winner a backend returned (batched calls: 64; vk_query: the longest slice of ITS shard): the ranks differ.  R = the
+	# longest merged winner some rank can have rows for; with every winner travels the room its owner had (`rows_room`): a winner
+	# longer than that has no rows anywhere and must read as one without -- not as rows cut short (the host would state a flow from them)
+	cap = max([t.sim_rows.shape[1] for t in local_tops if getattr(t, "sim_rows", None) is not None and t.n > 0] + [0])
+	Wt = torch.tensor([W, R, cap], dtype=torch.int64, device=device)
 	dist.all_reduce(Wt, op=dist.ReduceOp.MAX, group=group)   # a rank without winners knows no W of its own
-	W, R = int(Wt[0].item()), max(1, min(int(Wt[1].item()), -int(Wt[2].item())))
-	buf = np.zeros((nq, k, 2 if with_plan else 1, R * W), dtype=np.float32)
+	W, R = int(Wt[0].item()), max(1, min(int(Wt[1].item()), max(1, int(Wt[2].item()))))
+	planes = 2 if with_plan else 1
+	flat = np.zeros(nq * k * planes * R * W + nq * k, dtype=np.float32)
+	buf, room = flat[:nq * k * planes * R * W].reshape(nq, k, planes, R * W), flat[nq * k * planes * R * W:].reshape(nq, k)
 	for i, (loc, mer) in enumerate(zip(local_tops, merged_tops)):
 		if loc is None or getattr(loc, "sim_rows", None) is None or loc.n == 0:
 			continue
@@ -237,6 +240,7 @@ def rows_allreduce(local_tops, merged_tops, sentence_offset, n_local, lens, grou
 			if not (0 <= g < n_local) or g not in where:
 				continue
 			jl, ln = where[g], min(int(lens[i][j]), loc.sim_rows.shape[1], R)
+			room[i, j] = float(loc.sim_rows.shape[1])
 			rows = np.zeros((R, W), dtype=np.float32)
 			rows[:ln, :w_l] = loc.sim_rows[jl][:ln]
 			buf[i, j, 0] = rows.reshape(-1)
@@ -244,13 +248,15 @@ def rows_allreduce(local_tops, merged_tops, sentence_offset, n_local, lens, grou
 				plan = np.zeros((W, R), dtype=np.float32)
 				plan[:w_l, :ln] = loc.plan[jl][:, :ln]
 				buf[i, j, 1] = plan.reshape(-1)
-	t = torch.from_numpy(buf)
+	t = torch.from_numpy(flat)
 	on_gpu = torch.device(device).type == "cuda"
 	if on_gpu:
 		t = t.pin_memory().to(device, non_blocking=True)
 	dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-	allb = t.cpu().numpy() if on_gpu else t.numpy()
+	flat = t.cpu().numpy() if on_gpu else t.numpy()
+	allb, room = flat[:nq * k * planes * R * W].reshape(nq, k, planes, R * W), flat[nq * k * planes * R * W:].reshape(nq, k)
 	for i, mer in enumerate(merged_tops):
 		mer.sim_rows = np.ascontiguousarray(allb[i, :, 0]).reshape(k, R, W)
 		mer.plan = np.ascontiguousarray(allb[i, :, 1]).reshape(k, W, R) if with_plan else np.zeros((k, W, R), dtype=np.float32)
+		mer.rows_room = np.minimum(room[i], R).astype(np.int64)   # slice tokens winner j has rows for (0: none)
 
