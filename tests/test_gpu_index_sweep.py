@@ -118,6 +118,9 @@ def test_random_session_on_hip_equals_oracle_double(hip, seed):
 	n_slices = gpu.n_slices
 	if rng.random() < 0.3:
 		index_kw["saliency"] = rng.uniform(0.5, 1.5, size=n_slices).astype(np.float32)
+	if seed >= 60 and seed % 5 == 0:   # (the first 60 seeds keep the sessions of the first soaks)
+		index_kw["precision"] = "f32"
+	if index_kw:
 		gpu.close()
 		gpu = part.index(sim, nlp=nlp, **index_kw)
 	cpu = part.index(sim, nlp=nlp, corpus_factory=OracleCorpus, **index_kw)
@@ -136,6 +139,8 @@ def test_random_session_on_hip_equals_oracle_double(hip, seed):
 			options["submatch_weight"] = float(rng.choice([0.5, 1.0, 2.0]))
 		n = int(rng.choice([1, 5, 12]))
 		min_score = 0.0 if rng.random() < 0.7 else -100.0
+		if seed >= 60 and seed % 7 == 0:
+			n = int(rng.choice([60, 70, 150]))   # the margin of the canonical re-ranking across the selection's k <= 64 / k > 64 paths
 		a = gpu.find(text, n=n, min_score=min_score, options=options)
 		b = cpu.find(text, n=n, min_score=min_score, options=options)
 		ctx = (seed, type(strategy).__name__, getattr(strategy, '_options', None), text, options, bool(kw), part.to_args(), type(emb).__name__, n, min_score, bool(index_kw))
@@ -182,7 +187,7 @@ def test_random_session_find_many_equals_find(hip, seed):
 		part = session.partition("sentence", int(rng.integers(1, 4)), int(rng.integers(1, 3)))
 	else:
 		part = session.partition("token", int(rng.integers(4, 20)), int(rng.integers(1, 8)))
-	gpu = part.index(sim, nlp=nlp)
+	gpu = part.index(sim, nlp=nlp, **({"precision": "f32"} if seed >= 30 and seed % 5 == 0 else {}))
 	texts = []
 	wide = rng.random() < 0.2
 	for _ in range(int(rng.integers(2, 24))):
@@ -200,6 +205,8 @@ def test_random_session_find_many_equals_find(hip, seed):
 		options["submatch_weight"] = float(rng.choice([0.5, 1.0, 2.0]))
 	n = int(rng.choice([1, 5, 12]))
 	min_score = 0.0 if rng.random() < 0.7 else -100.0
+	if seed >= 30 and seed % 7 == 0:
+		n = int(rng.choice([60, 70, 150]))
 	many = gpu.find_many(texts, n=n, min_score=min_score, options=options, in_flight=int(rng.integers(1, 4)))
 	assert len(many) == len(texts)
 	for text, a in zip(texts, many):
