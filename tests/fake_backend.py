@@ -168,7 +168,7 @@ class OracleCorpus:
 			if transport and tag_weights is not None:
 				# the solvers (and the flows stated from these rows) see the modified similarity (TagWeightedSlice::similarity, slice/static.h:237-264)
 				wgt = np.asarray(tag_weights, dtype=np.float32)[None, :] * np.where(
-					self._pos[a:b, None] != np.asarray(q_pos, dtype=np.int8)[None, :], np.float32(1.0 - pos_mismatch_penalty), np.float32(1.0))
+					self._pos[a:b, None] != np.asarray(q_pos, dtype=np.int8)[None, :], (np.float32(1.0) - np.float32(pos_mismatch_penalty)), np.float32(1.0))
 				raw = S
 				S = (raw * wgt).astype(np.float32)
 				S[S <= similarity_threshold] = 0.0
@@ -182,7 +182,7 @@ class OracleCorpus:
 					for si in np.nonzero(in_t)[0]:
 						ft = int(np.nonzero(kt == ks[si])[0][0])
 						for tj in np.nonzero(in_s & (kt > ks[si]))[0]:
-							w = np.float32(tag_weights[ft]) * (np.float32(1.0 - pos_mismatch_penalty) if self._pos[a + si] != q_pos[tj] else np.float32(1.0))
+							w = np.float32(tag_weights[ft]) * ((np.float32(1.0) - np.float32(pos_mismatch_penalty)) if self._pos[a + si] != q_pos[tj] else np.float32(1.0))
 							v = np.float32(raw[si, tj] * w)
 							S[si, tj] = 0.0 if v <= similarity_threshold else v
 			if transport and b - a <= core.VK_FAST_SENT_LEN:

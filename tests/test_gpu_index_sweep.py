@@ -137,12 +137,28 @@ def test_random_session_on_hip_equals_oracle_double(hip, seed):
 			options["pos_filter"] = [str(x) for x in rng.choice(["DET", "PUNCT", "ADJ"], size=int(rng.integers(1, 3)), replace=False)]
 		if is_align and rng.random() < 0.2:
 			options["submatch_weight"] = float(rng.choice([0.5, 1.0, 2.0]))
+		if seed >= 60 and seed % 11 == 0:
+			options["tag_filter"] = [str(x) for x in rng.choice(TAGS, size=int(rng.integers(1, 3)), replace=False)]
 		n = int(rng.choice([1, 5, 12]))
 		min_score = 0.0 if rng.random() < 0.7 else -100.0
 		if seed >= 60 and seed % 7 == 0:
 			n = int(rng.choice([60, 70, 150]))   # the margin of the canonical re-ranking across the selection's k <= 64 / k > 64 paths
-		a = gpu.find(text, n=n, min_score=min_score, options=options)
-		b = cpu.find(text, n=n, min_score=min_score, options=options)
+		seen = {"hip": [], "double": []}
+		hooked = seed >= 60 and seed % 6 == 0 and (is_align or (getattr(strategy, "_options", None) or {}).get("relaxed"))
+		a = gpu.find(text, n=n, min_score=min_score, options=dict(options, debug=lambda name, data: seen["hip"].append((name, data))) if hooked else options)
+		b = cpu.find(text, n=n, min_score=min_score, options=dict(options, debug=lambda name, data: seen["double"].append((name, data))) if hooked else options)
+		if hooked:
+			# the debug hook (call_debug_hook, metric/alignment.h:145-173, 600-607), called for the winners: the same calls with the same data
+			assert [x[0] for x in seen["hip"]] == [x[0] for x in seen["double"]] and len(seen["hip"]) == len(a)
+			for (_, x), (_, y) in zip(seen["hip"], seen["double"]):
+				assert x.keys() == y.keys() and x["slice"] == y["slice"] and x["score"] == y["score"]
+				if "worst_score" in x:
+					assert x["worst_score"] == y["worst_score"]
+				if x.get("similarity") is not None and y.get("similarity") is not None:
+					if not np.array_equal(x["similarity"], y["similarity"]):
+						ne = x["similarity"] != y["similarity"]
+						raise AssertionError("the hook's similarity matrix differs: %r" % ((seed, type(strategy).__name__, bool(kw), type(emb).__name__, index_kw.get("precision"), options,
+							x["similarity"].shape, np.argwhere(ne).tolist()[:6], x["similarity"][ne][:6].tolist(), y["similarity"][ne][:6].tolist(), kw),))
 		ctx = (seed, type(strategy).__name__, getattr(strategy, '_options', None), text, options, bool(kw), part.to_args(), type(emb).__name__, n, min_score, bool(index_kw))
 		assert len(a) == len(b), ctx
 		if is_align:
