@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 9
+#define VK_ABI_VERSION 10
 #define VK_MAX_QUERY_LEN 64   /* query tokens */
 #define VK_FAST_QUERY_LEN 16  /* queries up to this length run in the fused kernels (one 16-wide MFMA column block); longer ones
                                  take the multi-block kernel (2 or 4 column blocks) or, where that does not apply, a
@@ -272,6 +272,16 @@ int vk_pack_records(const vk_topk_out *set, int32_t len_t, int32_t k, int64_t se
  * result sets.  records: [n_sets x k x words] as the all-gather delivers them; out as for vk_merge_topk (capacity >= k);
  * order: score descending, ties by slice index descending (Match::compare_by_score, match/match_impl.h:8-42). */
 int vk_merge_records(const int32_t *records, int32_t n_sets, int32_t len_t, int32_t k, vk_topk_out *out);
+
+/* The relaxed word mover's distance of ONE slice from its similarity rows, on the host, in the reference's order of operations
+ * (BOWBuilder / UniqueTokensBOWBuilder, vectorian/core/cpp/alignment/bow.h:204-333; distance matrix, alignment/wmd.h:107-135;
+ * RelaxedSolver, :287-416; cost_to_score, :138-140) -- what vk_query / vk_query_batch return for the winners of a relaxed-WMD query
+ * (vk_topk_out.sim_rows), exposed so that a caller holding rows can restate a score (no GPU needed).
+ * S[i * ld + j]: modified similarity of slice token i and query token j.  key_s / key_t: vocabulary keys of the tokens -- token ids,
+ * or (id, tag) pairs folded into one int for the tag-weighted similarity -- or both NULL (every position its own entry: contextual
+ * embeddings).  score_out: (max_cost - cost) / max_cost, the aligner score of RelaxedWordMoversDistance (metric/alignment.h:579-607). */
+int vk_rwmd_from_rows(const float *S, int32_t ld, int32_t len_s, int32_t len_t, const int32_t *key_s, const int32_t *key_t,
+	int32_t injective, int32_t symmetric, int32_t normalize_bow, float *score_out);
 
 #ifdef __cplusplus
 }

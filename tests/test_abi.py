@@ -24,7 +24,7 @@ def test_every_declared_symbol_is_exported():
 	missing = [s for s in syms if not hasattr(lib, s)]
 	assert not missing, missing
 	assert sorted(core.EXPORTS) == syms
-	assert lib.vk_abi_version() == 9
+	assert lib.vk_abi_version() == 10
 
 
 def test_no_gpu_means_loud_failure():
@@ -134,3 +134,32 @@ def test_struct_fields_agree_header_shim_and_integration_stub():
 		names = [f[0] for f in shim._fields_]
 		assert header_fields(cname) == names, (cname, header_fields(cname), names)
 		assert stub_fields(stub) == names, (stub, stub_fields(stub), names)
+
+
+def test_rwmd_from_rows_is_the_oracles_relaxed_solver(oracle):
+	# the host restatement of the winners' relaxed-WMD scores (vk_transport_host.h) against the oracle's vko_wmd on random rows: every
+	# form, position vocabularies and token vocabularies with repeated ids on both sides, ties among the distances -- bit for bit
+	from vectorian_amd import core
+	rng = np.random.default_rng(5)
+	n = 0
+	for trial in range(400):
+		len_s, len_t = int(rng.integers(1, 70)), int(rng.integers(1, 40))
+		S = rng.random((len_s, len_t)).astype(np.float32)
+		S[rng.random(S.shape) < 0.3] = 0.0                       # thresholded cells: ties at distance 1
+		S[rng.random(S.shape) < 0.05] = np.float32(1.7)          # tag-weighted similarities exceed 1: distance clamped at 0
+		if trial % 2:
+			ids_s, ids_t = rng.integers(0, 12, size=len_s).astype(np.int32), rng.integers(0, 12, size=len_t).astype(np.int32)
+			for i in range(len_s):                                  # equal tokens have equal rows / columns, as a similarity matrix has
+				S[i] = S[int(np.nonzero(ids_s == ids_s[i])[0][0])]
+			for j in range(len_t):
+				S[:, j] = S[:, int(np.nonzero(ids_t == ids_t[j])[0][0])]
+		else:
+			ids_s = ids_t = None
+		for inj, sym, nbow in ((True, True, True), (True, False, True), (True, False, False), (False, True, True), (False, False, True), (False, False, False)):
+			ref = np.float32(oracle.rwmd(S, ids_s, ids_t, injective=inj, symmetric=sym, normalize_bow=nbow))
+			got = core.rwmd_from_rows(S, ids_s, ids_t, injective=inj, symmetric=sym, normalize_bow=nbow)
+			assert got.view(np.uint32) == ref.view(np.uint32), (trial, inj, sym, nbow, got, ref)
+			n += 1
+	assert n == 2400
+	with pytest.raises(core.VkError):
+		core.rwmd_from_rows(S, None, None, injective=True, symmetric=True, normalize_bow=False)

@@ -93,7 +93,7 @@ EXPORTS = [
 	"vk_corpus_create", "vk_corpus_append_vectors", "vk_corpus_set_token_ids", "vk_corpus_set_token_pos", "vk_corpus_set_token_tags", "vk_corpus_filter",
 	"vk_corpus_set_sentences", "vk_corpus_set_slices", "vk_corpus_finalize", "vk_corpus_free", "vk_corpus_device_bytes",
 	"vk_query", "vk_query_batch", "vk_last_scores", "vk_last_timings", "vk_merge_topk",
-	"vk_record_words", "vk_pack_records", "vk_merge_records"]
+	"vk_record_words", "vk_pack_records", "vk_merge_records", "vk_rwmd_from_rows"]
 
 _lib = None
 
@@ -151,7 +151,8 @@ def lib():
 		L.vk_record_words.argtypes = [C.c_int32]
 		L.vk_pack_records.argtypes = [C.POINTER(_TopkOut), C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
 		L.vk_merge_records.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_TopkOut)]
-		if L.vk_abi_version() != 9:
+		L.vk_rwmd_from_rows.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float)]
+		if L.vk_abi_version() != 10:
 			raise RuntimeError("libvectorian_hip.so ABI version mismatch")
 		_lib = L
 	return _lib
@@ -277,6 +278,18 @@ def pack_records(top, sentence_offset, k, out=None):
 	s = top._struct()
 	_check(lib().vk_pack_records(C.byref(s), top.len_t, k, int(sentence_offset), _np_ptr(out)))
 	return out
+
+
+def rwmd_from_rows(S, key_s=None, key_t=None, injective=True, symmetric=True, normalize_bow=True):
+	"""the relaxed word mover's distance of one slice from its similarity rows S [len_s x len_t], as vk_query states it for a winner
+	(vk_rwmd_from_rows; host only)"""
+	S = np.ascontiguousarray(S, dtype=np.float32)
+	ks = None if key_s is None else np.ascontiguousarray(key_s, dtype=np.int32)
+	kt = None if key_t is None else np.ascontiguousarray(key_t, dtype=np.int32)
+	out = C.c_float()
+	_check(lib().vk_rwmd_from_rows(_np_ptr(S), S.shape[1], S.shape[0], S.shape[1], None if ks is None else _np_ptr(ks), None if kt is None else _np_ptr(kt),
+		int(bool(injective)), int(bool(symmetric)), int(bool(normalize_bow)), C.byref(out)))
+	return np.float32(out.value)
 
 
 def merge_records(records, n_sets, len_t, k):

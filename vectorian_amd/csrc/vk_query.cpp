@@ -989,6 +989,16 @@ int vk_merge_topk(const vk_topk_out *sets, int32_t n_sets, int32_t len_t, int32_
 	return VK_OK;
 }
 
+int vk_rwmd_from_rows(const float *S, int32_t ld, int32_t len_s, int32_t len_t, const int32_t *key_s, const int32_t *key_t,
+	int32_t injective, int32_t symmetric, int32_t normalize_bow, float *score_out) {
+	if (!S || !score_out) return fail(VK_ERR_INVALID, "null argument");
+	if (len_s < 0 || len_t < 0 || ld < len_t) return fail(VK_ERR_INVALID, "rows narrower than the query");
+	if ((key_s == nullptr) != (key_t == nullptr)) return fail(VK_ERR_INVALID, "vocabulary keys for both sides or for neither");
+	if (symmetric && !normalize_bow) return fail(VK_ERR_INVALID, "the symmetric relaxed WMD needs normalised bags of words (alignment/wmd.h:441-449)");
+	*score_out = vk_host::rwmd_from_rows(S, ld, len_s, len_t, key_s, key_t, injective != 0, symmetric != 0, normalize_bow != 0);
+	return VK_OK;
+}
+
 static inline int record_w(int len_t) { return (std::max(1, len_t) + 15) / 16 * 16; }
 
 int32_t vk_record_words(int32_t len_t) {

@@ -9,8 +9,9 @@
 //   distances                    alignment/wmd.h:107-135 (1 - similarity, clamped at 0, between the FIRST positions of two entries)
 //   relaxed costs                alignment/wmd.h:287-416 (t -> s, and s -> t when symmetric; 1:1 nearest entry, or 1:n by ascending
 //                                distance until the mass is placed), cost_to_score :138-140
-// The rows handed in are the slice's modified similarities (tag weights, and for the tag-weighted static layout the cells that
-// upstream's symmetric distance matrix holds twice already carry the value of its later write: static_vocab_fixup).
+// The rows handed in are the slice's modified similarities (tag weights applied).  The cells that upstream's symmetric distance matrix
+// holds twice are resolved here, from the rows' cells of the later write (the rows of vk_rows_kernel carry that value in the
+// earlier cell too, static_vocab_fixup: the host states flows from them; this function never reads a rewritten cell).
 #ifndef VK_TRANSPORT_HOST_H
 #define VK_TRANSPORT_HOST_H
 
@@ -23,6 +24,7 @@ namespace vk_host {
 struct BowEntry {
 	int32_t first;   // first position of the entry in its document
 	float mass;      // occurrences (divided by the document's length when the bags are normalised)
+	int32_t key;     // vocabulary key (position vocabularies: unused)
 };
 
 // entries of one document: key == nullptr -- every position is an entry, in position order; else one entry per distinct key, in
@@ -30,7 +32,7 @@ struct BowEntry {
 inline void bag_of_words(const int32_t *key, int n, bool normalise, std::vector<BowEntry> &out) {
 	out.clear();
 	if (!key) {
-		for (int i = 0; i < n; i++) out.push_back({i, 1.0f});
+		for (int i = 0; i < n; i++) out.push_back({i, 1.0f, 0});
 	} else {
 		std::vector<int32_t> by_key((size_t)n);
 		for (int i = 0; i < n; i++) by_key[(size_t)i] = i;
@@ -38,7 +40,7 @@ inline void bag_of_words(const int32_t *key, int n, bool normalise, std::vector<
 		for (int i = 0; i < n; i++) {
 			const int32_t pos = by_key[(size_t)i];
 			if (i > 0 && key[pos] == key[by_key[(size_t)i - 1]]) out.back().mass += 1.0f;
-			else out.push_back({pos, 1.0f});
+			else out.push_back({pos, 1.0f, key[pos]});
 		}
 	}
 	if (normalise) {
@@ -57,8 +59,22 @@ inline float rwmd_from_rows(const float *S, int ld, int len_s, int len_t, const 
 	bag_of_words(vocab ? key_s : nullptr, len_s, normalise, doc[0]);
 	bag_of_words(vocab ? key_t : nullptr, len_t, normalise, doc[1]);
 	const int len[2] = {len_s, len_t};
+	// first position of a key in a document, -1: absent (entries are in key order)
+	auto first_of = [&](int d, int32_t key) {
+		auto it = std::lower_bound(doc[d].begin(), doc[d].end(), key, [](const BowEntry &e, int32_t k) { return e.key < k; });
+		return it != doc[d].end() && it->key == key ? it->first : -1;
+	};
+	// Upstream fills a SYMMETRIC matrix over the joint vocabulary, dist(u, v) = dist(v, u) = d(first position of u in s, of v in t),
+	// u over the slice's entries in key order, v over the query's (wmd.h:121-133): a cell whose two keys occur in BOTH documents is
+	// written twice and the later write -- the larger slice-side key -- stands.  With a similarity that is not symmetric in the two
+	// sides (tag weights belong to the query side) the two values differ.
 	auto distance = [&](int from_doc, const BowEntry &a, const BowEntry &b) {   // a: entry of from_doc, b: entry of the other one
-		const int i = from_doc == 0 ? a.first : b.first, j = from_doc == 0 ? b.first : a.first;
+		const BowEntry &es = from_doc == 0 ? a : b, &et = from_doc == 0 ? b : a;   // the slice's entry, the query's entry
+		int i = es.first, j = et.first;
+		if (vocab && et.key > es.key) {
+			const int i2 = first_of(0, et.key), j2 = first_of(1, es.key);
+			if (i2 >= 0 && j2 >= 0) { i = i2; j = j2; }
+		}
 		const float d = 1.0f - S[(size_t)i * ld + j];
 		return d > 0.0f ? d : 0.0f;
 	};
