@@ -27,7 +27,33 @@ static bool same_gap(const vk_gap &a, const vk_gap &b, int upto) {
 static int batch_winner_rows(vk_corpus *c, const vk_query_desc *qs, int n_queries, vk_topk_out *outs, const uint64_t *keys, int kk, int k, hipStream_t st,
 	const uint8_t *packed16 = nullptr) {
 	int rc;
-	const size_t n_cand = (size_t)n_queries * (size_t)kk;
+	// which of a query's kk candidates are restated: its k best, and of the runners-up those the k-th could lose its place to -- a
+	// score of the scoring pass within rounding (2e-5, ten times what MFMA accumulation was seen to differ by) of the k-th's.
+	// Typically none: 10 rows per query travel instead of 18.  first[i]: where query i's candidates start in the compact list.
+	auto key_score = [](uint64_t key) {
+		const uint32_t ob = (uint32_t)(key >> 32);
+		const uint32_t bits = (ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob;
+		float s;
+		memcpy(&s, &bits, 4);
+		return s;
+	};
+	std::vector<int32_t> first((size_t)n_queries + 1, 0);
+	for (int i = 0; i < n_queries; i++) {
+		int cnt = 0;
+		while (cnt < kk && keys[(size_t)i * kk + cnt] != 0) cnt++;
+		int need = std::min(cnt, k);
+		if (cnt > k) {
+			const float sk = key_score(keys[(size_t)i * kk + k - 1]);
+			const float slack = 2e-5f * std::max(1.0f, std::fabs(sk));
+			while (need < cnt && key_score(keys[(size_t)i * kk + need]) >= sk - slack) need++;
+		}
+		first[(size_t)i + 1] = first[(size_t)i] + need;
+	}
+	const size_t n_cand = (size_t)first[(size_t)n_queries];
+	if (n_cand == 0) {
+		for (int i = 0; i < n_queries; i++) outs[i].n_out = 0;
+		return VK_OK;
+	}
 	const bool trace = getenv("VK_TRACE_BATCH") != nullptr;
 	const auto t_begin = std::chrono::steady_clock::now();
 	auto stamp = [&](const char *what) {
@@ -38,13 +64,14 @@ static int batch_winner_rows(vk_corpus *c, const vk_query_desc *qs, int n_querie
 		if ((rc = alloc_t(c, &c->d_bqt, (size_t)n_queries * c->tile_bytes))) return rc;
 		c->bqt_cap = (size_t)n_queries;
 	}
-	if (c->bcand_cap < n_cand) {
+	const size_t cap_cand = (size_t)n_queries * (size_t)kk;   // buffers for the most a batch of this shape can ask for: no regrowth from batch to batch
+	if (c->bcand_cap < cap_cand) {
 		for (void *ptr : {(void *)c->d_bcand, (void *)c->d_bcandq, (void *)c->d_brows}) if (ptr) VK_HIP(hipFree(ptr));
 		c->d_bcand = nullptr; c->d_bcandq = nullptr; c->d_brows = nullptr;
-		if ((rc = alloc_t(c, &c->d_bcand, n_cand))) return rc;
-		if ((rc = alloc_t(c, &c->d_bcandq, n_cand))) return rc;
-		if ((rc = alloc_t(c, &c->d_brows, n_cand * 64 * 16))) return rc;
-		c->bcand_cap = n_cand;
+		if ((rc = alloc_t(c, &c->d_bcand, cap_cand))) return rc;
+		if ((rc = alloc_t(c, &c->d_bcandq, cap_cand))) return rc;
+		if ((rc = alloc_t(c, &c->d_brows, cap_cand * 64 * 16))) return rc;
+		c->bcand_cap = cap_cand;
 	}
 	std::vector<uint8_t> qt, one;
 	std::vector<uint64_t> hk(n_cand, 0);
@@ -56,10 +83,9 @@ static int batch_winner_rows(vk_corpus *c, const vk_query_desc *qs, int n_querie
 			vk_pack_query(c, &qs[i], one, mags);
 			memcpy(qt.data() + (size_t)i * c->tile_bytes, one.data(), std::min(one.size(), (size_t)c->tile_bytes));
 		}
-		for (int j = 0; j < kk; j++) {
-			hq[(size_t)i * kk + j] = i;
-			if (keys[(size_t)i * kk + j] != 0)
-				hk[(size_t)i * kk + j] = (1ull << 32) | (uint64_t)(uint32_t)(keys[(size_t)i * kk + j] & 0xffffffffu);
+		for (int j = 0; j < first[(size_t)i + 1] - first[(size_t)i]; j++) {
+			hq[(size_t)first[(size_t)i] + j] = i;
+			hk[(size_t)first[(size_t)i] + j] = (1ull << 32) | (uint64_t)(uint32_t)(keys[(size_t)i * kk + j] & 0xffffffffu);
 		}
 	}
 	VK_HIP(hipMemcpyAsync(c->d_bqt, packed16 ? packed16 : qt.data(), (size_t)n_queries * c->tile_bytes, hipMemcpyHostToDevice, st));
@@ -75,11 +101,11 @@ static int batch_winner_rows(vk_corpus *c, const vk_query_desc *qs, int n_querie
 	VK_HIP(vk_launch_rows(&w, (int32_t)n_cand, st));
 	// one copy into pinned host memory, then into the callers' arrays (copies into pageable memory go through the runtime's
 	// staging: 256 of them, one per query, took 5 - 30 ms; a zero-initialised std::vector as the bounce buffer 3 ms)
-	const size_t bytes = n_cand * 64 * 16 * 4;
-	if (c->h_brows_cap < bytes) {
+	const size_t bytes = n_cand * 64 * 16 * 4, cap_bytes = cap_cand * 64 * 16 * 4;
+	if (c->h_brows_cap < cap_bytes) {
 		if (c->h_brows) { VK_HIP(hipHostFree(c->h_brows)); c->h_brows = nullptr; c->h_brows_cap = 0; }
-		VK_HIP(hipHostMalloc((void **)&c->h_brows, bytes, hipHostMallocDefault));
-		c->h_brows_cap = bytes;
+		VK_HIP(hipHostMalloc((void **)&c->h_brows, cap_bytes, hipHostMallocDefault));
+		c->h_brows_cap = cap_bytes;
 	}
 	stamp("kernel issued");
 	VK_HIP(hipMemcpyAsync(c->h_brows, c->d_brows, bytes, hipMemcpyDeviceToHost, st));
@@ -94,12 +120,12 @@ static int batch_winner_rows(vk_corpus *c, const vk_query_desc *qs, int n_querie
 			const vk_query_desc &q = qs[i];
 			vk_topk_out *out = &outs[i];
 			order.clear();
-			for (int j = 0; j < kk; j++) {
+			const size_t at = (size_t)first[(size_t)i];
+			for (int j = 0; j < first[(size_t)i + 1] - first[(size_t)i]; j++) {
 				const uint64_t key = keys[(size_t)i * kk + j];
-				if (key == 0) break;
 				const int64_t g = (int64_t)(uint32_t)(key & 0xffffffffu);
 				const int len_s = (*c->h_end)[(size_t)g] - (*c->h_start)[(size_t)g];
-				raw[(size_t)j] = vk_host::rwmd_from_rows(c->h_brows + ((size_t)i * kk + j) * 64 * 16, 16, len_s, q.len_t, nullptr, nullptr,
+				raw[(size_t)j] = vk_host::rwmd_from_rows(c->h_brows + (at + j) * 64 * 16, 16, len_s, q.len_t, nullptr, nullptr,
 					q.rwmd_injective != 0, q.rwmd_symmetric != 0, q.rwmd_normalize_bow != 0);
 				val[(size_t)j] = (raw[(size_t)j] / (float)q.len_t) * (q.boost ? q.boost[g] : 1.0f);
 				if (val[(size_t)j] > q.min_score) order.push_back(j);
@@ -120,7 +146,7 @@ static int batch_winner_rows(vk_corpus *c, const vk_query_desc *qs, int n_querie
 						out->edge_sim[(size_t)r * q.len_t + t] = 0.0f;
 					}
 				const size_t room = out->rows_per_winner > 0 ? (size_t)out->rows_per_winner : (size_t)VK_FAST_SENT_LEN;   // rows per winner of the caller's array (>= 64)
-				memcpy(out->sim_rows + (size_t)r * room * 16, c->h_brows + ((size_t)i * kk + j) * 64 * 16, (size_t)64 * 16 * 4);
+				memcpy(out->sim_rows + (size_t)r * room * 16, c->h_brows + (at + j) * 64 * 16, (size_t)64 * 16 * 4);
 			}
 			out->n_out = n_out;
 		}
