@@ -80,8 +80,11 @@ int vk_validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_topk_
 			if (q->q_tags && c->desc.layout == VK_LAYOUT_STATIC) {
 				// vocabulary keys (token id, tag) as id * 256 + tag in 32 bits, ordered as upstream's signed pairs: ids below 2^23, tags 0 .. 127
 				if (c->desc.vocab_size > (1 << 23)) return fail(VK_ERR_UNSUPPORTED, "tag-weighted transport with q_tags over the static layout: vocabularies of more than 2^23 entries overflow the (id, tag) keys");
-				for (int j = 0; j < q->len_t; j++)
+				for (int j = 0; j < q->len_t; j++) {
 					if (q->q_tags[j] < 0) return fail(VK_ERR_INVALID, "q_tags: tag codes must be 0 .. 127");
+					// (words the corpus does not hold carry ids of their own above the vocabulary, QueryVocabulary: they key entries too)
+					if (q->q_token_ids && q->q_token_ids[j] >= (1 << 23)) return fail(VK_ERR_UNSUPPORTED, "q_token_ids: ids of 2^23 and more overflow the (id, tag) keys");
+				}
 			}
 			if (q->q_tags && !q->rwmd_injective && !q->wmd_full && c->desc.layout == VK_LAYOUT_STATIC && !c->d_tag)
 				return fail(VK_ERR_STATE, "tag-weighted 1:n RWMD over the static layout with q_tags needs vk_corpus_set_token_tags (its vocabulary is keyed by (token, tag), bow.h:150-176)");
