@@ -69,18 +69,20 @@ def test_wide_query_static_and_long_slices(hip, oracle):
 	c.close()
 
 
-@pytest.mark.parametrize("len_t", [33, 48, 64])
+@pytest.mark.parametrize("len_t", [33, 40, 44, 48, 64])
 def test_four_block_kernel_general_gaps(hip, oracle, len_t):
-	"""33..64 query tokens with general gaps: vk_score32_kernel<3 or 6, ., 4>"""
+	"""33..64 query tokens with general gaps: vk_score32_kernel<3 or 6, ., 4>; 33..48 tokens: the three-block balance of the far
+	candidates (dp32_general<.., B3>: block 3 holds no column, its lanes and block 0's help blocks 1 and 2)"""
 	d = 128
-	corpus = synth.make_contextual_corpus(401, 1, 32 if len_t != 48 else 64, 900, d)   # 48: slices up to 64 tokens (64-row history)
+	corpus = synth.make_contextual_corpus(401, 1, 32 if len_t not in (44, 48) else 64, 900, d)   # 44, 48: slices up to 64 tokens (64-row history)
 	Xb = prep_contextual(corpus)
 	c = hip_contextual_corpus(hip, corpus, Xb)
+	steep = ("table", np.minimum(0.02 * np.arange(0, 65) ** 2, 3.0).astype(np.float32))   # not subadditive: chains of gaps are cheaper (the closure of w_t)
 	for Qb in [prep_query(q) for q in synth.make_queries(corpus, 2, len_t)]:
-		for loc, ms in ((0, 0.0), (1, -1e9), (2, -1e9)):
+		for loc, ms, gap in ((0, 0.0, EXP5L), (1, -1e9, EXP5L), (2, -1e9, EXP5L), (0, 0.0, steep), (1, -1e9, steep)):
 			ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=corpus["sent_off"], X=Xb, Q=Qb, locality=loc,
-				gap_s=EXP5L, gap_t=EXP5L, max_matches=10, min_score=ms, want_all_scores=True)
-			got = c.query(Qb, q_normalize=False, locality=loc, gap_s=EXP5L, gap_t=EXP5L, max_matches=10, min_score=ms)
+				gap_s=gap, gap_t=gap, max_matches=10, min_score=ms, want_all_scores=True)
+			got = c.query(Qb, q_normalize=False, locality=loc, gap_s=gap, gap_t=gap, max_matches=10, min_score=ms)
 			assert_same_results(got.trimmed(), ref)
 			np.testing.assert_allclose(c.last_scores(), ref["all_scores"], atol=1e-4)
 	c.close()

@@ -314,23 +314,35 @@ __device__ __forceinline__ float shr_sub(float x, float w) {
 	return r;
 }
 
-template <int MAXLEN, int NB>
+// B3 (NB = 4, queries of 33..48 tokens: block 3 holds no column): the far candidates are 16 for block 1's columns and 32 for block 2's,
+// 48 per pair of lanes v / 16 + v / 32 + v / 48 + v -- dealt out 12 per lane instead of 24:
+//   block 1 lanes: their sources 0..11;   block 3 lanes: sources 24..31 for column 32 + v, then sources 12..15 for column 16 + v
+//   block 2 lanes: their sources 0..11;   block 0 lanes: sources 12..23 for column 32 + v
+// the helpers' maxima cross through two 64-float slots (block 3's lanes help two columns).
+template <int MAXLEN, int NB, bool B3 = false>
 __device__ __forceinline__ float dp32_general(const float *__restrict__ S, int stride, int rowbase, int len, int maxlen, int col, int lane,
 	const VkWideParams &p, const float (&wsr)[MAXLEN + 1], float *__restrict__ xch) {
+	static_assert(!B3 || NB == 4, "the three-block balance is a form of the four-block kernel");
 	const int v16 = col & 15, blk = col >> 4;
 	const bool is_local = p.locality == VK_DEV_LOCAL, is_global = p.locality == VK_DEV_GLOBAL;
 	const float floor0 = is_local ? 0.0f : VK_NEG_INF;
 	const bool last_col = col == p.len_t - 1;
 	const float inf = __builtin_inff();
 	const float wt_border = p.wt[col + 1], wt_border0 = p.wt0[col + 1];   // chains of gaps from the border column / one gap (border row)
-	constexpr bool BAL = NB == 4;
-	constexpr int NFAR = BAL ? 24 : 16 * (NB - 1);   // far candidates a lane walks
+	constexpr bool BAL = NB == 4 && !B3;
+	constexpr int NFAR = B3 ? 12 : BAL ? 24 : 16 * (NB - 1);   // far candidates a lane walks
 	float wtv[16], wfar[NFAR];
 #pragma unroll
 	for (int k = 1; k < 16; k++) wtv[k] = v16 >= k ? p.wt[k] : inf;
 	// group g of four source columns this lane reads, and the column it works for there
-	auto far_group = [&](int g) { return !BAL ? g : blk == 0 ? g + 6 : (blk == 1 && g >= 4) ? g + 2 : g; };
-	auto far_target = [&](int g) { return !BAL ? col : blk == 0 ? 48 + v16 : (blk == 1 && g >= 4) ? 32 + v16 : col; };
+	auto far_group = [&](int g) {
+		if constexpr (B3) return blk == 0 ? g + 3 : blk == 3 ? (g < 2 ? g + 6 : 3) : g;
+		else return !BAL ? g : blk == 0 ? g + 6 : (blk == 1 && g >= 4) ? g + 2 : g;
+	};
+	auto far_target = [&](int g) {
+		if constexpr (B3) return blk == 0 ? 32 + v16 : blk == 3 ? (g < 2 ? 32 + v16 : 16 + v16) : col;
+		else return !BAL ? col : blk == 0 ? 48 + v16 : (blk == 1 && g >= 4) ? 32 + v16 : col;
+	};
 #pragma unroll
 	for (int i = 0; i < NFAR; i++) {
 		const int src = 4 * far_group(i >> 2) + (i & 3), tgt = far_target(i >> 2);
@@ -375,18 +387,26 @@ __device__ __forceinline__ float dp32_general(const float *__restrict__ S, int s
 			hc = fmaxf(hc, shr_sub<14>(c, wtv[14]));
 			hc = fmaxf(hc, shr_sub<15>(c, wtv[15]));
 			wave_lds_fence();
-			float fa = VK_NEG_INF, fb = VK_NEG_INF;   // maxima over the groups 0..3 / 4.. of the lane's list
+			float fa = VK_NEG_INF, fb = VK_NEG_INF;   // maxima over the groups 0..3 / 4.. of the lane's list (B3: groups 0, 1 / 2)
 #pragma unroll
 			for (int g = 0; g < NFAR / 4; g++) {
 				const f32x4 l = left[far_group(g)];
 #pragma unroll
 				for (int r = 0; r < 4; r++) {
 					const float cand = l[r] - wfar[g * 4 + r];
-					if (g < 4) fa = fmaxf(fa, cand);
+					if (g < (B3 ? 2 : 4)) fa = fmaxf(fa, cand);
 					else fb = fmaxf(fb, cand);
 				}
 			}
-			if constexpr (BAL) {
+			if constexpr (B3) {
+				// blocks 1, 2: everything they found is their own; block 0: for block 2's column; block 3: groups 0, 1 for block 2's, group 2 for block 1's
+				help[lane] = (blk == 0 || blk == 3) ? (blk == 0 ? fmaxf(fa, fb) : fa) : VK_NEG_INF;
+				help[64 + lane] = blk == 3 ? fb : VK_NEG_INF;
+				hc = fmaxf(hc, (blk == 1 || blk == 2) ? fmaxf(fa, fb) : VK_NEG_INF);
+				wave_lds_fence();
+				const float h0 = help[blk == 2 ? v16 : lane], h3 = help[blk == 2 ? 48 + v16 : blk == 1 ? 64 + 48 + v16 : lane];
+				hc = fmaxf(hc, blk == 2 ? fmaxf(h0, h3) : blk == 1 ? h3 : VK_NEG_INF);
+			} else if constexpr (BAL) {
 				// block 0: everything it found belongs to block 3's column; block 1: groups 4, 5 belong to block 2's
 				help[lane] = blk == 0 ? fmaxf(fa, fb) : fb;
 				hc = fmaxf(hc, blk == 0 ? VK_NEG_INF : blk == 1 ? fa : fmaxf(fa, fb));
@@ -410,7 +430,7 @@ __device__ __forceinline__ float dp32_general(const float *__restrict__ S, int s
 // STATIC: token ids + the two per-query tables [V x 16] (columns 0..15 and 16..31) instead of token tiles
 // (at least two waves per SIMD asked of the register allocator: the four-block general-gap form took 247 + 24 registers -- ONE wave
 // per SIMD, its tile loads and its DP never overlapping with another wave's)
-template <int GAP, bool STATIC, int NB>
+template <int GAP, bool STATIC, int NB, bool B3 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void vk_score32_kernel(VkWideParams p, int32_t rows_per_wave, int32_t stride, int32_t slack) {
 	constexpr int LPS = 16 * NB, PER = 64 / LPS;   // lanes per slice, slices per wave
 	extern __shared__ float4 vk_smem32[];
@@ -602,8 +622,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void v
 		}
 		auto evaluate = [&]() -> float {
 		float raw;
-		if constexpr (GAP == 3) raw = dp32_general<32, NB>(S, stride, rb, lenc, maxlen, col, lane, p, wsr, xch);
-		else if constexpr (GAP == 6) raw = dp32_general<64, NB>(S, stride, rb, lenc, maxlen, col, lane, p, wsr, xch);
+		if constexpr (GAP == 3) raw = dp32_general<32, NB, B3>(S, stride, rb, lenc, maxlen, col, lane, p, wsr, xch);
+		else if constexpr (GAP == 6) raw = dp32_general<64, NB, B3>(S, stride, rb, lenc, maxlen, col, lane, p, wsr, xch);
 		else if constexpr (GAP == 4) raw = rwmd32<NB>(S, stride, rb, lenc, maxlen, col, lane, p);
 		else if constexpr (GAP == 7) {
 			// masses of the slice's vocabulary entries (static layout: repeated token ids count once, at their first position),
@@ -669,7 +689,7 @@ static inline int strip_stride(int len_t) { return (len_t + 3) / 4 * 4; }
 // matter: at 32 query tokens and 300-d rows 1,280 bytes decide between two and three workgroups per CU (5.4 -> 4.3 ms).
 static inline int strip_slack(int gap_mode, int len_t) {
 	if (gap_mode == 7) return 144;   // 2 x 64 vocabulary masses
-	if (gap_mode == 3 || gap_mode == 6) return len_t > 32 ? 128 : 64;   // four-block form: the second slot of dp32_general
+	if (gap_mode == 3 || gap_mode == 6) return len_t > 48 ? 128 : len_t > 32 ? 192 : 64;   // four-block form: the second slot of dp32_general (33..48 tokens: a third)
 	return 16;
 }
 
@@ -708,9 +728,12 @@ extern "C" hipError_t vk_launch_score32(const VkWideParams *p, int32_t tiles, hi
 		: (is_static ? vk_score32_kernel<7, true, 2> : vk_score32_kernel<7, false, 2>); break;
 	case 5: kernel = four ? (is_static ? vk_score32_kernel<5, true, 4> : vk_score32_kernel<5, false, 4>)
 		: (is_static ? vk_score32_kernel<5, true, 2> : vk_score32_kernel<5, false, 2>); break;
-	case 3: kernel = four ? (is_static ? vk_score32_kernel<3, true, 4> : vk_score32_kernel<3, false, 4>)
+	// general gaps, 33..48 tokens: the three-block balance of the far candidates (dp32_general<.., B3>)
+	case 3: kernel = four ? (p->len_t <= 48 ? (is_static ? vk_score32_kernel<3, true, 4, true> : vk_score32_kernel<3, false, 4, true>)
+			: (is_static ? vk_score32_kernel<3, true, 4> : vk_score32_kernel<3, false, 4>))
 		: (is_static ? vk_score32_kernel<3, true, 2> : vk_score32_kernel<3, false, 2>); break;
-	default: kernel = four ? (is_static ? vk_score32_kernel<6, true, 4> : vk_score32_kernel<6, false, 4>)
+	default: kernel = four ? (p->len_t <= 48 ? (is_static ? vk_score32_kernel<6, true, 4, true> : vk_score32_kernel<6, false, 4, true>)
+			: (is_static ? vk_score32_kernel<6, true, 4> : vk_score32_kernel<6, false, 4>))
 		: (is_static ? vk_score32_kernel<6, true, 2> : vk_score32_kernel<6, false, 2>); break;
 	}
 	hipError_t e;
