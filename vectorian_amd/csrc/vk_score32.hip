@@ -10,6 +10,7 @@
 // long slices, and the tracebacks of the winners: 29 ms per 1 M x 32-token slices there (20 tokens, linear gap),
 // 3.5 ms here.
 #include "vk_common.hip.h"
+#include <algorithm>
 
 // NB = column blocks of 16 per slice: 2 (two slices per wave, queries of 17..32 tokens) or 4 (one slice, 33..64).
 // lane 15 of every 16-lane row, handed to all lanes of the NEXT row of the same slice (rows 1 and 3 for NB = 2,
@@ -319,10 +320,14 @@ __device__ __forceinline__ float shr_sub(float x, float w) {
 //   block 1 lanes: their sources 0..11;   block 3 lanes: sources 24..31 for column 32 + v, then sources 12..15 for column 16 + v
 //   block 2 lanes: their sources 0..11;   block 0 lanes: sources 12..23 for column 32 + v
 // the helpers' maxima cross through two 64-float slots (block 3's lanes help two columns).
+// B3 with NB = 2 (queries of 17..32 tokens, two slices per wave): block 1's 16 far candidates are shared with block 0's lanes, which
+// have none of their own -- 8 per lane: block 1 lanes walk sources 0..7, block 0's lane v sources 8..15 for column 16 + v of its slice;
+// the helpers' maxima cross through a second 64-float slot (the launcher takes this form when the slot does not cost a workgroup per CU).
 template <int MAXLEN, int NB, bool B3 = false>
 __device__ __forceinline__ float dp32_general(const float *__restrict__ S, int stride, int rowbase, int len, int maxlen, int col, int lane,
 	const VkWideParams &p, const float (&wsr)[MAXLEN + 1], float *__restrict__ xch) {
-	static_assert(!B3 || NB == 4, "the three-block balance is a form of the four-block kernel");
+	constexpr bool B2 = B3 && NB == 2;     // the balanced two-block form
+	constexpr bool B34 = B3 && NB == 4;    // the three-block balance of the four-block form
 	const int v16 = col & 15, blk = col >> 4;
 	const bool is_local = p.locality == VK_DEV_LOCAL, is_global = p.locality == VK_DEV_GLOBAL;
 	const float floor0 = is_local ? 0.0f : VK_NEG_INF;
@@ -330,17 +335,19 @@ __device__ __forceinline__ float dp32_general(const float *__restrict__ S, int s
 	const float inf = __builtin_inff();
 	const float wt_border = p.wt[col + 1], wt_border0 = p.wt0[col + 1];   // chains of gaps from the border column / one gap (border row)
 	constexpr bool BAL = NB == 4 && !B3;
-	constexpr int NFAR = B3 ? 12 : BAL ? 24 : 16 * (NB - 1);   // far candidates a lane walks
+	constexpr int NFAR = B2 ? 8 : B34 ? 12 : BAL ? 24 : 16 * (NB - 1);   // far candidates a lane walks
 	float wtv[16], wfar[NFAR];
 #pragma unroll
 	for (int k = 1; k < 16; k++) wtv[k] = v16 >= k ? p.wt[k] : inf;
 	// group g of four source columns this lane reads, and the column it works for there
 	auto far_group = [&](int g) {
-		if constexpr (B3) return blk == 0 ? g + 3 : blk == 3 ? (g < 2 ? g + 6 : 3) : g;
+		if constexpr (B2) return blk == 0 ? g + 2 : g;
+		else if constexpr (B34) return blk == 0 ? g + 3 : blk == 3 ? (g < 2 ? g + 6 : 3) : g;
 		else return !BAL ? g : blk == 0 ? g + 6 : (blk == 1 && g >= 4) ? g + 2 : g;
 	};
 	auto far_target = [&](int g) {
-		if constexpr (B3) return blk == 0 ? 32 + v16 : blk == 3 ? (g < 2 ? 32 + v16 : 16 + v16) : col;
+		if constexpr (B2) return blk == 0 ? 16 + v16 : col;
+		else if constexpr (B34) return blk == 0 ? 32 + v16 : blk == 3 ? (g < 2 ? 32 + v16 : 16 + v16) : col;
 		else return !BAL ? col : blk == 0 ? 48 + v16 : (blk == 1 && g >= 4) ? 32 + v16 : col;
 	};
 #pragma unroll
@@ -394,11 +401,17 @@ __device__ __forceinline__ float dp32_general(const float *__restrict__ S, int s
 #pragma unroll
 				for (int r = 0; r < 4; r++) {
 					const float cand = l[r] - wfar[g * 4 + r];
-					if (g < (B3 ? 2 : 4)) fa = fmaxf(fa, cand);
+					if (g < (B34 ? 2 : 4)) fa = fmaxf(fa, cand);
 					else fb = fmaxf(fb, cand);
 				}
 			}
-			if constexpr (B3) {
+			if constexpr (B2) {
+				help[lane] = blk == 0 ? fa : VK_NEG_INF;          // for column 16 + v of this lane's slice
+				hc = fmaxf(hc, blk == 1 ? fa : VK_NEG_INF);
+				wave_lds_fence();
+				const float hv = help[blk == 1 ? lane - 16 : lane];
+				hc = fmaxf(hc, blk == 1 ? hv : VK_NEG_INF);
+			} else if constexpr (B34) {
 				// blocks 1, 2: everything they found is their own; block 0: for block 2's column; block 3: groups 0, 1 for block 2's, group 2 for block 1's
 				help[lane] = (blk == 0 || blk == 3) ? (blk == 0 ? fmaxf(fa, fb) : fa) : VK_NEG_INF;
 				help[64 + lane] = blk == 3 ? fb : VK_NEG_INF;
@@ -715,7 +728,16 @@ extern "C" hipError_t vk_launch_score32(const VkWideParams *p, int32_t tiles, hi
 	const bool four = p->len_t > 32;   // 33..64 tokens: one slice per wave, four column blocks (linear / affine gaps)
 	const int waves = vk_score32_waves(is_static ? 0 : p->nk32, p->tail, tiles, p->len_t, p->gap_mode);
 	if (waves < 1) return hipErrorInvalidValue;
-	const size_t smem = vk_score32_lds_bytes(is_static ? 0 : p->nk32, p->tail, tiles, p->len_t, p->gap_mode, waves);
+	size_t smem = vk_score32_lds_bytes(is_static ? 0 : p->nk32, p->tail, tiles, p->len_t, p->gap_mode, waves);
+	int slack = strip_slack(p->gap_mode, p->len_t);
+	// general gaps, 17..32 tokens: the balanced form of the far candidates needs a second 64-float slot per wave; taken when that
+	// does not cost a workgroup per CU (LDS is handed out in 512-byte granules; at 32 tokens and 300-d rows it would: 4.2 -> 5.7 ms)
+	bool bal2 = false;
+	if (!four && (p->gap_mode == 3 || p->gap_mode == 6) && !getenv("VK_NO_BAL2")) {
+		auto per_cu = [](size_t bytes) { return (size_t)(156 * 1024) / ((bytes + 511) / 512 * 512); };   // (4 KB to spare: three workgroups of 54,272 bytes were not admitted)
+		const size_t more = smem + (size_t)waves * 64 * 4;
+		if (more <= 160 * 1024 && std::min<size_t>(per_cu(more), 3) == std::min<size_t>(per_cu(smem), 3)) { bal2 = true; smem = more; slack += 64; }
+	}
 	void (*kernel)(VkWideParams, int32_t, int32_t, int32_t);
 	switch (p->gap_mode) {
 	case 0: kernel = four ? (is_static ? vk_score32_kernel<0, true, 4> : vk_score32_kernel<0, false, 4>)
@@ -731,9 +753,11 @@ extern "C" hipError_t vk_launch_score32(const VkWideParams *p, int32_t tiles, hi
 	// general gaps, 33..48 tokens: the three-block balance of the far candidates (dp32_general<.., B3>)
 	case 3: kernel = four ? (p->len_t <= 48 ? (is_static ? vk_score32_kernel<3, true, 4, true> : vk_score32_kernel<3, false, 4, true>)
 			: (is_static ? vk_score32_kernel<3, true, 4> : vk_score32_kernel<3, false, 4>))
+		: bal2 ? (is_static ? vk_score32_kernel<3, true, 2, true> : vk_score32_kernel<3, false, 2, true>)
 		: (is_static ? vk_score32_kernel<3, true, 2> : vk_score32_kernel<3, false, 2>); break;
 	default: kernel = four ? (p->len_t <= 48 ? (is_static ? vk_score32_kernel<6, true, 4, true> : vk_score32_kernel<6, false, 4, true>)
 			: (is_static ? vk_score32_kernel<6, true, 4> : vk_score32_kernel<6, false, 4>))
+		: bal2 ? (is_static ? vk_score32_kernel<6, true, 2, true> : vk_score32_kernel<6, false, 2, true>)
 		: (is_static ? vk_score32_kernel<6, true, 2> : vk_score32_kernel<6, false, 2>); break;
 	}
 	hipError_t e;
@@ -752,7 +776,7 @@ extern "C" hipError_t vk_launch_score32(const VkWideParams *p, int32_t tiles, hi
 	const int per = four ? 1 : 2;
 	const int want = (int)((((int64_t)p->n_sent + per - 1) / per + waves - 1) / waves);
 	const int grid = want < cus * occ ? (want > 0 ? want : 1) : cus * occ;
-	kernel<<<grid, 64 * waves, smem, stream>>>(*p, tiles * 16, strip_stride(p->len_t), strip_slack(p->gap_mode, p->len_t));
+	kernel<<<grid, 64 * waves, smem, stream>>>(*p, tiles * 16, strip_stride(p->len_t), slack);
 	return hipGetLastError();
 }
 
