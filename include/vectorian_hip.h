@@ -147,7 +147,9 @@ typedef struct {
 	 * handle, n_only <= min(VK_MAX_MATCHES, capacity); NULL: off) makes vk_query skip the scoring pass and the selection and
 	 * state exactly these slices instead, in the given order: score, raw_score, mapping and edge_sim from the traceback kernel
 	 * (canonical arithmetic), sim_rows when the array is given; no min_score admission, n_out = n_only.  VK_ALG_ALIGN with
-	 * want_flow and submatch_weight = 0 only.  A caller walks the corpus in chunks with it (Index: debug = AllSlices(hook)). */
+	 * want_flow and submatch_weight = 0; since ABI 10 also the relaxed WMD (VK_ALG_RWMD without wmd_full) with sim_rows: score /
+	 * raw_score restated on the host from the rows (NaN for a slice longer than rows_per_winner, -inf for an empty one).
+	 * A caller walks the corpus in chunks with it (Index: debug = AllSlices(hook)). */
 	const int64_t *only_slices;
 	int32_t n_only;
 } vk_query_desc;

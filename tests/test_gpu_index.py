@@ -245,3 +245,26 @@ def test_debug_hook_and_abort_on_hip(hip):
 		gpu.corpus.query(np.ones((3, emb.dimension), np.float32), q_token_ids=np.zeros(3, np.int32), abort_flag=flag)
 	assert e.value.status == hip.VK_ERR_ABORTED
 	gpu.close()
+
+
+@pytest.mark.parametrize("variant", ["nbow", "nbow/distributed", "bow/fast"])
+def test_debug_hook_for_every_slice_relaxed_wmd_on_hip_equals_oracle_double(hip, variant):
+	"""debug = AllSlices(hook) under the relaxed word mover's distance: one 'alignment/word-movers-distance/make' call per slice with
+	its score and the worst score of the result set so far (metric/alignment.h:600-607).  The scores are restated from canonical
+	similarity rows on the host, chunk by chunk (vk_query_desc.only_slices): the oracle's floats for EVERY slice, not only the winners"""
+	from vectorian_amd.index import AllSlices
+	session, emb, words, rng = toy_session(n_docs=3, sents_per_doc=50, V=300, d=64)
+	sim = OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), alignment.WordMoversDistance.rwmd(variant))
+	doc = session.documents[1]
+	st = doc.spans["sentence"]["start"][11]
+	for text in (" ".join(doc.tokens[st:st + 5]), " ".join(doc.tokens[st:st + 21])):
+		calls = {}
+		for name, factory in (("gpu", None), ("cpu", OracleCorpus)):
+			index = session.partition("sentence", 2, 1).index(sim, corpus_factory=factory)   # sliding windows of two sentences
+			got = calls.setdefault(name, [])
+			index.find(text, n=4, min_score=-10.0, debug=AllSlices(lambda n_, d_, got=got: got.append((n_, d_)), chunk=64))
+			index.close()
+		assert len(calls["gpu"]) == len(calls["cpu"]) > 100
+		for (na, a), (nb, b) in zip(calls["gpu"], calls["cpu"]):
+			assert na == nb == "alignment/word-movers-distance/make" and a["slice"] == b["slice"]
+			assert a["score"] == b["score"] and a["worst_score"] == b["worst_score"]

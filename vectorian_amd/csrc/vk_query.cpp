@@ -52,8 +52,9 @@ int vk_validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_topk_
 	if (!(q->submatch_weight >= 0.0f)) return fail(VK_ERR_INVALID, "submatch_weight must be >= 0 (pow of a zero base, metric/alignment.h:97-99)");
 	if (q->only_slices) {
 		if (q->n_only < 1 || q->n_only > VK_MAX_MATCHES || q->n_only > out->capacity) return fail(VK_ERR_INVALID, "only_slices: n_only out of range (1 .. min(VK_MAX_MATCHES, capacity))");
-		if (q->algorithm != VK_ALG_ALIGN || !q->want_flow || q->submatch_weight != 0.0f)
-			return fail(VK_ERR_UNSUPPORTED, "only_slices states alignments with want_flow and submatch_weight = 0");
+		const bool relaxed = q->algorithm == VK_ALG_RWMD && !q->wmd_full && out->sim_rows != nullptr;   // restated on the host from the rows
+		if (!(q->algorithm == VK_ALG_ALIGN || relaxed) || !q->want_flow || q->submatch_weight != 0.0f)
+			return fail(VK_ERR_UNSUPPORTED, "only_slices states alignments, or relaxed WMD with sim_rows, with want_flow and submatch_weight = 0");
 		for (int i = 0; i < q->n_only; i++)
 			if (q->only_slices[i] < 0 || q->only_slices[i] >= c->desc.n_sentences) return fail(VK_ERR_INVALID, "only_slices: slice index out of range");
 	}
@@ -889,6 +890,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 			const int32_t t_a = (*c->h_start)[(size_t)row], len_s = (*c->h_end)[(size_t)row] - t_a;
 			const float boost = q->boost ? q->boost[sentence_of(row)] : 1.0f;
 			if (len_s < 1 || len_s > rows_R) {   // no rows for this one (longer than the caller's room): it keeps the scoring pass's value
+				if (only) { raw[(size_t)i] = val[(size_t)i] = len_s < 1 ? -INFINITY : NAN; continue; }   // (no scoring pass ran: an empty slice has no score, a longer one cannot be stated)
 				VK_HIP(hipMemcpy(&raw[(size_t)i], c->d_raw + row, 4, hipMemcpyDeviceToHost));
 				continue;
 			}

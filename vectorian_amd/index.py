@@ -1120,15 +1120,28 @@ class HipBruteForceIndex(Index):
 		order, with the reference's keys.  Alignments ('alignment': slice, similarity, flow, score; metric/alignment.h:145-173): the
 		slices are stated `hook.chunk` at a time by the traceback kernel (vk_query_desc.only_slices: aligner score, mapping, edge
 		similarities and the similarity rows, canonical arithmetic), whatever their score.  Relaxed WMD
-		('alignment/word-movers-distance/make': score, worst_score; :600-607): from the score vector of the search, with the worst
-		score of a result set filled in slice order as upstream fills it.  Opt-in and slow (a Python call per slice); a sharded
+		('alignment/word-movers-distance/make': score, worst_score; :600-607): the score of every slice restated from its canonical
+		similarity rows (only_slices again: the reference's floats), with the worst score of a result set filled in slice order as
+		upstream fills it.  Opt-in and slow (a Python call per slice); a sharded
 		index walks its own slices on every rank.  Other strategies: the winners (as without AllSlices)."""
 		args, p_query, corpus = local["args"], local["p_query"], local["corpus"]
 		alg = args.get("algorithm", core.VK_ALG_ALIGN)
 		n_loc, off, len_t = self._n_local, self._slice_off, len(p_query)
 		if alg == core.VK_ALG_RWMD and not args.get("wmd_full"):
 			import heapq
-			scores = corpus.last_scores()
+			# the scores of all slices as the backend states winners: restated from canonical similarity rows in the reference's order
+			# of operations (vk_query_desc.only_slices, `hook.chunk` slices per call) -- the floats upstream hands its hook; slices
+			# longer than the rows a call returns keep the scoring pass's value
+			scores = np.array(corpus.last_scores(), dtype=np.float32)
+			call, masks, lens_all = dict(local["call"]), local["masks"], self._slice_end[off:off + n_loc] - self._slice_start[off:off + n_loc]
+			for a in range(0, n_loc, max(1, int(getattr(hook, "chunk", 512)))):
+				ids = np.arange(a, min(n_loc, a + max(1, int(getattr(hook, "chunk", 512)))), dtype=np.int64)
+				ids = ids[(lens_all[ids] > 0) & np.isfinite(scores[ids])]
+				if len(ids) == 0:
+					continue
+				top = corpus.query(local["qv"].unmodified, q_normalize=True, boost=self._dev_boost, want_flow=True, only_slices=ids, **call)
+				stated = np.isfinite(top.score[:top.n])
+				scores[ids[:top.n][stated]] = top.score[:top.n][stated]
 			heap, k, floor = [], args["max_matches"], float(args["min_score"])
 			for g in range(n_loc):
 				sc = float(scores[g])
