@@ -107,6 +107,27 @@ class OracleCorpus:
 			sub._off = self._off[ids]
 			sub._end = (self._end if self._end is not None else self._off[1:])[ids]
 			b = None if boost is None else np.ascontiguousarray(np.asarray(boost, dtype=np.float32)[ids])
+			empty = (sub._end - sub._off) < 1   # (a filter may have emptied a slice: stated with score -inf, as the HIP backend does)
+			if empty.any():
+				full = self.query(q_vectors, locality=locality, gap_s=gap_s, gap_t=gap_t, algorithm=algorithm, q_token_ids=q_token_ids, q_normalize=q_normalize,
+					max_matches=max_matches, min_score=min_score, boost=boost, want_flow=want_flow, submatch_weight=submatch_weight, rwmd=rwmd,
+					wrd_normalize=wrd_normalize, tag_weights=tag_weights, q_pos=q_pos, pos_mismatch_penalty=pos_mismatch_penalty,
+					similarity_threshold=similarity_threshold, wmd_full=wmd_full, q_tags=q_tags, want_rows=want_rows, only_slices=ids[~empty]) if (~empty).any() else None
+				transport = (algorithm != core.VK_ALG_ALIGN or want_rows) and want_flow
+				t = core.TopK(len(ids), len(np.atleast_2d(q_vectors)), transport=transport, rows=core.VK_FAST_SENT_LEN)
+				t.n = len(ids)
+				t.score[:], t.raw_score[:] = -np.inf, -np.inf
+				t.sentence[:t.n] = ids
+				if full is not None:
+					at = np.nonzero(~empty)[0]
+					for name in ("score", "raw_score", "mapping", "edge_sim") + (("sim_rows", "plan") if getattr(full, "sim_rows", None) is not None and t.sim_rows is not None else ()):
+						dst, src = getattr(t, name), getattr(full, name)
+						if dst.ndim == 1:
+							dst[at] = src[:full.n]
+						else:
+							sl = tuple(slice(0, min(a_, b_)) for a_, b_ in zip(dst.shape[1:], src.shape[1:]))
+							dst[(at,) + sl] = src[(slice(0, full.n),) + sl]
+				return t
 			t = sub.query(q_vectors, locality=locality, gap_s=gap_s, gap_t=gap_t, algorithm=algorithm, q_token_ids=q_token_ids, q_normalize=q_normalize,
 				max_matches=len(ids), min_score=-3.0e38, boost=b, want_flow=want_flow, submatch_weight=submatch_weight, rwmd=rwmd,
 				wrd_normalize=wrd_normalize, tag_weights=tag_weights, q_pos=q_pos, pos_mismatch_penalty=pos_mismatch_penalty,
@@ -140,7 +161,9 @@ class OracleCorpus:
 		else:
 			kw.update(X=self._X, X_mag=self._mag, Q_mag=qmag)
 		r = vo.find(**kw)
-		self._all = r["all_scores"]
+		self._all = np.array(r["all_scores"], dtype=np.float32)
+		ends = self._end if self._end is not None else self._off[1:]
+		self._all[(ends - self._off[:len(ends)]) < 1] = -np.inf   # empty slices carry no score (vk_last_scores: -inf; Spans::iterate skips them)
 		transport = (algorithm != core.VK_ALG_ALIGN or want_rows) and want_flow
 		top = core.TopK(max_matches, len(q), transport=transport)
 		n = len(r["score"])

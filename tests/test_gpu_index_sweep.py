@@ -145,11 +145,18 @@ def test_random_session_on_hip_equals_oracle_double(hip, seed):
 			n = int(rng.choice([60, 70, 150]))   # the margin of the canonical re-ranking across the selection's k <= 64 / k > 64 paths
 		seen = {"hip": [], "double": []}
 		hooked = seed >= 60 and seed % 6 == 0 and (is_align or (getattr(strategy, "_options", None) or {}).get("relaxed"))
-		a = gpu.find(text, n=n, min_score=min_score, options=dict(options, debug=lambda name, data: seen["hip"].append((name, data))) if hooked else options)
-		b = cpu.find(text, n=n, min_score=min_score, options=dict(options, debug=lambda name, data: seen["double"].append((name, data))) if hooked else options)
+		every = hooked and seed % 12 == 0 and "submatch_weight" not in options   # AllSlices: the hook for EVERY slice, stated chunk by chunk
+		def hook_of(side):
+			from vectorian_amd.index import AllSlices
+			f = lambda name, data: seen[side].append((name, data))
+			return AllSlices(f, chunk=int(rng.integers(1, 200))) if every else f
+		a = gpu.find(text, n=n, min_score=min_score, options=dict(options, debug=hook_of("hip")) if hooked else options)
+		b = cpu.find(text, n=n, min_score=min_score, options=dict(options, debug=hook_of("double")) if hooked else options)
 		if hooked:
 			# the debug hook (call_debug_hook, metric/alignment.h:145-173, 600-607), called for the winners: the same calls with the same data
-			assert [x[0] for x in seen["hip"]] == [x[0] for x in seen["double"]] and len(seen["hip"]) == len(a)
+			assert [x[0] for x in seen["hip"]] == [x[0] for x in seen["double"]] and (every or len(seen["hip"]) == len(a)), ctx if False else (seed, every)
+			if every:
+				assert len(seen["hip"]) >= len(a)
 			for (_, x), (_, y) in zip(seen["hip"], seen["double"]):
 				assert x.keys() == y.keys() and x["slice"] == y["slice"] and x["score"] == y["score"]
 				if "worst_score" in x:
