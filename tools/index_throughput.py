@@ -16,16 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
-	ap = argparse.ArgumentParser()
-	ap.add_argument("--sentences", type=int, default=1000000)
-	ap.add_argument("--queries", type=int, default=60)
-	ap.add_argument("--in-flight", type=int, default=3)
-	ap.add_argument("--contextual", action="store_true", help="per-token vectors (contextual embedding) instead of the static layout: find_many then shares calls (vk_query_batch)")
-	ap.add_argument("--strategy", choices=["local", "rwmd"], default="local")
-	ap.add_argument("--no-batch", action="store_true", help="find_many(batch=False): one query per call")
-	ap.add_argument("--profile", action="store_true", help="cProfile of the timed find_many on stderr")
-	args = ap.parse_args()
+def build(n_sentences, contextual, strategy, n_queries=60):
+	"""the synthetic session and its index; returns (index, texts, seconds the index took to build)"""
 	from vectorian_amd import alignment, synth
 	from vectorian_amd.corpus import Corpus, Document
 	from vectorian_amd.embedding import ContextualEmbedding, StaticEmbedding
@@ -36,27 +28,41 @@ def main():
 	words = [f"w{i}" for i in range(V)]
 	E = synth.make_vocab(V, d)
 	word_id = {w: i for i, w in enumerate(words)}
-	if args.contextual:
+	if contextual:
 		emb = ContextualEmbedding("ctx", d, lambda tokens: E[[word_id[t] for t in tokens]])
 	else:
 		emb = StaticEmbedding("synthetic-300", words, E)
 	per_doc = 10000
 	docs = []
-	for di in range((args.sentences + per_doc - 1) // per_doc):
+	for di in range((n_sentences + per_doc - 1) // per_doc):
 		ids = synth.zipf_ids(per_doc * len_s, V, rng).reshape(per_doc, len_s)
 		sents = [[words[j] for j in row] for row in ids]
-		if args.contextual:
+		if contextual:
 			X = E[ids.reshape(-1)] + 0.1 * rng.standard_normal((per_doc * len_s, d)).astype(np.float32)
 			docs.append(Document(sents, contextual_embeddings={"ctx": X}))
 		else:
 			docs.append(Document(sents))
 	session = Session(Corpus(docs), embeddings=[emb])
-	strategy = alignment.LocalAlignment(gap=alignment.smooth_gap_cost(5)) if args.strategy == "local" else alignment.WordMoversDistance.rwmd("nbow")
+	strategy = alignment.LocalAlignment(gap=alignment.smooth_gap_cost(5)) if strategy == "local" else alignment.WordMoversDistance.rwmd("nbow")
 	sim = OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), strategy)
 	t0 = time.perf_counter()
 	index = session.partition("sentence").index(sim)
 	build_s = time.perf_counter() - t0
-	texts = [" ".join(docs[int(rng.integers(0, len(docs)))].tokens[a:a + 10]) for a in rng.integers(0, per_doc * len_s - 10, size=args.queries)]
+	texts = [" ".join(docs[int(rng.integers(0, len(docs)))].tokens[a:a + 10]) for a in rng.integers(0, per_doc * len_s - 10, size=n_queries)]
+	return index, texts, build_s
+
+
+def main():
+	ap = argparse.ArgumentParser()
+	ap.add_argument("--sentences", type=int, default=1000000)
+	ap.add_argument("--queries", type=int, default=60)
+	ap.add_argument("--in-flight", type=int, default=3)
+	ap.add_argument("--contextual", action="store_true", help="per-token vectors (contextual embedding) instead of the static layout: find_many then shares calls (vk_query_batch)")
+	ap.add_argument("--strategy", choices=["local", "rwmd"], default="local")
+	ap.add_argument("--no-batch", action="store_true", help="find_many(batch=False): one query per call")
+	ap.add_argument("--profile", action="store_true", help="cProfile of the timed find_many on stderr")
+	args = ap.parse_args()
+	index, texts, build_s = build(args.sentences, args.contextual, args.strategy, args.queries)
 	batch = False if args.no_batch else None
 	index.find_many(texts[:max(6, min(len(texts), 32))], in_flight=args.in_flight, batch=batch)
 	prof = None
