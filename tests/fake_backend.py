@@ -114,7 +114,8 @@ class OracleCorpus:
 					wrd_normalize=wrd_normalize, tag_weights=tag_weights, q_pos=q_pos, pos_mismatch_penalty=pos_mismatch_penalty,
 					similarity_threshold=similarity_threshold, wmd_full=wmd_full, q_tags=q_tags, want_rows=want_rows, only_slices=ids[~empty]) if (~empty).any() else None
 				transport = (algorithm != core.VK_ALG_ALIGN or want_rows) and want_flow
-				t = core.TopK(len(ids), len(np.atleast_2d(q_vectors)), transport=transport, rows=core.VK_FAST_SENT_LEN)
+				longest = int((sub._end - sub._off).max())
+				t = core.TopK(len(ids), len(np.atleast_2d(q_vectors)), transport=transport, rows=min(core.VK_MAX_SENT_LEN, max(core.VK_FAST_SENT_LEN, (longest + 63) // 64 * 64)))
 				t.n = len(ids)
 				t.score[:], t.raw_score[:] = -np.inf, -np.inf
 				t.sentence[:t.n] = ids
@@ -165,7 +166,11 @@ class OracleCorpus:
 		ends = self._end if self._end is not None else self._off[1:]
 		self._all[(ends - self._off[:len(ends)]) < 1] = -np.inf   # empty slices carry no score (vk_last_scores: -inf; Spans::iterate skips them)
 		transport = (algorithm != core.VK_ALG_ALIGN or want_rows) and want_flow
-		top = core.TopK(max_matches, len(q), transport=transport)
+		# room for the rows / plans of the corpus's longest slice, as the HIP backend's shim makes (core.Corpus._winner_rows)
+		all_ends = self._end if self._end is not None else self._off[1:]
+		longest = int((all_ends - self._off[:len(all_ends)]).max()) if len(all_ends) else 0
+		rows_room = min(core.VK_MAX_SENT_LEN, max(core.VK_FAST_SENT_LEN, (longest + 63) // 64 * 64))
+		top = core.TopK(max_matches, len(q), transport=transport, rows=rows_room)
 		n = len(r["score"])
 		top.n = n
 		top.score[:n], top.raw_score[:n], top.sentence[:n] = r["score"], r["raw"], r["sentence"]
@@ -208,7 +213,7 @@ class OracleCorpus:
 							w = np.float32(tag_weights[ft]) * ((np.float32(1.0) - np.float32(pos_mismatch_penalty)) if self._pos[a + si] != q_pos[tj] else np.float32(1.0))
 							v = np.float32(raw[si, tj] * w)
 							S[si, tj] = 0.0 if v <= similarity_threshold else v
-			if transport and b - a <= core.VK_FAST_SENT_LEN:
+			if transport and b - a <= rows_room:
 				# what the HIP backend returns for the host to state transport flows: rows, and the plan of exact transports
 				top.sim_rows[i, :b - a, :len(q)] = S
 				exact = algorithm == core.VK_ALG_WRD or (algorithm == core.VK_ALG_RWMD and wmd_full)

@@ -268,3 +268,34 @@ def test_debug_hook_for_every_slice_relaxed_wmd_on_hip_equals_oracle_double(hip,
 		for (na, a), (nb, b) in zip(calls["gpu"], calls["cpu"]):
 			assert na == nb == "alignment/word-movers-distance/make" and a["slice"] == b["slice"]
 			assert a["score"] == b["score"] and a["worst_score"] == b["worst_score"]
+
+
+@pytest.mark.parametrize("strategy", ["wrd", "wmd"])
+def test_debug_hook_for_every_slice_exact_transport_on_hip_equals_oracle_double(hip, strategy):
+	"""debug = AllSlices(hook) under the exact transports: EVERY slice solved (vk_query_desc.only_slices: no bound pass, nothing pruned)
+	and handed to the solver's hook -- tokens, masses, distance matrix, plan and cost (wrd.h:31-59, wmd.h:147-181); full WMD: 'make'
+	with the worst score so far as well"""
+	from vectorian_amd.index import AllSlices
+	session, emb, words, rng = toy_session(n_docs=3, sents_per_doc=40, V=300, d=64)
+	optimizer = alignment.WordRotatorsDistance() if strategy == "wrd" else alignment.WordMoversDistance.wmd("nbow")
+	sim = OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), optimizer)
+	doc = session.documents[1]
+	st = doc.spans["sentence"]["start"][9]
+	text = " ".join(doc.tokens[st:st + 6])
+	calls = {}
+	for name, factory in (("gpu", None), ("cpu", OracleCorpus)):
+		index = session.partition("sentence").index(sim, corpus_factory=factory)
+		got = calls.setdefault(name, [])
+		index.find(text, n=4, min_score=-10.0, debug=AllSlices(lambda n_, d_, got=got: got.append((n_, d_)), chunk=50))
+		index.close()
+	assert [x[0] for x in calls["gpu"]] == [x[0] for x in calls["cpu"]] and len(calls["gpu"]) >= 120
+	for (na, a), (nb, b) in zip(calls["gpu"], calls["cpu"]):
+		if na.endswith("/make"):
+			assert a["slice"] == b["slice"] and abs(a["score"] - b["score"]) < 2e-5 and abs(a["worst_score"] - b["worst_score"]) < 2e-5
+		else:
+			assert a["s"]["id"] == b["s"]["id"] and a["t"]["id"] == b["t"]["id"]
+			for key in a:
+				if isinstance(a[key], np.ndarray) and a[key].dtype.kind == "f" and key != "G":   # (an optimal plan need not be unique)
+					np.testing.assert_allclose(a[key], b[key], atol=2e-5, err_msg=key)
+				elif isinstance(a[key], float):
+					assert abs(a[key] - b[key]) < 2e-5, key

@@ -53,8 +53,9 @@ int vk_validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_topk_
 	if (q->only_slices) {
 		if (q->n_only < 1 || q->n_only > VK_MAX_MATCHES || q->n_only > out->capacity) return fail(VK_ERR_INVALID, "only_slices: n_only out of range (1 .. min(VK_MAX_MATCHES, capacity))");
 		const bool relaxed = q->algorithm == VK_ALG_RWMD && !q->wmd_full && out->sim_rows != nullptr;   // restated on the host from the rows
-		if (!(q->algorithm == VK_ALG_ALIGN || relaxed) || !q->want_flow || q->submatch_weight != 0.0f)
-			return fail(VK_ERR_UNSUPPORTED, "only_slices states alignments, or relaxed WMD with sim_rows, with want_flow and submatch_weight = 0");
+		const bool exact = q->algorithm == VK_ALG_WRD || (q->algorithm == VK_ALG_RWMD && q->wmd_full);  // every listed slice solved
+		if (!(q->algorithm == VK_ALG_ALIGN || relaxed || exact) || !q->want_flow || q->submatch_weight != 0.0f)
+			return fail(VK_ERR_UNSUPPORTED, "only_slices states alignments, relaxed WMD with sim_rows, or exact transports, with want_flow and submatch_weight = 0");
 		for (int i = 0; i < q->n_only; i++)
 			if (q->only_slices[i] < 0 || q->only_slices[i] >= c->desc.n_sentences) return fail(VK_ERR_INVALID, "only_slices: slice index out of range");
 	}
@@ -519,6 +520,61 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	}
 
 	const bool exact_transport = q->algorithm == VK_ALG_WRD || (q->algorithm == VK_ALG_RWMD && q->wmd_full);
+	if (exact_transport && only) {
+		// ---- only_slices: the listed slices solved exactly, in the caller's order (no bound pass ran, nothing is pruned)
+		if (!c->entry_sent.empty() && c->sent_entry.empty()) {
+			c->sent_entry.assign((size_t)c->desc.n_sentences, -1);
+			for (int64_t e = 0; e < n; e++) if (c->entry_sent[(size_t)e] >= 0) c->sent_entry[(size_t)c->entry_sent[(size_t)e]] = (int32_t)e;
+		}
+		const int cnt = q->n_only;
+		std::vector<uint64_t> hk((size_t)cnt);
+		std::vector<int64_t> rows_idx((size_t)cnt);
+		for (int i = 0; i < cnt; i++) {
+			rows_idx[(size_t)i] = c->sent_entry.empty() ? q->only_slices[i] : (int64_t)c->sent_entry[(size_t)q->only_slices[i]];
+			hk[(size_t)i] = (1ull << 32) | (uint64_t)(uint32_t)rows_idx[(size_t)i];
+		}
+		if (c->wrd_cap < (size_t)VK_MAX_MATCHES) {
+			if (c->d_wrd_raw) { VK_HIP(hipFree(c->d_wrd_raw)); VK_HIP(hipFree(c->d_wrd_val)); c->d_wrd_raw = c->d_wrd_val = nullptr; }
+			rc = alloc_t(c, &c->d_wrd_raw, (size_t)VK_MAX_MATCHES); if (rc) return rc;
+			rc = alloc_t(c, &c->d_wrd_val, (size_t)VK_MAX_MATCHES); if (rc) return rc;
+			c->wrd_cap = VK_MAX_MATCHES;
+		}
+		VK_HIP(hipMemcpyAsync(c->d_keys[0], hk.data(), hk.size() * 8, hipMemcpyHostToDevice, st));
+		VkWrdParams w{};
+		fill_transport(w);
+		w.mass_mode = q->algorithm == VK_ALG_WRD ? 0 : (q->rwmd_normalize_bow ? 1 : 2);
+		memcpy(w.qmass, qmass_all, sizeof w.qmass);
+		w.raw_masses = (q->algorithm == VK_ALG_WRD && !q->wrd_normalize_magnitudes) ? 1 : 0;
+		w.boost = p.boost; w.raw_out = c->d_wrd_raw; w.val_out = c->d_wrd_val; w.keys = c->d_keys[0];
+		VK_HIP(hipMemsetAsync(c->d_wrd_raw, 0xff, (size_t)cnt * 4, st));   // NaN: a slice no solver takes (empty) stays marked
+		VK_HIP(hipMemsetAsync(c->d_wrd_val, 0xff, (size_t)cnt * 4, st));
+		VK_HIP(vk_launch_wrd_exact(&w, cnt, nullptr, st));
+		if (c->max_len > VK_FAST_SENT_LEN) {
+			if (w.nq > 1 && !c->d_wrdl_scratch) {
+				if ((rc = alloc_t(c, &c->d_wrdl_scratch, (size_t)vk_wrd_long_blocks() * vk_wrd_long_scratch_bytes()))) return rc;
+			}
+			w.scratch = c->d_wrdl_scratch; w.scratch_stride = (int64_t)vk_wrd_long_scratch_bytes();
+			VK_HIP(vk_launch_wrd_exact_long(&w, cnt, st));
+		}
+		std::vector<float> vals((size_t)cnt), raws((size_t)cnt);
+		VK_HIP(hipMemcpyAsync(vals.data(), c->d_wrd_val, (size_t)cnt * 4, hipMemcpyDeviceToHost, st));
+		VK_HIP(hipMemcpyAsync(raws.data(), c->d_wrd_raw, (size_t)cnt * 4, hipMemcpyDeviceToHost, st));
+		VK_HIP(hipStreamSynchronize(st));
+		if ((rc = transport_flows(rows_idx, true, w.qmass, w.mass_mode, w.raw_masses))) return rc;
+		for (int i = 0; i < cnt; i++) {
+			const bool empty = (*c->h_end)[(size_t)rows_idx[(size_t)i]] - (*c->h_start)[(size_t)rows_idx[(size_t)i]] < 1;
+			out->score[i] = empty ? -INFINITY : vals[(size_t)i];
+			out->sentence[i] = q->only_slices[i];
+			if (out->raw_score) out->raw_score[i] = empty ? -INFINITY : raws[(size_t)i];
+			if (out->mapping && out->edge_sim)
+				for (int j = 0; j < q->len_t; j++) {
+					out->mapping[i * (size_t)q->len_t + j] = -1;
+					out->edge_sim[i * (size_t)q->len_t + j] = 0.0f;
+				}
+		}
+		out->n_out = cnt;
+		return VK_OK;
+	}
 	if (exact_transport) {
 		// ---- stage 2: exact EMD on the candidates with the largest bounds, until the k-th best
 		// exact score is above every remaining bound (then no unsolved sentence can enter)

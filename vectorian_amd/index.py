@@ -1122,8 +1122,9 @@ class HipBruteForceIndex(Index):
 		similarities and the similarity rows, canonical arithmetic), whatever their score.  Relaxed WMD
 		('alignment/word-movers-distance/make': score, worst_score; :600-607): the score of every slice restated from its canonical
 		similarity rows (only_slices again: the reference's floats), with the worst score of a result set filled in slice order as
-		upstream fills it.  Opt-in and slow (a Python call per slice); a sharded
-		index walks its own slices on every rank.  Other strategies: the winners (as without AllSlices)."""
+		upstream fills it.  Exact transports: every slice solved, the solver's hook per slice (tokens, masses, distance matrix, plan,
+		cost).  Opt-in and slow (a Python call per slice); a sharded index walks its own slices on every rank.  With a submatch weight:
+		the winners (as without AllSlices)."""
 		args, p_query, corpus = local["args"], local["p_query"], local["corpus"]
 		alg = args.get("algorithm", core.VK_ALG_ALIGN)
 		n_loc, off, len_t = self._n_local, self._slice_off, len(p_query)
@@ -1151,6 +1152,35 @@ class HipBruteForceIndex(Index):
 				hook("alignment/word-movers-distance/make", {"score": sc, "worst_score": worst, "slice": self._slice_id[off + g]})
 				if sc > worst:
 					heapq.heappush(heap, sc) if len(heap) < k else heapq.heapreplace(heap, sc)
+			return
+		if alg == core.VK_ALG_WRD or (alg == core.VK_ALG_RWMD and args.get("wmd_full")):
+			# exact transports: every slice solved (only_slices: no bound pass, nothing pruned), the solver's hook per slice
+			# (WRD::call_debug_hook, wrd.h:31-59; FullSolver::call_debug_hook, wmd.h:147-181) and, full WMD, 'make' with the worst
+			# score of a result set filled in slice order
+			import heapq
+			call, masks = dict(local["call"]), local["masks"]
+			qmag = np.asarray(local["qv"].magnitudes, dtype=np.float32) if alg == core.VK_ALG_WRD else None
+			lens_all = self._slice_end[off:off + n_loc] - self._slice_start[off:off + n_loc]
+			heap, k, floor = [], args["max_matches"], float(args["min_score"])
+			name = "alignment/word-rotators-distance/solver" if alg == core.VK_ALG_WRD else "alignment/word-movers-distance/solver"
+			for a in range(0, n_loc, max(1, int(getattr(hook, "chunk", 512)))):
+				ids = np.arange(a, min(n_loc, a + max(1, int(getattr(hook, "chunk", 512)))), dtype=np.int64)
+				ids = ids[lens_all[ids] > 0]
+				if len(ids) == 0:
+					continue
+				top = corpus.query(local["qv"].unmodified, q_normalize=True, boost=self._dev_boost, want_flow=True, only_slices=ids, **call)
+				chunk = self._matches_from_topk(p_query, top, local["gaps"], args, qmag, masks, local["q_tag_codes"])
+				for i, m in enumerate(chunk):
+					if not np.isfinite(m.score):
+						continue   # every token filtered out: the slice is not scored
+					data = self._solver_debug_data(p_query, top, i, m, args)
+					if data is not None:
+						hook(name, data)
+					if alg == core.VK_ALG_RWMD:
+						worst = heap[0] if len(heap) >= k else floor
+						hook("alignment/word-movers-distance/make", {"score": m.score, "worst_score": worst, "slice": m.slice_id, "flow": m.flow})
+						if m.score > worst:
+							heapq.heappush(heap, m.score) if len(heap) < k else heapq.heapreplace(heap, m.score)
 			return
 		if alg != core.VK_ALG_ALIGN or args.get("submatch_weight", 0.0) != 0.0:
 			return self._call_debug_hook(hook, p_query, local["top"], matches, args)
