@@ -265,6 +265,14 @@ def test_only_slices_states_every_slice_long_ones_included(hip, oracle, len_t):
 			assert (got.sim_rows[i, :b - a, :len_t] == S).all()
 	with pytest.raises(hip.VkError):
 		c.query(Qb, q_normalize=False, only_slices=np.array([n], dtype=np.int64), **kw)              # out of range
+	# the transports take the list too (ABI 10): relaxed WMD restated on the host from the rows -- the oracle's floats for every listed
+	# slice, the long ones included --, exact transports solved slice by slice
+	ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=off, X=Xb, Q=Qb, algorithm=oracle.ALG_RWMD, max_matches=n, min_score=-10.0)
+	by_sent = {int(s): j for j, s in enumerate(ref["sentence"])}
+	got = c.query(Qb, q_normalize=False, only_slices=ids, algorithm=hip.VK_ALG_RWMD)
+	assert got.n == len(ids) and list(got.sentence[:got.n]) == list(ids)
+	for i, s in enumerate(ids):
+		assert np.float32(got.score[i]).view(np.uint32) == np.float32(ref["score"][by_sent[int(s)]]).view(np.uint32)
 	with pytest.raises(hip.VkError):
-		c.query(Qb, q_normalize=False, only_slices=ids, algorithm=hip.VK_ALG_RWMD)                    # alignments only
+		c.query(Qb, q_normalize=False, only_slices=ids, submatch_weight=1.0, **kw)                     # submatch weights: not stated slice by slice
 	c.close()
