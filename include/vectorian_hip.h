@@ -31,15 +31,19 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 10
+#define VK_ABI_VERSION 11
 #define VK_MAX_QUERY_LEN 64   /* query tokens */
 #define VK_FAST_QUERY_LEN 16  /* queries up to this length run in the fused kernels (one 16-wide MFMA column block); longer ones
                                  take the multi-block kernel (2 or 4 column blocks) or, where that does not apply, a
                                  one-wave-per-slice kernel, ~10x slower */
-#define VK_MAX_SENT_LEN 512   /* tokens per sentence (slice) */
+#define VK_MAX_SENT_LEN 512   /* tokens per sentence (slice), every algorithm; see VK_MAX_DOC_LEN */
 #define VK_FAST_SENT_LEN 64   /* slices up to this length run 4 per wave in the fused kernel (|s| <= 64); longer
                                  ones take a second launch, one slice per wave (exact transport: a slower solver; with a query of
                                  more than VK_FAST_QUERY_LEN tokens its state lives in global memory) */
+#define VK_MAX_DOC_LEN 32767  /* alignments (VK_ALG_ALIGN): tokens per slice when slices are whole documents -- what the int16 of a
+                                 mapping can name, upstream's own bound (metric/alignment.h:357-358).  A corpus that holds a slice
+                                 of more than VK_MAX_SENT_LEN tokens is scored by one wave per slice with the slice's state (column
+                                 history of general gaps, traceback) in global memory; the transports return VK_ERR_UNSUPPORTED on it */
 #define VK_MAX_MATCHES 1024
 
 typedef enum {
@@ -223,7 +227,7 @@ int vk_corpus_set_token_tags(vk_corpus_t *c, const int8_t *tags, int64_t n, int3
 int vk_corpus_set_sentences(vk_corpus_t *c, const int64_t *sent_off, int64_t n_sentences);
 /* general slices, e.g. sliding windows with window_step != window_size (Spans::iterate with
  * bounded_len, document.h:147-169): slice i = tokens [start[i], end[i]); starts and ends non-decreasing,
- * at most VK_MAX_SENT_LEN tokens each; slices may overlap or leave gaps.  host arrays [n_sentences]. */
+ * at most VK_MAX_SENT_LEN tokens each (alignments: VK_MAX_DOC_LEN); slices may overlap or leave gaps.  host arrays [n_sentences]. */
 int vk_corpus_set_slices(vk_corpus_t *c, const int64_t *start, const int64_t *end, int64_t n_sentences);
 int vk_corpus_finalize(vk_corpus_t *c);
 /* A second handle on the same resident corpus (read-only arrays shared, own stream and workspaces): two handles serve

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VKO_MAX_LEN_S 1024
+#define VKO_MAX_LEN_S 32767 /* int16 of a mapping (metric/alignment.h:357-358) */
 #define VKO_MAX_LEN_T 64
 
 /* pyalign::enums::Locality as used at vectorian/core/cpp/metric/alignment.h:363-364

@@ -1,0 +1,183 @@
+"""-m gpu: whole documents as slices.  A corpus that holds a slice of more than VK_MAX_SENT_LEN (512) tokens -- up to VK_MAX_DOC_LEN
+= 32767, what the int16 of a mapping can name, upstream's own bound (metric/alignment.h:357-358) -- is scored by alignments through
+vk_wide_kernel's global-state form: one wave per slice, the column history of general gaps and the traceback in global memory.
+The same form takes queries of more than 16 tokens over slices whose state exceeds the LDS (VK_ERR_UNSUPPORTED until round 3).
+HIP (through the C-ABI) against the oracle: slice ids, scores and tracebacks bit for bit, the scores of ALL slices within 1e-4."""
+
+import numpy as np
+import pytest
+
+from vectorian_amd import synth
+
+from helpers import assert_same_results, hip_static_corpus
+
+pytestmark = pytest.mark.gpu
+
+
+def exp5(n):
+	return ("table", (1 - 2.0 ** (-np.arange(0, n + 1) / 5)).astype(np.float32))
+
+
+AFF = ("affine", 0.2, 0.05)
+
+
+def document_lengths(seed, n, docs):
+	rng = np.random.default_rng(seed)
+	lens = rng.integers(1, 60, size=n)
+	for pos, ln in docs:
+		lens[pos] = ln
+	return np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+
+
+def planted_query(X, off, sent, len_t, seed, spread=True):
+	"""noisy copy of tokens of one document, spread out over it so that long gaps matter"""
+	rng = np.random.default_rng(seed)
+	a, b = int(off[sent]), int(off[sent + 1])
+	if spread:
+		idx = np.sort(rng.choice(np.arange(a, b), size=min(len_t, b - a), replace=False))
+	else:
+		s0 = int(rng.integers(a, max(a + 1, b - 2 * len_t)))
+		idx = np.sort(rng.choice(np.arange(s0, min(b, s0 + 2 * len_t)), size=min(len_t, b - s0), replace=False))
+	q = X[idx] + 0.05 * rng.standard_normal((len(idx), X.shape[1])).astype(np.float32)
+	return synth.to_bf16_bits(synth.normalize_rows(q))
+
+
+def contextual(hip, off, d, seed):
+	X = np.random.default_rng(seed).standard_normal((int(off[-1]), d)).astype(np.float32)
+	Xb = synth.to_bf16_bits(synth.normalize_rows(X))
+	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=d, n_tokens=Xb.shape[0], n_sentences=len(off) - 1)
+	c.append_vectors(Xb, normalize=False)
+	c.set_sentences(off)
+	c.finalize()
+	return c, X, Xb
+
+
+@pytest.mark.parametrize("d,len_t", [(64, 5), (64, 12), (300, 16), (64, 20), (96, 40), (64, 64)])
+def test_documents_contextual(hip, oracle, d, len_t):
+	"""documents of 513 .. 3,000 tokens between short slices, every locality and gap family, queries of 5 .. 64 tokens (1 .. 4 column
+	blocks of the one-wave-per-slice kernel)"""
+	docs = ((0, 513), (5, 1200), (6, 700), (7, 65), (18, 3000), (23, 131), (40, 2049), (41, 512), (69, 900))
+	off = document_lengths(21, 70, docs)
+	c, X, Xb = contextual(hip, off, d, 22)
+	w = exp5(int(np.diff(off).max()))
+	boost = np.random.default_rng(23).uniform(0.5, 1.5, size=len(off) - 1).astype(np.float32)
+	for qi, (sent, spread) in enumerate(((18, True), (40, False), (3, True))):
+		Qb = planted_query(X, off, sent, len_t, 30 + qi, spread)
+		for loc, ms, gaps, bst in ((0, 0.0, (0.1, 0.1), None), (0, 0.0, (w, w), boost), (1, -1e9, (w, w), None),
+				(2, -1e9, (AFF, AFF), None), (1, -1e9, (0.05, 0.2), boost), (2, -1e9, (w, 0.1), None)):
+			ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=off, X=Xb, Q=Qb, locality=loc,
+				gap_s=gaps[0], gap_t=gaps[1], max_matches=12, min_score=ms, boost=bst, want_all_scores=True, n_threads=8)
+			got = c.query(Qb, q_normalize=False, locality=loc, gap_s=gaps[0], gap_t=gaps[1], max_matches=12, min_score=ms, boost=bst)
+			assert_same_results(got.trimmed(), ref)
+			np.testing.assert_allclose(c.last_scores(), ref["all_scores"], atol=1e-4)
+	c.close()
+
+
+def test_longest_document(hip, oracle):
+	"""one document of VK_MAX_DOC_LEN tokens (linear and affine gaps: the oracle's general-gap recurrence is cubic) and the limit"""
+	n_max = hip.VK_MAX_DOC_LEN
+	off = np.array([0, 40, 40 + n_max, 40 + n_max + 700, 40 + n_max + 700 + 9], dtype=np.int64)
+	c, X, Xb = contextual(hip, off, 32, 5)
+	for len_t in (8, 24):
+		Qb = planted_query(X, off, 1, len_t, 6 + len_t)
+		for loc, ms, gaps in ((0, 0.0, (0.1, 0.1)), (1, -1e9, (0.02, 0.1)), (2, -1e9, (AFF, AFF))):
+			ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=32, sent_off=off, X=Xb, Q=Qb, locality=loc,
+				gap_s=gaps[0], gap_t=gaps[1], max_matches=4, min_score=ms, want_all_scores=True)
+			got = c.query(Qb, q_normalize=False, locality=loc, gap_s=gaps[0], gap_t=gaps[1], max_matches=4, min_score=ms)
+			assert_same_results(got.trimmed(), ref)
+			if loc == 0:
+				assert got.sentence[0] == 1
+			np.testing.assert_allclose(c.last_scores(), ref["all_scores"], atol=1e-4)
+	# the transports are bounded by VK_MAX_SENT_LEN: refused before anything is enqueued
+	for kw in (dict(algorithm=hip.VK_ALG_RWMD), dict(algorithm=hip.VK_ALG_RWMD, rwmd=(False, False, True), wmd_full=True)):
+		with pytest.raises(hip.VkError) as e:
+			c.query(Qb, q_normalize=False, max_matches=3, **kw)
+		assert e.value.status == hip.VK_ERR_UNSUPPORTED
+	c.close()
+	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=16, n_tokens=n_max + 1, n_sentences=1)
+	c.append_vectors(np.ones((n_max + 1, 16), np.float32))
+	with pytest.raises(hip.VkError):
+		c.set_sentences(np.array([0, n_max + 1], dtype=np.int64))
+	c.close()
+
+
+@pytest.mark.parametrize("len_t", [9, 30])
+def test_documents_static_layout_and_tag_weights(hip, oracle, len_t):
+	"""token ids + vocabulary table (the reference's static layout), repeated words, sim[id(t_j)][j] = 1; with and without the
+	tag-weighted modifier; submatch_weight (candidate rounds of tracebacks)"""
+	corpus = synth.make_static_corpus(60, 1, 40, 900, 100, seed=5)
+	lens = np.diff(corpus["sent_off"]).copy()
+	for pos, ln in ((2, 600), (3, 2500), (30, 65), (59, 1100)):
+		lens[pos] = ln
+	off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+	rng = np.random.default_rng(6)
+	corpus["sent_off"] = off
+	corpus["tok_id"] = rng.integers(0, 900, size=int(off[-1])).astype(np.int32)
+	pos_s = rng.integers(0, 6, size=int(off[-1])).astype(np.int8)
+	c, Eb = hip_static_corpus(hip, corpus)
+	c.set_token_pos(pos_s)
+	w = exp5(int(lens.max()))
+	for qi, s in enumerate((3, 59, 20)):
+		a = int(off[s])
+		q_ids = corpus["tok_id"][a:a + 3 * len_t:3][:len_t].astype(np.int32)
+		if len(q_ids) < len_t:
+			q_ids = np.concatenate((q_ids, rng.integers(0, 900, size=len_t - len(q_ids)).astype(np.int32)))
+		Qb = Eb[q_ids]
+		tw = rng.uniform(0.3, 1.0, size=len_t).astype(np.float32)
+		q_pos = rng.integers(0, 6, size=len_t).astype(np.int8)
+		for loc, ms, gaps in ((0, 0.0, (0.1, 0.1)), (1, -1e9, (w, w)), (2, -1e9, (AFF, AFF))):
+			for tagged in (False, True):
+				okw = dict(tag_weights=tw, q_pos=q_pos, pos_s=pos_s, pos_mismatch_penalty=0.4, similarity_threshold=0.15) if tagged else {}
+				hkw = dict(tag_weights=tw, q_pos=q_pos, pos_mismatch_penalty=0.4, similarity_threshold=0.15) if tagged else {}
+				for sub in (0.0, 0.7) if loc == 0 else (0.0,):
+					ref = oracle.find(layout=oracle.LAYOUT_STATIC, d=100, sent_off=off, tok_id=corpus["tok_id"], E=Eb, Q=Qb, q_ids=q_ids,
+						locality=loc, gap_s=gaps[0], gap_t=gaps[1], max_matches=8, min_score=ms, submatch_weight=sub, **okw)
+					got = c.query(Qb, q_token_ids=q_ids, q_normalize=False, locality=loc, gap_s=gaps[0], gap_t=gaps[1], max_matches=8,
+						min_score=ms, submatch_weight=sub, **hkw)
+					assert_same_results(got.trimmed(), ref)
+	c.close()
+
+
+@pytest.mark.parametrize("len_t", [33, 64])
+def test_wide_query_state_beyond_the_lds(hip, oracle, len_t):
+	"""17 .. 64 query tokens with general gaps and traceback over slices of up to 512 tokens: H, the step lengths and the flags of
+	513 x 65 cells take 233 KB -- the global-state form (round 2 / 3: VK_ERR_UNSUPPORTED, 'exceeds the LDS of a workgroup')"""
+	off = document_lengths(3, 50, ((4, 512), (20, 400), (21, 66), (49, 300)))
+	c, X, Xb = contextual(hip, off, 64, 4)
+	w = exp5(512)
+	for qi, sent in enumerate((4, 49)):
+		Qb = planted_query(X, off, sent, len_t, 50 + qi)
+		for loc, ms in ((0, 0.0), (1, -1e9), (2, -1e9)):
+			ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=64, sent_off=off, X=Xb, Q=Qb, locality=loc,
+				gap_s=w, gap_t=w, max_matches=10, min_score=ms, want_all_scores=True, n_threads=8)
+			got = c.query(Qb, q_normalize=False, locality=loc, gap_s=w, gap_t=w, max_matches=10, min_score=ms)
+			assert_same_results(got.trimmed(), ref)
+			np.testing.assert_allclose(c.last_scores(), ref["all_scores"], atol=1e-4)
+	c.close()
+
+
+def test_document_windows_and_views(hip, oracle):
+	"""overlapping windows of 800 tokens, step 300, over one token stream (set_slices), queried from a view of the corpus too (a view
+	has workspaces of its own: gap table, scratch)"""
+	T, d = 6000, 48
+	start = np.arange(0, T - 800 + 1, 300, dtype=np.int64)
+	end = start + 800
+	X = np.random.default_rng(9).standard_normal((T, d)).astype(np.float32)
+	Xb = synth.to_bf16_bits(synth.normalize_rows(X))
+	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=d, n_tokens=T, n_sentences=len(start))
+	c.append_vectors(Xb, normalize=False)
+	c.set_slices(start, end)
+	c.finalize()
+	v = c.view()
+	w = exp5(800)
+	rng = np.random.default_rng(10)
+	idx = np.sort(rng.choice(np.arange(2000, 2600), size=14, replace=False))
+	Qb = synth.to_bf16_bits(synth.normalize_rows(X[idx] + 0.05 * rng.standard_normal((14, d)).astype(np.float32)))
+	for h in (c, v):
+		for loc, ms, gaps in ((0, 0.0, (w, w)), (1, -1e9, (0.1, 0.1)), (2, -1e9, (AFF, w))):
+			ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=start, sent_end=end, X=Xb, Q=Qb, locality=loc,
+				gap_s=gaps[0], gap_t=gaps[1], max_matches=6, min_score=ms)
+			got = h.query(Qb, q_normalize=False, locality=loc, gap_s=gaps[0], gap_t=gaps[1], max_matches=6, min_score=ms).trimmed()
+			assert_same_results(got, ref)
+	v.close()
+	c.close()

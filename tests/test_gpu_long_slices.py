@@ -124,11 +124,7 @@ def test_only_long_slices_and_limit(hip, oracle):
 	got = c.query(Qb, q_normalize=False, gap_s=EXP5L, gap_t=EXP5L, max_matches=5).trimmed()
 	assert_same_results(got, ref)
 	c.close()
-	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=16, n_tokens=513, n_sentences=1)
-	c.append_vectors(np.ones((513, 16), np.float32))
-	with pytest.raises(hip.VkError):
-		c.set_sentences(np.array([0, 513], dtype=np.int64))
-	c.close()
+	# (slices of more than 512 tokens: alignments only, tests/test_gpu_document_slices.py)
 
 
 @pytest.mark.parametrize("alg,opts", [

@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("VECTORIAN_HIP_LIB", os.path.join(_HERE, "lib", "libve
 
 VK_MAX_QUERY_LEN = 64
 VK_MAX_SENT_LEN = 512
+VK_MAX_DOC_LEN = 32767
 VK_FAST_SENT_LEN = 64
 VK_PREC_BF16, VK_PREC_F32 = 0, 1
 VK_FAST_QUERY_LEN = 16
@@ -152,7 +153,7 @@ def lib():
 		L.vk_pack_records.argtypes = [C.POINTER(_TopkOut), C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
 		L.vk_merge_records.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_TopkOut)]
 		L.vk_rwmd_from_rows.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float)]
-		if L.vk_abi_version() != 10:
+		if L.vk_abi_version() != 11:
 			raise RuntimeError("libvectorian_hip.so ABI version mismatch")
 		_lib = L
 	return _lib
@@ -396,7 +397,8 @@ class Corpus:
 			keep.append(ids)
 			q.q_token_ids = _np_ptr(ids)
 		q.locality = int(locality)
-		q.gap_s = gap_to_struct(gap_s, keep, VK_MAX_SENT_LEN + 1)
+		n_table = max(VK_MAX_SENT_LEN, getattr(self, "_max_len", 0)) + 1   # a gap table covers the corpus's longest slice
+		q.gap_s = gap_to_struct(gap_s, keep, n_table)
 		q.gap_t = gap_to_struct(gap_t, keep, VK_MAX_SENT_LEN + 1)
 		q.submatch_weight, q.bidirectional = float(submatch_weight), int(bool(bidirectional))
 		q.max_matches, q.min_score = int(max_matches), float(min_score)

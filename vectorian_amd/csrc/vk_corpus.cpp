@@ -151,7 +151,7 @@ int vk_corpus_free(vk_corpus_t *c) {
 		c->d_sent_start = c->d_sent_end = nullptr, c->d_long_groups = nullptr;
 	if (c->shares_vectors) c->d_tiles = nullptr, c->d_mag = nullptr;
 	void *ptrs[] = {c->d_tiles, c->d_mag, c->d_tok_id, c->d_pos, c->d_tag, c->d_sent_start, c->d_sent_end, c->d_stage, c->d_qtile, c->d_ws, c->d_wt, c->d_qids,
-		c->d_table, c->d_scores, c->d_raw, c->d_boost, c->d_keys[0], c->d_keys[1], c->d_out_raw, c->d_out_sim, c->d_out_map, c->d_wrd_raw, c->d_wrd_val, c->d_bq, c->d_bqlen, c->d_bscores, c->d_bkeys[0], c->d_bkeys[1], c->d_long_groups, c->d_counter, c->d_rows_out, c->d_plan_out, c->d_braw, c->d_wrdl_scratch, c->d_bqt, c->d_bcand, c->d_bcandq, c->d_brows, c->d_qbits};
+		c->d_table, c->d_scores, c->d_raw, c->d_boost, c->d_keys[0], c->d_keys[1], c->d_out_raw, c->d_out_sim, c->d_out_map, c->d_wrd_raw, c->d_wrd_val, c->d_bq, c->d_bqlen, c->d_bscores, c->d_bkeys[0], c->d_bkeys[1], c->d_long_groups, c->d_counter, c->d_rows_out, c->d_plan_out, c->d_braw, c->d_wrdl_scratch, c->d_wide_scratch, c->d_bqt, c->d_bcand, c->d_bcandq, c->d_brows, c->d_qbits};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	if (c->h_brows) (void)hipHostFree(c->h_brows);
 	for (auto &b : c->bl) for (void *p : {(void *)b.tiles, (void *)b.len, (void *)b.id}) if (p) (void)hipFree(p);
@@ -258,9 +258,9 @@ static int set_slices_impl(vk_corpus_t *c, const int64_t *start, const int64_t *
 		const int64_t len = end[s] - start[s];
 		if (start[s] < 0 || end[s] > c->desc.n_tokens || len < 0) return fail(VK_ERR_INVALID, "slice outside the token stream");
 		if (s > 0 && (start[s] < start[s - 1] || end[s] < end[s - 1])) return fail(VK_ERR_INVALID, "slice starts and ends must be non-decreasing");
-		if (len > VK_MAX_SENT_LEN) {
+		if (len > VK_MAX_DOC_LEN) {   // (65 .. VK_MAX_SENT_LEN: every algorithm; beyond: alignments, vk_validate_query)
 			char buf[128];
-			snprintf(buf, sizeof buf, "slice %lld has %lld tokens; the HIP path handles at most %d", (long long)s, (long long)len, VK_MAX_SENT_LEN);
+			snprintf(buf, sizeof buf, "slice %lld has %lld tokens; the HIP path handles at most %d", (long long)s, (long long)len, VK_MAX_DOC_LEN);
 			return fail(VK_ERR_UNSUPPORTED, buf);
 		}
 		max_len = std::max(max_len, (int)len);

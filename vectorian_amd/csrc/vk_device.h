@@ -251,6 +251,10 @@ struct VkWideParams {
 	float *raw_out;            // [k]
 	int16_t *mapping;          // [k x 64]
 	float *edge_sim;           // [k x 64]
+	// vk_wide_kernel, global-state form (non-null: the state of a slice that grows with its length lives here, not in LDS):
+	// one region of scratch_stride bytes per workgroup (vk_wide_scratch_bytes; vk_wide_gs_blocks regions)
+	uint8_t *scratch;
+	int64_t scratch_stride;
 };
 
 #ifdef __cplusplus
@@ -263,6 +267,8 @@ hipError_t vk_launch_mark(const uint64_t *keys, int32_t n, float *scores, hipStr
 hipError_t vk_launch_select_ge(const float *scores, int64_t n, float theta, float floor_excl, uint64_t *keys_out,
 	uint32_t *counter, uint32_t cap, hipStream_t stream);
 size_t vk_wide_lds_demand(int32_t max_len, int32_t nq, int32_t gap_mode, int32_t tagged, int32_t flow);
+size_t vk_wide_scratch_bytes(int32_t max_len, int32_t nq, int32_t gap_mode, int32_t flow);
+int32_t vk_wide_gs_blocks(int32_t max_len, int32_t nq, int32_t gap_mode, int32_t flow_k, int64_t n_sent);
 hipError_t vk_launch_pack(const void *in, int32_t dtype_bf16, int64_t n_rows, int32_t d, int32_t d_pad, int64_t row0,
 	uint8_t *tiles, float *mag_out, int32_t normalize, int32_t prec, hipStream_t stream);
 // queries of 17..32 tokens, linear / affine gaps (vk_score32.hip)

@@ -223,17 +223,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void vk
 // queries on the device, not a roofline kernel.
 // ---------------------------------------------------------------------------
 
-static inline size_t vk_wide_lds_bytes(int max_len, int nq, int gap_mode, bool tagged, bool flow) {
+static inline size_t vk_wide_lds_bytes(int max_len, int nq, int gap_mode, bool tagged, bool flow, bool gstate = false) {
 	const size_t LQ = (size_t)nq * 16, W = LQ + 1, rows = (size_t)max_len + 1;
 	size_t fl = 16 * LQ * (tagged ? 2 : 1);            // Sx (+ SWx)
-	fl += (rows + 3) / 4 * 4 + LQ + 4;                 // wsl, wtl
+	fl += (gstate ? 0 : (rows + 3) / 4 * 4) + LQ + 4;  // wsl, wtl
 	fl += 64 + 64;                                     // twl, tposl
-	if (gap_mode == 2) fl += rows * W;                 // H
+	if (gap_mode == 2 && !gstate) fl += rows * W;      // H
 	size_t b = fl * 4;
-	if (flow) b += 64 * 2 + rows * W * 2 + rows * W;   // mapl, dk, flags
+	if (flow) b += 64 * 2 + (gstate ? 0 : rows * W * 2 + rows * W);   // mapl, dk, flags
 	b = (b + 15) / 16 * 16;
 	if (flow) b += VK_CANON_LDS;                       // staging of sim_canon16, behind everything else
 	return b;
+}
+
+// The state of a slice that grows with its length -- the column history of general gaps (H), the traceback's step lengths and
+// flags -- in global memory (GS form, one region per workgroup): slices of any length the mapping's int16 can name (whole documents
+// as slices), and queries of more than 16 tokens over slices whose state does not fit the LDS.  Layout of a region: H [rows x W]
+// floats (general gaps), dk [rows x W] int16 and flags [rows x W] bytes (FLOW), each 16-byte aligned.
+static inline size_t vk_wide_scratch_bytes_impl(int max_len, int nq, int gap_mode, bool flow) {
+	const size_t W = (size_t)nq * 16 + 1, rows = (size_t)max_len + 1;
+	size_t b = 0;
+	if (gap_mode == 2) b += (rows * W * 4 + 15) / 16 * 16;
+	if (flow) b += (rows * W * 2 + 15) / 16 * 16 + (rows * W + 15) / 16 * 16;
+	return b < 16 ? 16 : b;
 }
 
 __device__ __forceinline__ float wave_min64(float m) {
@@ -242,25 +254,52 @@ __device__ __forceinline__ float wave_min64(float m) {
 	return m;
 }
 
-template <bool FLOW>
+// the fence between a wave's writes of its slice state and lane 0's walk over it: LDS form, or global memory (GS)
+template <bool GS>
+__device__ __forceinline__ void wide_state_fence() {
+	wave_lds_fence();
+	if constexpr (GS) {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+	}
+}
+
+template <bool FLOW, bool GS>
 __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 	extern __shared__ float4 vk_smem4[];
 	const int lane = threadIdx.x;
 	const int LQ = p.nq * 16, W = LQ + 1, rows = p.max_len + 1;
 	float *Sx = reinterpret_cast<float *>(vk_smem4);       // [16][LQ] similarities of the current 16 tokens
 	float *SWx = p.pos_s ? Sx + 16 * LQ : Sx;              // tag-weighted copy the DP runs on
-	float *wsl = SWx + 16 * LQ;
-	float *wtl = wsl + (rows + 3) / 4 * 4;
+	float *wsl_lds = SWx + 16 * LQ;
+	float *wtl = GS ? wsl_lds : wsl_lds + (rows + 3) / 4 * 4;
 	float *twl = wtl + LQ + 4;
 	int *tposl = reinterpret_cast<int *>(twl + 64);
-	float *H = reinterpret_cast<float *>(tposl + 64);      // general gaps: H[u][v], row stride W
-	float *after = p.gap_mode == 2 ? H + rows * W : H;
+	float *H_lds = reinterpret_cast<float *>(tposl + 64);  // general gaps: H[u][v], row stride W
+	float *after = (p.gap_mode == 2 && !GS) ? H_lds + rows * W : H_lds;
 	int16_t *mapl = reinterpret_cast<int16_t *>(after);    // FLOW: mapping of the winner
-	int16_t *dk = mapl + 64;
-	uint8_t *flags = reinterpret_cast<uint8_t *>(dk + rows * W);
-	uint8_t *canon = FLOW ? reinterpret_cast<uint8_t *>(vk_smem4) + (((size_t)(flags + rows * W - reinterpret_cast<uint8_t *>(vk_smem4)) + 15) / 16 * 16) : nullptr;
-
-	for (int i = lane; i <= p.max_len; i += 64) wsl[i] = p.ws[i];
+	int16_t *dk_lds = mapl + 64;
+	uint8_t *flags_lds = reinterpret_cast<uint8_t *>(dk_lds + rows * W);
+	uint8_t *lds_end = GS ? reinterpret_cast<uint8_t *>(dk_lds) : flags_lds + rows * W;
+	uint8_t *canon = FLOW ? reinterpret_cast<uint8_t *>(vk_smem4) + (((size_t)(lds_end - reinterpret_cast<uint8_t *>(vk_smem4)) + 15) / 16 * 16) : nullptr;
+	// GS: this workgroup's region of the scratch (vk_wide_scratch_bytes_impl); the gap table of the slices is read where it lies
+	uint8_t *region = GS ? p.scratch + (int64_t)blockIdx.x * p.scratch_stride : nullptr;
+	const size_t h_bytes = p.gap_mode == 2 ? ((size_t)rows * W * 4 + 15) / 16 * 16 : 0;
+	const size_t dk_bytes = ((size_t)rows * W * 2 + 15) / 16 * 16;
+	float *H;
+	int16_t *dk;
+	uint8_t *flags;
+	const float *wsl;
+	if constexpr (GS) {
+		H = reinterpret_cast<float *>(region);
+		dk = reinterpret_cast<int16_t *>(region + h_bytes);
+		flags = region + h_bytes + dk_bytes;
+		wsl = p.ws;
+	} else {
+		H = H_lds; dk = dk_lds; flags = flags_lds; wsl = wsl_lds;
+		for (int i = lane; i <= p.max_len; i += 64) wsl_lds[i] = p.ws[i];
+	}
 	if (lane <= LQ) wtl[lane] = p.wt[lane];
 	if (lane == 0) wtl[LQ] = p.wt[LQ <= 64 ? LQ : 64];
 	twl[lane] = p.tw[lane]; tposl[lane] = p.tpos[lane];
@@ -493,7 +532,7 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 		}
 		// ---- FLOW: traceback by lane 0, then the edge similarities from a second sweep over the tiles
 		mapl[lane] = -1;
-		wave_lds_fence();
+		wide_state_fence<GS>();
 		if (lane == 0 && gap != 4) {
 			int u = u_start, v2 = v_start, state = 0;
 			while (u > 0 && v2 > 0) {
@@ -525,25 +564,51 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 	}
 }
 
+// Residency of the global-state form: a region of scratch per workgroup, so the grid is what the scratch allows
+static const int64_t kWideScratchCap = 4ll << 30;
+
+extern "C" size_t vk_wide_scratch_bytes(int32_t max_len, int32_t nq, int32_t gap_mode, int32_t flow) {
+	return vk_wide_scratch_bytes_impl(max_len, nq, gap_mode, flow != 0);
+}
+
+// workgroups of a global-state launch: SCORE walks the slices with a grid stride (every CU filled, within the scratch cap);
+// FLOW takes one workgroup per winner
+extern "C" int32_t vk_wide_gs_blocks(int32_t max_len, int32_t nq, int32_t gap_mode, int32_t flow_k, int64_t n_sent) {
+	if (flow_k > 0) return flow_k;
+	const int64_t per = (int64_t)vk_wide_scratch_bytes_impl(max_len, nq, gap_mode, false);
+	int64_t blocks = gap_mode == 2 ? kWideScratchCap / per : 2048;
+	if (blocks > 2048) blocks = 2048;
+	if (blocks > n_sent) blocks = n_sent;
+	return (int32_t)(blocks < 1 ? 1 : blocks);
+}
+
 extern "C" hipError_t vk_launch_wide(const VkWideParams *p, int32_t flow_k, hipStream_t stream) {
 	const bool flow = flow_k > 0;
-	const size_t smem = vk_wide_lds_bytes(p->max_len, p->nq, p->gap_mode, p->pos_s != nullptr, flow);
+	const bool gs = p->scratch != nullptr;
+	const size_t smem = vk_wide_lds_bytes(p->max_len, p->nq, p->gap_mode, p->pos_s != nullptr, flow, gs);
 	if (smem > 160 * 1024) return hipErrorInvalidValue;
-	const void *fn = flow ? reinterpret_cast<const void *>(vk_wide_kernel<true>) : reinterpret_cast<const void *>(vk_wide_kernel<false>);
+	const void *fn = gs ? (flow ? reinterpret_cast<const void *>(vk_wide_kernel<true, true>) : reinterpret_cast<const void *>(vk_wide_kernel<false, true>))
+		: (flow ? reinterpret_cast<const void *>(vk_wide_kernel<true, false>) : reinterpret_cast<const void *>(vk_wide_kernel<false, false>));
 	if (smem > 64 * 1024) {
 		hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 		if (e != hipSuccess) return e;
 	}
-	if (flow) {
-		vk_wide_kernel<true><<<flow_k, 64, smem, stream>>>(*p);
+	if (gs) {
+		// the host sized p->scratch for vk_wide_gs_blocks regions of scratch_stride bytes
+		const int blocks = vk_wide_gs_blocks(p->max_len, p->nq, p->gap_mode, flow_k, p->n_sent);
+		if (p->scratch_stride < (int64_t)vk_wide_scratch_bytes_impl(p->max_len, p->nq, p->gap_mode, flow)) return hipErrorInvalidValue;
+		if (flow) vk_wide_kernel<true, true><<<blocks, 64, smem, stream>>>(*p);
+		else vk_wide_kernel<false, true><<<blocks, 64, smem, stream>>>(*p);
+	} else if (flow) {
+		vk_wide_kernel<true, false><<<flow_k, 64, smem, stream>>>(*p);
 	} else {
 		int occ = 0, dev = 0, cus = 256;
-		hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vk_wide_kernel<false>, 64, smem);
+		hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vk_wide_kernel<false, false>, 64, smem);
 		if (e != hipSuccess) return e;
 		if (occ < 1) occ = 1;
 		if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
 		const int64_t want = p->n_sent, cap = (int64_t)cus * occ;
-		vk_wide_kernel<false><<<(int)(want < cap ? want : cap), 64, smem, stream>>>(*p);
+		vk_wide_kernel<false, false><<<(int)(want < cap ? want : cap), 64, smem, stream>>>(*p);
 	}
 	return hipGetLastError();
 }

@@ -116,6 +116,8 @@ struct vk_corpus {
 	float *h_brows = nullptr; size_t h_brows_cap = 0;   // pinned host staging of the similarity rows of a batch's winners
 	uint32_t *d_qbits = nullptr;   // tag-weighted vocabulary transports over the static layout: bitmap of the query's token ids
 	uint8_t *d_wrdl_scratch = nullptr;   // exact transport, queries of 17..64 tokens over long slices: per-workgroup state
+	uint8_t *d_wide_scratch = nullptr; size_t wide_scratch_cap = 0;   // vk_wide_kernel, global-state form: per-workgroup state of a slice
+	size_t ws_cap = kGapTable;   // floats d_ws holds (grown by a query over a corpus with longer slices)
 	int rows_w = 0;              // columns per similarity row they are sized for (16, 32, 48 or 64)
 	// batched GEMM over a ragged corpus (vk_query_batch): a padded copy of the sentences, one bucket per padded length
 	// 16 / 32 / 48 / 64 tokens, built on the first such batch (this handle's; about 1.2 x the corpus for lengths 8..64)

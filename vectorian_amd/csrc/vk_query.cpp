@@ -39,11 +39,12 @@ int vk_validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_topk_
 	const bool exact_tr = q->algorithm == VK_ALG_WRD || (q->algorithm == VK_ALG_RWMD && (q->wmd_full || !q->rwmd_injective));   // multi-block kernel + kernels of their own for the long slices: no wide kernel
 	if (q->len_t > VK_FAST_QUERY_LEN && exact_tr && !score32_plan(c, q).fits)
 		return fail(VK_ERR_UNSUPPORTED, "exact transport / 1:n RWMD with a query of more than 16 tokens: the query tiles of rows this wide and one wave's similarity strip exceed the LDS of a workgroup (160 KiB)");
-	if (q->len_t > VK_FAST_QUERY_LEN && !exact_tr) {
-		const int gm = q->algorithm == VK_ALG_RWMD ? 4 : (q->gap_s.kind == VK_GAP_TABLE || q->gap_t.kind == VK_GAP_TABLE) ? 2 : 1;
-		if (vk_wide_lds_demand(c->max_len, (q->len_t + 15) / 16, gm, q->tag_weights != nullptr, q->want_flow) > 160 * 1024)
-			return fail(VK_ERR_UNSUPPORTED, "query of more than 16 tokens over slices this long exceeds the LDS of a workgroup");
-	}
+	// Slices of more than VK_MAX_SENT_LEN tokens (whole documents as slices, up to VK_MAX_DOC_LEN): alignments only -- the
+	// one-wave-per-slice kernel with the slice's state in global memory (vk_wide_kernel, global-state form).  The same form takes a
+	// query of more than 16 tokens whose state over the corpus's longest slice exceeds the LDS (round 2: VK_ERR_UNSUPPORTED), except
+	// the relaxed WMD with similarity rows, whose rows are bounded by VK_MAX_SENT_LEN anyway.
+	if (c->max_len > VK_MAX_SENT_LEN && q->algorithm != VK_ALG_ALIGN)
+		return fail(VK_ERR_UNSUPPORTED, "slices of more than VK_MAX_SENT_LEN (512) tokens are scored by alignments only (the transports' bags of words and solvers are bounded by it)");
 	if (!q->q_vectors) return fail(VK_ERR_INVALID, "q_vectors is null");
 	if (q->q_dtype != VK_F32 && q->q_dtype != VK_BF16) return fail(VK_ERR_INVALID, "bad q_dtype");
 	if (q->max_matches < 1 || q->max_matches > VK_MAX_MATCHES) return fail(VK_ERR_INVALID, "max_matches out of range");
@@ -242,7 +243,8 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	VK_HIP(hipEventRecord(c->ev[0], st));
 	std::vector<uint8_t> qtile;
 	float qmags[VK_MAX_QUERY_LEN] = {0};
-	const bool wide = q->len_t > VK_FAST_QUERY_LEN;
+	const bool xlong = c->max_len > VK_MAX_SENT_LEN;   // whole documents as slices: every slice through the one-wave-per-slice kernel
+	const bool wide = q->len_t > VK_FAST_QUERY_LEN || xlong;
 	const int nq = (q->len_t + 15) / 16;
 	vk_pack_query(c, q, qtile, qmags);
 	VK_HIP(hipMemcpyAsync(c->d_qtile, qtile.data(), qtile.size(), hipMemcpyHostToDevice, st));
@@ -251,7 +253,9 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	bool span_skip_raw = false;   // span-embedding path without its second output array
 	float qmass_all[VK_MAX_QUERY_LEN] = {0};   // masses of the query tokens (transport algorithms), all 64 columns
 	const int ks = q->gap_s.kind, kt = q->gap_t.kind;
-	float ws[kGapTable], wt[160];   // wt[0..79]: w_t as given; wt[80..159]: its subadditive closure
+	const size_t n_ws = std::max<size_t>((size_t)kGapTable, (size_t)c->max_len + 2);   // w_s up to the longest slice
+	std::vector<float> ws(n_ws);
+	float wt[160];   // wt[0..79]: w_t as given; wt[80..159]: its subadditive closure
 	const bool is_align = q->algorithm == VK_ALG_ALIGN;
 	if (q->algorithm == VK_ALG_WRD) {
 		p.gap_mode = 5;
@@ -305,7 +309,12 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	} else {
 		p.gap_mode = 2;
 	}
-	for (int i = 0; i < kGapTable; i++) ws[i] = (is_align && i <= c->max_len) ? gap_cost(q->gap_s, i) : 0.0f;
+	for (size_t i = 0; i < n_ws; i++) ws[i] = (is_align && (int64_t)i <= c->max_len) ? gap_cost(q->gap_s, (int)i) : 0.0f;
+	if (c->ws_cap < n_ws) {
+		if (c->d_ws) { VK_HIP(hipFree(c->d_ws)); c->d_ws = nullptr; c->ws_cap = 0; }
+		if ((rc = alloc_t(c, &c->d_ws, n_ws))) return rc;
+		c->ws_cap = n_ws;
+	}
 	for (int i = 0; i < 80; i++) wt[i] = (is_align && i <= q->len_t) ? gap_cost(q->gap_t, i) : 0.0f;
 	for (int i = 80; i < 160; i++) wt[i] = 0.0f;
 	// The register-history kernels take their in-row candidates from the row's values before in-row gaps, which is the
@@ -320,7 +329,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		if (!wide) p.gap_mode = c->max_short_len <= 32 ? 3 : 6;
 		wide_sub = wide;
 	}
-	VK_HIP(hipMemcpyAsync(c->d_ws, ws, sizeof ws, hipMemcpyHostToDevice, st));
+	VK_HIP(hipMemcpyAsync(c->d_ws, ws.data(), n_ws * sizeof(float), hipMemcpyHostToDevice, st));
 	VK_HIP(hipMemcpyAsync(c->d_wt, wt, sizeof wt, hipMemcpyHostToDevice, st));
 
 	std::vector<float> boost_rows;
@@ -393,6 +402,24 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		for (int j = 0; j < VK_FAST_QUERY_LEN; j++) p.qkey[j] = qkey_all[j];
 	}
 	VkWideParams wp{};
+	// vk_wide_kernel: the state of a slice in LDS where that fits, else in global memory (one region per workgroup)
+	auto wide_state = [&](int flow_k) -> int {
+		const bool flow = flow_k > 0;
+		wp.scratch = nullptr; wp.scratch_stride = 0;
+		if (!xlong && vk_wide_lds_demand(c->max_len, nq, wp.gap_mode, q->tag_weights != nullptr, flow) <= 160 * 1024) return VK_OK;
+		const size_t per = vk_wide_scratch_bytes(c->max_len, nq, wp.gap_mode, flow);
+		const size_t blocks = (size_t)vk_wide_gs_blocks(c->max_len, nq, wp.gap_mode, flow_k, n);
+		const size_t need = per * blocks;
+		if (need > ((size_t)16 << 30)) return fail(VK_ERR_UNSUPPORTED, "traceback state of this many slices this long exceeds 16 GiB of scratch");
+		if (c->wide_scratch_cap < need) {
+			if (c->d_wide_scratch) { VK_HIP(hipFree(c->d_wide_scratch)); c->d_wide_scratch = nullptr; c->wide_scratch_cap = 0; }
+			int rcw;
+			if ((rcw = alloc_t(c, &c->d_wide_scratch, need))) return rcw;
+			c->wide_scratch_cap = need;
+		}
+		wp.scratch = c->d_wide_scratch; wp.scratch_stride = (int64_t)per;
+		return VK_OK;
+	};
 	if (wide) {
 		wp.tiles = c->d_tiles; wp.tok_id = c->d_tok_id; wp.table = c->d_table; wp.table_stride = table_stride;
 		wp.sent_start = c->d_sent_start; wp.sent_end = c->d_sent_end; wp.n_sent = (int32_t)n; wp.layout = p.layout;
@@ -453,7 +480,10 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 			wp.gap_mode = p.gap_mode;                                        // the traceback kernel knows 0 / 1 / 2
 			wp.wt = c->d_wt;                                                 // ... and walks the caller's table
 		}
-		else VK_HIP(vk_launch_wide(&wp, 0, st));
+		else {
+			if ((rc = wide_state(0))) return rc;
+			VK_HIP(vk_launch_wide(&wp, 0, st));
+		}
 	} else if (is_align && !is_static && q->len_t == 1 && c->uniform_len == 1 && q->locality == VK_LOCAL && !p.pos_s) {
 		// span-embedding index: one vector per slice, one query vector -> the clipped cosine is the local alignment score.
 		// The aligner scores are written only if something reads them: the traceback kernel restates those of the winners, and
@@ -706,6 +736,8 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	auto launch_flow = [&](const uint64_t *d_keys, int count) -> int {
 		if (wide) {
 			wp.keys = d_keys; wp.raw_out = c->d_out_raw; wp.mapping = c->d_out_map; wp.edge_sim = c->d_out_sim;
+			int rcw = wide_state(count);
+			if (rcw) return rcw;
 			VK_HIP(vk_launch_wide(&wp, count, st));
 			return VK_OK;
 		}
