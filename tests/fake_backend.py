@@ -46,6 +46,11 @@ class OracleCorpus:
 		self._rows.append(b)
 		self._mags.append(m)
 
+	def _longest(self):
+		"""tokens of the longest slice (a gap table covers it; whole documents as slices: more than VK_MAX_SENT_LEN)"""
+		ends = self._end if self._end is not None else self._off[1:]
+		return int((ends - self._off[:len(ends)]).max(initial=0))
+
 	def set_token_ids(self, ids):
 		self._ids = np.ascontiguousarray(ids, dtype=np.int32)
 
@@ -115,7 +120,7 @@ class OracleCorpus:
 					similarity_threshold=similarity_threshold, wmd_full=wmd_full, q_tags=q_tags, want_rows=want_rows, only_slices=ids[~empty]) if (~empty).any() else None
 				transport = (algorithm != core.VK_ALG_ALIGN or want_rows) and want_flow
 				longest = int((sub._end - sub._off).max())
-				t = core.TopK(len(ids), len(np.atleast_2d(q_vectors)), transport=transport, rows=min(core.VK_MAX_SENT_LEN, max(core.VK_FAST_SENT_LEN, (longest + 63) // 64 * 64)))
+				t = core.TopK(len(ids), len(np.atleast_2d(q_vectors)), transport=transport, rows=core.winner_rows(longest))
 				t.n = len(ids)
 				t.score[:], t.raw_score[:] = -np.inf, -np.inf
 				t.sentence[:t.n] = ids
@@ -151,7 +156,7 @@ class OracleCorpus:
 		else:
 			Qb, qmag = synth.to_bf16_bits(q), np.ones(len(q), np.float32)
 		kw = dict(layout=self.layout, d=self.d, sent_off=self._off, sent_end=self._end, Q=Qb, algorithm=algorithm, locality=int(locality),
-			gap_s=_gap(gap_s), gap_t=_gap(gap_t), max_matches=max_matches, min_score=min_score, boost=boost,
+			gap_s=_gap(gap_s, max(core.VK_MAX_SENT_LEN, self._longest()) + 1), gap_t=_gap(gap_t), max_matches=max_matches, min_score=min_score, boost=boost,
 			submatch_weight=submatch_weight, rwmd=rwmd, wrd_normalize=wrd_normalize, want_all_scores=True,
 			pos_s=self._pos, tag_weights=tag_weights, q_pos=q_pos, pos_mismatch_penalty=pos_mismatch_penalty,
 			similarity_threshold=similarity_threshold, wmd_full=wmd_full)
@@ -169,7 +174,7 @@ class OracleCorpus:
 		# room for the rows / plans of the corpus's longest slice, as the HIP backend's shim makes (core.Corpus._winner_rows)
 		all_ends = self._end if self._end is not None else self._off[1:]
 		longest = int((all_ends - self._off[:len(all_ends)]).max()) if len(all_ends) else 0
-		rows_room = min(core.VK_MAX_SENT_LEN, max(core.VK_FAST_SENT_LEN, (longest + 63) // 64 * 64))
+		rows_room = core.winner_rows(longest)
 		top = core.TopK(max_matches, len(q), transport=transport, rows=rows_room)
 		n = len(r["score"])
 		top.n = n

@@ -88,11 +88,17 @@ def test_longest_document(hip, oracle):
 			if loc == 0:
 				assert got.sentence[0] == 1
 			np.testing.assert_allclose(c.last_scores(), ref["all_scores"], atol=1e-4)
-	# the transports are bounded by VK_MAX_SENT_LEN: refused before anything is enqueued
-	for kw in (dict(algorithm=hip.VK_ALG_RWMD), dict(algorithm=hip.VK_ALG_RWMD, rwmd=(False, False, True), wmd_full=True)):
+	# the relaxed 1:1 word mover's distance streams a document too, its rows come back through global memory
+	ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=32, sent_off=off, X=Xb, Q=Qb, algorithm=oracle.ALG_RWMD, max_matches=4, min_score=-1.0, want_all_scores=True)
+	got = c.query(Qb, q_normalize=False, algorithm=hip.VK_ALG_RWMD, max_matches=4, min_score=-1.0)
+	assert_same_results(got.trimmed(), ref, check_mapping=False, exact=True)
+	np.testing.assert_allclose(c.last_scores(), ref["all_scores"], atol=1e-5)
+	# the 1:n form and the exact transports keep a slice's bag of words in LDS: refused before anything is enqueued
+	for kw in (dict(algorithm=hip.VK_ALG_RWMD, rwmd=(False, True, True)), dict(algorithm=hip.VK_ALG_RWMD, rwmd=(False, False, True), wmd_full=True),
+			dict(algorithm=hip.VK_ALG_WRD)):
 		with pytest.raises(hip.VkError) as e:
 			c.query(Qb, q_normalize=False, max_matches=3, **kw)
-		assert e.value.status == hip.VK_ERR_UNSUPPORTED
+		assert e.value.status in (hip.VK_ERR_UNSUPPORTED, hip.VK_ERR_STATE)   # (WRD: this corpus keeps no magnitudes either)
 	c.close()
 	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=16, n_tokens=n_max + 1, n_sentences=1)
 	c.append_vectors(np.ones((n_max + 1, 16), np.float32))
@@ -180,4 +186,84 @@ def test_document_windows_and_views(hip, oracle):
 			got = h.query(Qb, q_normalize=False, locality=loc, gap_s=gaps[0], gap_t=gaps[1], max_matches=6, min_score=ms).trimmed()
 			assert_same_results(got, ref)
 	v.close()
+	c.close()
+
+
+RWMD_11 = {"nbow": (True, True, True), "bow/fast": (True, False, False), "nbow/fast": (True, False, True)}
+
+
+@pytest.mark.parametrize("variant", list(RWMD_11))
+@pytest.mark.parametrize("len_t", [7, 16, 40])
+def test_relaxed_wmd_over_documents(hip, oracle, variant, len_t):
+	"""rwmd('nbow') and its 1:1 siblings (vectorian/alignment.py:232-237) over documents of up to 3,000 tokens: the scoring pass
+	streams row / column minima (vk_wide_kernel), the winners' canonical similarity rows come back through global memory
+	(vk_rows_kernel<., true>) and the host restates their scores in the reference's order of operations -- the oracle's floats"""
+	docs = ((0, 513), (5, 1200), (18, 3000), (23, 131), (40, 2049), (41, 512), (69, 900))
+	off = document_lengths(31, 70, docs)
+	d = 64
+	c, X, Xb = contextual(hip, off, d, 32)
+	flags = RWMD_11[variant]
+	for qi, sent in enumerate((18, 40, 3)):
+		Qb = planted_query(X, off, sent, len_t, 40 + qi)
+		ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=off, X=Xb, Q=Qb, algorithm=oracle.ALG_RWMD, rwmd=flags,
+			max_matches=12, min_score=0.0, want_all_scores=True)
+		got = c.query(Qb, q_normalize=False, algorithm=hip.VK_ALG_RWMD, rwmd=flags, max_matches=12, min_score=0.0)
+		assert_same_results(got.trimmed(), ref, check_mapping=False, exact=True)
+		np.testing.assert_allclose(got.raw_score[:got.n], ref["raw"], atol=1e-4, rtol=0)
+		np.testing.assert_allclose(c.last_scores(), ref["all_scores"], atol=1e-5, rtol=0)
+		if len_t == 16:   # the tag-weighted modifier (TagWeightedSlice wraps any slice, match/instantiate.cpp:173-189)
+			rng = np.random.default_rng(70 + qi)
+			pos_s = rng.integers(0, 6, size=int(off[-1])).astype(np.int8)
+			c.set_token_pos(pos_s)
+			kw = dict(tag_weights=rng.uniform(0.3, 1.0, size=len(Qb)).astype(np.float32), q_pos=rng.integers(0, 6, size=len(Qb)).astype(np.int8),
+				pos_mismatch_penalty=0.4, similarity_threshold=0.15)
+			ref_t = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=off, X=Xb, Q=Qb, algorithm=oracle.ALG_RWMD, rwmd=flags,
+				max_matches=12, min_score=0.0, want_all_scores=True, pos_s=pos_s, **kw)
+			got_t = c.query(Qb, q_normalize=False, algorithm=hip.VK_ALG_RWMD, rwmd=flags, max_matches=12, min_score=0.0, **kw)
+			assert_same_results(got_t.trimmed(), ref_t, check_mapping=False, exact=True)
+			np.testing.assert_allclose(c.last_scores(), ref_t["all_scores"], atol=1e-5, rtol=0)
+		# the rows of the winners (what the host states a winner's flow from): the oracle's clipped cosines of the slice's tokens
+		top = got.trimmed()
+		s0 = int(top["sentence"][0])
+		ls = int(off[s0 + 1] - off[s0])
+		assert got.sim_rows.shape[1] >= 3000 and not got.sim_rows[0, ls:].any()
+	c.close()
+
+
+def test_relaxed_wmd_over_documents_static_layout(hip, oracle):
+	"""token ids + vocabulary table: bags of words keyed by token id (repeated words are one entry)"""
+	corpus = synth.make_static_corpus(60, 1, 40, 400, 100, seed=15)
+	lens = np.diff(corpus["sent_off"]).copy()
+	for pos, ln in ((2, 600), (3, 2500), (30, 65), (59, 1100)):
+		lens[pos] = ln
+	off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+	rng = np.random.default_rng(16)
+	corpus["sent_off"] = off
+	corpus["tok_id"] = synth.zipf_ids(int(off[-1]), 400, rng).astype(np.int32)
+	pos_s = rng.integers(0, 6, size=int(off[-1])).astype(np.int8)
+	c, Eb = hip_static_corpus(hip, corpus)
+	c.set_token_pos(pos_s)
+	for qi, s in enumerate((3, 59, 20)):
+		a = int(off[s])
+		q_ids = corpus["tok_id"][a:a + 27:3].astype(np.int32)
+		q_ids[4] = q_ids[1]
+		Qb = Eb[q_ids]
+		tw = rng.uniform(0.3, 1.0, size=len(q_ids)).astype(np.float32)
+		q_pos = rng.integers(0, 6, size=len(q_ids)).astype(np.int8)
+		for flags in RWMD_11.values():
+			ref = oracle.find(layout=oracle.LAYOUT_STATIC, d=100, sent_off=off, tok_id=corpus["tok_id"], E=Eb, Q=Qb, q_ids=q_ids,
+				algorithm=oracle.ALG_RWMD, rwmd=flags, max_matches=8, min_score=-1.0, want_all_scores=True)
+			got = c.query(Qb, q_token_ids=q_ids, q_normalize=False, algorithm=hip.VK_ALG_RWMD, rwmd=flags, max_matches=8, min_score=-1.0)
+			assert_same_results(got.trimmed(), ref, check_mapping=False, exact=True)
+			np.testing.assert_allclose(c.last_scores(), ref["all_scores"], atol=1e-5, rtol=0)
+		# (tag weights over the static layout: upstream's distance matrix holds the cells of words that occur on both sides twice,
+		# wmd.h:121-133, which the scoring pass resolves in LDS from the (id, tag) keys of both sides -- slices of at most 512 tokens;
+		# with q_tags such a query is refused on this corpus)
+		if qi == 0:
+			tags = rng.integers(0, 9, size=int(off[-1])).astype(np.int8)
+			c.set_token_tags(tags)
+			with pytest.raises(hip.VkError) as e:
+				c.query(Qb, q_token_ids=q_ids, q_normalize=False, algorithm=hip.VK_ALG_RWMD, max_matches=8, tag_weights=tw, q_pos=q_pos,
+					q_tags=rng.integers(0, 9, size=len(q_ids)).astype(np.int8))
+			assert e.value.status == hip.VK_ERR_UNSUPPORTED
 	c.close()

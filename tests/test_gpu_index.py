@@ -41,6 +41,36 @@ def test_index_find_on_hip_equals_oracle_double(hip, optimizer):
 	gpu.close()
 
 
+@pytest.mark.parametrize("optimizer", [
+	alignment.LocalAlignment(gap=alignment.smooth_gap_cost(5)),
+	alignment.SemiGlobalAlignment(gap={"s": alignment.AffineGapCost(0.2, 0.05), "t": alignment.LinearGapCost(0.1)}),
+])
+def test_document_partition_on_hip_equals_oracle_double(hip, optimizer):
+	"""session.partition("document"): whole documents as slices (the one span the importers give every document,
+	vectorian/importers.py:30-36; mkdocs/docs/documents.md:37) -- documents of ~ 1,100 tokens, beyond VK_MAX_SENT_LEN: the
+	one-wave-per-slice kernel with its state in global memory; also windows of 30 sentences, step 10"""
+	session, emb, words, rng = toy_session(n_docs=12, sents_per_doc=50, V=2000, d=100)
+	sim = OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), optimizer)
+	doc = session.documents[5]
+	st = doc.spans["sentence"]["start"][31]
+	for part in (("document",), ("sentence", 30, 10)):
+		gpu = session.partition(*part).index(sim)
+		cpu = session.partition(*part).index(sim, corpus_factory=OracleCorpus)
+		assert gpu.n_slices == cpu.n_slices
+		for text in (" ".join(doc.tokens[st:st + 6]), " ".join(doc.tokens[st:st + 40:2])):
+			a = gpu.find(text, n=5, min_score=-100.0)
+			b = cpu.find(text, n=5, min_score=-100.0)
+			assert [(m.doc_index, m.slice_id) for m in a] == [(m.doc_index, m.slice_id) for m in b]
+			assert [m.score for m in a] == [m.score for m in b]
+			for x, y in zip(a, b):
+				assert (x.flow["target"] == y.flow["target"]).all()
+				assert (x.flow["dist"] == y.flow["dist"]).all()
+			assert a[0].to_json()["regions"] == b[0].to_json()["regions"]
+			if part == ("document",) and isinstance(optimizer, alignment.LocalAlignment):
+				assert a[0].doc_index == 5 and a[0].slice_id == 0
+		gpu.close()
+
+
 def test_debug_hook_for_every_slice_on_hip_equals_oracle_double(hip):
 	"""debug = AllSlices(hook): every slice stated by the traceback kernel (vk_query_desc.only_slices) -- the same calls, slice by
 	slice, as on the oracle-backed double: aligner score, similarity matrix, flow"""

@@ -215,6 +215,11 @@ def gap_to_struct(gap, keep, n_table):
 	return g
 
 
+def winner_rows(longest):
+	"""rows of a winner's similarity matrix (vk_topk_out.rows_per_winner): the corpus's longest slice, a multiple of 64"""
+	return min(VK_MAX_DOC_LEN + 1, max(VK_FAST_SENT_LEN, (int(longest) + 63) // 64 * 64))
+
+
 class TopK:
 	"""Bounded result set as plain arrays (ResultSet, vectorian/core/cpp/result_set.h:17-153)."""
 
@@ -441,7 +446,7 @@ class Corpus:
 
 	def _winner_rows(self):
 		"""similarity rows / plans of the winners: room for the longest slice of the corpus (a multiple of 64 tokens)"""
-		return min(VK_MAX_SENT_LEN, max(VK_FAST_SENT_LEN, (getattr(self, "_max_len", 0) + 63) // 64 * 64))
+		return winner_rows(getattr(self, "_max_len", 0))
 
 	def query(self, q_vectors, **options):
 		"""One query against the shard (vk_query).  Returns a TopK."""

@@ -33,8 +33,11 @@ class Document:
 		tables = {"sentence": {
 			"start": np.concatenate(([0], np.cumsum(lens)[:-1])).astype(np.int32) if len(lens) else np.zeros(0, np.int32),
 			"end": np.cumsum(lens).astype(np.int32)}}
+		# the importers give every document one span over all of its tokens (vectorian/importers.py:30-36, 220-223):
+		# session.partition("document") makes whole documents the slices
+		tables["document"] = {"start": np.zeros(1, dtype=np.int32), "end": np.array([n_raw], dtype=np.int32)}
 		for level, table in (spans or {}).items():
-			if level in ("sentence", "token"):
+			if level in ("sentence", "token", "document"):
 				raise ValueError(f"span level {level} is built in")
 			st, en = np.asarray(table["start"], dtype=np.int32), np.asarray(table["end"], dtype=np.int32)
 			if st.shape != en.shape or (len(st) and (st.min() < 0 or en.max() > n_raw or (en < st).any())):

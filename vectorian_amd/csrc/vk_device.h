@@ -306,6 +306,7 @@ hipError_t vk_launch_topk_wave_batch(const float *scores, const uint64_t *keys_i
 	int64_t per_wave, int32_t n_queries, int64_t in_stride, int64_t out_stride, uint64_t *out, int64_t *n_waves_out, hipStream_t stream);
 hipError_t vk_launch_wrd_exact(const VkWrdParams *p, int32_t n_cand, float *scores_to_mark, hipStream_t stream);
 hipError_t vk_launch_rows(const VkWrdParams *p, int32_t n_cand, hipStream_t stream);
+size_t vk_rows_scratch_bytes(int32_t rows_len, int32_t nq);
 hipError_t vk_launch_wrd_exact_long(const VkWrdParams *p, int32_t n_cand, hipStream_t stream);
 // queries of 17..64 tokens over long slices: workgroups of the exact solver (each with its own scratch) and bytes per workgroup
 int vk_wrd_long_blocks(void);

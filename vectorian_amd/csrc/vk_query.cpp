@@ -43,8 +43,15 @@ int vk_validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_topk_
 	// one-wave-per-slice kernel with the slice's state in global memory (vk_wide_kernel, global-state form).  The same form takes a
 	// query of more than 16 tokens whose state over the corpus's longest slice exceeds the LDS (round 2: VK_ERR_UNSUPPORTED), except
 	// the relaxed WMD with similarity rows, whose rows are bounded by VK_MAX_SENT_LEN anyway.
-	if (c->max_len > VK_MAX_SENT_LEN && q->algorithm != VK_ALG_ALIGN)
-		return fail(VK_ERR_UNSUPPORTED, "slices of more than VK_MAX_SENT_LEN (512) tokens are scored by alignments only (the transports' bags of words and solvers are bounded by it)");
+	if (c->max_len > VK_MAX_SENT_LEN && q->algorithm != VK_ALG_ALIGN) {
+		// ... and the relaxed word mover's distance in its 1:1 form (a stream of row / column minima; the winners' rows restated
+		// through global memory, vk_rows_kernel); the 1:n form and the exact transports keep a slice's bag of words in LDS
+		const bool relaxed_11 = q->algorithm == VK_ALG_RWMD && !q->wmd_full && q->rwmd_injective;
+		if (!relaxed_11)
+			return fail(VK_ERR_UNSUPPORTED, "slices of more than VK_MAX_SENT_LEN (512) tokens: alignments and the relaxed 1:1 word mover's distance only (the 1:n form and the exact transports keep a slice's bag of words in LDS)");
+		if (c->desc.layout == VK_LAYOUT_STATIC && q->tag_weights && q->q_tags && q->q_token_ids && c->d_tag)
+			return fail(VK_ERR_UNSUPPORTED, "slices of more than VK_MAX_SENT_LEN (512) tokens: tag-weighted vocabulary transports keyed by (id, tag) rewrite cells of a slice's rows in LDS");
+	}
 	if (!q->q_vectors) return fail(VK_ERR_INVALID, "q_vectors is null");
 	if (q->q_dtype != VK_F32 && q->q_dtype != VK_BF16) return fail(VK_ERR_INVALID, "bad q_dtype");
 	if (q->max_matches < 1 || q->max_matches > VK_MAX_MATCHES) return fail(VK_ERR_INVALID, "max_matches out of range");
@@ -197,7 +204,8 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		if (!rows_dst) rows_dst = out->sim_rows;
 		const int nqw = (q->len_t + 15) / 16, W = 16 * nqw;   // columns of a similarity row: the query length padded to 16
 		const int R = out->rows_per_winner > 0 ? out->rows_per_winner : VK_FAST_SENT_LEN;   // rows per winner (longer winners: zero rows)
-		if (R % 64 != 0 || R > VK_MAX_SENT_LEN) return fail(VK_ERR_INVALID, "rows_per_winner must be a multiple of 64, at most VK_MAX_SENT_LEN");
+		if (R % 64 != 0 || R > VK_MAX_DOC_LEN + 1 || (exact && R > VK_MAX_SENT_LEN))
+			return fail(VK_ERR_INVALID, "rows_per_winner must be a multiple of 64, at most VK_MAX_SENT_LEN (rows without plans: VK_MAX_DOC_LEN + 1)");
 		int rc2;
 		const int cnt = (int)rows_idx.size();
 		const size_t need = (size_t)cnt * R * W;
@@ -218,7 +226,17 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		VkWrdParams w{};
 		fill_transport(w);
 		w.keys = c->d_keys[1]; w.rows_out = c->d_rows_out; w.rows_len = R;
+		if (R > VK_MAX_SENT_LEN) {   // rows of whole documents: assembled in global memory, a region per winner
+			const size_t per = vk_rows_scratch_bytes(R, w.nq), need_s = per * (size_t)cnt;
+			if (c->wide_scratch_cap < need_s) {
+				if (c->d_wide_scratch) { VK_HIP(hipFree(c->d_wide_scratch)); c->d_wide_scratch = nullptr; c->wide_scratch_cap = 0; }
+				if ((rc2 = alloc_t(c, &c->d_wide_scratch, need_s))) return rc2;
+				c->wide_scratch_cap = need_s;
+			}
+			w.scratch = c->d_wide_scratch; w.scratch_stride = (int64_t)per;
+		}
 		VK_HIP(vk_launch_rows(&w, cnt, c->stream));
+		w.scratch = nullptr; w.scratch_stride = 0;
 		VK_HIP(hipMemcpyAsync(rows_dst, c->d_rows_out, need * 4, hipMemcpyDeviceToHost, c->stream));
 		if (exact && out->plan) {
 			w.mass_mode = mass_mode; w.raw_masses = raw_masses;

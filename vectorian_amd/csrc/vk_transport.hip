@@ -676,15 +676,19 @@ extern "C" hipError_t vk_launch_long_bound(const VkWrdParams *p, hipStream_t str
 }
 
 // similarity rows of the winners of a transport query, for the host to state their flows: [64][16 nq] per winner
-template <int NQ>
+// GS: the rows of a winner are assembled in global memory (p.scratch, (rows_len + 32) rows per winner) instead of LDS -- winners of
+// more than 512 tokens (whole documents as slices); no vocabulary fixup in this form (vk_validate_query)
+template <int NQ, bool GS>
 __global__ __launch_bounds__(64) void vk_rows_kernel(VkWrdParams p) {
 	constexpr int N = 16 * NQ;
 	extern __shared__ double vk_smem_f64[];
 	uint8_t *canon = reinterpret_cast<uint8_t *>(vk_smem_f64);   // staging of sim_canon16 (VK_CANON_LDS bytes)
-	float *S = reinterpret_cast<float *>(canon + VK_CANON_LDS);   // [(R + 32)][N]
 	const int lane = threadIdx.x;
 	const int w = blockIdx.x;
 	const int R = p.rows_len > 0 ? p.rows_len : 64;
+	float *S;   // [(R + 32)][N]
+	if constexpr (GS) S = reinterpret_cast<float *>(p.scratch + (int64_t)w * p.scratch_stride);
+	else S = reinterpret_cast<float *>(canon + VK_CANON_LDS);
 	float *out = p.rows_out + (int64_t)w * R * N;
 	const uint64_t key = p.keys[w];
 	int m = 0, rowbase = 0;
@@ -697,6 +701,11 @@ __global__ __launch_bounds__(64) void vk_rows_kernel(VkWrdParams p) {
 		else rowbase = transport_sim_rows<NQ>(p, S, t_a, t_b, lane, canon);
 	}
 	wave_lds_fence();
+	if constexpr (GS) {   // the rows were written by other lanes, through global memory
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+	}
 	for (int i = lane; i < R * N; i += 64) out[i] = i / N < m ? S[rowbase * N + i] : 0.0f;
 }
 
@@ -717,10 +726,18 @@ extern "C" hipError_t vk_launch_wrd_exact(const VkWrdParams *p, int32_t n_cand, 
 	return hipGetLastError();
 }
 
+extern "C" size_t vk_rows_scratch_bytes(int32_t rows_len, int32_t nq) {
+	return (size_t)(rows_len + 32) * 16 * (size_t)(nq < 1 ? 1 : nq) * 4;
+}
+
 extern "C" hipError_t vk_launch_rows(const VkWrdParams *p, int32_t n_cand, hipStream_t stream) {
 	const int R = p->rows_len > 0 ? p->rows_len : 64;
-	const size_t smem = VK_CANON_LDS + (size_t)(R + 32) * 16 * (size_t)(p->nq < 1 ? 1 : p->nq) * 4;
-	void (*kernel)(VkWrdParams) = p->nq <= 1 ? vk_rows_kernel<1> : p->nq == 2 ? vk_rows_kernel<2> : p->nq == 3 ? vk_rows_kernel<3> : vk_rows_kernel<4>;
+	const bool gs = p->scratch != nullptr;   // rows assembled in global memory (the host: winners of more than 512 tokens)
+	if (gs && p->scratch_stride < (int64_t)vk_rows_scratch_bytes(R, p->nq)) return hipErrorInvalidValue;
+	const size_t smem = VK_CANON_LDS + (gs ? 0 : (size_t)(R + 32) * 16 * (size_t)(p->nq < 1 ? 1 : p->nq) * 4);
+	void (*kernel)(VkWrdParams) = gs
+		? (p->nq <= 1 ? vk_rows_kernel<1, true> : p->nq == 2 ? vk_rows_kernel<2, true> : p->nq == 3 ? vk_rows_kernel<3, true> : vk_rows_kernel<4, true>)
+		: (p->nq <= 1 ? vk_rows_kernel<1, false> : p->nq == 2 ? vk_rows_kernel<2, false> : p->nq == 3 ? vk_rows_kernel<3, false> : vk_rows_kernel<4, false>);
 	if (smem > 64 * 1024) {
 		const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 		if (e != hipSuccess) return e;
