@@ -151,7 +151,7 @@ int vk_corpus_free(vk_corpus_t *c) {
 		c->d_sent_start = c->d_sent_end = nullptr, c->d_long_groups = nullptr;
 	if (c->shares_vectors) c->d_tiles = nullptr, c->d_mag = nullptr;
 	void *ptrs[] = {c->d_tiles, c->d_mag, c->d_tok_id, c->d_pos, c->d_tag, c->d_sent_start, c->d_sent_end, c->d_stage, c->d_qtile, c->d_ws, c->d_wt, c->d_qids,
-		c->d_table, c->d_scores, c->d_raw, c->d_boost, c->d_keys[0], c->d_keys[1], c->d_out_raw, c->d_out_sim, c->d_out_map, c->d_wrd_raw, c->d_wrd_val, c->d_bq, c->d_bqlen, c->d_bscores, c->d_bkeys[0], c->d_bkeys[1], c->d_long_groups, c->d_counter, c->d_rows_out, c->d_plan_out, c->d_braw, c->d_wrdl_scratch, c->d_wide_scratch, c->d_bqt, c->d_bcand, c->d_bcandq, c->d_brows, c->d_qbits};
+		c->d_table, c->d_scores, c->d_raw, c->d_boost, c->d_keys[0], c->d_keys[1], c->d_out_raw, c->d_out_sim, c->d_out_map, c->d_wrd_raw, c->d_wrd_val, c->d_bq, c->d_bqlen, c->d_bscores, c->d_bkeys[0], c->d_bkeys[1], c->d_long_groups, c->d_counter, c->d_rows_out, c->d_plan_out, c->d_braw, c->d_wrdl_scratch, c->d_wide_scratch, c->d_wide_order, c->d_bqt, c->d_bcand, c->d_bcandq, c->d_brows, c->d_qbits};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	if (c->h_brows) (void)hipHostFree(c->h_brows);
 	for (auto &b : c->bl) for (void *p : {(void *)b.tiles, (void *)b.len, (void *)b.id}) if (p) (void)hipFree(p);
@@ -317,6 +317,8 @@ static int set_slices_impl(vk_corpus_t *c, const int64_t *start, const int64_t *
 	c->h_start = std::make_shared<std::vector<int32_t>>(st32);
 	c->h_end = std::make_shared<std::vector<int32_t>>(en32);
 	c->n_entries = n_entries;
+	if (c->d_wide_order) { VK_HIP(hipFree(c->d_wide_order)); c->d_wide_order = nullptr; }
+	c->n_wide_order = -1;   // the work list of the one-wave-per-slice pass follows the table
 	c->n_long_groups = (int)long_groups.size();
 	c->max_len = max_len;
 	c->max_short_len = max_short;

@@ -255,6 +255,9 @@ struct VkWideParams {
 	// one region of scratch_stride bytes per workgroup (vk_wide_scratch_bytes; vk_wide_gs_blocks regions)
 	uint8_t *scratch;
 	int64_t scratch_stride;
+	const int32_t *order;      // vk_wide_kernel SCORE: rows of the slice table to walk, longest first (null: all of them, in order)
+	int32_t n_order;
+	int32_t ws_tail;           // vk_wide_kernel, general gaps: w_s[k] == w_s[ws_tail] for every k >= ws_tail up to max_len (0: no such tail)
 };
 
 #ifdef __cplusplus

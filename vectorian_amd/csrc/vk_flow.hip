@@ -265,7 +265,9 @@ __device__ __forceinline__ void wide_state_fence() {
 	}
 }
 
-template <bool FLOW, bool GS>
+// GAPT: the gap mode at compile time (0 linear, 1 affine, 2 general, 4 relaxed WMD) -- the generic body took 106 scalar registers
+// and spilled more into a vector register's lanes, read back inside the row loop
+template <bool FLOW, bool GS, int GAPT>
 __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 	extern __shared__ float4 vk_smem4[];
 	const int lane = threadIdx.x;
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 	float *twl = wtl + LQ + 4;
 	int *tposl = reinterpret_cast<int *>(twl + 64);
 	float *H_lds = reinterpret_cast<float *>(tposl + 64);  // general gaps: H[u][v], row stride W
-	float *after = (p.gap_mode == 2 && !GS) ? H_lds + rows * W : H_lds;
+	float *after = (GAPT == 2 && !GS) ? H_lds + rows * W : H_lds;
 	int16_t *mapl = reinterpret_cast<int16_t *>(after);    // FLOW: mapping of the winner
 	int16_t *dk_lds = mapl + 64;
 	uint8_t *flags_lds = reinterpret_cast<uint8_t *>(dk_lds + rows * W);
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 	uint8_t *canon = FLOW ? reinterpret_cast<uint8_t *>(vk_smem4) + (((size_t)(lds_end - reinterpret_cast<uint8_t *>(vk_smem4)) + 15) / 16 * 16) : nullptr;
 	// GS: this workgroup's region of the scratch (vk_wide_scratch_bytes_impl); the gap table of the slices is read where it lies
 	uint8_t *region = GS ? p.scratch + (int64_t)blockIdx.x * p.scratch_stride : nullptr;
-	const size_t h_bytes = p.gap_mode == 2 ? ((size_t)rows * W * 4 + 15) / 16 * 16 : 0;
+	const size_t h_bytes = GAPT == 2 ? ((size_t)rows * W * 4 + 15) / 16 * 16 : 0;
 	const size_t dk_bytes = ((size_t)rows * W * 2 + 15) / 16 * 16;
 	float *H;
 	int16_t *dk;
@@ -309,13 +311,15 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 	const int v = lane + 1;
 	const bool col = v <= len_t;
 	const bool local = p.locality == VK_DEV_LOCAL, global = p.locality == VK_DEV_GLOBAL;
-	const int gap = p.gap_mode;
+	constexpr int gap = GAPT;
 	const float gs = p.gs, gt = p.gt, open_s = p.open_s, open_t = p.open_t, a_s = p.a_s, a_t = p.a_t;
 	const bool is_static = p.layout == VK_DEV_LAYOUT_STATIC;
 
-	const int64_t n_items = FLOW ? (int64_t)gridDim.x : (int64_t)p.n_sent;
+	// SCORE: every row of the slice table, or -- p.order -- the non-empty ones, longest first (one wave per slice: a wave's share of
+	// the work is then what the longest-processing-time rule deals it; the scores of the empty rows are preset by the host)
+	const int64_t n_items = FLOW ? (int64_t)gridDim.x : p.order ? (int64_t)p.n_order : (int64_t)p.n_sent;
 	for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
-		int64_t g = item;
+		int64_t g = (!FLOW && p.order) ? (int64_t)p.order[item] : item;
 		if (FLOW) {
 			const uint64_t key = p.keys[item];
 			if (key == 0) return;   // fewer than k admitted
@@ -436,6 +440,10 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 			if (gap == 2 && col) H[v] = hprev;
 			float bv = 0.0f;
 			int bu = 0, u = 0;
+			const int ktail = (gap == 2 && p.ws_tail > 0) ? p.ws_tail : 0x7fffffff;
+			const float wtail = ktail <= p.max_len ? wsl[ktail] : 0.0f;
+			float tmax = VK_NEG_INF;
+			int trow = 0;
 			for (int base = base0; base < t_b; base += 16) {
 				fill(base);
 				wave_lds_fence();
@@ -465,9 +473,33 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 						if (c > e) { e = c; ee = 1; }
 						if (e > best) { best = e; d = 2; }
 					} else {
-						for (int k = 1; k <= u; k++) {
-							c = H[(u - k) * W + (col ? v : 1)] - wsl[k];
+						// gaps of ktail tokens and more cost the same (a saturated table, e.g. 1 - 2^(-k/5) = 1.0f from k = 126 on): their
+						// candidates H[r][v] - w_tail, r <= u - ktail, are a running maximum over the rows as they leave the window -- kept
+						// with the largest row among equal values, i.e. the smallest k, which is the one the k-ascending scan with its strict
+						// comparison keeps -- and the scan stops at ktail - 1: O(len_s ktail) per column instead of O(len_s^2)
+						const int kmax = u < ktail ? u : ktail - 1;
+						const int cv = col ? v : 1;
+						int k = 1;
+						// eight candidates at a time: their loads are issued together (one after the other, each waited for, a candidate cost
+						// a round trip to the L2 when the history lives in global memory), the comparisons stay in k order
+						for (; k + 7 <= kmax; k += 8) {
+							float hv[8], wv[8];
+#pragma unroll
+							for (int i = 0; i < 8; i++) { hv[i] = H[(u - k - i) * W + cv]; wv[i] = wsl[k + i]; }
+#pragma unroll
+							for (int i = 0; i < 8; i++) {
+								c = hv[i] - wv[i];
+								if (c > best) { best = c; d = 2; kk = (int16_t)(k + i); }
+							}
+						}
+						for (; k <= kmax; k++) {
+							c = H[(u - k) * W + cv] - wsl[k];
 							if (c > best) { best = c; d = 2; kk = (int16_t)k; }
+						}
+						if (u >= ktail) {
+							c = H[(u - ktail) * W + (col ? v : 1)] - wtail;
+							if (c >= tmax) { tmax = c; trow = u - ktail; }
+							if (tmax > best) { best = tmax; d = 2; kk = (int16_t)(u - trow); }
 						}
 					}
 					// in-row candidates: columns become final left to right
@@ -551,7 +583,14 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 		wave_lds_fence();
 		const int mine = mapl[lane];
 		float es = 0.0f;
-		for (int base = base0; base < t_b; base += 16) {
+		// only the tiles that hold a mapped row (the mapping ascends with the query column: each such tile is restated once)
+		int done = -1;
+		for (int j = 0; j < len_t; j++) {
+			const int mj = mapl[j];
+			if (mj < 0) continue;
+			const int base = is_static ? t_a + ((mj >> 4) << 4) : ((t_a + mj) >> 4) << 4;
+			if (base == done) continue;
+			done = base;
 			fill(base);
 			wave_lds_fence();
 			const int row = t_a + mine - base;
@@ -582,35 +621,47 @@ extern "C" int32_t vk_wide_gs_blocks(int32_t max_len, int32_t nq, int32_t gap_mo
 	return (int32_t)(blocks < 1 ? 1 : blocks);
 }
 
+template <bool FLOW, bool GS>
+static hipError_t launch_wide_gap(const VkWideParams &p, int blocks, size_t smem, hipStream_t stream, bool occupancy_grid) {
+	auto go = [&](auto kernel) -> hipError_t {
+		if (smem > 64 * 1024) {
+			hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+			if (e != hipSuccess) return e;
+		}
+		if (occupancy_grid) {   // SCORE, state in LDS: the slices are walked with a grid stride by as many workgroups as are resident
+			int occ = 0, dev = 0, cus = 256;
+			hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 64, smem);
+			if (e != hipSuccess) return e;
+			if (occ < 1) occ = 1;
+			if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+			const int64_t want = p.n_sent, cap = (int64_t)cus * occ;
+			blocks = (int)(want < cap ? want : cap);
+		}
+		kernel<<<blocks, 64, smem, stream>>>(p);
+		return hipGetLastError();
+	};
+	switch (p.gap_mode) {
+	case 0: return go(vk_wide_kernel<FLOW, GS, 0>);
+	case 1: return go(vk_wide_kernel<FLOW, GS, 1>);
+	case 2: return go(vk_wide_kernel<FLOW, GS, 2>);
+	case 4: return go(vk_wide_kernel<FLOW, GS, 4>);
+	default: return hipErrorInvalidValue;
+	}
+}
+
 extern "C" hipError_t vk_launch_wide(const VkWideParams *p, int32_t flow_k, hipStream_t stream) {
 	const bool flow = flow_k > 0;
 	const bool gs = p->scratch != nullptr;
 	const size_t smem = vk_wide_lds_bytes(p->max_len, p->nq, p->gap_mode, p->pos_s != nullptr, flow, gs);
 	if (smem > 160 * 1024) return hipErrorInvalidValue;
-	const void *fn = gs ? (flow ? reinterpret_cast<const void *>(vk_wide_kernel<true, true>) : reinterpret_cast<const void *>(vk_wide_kernel<false, true>))
-		: (flow ? reinterpret_cast<const void *>(vk_wide_kernel<true, false>) : reinterpret_cast<const void *>(vk_wide_kernel<false, false>));
-	if (smem > 64 * 1024) {
-		hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-		if (e != hipSuccess) return e;
-	}
 	if (gs) {
 		// the host sized p->scratch for vk_wide_gs_blocks regions of scratch_stride bytes
-		const int blocks = vk_wide_gs_blocks(p->max_len, p->nq, p->gap_mode, flow_k, p->n_sent);
+		const int blocks = vk_wide_gs_blocks(p->max_len, p->nq, p->gap_mode, flow_k, p->order ? p->n_order : p->n_sent);
 		if (p->scratch_stride < (int64_t)vk_wide_scratch_bytes_impl(p->max_len, p->nq, p->gap_mode, flow)) return hipErrorInvalidValue;
-		if (flow) vk_wide_kernel<true, true><<<blocks, 64, smem, stream>>>(*p);
-		else vk_wide_kernel<false, true><<<blocks, 64, smem, stream>>>(*p);
-	} else if (flow) {
-		vk_wide_kernel<true, false><<<flow_k, 64, smem, stream>>>(*p);
-	} else {
-		int occ = 0, dev = 0, cus = 256;
-		hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vk_wide_kernel<false, false>, 64, smem);
-		if (e != hipSuccess) return e;
-		if (occ < 1) occ = 1;
-		if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-		const int64_t want = p->n_sent, cap = (int64_t)cus * occ;
-		vk_wide_kernel<false, false><<<(int)(want < cap ? want : cap), 64, smem, stream>>>(*p);
+		return flow ? launch_wide_gap<true, true>(*p, blocks, smem, stream, false) : launch_wide_gap<false, true>(*p, blocks, smem, stream, false);
 	}
-	return hipGetLastError();
+	if (flow) return launch_wide_gap<true, false>(*p, flow_k, smem, stream, false);
+	return launch_wide_gap<false, false>(*p, 0, smem, stream, true);
 }
 
 extern "C" size_t vk_wide_lds_demand(int32_t max_len, int32_t nq, int32_t gap_mode, int32_t tagged, int32_t flow) {

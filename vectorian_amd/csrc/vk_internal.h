@@ -117,6 +117,7 @@ struct vk_corpus {
 	uint32_t *d_qbits = nullptr;   // tag-weighted vocabulary transports over the static layout: bitmap of the query's token ids
 	uint8_t *d_wrdl_scratch = nullptr;   // exact transport, queries of 17..64 tokens over long slices: per-workgroup state
 	uint8_t *d_wide_scratch = nullptr; size_t wide_scratch_cap = 0;   // vk_wide_kernel, global-state form: per-workgroup state of a slice
+	int32_t *d_wide_order = nullptr; int32_t n_wide_order = -1;   // ... its work list: the non-empty rows of the slice table, longest first
 	size_t ws_cap = kGapTable;   // floats d_ws holds (grown by a query over a corpus with longer slices)
 	int rows_w = 0;              // columns per similarity row they are sized for (16, 32, 48 or 64)
 	// batched GEMM over a ragged corpus (vk_query_batch): a padded copy of the sentences, one bucket per padded length

@@ -436,6 +436,22 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 			c->wide_scratch_cap = need;
 		}
 		wp.scratch = c->d_wide_scratch; wp.scratch_stride = (int64_t)per;
+		if (!flow && xlong) {
+			// the scoring pass takes one wave per slice: the non-empty rows of the slice table, longest first; the others carry no score
+			if (c->n_wide_order < 0) {
+				std::vector<int32_t> ord;
+				for (int64_t e = 0; e < n; e++) if ((*c->h_end)[(size_t)e] > (*c->h_start)[(size_t)e]) ord.push_back((int32_t)e);
+				std::stable_sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) {
+					return (*c->h_end)[(size_t)a] - (*c->h_start)[(size_t)a] > (*c->h_end)[(size_t)b] - (*c->h_start)[(size_t)b]; });
+				int rcw;
+				if ((rcw = alloc_t(c, &c->d_wide_order, ord.size() + 1))) return rcw;
+				VK_HIP(hipMemcpy(c->d_wide_order, ord.data(), ord.size() * 4, hipMemcpyHostToDevice));
+				c->n_wide_order = (int32_t)ord.size();
+			}
+			wp.order = c->d_wide_order; wp.n_order = c->n_wide_order;
+			VK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->d_scores), (int)0xff800000u, (size_t)n, st));
+			if (wp.raw) VK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(wp.raw), (int)0xff800000u, (size_t)n, st));
+		}
 		return VK_OK;
 	};
 	if (wide) {
@@ -446,6 +462,11 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		wp.rwmd_symmetric = p.rwmd_symmetric; wp.rwmd_normalize_bow = p.rwmd_normalize_bow;
 		wp.gs = p.gs; wp.gt = p.gt; wp.a_s = p.a_s; wp.a_t = p.a_t; wp.open_s = p.open_s; wp.open_t = p.open_t;
 		wp.ws = c->d_ws; wp.wt = c->d_wt; wp.wt0 = c->d_wt;
+		if (p.gap_mode == 2 && c->max_len >= 2) {   // the constant tail of w_s (a saturated table): from which k on
+			int kt = c->max_len;
+			while (kt > 1 && ws[(size_t)kt - 1] == ws[(size_t)c->max_len]) kt--;
+			if (kt < c->max_len) wp.ws_tail = kt;
+		}
 		wp.pos_s = p.pos_s; wp.tag_s = p.tag_s; wp.qid_bits = p.qid_bits; wp.slices_overlap = p.slices_overlap; memcpy(wp.qkey, qkey_all, sizeof wp.qkey);
 		wp.tw_keep = p.tw_keep; wp.tw_threshold = p.tw_threshold; wp.ref_total = p.ref_total;
 		for (int j = 0; j < VK_MAX_QUERY_LEN; j++) {
