@@ -257,6 +257,9 @@ struct VkWideParams {
 	int64_t scratch_stride;
 	const int32_t *order;      // vk_wide_kernel SCORE: rows of the slice table to walk, longest first (null: all of them, in order)
 	int32_t n_order;
+	const float *dp_rows;      // vk_wide_kernel FLOW: the winners' similarities, restated tile-parallel beforehand (vk_canon_rows_kernel):
+	int32_t dp_rows_len;       //   [k][dp_rows_len][16 nq], row 0 = a winner's first token; null: the kernel restates them itself
+	int32_t h_ring;            // vk_wide_kernel, global-state form with ws_tail: rows of the LDS ring of the column history (vk_wide_ring_rows; 0: history in the scratch)
 	int32_t ws_tail;           // vk_wide_kernel, general gaps: w_s[k] == w_s[ws_tail] for every k >= ws_tail up to max_len (0: no such tail)
 };
 
@@ -270,8 +273,9 @@ hipError_t vk_launch_mark(const uint64_t *keys, int32_t n, float *scores, hipStr
 hipError_t vk_launch_select_ge(const float *scores, int64_t n, float theta, float floor_excl, uint64_t *keys_out,
 	uint32_t *counter, uint32_t cap, hipStream_t stream);
 size_t vk_wide_lds_demand(int32_t max_len, int32_t nq, int32_t gap_mode, int32_t tagged, int32_t flow);
-size_t vk_wide_scratch_bytes(int32_t max_len, int32_t nq, int32_t gap_mode, int32_t flow);
-int32_t vk_wide_gs_blocks(int32_t max_len, int32_t nq, int32_t gap_mode, int32_t flow_k, int64_t n_sent);
+size_t vk_wide_scratch_bytes(int32_t max_len, int32_t nq, int32_t gap_mode, int32_t flow, int32_t ring);
+int32_t vk_wide_gs_blocks(int32_t max_len, int32_t nq, int32_t gap_mode, int32_t flow_k, int64_t n_sent, int32_t ring);
+int32_t vk_wide_ring_rows(int32_t nq, int32_t gap_mode, int32_t ws_tail);
 hipError_t vk_launch_pack(const void *in, int32_t dtype_bf16, int64_t n_rows, int32_t d, int32_t d_pad, int64_t row0,
 	uint8_t *tiles, float *mag_out, int32_t normalize, int32_t prec, hipStream_t stream);
 // queries of 17..32 tokens, linear / affine gaps (vk_score32.hip)
@@ -309,7 +313,7 @@ hipError_t vk_launch_topk_wave_batch(const float *scores, const uint64_t *keys_i
 	int64_t per_wave, int32_t n_queries, int64_t in_stride, int64_t out_stride, uint64_t *out, int64_t *n_waves_out, hipStream_t stream);
 hipError_t vk_launch_wrd_exact(const VkWrdParams *p, int32_t n_cand, float *scores_to_mark, hipStream_t stream);
 hipError_t vk_launch_rows(const VkWrdParams *p, int32_t n_cand, hipStream_t stream);
-size_t vk_rows_scratch_bytes(int32_t rows_len, int32_t nq);
+hipError_t vk_launch_canon_rows(const VkWrdParams *p, int32_t n_cand, int32_t max_tiles, hipStream_t stream);
 hipError_t vk_launch_wrd_exact_long(const VkWrdParams *p, int32_t n_cand, hipStream_t stream);
 // queries of 17..64 tokens over long slices: workgroups of the exact solver (each with its own scratch) and bytes per workgroup
 int vk_wrd_long_blocks(void);

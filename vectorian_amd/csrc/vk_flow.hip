@@ -223,12 +223,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void vk
 // queries on the device, not a roofline kernel.
 // ---------------------------------------------------------------------------
 
-static inline size_t vk_wide_lds_bytes(int max_len, int nq, int gap_mode, bool tagged, bool flow, bool gstate = false) {
+static inline size_t vk_wide_lds_bytes(int max_len, int nq, int gap_mode, bool tagged, bool flow, bool gstate = false, int ring = 0) {
 	const size_t LQ = (size_t)nq * 16, W = LQ + 1, rows = (size_t)max_len + 1;
 	size_t fl = 16 * LQ * (tagged ? 2 : 1);            // Sx (+ SWx)
 	fl += (gstate ? 0 : (rows + 3) / 4 * 4) + LQ + 4;  // wsl, wtl
 	fl += 64 + 64;                                     // twl, tposl
 	if (gap_mode == 2 && !gstate) fl += rows * W;      // H
+	if (gap_mode == 2 && gstate && ring > 0) fl += (size_t)ring * W + (size_t)ring + 4;   // the last `ring` rows of H, w_s[0 .. ring)
 	size_t b = fl * 4;
 	if (flow) b += 64 * 2 + (gstate ? 0 : rows * W * 2 + rows * W);   // mapl, dk, flags
 	b = (b + 15) / 16 * 16;
@@ -240,10 +241,10 @@ static inline size_t vk_wide_lds_bytes(int max_len, int nq, int gap_mode, bool t
 // flags -- in global memory (GS form, one region per workgroup): slices of any length the mapping's int16 can name (whole documents
 // as slices), and queries of more than 16 tokens over slices whose state does not fit the LDS.  Layout of a region: H [rows x W]
 // floats (general gaps), dk [rows x W] int16 and flags [rows x W] bytes (FLOW), each 16-byte aligned.
-static inline size_t vk_wide_scratch_bytes_impl(int max_len, int nq, int gap_mode, bool flow) {
+static inline size_t vk_wide_scratch_bytes_impl(int max_len, int nq, int gap_mode, bool flow, int ring = 0) {
 	const size_t W = (size_t)nq * 16 + 1, rows = (size_t)max_len + 1;
 	size_t b = 0;
-	if (gap_mode == 2) b += (rows * W * 4 + 15) / 16 * 16;
+	if (gap_mode == 2 && ring == 0) b += (rows * W * 4 + 15) / 16 * 16;   // (a saturated gap table: the history is a ring in LDS)
 	if (flow) b += (rows * W * 2 + 15) / 16 * 16 + (rows * W + 15) / 16 * 16;
 	return b < 16 ? 16 : b;
 }
@@ -267,8 +268,12 @@ __device__ __forceinline__ void wide_state_fence() {
 
 // GAPT: the gap mode at compile time (0 linear, 1 affine, 2 general, 4 relaxed WMD) -- the generic body took 106 scalar registers
 // and spilled more into a vector register's lanes, read back inside the row loop
-template <bool FLOW, bool GS, int GAPT>
+// GSM: 0 the state of a slice in LDS, 1 in global memory, 2 (general gaps with a saturated table, ws_tail) traceback in global
+// memory and the column history as a ring of the last p.h_ring rows in LDS -- candidates further back than ws_tail rows are one
+// running maximum, so nothing older is read, and the scan's loads come back in an LDS round trip instead of one to the L2
+template <bool FLOW, int GSM, int GAPT>
 __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
+	constexpr bool GS = GSM != 0, HR = GSM == 2;
 	extern __shared__ float4 vk_smem4[];
 	const int lane = threadIdx.x;
 	const int LQ = p.nq * 16, W = LQ + 1, rows = p.max_len + 1;
@@ -279,7 +284,9 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 	float *twl = wtl + LQ + 4;
 	int *tposl = reinterpret_cast<int *>(twl + 64);
 	float *H_lds = reinterpret_cast<float *>(tposl + 64);  // general gaps: H[u][v], row stride W
-	float *after = (GAPT == 2 && !GS) ? H_lds + rows * W : H_lds;
+	const int ring = HR ? p.h_ring : 0, rmask = ring - 1;
+	float *wsk_lds = H_lds + ring * W;                     // HR: w_s[0 .. ring)
+	float *after = (GAPT == 2 && !GS) ? H_lds + rows * W : HR ? wsk_lds + ring + 4 : H_lds;
 	int16_t *mapl = reinterpret_cast<int16_t *>(after);    // FLOW: mapping of the winner
 	int16_t *dk_lds = mapl + 64;
 	uint8_t *flags_lds = reinterpret_cast<uint8_t *>(dk_lds + rows * W);
@@ -287,7 +294,7 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 	uint8_t *canon = FLOW ? reinterpret_cast<uint8_t *>(vk_smem4) + (((size_t)(lds_end - reinterpret_cast<uint8_t *>(vk_smem4)) + 15) / 16 * 16) : nullptr;
 	// GS: this workgroup's region of the scratch (vk_wide_scratch_bytes_impl); the gap table of the slices is read where it lies
 	uint8_t *region = GS ? p.scratch + (int64_t)blockIdx.x * p.scratch_stride : nullptr;
-	const size_t h_bytes = GAPT == 2 ? ((size_t)rows * W * 4 + 15) / 16 * 16 : 0;
+	const size_t h_bytes = (GAPT == 2 && !HR) ? ((size_t)rows * W * 4 + 15) / 16 * 16 : 0;
 	const size_t dk_bytes = ((size_t)rows * W * 2 + 15) / 16 * 16;
 	float *H;
 	int16_t *dk;
@@ -298,6 +305,7 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 		dk = reinterpret_cast<int16_t *>(region + h_bytes);
 		flags = region + h_bytes + dk_bytes;
 		wsl = p.ws;
+		if constexpr (HR) for (int i = lane; i < ring && i <= p.max_len; i += 64) wsk_lds[i] = p.ws[i];
 	} else {
 		H = H_lds; dk = dk_lds; flags = flags_lds; wsl = wsl_lds;
 		for (int i = lane; i <= p.max_len; i += 64) wsl_lds[i] = p.ws[i];
@@ -314,6 +322,13 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 	constexpr int gap = GAPT;
 	const float gs = p.gs, gt = p.gt, open_s = p.open_s, open_t = p.open_t, a_s = p.a_s, a_t = p.a_t;
 	const bool is_static = p.layout == VK_DEV_LAYOUT_STATIC;
+	auto Hrow = [&](int r) -> float * {
+		if constexpr (HR) return H_lds + (r & rmask) * W;
+		else return H + r * W;
+	};
+	const float *wsk;   // the gap table as the candidate scan reads it
+	if constexpr (HR) wsk = wsk_lds;
+	else wsk = wsl;
 
 	// SCORE: every row of the slice table, or -- p.order -- the non-empty ones, longest first (one wave per slice: a wave's share of
 	// the work is then what the longest-processing-time rule deals it; the scores of the empty rows are preset by the host)
@@ -402,6 +417,18 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 			}
 		};
 		const int base0 = is_static ? t_a : (t_a >> 4) * 16;
+		// FLOW over long winners: the rows the recurrence runs on were restated beforehand (vk_canon_rows_kernel: the same canonical
+		// arithmetic, sim[id(t_j)][j] = 1 and tag weights applied), [dp_rows_len][LQ] per winner, row 0 = the slice's first token
+		auto fill_dp = [&](int base) {
+			const float *rows = p.dp_rows + (int64_t)item * p.dp_rows_len * LQ;
+			for (int i = lane; i < 4 * LQ; i += 64) {   // 16 rows of LQ floats, a float4 per step
+				const int r = i / (LQ >> 2), c4 = i % (LQ >> 2);
+				const int rel = base + r - t_a;
+				float4 val = {0.0f, 0.0f, 0.0f, 0.0f};
+				if (rel >= 0 && rel < len_s) val = *reinterpret_cast<const float4 *>(rows + (int64_t)rel * LQ + c4 * 4);
+				*reinterpret_cast<float4 *>(SWx + r * LQ + c4 * 4) = val;
+			}
+		};
 
 		float raw;
 		int u_start = 0, v_start = 0;
@@ -437,15 +464,16 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 			// ---- alignment: fill, lane = column
 			float hprev = 0.0f, eprev = VK_NEG_INF;
 			if (global && col) hprev = gap == 0 ? -(gt * (float)v) : gap == 1 ? -(a_t + gt * (float)v) : -wtl[v];
-			if (gap == 2 && col) H[v] = hprev;
+			if (gap == 2 && col) Hrow(0)[v] = hprev;
 			float bv = 0.0f;
 			int bu = 0, u = 0;
 			const int ktail = (gap == 2 && p.ws_tail > 0) ? p.ws_tail : 0x7fffffff;
-			const float wtail = ktail <= p.max_len ? wsl[ktail] : 0.0f;
+			const float wtail = ktail <= p.max_len ? wsk[ktail] : 0.0f;
 			float tmax = VK_NEG_INF;
 			int trow = 0;
 			for (int base = base0; base < t_b; base += 16) {
-				fill(base);
+				if (FLOW && p.dp_rows) fill_dp(base);
+				else fill(base);
 				wave_lds_fence();
 				const int r0 = t_a > base ? t_a - base : 0, r1 = t_b - base < 16 ? t_b - base : 16;
 				for (int r = r0; r < r1; r++) {
@@ -478,26 +506,41 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 						// with the largest row among equal values, i.e. the smallest k, which is the one the k-ascending scan with its strict
 						// comparison keeps -- and the scan stops at ktail - 1: O(len_s ktail) per column instead of O(len_s^2)
 						const int kmax = u < ktail ? u : ktail - 1;
-						const int cv = col ? v : 1;
-						int k = 1;
-						// eight candidates at a time: their loads are issued together (one after the other, each waited for, a candidate cost
-						// a round trip to the L2 when the history lives in global memory), the comparisons stay in k order
-						for (; k + 7 <= kmax; k += 8) {
+						// The scan over k is dealt out over the lanes a short query leaves idle: with 16 (32) columns four (two) lanes share a
+						// column, lane group kg takes k = 1 + kg, 1 + kg + KG, ...; each keeps its best candidate and the smallest k that
+						// reached it, the groups are merged by value, then by k -- what the k-ascending scan with its strict comparison
+						// keeps -- and the result meets `best` once, strictly.  Eight loads are in flight per lane.
+						const int KG = LQ == 16 ? 4 : LQ == 32 ? 2 : 1;
+						const int kg = KG == 4 ? lane >> 4 : KG == 2 ? lane >> 5 : 0;
+						const int vs = (lane & (LQ - 1)) + 1;
+						const int cv = KG == 1 ? (col ? v : 1) : (vs <= len_t ? vs : 1);
+						float cb = VK_NEG_INF;
+						int ck = 0;
+						int k = 1 + kg;
+						for (; k + 7 * KG <= kmax; k += 8 * KG) {
 							float hv[8], wv[8];
 #pragma unroll
-							for (int i = 0; i < 8; i++) { hv[i] = H[(u - k - i) * W + cv]; wv[i] = wsl[k + i]; }
+							for (int i = 0; i < 8; i++) { hv[i] = Hrow(u - k - i * KG)[cv]; wv[i] = wsk[k + i * KG]; }
 #pragma unroll
 							for (int i = 0; i < 8; i++) {
 								c = hv[i] - wv[i];
-								if (c > best) { best = c; d = 2; kk = (int16_t)(k + i); }
+								if (c > cb) { cb = c; ck = k + i * KG; }
 							}
 						}
-						for (; k <= kmax; k++) {
-							c = H[(u - k) * W + cv] - wsl[k];
-							if (c > best) { best = c; d = 2; kk = (int16_t)k; }
+						for (; k <= kmax; k += KG) {
+							c = Hrow(u - k)[cv] - wsk[k];
+							if (c > cb) { cb = c; ck = k; }
 						}
+						if (KG >= 2) {
+							for (int off = 32; off >= LQ; off >>= 1) {
+								const float oc = __shfl_xor(cb, off, 64);
+								const int ok = __shfl_xor(ck, off, 64);
+								if (oc > cb || (oc == cb && ok < ck)) { cb = oc; ck = ok; }
+							}
+						}
+						if (cb > best) { best = cb; d = 2; kk = (int16_t)ck; }
 						if (u >= ktail) {
-							c = H[(u - ktail) * W + (col ? v : 1)] - wtail;
+							c = Hrow(u - ktail)[col ? v : 1] - wtail;
 							if (c >= tmax) { tmax = c; trow = u - ktail; }
 							if (tmax > best) { best = tmax; d = 2; kk = (int16_t)(u - trow); }
 						}
@@ -528,7 +571,7 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 						}
 					}
 					if (col) {
-						if (gap == 2) H[u * W + v] = best;
+						if (gap == 2) Hrow(u)[v] = best;
 						if (FLOW) {
 							dk[u * W + v] = kk;
 							flags[u * W + v] = (uint8_t)(d | (ee << 2) | (fe << 3));
@@ -606,22 +649,31 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 // Residency of the global-state form: a region of scratch per workgroup, so the grid is what the scratch allows
 static const int64_t kWideScratchCap = 4ll << 30;
 
-extern "C" size_t vk_wide_scratch_bytes(int32_t max_len, int32_t nq, int32_t gap_mode, int32_t flow) {
-	return vk_wide_scratch_bytes_impl(max_len, nq, gap_mode, flow != 0);
+extern "C" size_t vk_wide_scratch_bytes(int32_t max_len, int32_t nq, int32_t gap_mode, int32_t flow, int32_t ring) {
+	return vk_wide_scratch_bytes_impl(max_len, nq, gap_mode, flow != 0, ring);
+}
+
+// rows of the LDS ring that holds the column history of general gaps when the gap table is constant from ws_tail on: a power of
+// two above ws_tail, 0 when there is no such tail or the ring would not leave room for several workgroups per CU
+extern "C" int32_t vk_wide_ring_rows(int32_t nq, int32_t gap_mode, int32_t ws_tail) {
+	if (gap_mode != 2 || ws_tail < 1) return 0;
+	int ring = 16;
+	while (ring < ws_tail + 1) ring <<= 1;
+	return (size_t)ring * (16 * (size_t)nq + 2) * 4 <= 40 * 1024 ? ring : 0;
 }
 
 // workgroups of a global-state launch: SCORE walks the slices with a grid stride (every CU filled, within the scratch cap);
 // FLOW takes one workgroup per winner
-extern "C" int32_t vk_wide_gs_blocks(int32_t max_len, int32_t nq, int32_t gap_mode, int32_t flow_k, int64_t n_sent) {
+extern "C" int32_t vk_wide_gs_blocks(int32_t max_len, int32_t nq, int32_t gap_mode, int32_t flow_k, int64_t n_sent, int32_t ring) {
 	if (flow_k > 0) return flow_k;
-	const int64_t per = (int64_t)vk_wide_scratch_bytes_impl(max_len, nq, gap_mode, false);
-	int64_t blocks = gap_mode == 2 ? kWideScratchCap / per : 2048;
+	const int64_t per = (int64_t)vk_wide_scratch_bytes_impl(max_len, nq, gap_mode, false, ring);
+	int64_t blocks = (gap_mode == 2 && ring == 0) ? kWideScratchCap / per : 2048;
 	if (blocks > 2048) blocks = 2048;
 	if (blocks > n_sent) blocks = n_sent;
 	return (int32_t)(blocks < 1 ? 1 : blocks);
 }
 
-template <bool FLOW, bool GS>
+template <bool FLOW, int GSM>
 static hipError_t launch_wide_gap(const VkWideParams &p, int blocks, size_t smem, hipStream_t stream, bool occupancy_grid) {
 	auto go = [&](auto kernel) -> hipError_t {
 		if (smem > 64 * 1024) {
@@ -640,11 +692,12 @@ static hipError_t launch_wide_gap(const VkWideParams &p, int blocks, size_t smem
 		kernel<<<blocks, 64, smem, stream>>>(p);
 		return hipGetLastError();
 	};
-	switch (p.gap_mode) {
-	case 0: return go(vk_wide_kernel<FLOW, GS, 0>);
-	case 1: return go(vk_wide_kernel<FLOW, GS, 1>);
-	case 2: return go(vk_wide_kernel<FLOW, GS, 2>);
-	case 4: return go(vk_wide_kernel<FLOW, GS, 4>);
+	if constexpr (GSM == 2) return p.gap_mode == 2 ? go(vk_wide_kernel<FLOW, 2, 2>) : hipErrorInvalidValue;
+	else switch (p.gap_mode) {
+	case 0: return go(vk_wide_kernel<FLOW, GSM, 0>);
+	case 1: return go(vk_wide_kernel<FLOW, GSM, 1>);
+	case 2: return go(vk_wide_kernel<FLOW, GSM, 2>);
+	case 4: return go(vk_wide_kernel<FLOW, GSM, 4>);
 	default: return hipErrorInvalidValue;
 	}
 }
@@ -652,16 +705,19 @@ static hipError_t launch_wide_gap(const VkWideParams &p, int blocks, size_t smem
 extern "C" hipError_t vk_launch_wide(const VkWideParams *p, int32_t flow_k, hipStream_t stream) {
 	const bool flow = flow_k > 0;
 	const bool gs = p->scratch != nullptr;
-	const size_t smem = vk_wide_lds_bytes(p->max_len, p->nq, p->gap_mode, p->pos_s != nullptr, flow, gs);
+	const int ring = (gs && p->gap_mode == 2) ? p->h_ring : 0;
+	if (ring != 0 && (ring != vk_wide_ring_rows(p->nq, p->gap_mode, p->ws_tail) || (ring & (ring - 1)))) return hipErrorInvalidValue;
+	const size_t smem = vk_wide_lds_bytes(p->max_len, p->nq, p->gap_mode, p->pos_s != nullptr, flow, gs, ring);
 	if (smem > 160 * 1024) return hipErrorInvalidValue;
 	if (gs) {
 		// the host sized p->scratch for vk_wide_gs_blocks regions of scratch_stride bytes
-		const int blocks = vk_wide_gs_blocks(p->max_len, p->nq, p->gap_mode, flow_k, p->order ? p->n_order : p->n_sent);
-		if (p->scratch_stride < (int64_t)vk_wide_scratch_bytes_impl(p->max_len, p->nq, p->gap_mode, flow)) return hipErrorInvalidValue;
-		return flow ? launch_wide_gap<true, true>(*p, blocks, smem, stream, false) : launch_wide_gap<false, true>(*p, blocks, smem, stream, false);
+		const int blocks = vk_wide_gs_blocks(p->max_len, p->nq, p->gap_mode, flow_k, p->order ? p->n_order : p->n_sent, ring);
+		if (p->scratch_stride < (int64_t)vk_wide_scratch_bytes_impl(p->max_len, p->nq, p->gap_mode, flow, ring)) return hipErrorInvalidValue;
+		if (ring) return flow ? launch_wide_gap<true, 2>(*p, blocks, smem, stream, false) : launch_wide_gap<false, 2>(*p, blocks, smem, stream, false);
+		return flow ? launch_wide_gap<true, 1>(*p, blocks, smem, stream, false) : launch_wide_gap<false, 1>(*p, blocks, smem, stream, false);
 	}
-	if (flow) return launch_wide_gap<true, false>(*p, flow_k, smem, stream, false);
-	return launch_wide_gap<false, false>(*p, 0, smem, stream, true);
+	if (flow) return launch_wide_gap<true, 0>(*p, flow_k, smem, stream, false);
+	return launch_wide_gap<false, 0>(*p, 0, smem, stream, true);
 }
 
 extern "C" size_t vk_wide_lds_demand(int32_t max_len, int32_t nq, int32_t gap_mode, int32_t tagged, int32_t flow) {

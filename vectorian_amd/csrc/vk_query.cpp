@@ -226,17 +226,10 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		VkWrdParams w{};
 		fill_transport(w);
 		w.keys = c->d_keys[1]; w.rows_out = c->d_rows_out; w.rows_len = R;
-		if (R > VK_MAX_SENT_LEN) {   // rows of whole documents: assembled in global memory, a region per winner
-			const size_t per = vk_rows_scratch_bytes(R, w.nq), need_s = per * (size_t)cnt;
-			if (c->wide_scratch_cap < need_s) {
-				if (c->d_wide_scratch) { VK_HIP(hipFree(c->d_wide_scratch)); c->d_wide_scratch = nullptr; c->wide_scratch_cap = 0; }
-				if ((rc2 = alloc_t(c, &c->d_wide_scratch, need_s))) return rc2;
-				c->wide_scratch_cap = need_s;
-			}
-			w.scratch = c->d_wide_scratch; w.scratch_stride = (int64_t)per;
-		}
-		VK_HIP(vk_launch_rows(&w, cnt, c->stream));
-		w.scratch = nullptr; w.scratch_stride = 0;
+		if (R > VK_MAX_SENT_LEN) {   // rows of whole documents: one wave per 16 tokens of a winner (vk_canon_rows_kernel)
+			VK_HIP(hipMemsetAsync(c->d_rows_out, 0, need * 4, c->stream));
+			VK_HIP(vk_launch_canon_rows(&w, cnt, (c->max_len + 15) / 16 + 1, c->stream));
+		} else VK_HIP(vk_launch_rows(&w, cnt, c->stream));
 		VK_HIP(hipMemcpyAsync(rows_dst, c->d_rows_out, need * 4, hipMemcpyDeviceToHost, c->stream));
 		if (exact && out->plan) {
 			w.mass_mode = mass_mode; w.raw_masses = raw_masses;
@@ -423,10 +416,11 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	// vk_wide_kernel: the state of a slice in LDS where that fits, else in global memory (one region per workgroup)
 	auto wide_state = [&](int flow_k) -> int {
 		const bool flow = flow_k > 0;
-		wp.scratch = nullptr; wp.scratch_stride = 0;
+		wp.scratch = nullptr; wp.scratch_stride = 0; wp.h_ring = 0;
 		if (!xlong && vk_wide_lds_demand(c->max_len, nq, wp.gap_mode, q->tag_weights != nullptr, flow) <= 160 * 1024) return VK_OK;
-		const size_t per = vk_wide_scratch_bytes(c->max_len, nq, wp.gap_mode, flow);
-		const size_t blocks = (size_t)vk_wide_gs_blocks(c->max_len, nq, wp.gap_mode, flow_k, n);
+		wp.h_ring = vk_wide_ring_rows(nq, wp.gap_mode, wp.ws_tail);   // a saturated gap table: the column history is a ring in LDS
+		const size_t per = vk_wide_scratch_bytes(c->max_len, nq, wp.gap_mode, flow, wp.h_ring);
+		const size_t blocks = (size_t)vk_wide_gs_blocks(c->max_len, nq, wp.gap_mode, flow_k, n, wp.h_ring);
 		const size_t need = per * blocks;
 		if (need > ((size_t)16 << 30)) return fail(VK_ERR_UNSUPPORTED, "traceback state of this many slices this long exceeds 16 GiB of scratch");
 		if (c->wide_scratch_cap < need) {
@@ -777,6 +771,28 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 			wp.keys = d_keys; wp.raw_out = c->d_out_raw; wp.mapping = c->d_out_map; wp.edge_sim = c->d_out_sim;
 			int rcw = wide_state(count);
 			if (rcw) return rcw;
+			wp.dp_rows = nullptr; wp.dp_rows_len = 0;
+			if (xlong) {
+				// Long winners: their similarities (canonical arithmetic, tag weights applied) restated beforehand by one wave per 16
+				// tokens, so that the serial sweep of a winner is its recurrence alone (5,000 tokens: 8.4 -> ms of a 12 ms query were
+				// the sweep restating 313 tiles one after the other).  Within 2 GiB; else the sweep restates them itself.
+				const int R = (c->max_len + 63) / 64 * 64, Wq = 16 * nq;
+				const size_t need = (size_t)count * R * Wq;
+				if (need * 4 <= ((size_t)2 << 30)) {
+					if (c->rows_cap < need) {
+						if (c->d_rows_out) { VK_HIP(hipFree(c->d_rows_out)); VK_HIP(hipFree(c->d_plan_out)); c->d_rows_out = c->d_plan_out = nullptr; c->rows_cap = 0; }
+						if ((rcw = alloc_t(c, &c->d_rows_out, need))) return rcw;
+						if ((rcw = alloc_t(c, &c->d_plan_out, need))) return rcw;
+						c->rows_cap = need;
+					}
+					VkWrdParams w{};
+					fill_transport(w);
+					w.keys = d_keys; w.rows_out = c->d_rows_out; w.rows_len = R;
+					VK_HIP(hipMemsetAsync(c->d_rows_out, 0, need * 4, st));
+					VK_HIP(vk_launch_canon_rows(&w, count, (c->max_len + 15) / 16 + 1, st));
+					wp.dp_rows = c->d_rows_out; wp.dp_rows_len = R;
+				}
+			}
 			VK_HIP(vk_launch_wide(&wp, count, st));
 			return VK_OK;
 		}

@@ -676,19 +676,15 @@ extern "C" hipError_t vk_launch_long_bound(const VkWrdParams *p, hipStream_t str
 }
 
 // similarity rows of the winners of a transport query, for the host to state their flows: [64][16 nq] per winner
-// GS: the rows of a winner are assembled in global memory (p.scratch, (rows_len + 32) rows per winner) instead of LDS -- winners of
-// more than 512 tokens (whole documents as slices); no vocabulary fixup in this form (vk_validate_query)
-template <int NQ, bool GS>
+template <int NQ>
 __global__ __launch_bounds__(64) void vk_rows_kernel(VkWrdParams p) {
 	constexpr int N = 16 * NQ;
 	extern __shared__ double vk_smem_f64[];
 	uint8_t *canon = reinterpret_cast<uint8_t *>(vk_smem_f64);   // staging of sim_canon16 (VK_CANON_LDS bytes)
+	float *S = reinterpret_cast<float *>(canon + VK_CANON_LDS);   // [(R + 32)][N]
 	const int lane = threadIdx.x;
 	const int w = blockIdx.x;
 	const int R = p.rows_len > 0 ? p.rows_len : 64;
-	float *S;   // [(R + 32)][N]
-	if constexpr (GS) S = reinterpret_cast<float *>(p.scratch + (int64_t)w * p.scratch_stride);
-	else S = reinterpret_cast<float *>(canon + VK_CANON_LDS);
 	float *out = p.rows_out + (int64_t)w * R * N;
 	const uint64_t key = p.keys[w];
 	int m = 0, rowbase = 0;
@@ -701,12 +697,52 @@ __global__ __launch_bounds__(64) void vk_rows_kernel(VkWrdParams p) {
 		else rowbase = transport_sim_rows<NQ>(p, S, t_a, t_b, lane, canon);
 	}
 	wave_lds_fence();
-	if constexpr (GS) {   // the rows were written by other lanes, through global memory
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-		__builtin_amdgcn_wave_barrier();
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-	}
 	for (int i = lane; i < R * N; i += 64) out[i] = i / N < m ? S[rowbase * N + i] : 0.0f;
+}
+
+// The same rows for winners of any length (whole documents as slices): one wave per (winner, 16 tokens) instead of one per winner
+// -- a 5,000-token winner is 313 independent tiles, not a serial sweep -- each writing its tokens' rows where they belong (the host
+// zeroes rows_out first: rows past a winner's end stay 0).  The canonical arithmetic, sim[id(t_j)][j] = 1 and the tag-weighted
+// modifier as transport_sim_rows; no vocabulary fixup in this form (vk_validate_query refuses such queries over long slices).
+// Also the similarities the traceback kernel of long winners runs its recurrence on (vk_wide_kernel FLOW, dp_rows).
+template <int NQ>
+__global__ __launch_bounds__(64) void vk_canon_rows_kernel(VkWrdParams p) {
+	constexpr int N = 16 * NQ;
+	extern __shared__ double vk_smem_f64[];
+	uint8_t *canon = reinterpret_cast<uint8_t *>(vk_smem_f64);
+	const int lane = threadIdx.x;
+	const int w = blockIdx.y, ti = blockIdx.x;
+	const int R = p.rows_len;
+	const uint64_t key = p.keys[w];
+	if (key == 0) return;
+	const int64_t g = (int64_t)(uint32_t)(key & 0xffffffffu);
+	const int t_a = p.sent_start[g], t_b = p.sent_end[g];
+	const int m = t_b - t_a;
+	if (m < 1 || m > R) return;
+	const bool is_static = p.layout == VK_DEV_LAYOUT_STATIC;
+	const int tile0 = is_static ? 0 : t_a >> 4;
+	const int ntiles = is_static ? (m + 15) >> 4 : ((t_b + 15) >> 4) - tile0;
+	if (ti >= ntiles) return;
+	// this lane's token: row lane & 15 of the tile (static layout: the slice's own 16-token steps; past its end its first token, not written)
+	const int rel = is_static ? ti * 16 + (lane & 15) : (tile0 + ti) * 16 + (lane & 15) - t_a;   // row of the slice
+	const bool live = rel >= 0 && rel < m;
+	const int tok = is_static ? t_a + (live ? rel : 0) : (tile0 + ti) * 16 + (lane & 15);
+	const int id = is_static ? p.tok_id[tok] : 0;
+	const uint8_t *xrow = is_static ? canon_row_ptr_static(p.tiles, p.tile_bytes, id) : canon_row_ptr(p.tiles + (int64_t)(tile0 + ti) * p.tile_bytes, lane);
+	const int ps = (p.pos_s && live) ? p.pos_s[tok] : 0;
+	float *out = p.rows_out + ((int64_t)w * R + (live ? rel : 0)) * N;
+#pragma unroll 1
+	for (int b = 0; b < NQ; b++) {
+		float val[4];
+		sim_canon16(xrow, p.qtile + (int64_t)b * p.tile_bytes, p.nk32, p.tail, p.d, p.prec, canon, lane, val);
+		const int c0 = 16 * b + (lane >> 4) * 4;
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			val[r] = (is_static && p.q_ids && p.q_ids[c0 + r] == id) ? 1.0f : clip01(val[r]);
+			if (p.pos_s) val[r] = tag_weighted(val[r], p.tw[c0 + r], ps, p.tpos[c0 + r], p.tw_keep, p.tw_threshold);
+		}
+		if (live) *reinterpret_cast<float4 *>(out + c0) = make_float4(val[0], val[1], val[2], val[3]);
+	}
 }
 
 static size_t transport_lds_bytes(int nq, bool solver) {
@@ -726,22 +762,23 @@ extern "C" hipError_t vk_launch_wrd_exact(const VkWrdParams *p, int32_t n_cand, 
 	return hipGetLastError();
 }
 
-extern "C" size_t vk_rows_scratch_bytes(int32_t rows_len, int32_t nq) {
-	return (size_t)(rows_len + 32) * 16 * (size_t)(nq < 1 ? 1 : nq) * 4;
-}
-
 extern "C" hipError_t vk_launch_rows(const VkWrdParams *p, int32_t n_cand, hipStream_t stream) {
 	const int R = p->rows_len > 0 ? p->rows_len : 64;
-	const bool gs = p->scratch != nullptr;   // rows assembled in global memory (the host: winners of more than 512 tokens)
-	if (gs && p->scratch_stride < (int64_t)vk_rows_scratch_bytes(R, p->nq)) return hipErrorInvalidValue;
-	const size_t smem = VK_CANON_LDS + (gs ? 0 : (size_t)(R + 32) * 16 * (size_t)(p->nq < 1 ? 1 : p->nq) * 4);
-	void (*kernel)(VkWrdParams) = gs
-		? (p->nq <= 1 ? vk_rows_kernel<1, true> : p->nq == 2 ? vk_rows_kernel<2, true> : p->nq == 3 ? vk_rows_kernel<3, true> : vk_rows_kernel<4, true>)
-		: (p->nq <= 1 ? vk_rows_kernel<1, false> : p->nq == 2 ? vk_rows_kernel<2, false> : p->nq == 3 ? vk_rows_kernel<3, false> : vk_rows_kernel<4, false>);
+	const size_t smem = VK_CANON_LDS + (size_t)(R + 32) * 16 * (size_t)(p->nq < 1 ? 1 : p->nq) * 4;
+	void (*kernel)(VkWrdParams) = p->nq <= 1 ? vk_rows_kernel<1> : p->nq == 2 ? vk_rows_kernel<2> : p->nq == 3 ? vk_rows_kernel<3> : vk_rows_kernel<4>;
 	if (smem > 64 * 1024) {
 		const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 		if (e != hipSuccess) return e;
 	}
 	kernel<<<n_cand, 64, smem, stream>>>(*p);
+	return hipGetLastError();
+}
+
+// rows of winners of up to rows_len tokens, tile-parallel; rows_out must be zeroed by the caller (max_tiles: 16-token tiles the
+// longest slice of the corpus can touch)
+extern "C" hipError_t vk_launch_canon_rows(const VkWrdParams *p, int32_t n_cand, int32_t max_tiles, hipStream_t stream) {
+	if (n_cand < 1 || max_tiles < 1 || p->rows_len < 1) return hipErrorInvalidValue;
+	void (*kernel)(VkWrdParams) = p->nq <= 1 ? vk_canon_rows_kernel<1> : p->nq == 2 ? vk_canon_rows_kernel<2> : p->nq == 3 ? vk_canon_rows_kernel<3> : vk_canon_rows_kernel<4>;
+	kernel<<<dim3((unsigned)max_tiles, (unsigned)n_cand), 64, VK_CANON_LDS, stream>>>(*p);
 	return hipGetLastError();
 }
