@@ -27,12 +27,15 @@ def main():
 	ap.add_argument("--reps", type=int, default=5)
 	ap.add_argument("--oracle-docs", type=int, default=64, help="documents the CPU oracle scores (its time is scaled to the corpus by tokens)")
 	ap.add_argument("--strategies", default="linear,affine,wsb,rwmd")
+	ap.add_argument("--short", type=int, default=0, help="this many 32-token slices after the documents (a corpus of sentences that holds a few documents: the sentences keep their fused kernels)")
 	args = ap.parse_args()
 
 	from vectorian_amd import core, synth
 	core.init(0)
 	rng = np.random.default_rng(2345)
 	lens = rng.integers(args.min_len, args.max_len + 1, size=args.docs)
+	if args.short > 0:
+		lens = np.concatenate((lens, np.full(args.short, 32, dtype=lens.dtype)))
 	off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
 	T, d = int(off[-1]), args.d
 	V = 50000
@@ -42,7 +45,7 @@ def main():
 		b = min(T, a + (1 << 18))
 		X = E[synth.zipf_ids(b - a, V, rng)] + 0.1 * rng.standard_normal((b - a, d)).astype(np.float32)
 		Xb[a:b] = synth.to_bf16_bits(synth.normalize_rows(X))
-	c = core.Corpus(layout=core.VK_LAYOUT_CONTEXTUAL, d=d, n_tokens=T, n_sentences=args.docs)
+	c = core.Corpus(layout=core.VK_LAYOUT_CONTEXTUAL, d=d, n_tokens=T, n_sentences=len(lens))
 	c.append_vectors(Xb, normalize=False)
 	c.set_sentences(off)
 	c.finalize()
@@ -59,7 +62,7 @@ def main():
 		"wsb": dict(locality=0, gap_s=w, gap_t=w),
 		"rwmd": dict(algorithm=core.VK_ALG_RWMD, rwmd=(True, True, True)),
 	}
-	n_o = min(args.oracle_docs, args.docs)
+	n_o = min(args.oracle_docs, len(lens))
 	for name in args.strategies.split(","):
 		kw = strategies[name]
 		got = c.query(Qb, q_normalize=False, max_matches=10, **kw)   # warm-up (scratch, gap table)
@@ -70,7 +73,7 @@ def main():
 			times.append((time.perf_counter() - t0) * 1e3)
 			tm = c.last_timings()
 			score_ms.append(tm["score_ms"]); flow_ms.append(tm["flow_ms"])
-		line = {"strategy": name, "docs": args.docs, "tokens": T, "len_min": args.min_len, "len_max": args.max_len, "d": d, "len_t": args.len_t,
+		line = {"strategy": name, "docs": args.docs, "short_slices": args.short, "tokens": T, "len_min": args.min_len, "len_max": args.max_len, "d": d, "len_t": args.len_t,
 			"query_ms": round(float(np.median(times)), 3), "score_kernel_ms": round(float(np.median(score_ms)), 3), "flow_ms": round(float(np.median(flow_ms)), 3),
 			"docs_per_s": round(args.docs / (np.median(times) * 1e-3), 1), "tokens_per_s": round(T / (np.median(times) * 1e-3), 1),
 			"hbm_frac_of_8TBps": round(T * d * 2 / (np.median(score_ms) * 1e-3) / 8e12, 4), "top": [int(got.sentence[0]), float(got.score[0])], "planted": s}

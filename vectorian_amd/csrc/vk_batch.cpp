@@ -166,7 +166,7 @@ static int batch_winner_rows(vk_corpus *c, const vk_query_desc *qs, int n_querie
 // (vk_score_batch_kernel).  Returns VK_ERR_UNSUPPORTED (without setting an error) when the batch does not qualify;
 // the caller then runs the queries one by one.
 static int query_batch_shared_pass(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, vk_topk_out *outs) {
-	if (n_queries < 2 || !c->finalized || c->prec != 0 || c->desc.layout != VK_LAYOUT_CONTEXTUAL || c->n_long_groups > 0 || c->desc.n_sentences < 1) return VK_ERR_UNSUPPORTED;
+	if (n_queries < 2 || !c->finalized || c->prec != 0 || c->desc.layout != VK_LAYOUT_CONTEXTUAL || c->n_long_groups > 0 || c->max_len > VK_FAST_SENT_LEN || c->desc.n_sentences < 1) return VK_ERR_UNSUPPORTED;
 	if (c->nk32 > 10 && !getenv("VK_BATCH_QB")) return VK_ERR_UNSUPPORTED;   // measured: no gain over single queries for 768-d rows (the kernel pipelines tiles of <= 10 K-steps)
 	const vk_query_desc &q0 = qs[0];
 	if (q0.max_matches > 64) return VK_ERR_UNSUPPORTED;

@@ -107,7 +107,7 @@ int vk_corpus_view(vk_corpus_t *src, vk_corpus_t **out) {
 	c->max_len = src->max_len; c->max_group_tiles = src->max_group_tiles; c->max_group_tokens = src->max_group_tokens; c->max_pair_tiles = src->max_pair_tiles; c->max_short_pair_tiles = src->max_short_pair_tiles;
 	c->n_entries = src->n_entries; c->entry_sent = src->entry_sent;
 	c->h_start = src->h_start; c->h_end = src->h_end; c->h_tok = src->h_tok; c->h_tag = src->h_tag;
-	c->n_long_groups = src->n_long_groups; c->max_short_len = src->max_short_len;
+	c->n_long_groups = src->n_long_groups; c->max_short_len = src->max_short_len; c->max_long_len = src->max_long_len; c->h_xlong = src->h_xlong;
 	c->long_group_tiles = src->long_group_tiles; c->long_group_tokens = src->long_group_tokens;
 	c->uniform_len = src->uniform_len;
 	c->is_view = true;
@@ -151,7 +151,7 @@ int vk_corpus_free(vk_corpus_t *c) {
 		c->d_sent_start = c->d_sent_end = nullptr, c->d_long_groups = nullptr;
 	if (c->shares_vectors) c->d_tiles = nullptr, c->d_mag = nullptr;
 	void *ptrs[] = {c->d_tiles, c->d_mag, c->d_tok_id, c->d_pos, c->d_tag, c->d_sent_start, c->d_sent_end, c->d_stage, c->d_qtile, c->d_ws, c->d_wt, c->d_qids,
-		c->d_table, c->d_scores, c->d_raw, c->d_boost, c->d_keys[0], c->d_keys[1], c->d_out_raw, c->d_out_sim, c->d_out_map, c->d_wrd_raw, c->d_wrd_val, c->d_bq, c->d_bqlen, c->d_bscores, c->d_bkeys[0], c->d_bkeys[1], c->d_long_groups, c->d_counter, c->d_rows_out, c->d_plan_out, c->d_braw, c->d_wrdl_scratch, c->d_wide_scratch, c->d_wide_order, c->d_bqt, c->d_bcand, c->d_bcandq, c->d_brows, c->d_qbits};
+		c->d_table, c->d_scores, c->d_raw, c->d_boost, c->d_keys[0], c->d_keys[1], c->d_out_raw, c->d_out_sim, c->d_out_map, c->d_wrd_raw, c->d_wrd_val, c->d_bq, c->d_bqlen, c->d_bscores, c->d_bkeys[0], c->d_bkeys[1], c->d_long_groups, c->d_counter, c->d_rows_out, c->d_plan_out, c->d_braw, c->d_wrdl_scratch, c->d_wide_scratch, c->d_wide_order, c->d_xlong_order, c->d_bqt, c->d_bcand, c->d_bcandq, c->d_brows, c->d_qbits};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	if (c->h_brows) (void)hipHostFree(c->h_brows);
 	for (auto &b : c->bl) for (void *p : {(void *)b.tiles, (void *)b.len, (void *)b.id}) if (p) (void)hipFree(p);
@@ -252,7 +252,7 @@ int vk_corpus_set_token_tags(vk_corpus_t *c, const int8_t *tags, int64_t n, int3
 }
 
 static int set_slices_impl(vk_corpus_t *c, const int64_t *start, const int64_t *end, int64_t n_sentences, bool contiguous) {
-	int max_len = 0, max_short = 0;
+	int max_len = 0, max_short = 0, max_long = 0;
 	int64_t n_long = 0;
 	for (int64_t s = 0; s < n_sentences; s++) {
 		const int64_t len = end[s] - start[s];
@@ -266,13 +266,17 @@ static int set_slices_impl(vk_corpus_t *c, const int64_t *start, const int64_t *
 		max_len = std::max(max_len, (int)len);
 		if (len > VK_FAST_SENT_LEN) n_long++;
 		else max_short = std::max(max_short, (int)len);
+		if (len > VK_FAST_SENT_LEN && len <= VK_MAX_SENT_LEN) max_long = std::max(max_long, (int)len);
 	}
 	VK_HIP(hipSetDevice(c->device));
 
 	// ---- the slice table.  Without long slices it is the caller's table.  A long slice gets a group of 4 rows
 	// of its own ([L, empty, empty, empty]); the group before it is closed with empty rows, so that no group of
 	// the main launch spans the tokens of a long slice.  Rows stay in slice order (ties are broken by row).
-	std::vector<int32_t> st32, en32, long_groups;
+	// apart_groups: every group that holds a slice of more than 64 tokens; long_groups: those of them the long pass takes (65 .. 512
+	// tokens, LDS strips); the slices beyond (whole documents) are left to the one-wave-per-slice kernel (xlong_entries: their rows)
+	std::vector<int32_t> st32, en32, long_groups, apart_groups;
+	auto xlong_entries = std::make_shared<std::vector<int32_t>>();
 	c->entry_sent.clear(); c->sent_entry.clear();
 	if (n_long == 0) {
 		st32.resize((size_t)n_sentences); en32.resize((size_t)n_sentences);
@@ -283,7 +287,11 @@ static int set_slices_impl(vk_corpus_t *c, const int64_t *start, const int64_t *
 		for (int64_t s = 0; s < n_sentences; s++) {
 			if (end[s] - start[s] > VK_FAST_SENT_LEN) {
 				while (st32.size() % 4) push(en32.back(), en32.back(), -1);
-				long_groups.push_back((int32_t)(st32.size() / 4));
+				apart_groups.push_back((int32_t)(st32.size() / 4));
+				if (end[s] - start[s] > VK_MAX_SENT_LEN) {
+					// (the four rows of its group: no other pass writes the scores of the three empty ones)
+					for (int i = 0; i < 4; i++) xlong_entries->push_back((int32_t)st32.size() + i);
+				} else long_groups.push_back((int32_t)(st32.size() / 4));
 				push((int32_t)start[s], (int32_t)end[s], (int32_t)s);
 				for (int i = 0; i < 3; i++) push((int32_t)end[s], (int32_t)end[s], -1);
 			} else {
@@ -318,10 +326,13 @@ static int set_slices_impl(vk_corpus_t *c, const int64_t *start, const int64_t *
 	c->h_end = std::make_shared<std::vector<int32_t>>(en32);
 	c->n_entries = n_entries;
 	if (c->d_wide_order) { VK_HIP(hipFree(c->d_wide_order)); c->d_wide_order = nullptr; }
-	c->n_wide_order = -1;   // the work list of the one-wave-per-slice pass follows the table
+	if (c->d_xlong_order) { VK_HIP(hipFree(c->d_xlong_order)); c->d_xlong_order = nullptr; }
+	c->n_wide_order = c->n_xlong_order = -1;   // the work list of the one-wave-per-slice pass follows the table
 	c->n_long_groups = (int)long_groups.size();
 	c->max_len = max_len;
 	c->max_short_len = max_short;
+	c->max_long_len = max_long;
+	c->h_xlong = xlong_entries;
 	c->contiguous = contiguous;
 	c->overlapping = false;
 	for (int64_t s = 1; s < n_sentences && !c->overlapping; s++) c->overlapping = start[s] < end[s - 1] && end[s] > start[s];
@@ -338,10 +349,12 @@ static int set_slices_impl(vk_corpus_t *c, const int64_t *start, const int64_t *
 	for (int64_t g = 0; g * 4 < n_entries; g++) {
 		const int64_t a = st32[(size_t)(g * 4)], b = en32[(size_t)std::min<int64_t>(g * 4 + 3, n_entries - 1)];
 		const int tiles = (int)(((b + 15) >> 4) - (a >> 4));
-		if (li < long_groups.size() && long_groups[li] == g) {
+		if (li < apart_groups.size() && apart_groups[li] == g) {
 			li++;
-			lt = std::max(lt, tiles);
-			ltok = std::max(ltok, (int)(b - a));
+			if (b - a <= VK_MAX_SENT_LEN) {   // (a group apart holds one slice: its tokens are the slice's)
+				lt = std::max(lt, tiles);
+				ltok = std::max(ltok, (int)(b - a));
+			}
 		} else {
 			mt = std::max(mt, tiles);
 			mtok = std::max(mtok, (int)(b - a));
@@ -353,8 +366,8 @@ static int set_slices_impl(vk_corpus_t *c, const int64_t *start, const int64_t *
 		const int64_t a = st32[(size_t)(g * 2)], b = en32[(size_t)std::min<int64_t>(g * 2 + 1, n_entries - 1)];
 		const int tiles = (int)(((b + 15) >> 4) - (a >> 4));
 		pt = std::max(pt, tiles);
-		while (li < long_groups.size() && long_groups[li] < g / 2) li++;
-		if (!(li < long_groups.size() && long_groups[li] == g / 2)) spt = std::max(spt, tiles);
+		while (li < apart_groups.size() && apart_groups[li] < g / 2) li++;
+		if (!(li < apart_groups.size() && apart_groups[li] == g / 2)) spt = std::max(spt, tiles);
 	}
 	c->max_pair_tiles = pt;
 	c->max_short_pair_tiles = spt;

@@ -254,8 +254,11 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	VK_HIP(hipEventRecord(c->ev[0], st));
 	std::vector<uint8_t> qtile;
 	float qmags[VK_MAX_QUERY_LEN] = {0};
-	const bool xlong = c->max_len > VK_MAX_SENT_LEN;   // whole documents as slices: every slice through the one-wave-per-slice kernel
-	const bool wide = q->len_t > VK_FAST_QUERY_LEN || xlong;
+	// whole documents as slices (beyond VK_MAX_SENT_LEN tokens): scored by the one-wave-per-slice kernel, every winner retraced by it;
+	// the other slices of such a corpus keep their fused kernels when the query has at most 16 tokens (wide_score false)
+	const bool xlong = c->max_len > VK_MAX_SENT_LEN;
+	const bool wide_score = q->len_t > VK_FAST_QUERY_LEN;
+	const bool wide = wide_score || xlong;
 	const int nq = (q->len_t + 15) / 16;
 	vk_pack_query(c, q, qtile, qmags);
 	VK_HIP(hipMemcpyAsync(c->d_qtile, qtile.data(), qtile.size(), hipMemcpyHostToDevice, st));
@@ -337,7 +340,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	for (int k = 2; k <= q->len_t && k < 80; k++)
 		for (int a = 1; a < k; a++) wt[80 + k] = std::min(wt[80 + k], wt[80 + a] + wt[80 + k - a]);
 	if (p.gap_mode == 2) {
-		if (!wide) p.gap_mode = c->max_short_len <= 32 ? 3 : 6;
+		if (!wide_score) p.gap_mode = c->max_short_len <= 32 ? 3 : 6;
 		wide_sub = wide;
 	}
 	VK_HIP(hipMemcpyAsync(c->d_ws, ws.data(), n_ws * sizeof(float), hipMemcpyHostToDevice, st));
@@ -432,19 +435,25 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		wp.scratch = c->d_wide_scratch; wp.scratch_stride = (int64_t)per;
 		if (!flow && xlong) {
 			// the scoring pass takes one wave per slice: the non-empty rows of the slice table, longest first; the others carry no score
-			if (c->n_wide_order < 0) {
+			// (a query of at most 16 tokens: only the slices beyond VK_MAX_SENT_LEN -- the fused kernels have scored the others)
+			int32_t *&d_ord = wide_score ? c->d_wide_order : c->d_xlong_order;
+			int32_t &n_ord = wide_score ? c->n_wide_order : c->n_xlong_order;
+			if (n_ord < 0) {
 				std::vector<int32_t> ord;
-				for (int64_t e = 0; e < n; e++) if ((*c->h_end)[(size_t)e] > (*c->h_start)[(size_t)e]) ord.push_back((int32_t)e);
+				if (wide_score) { for (int64_t e = 0; e < n; e++) if ((*c->h_end)[(size_t)e] > (*c->h_start)[(size_t)e]) ord.push_back((int32_t)e); }
+				else if (c->h_xlong) ord = *c->h_xlong;
 				std::stable_sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) {
 					return (*c->h_end)[(size_t)a] - (*c->h_start)[(size_t)a] > (*c->h_end)[(size_t)b] - (*c->h_start)[(size_t)b]; });
 				int rcw;
-				if ((rcw = alloc_t(c, &c->d_wide_order, ord.size() + 1))) return rcw;
-				VK_HIP(hipMemcpy(c->d_wide_order, ord.data(), ord.size() * 4, hipMemcpyHostToDevice));
-				c->n_wide_order = (int32_t)ord.size();
+				if ((rcw = alloc_t(c, &d_ord, ord.size() + 1))) return rcw;
+				VK_HIP(hipMemcpy(d_ord, ord.data(), ord.size() * 4, hipMemcpyHostToDevice));
+				n_ord = (int32_t)ord.size();
 			}
-			wp.order = c->d_wide_order; wp.n_order = c->n_wide_order;
-			VK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->d_scores), (int)0xff800000u, (size_t)n, st));
-			if (wp.raw) VK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(wp.raw), (int)0xff800000u, (size_t)n, st));
+			wp.order = d_ord; wp.n_order = n_ord;
+			if (wide_score) {
+				VK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->d_scores), (int)0xff800000u, (size_t)n, st));
+				if (wp.raw) VK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(wp.raw), (int)0xff800000u, (size_t)n, st));
+			}
 		}
 		return VK_OK;
 	};
@@ -452,11 +461,12 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		wp.tiles = c->d_tiles; wp.tok_id = c->d_tok_id; wp.table = c->d_table; wp.table_stride = table_stride;
 		wp.sent_start = c->d_sent_start; wp.sent_end = c->d_sent_end; wp.n_sent = (int32_t)n; wp.layout = p.layout;
 		wp.nk32 = c->nk32; wp.tail = c->tail; wp.tile_bytes = c->tile_bytes; wp.prec = c->prec;
-		wp.qtile = c->d_qtile; wp.nq = nq; wp.len_t = q->len_t; wp.locality = q->locality; wp.gap_mode = p.gap_mode; wp.max_len = c->max_len;
+		wp.qtile = c->d_qtile; wp.nq = nq; wp.len_t = q->len_t; wp.locality = q->locality; wp.max_len = c->max_len;
+		wp.gap_mode = (p.gap_mode == 3 || p.gap_mode == 6) ? 2 : p.gap_mode;   // (the fused kernels' register-history forms of general gaps)
 		wp.rwmd_symmetric = p.rwmd_symmetric; wp.rwmd_normalize_bow = p.rwmd_normalize_bow;
 		wp.gs = p.gs; wp.gt = p.gt; wp.a_s = p.a_s; wp.a_t = p.a_t; wp.open_s = p.open_s; wp.open_t = p.open_t;
 		wp.ws = c->d_ws; wp.wt = c->d_wt; wp.wt0 = c->d_wt;
-		if (p.gap_mode == 2 && c->max_len >= 2) {   // the constant tail of w_s (a saturated table): from which k on
+		if (wp.gap_mode == 2 && c->max_len >= 2) {   // the constant tail of w_s (a saturated table): from which k on
 			int kt = c->max_len;
 			while (kt > 1 && ws[(size_t)kt - 1] == ws[(size_t)c->max_len]) kt--;
 			if (kt < c->max_len) wp.ws_tail = kt;
@@ -473,6 +483,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 			const bool exact_tr2 = q->algorithm == VK_ALG_WRD || (q->algorithm == VK_ALG_RWMD && q->wmd_full);
 			if (((is_align && q->want_flow) || exact_tr2) && !(q->submatch_weight > 0.0f) && !getenv("VK_KEEP_RAW")) wp.raw = nullptr;
 		}
+		if (wide_score) {
 		// 17..32 tokens with linear / affine gaps over a bf16 contextual corpus of short slices: the fused two-block kernel
 		// (affine: the prefix-scan form of F needs open_t >= extend_t, as dp_affine)
 		// (33..64 tokens: one slice per wave and four column blocks)
@@ -517,6 +528,9 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 			if ((rc = wide_state(0))) return rc;
 			VK_HIP(vk_launch_wide(&wp, 0, st));
 		}
+		}
+	}
+	if (wide_score) {
 	} else if (is_align && !is_static && q->len_t == 1 && c->uniform_len == 1 && q->locality == VK_LOCAL && !p.pos_s) {
 		// span-embedding index: one vector per slice, one query vector -> the clipped cosine is the local alignment score.
 		// The aligner scores are written only if something reads them: the traceback kernel restates those of the winners, and
@@ -572,13 +586,18 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		pl.s_rows_per_wave = is_static ? (c->long_group_tokens + 15) / 16 * 16 : c->long_group_tiles * 16;
 		pl.h_rows = 0;
 		int lf = pl.s_rows_per_wave * lt + 16;
-		if (pl.gap_mode == 2) lf += (c->max_len + 1) * 16;
+		if (pl.gap_mode == 2) lf += (c->max_long_len + 1) * 16;
 		pl.m_rows = 0;
-		if (pl.gap_mode == 7) lf += (c->max_len + 4) / 4 * 4;
+		if (pl.gap_mode == 7) lf += (c->max_long_len + 4) / 4 * 4;
 		pl.lds_floats_per_wave = lf;
 		const size_t smem_l = (size_t)lf * 4 + qlds + (size_t)pl.q_lds;
 		if (smem_l > 160 * 1024) return fail(VK_ERR_UNSUPPORTED, "LDS demand of the long-slice pass exceeds 160 KiB");
 		VK_HIP(vk_launch_score(&pl, c->n_long_groups, smem_l, st));
+	}
+	if (xlong && !only) {
+		// slices beyond VK_MAX_SENT_LEN (whole documents): one wave per slice, state in global memory, longest first
+		if ((rc = wide_state(0))) return rc;
+		if (wp.n_order > 0) VK_HIP(vk_launch_wide(&wp, 0, st));
 	}
 	}
 
