@@ -151,7 +151,7 @@ typedef struct {
 	 * handle, n_only <= min(VK_MAX_MATCHES, capacity); NULL: off) makes vk_query skip the scoring pass and the selection and
 	 * state exactly these slices instead, in the given order: score, raw_score, mapping and edge_sim from the traceback kernel
 	 * (canonical arithmetic), sim_rows when the array is given; no min_score admission, n_out = n_only.  VK_ALG_ALIGN with
-	 * want_flow and submatch_weight = 0; since ABI 10 also the relaxed WMD (VK_ALG_RWMD without wmd_full) with sim_rows: score /
+	 * want_flow (ABI 11: any submatch_weight -- the score of a listed slice rests on its own traceback); since ABI 10 also the relaxed WMD (VK_ALG_RWMD without wmd_full) with sim_rows: score /
 	 * raw_score restated on the host from the rows (NaN for a slice longer than rows_per_winner, -inf for an empty one); and the
 	 * exact transports (VK_ALG_WRD, wmd_full): every listed slice solved, no bound pass, sim_rows and plan filled when given.
 	 * A caller walks the corpus in chunks with it (Index: debug = AllSlices(hook)). */

@@ -94,6 +94,28 @@ def test_debug_hook_for_every_slice_on_hip_equals_oracle_double(hip):
 			assert (a["similarity"] == b["similarity"]).all()
 
 
+def test_debug_hook_for_every_slice_under_a_submatch_weight(hip):
+	"""AllSlices(hook) with submatch_weight != 0 (round 3 fell back to the winners): the listed slices are stated from their own
+	tracebacks, whatever the weight; the result set itself comes out of the candidate rounds as before"""
+	from vectorian_amd.index import AllSlices
+	session, emb, words, rng = toy_session(n_docs=3, sents_per_doc=40, V=500, d=100)
+	sim = OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), alignment.LocalAlignment(gap=alignment.smooth_gap_cost(5)))
+	doc = session.documents[1]
+	st = doc.spans["sentence"]["start"][9]
+	text = " ".join(doc.tokens[st:st + 7])
+	calls, results = {}, {}
+	for name, factory in (("gpu", None), ("cpu", OracleCorpus)):
+		index = session.partition("sentence").index(sim, corpus_factory=factory)
+		got = calls.setdefault(name, [])
+		results[name] = index.find(text, n=4, options={"submatch_weight": 1.5, "debug": AllSlices(lambda n_, d_, got=got: got.append((n_, d_)), chunk=50)})
+		index.close()
+	assert len(calls["gpu"]) == len(calls["cpu"]) == 120
+	for (na, a), (nb, b) in zip(calls["gpu"], calls["cpu"]):
+		assert na == nb == "alignment" and a["slice"] == b["slice"] and a["score"] == b["score"]
+		assert (a["flow"]["target"] == b["flow"]["target"]).all() and (a["similarity"] == b["similarity"]).all()
+	assert [(m.doc_index, m.slice_id, m.score) for m in results["gpu"]] == [(m.doc_index, m.slice_id, m.score) for m in results["cpu"]]
+
+
 def test_span_embedding_index_on_hip(hip):
 	from test_host_api import Document, Session
 	from vectorian_amd.sim import EmbeddedSpanSim, SpanEmbedding

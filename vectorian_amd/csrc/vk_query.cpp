@@ -62,8 +62,10 @@ int vk_validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_topk_
 		if (q->n_only < 1 || q->n_only > VK_MAX_MATCHES || q->n_only > out->capacity) return fail(VK_ERR_INVALID, "only_slices: n_only out of range (1 .. min(VK_MAX_MATCHES, capacity))");
 		const bool relaxed = q->algorithm == VK_ALG_RWMD && !q->wmd_full && out->sim_rows != nullptr;   // restated on the host from the rows
 		const bool exact = q->algorithm == VK_ALG_WRD || (q->algorithm == VK_ALG_RWMD && q->wmd_full);  // every listed slice solved
-		if (!(q->algorithm == VK_ALG_ALIGN || relaxed || exact) || !q->want_flow || q->submatch_weight != 0.0f)
-			return fail(VK_ERR_UNSUPPORTED, "only_slices states alignments, relaxed WMD with sim_rows, or exact transports, with want_flow and submatch_weight = 0");
+		// (a submatch weight: alignments only -- the score of a listed slice is its aligner score over the reference score of its own
+		// traceback, metric/alignment.h:84-106, no candidate rounds; the transports' reference score does not depend on it)
+		if (!(q->algorithm == VK_ALG_ALIGN || relaxed || exact) || !q->want_flow || (q->submatch_weight != 0.0f && q->algorithm != VK_ALG_ALIGN))
+			return fail(VK_ERR_UNSUPPORTED, "only_slices states alignments, relaxed WMD with sim_rows, or exact transports, with want_flow (and submatch_weight = 0 for the transports)");
 		for (int i = 0; i < q->n_only; i++)
 			if (q->only_slices[i] < 0 || q->only_slices[i] >= c->desc.n_sentences) return fail(VK_ERR_INVALID, "only_slices: slice index out of range");
 	}
@@ -831,7 +833,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		return VK_OK;
 	};
 
-	if (is_align && q->submatch_weight != 0.0f) {
+	if (is_align && q->submatch_weight != 0.0f && !only) {
 		// ---- submatch_weight: bound from raw, then exact scores of the candidates from their tracebacks, until the
 		// k-th best exact score is above every remaining bound (vk_submatch_bound_kernel)
 		VK_HIP(hipEventRecord(c->ev[2], st));
@@ -1014,7 +1016,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 			float matched = 0.0f;
 			for (int j = 0; j < q->len_t; j++)
 				if (map[(size_t)i * ostride + j] >= 0) matched += q->tag_weights ? q->tag_weights[j] : 1.0f;
-			const float uw = powf((total - matched) / total, 0.0f);
+			const float uw = powf((total - matched) / total, only ? q->submatch_weight : 0.0f);   // (searches with a submatch weight take the candidate rounds above)
 			const float ref = matched + uw * (total - matched);
 			const int64_t row = (int64_t)(uint32_t)(keys[(size_t)i] & 0xffffffffu);
 			const float boost = q->boost ? q->boost[sentence_of(row)] : 1.0f;

@@ -1123,8 +1123,8 @@ class HipBruteForceIndex(Index):
 		('alignment/word-movers-distance/make': score, worst_score; :600-607): the score of every slice restated from its canonical
 		similarity rows (only_slices again: the reference's floats), with the worst score of a result set filled in slice order as
 		upstream fills it.  Exact transports: every slice solved, the solver's hook per slice (tokens, masses, distance matrix, plan,
-		cost).  Opt-in and slow (a Python call per slice); a sharded index walks its own slices on every rank.  With a submatch weight:
-		the winners (as without AllSlices)."""
+		cost).  Opt-in and slow (a Python call per slice); a sharded index walks its own slices on every rank.  A submatch weight does
+		not change what the hook of an alignment is handed (the aligner's score, not Score::value)."""
 		args, p_query, corpus = local["args"], local["p_query"], local["corpus"]
 		alg = args.get("algorithm", core.VK_ALG_ALIGN)
 		n_loc, off, len_t = self._n_local, self._slice_off, len(p_query)
@@ -1182,7 +1182,7 @@ class HipBruteForceIndex(Index):
 						if m.score > worst:
 							heapq.heappush(heap, m.score) if len(heap) < k else heapq.heapreplace(heap, m.score)
 			return
-		if alg != core.VK_ALG_ALIGN or args.get("submatch_weight", 0.0) != 0.0:
+		if alg != core.VK_ALG_ALIGN:
 			return self._call_debug_hook(hook, p_query, local["top"], matches, args)
 		call = dict(local["call"], want_rows=True)
 		masks = local["masks"]
