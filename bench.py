@@ -64,15 +64,20 @@ WORKLOADS = {
 	# several queries with the same options in one call (Index.find_many / vk_query_batch): every token tile is read once per PAIR of
 	# queries (vk_score_batch_kernel), so the pairs per second are not bound by |s| d 2 bytes per pair
 	"2shared": dict(name="config2_shared_pass", n_sent=1000000, min_len=32, max_len=32, d=300, alg="align", locality="local", gap="exp5", prec="bf16", batch=8, per_pass=2),
+	# whole documents as slices (session.partition("document")): one wave per document, its state in global memory
+	"docs": dict(name="documents_wsb", n_sent=2000, min_n=2000, min_len=500, max_len=5000, d=300, alg="align", locality="local", gap="exp5", prec="bf16",
+		kernel="vk_wide_kernel (one wave per document)", rate_frac=0.03),
+	"docslin": dict(name="documents_linear", n_sent=2000, min_n=2000, min_len=500, max_len=5000, d=300, alg="align", locality="local", gap="linear", prec="bf16",
+		kernel="vk_wide_kernel (one wave per document)", rate_frac=0.1),
 	"2static": dict(name="config2_static", n_sent=4000000, min_len=32, max_len=32, d=300, alg="align", locality="local", gap="exp5", prec="bf16", layout="static"),
 }
 LOCALITIES = {"local": 0, "global": 1, "semiglobal": 2}
 
 
-def gap_spec(name):
+def gap_spec(name, max_len=64):
 	if name == "linear":
 		return 0.1, 0.1, "linear gap u=0.1"
-	w = (1 - 2.0 ** (-np.arange(0, 65) / 5)).astype(np.float32)   # smooth_gap_cost(5)
+	w = (1 - 2.0 ** (-np.arange(0, max(64, max_len) + 1) / 5)).astype(np.float32)   # smooth_gap_cost(5), up to the longest slice
 	return ("table", w), ("table", w), "general gap w(k)=1-2^(-k/5) (Waterman-Smith-Beyer)"
 
 
@@ -220,7 +225,7 @@ def cpu_baseline(spec, budget_s=10.0):
 	Xb = synth.to_bf16_bits(Xn)
 	qraw = synth.make_queries(corpus, 16, LEN_T)
 	qs = [synth.to_bf16_bits(synth.normalize_rows(q["vectors"])) for q in qraw]
-	gs, gt, _ = gap_spec(spec["gap"])
+	gs, gt, _ = gap_spec(spec["gap"], spec["max_len"])
 	alg = {"align": vo.ALG_ALIGN, "rwmd": vo.ALG_RWMD, "wrd": vo.ALG_WRD}[spec["alg"]]
 	kw = dict(layout=vo.LAYOUT_CONTEXTUAL, d=d, sent_off=corpus["sent_off"], X=Xb, algorithm=alg, locality=LOCALITIES[spec["locality"]],
 		gap_s=gs, gap_t=gt, max_matches=K_MATCHES, min_score=0.0, n_threads=cores)
@@ -288,7 +293,7 @@ class Runner:
 		self.gather_depth = int(os.environ.get("VK_BENCH_GATHER_DEPTH", "1"))   # a collective gets this many further exchanges to complete before anyone waits for it
 		self.submitted = 0
 		self.score_ms, self.phases, self.retired_at, self.median_gap_ms = [], [], [], None
-		gs, gt, _ = gap_spec(gap_name or spec["gap"])
+		gs, gt, _ = gap_spec(gap_name or spec["gap"], spec["max_len"])
 		alg = {"align": core.VK_ALG_ALIGN, "rwmd": core.VK_ALG_RWMD, "wrd": core.VK_ALG_WRD}[spec["alg"]]
 		self.options = dict(algorithm=alg, locality=LOCALITIES[locality or spec["locality"]], gap_s=gs, gap_t=gt, q_normalize=True,
 			max_matches=K_MATCHES, min_score=0.0, want_flow=spec["alg"] == "align")
@@ -409,7 +414,7 @@ def roofline_of(spec, n_sent, n_tok, kern_s):
 	nbytes = n_tok * d * (4 if spec["prec"] == "f32" else 2) + (4 * n_tok if spec["alg"] == "wrd" else 0)
 	ach = nbytes / kern_s
 	return {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
-		"kernel": "vk_score_kernel" + (" (WRD bound pass)" if spec["alg"] == "wrd" else ""), "kernel_ms": kern_s * 1e3,
+		"kernel": spec.get("kernel") or ("vk_score_kernel" + (" (WRD bound pass)" if spec["alg"] == "wrd" else "")), "kernel_ms": kern_s * 1e3,
 		"algorithmic_bytes_per_launch": nbytes}
 
 
@@ -441,7 +446,7 @@ def main():
 	ap.add_argument("--no-cpu-baseline", action="store_true")
 	ap.add_argument("--no-pipeline", action="store_true", help="one handle, one query at a time")
 	ap.add_argument("--no-extra", action="store_true", help="headline workload only (no \"configs\" object)")
-	ap.add_argument("--extra", default="4,3,2f32,2static,2shared,5,5wrd,5rwmd", help="the other configurations timed at N = 1 after the headline")
+	ap.add_argument("--extra", default="4,3,2f32,2static,2shared,5,5wrd,5rwmd,docs,docslin", help="the other configurations timed at N = 1 after the headline")
 	ap.add_argument("--extra-steps", type=int, default=12)
 	ap.add_argument("--extra-warmup", type=int, default=4)
 	ap.add_argument("--extra-min-ms", type=float, default=300.0, help="the extra configurations run at least this long inside their timed region")
@@ -591,7 +596,7 @@ def main():
 		E = keep["shard"][1]
 		rq = np.random.default_rng(777)
 		qv = np.ascontiguousarray(E[rq.integers(0, VOCAB, size=LEN_T)] + 0.05 * rq.standard_normal((LEN_T, spec["d"])).astype(np.float32), dtype=np.float32)
-		gs_, gt_, _ = gap_spec(spec["gap"])
+		gs_, gt_, _ = gap_spec(spec["gap"], spec["max_len"])
 		opts = dict(algorithm=core.VK_ALG_ALIGN, locality=LOCALITIES[spec["locality"]], gap_s=gs_, gap_t=gt_, q_normalize=True,
 			max_matches=K_MATCHES, min_score=0.0 if spec["locality"] == "local" else -1e9, want_flow=True)
 		local = corpus.query(qv, **opts)
@@ -656,7 +661,7 @@ def main():
 		configs = {}
 		for key in [k for k in args.extra.split(",") if k and k in WORKLOADS and k != args.config]:
 			w = WORKLOADS[key]
-			n_x = max(4096, int(w["n_sent"] * args.extra_scale))
+			n_x = max(w.get("min_n", 4096), int(w["n_sent"] * args.extra_scale))
 			# a timed region of a few steps of 3.5 ms is at the mercy of whatever the previous configuration left running in the
 			# driver (freed corpora: the static layout once showed 9 ms per step over 12 steps, 3.44 over 60): at least
 			# --extra-min-ms of timed steps, a third of that as warm-up
@@ -668,7 +673,7 @@ def main():
 			elif w.get("layout") == "static":
 				est_ms = n_x * avg_len * LEN_T / 370e9 * 1e3
 			else:
-				est_ms = n_x * avg_len * w["d"] * (4 if w["prec"] == "f32" else 2) / (0.8 * HBM_PEAK) * 1e3
+				est_ms = n_x * avg_len * w["d"] * (4 if w["prec"] == "f32" else 2) / (w.get("rate_frac", 0.8) * HBM_PEAK) * 1e3
 			x_steps = max(args.extra_steps, int(np.ceil(args.extra_min_ms / est_ms)))
 			x_warmup = max(args.extra_warmup, int(np.ceil(args.extra_min_ms / 3 / est_ms)))
 			try:
