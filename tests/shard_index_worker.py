@@ -28,6 +28,28 @@ def build(shard, strategy="align"):
 	return index, queries
 
 
+def documents_answers(shard):
+	"""session.partition("document"): whole documents of ~ 650 tokens as the slices of a (sharded) index -- alignments and the relaxed
+	WMD, whose winners' similarity rows (sized by the longest document) travel in the rows exchange"""
+	from fake_backend import OracleCorpus
+	from test_host_api import toy_session
+	from vectorian_amd import alignment
+	from vectorian_amd.sim import CosineSim, EmbeddingTokenSim, OptimizedSpanSim
+	session, emb, words, rng = toy_session(n_docs=7, sents_per_doc=30, V=400, d=32)
+	out = {}
+	for strategy in ("align", "rwmd"):
+		optimizer = {"align": alignment.LocalAlignment(gap=alignment.smooth_gap_cost(5)), "rwmd": alignment.WordMoversDistance.rwmd("nbow")}[strategy]
+		sim = OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), optimizer)
+		index = session.partition("document").index(sim, corpus_factory=OracleCorpus, shard=shard)
+		queries = []
+		for di, si in ((1, 3), (4, 20), (6, 29)):
+			doc = session.documents[di]
+			st = doc.spans["sentence"]["start"][si]
+			queries.append(" ".join(doc.tokens[st:st + 6]))
+		out[strategy] = [summary(r) for r in (index.find(q, n=4) for q in queries)]
+	return out
+
+
 def answers(index, queries):
 	out = []
 	for q in queries:
@@ -127,6 +149,7 @@ def main(outdir):
 		res[strategy] = answers(index, queries)
 	res["find_many"] = find_many_answers((rank, world))
 	res["abort"] = abort_answers((rank, world))
+	res["documents"] = documents_answers((rank, world))
 	with open(os.path.join(outdir, f"index_rank{rank}.json"), "w") as f:
 		json.dump(res, f)
 	dist.barrier()

@@ -105,6 +105,9 @@ def test_sharded_index(tmp_path):
 		assert ref["find_many"][strategy + "_pipelined"] == ref["find_many"][strategy][:9]
 		assert ref["find_many"][strategy + "_progress"][-1] == 1.0
 	assert ref["find_many"]["rwmd"][0][0][3] == "sparse"
+	# whole documents as slices (longer than VK_MAX_SENT_LEN): the planted document wins on every rank, rows of the merged winners included
+	ref["documents"] = shard_index_worker.documents_answers(None)
+	assert [rows[0][:2] for rows in ref["documents"]["align"]] == [[1, 0], [4, 0], [6, 0]] and ref["documents"]["rwmd"][0][0][3] == "sparse"
 	for k in range(2):
 		got = json.load(open(tmp_path / f"index_rank{k}.json"))
 		# Query.abort raised on rank 1 only: no rank hangs in the collective, and the query yields no matches on either rank
