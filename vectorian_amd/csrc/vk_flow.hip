@@ -382,7 +382,30 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 				}
 				return;
 			}
-			if (is_static) {
+			if (is_static && !vmask) {
+				// 16 tokens at once: lane -> token lane >> 2, four query columns 4 (lane & 3) .. + 3 of each 16-column table (one id
+				// load and one 16-byte row load per lane and table, all in flight together; token by token the two dependent loads of
+				// each cost a round trip to the L2, sixteen times per tile)
+				const int r = lane >> 2, c4 = (lane & 3) * 4;
+				const int tok = base + r;
+				if (tok < t_b) {
+					const int id = p.tok_id[tok];
+					const int ps = p.pos_s ? p.pos_s[tok] : 0;
+					for (int qt = 0; qt < p.nq; qt++) {
+						const float4 sv = *reinterpret_cast<const float4 *>(p.table + (int64_t)qt * p.table_stride + (int64_t)id * 16 + c4);
+						const int c0 = qt * 16 + c4;
+						*reinterpret_cast<float4 *>(Sx + r * LQ + c0) = sv;
+						if (p.pos_s) {
+							float4 wv;
+							wv.x = tag_weighted(sv.x, twl[c0 + 0], ps, tposl[c0 + 0], p.tw_keep, p.tw_threshold);
+							wv.y = tag_weighted(sv.y, twl[c0 + 1], ps, tposl[c0 + 1], p.tw_keep, p.tw_threshold);
+							wv.z = tag_weighted(sv.z, twl[c0 + 2], ps, tposl[c0 + 2], p.tw_keep, p.tw_threshold);
+							wv.w = tag_weighted(sv.w, twl[c0 + 3], ps, tposl[c0 + 3], p.tw_keep, p.tw_threshold);
+							*reinterpret_cast<float4 *>(SWx + r * LQ + c0) = wv;
+						}
+					}
+				}
+			} else if (is_static) {
 				for (int r = 0; r < 16; r++) {
 					const int tok = base + r;
 					if (tok < t_b && lane < LQ) {
