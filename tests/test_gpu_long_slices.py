@@ -269,6 +269,13 @@ def test_only_slices_states_every_slice_long_ones_included(hip, oracle, len_t):
 	assert got.n == len(ids) and list(got.sentence[:got.n]) == list(ids)
 	for i, s in enumerate(ids):
 		assert np.float32(got.score[i]).view(np.uint32) == np.float32(ref["score"][by_sent[int(s)]]).view(np.uint32)
-	with pytest.raises(hip.VkError):
-		c.query(Qb, q_normalize=False, only_slices=ids, submatch_weight=1.0, **kw)                     # submatch weights: not stated slice by slice
+	# a submatch weight (ABI 11): the score of a listed slice over the reference score of its own traceback (metric/alignment.h:84-106)
+	ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=off, X=Xb, Q=Qb, max_matches=n, min_score=-1.0, submatch_weight=1.0, **kw)
+	by_sent = {int(s): j for j, s in enumerate(ref["sentence"])}
+	got = c.query(Qb, q_normalize=False, only_slices=ids, submatch_weight=1.0, **kw)
+	assert got.n == len(ids) and list(got.sentence[:got.n]) == list(ids)
+	for i, s in enumerate(ids):
+		j = by_sent[int(s)]
+		assert np.float32(got.score[i]).view(np.uint32) == np.float32(ref["score"][j]).view(np.uint32)
+		assert list(got.mapping[i]) == list(ref["mapping"][j])
 	c.close()

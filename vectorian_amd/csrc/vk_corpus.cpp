@@ -107,7 +107,7 @@ int vk_corpus_view(vk_corpus_t *src, vk_corpus_t **out) {
 	c->max_len = src->max_len; c->max_group_tiles = src->max_group_tiles; c->max_group_tokens = src->max_group_tokens; c->max_pair_tiles = src->max_pair_tiles; c->max_short_pair_tiles = src->max_short_pair_tiles;
 	c->n_entries = src->n_entries; c->entry_sent = src->entry_sent;
 	c->h_start = src->h_start; c->h_end = src->h_end; c->h_tok = src->h_tok; c->h_tag = src->h_tag;
-	c->n_long_groups = src->n_long_groups; c->max_short_len = src->max_short_len; c->max_long_len = src->max_long_len; c->h_xlong = src->h_xlong;
+	c->n_long_groups = src->n_long_groups; c->max_short_len = src->max_short_len; c->max_long_len = src->max_long_len; c->h_xlong = src->h_xlong; c->h_apart = src->h_apart;
 	c->long_group_tiles = src->long_group_tiles; c->long_group_tokens = src->long_group_tokens;
 	c->uniform_len = src->uniform_len;
 	c->is_view = true;
@@ -151,7 +151,7 @@ int vk_corpus_free(vk_corpus_t *c) {
 		c->d_sent_start = c->d_sent_end = nullptr, c->d_long_groups = nullptr;
 	if (c->shares_vectors) c->d_tiles = nullptr, c->d_mag = nullptr;
 	void *ptrs[] = {c->d_tiles, c->d_mag, c->d_tok_id, c->d_pos, c->d_tag, c->d_sent_start, c->d_sent_end, c->d_stage, c->d_qtile, c->d_ws, c->d_wt, c->d_qids,
-		c->d_table, c->d_scores, c->d_raw, c->d_boost, c->d_keys[0], c->d_keys[1], c->d_out_raw, c->d_out_sim, c->d_out_map, c->d_wrd_raw, c->d_wrd_val, c->d_bq, c->d_bqlen, c->d_bscores, c->d_bkeys[0], c->d_bkeys[1], c->d_long_groups, c->d_counter, c->d_rows_out, c->d_plan_out, c->d_braw, c->d_wrdl_scratch, c->d_wide_scratch, c->d_wide_order, c->d_xlong_order, c->d_bqt, c->d_bcand, c->d_bcandq, c->d_brows, c->d_qbits};
+		c->d_table, c->d_scores, c->d_raw, c->d_boost, c->d_keys[0], c->d_keys[1], c->d_out_raw, c->d_out_sim, c->d_out_map, c->d_wrd_raw, c->d_wrd_val, c->d_bq, c->d_bqlen, c->d_bscores, c->d_bkeys[0], c->d_bkeys[1], c->d_long_groups, c->d_counter, c->d_rows_out, c->d_plan_out, c->d_braw, c->d_wrdl_scratch, c->d_wide_scratch, c->d_wide_order, c->d_xlong_order, c->d_apart_order, c->d_bqt, c->d_bcand, c->d_bcandq, c->d_brows, c->d_qbits};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	if (c->h_brows) (void)hipHostFree(c->h_brows);
 	for (auto &b : c->bl) for (void *p : {(void *)b.tiles, (void *)b.len, (void *)b.id}) if (p) (void)hipFree(p);
@@ -277,6 +277,7 @@ static int set_slices_impl(vk_corpus_t *c, const int64_t *start, const int64_t *
 	// tokens, LDS strips); the slices beyond (whole documents) are left to the one-wave-per-slice kernel (xlong_entries: their rows)
 	std::vector<int32_t> st32, en32, long_groups, apart_groups;
 	auto xlong_entries = std::make_shared<std::vector<int32_t>>();
+	auto apart_entries = std::make_shared<std::vector<int32_t>>();   // the rows of every group apart (general gaps: all of them take the one-wave-per-slice pass)
 	c->entry_sent.clear(); c->sent_entry.clear();
 	if (n_long == 0) {
 		st32.resize((size_t)n_sentences); en32.resize((size_t)n_sentences);
@@ -288,6 +289,7 @@ static int set_slices_impl(vk_corpus_t *c, const int64_t *start, const int64_t *
 			if (end[s] - start[s] > VK_FAST_SENT_LEN) {
 				while (st32.size() % 4) push(en32.back(), en32.back(), -1);
 				apart_groups.push_back((int32_t)(st32.size() / 4));
+				for (int i = 0; i < 4; i++) apart_entries->push_back((int32_t)st32.size() + i);
 				if (end[s] - start[s] > VK_MAX_SENT_LEN) {
 					// (the four rows of its group: no other pass writes the scores of the three empty ones)
 					for (int i = 0; i < 4; i++) xlong_entries->push_back((int32_t)st32.size() + i);
@@ -327,12 +329,14 @@ static int set_slices_impl(vk_corpus_t *c, const int64_t *start, const int64_t *
 	c->n_entries = n_entries;
 	if (c->d_wide_order) { VK_HIP(hipFree(c->d_wide_order)); c->d_wide_order = nullptr; }
 	if (c->d_xlong_order) { VK_HIP(hipFree(c->d_xlong_order)); c->d_xlong_order = nullptr; }
-	c->n_wide_order = c->n_xlong_order = -1;   // the work list of the one-wave-per-slice pass follows the table
+	if (c->d_apart_order) { VK_HIP(hipFree(c->d_apart_order)); c->d_apart_order = nullptr; }
+	c->n_wide_order = c->n_xlong_order = c->n_apart_order = -1;   // the work list of the one-wave-per-slice pass follows the table
 	c->n_long_groups = (int)long_groups.size();
 	c->max_len = max_len;
 	c->max_short_len = max_short;
 	c->max_long_len = max_long;
 	c->h_xlong = xlong_entries;
+	c->h_apart = apart_entries;
 	c->contiguous = contiguous;
 	c->overlapping = false;
 	for (int64_t s = 1; s < n_sentences && !c->overlapping; s++) c->overlapping = start[s] < end[s - 1] && end[s] > start[s];

@@ -709,7 +709,7 @@ static hipError_t launch_wide_gap(const VkWideParams &p, int blocks, size_t smem
 			if (e != hipSuccess) return e;
 			if (occ < 1) occ = 1;
 			if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-			const int64_t want = p.n_sent, cap = (int64_t)cus * occ;
+			const int64_t want = p.order ? p.n_order : p.n_sent, cap = (int64_t)cus * occ;
 			blocks = (int)(want < cap ? want : cap);
 		}
 		kernel<<<blocks, 64, smem, stream>>>(p);

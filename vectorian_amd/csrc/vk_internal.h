@@ -94,6 +94,7 @@ struct vk_corpus {
 	int32_t *d_long_groups = nullptr;
 	int n_long_groups = 0, max_short_len = 0, long_group_tiles = 0, long_group_tokens = 0;   // the long pass: slices of 65 .. VK_MAX_SENT_LEN tokens
 	int max_long_len = 0;      // ... the longest of them
+	std::shared_ptr<std::vector<int32_t>> h_apart;   // rows of the slice table of every group that holds a slice of more than 64 tokens
 	std::shared_ptr<std::vector<int32_t>> h_xlong;   // rows of the slice table of slices beyond VK_MAX_SENT_LEN (whole documents)
 	int uniform_len = 0;       // > 0: every sentence has exactly this many tokens
 	uint8_t *d_bq = nullptr; int32_t *d_bqlen = nullptr; float *d_bscores = nullptr; uint64_t *d_bkeys[2] = {nullptr, nullptr};
@@ -119,6 +120,7 @@ struct vk_corpus {
 	uint32_t *d_qbits = nullptr;   // tag-weighted vocabulary transports over the static layout: bitmap of the query's token ids
 	uint8_t *d_wrdl_scratch = nullptr;   // exact transport, queries of 17..64 tokens over long slices: per-workgroup state
 	uint8_t *d_wide_scratch = nullptr; size_t wide_scratch_cap = 0;   // vk_wide_kernel, global-state form: per-workgroup state of a slice
+	int32_t *d_apart_order = nullptr; int32_t n_apart_order = -1;   // ... over the slices of more than 64 tokens (general gaps: the one-wave-per-slice pass is their fastest kernel)
 	int32_t *d_xlong_order = nullptr; int32_t n_xlong_order = -1;   // the same list over the slices beyond VK_MAX_SENT_LEN only (queries of at most 16 tokens: the other slices keep their fused kernels)
 	int32_t *d_wide_order = nullptr; int32_t n_wide_order = -1;   // ... its work list: the non-empty rows of the slice table, longest first
 	size_t ws_cap = kGapTable;   // floats d_ws holds (grown by a query over a corpus with longer slices)

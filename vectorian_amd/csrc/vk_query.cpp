@@ -260,7 +260,13 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	// the other slices of such a corpus keep their fused kernels when the query has at most 16 tokens (wide_score false)
 	const bool xlong = c->max_len > VK_MAX_SENT_LEN;
 	const bool wide_score = q->len_t > VK_FAST_QUERY_LEN;
-	const bool wide = wide_score || xlong;
+	// General gaps over slices of 65 .. 512 tokens: the one-wave-per-slice kernel (candidate scan dealt out over the idle lanes, eight
+	// loads deep, a saturated table as a running maximum) is several times faster than the fused kernel's pass over long slices with
+	// its serial LDS-history scan (8,000 slices of 300 .. 512 tokens at 300-d: 101 ms) -- they take the documents' pass as well,
+	// and every winner is retraced by the same kernel
+	const bool long_via_wide = q->algorithm == VK_ALG_ALIGN && !wide_score && c->n_long_groups > 0 &&
+		(q->gap_s.kind == VK_GAP_TABLE || q->gap_t.kind == VK_GAP_TABLE) && !getenv("VK_LONG_PASS");
+	const bool wide = wide_score || xlong || long_via_wide;
 	const int nq = (q->len_t + 15) / 16;
 	vk_pack_query(c, q, qtile, qmags);
 	VK_HIP(hipMemcpyAsync(c->d_qtile, qtile.data(), qtile.size(), hipMemcpyHostToDevice, st));
@@ -419,10 +425,45 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	}
 	VkWideParams wp{};
 	// vk_wide_kernel: the state of a slice in LDS where that fits, else in global memory (one region per workgroup)
+	// The scoring pass of vk_wide_kernel takes one wave per slice: its work list, longest first (wp.order).  A query of more than 16
+	// tokens: every non-empty row of the slice table (the others carry no score: preset); at most 16 tokens: only the slices the fused
+	// kernels leave to it -- those beyond VK_MAX_SENT_LEN, or, under general gaps, every slice of more than 64 tokens.
+	auto wide_order = [&]() -> int {
+		const int which = wide_score ? 0 : long_via_wide ? 1 : 2;
+		int32_t *&d_ord = which == 0 ? c->d_wide_order : which == 1 ? c->d_apart_order : c->d_xlong_order;
+		int32_t &n_ord = which == 0 ? c->n_wide_order : which == 1 ? c->n_apart_order : c->n_xlong_order;
+		if (n_ord < 0) {
+			std::vector<int32_t> ord;
+			if (which == 0) { for (int64_t e = 0; e < n; e++) if ((*c->h_end)[(size_t)e] > (*c->h_start)[(size_t)e]) ord.push_back((int32_t)e); }
+			else if (which == 1 && c->h_apart) ord = *c->h_apart;
+			else if (which == 2 && c->h_xlong) ord = *c->h_xlong;
+			std::stable_sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) {
+				return (*c->h_end)[(size_t)a] - (*c->h_start)[(size_t)a] > (*c->h_end)[(size_t)b] - (*c->h_start)[(size_t)b]; });
+			int rcw;
+			if ((rcw = alloc_t(c, &d_ord, ord.size() + 1))) return rcw;
+			VK_HIP(hipMemcpy(d_ord, ord.data(), ord.size() * 4, hipMemcpyHostToDevice));
+			n_ord = (int32_t)ord.size();
+		}
+		wp.order = d_ord; wp.n_order = n_ord;
+		if (which == 0) {
+			VK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->d_scores), (int)0xff800000u, (size_t)n, st));
+			if (wp.raw) VK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(wp.raw), (int)0xff800000u, (size_t)n, st));
+		}
+		return VK_OK;
+	};
 	auto wide_state = [&](int flow_k) -> int {
 		const bool flow = flow_k > 0;
-		wp.scratch = nullptr; wp.scratch_stride = 0; wp.h_ring = 0;
-		if (!xlong && vk_wide_lds_demand(c->max_len, nq, wp.gap_mode, q->tag_weights != nullptr, flow) <= 160 * 1024) return VK_OK;
+		wp.scratch = nullptr; wp.scratch_stride = 0; wp.h_ring = 0; wp.order = nullptr; wp.n_order = 0;
+		// (the pass over the long slices of a corpus: the ring form where the gap table saturates -- 9 KB of LDS per wave, not 35)
+		const bool part = !flow && !wide_score && (xlong || long_via_wide);
+		const bool want_ring = part && vk_wide_ring_rows(nq, wp.gap_mode, wp.ws_tail) > 0;
+		if (!xlong && !want_ring && vk_wide_lds_demand(c->max_len, nq, wp.gap_mode, q->tag_weights != nullptr, flow) <= 160 * 1024) {
+			if (part) {   // state in LDS, but still only the long slices
+				int rcw = VK_OK;
+				if ((rcw = wide_order())) return rcw;
+			}
+			return VK_OK;
+		}
 		wp.h_ring = vk_wide_ring_rows(nq, wp.gap_mode, wp.ws_tail);   // a saturated gap table: the column history is a ring in LDS
 		const size_t per = vk_wide_scratch_bytes(c->max_len, nq, wp.gap_mode, flow, wp.h_ring);
 		const size_t blocks = (size_t)vk_wide_gs_blocks(c->max_len, nq, wp.gap_mode, flow_k, n, wp.h_ring);
@@ -435,27 +476,9 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 			c->wide_scratch_cap = need;
 		}
 		wp.scratch = c->d_wide_scratch; wp.scratch_stride = (int64_t)per;
-		if (!flow && xlong) {
-			// the scoring pass takes one wave per slice: the non-empty rows of the slice table, longest first; the others carry no score
-			// (a query of at most 16 tokens: only the slices beyond VK_MAX_SENT_LEN -- the fused kernels have scored the others)
-			int32_t *&d_ord = wide_score ? c->d_wide_order : c->d_xlong_order;
-			int32_t &n_ord = wide_score ? c->n_wide_order : c->n_xlong_order;
-			if (n_ord < 0) {
-				std::vector<int32_t> ord;
-				if (wide_score) { for (int64_t e = 0; e < n; e++) if ((*c->h_end)[(size_t)e] > (*c->h_start)[(size_t)e]) ord.push_back((int32_t)e); }
-				else if (c->h_xlong) ord = *c->h_xlong;
-				std::stable_sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) {
-					return (*c->h_end)[(size_t)a] - (*c->h_start)[(size_t)a] > (*c->h_end)[(size_t)b] - (*c->h_start)[(size_t)b]; });
-				int rcw;
-				if ((rcw = alloc_t(c, &d_ord, ord.size() + 1))) return rcw;
-				VK_HIP(hipMemcpy(d_ord, ord.data(), ord.size() * 4, hipMemcpyHostToDevice));
-				n_ord = (int32_t)ord.size();
-			}
-			wp.order = d_ord; wp.n_order = n_ord;
-			if (wide_score) {
-				VK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->d_scores), (int)0xff800000u, (size_t)n, st));
-				if (wp.raw) VK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(wp.raw), (int)0xff800000u, (size_t)n, st));
-			}
+		if (!flow && (xlong || part)) {
+			int rcw = VK_OK;
+			if ((rcw = wide_order())) return rcw;
 		}
 		return VK_OK;
 	};
@@ -579,7 +602,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	const int64_t n_groups = (n + 3) / 4;
 	const int grid = (int)std::min<int64_t>((n_groups + 3) / 4, (int64_t)1 << 20);   // capped to residency by the launcher
 	if (!only) VK_HIP(vk_launch_score(&p, grid, smem, st));
-	if (c->n_long_groups > 0 && !only) {
+	if (c->n_long_groups > 0 && !only && !long_via_wide) {
 		// slices longer than VK_FAST_SENT_LEN: one per wave, one wave per workgroup, LDS strip for the longest;
 		// general gaps take the LDS-history form (the four DPP rows share one history: only row 0 is active)
 		VkScoreParams pl = p;
@@ -596,8 +619,8 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		if (smem_l > 160 * 1024) return fail(VK_ERR_UNSUPPORTED, "LDS demand of the long-slice pass exceeds 160 KiB");
 		VK_HIP(vk_launch_score(&pl, c->n_long_groups, smem_l, st));
 	}
-	if (xlong && !only) {
-		// slices beyond VK_MAX_SENT_LEN (whole documents): one wave per slice, state in global memory, longest first
+	if ((xlong || long_via_wide) && !only) {
+		// slices beyond VK_MAX_SENT_LEN (whole documents; general gaps: beyond 64 tokens): one wave per slice, longest first
 		if ((rc = wide_state(0))) return rc;
 		if (wp.n_order > 0) VK_HIP(vk_launch_wide(&wp, 0, st));
 	}
