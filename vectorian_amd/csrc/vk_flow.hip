@@ -322,6 +322,15 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 	constexpr int gap = GAPT;
 	const float gs = p.gs, gt = p.gt, open_s = p.open_s, open_t = p.open_t, a_s = p.a_s, a_t = p.a_t;
 	const bool is_static = p.layout == VK_DEV_LAYOUT_STATIC;
+	// general gaps, one block of 16 query columns: this lane's in-row costs w_t[v - pp], pp = 0 .. 15
+	float wreg[16];
+	if (gap == 2) {
+#pragma unroll
+		for (int pp = 0; pp < 16; pp++) {
+			const int k = v - pp;
+			wreg[pp] = wtl[k < 0 ? 0 : k > 16 ? 16 : k];
+		}
+	}
 	auto Hrow = [&](int r) -> float * {
 		if constexpr (HR) return H_lds + (r & rmask) * W;
 		else return H + r * W;
@@ -571,6 +580,24 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 					// in-row candidates: columns become final left to right
 					float left_best = VK_NEG_INF, f = VK_NEG_INF, fin = best, ffin = VK_NEG_INF;
 					int16_t left_k = 0;
+					if (gap == 2 && LQ == 16) {
+						// one block of 16 columns: the same chain unrolled, the costs w_t[v - pp] in registers (wreg: read once per kernel; the
+						// rolled form reads LDS inside every step of the dependent chain) and the lane of every v_readlane a constant
+#pragma unroll
+						for (int pp = 0; pp < 16; pp++) {
+							if (pp < len_t) {
+								const float sp = pp == 0 ? bcur : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fin), pp > 0 ? pp - 1 : 0));
+								if (col && v > pp) {
+									const float cc = sp - wreg[pp];
+									if (cc >= left_best) { left_best = cc; left_k = (int16_t)(v - pp); }
+								}
+								if (v == pp + 1) {
+									if (left_best > best) { best = left_best; d = 3; kk = left_k; }
+									fin = best;
+								}
+							}
+						}
+					} else
 					for (int pp = 0; pp < len_t; pp++) {
 						const float sp = pp == 0 ? bcur : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fin), pp - 1));
 						const float fp = pp == 0 ? VK_NEG_INF : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ffin), pp - 1));
