@@ -332,8 +332,9 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 		}
 	}
 	auto Hrow = [&](int r) -> float * {
-		if constexpr (HR) return H_lds + (r & rmask) * W;
-		else return H + r * W;
+		// (24-bit multiplies: rows < 2^15, W <= 65 -- v_mul_u32_u24 issues at full rate, v_mul_lo_u32 at a quarter, eight per batch of the scan)
+		if constexpr (HR) return H_lds + __umul24((unsigned)(r & rmask), (unsigned)W);
+		else return H + __umul24((unsigned)r, (unsigned)W);
 	};
 	const float *wsk;   // the gap table as the candidate scan reads it
 	if constexpr (HR) wsk = wsk_lds;
@@ -556,18 +557,22 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 #pragma unroll
 							for (int i = 0; i < 8; i++) {
 								c = hv[i] - wv[i];
-								if (c > cb) { cb = c; ck = k + i * KG; }
+								if constexpr (FLOW) { if (c > cb) { cb = c; ck = k + i * KG; } }
+								else cb = fmaxf(cb, c);   // the scoring pass needs the value only
 							}
 						}
 						for (; k <= kmax; k += KG) {
 							c = Hrow(u - k)[cv] - wsk[k];
-							if (c > cb) { cb = c; ck = k; }
+							if constexpr (FLOW) { if (c > cb) { cb = c; ck = k; } }
+							else cb = fmaxf(cb, c);
 						}
 						if (KG >= 2) {
 							for (int off = 32; off >= LQ; off >>= 1) {
 								const float oc = __shfl_xor(cb, off, 64);
-								const int ok = __shfl_xor(ck, off, 64);
-								if (oc > cb || (oc == cb && ok < ck)) { cb = oc; ck = ok; }
+								if constexpr (FLOW) {
+									const int ok = __shfl_xor(ck, off, 64);
+									if (oc > cb || (oc == cb && ok < ck)) { cb = oc; ck = ok; }
+								} else cb = fmaxf(cb, oc);
 							}
 						}
 						if (cb > best) { best = cb; d = 2; kk = (int16_t)ck; }
