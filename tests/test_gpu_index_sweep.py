@@ -51,7 +51,7 @@ def random_strategy(rng):
 	return alignment.WordRotatorsDistance(normalize_magnitudes=bool(rng.integers(0, 2))), False
 
 
-def build_session(rng):
+def build_session(rng, sentences=(8, 40)):
 	V, d = int(rng.integers(30, 400)), int(rng.choice([32, 100, 300]))
 	words = [f"w{i}" for i in range(V)]
 	E = (synth.make_vocab(V, d) * rng.lognormal(0, 0.3, size=(V, 1))).astype(np.float32)
@@ -60,7 +60,7 @@ def build_session(rng):
 	docs = []
 	for di in range(int(rng.integers(2, 6))):
 		sents = []
-		for _ in range(int(rng.integers(8, 40))):
+		for _ in range(int(rng.integers(*sentences))):
 			n = int(rng.integers(1, 31)) if rng.random() > 0.05 else int(rng.integers(65, 120))   # now and then a long sentence
 			sents.append([words[int(i)] for i in rng.integers(0, V, size=n)])
 		kw = dict(pos=[[POS_OF[tag_of(w)] for w in s] for s in sents], tags=[[tag_of(w) for w in s] for s in sents])
@@ -199,6 +199,60 @@ def test_random_session_on_hip_equals_oracle_double(hip, seed):
 					continue
 				if i < 3:
 					flows_close(x.flow, y.flow, False)
+	gpu.close(); cpu.close()
+
+
+@pytest.mark.parametrize("seed", range(16 * SCALE))
+def test_random_document_session_on_hip_equals_oracle_double(hip, seed):
+	"""whole documents (600 .. 1,500 tokens) and windows of 30 .. 50 sentences as slices -- beyond VK_MAX_SENT_LEN: the
+	one-wave-per-slice kernel with its state in global memory -- under alignments of every locality and gap family (tag weights,
+	submatch weight, token filters, saliency) and the relaxed 1:1 word mover's distances: documents, slices, scores, flows and the
+	JSON report of the best match equal the oracle double's with `==`"""
+	rng = np.random.default_rng(55000 + seed)
+	session, emb, nlp, words = build_session(rng, sentences=(40, 90))
+	if rng.random() < 0.7:
+		gap = random_gap(rng) if rng.random() < 0.6 else {"s": random_gap(rng), "t": random_gap(rng)}
+		strategy, is_align = [alignment.LocalAlignment, alignment.GlobalAlignment, alignment.SemiGlobalAlignment][int(rng.integers(0, 3))](gap=gap), True
+	else:
+		strategy, is_align = alignment.WordMoversDistance.rwmd(str(rng.choice(["nbow", "bow/fast"]))), False
+	kw = {}
+	if is_align and rng.random() < 0.3:   # (tag-weighted vocabulary transports keyed by (id, tag) are refused over such slices)
+		kw = dict(tag_weights={t: float(rng.uniform(0.25, 2.5)) for t in rng.choice(TAGS, size=3, replace=False)},
+			pos_mismatch_penalty=float(rng.uniform(0, 0.5)), similarity_threshold=float(rng.uniform(0, 0.2)))
+	sim = OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), strategy, **kw)
+	part = session.partition("document") if rng.random() < 0.6 else session.partition("sentence", int(rng.integers(30, 50)), int(rng.integers(10, 20)))
+	index_kw = {}
+	gpu = part.index(sim, nlp=nlp)
+	if max(gpu._slice_end - gpu._slice_start) <= 512:   # (windows of short sentences)
+		gpu.close()
+		part = session.partition("document")
+		gpu = part.index(sim, nlp=nlp)
+	assert max(gpu._slice_end - gpu._slice_start) > 512
+	if rng.random() < 0.3:
+		index_kw["saliency"] = rng.uniform(0.5, 1.5, size=gpu.n_slices).astype(np.float32)
+		gpu.close()
+		gpu = part.index(sim, nlp=nlp, **index_kw)
+	cpu = part.index(sim, nlp=nlp, corpus_factory=OracleCorpus, **index_kw)
+	for _ in range(2):
+		doc = session.documents[int(rng.integers(0, len(session.documents)))]
+		len_t = int(rng.integers(1, 13)) if rng.random() < 0.7 else int(rng.integers(17, 40))
+		a0 = int(rng.integers(0, len(doc.tokens) - 3 * len_t))
+		text = " ".join(doc.tokens[a0:a0 + 3 * len_t:3]) if rng.random() < 0.5 else " ".join(doc.tokens[a0:a0 + len_t])
+		options = {}
+		if rng.random() < 0.25:
+			options["pos_filter"] = [str(x) for x in rng.choice(["DET", "PUNCT", "ADJ"], size=int(rng.integers(1, 3)), replace=False)]
+		if is_align and rng.random() < 0.25:
+			options["submatch_weight"] = float(rng.choice([0.5, 1.0, 2.0]))
+		n = int(rng.choice([1, 3, 8]))
+		min_score = 0.0 if rng.random() < 0.6 else -100.0
+		a = gpu.find(text, n=n, min_score=min_score, options=options)
+		b = cpu.find(text, n=n, min_score=min_score, options=options)
+		ctx = (seed, type(strategy).__name__, getattr(strategy, "_options", None), text, options, bool(kw), part.to_args(), type(emb).__name__, n, min_score, bool(index_kw))
+		assert [(m.doc_index, m.slice_id, m.score) for m in a] == [(m.doc_index, m.slice_id, m.score) for m in b], ctx
+		for x, y in zip(a, b):
+			flows_close(x.flow, y.flow, is_align)
+		if len(a) and is_align:
+			assert a[0].to_json() == b[0].to_json(), ctx
 	gpu.close(); cpu.close()
 
 
