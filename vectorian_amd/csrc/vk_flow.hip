@@ -500,6 +500,8 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 			if (gap == 2 && col) Hrow(0)[v] = hprev;
 			float bv = 0.0f;
 			int bu = 0, u = 0;
+			const bool fast16 = !FLOW && LQ == 16 && (gap == 0 || (gap == 1 && a_t >= 0.0f));
+			const DecaySteps dt16 = decay_steps(gt, lane & 15);
 			const int ktail = (gap == 2 && p.ws_tail > 0) ? p.ws_tail : 0x7fffffff;
 			const float wtail = ktail <= p.max_len ? wsk[ktail] : 0.0f;
 			float tmax = VK_NEG_INF;
@@ -517,11 +519,29 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 						bcur = gap == 0 ? -(gs * (float)u) : gap == 1 ? -(a_s + gs * (float)u) : -wsl[u];
 					}
 					const float sv = SWx[r * LQ + (col ? v - 1 : 0)];
+					float best, e = VK_NEG_INF;
+					uint8_t d = 0, ee = 0, fe = 0;
+					int16_t kk = 0;
+					if (fast16) {
+						// The scoring pass of a query of at most 16 tokens under linear / affine gaps: the row as the fused kernel takes it
+						// (dp_linear / dp_affine, vk_common.hip.h) -- the in-row gaps as a decayed prefix maximum, four DPP steps within the
+						// lanes' row of 16, instead of a chain of len_t dependent v_readlane steps; values agree to the last bits (the
+						// winners are restated by the serial form, FLOW)
+						const float diag = dpp_f<DPP_ROW_SHR1>(bprev, hprev);
+						const float floor0 = local ? 0.0f : VK_NEG_INF;
+						if (gap == 0) {
+							float c = fmaxf(fmaxf(diag + sv, floor0), hprev - gs);
+							best = decay_scan<16>(c, dt16);
+							if (!local) best = fmaxf(best, bcur - gt * (float)v);
+						} else {
+							e = fmaxf(hprev - open_s, eprev - gs);
+							const float c = fmaxf(fmaxf(diag + sv, floor0), e);
+							const float fsc = decay_scan<16>(dpp_f<DPP_ROW_SHR1>(bcur, c) - open_t, dt16);
+							best = fmaxf(c, fsc);
+						}
+					} else {
 					const float up = __shfl_up(hprev, 1, 64);
 					const float diag = lane == 0 ? bprev : up;
-					float best, e = VK_NEG_INF;
-					uint8_t d, ee = 0, fe = 0;
-					int16_t kk = 0;
 					float c = diag + sv;
 					if (local) { best = 0.0f; d = 0; if (c > best) { best = c; d = 1; } }
 					else { best = c; d = 1; }
@@ -624,6 +644,7 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 							else if (left_best > best) { best = left_best; d = 3; kk = left_k; }
 							fin = best;
 						}
+					}
 					}
 					if (col) {
 						if (gap == 2) Hrow(u)[v] = best;
