@@ -331,6 +331,13 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 			wreg[pp] = wtl[k < 0 ? 0 : k > 16 ? 16 : k];
 		}
 	}
+	// ... and, for the scoring pass, the closure of w_t: wcl[s] = w*(s) (uniform), wcb = w*(v) (the border column is v columns away)
+	float wcl[16], wcb = 0.0f;
+	if (gap == 2 && !FLOW) {
+#pragma unroll
+		for (int sh = 0; sh < 16; sh++) wcl[sh] = p.wt[80 + sh];
+		wcb = p.wt[80 + (v <= 64 ? v : 64)];
+	}
 	auto Hrow = [&](int r) -> float * {
 		// (24-bit multiplies: rows < 2^15, W <= 65 -- v_mul_u32_u24 issues at full rate, v_mul_lo_u32 at a quarter, eight per batch of the scan)
 		if constexpr (HR) return H_lds + __umul24((unsigned)(r & rmask), (unsigned)W);
@@ -605,7 +612,20 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 					// in-row candidates: columns become final left to right
 					float left_best = VK_NEG_INF, f = VK_NEG_INF, fin = best, ffin = VK_NEG_INF;
 					int16_t left_k = 0;
-					if (gap == 2 && LQ == 16) {
+					if (!FLOW && gap == 2 && LQ == 16) {
+						// The scoring pass, one block of 16 columns: the in-row candidates taken from the row's values BEFORE in-row gaps, with
+						// w_t replaced by its subadditive closure (the host's wt[80 ..]; dp_general_reg of the fused kernel: the sequential
+						// recurrence chains gaps, which is what the closure prices) -- fifteen independent DPP shifts instead of a chain of
+						// len_t dependent steps; values agree to the last bits, the winners are restated by the serial form (FLOW)
+						const float arow = best;
+						float x = fmaxf(arow, bcur - wcb);
+#define VK_CLOSURE_STEP(SH) x = fmaxf(x, dpp_f<0x110 + SH>(VK_NEG_INF, arow) - wcl[SH]);   /* row_shr:SH, lanes without a source drop out */
+						VK_CLOSURE_STEP(1) VK_CLOSURE_STEP(2) VK_CLOSURE_STEP(3) VK_CLOSURE_STEP(4) VK_CLOSURE_STEP(5)
+						VK_CLOSURE_STEP(6) VK_CLOSURE_STEP(7) VK_CLOSURE_STEP(8) VK_CLOSURE_STEP(9) VK_CLOSURE_STEP(10)
+						VK_CLOSURE_STEP(11) VK_CLOSURE_STEP(12) VK_CLOSURE_STEP(13) VK_CLOSURE_STEP(14) VK_CLOSURE_STEP(15)
+#undef VK_CLOSURE_STEP
+						best = x;
+					} else if (gap == 2 && LQ == 16) {
 						// one block of 16 columns: the same chain unrolled, the costs w_t[v - pp] in registers (wreg: read once per kernel; the
 						// rolled form reads LDS inside every step of the dependent chain) and the lane of every v_readlane a constant
 #pragma unroll
