@@ -484,7 +484,19 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 				for (int r = r0; r < r1; r++) {
 					const float dist = fmaxf(1.0f - SWx[r * LQ + (col ? v - 1 : 0)], 0.0f);   // the tag-weighted similarity (SWx == Sx without tag weights); round 2 read Sx here
 					colmin = fminf(colmin, dist);
-					acc1 += w_s * wave_min64(col ? dist : 3.402823466e+38F);
+					// the row's minimum over the query columns (the s -> t direction: read by the symmetric form only); one block of 16
+					// columns: four DPP steps within the lanes' row and one v_readlane instead of six cross-lane round trips
+					if (p.rwmd_symmetric) {
+						float m = col ? dist : 3.402823466e+38F;
+						if (LQ == 16) {
+							m = fminf(m, dpp_f<DPP_ROW_SHR1>(3.402823466e+38F, m));
+							m = fminf(m, dpp_f<DPP_ROW_SHR2>(3.402823466e+38F, m));
+							m = fminf(m, dpp_f<DPP_ROW_SHR4>(3.402823466e+38F, m));
+							m = fminf(m, dpp_f<DPP_ROW_SHR8>(3.402823466e+38F, m));
+							m = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 15));
+						} else m = wave_min64(m);
+						acc1 += w_s * m;
+					}
 				}
 				wave_lds_fence();
 			}
