@@ -530,6 +530,39 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 				else fill(base);
 				wave_lds_fence();
 				const int r0 = t_a > base ? t_a - base : 0, r1 = t_b - base < 16 ? t_b - base : 16;
+				if (fast16) {
+					// the fast rows of a tile: its sixteen similarities read from the strip up front (the rolled loop waits out an LDS round
+					// trip at the head of every row's dependent chain), then the rows one after the other
+					float svv[16];
+#pragma unroll
+					for (int r = 0; r < 16; r++) svv[r] = SWx[r * LQ + (col ? v - 1 : 0)];
+					const float floor0 = local ? 0.0f : VK_NEG_INF;
+#pragma unroll
+					for (int r = 0; r < 16; r++) {
+						if (r >= r0 && r < r1) {
+							u++;
+							float bprev = 0.0f, bcur = 0.0f;
+							if (global) {
+								bprev = u == 1 ? 0.0f : (gap == 0 ? -(gs * (float)(u - 1)) : -(a_s + gs * (float)(u - 1)));
+								bcur = gap == 0 ? -(gs * (float)u) : -(a_s + gs * (float)u);
+							}
+							const float diag = dpp_f<DPP_ROW_SHR1>(bprev, hprev);
+							float best, e = VK_NEG_INF;
+							if (gap == 0) {
+								const float c = fmaxf(fmaxf(diag + svv[r], floor0), hprev - gs);
+								best = decay_scan<16>(c, dt16);
+								if (!local) best = fmaxf(best, bcur - gt * (float)v);
+							} else {
+								e = fmaxf(hprev - open_s, eprev - gs);
+								const float c = fmaxf(fmaxf(diag + svv[r], floor0), e);
+								best = fmaxf(c, decay_scan<16>(dpp_f<DPP_ROW_SHR1>(bcur, c) - open_t, dt16));
+							}
+							if (col && !global && (local || u == len_s || v == len_t) && best > bv) { bv = best; bu = u; }
+							hprev = best;
+							eprev = e;
+						}
+					}
+				} else
 				for (int r = r0; r < r1; r++) {
 					u++;
 					float bprev = 0.0f, bcur = 0.0f;
