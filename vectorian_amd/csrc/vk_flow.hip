@@ -457,6 +457,51 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 			}
 		};
 		const int base0 = is_static ? t_a : (t_a >> 4) * 16;
+		// Scoring passes whose rows are cheap (linear / affine gaps on the fast rows, relaxed WMD) over bf16 contextual rows of up to
+		// 12 K-steps: the token tile of the NEXT 16 rows is requested before the rows of the current tile are walked -- three dependent
+		// batches of loads per tile were 60 % of such a pass once its rows took 0.1 us each -- and every query tile reuses the one copy
+		// in registers.  (Tried under slow rows first, and dropped there: DESIGN 9.)
+		constexpr int NKP = 12;
+		constexpr bool PIPE = GSM == 1 && !FLOW && (GAPT == 0 || GAPT == 1 || GAPT == 4);
+		const int nfull = p.tail ? p.nk32 - 1 : p.nk32;
+		const bool pipe = PIPE && !is_static && p.prec == 0 && p.nk32 <= NKP;
+		bf16x8 xn[NKP], xh = {0, 0, 0, 0, 0, 0, 0, 0};
+		auto tile_load = [&](int base) {
+			if constexpr (PIPE) {
+				const uint8_t *tp = p.tiles + (int64_t)(base >> 4) * p.tile_bytes;
+#pragma unroll
+				for (int i = 0; i < NKP; i++)   // (K-steps the row does not have re-read its first one: unconditional loads, no copies of xn kept alive)
+					xn[i] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(tp + (i < nfull ? i : 0) * 1024 + lane * 16));
+				xh = load_half_block(tp + (p.tail ? nfull : 0) * 1024, lane, true);
+			}
+		};
+		auto tile_mma = [&](int base) {   // the MFMA sequence of sim_tile_generic over the tile in xn / xh
+			if constexpr (PIPE)
+			for (int qt = 0; qt < p.nq; qt++) {
+				const uint8_t *qp = p.qtile + (int64_t)qt * p.tile_bytes;
+				f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+				for (int i = 0; i < NKP; i++)
+					if (i < nfull) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(qp + i * 1024 + lane * 16), xn[i], acc, 0, 0, 0);
+				if (p.tail) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(load_half_block(qp + nfull * 1024, lane, false), xh, acc, 0, 0, 0);
+				acc[0] = clip01(acc[0]); acc[1] = clip01(acc[1]); acc[2] = clip01(acc[2]); acc[3] = clip01(acc[3]);
+				const int c0 = qt * 16 + (lane >> 4) * 4;
+				*reinterpret_cast<f32x4 *>(Sx + (lane & 15) * LQ + c0) = acc;
+				if (p.pos_s) {
+					const int ps = p.pos_s[base + (lane & 15)];
+#pragma unroll
+					for (int r = 0; r < 4; r++) acc[r] = tag_weighted(acc[r], twl[c0 + r], ps, tposl[c0 + r], p.tw_keep, p.tw_threshold);
+					*reinterpret_cast<f32x4 *>(SWx + (lane & 15) * LQ + c0) = acc;
+				}
+			}
+		};
+		auto fill_next = [&](int base) {   // the rows of tile `base` into the strip; on the pipelined form: and the next tile requested
+			if (pipe) {
+				tile_mma(base);
+				if (base + 16 < t_b) tile_load(base + 16);
+			} else fill(base);
+		};
+		if (pipe) tile_load(base0);
 		// FLOW over long winners: the rows the recurrence runs on were restated beforehand (vk_canon_rows_kernel: the same canonical
 		// arithmetic, sim[id(t_j)][j] = 1 and tag weights applied), [dp_rows_len][LQ] per winner, row 0 = the slice's first token
 		auto fill_dp = [&](int base) {
@@ -478,7 +523,7 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 			const float w_t = nbow ? 1.0f / (float)len_t : 1.0f, w_s = nbow ? 1.0f / (float)len_s : 1.0f;
 			float colmin = 3.402823466e+38F, acc1 = 0.0f;
 			for (int base = base0; base < t_b; base += 16) {
-				fill(base);
+				fill_next(base);
 				wave_lds_fence();
 				const int r0 = t_a > base ? t_a - base : 0, r1 = t_b - base < 16 ? t_b - base : 16;
 				for (int r = r0; r < r1; r++) {
@@ -527,7 +572,7 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 			int trow = 0;
 			for (int base = base0; base < t_b; base += 16) {
 				if (FLOW && p.dp_rows) fill_dp(base);
-				else fill(base);
+				else fill_next(base);
 				wave_lds_fence();
 				const int r0 = t_a > base ? t_a - base : 0, r1 = t_b - base < 16 ? t_b - base : 16;
 				if (fast16) {
