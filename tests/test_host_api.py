@@ -330,6 +330,33 @@ def test_sliding_windows_overlap():
 		assert r[0].to_json()["location"]["start"] == st[r[0].slice_id]
 
 
+def test_document_partition():
+	"""session.partition("document") (mkdocs/docs/documents.md:37): the one span the importers give every document
+	(vectorian/importers.py:30-36, 220-223) -- whole documents as the slices of an index, here ~ 700 tokens each (beyond
+	VK_MAX_SENT_LEN: the gap tables and the winners' similarity rows are sized by the longest document)"""
+	session, emb, words, rng = toy_session(n_docs=5, sents_per_doc=32, V=300, d=32)
+	for doc in session.documents:
+		assert list(doc.spans["document"]["start"]) == [0] and list(doc.spans["document"]["end"]) == [doc.n_tokens]
+	assert session.max_len("document", 1) == max(d.n_tokens for d in session.documents) > core.VK_MAX_SENT_LEN
+	doc = session.documents[3]
+	st = doc.spans["sentence"]["start"][17]
+	planted = " ".join(doc.tokens[st:st + 6])
+	for strategy in (alignment.LocalAlignment(gap=alignment.smooth_gap_cost(5)), alignment.WordMoversDistance.rwmd("nbow")):
+		index = session.partition("document").index(OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), strategy), corpus_factory=OracleCorpus)
+		assert index.n_slices == 5 and index.corpus._longest() == session.max_len("document", 1)
+		top = index.find(planted, n=3)[0]
+		assert (top.doc_index, top.slice_id) == (3, 0)
+		if isinstance(strategy, alignment.LocalAlignment):
+			assert abs(top.score - 1.0) < 1e-2 and list(top.flow["target"]) == list(range(st, st + 6))   # token positions in the document
+			j = top.to_json()
+			assert j["location"] == {"start": 0, "end": doc.n_tokens} and [r["s"] for r in j["regions"] if "edges" in r] == doc.tokens[st:st + 6]
+		else:
+			assert top.flow["type"] == "sparse" and len(top.flow["target"]) >= 6   # (the symmetric form: edges of both directions)
+	assert core.winner_rows(700) == 704 and core.winner_rows(40000) == core.VK_MAX_DOC_LEN + 1 and core.winner_rows(3) == core.VK_FAST_SENT_LEN
+	with pytest.raises(ValueError):
+		Document([["a"]], spans={"document": {"start": [0], "end": [1]}})   # built in, like "sentence" and "token"
+
+
 def test_token_mask_and_span_levels():
 	# PreparedDocument (vectorian/corpus/document.py:626-662): masked tokens disappear from the token table, every span
 	# table is re-indexed with the cumulative sum of the mask; "token" is a partition level of its own (document.cpp:52-53)
