@@ -39,13 +39,12 @@ int vk_validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_topk_
 	const bool exact_tr = q->algorithm == VK_ALG_WRD || (q->algorithm == VK_ALG_RWMD && (q->wmd_full || !q->rwmd_injective));   // multi-block kernel + kernels of their own for the long slices: no wide kernel
 	if (q->len_t > VK_FAST_QUERY_LEN && exact_tr && !score32_plan(c, q).fits)
 		return fail(VK_ERR_UNSUPPORTED, "exact transport / 1:n RWMD with a query of more than 16 tokens: the query tiles of rows this wide and one wave's similarity strip exceed the LDS of a workgroup (160 KiB)");
-	// Slices of more than VK_MAX_SENT_LEN tokens (whole documents as slices, up to VK_MAX_DOC_LEN): alignments only -- the
-	// one-wave-per-slice kernel with the slice's state in global memory (vk_wide_kernel, global-state form).  The same form takes a
-	// query of more than 16 tokens whose state over the corpus's longest slice exceeds the LDS (round 2: VK_ERR_UNSUPPORTED), except
-	// the relaxed WMD with similarity rows, whose rows are bounded by VK_MAX_SENT_LEN anyway.
+	// Slices of more than VK_MAX_SENT_LEN tokens (whole documents as slices, up to VK_MAX_DOC_LEN): alignments -- the
+	// one-wave-per-slice kernel with the slice's state in global memory (vk_wide_kernel, global-state form; the same form takes a
+	// query of more than 16 tokens whose state over the corpus's longest slice exceeds the LDS: VK_ERR_UNSUPPORTED in round 2) --
 	if (c->max_len > VK_MAX_SENT_LEN && q->algorithm != VK_ALG_ALIGN) {
 		// ... and the relaxed word mover's distance in its 1:1 form (a stream of row / column minima; the winners' rows restated
-		// through global memory, vk_rows_kernel); the 1:n form and the exact transports keep a slice's bag of words in LDS
+		// tile by tile, vk_canon_rows_kernel); the 1:n form and the exact transports keep a slice's bag of words in LDS
 		const bool relaxed_11 = q->algorithm == VK_ALG_RWMD && !q->wmd_full && q->rwmd_injective;
 		if (!relaxed_11)
 			return fail(VK_ERR_UNSUPPORTED, "slices of more than VK_MAX_SENT_LEN (512) tokens: alignments and the relaxed 1:1 word mover's distance only (the 1:n form and the exact transports keep a slice's bag of words in LDS)");
@@ -818,8 +817,8 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 			wp.dp_rows = nullptr; wp.dp_rows_len = 0;
 			if (xlong) {
 				// Long winners: their similarities (canonical arithmetic, tag weights applied) restated beforehand by one wave per 16
-				// tokens, so that the serial sweep of a winner is its recurrence alone (5,000 tokens: 8.4 -> ms of a 12 ms query were
-				// the sweep restating 313 tiles one after the other).  Within 2 GiB; else the sweep restates them itself.
+				// tokens, so that the serial sweep of a winner is its recurrence alone (5,000 tokens: 8.4 ms of a 12 ms query were the
+				// sweep restating 313 tiles one after the other; 3.6 ms since).  Within 2 GiB; else the sweep restates them itself.
 				const int R = (c->max_len + 63) / 64 * 64, Wq = 16 * nq;
 				const size_t need = (size_t)count * R * Wq;
 				if (need * 4 <= ((size_t)2 << 30)) {
