@@ -27,6 +27,43 @@ def test_every_declared_symbol_is_exported():
 	assert lib.vk_abi_version() == 11
 
 
+def test_document_pass_sizing():
+	"""the host-side sizing of the one-wave-per-slice pass (internal helpers of the library, pure host code): the LDS ring of the
+	column history covers the window a saturated gap table leaves (a power of two above ws_tail), the launch takes one scratch region
+	per workgroup within its caps, and the launcher's own figures are what the query code sizes the scratch by"""
+	import ctypes as C
+	from vectorian_amd import core
+	lib = core.lib()
+	lib.vk_wide_ring_rows.restype = C.c_int32
+	lib.vk_wide_ring_rows.argtypes = [C.c_int32] * 3
+	lib.vk_wide_gs_blocks.restype = C.c_int32
+	lib.vk_wide_gs_blocks.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32]
+	lib.vk_wide_scratch_bytes.restype = C.c_size_t
+	lib.vk_wide_scratch_bytes.argtypes = [C.c_int32] * 5
+	lib.vk_wide_lds_demand.restype = C.c_size_t
+	lib.vk_wide_lds_demand.argtypes = [C.c_int32] * 5
+	for nq in (1, 2, 3, 4):
+		for tail in (1, 5, 126, 127, 128, 300):
+			ring = lib.vk_wide_ring_rows(nq, 2, tail)
+			assert ring == 0 or (ring > tail and ring & (ring - 1) == 0 and ring * (16 * nq + 2) * 4 <= 40 * 1024)
+		assert lib.vk_wide_ring_rows(nq, 2, 126) == 128                     # 1 - 2^(-k/5) saturates at k = 126
+		assert lib.vk_wide_ring_rows(nq, 2, 0) == 0 and lib.vk_wide_ring_rows(nq, 0, 126) == 0 and lib.vk_wide_ring_rows(nq, 1, 126) == 0
+	doc = core.VK_MAX_DOC_LEN
+	# scoring: no state in the scratch without general gaps or with the ring; the whole history of a document otherwise
+	assert lib.vk_wide_scratch_bytes(doc, 1, 0, 0, 0) == 16 and lib.vk_wide_scratch_bytes(doc, 1, 2, 0, 128) == 16
+	assert lib.vk_wide_scratch_bytes(doc, 1, 2, 0, 0) >= (doc + 1) * 17 * 4
+	# tracebacks: 3 bytes per cell (step lengths + flags), plus the history unless it is the ring
+	assert (doc + 1) * 17 * 3 <= lib.vk_wide_scratch_bytes(doc, 1, 0, 1, 0) <= (doc + 1) * 17 * 3 + 64
+	assert lib.vk_wide_scratch_bytes(doc, 4, 2, 1, 0) >= (doc + 1) * 65 * 7
+	for gap, ring in ((0, 0), (2, 0), (2, 128)):
+		for n in (1, 100, 10 ** 6):
+			b = lib.vk_wide_gs_blocks(doc, 4, gap, 0, n, ring)
+			assert 1 <= b <= min(2048, n) and b * lib.vk_wide_scratch_bytes(doc, 4, gap, 0, ring) <= 4 << 30
+		assert lib.vk_wide_gs_blocks(doc, 4, gap, 18, 10 ** 6, ring) == 18          # tracebacks: one workgroup per winner
+	# 64 query tokens over 512-token slices with general gaps and traceback: beyond the LDS (the global-state form takes them)
+	assert lib.vk_wide_lds_demand(512, 4, 2, 0, 1) > 160 * 1024 >= lib.vk_wide_lds_demand(512, 1, 2, 0, 1)
+
+
 def test_no_gpu_means_loud_failure():
 	import torch
 	if torch.cuda.is_available():
