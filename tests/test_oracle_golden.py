@@ -129,6 +129,33 @@ def test_alignment_against_exhaustive_enumeration(oracle, locality, gapname):
 		assert abs(raw - raw2) < 1e-5
 
 
+@pytest.mark.parametrize("gapname,len_long", [("linear", 30000), ("affine", 30000), ("exp5", 4000)])
+def test_document_length_slices_embed_short_ones(oracle, gapname, len_long):
+	"""Slices of document length (up to the mapping's int16, metric/alignment.h:357-358) through the same solvers: a short slice
+	set into a long run of tokens that resemble nothing (similarity 0) keeps its local alignment -- the same aligner score, bit for
+	bit, the same mapping shifted by its offset -- whatever the gap family; the short case is what the exhaustive enumeration and the
+	reference's known answer pin"""
+	rng = np.random.default_rng(7)
+	g = {"linear": ("linear", 0.1), "affine": ("affine", 0.2, 0.05),
+		"exp5": ("table", (1 - 2.0 ** (-np.arange(0, len_long + 1) / 5)).astype(np.float32))}[gapname]
+	for trial in range(6):
+		ls, lt = int(rng.integers(5, 60)), int(rng.integers(2, 14))
+		S = np.clip(rng.normal(0.1, 0.35, size=(ls, lt)), 0, 1).astype(np.float32)
+		raw, mapping = oracle.align(S, 0, g, g)
+		off = int(rng.integers(0, len_long - ls))
+		L = np.zeros((len_long, lt), dtype=np.float32)
+		L[off:off + ls] = S
+		raw_l, mapping_l = oracle.align(L, 0, g, g)
+		assert np.float32(raw_l).view(np.uint32) == np.float32(raw).view(np.uint32), (trial, raw, raw_l)
+		assert (np.asarray(mapping_l) == np.where(np.asarray(mapping) >= 0, np.asarray(mapping) + off, -1)).all(), (trial, off)
+	# the longest slice there is, matched at its far end
+	n_max, lt = 32767, 5
+	L = np.zeros((n_max, lt), dtype=np.float32)
+	L[n_max - lt + np.arange(lt), np.arange(lt)] = 0.5
+	raw_l, mapping_l = oracle.align(L, 0, ("linear", 0.1), ("linear", 0.1))
+	assert raw_l == 2.5 and list(mapping_l) == list(range(n_max - lt, n_max))
+
+
 @settings(max_examples=60, deadline=None)
 @given(st.integers(1, 12), st.integers(1, 8), st.integers(0, 10 ** 6), st.floats(0.0, 0.5))
 def test_locality_ordering_property(ls, lt, seed, g):
