@@ -232,7 +232,8 @@ int vk_corpus_set_slices(vk_corpus_t *c, const int64_t *start, const int64_t *en
 int vk_corpus_finalize(vk_corpus_t *c);
 /* A second handle on the same resident corpus (read-only arrays shared, own stream and workspaces): two handles serve
  * two queries at a time from two host threads, so that selection, traceback and the host part of one query overlap the
- * scoring kernel of the next.  Free the views before the owning handle.  (The reference runs one ThreadPool task per
+ * scoring kernel of the next.  The shared arrays are reference-counted: handles may be freed in any order, and freeing one while
+ * ANOTHER handle of the corpus is inside a call is safe (calls on one handle stay the caller's to serialise).  (The reference runs one ThreadPool task per
  * document, vectorian/index.py:544-558; here the unit of concurrency is the query.) */
 int vk_corpus_view(vk_corpus_t *src, vk_corpus_t **out);
 /* Token filter (TokenFilter::pass, vectorian/core/cpp/query.h:8-28; options pos_filter / tag_filter of
@@ -241,7 +242,7 @@ int vk_corpus_view(vk_corpus_t *src, vk_corpus_t **out);
  * slice/static.h:366-416); here the filtered corpus is built once on the device -- rows of the dropped tokens removed,
  * slices re-indexed, same slice ids -- and queried like any other corpus; traceback positions count the tokens that
  * passed, as upstream's do (flow.cpp:49-60 maps them back).  The static layout shares the vocabulary vectors with
- * `src`: free the filtered corpus first. */
+ * `src` (reference-counted: either may be freed first). */
 int vk_corpus_filter(vk_corpus_t *src, uint64_t pos_mask, uint64_t tag_mask, vk_corpus_t **out);
 int vk_corpus_free(vk_corpus_t *c);
 int vk_corpus_device_bytes(const vk_corpus_t *c, int64_t *bytes);

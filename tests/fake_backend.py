@@ -2,6 +2,8 @@
 oracle.  Lives in tests/ only -- it lets the host-side plumbing (Session / Index / shards)
 run in the no-GPU tier; the product never imports it."""
 
+import threading
+
 import numpy as np
 
 from oracle import vk_oracle as vo
@@ -32,6 +34,7 @@ class OracleCorpus:
 		self._tags = None
 		self._off = None
 		self._all = None
+		self.lock = threading.RLock()   # as core.Corpus: one call at a time per handle (view() returns this same object)
 
 	def append_vectors(self, rows, normalize=True):
 		rows = np.ascontiguousarray(rows)

@@ -139,6 +139,22 @@ def abort_answers(shard):
 	return res
 
 
+def hook_answers(shard):
+	"""find_many(debug = AllSlices(hook)) over a (sharded) index: every rank's hook walks the slices of ITS shard, per query, while the
+	lanes' threads go on with the next queries on the same handles"""
+	from vectorian_amd.index import AllSlices
+	out = {}
+	for strategy in ("align", "rwmd"):
+		index = build_contextual(shard, strategy)
+		queries = many_queries(index, 7)
+		calls = []
+		hook = AllSlices(lambda name, data: calls.append([int(data["slice"]), float(data["score"])]), chunk=32)
+		results = index.find_many(queries, n=4, in_flight=3, batch=False, options={"debug": hook})
+		per = len(calls) // len(queries)
+		out[strategy] = {"matches": [summary(r) for r in results], "calls": [calls[i * per:(i + 1) * per] for i in range(len(queries))]}
+	return out
+
+
 def main(outdir):
 	import torch.distributed as dist
 	dist.init_process_group(backend="gloo")
@@ -150,6 +166,7 @@ def main(outdir):
 	res["find_many"] = find_many_answers((rank, world))
 	res["abort"] = abort_answers((rank, world))
 	res["documents"] = documents_answers((rank, world))
+	res["hooks"] = hook_answers((rank, world))
 	with open(os.path.join(outdir, f"index_rank{rank}.json"), "w") as f:
 		json.dump(res, f)
 	dist.barrier()

@@ -351,3 +351,29 @@ def test_debug_hook_for_every_slice_exact_transport_on_hip_equals_oracle_double(
 					np.testing.assert_allclose(a[key], b[key], atol=2e-5, err_msg=key)
 				elif isinstance(a[key], float):
 					assert abs(a[key] - b[key]) < 2e-5, key
+
+
+@pytest.mark.parametrize("strategy", ["wsb", "rwmd"])
+def test_find_many_with_a_hook_for_every_slice_on_hip_equals_find(hip, strategy):
+	"""find_many(debug = AllSlices(hook)) on the real backend, three handles in flight: per query the hook is handed what `find`
+	hands it (the walk raced the lane's next query on the same handle; relaxed WMD read the wrong query's scores)"""
+	from vectorian_amd.index import AllSlices
+	session, emb, words, rng = toy_session(n_docs=6, sents_per_doc=40)
+	optimizer = alignment.LocalAlignment(gap=alignment.smooth_gap_cost(5)) if strategy == "wsb" else alignment.WordMoversDistance.rwmd("nbow")
+	gpu = session.partition("sentence").index(OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), optimizer))
+	texts = [" ".join(session.documents[i % 6].tokens[9 * i:9 * i + 3 + i % 4]) for i in range(9)]
+	calls = []
+	hook = AllSlices(lambda name, data: calls.append((name, data["slice"], float(data["score"]), data.get("worst_score"))), chunk=64)
+	want = []
+	for t in texts:
+		calls.clear()
+		r = gpu.find(t, n=4, debug=hook)
+		want.append(([(m.doc_index, m.slice_id, m.score) for m in r], list(calls)))
+	calls.clear()
+	many = gpu.find_many(texts, n=4, in_flight=3, options={"debug": hook})
+	per_query = len(calls) // len(texts)
+	assert per_query == 240 and per_query * len(texts) == len(calls)
+	for i, (r, (w_matches, w_calls)) in enumerate(zip(many, want)):
+		assert [(m.doc_index, m.slice_id, m.score) for m in r] == w_matches
+		assert calls[i * per_query:(i + 1) * per_query] == w_calls
+	gpu.close()

@@ -587,3 +587,29 @@ def test_query_tokens_outside_the_corpus_get_ids_of_their_own():
 	ids = p.token_ids.tolist()
 	assert ids[1] == session.vocab.token_to_id(known) and ids[0] == ids[3] == V and ids[2] == V + 1 and ids[4] == V + 2
 	assert len(index.find(" ".join(unknown), n=3, min_score=-10.0)) == 3
+
+
+def test_find_many_with_a_hook_for_every_slice_equals_find():
+	"""find_many(debug = AllSlices(hook)): the walk over all slices of query i runs while the lane's thread is already inside query
+	i + 1 on the same handle (two concurrent calls on one handle, and `last_scores` of the wrong query).  The handle's
+	lock serialises the calls and the scores of every slice are read under the query's own hold of it: per query, the hook sees what
+	`find` shows it.  Reference: the hook is called per slice inside the matcher, vectorian/core/cpp/metric/alignment.h:145-173."""
+	from vectorian_amd.index import AllSlices
+	session, emb, words, rng = toy_session(n_docs=3, sents_per_doc=20, V=200, d=32)
+	texts = [" ".join(session.documents[i % 3].tokens[7 * i:7 * i + 4]) for i in range(7)]
+	for optimizer in (alignment.LocalAlignment(gap=alignment.LinearGapCost(0.2)), alignment.WordMoversDistance.rwmd("nbow")):
+		index = session.partition("sentence").index(OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), optimizer), corpus_factory=OracleCorpus)
+		calls = []
+		hook = AllSlices(lambda name, data: calls.append((name, data["slice"], float(data["score"]), data.get("worst_score"))), chunk=16)
+		want = []
+		for t in texts:
+			calls.clear()
+			r = index.find(t, n=3, debug=hook)
+			want.append(([(m.doc_index, m.slice_id, m.score) for m in r], list(calls)))
+		calls.clear()
+		many = index.find_many(texts, n=3, in_flight=3, options={"debug": hook})
+		per_query = len(calls) // len(texts)
+		assert per_query * len(texts) == len(calls) == 60 * len(texts)
+		for i, (r, (w_matches, w_calls)) in enumerate(zip(many, want)):
+			assert [(m.doc_index, m.slice_id, m.score) for m in r] == w_matches
+			assert calls[i * per_query:(i + 1) * per_query] == w_calls   # in query order, on the calling thread

@@ -108,8 +108,18 @@ def test_sharded_index(tmp_path):
 	# whole documents as slices (longer than VK_MAX_SENT_LEN): the planted document wins on every rank, rows of the merged winners included
 	ref["documents"] = shard_index_worker.documents_answers(None)
 	assert [rows[0][:2] for rows in ref["documents"]["align"]] == [[1, 0], [4, 0], [6, 0]] and ref["documents"]["rwmd"][0][0][3] == "sparse"
+	# find_many(debug = AllSlices(hook)): every rank's hook walks the slices of its own shard per query (scores as on one GPU); the
+	# two ranks' calls, rank 0 first, are the calls of the unsharded index; the merged matches are the same on both ranks
+	ref_hooks = shard_index_worker.hook_answers(None)
+	got_hooks = [json.load(open(tmp_path / f"index_rank{k}.json"))["hooks"] for k in range(2)]
+	for strategy in ("align", "rwmd"):
+		for k in range(2):
+			assert got_hooks[k][strategy]["matches"] == ref_hooks[strategy]["matches"]
+		for qi, want in enumerate(ref_hooks[strategy]["calls"]):
+			assert got_hooks[0][strategy]["calls"][qi] + got_hooks[1][strategy]["calls"][qi] == want
 	for k in range(2):
 		got = json.load(open(tmp_path / f"index_rank{k}.json"))
+		got.pop("hooks")
 		# Query.abort raised on rank 1 only: no rank hangs in the collective, and the query yields no matches on either rank
 		assert got.pop("abort") == {"batched": [0] * 6, "pipelined": [0] * 6, "find": 0, "rwmd": [0] * 12}
 		assert got == ref

@@ -6,9 +6,13 @@ CPU fallback: if the shared library is missing or no gfx950 device is present th
 calls raise (RuntimeError), they never compute elsewhere.
 """
 
+import atexit
+import collections
 import ctypes as C
 import enum
 import os
+import threading
+import warnings
 
 import numpy as np
 
@@ -309,8 +313,36 @@ def merge_records(records, n_sets, len_t, k):
 	return out
 
 
+# Handles of Corpus objects that were garbage-collected without close().  The collector runs finalizers on whichever thread
+# happens to allocate, possibly while other threads are inside vk_query: a finalizer therefore never frees GPU resources -- it
+# parks the handle here, and the handles are freed at the next safe point of a calling thread (reap(): before a corpus is
+# created, after one is closed, at exit).  The library itself tolerates any order of frees (the arrays handles share are
+# reference-counted, vk_internal.h vk_devblock).
+_graveyard = collections.deque()
+
+
+def reap():
+	"""frees the handles parked by finalizers; returns how many.  Called from the thread that creates / closes corpora."""
+	n = 0
+	while True:
+		try:
+			h = _graveyard.popleft()
+		except IndexError:
+			return n
+		if _lib is not None:
+			_lib.vk_corpus_free(C.c_void_p(h))
+		n += 1
+
+
+atexit.register(reap)
+
+
 class Corpus:
-	"""A corpus shard resident in HBM (opaque vk_corpus_t handle)."""
+	"""A corpus shard resident in HBM (opaque vk_corpus_t handle).
+
+	Lifetime: close() it (Index.close() does, views and filtered corpora first); `with Corpus(...) as c:` works.  A Corpus that
+	is garbage-collected unclosed warns (ResourceWarning) and its handle is parked for reap() -- the finalizer itself makes no GPU
+	call.  A handle serves one call at a time: `lock` is held for the duration of every native call on it (and by close())."""
 
 	takes_q_tags = True   # query(q_tags=...): tag codes of the query tokens (tag-weighted transport over (id, tag) vocabularies)
 
@@ -318,6 +350,8 @@ class Corpus:
 		"""precision: "bf16" (unit rows rounded to bf16, the fast path) or "f32" (the reference's own precision, twice the bytes)"""
 		if device is not None:
 			init(device)
+		reap()
+		self.lock = threading.RLock()
 		self._h = C.c_void_p()
 		desc = _CorpusDesc(layout, d, n_tokens, n_sentences, vocab_size, int(keep_magnitudes), {"bf16": VK_PREC_BF16, "f32": VK_PREC_F32}[precision])
 		_check(lib().vk_corpus_create(C.byref(desc), C.byref(self._h)))
@@ -455,7 +489,8 @@ class Corpus:
 		rows = self._winner_rows()
 		out = TopK(max(1, q.max_matches), len_t, transport=bool(q.want_flow) and (q.algorithm != VK_ALG_ALIGN or bool(options.get("want_rows"))), rows=rows)
 		so = out._struct()
-		_check(lib().vk_query(self._h, C.byref(q), C.byref(so)))
+		with self.lock:
+			_check(lib().vk_query(self._h, C.byref(q), C.byref(so)))
 		out.n = so.n_out
 		return out
 
@@ -497,7 +532,8 @@ class Corpus:
 				(n <= 16 or (q.algorithm == VK_ALG_RWMD and not q.wmd_full)), rows=self._winner_rows())
 			outs.append(t)
 			sos[i] = t._struct()
-		_check(lib().vk_query_batch(self._h, qs, n, sos))
+		with self.lock:
+			_check(lib().vk_query_batch(self._h, qs, n, sos))
 		for t, so in zip(outs, sos):
 			t.n = so.n_out
 		return outs
@@ -507,6 +543,10 @@ class Corpus:
 		descriptors filled by pointer arithmetic (256 queries: 6 ms of per-query numpy / ctypes work otherwise)"""
 		n = len(queries)
 		if per_query or n < 8:
+			return None
+		if getattr(self, "_max_len", 0) > VK_FAST_SENT_LEN:
+			# a corpus with slices of more than 64 tokens is answered query by query (vk_query_batch): per-query result sets sized by
+			# that query -- one [n x k x R x 16] block with R = the longest slice would be gigabytes for documents (256 x 10 x 32768)
 			return None
 		arrs = [np.asarray(q) for q in queries]
 		if any(a.ndim != 2 or a.shape[1] != self.d or a.shape[0] < 1 or a.dtype != arrs[0].dtype for a in arrs):
@@ -567,41 +607,61 @@ class Corpus:
 
 	def last_scores(self):
 		s = np.empty(self.n_sentences, dtype=np.float32)
-		_check(lib().vk_last_scores(self._h, _np_ptr(s), len(s)))
+		with self.lock:
+			_check(lib().vk_last_scores(self._h, _np_ptr(s), len(s)))
 		return s
 
 	def last_timings(self):
 		t = _Timings()
-		_check(lib().vk_last_timings(self._h, C.byref(t)))
+		with self.lock:
+			_check(lib().vk_last_timings(self._h, C.byref(t)))
 		return {k: getattr(t, k) for k, _ in _Timings._fields_}
 
 	def view(self):
 		"""a second handle on the same resident corpus (vk_corpus_view): own stream and workspaces, shared arrays.
 		Queries on different handles may run from different threads at the same time."""
 		v = Corpus.__new__(Corpus)
-		v.__dict__.update({k: val for k, val in self.__dict__.items() if k != "_h"})
+		v.__dict__.update({k: val for k, val in self.__dict__.items() if k not in ("_h", "lock")})
 		v._h = C.c_void_p()
-		v._owner = self   # the shared arrays live as long as the owning handle: keep it alive
-		_check(lib().vk_corpus_view(self._h, C.byref(v._h)))
+		v.lock = threading.RLock()
+		with self.lock:
+			_check(lib().vk_corpus_view(self._h, C.byref(v._h)))
 		return v
 
 	def filtered(self, pos_mask=0, tag_mask=0):
 		"""the corpus without the tokens whose POS / tag code has its bit set in the masks (vk_corpus_filter;
 		TokenFilter, vectorian/core/cpp/query.h:8-28): same slices, re-indexed; built once on the device"""
 		f = Corpus.__new__(Corpus)
-		f.__dict__.update({k: val for k, val in self.__dict__.items() if k != "_h"})
+		f.__dict__.update({k: val for k, val in self.__dict__.items() if k not in ("_h", "lock")})
 		f._h = C.c_void_p()
-		f._owner = self   # static layout: the vocabulary vectors stay the source's
-		_check(lib().vk_corpus_filter(self._h, C.c_uint64(int(pos_mask)), C.c_uint64(int(tag_mask)), C.byref(f._h)))
+		f.lock = threading.RLock()
+		reap()
+		with self.lock:
+			_check(lib().vk_corpus_filter(self._h, C.c_uint64(int(pos_mask)), C.c_uint64(int(tag_mask)), C.byref(f._h)))
 		return f
 
 	def close(self):
-		if self._h:
-			lib().vk_corpus_free(self._h)
-			self._h = C.c_void_p()
+		"""frees the handle (idempotent).  Waits for a call in progress on THIS handle; other handles of the corpus may be mid-call
+		(the arrays they share are reference-counted in the library)."""
+		with self.lock:
+			h, self._h = self._h, C.c_void_p()
+			if h:
+				lib().vk_corpus_free(h)
+		reap()
+
+	def __enter__(self):
+		return self
+
+	def __exit__(self, *exc):
+		self.close()
 
 	def __del__(self):
-		try:
-			self.close()
-		except Exception:
-			pass
+		# never a GPU call from a finalizer (module docstring of _graveyard): park the handle, warn
+		h = self.__dict__.get("_h")
+		if h:
+			_graveyard.append(h.value)
+			self.__dict__["_h"] = C.c_void_p()
+			try:
+				warnings.warn("vectorian_amd Corpus was garbage-collected without close(); its handle is queued for core.reap()", ResourceWarning, source=self)
+			except Exception:
+				pass   # interpreter shutdown

@@ -4,6 +4,7 @@
 // would compute returns VK_ERR_NO_DEVICE / VK_ERR_HIP.
 
 #include "vk_internal.h"
+#include "vk_guard.h"
 #include "vk_transport_host.h"
 
 #include <chrono>
@@ -25,7 +26,7 @@ static bool same_gap(const vk_gap &a, const vk_gap &b, int upto) {
 // packed16: the queries' 16-row tiles as vk_pack_query lays them out, tile_bytes apart, when the caller has packed them already
 // (the GEMM path: packing 256 queries a second time, on one thread, cost 12 ms per batch); null: packed here
 static int batch_winner_rows(vk_corpus *c, const vk_query_desc *qs, int n_queries, vk_topk_out *outs, const uint64_t *keys, int kk, int k, hipStream_t st,
-	const uint8_t *packed16 = nullptr) {
+	vk_host_keep &keep, const uint8_t *packed16 = nullptr) {
 	int rc;
 	// which of a query's kk candidates are restated: its k best, and of the runners-up those the k-th could lose its place to -- a
 	// score of the scoring pass within rounding (2e-5, ten times what MFMA accumulation was seen to differ by) of the k-th's.
@@ -73,9 +74,9 @@ static int batch_winner_rows(vk_corpus *c, const vk_query_desc *qs, int n_querie
 		if ((rc = alloc_t(c, &c->d_brows, cap_cand * 64 * 16))) return rc;
 		c->bcand_cap = cap_cand;
 	}
-	std::vector<uint8_t> qt, one;
-	std::vector<uint64_t> hk(n_cand, 0);
-	std::vector<int32_t> hq(n_cand, 0);
+	std::vector<uint8_t> &qt = keep.vec<uint8_t>(), one;
+	std::vector<uint64_t> &hk = keep.vec<uint64_t>(n_cand, 0);
+	std::vector<int32_t> &hq = keep.vec<int32_t>(n_cand, 0);
 	float mags[VK_MAX_QUERY_LEN];
 	if (!packed16) qt.assign((size_t)n_queries * c->tile_bytes, 0);
 	for (int i = 0; i < n_queries; i++) {
@@ -165,11 +166,23 @@ static int batch_winner_rows(vk_corpus *c, const vk_query_desc *qs, int n_querie
 // Queries with common options over a contextual corpus: up to 4 queries share one pass over the token tiles
 // (vk_score_batch_kernel).  Returns VK_ERR_UNSUPPORTED (without setting an error) when the batch does not qualify;
 // the caller then runs the queries one by one.
-static int query_batch_shared_pass(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, vk_topk_out *outs) {
+static int query_batch_shared_pass(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, vk_topk_out *outs, vk_host_keep &keep) {
 	if (n_queries < 2 || !c->finalized || c->prec != 0 || c->desc.layout != VK_LAYOUT_CONTEXTUAL || c->n_long_groups > 0 || c->max_len > VK_FAST_SENT_LEN || c->desc.n_sentences < 1) return VK_ERR_UNSUPPORTED;
 	if (c->nk32 > 10 && !getenv("VK_BATCH_QB")) return VK_ERR_UNSUPPORTED;   // measured: no gain over single queries for 768-d rows (the kernel pipelines tiles of <= 10 K-steps)
 	const vk_query_desc &q0 = qs[0];
-	if (q0.max_matches > 64) return VK_ERR_UNSUPPORTED;
+	{
+		// The wave-streaming selection of a batch holds at most 64 keys per query, and queries whose winners are restated (alignments
+		// with traceback; relaxed WMD with similarity rows) select k + 8 candidates as vk_query does: beyond k = 56 such a batch is
+		// answered query by query, with the full margin (round 3 shrank the margin to 64 - k instead: at k = 64 no runner-up was restated
+		// and a near tie could differ from vk_query).  A batch in which only SOME result sets carry sim_rows would be restated for none:
+		// per query as well.
+		bool all_rows = true, any_rows = false;
+		for (int i = 0; i < n_queries; i++) { all_rows = all_rows && outs[i].sim_rows != nullptr; any_rows = any_rows || outs[i].sim_rows != nullptr; }
+		const bool align0 = q0.algorithm == VK_ALG_ALIGN;
+		if (!align0 && q0.want_flow && any_rows && !all_rows) return VK_ERR_UNSUPPORTED;
+		const bool restated = q0.want_flow && (align0 || all_rows);
+		if (q0.max_matches + (restated ? 8 : 0) > 64) return VK_ERR_UNSUPPORTED;
+	}
 	int max_len_t = 0;
 	for (int i = 0; i < n_queries; i++) {
 		const vk_query_desc &q = qs[i];
@@ -196,13 +209,13 @@ static int query_batch_shared_pass(vk_corpus_t *c, const vk_query_desc *qs, int3
 	bool canon_tr = !is_align && q0.want_flow;
 	for (int i = 0; i < n_queries; i++) canon_tr = canon_tr && outs[i].sim_rows != nullptr;
 	const bool margin = (q0.want_flow && is_align) || canon_tr;
-	const int kk = margin ? std::min(k + 8, 64) : k;
+	const int kk = margin ? k + 8 : k;   // (<= 64: checked above)
 	const float sel_floor = margin ? q0.min_score - 1e-5f * std::max(1.0f, std::fabs(q0.min_score)) : q0.min_score;
 
 	// ---- common options: gap tables, DP form
 	VkScoreBatchParams p{};
 	const int ks = q0.gap_s.kind, kt = q0.gap_t.kind;
-	float ws[kGapTable], wt[160] = {0};   // wt[80..159]: the subadditive closure of w_t
+	float *ws = keep.array<float>(kGapTable), *wt = keep.array<float>(160);   // wt[80..159]: the subadditive closure of w_t
 	if (!is_align) {
 		p.gap_mode = 4; p.rwmd_symmetric = q0.rwmd_symmetric; p.rwmd_normalize_bow = q0.rwmd_normalize_bow;
 	} else if (ks == VK_GAP_LINEAR && kt == VK_GAP_LINEAR) {
@@ -266,9 +279,8 @@ static int query_batch_shared_pass(vk_corpus_t *c, const vk_query_desc *qs, int3
 		if ((rc = alloc_t(c, &c->d_bkeys[1], need_k))) return rc;
 		c->bkeys_cap = need_k;
 	}
-	VK_HIP(hipMemcpyAsync(c->d_ws, ws, sizeof ws, hipMemcpyHostToDevice, st));
-	VK_HIP(hipMemcpyAsync(c->d_wt, wt, sizeof wt, hipMemcpyHostToDevice, st));
-	std::vector<float> boost_rows;
+	VK_HIP(hipMemcpyAsync(c->d_ws, ws, kGapTable * sizeof(float), hipMemcpyHostToDevice, st));
+	VK_HIP(hipMemcpyAsync(c->d_wt, wt, 160 * sizeof(float), hipMemcpyHostToDevice, st));
 	if (q0.boost) {
 		if (!c->d_boost) { rc = alloc_t(c, &c->d_boost, (size_t)n + 8); if (rc) return rc; }
 		VK_HIP(hipMemcpyAsync(c->d_boost, q0.boost, (size_t)n * 4, hipMemcpyHostToDevice, st));   // no long slices: rows == slices
@@ -280,8 +292,12 @@ static int query_batch_shared_pass(vk_corpus_t *c, const vk_query_desc *qs, int3
 	if (q0.want_flow && q0.algorithm == VK_ALG_ALIGN) p.raw = nullptr;   // the flow kernel restates the winners' aligner scores; nothing else reads the array (no submatch weights here)
 
 	float score_ms_total = 0.0f, total_ms = 0.0f;
-	std::vector<uint8_t> all(need_q), one;
+	std::vector<uint8_t> &all = keep.vec<uint8_t>(need_q), one;
 	float mags[VK_MAX_QUERY_LEN];
+	// (host ends of the copies below: one set for all passes -- every pass ends synchronised)
+	std::vector<uint64_t> &keys = keep.vec<uint64_t>((size_t)qb_max * kk);
+	std::vector<float> &raw = keep.vec<float>((size_t)qb_max * kk), &sim = keep.vec<float>((size_t)qb_max * kk * 16);
+	std::vector<int16_t> &map = keep.vec<int16_t>((size_t)qb_max * kk * 16);
 	for (int base = 0; base < n_queries; base += qb_max) {
 		const int qb = std::min(qb_max, n_queries - base);
 		// Query::abort (query.h:183-189): polled between the passes; the queries before `base` are complete
@@ -330,14 +346,11 @@ static int query_batch_shared_pass(vk_corpus_t *c, const vk_query_desc *qs, int3
 			}
 		}
 		VK_HIP(hipEventRecord(c->ev[4], st));
-		std::vector<uint64_t> keys((size_t)qb * kk);
-		std::vector<float> raw((size_t)qb * kk), sim((size_t)qb * kk * 16);
-		std::vector<int16_t> map((size_t)qb * kk * 16);
 		VK_HIP(hipMemcpy2DAsync(keys.data(), (size_t)kk * 8, c->d_bkeys[cur], (size_t)stride * 8, (size_t)kk * 8, (size_t)qb, hipMemcpyDeviceToHost, st));
 		if (do_flow) {
-			VK_HIP(hipMemcpyAsync(raw.data(), c->d_out_raw, raw.size() * 4, hipMemcpyDeviceToHost, st));
-			VK_HIP(hipMemcpyAsync(map.data(), c->d_out_map, map.size() * 2, hipMemcpyDeviceToHost, st));
-			VK_HIP(hipMemcpyAsync(sim.data(), c->d_out_sim, sim.size() * 4, hipMemcpyDeviceToHost, st));
+			VK_HIP(hipMemcpyAsync(raw.data(), c->d_out_raw, (size_t)qb * kk * 4, hipMemcpyDeviceToHost, st));
+			VK_HIP(hipMemcpyAsync(map.data(), c->d_out_map, (size_t)qb * kk * 16 * 2, hipMemcpyDeviceToHost, st));
+			VK_HIP(hipMemcpyAsync(sim.data(), c->d_out_sim, (size_t)qb * kk * 16 * 4, hipMemcpyDeviceToHost, st));
 		}
 		VK_HIP(hipStreamSynchronize(st));
 		for (int i = 0; i < qb && !canon_tr; i++) {   // (relaxed WMD with flows: batch_winner_rows below writes the result sets)
@@ -388,7 +401,7 @@ static int query_batch_shared_pass(vk_corpus_t *c, const vk_query_desc *qs, int3
 			}
 			out->n_out = n_out;
 		}
-		if (canon_tr && (rc = batch_winner_rows(c, qs + base, qb, outs + base, keys.data(), kk, k, st))) return rc;
+		if (canon_tr && (rc = batch_winner_rows(c, qs + base, qb, outs + base, keys.data(), kk, k, st, keep))) return rc;
 		float ms = 0;
 		if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) score_ms_total += ms;
 		if (hipEventElapsedTime(&ms, c->ev[0], c->ev[4]) == hipSuccess) total_ms += ms;
@@ -432,8 +445,8 @@ static int build_batch_layout(vk_corpus *c, int gran) {
 		if ((rc = alloc_t(c, &B.len, (size_t)B.n))) return rc;
 		if ((rc = alloc_t(c, &B.id, (size_t)B.n))) return rc;
 		VK_HIP(hipMemsetAsync(B.tiles + (size_t)B.n * tps * c->tile_bytes, 0, (size_t)c->tile_bytes, c->stream));
-		VK_HIP(hipMemcpyAsync(B.len, lens[b].data(), (size_t)B.n * 4, hipMemcpyHostToDevice, c->stream));
-		VK_HIP(hipMemcpyAsync(B.id, ids[b].data(), (size_t)B.n * 4, hipMemcpyHostToDevice, c->stream));
+		VK_HIP(hipMemcpy(B.len, lens[b].data(), (size_t)B.n * 4, hipMemcpyHostToDevice));   // (blocking: the host vectors are this function's)
+		VK_HIP(hipMemcpy(B.id, ids[b].data(), (size_t)B.n * 4, hipMemcpyHostToDevice));
 		VK_HIP(vk_launch_batch_pack(c->d_tiles, B.tiles, B.id, c->d_sent_start, c->d_sent_end, B.n, tps, c->tile_bytes, c->stream));
 		VK_HIP(hipStreamSynchronize(c->stream));   // the host vectors go out of scope
 	}
@@ -441,15 +454,9 @@ static int build_batch_layout(vk_corpus *c, int gran) {
 	return VK_OK;
 }
 
-extern "C" {
-
-int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, vk_topk_out *outs) {
-	if (!c || !qs || !outs || n_queries < 0) return fail(VK_ERR_INVALID, "null argument");
-	if (n_queries == 0) return VK_OK;
-	if (qs[0].abort && *qs[0].abort) {
-		for (int i = 0; i < n_queries; i++) outs[i].n_out = 0;
-		return fail(VK_ERR_ABORTED, "batch aborted by the caller");
-	}
+// Every host buffer that is the source or the destination of an asynchronous copy lives in `keep` (owned by vk_query_batch below,
+// which drains the stream before the buffers die when this body fails or is aborted: vk_guard.h).
+static int query_batch_body(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, vk_topk_out *outs, vk_host_keep &keep) {
 	// the GEMM path: injective RWMD, contextual layout, one sentence length (multiple of 16), common options
 	// (uniform corpora of 16 / 32 / 48 / 64-token sentences run on the resident tiles; any other corpus of slices of at most 64
 	// tokens on a padded copy, bucket by bucket)
@@ -457,6 +464,12 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 	// (the kernels address a score row by a 32-bit sentence offset: 9 x n_sentences must stay below 2^31)
 	bool gemm = c->finalized && c->prec == 0 && c->desc.layout == VK_LAYOUT_CONTEXTUAL && c->desc.n_sentences > 0 && c->desc.n_sentences < (1ll << 27) && qs[0].max_matches <= 64 &&
 		vk_rwmd_batch_supported(c->nk32, c->tail) && (uniform16 || (c->max_len <= VK_FAST_SENT_LEN && c->entry_sent.empty() && !getenv("VK_BATCH_NO_RAGGED")));
+	{   // as in the shared pass: restated winners need k + 8 <= 64 keys per query, and every result set or none carries sim_rows
+		bool all_rows = true, any_rows = false;
+		for (int i = 0; i < n_queries; i++) { all_rows = all_rows && outs[i].sim_rows != nullptr; any_rows = any_rows || outs[i].sim_rows != nullptr; }
+		if (qs[0].want_flow && any_rows && !all_rows) gemm = false;
+		if (qs[0].want_flow && all_rows && qs[0].max_matches + 8 > 64) gemm = false;
+	}
 	for (int i = 0; i < n_queries && gemm; i++) {
 		const vk_query_desc &q = qs[i];
 		gemm = q.len_t <= VK_FAST_QUERY_LEN && q.algorithm == VK_ALG_RWMD && q.rwmd_injective && !q.wmd_full && q.rwmd_symmetric == qs[0].rwmd_symmetric &&
@@ -464,7 +477,7 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 			q.min_score == qs[0].min_score && q.boost == qs[0].boost && !q.tag_weights;
 	}
 	if (!gemm) {
-		const int rcb = query_batch_shared_pass(c, qs, n_queries, outs);
+		const int rcb = query_batch_shared_pass(c, qs, n_queries, outs, keep);
 		if (rcb != VK_ERR_UNSUPPORTED) return rcb;
 		for (int i = 0; i < n_queries; i++) {
 			const int rc = vk_query(c, &qs[i], &outs[i]);   // polls the query's abort flag
@@ -526,7 +539,7 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 	// with flows: k + 8 candidates per query, restated on the host from their canonical rows; the k best are kept (batch_winner_rows)
 	bool canon_tr = qs[0].want_flow != 0;
 	for (int i = 0; i < n_queries; i++) canon_tr = canon_tr && outs[i].sim_rows != nullptr;
-	const int kk = canon_tr ? std::min(k + 8, 64) : k;
+	const int kk = canon_tr ? k + 8 : k;   // (<= 64: checked above)
 	const float sel_floor = canon_tr ? qs[0].min_score - 1e-5f * std::max(1.0f, std::fabs(qs[0].min_score)) : qs[0].min_score;
 	const int64_t nw1 = (n + 4095) / 4096;
 	const size_t need_k = (size_t)n_queries * (size_t)nw1 * (size_t)kk;
@@ -538,12 +551,12 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 	}
 
 	VK_HIP(hipEventRecord(c->ev[0], st));
-	std::vector<uint8_t> all((size_t)need_q, 0);
-	std::vector<int32_t> qlen((size_t)n_queries);
+	std::vector<uint8_t> &all = keep.vec<uint8_t>((size_t)need_q, 0);
+	std::vector<int32_t> &qlen = keep.vec<int32_t>((size_t)n_queries);
 	// the queries' 16-row tiles are kept when the winners' similarity rows will be asked for (batch_winner_rows)
 	bool rows_wanted = false;
 	for (int i = 0; i < n_queries; i++) rows_wanted |= qs[i].want_flow && outs[i].sim_rows;
-	std::vector<uint8_t> tiles16(rows_wanted ? (size_t)n_queries * c->tile_bytes : 0, 0);
+	std::vector<uint8_t> &tiles16 = keep.vec<uint8_t>(rows_wanted ? (size_t)n_queries * c->tile_bytes : 0, 0);
 	// normalise, round and lay out the queries: a few host threads over disjoint query ranges (256 queries: 1.6 ms on one)
 	auto pack_range = [&](int i0, int i1) {
 	std::vector<uint8_t> one;
@@ -599,13 +612,13 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 	}
 	VK_HIP(hipMemcpyAsync(c->d_bq, all.data(), all.size(), hipMemcpyHostToDevice, st));
 	VK_HIP(hipMemcpyAsync(c->d_bqlen, qlen.data(), qlen.size() * 4, hipMemcpyHostToDevice, st));
-	std::vector<float> qinv((size_t)n_queries);
+	std::vector<float> &qinv = keep.vec<float>((size_t)n_queries);
 	for (int i = 0; i < n_queries; i++) qinv[(size_t)i] = 1.0f / (float)qs[i].len_t;
 	float *d_qinv = reinterpret_cast<float *>(c->d_bqlen + n_queries + 4);
 	VK_HIP(hipMemcpyAsync(d_qinv, qinv.data(), qinv.size() * 4, hipMemcpyHostToDevice, st));
 	// vk_rwmd_batch32_kernel: per A tile the lengths of its queries (as floats) and their reciprocals, 0 for an absent query
 	float *d_qparam = d_qinv + n_queries + 4;
-	std::vector<float> qparam((size_t)(n_qtiles + 1) * 8, 0.0f);
+	std::vector<float> &qparam = keep.vec<float>((size_t)(n_qtiles + 1) * 8, 0.0f);
 	if (dense) qparam.assign((size_t)(n_super + 1) * 32, 0.0f);
 	for (int i = 0; i < n_queries; i++) {
 		if (dense) {   // [query][2]
@@ -625,7 +638,7 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 	// handles on one corpus take turns, as in vk_query: this batch's GEMM starts when the peer's has finished, so that the
 	// selection, the copies and the host part of one batch run beside the GEMM of the next (the wait is on the device)
 	VK_HIP(hipEventRecord(c->ev[5], st));
-	if (c->peer && c->peer->ev2_recorded) VK_HIP(hipStreamWaitEvent(st, c->peer->ev[2], 0));
+	if ((rc = vk_wait_peer_turn(c, st))) return rc;
 	VK_HIP(hipEventRecord(c->ev[1], st));
 	VkRwmdBatchParams p{};
 	p.tiles = c->d_tiles; p.n_tiles = (c->desc.n_tokens + 15) / 16;
@@ -671,7 +684,7 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 	c->ev2_recorded = true;
 	VK_HIP(hipEventRecord(c->ev[3], st));
 	VK_HIP(hipEventRecord(c->ev[4], st));
-	std::vector<uint64_t> keys((size_t)n_queries * (size_t)kk);
+	std::vector<uint64_t> &keys = keep.vec<uint64_t>((size_t)n_queries * (size_t)kk);
 	VK_HIP(hipMemcpy2DAsync(keys.data(), (size_t)kk * 8, c->d_bkeys[cur], (size_t)stride * 8, (size_t)kk * 8, (size_t)n_queries, hipMemcpyDeviceToHost, st));
 	VK_HIP(hipStreamSynchronize(st));
 	for (int i = 0; i < n_queries && !canon_tr; i++) {   // without flows: the scores of the GEMM pass (kk == k)
@@ -697,7 +710,7 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 		}
 		out->n_out = n_out;
 	}
-	if (canon_tr && (rc = batch_winner_rows(c, qs, n_queries, outs, keys.data(), kk, k, st, tiles16.empty() ? nullptr : tiles16.data()))) return rc;
+	if (canon_tr && (rc = batch_winner_rows(c, qs, n_queries, outs, keys.data(), kk, k, st, keep, tiles16.empty() ? nullptr : tiles16.data()))) return rc;
 	c->have_scores = false;
 	float ms = 0;
 	vk_timings t{};
@@ -708,6 +721,21 @@ int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, v
 	if (hipEventElapsedTime(&ms, c->ev[0], c->ev[4]) == hipSuccess) t.total_ms = ms - t.queue_ms;
 	c->last = t;
 	return VK_OK;
+}
+
+extern "C" {
+
+int vk_query_batch(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_queries, vk_topk_out *outs) {
+	if (!c || !qs || !outs || n_queries < 0) return fail(VK_ERR_INVALID, "null argument");
+	if (n_queries == 0) return VK_OK;
+	if (qs[0].abort && *qs[0].abort) {
+		for (int i = 0; i < n_queries; i++) outs[i].n_out = 0;
+		return fail(VK_ERR_ABORTED, "batch aborted by the caller");
+	}
+	// an error or an abort between the passes leaves no copy in flight behind (vk_guard.h)
+	return vk_run_guarded([&](vk_host_keep &keep) { return query_batch_body(c, qs, n_queries, outs, keep); },
+		[&]() { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); },
+		[](const char *what) { return fail(VK_ERR_INVALID, std::string("vk_query_batch: ") + what); });
 }
 
 } // extern "C"

@@ -9,6 +9,32 @@ std::string &vk_error_slot() {
 	return err;
 }
 
+std::mutex &vk_ring_mutex() {
+	static std::mutex mu;
+	return mu;
+}
+
+void vk_devblock::release(void *p) {
+	if (!p) return;
+	{
+		std::lock_guard<std::mutex> g(mu);
+		ptrs.erase(std::remove(ptrs.begin(), ptrs.end(), p), ptrs.end());
+	}
+	(void)hipFree(p);
+}
+
+vk_devblock::~vk_devblock() {
+	(void)hipSetDevice(device);
+	for (void *p : ptrs) if (p) (void)hipFree(p);
+}
+
+int vk_wait_peer_turn(vk_corpus *c, hipStream_t st) {
+	std::lock_guard<std::mutex> g(vk_ring_mutex());
+	vk_corpus *p = c->peer;
+	if (p && p->ev2_recorded.load()) VK_HIP(hipStreamWaitEvent(st, p->ev[2], 0));
+	return VK_OK;
+}
+
 extern "C" {
 
 int vk_abi_version(void) { return VK_ABI_VERSION; }
@@ -50,6 +76,8 @@ int vk_corpus_create(const vk_corpus_desc *desc, vk_corpus_t **out) {
 	vk_corpus *c = new vk_corpus();
 	c->desc = *desc;
 	c->device = dev;
+	c->shared = std::make_shared<vk_devblock>();
+	c->shared->device = dev;
 	c->d_pad = (desc->d + 15) / 16 * 16;
 	c->prec = desc->precision == VK_PREC_F32 ? 1 : 0;
 	if (c->prec) {
@@ -69,11 +97,11 @@ int vk_corpus_create(const vk_corpus_desc *desc, vk_corpus_t **out) {
 		if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = fail(VK_ERR_HIP, "hipStreamCreate failed"); break; }
 		for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { rc = fail(VK_ERR_HIP, "hipEventCreate failed"); break; }
 		if (rc) break;
-		if ((rc = alloc_t(c, &c->d_tiles, (size_t)c->n_tiles * c->tile_bytes))) break;
+		if ((rc = alloc_shared(c, &c->d_tiles, (size_t)c->n_tiles * c->tile_bytes))) break;
 		if (hipMemsetAsync(c->d_tiles, 0, (size_t)c->n_tiles * c->tile_bytes, c->stream) != hipSuccess) { rc = fail(VK_ERR_HIP, "memset failed"); break; }
-		if (desc->keep_magnitudes && (rc = alloc_t(c, &c->d_mag, (size_t)c->rows_total + 16))) break;
+		if (desc->keep_magnitudes && (rc = alloc_shared(c, &c->d_mag, (size_t)c->rows_total + 16))) break;
 		if (desc->layout == VK_LAYOUT_STATIC) {
-			if ((rc = alloc_t(c, &c->d_tok_id, (size_t)desc->n_tokens + 64))) break;
+			if ((rc = alloc_shared(c, &c->d_tok_id, (size_t)desc->n_tokens + 64))) break;
 			if ((rc = alloc_t(c, &c->d_table, (size_t)c->n_tiles * 16 * 16 * 4))) break;   // one [V_pad x 16] table per query tile
 		}
 		if ((rc = alloc_t(c, &c->d_qtile, (size_t)c->tile_bytes * 4))) break;   // up to 4 tiles of 16 query rows
@@ -111,8 +139,9 @@ int vk_corpus_view(vk_corpus_t *src, vk_corpus_t **out) {
 	c->long_group_tiles = src->long_group_tiles; c->long_group_tokens = src->long_group_tokens;
 	c->uniform_len = src->uniform_len;
 	c->is_view = true;
-	c->peer = src->peer ? src->peer : src;
-	src->peer = c;
+	c->shared = src->shared;           // the arrays live as long as any handle names them
+	c->vectors_of = src->vectors_of;
+	c->shares_vectors = src->shares_vectors;
 	int rc = VK_OK;
 	do {
 		if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = fail(VK_ERR_HIP, "hipStreamCreate failed"); break; }
@@ -133,25 +162,33 @@ int vk_corpus_view(vk_corpus_t *src, vk_corpus_t **out) {
 		if ((rc = alloc_t(c, &c->d_keys[1], (nblk * VK_MAX_MATCHES) / 2 + 2 * kTopkChunk))) break;
 	} while (0);
 	if (rc) { vk_corpus_free(c); return rc; }
+	{   // into the ring of the handles on this corpus, once the handle is complete
+		std::lock_guard<std::mutex> g(vk_ring_mutex());
+		c->peer = src->peer ? src->peer : src;
+		src->peer = c;
+	}
 	*out = c;
 	return VK_OK;
 }
 
+// Frees this handle's own stream, events and workspaces.  The arrays it shares with other handles (a corpus and its views, the
+// vocabulary of a filtered static corpus) belong to refcounted blocks and go with the last handle: any order of frees is fine, and
+// a peer that is inside vk_query on another thread keeps everything it reads.  (Calls on ONE handle are the caller's to serialise.)
 int vk_corpus_free(vk_corpus_t *c) {
 	if (!c) return VK_OK;
 	(void)hipSetDevice(c->device);
-	if (c->stream) (void)hipStreamSynchronize(c->stream);
-	if (c->peer) {   // unlink from the ring of handles
-		vk_corpus *p = c->peer;
-		while (p->peer != c) p = p->peer;
-		p->peer = c->peer == p ? nullptr : c->peer;
-		c->peer = nullptr;
+	{   // out of the ring first: from here on no peer reaches this handle's events
+		std::lock_guard<std::mutex> g(vk_ring_mutex());
+		if (c->peer) {
+			vk_corpus *p = c->peer;
+			while (p->peer != c) p = p->peer;
+			p->peer = c->peer == p ? nullptr : c->peer;
+			c->peer = nullptr;
+		}
 	}
-	if (c->is_view) c->d_tiles = nullptr, c->d_mag = nullptr, c->d_tok_id = nullptr, c->d_pos = nullptr, c->d_tag = nullptr,
-		c->d_sent_start = c->d_sent_end = nullptr, c->d_long_groups = nullptr;
-	if (c->shares_vectors) c->d_tiles = nullptr, c->d_mag = nullptr;
-	void *ptrs[] = {c->d_tiles, c->d_mag, c->d_tok_id, c->d_pos, c->d_tag, c->d_sent_start, c->d_sent_end, c->d_stage, c->d_qtile, c->d_ws, c->d_wt, c->d_qids,
-		c->d_table, c->d_scores, c->d_raw, c->d_boost, c->d_keys[0], c->d_keys[1], c->d_out_raw, c->d_out_sim, c->d_out_map, c->d_wrd_raw, c->d_wrd_val, c->d_bq, c->d_bqlen, c->d_bscores, c->d_bkeys[0], c->d_bkeys[1], c->d_long_groups, c->d_counter, c->d_rows_out, c->d_plan_out, c->d_braw, c->d_wrdl_scratch, c->d_wide_scratch, c->d_wide_order, c->d_xlong_order, c->d_apart_order, c->d_bqt, c->d_bcand, c->d_bcandq, c->d_brows, c->d_qbits};
+	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	void *ptrs[] = {c->d_stage, c->d_qtile, c->d_ws, c->d_wt, c->d_qids,
+		c->d_table, c->d_scores, c->d_raw, c->d_boost, c->d_keys[0], c->d_keys[1], c->d_out_raw, c->d_out_sim, c->d_out_map, c->d_wrd_raw, c->d_wrd_val, c->d_bq, c->d_bqlen, c->d_bscores, c->d_bkeys[0], c->d_bkeys[1], c->d_counter, c->d_rows_out, c->d_plan_out, c->d_braw, c->d_wrdl_scratch, c->d_wide_scratch, c->d_wide_order, c->d_xlong_order, c->d_apart_order, c->d_bqt, c->d_bcand, c->d_bcandq, c->d_brows, c->d_qbits};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	if (c->h_brows) (void)hipHostFree(c->h_brows);
 	for (auto &b : c->bl) for (void *p : {(void *)b.tiles, (void *)b.len, (void *)b.id}) if (p) (void)hipFree(p);
@@ -224,7 +261,7 @@ static int set_token_codes(vk_corpus_t *c, int8_t **slot, const int8_t *codes, i
 	if (c->is_view) return fail(VK_ERR_STATE, std::string("set ") + what + " codes on the owning handle, before taking views");
 	VK_HIP(hipSetDevice(c->device));
 	if (!*slot) {
-		int rc = alloc_t(c, slot, (size_t)n + 64);
+		int rc = alloc_shared(c, slot, (size_t)n + 64);
 		if (rc) return rc;
 		VK_HIP(hipMemsetAsync(*slot, 0, (size_t)n + 64, c->stream));
 	}
@@ -306,20 +343,20 @@ static int set_slices_impl(vk_corpus_t *c, const int64_t *start, const int64_t *
 	for (int i = 0; i < 8; i++) { st32.push_back(tail); en32.push_back(tail); }   // padding: empty slices at the end
 
 	// ---- device arrays sized by the table (re-created when the slices are set again)
-	for (void *p : {(void *)c->d_sent_start, (void *)c->d_sent_end, (void *)c->d_scores, (void *)c->d_raw, (void *)c->d_keys[0], (void *)c->d_keys[1],
-			(void *)c->d_boost, (void *)c->d_long_groups})
+	for (void *p : {(void *)c->d_sent_start, (void *)c->d_sent_end, (void *)c->d_long_groups}) c->shared->release(p);
+	for (void *p : {(void *)c->d_scores, (void *)c->d_raw, (void *)c->d_keys[0], (void *)c->d_keys[1], (void *)c->d_boost})
 		if (p) VK_HIP(hipFree(p));
 	c->d_sent_start = c->d_sent_end = nullptr; c->d_scores = c->d_raw = c->d_boost = nullptr; c->d_keys[0] = c->d_keys[1] = nullptr; c->d_long_groups = nullptr;
 	int rc;
-	if ((rc = alloc_t(c, &c->d_sent_start, st32.size()))) return rc;
-	if ((rc = alloc_t(c, &c->d_sent_end, en32.size()))) return rc;
+	if ((rc = alloc_shared(c, &c->d_sent_start, st32.size()))) return rc;
+	if ((rc = alloc_shared(c, &c->d_sent_end, en32.size()))) return rc;
 	if ((rc = alloc_t(c, &c->d_scores, (size_t)n_entries + 8))) return rc;
 	if ((rc = alloc_t(c, &c->d_raw, (size_t)n_entries + 8))) return rc;
 	const size_t nblk = (size_t)((n_entries + kTopkChunk - 1) / kTopkChunk) + 1;
 	if ((rc = alloc_t(c, &c->d_keys[0], nblk * VK_MAX_MATCHES + kTopkChunk))) return rc;
 	if ((rc = alloc_t(c, &c->d_keys[1], (nblk * VK_MAX_MATCHES) / 2 + 2 * kTopkChunk))) return rc;
 	if (!long_groups.empty()) {
-		if ((rc = alloc_t(c, &c->d_long_groups, long_groups.size()))) return rc;
+		if ((rc = alloc_shared(c, &c->d_long_groups, long_groups.size()))) return rc;
 		VK_HIP(hipMemcpy(c->d_long_groups, long_groups.data(), long_groups.size() * 4, hipMemcpyHostToDevice));
 	}
 	VK_HIP(hipMemcpy(c->d_sent_start, st32.data(), st32.size() * 4, hipMemcpyHostToDevice));
@@ -463,13 +500,16 @@ int vk_corpus_filter(vk_corpus_t *src, uint64_t pos_mask, uint64_t tag_mask, vk_
 			// token ids and slices are this handle's, the vocabulary (tiles, magnitudes) stays the source's
 			c = new vk_corpus();
 			c->desc = desc; c->device = src->device;
+			c->shared = std::make_shared<vk_devblock>();
+			c->shared->device = src->device;
 			c->d_pad = src->d_pad; c->nk32 = src->nk32; c->tail = src->tail; c->tile_bytes = src->tile_bytes; c->prec = src->prec;
 			c->rows_total = c->rows_appended = src->rows_total; c->n_tiles = src->n_tiles;
 			c->d_tiles = src->d_tiles; c->d_mag = src->d_mag; c->shares_vectors = true;
+			c->vectors_of = src->shares_vectors ? src->vectors_of : src->shared;   // the vocabulary stays alive with this handle
 			if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(VK_ERR_HIP, "hipStreamCreate failed");
 			for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) return fail(VK_ERR_HIP, "hipEventCreate failed");
 			int r;
-			if ((r = alloc_t(c, &c->d_tok_id, (size_t)n_kept + 64))) return r;
+			if ((r = alloc_shared(c, &c->d_tok_id, (size_t)n_kept + 64))) return r;
 			if ((r = alloc_t(c, &c->d_table, (size_t)c->n_tiles * 16 * 16 * 4))) return r;
 			if ((r = alloc_t(c, &c->d_qtile, (size_t)c->tile_bytes * 4))) return r;
 			if ((r = alloc_t(c, &c->d_ws, kGapTable))) return r;
@@ -493,7 +533,7 @@ int vk_corpus_filter(vk_corpus_t *src, uint64_t pos_mask, uint64_t tag_mask, vk_
 			int8_t *from = which ? src->d_tag : src->d_pos;
 			int8_t **to = which ? &c->d_tag : &c->d_pos;
 			if (!from) continue;
-			int r = alloc_t(c, to, (size_t)n_kept + 64);
+			int r = alloc_shared(c, to, (size_t)n_kept + 64);
 			if (r) return r;
 			VK_HIP(hipMemsetAsync(*to, 0, (size_t)n_kept + 64, st));
 			VK_HIP(vk_launch_filter_gather(from, *to, 1, src_of, n_kept, st));

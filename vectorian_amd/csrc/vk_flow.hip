@@ -769,6 +769,13 @@ __global__ __launch_bounds__(64) void vk_wide_kernel(VkWideParams p) {
 					eprev = e;
 				}
 				wave_lds_fence();
+				if constexpr (GS && !HR && GAPT == 2) {
+					// the history row just stored lives in global memory and is read by OTHER lanes in the next row's candidate scan:
+					// same-wave vector memory is in order, this pins the compiler to it (wavefront scope: no instructions)
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+					__builtin_amdgcn_wave_barrier();
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+				}
 			}
 			if (global) {
 				raw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hprev), len_t - 1));

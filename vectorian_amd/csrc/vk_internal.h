@@ -7,10 +7,12 @@
 #include "vk_device.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -62,6 +64,23 @@ constexpr int kGapTable = 640;   // entries of the gap tables sent to the device
 constexpr int64_t kStageBytes = 64ll << 20;
 
 } // namespace
+
+// Device arrays that several handles read -- a corpus, its views (vk_corpus_view), the filtered corpora of a static layout
+// (vk_corpus_filter shares the vocabulary vectors): owned by a refcounted block, freed when the LAST handle that names them is
+// freed.  The order in which a caller (or a garbage collector) frees the handles of one corpus therefore cannot matter; the reference
+// keeps its results alive the same way (shared_ptr graph, vectorian/core/cpp/result_set.h:17-30).
+struct vk_devblock {
+	int device = 0;
+	std::mutex mu;
+	std::vector<void *> ptrs;
+	void add(void *p) { std::lock_guard<std::mutex> g(mu); ptrs.push_back(p); }
+	void release(void *p);   // free one array now (the slice table is re-created when the slices are set again before finalize)
+	~vk_devblock();
+};
+
+// The ring of the handles on one corpus (vk_corpus::peer) is read by every query of every handle and written by vk_corpus_view /
+// vk_corpus_free, from whichever threads the caller uses: one mutex around insert, unlink and the peer's turn-taking event.
+std::mutex &vk_ring_mutex();
 
 struct vk_corpus {
 	vk_corpus_desc desc{};
@@ -136,10 +155,14 @@ struct vk_corpus {
 	hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // 0 start, 5 before / 1 after the wait for the peer's kernel, 2 scored (the peer's turn), 3 selected, 4 done; 6: the batched GEMM has ended (its turn ends after the selection)
 	vk_timings last{};
 	bool have_scores = false;
-	bool is_view = false;        // shares the corpus arrays of another handle (vk_corpus_view): does not free them
+	bool is_view = false;        // shares the corpus arrays of another handle (vk_corpus_view)
 	bool shares_vectors = false; // a filtered corpus of the static layout: vocabulary tiles and magnitudes belong to its source
-	vk_corpus *peer = nullptr;   // ring of the handles on one corpus: a handle's scoring kernel starts after its peer's
-	bool ev2_recorded = false;   // (device-side wait on ev[2]), so that scoring kernels run back to back, never queued inside each other
+	// who owns the arrays several handles read (d_tiles, d_mag, d_tok_id, d_pos, d_tag, d_sent_start, d_sent_end, d_long_groups):
+	// `shared` the block this handle allocates into (a view: its source's), `vectors_of` the block of the source of a filtered
+	// static corpus (its vocabulary tiles and magnitudes).  The raw pointers above are aliases into these blocks.
+	std::shared_ptr<vk_devblock> shared, vectors_of;
+	vk_corpus *peer = nullptr;   // ring of the handles on one corpus: a handle's scoring kernel starts after its peer's (under vk_ring_mutex)
+	std::atomic<bool> ev2_recorded{false};   // (device-side wait on ev[2]), so that scoring kernels run back to back, never queued inside each other
 };
 
 namespace {
@@ -152,9 +175,19 @@ int alloc(vk_corpus *c, void **p, size_t bytes) {
 
 template <typename T> int alloc_t(vk_corpus *c, T **p, size_t n) { return alloc(c, (void **)p, n * sizeof(T)); }
 
+// an array the views of this corpus read too: owned by the handle's refcounted block
+template <typename T> int alloc_shared(vk_corpus *c, T **p, size_t n) {
+	const int rc = alloc(c, (void **)p, n * sizeof(T));
+	if (rc == VK_OK) c->shared->add((void *)*p);
+	return rc;
+}
+
 } // namespace
 
 // units
+// this handle's scoring kernel starts when its peer's has finished: a device-side wait on the peer's event, taken under the
+// ring's mutex so that the peer cannot be unlinked and destroyed in between (vk_corpus.cpp)
+int vk_wait_peer_turn(vk_corpus *c, hipStream_t st);
 int vk_validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_topk_out *out);
 void vk_pack_query(const vk_corpus *c, const vk_query_desc *q, std::vector<uint8_t> &tile, float *mags);
 

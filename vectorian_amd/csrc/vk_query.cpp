@@ -4,6 +4,7 @@
 // would compute returns VK_ERR_NO_DEVICE / VK_ERR_HIP.
 
 #include "vk_internal.h"
+#include "vk_guard.h"
 #include "vk_transport_host.h"
 
 // The multi-block kernel (vk_score32_kernel) for a query of 17..64 tokens: the gap mode it is launched with, the token tiles a
@@ -56,6 +57,9 @@ int vk_validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_topk_
 	if (q->max_matches < 1 || q->max_matches > VK_MAX_MATCHES) return fail(VK_ERR_INVALID, "max_matches out of range");
 	if (out->capacity < q->max_matches) return fail(VK_ERR_INVALID, "output capacity smaller than max_matches");
 	if (!out->score || !out->sentence) return fail(VK_ERR_INVALID, "output arrays missing");
+	// (the batched paths copy 64 rows per winner into sim_rows at a stride of rows_per_winner: never below 64)
+	if (out->sim_rows && out->rows_per_winner != 0 && (out->rows_per_winner < VK_FAST_SENT_LEN || out->rows_per_winner % 64 != 0 || out->rows_per_winner > VK_MAX_DOC_LEN + 1))
+		return fail(VK_ERR_INVALID, "rows_per_winner must be 0 or a multiple of 64 (64 .. VK_MAX_DOC_LEN + 1)");
 	if (!(q->submatch_weight >= 0.0f)) return fail(VK_ERR_INVALID, "submatch_weight must be >= 0 (pow of a zero base, metric/alignment.h:97-99)");
 	if (q->only_slices) {
 		if (q->n_only < 1 || q->n_only > VK_MAX_MATCHES || q->n_only > out->capacity) return fail(VK_ERR_INVALID, "only_slices: n_only out of range (1 .. min(VK_MAX_MATCHES, capacity))");
@@ -157,12 +161,11 @@ void vk_pack_query(const vk_corpus *c, const vk_query_desc *q, std::vector<uint8
 	}
 }
 
-extern "C" {
-
-int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
-	int rc = vk_validate_query(c, q, out);
-	if (rc) return rc;
-	if (q->abort && *q->abort) { out->n_out = 0; return fail(VK_ERR_ABORTED, "query aborted by the caller"); }
+// One query.  Every host buffer that is the source or the destination of an asynchronous copy lives in `keep`, which the entry point
+// (vk_query below) owns: when this body returns an error with copies still in flight, the entry point synchronises the stream before
+// the buffers die (vk_guard.h).
+static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, vk_host_keep &keep) {
+	int rc = VK_OK;
 	VK_HIP(hipSetDevice(c->device));
 	hipStream_t st = c->stream;
 	const int64_t n = c->n_entries;           // rows of the slice table (== n_sentences unless long slices were padded)
@@ -221,7 +224,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 			if ((rc2 = alloc_t(c, &c->d_wrd_val, (size_t)VK_MAX_MATCHES))) return rc2;
 			c->wrd_cap = VK_MAX_MATCHES;
 		}
-		std::vector<uint64_t> hk((size_t)cnt);
+		std::vector<uint64_t> &hk = keep.vec<uint64_t>((size_t)cnt);
 		for (int i = 0; i < cnt; i++) hk[(size_t)i] = (1ull << 32) | (uint64_t)(uint32_t)rows_idx[(size_t)i];
 		VK_HIP(hipMemcpyAsync(c->d_keys[1], hk.data(), hk.size() * 8, hipMemcpyHostToDevice, c->stream));
 		VkWrdParams w{};
@@ -253,7 +256,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 
 	// ---- prepare: query tile, gap tables, boost, static table -------------
 	VK_HIP(hipEventRecord(c->ev[0], st));
-	std::vector<uint8_t> qtile;
+	std::vector<uint8_t> &qtile = keep.vec<uint8_t>();
 	float qmags[VK_MAX_QUERY_LEN] = {0};
 	// whole documents as slices (beyond VK_MAX_SENT_LEN tokens): scored by the one-wave-per-slice kernel, every winner retraced by it;
 	// the other slices of such a corpus keep their fused kernels when the query has at most 16 tokens (wide_score false)
@@ -275,8 +278,8 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	float qmass_all[VK_MAX_QUERY_LEN] = {0};   // masses of the query tokens (transport algorithms), all 64 columns
 	const int ks = q->gap_s.kind, kt = q->gap_t.kind;
 	const size_t n_ws = std::max<size_t>((size_t)kGapTable, (size_t)c->max_len + 2);   // w_s up to the longest slice
-	std::vector<float> ws(n_ws);
-	float wt[160];   // wt[0..79]: w_t as given; wt[80..159]: its subadditive closure
+	std::vector<float> &ws = keep.vec<float>(n_ws);
+	float *wt = keep.array<float>(160);   // wt[0..79]: w_t as given; wt[80..159]: its subadditive closure
 	const bool is_align = q->algorithm == VK_ALG_ALIGN;
 	if (q->algorithm == VK_ALG_WRD) {
 		p.gap_mode = 5;
@@ -351,9 +354,9 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		wide_sub = wide;
 	}
 	VK_HIP(hipMemcpyAsync(c->d_ws, ws.data(), n_ws * sizeof(float), hipMemcpyHostToDevice, st));
-	VK_HIP(hipMemcpyAsync(c->d_wt, wt, sizeof wt, hipMemcpyHostToDevice, st));
+	VK_HIP(hipMemcpyAsync(c->d_wt, wt, 160 * sizeof(float), hipMemcpyHostToDevice, st));
 
-	std::vector<float> boost_rows;
+	std::vector<float> &boost_rows = keep.vec<float>();
 	if (q->boost) {
 		if (!c->d_boost) { rc = alloc_t(c, &c->d_boost, (size_t)n + 8); if (rc) return rc; }
 		const float *src = q->boost;
@@ -368,9 +371,9 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	const bool is_static = c->desc.layout == VK_LAYOUT_STATIC;
 	const int64_t table_stride = (int64_t)c->n_tiles * 16 * 16;
 	if (is_static) {
-		int32_t ids[80];
+		int32_t *ids = keep.array<int32_t>(80);
 		for (int j = 0; j < 80; j++) ids[j] = (q->q_token_ids && j < q->len_t) ? q->q_token_ids[j] : -1;
-		VK_HIP(hipMemcpyAsync(c->d_qids, ids, sizeof ids, hipMemcpyHostToDevice, st));
+		VK_HIP(hipMemcpyAsync(c->d_qids, ids, 80 * sizeof(int32_t), hipMemcpyHostToDevice, st));
 		for (int t = 0; t < nq && !only; t++)   // one [V_pad x 16] table per 16 query tokens (the traceback kernels restate their cells themselves)
 			VK_HIP(vk_launch_table(c->d_tiles, c->d_qtile + (size_t)t * c->tile_bytes, (int32_t)c->n_tiles, c->nk32, c->tail, c->tile_bytes,
 				c->d_table + t * table_stride, q->q_token_ids ? c->d_qids + t * 16 : nullptr, std::min(16, q->len_t - t * 16), c->desc.vocab_size, c->prec, st));
@@ -380,7 +383,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	// handles on one corpus take turns: this scoring kernel starts when the peer's has finished (its selection and
 	// traceback then run beside this kernel); the wait is on the device, the host does not block
 	VK_HIP(hipEventRecord(c->ev[5], st));
-	if (c->peer && c->peer->ev2_recorded) VK_HIP(hipStreamWaitEvent(st, c->peer->ev[2], 0));
+	if ((rc = vk_wait_peer_turn(c, st))) return rc;
 	VK_HIP(hipEventRecord(c->ev[1], st));
 	p.tiles = c->d_tiles; p.tok_id = c->d_tok_id; p.table = c->d_table; p.sent_start = c->d_sent_start; p.sent_end = c->d_sent_end;
 	p.n_sent = (int32_t)n; p.layout = is_static ? VK_DEV_LAYOUT_STATIC : VK_DEV_LAYOUT_CONTEXTUAL;
@@ -410,7 +413,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	if (vocab_fix) {
 		const size_t words = ((size_t)c->desc.vocab_size + 31) / 32 + 1;
 		if (!c->d_qbits && (rc = alloc_t(c, &c->d_qbits, words))) return rc;
-		std::vector<uint32_t> bits(words, 0);
+		std::vector<uint32_t> &bits = keep.vec<uint32_t>(words, 0u);
 		for (int j = 0; j < q->len_t; j++) {
 			const int32_t id = q->q_token_ids[j];
 			if (id < 0 || id >= c->desc.vocab_size) continue;
@@ -633,7 +636,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 			for (int64_t e = 0; e < n; e++) if (c->entry_sent[(size_t)e] >= 0) c->sent_entry[(size_t)c->entry_sent[(size_t)e]] = (int32_t)e;
 		}
 		const int cnt = q->n_only;
-		std::vector<uint64_t> hk((size_t)cnt);
+		std::vector<uint64_t> &hk = keep.vec<uint64_t>((size_t)cnt);
 		std::vector<int64_t> rows_idx((size_t)cnt);
 		for (int i = 0; i < cnt; i++) {
 			rows_idx[(size_t)i] = c->sent_entry.empty() ? q->only_slices[i] : (int64_t)c->sent_entry[(size_t)q->only_slices[i]];
@@ -662,7 +665,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 			w.scratch = c->d_wrdl_scratch; w.scratch_stride = (int64_t)vk_wrd_long_scratch_bytes();
 			VK_HIP(vk_launch_wrd_exact_long(&w, cnt, st));
 		}
-		std::vector<float> vals((size_t)cnt), raws((size_t)cnt);
+		std::vector<float> &vals = keep.vec<float>((size_t)cnt), &raws = keep.vec<float>((size_t)cnt);
 		VK_HIP(hipMemcpyAsync(vals.data(), c->d_wrd_val, (size_t)cnt * 4, hipMemcpyDeviceToHost, st));
 		VK_HIP(hipMemcpyAsync(raws.data(), c->d_wrd_raw, (size_t)cnt * 4, hipMemcpyDeviceToHost, st));
 		VK_HIP(hipStreamSynchronize(st));
@@ -702,8 +705,8 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		if (!c->d_counter) { rc = alloc_t(c, &c->d_counter, 4); if (rc) return rc; }
 		struct Cand { float val, raw; int64_t g; };
 		std::vector<Cand> best;
-		std::vector<uint64_t> keys;
-		std::vector<float> vals, raws;
+		std::vector<uint64_t> &keys = keep.vec<uint64_t>();
+		std::vector<float> &vals = keep.vec<float>(), &raws = keep.vec<float>();
 		VkWrdParams w{};
 		fill_transport(w);
 		w.mass_mode = q->algorithm == VK_ALG_WRD ? 0 : (q->rwmd_normalize_bow ? 1 : 2);
@@ -767,7 +770,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 			while (!done) {
 				const float theta = (int)best.size() == k ? best.back().val : -INFINITY;
 				VK_HIP(vk_launch_select_ge(c->d_scores, n, theta, q->min_score, c->d_keys[0], c->d_counter, (uint32_t)cap, st));
-				uint32_t count = 0;
+				uint32_t &count = *keep.array<uint32_t>(1);
 				VK_HIP(hipMemcpyAsync(&count, c->d_counter, 4, hipMemcpyDeviceToHost, st));
 				VK_HIP(hipStreamSynchronize(st));
 				if (count == 0) break;
@@ -866,9 +869,9 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		const int M = 512;
 		struct Cand { float val, raw; int64_t row; std::vector<int16_t> map; std::vector<float> sim; };
 		std::vector<Cand> best;
-		std::vector<uint64_t> keys((size_t)M);
-		std::vector<float> raws((size_t)M), sims((size_t)M * ostride);
-		std::vector<int16_t> maps((size_t)M * ostride);
+		std::vector<uint64_t> &keys = keep.vec<uint64_t>((size_t)M);
+		std::vector<float> &raws = keep.vec<float>((size_t)M), &sims = keep.vec<float>((size_t)M * ostride);
+		std::vector<int16_t> &maps = keep.vec<int16_t>((size_t)M * ostride);
 		for (;;) {
 			int nb = 0, cur = 0;
 			VK_HIP(vk_launch_topk_scores(c->d_scores, n, q->min_score, M, c->d_keys[0], &nb, st));
@@ -971,7 +974,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 			c->sent_entry.assign((size_t)c->desc.n_sentences, -1);
 			for (int64_t e = 0; e < n; e++) if (c->entry_sent[(size_t)e] >= 0) c->sent_entry[(size_t)c->entry_sent[(size_t)e]] = (int32_t)e;
 		}
-		std::vector<uint64_t> hk((size_t)q->n_only);
+		std::vector<uint64_t> &hk = keep.vec<uint64_t>((size_t)q->n_only);
 		for (int i = 0; i < q->n_only; i++) {
 			const int64_t row = c->sent_entry.empty() ? q->only_slices[i] : (int64_t)c->sent_entry[(size_t)q->only_slices[i]];
 			hk[(size_t)i] = (1ull << 32) | (uint64_t)(uint32_t)row;
@@ -1004,9 +1007,9 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	VK_HIP(hipEventRecord(c->ev[4], st));
 
 	// ---- results to host ------------------------------------------------------
-	std::vector<uint64_t> keys((size_t)kk);
-	std::vector<float> raw((size_t)kk), sim((size_t)kk * ostride);
-	std::vector<int16_t> map((size_t)kk * ostride);
+	std::vector<uint64_t> &keys = keep.vec<uint64_t>((size_t)kk);
+	std::vector<float> &raw = keep.vec<float>((size_t)kk), &sim = keep.vec<float>((size_t)kk * ostride);
+	std::vector<int16_t> &map = keep.vec<int16_t>((size_t)kk * ostride);
 	VK_HIP(hipMemcpyAsync(keys.data(), c->d_keys[cur], (size_t)kk * 8, hipMemcpyDeviceToHost, st));
 	if (do_flow) {
 		VK_HIP(hipMemcpyAsync(raw.data(), c->d_out_raw, (size_t)kk * 4, hipMemcpyDeviceToHost, st));
@@ -1053,7 +1056,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		}
 		n_out = std::min((int)order.size(), only ? q->n_only : k);
 	}
-	std::vector<float> rows_all;   // canon_tr: similarity rows of every selected slice
+	std::vector<float> &rows_all = keep.vec<float>();   // canon_tr: similarity rows of every selected slice
 	const int rows_R = out->rows_per_winner > 0 ? out->rows_per_winner : VK_FAST_SENT_LEN, rows_W = 16 * ((q->len_t + 15) / 16);
 	if (canon_tr && n_sel > 0) {
 		rows_all.resize((size_t)n_sel * rows_R * rows_W);
@@ -1098,7 +1101,7 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 		}
 		n_out = std::min((int)order.size(), only ? q->n_only : k);
 	}
-	std::vector<float> raw_sel((size_t)std::max(n_out, 1));
+	std::vector<float> &raw_sel = keep.vec<float>((size_t)std::max(n_out, 1));
 	if (!do_flow && !(canon_tr && n_sel > 0) && out->raw_score && n_out > 0) {
 		// gather the aligner scores of the winners
 		for (int i = 0; i < n_out; i++) {
@@ -1149,6 +1152,18 @@ int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
 	if (hipEventElapsedTime(&ms, c->ev[0], c->ev[4]) == hipSuccess) t.total_ms = ms - t.queue_ms;
 	c->last = t;
 	return VK_OK;
+}
+
+extern "C" {
+
+int vk_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out) {
+	const int rc = vk_validate_query(c, q, out);
+	if (rc) return rc;
+	if (q->abort && *q->abort) { out->n_out = 0; return fail(VK_ERR_ABORTED, "query aborted by the caller"); }
+	// an error inside the body leaves no copy in flight behind: the stream is drained before the body's host buffers die
+	return vk_run_guarded([&](vk_host_keep &keep) { return query_body(c, q, out, keep); },
+		[&]() { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); },
+		[](const char *what) { return fail(VK_ERR_INVALID, std::string("vk_query: ") + what); });
 }
 
 int vk_merge_topk(const vk_topk_out *sets, int32_t n_sets, int32_t len_t, int32_t max_matches, vk_topk_out *out) {
