@@ -8,12 +8,14 @@ query upload -> fused similarity (MFMA) + DP kernel -> bounded result set -> flo
 winners -> results on the host (N > 1: + all-gather of the per-rank result sets + merge).
 
   python bench.py --gpus N --steps K --warmup W [--config 2|3|4|5|5wrd|2f32] [--gap exp5|linear]
-                  [--locality local|global|semiglobal] [--sentences n] [--no-extra]
+                  [--locality local|global|semiglobal] [--sentences n] [--no-extra] [--scaling weak|strong]
 
 N > 1 is launched by the driver as
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 Rank 0 prints ONE JSON line.  The corpus is sharded by sentence range (weak scaling: every
 rank holds its own shard of the workload's per-GPU size); the only exchange is the all-gather of k records.
+--scaling strong keeps the configuration's TOTAL fixed instead (config 3: 10 M sentences, config 5: 4 M, configs 2 / 4: 1 M;
+--sentences then names the total) and gives every rank total / N of it: the configurations at their literal sizes for every N.
 
 --config picks the workload of the headline `value` (default 2); at N = 1 the other SURVEY 8(d)
 configurations are then timed as well, each on its own resident corpus at its per-GPU shape, and reported
@@ -44,19 +46,23 @@ K_MATCHES = 10
 LEN_T = 10
 HBM_PEAK = 8.0e12          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_BF16_PEAK = 2.5e15    # MI355X_MICROARCH.md: dense bf16 MFMA (the 5 PF headline includes 2:1 sparsity)
+# VALU issue: 256 CUs x 4 SIMDs, one wave64 vector instruction per 2 cycles and SIMD with two or more waves resident (SIMD-32;
+# MI355X_MICROARCH.md cycle constants: `v_fma_f32` (wave64) 2 cyc, one wave alone 4), at the 2.4 GHz maximum clock.  Wave-level
+# instructions per second, the unit SQ_INSTS_VALU counts in.
+VALU_PEAK = 256 * 4 * 2.4e9 / 2
 
 # the per-GPU shape of each configuration
 WORKLOADS = {
-	"2": dict(name="config2", n_sent=1000000, min_len=32, max_len=32, d=300, alg="align", locality="local", gap="exp5", prec="bf16"),
-	"3": dict(name="config3", n_sent=1250000, min_len=32, max_len=32, d=300, alg="align", locality="global", gap="linear", prec="bf16"),
-	"4": dict(name="config4", n_sent=1000000, min_len=32, max_len=32, d=300, alg="rwmd", locality="local", gap="linear", prec="bf16", batch=256),
-	"5": dict(name="config5_wsb", n_sent=1000000, min_len=8, max_len=64, d=768, alg="align", locality="local", gap="exp5", prec="bf16",
+	"2": dict(name="config2", total=1000000, n_sent=1000000, min_len=32, max_len=32, d=300, alg="align", locality="local", gap="exp5", prec="bf16"),
+	"3": dict(name="config3", total=10000000, n_sent=1250000, min_len=32, max_len=32, d=300, alg="align", locality="global", gap="linear", prec="bf16"),
+	"4": dict(name="config4", total=1000000, n_sent=1000000, min_len=32, max_len=32, d=300, alg="rwmd", locality="local", gap="linear", prec="bf16", batch=256),
+	"5": dict(name="config5_wsb", total=4000000, n_sent=1000000, min_len=8, max_len=64, d=768, alg="align", locality="local", gap="exp5", prec="bf16",
 		noise=0.3, norm_sigma=0.25, magnitudes=True),
-	"5wrd": dict(name="config5_wrd", n_sent=1000000, min_len=8, max_len=64, d=768, alg="wrd", locality="local", gap="linear", prec="bf16",
+	"5wrd": dict(name="config5_wrd", total=4000000, n_sent=1000000, min_len=8, max_len=64, d=768, alg="wrd", locality="local", gap="linear", prec="bf16",
 		noise=0.3, norm_sigma=0.25, magnitudes=True),
 	# config 5's corpus under a batch of 256 relaxed-WMD queries: the GEMM-shaped pass over 768-d rows (round 3: the 32-row kernels with
 	# one fat wave per SIMD; the 16-row kernel of round 2 ran at 0.64 G pairs/s)
-	"5rwmd": dict(name="config5_rwmd_batch", n_sent=1000000, min_len=8, max_len=64, d=768, alg="rwmd", locality="local", gap="linear", prec="bf16",
+	"5rwmd": dict(name="config5_rwmd_batch", total=4000000, n_sent=1000000, min_len=8, max_len=64, d=768, alg="rwmd", locality="local", gap="linear", prec="bf16",
 		noise=0.3, norm_sigma=0.25, magnitudes=True, batch=256),
 	"2f32": dict(name="config2_f32", n_sent=1000000, min_len=32, max_len=32, d=300, alg="align", locality="local", gap="exp5", prec="f32"),
 	# the reference's own layout for static embeddings (fastText / GloVe: token ids + vocabulary table, per-query table [V x |q|],
@@ -66,10 +72,13 @@ WORKLOADS = {
 	"2shared": dict(name="config2_shared_pass", n_sent=1000000, min_len=32, max_len=32, d=300, alg="align", locality="local", gap="exp5", prec="bf16", batch=8, per_pass=2),
 	# whole documents as slices (session.partition("document")): one wave per document, its state in global memory
 	"docs": dict(name="documents_wsb", n_sent=2000, min_n=2000, min_len=500, max_len=5000, d=300, alg="align", locality="local", gap="exp5", prec="bf16",
-		kernel="vk_wide_kernel (one wave per document)", rate_frac=0.03),
+		kernel="vk_wide_kernel (one wave per document)", rate_frac=0.03, bound="valu"),
 	"docslin": dict(name="documents_linear", n_sent=2000, min_n=2000, min_len=500, max_len=5000, d=300, alg="align", locality="local", gap="linear", prec="bf16",
-		kernel="vk_wide_kernel (one wave per document)", rate_frac=0.1),
-	"2static": dict(name="config2_static", n_sent=4000000, min_len=32, max_len=32, d=300, alg="align", locality="local", gap="exp5", prec="bf16", layout="static"),
+		kernel="vk_wide_kernel (one wave per document)", rate_frac=0.1, bound="valu"),
+	"2static": dict(name="config2_static", n_sent=4000000, min_len=32, max_len=32, d=300, alg="align", locality="local", gap="exp5", prec="bf16", layout="static", bound="valu"),
+	# a whole sentence as the query (40 tokens, general gaps): the four-block kernel, VALU-issue bound
+	"2q40": dict(name="config2_q40", n_sent=1000000, min_len=32, max_len=32, d=300, alg="align", locality="local", gap="exp5", prec="bf16", len_t=40,
+		kernel="vk_score32_kernel (four column blocks)", rate_frac=0.27, bound="valu"),
 }
 LOCALITIES = {"local": 0, "global": 1, "semiglobal": 2}
 
@@ -86,6 +95,7 @@ def describe(spec, n_sent):
 	lens = f"{spec['min_len']}" if spec["min_len"] == spec["max_len"] else f"{spec['min_len']}..{spec['max_len']}"
 	rows = f"{n_sent} x {lens} tok x {spec['d']}-d {spec['prec']}" + (f" static layout (ids over {VOCAB} words)" if spec.get("layout") == "static" else " contextual")
 	gap = "WSB general gap 1-2^(-k/5)" if spec["gap"] == "exp5" else "linear gap 0.1"
+	LEN_T = spec.get("len_t", globals()["LEN_T"])
 	if spec["alg"] == "align" and spec.get("batch"):
 		return f"{spec['batch']} x {LEN_T}-tok queries/call over {rows} per GPU, {spec['locality']} {gap}, top-{K_MATCHES}+flow, tiles read once per {spec.get('per_pass', 2)} queries"
 	if spec["alg"] == "rwmd":
@@ -155,9 +165,10 @@ def build_shard(core, torch, spec, n_sent, rank, device):
 	return corpus, E, ids, off
 
 
-def make_queries(E, ids, off, n_queries, seed, static=False):
+def make_queries(E, ids, off, n_queries, seed, static=False, len_t=LEN_T):
 	"""half of the queries are noisy copies of LEN_T consecutive tokens of a corpus sentence (planted hits), half random;
 	static layout: the words themselves (their vectors and vocabulary ids)"""
+	LEN_T = len_t
 	rng = np.random.default_rng(seed)
 	n_sent = len(off) - 1
 	d = E.shape[1]
@@ -292,7 +303,7 @@ class Runner:
 		self.gather_batch = max(1, int(os.environ.get("VK_BENCH_GATHER_BATCH", "4")))   # result sets of this many queries travel in one all-gather
 		self.gather_depth = int(os.environ.get("VK_BENCH_GATHER_DEPTH", "1"))   # a collective gets this many further exchanges to complete before anyone waits for it
 		self.submitted = 0
-		self.score_ms, self.phases, self.retired_at, self.median_gap_ms = [], [], [], None
+		self.score_ms, self.phases, self.retired_at, self.median_gap_ms, self.gap_min_max_ms = [], [], [], None, None
 		gs, gt, _ = gap_spec(gap_name or spec["gap"], spec["max_len"])
 		alg = {"align": core.VK_ALG_ALIGN, "rwmd": core.VK_ALG_RWMD, "wrd": core.VK_ALG_WRD}[spec["alg"]]
 		self.options = dict(algorithm=alg, locality=LOCALITIES[locality or spec["locality"]], gap_s=gs, gap_t=gt, q_normalize=True,
@@ -370,7 +381,10 @@ class Runner:
 			elapsed = time.perf_counter() - t0
 		finally:
 			gc.enable()
-		self.median_gap_ms = float(np.median(np.diff(np.array([t0] + self.retired_at)))) * 1e3 if self.retired_at else None
+		gaps_ = np.diff(np.array([t0] + self.retired_at)) * 1e3 if self.retired_at else None
+		self.median_gap_ms = float(np.median(gaps_)) if gaps_ is not None else None
+		# (the first gap holds the pipeline's fill: the spread is taken over the steps after it)
+		self.gap_min_max_ms = [float(gaps_[1:].min()), float(gaps_[1:].max())] if gaps_ is not None and len(gaps_) > 1 else None
 		if os.environ.get("VK_BENCH_TRACE"):   # where the time between completed queries went (stalls show as single long gaps)
 			gaps = np.diff(np.array([t0] + self.retired_at)) * 1e3
 			top = np.argsort(-gaps)[:4]
@@ -389,6 +403,20 @@ def roofline_of(spec, n_sent, n_tok, kern_s):
 	sentence) pair (bf16 token vectors read once; fp32 rows: * 4; WRD: + 4 bytes of magnitude per token), padding not
 	counted; config 4: 2 * |s| * |q| * d flops per pair against the dense bf16 MFMA peak"""
 	d = spec["d"]
+	LEN_T = spec.get("len_t", globals()["LEN_T"])
+	if spec.get("bound") == "valu":
+		# DP-bound kernels (the static layout, whole documents, queries of 33..64 tokens): neither HBM nor MFMA binds them, the
+		# vector ALU's issue port does.  achieved = wave-level VALU instructions per second: SQ_INSTS_VALU of the dominant kernel
+		# from a kept --pmc pass (profiles/valu.json, per token of the launch: the count is linear in the tokens of a fixed shape)
+		# x this launch's tokens / the kernel's duration, against VALU_PEAK.  GCUPS and the HBM share are stated beside it.
+		nbytes = (4 * n_tok) if spec.get("layout") == "static" else n_tok * d * 2
+		per_tok, src = valu_per_token(spec["name"])
+		ach = per_tok * n_tok / kern_s if per_tok else None
+		return {"bound": "valu", "achieved": (ach / 1e9) if ach else None, "peak": VALU_PEAK / 1e9, "unit": "Ginst/s", "frac": (ach / VALU_PEAK) if ach else None,
+			"kernel": spec.get("kernel") or "vk_score_kernel (static layout)", "kernel_ms": kern_s * 1e3,
+			"valu_insts_per_launch": per_tok * n_tok if per_tok else None, "valu_source": src,
+			"gcups": n_tok * LEN_T / kern_s / 1e9, "hbm_frac": nbytes / kern_s / HBM_PEAK, "algorithmic_bytes_per_launch": nbytes,
+			"note": "VALU-issue bound: wave-level vector instructions/s (SQ_INSTS_VALU) against CUs x 4 SIMDs x 2.4 GHz / 2 cycles"}
 	if spec.get("batch") and spec["alg"] == "align":
 		# shared pass: kern_s is the sum over the call's passes (ceil(batch / per_pass)); one pass streams the corpus once
 		passes = -(-spec["batch"] // spec.get("per_pass", 2))
@@ -416,6 +444,19 @@ def roofline_of(spec, n_sent, n_tok, kern_s):
 	return {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
 		"kernel": spec.get("kernel") or ("vk_score_kernel" + (" (WRD bound pass)" if spec["alg"] == "wrd" else "")), "kernel_ms": kern_s * 1e3,
 		"algorithmic_bytes_per_launch": nbytes}
+
+
+def valu_per_token(name):
+	"""wave-level VALU instructions per corpus token of the configuration's dominant kernel, from the committed counter pass
+	(profiles/valu.json: rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU of this script, tools/pmc_valu.sh) -- not measured in this run"""
+	path = os.path.join(ROOT, "profiles", "valu.json")
+	try:
+		e = json.load(open(path)).get(name)
+	except Exception:
+		e = None
+	if not e or not e.get("tokens_per_launch"):
+		return None, None
+	return e["valu_insts_per_launch"] / e["tokens_per_launch"], "profiles/valu.json (" + e.get("source", "rocprofv3 --pmc SQ_INSTS_VALU") + "); not measured in this run"
 
 
 def traffic_of(name, gap, n_sent, nominal):
@@ -446,7 +487,9 @@ def main():
 	ap.add_argument("--no-cpu-baseline", action="store_true")
 	ap.add_argument("--no-pipeline", action="store_true", help="one handle, one query at a time")
 	ap.add_argument("--no-extra", action="store_true", help="headline workload only (no \"configs\" object)")
-	ap.add_argument("--extra", default="4,3,2f32,2static,2shared,5,5wrd,5rwmd,docs,docslin", help="the other configurations timed at N = 1 after the headline")
+	ap.add_argument("--extra", default="4,3,2f32,2static,2shared,2q40,5,5wrd,5rwmd,docs,docslin", help="the other configurations timed at N = 1 after the headline")
+	ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="weak: every rank holds the configuration's per-GPU shard; "
+		"strong: the configuration's total (config 3: 10 M, config 5: 4 M sentences) is divided among the ranks")
 	ap.add_argument("--extra-steps", type=int, default=12)
 	ap.add_argument("--extra-warmup", type=int, default=4)
 	ap.add_argument("--extra-min-ms", type=float, default=300.0, help="the extra configurations run at least this long inside their timed region")
@@ -533,11 +576,12 @@ def main():
 				keep["shard"] = (corpus, E, ids, off)
 		n_tok = int(off[-1])
 		batch = int(spec.get("batch", 0))
+		len_t = spec.get("len_t", LEN_T)
 		if batch:
 			pool_q = make_queries(E, ids, off, batch + 8, seed=3456)
 			queries = [[pool_q[(i + j) % len(pool_q)] for j in range(batch)] for i in range(warmup + steps)]
 		else:
-			queries = make_queries(E, ids, off, warmup + steps, seed=3456, static=spec.get("layout") == "static")
+			queries = make_queries(E, ids, off, warmup + steps, seed=3456, static=spec.get("layout") == "static", len_t=len_t)
 			if use_dist is not None and spec.get("layout") != "static":   # one query stream for the whole job: rank 0's
 				qt = torch.from_numpy(np.stack(queries)).to(xdev)
 				use_dist.broadcast(qt, src=0)
@@ -572,6 +616,7 @@ def main():
 			"workload": describe(spec, n_sent), "value": pairs / elapsed, "unit": "sentence-alignments/sec",
 			"steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "dtype": spec["prec"],
 			"ms_per_step_median": r.median_gap_ms,   # median time between completed steps: a host stall shows in ms_per_step, not here
+			"step_gap_ms": r.gap_min_max_ms,         # shortest and longest time between two completed steps of the timed region
 			"sentences_per_gpu": n_sent, "tokens_per_gpu": n_tok, "d": spec["d"],
 			"roofline": roofline_of(spec, n_sent, n_tok, kern_s),
 			"phases_ms_mean": {k: float(np.mean([p[k] for p in r.phases])) for k in r.phases[0]} if r.phases else {},
@@ -584,9 +629,16 @@ def main():
 
 	keep = {}
 	head = WORKLOADS[args.config]
-	n_sent = args.sentences or head["n_sent"]
+	if args.scaling == "strong":
+		# the configuration's total, divided: rank r holds sentences [r, r + 1) * (total // world) of the job's corpus
+		total = args.sentences or head.get("total", head["n_sent"])
+		n_sent = max(1, total // world)
+	else:
+		n_sent = args.sentences or head["n_sent"]
 	spec, entry = measure(args.config, n_sent, args.warmup, args.steps, dist, gap=args.gap, locality=args.locality, keep=keep)
 	traffic, traffic_source = traffic_of(spec["name"], spec["gap"], n_sent, head["n_sent"])
+	if entry["roofline"]["bound"] != "hbm":
+		traffic, traffic_source = None, None
 
 	# ---- self-check of the sharded path (tests/test_gpu_bench_ranks.py runs this with two gloo ranks on one GPU)
 	selfcheck = None
@@ -625,8 +677,8 @@ def main():
 
 	def compact_roofline(e):
 		r = e["roofline"]
-		return {"bound": r["bound"], "achieved": round(r["achieved"], 1), "peak": r["peak"], "unit": r["unit"], "frac": round(r["frac"], 4),
-			"kernel": r["kernel"], "kernel_ms": round(r["kernel_ms"], 4)}
+		return {"bound": r["bound"], "achieved": None if r["achieved"] is None else round(r["achieved"], 1), "peak": r["peak"], "unit": r["unit"],
+			"frac": None if r["frac"] is None else round(r["frac"], 4), "kernel": r["kernel"], "kernel_ms": round(r["kernel_ms"], 4)}
 
 	out = full = None
 	if rank == 0:
@@ -640,7 +692,11 @@ def main():
 			"value": round(entry["value"], 1), "unit": "sentence-alignments/sec",
 			"n_gpus": world, "steps": args.steps, "warmup": args.warmup,
 			"ms_per_step": round(entry["ms_per_step"], 4),
-			"higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+			# the timed region is short (steps x ~3 ms): the median and the shortest / longest time between two completed steps say
+			# how far a single slow step (or a slow box) moved `value`
+			"ms_per_step_median": None if entry["ms_per_step_median"] is None else round(entry["ms_per_step_median"], 4),
+			"step_gap_ms": None if entry["step_gap_ms"] is None else [round(x, 4) for x in entry["step_gap_ms"]],
+			"higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
 			"dtype": spec["prec"], "data": "synthetic",
 			"config": {"workload": entry["workload"], "name": spec["name"],
 				"parallelism": f"corpus shards x{world}, RCCL all-gather of k records"},
@@ -650,9 +706,10 @@ def main():
 		if selfcheck is not None:
 			out["selfcheck"] = selfcheck
 		full = dict(out)
-		full["config"] = dict(out["config"], sentences_per_gpu=n_sent, len_s=[spec["min_len"], spec["max_len"]], len_t=LEN_T, d=spec["d"], k=K_MATCHES,
+		full["config"] = dict(out["config"], sentences_per_gpu=n_sent, sentences_total=n_sent * world, len_s=[spec["min_len"], spec["max_len"]], len_t=spec.get("len_t", LEN_T), d=spec["d"], k=K_MATCHES,
 			algorithm=spec["alg"], locality=spec["locality"], gap=spec["gap"], queries_per_step=max(1, int(spec.get("batch", 0))))
 		full["roofline"] = dict(entry["roofline"], traffic=traffic, traffic_source=traffic_source)
+		full["tokens_per_gpu"] = entry["tokens_per_gpu"]
 		full["ms_per_step_median"] = entry["ms_per_step_median"]
 		full["phases_ms_mean"] = entry["phases_ms_mean"]
 
@@ -672,6 +729,8 @@ def main():
 				est_ms = 2.0 * n_x * avg_len * w["batch"] * LEN_T * w["d"] / (0.5 * MFMA_BF16_PEAK) * 1e3
 			elif w.get("layout") == "static":
 				est_ms = n_x * avg_len * LEN_T / 370e9 * 1e3
+			elif w.get("len_t", LEN_T) > 32:
+				est_ms = 9.0 * n_x / 1e6
 			else:
 				est_ms = n_x * avg_len * w["d"] * (4 if w["prec"] == "f32" else 2) / (w.get("rate_frac", 0.8) * HBM_PEAK) * 1e3
 			x_steps = max(args.extra_steps, int(np.ceil(args.extra_min_ms / est_ms)))
@@ -684,9 +743,10 @@ def main():
 				e = {"workload": describe(w, n_x), "error": f"{type(ex).__name__}: {ex}"}
 			configs[w["name"]] = e
 		full["configs"] = configs
-		# [value, kernel_ms, frac of the roofline that bounds it] per configuration; units as the headline's (config4: pairs/s, MFMA)
-		out["roofline"]["by_config"] = {name: ([round(e["value"], 1), round(e["kernel_ms"], 4), round(e["roofline"]["frac"], 4)] if "error" not in e else "error")
-			for name, e in configs.items()}
+		# [value, kernel_ms, frac of the roofline that bounds it, which roofline] per configuration; units as the headline's
+		# (config4: pairs/s against the MFMA peak; "valu": VALU instructions/s against the issue peak, null without a counter pass)
+		out["roofline"]["by_config"] = {name: ([round(e["value"], 1), round(e["kernel_ms"], 4), None if e["roofline"]["frac"] is None else round(e["roofline"]["frac"], 4),
+			e["roofline"]["bound"]] if "error" not in e else "error") for name, e in configs.items()}
 	if keep.get("shard"):
 		keep["shard"][0].close()
 		keep.clear()

@@ -54,6 +54,20 @@ def test_two_ranks_bench_line_and_selfcheck(config, locality):
 	assert sc["ranks_with_winners"] == [0, 1], sc       # winners from both shards: the merge did merge
 
 
+@pytest.mark.parametrize("config", ["3", "5"])
+def test_two_ranks_strong_scaling(config):
+	"""--scaling strong: the configuration's TOTAL (here --sentences 131072, standing in for config 3's 10 M / config 5's 4 M) is
+	divided among the ranks; the line says "strong", value = the total's pairs over the max-over-ranks time, the self-check holds"""
+	total = 131072 if config == "3" else 32768
+	out = run_bench(2, ["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--sentences", str(total), "--config", config, "--scaling", "strong", "--selfcheck"])
+	assert out["n_gpus"] == 2 and out["scaling"] == "strong"
+	assert abs(out["value"] - total * 6 / (out["ms_per_step"] * 6e-3)) / out["value"] < 1e-3    # (total // 2) sentences on each of 2 ranks
+	assert out["ms_per_step_median"] > 0 and len(out["step_gap_ms"]) == 2 and out["step_gap_ms"][0] <= out["ms_per_step_median"] <= out["step_gap_ms"][1] + 1e-9
+	sc = out["selfcheck"]
+	assert sc["ok"], sc
+	assert sc["merged"] == sc["one_corpus"] and set(sc["ranks_with_winners"]) <= {0, 1}, sc
+
+
 def test_one_rank_over_rccl_runs_the_multi_rank_code_path():
 	"""VK_BENCH_FORCE_DIST=1: the N > 1 code path of bench.py with the backend the driver's multi-GPU run uses (torch.distributed
 	"nccl" = RCCL: communicator with a high-priority stream, stdout kept clean of RCCL's banner, all_gather_object of the ranks'

@@ -284,7 +284,67 @@ __device__ __forceinline__ float clip01_bits(int x) { return __builtin_amdgcn_fm
 // maximum of register v.  Halving exchange: at the step for lane bit b a lane keeps the registers whose index bit
 // equals its own lane bit and hands the others to its partner (lane ^ (1 << b)), so the register count halves while
 // the lane span doubles: 8 + 4 + 2 + 1 exchanges (47 instructions) instead of 16 four-step DPP reductions (64+).
-__device__ __forceinline__ int row_transpose_imax16(const int (&v)[16], int lane) {
+#ifndef VK_TR_OLD
+// Round 4: the same halving exchange, started with the lane bits a DPP write mask can select.  bank_mask enables the four quads
+// of a row separately (bank = lane bits 2 and 3), so the steps for lane ^ 4 and lane ^ 8 need no selects at all: two
+// v_max_i32_dpp per register pair, each writing only the quads of one parity -- banks 0, 2 take max(v[2k], v[2k] of lane + 4),
+// banks 1, 3 take max(v[2k + 1], v[2k + 1] of lane - 4); likewise lane ^ 8 through row_ror:8 with banks {0, 1} / {2, 3}.  Those
+// two steps come first, while there are 8 and 4 pairs; the steps inside a quad (lane ^ 1, lane ^ 2; 2 + 1 pairs) take both maxima and
+// one select.  16 + 8 + 6 + 3 = 33 vector instructions instead of 24 + 12 + 10 + 3 = 49, and the selects' results no longer feed
+// DPP reads (each cost two wait states).  Inline asm: the compiler has no partial-write form of update_dpp + max.
+// The register a lane ends up with: bit 0 of its index = lane bit 2, bit 1 = lane bit 3, bit 2 = lane bit 0, bit 3 = lane bit 1.
+__device__ __forceinline__ int row_transpose_reg(int lane) {
+	return ((lane >> 2) & 1) | (((lane >> 3) & 1) << 1) | ((lane & 1) << 2) | (((lane >> 1) & 1) << 3);
+}
+__device__ __forceinline__ int row_transpose_imax16(int (&v)[16], int lane) {
+	// ONE asm block for both masked steps, IN PLACE (the kernel sits at the VGPR cap): the result of pair (2k, 2k + 1) lands in the
+	// register of v[2k] -- banks 0, 2 of it first (they read v[2k] of lane + 4, in banks 1, 3, still untouched), then banks 1, 3 from
+	// v[2k + 1]; the second step pairs the results (0, 2), (4, 6), .. into v[0], v[4], v[8], v[12] likewise.  The compiler's hazard
+	// recogniser does not look into asm, so the distances are kept by hand -- a DPP read needs two wait states behind the vector
+	// write of its source: `s_nop 1` in front (the inputs may have been written just before) and behind (the results are read by DPP
+	// next); inside, every source is at least four instructions old.
+	asm("s_nop 1\n\t"
+		"v_max_i32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+		"v_max_i32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+		"v_max_i32_dpp %2, %2, %2 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+		"v_max_i32_dpp %3, %3, %3 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+		"v_max_i32_dpp %4, %4, %4 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+		"v_max_i32_dpp %5, %5, %5 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+		"v_max_i32_dpp %6, %6, %6 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+		"v_max_i32_dpp %7, %7, %7 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+		"v_max_i32_dpp %0, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+		"v_max_i32_dpp %1, %9, %9 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+		"v_max_i32_dpp %2, %10, %10 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+		"v_max_i32_dpp %3, %11, %11 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+		"v_max_i32_dpp %4, %12, %12 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+		"v_max_i32_dpp %5, %13, %13 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+		"v_max_i32_dpp %6, %14, %14 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+		"v_max_i32_dpp %7, %15, %15 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+		"v_max_i32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+		"v_max_i32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+		"v_max_i32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+		"v_max_i32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+		"v_max_i32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+		"v_max_i32_dpp %2, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+		"v_max_i32_dpp %4, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+		"v_max_i32_dpp %6, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+		"s_nop 1"
+		: "+v"(v[0]), "+v"(v[2]), "+v"(v[4]), "+v"(v[6]), "+v"(v[8]), "+v"(v[10]), "+v"(v[12]), "+v"(v[14])
+		: "v"(v[1]), "v"(v[3]), "v"(v[5]), "v"(v[7]), "v"(v[9]), "v"(v[11]), "v"(v[13]), "v"(v[15]));
+	const int x[4] = {v[0], v[4], v[8], v[12]};
+	const bool b0 = lane & 1, b1 = lane & 2;
+	int y[2];
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		const int u0 = dpp_imax<0xB1>(x[2 * k]), u1 = dpp_imax<0xB1>(x[2 * k + 1]);   // quad_perm [1,0,3,2]: lane ^ 1
+		y[k] = b0 ? u1 : u0;
+	}
+	const int u0 = dpp_imax<0x4E>(y[0]), u1 = dpp_imax<0x4E>(y[1]);                     // quad_perm [2,3,0,1]: lane ^ 2
+	return b1 ? u1 : u0;
+}
+#else
+__device__ __forceinline__ int row_transpose_reg(int lane) { return lane & 15; }
+__device__ __forceinline__ int row_transpose_imax16(int (&v)[16], int lane) {
 	const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
 	const int NEG = (int)0x80000000;
 	int w[8], x[4], y[2];
@@ -308,6 +368,7 @@ __device__ __forceinline__ int row_transpose_imax16(const int (&v)[16], int lane
 	const int keep = b3 ? y[1] : y[0], send = b3 ? y[0] : y[1];
 	return imax(keep, __builtin_amdgcn_update_dpp(NEG, send, 0x128, 0xf, 0xf, false));          // row_ror:8: lane ^ 8
 }
+#endif
 
 // S tiles of one query tile against the wave's two sentences: 2 x NK16 MFMAs, A fragments DEPTH steps ahead.
 // The wave's share of the NEXT query tile (1 KiB pieces wv, wv + 8, wv + 16) leaves as LDS-DMA right after the first MFMA
@@ -419,9 +480,9 @@ __device__ __forceinline__ B32Vals batch32_epilogue(const VkRwmdBatchParams &p, 
 		int m[16];
 #pragma unroll
 		for (int i = 0; i < 16; i++) m[i] = imax(fbits(acc0[i]), fbits(acc1[i]));
-		float z = clip01_bits(row_transpose_imax16(m, lane));    // lane v of the row: maximum of query row v over the sentence
+		float z = clip01_bits(row_transpose_imax16(m, lane));    // this lane: maximum of query row v = row_transpose_reg(lane) over the sentence
 		if (W64) z = fmaxf(z, xor16_f(z));                          // ... over both halves of a 64-token sentence
-		const int v = lane & 15;
+		const int v = row_transpose_reg(lane);
 		s_main = row_sum_to_lane15(v < NMAIN ? z : 0.0f);
 		if (QPT == 3) {
 			s_third = row_sum_to_lane15((v >= 10 && v < 15) ? z : 0.0f);
@@ -554,7 +615,7 @@ __device__ __forceinline__ B32Vals batch32d_epilogue(const VkRwmdBatchParams &p,
 	constexpr bool CLOSES = K == 1 || K == 3 || K == 4;                  // ... and complete it
 	constexpr bool STARTS = K == 0 || K == 1 || K == 3;                  // slots [C_HI, 16) start the next one
 	constexpr int G = K == 1 ? 0 : K == 3 ? 1 : 2;
-	const int h = lane >> 5, v = lane & 15;
+	const int h = lane >> 5, v = row_transpose_reg(lane);   // v: the query row whose maximum over the sentence this lane holds after the transposing exchange
 	const float inv_s = sn.inv_s;
 	const float len_f = super_param[2 * (8 * h + K)], inv_f = super_param[2 * (8 * h + K) + 1];
 	float len_g = 0.0f, inv_g = 0.0f;
