@@ -76,6 +76,10 @@ WORKLOADS = {
 	"docslin": dict(name="documents_linear", n_sent=2000, min_n=2000, min_len=500, max_len=5000, d=300, alg="align", locality="local", gap="linear", prec="bf16",
 		kernel="vk_wide_kernel (one wave per document)", rate_frac=0.1, bound="valu"),
 	"2static": dict(name="config2_static", n_sent=4000000, min_len=32, max_len=32, d=300, alg="align", locality="local", gap="exp5", prec="bf16", layout="static", bound="valu"),
+	# config 4 in the reference's own layout for static embeddings (round 4): ONE similarity table over the vocabulary per batch (an
+	# MFMA GEMM 600 x smaller than config 4's) and one gather pass over the token ids with config 4's epilogues -- VALU / L2 bound
+	"4static": dict(name="config4_static", n_sent=1000000, min_len=32, max_len=32, d=300, alg="rwmd", locality="local", gap="linear", prec="bf16", batch=256,
+		layout="static", bound="valu", kernel="vk_rwmd_static32_kernel (table gather + config 4's epilogues)"),
 	# a whole sentence as the query (40 tokens, general gaps): the four-block kernel, VALU-issue bound
 	"2q40": dict(name="config2_q40", n_sent=1000000, min_len=32, max_len=32, d=300, alg="align", locality="local", gap="exp5", prec="bf16", len_t=40,
 		kernel="vk_score32_kernel (four column blocks)", rate_frac=0.27, bound="valu"),
@@ -311,7 +315,10 @@ class Runner:
 
 	def _run(self, h, q):
 		if self.batch:
-			tops = h.query_batch(q, **self.options)
+			if isinstance(q[0], tuple):   # static layout: the vectors and the vocabulary ids of every query's words
+				tops = h.query_batch([v for v, _ in q], token_ids=[i for _, i in q], **self.options)
+			else:
+				tops = h.query_batch(q, **self.options)
 			return tops, h.last_timings()
 		if isinstance(q, tuple):   # static layout: vectors and vocabulary ids of the query's words
 			top = h.query(q[0], q_token_ids=q[1], **self.options)
@@ -415,7 +422,7 @@ def roofline_of(spec, n_sent, n_tok, kern_s):
 		return {"bound": "valu", "achieved": (ach / 1e9) if ach else None, "peak": VALU_PEAK / 1e9, "unit": "Ginst/s", "frac": (ach / VALU_PEAK) if ach else None,
 			"kernel": spec.get("kernel") or "vk_score_kernel (static layout)", "kernel_ms": kern_s * 1e3,
 			"valu_insts_per_launch": per_tok * n_tok if per_tok else None, "valu_source": src,
-			"gcups": n_tok * LEN_T / kern_s / 1e9, "hbm_frac": nbytes / kern_s / HBM_PEAK, "algorithmic_bytes_per_launch": nbytes,
+			"gcups": n_tok * LEN_T * max(1, int(spec.get("batch", 0))) / kern_s / 1e9, "hbm_frac": nbytes / kern_s / HBM_PEAK, "algorithmic_bytes_per_launch": nbytes,
 			"note": "VALU-issue bound: wave-level vector instructions/s (SQ_INSTS_VALU) against CUs x 4 SIMDs x 2.4 GHz / 2 cycles"}
 	if spec.get("batch") and spec["alg"] == "align":
 		# shared pass: kern_s is the sum over the call's passes (ceil(batch / per_pass)); one pass streams the corpus once
@@ -487,7 +494,7 @@ def main():
 	ap.add_argument("--no-cpu-baseline", action="store_true")
 	ap.add_argument("--no-pipeline", action="store_true", help="one handle, one query at a time")
 	ap.add_argument("--no-extra", action="store_true", help="headline workload only (no \"configs\" object)")
-	ap.add_argument("--extra", default="4,3,2f32,2static,2shared,2q40,5,5wrd,5rwmd,docs,docslin", help="the other configurations timed at N = 1 after the headline")
+	ap.add_argument("--extra", default="4,4static,3,2f32,2static,2shared,2q40,5,5wrd,5rwmd,docs,docslin", help="the other configurations timed at N = 1 after the headline")
 	ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="weak: every rank holds the configuration's per-GPU shard; "
 		"strong: the configuration's total (config 3: 10 M, config 5: 4 M sentences) is divided among the ranks")
 	ap.add_argument("--extra-steps", type=int, default=12)
@@ -578,7 +585,7 @@ def main():
 		batch = int(spec.get("batch", 0))
 		len_t = spec.get("len_t", LEN_T)
 		if batch:
-			pool_q = make_queries(E, ids, off, batch + 8, seed=3456)
+			pool_q = make_queries(E, ids, off, batch + 8, seed=3456, static=spec.get("layout") == "static")
 			queries = [[pool_q[(i + j) % len(pool_q)] for j in range(batch)] for i in range(warmup + steps)]
 		else:
 			queries = make_queries(E, ids, off, warmup + steps, seed=3456, static=spec.get("layout") == "static", len_t=len_t)

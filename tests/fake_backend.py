@@ -239,9 +239,11 @@ class OracleCorpus:
 					top.plan[i, :len(q), :b - a] = G
 		return top
 
-	def query_batch(self, queries, **options):
+	def query_batch(self, queries, token_ids=None, **options):
 		"""vk_query_batch's contract: n_queries calls of vk_query with common options"""
 		self.batch_calls = getattr(self, "batch_calls", 0) + 1
+		if token_ids is not None:
+			return [self.query(q, **dict(options, q_token_ids=t)) for q, t in zip(queries, token_ids)]
 		return [self.query(q, **options) for q in queries]
 
 	def view(self):

@@ -203,3 +203,52 @@ def test_batch_rows_of_relaxed_wmd_winners(hip):
 			np.testing.assert_array_equal(b.sim_rows[:b.n, :, :one.sim_rows.shape[2]], one.sim_rows[:one.n])
 			assert not b.sim_rows[b.n:].any()
 		c.close()
+
+
+@pytest.mark.parametrize("shape,n_q,len_t,flags", [
+	("ragged40", 9, 6, (True, True, True)),        # 3 queries per tile, slices of 1..40 tokens: both length buckets, empty slices
+	("ragged40", 53, 10, (True, True, True)),      # >= 32 ten-token queries: 16 per five tiles (the dense epilogues)
+	("uniform32", 40, 9, (True, False, True)),     # every slice 32 tokens: no bucket lists
+	("ragged64", 7, 16, (True, True, True)),       # queries of up to 16 tokens: 2 per tile; slices of up to 64 tokens
+	("ragged64", 34, 10, (True, False, False)),    # bow
+	("wide", 12, 8, (True, True, True)),           # 96-d rows: no GEMM kernel exists for this width, the table kernel takes any
+])
+def test_static_rwmd_batch(hip, oracle, shape, n_q, len_t, flags):
+	"""vk_query_batch over the static layout (round 4): one similarity table over the vocabulary for the whole batch
+	(vk_table_batch_kernel), one gather pass over the token ids (vk_rwmd_static32_kernel), winners restated from canonical rows with
+	the vocabulary keys -- slice ids and scores equal to vk_query's and to the oracle's bit for bit.
+	Reference: metric/static.cpp:9-78 (table, sim[id(t_j)][j] = 1, clip), slice/static.h:71-75 (gather by token id)."""
+	n, lo, hi, V, d = {"ragged40": (1500, 0, 40, 400, 300), "uniform32": (1003, 32, 32, 300, 300), "ragged64": (900, 1, 64, 500, 128),
+		"wide": (700, 2, 50, 350, 96)}[shape]
+	corpus = synth.make_static_corpus(n, lo, hi, V, d)
+	from helpers import hip_static_corpus
+	c, Eb = hip_static_corpus(hip, corpus)
+	rng = np.random.default_rng(7)
+	qids, qs = [], []
+	for i in range(n_q):
+		ids = rng.integers(0, 60 if i % 2 else V, size=1 + (i * 3) % len_t if i % 5 == 3 else len_t).astype(np.int32)   # frequent words: the query's own ids occur in slices
+		if len(ids) > 3:
+			ids[3] = ids[0]            # a repeated query token: one vocabulary entry of mass 2
+		if i % 7 == 2:
+			ids[-1] = -1               # a word the vocabulary does not hold: no diagonal cell (its vector: some other word's)
+		qids.append(ids)
+		qs.append(Eb[np.where(ids >= 0, ids, 5)])
+	boost = rng.uniform(0.5, 1.5, size=n).astype(np.float32) if shape == "ragged40" else None
+	kw = dict(algorithm=hip.VK_ALG_RWMD, rwmd=flags, q_normalize=False, max_matches=12, min_score=0.0, boost=boost)
+	outs = c.query_batch(qs, token_ids=qids, **kw)
+	assert len(outs) == n_q
+	for Qb, ids, got in zip(qs, qids, outs):
+		one = c.query(Qb, q_token_ids=ids, **kw)
+		assert got.n == one.n and (got.sentence[:got.n] == one.sentence[:one.n]).all()
+		assert (got.score[:got.n].view(np.uint32) == one.score[:one.n].view(np.uint32)).all(), (got.score[:got.n], one.score[:one.n])
+		assert (got.sim_rows[:got.n, :64] == one.sim_rows[:one.n, :64]).all()   # the rows the flows are stated from
+		ref = oracle.find(layout=oracle.LAYOUT_STATIC, d=d, sent_off=corpus["sent_off"], tok_id=corpus["tok_id"], E=Eb, Q=Qb, q_ids=ids,
+			algorithm=oracle.ALG_RWMD, rwmd=flags, max_matches=12, min_score=0.0, boost=boost)
+		assert_same_results(got.trimmed(), ref, check_mapping=False, exact=True)
+	# without flows: the scores of the gather pass itself (MFMA table cells, fp32 sums in another order) within 2e-5 of the oracle's
+	outs = c.query_batch(qs, token_ids=qids, want_flow=False, **kw)
+	for Qb, ids, got in zip(qs, qids, outs):
+		ref = oracle.find(layout=oracle.LAYOUT_STATIC, d=d, sent_off=corpus["sent_off"], tok_id=corpus["tok_id"], E=Eb, Q=Qb, q_ids=ids,
+			algorithm=oracle.ALG_RWMD, rwmd=flags, max_matches=12, min_score=0.0, boost=boost)
+		assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=2e-5, tie_tol=2e-5)
+	c.close()

@@ -377,3 +377,30 @@ def test_find_many_with_a_hook_for_every_slice_on_hip_equals_find(hip, strategy)
 		assert [(m.doc_index, m.slice_id, m.score) for m in r] == w_matches
 		assert calls[i * per_query:(i + 1) * per_query] == w_calls
 	gpu.close()
+
+
+@pytest.mark.parametrize("strategy", ["rwmd", "rwmd_bow", "local"])
+def test_find_many_shares_calls_over_static_embeddings_on_hip(hip, strategy):
+	"""find_many(batch=True) over a STATIC embedding (refused until round 4): relaxed-WMD queries share one table over the vocabulary
+	and one gather pass per call (vk_rwmd_static32_kernel), alignments are answered inside the call; every Result as from find() and
+	as on the oracle double.  Reference path: metric/static.cpp:9-78, slice/static.h:71-75."""
+	from vectorian_amd.alignment import WordMoversDistance
+	session, emb, words, rng = toy_session(n_docs=8, sents_per_doc=60)
+	al = {"local": alignment.LocalAlignment(gap=alignment.smooth_gap_cost(5)), "rwmd": WordMoversDistance.rwmd("nbow"),
+		"rwmd_bow": WordMoversDistance.rwmd("bow/fast")}[strategy]
+	sim = OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), al)
+	gpu = session.partition("sentence").index(sim)
+	cpu = session.partition("sentence").index(sim, corpus_factory=OracleCorpus)
+	texts = [" ".join(session.documents[i % 8].tokens[9 * i:9 * i + 3 + i % 8]) for i in range(40)] + ["w3 w17 zzz-unknown w4", "w1"]
+	many = gpu.find_many(texts, n=6, batch=True)
+	for text, res in zip(texts, many):
+		one, ref = gpu.find(text, n=6), cpu.find(text, n=6)
+		assert [(m.doc_index, m.slice_id) for m in res] == [(m.doc_index, m.slice_id) for m in one] == [(m.doc_index, m.slice_id) for m in ref]
+		assert [m.score for m in res] == [m.score for m in one] == [m.score for m in ref]
+		for a, b in zip(res, one):
+			fa, fb = a.flow, b.flow
+			assert fa["type"] == fb["type"] and set(fa) == set(fb)
+			for key in fa:
+				if key != "type":
+					assert (np.asarray(fa[key]) == np.asarray(fb[key])).all()
+	gpu.close()

@@ -517,8 +517,12 @@ def test_debug_hook_for_every_slice_and_progress():
 	assert np.allclose(admitted, [m.score for m in r], atol=1e-7)
 	# find_many: progress after every query (pipelined path) and after every chunk (batched calls)
 	seen.clear()
-	res = index.find_many([text] * 5, n=2, progress=seen.append)
+	res = index.find_many([text] * 5, n=2, progress=seen.append, batch=False)
 	assert len(res) == 5 and seen == [0.2, 0.4, 0.6, 0.8, 1.0]
+	# static embeddings share calls too since round 4 (one table over the vocabulary per call): one chunk here, the same results
+	seen.clear()
+	shared = index.find_many([text] * 5, n=2, progress=seen.append)
+	assert seen == [1.0] and [[(m.doc_index, m.slice_id, m.score) for m in r] for r in shared] == [[(m.doc_index, m.slice_id, m.score) for m in r] for r in res]
 
 
 def test_matches_are_lazy():

@@ -8,5 +8,5 @@ for v in "$@"; do
 	if [ "$name" != "$v" ]; then envs=${v#*@}; fi
 	lib=""
 	if [ "$name" != "base" ]; then lib="VECTORIAN_HIP_LIB=$(pwd)/vectorian_amd/lib/variants/$name.so"; fi
-	env $lib $envs python bench.py $args --no-extra --no-cpu-baseline 2>/dev/null | python -c "import sys,json; o=json.loads(sys.stdin.read()); print('$v', round(o['value']/1e6,1), 'M/s', round(o['ms_per_step'],3), 'ms/step kernel', round(o['roofline']['kernel_ms'],3), 'frac', round(o['roofline']['frac'],3))"
+	env $lib $envs python bench.py $args --no-extra --no-cpu-baseline 2>/dev/null | python -c "import sys,json; o=json.loads(sys.stdin.read()); print('$v', round(o['value']/1e6,1), 'M/s', round(o['ms_per_step'],3), 'ms/step kernel', round(o['roofline']['kernel_ms'],3), 'frac', o['roofline']['frac'])"
 done; done

@@ -494,10 +494,13 @@ class Corpus:
 		out.n = so.n_out
 		return out
 
-	def query_batch(self, queries, **options):
-		"""A batch of queries with common options (vk_query_batch).  Returns a list of TopK."""
+	def query_batch(self, queries, token_ids=None, **options):
+		"""A batch of queries with common options (vk_query_batch).  Returns a list of TopK.
+		token_ids: static layout -- the vocabulary ids of every query's tokens, a list parallel to `queries` (vk_query_desc.q_token_ids)"""
 		keep = []
 		n = len(queries)
+		if token_ids is not None and len(token_ids) != n:
+			raise ValueError("token_ids must hold one array per query")
 		qs = (_QueryDesc * n)()
 		sos = (_TopkOut * n)()
 		outs = []
@@ -507,13 +510,13 @@ class Corpus:
 		# and POS codes are per query and take the full path)
 		per_query = any(options.get(k) is not None for k in ("q_token_ids", "tag_weights", "q_pos", "q_tags"))
 		first = None
-		fast = self._batch_fast(queries, per_query, options, qs, sos, keep)
+		fast = self._batch_fast(queries, per_query, options, qs, sos, keep, token_ids)
 		if fast is not None:
 			outs = fast
 			queries = ()
 		for i, qv in enumerate(queries):
-			if first is None or per_query:
-				q, len_t = self._desc(qv, keep, **options)
+			if first is None or per_query or token_ids is not None:
+				q, len_t = self._desc(qv, keep, **(options if token_ids is None else dict(options, q_token_ids=token_ids[i])))
 				first = first or q
 			else:
 				qv = np.ascontiguousarray(qv)
@@ -538,7 +541,7 @@ class Corpus:
 			t.n = so.n_out
 		return outs
 
-	def _batch_fast(self, queries, per_query, options, qs, sos, keep):
+	def _batch_fast(self, queries, per_query, options, qs, sos, keep, token_ids=None):
 		"""large batches: the queries in one array (their lengths may differ), one allocation per result field, the
 		descriptors filled by pointer arithmetic (256 queries: 6 ms of per-query numpy / ctypes work otherwise)"""
 		n = len(queries)
@@ -576,6 +579,12 @@ class Corpus:
 		qrows = np.frombuffer(qs, dtype=np.uint8).reshape(n, C.sizeof(_QueryDesc))
 		qrows[:] = np.frombuffer(first, dtype=np.uint8)
 		patch(qrows, _QueryDesc.q_vectors, Q, offsets=row_off[:-1] * self.d)
+		if token_ids is not None:
+			T = np.ascontiguousarray(np.concatenate([np.asarray(t, dtype=np.int32) for t in token_ids]), dtype=np.int32)
+			if len(T) != int(row_off[-1]) or any(len(t) != l for t, l in zip(token_ids, lens)):
+				raise ValueError("token_ids must hold one id per query token")
+			keep.append(T)
+			patch(qrows, _QueryDesc.q_token_ids, T, offsets=row_off[:-1])
 		qrows[:, _QueryDesc.len_t.offset:_QueryDesc.len_t.offset + 4].view(np.int32)[:, 0] = lens
 		proto = _TopkOut()
 		proto.capacity, proto.n_out = k, 0

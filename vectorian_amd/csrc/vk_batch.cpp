@@ -10,6 +10,8 @@
 #include <chrono>
 #include <thread>
 
+static int build_static_buckets(vk_corpus *c);
+
 static bool same_gap(const vk_gap &a, const vk_gap &b, int upto) {
 	if (a.kind != b.kind) return false;
 	if (a.kind != VK_GAP_TABLE) return a.u == b.u && (a.kind == VK_GAP_LINEAR || a.v == b.v);
@@ -45,7 +47,8 @@ static int batch_winner_rows(vk_corpus *c, const vk_query_desc *qs, int n_querie
 		int need = std::min(cnt, k);
 		if (cnt > k) {
 			const float sk = key_score(keys[(size_t)i * kk + k - 1]);
-			const float slack = 2e-5f * std::max(1.0f, std::fabs(sk));
+			// (the static layout's pass ranks on 16-bit cells: its scores sit within 1e-5 of the fp32 ones, the slack is doubled)
+			const float slack = (c->desc.layout == VK_LAYOUT_STATIC ? 4e-5f : 2e-5f) * std::max(1.0f, std::fabs(sk));
 			while (need < cnt && key_score(keys[(size_t)i * kk + need]) >= sk - slack) need++;
 		}
 		first[(size_t)i + 1] = first[(size_t)i] + need;
@@ -77,6 +80,19 @@ static int batch_winner_rows(vk_corpus *c, const vk_query_desc *qs, int n_querie
 	std::vector<uint8_t> &qt = keep.vec<uint8_t>(), one;
 	std::vector<uint64_t> &hk = keep.vec<uint64_t>(n_cand, 0);
 	std::vector<int32_t> &hq = keep.vec<int32_t>(n_cand, 0);
+	// static layout: the token ids of every query, 16 per query (-1: none) -- the rows kernel sets sim[id(t_j)][j] = 1 from them
+	const bool is_static = c->desc.layout == VK_LAYOUT_STATIC;
+	std::vector<int32_t> &hids = keep.vec<int32_t>(is_static ? (size_t)n_queries * 16 : 0, -1);
+	if (is_static) {
+		for (int i = 0; i < n_queries; i++)
+			for (int j = 0; j < qs[i].len_t && j < 16 && qs[i].q_token_ids; j++) hids[(size_t)i * 16 + j] = qs[i].q_token_ids[j];
+		if (c->bqids_cap < hids.size()) {
+			if (c->d_bqids) { VK_HIP(hipFree(c->d_bqids)); c->d_bqids = nullptr; c->bqids_cap = 0; }
+			if ((rc = alloc_t(c, &c->d_bqids, hids.size()))) return rc;
+			c->bqids_cap = hids.size();
+		}
+		VK_HIP(hipMemcpyAsync(c->d_bqids, hids.data(), hids.size() * 4, hipMemcpyHostToDevice, st));
+	}
 	float mags[VK_MAX_QUERY_LEN];
 	if (!packed16) qt.assign((size_t)n_queries * c->tile_bytes, 0);
 	for (int i = 0; i < n_queries; i++) {
@@ -95,7 +111,9 @@ static int batch_winner_rows(vk_corpus *c, const vk_query_desc *qs, int n_querie
 	stamp("uploads issued");
 	VkWrdParams w{};
 	w.tiles = c->d_tiles; w.sent_start = c->d_sent_start; w.sent_end = c->d_sent_end;
-	w.layout = VK_DEV_LAYOUT_CONTEXTUAL; w.nk32 = c->nk32; w.tail = c->tail; w.tile_bytes = c->tile_bytes; w.prec = c->prec;
+	w.layout = is_static ? VK_DEV_LAYOUT_STATIC : VK_DEV_LAYOUT_CONTEXTUAL;
+	if (is_static) { w.tok_id = c->d_tok_id; w.q_ids = c->d_bqids; w.q_ids_stride = 16; }
+	w.nk32 = c->nk32; w.tail = c->tail; w.tile_bytes = c->tile_bytes; w.prec = c->prec;
 	w.qtile = c->d_bqt; w.qtile_stride = c->tile_bytes; w.cand_query = c->d_bcandq; w.nq = 1; w.len_t = qs[0].len_t;
 	w.d = c->desc.d;   // canonical similarity rows (sim_canon)
 	w.keys = c->d_bcand; w.rows_out = c->d_brows;
@@ -117,6 +135,7 @@ static int batch_winner_rows(vk_corpus *c, const vk_query_desc *qs, int n_querie
 	auto rank_range = [&](int i0, int i1) {
 		std::vector<int> order;
 		std::vector<float> val((size_t)kk), raw((size_t)kk);
+		std::vector<int32_t> key_s, key_t;   // static layout: vocabulary keys (token ids) of both sides (alignment/bow.h:204-275)
 		for (int i = i0; i < i1; i++) {
 			const vk_query_desc &q = qs[i];
 			vk_topk_out *out = &outs[i];
@@ -125,8 +144,13 @@ static int batch_winner_rows(vk_corpus *c, const vk_query_desc *qs, int n_querie
 			for (int j = 0; j < first[(size_t)i + 1] - first[(size_t)i]; j++) {
 				const uint64_t key = keys[(size_t)i * kk + j];
 				const int64_t g = (int64_t)(uint32_t)(key & 0xffffffffu);
-				const int len_s = (*c->h_end)[(size_t)g] - (*c->h_start)[(size_t)g];
-				raw[(size_t)j] = vk_host::rwmd_from_rows(c->h_brows + (at + j) * 64 * 16, 16, len_s, q.len_t, nullptr, nullptr,
+				const int t_a = (*c->h_start)[(size_t)g], len_s = (*c->h_end)[(size_t)g] - t_a;
+				const bool vocab = is_static && q.q_token_ids && c->h_tok;
+				if (vocab) {
+					key_t.assign(q.q_token_ids, q.q_token_ids + q.len_t);
+					key_s.assign(c->h_tok->begin() + t_a, c->h_tok->begin() + t_a + len_s);
+				}
+				raw[(size_t)j] = vk_host::rwmd_from_rows(c->h_brows + (at + j) * 64 * 16, 16, len_s, q.len_t, vocab ? key_s.data() : nullptr, vocab ? key_t.data() : nullptr,
 					q.rwmd_injective != 0, q.rwmd_symmetric != 0, q.rwmd_normalize_bow != 0);
 				val[(size_t)j] = (raw[(size_t)j] / (float)q.len_t) * (q.boost ? q.boost[g] : 1.0f);
 				if (val[(size_t)j] > q.min_score) order.push_back(j);
@@ -462,8 +486,13 @@ static int query_batch_body(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_q
 	// tokens on a padded copy, bucket by bucket)
 	const bool uniform16 = c->contiguous && c->uniform_len > 0 && c->uniform_len % 16 == 0 && c->uniform_len <= 64;
 	// (the kernels address a score row by a 32-bit sentence offset: 9 x n_sentences must stay below 2^31)
-	bool gemm = c->finalized && c->prec == 0 && c->desc.layout == VK_LAYOUT_CONTEXTUAL && c->desc.n_sentences > 0 && c->desc.n_sentences < (1ll << 27) && qs[0].max_matches <= 64 &&
-		vk_rwmd_batch_supported(c->nk32, c->tail) && (uniform16 || (c->max_len <= VK_FAST_SENT_LEN && c->entry_sent.empty() && !getenv("VK_BATCH_NO_RAGGED")));
+	// The static layout (round 4): the same epilogues over a per-batch similarity table gathered by token id instead of MFMA tiles
+	// (vk_rwmd_static32_kernel): slices of at most 64 tokens, any row width; the table -- 64 bytes per (word, query tile) -- within 4 GiB
+	const bool stat = c->desc.layout == VK_LAYOUT_STATIC;
+	bool gemm = c->finalized && c->prec == 0 && c->desc.n_sentences > 0 && c->desc.n_sentences < (1ll << 27) && qs[0].max_matches <= 64 &&
+		(stat ? (n_queries >= 2 && c->max_len <= VK_FAST_SENT_LEN && c->entry_sent.empty() && !getenv("VK_BATCH_NO_STATIC") &&
+				(size_t)((c->n_tiles + 1) / 2) * 32 * (size_t)((n_queries + 1) / 2 + 5) * 64 <= ((size_t)4 << 30))
+			: (vk_rwmd_batch_supported(c->nk32, c->tail) && (uniform16 || (c->max_len <= VK_FAST_SENT_LEN && c->entry_sent.empty() && !getenv("VK_BATCH_NO_RAGGED")))));
 	{   // as in the shared pass: restated winners need k + 8 <= 64 keys per query, and every result set or none carries sim_rows
 		bool all_rows = true, any_rows = false;
 		for (int i = 0; i < n_queries; i++) { all_rows = all_rows && outs[i].sim_rows != nullptr; any_rows = any_rows || outs[i].sim_rows != nullptr; }
@@ -504,9 +533,11 @@ static int query_batch_body(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_q
 	const bool wide32 = c->nk32 == 24 && c->tail == 0 && !getenv("VK_BATCH_WIDE16");
 	bool b32 = uniform16 && (c->uniform_len == 32 || c->uniform_len == 64) && (c->nk32 <= 10 || wide32);   // 64 tokens: one sentence per wave (W64)
 	const int gran = (c->nk32 <= 10 || wide32) ? 2 : 1;   // ragged corpora: bucket step in tiles
-	if (!uniform16 && (rc = build_batch_layout(c, gran))) return rc;
-	const bool r32 = !uniform16 && gran == 2;   // ragged, on the 32x32x16 kernels
-	b32 = b32 || r32;                           // query tiles packed for them
+	if (!stat && !uniform16 && (rc = build_batch_layout(c, gran))) return rc;
+	const bool r32 = !stat && !uniform16 && gran == 2;   // ragged, on the 32x32x16 kernels
+	b32 = b32 || r32 || stat;                            // query tiles packed for them (the static layout's table is built from the same tiles)
+	const bool stat_uniform32 = stat && c->contiguous && c->uniform_len == 32;
+	if (stat && !stat_uniform32 && (rc = build_static_buckets(c))) return rc;
 	int qpt = 3;
 	for (int i = 0; i < n_queries; i++) if (qs[i].len_t > 10) qpt = 2;
 	const int nk16 = c->d_pad / 16;
@@ -557,6 +588,27 @@ static int query_batch_body(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_q
 	bool rows_wanted = false;
 	for (int i = 0; i < n_queries; i++) rows_wanted |= qs[i].want_flow && outs[i].sim_rows;
 	std::vector<uint8_t> &tiles16 = keep.vec<uint8_t>(rows_wanted ? (size_t)n_queries * c->tile_bytes : 0, 0);
+	// where token j of query i sits in the 32-row A tiles: tile, lane half hd, accumulator register acc of the MFMA result
+	auto slot_of = [&](int i, int j, int &tile, int &hd, int &acc) {
+		const int slot = i % qpt;
+		tile = i / qpt;
+		if (dense) {
+			// super tile i / 16; lane half hd serves its queries 8 hd .. 8 hd + 7: five whole ones (registers 0..9 of tile k) and
+			// three in the registers 10..15 of the five tiles, in slot order (vk_rwmd_batch32d_kernel)
+			const int idx = i % 16, r = idx % 8;
+			int k;
+			hd = idx / 8;
+			if (r < 5) { k = r; acc = j; }
+			else {
+				const int lin = (r - 5) * 10 + j;   // 0..29 over the 30 spare slots of the half
+				k = lin / 6; acc = 10 + lin % 6;
+			}
+			tile = (i / 16) * 5 + k;
+		}
+		else if (qpt == 2) { hd = slot; acc = j; }
+		else if (slot < 2) { hd = slot; acc = j; }
+		else { hd = j / 5; acc = 10 + j % 5; }
+	};
 	// normalise, round and lay out the queries: a few host threads over disjoint query ranges (256 queries: 1.6 ms on one)
 	auto pack_range = [&](int i0, int i1) {
 	std::vector<uint8_t> one;
@@ -572,26 +624,10 @@ static int query_batch_body(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_q
 		// A tile of v_mfma_f32_32x32x16_bf16: K-step t = 1 KiB, lane l = 32 (k >> 3 & 1) + M owns row M, 8 features.
 		// Row M of the result lands in accumulator register acc = 4 (M >> 3) + (M & 3) of lane half hd = M >> 2 & 1;
 		// the kernel (vk_rwmd_batch32_kernel) expects query tokens at (hd, acc) as laid out below.
-		uint8_t *dst = all.data() + (size_t)(i / qpt) * nk16 * 1024;
-		const int slot = i % qpt;
 		for (int j = 0; j < qs[i].len_t; j++) {
-			int hd, acc;
-			if (dense) {
-				// super tile i / 16; lane half hd serves its queries 8 hd .. 8 hd + 7: five whole ones (registers 0..9 of tile k) and
-				// three in the registers 10..15 of the five tiles, in slot order (vk_rwmd_batch32d_kernel)
-				const int idx = i % 16, r = idx % 8;
-				int k;
-				hd = idx / 8;
-				if (r < 5) { k = r; acc = j; }
-				else {
-					const int lin = (r - 5) * 10 + j;   // 0..29 over the 30 spare slots of the half
-					k = lin / 6; acc = 10 + lin % 6;
-				}
-				dst = all.data() + ((size_t)(i / 16) * 5 + (size_t)k) * nk16 * 1024;
-			}
-			else if (qpt == 2) { hd = slot; acc = j; }
-			else if (slot < 2) { hd = slot; acc = j; }
-			else { hd = j / 5; acc = 10 + j % 5; }
+			int hd, acc, tile_ij;
+			slot_of(i, j, tile_ij, hd, acc);
+			uint8_t *dst = all.data() + (size_t)tile_ij * nk16 * 1024;
 			const int M = 8 * (acc >> 2) + 4 * hd + (acc & 3);
 			for (int k = 0; k < c->d_pad; k += 8) {   // 8 features = one 16-byte piece in both layouts
 				const size_t src = (size_t)(k >> 5) * 1024 + (size_t)(((k & 31) >> 3) * 16 + j) * 16;
@@ -651,7 +687,48 @@ static int query_batch_body(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_q
 	p.n_qtiles = n_qtiles; p.qpt = qpt; p.q_inv_len = d_qinv; p.q_param = d_qparam; p.dense = dense ? 1 : 0;
 	p.late_mask = wide32 ? 0 : 4;   // waves w and w + 4 of a workgroup share a SIMD (768-d rows: one wave per SIMD, nobody to alternate with)
 	if (const char *e = getenv("VK_BATCH32_LATE_MASK")) p.late_mask = atoi(e);   // tuning aid
-	if (b32 && !r32) VK_HIP(vk_launch_rwmd_batch32(&p, st));
+	if (stat) {
+		// ---- the static layout: table of the batch over the vocabulary, its diagonal cells, then the gather pass per length bucket
+		const int64_t v_rows = (int64_t)((c->n_tiles + 1) / 2) * 32;
+		const int64_t table_row = (int64_t)n_qtiles * 32;
+		const size_t need_t = (size_t)v_rows * (size_t)table_row;
+		if (c->btable_cap < need_t) {
+			if (c->d_btable) { VK_HIP(hipFree(c->d_btable)); c->d_btable = nullptr; c->btable_cap = 0; }
+			if ((rc = alloc_t(c, &c->d_btable, need_t))) return rc;
+			c->btable_cap = need_t;
+		}
+		// sim[id(t_j)][j] = 1 for every query token the vocabulary holds (metric/static.cpp:58-67), after the clip as there
+		std::vector<int64_t> &fix = keep.vec<int64_t>();
+		for (int i = 0; i < n_queries; i++)
+			for (int j = 0; j < qs[i].len_t && qs[i].q_token_ids; j++) {
+				const int32_t id = qs[i].q_token_ids[j];
+				if (id < 0 || id >= c->desc.vocab_size) continue;
+				int tile, hd, acc;
+				slot_of(i, j, tile, hd, acc);
+				fix.push_back((int64_t)id * table_row + (int64_t)tile * 32 + hd * 16 + acc);
+			}
+		if (c->bfix_cap < fix.size()) {
+			if (c->d_bfix) { VK_HIP(hipFree(c->d_bfix)); c->d_bfix = nullptr; c->bfix_cap = 0; }
+			if ((rc = alloc_t(c, &c->d_bfix, fix.size() + 16))) return rc;
+			c->bfix_cap = fix.size() + 16;
+		}
+		if (!fix.empty()) VK_HIP(hipMemcpyAsync(c->d_bfix, fix.data(), fix.size() * 8, hipMemcpyHostToDevice, st));
+		VK_HIP(vk_launch_table_batch(c->d_tiles, c->n_tiles, c->tile_bytes, nk16, c->d_bq, n_qtiles, c->d_btable, st));
+		VK_HIP(vk_launch_table_batch_fix(c->d_btable, c->d_bfix, (int32_t)fix.size(), st));
+		p.tok_id = c->d_tok_id; p.sent_start = c->d_sent_start; p.sent_end = c->d_sent_end;
+		p.table = c->d_btable; p.table_row = table_row; p.zero_row = (int32_t)((c->n_tiles - 1) * 16);   // the zero tile behind the vocabulary
+		if (stat_uniform32) VK_HIP(vk_launch_rwmd_static32(&p, 0, st));
+		else {
+			if (c->sb_empty > 0) VK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->d_bscores), (int)0xff800000u, (size_t)score_rows * (size_t)n, st));   // -inf: empty slices
+			for (int b = 0; b < 2; b++) {
+				if (c->sb_n[b] == 0) continue;
+				VkRwmdBatchParams pb = p;
+				pb.sent_id = c->d_sb_id[b]; pb.n_sent = (int32_t)c->sb_n[b]; pb.score_stride = n;
+				VK_HIP(vk_launch_rwmd_static32(&pb, b, st));
+			}
+		}
+	}
+	else if (b32 && !r32) VK_HIP(vk_launch_rwmd_batch32(&p, st));
 	else if (uniform16) VK_HIP(vk_launch_rwmd_batch(&p, st));
 	else {
 		if (c->bl_empty > 0) VK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->d_bscores), (int)0xff800000u, (size_t)n_queries * (size_t)n, st));   // -inf: empty slices
@@ -720,6 +797,29 @@ static int query_batch_body(vk_corpus_t *c, const vk_query_desc *qs, int32_t n_q
 	if (hipEventElapsedTime(&ms, c->ev[6], c->ev[3]) == hipSuccess) t.topk_ms = ms;
 	if (hipEventElapsedTime(&ms, c->ev[0], c->ev[4]) == hipSuccess) t.total_ms = ms - t.queue_ms;
 	c->last = t;
+	return VK_OK;
+}
+
+// The rows of the slice table by length bucket, for the batched relaxed WMD over the static layout (vk_rwmd_static32_kernel takes two
+// slices of at most 32 tokens per wave, or one of 33..64): built once per handle from the host mirror of the table.
+static int build_static_buckets(vk_corpus *c) {
+	if (c->sb_built) return VK_OK;
+	const int64_t n = c->desc.n_sentences;
+	std::vector<int32_t> ids[2];
+	c->sb_empty = 0;
+	for (int64_t s = 0; s < n; s++) {
+		const int len = (*c->h_end)[(size_t)s] - (*c->h_start)[(size_t)s];
+		if (len < 1) { c->sb_empty++; continue; }
+		ids[len <= 32 ? 0 : 1].push_back((int32_t)s);
+	}
+	for (int b = 0; b < 2; b++) {
+		c->sb_n[b] = (int64_t)ids[b].size();
+		if (c->sb_n[b] == 0) continue;
+		int rc;
+		if ((rc = alloc_t(c, &c->d_sb_id[b], ids[b].size()))) return rc;
+		VK_HIP(hipMemcpy(c->d_sb_id[b], ids[b].data(), ids[b].size() * 4, hipMemcpyHostToDevice));   // (blocking: the host vector is this function's)
+	}
+	c->sb_built = true;
 	return VK_OK;
 }
 

@@ -98,6 +98,14 @@ struct VkRwmdBatchParams {
 	const int32_t *sent_len;
 	const int32_t *sent_id;
 	int64_t score_stride;
+	// the static layout (vk_rwmd_static32_kernel): the similarities come out of a per-batch table instead of MFMAs --
+	// table[vocabulary row][query tile][lane half][16 accumulator slots], 16-bit fixed point (65535 = 1), i.e. for every word what the
+	// 32x32 MFMA result holds for a token column of that word (vk_table_batch_kernel); tokens are gathered by id, a sentence's padding points at zero_row
+	const int32_t *tok_id;
+	const int32_t *sent_start, *sent_end;   // the slice table (p.sent_id: rows of it in this launch's bucket; null: rows 0 .. n_sent)
+	const uint16_t *table;
+	int64_t table_row;         // cells per vocabulary row of the table: 32 x (query tiles of the table)
+	int32_t zero_row;          // a vocabulary row of zeros (the zero tile behind the vocabulary)
 };
 
 struct VkWrdParams {
@@ -134,7 +142,8 @@ struct VkWrdParams {
 	const uint32_t *qid_bits;  // the query tokens (static_vocab_fixup; qid_bits null: off)
 	int32_t qkey[VK_DEV_MAX_WIDE_QUERY_LEN];
 	const int32_t *cand_query; // vk_rows_kernel, batches: candidate w belongs to query cand_query[w], whose tile sits at qtile + that * qtile_stride
-	int64_t qtile_stride;
+	int64_t qtile_stride;      // (static layout: its token ids at q_ids + that * q_ids_stride)
+	int32_t q_ids_stride;
 	// queries of more than 16 tokens over slices of more than VK_DEV_MAX_SENT_LEN tokens
 	const int32_t *group_list; // vk_long_bound_kernel: groups of the slice table that hold one long slice (row 4 g)
 	int32_t n_list;
@@ -309,6 +318,12 @@ hipError_t vk_launch_rwmd_batch32(const VkRwmdBatchParams *p, hipStream_t stream
 hipError_t vk_launch_batch_pack(const uint8_t *src_tiles, uint8_t *dst_tiles, const int32_t *ids, const int32_t *sent_start, const int32_t *sent_end,
 	int64_t n, int32_t tps, int32_t tile_bytes, hipStream_t stream);
 int vk_rwmd_batch_supported(int32_t nk, int32_t half);
+// the static layout's batch: table[V rows][n_qtiles][2][16] from the packed 32-row query tiles (any row width), its diagonal cells
+// (sim[id(t_j)][j] = 1, metric/static.cpp:58-67: `offsets` floats of the table set to 1), and the gather + epilogue pass
+hipError_t vk_launch_table_batch(const uint8_t *etiles, int64_t n_vtiles, int32_t tile_bytes, int32_t nk16, const uint8_t *qtiles, int32_t n_qtiles,
+	uint16_t *table, hipStream_t stream);
+hipError_t vk_launch_table_batch_fix(uint16_t *table, const int64_t *offsets, int32_t n, hipStream_t stream);
+hipError_t vk_launch_rwmd_static32(const VkRwmdBatchParams *p, int32_t w64, hipStream_t stream);
 hipError_t vk_launch_topk_wave_batch(const float *scores, const uint64_t *keys_in, int64_t n, float min_score, int32_t k,
 	int64_t per_wave, int32_t n_queries, int64_t in_stride, int64_t out_stride, uint64_t *out, int64_t *n_waves_out, hipStream_t stream);
 hipError_t vk_launch_wrd_exact(const VkWrdParams *p, int32_t n_cand, float *scores_to_mark, hipStream_t stream);

@@ -150,6 +150,12 @@ struct vk_corpus {
 	batch_bucket bl[4];
 	bool bl_built = false;
 	int64_t bl_empty = 0;        // slices without tokens (in no bucket: their scores stay -inf)
+	// batched relaxed WMD over the static layout (vk_rwmd_static32_kernel): the rows of the slice table by length bucket (1..32 /
+	// 33..64 tokens; null lists when every slice has exactly 32 tokens), the batch's similarity table and its diagonal cells
+	int32_t *d_sb_id[2] = {nullptr, nullptr}; int64_t sb_n[2] = {0, 0}; bool sb_built = false; int64_t sb_empty = 0;
+	uint16_t *d_btable = nullptr; size_t btable_cap = 0;
+	int64_t *d_bfix = nullptr; size_t bfix_cap = 0;
+	int32_t *d_bqids = nullptr; size_t bqids_cap = 0;   // token ids of a batch's queries, 16 per query (the winners' rows: sim[id(t_j)][j] = 1)
 	size_t wrd_cap = 0;          // candidates d_wrd_raw / d_wrd_val (and d_keys[0]) can hold
 	int16_t *d_out_map = nullptr;
 	hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // 0 start, 5 before / 1 after the wait for the peer's kernel, 2 scored (the peer's turn), 3 selected, 4 done; 6: the batched GEMM has ended (its turn ends after the selection)

@@ -279,6 +279,10 @@ __device__ __forceinline__ int row_imax_to_lane15(int x) {
 	return x;
 }
 __device__ __forceinline__ float clip01_bits(int x) { return __builtin_amdgcn_fmed3f(__builtin_bit_cast(float, x), 0.0f, 1.0f); }
+// U16: the accumulator registers hold clipped similarities as 16-bit fixed point (0 .. 65535 = 0 .. 1; the static layout's table,
+// vk_table_batch_kernel) instead of float bits: the integer maxima are the same code, only the reduced values are converted
+template <bool U16>
+__device__ __forceinline__ float sim_of_bits(int x) { return U16 ? (float)x * (1.0f / 65535.0f) : clip01_bits(x); }
 
 // Maxima of 16 registers over the 16 lanes of each DPP row, transposed: lane v of the row ends up with the row
 // maximum of register v.  Halving exchange: at the step for lane bit b a lane keeps the registers whose index bit
@@ -442,7 +446,7 @@ __device__ __forceinline__ float tokens_sum(float x) {
 }
 constexpr int B32_MAX_QTILES = 256;   // query tiles per launch (their parameters: 8 KiB of LDS); larger batches take several launches
 
-template <int QPT, bool W64>
+template <int QPT, bool W64, bool U16 = false>
 __device__ __forceinline__ B32Vals batch32_epilogue(const VkRwmdBatchParams &p, int lane, const f32x16 &acc0, const f32x16 &acc1,
 	const float *tile_param, float boost, const B32Sent &sn) {
 	constexpr int NMAIN = QPT == 3 ? 10 : 16;          // rows of the half's own query
@@ -463,7 +467,7 @@ __device__ __forceinline__ B32Vals batch32_epilogue(const VkRwmdBatchParams &p, 
 	int ca0 = fbits(acc0[0]), ca1 = fbits(acc1[0]);
 #pragma unroll
 	for (int i = 1; i < NMAIN; i++) { ca0 = imax(ca0, fbits(acc0[i])); ca1 = imax(ca1, fbits(acc1[i])); }
-	const float ts_main = tokens_sum<W64>((2.0f - clip01_bits(ca0)) - clip01_bits(ca1)) - sn.pad;
+	const float ts_main = tokens_sum<W64>((2.0f - sim_of_bits<U16>(ca0)) - sim_of_bits<U16>(ca1)) - sn.pad;
 	float ts_third = 0.0f;
 	if (QPT == 3) {
 		int cb0 = fbits(acc0[10]), cb1 = fbits(acc1[10]);
@@ -472,7 +476,7 @@ __device__ __forceinline__ B32Vals batch32_epilogue(const VkRwmdBatchParams &p, 
 		const int e0 = __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, cb0);
 		const int e1 = __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, cb1);
 		cb0 = imax(cb0, e0); cb1 = imax(cb1, e1);
-		ts_third = tokens_sum<W64>((2.0f - clip01_bits(cb0)) - clip01_bits(cb1)) - sn.pad;
+		ts_third = tokens_sum<W64>((2.0f - sim_of_bits<U16>(cb0)) - sim_of_bits<U16>(cb1)) - sn.pad;
 	}
 	// (b) per query row: max over the sentence's tokens -> lane 15 of the DPP row
 	float s_main = 0.0f, s_third = 0.0f;
@@ -480,7 +484,7 @@ __device__ __forceinline__ B32Vals batch32_epilogue(const VkRwmdBatchParams &p, 
 		int m[16];
 #pragma unroll
 		for (int i = 0; i < 16; i++) m[i] = imax(fbits(acc0[i]), fbits(acc1[i]));
-		float z = clip01_bits(row_transpose_imax16(m, lane));    // this lane: maximum of query row v = row_transpose_reg(lane) over the sentence
+		float z = sim_of_bits<U16>(row_transpose_imax16(m, lane));    // this lane: maximum of query row v = row_transpose_reg(lane) over the sentence
 		if (W64) z = fmaxf(z, xor16_f(z));                          // ... over both halves of a 64-token sentence
 		const int v = row_transpose_reg(lane);
 		s_main = row_sum_to_lane15(v < NMAIN ? z : 0.0f);
@@ -608,7 +612,7 @@ __global__ __launch_bounds__(64 * NW) void vk_rwmd_batch32_kernel(VkRwmdBatchPar
 
 struct B32DState { int cb0, cb1; float zg; };
 
-template <int K, bool W64>
+template <int K, bool W64, bool U16 = false>
 __device__ __forceinline__ B32Vals batch32d_epilogue(const VkRwmdBatchParams &p, int lane, const f32x16 &acc0, const f32x16 &acc1,
 	const float *super_param /* [16][2]: len, 1 / len of the super tile's queries */, float boost, B32DState &st, const B32Sent &sn) {
 	constexpr int C_HI = K == 0 ? 10 : K == 1 ? 14 : K == 3 ? 12 : 16;   // slots [10, C_HI) continue the split query in progress
@@ -631,11 +635,11 @@ __device__ __forceinline__ B32Vals batch32d_epilogue(const VkRwmdBatchParams &p,
 	int ca0 = fbits(acc0[0]), ca1 = fbits(acc1[0]);
 #pragma unroll
 	for (int i = 1; i < 10; i++) { ca0 = imax(ca0, fbits(acc0[i])); ca1 = imax(ca1, fbits(acc1[i])); }
-	const float ts_f = tokens_sum<W64>((2.0f - clip01_bits(ca0)) - clip01_bits(ca1)) - sn.pad;
+	const float ts_f = tokens_sum<W64>((2.0f - sim_of_bits<U16>(ca0)) - sim_of_bits<U16>(ca1)) - sn.pad;
 #pragma unroll
 	for (int i = 10; i < C_HI; i++) { st.cb0 = imax(st.cb0, fbits(acc0[i])); st.cb1 = imax(st.cb1, fbits(acc1[i])); }
 	float ts_g = 0.0f;
-	if (CLOSES) ts_g = tokens_sum<W64>((2.0f - clip01_bits(st.cb0)) - clip01_bits(st.cb1)) - sn.pad;
+	if (CLOSES) ts_g = tokens_sum<W64>((2.0f - sim_of_bits<U16>(st.cb0)) - sim_of_bits<U16>(st.cb1)) - sn.pad;
 	if (STARTS) {
 		st.cb0 = fbits(acc0[C_HI]); st.cb1 = fbits(acc1[C_HI]);
 #pragma unroll
@@ -646,7 +650,7 @@ __device__ __forceinline__ B32Vals batch32d_epilogue(const VkRwmdBatchParams &p,
 	int m[16];
 #pragma unroll
 	for (int i = 0; i < 16; i++) m[i] = imax(fbits(acc0[i]), fbits(acc1[i]));
-	float z = clip01_bits(row_transpose_imax16(m, lane));
+	float z = sim_of_bits<U16>(row_transpose_imax16(m, lane));
 	if (W64) z = fmaxf(z, xor16_f(z));
 	const float s_f = row_sum_to_lane15(v < 10 ? z : 0.0f);
 	if (C_HI > 10) st.zg += (v >= 10 && v < C_HI) ? z : 0.0f;
@@ -675,15 +679,15 @@ constexpr int B32D_MAX_SUPER = 48;   // super tiles per launch: 768 queries, the
 
 // epilogue / store of tile K (0..4) of a super tile; K is wave-uniform, the five forms are the arms of one switch (unrolling the
 // five tiles into the loop body instead let hipcc hoist their addresses and parameters: 30 more registers, scratch)
-template <bool W64>
+template <bool W64, bool U16 = false>
 __device__ __forceinline__ B32Vals batch32d_epilogue_k(int K, const VkRwmdBatchParams &p, int lane, const f32x16 &acc0, const f32x16 &acc1,
 	const float *super_param, float boost, B32DState &st, const B32Sent &sn) {
 	switch (K) {
-	case 0: return batch32d_epilogue<0, W64>(p, lane, acc0, acc1, super_param, boost, st, sn);
-	case 1: return batch32d_epilogue<1, W64>(p, lane, acc0, acc1, super_param, boost, st, sn);
-	case 2: return batch32d_epilogue<2, W64>(p, lane, acc0, acc1, super_param, boost, st, sn);
-	case 3: return batch32d_epilogue<3, W64>(p, lane, acc0, acc1, super_param, boost, st, sn);
-	default: return batch32d_epilogue<4, W64>(p, lane, acc0, acc1, super_param, boost, st, sn);
+	case 0: return batch32d_epilogue<0, W64, U16>(p, lane, acc0, acc1, super_param, boost, st, sn);
+	case 1: return batch32d_epilogue<1, W64, U16>(p, lane, acc0, acc1, super_param, boost, st, sn);
+	case 2: return batch32d_epilogue<2, W64, U16>(p, lane, acc0, acc1, super_param, boost, st, sn);
+	case 3: return batch32d_epilogue<3, W64, U16>(p, lane, acc0, acc1, super_param, boost, st, sn);
+	default: return batch32d_epilogue<4, W64, U16>(p, lane, acc0, acc1, super_param, boost, st, sn);
 	}
 }
 
@@ -762,6 +766,178 @@ __global__ __launch_bounds__(64 * NW) void vk_rwmd_batch32d_kernel(VkRwmdBatchPa
 		if (late) pend = batch32d_epilogue<4, W64>(p, lane, acc0, acc1, param + (n_super - 1) * 32, boost, st, sn);
 		batch32d_store_k(4, p, n_super - 1, store_lane, lane_off, pend, stride);
 	}
+}
+
+// ---------------------------------------------------------------------------
+// The static layout (token ids + vocabulary; StaticEmbeddingSlice, vectorian/core/cpp/slice/static.h:71-75) under a batch of
+// relaxed-WMD queries.  The reference builds ONE similarity table per query over the vocabulary (metric/static.cpp:9-78) and
+// gathers a slice's rows from it by token id; so does this path, for the whole batch at once:
+//   1. vk_table_batch_kernel: table[word][query tile][lane half][16] = clip(cosine), the packed 32-row query tiles (as the GEMM
+//      kernels above take them) against the vocabulary on MFMA -- V x 32 n_qtiles x d, 77 GFLOP for 50,000 words and 256 queries
+//      where the contextual GEMM issues 49 TFLOP -- stored in the accumulator layout of a 32x32 MFMA result, so that
+//   2. vk_rwmd_static32_kernel fills acc0 / acc1 of a lane with two 16-byte loads each -- the 16 query rows of its lane half
+//      against its token, gathered by token id -- and runs the SAME epilogues as the GEMM kernels (batch32_epilogue,
+//      batch32d_epilogue): maxima over the query's rows in-lane, over the sentence's tokens by the transposing exchange, scores.
+//      No LDS tiles, no barriers, waves independent; a sentence's padding points at a row of zeros (S = 0 exactly, as the zero
+//      rows of the padded copy a ragged contextual corpus runs on).
+// Every token id is read once per launch for all queries; what streams is the table, and it decides the time (the first form kept
+// fp32 cells, 128 bytes per (token, query tile): 328 GB of gathers per 256 x 1 M x 32, a quarter of them past the L2 for Zipf(1.1)
+// words -- 35.2 ms, no faster than the GEMM).  The cells are therefore 16-bit fixed point, round(65535 clip(S)): 64 bytes per
+// (token, tile).  The similarities are clipped to [0, 1] anyway, the maxima of the epilogues are integer maxima either way, and a
+// cell is within 7.7e-6 of its fp32 value -- the scores of this pass rank the slices (within 1e-5 of the fp32 scores: the margin of
+// the canonical restating covers it, vk_batch.cpp), the scores a caller with flows receives are restated from canonical rows.
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void vk_table_batch_kernel(const uint8_t *__restrict__ etiles, int64_t n_vtiles, int tile_bytes, int nk16,
+	const uint8_t *__restrict__ qtiles, int n_qtiles, uint16_t *__restrict__ table) {
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int n32 = lane & 31, h = lane >> 5;
+	const int64_t pair = (int64_t)blockIdx.x * 4 + wv;           // vocabulary tiles 2 pair, 2 pair + 1: 32 words = the 32 columns
+	if (pair * 2 >= n_vtiles) return;
+	int64_t tile = pair * 2 + (n32 >> 4);
+	if (tile >= n_vtiles) tile = n_vtiles - 1;                  // (an odd count: the zero tile behind the vocabulary once more)
+	const uint8_t *tp = etiles + tile * tile_bytes + (n32 & 15) * 16;
+	uint16_t *out = table + (pair * 32 + n32) * ((int64_t)n_qtiles * 32) + h * 16;
+	for (int qt = 0; qt < n_qtiles; qt++) {
+		f32x16 acc;
+#pragma unroll
+		for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+		const uint8_t *a = qtiles + (int64_t)qt * nk16 * 1024 + lane * 16;
+#pragma unroll 2
+		for (int t = 0; t < nk16; t++) {
+			const bf16x8 av = *reinterpret_cast<const bf16x8 *>(a + t * 1024);
+			const bf16x8 bv = *reinterpret_cast<const bf16x8 *>(tp + (t >> 1) * 1024 + (2 * (t & 1) + h) * 256);
+			acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8n, av), __builtin_bit_cast(bf16x8n, bv), acc, 0, 0, 0);
+		}
+		// clip to [0, 1] (SimilarityMatrix::clip, metric/metric.h:28-30), then 16-bit fixed point: slots 2 k, 2 k + 1 in one dword
+		uint32_t w[8];
+#pragma unroll
+		for (int k = 0; k < 8; k++)
+			w[k] = (uint32_t)__builtin_rintf(clip01(acc[2 * k]) * 65535.0f) | ((uint32_t)__builtin_rintf(clip01(acc[2 * k + 1]) * 65535.0f) << 16);
+		*reinterpret_cast<uint4 *>(out + qt * 32) = make_uint4(w[0], w[1], w[2], w[3]);
+		*reinterpret_cast<uint4 *>(out + qt * 32 + 8) = make_uint4(w[4], w[5], w[6], w[7]);
+	}
+}
+
+__global__ void vk_table_batch_fix_kernel(uint16_t *__restrict__ table, const int64_t *__restrict__ offsets, int n) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) table[offsets[i]] = 65535;   // sim[id(t_j)][j] = 1
+}
+
+// the lane's two tokens of its sentence: chain m holds token 16 m + (n & 15) of sentence n >> 4, or (W64) token
+// 16 (2 (n >> 4) + m) + (n & 15) of the wave's one sentence -- the column order of the GEMM kernels above
+template <int QPT, bool DENSE, bool W64>
+__global__ __launch_bounds__(256) void vk_rwmd_static32_kernel(VkRwmdBatchParams p) {
+	extern __shared__ float4 vk_smem4[];
+	float *param = reinterpret_cast<float *>(vk_smem4);
+	const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int n32 = lane & 31, h = lane >> 5;
+	constexpr int SPW = W64 ? 1 : 2;                 // sentences per wave
+	const int64_t n_chunks = ((int64_t)p.n_sent + SPW - 1) / SPW;
+	const int64_t stride = p.score_stride > 0 ? p.score_stride : p.n_sent;
+	const int n_super = p.n_qtiles / 5;
+	for (int i = threadIdx.x; i < (DENSE ? n_super * 32 : p.n_qtiles * 8); i += 256) param[i] = p.q_param[i];
+	__syncthreads();
+	for (int64_t chunk = (int64_t)blockIdx.x * 4 + wv; chunk < n_chunks; chunk += (int64_t)gridDim.x * 4) {
+		const int64_t sent = W64 ? chunk : chunk * 2 + (n32 >> 4);
+		const bool have = sent < p.n_sent;
+		const int64_t srow = have ? (p.sent_id ? (int64_t)p.sent_id[sent] : sent) : 0;   // row of the slice table = where its scores go
+		const int s_a = have ? p.sent_start[srow] : 0;
+		const int slen = have ? p.sent_end[srow] - s_a : 1;
+		const B32Sent sn{1.0f / (float)slen, (float)((W64 ? 64 : 32) - slen)};
+		const float boost = (p.boost && have) ? p.boost[srow] : 1.0f;
+		const bool store_lane = (W64 ? (lane & 31) == 31 : (lane & 15) == 15) && have;
+		const unsigned lane_off = (unsigned)((DENSE ? 8 : 1) * h) * (unsigned)stride + (unsigned)srow;
+		const uint16_t *r0, *r1;
+		{
+			const int pos0 = (W64 ? 32 * (n32 >> 4) : 0) + (n32 & 15), pos1 = pos0 + 16;
+			const int64_t w0 = (have && pos0 < slen) ? p.tok_id[s_a + pos0] : p.zero_row;
+			const int64_t w1 = (have && pos1 < slen) ? p.tok_id[s_a + pos1] : p.zero_row;
+			r0 = p.table + w0 * p.table_row + h * 16;
+			r1 = p.table + w1 * p.table_row + h * 16;
+		}
+		f32x16 acc0, acc1;   // (holding the cells' integers as bit patterns: the epilogues' U16 form)
+		uint4 nx0[2], nx1[2];
+#pragma unroll
+		for (int j = 0; j < 2; j++) { nx0[j] = *reinterpret_cast<const uint4 *>(r0 + 8 * j); nx1[j] = *reinterpret_cast<const uint4 *>(r1 + 8 * j); }
+		B32DState st{0, 0, 0.0f};
+		int K = 0, super = 0;
+		for (int qt = 0; qt < p.n_qtiles; qt++) {
+#pragma unroll
+			for (int j = 0; j < 2; j++) {
+				const uint32_t a[4] = {nx0[j].x, nx0[j].y, nx0[j].z, nx0[j].w}, b[4] = {nx1[j].x, nx1[j].y, nx1[j].z, nx1[j].w};
+#pragma unroll
+				for (int e = 0; e < 4; e++) {
+					acc0[8 * j + 2 * e] = __builtin_bit_cast(float, a[e] & 0xffffu); acc0[8 * j + 2 * e + 1] = __builtin_bit_cast(float, a[e] >> 16);
+					acc1[8 * j + 2 * e] = __builtin_bit_cast(float, b[e] & 0xffffu); acc1[8 * j + 2 * e + 1] = __builtin_bit_cast(float, b[e] >> 16);
+				}
+			}
+			// the next tile's cells are requested before this tile's epilogue runs (the last request re-reads tile 0: in range, unused)
+			const int qn = qt + 1 < p.n_qtiles ? qt + 1 : 0;
+#pragma unroll
+			for (int j = 0; j < 2; j++) { nx0[j] = *reinterpret_cast<const uint4 *>(r0 + qn * 32 + 8 * j); nx1[j] = *reinterpret_cast<const uint4 *>(r1 + qn * 32 + 8 * j); }
+			if constexpr (DENSE) {
+				const B32Vals v = batch32d_epilogue_k<W64, true>(K, p, lane, acc0, acc1, param + super * 32, boost, st, sn);
+				batch32d_store_k(K, p, super, store_lane, lane_off, v, stride);
+				if (++K == 5) { K = 0; super++; }
+			} else {
+				const B32Vals v = batch32_epilogue<QPT, W64, true>(p, lane, acc0, acc1, param + qt * 8, boost, sn);
+				batch32_store<QPT>(p, qt, store_lane, lane_off, lane, v, stride);
+			}
+		}
+	}
+}
+
+extern "C" hipError_t vk_launch_table_batch(const uint8_t *etiles, int64_t n_vtiles, int32_t tile_bytes, int32_t nk16, const uint8_t *qtiles, int32_t n_qtiles,
+	uint16_t *table, hipStream_t stream) {
+	const int64_t pairs = (n_vtiles + 1) / 2;
+	if (pairs < 1 || n_qtiles < 1) return hipSuccess;
+	vk_table_batch_kernel<<<(unsigned)((pairs + 3) / 4), 256, 0, stream>>>(etiles, n_vtiles, tile_bytes, nk16, qtiles, n_qtiles, table);
+	return hipGetLastError();
+}
+
+extern "C" hipError_t vk_launch_table_batch_fix(uint16_t *table, const int64_t *offsets, int32_t n, hipStream_t stream) {
+	if (n < 1) return hipSuccess;
+	vk_table_batch_fix_kernel<<<(n + 255) / 256, 256, 0, stream>>>(table, offsets, n);
+	return hipGetLastError();
+}
+
+// p->n_qtiles tiles of the table (dense: 5 per super tile of 16 queries), p->table_row floats per word; p->sent_id: the rows of the
+// slice table this launch takes (null: 0 .. n_sent), each of at most 32 tokens (w64: 64); scores as the GEMM kernels write them
+extern "C" hipError_t vk_launch_rwmd_static32(const VkRwmdBatchParams *pp, int32_t w64, hipStream_t stream) {
+	int dev = 0, cus = 256;
+	if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+	if (pp->qpt != 2 && pp->qpt != 3) return hipErrorNotSupported;
+	const int64_t n_chunks = ((int64_t)pp->n_sent + (w64 ? 0 : 1)) / (w64 ? 1 : 2);
+	const int64_t blocks = (n_chunks + 3) / 4;
+	const int grid = (int)(blocks < (int64_t)cus * 8 ? blocks : (int64_t)cus * 8);
+	if (grid < 1) return hipSuccess;
+	const int64_t stride = pp->score_stride > 0 ? pp->score_stride : pp->n_sent;
+	void (*kernel)(VkRwmdBatchParams);
+	if (pp->dense) kernel = w64 ? vk_rwmd_static32_kernel<3, true, true> : vk_rwmd_static32_kernel<3, true, false>;
+	else if (pp->qpt == 3) kernel = w64 ? vk_rwmd_static32_kernel<3, false, true> : vk_rwmd_static32_kernel<3, false, false>;
+	else kernel = w64 ? vk_rwmd_static32_kernel<2, false, true> : vk_rwmd_static32_kernel<2, false, false>;
+	// the tiles' parameters are staged in LDS (as the GEMM kernels do): launches of at most B32D_MAX_SUPER super tiles / B32_MAX_QTILES tiles
+	// 40 query tiles per pass over the token ids (2.5 KB of a word's table row per visit): 256 queries in two passes took 19.1 ms where one
+	// pass over all 80 tiles took 20.3 and four passes of 20 tiles 19.5 (MI355X, 1 M x 32 tokens, Zipf(1.1) over 50,000 words)
+	int step = 40;
+	if (const char *e = getenv("VK_STATIC_TILES")) {   // tuning aid
+		const int v = atoi(e);
+		if (v > 0) step = pp->dense ? (v + 4) / 5 * 5 : v;
+		if (step > (pp->dense ? B32D_MAX_SUPER * 5 : B32_MAX_QTILES)) step = pp->dense ? B32D_MAX_SUPER * 5 : B32_MAX_QTILES;
+	}
+	for (int t0 = 0; t0 < pp->n_qtiles; t0 += step) {
+		VkRwmdBatchParams p = *pp;
+		p.n_qtiles = pp->n_qtiles - t0 < step ? pp->n_qtiles - t0 : step;
+		p.table = pp->table + (size_t)t0 * 32;
+		p.q_param = pp->q_param + (pp->dense ? (size_t)(t0 / 5) * 32 : (size_t)t0 * 8);
+		p.scores = pp->scores + (size_t)(pp->dense ? (t0 / 5) * 16 : t0 * pp->qpt) * stride;
+		const size_t smem = (size_t)(pp->dense ? (p.n_qtiles / 5) * 32 : p.n_qtiles * 8) * 4 + 16;
+		kernel<<<grid, 256, smem, stream>>>(p);
+		const hipError_t e = hipGetLastError();
+		if (e != hipSuccess) return e;
+	}
+	return hipSuccess;
 }
 
 template <int NK, bool HALF>

@@ -688,7 +688,10 @@ __global__ __launch_bounds__(64) void vk_rows_kernel(VkWrdParams p) {
 	float *out = p.rows_out + (int64_t)w * R * N;
 	const uint64_t key = p.keys[w];
 	int m = 0, rowbase = 0;
-	if (p.cand_query) p.qtile += (int64_t)p.cand_query[w] * p.qtile_stride;   // a batch: every candidate against its own query
+	if (p.cand_query) {   // a batch: every candidate against its own query (static layout: its own token ids)
+		p.qtile += (int64_t)p.cand_query[w] * p.qtile_stride;
+		if (p.q_ids) p.q_ids += (int64_t)p.cand_query[w] * p.q_ids_stride;
+	}
 	if (key != 0) {
 		const int64_t g = (int64_t)(uint32_t)(key & 0xffffffffu);
 		const int t_a = p.sent_start[g], t_b = p.sent_end[g];

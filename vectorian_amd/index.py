@@ -248,7 +248,7 @@ class HipBruteForceIndex(LanesMixin, ShardExchangeMixin, DebugHookMixin, Index):
 				q._abort = abort
 		batches = self._batch_plan(queries, options) if batch is not False else None
 		if batch is True and batches is None:
-			raise RuntimeError("find_many(batch=True): these queries cannot share a call (static embeddings, filters, tag weights, "
+			raise RuntimeError("find_many(batch=True): these queries cannot share a call (filters, tag weights, "
 				"a debug hook, exact transport, or queries that differ in their options)")
 		start = time.time()
 		if batches is not None:

@@ -59,8 +59,10 @@ class LanesMixin:
 	def _batch_plan(self, queries, options):
 		"""chunks of queries that can go to the backend in one call each, or None"""
 		if (self._filter_masks(options) is not None or options.get("debug") is not None
-				or not hasattr(self._corpus, "query_batch") or not self._embedding.is_contextual or len(queries) < 2):
+				or not hasattr(self._corpus, "query_batch") or len(queries) < 2):
 			return None
+		# (static embeddings since round 4: relaxed-WMD queries share one table over the vocabulary and one gather pass over the token
+		# ids per call -- vk_rwmd_static32_kernel; alignments are accepted and answered query by query inside the call)
 		args, _ = self._backend_args(queries[0].options)
 		if "tag_weighted" in args or args["submatch_weight"] != 0.0:
 			return None
@@ -90,9 +92,10 @@ class LanesMixin:
 			if not idx and self._shard is None:
 				return idx, [], False
 			qvs = [emb.encode_tokens(prepared[i].tokens) for i in idx]
+			ids = dict(token_ids=[prepared[i].token_ids for i in idx]) if emb.is_static else {}   # static layout: sim[id(t_j)][j] = 1 needs the words' ids
 			try:
 				tops = handles[l].query_batch([np.ascontiguousarray(qv.unmodified, dtype=np.float32) for qv in qvs], q_normalize=True,
-					boost=self._dev_boost, want_flow=True, abort_flag=queries[idx[0]]._abort, **args) if idx else []
+					boost=self._dev_boost, want_flow=True, abort_flag=queries[idx[0]]._abort, **ids, **args) if idx else []
 			except core.VkError as e:
 				if e.status != core.VK_ERR_ABORTED:
 					raise
