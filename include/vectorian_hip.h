@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 11
+#define VK_ABI_VERSION 12
 #define VK_MAX_QUERY_LEN 64   /* query tokens */
 #define VK_FAST_QUERY_LEN 16  /* queries up to this length run in the fused kernels (one 16-wide MFMA column block); longer ones
                                  take the multi-block kernel (2 or 4 column blocks) or, where that does not apply, a
@@ -44,7 +44,10 @@ extern "C" {
                                  mapping can name, upstream's own bound (metric/alignment.h:357-358).  A corpus that holds a slice
                                  of more than VK_MAX_SENT_LEN tokens is scored by one wave per slice with the slice's state (column
                                  history of general gaps, traceback) in global memory; the transports return VK_ERR_UNSUPPORTED on it */
-#define VK_MAX_MATCHES 1024
+#define VK_MAX_MATCHES 1024   /* result sets up to this size come out of the streaming / block selection kernels; every strategy */
+#define VK_MAX_MATCHES_SORTED 1048576   /* alignments (VK_ALG_ALIGN, submatch_weight = 0): result sets of up to this many matches -- a
+                                 query that asks for more than VK_MAX_MATCHES has every score sorted on the device (upstream's
+                                 ResultSet is bounded by max_matches alone, vectorian/core/cpp/result_set.h:32-68) */
 
 typedef enum {
 	VK_OK = 0,

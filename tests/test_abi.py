@@ -24,7 +24,7 @@ def test_every_declared_symbol_is_exported():
 	missing = [s for s in syms if not hasattr(lib, s)]
 	assert not missing, missing
 	assert sorted(core.EXPORTS) == syms
-	assert lib.vk_abi_version() == 11
+	assert lib.vk_abi_version() == 12
 
 
 def test_document_pass_sizing():

@@ -8,7 +8,7 @@ import pytest
 
 from vectorian_amd import synth
 
-from helpers import assert_same_results, prep_query
+from helpers import assert_same_results, hip_contextual_corpus, prep_contextual, prep_query
 
 pytestmark = pytest.mark.gpu
 
@@ -309,3 +309,37 @@ def test_near_ties_at_the_k_boundary_are_resolved_in_the_oracles_arithmetic(hip,
 		assert set(int(x) for x in ref["sentence"]) <= set(int(x) for x in dup) | {base}
 		assert np.ptp(ref["score"]) < 1e-4 and len(np.unique(ref["score"])) > 1      # near-ties, not exact ties
 		assert_same_results(got, ref)
+
+
+@pytest.mark.parametrize("layout", ["contextual", "static"])
+def test_result_sets_beyond_1024_matches(hip, oracle, layout):
+	"""max_matches > VK_MAX_MATCHES (refused until round 4): upstream's ResultSet is bounded by max_matches alone
+	(vectorian/core/cpp/result_set.h:32-68).  Alignments: every score sorted on the device (hipcub), the k + 8 best retraced --
+	slice ids, scores and tracebacks equal to the oracle's bit for bit, with and without flows; a result set larger than the corpus
+	returns every admitted slice; the transports refuse"""
+	n = 5000
+	if layout == "static":
+		corpus = synth.make_static_corpus(n, 0, 30, 500, 64)
+		from helpers import hip_static_corpus
+		c, Eb = hip_static_corpus(hip, corpus)
+		q = synth.make_queries(corpus, 1, 6)[0]
+		Qb = synth.to_bf16_bits(synth.normalize_rows(q["vectors"]))
+		ckw, okw = dict(q_token_ids=q["ids"]), dict(layout=oracle.LAYOUT_STATIC, d=64, sent_off=corpus["sent_off"], tok_id=corpus["tok_id"], E=Eb, q_ids=q["ids"])
+	else:
+		corpus = synth.make_contextual_corpus(n, 0, 30, 500, 64)
+		Xb = prep_contextual(corpus)
+		c = hip_contextual_corpus(hip, corpus, Xb)
+		Qb = prep_query(synth.make_queries(corpus, 1, 6)[0])
+		ckw, okw = {}, dict(layout=oracle.LAYOUT_CONTEXTUAL, d=64, sent_off=corpus["sent_off"], X=Xb)
+	for k, min_score in ((1500, 0.0), (3000, 0.15), (8000, -1.0)):
+		ref = oracle.find(Q=Qb, locality=oracle.LOCAL, gap_s=0.1, gap_t=0.1, max_matches=k, min_score=min_score, **okw)
+		got = c.query(Qb, locality=hip.Locality.LOCAL, gap_s=0.1, gap_t=0.1, q_normalize=False, max_matches=k, min_score=min_score, **ckw)
+		assert got.n == len(ref["score"]) and (got.n > 1024 or min_score > 0.1)
+		assert_same_results(got.trimmed(), ref)
+		noflow = c.query(Qb, locality=hip.Locality.LOCAL, gap_s=0.1, gap_t=0.1, q_normalize=False, max_matches=k, min_score=min_score, want_flow=False, **ckw)
+		assert_same_results(noflow.trimmed(), ref, check_mapping=False, score_tol=1e-4)
+		np.testing.assert_allclose(noflow.raw_score[:noflow.n], ref["raw"], atol=1e-4)
+	with pytest.raises(hip.VkError) as e:
+		c.query(Qb, algorithm=hip.VK_ALG_RWMD, q_normalize=False, max_matches=2000, **ckw)
+	assert e.value.status == hip.VK_ERR_UNSUPPORTED
+	c.close()

@@ -26,6 +26,7 @@ VK_FAST_SENT_LEN = 64
 VK_PREC_BF16, VK_PREC_F32 = 0, 1
 VK_FAST_QUERY_LEN = 16
 VK_MAX_MATCHES = 1024
+VK_MAX_MATCHES_SORTED = 1048576   # alignments: result sets beyond VK_MAX_MATCHES (every score sorted on the device)
 
 VK_F32, VK_BF16 = 0, 1
 VK_MEM_HOST, VK_MEM_DEVICE = 0, 1
@@ -157,7 +158,7 @@ def lib():
 		L.vk_pack_records.argtypes = [C.POINTER(_TopkOut), C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
 		L.vk_merge_records.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_TopkOut)]
 		L.vk_rwmd_from_rows.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float)]
-		if L.vk_abi_version() != 11:
+		if L.vk_abi_version() != 12:
 			raise RuntimeError("libvectorian_hip.so ABI version mismatch")
 		_lib = L
 	return _lib

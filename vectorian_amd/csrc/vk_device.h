@@ -312,6 +312,10 @@ hipError_t vk_launch_topk_keys(const uint64_t *in, int64_t n, int32_t k, uint64_
 hipError_t vk_launch_topk_wave(const float *scores, const uint64_t *keys_in, int64_t n, float min_score, int32_t k,
 	int64_t per_wave, uint64_t *out, int64_t *n_waves_out, hipStream_t stream);
 hipError_t vk_launch_flow(const VkFlowParams *p, int32_t k, hipStream_t stream);
+// result sets of more than VK_MAX_MATCHES entries: keys of ALL n scores (0 where score <= min_score), sorted descending (hipcub radix
+// sort); keys_a / keys_b: n entries each; temp == nullptr only sizes the workspace; *sorted_out: whichever buffer holds the result
+hipError_t vk_launch_sort_all(const float *scores, int64_t n, float min_score, uint64_t *keys_a, uint64_t *keys_b, void *temp, size_t *temp_bytes,
+	uint64_t **sorted_out, hipStream_t stream);
 hipError_t vk_launch_rwmd_batch(const VkRwmdBatchParams *p, hipStream_t stream);
 hipError_t vk_launch_rwmd_batch32(const VkRwmdBatchParams *p, hipStream_t stream);
 // padded copy of the sentences `ids` (n of them, each `tps` tiles long) for the batched GEMM over a ragged corpus

@@ -158,6 +158,8 @@ struct vk_corpus {
 	int32_t *d_bqids = nullptr; size_t bqids_cap = 0;   // token ids of a batch's queries, 16 per query (the winners' rows: sim[id(t_j)][j] = 1)
 	size_t wrd_cap = 0;          // candidates d_wrd_raw / d_wrd_val (and d_keys[0]) can hold
 	int16_t *d_out_map = nullptr;
+	size_t out_cap = VK_MAX_MATCHES;   // winners d_out_raw / d_out_sim / d_out_map hold (grown by a query that asks for more matches)
+	uint64_t *d_sort[2] = {nullptr, nullptr}; void *d_sort_temp = nullptr; size_t sort_cap = 0, sort_temp_cap = 0;   // result sets beyond VK_MAX_MATCHES: all keys, sorted
 	hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // 0 start, 5 before / 1 after the wait for the peer's kernel, 2 scored (the peer's turn), 3 selected, 4 done; 6: the batched GEMM has ended (its turn ends after the selection)
 	vk_timings last{};
 	bool have_scores = false;

@@ -54,7 +54,11 @@ int vk_validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_topk_
 	}
 	if (!q->q_vectors) return fail(VK_ERR_INVALID, "q_vectors is null");
 	if (q->q_dtype != VK_F32 && q->q_dtype != VK_BF16) return fail(VK_ERR_INVALID, "bad q_dtype");
-	if (q->max_matches < 1 || q->max_matches > VK_MAX_MATCHES) return fail(VK_ERR_INVALID, "max_matches out of range");
+	if (q->max_matches < 1 || q->max_matches > VK_MAX_MATCHES_SORTED) return fail(VK_ERR_INVALID, "max_matches out of range");
+	// beyond VK_MAX_MATCHES: every score sorted on the device -- alignments (with or without their tracebacks), no submatch weight;
+	// the transports' candidate rounds and row buffers are sized for VK_MAX_MATCHES
+	if (q->max_matches > VK_MAX_MATCHES && !q->only_slices && (q->algorithm != VK_ALG_ALIGN || q->submatch_weight != 0.0f || out->sim_rows))
+		return fail(VK_ERR_UNSUPPORTED, "max_matches beyond VK_MAX_MATCHES (1024): alignments without a submatch weight only");
 	if (out->capacity < q->max_matches) return fail(VK_ERR_INVALID, "output capacity smaller than max_matches");
 	if (!out->score || !out->sentence) return fail(VK_ERR_INVALID, "output arrays missing");
 	// (the batched paths copy 64 rows per winner into sim_rows at a stride of rows_per_winner: never below 64)
@@ -965,7 +969,17 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 	// result set are the oracle's floats, whichever kernel ranked the slices (per query, batched GEMM, a shard of the corpus).
 	const bool canon_tr = q->algorithm == VK_ALG_RWMD && !q->wmd_full && q->want_flow && out->sim_rows != nullptr;
 	constexpr int kCanonMargin = 8;
-	const int kk = only ? q->n_only : !(do_flow || canon_tr) ? k : std::min(k + kCanonMargin, VK_MAX_MATCHES);   // (57 .. 64 matches: the margin takes the selection to the k > 64 path)
+	// (57 .. 64 matches: the margin takes the selection to the k > 64 path; beyond VK_MAX_MATCHES: every score is sorted, never more winners than rows)
+	const int kk = only ? q->n_only : (int)std::min<int64_t>(!(do_flow || canon_tr) ? k : (k <= VK_MAX_MATCHES ? std::min(k + kCanonMargin, VK_MAX_MATCHES) : k + kCanonMargin), std::max<int64_t>(n, 1));
+	const uint64_t *d_sel = nullptr;   // the selected keys on the device, best first
+	if ((size_t)kk > c->out_cap) {   // the winners' device arrays: grown to this result set
+		for (void *ptr : {(void *)c->d_out_raw, (void *)c->d_out_sim, (void *)c->d_out_map}) if (ptr) VK_HIP(hipFree(ptr));
+		c->d_out_raw = nullptr; c->d_out_sim = nullptr; c->d_out_map = nullptr; c->out_cap = 0;
+		if ((rc = alloc_t(c, &c->d_out_raw, (size_t)kk))) return rc;
+		if ((rc = alloc_t(c, &c->d_out_sim, (size_t)kk * 64))) return rc;
+		if ((rc = alloc_t(c, &c->d_out_map, (size_t)kk * 64))) return rc;
+		c->out_cap = (size_t)kk;
+	}
 	const float sel_floor = (do_flow || canon_tr) ? q->min_score - 1e-5f * std::max(1.0f, std::fabs(q->min_score)) : q->min_score;
 	int cur = 0;
 	if (only) {
@@ -981,6 +995,25 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 		}
 		VK_HIP(hipMemcpyAsync(c->d_keys[0], hk.data(), hk.size() * 8, hipMemcpyHostToDevice, st));
 		VK_HIP(hipStreamSynchronize(st));   // `hk` leaves scope
+	} else if (kk > VK_MAX_MATCHES) {
+		// more matches than the block selection keeps per 2,048 keys: the keys of all n rows, sorted
+		if (c->sort_cap < (size_t)n) {
+			for (auto &b : c->d_sort) if (b) { VK_HIP(hipFree(b)); b = nullptr; }
+			c->sort_cap = 0;
+			if ((rc = alloc_t(c, &c->d_sort[0], (size_t)n + 64))) return rc;
+			if ((rc = alloc_t(c, &c->d_sort[1], (size_t)n + 64))) return rc;
+			c->sort_cap = (size_t)n;
+		}
+		size_t temp_bytes = 0;
+		uint64_t *sorted = nullptr;
+		VK_HIP(vk_launch_sort_all(nullptr, n, sel_floor, c->d_sort[0], c->d_sort[1], nullptr, &temp_bytes, &sorted, st));
+		if (c->sort_temp_cap < temp_bytes) {
+			if (c->d_sort_temp) { VK_HIP(hipFree(c->d_sort_temp)); c->d_sort_temp = nullptr; c->sort_temp_cap = 0; }
+			if ((rc = alloc(c, &c->d_sort_temp, temp_bytes))) return rc;
+			c->sort_temp_cap = temp_bytes;
+		}
+		VK_HIP(vk_launch_sort_all(c->d_scores, n, sel_floor, c->d_sort[0], c->d_sort[1], c->d_sort_temp, &temp_bytes, &sorted, st));
+		d_sel = sorted;
 	} else if (kk <= 64) {
 		// wave-streaming selection: n -> ceil(n/4096) * k keys -> ... -> k keys
 		int64_t nw = 0;
@@ -1002,15 +1035,16 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 	}
 
 	// ---- flow of the winners ------------------------------------------------
+	if (!d_sel) d_sel = c->d_keys[cur];
 	VK_HIP(hipEventRecord(c->ev[3], st));
-	if (do_flow && (rc = launch_flow(c->d_keys[cur], kk))) return rc;
+	if (do_flow && (rc = launch_flow(d_sel, kk))) return rc;
 	VK_HIP(hipEventRecord(c->ev[4], st));
 
 	// ---- results to host ------------------------------------------------------
 	std::vector<uint64_t> &keys = keep.vec<uint64_t>((size_t)kk);
 	std::vector<float> &raw = keep.vec<float>((size_t)kk), &sim = keep.vec<float>((size_t)kk * ostride);
 	std::vector<int16_t> &map = keep.vec<int16_t>((size_t)kk * ostride);
-	VK_HIP(hipMemcpyAsync(keys.data(), c->d_keys[cur], (size_t)kk * 8, hipMemcpyDeviceToHost, st));
+	VK_HIP(hipMemcpyAsync(keys.data(), d_sel, (size_t)kk * 8, hipMemcpyDeviceToHost, st));
 	if (do_flow) {
 		VK_HIP(hipMemcpyAsync(raw.data(), c->d_out_raw, (size_t)kk * 4, hipMemcpyDeviceToHost, st));
 		VK_HIP(hipMemcpyAsync(map.data(), c->d_out_map, map.size() * 2, hipMemcpyDeviceToHost, st));
@@ -1103,8 +1137,13 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 	}
 	std::vector<float> &raw_sel = keep.vec<float>((size_t)std::max(n_out, 1));
 	if (!do_flow && !(canon_tr && n_sel > 0) && out->raw_score && n_out > 0) {
-		// gather the aligner scores of the winners
-		for (int i = 0; i < n_out; i++) {
+		// gather the aligner scores of the winners (a large result set: the whole array in one copy, gathered here)
+		if (n_out > 256 && !span_skip_raw) {
+			std::vector<float> &all_raw = keep.vec<float>((size_t)n);
+			VK_HIP(hipMemcpyAsync(all_raw.data(), c->d_raw, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+			VK_HIP(hipStreamSynchronize(st));
+			for (int i = 0; i < n_out; i++) raw_sel[(size_t)i] = all_raw[(size_t)(uint32_t)(keys[(size_t)i] & 0xffffffffu)];
+		} else for (int i = 0; i < n_out; i++) {
 			const int64_t g = (int64_t)(uint32_t)(keys[(size_t)i] & 0xffffffffu);
 			if (!span_skip_raw) VK_HIP(hipMemcpyAsync(&raw_sel[(size_t)i], c->d_raw + g, 4, hipMemcpyDeviceToHost, st));
 		}

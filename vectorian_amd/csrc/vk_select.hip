@@ -1,6 +1,8 @@
 // vk_select.hip -- bounded result sets (top-k), candidate selection and the small per-row kernels around them.
 #include "vk_common.hip.h"
 
+#include <hipcub/hipcub.hpp>
+
 // ---------------------------------------------------------------------------
 // bounded result set: keys = (orderable(score) << 32) | sentence, descending.
 // Order = score desc, sentence index desc (match/match_impl.h:8-42);
@@ -268,4 +270,28 @@ extern "C" hipError_t vk_launch_topk_wave_batch(const float *scores, const uint6
 	else vk_topk_wave_batch_kernel<0><<<grid, 256, 0, stream>>>(scores, nullptr, n, min_score, k, per_wave, in_stride, out_stride, out);
 	*n_waves_out = nw;
 	return hipGetLastError();
+}
+
+
+// ---------------------------------------------------------------------------
+// Result sets of more than VK_MAX_MATCHES entries: the keys of ALL slices, sorted (upstream's ResultSet holds whatever max_matches
+// allows, result_set.h:32-68; the block selection above keeps at most 1,024 per 2,048 keys).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vk_keys_all_kernel(const float *__restrict__ scores, int64_t n, float min_score, uint64_t *__restrict__ out) {
+	const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= n) return;
+	const float s = scores[g];
+	out[g] = s > min_score ? ((uint64_t)float_orderable(s) << 32) | (uint32_t)g : 0ull;
+}
+
+extern "C" hipError_t vk_launch_sort_all(const float *scores, int64_t n, float min_score, uint64_t *keys_a, uint64_t *keys_b, void *temp, size_t *temp_bytes,
+	uint64_t **sorted_out, hipStream_t stream) {
+	hipcub::DoubleBuffer<uint64_t> buf(keys_a, keys_b);
+	if (!temp) return hipcub::DeviceRadixSort::SortKeysDescending(nullptr, *temp_bytes, buf, (int)n, 0, 64, stream);
+	vk_keys_all_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(scores, n, min_score, keys_a);
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) return e;
+	e = hipcub::DeviceRadixSort::SortKeysDescending(temp, *temp_bytes, buf, (int)n, 0, 64, stream);
+	*sorted_out = buf.Current();
+	return e;
 }
