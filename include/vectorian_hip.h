@@ -32,7 +32,11 @@ extern "C" {
 #endif
 
 #define VK_ABI_VERSION 12
-#define VK_MAX_QUERY_LEN 64   /* query tokens */
+#define VK_MAX_QUERY_LEN 64   /* query tokens, every strategy */
+#define VK_MAX_LONG_QUERY_LEN 512 /* alignments (VK_ALG_ALIGN, submatch_weight = 0) over slices of at most VK_FAST_SENT_LEN tokens: queries of up to
+                                 this many tokens (a whole paragraph as the query) -- one wave per slice with the roles swapped, lanes = the
+                                 slice's tokens, the query's tokens streamed (vk_longq_kernel); upstream's own bound is the int16 of a
+                                 mapping (metric/alignment.h:357-358) */
 #define VK_FAST_QUERY_LEN 16  /* queries up to this length run in the fused kernels (one 16-wide MFMA column block); longer ones
                                  take the multi-block kernel (2 or 4 column blocks) or, where that does not apply, a
                                  one-wave-per-slice kernel, ~10x slower */
@@ -107,7 +111,7 @@ typedef struct {
 
 typedef struct {
 	int32_t algorithm;       /* vk_algorithm */
-	int32_t len_t;           /* query tokens, 1..VK_MAX_QUERY_LEN */
+	int32_t len_t;           /* query tokens, 1..VK_MAX_QUERY_LEN (alignments: ..VK_MAX_LONG_QUERY_LEN) */
 	const void *q_vectors;   /* host [len_t x d] row-major */
 	int32_t q_dtype;         /* vk_dtype */
 	int32_t q_normalize;     /* 1: rows are L2-normalised by the library (Vectors.normalized) */

@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define VKO_MAX_LEN_S 32767 /* int16 of a mapping (metric/alignment.h:357-358) */
-#define VKO_MAX_LEN_T 64
+#define VKO_MAX_LEN_T 512 /* (64 until round 4: queries of up to 512 tokens, alignments) */
 
 /* pyalign::enums::Locality as used at vectorian/core/cpp/metric/alignment.h:363-364
  * and vectorian/alignment.py:97,130,187 */

@@ -172,3 +172,99 @@ def test_two_block_kernel_static_layout(hip, oracle, len_t):
 			assert_same_results(got.trimmed(), ref, check_mapping=False, score_tol=2e-5, tie_tol=2e-5)
 			np.testing.assert_allclose(c.last_scores(), ref["all_scores"], atol=2e-5)
 	c.close()
+
+
+LONG_GAPS = {"linear": (0.1, 0.05), "affine": (AFF, ("affine", 0.1, 0.02)), "exp5": (EXP5L, EXP5L)}
+
+
+@pytest.mark.parametrize("len_t", [65, 100, 200, 512])
+@pytest.mark.parametrize("gap", ["linear", "affine", "exp5"])
+def test_long_query_contextual(hip, oracle, len_t, gap):
+	"""queries of 65 .. 512 tokens (round 4: VK_ERR_UNSUPPORTED until then; upstream's only bound is the int16 of a mapping,
+	vectorian/core/cpp/metric/alignment.h:357-358): vk_longq_kernel -- one wave per slice, lane = slice token, anti-diagonal sweep over
+	the query's tokens; the k + 8 best retraced in the canonical arithmetic with the oracle's order of candidates.  Slice ids, scores
+	and tracebacks equal to the oracle's bit for bit, every locality; the score vector of all slices within 1e-4"""
+	d = 64 if len_t >= 200 else 300
+	n = 90 if (gap == "exp5" and len_t == 512) else 260
+	corpus = synth.make_contextual_corpus(n, 0, 64, 600, d)
+	Xb = prep_contextual(corpus)
+	c = hip_contextual_corpus(hip, corpus, Xb)
+	rng = np.random.default_rng(len_t)
+	# a query that quotes a passage of the corpus (several consecutive slices) with noise, so that long alignments exist
+	off = corpus["sent_off"]
+	s0 = 40
+	toks = np.arange(off[s0], off[s0] + len_t) % off[-1]
+	Q = corpus["X"][toks] + 0.3 * rng.standard_normal((len_t, d)).astype(np.float32)
+	Qb = synth.to_bf16_bits(synth.normalize_rows(Q))
+	gs, gt = LONG_GAPS[gap]
+	boost = rng.uniform(0.5, 1.5, size=n).astype(np.float32)
+	for loc, ms in ((0, 0.0), (1, -1e9), (2, -1e9)):
+		bst = boost if loc == 2 else None
+		ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=off, X=Xb, Q=Qb, locality=loc, gap_s=gs, gap_t=gt, max_matches=9, min_score=ms,
+			boost=bst, want_all_scores=True)
+		got = c.query(Qb, q_normalize=False, locality=loc, gap_s=gs, gap_t=gt, max_matches=9, min_score=ms, boost=bst)
+		assert_same_results(got.trimmed(), ref)
+		full = np.diff(off) > 0      # (empty slices carry no score: -inf)
+		np.testing.assert_allclose(c.last_scores()[full], np.asarray(ref["all_scores"])[full], atol=1e-4)
+		assert np.isneginf(c.last_scores()[~full]).all()
+		for i in range(got.n):   # edge similarities of the matched pairs
+			s = int(got.sentence[i])
+			S = oracle.sim_bf16(Xb[off[s]:off[s + 1]], Qb)
+			for j in np.nonzero(got.mapping[i] >= 0)[0]:
+				assert abs(got.edge_sim[i, j] - S[int(got.mapping[i, j]), j]) < 2e-6
+		noflow = c.query(Qb, q_normalize=False, locality=loc, gap_s=gs, gap_t=gt, max_matches=9, min_score=ms, boost=bst, want_flow=False)
+		assert_same_results(noflow.trimmed(), ref, check_mapping=False, score_tol=1e-4, tie_tol=1e-4)
+	c.close()
+
+
+@pytest.mark.parametrize("len_t,gap", [(80, "linear"), (130, "exp5"), (300, "affine")])
+def test_long_query_static_with_tag_weights_and_views(hip, oracle, len_t, gap):
+	"""the static layout (per-tile tables gathered by token id, sim[id(t_j)][j] = 1), the tag-weighted modifier, a view beside its owner,
+	only_slices (the debug hook's walk), and the refusals: transports, long slices, a submatch weight"""
+	corpus = synth.make_static_corpus(300, 1, 50, 400, 96, seed=5)
+	off = corpus["sent_off"]
+	n_tok = int(off[-1])
+	Eb = synth.to_bf16_bits(synth.normalize_rows(corpus["E"]))
+	rng = np.random.default_rng(17 + len_t)
+	pos = rng.integers(1, 6, size=n_tok).astype(np.int8)
+	c = hip.Corpus(layout=hip.VK_LAYOUT_STATIC, d=96, n_tokens=n_tok, n_sentences=300, vocab_size=400)
+	c.append_vectors(Eb, normalize=False)
+	c.set_token_ids(corpus["tok_id"])
+	c.set_token_pos(pos)
+	c.set_sentences(off)
+	c.finalize()
+	q_ids = np.concatenate([corpus["tok_id"][off[s]:off[s + 1]] for s in range(60, 75)])[:len_t].astype(np.int32)
+	if len(q_ids) < len_t:
+		q_ids = np.concatenate((q_ids, rng.integers(0, 400, size=len_t - len(q_ids)).astype(np.int32)))
+	q_ids[5] = -1                                # a word the vocabulary does not hold
+	Qb = Eb[np.where(q_ids >= 0, q_ids, 3)]
+	gs, gt = LONG_GAPS[gap]
+	tw = rng.uniform(0.5, 1.5, size=len_t).astype(np.float32)
+	q_pos = rng.integers(1, 6, size=len_t).astype(np.int8)
+	v = c.view()
+	for loc, ms, tagged in ((0, 0.0, False), (1, -1e9, True), (2, -1e9, True), (0, 0.05, True)):
+		okw = dict(tag_weights=tw, q_pos=q_pos, pos_s=pos, pos_mismatch_penalty=0.3, similarity_threshold=0.1) if tagged else {}
+		ckw = dict(tag_weights=tw, q_pos=q_pos, pos_mismatch_penalty=0.3, similarity_threshold=0.1) if tagged else {}
+		ref = oracle.find(layout=oracle.LAYOUT_STATIC, d=96, sent_off=off, tok_id=corpus["tok_id"], E=Eb, Q=Qb, q_ids=q_ids, locality=loc,
+			gap_s=gs, gap_t=gt, max_matches=7, min_score=ms, **okw)
+		for h in (c, v):
+			got = h.query(Qb, q_token_ids=q_ids, q_normalize=False, locality=loc, gap_s=gs, gap_t=gt, max_matches=7, min_score=ms, **ckw)
+			assert_same_results(got.trimmed(), ref)
+	# only_slices: exactly these slices, in this order, whatever their score
+	ids = np.array([70, 3, 61, 299, 0], dtype=np.int64)
+	got = c.query(Qb, q_token_ids=q_ids, q_normalize=False, locality=0, gap_s=gs, gap_t=gt, only_slices=ids)
+	full = oracle.find(layout=oracle.LAYOUT_STATIC, d=96, sent_off=off, tok_id=corpus["tok_id"], E=Eb, Q=Qb, q_ids=q_ids, locality=0, gap_s=gs, gap_t=gt,
+		max_matches=300, min_score=-1.0)
+	by_id = {int(s): i for i, s in enumerate(full["sentence"])}
+	assert got.n == 5 and (got.sentence[:5] == ids).all()
+	for i, s in enumerate(ids):
+		assert got.score[i] == np.float32(full["score"][by_id[int(s)]]) and (got.mapping[i] == full["mapping"][by_id[int(s)]]).all()
+	for kw in (dict(algorithm=hip.VK_ALG_RWMD), dict(algorithm=hip.VK_ALG_WRD), dict(submatch_weight=0.5)):
+		with pytest.raises(hip.VkError) as e:
+			c.query(Qb, q_token_ids=q_ids, q_normalize=False, **kw)
+		assert e.value.status in (hip.VK_ERR_UNSUPPORTED, hip.VK_ERR_STATE)
+	with pytest.raises(hip.VkError) as e:
+		c.query(np.zeros((513, 96), np.float32))
+	assert e.value.status == hip.VK_ERR_UNSUPPORTED
+	v.close()
+	c.close()

@@ -20,6 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VECTORIAN_HIP_LIB", os.path.join(_HERE, "lib", "libvectorian_hip.so"))
 
 VK_MAX_QUERY_LEN = 64
+VK_MAX_LONG_QUERY_LEN = 512   # alignments over slices of at most 64 tokens (vk_longq_kernel)
 VK_MAX_SENT_LEN = 512
 VK_MAX_DOC_LEN = 32767
 VK_FAST_SENT_LEN = 64

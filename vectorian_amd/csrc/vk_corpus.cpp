@@ -189,7 +189,8 @@ int vk_corpus_free(vk_corpus_t *c) {
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	void *ptrs[] = {c->d_stage, c->d_qtile, c->d_ws, c->d_wt, c->d_qids,
 		c->d_table, c->d_scores, c->d_raw, c->d_boost, c->d_keys[0], c->d_keys[1], c->d_out_raw, c->d_out_sim, c->d_out_map, c->d_wrd_raw, c->d_wrd_val, c->d_bq, c->d_bqlen, c->d_bscores, c->d_bkeys[0], c->d_bkeys[1], c->d_counter, c->d_rows_out, c->d_plan_out, c->d_braw, c->d_wrdl_scratch, c->d_wide_scratch, c->d_wide_order, c->d_xlong_order, c->d_apart_order, c->d_bqt, c->d_bcand, c->d_bcandq, c->d_brows, c->d_qbits,
-		c->d_sb_id[0], c->d_sb_id[1], c->d_btable, c->d_bfix, c->d_bqids, c->d_sort[0], c->d_sort[1], c->d_sort_temp};
+		c->d_sb_id[0], c->d_sb_id[1], c->d_btable, c->d_bfix, c->d_bqids, c->d_sort[0], c->d_sort[1], c->d_sort_temp,
+		c->lq.qt, c->lq.fl, c->lq.il, c->lq.table, c->lq.scratch, c->lq.fscratch, c->lq.raw, c->lq.sim, c->lq.map};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	if (c->h_brows) (void)hipHostFree(c->h_brows);
 	for (auto &b : c->bl) for (void *p : {(void *)b.tiles, (void *)b.len, (void *)b.id}) if (p) (void)hipFree(p);

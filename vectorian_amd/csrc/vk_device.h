@@ -272,9 +272,52 @@ struct VkWideParams {
 	int32_t ws_tail;           // vk_wide_kernel, general gaps: w_s[k] == w_s[ws_tail] for every k >= ws_tail up to max_len (0: no such tail)
 };
 
+// queries of 65 .. VK_MAX_QUERY_LEN tokens (vk_longq_kernel): one wave per slice, lane = slice token, anti-diagonal sweep
+struct VkLongqParams {
+	const uint8_t *tiles;
+	const int32_t *tok_id;
+	const float *table;        // static: nq tables [V_pad x 16] (one per 16 query tokens), table_stride floats apart
+	int64_t table_stride;
+	const int32_t *sent_start;
+	const int32_t *sent_end;
+	int32_t n_sent;
+	int32_t layout;
+	int32_t nk32, tail, tile_bytes;
+	int32_t prec;
+	const uint8_t *qtile;      // nq query tiles of 16 rows, tile_bytes apart
+	int32_t nq, len_t;
+	int32_t locality;
+	int32_t gap_mode;          // 0 linear, 1 affine, 2 general
+	float gs, gt, a_s, a_t, open_s, open_t;
+	const float *ws;           // general: w_s[0 .. 64]
+	const float *wt;           // general: w_t[0 .. len_t]
+	const int8_t *pos_s;       // tag-weighted similarity modifier (null: off)
+	const float *tw;           // [16 nq] t_pos_weights (device)
+	const int32_t *tpos;       // [16 nq] POS code per query token (device)
+	float tw_keep, tw_threshold;
+	float ref_total;
+	const float *boost;
+	float *scores;
+	float *raw;
+	int32_t d;                 // FLOW: features per row (unpadded) and, static layout, the query's token ids [16 nq] (sim_canon)
+	const int32_t *q_ids;
+	const uint64_t *keys;      // FLOW: winners
+	int32_t n_keys;
+	float *raw_out;            // [k]
+	int16_t *mapping;          // [k x out_stride]
+	float *edge_sim;           // [k x out_stride]
+	int32_t out_stride;
+	uint8_t *scratch;          // one region of scratch_stride bytes per workgroup (vk_longq_scratch_bytes): the matrix of general gaps, the cells' records
+	int64_t scratch_stride;
+};
+
 #ifdef __cplusplus
 extern "C" {
 #endif
+size_t vk_longq_scratch_bytes(int32_t len_t, int32_t gap_mode, int32_t flow, int32_t tagged);
+size_t vk_longq_lds_bytes(int32_t len_t, int32_t flow);
+int32_t vk_longq_blocks(int32_t len_t, int64_t n_sent);
+hipError_t vk_launch_longq(const VkLongqParams *p, int32_t flow_k, hipStream_t stream);
 hipError_t vk_launch_wide(const VkWideParams *p, int32_t flow_k, hipStream_t stream);
 hipError_t vk_launch_submatch_bound(const float *raw, const float *boost, int64_t n, float total, float w, float m_star,
 	float *scores, hipStream_t stream);

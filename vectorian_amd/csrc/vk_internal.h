@@ -169,6 +169,19 @@ struct vk_corpus {
 	// `shared` the block this handle allocates into (a view: its source's), `vectors_of` the block of the source of a filtered
 	// static corpus (its vocabulary tiles and magnitudes).  The raw pointers above are aliases into these blocks.
 	std::shared_ptr<vk_devblock> shared, vectors_of;
+	// queries of 65 .. VK_MAX_LONG_QUERY_LEN tokens (vk_longq_host.cpp): query tiles, small per-query arrays (floats / ints), the static
+	// layout's tables (one per 16 query tokens), scratch of the scoring pass and of the tracebacks, the winners' outputs
+	struct longq_bufs {
+		uint8_t *qt = nullptr; size_t qt_cap = 0;
+		float *fl = nullptr; size_t fl_cap = 0;
+		int32_t *il = nullptr; size_t il_cap = 0;
+		float *table = nullptr; size_t table_cap = 0;
+		uint8_t *scratch = nullptr; size_t scratch_cap = 0;
+		uint8_t *fscratch = nullptr; size_t fscratch_cap = 0;
+		float *raw = nullptr; size_t raw_cap = 0;
+		float *sim = nullptr; size_t sim_cap = 0;
+		int16_t *map = nullptr; size_t map_cap = 0;
+	} lq;
 	vk_corpus *peer = nullptr;   // ring of the handles on one corpus: a handle's scoring kernel starts after its peer's (under vk_ring_mutex)
 	std::atomic<bool> ev2_recorded{false};   // (device-side wait on ev[2]), so that scoring kernels run back to back, never queued inside each other
 };
@@ -197,6 +210,8 @@ template <typename T> int alloc_shared(vk_corpus *c, T **p, size_t n) {
 // ring's mutex so that the peer cannot be unlinked and destroyed in between (vk_corpus.cpp)
 int vk_wait_peer_turn(vk_corpus *c, hipStream_t st);
 int vk_validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_topk_out *out);
+class vk_host_keep;
+int vk_longq_query(vk_corpus *c, const vk_query_desc *q, vk_topk_out *out, vk_host_keep &keep);   // vk_longq_host.cpp
 void vk_pack_query(const vk_corpus *c, const vk_query_desc *q, std::vector<uint8_t> &tile, float *mags);
 
 #endif

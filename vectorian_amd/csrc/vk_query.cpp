@@ -36,7 +36,15 @@ int vk_validate_query(const vk_corpus *c, const vk_query_desc *q, const vk_topk_
 	if (!c || !q || !out) return fail(VK_ERR_INVALID, "null argument");
 	if (!c->finalized) return fail(VK_ERR_STATE, "corpus not finalized");
 	if (q->len_t < 1) return fail(VK_ERR_INVALID, "empty query");
-	if (q->len_t > VK_MAX_QUERY_LEN) return fail(VK_ERR_UNSUPPORTED, "query longer than VK_MAX_QUERY_LEN (64) tokens");
+	if (q->len_t > VK_MAX_LONG_QUERY_LEN) return fail(VK_ERR_UNSUPPORTED, "query longer than VK_MAX_LONG_QUERY_LEN (512) tokens");
+	if (q->len_t > VK_MAX_QUERY_LEN) {
+		// 65 .. 512 tokens: the role-swapped one-wave-per-slice kernel (vk_longq_kernel) -- alignments over slices of at most 64 tokens
+		if (q->algorithm != VK_ALG_ALIGN) return fail(VK_ERR_UNSUPPORTED, "queries of more than VK_MAX_QUERY_LEN (64) tokens: alignments only (the transports keep a lane per query token)");
+		if (c->max_len > VK_FAST_SENT_LEN) return fail(VK_ERR_UNSUPPORTED, "queries of more than 64 tokens over a corpus that holds a slice of more than 64 tokens: a lane per slice token");
+		if (q->submatch_weight != 0.0f) return fail(VK_ERR_UNSUPPORTED, "queries of more than 64 tokens with a submatch weight");
+		if (out->sim_rows) return fail(VK_ERR_UNSUPPORTED, "queries of more than 64 tokens: similarity rows of the winners are not returned");
+		if (q->max_matches > VK_MAX_MATCHES) return fail(VK_ERR_UNSUPPORTED, "queries of more than 64 tokens: max_matches <= VK_MAX_MATCHES");
+	}
 	const bool exact_tr = q->algorithm == VK_ALG_WRD || (q->algorithm == VK_ALG_RWMD && (q->wmd_full || !q->rwmd_injective));   // multi-block kernel + kernels of their own for the long slices: no wide kernel
 	if (q->len_t > VK_FAST_QUERY_LEN && exact_tr && !score32_plan(c, q).fits)
 		return fail(VK_ERR_UNSUPPORTED, "exact transport / 1:n RWMD with a query of more than 16 tokens: the query tiles of rows this wide and one wave's similarity strip exceed the LDS of a workgroup (160 KiB)");
@@ -171,6 +179,7 @@ void vk_pack_query(const vk_corpus *c, const vk_query_desc *q, std::vector<uint8
 static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, vk_host_keep &keep) {
 	int rc = VK_OK;
 	VK_HIP(hipSetDevice(c->device));
+	if (q->len_t > VK_MAX_QUERY_LEN) return vk_longq_query(c, q, out, keep);   // 65 .. 512 tokens (vk_longq_host.cpp)
 	hipStream_t st = c->stream;
 	const int64_t n = c->n_entries;           // rows of the slice table (== n_sentences unless long slices were padded)
 	const int k = q->max_matches;

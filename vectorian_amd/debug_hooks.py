@@ -179,7 +179,7 @@ class DebugHookMixin:
 			return
 		if alg != core.VK_ALG_ALIGN:
 			return self._call_debug_hook(hook, p_query, local["top"], matches, args)
-		call = dict(local["call"], want_rows=True)
+		call = dict(local["call"], want_rows=len_t <= core.VK_MAX_QUERY_LEN)   # (queries of more than 64 tokens: no similarity rows)
 		masks = local["masks"]
 		for a in range(0, n_loc, max(1, int(getattr(hook, "chunk", 512)))):
 			ids = np.arange(a, min(n_loc, a + max(1, int(getattr(hook, "chunk", 512)))), dtype=np.int64)
@@ -197,5 +197,5 @@ class DebugHookMixin:
 				matched = target >= 0
 				flow = {"type": "injective", "target": target, "flow": matched.astype(np.float32),
 					"dist": np.where(matched, 1.0 - top.edge_sim[i], 1.0).astype(np.float32)}
-				sim = top.sim_rows[i][:len_s, :len_t].copy() if len_s <= top.sim_rows.shape[1] else None
+				sim = top.sim_rows[i][:len_s, :len_t].copy() if (top.sim_rows is not None and len_s <= top.sim_rows.shape[1]) else None
 				hook("alignment", {"slice": self._slice_id[g], "similarity": sim, "flow": flow, "score": float(top.raw_score[i])})

@@ -302,7 +302,7 @@ class HipBruteForceIndex(LanesMixin, ShardExchangeMixin, DebugHookMixin, Index):
 		if hook is not None and not callable(hook):
 			raise TypeError("debug must be callable: hook(name, data)")   # query.cpp:73-75 casts to a py::object it later calls
 		call = dict(args)
-		if hook is not None:
+		if hook is not None and len(p_query) <= core.VK_MAX_QUERY_LEN:   # (queries of more than 64 tokens: the winners' similarity rows are not returned)
 			call["want_rows"] = True
 		call["abort_flag"] = query._abort
 		if emb.is_static:
