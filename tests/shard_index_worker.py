@@ -87,7 +87,8 @@ def many_queries(index, n=37):
 	for i in range(n):
 		doc = session.documents[i % len(session.documents)]
 		st = int(doc.spans["sentence"]["start"][(7 * i) % len(doc.spans["sentence"]["start"])])
-		out.append(" ".join(doc.tokens[st:st + (20 if i % 9 == 4 else 3 + i % 4)]))   # now and then a record of another size (32 columns)
+		# now and then a record of another size (32 columns); once a query of 70 tokens (round 4: the long-query path, records of 80 columns)
+		out.append(" ".join(doc.tokens[st:st + (70 if i == 19 else 20 if i % 9 == 4 else 3 + i % 4)]))
 	return out
 
 

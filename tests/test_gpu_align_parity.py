@@ -125,9 +125,11 @@ def test_all_scores_and_boost(hip, oracle):
 def test_errors_are_loud(hip):
 	corpus = synth.make_contextual_corpus(10, 4, 8, 100, 32)
 	c = hip_contextual_corpus(hip, corpus)
-	q = np.ones((65, 32), dtype=np.float32)
+	q = np.ones((513, 32), dtype=np.float32)   # (65 .. 512 tokens run since round 4: vk_longq_kernel)
 	with pytest.raises(hip.VkError):
 		c.query(q)
+	with pytest.raises(hip.VkError):
+		c.query(q[:65], algorithm=hip.VK_ALG_RWMD)
 	with pytest.raises(hip.VkError):
 		c.query(q[:3], submatch_weight=-0.5)
 	with pytest.raises(hip.VkError):

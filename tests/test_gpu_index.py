@@ -404,3 +404,28 @@ def test_find_many_shares_calls_over_static_embeddings_on_hip(hip, strategy):
 				if key != "type":
 					assert (np.asarray(fa[key]) == np.asarray(fb[key])).all()
 	gpu.close()
+
+
+def test_a_paragraph_as_the_query_on_hip_equals_oracle_double(hip):
+	"""queries of more than 64 tokens through the operator surface (round 4; refused until then): a passage of 90 / 150 tokens as the
+	query of Index.find and find_many -- matches, scores, flows and regions as on the oracle double; the debug hook is called for the
+	winners without a similarity matrix (the rows of such queries are not returned)"""
+	session, emb, words, rng = toy_session(n_docs=10, sents_per_doc=40)
+	for optimizer in (alignment.LocalAlignment(gap=alignment.smooth_gap_cost(5)), alignment.SemiGlobalAlignment(gap=alignment.LinearGapCost(0.1))):
+		sim = OptimizedSpanSim(EmbeddingTokenSim(emb, CosineSim()), optimizer)
+		gpu = session.partition("sentence").index(sim)
+		cpu = session.partition("sentence").index(sim, corpus_factory=OracleCorpus)
+		doc = session.documents[4]
+		texts = [" ".join(doc.tokens[30:120]), " ".join(doc.tokens[200:350]), " ".join(doc.tokens[5:9])]
+		many = gpu.find_many(texts, n=8, min_score=-100.0)
+		for text, res in zip(texts, many):
+			a, b = gpu.find(text, n=8, min_score=-100.0), cpu.find(text, n=8, min_score=-100.0)
+			assert [(m.doc_index, m.slice_id) for m in a] == [(m.doc_index, m.slice_id) for m in b] == [(m.doc_index, m.slice_id) for m in res]
+			assert [m.score for m in a] == [m.score for m in b] == [m.score for m in res]
+			for x, y in zip(a, b):
+				assert (x.flow["target"] == y.flow["target"]).all() and (x.flow["dist"] == y.flow["dist"]).all()
+			assert a[0].to_json()["regions"] == b[0].to_json()["regions"]
+		calls = []
+		gpu.find(texts[0], n=3, debug=lambda name, data: calls.append(data))
+		assert len(calls) == 3 and all(d["similarity"] is None for d in calls)
+		gpu.close()

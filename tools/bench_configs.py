@@ -58,7 +58,7 @@ def main():
 		corpus.set_token_ids(ids)
 		corpus.set_sentences(off)
 		corpus.finalize()
-		w = (1 - 2.0 ** (-np.arange(0, 65) / 5)).astype(np.float32)
+		w = (1 - 2.0 ** (-np.arange(0, max(65, args.len_t + 1)) / 5)).astype(np.float32)
 		gap = {"exp5": ("table", w), "linear": 0.1, "affine": ("affine", 0.2, 0.05)}[args.gap]
 		loc = {"local": 0, "global": 1, "semiglobal": 2}[args.locality]
 		alg = {"align": core.VK_ALG_ALIGN, "rwmd": core.VK_ALG_RWMD, "wrd": core.VK_ALG_WRD}[args.alg]
@@ -120,7 +120,7 @@ def main():
 		corpus = source.filtered(pos_mask=2)
 		filter_ms = (time.perf_counter() - t0) * 1e3
 
-	w = (1 - 2.0 ** (-np.arange(0, 65) / 5)).astype(np.float32)
+	w = (1 - 2.0 ** (-np.arange(0, max(65, args.len_t + 1)) / 5)).astype(np.float32)
 	gap = {"exp5": ("table", w), "linear": 0.1, "affine": ("affine", 0.2, 0.05),
 		"lintable": ("table", (0.1 * np.arange(0, 65)).astype(np.float32)),
 		"convex": ("table", np.minimum(0.02 * np.arange(0, 65) ** 2, 1.0).astype(np.float32))}[args.gap]

@@ -286,11 +286,13 @@ struct VkLongqParams {
 	int32_t prec;
 	const uint8_t *qtile;      // nq query tiles of 16 rows, tile_bytes apart
 	int32_t nq, len_t;
+	int32_t s_stride;          // floats per row of the LDS strip: the corpus's longest slice rounded up to 16 (vk_longq_stride)
 	int32_t locality;
 	int32_t gap_mode;          // 0 linear, 1 affine, 2 general
 	float gs, gt, a_s, a_t, open_s, open_t;
 	const float *ws;           // general: w_s[0 .. 64]
 	const float *wt;           // general: w_t[0 .. len_t]
+	int32_t wt_tail;           // general, scoring pass: w_t[k] == w_t[wt_tail] for every k >= wt_tail up to len_t (0: no such tail)
 	const int8_t *pos_s;       // tag-weighted similarity modifier (null: off)
 	const float *tw;           // [16 nq] t_pos_weights (device)
 	const int32_t *tpos;       // [16 nq] POS code per query token (device)
@@ -315,8 +317,10 @@ struct VkLongqParams {
 extern "C" {
 #endif
 size_t vk_longq_scratch_bytes(int32_t len_t, int32_t gap_mode, int32_t flow, int32_t tagged);
-size_t vk_longq_lds_bytes(int32_t len_t, int32_t flow);
-int32_t vk_longq_blocks(int32_t len_t, int64_t n_sent);
+size_t vk_longq_lds_bytes(int32_t len_t, int32_t max_len, int32_t flow);
+int32_t vk_longq_blocks(int32_t len_t, int32_t max_len, int64_t n_sent, int32_t hm_in_lds);
+int32_t vk_longq_hm_in_lds(int32_t len_t, int32_t max_len);
+int32_t vk_longq_stride(int32_t max_len);
 hipError_t vk_launch_longq(const VkLongqParams *p, int32_t flow_k, hipStream_t stream);
 hipError_t vk_launch_wide(const VkWideParams *p, int32_t flow_k, hipStream_t stream);
 hipError_t vk_launch_submatch_bound(const float *raw, const float *boost, int64_t n, float total, float w, float m_star,

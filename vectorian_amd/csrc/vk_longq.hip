@@ -25,6 +25,10 @@
 // kernel.
 // ---------------------------------------------------------------------------
 
+// the strip's row: the corpus's longest slice rounded up to 16 columns (a 32-token corpus takes half the LDS of a 64-token one:
+// twice the waves per CU)
+static inline int longq_stride(int max_len) { const int w = (max_len + 15) / 16 * 16; return w < 16 ? 16 : w > 64 ? 64 : w; }
+
 struct VkLongqGeom { int lt_pad; size_t s_bytes, hm_bytes, dm_bytes, su_bytes; };
 
 static inline VkLongqGeom longq_geom(int len_t, bool general, bool flow, bool tagged) {
@@ -37,32 +41,58 @@ static inline VkLongqGeom longq_geom(int len_t, bool general, bool flow, bool ta
 	return g;
 }
 
+extern "C" int32_t vk_longq_stride(int32_t max_len) { return longq_stride(max_len); }
+
 extern "C" size_t vk_longq_scratch_bytes(int32_t len_t, int32_t gap_mode, int32_t flow, int32_t tagged) {
 	const VkLongqGeom g = longq_geom(len_t, gap_mode == 2, flow != 0, tagged != 0);
 	return (g.hm_bytes + g.dm_bytes + g.su_bytes + 255) / 256 * 256 + 256;
 }
 
-extern "C" size_t vk_longq_lds_bytes(int32_t len_t, int32_t flow) {
-	return longq_geom(len_t, false, false, false).s_bytes + (flow ? VK_CANON_LDS : 0) + 64;
+extern "C" size_t vk_longq_lds_bytes(int32_t len_t, int32_t max_len, int32_t flow) {
+	return (size_t)((len_t + 15) / 16 * 16) * longq_stride(max_len) * 4 + (flow ? VK_CANON_LDS : 0) + 64;
 }
 
-// value of lane - 1 (lane 0: `border`)
-__device__ __forceinline__ float lane_up(float x, float border, int lane) {
-	const float y = __shfl_up(x, 1, 64);
-	return lane == 0 ? border : y;
+// value of lane - 1 (lane 0: `border`): one DPP move across the wave (wave_shr:1; the first version shifted through ds_bpermute, an LDS
+// round trip per step and register, and twice per step)
+__device__ __forceinline__ float lane_up(float x, float border) {
+	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, border), __builtin_bit_cast(int, x), 0x138, 0xf, 0xf, false));
+}
+
+// 300-d bf16 rows: the slice's token tiles (up to three at a time) stay in registers as A fragments while the query's tiles stream
+// past them -- each query tile is fetched from L2 once per slice (the second and third use hit the L1) instead of once per token
+// tile, and the token tiles once instead of once per query tile: 407 -> 97 KB of L2 traffic per 32-token slice and 100-token query,
+// which is what the first form of this pass was bound by (39 -> ms per million slices).  Plain loads for the query
+// tile (it is re-read by every wave), same MFMA sequence as sim_tile.
+template <int NK, bool HALF>
+__device__ __forceinline__ f32x4 longq_sim_tile(const QFrag<NK, HALF> &f, const uint8_t *__restrict__ qtile, int lane) {
+	bf16x8 x[NK];
+#pragma unroll
+	for (int t = 0; t < NK; t++) {
+		if (HALF && t == NK - 1) x[t] = load_half_block(qtile + t * 1024, lane, false);
+		else x[t] = *reinterpret_cast<const bf16x8 *>(qtile + t * 1024 + lane * 16);
+	}
+	f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+	for (int t = 0; t < NK; t++) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.q[t], x[t], acc, 0, 0, 0);
+	acc[0] = clip01(acc[0]); acc[1] = clip01(acc[1]); acc[2] = clip01(acc[2]); acc[3] = clip01(acc[3]);
+	return acc;
 }
 
 enum { LQ_STOP = 0, LQ_DIAG = 1, LQ_UP = 2, LQ_LEFT = 3 };   // D_* of the oracle; bits 0-1 of a cell's record, bit 2: E extended, bit 3: F extended, bits 4..: gap length
 
-template <bool FLOW, int GAP>
+// HL: general gaps, scoring pass: the matrix H[v][lane] in LDS behind the strip (queries of up to ~280 tokens over 64-token slices,
+// ~570 over 32-token ones: vk_longq_hm_in_lds) instead of the workgroup's scratch region in global memory -- the candidate scans
+// are loads from it, one per candidate (200,000 slices of 32 tokens, 100-token query, exp5: 396 -> ms)
+template <bool FLOW, int GAP, bool HL = false>
 __global__ __launch_bounds__(64) void vk_longq_kernel(VkLongqParams p) {
 	extern __shared__ float4 vk_smem4[];
 	uint8_t *canon = reinterpret_cast<uint8_t *>(vk_smem4);
 	float *Sl = reinterpret_cast<float *>(canon + (FLOW ? VK_CANON_LDS : 0));   // [lt_pad][64]: S[v - 1][u - 1], what the DP runs on
 	const int lane = threadIdx.x;
-	const int LT = p.len_t;
+	const int LT = p.len_t, SW = p.s_stride;
 	uint8_t *region = p.scratch ? p.scratch + (int64_t)blockIdx.x * p.scratch_stride : nullptr;
-	float *Hm = reinterpret_cast<float *>(region);                                                     // GAP 2: H[v][lane], v = 0 .. LT
+	const int HS = HL ? SW : 64;                                                                       // row stride of the matrix
+	float *Hm = HL ? Sl + (size_t)((LT + 15) / 16 * 16) * SW : reinterpret_cast<float *>(region);      // GAP 2: H[v][lane], v = 0 .. LT
 	const size_t hm_bytes = GAP == 2 ? (size_t)(LT + 1) * 64 * 4 : 0;
 	int16_t *Dm = reinterpret_cast<int16_t *>(region + hm_bytes);                                      // FLOW: the cells' records
 	float *Su = reinterpret_cast<float *>(region + hm_bytes + (FLOW ? (size_t)(LT + 1) * 64 * 2 : 0)); // FLOW with tag weights: unmodified S
@@ -107,7 +137,7 @@ __global__ __launch_bounds__(64) void vk_longq_kernel(VkLongqParams p) {
 							if (rel < len_s && c0 + r < LT) Su[(c0 + r) * 64 + rel] = x;
 							x = tag_weighted(x, p.tw[c0 + r], ps, p.tpos[c0 + r], p.tw_keep, p.tw_threshold);
 						}
-						if (rel < len_s) Sl[(c0 + r) * 64 + rel] = x;
+						if (rel < len_s) Sl[(c0 + r) * SW + rel] = x;
 					}
 				}
 			}
@@ -127,12 +157,37 @@ __global__ __launch_bounds__(64) void vk_longq_kernel(VkLongqParams p) {
 						const int c = 16 * b + 4 * j + r;
 						float y = e[r];
 						if (p.pos_s) y = tag_weighted(y, p.tw[c], ps, p.tpos[c], p.tw_keep, p.tw_threshold);
-						if (ucol) Sl[c * 64 + lane] = y;
+						if (ucol) Sl[c * SW + lane] = y;
 					}
 				}
 			}
 		} else {
 			const int tile0 = t_a >> 4, off = t_a - tile0 * 16, ntiles = ((t_b + 15) >> 4) - tile0;
+			if (p.prec == 0 && p.nk32 == 10 && p.tail == 1) {
+				for (int j0 = 0; j0 < ntiles; j0 += 3) {
+					QFrag<10, true> tf[3];
+#pragma unroll
+					for (int jj = 0; jj < 3; jj++)   // (past the slice's last tile: that tile again, its columns fall outside the slice and are dropped)
+						load_qfrag(tf[jj], p.tiles + (int64_t)(tile0 + (j0 + jj < ntiles ? j0 + jj : ntiles - 1)) * p.tile_bytes, lane);
+					for (int b = 0; b < p.nq; b++) {
+						const int vq = 16 * b + (lane & 15);
+#pragma unroll
+						for (int jj = 0; jj < 3; jj++) {
+							if (j0 + jj >= ntiles) break;
+							const f32x4 acc = longq_sim_tile(tf[jj], p.qtile + (int64_t)b * p.tile_bytes, lane);
+#pragma unroll
+							for (int r = 0; r < 4; r++) {
+								const int c = 16 * (j0 + jj) + 4 * (lane >> 4) + r - off;
+								if (c >= 0 && c < len_s) {
+									float y = acc[r];
+									if (p.pos_s) y = tag_weighted(y, p.tw[vq], p.pos_s[t_a + c], p.tpos[vq], p.tw_keep, p.tw_threshold);
+									Sl[vq * SW + c] = y;
+								}
+							}
+						}
+					}
+				}
+			} else
 			for (int b = 0; b < p.nq; b++) {
 				const int vq = 16 * b + (lane & 15);   // this lane's query token (0-based)
 				for (int j = 0; j < ntiles; j++) {
@@ -144,7 +199,7 @@ __global__ __launch_bounds__(64) void vk_longq_kernel(VkLongqParams p) {
 						if (c >= 0 && c < len_s) {
 							float y = acc[r];
 							if (p.pos_s) y = tag_weighted(y, p.tw[vq], p.pos_s[t_a + c], p.tpos[vq], p.tw_keep, p.tw_threshold);
-							Sl[vq * 64 + c] = y;
+							Sl[vq * SW + c] = y;
 						}
 					}
 				}
@@ -152,7 +207,7 @@ __global__ __launch_bounds__(64) void vk_longq_kernel(VkLongqParams p) {
 		}
 		wave_lds_fence();
 
-		// ---- the sweep.  a1 = H[u][v - 1], a2 = H[u][v - 2] of this lane's row (borders included); e1 / f1: the affine solver's states
+		// ---- the sweep.  a1 = H[u][v - 1] of this lane's row (borders included), prev_up = H[u - 1][v - 1]; e1 / f1: the affine solver's states
 		auto border_s = [&](int k) -> float {   // H[k][0]
 			if (!global || k == 0) return 0.0f;
 			return GAP == 0 ? -(gs * (float)k) : GAP == 1 ? -(a_s + gs * (float)k) : -p.ws[k];
@@ -161,8 +216,10 @@ __global__ __launch_bounds__(64) void vk_longq_kernel(VkLongqParams p) {
 			if (!global || k <= 0) return 0.0f;
 			return GAP == 0 ? -(gt * (float)k) : GAP == 1 ? -(a_t + gt * (float)k) : -p.wt[k];
 		};
-		float a1 = border_s(u), a2 = 0.0f;
+		float a1 = border_s(u);
+		float prev_up = 0.0f;         // H[u - 1][v - 1]: what `up` was one step ago (step 2: H[0][0] = 0)
 		float e1 = VK_NEG_INF, f1 = VK_NEG_INF;
+		float tail_max = VK_NEG_INF;   // general gaps, scoring pass: max of H[u][v'] over v' <= v - tail (see the scan below)
 		float best_v = 0.0f;          // LOCAL / SEMIGLOBAL: this row's best cell, first v among equals (borders are 0: "borders first")
 		int best_at = 0;
 		// (general gaps: row 0 and column 0 of the matrix are not stored -- the scans below take the borders from border_t / border_s)
@@ -170,11 +227,12 @@ __global__ __launch_bounds__(64) void vk_longq_kernel(VkLongqParams p) {
 		for (int dg = 2; dg <= steps_end; dg++) {
 			const int v = dg - u;
 			const bool act = ucol && v >= 1 && v <= LT;
-			const float up_h = lane_up(a1, border_t(dg - 1), lane);       // H[u - 1][v]
-			const float dg_h = lane_up(a2, border_t(dg - 2), lane);       // H[u - 1][v - 1]
+			const float up_h = lane_up(a1, border_t(dg - 1));       // H[u - 1][v] (lane 0: the border row)
+			const float dg_h = prev_up;                              // H[u - 1][v - 1] = H[u - 1][v] of the step before
+			prev_up = up_h;
 			float up_e = VK_NEG_INF;
-			if (GAP == 1) up_e = lane_up(e1, VK_NEG_INF, lane);           // E[u - 1][v]
-			const float s = act ? Sl[(v - 1) * 64 + lane] : 0.0f;
+			if (GAP == 1) up_e = lane_up(e1, VK_NEG_INF);            // E[u - 1][v]
+			const float s = act ? Sl[(v - 1) * SW + lane] : 0.0f;
 			float best, e = VK_NEG_INF, f = VK_NEG_INF;
 			int dir = LQ_DIAG, kk = 0, ee = 0, fe = 0;
 			{
@@ -200,29 +258,50 @@ __global__ __launch_bounds__(64) void vk_longq_kernel(VkLongqParams p) {
 			} else {
 				// general gaps: H[u - k][v] - w_s(k), k = 1 .. u, then H[u][v - k] - w_t(k), k = 1 .. v (align_general); the trip counts are
 				// the wave's (lanes beyond their own range sit out)
+				// (eight candidates at a time: their loads first -- addresses clamped into the matrix, no loads under branches --, then the
+				// compares in the oracle's order; one load per trip of a branchy loop waited out an LDS round trip per candidate)
 				const int ku = len_s < 64 ? len_s : 64;
-				for (int k = 1; k <= ku; k++) {
-					if (act && k <= u) {
-						const float src = k == u ? border_t(v) : Hm[v * 64 + (lane - k)];
-						const float c = src - p.ws[k];
-						if (c > best) { best = c; dir = LQ_UP; kk = k; }
+				const int vc = v < 1 ? 1 : v > LT ? LT : v;   // this lane's row of the matrix, clamped for the lanes that sit out
+				for (int k0 = 1; k0 <= ku; k0 += 8) {
+					float src[8];
+#pragma unroll
+					for (int i = 0; i < 8; i++) { const int l2 = lane - (k0 + i); src[i] = Hm[vc * HS + (l2 < 0 ? 0 : l2)]; }
+#pragma unroll
+					for (int i = 0; i < 8; i++) {
+						const int k = k0 + i;
+						const float c = (k == u ? border_t(v) : src[i]) - p.ws[k < 64 ? k : 64];
+						if (act && k <= u && k <= ku && c > best) { best = c; dir = LQ_UP; kk = k; }
 					}
 				}
-				const int kv = dg - 1 < LT ? dg - 1 : LT;
-				for (int k = 1; k <= kv; k++) {
-					if (act && k <= v) {
-						const float src = k == v ? border_s(u) : Hm[(v - k) * 64 + lane];
-						const float c = src - p.wt[k];
-						if (c > best) { best = c; dir = LQ_LEFT; kk = k; }
+				// (scoring pass under a table that saturates -- w_t(k) = w_t(tail) for every k >= tail, exp5: from 126 on --: the candidates
+				// further back than `tail` columns all cost the same and are ONE running maximum per lane, tail_max; the scan stops at tail - 1)
+				const int tail = (!FLOW && p.wt_tail > 0) ? p.wt_tail : LT + 1;
+				int kv = dg - 1 < LT ? dg - 1 : LT;
+				if (kv > tail - 1) kv = tail - 1;
+				for (int k0 = 1; k0 <= kv; k0 += 8) {
+					float src[8];
+#pragma unroll
+					for (int i = 0; i < 8; i++) { const int r2 = vc - (k0 + i); src[i] = Hm[(r2 < 1 ? 1 : r2) * HS + lane]; }
+#pragma unroll
+					for (int i = 0; i < 8; i++) {
+						const int k = k0 + i;
+						const float c = (k == v ? border_s(u) : src[i]) - p.wt[k <= LT ? k : LT];
+						if (act && k <= v && k <= kv && c > best) { best = c; dir = LQ_LEFT; kk = k; }
 					}
+				}
+				if (!FLOW && p.wt_tail > 0 && act && v >= tail) {
+					const float x = v == tail ? border_s(u) : Hm[(v - tail) * HS + lane];   // H[u][v - tail] joins the candidates that far back
+					tail_max = fmaxf(tail_max, x);
+					const float c = tail_max - p.wt[tail];
+					if (c > best) { best = c; dir = LQ_LEFT; }
 				}
 			}
 			if (act) {
-				if (GAP == 2) Hm[v * 64 + lane] = best;
+				if (GAP == 2) Hm[v * HS + lane] = best;
 				if (FLOW) Dm[v * 64 + lane] = (int16_t)(dir | (ee << 2) | (fe << 3) | (kk << 4));
 				// start cell: LOCAL over all cells, SEMIGLOBAL over the last row and the last column (start_cell of the oracle)
 				if (!global && (local || u == len_s || v == LT) && best > best_v) { best_v = best; best_at = v; }
-				a2 = a1; a1 = best;
+				a1 = best;
 				if (GAP == 1) { e1 = e; f1 = f; }
 			}
 			if (GAP == 2) {   // the row just stored is read by other lanes on later steps: same wave, in order; pin the compiler to it
@@ -276,7 +355,7 @@ __global__ __launch_bounds__(64) void vk_longq_kernel(VkLongqParams p) {
 					if (d == LQ_STOP) break;
 					if (d == LQ_DIAG) {
 						map[cv - 1] = (int16_t)(cu - 1);
-						esim[cv - 1] = (p.pos_s ? Su : Sl)[(cv - 1) * 64 + (cu - 1)];   // the unmodified similarity of the edge (metric/alignment.h:339)
+						esim[cv - 1] = p.pos_s ? Su[(cv - 1) * 64 + (cu - 1)] : Sl[(cv - 1) * SW + (cu - 1)];   // the unmodified similarity of the edge (metric/alignment.h:339)
 						cu--; cv--;
 					} else if (d == LQ_UP) {
 						if (GAP == 1) state = 1; else cu -= GAP == 2 ? k : 1;
@@ -290,9 +369,18 @@ __global__ __launch_bounds__(64) void vk_longq_kernel(VkLongqParams p) {
 	}
 }
 
+// general gaps, scoring pass: does the matrix fit the LDS behind the strip (leaving room for at least two workgroups per CU)?
+extern "C" int32_t vk_longq_hm_in_lds(int32_t len_t, int32_t max_len) {
+	const size_t hm = (size_t)(len_t + 1) * longq_stride(max_len) * 4;
+	return vk_longq_lds_bytes(len_t, max_len, 0) + hm <= 78 * 1024 ? 1 : 0;
+}
+
 template <bool FLOW>
 static hipError_t launch_longq(const VkLongqParams *p, int grid, size_t smem, hipStream_t stream) {
-	void (*kernel)(VkLongqParams) = p->gap_mode == 0 ? vk_longq_kernel<FLOW, 0> : p->gap_mode == 1 ? vk_longq_kernel<FLOW, 1> : vk_longq_kernel<FLOW, 2>;
+	const bool hl = !FLOW && p->gap_mode == 2 && p->scratch == nullptr;   // (the host leaves scratch null when the matrix goes to LDS)
+	void (*kernel)(VkLongqParams) = p->gap_mode == 0 ? vk_longq_kernel<FLOW, 0> : p->gap_mode == 1 ? vk_longq_kernel<FLOW, 1> :
+		hl ? vk_longq_kernel<FLOW, 2, true> : vk_longq_kernel<FLOW, 2>;
+	if (hl) smem += (size_t)(p->len_t + 1) * p->s_stride * 4;
 	if (smem > 64 * 1024) {
 		const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 		if (e != hipSuccess) return e;
@@ -302,10 +390,10 @@ static hipError_t launch_longq(const VkLongqParams *p, int grid, size_t smem, hi
 }
 
 // workgroups (one wave each) of the scoring pass: as many as the CUs hold with this much LDS each, at most one per slice
-extern "C" int32_t vk_longq_blocks(int32_t len_t, int64_t n_sent) {
+extern "C" int32_t vk_longq_blocks(int32_t len_t, int32_t max_len, int64_t n_sent, int32_t hm_in_lds) {
 	int dev = 0, cus = 256;
 	if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-	const size_t smem = vk_longq_lds_bytes(len_t, 0);
+	const size_t smem = vk_longq_lds_bytes(len_t, max_len, 0) + (hm_in_lds ? (size_t)(len_t + 1) * longq_stride(max_len) * 4 : 0);
 	int per_cu = (int)((160 * 1024) / ((smem + 511) / 512 * 512 + 512));
 	if (per_cu < 1) per_cu = 1;
 	if (per_cu > 16) per_cu = 16;
@@ -316,6 +404,8 @@ extern "C" int32_t vk_longq_blocks(int32_t len_t, int64_t n_sent) {
 // flow_k == 0: scores of all p->n_sent slices (grid: vk_longq_blocks; scratch regions: one per workgroup when gap_mode == 2);
 // flow_k > 0: the flow_k winners of p->keys (one workgroup each, scratch regions likewise)
 extern "C" hipError_t vk_launch_longq(const VkLongqParams *p, int32_t flow_k, hipStream_t stream) {
-	if (flow_k > 0) return launch_longq<true>(p, flow_k, vk_longq_lds_bytes(p->len_t, 1), stream);
-	return launch_longq<false>(p, vk_longq_blocks(p->len_t, p->n_sent), vk_longq_lds_bytes(p->len_t, 0), stream);
+	const int max_len = p->s_stride;   // (the host sets the strip's stride from the corpus's longest slice: vk_longq_stride)
+	if (flow_k > 0) return launch_longq<true>(p, flow_k, vk_longq_lds_bytes(p->len_t, max_len, 1), stream);
+	const int hl = (p->gap_mode == 2 && p->scratch == nullptr) ? 1 : 0;
+	return launch_longq<false>(p, vk_longq_blocks(p->len_t, max_len, p->n_sent, hl), vk_longq_lds_bytes(p->len_t, max_len, 0), stream);
 }

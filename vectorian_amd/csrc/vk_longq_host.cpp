@@ -92,7 +92,7 @@ int vk_longq_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, vk_
 	p.sent_start = c->d_sent_start; p.sent_end = c->d_sent_end; p.n_sent = (int32_t)n;
 	p.layout = is_static ? VK_DEV_LAYOUT_STATIC : VK_DEV_LAYOUT_CONTEXTUAL;
 	p.nk32 = c->nk32; p.tail = c->tail; p.tile_bytes = c->tile_bytes; p.prec = c->prec;
-	p.qtile = lq.qt; p.nq = nq; p.len_t = LT; p.locality = q->locality;
+	p.qtile = lq.qt; p.nq = nq; p.len_t = LT; p.locality = q->locality; p.s_stride = vk_longq_stride(c->max_len);
 	p.ws = lq.fl; p.wt = lq.fl + n_ws;
 	if (q->tag_weights) {
 		p.pos_s = c->d_pos; p.tw = lq.fl + n_ws + n_wt; p.tpos = lq.il;
@@ -109,9 +109,15 @@ int vk_longq_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, vk_
 	VK_HIP(hipEventRecord(c->ev[1], st));
 	if (!only) {
 		if (p.gap_mode == 2) {
-			const size_t per = vk_longq_scratch_bytes(LT, 2, 0, 0);
-			if ((rc = grow(c, &lq.scratch, &lq.scratch_cap, per * (size_t)vk_longq_blocks(LT, n)))) return rc;
-			p.scratch = lq.scratch; p.scratch_stride = (int64_t)per;
+			// the constant tail of w_t (a saturated table): from which k on
+			int kt_ = LT;
+			while (kt_ > 1 && fl[n_ws + (size_t)kt_ - 1] == fl[n_ws + (size_t)LT]) kt_--;
+			if (kt_ < LT) p.wt_tail = kt_;
+			if (!vk_longq_hm_in_lds(LT, c->max_len)) {   // the matrix of the scans: in LDS behind the strip where it fits, else a region per workgroup
+				const size_t per = vk_longq_scratch_bytes(LT, 2, 0, 0);
+				if ((rc = grow(c, &lq.scratch, &lq.scratch_cap, per * (size_t)vk_longq_blocks(LT, c->max_len, n, 0)))) return rc;
+				p.scratch = lq.scratch; p.scratch_stride = (int64_t)per;
+			}
 		}
 		VK_HIP(vk_launch_longq(&p, 0, st));
 	}
@@ -156,6 +162,7 @@ int vk_longq_query(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, vk_
 		if ((rc = grow(c, &lq.map, &lq.map_cap, (size_t)kk * LTP))) return rc;
 		if ((rc = grow(c, &lq.sim, &lq.sim_cap, (size_t)kk * LTP))) return rc;
 		VkLongqParams f = p;
+		f.wt_tail = 0;   // (the tracebacks meet every candidate, in the oracle's order)
 		f.keys = c->d_keys[cur]; f.n_keys = kk; f.raw_out = lq.raw; f.mapping = lq.map; f.edge_sim = lq.sim; f.out_stride = LTP;
 		f.scratch = lq.fscratch; f.scratch_stride = (int64_t)per;
 		VK_HIP(vk_launch_longq(&f, kk, st));
