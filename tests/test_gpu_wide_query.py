@@ -92,8 +92,9 @@ def test_wide_query_limits(hip):
 	corpus = synth.make_contextual_corpus(20, 4, 20, 100, 32, norm_sigma=0.2)
 	c = hip_contextual_corpus(hip, corpus, keep_magnitudes=True)
 	Q65 = np.random.default_rng(1).standard_normal((65, 32)).astype(np.float32)
+	assert c.query(Q65, max_matches=3).n == 3            # alignments: up to 512 query tokens since round 4 (vk_longq_kernel)
 	with pytest.raises(hip.VkError):
-		c.query(Q65, max_matches=3)
+		c.query(Q65, algorithm=hip.VK_ALG_WRD, max_matches=3)   # the transports stop at 64
 	assert c.query(Q65[:20], algorithm=hip.VK_ALG_WRD, max_matches=3).n == 3   # exact transport runs up to 64 query tokens
 	assert c.query(Q65[:20], algorithm=hip.VK_ALG_RWMD, rwmd=(False, False, True), max_matches=3, min_score=-1.0).n == 3   # ... and the 1:n form of RWMD
 	c.close()
