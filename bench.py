@@ -74,7 +74,7 @@ WORKLOADS = {
 	"docs": dict(name="documents_wsb", n_sent=2000, min_n=2000, min_len=500, max_len=5000, d=300, alg="align", locality="local", gap="exp5", prec="bf16",
 		kernel="vk_wide_kernel (one wave per document)", rate_frac=0.03, bound="valu"),
 	"docslin": dict(name="documents_linear", n_sent=2000, min_n=2000, min_len=500, max_len=5000, d=300, alg="align", locality="local", gap="linear", prec="bf16",
-		kernel="vk_wide_kernel (one wave per document)", rate_frac=0.1, bound="valu"),
+		kernel="vk_doc_kernel (one wave per document, skewed sweep)", rate_frac=0.1, bound="valu"),
 	"2static": dict(name="config2_static", n_sent=4000000, min_len=32, max_len=32, d=300, alg="align", locality="local", gap="exp5", prec="bf16", layout="static", bound="valu"),
 	# config 4 in the reference's own layout for static embeddings (round 4): ONE similarity table over the vocabulary per batch (an
 	# MFMA GEMM 600 x smaller than config 4's) and one gather pass over the token ids with config 4's epilogues -- VALU / L2 bound

@@ -282,6 +282,8 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 	const bool long_via_wide = q->algorithm == VK_ALG_ALIGN && !wide_score && c->n_long_groups > 0 &&
 		(q->gap_s.kind == VK_GAP_TABLE || q->gap_t.kind == VK_GAP_TABLE) && !getenv("VK_LONG_PASS");
 	const bool wide = wide_score || xlong || long_via_wide;
+	// whole documents under linear / affine gaps with a query of at most 16 tokens: vk_doc_kernel scores them and retraces the winners
+	const bool doc_fast = xlong && !wide_score && q->algorithm == VK_ALG_ALIGN && q->gap_s.kind != VK_GAP_TABLE && q->gap_t.kind != VK_GAP_TABLE && !getenv("VK_NO_DOC_KERNEL");
 	const int nq = (q->len_t + 15) / 16;
 	vk_pack_query(c, q, qtile, qmags);
 	VK_HIP(hipMemcpyAsync(c->d_qtile, qtile.data(), qtile.size(), hipMemcpyHostToDevice, st));
@@ -637,7 +639,8 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 	if ((xlong || long_via_wide) && !only) {
 		// slices beyond VK_MAX_SENT_LEN (whole documents; general gaps: beyond 64 tokens): one wave per slice, longest first
 		if ((rc = wide_state(0))) return rc;
-		if (wp.n_order > 0) VK_HIP(vk_launch_wide(&wp, 0, st));
+		// (linear / affine gaps: the skewed sweep of vk_doc_kernel -- no in-row dependency, a fifth of the time per row; round 4)
+		if (wp.n_order > 0) VK_HIP(doc_fast ? vk_launch_doc(&wp, 0, st) : vk_launch_wide(&wp, 0, st));
 	}
 	}
 
@@ -852,7 +855,8 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 					wp.dp_rows = c->d_rows_out; wp.dp_rows_len = R;
 				}
 			}
-			VK_HIP(vk_launch_wide(&wp, count, st));
+			if (doc_fast && wp.dp_rows && wp.scratch && wp.scratch_stride >= (int64_t)vk_doc_scratch_bytes(c->max_len)) VK_HIP(vk_launch_doc(&wp, count, st));
+			else VK_HIP(vk_launch_wide(&wp, count, st));
 			return VK_OK;
 		}
 		VkFlowParams f{};
