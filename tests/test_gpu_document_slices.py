@@ -107,6 +107,37 @@ def test_longest_document(hip, oracle):
 	c.close()
 
 
+def saturating(n, t, seed):
+	"""a gap table that rises (not monotonically: nothing asks for that) up to k = t - 1 and is constant from k = t on"""
+	rng = np.random.default_rng(seed)
+	w = np.sort(rng.uniform(0.02, 0.9, size=n + 1)).astype(np.float32)
+	w[1:t][::3] *= np.float32(0.5)
+	w[0] = 0.0
+	w[t:] = w[t]
+	return ("table", w)
+
+
+@pytest.mark.parametrize("tail", [1, 2, 3, 9, 34, 66, 126, 127, 400])
+def test_documents_general_gaps_by_where_the_table_saturates(hip, oracle, tail):
+	"""general gaps over documents: vk_doc_kernel's forms by the number of 8-candidate chunks a DPP row scans (table constant from
+	k = 1, 2, 3, 9, 34, 66, 126 on), and the tables it leaves to vk_wide_kernel (127: beyond its ring of rows; 400: the matrix form).
+	Scores of every slice and the winners' tracebacks against the oracle, every locality, gap_t a table of its own"""
+	docs = ((0, 520), (3, 777), (9, 1500), (10, 64), (11, 65), (25, 129), (39, 1023))
+	off = document_lengths(31, 40, docs)
+	c, X, Xb = contextual(hip, off, 64, 32)
+	n = int(np.diff(off).max())
+	ws, wt = saturating(n, tail, 40 + tail), saturating(n, min(tail, 7), 41 + tail)
+	for qi, (sent, spread, len_t) in enumerate(((9, True, 7), (39, False, 16), (0, True, 11))):
+		Qb = planted_query(X, off, sent, len_t, 60 + qi, spread)
+		for loc, ms in ((0, 0.0), (1, -1e9), (2, -1e9)):
+			ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=64, sent_off=off, X=Xb, Q=Qb, locality=loc,
+				gap_s=ws, gap_t=wt, max_matches=9, min_score=ms, want_all_scores=True, n_threads=8)
+			got = c.query(Qb, q_normalize=False, locality=loc, gap_s=ws, gap_t=wt, max_matches=9, min_score=ms)
+			assert_same_results(got.trimmed(), ref)
+			np.testing.assert_allclose(c.last_scores(), ref["all_scores"], atol=1e-4)
+	c.close()
+
+
 @pytest.mark.parametrize("len_t", [9, 30])
 def test_documents_static_layout_and_tag_weights(hip, oracle, len_t):
 	"""token ids + vocabulary table (the reference's static layout), repeated words, sim[id(t_j)][j] = 1; with and without the

@@ -1,4 +1,5 @@
 // vk_doc.hip -- whole documents as slices under linear / affine gaps (round 4): a skewed sweep without an in-row dependency.
+#include <type_traits>
 #include "vk_common.hip.h"
 
 // ---------------------------------------------------------------------------
@@ -21,7 +22,13 @@
 
 #define VK_DOC_RING 64   // rows of the LDS ring: four tiles (one being consumed, the next, the one being written, slack)
 
-extern "C" size_t vk_doc_scratch_bytes(int32_t max_len) { return ((size_t)(max_len + 2) * 16 + 255) / 256 * 256; }
+// FLOW: one record per cell -- a byte under linear / affine gaps (direction, E / F extended), a dword under general gaps (+ gap length)
+extern "C" size_t vk_doc_scratch_bytes(int32_t max_len, int32_t gap_mode) { return ((size_t)(max_len + 2) * 16 * (gap_mode == 2 ? 4 : 1) + 255) / 256 * 256; }
+
+__device__ __forceinline__ uint32_t doc_orderable(float f) {
+	const uint32_t u = __builtin_bit_cast(uint32_t, f);
+	return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
 
 __device__ __forceinline__ float doc_left(float x, float border) {   // value of lane v - 2 within the DPP row (lane 0 of a row: `border`)
 	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, border), __builtin_bit_cast(int, x), DPP_ROW_SHR1, 0xf, 0xf, false));
@@ -37,8 +44,27 @@ __global__ __launch_bounds__(64) void vk_doc_kernel(VkWideParams p) {
 	__shared__ float twl[16];
 	__shared__ int tposl[16];
 	__shared__ int16_t mapl[16];
+	// general gaps (GAP 2; a gap table that saturates: w_s(k) = w_s(T) for k >= T = p.ws_tail <= 126).  The sweep keeps VALUES only (a
+	// max over the candidates; FLOW stores H, and the traceback finds which candidate the reference's scan would have kept):
+	//   Hr2  the column history, H[row & 127][v], every row stored twice (at r and r + 128) so that the rows u - 1 .. u - 128 lie at
+	//        descending addresses without a wrap: one base per step, immediate offsets (rows before the document: -inf)
+	//   Ht2  the lanes' values of the last 16 steps, likewise doubled, 17 columns: column c >= 1 = lane c - 1, column 0 = the border
+	//        H[step][0]; H[u][v - k] is column v - k of step d - k, H[u - 1][v - 1] column v - 1 of step d - 2
+	//   wq   w_s dealt to the four DPP rows (row r scans k = r + 1 + 4 i): wq[r][i] = w_s(k) for k < T, else +inf (no candidate)
+	__shared__ float Hr2[GAP == 2 ? 256 * 16 : 1];
+	__shared__ float Htb[GAP == 2 ? 16 + 32 * 17 : 1];
+	__shared__ float wq[GAP == 2 ? 4 * 32 : 1];
+	__shared__ float wsl[GAP == 2 ? 128 : 1];
+	__shared__ float wtl[GAP == 2 ? 32 : 1];
+	float *Ht2 = Htb + (GAP == 2 ? 16 : 0);
 	const int lane = threadIdx.x;
 	if (lane < 16) { twl[lane] = p.tw[lane]; tposl[lane] = p.tpos[lane]; }
+	if constexpr (GAP == 2) {
+		wsl[lane] = p.ws[lane]; wsl[64 + lane] = p.ws[64 + lane];
+		if (lane < 32) wtl[lane] = p.wt[lane < 17 ? lane : 16];
+		for (int j = lane; j < 128; j += 64) { const int k = (j >> 5) + 1 + 4 * (j & 31); wq[j] = k < p.ws_tail ? p.ws[k] : __builtin_inff(); }
+		for (int j = lane; j < 16 + 32 * 17; j += 64) Htb[j] = 0.0f;
+	}
 	wave_lds_fence();
 	const int v = (lane & 15) + 1, len_t = p.len_t;
 	const bool col = v <= len_t;
@@ -47,6 +73,21 @@ __global__ __launch_bounds__(64) void vk_doc_kernel(VkWideParams p) {
 	const bool local = p.locality == VK_DEV_LOCAL, global = p.locality == VK_DEV_GLOBAL;
 	const float gs = p.gs, gt = p.gt, a_s = p.a_s, a_t = p.a_t, open_s = p.open_s, open_t = p.open_t;
 	uint8_t *D = FLOW ? p.scratch + (int64_t)blockIdx.x * p.scratch_stride : nullptr;   // FLOW: D[u * 16 + v - 1]
+	float *Hs = reinterpret_cast<float *>(D);                                            // ... general gaps: H[u * 16 + v - 1]
+	const int T = GAP == 2 ? p.ws_tail : 0;
+	const int r4 = lane >> 4;
+	const int n_chunks = (((T + 2) >> 2) + 7) >> 3;   // general gaps: chunks of 8 candidates per DPP row (i < ceil((T - 1) / 4))
+	float wtr[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // general gaps: this lane's four gaps over t (k = r4 + 1 + 4 i <= v)
+	float wsT = 0.0f;
+	typedef float f2w __attribute__((ext_vector_type(2)));
+	f2w wr[GAP == 2 ? 16 : 1];   // ... and its 32 gaps over s (k = r4 + 1 + 4 i), in pairs
+	if constexpr (GAP == 2) {
+#pragma unroll
+		for (int i = 0; i < 16; i++) { wr[i].x = wq[r4 * 32 + 2 * i]; wr[i].y = wq[r4 * 32 + 2 * i + 1]; }
+#pragma unroll
+		for (int i = 0; i < 4; i++) { const int k = r4 + 1 + 4 * i; wtr[i] = k <= v ? wtl[k] : __builtin_inff(); }
+		wsT = wsl[T];
+	}
 
 	// contextual scoring over bf16 rows of up to 12 K-steps: the query's A fragments in registers for the whole launch
 	constexpr int NKP = 12;
@@ -60,7 +101,10 @@ __global__ __launch_bounds__(64) void vk_doc_kernel(VkWideParams p) {
 	}
 
 	const int64_t n_items = FLOW ? (int64_t)gridDim.x : (int64_t)p.n_order;
-	for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+	// (the work list is sorted longest first: rounds deal it back and forth over the workgroups, so that every one gets long and short)
+	for (int64_t round = 0; round * gridDim.x < n_items; round++) {
+		const int64_t item = round * gridDim.x + ((round & 1) ? gridDim.x - 1 - blockIdx.x : blockIdx.x);
+		if (item >= n_items) continue;
 		int64_t g;
 		if (FLOW) {
 			const uint64_t key = p.keys[item];
@@ -157,11 +201,33 @@ __global__ __launch_bounds__(64) void vk_doc_kernel(VkWideParams p) {
 			}
 			wave_lds_fence();
 		};
+		if constexpr (GAP == 2) {   // the column history before the document: no candidates
+			const float4 ninf = {VK_NEG_INF, VK_NEG_INF, VK_NEG_INF, VK_NEG_INF};
+#pragma unroll
+			for (int j = 0; j < 16; j++) reinterpret_cast<float4 *>(Hr2)[lane + 64 * j] = ninf;
+		}
 		wave_lds_fence();
 
 		// ---- the sweep: a1 = H[u - 1][v] (this lane's last value; before its first row the border H[0][v])
-		auto border_s = [&](int k) -> float { return (!global || k <= 0) ? 0.0f : (GAP == 0 ? -(gs * (float)k) : -(a_s + gs * (float)k)); };   // H[k][0]
-		float a1 = (!global) ? 0.0f : (GAP == 0 ? -(gt * (float)v) : -(a_t + gt * (float)v));   // H[0][v]
+		auto border_s = [&](int k) -> float {   // H[k][0]
+			if (!global || k <= 0) return 0.0f;
+			if constexpr (GAP == 2) return -(k < T ? wsl[k] : wsl[T]);
+			return GAP == 0 ? -(gs * (float)k) : -(a_s + gs * (float)k);
+		};
+		float b_t = 0.0f;   // H[0][v]
+		if (global) { if constexpr (GAP == 2) b_t = -wtl[v]; else b_t = GAP == 0 ? -(gt * (float)v) : -(a_t + gt * (float)v); }
+		float a1 = b_t;
+		float tail_m = VK_NEG_INF;   // general gaps: max of H[u'][v] over u' <= u - T (the candidates at and beyond the table's tail: all cost w_s(T))
+		if constexpr (GAP == 2) {   // what the first steps read of the steps before them: H[0][0], H[1][0]; H[0][1] (lane v = 1's border)
+			if (lane == 0) {
+				Ht2[0] = 0.0f; Ht2[16 * 17] = 0.0f;
+				const float b1 = border_s(1);
+				Ht2[17] = b1; Ht2[17 * 17] = b1;
+				Ht2[17 + 1] = b_t; Ht2[17 * 17 + 1] = b_t;
+				Hr2[0] = b_t; Hr2[128 * 16] = b_t;
+			}
+			wave_lds_fence();
+		}
 		float e1 = VK_NEG_INF, f1 = VK_NEG_INF;   // affine: E[u - 1][v], F[u][v] of this lane's last step
 		float prev_left = 0.0f;                     // H[u - 1][v - 1]: last step's `left` (lane 0, step 2: H[0][0] = 0)
 		float best_v = 0.0f;
@@ -178,9 +244,14 @@ __global__ __launch_bounds__(64) void vk_doc_kernel(VkWideParams p) {
 			// boundary: the first lane (v = 1) is about to enter a new tile -> the tile after it is written, the one after that requested
 			const int tok1 = t_a + d - 2;   // token of lane v = 1 on this step
 			if ((tok1 & 15) == 0 && d > 2) boundary(tok1 >> 4);
-			const float left = doc_left(a1, border_s(d - 1));   // H[u][v - 1] (lane 0 of the row: the border column)
-			const float diag = prev_left;                       // H[u - 1][v - 1]
-			prev_left = left;
+			float left = 0.0f, diag;
+			const int B = ((d & 15) + 16) * 17;   // general gaps: this step's (upper) slot of Ht2
+			if constexpr (GAP == 2) diag = Ht2[B - 34 + (v - 1)];   // H[u - 1][v - 1] (borders included: they were written like values)
+			else {
+				left = doc_left(a1, border_s(d - 1));   // H[u][v - 1] (lane 0 of the row: the border column)
+				diag = prev_left;                       // H[u - 1][v - 1]
+				prev_left = left;
+			}
 			float left_f = VK_NEG_INF;
 			if (GAP == 1) left_f = doc_left(f1, VK_NEG_INF);     // F[u][v - 1]
 			const float s = act ? s_next : 0.0f;
@@ -194,7 +265,58 @@ __global__ __launch_bounds__(64) void vk_doc_kernel(VkWideParams p) {
 				best = take ? c : 0.0f;
 				dir = take ? 1 : 0;
 			}
-			if (GAP == 0) {
+			if constexpr (GAP == 2) {
+				// gaps over s inside the table: this DPP row's share, k = r4 + 1 + 4 i (i < 32), row u - k at hp[(31 - i) * 64].  One
+				// form per number of 8-candidate chunks the table needs, each a single block: all its loads (history, costs, the tail's
+				// row, the gaps over t) leave together -- chunk after chunk behind uniform branches was four LDS round trips a step
+				const float *hp = Hr2 + ((u & 127) + 3 - r4) * 16 + (v - 1);
+				const float *tp = Hr2 + ((u & 127) + 128 - T) * 16 + (v - 1);
+				const float *gp = Ht2 + B + v - 18 * (r4 + 1);
+				auto gaps = [&](auto nc) -> float {
+					constexpr int NC = decltype(nc)::value;
+					typedef float f2 __attribute__((ext_vector_type(2)));
+					f2 hv[NC > 0 ? NC * 4 : 1];
+#pragma unroll
+					for (int i = 0; i < NC * 4; i++) { hv[i].x = hp[(31 - 2 * i) * 64]; hv[i].y = hp[(30 - 2 * i) * 64]; }
+					const float xt = *tp;
+					float ht[4];
+#pragma unroll
+					for (int i = 0; i < 4; i++) ht[i] = gp[-72 * i];
+					float mm = VK_NEG_INF;
+#pragma unroll
+					for (int j = 0; j < NC * 2; j++) {   // (packed subtractions: two candidates an instruction)
+						const f2 c0 = hv[2 * j] - wr[2 * j], c1 = hv[2 * j + 1] - wr[2 * j + 1];
+						mm = fmaxf(mm, fmaxf(c0.x, c0.y));
+						mm = fmaxf(mm, fmaxf(c1.x, c1.y));
+					}
+					// ... at T rows and more: one running maximum
+					tail_m = fmaxf(tail_m, xt);
+					mm = fmaxf(mm, tail_m - wsT);
+					// gaps over t: k = r4 + 1 + 4 i <= v (others: +inf in wtr)
+#pragma unroll
+					for (int i = 0; i < 4; i++) mm = fmaxf(mm, ht[i] - wtr[i]);
+					return mm;
+				};
+				float m;
+				switch (n_chunks) {
+					case 0: m = gaps(std::integral_constant<int, 0>{}); break;
+					case 1: m = gaps(std::integral_constant<int, 1>{}); break;
+					case 2: m = gaps(std::integral_constant<int, 2>{}); break;
+					case 3: m = gaps(std::integral_constant<int, 3>{}); break;
+					default: m = gaps(std::integral_constant<int, 4>{}); break;
+				}
+				// the four shares meet in DPP row 0 (lanes < 16: the only ones whose values are kept)
+				{   // (v_permlane{32,16}_swap: halves / DPP rows exchanged between two registers, at VALU speed; either output holds the partner's value)
+					float x0 = m, x1 = m;
+					asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x0), "+v"(x1));
+					m = fmaxf(m, fmaxf(x0, x1));
+					x0 = m; x1 = m;
+					asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x0), "+v"(x1));
+					m = fmaxf(m, fmaxf(x0, x1));
+				}
+				dir = m > best ? 2 : dir;
+				best = fmaxf(best, m);
+			} else if (GAP == 0) {
 				const float cu = a1 - gs, cl = left - gt;
 				const bool tu = cu > best;
 				best = tu ? cu : best; dir = tu ? 2 : dir;
@@ -213,7 +335,16 @@ __global__ __launch_bounds__(64) void vk_doc_kernel(VkWideParams p) {
 				const bool tl = f > best;
 				best = tl ? f : best; dir = tl ? 3 : dir;
 			}
-			if (FLOW && act && lane < 16) D[u * 16 + (v - 1)] = (uint8_t)(dir | (ee << 2) | (fe << 3));
+			if constexpr (GAP == 2) {   // this cell (before the first row: the border H[0][v]) joins the histories, read from the next step on
+				if (FLOW && act && lane < 16) Hs[u * 16 + (v - 1)] = best;
+				if (lane < 16 && col && u >= 0 && u <= len_s) {
+					const float x = u == 0 ? b_t : best;
+					Hr2[(u & 127) * 16 + (v - 1)] = x; Hr2[((u & 127) + 128) * 16 + (v - 1)] = x;
+					Ht2[B - 16 * 17 + v] = x; Ht2[B + v] = x;
+				}
+				if (lane == 0) { const float x = border_s(d); Ht2[B - 16 * 17] = x; Ht2[B] = x; }
+				wave_lds_fence();
+			} else if (FLOW && act && lane < 16) D[u * 16 + (v - 1)] = (uint8_t)(dir | (ee << 2) | (fe << 3));
 			{
 				const bool nb = act && !global && (local || u == len_s || v == len_t) && best > best_v;   // first maximum of this column
 				best_v = nb ? best : best_v;
@@ -257,10 +388,42 @@ __global__ __launch_bounds__(64) void vk_doc_kernel(VkWideParams p) {
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 			if (lane < 16) mapl[lane] = -1;
 			wave_lds_fence();
-			if (lane == 0) {
+			if constexpr (GAP == 2) {
+				// the whole wave walks back over the stored H: at each cell the FIRST candidate in the reference's order (zero, diagonal,
+				// gaps over s by length, gaps over t by length) whose value is the cell's -- what a scan replacing on strictly greater keeps
+				auto h_at = [&](int uu, int vv) -> float {
+					if (vv == 0) return border_s(uu);
+					if (uu == 0) return global ? -wtl[vv] : 0.0f;
+					return Hs[uu * 16 + (vv - 1)];
+				};
+				int cu = su, cv = sv;
+				while (cu > 0 && cv > 0) {
+					const float h = Hs[cu * 16 + (cv - 1)];
+					if (local && !(h > 0.0f)) break;
+					const float sdp = p.dp_rows[((int64_t)item * p.dp_rows_len + (cu - 1)) * 16 + (cv - 1)];
+					if (h_at(cu - 1, cv - 1) + sdp == h) { if (lane == 0) mapl[cv - 1] = (int16_t)(cu - 1); cu--; cv--; continue; }
+					int found = 0;
+					for (int k0 = 0; k0 < cu && !found; k0 += 64) {
+						const int k = k0 + lane + 1;
+						bool hit = false;
+						if (k <= cu) hit = h_at(cu - k, cv) - (k < T ? wsl[k] : wsT) == h;
+						const unsigned long long bal = __ballot(hit);
+						if (bal) found = k0 + __builtin_ctzll(bal) + 1;
+					}
+					if (found) { cu -= found; continue; }
+					{
+						const int k = lane + 1;
+						bool hit = false;
+						if (k <= cv) hit = h_at(cu, cv - k) - wtl[k] == h;
+						const unsigned long long bal = __ballot(hit);
+						if (!bal) break;   // (cannot happen: the cell's value is one of its candidates)
+						cv -= __builtin_ctzll(bal) + 1;
+					}
+				}
+			} else if (lane == 0) {
 				int cu = su, cv = sv, state = 0;
 				while (cu > 0 && cv > 0) {
-					const int rec = D[cu * 16 + (cv - 1)];
+					const int rec = (int)D[cu * 16 + (cv - 1)];
 					if (GAP == 1 && state == 1) { if (!(rec & 4)) state = 0; cu--; continue; }
 					if (GAP == 1 && state == 2) { if (!(rec & 8)) state = 0; cv--; continue; }
 					const int dd = rec & 3;
@@ -296,22 +459,27 @@ __global__ __launch_bounds__(64) void vk_doc_kernel(VkWideParams p) {
 // flow_k == 0: scores of the p->n_order slices of p->order (longest first; grid stride); flow_k > 0: the flow_k winners of p->keys,
 // their rows in p->dp_rows, one scratch region of p->scratch_stride >= vk_doc_scratch_bytes(max_len) bytes per winner
 extern "C" hipError_t vk_launch_doc(const VkWideParams *p, int32_t flow_k, hipStream_t stream) {
-	if (p->len_t > 16 || (p->gap_mode != 0 && p->gap_mode != 1)) return hipErrorInvalidValue;
+	if (p->len_t > 16 || p->gap_mode < 0 || p->gap_mode > 2) return hipErrorInvalidValue;
+	if (p->gap_mode == 2 && (p->ws_tail < 1 || p->ws_tail > 126)) return hipErrorInvalidValue;   // (the history ring holds 128 rows)
 	if (flow_k > 0) {
-		if (!p->dp_rows || !p->scratch || p->scratch_stride < (int64_t)vk_doc_scratch_bytes(p->max_len)) return hipErrorInvalidValue;
+		if (!p->dp_rows || !p->scratch || p->scratch_stride < (int64_t)vk_doc_scratch_bytes(p->max_len, p->gap_mode)) return hipErrorInvalidValue;
 		if (p->gap_mode == 0) vk_doc_kernel<true, 0, 3><<<flow_k, 64, 0, stream>>>(*p);
-		else vk_doc_kernel<true, 1, 3><<<flow_k, 64, 0, stream>>>(*p);
+		else if (p->gap_mode == 1) vk_doc_kernel<true, 1, 3><<<flow_k, 64, 0, stream>>>(*p);
+		else vk_doc_kernel<true, 2, 3><<<flow_k, 64, 0, stream>>>(*p);
 		return hipGetLastError();
 	}
 	if (!p->order || p->n_order < 1) return hipSuccess;
 	int dev = 0, cus = 256;
 	if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+	// (general gaps: 23 KB of LDS a wave, six resident per CU, the others follow as those end -- measured against one wave per SIMD over
+	// a dealt list, 3.9 ms against 4.5 ms on 2,000 documents: a wave issues at most one instruction every four cycles, two fill the gaps)
 	const int64_t cap = (int64_t)cus * 16;
 	const int grid = (int)(p->n_order < cap ? p->n_order : cap);
 	const int src = p->layout == VK_DEV_LAYOUT_STATIC ? 2 : (p->prec == 0 && p->nk32 <= 12) ? 0 : 1;
 	void (*kernel)(VkWideParams);
 	if (p->gap_mode == 0) kernel = src == 2 ? vk_doc_kernel<false, 0, 2> : src == 0 ? vk_doc_kernel<false, 0, 0> : vk_doc_kernel<false, 0, 1>;
-	else kernel = src == 2 ? vk_doc_kernel<false, 1, 2> : src == 0 ? vk_doc_kernel<false, 1, 0> : vk_doc_kernel<false, 1, 1>;
+	else if (p->gap_mode == 1) kernel = src == 2 ? vk_doc_kernel<false, 1, 2> : src == 0 ? vk_doc_kernel<false, 1, 0> : vk_doc_kernel<false, 1, 1>;
+	else kernel = src == 2 ? vk_doc_kernel<false, 2, 2> : vk_doc_kernel<false, 2, 1>;   // (the gap scans want the registers the query's fragments would take)
 	kernel<<<grid, 64, 0, stream>>>(*p);
 	return hipGetLastError();
 }

@@ -283,7 +283,8 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 		(q->gap_s.kind == VK_GAP_TABLE || q->gap_t.kind == VK_GAP_TABLE) && !getenv("VK_LONG_PASS");
 	const bool wide = wide_score || xlong || long_via_wide;
 	// whole documents under linear / affine gaps with a query of at most 16 tokens: vk_doc_kernel scores them and retraces the winners
-	const bool doc_fast = xlong && !wide_score && q->algorithm == VK_ALG_ALIGN && q->gap_s.kind != VK_GAP_TABLE && q->gap_t.kind != VK_GAP_TABLE && !getenv("VK_NO_DOC_KERNEL");
+	// (general gaps: under a table that saturates within 126 tokens -- wp.ws_tail, set below; doc_ok() asks once wp is filled)
+	const bool doc_fast = xlong && !wide_score && q->algorithm == VK_ALG_ALIGN && !getenv("VK_NO_DOC_KERNEL");
 	const int nq = (q->len_t + 15) / 16;
 	vk_pack_query(c, q, qtile, qmags);
 	VK_HIP(hipMemcpyAsync(c->d_qtile, qtile.data(), qtile.size(), hipMemcpyHostToDevice, st));
@@ -441,6 +442,7 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 		for (int j = 0; j < VK_FAST_QUERY_LEN; j++) p.qkey[j] = qkey_all[j];
 	}
 	VkWideParams wp{};
+	auto doc_ok = [&]() { return doc_fast && (wp.gap_mode == 0 || wp.gap_mode == 1 || (wp.gap_mode == 2 && wp.ws_tail >= 1 && wp.ws_tail <= 126 && !getenv("VK_NO_DOC_GENERAL"))); };
 	// vk_wide_kernel: the state of a slice in LDS where that fits, else in global memory (one region per workgroup)
 	// The scoring pass of vk_wide_kernel takes one wave per slice: its work list, longest first (wp.order).  A query of more than 16
 	// tokens: every non-empty row of the slice table (the others carry no score: preset); at most 16 tokens: only the slices the fused
@@ -482,7 +484,8 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 			return VK_OK;
 		}
 		wp.h_ring = vk_wide_ring_rows(nq, wp.gap_mode, wp.ws_tail);   // a saturated gap table: the column history is a ring in LDS
-		const size_t per = vk_wide_scratch_bytes(c->max_len, nq, wp.gap_mode, flow, wp.h_ring);
+		size_t per = vk_wide_scratch_bytes(c->max_len, nq, wp.gap_mode, flow, wp.h_ring);
+		if (flow && doc_ok()) per = std::max(per, vk_doc_scratch_bytes(c->max_len, wp.gap_mode));   // (vk_doc_kernel's records of a winner)
 		const size_t blocks = (size_t)vk_wide_gs_blocks(c->max_len, nq, wp.gap_mode, flow_k, n, wp.h_ring);
 		const size_t need = per * blocks;
 		if (need > ((size_t)16 << 30)) return fail(VK_ERR_UNSUPPORTED, "traceback state of this many slices this long exceeds 16 GiB of scratch");
@@ -640,7 +643,7 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 		// slices beyond VK_MAX_SENT_LEN (whole documents; general gaps: beyond 64 tokens): one wave per slice, longest first
 		if ((rc = wide_state(0))) return rc;
 		// (linear / affine gaps: the skewed sweep of vk_doc_kernel -- no in-row dependency, a fifth of the time per row; round 4)
-		if (wp.n_order > 0) VK_HIP(doc_fast ? vk_launch_doc(&wp, 0, st) : vk_launch_wide(&wp, 0, st));
+		if (wp.n_order > 0) VK_HIP(doc_ok() ? vk_launch_doc(&wp, 0, st) : vk_launch_wide(&wp, 0, st));
 	}
 	}
 
@@ -855,7 +858,7 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 					wp.dp_rows = c->d_rows_out; wp.dp_rows_len = R;
 				}
 			}
-			if (doc_fast && wp.dp_rows && wp.scratch && wp.scratch_stride >= (int64_t)vk_doc_scratch_bytes(c->max_len)) VK_HIP(vk_launch_doc(&wp, count, st));
+			if (doc_ok() && wp.dp_rows && wp.scratch && wp.scratch_stride >= (int64_t)vk_doc_scratch_bytes(c->max_len, wp.gap_mode)) VK_HIP(vk_launch_doc(&wp, count, st));
 			else VK_HIP(vk_launch_wide(&wp, count, st));
 			return VK_OK;
 		}
