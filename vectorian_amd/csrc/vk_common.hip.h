@@ -89,6 +89,21 @@ __device__ __forceinline__ void wave_lds_fence() {
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// The value of the lane 32 / 16 away at VALU speed: gfx950's v_permlane32_swap / v_permlane16_swap exchange the halves / the odd and
+// even DPP rows of two registers (tools/probe/permlane_swap.hip prints what lands where).  Written as asm: given the same value
+// twice the builtin came back folded to one of its two results (vk_doc_kernel lost three of its four shares), and operands fresh
+// from the VALU were swapped stale in the probe -- wait states either side.
+__device__ __forceinline__ float lane_xor32(float x, int lane) {
+	float a = x, b = x;
+	asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+	return lane < 32 ? b : a;
+}
+__device__ __forceinline__ float lane_xor16(float x, int lane) {
+	float a = x, b = x;
+	asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+	return (lane & 16) ? a : b;
+}
+
 __device__ __forceinline__ float clip01(float x) {
 	// xt::clip(sim, 0, 1); NaN -> 0 as the oracle does
 	return fminf(fmaxf(x, 0.0f), 1.0f);

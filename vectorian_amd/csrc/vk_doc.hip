@@ -480,6 +480,7 @@ extern "C" hipError_t vk_launch_doc(const VkWideParams *p, int32_t flow_k, hipSt
 	if (p->gap_mode == 0) kernel = src == 2 ? vk_doc_kernel<false, 0, 2> : src == 0 ? vk_doc_kernel<false, 0, 0> : vk_doc_kernel<false, 0, 1>;
 	else if (p->gap_mode == 1) kernel = src == 2 ? vk_doc_kernel<false, 1, 2> : src == 0 ? vk_doc_kernel<false, 1, 0> : vk_doc_kernel<false, 1, 1>;
 	else kernel = src == 2 ? vk_doc_kernel<false, 2, 2> : vk_doc_kernel<false, 2, 1>;   // (the gap scans want the registers the query's fragments would take)
+	// (fewer waves per CU -- dynamic LDS nobody uses -- only slow it down: general gaps 3.8 / 4.3 / 5.9 ms at 6 / 4 / 3 waves per CU)
 	kernel<<<grid, 64, 0, stream>>>(*p);
 	return hipGetLastError();
 }

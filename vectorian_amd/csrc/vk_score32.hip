@@ -405,6 +405,24 @@ __device__ __forceinline__ float dp32_general(const float *__restrict__ S, int s
 					else fb = fmaxf(fb, cand);
 				}
 			}
+#ifndef VK_HELP_LDS
+			// the helpers' maxima cross between the DPP rows by lane swaps (round 3: a second LDS slot, a write, a fence and a read per row)
+			if constexpr (B2) {
+				hc = fmaxf(hc, blk == 1 ? fa : VK_NEG_INF);
+				const float hv = lane_xor16(fa, lane);              // block 1 <- block 0's lane v of its slice
+				hc = fmaxf(hc, blk == 1 ? hv : VK_NEG_INF);
+			} else if constexpr (B34) {
+				// blocks 1, 2: everything they found is their own; block 0: for block 2's column; block 3: groups 0, 1 for block 2's, group 2 for block 1's
+				hc = fmaxf(hc, (blk == 1 || blk == 2) ? fmaxf(fa, fb) : VK_NEG_INF);
+				const float r32 = lane_xor32(blk == 0 ? fmaxf(fa, fb) : fb, lane);   // block 2 <- block 0, block 1 <- block 3
+				const float r16 = lane_xor16(fa, lane);                               // block 2 <- block 3
+				hc = fmaxf(hc, blk == 2 ? fmaxf(r32, r16) : blk == 1 ? r32 : VK_NEG_INF);
+			} else if constexpr (BAL) {
+				// block 0: everything it found belongs to block 3's column; block 1: groups 4, 5 belong to block 2's
+				hc = fmaxf(hc, blk == 0 ? VK_NEG_INF : blk == 1 ? fa : fmaxf(fa, fb));
+				const float hv = lane_xor32(lane_xor16(blk == 0 ? fmaxf(fa, fb) : fb, lane), lane);   // block 3 <- block 0, block 2 <- block 1
+				hc = fmaxf(hc, blk >= 2 ? hv : VK_NEG_INF);
+#else
 			if constexpr (B2) {
 				help[lane] = blk == 0 ? fa : VK_NEG_INF;          // for column 16 + v of this lane's slice
 				hc = fmaxf(hc, blk == 1 ? fa : VK_NEG_INF);
@@ -426,6 +444,7 @@ __device__ __forceinline__ float dp32_general(const float *__restrict__ S, int s
 				wave_lds_fence();
 				const float hv = help[blk >= 2 ? partner : lane];
 				hc = fmaxf(hc, blk >= 2 ? hv : VK_NEG_INF);
+#endif
 			} else hc = fmaxf(hc, fmaxf(fa, fb));
 			hreg[u] = hc;
 			h = act ? hc : h;
