@@ -72,7 +72,7 @@ WORKLOADS = {
 	"2shared": dict(name="config2_shared_pass", n_sent=1000000, min_len=32, max_len=32, d=300, alg="align", locality="local", gap="exp5", prec="bf16", batch=8, per_pass=2),
 	# whole documents as slices (session.partition("document")): one wave per document, its state in global memory
 	"docs": dict(name="documents_wsb", n_sent=2000, min_n=2000, min_len=500, max_len=5000, d=300, alg="align", locality="local", gap="exp5", prec="bf16",
-		kernel="vk_wide_kernel (one wave per document)", rate_frac=0.03, bound="valu"),
+		kernel="vk_doc_kernel (one wave per document, skewed sweep, general gaps)", rate_frac=0.03, bound="valu"),
 	"docslin": dict(name="documents_linear", n_sent=2000, min_n=2000, min_len=500, max_len=5000, d=300, alg="align", locality="local", gap="linear", prec="bf16",
 		kernel="vk_doc_kernel (one wave per document, skewed sweep)", rate_frac=0.1, bound="valu"),
 	"2static": dict(name="config2_static", n_sent=4000000, min_len=32, max_len=32, d=300, alg="align", locality="local", gap="exp5", prec="bf16", layout="static", bound="valu"),

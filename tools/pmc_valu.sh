@@ -23,7 +23,7 @@ cd "$root"
 python3 - "$out" "$tag" $configs <<'PY'
 import csv, glob, json, os, sys, collections
 out, tag, configs = sys.argv[1], sys.argv[2], sys.argv[3:]
-pattern = {"4static": "vk_rwmd_static32_kernel", "2static": "vk_score_kernel<2", "2q40": "vk_score32_kernel", "docs": "vk_wide_kernel<false", "docslin": "vk_doc_kernel<false"}
+pattern = {"4static": "vk_rwmd_static32_kernel", "2static": "vk_score_kernel<2", "2q40": "vk_score32_kernel", "docs": "vk_doc_kernel<false", "docslin": "vk_doc_kernel<false"}
 res = {}
 for c in configs:
 	full = json.load(open(os.path.join(out, f"full_{c}.json")))

@@ -356,8 +356,8 @@ __device__ __forceinline__ float dp32_general(const float *__restrict__ S, int s
 		wfar[i] = (src >> 4) < (tgt >> 4) ? p.wt[tgt - src] : inf;   // a source in a block left of the target's
 	}
 	const f32x4 *left = reinterpret_cast<const f32x4 *>(xch + (lane & ~(16 * NB - 1)));   // c of columns 0.. of this slice
-	float *help = xch + 64;                           // NB = 4: the helpers' partial maxima
-	const int partner = blk == 3 ? col - 48 : col - 16;   // block 3 <- block 0's lane v, block 2 <- block 1's lane 16 + v
+	[[maybe_unused]] float *help = xch + 64;                           // (VK_HELP_LDS) NB = 4: the helpers' partial maxima
+	[[maybe_unused]] const int partner = blk == 3 ? col - 48 : col - 16;   // block 3 <- block 0's lane v, block 2 <- block 1's lane 16 + v
 
 	float hreg[MAXLEN + 1];
 	float h = is_global ? -wt_border0 : 0.0f;
@@ -721,7 +721,11 @@ static inline int strip_stride(int len_t) { return (len_t + 3) / 4 * 4; }
 // matter: at 32 query tokens and 300-d rows 1,280 bytes decide between two and three workgroups per CU (5.4 -> 4.3 ms).
 static inline int strip_slack(int gap_mode, int len_t) {
 	if (gap_mode == 7) return 144;   // 2 x 64 vocabulary masses
+#ifdef VK_HELP_LDS
 	if (gap_mode == 3 || gap_mode == 6) return len_t > 48 ? 128 : len_t > 32 ? 192 : 64;   // four-block form: the second slot of dp32_general (33..48 tokens: a third)
+#else
+	if (gap_mode == 3 || gap_mode == 6) return 64;   // the in-row exchange slot of dp32_general (the helpers' maxima cross by lane swaps since round 4)
+#endif
 	return 16;
 }
 
@@ -749,6 +753,7 @@ extern "C" hipError_t vk_launch_score32(const VkWideParams *p, int32_t tiles, hi
 	if (waves < 1) return hipErrorInvalidValue;
 	size_t smem = vk_score32_lds_bytes(is_static ? 0 : p->nk32, p->tail, tiles, p->len_t, p->gap_mode, waves);
 	int slack = strip_slack(p->gap_mode, p->len_t);
+#ifdef VK_HELP_LDS
 	// general gaps, 17..32 tokens: the balanced form of the far candidates needs a second 64-float slot per wave; taken when that
 	// does not cost a workgroup per CU (LDS is handed out in 512-byte granules; at 32 tokens and 300-d rows it would: 4.2 -> 5.7 ms)
 	bool bal2 = false;
@@ -757,6 +762,11 @@ extern "C" hipError_t vk_launch_score32(const VkWideParams *p, int32_t tiles, hi
 		const size_t more = smem + (size_t)waves * 64 * 4;
 		if (more <= 160 * 1024 && std::min<size_t>(per_cu(more), 3) == std::min<size_t>(per_cu(smem), 3)) { bal2 = true; smem = more; slack += 64; }
 	}
+#else
+	// general gaps, 17..32 tokens: the balanced form of the far candidates (round 3: only where its second 64-float slot per wave did not
+	// cost a workgroup per CU -- up to 28 tokens at 300-d; the lane swaps need no slot)
+	const bool bal2 = !four && (p->gap_mode == 3 || p->gap_mode == 6) && !getenv("VK_NO_BAL2");
+#endif
 	void (*kernel)(VkWideParams, int32_t, int32_t, int32_t);
 	switch (p->gap_mode) {
 	case 0: kernel = four ? (is_static ? vk_score32_kernel<0, true, 4> : vk_score32_kernel<0, false, 4>)
