@@ -40,7 +40,10 @@ __device__ __forceinline__ float doc_left(float x, float border) {   // value of
 // table, gathered by token id; 3: FLOW (the restated rows)
 template <bool FLOW, int GAP, int SRC>
 __global__ __launch_bounds__(64) void vk_doc_kernel(VkWideParams p) {
-	__shared__ float ring[VK_DOC_RING * 16];   // S[token & 63][query column]: what the DP runs on (tag weights applied)
+	// S[token & 63][query column]: what the DP runs on (tag weights applied).  Linear / affine gaps: every row a second time 64 rows up, so
+	// that the sixteen steps between two tile boundaries read their rows at immediate offsets from one base (no wrap inside a block)
+	constexpr bool RING2 = GAP != 2;
+	__shared__ float ring[VK_DOC_RING * 16 * (RING2 ? 2 : 1)];
 	__shared__ float twl[16];
 	__shared__ int tposl[16];
 	__shared__ int16_t mapl[16];
@@ -62,7 +65,7 @@ __global__ __launch_bounds__(64) void vk_doc_kernel(VkWideParams p) {
 	if constexpr (GAP == 2) {
 		wsl[lane] = p.ws[lane]; wsl[64 + lane] = p.ws[64 + lane];
 		if (lane < 32) wtl[lane] = p.wt[lane < 17 ? lane : 16];
-		for (int j = lane; j < 128; j += 64) { const int k = (j >> 5) + 1 + 4 * (j & 31); wq[j] = k < p.ws_tail ? p.ws[k] : __builtin_inff(); }
+		for (int j = lane; j < 128; j += 64) { const int k = (j >> 5) + 1 + 4 * (j & 31); wq[j] = (k >= 2 && k < p.ws_tail) ? p.ws[k] : __builtin_inff(); }
 		for (int j = lane; j < 16 + 32 * 17; j += 64) Htb[j] = 0.0f;
 	}
 	wave_lds_fence();
@@ -75,18 +78,20 @@ __global__ __launch_bounds__(64) void vk_doc_kernel(VkWideParams p) {
 	uint8_t *D = FLOW ? p.scratch + (int64_t)blockIdx.x * p.scratch_stride : nullptr;   // FLOW: D[u * 16 + v - 1]
 	float *Hs = reinterpret_cast<float *>(D);                                            // ... general gaps: H[u * 16 + v - 1]
 	const int T = GAP == 2 ? p.ws_tail : 0;
+	const int T2 = T > 2 ? T : 2;   // the running maximum of the tail starts two rows back at the earliest (one row back: the lane's own last value)
 	const int r4 = lane >> 4;
 	const int n_chunks = (((T + 2) >> 2) + 7) >> 3;   // general gaps: chunks of 8 candidates per DPP row (i < ceil((T - 1) / 4))
 	float wtr[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // general gaps: this lane's four gaps over t (k = r4 + 1 + 4 i <= v)
-	float wsT = 0.0f;
+	float wsT = 0.0f, ws1 = 0.0f, wt1 = 0.0f;
 	typedef float f2w __attribute__((ext_vector_type(2)));
 	f2w wr[GAP == 2 ? 16 : 1];   // ... and its 32 gaps over s (k = r4 + 1 + 4 i), in pairs
 	if constexpr (GAP == 2) {
 #pragma unroll
 		for (int i = 0; i < 16; i++) { wr[i].x = wq[r4 * 32 + 2 * i]; wr[i].y = wq[r4 * 32 + 2 * i + 1]; }
 #pragma unroll
-		for (int i = 0; i < 4; i++) { const int k = r4 + 1 + 4 * i; wtr[i] = k <= v ? wtl[k] : __builtin_inff(); }
+		for (int i = 0; i < 4; i++) { const int k = r4 + 1 + 4 * i; wtr[i] = (k >= 2 && k <= v) ? wtl[k] : __builtin_inff(); }
 		wsT = wsl[T];
+		ws1 = wsl[1]; wt1 = wtl[1];
 	}
 
 	// contextual scoring over bf16 rows of up to 12 K-steps: the query's A fragments in registers for the whole launch
@@ -152,6 +157,7 @@ __global__ __launch_bounds__(64) void vk_doc_kernel(VkWideParams p) {
 				x.w = tag_weighted(x.w, twl[c4 + 3], st_ps, tposl[c4 + 3], p.tw_keep, p.tw_threshold);
 			}
 			*reinterpret_cast<float4 *>(ring + (tok & (VK_DOC_RING - 1)) * 16 + c4) = x;
+			if constexpr (RING2) *reinterpret_cast<float4 *>(ring + ((tok & (VK_DOC_RING - 1)) + VK_DOC_RING) * 16 + c4) = x;
 		};
 		auto tile_load = [&](int k) {   // contextual, `regs`: the K-steps of tile k into registers
 			if (k > k_last) return;
@@ -178,6 +184,7 @@ __global__ __launch_bounds__(64) void vk_doc_kernel(VkWideParams p) {
 				for (int r = 0; r < 4; r++) acc[r] = tag_weighted(acc[r], twl[c0 + r], ps, tposl[c0 + r], p.tw_keep, p.tw_threshold);
 			}
 			*reinterpret_cast<f32x4 *>(ring + (tok & (VK_DOC_RING - 1)) * 16 + c0) = acc;
+			if constexpr (RING2) *reinterpret_cast<f32x4 *>(ring + ((tok & (VK_DOC_RING - 1)) + VK_DOC_RING) * 16 + c0) = acc;
 		};
 		// before the sweep: tiles k_first, k_first + 1 in the ring; k_first + 2 (and + 3: static / FLOW) requested
 		if constexpr (FLOW || is_static) {
@@ -217,6 +224,7 @@ __global__ __launch_bounds__(64) void vk_doc_kernel(VkWideParams p) {
 		float b_t = 0.0f;   // H[0][v]
 		if (global) { if constexpr (GAP == 2) b_t = -wtl[v]; else b_t = GAP == 0 ? -(gt * (float)v) : -(a_t + gt * (float)v); }
 		float a1 = b_t;
+		float m_far = VK_NEG_INF;    // general gaps: the best candidate of length two and more of the coming step (the first cell has none)
 		float tail_m = VK_NEG_INF;   // general gaps: max of H[u'][v] over u' <= u - T (the candidates at and beyond the table's tail: all cost w_s(T))
 		if constexpr (GAP == 2) {   // what the first steps read of the steps before them: H[0][0], H[1][0]; H[0][1] (lane v = 1's border)
 			if (lane == 0) {
@@ -238,20 +246,93 @@ __global__ __launch_bounds__(64) void vk_doc_kernel(VkWideParams p) {
 		// (any ring slot exists: rows outside the document read as whatever lies there and are never used)
 		auto s_of = [&](int u) -> float { return ring[((t_a + u - 1) & (VK_DOC_RING - 1)) * 16 + (v - 1)]; };
 		float s_next = s_of(2 - v);
+		// Sixteen steps from a tile boundary on, while every query column is inside the document (d > len_t, d + 15 <= len_s: 1 <= u < len_s in
+		// all lanes that hold a column): no activity masks, no border row, the block's similarities read up front at immediate offsets, the
+		// locality at compile time.  (One loop of general steps: ~60 instructions and 450 cycles a step for a wave alone -- and a pass over
+		// documents lasts as long as its longest document's chain.)
+		auto steps16 = [&](int d0, auto loc) {
+			constexpr int LOC = decltype(loc)::value;   // 0 local, 1 global, 2 semiglobal
+			constexpr bool is_local = LOC == 0, is_global = LOC == 1;
+			const int tok1 = t_a + d0 - 2;
+			const float *sp = ring + ((tok1 + 1 - v) & (VK_DOC_RING - 1)) * 16 + (v - 1);
+			float sv[17];
+#pragma unroll
+			for (int i = 0; i < 17; i++) sv[i] = sp[i * 16];
+			const bool track = col && (is_local || (!is_global && v == len_t));
+			const bool store = FLOW && col && lane < 16;
+			uint8_t *dp = FLOW ? D + (d0 - v) * 16 + (v - 1) : nullptr;
+#pragma unroll
+			for (int i = 0; i < 16; i++) {
+				const float left = doc_left(a1, border_s(d0 + i - 1));   // H[u][v - 1] (lane 0 of the row: the border column)
+				const float diag = prev_left;                             // H[u - 1][v - 1]
+				prev_left = left;
+				float best, e = VK_NEG_INF, f = VK_NEG_INF;
+				int dir = 1, ee = 0, fe = 0;
+				{
+					const float c = diag + sv[i];
+					if constexpr (is_local) { const bool take = c > 0.0f; best = take ? c : 0.0f; if (FLOW) dir = take ? 1 : 0; }
+					else best = c;
+				}
+				if constexpr (GAP == 0) {
+					const float cu = a1 - gs, cl = left - gt;
+					if constexpr (FLOW) {
+						const bool tu = cu > best;
+						best = tu ? cu : best; dir = tu ? 2 : dir;
+						const bool tl = cl > best;
+						best = tl ? cl : best; dir = tl ? 3 : dir;
+					} else best = fmaxf(best, fmaxf(cu, cl));
+				} else {
+					const float left_f = doc_left(f1, VK_NEG_INF);   // F[u][v - 1]
+					e = a1 - open_s;
+					const float ce = e1 - gs;
+					f = left - open_t;
+					const float cf = left_f - gt;
+					if constexpr (FLOW) {
+						ee = ce > e ? 1 : 0; e = ce > e ? ce : e;
+						fe = cf > f ? 1 : 0; f = cf > f ? cf : f;
+						const bool tu = e > best;
+						best = tu ? e : best; dir = tu ? 2 : dir;
+						const bool tl = f > best;
+						best = tl ? f : best; dir = tl ? 3 : dir;
+					} else {
+						e = fmaxf(e, ce); f = fmaxf(f, cf);
+						best = fmaxf(best, fmaxf(e, f));
+					}
+					e1 = e; f1 = f;
+				}
+				if constexpr (FLOW) { if (store) dp[i * 16] = (uint8_t)(dir | (ee << 2) | (fe << 3)); }
+				if constexpr (!is_global) {
+					if constexpr (FLOW) {
+						const bool nb = track && best > best_v;   // first maximum of this column
+						best_v = nb ? best : best_v;
+						best_u = nb ? d0 + i - v : best_u;
+					} else best_v = track ? fmaxf(best_v, best) : best_v;
+				}
+				a1 = best;
+			}
+			s_next = sv[16];
+		};
 		for (int d = 2; d <= steps_end; d++) {
 			const int u = d - v;
 			const bool act = col && u >= 1 && u <= len_s;
 			// boundary: the first lane (v = 1) is about to enter a new tile -> the tile after it is written, the one after that requested
 			const int tok1 = t_a + d - 2;   // token of lane v = 1 on this step
-			if ((tok1 & 15) == 0 && d > 2) boundary(tok1 >> 4);
-			float left = 0.0f, diag;
-			const int B = ((d & 15) + 16) * 17;   // general gaps: this step's (upper) slot of Ht2
-			if constexpr (GAP == 2) diag = Ht2[B - 34 + (v - 1)];   // H[u - 1][v - 1] (borders included: they were written like values)
-			else {
-				left = doc_left(a1, border_s(d - 1));   // H[u][v - 1] (lane 0 of the row: the border column)
-				diag = prev_left;                       // H[u - 1][v - 1]
-				prev_left = left;
+			if ((tok1 & 15) == 0 && d > 2) {
+				boundary(tok1 >> 4);
+				if constexpr (GAP != 2) {
+					if (d > len_t && d + 15 <= len_s) {
+						if (local) steps16(d, std::integral_constant<int, 0>{});
+						else if (global) steps16(d, std::integral_constant<int, 1>{});
+						else steps16(d, std::integral_constant<int, 2>{});
+						d += 15;
+						continue;
+					}
+				}
 			}
+			const int B = ((d & 15) + 16) * 17;   // general gaps: this step's (upper) slot of Ht2
+			const float left = doc_left(a1, border_s(d - 1));   // H[u][v - 1] (lane 0 of the row: the border column)
+			const float diag = prev_left;                       // H[u - 1][v - 1]
+			prev_left = left;
 			float left_f = VK_NEG_INF;
 			if (GAP == 1) left_f = doc_left(f1, VK_NEG_INF);     // F[u][v - 1]
 			const float s = act ? s_next : 0.0f;
@@ -266,54 +347,9 @@ __global__ __launch_bounds__(64) void vk_doc_kernel(VkWideParams p) {
 				dir = take ? 1 : 0;
 			}
 			if constexpr (GAP == 2) {
-				// gaps over s inside the table: this DPP row's share, k = r4 + 1 + 4 i (i < 32), row u - k at hp[(31 - i) * 64].  One
-				// form per number of 8-candidate chunks the table needs, each a single block: all its loads (history, costs, the tail's
-				// row, the gaps over t) leave together -- chunk after chunk behind uniform branches was four LDS round trips a step
-				const float *hp = Hr2 + ((u & 127) + 3 - r4) * 16 + (v - 1);
-				const float *tp = Hr2 + ((u & 127) + 128 - T) * 16 + (v - 1);
-				const float *gp = Ht2 + B + v - 18 * (r4 + 1);
-				auto gaps = [&](auto nc) -> float {
-					constexpr int NC = decltype(nc)::value;
-					typedef float f2 __attribute__((ext_vector_type(2)));
-					f2 hv[NC > 0 ? NC * 4 : 1];
-#pragma unroll
-					for (int i = 0; i < NC * 4; i++) { hv[i].x = hp[(31 - 2 * i) * 64]; hv[i].y = hp[(30 - 2 * i) * 64]; }
-					const float xt = *tp;
-					float ht[4];
-#pragma unroll
-					for (int i = 0; i < 4; i++) ht[i] = gp[-72 * i];
-					float mm = VK_NEG_INF;
-#pragma unroll
-					for (int j = 0; j < NC * 2; j++) {   // (packed subtractions: two candidates an instruction)
-						const f2 c0 = hv[2 * j] - wr[2 * j], c1 = hv[2 * j + 1] - wr[2 * j + 1];
-						mm = fmaxf(mm, fmaxf(c0.x, c0.y));
-						mm = fmaxf(mm, fmaxf(c1.x, c1.y));
-					}
-					// ... at T rows and more: one running maximum
-					tail_m = fmaxf(tail_m, xt);
-					mm = fmaxf(mm, tail_m - wsT);
-					// gaps over t: k = r4 + 1 + 4 i <= v (others: +inf in wtr)
-#pragma unroll
-					for (int i = 0; i < 4; i++) mm = fmaxf(mm, ht[i] - wtr[i]);
-					return mm;
-				};
-				float m;
-				switch (n_chunks) {
-					case 0: m = gaps(std::integral_constant<int, 0>{}); break;
-					case 1: m = gaps(std::integral_constant<int, 1>{}); break;
-					case 2: m = gaps(std::integral_constant<int, 2>{}); break;
-					case 3: m = gaps(std::integral_constant<int, 3>{}); break;
-					default: m = gaps(std::integral_constant<int, 4>{}); break;
-				}
-				// the four shares meet in DPP row 0 (lanes < 16: the only ones whose values are kept)
-				{   // (v_permlane{32,16}_swap: halves / DPP rows exchanged between two registers, at VALU speed; either output holds the partner's value)
-					float x0 = m, x1 = m;
-					asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x0), "+v"(x1));
-					m = fmaxf(m, fmaxf(x0, x1));
-					x0 = m; x1 = m;
-					asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x0), "+v"(x1));
-					m = fmaxf(m, fmaxf(x0, x1));
-				}
+				// the gaps of length 1 come from the step before, as under linear gaps (the lane's own value; its left neighbour's through the
+				// DPP shift); all longer ones were gathered DURING the step before (m_far: they end in rows and steps that were complete then)
+				const float m = fmaxf(m_far, fmaxf(a1 - ws1, left - wt1));
 				dir = m > best ? 2 : dir;
 				best = fmaxf(best, m);
 			} else if (GAP == 0) {
@@ -344,6 +380,61 @@ __global__ __launch_bounds__(64) void vk_doc_kernel(VkWideParams p) {
 				}
 				if (lane == 0) { const float x = border_s(d); Ht2[B - 16 * 17] = x; Ht2[B] = x; }
 				wave_lds_fence();
+				// ---- the gaps of two and more of the NEXT step (row u + 1, step d + 1): nothing of this step's cell enters them, so their ~150
+				// instructions are off the chain from cell to cell (first form: all candidates inside the step, 1,670 cycles a step for a wave alone).
+				// Gaps over s inside the table: this DPP row's share, k = r4 + 1 + 4 i (i < 32; k = 1 and k >= T: +inf in wr), row u + 1 - k at
+				// hp[(31 - i) * 64].  One form per number of 8-candidate chunks the table needs, each a single block: all its loads (history,
+				// the tail's row, the gaps over t) leave together.
+				const float *hp = Hr2 + (((u + 1) & 127) + 3 - r4) * 16 + (v - 1);
+				const float *tp = Hr2 + (((u + 1) & 127) + 128 - T2) * 16 + (v - 1);
+				const float *gp = Ht2 + ((((d + 1) & 15) + 16) * 17) + v - 18 * (r4 + 1);
+				auto gaps = [&](auto nc) -> float {
+					constexpr int NC = decltype(nc)::value;
+					typedef float f2 __attribute__((ext_vector_type(2)));
+					f2 hv[NC > 0 ? NC * 4 : 1];
+#pragma unroll
+					for (int i = 0; i < NC * 4; i++) { hv[i].x = hp[(31 - 2 * i) * 64]; hv[i].y = hp[(30 - 2 * i) * 64]; }
+					const float xt = *tp;
+					float ht[4];
+#pragma unroll
+					for (int i = 0; i < 4; i++) ht[i] = gp[-72 * i];
+					float mm = VK_NEG_INF, mm2 = VK_NEG_INF;
+					float mm3 = VK_NEG_INF, mm4 = VK_NEG_INF;   // (four chains of maxima; plain subtractions -- v_pk_add_f32 on the register pairs measured 7 % slower)
+#pragma unroll
+					for (int j = 0; j < NC; j++) {
+						mm = fmaxf(mm, fmaxf(hv[4 * j].x - wr[4 * j].x, hv[4 * j].y - wr[4 * j].y));
+						mm2 = fmaxf(mm2, fmaxf(hv[4 * j + 1].x - wr[4 * j + 1].x, hv[4 * j + 1].y - wr[4 * j + 1].y));
+						mm3 = fmaxf(mm3, fmaxf(hv[4 * j + 2].x - wr[4 * j + 2].x, hv[4 * j + 2].y - wr[4 * j + 2].y));
+						mm4 = fmaxf(mm4, fmaxf(hv[4 * j + 3].x - wr[4 * j + 3].x, hv[4 * j + 3].y - wr[4 * j + 3].y));
+					}
+					mm = fmaxf(mm, mm3); mm2 = fmaxf(mm2, mm4);
+					// ... at T rows and more (at two and more under a constant table): one running maximum
+					tail_m = fmaxf(tail_m, xt);
+					mm = fmaxf(mm, tail_m - wsT);
+					// gaps over t: k = r4 + 1 + 4 i, 2 <= k <= v (others: +inf in wtr)
+#pragma unroll
+					for (int i = 0; i < 4; i++) mm2 = fmaxf(mm2, ht[i] - wtr[i]);
+					return fmaxf(mm, mm2);
+				};
+				float mf;
+				switch (n_chunks) {
+					case 0: mf = gaps(std::integral_constant<int, 0>{}); break;
+					case 1: mf = gaps(std::integral_constant<int, 1>{}); break;
+					case 2: mf = gaps(std::integral_constant<int, 2>{}); break;
+					case 3: mf = gaps(std::integral_constant<int, 3>{}); break;
+					default: mf = gaps(std::integral_constant<int, 4>{}); break;
+				}
+				// the four shares meet (v_permlane{32,16}_swap: halves / DPP rows exchanged between two registers at VALU speed; one of the two
+				// outputs holds the partner's value, so every DPP row ends with the maximum of all four and repeats row 0's chain)
+				{
+					float x0 = mf, x1 = mf;
+					asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x0), "+v"(x1));
+					mf = fmaxf(mf, fmaxf(x0, x1));
+					x0 = mf; x1 = mf;
+					asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x0), "+v"(x1));
+					mf = fmaxf(mf, fmaxf(x0, x1));
+				}
+				m_far = mf;
 			} else if (FLOW && act && lane < 16) D[u * 16 + (v - 1)] = (uint8_t)(dir | (ee << 2) | (fe << 3));
 			{
 				const bool nb = act && !global && (local || u == len_s || v == len_t) && best > best_v;   // first maximum of this column
