@@ -42,7 +42,7 @@ template <bool FLOW, int GAP, int SRC>
 __global__ __launch_bounds__(64) void vk_doc_kernel(VkWideParams p) {
 	// S[token & 63][query column]: what the DP runs on (tag weights applied).  Linear / affine gaps: every row a second time 64 rows up, so
 	// that the sixteen steps between two tile boundaries read their rows at immediate offsets from one base (no wrap inside a block)
-	constexpr bool RING2 = GAP != 2;
+	constexpr bool RING2 = GAP == 0 || GAP == 1;
 	__shared__ float ring[VK_DOC_RING * 16 * (RING2 ? 2 : 1)];
 	__shared__ float twl[16];
 	__shared__ int tposl[16];
@@ -147,15 +147,20 @@ __global__ __launch_bounds__(64) void vk_doc_kernel(VkWideParams p) {
 				st_ps = (p.pos_s && in) ? p.pos_s[tok] : 0;
 			}
 		};
-		auto write_st = [&](int k, float4 x, int st_ps) {
-			if (k > k_last) return;
-			const int tok = 16 * k + (lane >> 2), c4 = (lane & 3) * 4;
+		auto st_values = [&](float4 x, int st_ps) -> float4 {   // ... with the tag weights applied
+			const int c4 = (lane & 3) * 4;
 			if (!FLOW && p.pos_s) {   // (FLOW: the restated rows carry the tag weights already)
 				x.x = tag_weighted(x.x, twl[c4 + 0], st_ps, tposl[c4 + 0], p.tw_keep, p.tw_threshold);
 				x.y = tag_weighted(x.y, twl[c4 + 1], st_ps, tposl[c4 + 1], p.tw_keep, p.tw_threshold);
 				x.z = tag_weighted(x.z, twl[c4 + 2], st_ps, tposl[c4 + 2], p.tw_keep, p.tw_threshold);
 				x.w = tag_weighted(x.w, twl[c4 + 3], st_ps, tposl[c4 + 3], p.tw_keep, p.tw_threshold);
 			}
+			return x;
+		};
+		auto write_st = [&](int k, float4 x, int st_ps) {
+			if (k > k_last) return;
+			const int tok = 16 * k + (lane >> 2), c4 = (lane & 3) * 4;
+			x = st_values(x, st_ps);
 			*reinterpret_cast<float4 *>(ring + (tok & (VK_DOC_RING - 1)) * 16 + c4) = x;
 			if constexpr (RING2) *reinterpret_cast<float4 *>(ring + ((tok & (VK_DOC_RING - 1)) + VK_DOC_RING) * 16 + c4) = x;
 		};
@@ -167,8 +172,7 @@ __global__ __launch_bounds__(64) void vk_doc_kernel(VkWideParams p) {
 				xn[i] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(tp + (i < nfull ? i : 0) * 1024 + lane * 16));
 			xh = load_half_block(tp + (p.tail ? nfull : 0) * 1024, lane, true);
 		};
-		auto tile_write = [&](int k) {   // contextual: S of tile k into the ring (from the registers, or loaded here)
-			if (k > k_last) return;
+		auto tile_values = [&](int k) -> f32x4 {   // contextual: S of tile k (from the registers, or loaded here), tag weights applied
 			f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 			if constexpr (regs) {
 #pragma unroll
@@ -183,9 +187,88 @@ __global__ __launch_bounds__(64) void vk_doc_kernel(VkWideParams p) {
 #pragma unroll
 				for (int r = 0; r < 4; r++) acc[r] = tag_weighted(acc[r], twl[c0 + r], ps, tposl[c0 + r], p.tw_keep, p.tw_threshold);
 			}
+			return acc;
+		};
+		auto tile_write = [&](int k) {   // ... into the ring
+			if (k > k_last) return;
+			const f32x4 acc = tile_values(k);
+			const int tok = 16 * k + (lane & 15), c0 = (lane >> 4) * 4;
 			*reinterpret_cast<f32x4 *>(ring + (tok & (VK_DOC_RING - 1)) * 16 + c0) = acc;
 			if constexpr (RING2) *reinterpret_cast<f32x4 *>(ring + ((tok & (VK_DOC_RING - 1)) + VK_DOC_RING) * 16 + c0) = acc;
 		};
+		if constexpr (GAP == 4) {
+			// ---- relaxed 1:1 word mover's distance (rwmd_rows of vk_score_kernel; vk_wide_kernel's gap == 4 arm): no recurrence, so
+			// the tiles are consumed where the MFMA (or the table gather) leaves them -- a lane holds four query columns of one token:
+			// column minima stay in the lane until the document ends, a token's minimum over the columns crosses the four lanes that
+			// share it (lane swaps / quad shifts), the sums are per-lane partial sums.
+			const float BIG = 3.402823466e+38F;
+			const bool nbow = p.rwmd_normalize_bow != 0, sym = p.rwmd_symmetric != 0;
+			const float w_t = nbow ? 1.0f / (float)len_t : 1.0f, w_s = nbow ? 1.0f / (float)len_s : 1.0f;
+			float cmin[4] = {BIG, BIG, BIG, BIG}, acc1 = 0.0f;
+			auto consume = [&](float v0, float v1, float v2, float v3, int tok, int cbase, bool first_group, auto group_min) {
+				const bool in = tok >= t_a && tok < t_b;
+				const float val[4] = {v0, v1, v2, v3};
+				float rmin = BIG;
+#pragma unroll
+				for (int r = 0; r < 4; r++) {
+					float dist = fmaxf(1.0f - val[r], 0.0f);
+					dist = (in && cbase + r < len_t) ? dist : BIG;
+					cmin[r] = fminf(cmin[r], dist);
+					rmin = fminf(rmin, dist);
+				}
+				if (sym) {
+					rmin = group_min(rmin);
+					acc1 += (in && first_group) ? w_s * rmin : 0.0f;
+				}
+			};
+			if constexpr (is_static) {
+				request(k_first, st4a, st_psa);
+				request(k_first + 1, st4b, st_psb);
+				for (int k = k_first; k <= k_last; k++) {
+					const float4 x = st_values(st4a, st_psa);
+					st4a = st4b; st_psa = st_psb;
+					request(k + 2, st4b, st_psb);
+					consume(x.x, x.y, x.z, x.w, 16 * k + (lane >> 2), (lane & 3) * 4, (lane & 3) == 0,
+						[&](float m) { m = fminf(m, __shfl_xor(m, 1, 64)); return fminf(m, __shfl_xor(m, 2, 64)); });
+				}
+			} else {
+				if constexpr (regs) tile_load(k_first);
+				for (int k = k_first; k <= k_last; k++) {
+					const f32x4 acc = tile_values(k);
+					if constexpr (regs) tile_load(k + 1);
+					consume(acc[0], acc[1], acc[2], acc[3], 16 * k + (lane & 15), (lane >> 4) * 4, lane < 16,
+						[&](float m) { m = fminf(m, lane_xor16(m, lane)); return fminf(m, lane_xor32(m, lane)); });
+				}
+			}
+			// the column minima over all tokens: across the lanes that hold the same columns
+#pragma unroll
+			for (int r = 0; r < 4; r++) {
+#pragma unroll
+				for (int o = is_static ? 4 : 1; o <= (is_static ? 32 : 8); o <<= 1) cmin[r] = fminf(cmin[r], __shfl_xor(cmin[r], o, 64));
+			}
+			float acc0 = 0.0f;
+#pragma unroll
+			for (int j = 0; j < 16; j++) {
+				if (j < len_t) {
+					const float xj = w_t * __shfl(cmin[j & 3], is_static ? (j >> 2) : 16 * (j >> 2), 64);
+					acc0 = j == 0 ? xj : acc0 + xj;
+				}
+			}
+#pragma unroll
+			for (int o = 1; o <= 32; o <<= 1) acc1 += __shfl_xor(acc1, o, 64);
+			if (!nbow) { acc0 = acc0 / (float)len_t; acc1 = acc1 / (float)len_s; }
+			float cost = 0.0f;
+			if (sym) { if (acc0 > cost) cost = acc0; if (acc1 > cost) cost = acc1; }
+			else cost = acc0;
+			const float max_cost = nbow ? 1.0f : (float)len_t;
+			const float raw4 = (max_cost - cost) / max_cost;
+			if (lane == 0) {
+				const float boost = p.boost ? p.boost[g] : 1.0f;
+				p.scores[g] = (raw4 / p.ref_total) * boost;
+				if (p.raw) p.raw[g] = raw4;
+			}
+			continue;
+		}
 		// before the sweep: tiles k_first, k_first + 1 in the ring; k_first + 2 (and + 3: static / FLOW) requested
 		if constexpr (FLOW || is_static) {
 			request(k_first, st4a, st_psa); write_st(k_first, st4a, st_psa);
@@ -550,7 +633,7 @@ __global__ __launch_bounds__(64) void vk_doc_kernel(VkWideParams p) {
 // flow_k == 0: scores of the p->n_order slices of p->order (longest first; grid stride); flow_k > 0: the flow_k winners of p->keys,
 // their rows in p->dp_rows, one scratch region of p->scratch_stride >= vk_doc_scratch_bytes(max_len) bytes per winner
 extern "C" hipError_t vk_launch_doc(const VkWideParams *p, int32_t flow_k, hipStream_t stream) {
-	if (p->len_t > 16 || p->gap_mode < 0 || p->gap_mode > 2) return hipErrorInvalidValue;
+	if (p->len_t > 16 || p->gap_mode < 0 || (p->gap_mode > 2 && !(p->gap_mode == 4 && flow_k == 0))) return hipErrorInvalidValue;
 	if (p->gap_mode == 2 && (p->ws_tail < 1 || p->ws_tail > 126)) return hipErrorInvalidValue;   // (the history ring holds 128 rows)
 	if (flow_k > 0) {
 		if (!p->dp_rows || !p->scratch || p->scratch_stride < (int64_t)vk_doc_scratch_bytes(p->max_len, p->gap_mode)) return hipErrorInvalidValue;
@@ -570,6 +653,7 @@ extern "C" hipError_t vk_launch_doc(const VkWideParams *p, int32_t flow_k, hipSt
 	void (*kernel)(VkWideParams);
 	if (p->gap_mode == 0) kernel = src == 2 ? vk_doc_kernel<false, 0, 2> : src == 0 ? vk_doc_kernel<false, 0, 0> : vk_doc_kernel<false, 0, 1>;
 	else if (p->gap_mode == 1) kernel = src == 2 ? vk_doc_kernel<false, 1, 2> : src == 0 ? vk_doc_kernel<false, 1, 0> : vk_doc_kernel<false, 1, 1>;
+	else if (p->gap_mode == 4) kernel = src == 2 ? vk_doc_kernel<false, 4, 2> : src == 0 ? vk_doc_kernel<false, 4, 0> : vk_doc_kernel<false, 4, 1>;   // relaxed 1:1 WMD
 	else kernel = src == 2 ? vk_doc_kernel<false, 2, 2> : vk_doc_kernel<false, 2, 1>;   // (the gap scans want the registers the query's fragments would take)
 	// (fewer waves per CU -- dynamic LDS nobody uses -- only slow it down: general gaps 3.8 / 4.3 / 5.9 ms at 6 / 4 / 3 waves per CU)
 	kernel<<<grid, 64, 0, stream>>>(*p);

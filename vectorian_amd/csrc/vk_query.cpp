@@ -284,7 +284,7 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 	const bool wide = wide_score || xlong || long_via_wide;
 	// whole documents under linear / affine gaps with a query of at most 16 tokens: vk_doc_kernel scores them and retraces the winners
 	// (general gaps: under a table that saturates within 126 tokens -- wp.ws_tail, set below; doc_ok() asks once wp is filled)
-	const bool doc_fast = xlong && !wide_score && q->algorithm == VK_ALG_ALIGN && !getenv("VK_NO_DOC_KERNEL");
+	const bool doc_fast = xlong && !wide_score && (q->algorithm == VK_ALG_ALIGN || q->algorithm == VK_ALG_RWMD) && !getenv("VK_NO_DOC_KERNEL");
 	const int nq = (q->len_t + 15) / 16;
 	vk_pack_query(c, q, qtile, qmags);
 	VK_HIP(hipMemcpyAsync(c->d_qtile, qtile.data(), qtile.size(), hipMemcpyHostToDevice, st));
@@ -442,7 +442,8 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 		for (int j = 0; j < VK_FAST_QUERY_LEN; j++) p.qkey[j] = qkey_all[j];
 	}
 	VkWideParams wp{};
-	auto doc_ok = [&]() { return doc_fast && (wp.gap_mode == 0 || wp.gap_mode == 1 || (wp.gap_mode == 2 && wp.ws_tail >= 1 && wp.ws_tail <= 126 && !getenv("VK_NO_DOC_GENERAL"))); };
+	auto doc_ok = [&]() { return doc_fast && (q->algorithm == VK_ALG_RWMD ? wp.gap_mode == 4 && !getenv("VK_NO_DOC_RWMD")   // (the relaxed 1:1 form)
+		: (wp.gap_mode == 0 || wp.gap_mode == 1 || (wp.gap_mode == 2 && wp.ws_tail >= 1 && wp.ws_tail <= 126 && !getenv("VK_NO_DOC_GENERAL")))); };
 	// vk_wide_kernel: the state of a slice in LDS where that fits, else in global memory (one region per workgroup)
 	// The scoring pass of vk_wide_kernel takes one wave per slice: its work list, longest first (wp.order).  A query of more than 16
 	// tokens: every non-empty row of the slice table (the others carry no score: preset); at most 16 tokens: only the slices the fused
