@@ -284,7 +284,8 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 	const bool wide = wide_score || xlong || long_via_wide;
 	// whole documents under linear / affine gaps with a query of at most 16 tokens: vk_doc_kernel scores them and retraces the winners
 	// (general gaps: under a table that saturates within 126 tokens -- wp.ws_tail, set below; doc_ok() asks once wp is filled)
-	const bool doc_fast = xlong && !wide_score && (q->algorithm == VK_ALG_ALIGN || q->algorithm == VK_ALG_RWMD) && !getenv("VK_NO_DOC_KERNEL");
+	// (... and the slices of 65 .. 512 tokens that general gaps send through the one-wave-per-slice pass)
+	const bool doc_fast = (xlong || (long_via_wide && !getenv("VK_NO_DOC_MID"))) && !wide_score && (q->algorithm == VK_ALG_ALIGN || q->algorithm == VK_ALG_RWMD) && !getenv("VK_NO_DOC_KERNEL");
 	const int nq = (q->len_t + 15) / 16;
 	vk_pack_query(c, q, qtile, qmags);
 	VK_HIP(hipMemcpyAsync(c->d_qtile, qtile.data(), qtile.size(), hipMemcpyHostToDevice, st));
@@ -442,7 +443,10 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 		for (int j = 0; j < VK_FAST_QUERY_LEN; j++) p.qkey[j] = qkey_all[j];
 	}
 	VkWideParams wp{};
-	auto doc_ok = [&]() { return doc_fast && (q->algorithm == VK_ALG_RWMD ? wp.gap_mode == 4 && !getenv("VK_NO_DOC_RWMD")   // (the relaxed 1:1 form)
+	// Winners of 65 .. 512 tokens under linear / affine gaps (scored by the fused kernel's long pass): their tracebacks on vk_doc_kernel's
+	// sweep as well -- vk_flow_kernel fills such a matrix row by row in LDS (8,000 slices of 300 .. 512 tokens: 1.6 ms of a 2.8 ms query)
+	const bool flow_doc = is_align && !wide && c->max_len > VK_FAST_SENT_LEN && q->len_t <= 16 && (p.gap_mode == 0 || p.gap_mode == 1) && !getenv("VK_NO_DOC_FLOW");
+	auto doc_ok = [&]() { return (doc_fast || flow_doc) && (q->algorithm == VK_ALG_RWMD ? wp.gap_mode == 4 && !getenv("VK_NO_DOC_RWMD")   // (the relaxed 1:1 form)
 		: (wp.gap_mode == 0 || wp.gap_mode == 1 || (wp.gap_mode == 2 && wp.ws_tail >= 1 && wp.ws_tail <= 126 && !getenv("VK_NO_DOC_GENERAL")))); };
 	// vk_wide_kernel: the state of a slice in LDS where that fits, else in global memory (one region per workgroup)
 	// The scoring pass of vk_wide_kernel takes one wave per slice: its work list, longest first (wp.order).  A query of more than 16
@@ -477,7 +481,7 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 		// (the pass over the long slices of a corpus: the ring form where the gap table saturates -- 9 KB of LDS per wave, not 35)
 		const bool part = !flow && !wide_score && (xlong || long_via_wide);
 		const bool want_ring = part && vk_wide_ring_rows(nq, wp.gap_mode, wp.ws_tail) > 0;
-		if (!xlong && !want_ring && vk_wide_lds_demand(c->max_len, nq, wp.gap_mode, q->tag_weights != nullptr, flow) <= 160 * 1024) {
+		if (!xlong && !want_ring && !(flow && doc_ok()) && vk_wide_lds_demand(c->max_len, nq, wp.gap_mode, q->tag_weights != nullptr, flow) <= 160 * 1024) {
 			if (part) {   // state in LDS, but still only the long slices
 				int rcw = VK_OK;
 				if ((rcw = wide_order())) return rcw;
@@ -503,7 +507,7 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 		}
 		return VK_OK;
 	};
-	if (wide) {
+	if (wide || flow_doc) {
 		wp.tiles = c->d_tiles; wp.tok_id = c->d_tok_id; wp.table = c->d_table; wp.table_stride = table_stride;
 		wp.sent_start = c->d_sent_start; wp.sent_end = c->d_sent_end; wp.n_sent = (int32_t)n; wp.layout = p.layout;
 		wp.nk32 = c->nk32; wp.tail = c->tail; wp.tile_bytes = c->tile_bytes; wp.prec = c->prec;
@@ -831,14 +835,14 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 	}
 
 	// ---- flow (traceback) of `count` slices named by device keys: narrow or wide kernel
-	const int ostride = wide ? 64 : 16;   // row stride of the mapping / edge_sim device arrays
+	const int ostride = (wide || flow_doc) ? 64 : 16;   // row stride of the mapping / edge_sim device arrays
 	auto launch_flow = [&](const uint64_t *d_keys, int count) -> int {
-		if (wide) {
+		if (wide || flow_doc) {
 			wp.keys = d_keys; wp.raw_out = c->d_out_raw; wp.mapping = c->d_out_map; wp.edge_sim = c->d_out_sim;
 			int rcw = wide_state(count);
 			if (rcw) return rcw;
 			wp.dp_rows = nullptr; wp.dp_rows_len = 0;
-			if (xlong) {
+			if (xlong || doc_ok()) {
 				// Long winners: their similarities (canonical arithmetic, tag weights applied) restated beforehand by one wave per 16
 				// tokens, so that the serial sweep of a winner is its recurrence alone (5,000 tokens: 8.4 ms of a 12 ms query were the
 				// sweep restating 313 tiles one after the other; 3.6 ms since).  Within 2 GiB; else the sweep restates them itself.
