@@ -279,8 +279,9 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 	// loads deep, a saturated table as a running maximum) is several times faster than the fused kernel's pass over long slices with
 	// its serial LDS-history scan (8,000 slices of 300 .. 512 tokens at 300-d: 101 ms) -- they take the documents' pass as well,
 	// and every winner is retraced by the same kernel
+	// (round 4: linear / affine gaps too -- the skewed sweep of vk_doc_kernel is faster than the fused kernel's long pass; VK_LONG_LINEAR=1: that pass)
 	const bool long_via_wide = q->algorithm == VK_ALG_ALIGN && !wide_score && c->n_long_groups > 0 &&
-		(q->gap_s.kind == VK_GAP_TABLE || q->gap_t.kind == VK_GAP_TABLE) && !getenv("VK_LONG_PASS");
+		(q->gap_s.kind == VK_GAP_TABLE || q->gap_t.kind == VK_GAP_TABLE || !getenv("VK_LONG_LINEAR")) && !getenv("VK_LONG_PASS");
 	const bool wide = wide_score || xlong || long_via_wide;
 	// whole documents under linear / affine gaps with a query of at most 16 tokens: vk_doc_kernel scores them and retraces the winners
 	// (general gaps: under a table that saturates within 126 tokens -- wp.ws_tail, set below; doc_ok() asks once wp is filled)
