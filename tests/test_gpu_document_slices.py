@@ -224,6 +224,48 @@ RWMD_11 = {"nbow": (True, True, True), "bow/fast": (True, False, False), "nbow/f
 
 
 @pytest.mark.parametrize("variant", list(RWMD_11))
+def test_relaxed_wmd_over_slices_of_65_to_512_tokens(hip, oracle, variant):
+	"""no slice beyond 512 tokens: the slices of 65 .. 512 take vk_doc_kernel's streaming arm (round 4; the fused kernel's long pass
+	before), the others the fused kernel; contextual and static layout, with tag weights; winners restated on the host as everywhere"""
+	docs = ((0, 512), (5, 65), (18, 300), (23, 131), (40, 64), (41, 511), (69, 90))
+	off = document_lengths(33, 70, docs)
+	flags = RWMD_11[variant]
+	c, X, Xb = contextual(hip, off, 96, 34)
+	rng = np.random.default_rng(35)
+	pos_s = rng.integers(0, 6, size=int(off[-1])).astype(np.int8)
+	for qi, (sent, len_t) in enumerate(((18, 9), (41, 16), (3, 5))):
+		Qb = planted_query(X, off, sent, len_t, 80 + qi)
+		ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=96, sent_off=off, X=Xb, Q=Qb, algorithm=oracle.ALG_RWMD, rwmd=flags,
+			max_matches=12, min_score=0.0, want_all_scores=True)
+		got = c.query(Qb, q_normalize=False, algorithm=hip.VK_ALG_RWMD, rwmd=flags, max_matches=12, min_score=0.0)
+		assert_same_results(got.trimmed(), ref, check_mapping=False, exact=True)
+		np.testing.assert_allclose(c.last_scores(), ref["all_scores"], atol=1e-5, rtol=0)
+	c.set_token_pos(pos_s)
+	kw = dict(tag_weights=rng.uniform(0.3, 1.0, size=len(Qb)).astype(np.float32), q_pos=rng.integers(0, 6, size=len(Qb)).astype(np.int8),
+		pos_mismatch_penalty=0.4, similarity_threshold=0.15)
+	ref_t = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=96, sent_off=off, X=Xb, Q=Qb, algorithm=oracle.ALG_RWMD, rwmd=flags,
+		max_matches=12, min_score=0.0, want_all_scores=True, pos_s=pos_s, **kw)
+	got_t = c.query(Qb, q_normalize=False, algorithm=hip.VK_ALG_RWMD, rwmd=flags, max_matches=12, min_score=0.0, **kw)
+	assert_same_results(got_t.trimmed(), ref_t, check_mapping=False, exact=True)
+	np.testing.assert_allclose(c.last_scores(), ref_t["all_scores"], atol=3e-5, rtol=0)
+	c.close()
+	# static layout: token ids + vocabulary
+	corpus = synth.make_static_corpus(70, 1, 40, 700, 100, seed=36)
+	corpus["sent_off"] = off
+	corpus["tok_id"] = rng.integers(0, 700, size=int(off[-1])).astype(np.int32)
+	cs, Eb = hip_static_corpus(hip, corpus)
+	for s0, len_t in ((0, 8), (41, 13)):
+		a = int(off[s0])
+		q_ids = corpus["tok_id"][a:a + 2 * len_t:2][:len_t].astype(np.int32)
+		ref = oracle.find(layout=oracle.LAYOUT_STATIC, d=100, sent_off=off, tok_id=corpus["tok_id"], E=Eb, Q=Eb[q_ids], q_ids=q_ids,
+			algorithm=oracle.ALG_RWMD, rwmd=flags, max_matches=9, min_score=0.0, want_all_scores=True)
+		got = cs.query(Eb[q_ids], q_token_ids=q_ids, q_normalize=False, algorithm=hip.VK_ALG_RWMD, rwmd=flags, max_matches=9, min_score=0.0)
+		assert_same_results(got.trimmed(), ref, check_mapping=False, exact=True)
+		np.testing.assert_allclose(cs.last_scores(), ref["all_scores"], atol=1e-5, rtol=0)
+	cs.close()
+
+
+@pytest.mark.parametrize("variant", list(RWMD_11))
 @pytest.mark.parametrize("len_t", [7, 16, 40])
 def test_relaxed_wmd_over_documents(hip, oracle, variant, len_t):
 	"""rwmd('nbow') and its 1:1 siblings (vectorian/alignment.py:232-237) over documents of up to 3,000 tokens: the scoring pass

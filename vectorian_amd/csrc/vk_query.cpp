@@ -283,10 +283,13 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 	const bool long_via_wide = q->algorithm == VK_ALG_ALIGN && !wide_score && c->n_long_groups > 0 &&
 		(q->gap_s.kind == VK_GAP_TABLE || q->gap_t.kind == VK_GAP_TABLE || !getenv("VK_LONG_LINEAR")) && !getenv("VK_LONG_PASS");
 	const bool wide = wide_score || xlong || long_via_wide;
+	// the relaxed 1:1 WMD over slices of 65 .. 512 tokens: scored by vk_doc_kernel's streaming arm instead of the fused kernel's long pass
+	// (the winners keep their path: rows from vk_rows_kernel, scores restated on the host)
+	const bool rwmd_long_doc = q->algorithm == VK_ALG_RWMD && q->rwmd_injective && !q->wmd_full && !wide_score && !xlong && c->n_long_groups > 0 && !getenv("VK_LONG_PASS");
 	// whole documents under linear / affine gaps with a query of at most 16 tokens: vk_doc_kernel scores them and retraces the winners
 	// (general gaps: under a table that saturates within 126 tokens -- wp.ws_tail, set below; doc_ok() asks once wp is filled)
 	// (... and the slices of 65 .. 512 tokens that general gaps send through the one-wave-per-slice pass)
-	const bool doc_fast = (xlong || (long_via_wide && !getenv("VK_NO_DOC_MID"))) && !wide_score && (q->algorithm == VK_ALG_ALIGN || q->algorithm == VK_ALG_RWMD) && !getenv("VK_NO_DOC_KERNEL");
+	const bool doc_fast = (xlong || rwmd_long_doc || (long_via_wide && !getenv("VK_NO_DOC_MID"))) && !wide_score && (q->algorithm == VK_ALG_ALIGN || q->algorithm == VK_ALG_RWMD) && !getenv("VK_NO_DOC_KERNEL");
 	const int nq = (q->len_t + 15) / 16;
 	vk_pack_query(c, q, qtile, qmags);
 	VK_HIP(hipMemcpyAsync(c->d_qtile, qtile.data(), qtile.size(), hipMemcpyHostToDevice, st));
@@ -454,7 +457,7 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 	// tokens: every non-empty row of the slice table (the others carry no score: preset); at most 16 tokens: only the slices the fused
 	// kernels leave to it -- those beyond VK_MAX_SENT_LEN, or, under general gaps, every slice of more than 64 tokens.
 	auto wide_order = [&]() -> int {
-		const int which = wide_score ? 0 : long_via_wide ? 1 : 2;
+		const int which = wide_score ? 0 : (long_via_wide || rwmd_long_doc) ? 1 : 2;
 		int32_t *&d_ord = which == 0 ? c->d_wide_order : which == 1 ? c->d_apart_order : c->d_xlong_order;
 		int32_t &n_ord = which == 0 ? c->n_wide_order : which == 1 ? c->n_apart_order : c->n_xlong_order;
 		if (n_ord < 0) {
@@ -480,7 +483,7 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 		const bool flow = flow_k > 0;
 		wp.scratch = nullptr; wp.scratch_stride = 0; wp.h_ring = 0; wp.order = nullptr; wp.n_order = 0;
 		// (the pass over the long slices of a corpus: the ring form where the gap table saturates -- 9 KB of LDS per wave, not 35)
-		const bool part = !flow && !wide_score && (xlong || long_via_wide);
+		const bool part = !flow && !wide_score && (xlong || long_via_wide || rwmd_long_doc);
 		const bool want_ring = part && vk_wide_ring_rows(nq, wp.gap_mode, wp.ws_tail) > 0;
 		if (!xlong && !want_ring && !(flow && doc_ok()) && vk_wide_lds_demand(c->max_len, nq, wp.gap_mode, q->tag_weights != nullptr, flow) <= 160 * 1024) {
 			if (part) {   // state in LDS, but still only the long slices
@@ -508,7 +511,7 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 		}
 		return VK_OK;
 	};
-	if (wide || flow_doc) {
+	if (wide || flow_doc || rwmd_long_doc) {
 		wp.tiles = c->d_tiles; wp.tok_id = c->d_tok_id; wp.table = c->d_table; wp.table_stride = table_stride;
 		wp.sent_start = c->d_sent_start; wp.sent_end = c->d_sent_end; wp.n_sent = (int32_t)n; wp.layout = p.layout;
 		wp.nk32 = c->nk32; wp.tail = c->tail; wp.tile_bytes = c->tile_bytes; wp.prec = c->prec;
@@ -628,7 +631,7 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 	const int64_t n_groups = (n + 3) / 4;
 	const int grid = (int)std::min<int64_t>((n_groups + 3) / 4, (int64_t)1 << 20);   // capped to residency by the launcher
 	if (!only) VK_HIP(vk_launch_score(&p, grid, smem, st));
-	if (c->n_long_groups > 0 && !only && !long_via_wide) {
+	if (c->n_long_groups > 0 && !only && !long_via_wide && !rwmd_long_doc) {
 		// slices longer than VK_FAST_SENT_LEN: one per wave, one wave per workgroup, LDS strip for the longest;
 		// general gaps take the LDS-history form (the four DPP rows share one history: only row 0 is active)
 		VkScoreParams pl = p;
@@ -645,7 +648,7 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 		if (smem_l > 160 * 1024) return fail(VK_ERR_UNSUPPORTED, "LDS demand of the long-slice pass exceeds 160 KiB");
 		VK_HIP(vk_launch_score(&pl, c->n_long_groups, smem_l, st));
 	}
-	if ((xlong || long_via_wide) && !only) {
+	if ((xlong || long_via_wide || rwmd_long_doc) && !only) {
 		// slices beyond VK_MAX_SENT_LEN (whole documents; general gaps: beyond 64 tokens): one wave per slice, longest first
 		if ((rc = wide_state(0))) return rc;
 		// (linear / affine gaps: the skewed sweep of vk_doc_kernel -- no in-row dependency, a fifth of the time per row; round 4)
