@@ -329,6 +329,85 @@ __global__ __launch_bounds__(64) void vk_doc_kernel(VkWideParams p) {
 		// (any ring slot exists: rows outside the document read as whatever lies there and are never used)
 		auto s_of = [&](int u) -> float { return ring[((t_a + u - 1) & (VK_DOC_RING - 1)) * 16 + (v - 1)]; };
 		float s_next = s_of(2 - v);
+		// General gaps: the gaps of two and more of a coming step (row u1, step d1): nothing of the current cell enters them, so their ~110
+		// instructions are off the chain from cell to cell.  Gaps over s inside the table: this DPP row's share, k = r4 + 1 + 4 i (i < 32;
+		// k = 1 and k >= T: +inf in wr), row u1 - k at hp[(31 - i) * 64]; one form per number of 8-candidate chunks the table needs (NC), each
+		// a single block: all its loads (history, the tail's row, the gaps over t) leave together.  Then the four shares meet
+		// (v_permlane{32,16}_swap: halves / DPP rows exchanged between two registers at VALU speed; one of the two outputs holds the
+		// partner's value, so every DPP row ends with the maximum of all four and repeats row 0's chain).
+		auto far_next = [&](int u1, int d1, auto nc) -> float {
+			constexpr int NC = decltype(nc)::value;
+			const float *hp = Hr2 + ((u1 & 127) + 3 - r4) * 16 + (v - 1);
+			const float *tp = Hr2 + ((u1 & 127) + 128 - T2) * 16 + (v - 1);
+			const float *gp = Ht2 + (((d1 & 15) + 16) * 17) + v - 18 * (r4 + 1);
+			typedef float f2 __attribute__((ext_vector_type(2)));
+			f2 hv[NC > 0 ? NC * 4 : 1];
+#pragma unroll
+			for (int i = 0; i < NC * 4; i++) { hv[i].x = hp[(31 - 2 * i) * 64]; hv[i].y = hp[(30 - 2 * i) * 64]; }
+			const float xt = *tp;
+			float ht[4];
+#pragma unroll
+			for (int i = 0; i < 4; i++) ht[i] = gp[-72 * i];
+			float mm = VK_NEG_INF, mm2 = VK_NEG_INF;
+			float mm3 = VK_NEG_INF, mm4 = VK_NEG_INF;   // (four chains of maxima; plain subtractions -- v_pk_add_f32 on the register pairs measured 7 % slower)
+#pragma unroll
+			for (int j = 0; j < NC; j++) {
+				mm = fmaxf(mm, fmaxf(hv[4 * j].x - wr[4 * j].x, hv[4 * j].y - wr[4 * j].y));
+				mm2 = fmaxf(mm2, fmaxf(hv[4 * j + 1].x - wr[4 * j + 1].x, hv[4 * j + 1].y - wr[4 * j + 1].y));
+				mm3 = fmaxf(mm3, fmaxf(hv[4 * j + 2].x - wr[4 * j + 2].x, hv[4 * j + 2].y - wr[4 * j + 2].y));
+				mm4 = fmaxf(mm4, fmaxf(hv[4 * j + 3].x - wr[4 * j + 3].x, hv[4 * j + 3].y - wr[4 * j + 3].y));
+			}
+			mm = fmaxf(mm, mm3); mm2 = fmaxf(mm2, mm4);
+			// ... at T rows and more (at two and more under a constant table): one running maximum
+			tail_m = fmaxf(tail_m, xt);
+			mm = fmaxf(mm, tail_m - wsT);
+			// gaps over t: k = r4 + 1 + 4 i, 2 <= k <= v (others: +inf in wtr)
+#pragma unroll
+			for (int i = 0; i < 4; i++) mm2 = fmaxf(mm2, ht[i] - wtr[i]);
+			float mf = fmaxf(mm, mm2);
+			float x0 = mf, x1 = mf;
+			asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x0), "+v"(x1));
+			mf = fmaxf(mf, fmaxf(x0, x1));
+			x0 = mf; x1 = mf;
+			asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x0), "+v"(x1));
+			return fmaxf(mf, fmaxf(x0, x1));
+		};
+		// ... and sixteen steps of them from a tile boundary on while every query column is inside the document (as steps16 below: no
+		// activity masks, no first row; local: no border column -- its slots hold zeros from the start).  The general step is 270
+		// instructions with its masks, guarded stores and border look-ups, 140 of them this.
+		auto steps16g = [&](int d0, auto loc, auto nc) {
+			constexpr bool is_local = decltype(loc)::value == 0;
+			const bool track = col && (is_local || (!global && v == len_t));
+			const bool keep = col && lane < 16;
+			for (int i = 0; i < 16; i++) {
+				const int d = d0 + i, u = d - v;
+				const float left = doc_left(a1, is_local ? 0.0f : border_s(d - 1));
+				const float diag = prev_left;
+				prev_left = left;
+				const float sim = s_next;
+				s_next = s_of(u + 1);
+				float best = diag + sim;
+				if constexpr (is_local) best = fmaxf(best, 0.0f);
+				best = fmaxf(best, fmaxf(m_far, fmaxf(a1 - ws1, left - wt1)));
+				const int B = ((d & 15) + 16) * 17;
+				if (keep) {
+					if constexpr (FLOW) Hs[u * 16 + (v - 1)] = best;
+					Hr2[(u & 127) * 16 + (v - 1)] = best; Hr2[((u & 127) + 128) * 16 + (v - 1)] = best;
+					Ht2[B - 16 * 17 + v] = best; Ht2[B + v] = best;
+				}
+				if constexpr (!is_local) {
+					if (lane == 0) { const float x = border_s(d); Ht2[B - 16 * 17] = x; Ht2[B] = x; }
+				}
+				wave_lds_fence();
+				m_far = far_next(u + 1, d + 1, nc);
+				if constexpr (FLOW) {
+					const bool nb = track && best > best_v;
+					best_v = nb ? best : best_v;
+					best_u = nb ? u : best_u;
+				} else best_v = track ? fmaxf(best_v, best) : best_v;
+				a1 = best;
+			}
+		};
 		// Sixteen steps from a tile boundary on, while every query column is inside the document (d > len_t, d + 15 <= len_s: 1 <= u < len_s in
 		// all lanes that hold a column): no activity masks, no border row, the block's similarities read up front at immediate offsets, the
 		// locality at compile time.  (One loop of general steps: ~60 instructions and 450 cycles a step for a wave alone -- and a pass over
@@ -402,14 +481,23 @@ __global__ __launch_bounds__(64) void vk_doc_kernel(VkWideParams p) {
 			const int tok1 = t_a + d - 2;   // token of lane v = 1 on this step
 			if ((tok1 & 15) == 0 && d > 2) {
 				boundary(tok1 >> 4);
-				if constexpr (GAP != 2) {
-					if (d > len_t && d + 15 <= len_s) {
+				if (d > len_t && d + 15 <= len_s) {
+					if constexpr (GAP != 2) {
 						if (local) steps16(d, std::integral_constant<int, 0>{});
 						else if (global) steps16(d, std::integral_constant<int, 1>{});
 						else steps16(d, std::integral_constant<int, 2>{});
-						d += 15;
-						continue;
+					} else {
+						auto go = [&](auto nc) { if (local) steps16g(d, std::integral_constant<int, 0>{}, nc); else steps16g(d, std::integral_constant<int, 1>{}, nc); };
+						switch (n_chunks) {
+							case 0: go(std::integral_constant<int, 0>{}); break;
+							case 1: go(std::integral_constant<int, 1>{}); break;
+							case 2: go(std::integral_constant<int, 2>{}); break;
+							case 3: go(std::integral_constant<int, 3>{}); break;
+							default: go(std::integral_constant<int, 4>{}); break;
+						}
 					}
+					d += 15;
+					continue;
 				}
 			}
 			const int B = ((d & 15) + 16) * 17;   // general gaps: this step's (upper) slot of Ht2
@@ -463,61 +551,14 @@ __global__ __launch_bounds__(64) void vk_doc_kernel(VkWideParams p) {
 				}
 				if (lane == 0) { const float x = border_s(d); Ht2[B - 16 * 17] = x; Ht2[B] = x; }
 				wave_lds_fence();
-				// ---- the gaps of two and more of the NEXT step (row u + 1, step d + 1): nothing of this step's cell enters them, so their ~150
-				// instructions are off the chain from cell to cell (first form: all candidates inside the step, 1,670 cycles a step for a wave alone).
-				// Gaps over s inside the table: this DPP row's share, k = r4 + 1 + 4 i (i < 32; k = 1 and k >= T: +inf in wr), row u + 1 - k at
-				// hp[(31 - i) * 64].  One form per number of 8-candidate chunks the table needs, each a single block: all its loads (history,
-				// the tail's row, the gaps over t) leave together.
-				const float *hp = Hr2 + (((u + 1) & 127) + 3 - r4) * 16 + (v - 1);
-				const float *tp = Hr2 + (((u + 1) & 127) + 128 - T2) * 16 + (v - 1);
-				const float *gp = Ht2 + ((((d + 1) & 15) + 16) * 17) + v - 18 * (r4 + 1);
-				auto gaps = [&](auto nc) -> float {
-					constexpr int NC = decltype(nc)::value;
-					typedef float f2 __attribute__((ext_vector_type(2)));
-					f2 hv[NC > 0 ? NC * 4 : 1];
-#pragma unroll
-					for (int i = 0; i < NC * 4; i++) { hv[i].x = hp[(31 - 2 * i) * 64]; hv[i].y = hp[(30 - 2 * i) * 64]; }
-					const float xt = *tp;
-					float ht[4];
-#pragma unroll
-					for (int i = 0; i < 4; i++) ht[i] = gp[-72 * i];
-					float mm = VK_NEG_INF, mm2 = VK_NEG_INF;
-					float mm3 = VK_NEG_INF, mm4 = VK_NEG_INF;   // (four chains of maxima; plain subtractions -- v_pk_add_f32 on the register pairs measured 7 % slower)
-#pragma unroll
-					for (int j = 0; j < NC; j++) {
-						mm = fmaxf(mm, fmaxf(hv[4 * j].x - wr[4 * j].x, hv[4 * j].y - wr[4 * j].y));
-						mm2 = fmaxf(mm2, fmaxf(hv[4 * j + 1].x - wr[4 * j + 1].x, hv[4 * j + 1].y - wr[4 * j + 1].y));
-						mm3 = fmaxf(mm3, fmaxf(hv[4 * j + 2].x - wr[4 * j + 2].x, hv[4 * j + 2].y - wr[4 * j + 2].y));
-						mm4 = fmaxf(mm4, fmaxf(hv[4 * j + 3].x - wr[4 * j + 3].x, hv[4 * j + 3].y - wr[4 * j + 3].y));
-					}
-					mm = fmaxf(mm, mm3); mm2 = fmaxf(mm2, mm4);
-					// ... at T rows and more (at two and more under a constant table): one running maximum
-					tail_m = fmaxf(tail_m, xt);
-					mm = fmaxf(mm, tail_m - wsT);
-					// gaps over t: k = r4 + 1 + 4 i, 2 <= k <= v (others: +inf in wtr)
-#pragma unroll
-					for (int i = 0; i < 4; i++) mm2 = fmaxf(mm2, ht[i] - wtr[i]);
-					return fmaxf(mm, mm2);
-				};
-				float mf;
+				// ---- the gaps of two and more of the NEXT step (row u + 1, step d + 1)
 				switch (n_chunks) {
-					case 0: mf = gaps(std::integral_constant<int, 0>{}); break;
-					case 1: mf = gaps(std::integral_constant<int, 1>{}); break;
-					case 2: mf = gaps(std::integral_constant<int, 2>{}); break;
-					case 3: mf = gaps(std::integral_constant<int, 3>{}); break;
-					default: mf = gaps(std::integral_constant<int, 4>{}); break;
+					case 0: m_far = far_next(u + 1, d + 1, std::integral_constant<int, 0>{}); break;
+					case 1: m_far = far_next(u + 1, d + 1, std::integral_constant<int, 1>{}); break;
+					case 2: m_far = far_next(u + 1, d + 1, std::integral_constant<int, 2>{}); break;
+					case 3: m_far = far_next(u + 1, d + 1, std::integral_constant<int, 3>{}); break;
+					default: m_far = far_next(u + 1, d + 1, std::integral_constant<int, 4>{}); break;
 				}
-				// the four shares meet (v_permlane{32,16}_swap: halves / DPP rows exchanged between two registers at VALU speed; one of the two
-				// outputs holds the partner's value, so every DPP row ends with the maximum of all four and repeats row 0's chain)
-				{
-					float x0 = mf, x1 = mf;
-					asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x0), "+v"(x1));
-					mf = fmaxf(mf, fmaxf(x0, x1));
-					x0 = mf; x1 = mf;
-					asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x0), "+v"(x1));
-					mf = fmaxf(mf, fmaxf(x0, x1));
-				}
-				m_far = mf;
 			} else if (FLOW && act && lane < 16) D[u * 16 + (v - 1)] = (uint8_t)(dir | (ee << 2) | (fe << 3));
 			{
 				const bool nb = act && !global && (local || u == len_s || v == len_t) && best > best_v;   // first maximum of this column
