@@ -107,6 +107,25 @@ def test_longest_document(hip, oracle):
 	c.close()
 
 
+@pytest.mark.parametrize("len_t", [1, 2, 3, 15, 16])
+def test_documents_shortest_and_widest_queries(hip, oracle, len_t):
+	"""the edges of vk_doc_kernel's lane layout: one query column (no left neighbour at all), two, three, and all sixteen; documents
+	whose length leaves no room for a sixteen-step block (66, 79), exactly one (81 with the right alignment), many; every gap family"""
+	docs = ((0, 600), (1, 66), (2, 79), (3, 81), (4, 97), (9, 1100), (10, 513), (20, 2000))
+	off = document_lengths(51, 30, docs)
+	c, X, Xb = contextual(hip, off, 32, 52)
+	w = exp5(int(np.diff(off).max()))
+	for qi, sent in enumerate((20, 9, 4)):
+		Qb = planted_query(X, off, sent, len_t, 90 + qi)
+		for loc, ms, gaps in ((0, 0.0, (0.1, 0.1)), (1, -1e9, (0.05, 0.2)), (2, -1e9, (AFF, AFF)), (0, 0.0, (w, w)), (1, -1e9, (w, w)), (2, -1e9, (w, 0.1))):
+			ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=32, sent_off=off, X=Xb, Q=Qb, locality=loc,
+				gap_s=gaps[0], gap_t=gaps[1], max_matches=10, min_score=ms, want_all_scores=True, n_threads=8)
+			got = c.query(Qb, q_normalize=False, locality=loc, gap_s=gaps[0], gap_t=gaps[1], max_matches=10, min_score=ms)
+			assert_same_results(got.trimmed(), ref)
+			np.testing.assert_allclose(c.last_scores(), ref["all_scores"], atol=1e-4)
+	c.close()
+
+
 def saturating(n, t, seed):
 	"""a gap table that rises (not monotonically: nothing asks for that) up to k = t - 1 and is constant from k = t on"""
 	rng = np.random.default_rng(seed)
