@@ -462,8 +462,11 @@ __device__ __forceinline__ float dp32_general(const float *__restrict__ S, int s
 // STATIC: token ids + the two per-query tables [V x 16] (columns 0..15 and 16..31) instead of token tiles
 // (at least two waves per SIMD asked of the register allocator: the four-block general-gap form took 247 + 24 registers -- ONE wave
 // per SIMD, its tile loads and its DP never overlapping with another wave's)
-template <int GAP, bool STATIC, int NB, bool B3 = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void vk_score32_kernel(VkWideParams p, int32_t rows_per_wave, int32_t stride, int32_t slack) {
+// NWMAX: waves per workgroup the kernel may be launched with.  12 (round 4; the three-block balance of 33..48-token queries over slices
+// of at most 32 tokens takes 165 registers): ONE workgroup of twelve waves per CU shares the query tiles -- three waves per SIMD where
+// two workgroups of four left two (the LDS of a CU holds the 39 KB of query tiles twice, not three times)
+template <int GAP, bool STATIC, int NB, bool B3 = false, int NWMAX = 4>
+__global__ __launch_bounds__(64 * NWMAX) __attribute__((amdgpu_waves_per_eu(NWMAX > 4 ? 3 : 2))) void vk_score32_kernel(VkWideParams p, int32_t rows_per_wave, int32_t stride, int32_t slack) {
 	constexpr int LPS = 16 * NB, PER = 64 / LPS;   // lanes per slice, slices per wave
 	extern __shared__ float4 vk_smem32[];
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -749,7 +752,7 @@ extern "C" int32_t vk_score32_waves(int32_t nk32, int32_t tail, int32_t tiles, i
 extern "C" hipError_t vk_launch_score32(const VkWideParams *p, int32_t tiles, hipStream_t stream) {
 	const bool is_static = p->layout == VK_DEV_LAYOUT_STATIC;
 	const bool four = p->len_t > 32;   // 33..64 tokens: one slice per wave, four column blocks (linear / affine gaps)
-	const int waves = vk_score32_waves(is_static ? 0 : p->nk32, p->tail, tiles, p->len_t, p->gap_mode);
+	int waves = vk_score32_waves(is_static ? 0 : p->nk32, p->tail, tiles, p->len_t, p->gap_mode);
 	if (waves < 1) return hipErrorInvalidValue;
 	size_t smem = vk_score32_lds_bytes(is_static ? 0 : p->nk32, p->tail, tiles, p->len_t, p->gap_mode, waves);
 	int slack = strip_slack(p->gap_mode, p->len_t);
@@ -768,6 +771,10 @@ extern "C" hipError_t vk_launch_score32(const VkWideParams *p, int32_t tiles, hi
 	const bool bal2 = !four && (p->gap_mode == 3 || p->gap_mode == 6) && !getenv("VK_NO_BAL2");
 #endif
 	void (*kernel)(VkWideParams, int32_t, int32_t, int32_t);
+	// 33..48 tokens, general gaps over slices of at most 32 tokens, contextual rows: twelve waves in one workgroup when they fit
+	const bool twelve = four && p->gap_mode == 3 && p->len_t <= 48 && !is_static && waves == 4 && !getenv("VK_NO_TWELVE") &&
+		vk_score32_lds_bytes(p->nk32, p->tail, tiles, p->len_t, p->gap_mode, 12) <= 156 * 1024;
+	if (twelve) { waves = 12; smem = vk_score32_lds_bytes(p->nk32, p->tail, tiles, p->len_t, p->gap_mode, 12); }
 	switch (p->gap_mode) {
 	case 0: kernel = four ? (is_static ? vk_score32_kernel<0, true, 4> : vk_score32_kernel<0, false, 4>)
 		: (is_static ? vk_score32_kernel<0, true, 2> : vk_score32_kernel<0, false, 2>); break;
@@ -780,7 +787,7 @@ extern "C" hipError_t vk_launch_score32(const VkWideParams *p, int32_t tiles, hi
 	case 5: kernel = four ? (is_static ? vk_score32_kernel<5, true, 4> : vk_score32_kernel<5, false, 4>)
 		: (is_static ? vk_score32_kernel<5, true, 2> : vk_score32_kernel<5, false, 2>); break;
 	// general gaps, 33..48 tokens: the three-block balance of the far candidates (dp32_general<.., B3>)
-	case 3: kernel = four ? (p->len_t <= 48 ? (is_static ? vk_score32_kernel<3, true, 4, true> : vk_score32_kernel<3, false, 4, true>)
+	case 3: kernel = twelve ? vk_score32_kernel<3, false, 4, true, 12> : four ? (p->len_t <= 48 ? (is_static ? vk_score32_kernel<3, true, 4, true> : vk_score32_kernel<3, false, 4, true>)
 			: (is_static ? vk_score32_kernel<3, true, 4> : vk_score32_kernel<3, false, 4>))
 		: bal2 ? (is_static ? vk_score32_kernel<3, true, 2, true> : vk_score32_kernel<3, false, 2, true>)
 		: (is_static ? vk_score32_kernel<3, true, 2> : vk_score32_kernel<3, false, 2>); break;
