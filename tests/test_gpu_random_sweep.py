@@ -103,6 +103,12 @@ def test_random_transport_and_modifiers(hip, oracle, seed):
 	d = int(rng.choice([24, 64, 300]))
 	n = int(rng.integers(2, 250))
 	lens = rng.integers(1, 41, size=n)
+	mode = int(np.random.default_rng(77000 + seed).integers(0, 5))   # (drawn apart: the other draws keep their sequence)
+	if mode in (0, 3, 4) and np.random.default_rng(78000 + seed).random() < 0.35:
+		# a few slices of 65 .. 400 tokens: the relaxed 1:1 WMD streams them (vk_doc_kernel<false, 4, .>), their alignments and the
+		# tracebacks of submatch candidates / tag-weighted winners run on vk_doc_kernel's sweep
+		r2 = np.random.default_rng(79000 + seed)
+		lens[r2.integers(0, n, size=max(1, n // 15))] = r2.integers(65, 401)
 	off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
 	T = int(off[-1])
 	len_t = int(rng.integers(1, 17))
@@ -120,7 +126,7 @@ def test_random_transport_and_modifiers(hip, oracle, seed):
 	c.set_token_pos(pos)
 	c.finalize()
 	k = int(rng.choice([1, 6, 20]))
-	mode = int(rng.integers(0, 5))
+	rng.integers(0, 5)   # (the draw the mode used to take)
 	base = dict(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=off, X=Xn, Q=Qn, max_matches=k)
 	if mode == 0:      # relaxed WMD, any legal form
 		inj, sym, nbow = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
