@@ -74,7 +74,10 @@ WORKLOADS = {
 	"docs": dict(name="documents_wsb", n_sent=2000, min_n=2000, min_len=500, max_len=5000, d=300, alg="align", locality="local", gap="exp5", prec="bf16",
 		kernel="vk_doc_kernel (one wave per document, skewed sweep, general gaps)", rate_frac=0.03, bound="valu"),
 	"docslin": dict(name="documents_linear", n_sent=2000, min_n=2000, min_len=500, max_len=5000, d=300, alg="align", locality="local", gap="linear", prec="bf16",
-		kernel="vk_doc_kernel (one wave per document, skewed sweep)", rate_frac=0.1, bound="valu"),
+		kernel="vk_doc_kernel (one wave per document, skewed sweep)", rate_frac=0.5),   # (round 4: within 1.5 x of the HBM roofline -- priced against it)
+	# slices of 300 .. 512 tokens (paragraphs, windows of sentences): the same kernel with enough slices to fill the chip
+	"mid": dict(name="slices_300_512_linear", n_sent=8000, min_n=8000, min_len=300, max_len=512, d=300, alg="align", locality="local", gap="linear", prec="bf16",
+		kernel="vk_doc_kernel (one wave per slice, skewed sweep)", rate_frac=0.6),
 	"2static": dict(name="config2_static", n_sent=4000000, min_len=32, max_len=32, d=300, alg="align", locality="local", gap="exp5", prec="bf16", layout="static", bound="valu"),
 	# config 4 in the reference's own layout for static embeddings (round 4): ONE similarity table over the vocabulary per batch (an
 	# MFMA GEMM 600 x smaller than config 4's) and one gather pass over the token ids with config 4's epilogues -- VALU / L2 bound
@@ -494,7 +497,7 @@ def main():
 	ap.add_argument("--no-cpu-baseline", action="store_true")
 	ap.add_argument("--no-pipeline", action="store_true", help="one handle, one query at a time")
 	ap.add_argument("--no-extra", action="store_true", help="headline workload only (no \"configs\" object)")
-	ap.add_argument("--extra", default="4,4static,3,2f32,2static,2shared,2q40,5,5wrd,5rwmd,docs,docslin", help="the other configurations timed at N = 1 after the headline")
+	ap.add_argument("--extra", default="4,4static,3,2f32,2static,2shared,2q40,5,5wrd,5rwmd,docs,docslin,mid", help="the other configurations timed at N = 1 after the headline")
 	ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="weak: every rank holds the configuration's per-GPU shard; "
 		"strong: the configuration's total (config 3: 10 M, config 5: 4 M sentences) is divided among the ranks")
 	ap.add_argument("--extra-steps", type=int, default=12)
