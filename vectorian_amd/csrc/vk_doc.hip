@@ -1,4 +1,5 @@
-// vk_doc.hip -- whole documents as slices under linear / affine gaps (round 4): a skewed sweep without an in-row dependency.
+// vk_doc.hip -- long slices (65 tokens .. whole documents) under a query of at most 16 tokens (round 4): a skewed sweep without an
+// in-row dependency for linear, affine and (saturating) general gaps; the relaxed 1:1 word mover's distance streamed tile by tile.
 #include <type_traits>
 #include "vk_common.hip.h"
 
@@ -15,9 +16,14 @@
 // meets its candidates in the oracle's order (zero, diagonal, gap over s, gap over t; replaced on strictly greater), so the SAME
 // sweep serves the scoring pass (MFMA similarities, 16 rows per tile, two tiles ahead in an LDS ring) and the winners' tracebacks
 // (rows restated canonically beforehand by vk_canon_rows_kernel; one byte per cell -- direction, E / F extended -- in a scratch
-// region; start cell = first maximum in row-major order; lane 0 walks back).  Queries of at most 16 tokens, gap modes 0 / 1; general
-// gaps keep vk_wide_kernel (their candidate scans dominate either way).
+// region; start cell = first maximum in row-major order; lane 0 walks back).  Queries of at most 16 tokens.
+// General gaps (GAP 2; tables constant from some k <= 126 on, others keep vk_wide_kernel): the same sweep on VALUES only -- the column
+// history in a doubled LDS ring read at immediate offsets, the four DPP rows scanning a quarter of the candidates each, the gaps of
+// two and more gathered one step ahead; FLOW stores H and the whole wave walks back (comments at the code).
+// GAP 4: the relaxed 1:1 WMD has no recurrence; its arm consumes the tiles where the MFMA leaves them.
 // One document per wave, DP in the 16 lanes of DPP row 0 (the other rows repeat it: their lanes are needed for the tiles anyway).
+// A wave alone on its SIMD pays ~10 cycles per instruction it issues and a pass lasts as long as its longest document's chain: between
+// two tile boundaries, while every query column is inside the document, sixteen steps run without masks, borders or bookkeeping.
 // ---------------------------------------------------------------------------
 
 #define VK_DOC_RING 64   // rows of the LDS ring: four tiles (one being consumed, the next, the one being written, slack)
