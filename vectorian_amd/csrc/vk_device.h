@@ -326,6 +326,9 @@ hipError_t vk_launch_wide(const VkWideParams *p, int32_t flow_k, hipStream_t str
 // whole documents under linear / affine gaps, queries of at most 16 tokens: the skewed sweep (vk_doc.hip); flow_k > 0: p->dp_rows required
 hipError_t vk_launch_doc(const VkWideParams *p, int32_t flow_k, hipStream_t stream);
 size_t vk_doc_scratch_bytes(int32_t max_len, int32_t gap_mode);
+// queries of 17 .. 64 tokens over long slices, linear / affine gaps (vk_docw.hip)
+hipError_t vk_launch_docw(const VkWideParams *p, int32_t flow_k, hipStream_t stream);
+size_t vk_docw_scratch_bytes(int32_t max_len, int32_t nq);
 hipError_t vk_launch_submatch_bound(const float *raw, const float *boost, int64_t n, float total, float w, float m_star,
 	float *scores, hipStream_t stream);
 hipError_t vk_launch_mark(const uint64_t *keys, int32_t n, float *scores, hipStream_t stream);

@@ -25,7 +25,9 @@ static Score32Plan score32_plan(const vk_corpus *c, const vk_query_desc *q) {
 	else if (ks == VK_GAP_LINEAR && kt == VK_GAP_LINEAR) gm = 0;
 	else if (ks != VK_GAP_TABLE && kt != VK_GAP_TABLE) gm = 1;
 	else gm = c->max_len <= 32 ? 3 : 6;
-	const bool long_apart = (bound_pass || fill) && c->n_long_groups > 0;   // the long slices have kernels of their own
+	// (alignments under linear / affine gaps: vk_docw_kernel takes the long slices, round 4)
+	const bool long_apart = ((bound_pass || fill) && c->n_long_groups > 0) ||   // the long slices have kernels of their own
+		(q->algorithm == VK_ALG_ALIGN && (gm == 0 || gm == 1) && !getenv("VK_NO_DOCW") && c->h_apart && !c->h_apart->empty());   // (every slice of more than 64 tokens)
 	const int wave_tiles = long_apart ? (q->len_t <= 32 ? c->max_short_pair_tiles : (c->max_short_len + 15) / 16 + 1)
 		: (q->len_t <= 32 ? c->max_pair_tiles : (c->max_len + 15) / 16 + 1);
 	const bool fits = vk_score32_waves(is_static ? 0 : c->nk32, c->tail, wave_tiles, q->len_t, gm) >= 1;
@@ -450,14 +452,17 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 	// Winners of 65 .. 512 tokens under linear / affine gaps (scored by the fused kernel's long pass): their tracebacks on vk_doc_kernel's
 	// sweep as well -- vk_flow_kernel fills such a matrix row by row in LDS (8,000 slices of 300 .. 512 tokens: 1.6 ms of a 2.8 ms query)
 	const bool flow_doc = is_align && !wide && c->max_len > VK_FAST_SENT_LEN && q->len_t <= 16 && (p.gap_mode == 0 || p.gap_mode == 1) && !getenv("VK_NO_DOC_FLOW");
+	// a query of 17 .. 64 tokens under linear / affine gaps: the long slices (65 tokens .. whole documents) and every winner's traceback on
+	// the wave-wide skewed sweep (vk_docw_kernel); the slices of at most 64 tokens keep the multi-block kernel
+	const bool docw = is_align && wide_score && q->len_t <= VK_MAX_QUERY_LEN && (p.gap_mode == 0 || p.gap_mode == 1) && !getenv("VK_NO_DOCW");
 	auto doc_ok = [&]() { return (doc_fast || flow_doc) && (q->algorithm == VK_ALG_RWMD ? wp.gap_mode == 4 && !getenv("VK_NO_DOC_RWMD")   // (the relaxed 1:1 form)
 		: (wp.gap_mode == 0 || wp.gap_mode == 1 || (wp.gap_mode == 2 && wp.ws_tail >= 1 && wp.ws_tail <= 126 && !getenv("VK_NO_DOC_GENERAL")))); };
 	// vk_wide_kernel: the state of a slice in LDS where that fits, else in global memory (one region per workgroup)
 	// The scoring pass of vk_wide_kernel takes one wave per slice: its work list, longest first (wp.order).  A query of more than 16
 	// tokens: every non-empty row of the slice table (the others carry no score: preset); at most 16 tokens: only the slices the fused
 	// kernels leave to it -- those beyond VK_MAX_SENT_LEN, or, under general gaps, every slice of more than 64 tokens.
-	auto wide_order = [&]() -> int {
-		const int which = wide_score ? 0 : (long_via_wide || rwmd_long_doc) ? 1 : 2;
+	auto wide_order = [&](int force = -1) -> int {
+		const int which = force >= 0 ? force : wide_score ? 0 : (long_via_wide || rwmd_long_doc) ? 1 : 2;
 		int32_t *&d_ord = which == 0 ? c->d_wide_order : which == 1 ? c->d_apart_order : c->d_xlong_order;
 		int32_t &n_ord = which == 0 ? c->n_wide_order : which == 1 ? c->n_apart_order : c->n_xlong_order;
 		if (n_ord < 0) {
@@ -485,7 +490,7 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 		// (the pass over the long slices of a corpus: the ring form where the gap table saturates -- 9 KB of LDS per wave, not 35)
 		const bool part = !flow && !wide_score && (xlong || long_via_wide || rwmd_long_doc);
 		const bool want_ring = part && vk_wide_ring_rows(nq, wp.gap_mode, wp.ws_tail) > 0;
-		if (!xlong && !want_ring && !(flow && doc_ok()) && vk_wide_lds_demand(c->max_len, nq, wp.gap_mode, q->tag_weights != nullptr, flow) <= 160 * 1024) {
+		if (!xlong && !want_ring && !(flow && (doc_ok() || docw)) && vk_wide_lds_demand(c->max_len, nq, wp.gap_mode, q->tag_weights != nullptr, flow) <= 160 * 1024) {
 			if (part) {   // state in LDS, but still only the long slices
 				int rcw = VK_OK;
 				if ((rcw = wide_order())) return rcw;
@@ -495,6 +500,7 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 		wp.h_ring = vk_wide_ring_rows(nq, wp.gap_mode, wp.ws_tail);   // a saturated gap table: the column history is a ring in LDS
 		size_t per = vk_wide_scratch_bytes(c->max_len, nq, wp.gap_mode, flow, wp.h_ring);
 		if (flow && doc_ok()) per = std::max(per, vk_doc_scratch_bytes(c->max_len, wp.gap_mode));   // (vk_doc_kernel's records of a winner)
+		if (flow && docw) per = std::max(per, vk_docw_scratch_bytes(c->max_len, nq));
 		const size_t blocks = (size_t)vk_wide_gs_blocks(c->max_len, nq, wp.gap_mode, flow_k, n, wp.h_ring);
 		const size_t need = per * blocks;
 		if (need > ((size_t)16 << 30)) return fail(VK_ERR_UNSUPPORTED, "traceback state of this many slices this long exceeds 16 GiB of scratch");
@@ -548,8 +554,9 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 		const bool long_apart = (bound_pass || p.gap_mode == 7) && c->n_long_groups > 0;
 		const Score32Plan plan32 = score32_plan(c, q);
 		const int wave_tiles = plan32.wave_tiles;
-		const bool two_blocks = (is_align || rwmd_inj || bound_pass) && (long_apart || (c->n_long_groups == 0 &&
-			c->max_len <= VK_FAST_SENT_LEN)) && (rwmd_inj || bound_pass || p.gap_mode == 0 || (p.gap_mode == 1 && p.a_t >= 0.0f) || (p.gap_mode == 2 && wide_sub)) &&
+		const bool docw_apart = docw && c->h_apart && !c->h_apart->empty();   // the multi-block kernel skips the slices of more than 64 tokens, vk_docw_kernel scores them
+		const bool two_blocks = (is_align || rwmd_inj || bound_pass) && (long_apart || docw_apart || (c->n_long_groups == 0 &&
+			c->max_len <= VK_FAST_SENT_LEN)) && (docw_apart || c->max_len <= VK_MAX_SENT_LEN) && (rwmd_inj || bound_pass || p.gap_mode == 0 || (p.gap_mode == 1 && p.a_t >= 0.0f) || (p.gap_mode == 2 && wide_sub)) &&
 			plan32.fits && (bound_pass || p.gap_mode == 7 || !getenv("VK_NO_SCORE32"));
 		if ((bound_pass || p.gap_mode == 7) && !two_blocks)
 			return fail(VK_ERR_UNSUPPORTED, "exact transport / 1:n RWMD with a query of more than 16 tokens: the multi-block kernel does not fit this corpus (LDS)");
@@ -577,6 +584,14 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 			}
 			wp.gap_mode = p.gap_mode;                                        // the traceback kernel knows 0 / 1 / 2
 			wp.wt = c->d_wt;                                                 // ... and walks the caller's table
+			if (docw_apart) {
+				if ((rc = wide_order(1))) return rc;
+				if (wp.n_order > 0) VK_HIP(vk_launch_docw(&wp, 0, st));
+			}
+		}
+		else if (docw) {   // (the multi-block kernel does not fit this corpus: every slice on the sweep)
+			if ((rc = wide_order(0))) return rc;
+			if (wp.n_order > 0) VK_HIP(vk_launch_docw(&wp, 0, st));
 		}
 		else {
 			if ((rc = wide_state(0))) return rc;
@@ -846,7 +861,7 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 			int rcw = wide_state(count);
 			if (rcw) return rcw;
 			wp.dp_rows = nullptr; wp.dp_rows_len = 0;
-			if (xlong || doc_ok()) {
+			if (xlong || doc_ok() || docw) {
 				// Long winners: their similarities (canonical arithmetic, tag weights applied) restated beforehand by one wave per 16
 				// tokens, so that the serial sweep of a winner is its recurrence alone (5,000 tokens: 8.4 ms of a 12 ms query were the
 				// sweep restating 313 tiles one after the other; 3.6 ms since).  Within 2 GiB; else the sweep restates them itself.
@@ -867,7 +882,8 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 					wp.dp_rows = c->d_rows_out; wp.dp_rows_len = R;
 				}
 			}
-			if (doc_ok() && wp.dp_rows && wp.scratch && wp.scratch_stride >= (int64_t)vk_doc_scratch_bytes(c->max_len, wp.gap_mode)) VK_HIP(vk_launch_doc(&wp, count, st));
+			if (docw && wp.dp_rows && wp.scratch && wp.scratch_stride >= (int64_t)vk_docw_scratch_bytes(c->max_len, nq)) VK_HIP(vk_launch_docw(&wp, count, st));
+			else if (doc_ok() && wp.dp_rows && wp.scratch && wp.scratch_stride >= (int64_t)vk_doc_scratch_bytes(c->max_len, wp.gap_mode)) VK_HIP(vk_launch_doc(&wp, count, st));
 			else VK_HIP(vk_launch_wide(&wp, count, st));
 			return VK_OK;
 		}
