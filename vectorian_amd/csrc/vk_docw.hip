@@ -32,8 +32,9 @@ template <int NQ> struct DocwRings {
 
 extern "C" size_t vk_docw_scratch_bytes(int32_t max_len, int32_t nq) { return ((size_t)(max_len + 2) * 16 * (size_t)nq + 255) / 256 * 256; }
 
-// SRC: 1 contextual tiles (any row type; the MFMA sequence loads them), 2 the static layout's per-block tables gathered by token id,
-// 3 FLOW (the restated rows)
+// SRC: 0 contextual tiles, bf16 rows of up to 12 K-steps: a tile's K-steps are loaded into registers one boundary ahead and multiplied
+// with the query tiles' fragments (from L2: 48 NQ registers would not fit) at the next; 1 contextual tiles, any row type (the MFMA
+// sequence loads them); 2 the static layout's per-block tables gathered by token id; 3 FLOW (the restated rows)
 template <bool FLOW, int GAP, int SRC, int NQ>
 __global__ __launch_bounds__(64) void vk_docw_kernel(VkWideParams p) {
 	using RG = DocwRings<NQ>;
@@ -74,6 +75,19 @@ __global__ __launch_bounds__(64) void vk_docw_kernel(VkWideParams p) {
 			continue;
 		}
 		const int k_first = t_a >> 4, k_last = (t_b - 1) >> 4;
+		constexpr int NKP = 12;
+		const int nfull = p.tail ? p.nk32 - 1 : p.nk32;
+		bf16x8 xn[SRC == 0 ? NKP : 1], xh = {0, 0, 0, 0, 0, 0, 0, 0};
+		auto tile_load = [&](int k) {   // SRC 0: the K-steps of tile k into registers
+			if constexpr (SRC == 0) {
+				if (k > k_last) return;
+				const uint8_t *tp = p.tiles + (int64_t)k * p.tile_bytes;
+#pragma unroll
+				for (int i = 0; i < NKP; i++)   // (K-steps the row does not have re-read its first one: unconditional loads)
+					xn[i] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(tp + (i < nfull ? i : 0) * 1024 + lane * 16));
+				xh = load_half_block(tp + (p.tail ? nfull : 0) * 1024, lane, true);
+			}
+		};
 		// tile k (tokens 16 k ..) for every block of query columns, into the blocks' rings
 		auto tile_write = [&](int k) {
 			if (k > k_last) return;
@@ -81,8 +95,20 @@ __global__ __launch_bounds__(64) void vk_docw_kernel(VkWideParams p) {
 			for (int b = 0; b < NQ; b++) {
 				const int slot = (16 * k) & RG::mask(b);
 				float *rb = ring + RG::base(b) * 16;
-				if constexpr (SRC == 1) {
-					f32x4 acc = sim_tile_generic(p.qtile + (int64_t)b * p.tile_bytes, p.tiles + (int64_t)k * p.tile_bytes, p.nk32, p.tail, lane, p.prec);   // lane: S[token lane & 15][query 16 b + 4 (lane >> 4) + r]
+				if constexpr (SRC == 0 || SRC == 1) {
+					f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+					if constexpr (SRC == 0) {
+						const uint8_t *qb = p.qtile + (int64_t)b * p.tile_bytes;
+						bf16x8 qf[NKP];
+#pragma unroll
+						for (int i = 0; i < NKP; i++) qf[i] = *reinterpret_cast<const bf16x8 *>(qb + (i < nfull ? i : 0) * 1024 + lane * 16);
+						const bf16x8 qh = load_half_block(qb + (p.tail ? nfull : 0) * 1024, lane, false);
+#pragma unroll
+						for (int i = 0; i < NKP; i++)
+							if (i < nfull) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[i], xn[i], acc, 0, 0, 0);
+						if (p.tail) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh, xh, acc, 0, 0, 0);
+						acc[0] = clip01(acc[0]); acc[1] = clip01(acc[1]); acc[2] = clip01(acc[2]); acc[3] = clip01(acc[3]);
+					} else acc = sim_tile_generic(p.qtile + (int64_t)b * p.tile_bytes, p.tiles + (int64_t)k * p.tile_bytes, p.nk32, p.tail, lane, p.prec);   // lane: S[token lane & 15][query 16 b + 4 (lane >> 4) + r]
 					const int tok = 16 * k + (lane & 15), c0 = (lane >> 4) * 4;
 					if (p.pos_s) {
 						const int ps = (tok >= t_a && tok < t_b) ? p.pos_s[tok] : 0;
@@ -113,8 +139,9 @@ __global__ __launch_bounds__(64) void vk_docw_kernel(VkWideParams p) {
 				}
 			}
 		};
-		tile_write(k_first);
-		tile_write(k_first + 1);
+		tile_load(k_first); tile_write(k_first);
+		tile_load(k_first + 1); tile_write(k_first + 1);
+		tile_load(k_first + 2);
 		wave_lds_fence();
 
 		// ---- the sweep: a1 = H[u - 1][v] (this lane's last value; before its first row the border H[0][v])
@@ -202,6 +229,7 @@ __global__ __launch_bounds__(64) void vk_docw_kernel(VkWideParams p) {
 			const int tok1 = t_a + d - 2;   // token of lane v = 1 on this step
 			if ((tok1 & 15) == 0 && d > 2) {
 				tile_write((tok1 >> 4) + 1);
+				tile_load((tok1 >> 4) + 2);
 				wave_lds_fence();
 				if (d > len_t && d + 15 <= len_s) {
 					if (local) steps16(d, std::integral_constant<int, 0>{});
@@ -343,11 +371,14 @@ extern "C" hipError_t vk_launch_docw(const VkWideParams *p, int32_t flow_k, hipS
 	const int64_t cap = (int64_t)cus * 8;
 	const int grid = (int)(p->n_order < cap ? p->n_order : cap);
 	const bool st = p->layout == VK_DEV_LAYOUT_STATIC;
+	const bool regs = !st && p->prec == 0 && p->nk32 <= 12 && !getenv("VK_DOCW_GENERIC");
 	if (p->gap_mode == 0) {
 		if (st) kernel = nq == 2 ? vk_docw_kernel<false, 0, 2, 2> : nq == 3 ? vk_docw_kernel<false, 0, 2, 3> : vk_docw_kernel<false, 0, 2, 4>;
+		else if (regs) kernel = nq == 2 ? vk_docw_kernel<false, 0, 0, 2> : nq == 3 ? vk_docw_kernel<false, 0, 0, 3> : vk_docw_kernel<false, 0, 0, 4>;
 		else kernel = nq == 2 ? vk_docw_kernel<false, 0, 1, 2> : nq == 3 ? vk_docw_kernel<false, 0, 1, 3> : vk_docw_kernel<false, 0, 1, 4>;
 	} else {
 		if (st) kernel = nq == 2 ? vk_docw_kernel<false, 1, 2, 2> : nq == 3 ? vk_docw_kernel<false, 1, 2, 3> : vk_docw_kernel<false, 1, 2, 4>;
+		else if (regs) kernel = nq == 2 ? vk_docw_kernel<false, 1, 0, 2> : nq == 3 ? vk_docw_kernel<false, 1, 0, 3> : vk_docw_kernel<false, 1, 0, 4>;
 		else kernel = nq == 2 ? vk_docw_kernel<false, 1, 1, 2> : nq == 3 ? vk_docw_kernel<false, 1, 1, 3> : vk_docw_kernel<false, 1, 1, 4>;
 	}
 	kernel<<<grid, 64, 0, stream>>>(*p);
