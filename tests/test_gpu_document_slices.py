@@ -126,6 +126,41 @@ def test_documents_shortest_and_widest_queries(hip, oracle, len_t):
 	c.close()
 
 
+@pytest.mark.parametrize("d,precision", [(300, "bf16"), (64, "bf16"), (40, "f32")])
+def test_sentence_queries_over_sentences_paragraphs_and_documents(hip, oracle, monkeypatch, d, precision):
+	"""a query of 17 .. 64 tokens over a corpus that holds all three kinds of slices: at most 64 tokens (the multi-block kernel), 65 .. 512
+	and beyond (vk_docw_kernel: the skewed sweep across the wave; 300-d bf16 rows with a half K-step and 64-d rows in registers, fp32 rows
+	through the generic tile routine), linear and affine gaps, every locality; then every slice on the sweep (VK_NO_SCORE32)"""
+	docs = ((0, 700), (4, 65), (5, 512), (6, 513), (17, 129), (30, 2100), (31, 64), (49, 300))
+	off = document_lengths(61, 50, docs)
+	X = np.random.default_rng(62).standard_normal((int(off[-1]), d)).astype(np.float32)
+	Xn = synth.normalize_rows(X)
+	Xb = Xn if precision == "f32" else synth.to_bf16_bits(Xn)
+	c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=d, n_tokens=Xb.shape[0], n_sentences=len(off) - 1, precision=precision)
+	c.append_vectors(Xb, normalize=False)
+	c.set_sentences(off)
+	c.finalize()
+	boost = np.random.default_rng(63).uniform(0.5, 1.5, size=len(off) - 1).astype(np.float32)
+	for round_ in range(2):
+		if round_ == 1:
+			monkeypatch.setenv("VK_NO_SCORE32", "1")
+		for qi, (sent, len_t) in enumerate(((30, 17), (5, 33), (0, 48), (12, 64), (6, 25))):
+			rng = np.random.default_rng(100 + qi)
+			a, b = int(off[sent]), int(off[sent + 1])
+			idx = np.sort(rng.choice(np.arange(a, b), size=min(len_t, b - a), replace=False))
+			q = synth.normalize_rows(X[idx] + 0.05 * rng.standard_normal((len(idx), d)).astype(np.float32))
+			if len(q) < len_t:
+				q = np.concatenate((q, synth.normalize_rows(rng.standard_normal((len_t - len(q), d)).astype(np.float32))))
+			Qb = q if precision == "f32" else synth.to_bf16_bits(q)
+			for loc, ms, gaps, bst in ((0, 0.0, (0.1, 0.1), None), (1, -1e9, (0.05, 0.2), boost), (2, -1e9, (AFF, AFF), None), (0, 0.0, (AFF, 0.1), boost)):
+				ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=off, X=Xb, Q=Qb, locality=loc,
+					gap_s=gaps[0], gap_t=gaps[1], max_matches=11, min_score=ms, boost=bst, want_all_scores=True, n_threads=8)
+				got = c.query(Qb, q_normalize=False, locality=loc, gap_s=gaps[0], gap_t=gaps[1], max_matches=11, min_score=ms, boost=bst)
+				assert_same_results(got.trimmed(), ref)
+				np.testing.assert_allclose(c.last_scores(), ref["all_scores"], atol=1e-4)
+	c.close()
+
+
 def saturating(n, t, seed):
 	"""a gap table that rises (not monotonically: nothing asks for that) up to k = t - 1 and is constant from k = t on"""
 	rng = np.random.default_rng(seed)
