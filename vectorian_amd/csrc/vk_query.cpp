@@ -24,10 +24,12 @@ static Score32Plan score32_plan(const vk_corpus *c, const vk_query_desc *q) {
 	else if (q->algorithm == VK_ALG_RWMD) gm = 4;
 	else if (ks == VK_GAP_LINEAR && kt == VK_GAP_LINEAR) gm = 0;
 	else if (ks != VK_GAP_TABLE && kt != VK_GAP_TABLE) gm = 1;
-	else gm = c->max_len <= 32 ? 3 : 6;
-	// (alignments under linear / affine gaps: vk_docw_kernel takes the long slices, round 4)
-	const bool long_apart = ((bound_pass || fill) && c->n_long_groups > 0) ||   // the long slices have kernels of their own
-		(q->algorithm == VK_ALG_ALIGN && (gm == 0 || gm == 1) && !getenv("VK_NO_DOCW") && c->h_apart && !c->h_apart->empty());   // (every slice of more than 64 tokens)
+	else gm = -1;   // general gaps: by the longest slice the kernel sees (below)
+	// alignments and the relaxed 1:1 WMD over a corpus that holds slices of more than 64 tokens (round 4): the multi-block kernel takes the
+	// others, the slices apart a pass of their own (vk_docw_kernel under linear / affine gaps, else vk_wide_kernel over their list)
+	const bool apart = (q->algorithm == VK_ALG_ALIGN || gm == 4) && c->h_apart && !c->h_apart->empty() && !getenv("VK_NO_APART");
+	if (gm < 0) gm = (apart ? c->max_short_len : c->max_len) <= 32 ? 3 : 6;
+	const bool long_apart = ((bound_pass || fill) && c->n_long_groups > 0) || apart;   // the long slices have kernels of their own
 	const int wave_tiles = long_apart ? (q->len_t <= 32 ? c->max_short_pair_tiles : (c->max_short_len + 15) / 16 + 1)
 		: (q->len_t <= 32 ? c->max_pair_tiles : (c->max_len + 15) / 16 + 1);
 	const bool fits = vk_score32_waves(is_static ? 0 : c->nk32, c->tail, wave_tiles, q->len_t, gm) >= 1;
@@ -484,16 +486,16 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 		}
 		return VK_OK;
 	};
-	auto wide_state = [&](int flow_k) -> int {
+	auto wide_state = [&](int flow_k, int force = -1) -> int {   // force: the work list (wide_order), whatever the query's own choice
 		const bool flow = flow_k > 0;
 		wp.scratch = nullptr; wp.scratch_stride = 0; wp.h_ring = 0; wp.order = nullptr; wp.n_order = 0;
 		// (the pass over the long slices of a corpus: the ring form where the gap table saturates -- 9 KB of LDS per wave, not 35)
-		const bool part = !flow && !wide_score && (xlong || long_via_wide || rwmd_long_doc);
+		const bool part = !flow && ((!wide_score && (xlong || long_via_wide || rwmd_long_doc)) || force >= 0);
 		const bool want_ring = part && vk_wide_ring_rows(nq, wp.gap_mode, wp.ws_tail) > 0;
 		if (!xlong && !want_ring && !(flow && (doc_ok() || docw)) && vk_wide_lds_demand(c->max_len, nq, wp.gap_mode, q->tag_weights != nullptr, flow) <= 160 * 1024) {
 			if (part) {   // state in LDS, but still only the long slices
 				int rcw = VK_OK;
-				if ((rcw = wide_order())) return rcw;
+				if ((rcw = wide_order(force))) return rcw;
 			}
 			return VK_OK;
 		}
@@ -513,7 +515,7 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 		wp.scratch = c->d_wide_scratch; wp.scratch_stride = (int64_t)per;
 		if (!flow && (xlong || part)) {
 			int rcw = VK_OK;
-			if ((rcw = wide_order())) return rcw;
+			if ((rcw = wide_order(force))) return rcw;
 		}
 		return VK_OK;
 	};
@@ -554,9 +556,10 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 		const bool long_apart = (bound_pass || p.gap_mode == 7) && c->n_long_groups > 0;
 		const Score32Plan plan32 = score32_plan(c, q);
 		const int wave_tiles = plan32.wave_tiles;
-		const bool docw_apart = docw && c->h_apart && !c->h_apart->empty();   // the multi-block kernel skips the slices of more than 64 tokens, vk_docw_kernel scores them
-		const bool two_blocks = (is_align || rwmd_inj || bound_pass) && (long_apart || docw_apart || (c->n_long_groups == 0 &&
-			c->max_len <= VK_FAST_SENT_LEN)) && (docw_apart || c->max_len <= VK_MAX_SENT_LEN) && (rwmd_inj || bound_pass || p.gap_mode == 0 || (p.gap_mode == 1 && p.a_t >= 0.0f) || (p.gap_mode == 2 && wide_sub)) &&
+		// the multi-block kernel skips the slices of more than 64 tokens; a pass of their own scores them (vk_docw_kernel, else vk_wide_kernel)
+		const bool apart_route = (is_align || (rwmd_inj && p.gap_mode == 4)) && c->h_apart && !c->h_apart->empty() && !getenv("VK_NO_APART");
+		const bool two_blocks = (is_align || rwmd_inj || bound_pass) && (long_apart || apart_route || (c->n_long_groups == 0 &&
+			c->max_len <= VK_FAST_SENT_LEN)) && (apart_route || c->max_len <= VK_MAX_SENT_LEN) && (rwmd_inj || bound_pass || p.gap_mode == 0 || (p.gap_mode == 1 && p.a_t >= 0.0f) || (p.gap_mode == 2 && wide_sub)) &&
 			plan32.fits && (bound_pass || p.gap_mode == 7 || !getenv("VK_NO_SCORE32"));
 		if ((bound_pass || p.gap_mode == 7) && !two_blocks)
 			return fail(VK_ERR_UNSUPPORTED, "exact transport / 1:n RWMD with a query of more than 16 tokens: the multi-block kernel does not fit this corpus (LDS)");
@@ -569,7 +572,7 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 				memcpy(wp.qmass, qmass_all, sizeof wp.qmass);
 				wp.wrd_raw_total = p.wrd_raw_total; wp.wmd_bound = q->algorithm == VK_ALG_WRD ? 0 : p.wmd_bound;
 			}
-			if (p.gap_mode == 2) { wp.gap_mode = c->max_len <= 32 ? 3 : 6; wp.wt = c->d_wt + 80; }   // register history of 32 / 64 rows, closure of w_t
+			if (p.gap_mode == 2) { wp.gap_mode = (apart_route ? c->max_short_len : c->max_len) <= 32 ? 3 : 6; wp.wt = c->d_wt + 80; }   // register history of 32 / 64 rows, closure of w_t
 			VK_HIP(vk_launch_score32(&wp, wave_tiles, st));
 			if (long_apart && p.gap_mode == 7) VK_HIP(vk_launch_long_rwmd_fill(&wp, c->d_long_groups, c->n_long_groups, (int32_t)n, st));
 			else if (long_apart) {
@@ -584,9 +587,12 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 			}
 			wp.gap_mode = p.gap_mode;                                        // the traceback kernel knows 0 / 1 / 2
 			wp.wt = c->d_wt;                                                 // ... and walks the caller's table
-			if (docw_apart) {
+			if (apart_route && docw) {
 				if ((rc = wide_order(1))) return rc;
 				if (wp.n_order > 0) VK_HIP(vk_launch_docw(&wp, 0, st));
+			} else if (apart_route) {   // general gaps, relaxed 1:1 WMD: row by row, but only the slices apart
+				if ((rc = wide_state(0, 1))) return rc;
+				if (wp.n_order > 0) VK_HIP(vk_launch_wide(&wp, 0, st));
 			}
 		}
 		else if (docw) {   // (the multi-block kernel does not fit this corpus: every slice on the sweep)
