@@ -329,6 +329,8 @@ size_t vk_doc_scratch_bytes(int32_t max_len, int32_t gap_mode);
 // queries of 17 .. 64 tokens over long slices, linear / affine gaps (vk_docw.hip)
 hipError_t vk_launch_docw(const VkWideParams *p, int32_t flow_k, hipStream_t stream);
 size_t vk_docw_scratch_bytes(int32_t max_len, int32_t nq);
+hipError_t vk_launch_docg(const VkWideParams *p, int32_t flow_k, hipStream_t stream);   // ... general gaps, 17 .. 32 tokens
+size_t vk_docg_scratch_bytes(int32_t max_len);
 hipError_t vk_launch_submatch_bound(const float *raw, const float *boost, int64_t n, float total, float w, float m_star,
 	float *scores, hipStream_t stream);
 hipError_t vk_launch_mark(const uint64_t *keys, int32_t n, float *scores, hipStream_t stream);

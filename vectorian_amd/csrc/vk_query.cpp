@@ -457,6 +457,8 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 	// a query of 17 .. 64 tokens under linear / affine gaps: the long slices (65 tokens .. whole documents) and every winner's traceback on
 	// the wave-wide skewed sweep (vk_docw_kernel); the slices of at most 64 tokens keep the multi-block kernel
 	const bool docw = is_align && wide_score && q->len_t <= VK_MAX_QUERY_LEN && (p.gap_mode == 0 || p.gap_mode == 1) && !getenv("VK_NO_DOCW");
+	// ... of 17 .. 32 tokens under general gaps whose table saturates within 126 tokens (wp.ws_tail): vk_docg_kernel
+	auto docg_ok = [&]() { return is_align && wide_score && q->len_t <= 32 && c->max_len > VK_FAST_SENT_LEN && p.gap_mode == 2 && wp.ws_tail >= 1 && wp.ws_tail <= 126 && !getenv("VK_NO_DOCG"); };
 	auto doc_ok = [&]() { return (doc_fast || flow_doc) && (q->algorithm == VK_ALG_RWMD ? wp.gap_mode == 4 && !getenv("VK_NO_DOC_RWMD")   // (the relaxed 1:1 form)
 		: (wp.gap_mode == 0 || wp.gap_mode == 1 || (wp.gap_mode == 2 && wp.ws_tail >= 1 && wp.ws_tail <= 126 && !getenv("VK_NO_DOC_GENERAL")))); };
 	// vk_wide_kernel: the state of a slice in LDS where that fits, else in global memory (one region per workgroup)
@@ -492,7 +494,7 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 		// (the pass over the long slices of a corpus: the ring form where the gap table saturates -- 9 KB of LDS per wave, not 35)
 		const bool part = !flow && ((!wide_score && (xlong || long_via_wide || rwmd_long_doc)) || force >= 0);
 		const bool want_ring = part && vk_wide_ring_rows(nq, wp.gap_mode, wp.ws_tail) > 0;
-		if (!xlong && !want_ring && !(flow && (doc_ok() || docw)) && vk_wide_lds_demand(c->max_len, nq, wp.gap_mode, q->tag_weights != nullptr, flow) <= 160 * 1024) {
+		if (!xlong && !want_ring && !(flow && (doc_ok() || docw || docg_ok())) && vk_wide_lds_demand(c->max_len, nq, wp.gap_mode, q->tag_weights != nullptr, flow) <= 160 * 1024) {
 			if (part) {   // state in LDS, but still only the long slices
 				int rcw = VK_OK;
 				if ((rcw = wide_order(force))) return rcw;
@@ -503,6 +505,7 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 		size_t per = vk_wide_scratch_bytes(c->max_len, nq, wp.gap_mode, flow, wp.h_ring);
 		if (flow && doc_ok()) per = std::max(per, vk_doc_scratch_bytes(c->max_len, wp.gap_mode));   // (vk_doc_kernel's records of a winner)
 		if (flow && docw) per = std::max(per, vk_docw_scratch_bytes(c->max_len, nq));
+		if (flow && docg_ok()) per = std::max(per, vk_docg_scratch_bytes(c->max_len));
 		const size_t blocks = (size_t)vk_wide_gs_blocks(c->max_len, nq, wp.gap_mode, flow_k, n, wp.h_ring);
 		const size_t need = per * blocks;
 		if (need > ((size_t)16 << 30)) return fail(VK_ERR_UNSUPPORTED, "traceback state of this many slices this long exceeds 16 GiB of scratch");
@@ -590,6 +593,9 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 			if (apart_route && docw) {
 				if ((rc = wide_order(1))) return rc;
 				if (wp.n_order > 0) VK_HIP(vk_launch_docw(&wp, 0, st));
+			} else if (apart_route && docg_ok()) {
+				if ((rc = wide_order(1))) return rc;
+				if (wp.n_order > 0) VK_HIP(vk_launch_docg(&wp, 0, st));
 			} else if (apart_route) {   // general gaps, relaxed 1:1 WMD: row by row, but only the slices apart
 				if ((rc = wide_state(0, 1))) return rc;
 				if (wp.n_order > 0) VK_HIP(vk_launch_wide(&wp, 0, st));
@@ -598,6 +604,10 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 		else if (docw) {   // (the multi-block kernel does not fit this corpus: every slice on the sweep)
 			if ((rc = wide_order(0))) return rc;
 			if (wp.n_order > 0) VK_HIP(vk_launch_docw(&wp, 0, st));
+		}
+		else if (docg_ok()) {
+			if ((rc = wide_order(0))) return rc;
+			if (wp.n_order > 0) VK_HIP(vk_launch_docg(&wp, 0, st));
 		}
 		else {
 			if ((rc = wide_state(0))) return rc;
@@ -867,7 +877,7 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 			int rcw = wide_state(count);
 			if (rcw) return rcw;
 			wp.dp_rows = nullptr; wp.dp_rows_len = 0;
-			if (xlong || doc_ok() || docw) {
+			if (xlong || doc_ok() || docw || docg_ok()) {
 				// Long winners: their similarities (canonical arithmetic, tag weights applied) restated beforehand by one wave per 16
 				// tokens, so that the serial sweep of a winner is its recurrence alone (5,000 tokens: 8.4 ms of a 12 ms query were the
 				// sweep restating 313 tiles one after the other; 3.6 ms since).  Within 2 GiB; else the sweep restates them itself.
@@ -889,6 +899,7 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 				}
 			}
 			if (docw && wp.dp_rows && wp.scratch && wp.scratch_stride >= (int64_t)vk_docw_scratch_bytes(c->max_len, nq)) VK_HIP(vk_launch_docw(&wp, count, st));
+			else if (docg_ok() && wp.dp_rows && wp.scratch && wp.scratch_stride >= (int64_t)vk_docg_scratch_bytes(c->max_len)) VK_HIP(vk_launch_docg(&wp, count, st));
 			else if (doc_ok() && wp.dp_rows && wp.scratch && wp.scratch_stride >= (int64_t)vk_doc_scratch_bytes(c->max_len, wp.gap_mode)) VK_HIP(vk_launch_doc(&wp, count, st));
 			else VK_HIP(vk_launch_wide(&wp, count, st));
 			return VK_OK;
