@@ -181,8 +181,13 @@ def test_documents_general_gaps_by_where_the_table_saturates(hip, oracle, tail):
 	c, X, Xb = contextual(hip, off, 64, 32)
 	n = int(np.diff(off).max())
 	ws, wt = saturating(n, tail, 40 + tail), saturating(n, min(tail, 7), 41 + tail)
-	for qi, (sent, spread, len_t) in enumerate(((9, True, 7), (39, False, 16), (0, True, 11))):
+	# (17 .. 32 tokens: vk_docg_kernel -- two blocks of columns, the candidates dealt to two shares; its forms by chunks likewise)
+	for qi, (sent, spread, len_t) in enumerate(((9, True, 7), (39, False, 16), (0, True, 11), (9, True, 20), (39, False, 32), (25, True, 17))):
 		Qb = planted_query(X, off, sent, len_t, 60 + qi, spread)
+		if len(Qb) < len_t:   # (a slice shorter than the query: random tokens behind the planted ones)
+			extra = synth.normalize_rows(np.random.default_rng(600 + qi).standard_normal((len_t - len(Qb), 64)).astype(np.float32))
+			Qb = np.concatenate((Qb, synth.to_bf16_bits(extra)))
+		wt = saturating(n, min(tail, 7 if len_t <= 16 else 19), 41 + tail)
 		for loc, ms in ((0, 0.0), (1, -1e9), (2, -1e9)):
 			ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=64, sent_off=off, X=Xb, Q=Qb, locality=loc,
 				gap_s=ws, gap_t=wt, max_matches=9, min_score=ms, want_all_scores=True, n_threads=8)
