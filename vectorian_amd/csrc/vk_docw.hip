@@ -88,57 +88,128 @@ __global__ __launch_bounds__(64) void vk_docw_kernel(VkWideParams p) {
 				xh = load_half_block(tp + (p.tail ? nfull : 0) * 1024, lane, true);
 			}
 		};
-		// tile k (tokens 16 k ..) for every block of query columns, into the blocks' rings
+		// S of tile k (tokens 16 k ..) x block b of query columns, tag weights applied: SRC 0 / 1 -- this lane: token lane & 15, columns
+		// 4 (lane >> 4) + r; SRC 2 / 3 -- token lane >> 2, columns 4 (lane & 3) + r
+		auto tile_values = [&](int k, int b) -> f32x4 {
+			f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+			if constexpr (SRC == 0 || SRC == 1) {
+				if constexpr (SRC == 0) {
+					const uint8_t *qb = p.qtile + (int64_t)b * p.tile_bytes;
+					bf16x8 qf[NKP];
+#pragma unroll
+					for (int i = 0; i < NKP; i++) qf[i] = *reinterpret_cast<const bf16x8 *>(qb + (i < nfull ? i : 0) * 1024 + lane * 16);
+					const bf16x8 qh = load_half_block(qb + (p.tail ? nfull : 0) * 1024, lane, false);
+#pragma unroll
+					for (int i = 0; i < NKP; i++)
+						if (i < nfull) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[i], xn[i], acc, 0, 0, 0);
+					if (p.tail) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh, xh, acc, 0, 0, 0);
+					acc[0] = clip01(acc[0]); acc[1] = clip01(acc[1]); acc[2] = clip01(acc[2]); acc[3] = clip01(acc[3]);
+				} else acc = sim_tile_generic(p.qtile + (int64_t)b * p.tile_bytes, p.tiles + (int64_t)k * p.tile_bytes, p.nk32, p.tail, lane, p.prec);
+				const int tok = 16 * k + (lane & 15), c0 = (lane >> 4) * 4;
+				if (p.pos_s) {
+					const int ps = (tok >= t_a && tok < t_b) ? p.pos_s[tok] : 0;
+#pragma unroll
+					for (int r = 0; r < 4; r++) acc[r] = tag_weighted(acc[r], twl[16 * b + c0 + r], ps, tposl[16 * b + c0 + r], p.tw_keep, p.tw_threshold);
+				}
+			} else {
+				const int tok = 16 * k + (lane >> 2), c4 = (lane & 3) * 4;
+				const bool in = tok >= t_a && tok < t_b;
+				float4 x;
+				if constexpr (FLOW) {   // (the restated rows carry the tag weights already)
+					x = in ? *reinterpret_cast<const float4 *>(p.dp_rows + ((int64_t)item * p.dp_rows_len + (tok - t_a)) * W + 16 * b + c4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+				} else {
+					const int id = in ? p.tok_id[tok] : 0;
+					x = *reinterpret_cast<const float4 *>(p.table + (int64_t)b * p.table_stride + (int64_t)id * 16 + c4);
+					if (p.pos_s) {
+						const int ps = in ? p.pos_s[tok] : 0;
+						x.x = tag_weighted(x.x, twl[16 * b + c4 + 0], ps, tposl[16 * b + c4 + 0], p.tw_keep, p.tw_threshold);
+						x.y = tag_weighted(x.y, twl[16 * b + c4 + 1], ps, tposl[16 * b + c4 + 1], p.tw_keep, p.tw_threshold);
+						x.z = tag_weighted(x.z, twl[16 * b + c4 + 2], ps, tposl[16 * b + c4 + 2], p.tw_keep, p.tw_threshold);
+						x.w = tag_weighted(x.w, twl[16 * b + c4 + 3], ps, tposl[16 * b + c4 + 3], p.tw_keep, p.tw_threshold);
+					}
+				}
+				acc[0] = x.x; acc[1] = x.y; acc[2] = x.z; acc[3] = x.w;
+			}
+			return acc;
+		};
+		// ... for every block, into the blocks' rings
 		auto tile_write = [&](int k) {
 			if (k > k_last) return;
 #pragma unroll
 			for (int b = 0; b < NQ; b++) {
 				const int slot = (16 * k) & RG::mask(b);
 				float *rb = ring + RG::base(b) * 16;
-				if constexpr (SRC == 0 || SRC == 1) {
-					f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-					if constexpr (SRC == 0) {
-						const uint8_t *qb = p.qtile + (int64_t)b * p.tile_bytes;
-						bf16x8 qf[NKP];
-#pragma unroll
-						for (int i = 0; i < NKP; i++) qf[i] = *reinterpret_cast<const bf16x8 *>(qb + (i < nfull ? i : 0) * 1024 + lane * 16);
-						const bf16x8 qh = load_half_block(qb + (p.tail ? nfull : 0) * 1024, lane, false);
-#pragma unroll
-						for (int i = 0; i < NKP; i++)
-							if (i < nfull) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[i], xn[i], acc, 0, 0, 0);
-						if (p.tail) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh, xh, acc, 0, 0, 0);
-						acc[0] = clip01(acc[0]); acc[1] = clip01(acc[1]); acc[2] = clip01(acc[2]); acc[3] = clip01(acc[3]);
-					} else acc = sim_tile_generic(p.qtile + (int64_t)b * p.tile_bytes, p.tiles + (int64_t)k * p.tile_bytes, p.nk32, p.tail, lane, p.prec);   // lane: S[token lane & 15][query 16 b + 4 (lane >> 4) + r]
-					const int tok = 16 * k + (lane & 15), c0 = (lane >> 4) * 4;
-					if (p.pos_s) {
-						const int ps = (tok >= t_a && tok < t_b) ? p.pos_s[tok] : 0;
-#pragma unroll
-						for (int r = 0; r < 4; r++) acc[r] = tag_weighted(acc[r], twl[16 * b + c0 + r], ps, tposl[16 * b + c0 + r], p.tw_keep, p.tw_threshold);
-					}
-					*reinterpret_cast<f32x4 *>(rb + (slot + (lane & 15)) * 16 + c0) = acc;
-					if (slot == 0) *reinterpret_cast<f32x4 *>(rb + (RG::mask(b) + 1 + (lane & 15)) * 16 + c0) = acc;
-				} else {
-					const int tok = 16 * k + (lane >> 2), c4 = (lane & 3) * 4;
-					const bool in = tok >= t_a && tok < t_b;
-					float4 x;
-					if constexpr (FLOW) {   // (the restated rows carry the tag weights already)
-						x = in ? *reinterpret_cast<const float4 *>(p.dp_rows + ((int64_t)item * p.dp_rows_len + (tok - t_a)) * W + 16 * b + c4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-					} else {
-						const int id = in ? p.tok_id[tok] : 0;
-						x = *reinterpret_cast<const float4 *>(p.table + (int64_t)b * p.table_stride + (int64_t)id * 16 + c4);
-						if (p.pos_s) {
-							const int ps = in ? p.pos_s[tok] : 0;
-							x.x = tag_weighted(x.x, twl[16 * b + c4 + 0], ps, tposl[16 * b + c4 + 0], p.tw_keep, p.tw_threshold);
-							x.y = tag_weighted(x.y, twl[16 * b + c4 + 1], ps, tposl[16 * b + c4 + 1], p.tw_keep, p.tw_threshold);
-							x.z = tag_weighted(x.z, twl[16 * b + c4 + 2], ps, tposl[16 * b + c4 + 2], p.tw_keep, p.tw_threshold);
-							x.w = tag_weighted(x.w, twl[16 * b + c4 + 3], ps, tposl[16 * b + c4 + 3], p.tw_keep, p.tw_threshold);
-						}
-					}
-					*reinterpret_cast<float4 *>(rb + (slot + (lane >> 2)) * 16 + c4) = x;
-					if (slot == 0) *reinterpret_cast<float4 *>(rb + (RG::mask(b) + 1 + (lane >> 2)) * 16 + c4) = x;
-				}
+				const f32x4 acc = tile_values(k, b);
+				const int row = (SRC == 0 || SRC == 1) ? (lane & 15) : (lane >> 2), c0 = (SRC == 0 || SRC == 1) ? (lane >> 4) * 4 : (lane & 3) * 4;
+				*reinterpret_cast<f32x4 *>(rb + (slot + row) * 16 + c0) = acc;
+				if (slot == 0) *reinterpret_cast<f32x4 *>(rb + (RG::mask(b) + 1 + row) * 16 + c0) = acc;
 			}
 		};
+		if constexpr (GAP == 4) {
+			// ---- relaxed 1:1 word mover's distance (vk_doc_kernel's GAP 4 arm over NQ blocks of columns): no recurrence, the tiles are
+			// consumed where they are produced; column minima stay in the lane, a token's minimum over all columns crosses the four lanes
+			// that share the token
+			const float BIG = 3.402823466e+38F;
+			const bool nbow = p.rwmd_normalize_bow != 0, sym = p.rwmd_symmetric != 0;
+			const float w_t = nbow ? 1.0f / (float)len_t : 1.0f, w_s = nbow ? 1.0f / (float)len_s : 1.0f;
+			constexpr bool quad = SRC == 2 || SRC == 3;   // (token lane >> 2, columns by lane & 3)
+			float cmin[NQ][4], acc1 = 0.0f;
+#pragma unroll
+			for (int b = 0; b < NQ; b++) { cmin[b][0] = BIG; cmin[b][1] = BIG; cmin[b][2] = BIG; cmin[b][3] = BIG; }
+			tile_load(k_first);
+			for (int k = k_first; k <= k_last; k++) {
+				const int tok = 16 * k + (quad ? (lane >> 2) : (lane & 15)), cbase = quad ? (lane & 3) * 4 : (lane >> 4) * 4;
+				const bool in = tok >= t_a && tok < t_b;
+				float rmin = BIG;
+#pragma unroll
+				for (int b = 0; b < NQ; b++) {
+					const f32x4 acc = tile_values(k, b);
+#pragma unroll
+					for (int r = 0; r < 4; r++) {
+						float dist = fmaxf(1.0f - acc[r], 0.0f);
+						dist = (in && 16 * b + cbase + r < len_t) ? dist : BIG;
+						cmin[b][r] = fminf(cmin[b][r], dist);
+						rmin = fminf(rmin, dist);
+					}
+				}
+				tile_load(k + 1);
+				if (sym) {
+					if constexpr (quad) { rmin = fminf(rmin, __shfl_xor(rmin, 1, 64)); rmin = fminf(rmin, __shfl_xor(rmin, 2, 64)); }
+					else { rmin = fminf(rmin, lane_xor16(rmin, lane)); rmin = fminf(rmin, lane_xor32(rmin, lane)); }
+					acc1 += (in && (quad ? (lane & 3) == 0 : lane < 16)) ? w_s * rmin : 0.0f;
+				}
+			}
+			float acc0 = 0.0f;
+#pragma unroll
+			for (int b = 0; b < NQ; b++) {
+#pragma unroll
+				for (int r = 0; r < 4; r++) {
+#pragma unroll
+					for (int o = quad ? 4 : 1; o <= (quad ? 32 : 8); o <<= 1) cmin[b][r] = fminf(cmin[b][r], __shfl_xor(cmin[b][r], o, 64));
+				}
+			}
+#pragma unroll
+			for (int j = 0; j < W; j++) {
+				if (j < len_t) {
+					const float xj = w_t * __shfl(cmin[j >> 4][j & 3], quad ? ((j & 15) >> 2) : 16 * ((j & 15) >> 2), 64);
+					acc0 = j == 0 ? xj : acc0 + xj;
+				}
+			}
+#pragma unroll
+			for (int o = 1; o <= 32; o <<= 1) acc1 += __shfl_xor(acc1, o, 64);
+			if (!nbow) { acc0 = acc0 / (float)len_t; acc1 = acc1 / (float)len_s; }
+			float cost = 0.0f;
+			if (sym) { if (acc0 > cost) cost = acc0; if (acc1 > cost) cost = acc1; }
+			else cost = acc0;
+			const float max_cost = nbow ? 1.0f : (float)len_t;
+			const float raw4 = (max_cost - cost) / max_cost;
+			if (lane == 0) {
+				const float boost = p.boost ? p.boost[g] : 1.0f;
+				p.scores[g] = (raw4 / p.ref_total) * boost;
+				if (p.raw) p.raw[g] = raw4;
+			}
+			continue;
+		}
 		tile_load(k_first); tile_write(k_first);
 		tile_load(k_first + 1); tile_write(k_first + 1);
 		tile_load(k_first + 2);
@@ -355,7 +426,7 @@ __global__ __launch_bounds__(64) void vk_docw_kernel(VkWideParams p) {
 // flow_k == 0: scores of the p->n_order slices of p->order (longest first); flow_k > 0: the flow_k winners of p->keys, their rows
 // [dp_rows_len][16 nq] in p->dp_rows, one scratch region of p->scratch_stride >= vk_docw_scratch_bytes(max_len, nq) bytes per winner
 extern "C" hipError_t vk_launch_docw(const VkWideParams *p, int32_t flow_k, hipStream_t stream) {
-	if (p->len_t <= 16 || p->len_t > 64 || p->gap_mode < 0 || p->gap_mode > 1) return hipErrorInvalidValue;
+	if (p->len_t <= 16 || p->len_t > 64 || p->gap_mode < 0 || (p->gap_mode > 1 && !(p->gap_mode == 4 && flow_k == 0))) return hipErrorInvalidValue;
 	const int nq = (p->len_t + 15) / 16;
 	void (*kernel)(VkWideParams) = nullptr;
 	if (flow_k > 0) {
@@ -372,7 +443,11 @@ extern "C" hipError_t vk_launch_docw(const VkWideParams *p, int32_t flow_k, hipS
 	const int grid = (int)(p->n_order < cap ? p->n_order : cap);
 	const bool st = p->layout == VK_DEV_LAYOUT_STATIC;
 	const bool regs = !st && p->prec == 0 && p->nk32 <= 12 && !getenv("VK_DOCW_GENERIC");
-	if (p->gap_mode == 0) {
+	if (p->gap_mode == 4) {   // the relaxed 1:1 WMD
+		if (st) kernel = nq == 2 ? vk_docw_kernel<false, 4, 2, 2> : nq == 3 ? vk_docw_kernel<false, 4, 2, 3> : vk_docw_kernel<false, 4, 2, 4>;
+		else if (regs) kernel = nq == 2 ? vk_docw_kernel<false, 4, 0, 2> : nq == 3 ? vk_docw_kernel<false, 4, 0, 3> : vk_docw_kernel<false, 4, 0, 4>;
+		else kernel = nq == 2 ? vk_docw_kernel<false, 4, 1, 2> : nq == 3 ? vk_docw_kernel<false, 4, 1, 3> : vk_docw_kernel<false, 4, 1, 4>;
+	} else if (p->gap_mode == 0) {
 		if (st) kernel = nq == 2 ? vk_docw_kernel<false, 0, 2, 2> : nq == 3 ? vk_docw_kernel<false, 0, 2, 3> : vk_docw_kernel<false, 0, 2, 4>;
 		else if (regs) kernel = nq == 2 ? vk_docw_kernel<false, 0, 0, 2> : nq == 3 ? vk_docw_kernel<false, 0, 0, 3> : vk_docw_kernel<false, 0, 0, 4>;
 		else kernel = nq == 2 ? vk_docw_kernel<false, 0, 1, 2> : nq == 3 ? vk_docw_kernel<false, 0, 1, 3> : vk_docw_kernel<false, 0, 1, 4>;

@@ -560,6 +560,7 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 		const Score32Plan plan32 = score32_plan(c, q);
 		const int wave_tiles = plan32.wave_tiles;
 		// the multi-block kernel skips the slices of more than 64 tokens; a pass of their own scores them (vk_docw_kernel, else vk_wide_kernel)
+		const bool docw_rwmd = rwmd_inj && p.gap_mode == 4 && c->max_len > VK_FAST_SENT_LEN && !getenv("VK_NO_DOCW");   // the relaxed 1:1 WMD: vk_docw_kernel's streaming arm
 		const bool apart_route = (is_align || (rwmd_inj && p.gap_mode == 4)) && c->h_apart && !c->h_apart->empty() && !getenv("VK_NO_APART");
 		const bool two_blocks = (is_align || rwmd_inj || bound_pass) && (long_apart || apart_route || (c->n_long_groups == 0 &&
 			c->max_len <= VK_FAST_SENT_LEN)) && (apart_route || c->max_len <= VK_MAX_SENT_LEN) && (rwmd_inj || bound_pass || p.gap_mode == 0 || (p.gap_mode == 1 && p.a_t >= 0.0f) || (p.gap_mode == 2 && wide_sub)) &&
@@ -590,7 +591,7 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 			}
 			wp.gap_mode = p.gap_mode;                                        // the traceback kernel knows 0 / 1 / 2
 			wp.wt = c->d_wt;                                                 // ... and walks the caller's table
-			if (apart_route && docw) {
+			if (apart_route && (docw || docw_rwmd)) {
 				if ((rc = wide_order(1))) return rc;
 				if (wp.n_order > 0) VK_HIP(vk_launch_docw(&wp, 0, st));
 			} else if (apart_route && docg_ok()) {
@@ -601,7 +602,7 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 				if (wp.n_order > 0) VK_HIP(vk_launch_wide(&wp, 0, st));
 			}
 		}
-		else if (docw) {   // (the multi-block kernel does not fit this corpus: every slice on the sweep)
+		else if (docw || docw_rwmd) {   // (the multi-block kernel does not fit this corpus: every slice on the sweep)
 			if ((rc = wide_order(0))) return rc;
 			if (wp.n_order > 0) VK_HIP(vk_launch_docw(&wp, 0, st));
 		}
