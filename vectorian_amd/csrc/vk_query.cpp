@@ -1149,14 +1149,22 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 		}
 		n_out = std::min((int)order.size(), only ? q->n_only : k);
 	}
-	std::vector<float> &rows_all = keep.vec<float>();   // canon_tr: similarity rows of every selected slice
+	// canon_tr: similarity rows of every selected slice -- in the handle's pinned staging (a std::vector made the copy of a document
+	// corpus's winners, 12 MB for 18 x 5,056 rows x 32 columns, go through the runtime's bounce buffers: 2 - 4 ms of a 5.7 ms query)
+	float *rows_all = nullptr;
 	const int rows_R = out->rows_per_winner > 0 ? out->rows_per_winner : VK_FAST_SENT_LEN, rows_W = 16 * ((q->len_t + 15) / 16);
 	if (canon_tr && n_sel > 0) {
-		rows_all.resize((size_t)n_sel * rows_R * rows_W);
+		const size_t rows_bytes = (size_t)n_sel * rows_R * rows_W * 4;
+		if (c->h_brows_cap < rows_bytes) {
+			if (c->h_brows) { VK_HIP(hipHostFree(c->h_brows)); c->h_brows = nullptr; c->h_brows_cap = 0; }
+			VK_HIP(hipHostMalloc((void **)&c->h_brows, rows_bytes, hipHostMallocDefault));
+			c->h_brows_cap = rows_bytes;
+		}
+		rows_all = c->h_brows;
 		std::vector<int64_t> rows_idx;
 		for (int i = 0; i < n_sel; i++) rows_idx.push_back((int64_t)(uint32_t)(keys[(size_t)i] & 0xffffffffu));
 		float no_mass[VK_MAX_QUERY_LEN] = {0};
-		if ((rc = transport_flows(rows_idx, false, no_mass, 0, 0, rows_all.data()))) return rc;
+		if ((rc = transport_flows(rows_idx, false, no_mass, 0, 0, rows_all))) return rc;
 		// vocabulary keys (static layout): token ids, or (id, tag) pairs when the similarity is tag-weighted (alignment/bow.h:106-127, 150-176)
 		const bool vocab = is_static && q->q_token_ids && c->h_tok;
 		const bool tagged = vocab && q->tag_weights && q->q_tags && c->h_tag;
@@ -1181,7 +1189,7 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 				for (int u = 0; u < len_s; u++)
 					key_s[(size_t)u] = tagged ? (*c->h_tok)[(size_t)(t_a + u)] * 256 + (int32_t)(uint8_t)(*c->h_tag)[(size_t)(t_a + u)] : (*c->h_tok)[(size_t)(t_a + u)];
 			}
-			raw[(size_t)i] = vk_host::rwmd_from_rows(rows_all.data() + (size_t)i * rows_R * rows_W, rows_W, len_s, q->len_t,
+			raw[(size_t)i] = vk_host::rwmd_from_rows(rows_all + (size_t)i * rows_R * rows_W, rows_W, len_s, q->len_t,
 				vocab ? key_s.data() : nullptr, vocab ? key_t.data() : nullptr, q->rwmd_injective != 0, q->rwmd_symmetric != 0, q->rwmd_normalize_bow != 0);
 			val[(size_t)i] = (raw[(size_t)i] / total) * boost;   // reference_score with every query token matched: the sum of the weights (match.h:165-176)
 		}
@@ -1232,7 +1240,7 @@ static int query_body(vk_corpus_t *c, const vk_query_desc *q, vk_topk_out *out, 
 	c->have_scores = !only;
 	if (canon_tr && n_out > 0) {
 		for (int i = 0; i < n_out; i++)   // the rows of the winners, in their final order
-			memcpy(out->sim_rows + (size_t)i * rows_R * rows_W, rows_all.data() + (size_t)order[(size_t)i] * rows_R * rows_W, (size_t)rows_R * rows_W * 4);
+			memcpy(out->sim_rows + (size_t)i * rows_R * rows_W, rows_all + (size_t)order[(size_t)i] * rows_R * rows_W, (size_t)rows_R * rows_W * 4);
 	} else if ((q->algorithm == VK_ALG_RWMD || (is_align && rows_on_request)) && n_out > 0) {
 		std::vector<int64_t> rows_idx;
 		for (int i = 0; i < n_out; i++) rows_idx.push_back((int64_t)(uint32_t)(keys[(size_t)order[(size_t)i]] & 0xffffffffu));
