@@ -161,3 +161,78 @@ def test_random_transport_and_modifiers(hip, oracle, seed):
 		got = c.query(qv, q_normalize=True, max_matches=k, **kw)
 		assert_same_results(got.trimmed(), ref, score_tol=2e-5)
 	c.close()
+
+
+@pytest.mark.parametrize("seed", range(30 * SCALE))
+def test_random_documents(hip, oracle, seed):
+	"""random corpora that mix sentences, paragraphs (65 .. 512 tokens) and documents (up to 1,500): query of 1 .. 64 tokens, every
+	locality and gap family (tables that saturate early, late or never), both layouts and row types, boost -- the routes of round 4
+	(vk_doc_kernel, vk_docw_kernel, vk_docg_kernel, the multi-block kernel beside them, vk_wide_kernel for the rest) against the oracle"""
+	rng = np.random.default_rng(9000 + seed)
+	static = bool(rng.integers(0, 2))
+	d = int(rng.choice([32, 64, 100, 300]))
+	n = int(rng.integers(5, 60))
+	lens = rng.integers(0, 50, size=n)
+	for _ in range(int(rng.integers(1, 5))):
+		lens[rng.integers(0, n)] = rng.integers(65, 513)
+	for _ in range(int(rng.integers(0, 3))):
+		lens[rng.integers(0, n)] = rng.integers(513, 1501)
+	off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+	T = int(off[-1])
+	len_t = int(rng.choice([1, 3, 9, 16, 17, 24, 32, 33, 48, 64]))
+	precision = "f32" if rng.random() < 0.2 else "bf16"
+	loc = int(rng.integers(0, 3))
+	def gap(n_tab):
+		kind = rng.integers(0, 5)
+		if kind == 0:
+			return float(rng.uniform(0.0, 0.4))
+		if kind == 1:
+			return ("affine", float(rng.uniform(0.0, 0.4)), float(rng.uniform(0.0, 0.2)))
+		if kind == 2:   # saturates somewhere between 10 and 200 tokens
+			return ("table", (rng.uniform(0.3, 1.0) * (1 - 2.0 ** (-np.arange(0, n_tab) / rng.uniform(0.4, 8.0)))).astype(np.float32))
+		if kind == 3:   # constant from a random k on
+			w = np.sort(rng.uniform(0.0, 1.0, size=n_tab)).astype(np.float32)
+			w[0] = 0.0
+			t = int(rng.integers(1, min(140, n_tab - 1)))
+			w[t:] = w[t]
+			return ("table", w)
+		return ("table", np.concatenate(([0.0], np.cumsum(rng.uniform(0.0, 0.05, size=n_tab - 1)))).astype(np.float32))   # never
+	gs, gt = gap(1502), gap(65)
+	k = int(rng.choice([1, 4, 12]))
+	boost = rng.uniform(0.5, 1.5, size=n).astype(np.float32) if rng.random() < 0.3 else None
+	ms = 0.0 if loc == 0 else -1e9
+	kw = dict(locality=loc, gap_s=gs, gap_t=gt, max_matches=k, min_score=ms, boost=boost)
+	s0 = int(np.argmax(lens))
+	if static:
+		V = int(rng.integers(20, 300))
+		E = rng.standard_normal((V, d)).astype(np.float32)
+		ids = rng.integers(0, V, size=T).astype(np.int32)
+		a = int(off[s0])
+		q_ids = ids[a:a + 3 * len_t:3][:len_t].astype(np.int32)
+		if len(q_ids) < len_t:
+			q_ids = np.concatenate((q_ids, rng.integers(0, V, size=len_t - len(q_ids)).astype(np.int32)))
+		c = hip.Corpus(layout=hip.VK_LAYOUT_STATIC, d=d, n_tokens=T, n_sentences=n, vocab_size=V, precision=precision)
+		c.append_vectors(E, normalize=True)
+		c.set_token_ids(ids)
+		c.set_sentences(off)
+		c.finalize()
+		En = oracle.normalize_rows(E) if precision == "f32" else oracle.normalize_rows_bf16(E)[0]
+		ref = oracle.find(layout=oracle.LAYOUT_STATIC, d=d, sent_off=off, tok_id=ids, E=En, Q=En[q_ids], q_ids=q_ids, n_threads=8, **kw)
+		got = c.query(E[q_ids], q_token_ids=q_ids, q_normalize=True, **kw)
+	else:
+		X = rng.standard_normal((T, d)).astype(np.float32)
+		qv = rng.standard_normal((len_t, d)).astype(np.float32)
+		m = min(len_t, int(lens[s0]))
+		idx = np.sort(rng.choice(np.arange(int(off[s0]), int(off[s0 + 1])), size=m, replace=False))
+		qv[:m] = X[idx] + 0.1 * rng.standard_normal((m, d)).astype(np.float32)
+		c = hip.Corpus(layout=hip.VK_LAYOUT_CONTEXTUAL, d=d, n_tokens=T, n_sentences=n, precision=precision)
+		c.append_vectors(X, normalize=True)
+		c.set_sentences(off)
+		c.finalize()
+		Xn = oracle.normalize_rows(X) if precision == "f32" else oracle.normalize_rows_bf16(X)[0]
+		Qn = oracle.normalize_rows(qv) if precision == "f32" else oracle.normalize_rows_bf16(qv)[0]
+		ref = oracle.find(layout=oracle.LAYOUT_CONTEXTUAL, d=d, sent_off=off, X=Xn, Q=Qn, n_threads=8, **kw)
+		got = c.query(qv, q_normalize=True, **kw)
+	assert_same_results(got.trimmed(), ref)
+	c.close()
+
