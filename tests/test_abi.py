@@ -62,6 +62,20 @@ def test_document_pass_sizing():
 		assert lib.vk_wide_gs_blocks(doc, 4, gap, 18, 10 ** 6, ring) == 18          # tracebacks: one workgroup per winner
 	# 64 query tokens over 512-token slices with general gaps and traceback: beyond the LDS (the global-state form takes them)
 	assert lib.vk_wide_lds_demand(512, 4, 2, 0, 1) > 160 * 1024 >= lib.vk_wide_lds_demand(512, 1, 2, 0, 1)
+	# the skewed sweeps (round 4): a winner's records -- a byte per cell, general gaps the cell's value -- for every row 0 .. len and
+	# every column of the query's blocks, in whole 256-byte lines
+	for fn, argtypes in (("vk_doc_scratch_bytes", [C.c_int32] * 2), ("vk_docw_scratch_bytes", [C.c_int32] * 2), ("vk_docg_scratch_bytes", [C.c_int32])):
+		getattr(lib, fn).restype = C.c_size_t
+		getattr(lib, fn).argtypes = argtypes
+	for n in (1, 65, 512, 5000, doc):
+		for gap, cell in ((0, 1), (1, 1), (2, 4)):
+			b = lib.vk_doc_scratch_bytes(n, gap)
+			assert b % 256 == 0 and (n + 1) * 16 * cell <= b <= (n + 2) * 16 * cell + 255
+		for nq in (2, 3, 4):
+			b = lib.vk_docw_scratch_bytes(n, nq)
+			assert b % 256 == 0 and (n + 1) * 16 * nq <= b <= (n + 2) * 16 * nq + 255
+		b = lib.vk_docg_scratch_bytes(n)
+		assert b % 256 == 0 and (n + 1) * 32 * 4 <= b <= (n + 2) * 32 * 4 + 255
 
 
 def test_no_gpu_means_loud_failure():
